@@ -1,0 +1,81 @@
+"""Deterministic synthetic windows and formula-initialised weights.
+
+There is no dataset and no checkpoint offline, so benchmarks and parity tests
+use (a) the synthetic moving-disk clip of SURVEY.md §8(d) and (b) weights that
+are a closed-form function of (state_dict key, element index), evaluated
+identically for the reference (golden generation), the oracle and the HIP path.
+The generator is a counter-based splitmix64 hash in numpy uint64 arithmetic, so
+it does not depend on any library's RNG stream.
+"""
+import zlib
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix(idx):
+    z = (idx + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_uniform(tag, numel, salt=0):
+    """numel float64 values in [-1, 1), a pure function of (tag, salt, index)."""
+    with np.errstate(over='ignore'):
+        base = np.uint64(zlib.crc32(tag.encode()) & 0xFFFFFFFF) * np.uint64(0x100000001B3) + np.uint64(salt)
+        h = _splitmix(np.arange(numel, dtype=np.uint64) + (base << np.uint64(20)))
+    return (h >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0
+
+
+def formula_tensor(key, shape, dtype=torch.float32, salt=0):
+    """Value of state_dict entry ``key`` under the formula initialisation."""
+    shape = tuple(shape)
+    n = int(np.prod(shape)) if len(shape) else 1
+    leaf = key.rsplit('.', 1)[-1]
+    if leaf == 'num_batches_tracked':
+        return torch.zeros(shape, dtype=torch.int64)
+    r = hash_uniform(key, n, salt)
+    if leaf in ('weight_u', 'weight_v'):                      # unit vectors, like l2normalize(normal_())
+        r = r / (np.linalg.norm(r) + 1e-12)
+    elif leaf == 'running_mean':
+        r = 0.1 * r
+    elif leaf == 'running_var':
+        r = 1.0 + 0.3 * r
+    elif leaf == 'bias':
+        r = 0.1 * r
+    elif len(shape) == 1:                                     # norm-layer scale
+        r = 0.6 + 0.25 * r
+    else:                                                     # conv kernels: uniform, std ~ 1/sqrt(fan_in)
+        fan_in = n // shape[0]
+        r = r * np.sqrt(3.0 / fan_in)
+    return torch.from_numpy(r.reshape(shape)).to(dtype)
+
+
+def formula_state_dict(template, salt=0):
+    """template: mapping key -> tensor (only shape/dtype are read)."""
+    return {k: formula_tensor(k, v.shape, v.dtype, salt) for k, v in template.items()}
+
+
+def synthetic_window(B, S, H, W, seed=0):
+    """Moving soft-edged disk alpha + uniform-random fg/bg, float32 0..255, BGR layout
+    [B,S,C,H,W] exactly as `dataset/VMD.py:293-301` hands clips to the model
+    (SURVEY.md §8d).  Clip b of a batch uses seed ``seed + b``."""
+    a = torch.empty(B, S, 1, H, W)
+    fg = torch.empty(B, S, 3, H, W)
+    bg = torch.empty(B, S, 3, H, W)
+    ys = torch.arange(H, dtype=torch.float32).reshape(H, 1)
+    xs = torch.arange(W, dtype=torch.float32).reshape(1, W)
+    rad = min(H, W) / 4.0
+    for b in range(B):
+        for s in range(S):
+            cx, cy = W / 2.0 + 4.0 * s + 3.0 * b, H / 2.0 + 2.0 * s - 2.0 * b
+            d = torch.sqrt((xs - cx) ** 2 + (ys - cy) ** 2)
+            a[b, s, 0] = torch.round(255.0 * torch.clamp((rad + 8.0 - d) / 16.0, 0.0, 1.0))
+        n = S * 3 * H * W
+        for name, dst in (('fg', fg), ('bg', bg)):
+            r = hash_uniform('synthetic_window.' + name, n, salt=seed + b)
+            dst[b] = torch.from_numpy(np.clip(np.floor((r + 1.0) * 128.0), 0, 255)
+                                      .astype(np.float32).reshape(S, 3, H, W))
+    return a, fg, bg

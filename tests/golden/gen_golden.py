@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors in tests/golden/*.npz.
+
+Runs ONLY in the build container: it imports the real reference from
+/root/reference (pure Python/PyTorch, CPU) behind three import-time shims
+(cv2, torchvision, torch.cuda.current_device — SURVEY.md §8c), evaluates it on
+formula-initialised weights and hash-generated inputs (tcvom_amd/synthetic.py)
+and stores OUTPUTS only.  Inputs are re-derived from the same formulas by the
+tests, so fixtures stay small.  Nothing from the reference is copied: the
+fixtures are numbers.
+
+    python tests/golden/gen_golden.py            # rewrites every fixture
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+
+
+def _import_reference():
+    import scipy.ndimage as ndi
+    cv2 = types.ModuleType('cv2')
+    cv2.DIST_L2 = 2
+    cv2.setNumThreads = lambda n: None
+    cv2.distanceTransform = lambda x, dist, mask: ndi.distance_transform_edt(x != 0).astype(np.float32)
+    tv = types.ModuleType('torchvision')
+    tv.utils = types.ModuleType('torchvision.utils')
+    sys.modules.update({'cv2': cv2, 'torchvision': tv, 'torchvision.utils': tv.utils})
+    torch.cuda.current_device = lambda: torch.device('cpu')
+    # the repo has its own top-level `models` package (the drop-in API); make sure
+    # the reference's wins for this process only
+    sys.path = [p for p in sys.path if os.path.abspath(p or '.') != REPO]
+    sys.path.insert(0, REF)
+    import models.model as ref_model
+    import models.VMN.VMN_model as ref_vmn
+    import models.GCA.ops as ref_ops
+    import utils.loss_func as ref_loss
+    sys.path.remove(REF)
+    sys.path.insert(0, REPO)
+    return ref_model, ref_vmn, ref_ops, ref_loss
+
+
+ref_model, ref_vmn, ref_ops, ref_loss = _import_reference()
+from tcvom_amd.synthetic import formula_tensor, formula_state_dict, synthetic_window, hash_uniform  # noqa: E402
+
+
+def hu(tag, shape, scale=1.0):
+    return torch.from_numpy(hash_uniform(tag, int(np.prod(shape))).reshape(shape)).float() * scale
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+# ----------------------------------------------------------------------------- TAM
+TAM_CASES = {
+    # name: (B, C, H, W, window, mask kind)
+    'tam_w7_random': (2, 16, 9, 11, 7, 'random'),
+    'tam_w1_random': (2, 16, 9, 11, 1, 'random'),
+    'tam_w7_empty': (1, 16, 9, 11, 7, 'empty'),
+    'tam_w7_single': (1, 16, 9, 11, 7, 'single'),
+    'tam_w7_full_c128': (1, 128, 6, 8, 7, 'full'),
+}
+
+
+def tam_mask(kind, B, H, W):
+    m = torch.zeros(B, 1, H * 8, W * 8)
+    if kind == 'random':
+        small = (hu('tam.mask', (B, 1, H, W)) > 0.1).float()
+    elif kind == 'full':
+        small = torch.ones(B, 1, H, W)
+    elif kind == 'single':
+        small = torch.zeros(B, 1, H, W)
+        small[0, 0, 4, 7] = 1
+    else:
+        small = torch.zeros(B, 1, H, W)
+    m[:, :, ::8, ::8] = small
+    # off-grid pixels must be ignored by the nearest down-sampling
+    m[:, :, 1::8, 3::8] = 1 - small
+    return m
+
+
+def gen_tam():
+    for name, (B, C, H, W, win, kind) in TAM_CASES.items():
+        fam = ref_vmn.FeatureAggregationModule(C, 1, win)
+        sd = {k: formula_tensor('decoder.fam.' + k, v.shape) for k, v in fam.state_dict().items()}
+        fam.load_state_dict(sd)
+        x, b, f = (hu('tam.' + t, (B, C, H, W)).requires_grad_(True) for t in 'xbf')
+        out, attb, attf, small = fam(x, b, f, tam_mask(kind, B, H, W))
+        go, gb, gf = hu('tam.gout', out.shape), hu('tam.gattb', attb.shape), hu('tam.gattf', attf.shape)
+        ((out * go).sum() + (attb * gb).sum() + (attf * gf).sum()).backward()
+        save(name, out=out, attb=attb, attf=attf, small=small.numpy().astype(np.uint8),
+             gx=x.grad, gb=b.grad, gf=f.grad,
+             gkw=fam.key_conv.weight.grad, gqw=fam.query_conv.weight.grad, gvb=fam.value_conv.bias.grad,
+             gkb=fam.key_conv.bias.grad)
+
+
+# ----------------------------------------------------------------------------- GCA attention
+GCA_CASES = {'gca_random': 'random', 'gca_all_known': 'zeros', 'gca_all_unknown': 'ones'}
+
+
+def gca_unknown(kind, B, h, w):
+    if kind == 'random':
+        return (hu('gca.unknown', (B, 1, h, w)) > 0.3).float()
+    return torch.zeros(B, 1, h, w) if kind == 'zeros' else torch.ones(B, 1, h, w)
+
+
+def gen_gca():
+    B, h, w = 2, 12, 16
+    for name, kind in GCA_CASES.items():
+        mod = ref_ops.GuidedCxtAtten(128, 128)
+        sd = {k: formula_tensor('encoder.gca.' + k, v.shape, v.dtype) for k, v in mod.state_dict().items()}
+        mod.load_state_dict(sd)
+        mod.train()
+        f = hu('gca.f', (B, 128, h, w)).requires_grad_(True)
+        al = hu('gca.alpha', (B, 128, h, w)).requires_grad_(True)
+        y, (offs, scale) = mod(f, al, gca_unknown(kind, B, h, w))
+        (y * hu('gca.gy', y.shape)).sum().backward()
+        save(name, y=y, scale=scale, gf=f.grad, galpha=al.grad,
+             gW0=mod.W[0].weight.grad, ggw=mod.guidance_conv.weight.grad,
+             run_mean=mod.W[1].running_mean, run_var=mod.W[1].running_var)
+
+
+# ----------------------------------------------------------------------------- SpectralNorm
+def gen_sn():
+    import torch.nn as nn
+    arrs = {}
+    for tag, conv in (('conv', nn.Conv2d(4, 8, 3, padding=1, bias=False)),
+                      ('convT', nn.ConvTranspose2d(4, 8, 4, stride=2, padding=1, bias=False))):
+        sn = ref_ops.SpectralNorm(conv)
+        sd = {k: formula_tensor('sn.%s.%s' % (tag, k), v.shape) for k, v in sn.state_dict().items()}
+        sn.load_state_dict(sd)
+        x = hu('sn.x.' + tag, (2, 4, 6, 5))
+        for mode in ('train', 'train2', 'eval'):
+            sn.train(mode != 'eval')
+            sn.zero_grad()
+            y = sn(x)
+            (y * hu('sn.gy.' + tag, y.shape)).sum().backward()
+            arrs['%s_%s_w' % (tag, mode)] = sn.module.weight.detach()
+            arrs['%s_%s_u' % (tag, mode)] = sn.module.weight_u.detach().clone()
+            arrs['%s_%s_v' % (tag, mode)] = sn.module.weight_v.detach().clone()
+            arrs['%s_%s_gbar' % (tag, mode)] = sn.module.weight_bar.grad.clone()
+            arrs['%s_%s_y' % (tag, mode)] = y.detach()
+    save('spectral_norm', **arrs)
+
+
+# ----------------------------------------------------------------------------- facade pieces
+def gen_facade():
+    B, S, H, W = 2, 3, 48, 64
+    a, fg, bg = synthetic_window(B, S, H, W, seed=3)
+    arrs = {}
+    for r in (0, 2, 5, 12, 20):
+        fm = ref_model.FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=r)
+        scaled_imgs, fgs, bgs, gts, tris, trimasks, imgs = fm.preprocess(a, fg, bg)
+        arrs['tris_r%d' % r] = tris.numpy().astype(np.uint8)
+        arrs['trimask_r%d' % r] = trimasks.numpy().astype(np.uint8)
+    arrs['imgs'] = imgs
+    arrs['scaled_imgs'] = scaled_imgs
+    fm = ref_model.FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=2, eps=0.3)
+    _, _, _, _, tris, trimasks, _ = fm.preprocess(a, fg, bg)
+    arrs['tris_eps'] = tris.numpy().astype(np.uint8)
+    arrs['trimask_eps'] = trimasks.numpy().astype(np.uint8)
+    # L1_mask incl. the empty-mask clamp
+    x, y = hu('l1.x', (2, 1, 8, 9)), hu('l1.y', (2, 1, 8, 9))
+    m = (hu('l1.m', (2, 1, 8, 9)) > 0).float()
+    arrs['l1_random'] = ref_loss.L1_mask(x, y, m)
+    arrs['l1_empty'] = ref_loss.L1_mask(x, y, torch.zeros_like(m))
+    save('facade', **arrs)
+
+
+# ----------------------------------------------------------------------------- whole window
+WINDOW_CASES = {
+    # name: (B, S, H, W, dilate, window)
+    'window_s3_64x64': (2, 3, 64, 64, 3, 7),
+    'window_s5_64x96': (1, 5, 64, 96, 4, 7),
+    'window_s3_128x160': (1, 3, 128, 160, 12, 7),
+}
+FULL_GRADS = ('decoder.fam.key_conv.bias', 'decoder.fam.query_conv.bias', 'encoder.bn1.weight',
+              'decoder.conv2.weight', 'encoder.gca.W.1.weight', 'decoder.layer3.0.bn1.bias')
+
+
+def gen_window():
+    for name, (B, S, H, W, dil, win) in WINDOW_CASES.items():
+        fm = ref_model.FullModel_VMD('vmn_gca', agg_window=win, dilate_kernel=dil)
+        sd = formula_state_dict(fm.NET.state_dict())
+        fm.NET.load_state_dict(sd)
+        fm.train()
+        a, fg, bg = synthetic_window(B, S, H, W, seed=0)
+        out = fm(a, fg, bg)
+        loss = out[0].mean() + out[1].mean() + out[2].mean() + 0.5 * out[3].mean() + 0.25 * out[4].mean()
+        loss.backward()
+        arrs = {'losses': torch.stack([o.detach() for o in out[:5]]), 'total': loss.detach(),
+                'alphas': out[7], 'comps_sum': out[8].sum(), 'tris_vis_sum': out[6].sum()}
+        names, norms = [], []
+        for k, p in fm.NET.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        arrs['grad_names'] = np.array(names)
+        arrs['grad_norms'] = np.array(norms)
+        gd = dict(fm.NET.named_parameters())
+        for k in FULL_GRADS:
+            arrs['grad:' + k] = gd[k].grad
+        post = fm.NET.state_dict()
+        for k in ('encoder.bn1.running_mean', 'encoder.bn1.running_var', 'encoder.conv1.module.weight_u',
+                  'decoder.layer1.0.conv1.module.weight_v', 'encoder.bn1.num_batches_tracked'):
+            arrs['state:' + k] = post[k].clone()
+        if name == 'window_s3_64x64':
+            # eval-mode alphas after one more train-mode calibration pass (SURVEY.md §7 "eval degeneracy")
+            with torch.no_grad():
+                fm(a, fg, bg)
+                fm.eval()
+                ev = fm(a, fg, bg)
+            arrs['eval_alphas'] = ev[7]
+            arrs['eval_losses'] = torch.stack(list(ev[:5]))
+        save(name, **arrs)
+
+
+def gen_state_keys():
+    sd = ref_model.FullModel_VMD('vmn_gca', agg_window=7).NET.state_dict()
+    save('state_keys', keys=np.array(list(sd.keys())),
+         shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]),
+         n_trainable=np.array(sum(p.numel() for p in
+                                  ref_model.FullModel_VMD('vmn_gca', agg_window=7).NET.parameters()
+                                  if p.requires_grad)))
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_state_keys()
+    gen_sn()
+    gen_tam()
+    gen_gca()
+    gen_facade()
+    gen_window()

@@ -1,0 +1,73 @@
+"""Shared test helpers: hash-generated inputs (same formulas as tests/golden/gen_golden.py)."""
+import os
+import numpy as np
+import torch
+
+from tcvom_amd.synthetic import hash_uniform, formula_tensor
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def hu(tag, shape, scale=1.0):
+    return torch.from_numpy(hash_uniform(tag, int(np.prod(shape))).reshape(shape)).float() * scale
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def tam_mask(kind, B, H, W):
+    m = torch.zeros(B, 1, H * 8, W * 8)
+    if kind == 'random':
+        small = (hu('tam.mask', (B, 1, H, W)) > 0.1).float()
+    elif kind == 'full':
+        small = torch.ones(B, 1, H, W)
+    elif kind == 'single':
+        small = torch.zeros(B, 1, H, W)
+        small[0, 0, 4, 7] = 1
+    else:
+        small = torch.zeros(B, 1, H, W)
+    m[:, :, ::8, ::8] = small
+    m[:, :, 1::8, 3::8] = 1 - small
+    return m
+
+
+def gca_unknown(kind, B, h, w):
+    if kind == 'random':
+        return (hu('gca.unknown', (B, 1, h, w)) > 0.3).float()
+    return torch.zeros(B, 1, h, w) if kind == 'zeros' else torch.ones(B, 1, h, w)
+
+
+TAM_CASES = {
+    'tam_w7_random': (2, 16, 9, 11, 7, 'random'),
+    'tam_w1_random': (2, 16, 9, 11, 1, 'random'),
+    'tam_w7_empty': (1, 16, 9, 11, 7, 'empty'),
+    'tam_w7_single': (1, 16, 9, 11, 7, 'single'),
+    'tam_w7_full_c128': (1, 128, 6, 8, 7, 'full'),
+}
+GCA_CASES = {'gca_random': 'random', 'gca_all_known': 'zeros', 'gca_all_unknown': 'ones'}
+WINDOW_CASES = {
+    'window_s3_64x64': (2, 3, 64, 64, 3, 7),
+    'window_s5_64x96': (1, 5, 64, 96, 4, 7),
+    'window_s3_128x160': (1, 3, 128, 160, 12, 7),
+}
+FULL_GRADS = ('decoder.fam.key_conv.bias', 'decoder.fam.query_conv.bias', 'encoder.bn1.weight',
+              'decoder.conv2.weight', 'encoder.gca.W.1.weight', 'decoder.layer3.0.bn1.bias')
+
+
+def assert_close(got, want, rtol, atol, what=''):
+    got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got)).double()
+    want = torch.as_tensor(np.asarray(want)).double()
+    assert got.shape == want.shape, '%s: shape %s vs %s' % (what, tuple(got.shape), tuple(want.shape))
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bool(bad.any()), '%s: %d/%d off, max err %.3e (max |want| %.3e)' % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(want.abs().max()))
+
+
+def vmn_gca_template():
+    """key -> (shape, dtype) of FullModel_VMD('vmn_gca').NET.state_dict() — from the product's own module."""
+    from tcvom_amd.vmn import build_vmn_gca
+    net = build_vmn_gca(agg_window=7)
+    return net.state_dict()

@@ -1,0 +1,160 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the real
+reference (tests/golden/gen_golden.py).  fp32 on both sides; tolerances reflect
+fp32 re-association only (the oracle uses dense formulations where the reference
+gathers/scatters)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.state_spec import vmn_gca_state_spec
+from tcvom_amd.synthetic import formula_tensor, synthetic_window
+from helpers import (hu, golden, tam_mask, gca_unknown, TAM_CASES, GCA_CASES, WINDOW_CASES,
+                     FULL_GRADS, assert_close)
+
+
+def test_state_dict_layout_matches_reference():
+    g = golden('state_keys')
+    spec = vmn_gca_state_spec()
+    assert list(spec.keys()) == [str(k) for k in g['keys']]
+    assert [','.join(str(d) for d in s) for s in spec.values()] == [str(s) for s in g['shapes']]
+    n_train = sum(int(np.prod(s)) for k, s in spec.items()
+                  if not any(t in k for t in ('weight_u', 'weight_v', 'running_', 'num_batches')))
+    assert n_train == int(g['n_trainable']) == 25607281
+
+
+def _formula_state(requires_grad=True):
+    state = {k: formula_tensor(k, s, torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
+             for k, s in vmn_gca_state_spec().items()}
+    if requires_grad:
+        for k, v in state.items():
+            if v.is_floating_point() and not any(t in k for t in ('weight_u', 'weight_v', 'running_')):
+                v.requires_grad_(True)
+    return state
+
+
+@pytest.mark.parametrize('name', list(TAM_CASES))
+def test_tam(name):
+    B, C, H, W, win, kind = TAM_CASES[name]
+    g = golden(name)
+    state = {'decoder.fam.%s.%s' % (n, t): formula_tensor('decoder.fam.%s.%s' % (n, t),
+                                                         (C, C, 3, 3) if t == 'weight' else (C,)).requires_grad_(True)
+             for n in ('key_conv', 'query_conv', 'value_conv') for t in ('weight', 'bias')}
+    x, b, f = (hu('tam.' + t, (B, C, H, W)).requires_grad_(True) for t in 'xbf')
+    out, attb, attf, small = oracle.tam_forward(state, 'decoder.fam', x, b, f, tam_mask(kind, B, H, W), win)
+    assert_close(out, g['out'], 1e-5, 1e-5, 'out')
+    assert_close(attb, g['attb'], 1e-5, 1e-5, 'attb')
+    assert_close(attf, g['attf'], 1e-5, 1e-5, 'attf')
+    assert np.array_equal(small.numpy().astype(np.uint8), g['small'])
+    ((out * hu('tam.gout', out.shape)).sum() + (attb * hu('tam.gattb', attb.shape)).sum()
+     + (attf * hu('tam.gattf', attf.shape)).sum()).backward()
+    assert_close(x.grad, g['gx'], 1e-4, 1e-5, 'gx')
+    assert_close(b.grad, g['gb'], 1e-4, 1e-5, 'gb')
+    assert_close(f.grad, g['gf'], 1e-4, 1e-5, 'gf')
+    assert_close(state['decoder.fam.key_conv.weight'].grad, g['gkw'], 1e-4, 2e-5, 'gkw')
+    assert_close(state['decoder.fam.query_conv.weight'].grad, g['gqw'], 1e-4, 2e-5, 'gqw')
+    assert_close(state['decoder.fam.value_conv.bias'].grad, g['gvb'], 1e-4, 2e-5, 'gvb')
+    assert_close(state['decoder.fam.key_conv.bias'].grad, g['gkb'], 1e-4, 2e-5, 'gkb')
+
+
+@pytest.mark.parametrize('name', list(GCA_CASES))
+def test_guided_context_attention(name):
+    B, h, w = 2, 12, 16
+    g = golden(name)
+    shapes = {'guidance_conv.weight': (64, 128, 1, 1), 'guidance_conv.bias': (64,), 'W.0.weight': (128, 128, 1, 1),
+              'W.1.weight': (128,), 'W.1.bias': (128,), 'W.1.running_mean': (128,), 'W.1.running_var': (128,),
+              'W.1.num_batches_tracked': ()}
+    state = {'encoder.gca.' + k: formula_tensor('encoder.gca.' + k, s,
+                                                torch.int64 if k.endswith('tracked') else torch.float32)
+             for k, s in shapes.items()}
+    for k in ('guidance_conv.weight', 'guidance_conv.bias', 'W.0.weight', 'W.1.weight', 'W.1.bias'):
+        state['encoder.gca.' + k].requires_grad_(True)
+    f = hu('gca.f', (B, 128, h, w)).requires_grad_(True)
+    al = hu('gca.alpha', (B, 128, h, w)).requires_grad_(True)
+    y, scale = oracle.guided_context_attention(state, 'encoder.gca', f, al, gca_unknown(GCA_CASES[name], B, h, w), True)
+    assert_close(scale, g['scale'], 1e-6, 1e-6, 'scale')
+    assert_close(y, g['y'], 1e-4, 1e-4, 'y')
+    (y * hu('gca.gy', y.shape)).sum().backward()
+    assert_close(al.grad, g['galpha'], 1e-3, 1e-4, 'galpha')
+    assert_close(f.grad, g['gf'], 1e-3, 2e-4, 'gf')
+    assert_close(state['encoder.gca.W.0.weight'].grad, g['gW0'], 1e-3, 5e-4, 'gW0')
+    assert_close(state['encoder.gca.guidance_conv.weight'].grad, g['ggw'], 1e-3, 5e-4, 'ggw')
+    assert_close(state['encoder.gca.W.1.running_mean'], g['run_mean'], 1e-5, 1e-6, 'running_mean')
+    assert_close(state['encoder.gca.W.1.running_var'], g['run_var'], 1e-5, 1e-6, 'running_var')
+
+
+@pytest.mark.parametrize('tag,shape,transposed', [('conv', (8, 4, 3, 3), False), ('convT', (4, 8, 4, 4), True)])
+def test_spectral_norm(tag, shape, transposed):
+    import torch.nn.functional as F
+    g = golden('spectral_norm')
+    h = shape[0]
+    wdt = int(np.prod(shape[1:]))
+    state = {'sn.module.weight_u': formula_tensor('sn.%s.module.weight_u' % tag, (h,)),
+             'sn.module.weight_v': formula_tensor('sn.%s.module.weight_v' % tag, (wdt,)),
+             'sn.module.weight_bar': formula_tensor('sn.%s.module.weight_bar' % tag, shape).requires_grad_(True)}
+    x = hu('sn.x.' + tag, (2, 4, 6, 5))
+    for mode in ('train', 'train2', 'eval'):
+        state['sn.module.weight_bar'].grad = None
+        wn = oracle.spectral_weight(state, 'sn.module', mode != 'eval')
+        y = F.conv_transpose2d(x, wn, None, 2, 1) if transposed else F.conv2d(x, wn, None, 1, 1)
+        (y * hu('sn.gy.' + tag, y.shape)).sum().backward()
+        assert_close(wn, g['%s_%s_w' % (tag, mode)], 1e-5, 1e-6, 'w ' + mode)
+        assert_close(state['sn.module.weight_u'], g['%s_%s_u' % (tag, mode)], 1e-5, 1e-6, 'u ' + mode)
+        assert_close(state['sn.module.weight_v'], g['%s_%s_v' % (tag, mode)], 1e-5, 1e-6, 'v ' + mode)
+        assert_close(state['sn.module.weight_bar'].grad, g['%s_%s_gbar' % (tag, mode)], 1e-4, 1e-5, 'gbar ' + mode)
+        assert_close(y, g['%s_%s_y' % (tag, mode)], 1e-5, 1e-5, 'y ' + mode)
+
+
+def test_facade_preprocess_and_trimap():
+    g = golden('facade')
+    a, fg, bg = synthetic_window(2, 3, 48, 64, seed=3)
+    for r in (0, 2, 5, 12, 20):
+        scaled, fgs, bgs, gts, tris, trimasks, imgs = oracle.preprocess(a, fg, bg, r)
+        assert np.array_equal(tris.numpy().astype(np.uint8), g['tris_r%d' % r])
+        assert np.array_equal(trimasks.numpy().astype(np.uint8), g['trimask_r%d' % r])
+    assert_close(imgs, g['imgs'], 1e-6, 1e-6, 'imgs')
+    assert_close(scaled, g['scaled_imgs'], 1e-6, 1e-6, 'scaled')
+    _, _, _, _, tris, trimasks, _ = oracle.preprocess(a, fg, bg, 2, eps=0.3)
+    assert np.array_equal(tris.numpy().astype(np.uint8), g['tris_eps'])
+    assert np.array_equal(trimasks.numpy().astype(np.uint8), g['trimask_eps'])
+    x, y = hu('l1.x', (2, 1, 8, 9)), hu('l1.y', (2, 1, 8, 9))
+    m = (hu('l1.m', (2, 1, 8, 9)) > 0).float()
+    assert_close(oracle.l1_mask(x, y, m), g['l1_random'], 1e-6, 1e-7)
+    assert_close(oracle.l1_mask(x, y, torch.zeros_like(m)), g['l1_empty'], 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize('name', list(WINDOW_CASES))
+def test_window_forward_backward(name):
+    B, S, H, W, dil, win = WINDOW_CASES[name]
+    g = golden(name)
+    state = _formula_state()
+    leaves = {k: v for k, v in state.items() if v.requires_grad}
+    a, fg, bg = synthetic_window(B, S, H, W, seed=0)
+    out, extra = oracle.window_forward(state, a, fg, bg, window=win, dilate_kernel=dil, training=True)
+    loss = oracle.train_step_loss(out)
+    loss.backward()
+    assert_close(torch.stack([o.detach() for o in out[:5]]), g['losses'], 1e-5, 1e-6, 'losses')
+    assert_close(loss, g['total'], 1e-5, 1e-6, 'total')
+    assert_close(out[7], g['alphas'], 0, 2e-4, 'alphas')
+    assert_close(out[8].sum(), g['comps_sum'], 1e-5, 1e-2, 'comps')
+    assert_close(out[6].sum(), g['tris_vis_sum'], 1e-6, 1e-3, 'tris_vis')
+    # Gradients: tiny BN batches at os32 make the fp32 backward ill-conditioned (float64 runs of
+    # reference and oracle agree to 3e-5); norms to 5 %, spot-checked full tensors to 8 % of max.
+    names = [str(n) for n in g['grad_names']]
+    assert sorted(names) == sorted(k for k, v in leaves.items() if v.grad is not None)
+    mine = np.array([float(leaves[k].grad.double().norm()) for k in names])
+    ref = g['grad_norms']
+    big = ref > 1e-3 * ref.max()
+    assert np.all(np.abs(mine[big] - ref[big]) <= 0.05 * ref[big]), np.max(np.abs(mine[big] - ref[big]) / ref[big])
+    for k in FULL_GRADS:
+        want = g['grad:' + k]
+        assert_close(leaves[k].grad, want, 0, 0.08 * float(np.abs(want).max()) + 1e-7, 'grad ' + k)
+    for k in ('encoder.bn1.running_mean', 'encoder.bn1.running_var', 'encoder.conv1.module.weight_u',
+              'decoder.layer1.0.conv1.module.weight_v', 'encoder.bn1.num_batches_tracked'):
+        assert_close(state[k].detach().float(), g['state:' + k].astype(np.float32), 1e-4, 1e-5, k)
+    if 'eval_alphas' in g.files:
+        with torch.no_grad():
+            oracle.window_forward(state, a, fg, bg, window=win, dilate_kernel=dil, training=True)
+            ev, _ = oracle.window_forward(state, a, fg, bg, window=win, dilate_kernel=dil, training=False)
+        assert_close(ev[7], g['eval_alphas'], 0, 5e-4, 'eval alphas')
+        assert_close(torch.stack(list(ev[:5])), g['eval_losses'], 1e-4, 1e-5, 'eval losses')
