@@ -1,0 +1,198 @@
+/* libtcvom_hip.so — C ABI of the MI355X (gfx950) kernels behind the TCVOM
+ * per-frame-window hot path (GCA base + Temporal Attention Module).
+ *
+ * The reference (yunkezhang/TCVOM) is pure PyTorch and has no FFI of its own;
+ * its operator boundary is the Python module API (models/model.py,
+ * models/VMN/VMN_model.py, models/GCA/ops.py).  Each entry point below replaces
+ * the chain of stock aten/cuDNN ops that the cited reference lines run; the
+ * Python mirror of that API (package tcvom_amd, re-exported as models.X) binds
+ * them with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned memory (PyTorch's
+ *    caching allocator); the library never allocates, frees or synchronises;
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, <0 on error; tcvom_last_error() gives the message
+ *    (thread-local); no C++ exception crosses the boundary;
+ *  - activations are NHWC bf16 ("bf16" below = uint16 bit pattern), statistics,
+ *    losses, logits and master weights are fp32;
+ *  - re-entrant, no global mutable state.
+ */
+#ifndef TCVOM_HIP_H
+#define TCVOM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCVOM_OK 0
+#define TCVOM_ERR_ARG (-1)
+#define TCVOM_ERR_LAUNCH (-2)
+
+const char* tcvom_last_error(void);
+int tcvom_abi_version(void);
+
+/* ------------------------------------------------------------------ implicit-GEMM convolution
+ * One "phase" of a (possibly transposed) convolution on bf16 MFMA:
+ *   out[n, i*out_step+out_off_h, j*out_step+out_off_w, k] =
+ *        act( bias[k] + sum_{t<ntaps} sum_{c<C} in[n, i*in_step+dh[t], j*in_step+dw[t], c] * w[k][wslot[t]][c] )
+ * for i<PH, j<PW (taps falling outside the input read zero).  Replaces
+ * nn.Conv2d / nn.ConvTranspose2d calls of models/GCA/encoders/resnet_enc.py:33-49,
+ * decoders/resnet_dec.py:33-59, res_gca_enc.py:20-55, VMN_model.py:13-15,63-66 and
+ * (with ntaps==1) the dense GEMMs of GuidedCxtAtten (models/GCA/ops.py:177,204).
+ * Optional fused epilogue: per-output-channel scale, "diagonal" subtraction
+ * (GCA self-mask, ops.py:188), bias, ReLU, BatchNorm partial statistics
+ * (sum, sum of squares per channel per 64-pixel group).                       */
+#define TCVOM_MAX_TAPS 16
+typedef struct {
+    int32_t N, H, W, C;          /* input NHWC; C power of two >= 8 unless ntaps == 1 */
+    int32_t OH, OW, K;           /* output tensor dims; K = output channels (multiple of 4) */
+    int32_t PH, PW;              /* phase grid */
+    int32_t in_step, out_step, out_off_h, out_off_w;
+    int32_t ntaps;               /* ntaps*C must be a multiple of 32 */
+    int32_t tap_dh[TCVOM_MAX_TAPS], tap_dw[TCVOM_MAX_TAPS];
+    int32_t tap_w[TCVOM_MAX_TAPS];   /* weight slot of tap t, -1 = zero tap (padding) */
+    int32_t wt;                  /* weight slots: w is [K][wt][C] bf16 */
+    int32_t ldo;                 /* output pixel stride in elements */
+    int32_t act;                 /* 0 none, 1 ReLU (before store and statistics) */
+    int32_t out_fp32;            /* store fp32 instead of bf16 */
+    int32_t stats_group_offset;  /* first statistics group written by this launch */
+    int32_t batch;               /* >1: blockIdx.z batches with the strides below (dense GEMM use) */
+    int64_t in_bstride, w_bstride, out_bstride, vec_bstride;
+} tcvom_conv_desc;
+
+/* stats_partial: [groups][2][K] fp32 or NULL; mscale/mdiag/bias: [K] fp32 or NULL. */
+int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias,
+                     const float* mscale, const float* mdiag, float* stats_partial,
+                     const tcvom_conv_desc* d, void* stream);
+/* number of statistics groups one launch of `d` writes (64 output pixels each) */
+int tcvom_conv_stats_groups(const tcvom_conv_desc* d);
+
+/* Weight gradient of the same phase (reduction over pixels, both operands pixel-major):
+ *   dw[k][wslot[t]][c] += sum_{n,i,j} dy[n, out pixel(i,j), k] * in[n, i*in_step+dh[t], j*in_step+dw[t], c]
+ * dw is fp32 [K][wt][C], accumulated with atomics (caller zeroes it).  With
+ * ntaps==1 this is the dense "both operands k-major" GEMM used by the GCA backward. */
+int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_conv_desc* d,
+                      int32_t ldy, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm around the convs
+ * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks
+ * (models/GCA/encoders/resnet_enc.py:33-49, decoders/resnet_dec.py:43-59).
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).   z = act(y*scale + shift + res1) + res2          */
+/* unbias_count: element count used for the unbiased running_var correction (0 = count); differs from
+ * count when the statistics were taken before a nearest x2 up-sampling (resnet_dec.py:112-118) */
+int tcvom_bn_finalize(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* scale_shift /*[2][C]*/, float* saved /*[2][C] mean,invstd*/,
+                      void* stream);
+int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
+int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
+                   int64_t pixels, int32_t C, int32_t act, void* stream);
+int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
+int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
+                        const float* saved, float* partial /*[groups][2][C]*/, int64_t pixels, int32_t C,
+                        int32_t act, void* stream);
+/* dgamma/dbeta are WRITTEN (not accumulated); coef is [3][C] scratch consumed by bn_bwd_apply */
+int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, const float* gamma,
+                          const float* saved, float* dgamma, float* dbeta, float* coef, void* stream);
+/* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
+ * gradient is additionally masked by y > 0 */
+int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
+                       const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                       int32_t C, int32_t act, int32_t training, int32_t in_relu, void* stream);
+
+/* ------------------------------------------------------------------ batched SpectralNorm + weight packing
+ * Replaces SpectralNorm._update_u_v/_noupdate_u_v (models/GCA/ops.py:25-45,74-80) for every wrapped
+ * conv of the network at once; see tcvom_amd/csrc/spectral.hip for the table layout (24 int64 words
+ * per layer) and tcvom_amd/weights.py for the host side that builds it.                      */
+typedef struct {
+    float* tvec;   /* [sum_wd] */
+    float* svec;   /* [sum_h]  */
+    float* sigma;  /* [max_calls][num_layers] */
+    float* uhist;  /* [max_calls][sum_h]  */
+    float* vhist;  /* [max_calls][sum_wd] */
+    int64_t sum_h, sum_wd;
+    int32_t num_layers;
+} tcvom_sn_scratch;
+int tcvom_sn_power_iteration(const int64_t* table, const tcvom_sn_scratch* s,
+                             const int32_t* work_wtu, int32_t n_wtu, const int32_t* work_wv, int32_t n_wv,
+                             const int32_t* sn_layers, int32_t n_sn, int32_t call, int32_t training, void* stream);
+int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, const int32_t* work_pack, int32_t n_pack,
+                  int32_t call, void* fwd_arena, void* bwd_arena, int64_t fwd_call_stride,
+                  int64_t bwd_call_stride, void* stream);
+int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
+                      const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
+                      const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,
+                      float* inner, int32_t max_calls, float* grad_arena, void* stream);
+
+/* ------------------------------------------------------------------ layout / resampling helpers (NHWC bf16) */
+int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_upsample2(const void* y, void* x, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream);
+int tcvom_sumpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream);
+int tcvom_reflect_pad1(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_reflect_pad1_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_add(const void* a, const void* b, const void* c, void* z, int64_t numel, void* stream);
+int tcvom_colsum(const void* dy, float* out, int64_t P, int32_t K, int32_t ld, void* stream);
+int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_t Cc, int64_t ldi, int64_t ldo,
+                         int32_t batch, int64_t in_bstride, int64_t out_bstride, void* stream);
+/* decoder head: conv2 (3x3, 32->1, bias) + (tanh+1)/2   (resnet_dec.py:80, VMN_GCA.py:45-47); w is fp32 [9][C] */
+int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
+                        int32_t W, int32_t C, void* stream);
+int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
+                        float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------ Temporal Attention Module
+ * Replaces FeatureAggregationModule._attention x2 + `v + xb + xf` (models/VMN/VMN_model.py:24-68).
+ * q,kb,kf,v,out: NHWC bf16 [B,H,W,C]; mask uint8 [B,H,W]; attb/attf fp32 [B,window^2,H*W].      */
+int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, const void* v, const uint8_t* mask,
+                  void* out, float* attb, float* attf, int32_t B, int32_t H, int32_t W, int32_t C,
+                  int32_t window, void* stream);
+/* pbuf, dsbuf: fp32 scratch [B][2][window^2][H*W]; dattb/dattf may be NULL */
+int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, const uint8_t* mask, const void* dout,
+                  const float* dattb, const float* dattf, void* dq, void* dkb, void* dkf,
+                  float* pbuf, float* dsbuf, int32_t B, int32_t H, int32_t W, int32_t C, int32_t window, void* stream);
+
+/* ------------------------------------------------------------------ Guided Contextual Attention pieces
+ * (models/GCA/ops.py:106-229); the two N x N GEMMs go through tcvom_conv_igemm / tcvom_wgrad_igemm. */
+int tcvom_gca_prepare(const void* g8, const uint8_t* unk8, void* G, float* scales, float* cvec, float* dvec,
+                      float* nrm, int32_t B, int32_t h8, int32_t w8, int32_t CG, void* stream);
+int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, void* stream);
+int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec, void* T, int32_t rows,
+                          int32_t ncols, int64_t ld, int64_t ldp, void* stream);
+int tcvom_gca_value_patches(const void* alpha, void* V, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);
+int tcvom_gca_value_patches_bwd(const float* dV, void* dalpha, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);
+int tcvom_gca_fold(const void* O, void* Y, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);
+int tcvom_gca_unfold(const void* dY, void* dO, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);
+int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G, const float* nrm, void* dg8, int32_t B,
+                          int32_t h8, int32_t w8, int32_t CG, void* stream);
+
+/* ------------------------------------------------------------------ facade: preprocessing, losses, optimizer
+ * (models/model.py:54-127,285-345; utils/loss_func.py:9-22; train_ddp.py:296-297)               */
+int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                     float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
+                     float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
+                     void* stream);
+int tcvom_masked_l1_fwd(const float* p1, const float* g1, const float* m1, const float* p2, const float* g2,
+                        const float* m2, const float* fgs, const float* bgs, float* alphas, float* comps,
+                        float* acc, int64_t B, int64_t HW, int64_t p_stride, int64_t frame_stride, int64_t rgb_stride, void* stream);
+int tcvom_masked_l1_bwd(const float* p1, const float* g1, const float* m1, const float* p2, const float* g2,
+                        const float* m2, const float* acc, const float* gout, float weight, float* dp1,
+                        float* dp2, int32_t accumulate, int64_t B, int64_t HW, int64_t p_stride, int64_t frame_stride, void* stream);
+int tcvom_avgpool8(const float* g, float* out, int64_t frames, int32_t H, int32_t W, void* stream);
+int tcvom_att_bce(const float* logits, const float* cg, const float* adj, const uint8_t* mask, float* dlogit,
+                  float* acc, int32_t B, int32_t h, int32_t w, int32_t window, float thres, float smooth,
+                  int64_t g_bstride, int32_t zero_acc, void* stream);
+int tcvom_att_bce_bwd(const float* dlogit_unscaled, const float* acc, const float* gout, float weight,
+                      float* dlogit, int64_t numel, int32_t window, void* stream);
+int tcvom_loss_finalize(const float* acc, float* out, float weight, int32_t denom_mode, float numel_total,
+                        int32_t window, int32_t accumulate, void* stream);
+int tcvom_adam_mt(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

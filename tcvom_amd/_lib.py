@@ -1,0 +1,144 @@
+"""ctypes binding of libtcvom_hip.so (the C ABI declared in include/tcvom_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent, importing this module raises.  (`__graft_entry__.build()` / `make -C
+tcvom_amd/csrc` produces the library; it cross-compiles without a GPU.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtcvom_hip.so')
+
+MAX_TAPS = 16
+
+
+class ConvDesc(C.Structure):
+    """struct tcvom_conv_desc (include/tcvom_hip.h)."""
+    _fields_ = [
+        ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32),
+        ('OH', C.c_int32), ('OW', C.c_int32), ('K', C.c_int32),
+        ('PH', C.c_int32), ('PW', C.c_int32),
+        ('in_step', C.c_int32), ('out_step', C.c_int32), ('out_off_h', C.c_int32), ('out_off_w', C.c_int32),
+        ('ntaps', C.c_int32),
+        ('tap_dh', C.c_int32 * MAX_TAPS), ('tap_dw', C.c_int32 * MAX_TAPS), ('tap_w', C.c_int32 * MAX_TAPS),
+        ('wt', C.c_int32), ('ldo', C.c_int32), ('act', C.c_int32), ('out_fp32', C.c_int32),
+        ('stats_group_offset', C.c_int32), ('batch', C.c_int32),
+        ('in_bstride', C.c_int64), ('w_bstride', C.c_int64), ('out_bstride', C.c_int64), ('vec_bstride', C.c_int64),
+    ]
+
+
+class SnScratch(C.Structure):
+    """struct tcvom_sn_scratch."""
+    _fields_ = [('tvec', C.c_void_p), ('svec', C.c_void_p), ('sigma', C.c_void_p), ('uhist', C.c_void_p),
+                ('vhist', C.c_void_p), ('sum_h', C.c_int64), ('sum_wd', C.c_int64), ('num_layers', C.c_int32)]
+
+
+class TcvomError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'tcvom_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C tcvom_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % LIB_PATH)
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+_lib.tcvom_last_error.restype = C.c_char_p
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+DP = C.POINTER(ConvDesc)
+SP = C.POINTER(SnScratch)
+
+# name -> argtypes (all return int except the explicitly listed ones)
+_PROTOS = {
+    'tcvom_conv_igemm': [vp, vp, vp, vp, vp, vp, vp, DP, vp],
+    'tcvom_conv_stats_groups': [DP],
+    'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
+    'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp],
+    'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
+    'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    'tcvom_bn_bwd_groups': [i64, i32],
+    'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp],
+    'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
+    'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
+    'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
+    'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, vp],
+    'tcvom_avgpool2': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_upsample2': [vp, vp, i32, i32, i32, i32, f32, vp],
+    'tcvom_sumpool2': [vp, vp, i32, i32, i32, i32, f32, vp],
+    'tcvom_reflect_pad1': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_reflect_pad1_bwd': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_add': [vp, vp, vp, vp, i64, vp],
+    'tcvom_colsum': [vp, vp, i64, i32, i32, vp],
+    'tcvom_transpose_bf16': [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp],
+    'tcvom_head_conv_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_head_conv_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_tam_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_tam_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_gca_prepare': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_row_softmax': [vp, vp, i32, i32, i64, i64, vp],
+    'tcvom_row_softmax_bwd': [vp, vp, vp, vp, i32, i32, i64, i64, vp],
+    'tcvom_gca_value_patches': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_gca_value_patches_bwd': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_gca_fold': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_gca_unfold': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_gca_patches_bwd': [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_preprocess': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, vp],
+    'tcvom_masked_l1_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
+    'tcvom_masked_l1_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i64, i64, i64, vp],
+    'tcvom_avgpool8': [vp, vp, i64, i32, i32, vp],
+    'tcvom_att_bce': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i64, i32, vp],
+    'tcvom_att_bce_bwd': [vp, vp, vp, f32, vp, i64, i32, vp],
+    'tcvom_loss_finalize': [vp, vp, f32, i32, f32, i32, i32, vp],
+    'tcvom_adam_mt': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp],
+    'tcvom_abi_version': [],
+}
+# entry points that return a count, not a status
+_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version'}
+
+EXPORTS = sorted(list(_PROTOS) + ['tcvom_last_error'])
+
+
+def _bind():
+    fns = {}
+    for name, argtypes in _PROTOS.items():
+        try:
+            fn = getattr(_lib, name)
+        except AttributeError as e:
+            raise ImportError('tcvom_amd: %s does not export %s (stale build?)' % (LIB_PATH, name)) from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+        fns[name] = fn
+    return fns
+
+
+_FNS = _bind()
+
+
+def last_error():
+    return (_lib.tcvom_last_error() or b'').decode()
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise TcvomError on failure."""
+    rc = _FNS[name](*args)
+    if name in _PLAIN:
+        return rc
+    if rc != 0:
+        raise TcvomError('%s failed (%d): %s' % (name, rc, last_error()))
+    return rc
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,66 @@
+// Shared device/host helpers for libtcvom_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tcvom_hip.h"
+
+typedef unsigned short bf16raw;  // bf16 bit pattern
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- error reporting across the C ABI (no exceptions cross the boundary) ----
+extern thread_local char g_tcvom_err[512];
+int tcvom_fail(int code, const char* fmt, ...);
+#define TCVOM_CHECK_ARG(cond, ...) \
+    do { if (!(cond)) return tcvom_fail(TCVOM_ERR_ARG, __VA_ARGS__); } while (0)
+#define TCVOM_LAUNCH_CHECK(name) \
+    do { hipError_t e_ = hipGetLastError(); \
+         if (e_ != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---- bf16 <-> f32 ----
+__device__ __forceinline__ float bf2f(bf16raw h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    bf16x2_t v = {(__bf16)a, (__bf16)b};           // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16raw f2bf(float a) {
+    __bf16 v = (__bf16)a;
+    return __builtin_bit_cast(bf16raw, v);
+}
+__device__ __forceinline__ void unpack8(const uint4& q, float* f) {
+    f[0] = bflo(q.x); f[1] = bfhi(q.x); f[2] = bflo(q.y); f[3] = bfhi(q.y);
+    f[4] = bflo(q.z); f[5] = bfhi(q.z); f[6] = bflo(q.w); f[7] = bfhi(q.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 q;
+    q.x = pack2bf(f[0], f[1]); q.y = pack2bf(f[2], f[3]);
+    q.z = pack2bf(f[4], f[5]); q.w = pack2bf(f[6], f[7]);
+    return q;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over a 256-thread block; result valid in every thread.  `red` = 4+ floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,305 @@
+// Guided Contextual Attention (models/GCA/ops.py:106-229) — the data-movement kernels around the
+// two big MFMA GEMMs (scores S = G G^T and O = P V, run through igemm_nt with ntaps == 1).
+//
+//   G  [B][N][576]   raw reflect-padded 3x3x64 patches of the os16 guidance map (queries AND keys)
+//   c_j = (mm_j ? s0 : s1) / max(||G_j||, 1e-4)      per-key scale  (ops.py:139-143,174-175,186)
+//   d_j = 1e4 * mm_j                                  self-mask      (ops.py:159-161,188)
+//   S'[i][j] = c_j <G_i, G_j> - d_j [i == j];   P = softmax_j S'   (ops.py:177-190)
+//   V  [B][N][2048]  reflect-padded 4x4 stride-2 patches of the os8 feature (ops.py:115-119)
+//   O = P V ;  y = fold_{4x4,s2,p1}(O) / 4                          (ops.py:204)
+// and the matching backward pieces.  Patch column order is (tap, channel) everywhere.
+#include "common.h"
+
+__device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// ------------------------------------------------------------------ unknown-area statistics -> [B][2] scales
+__global__ __launch_bounds__(256) void gca_scale_kernel(const unsigned char* __restrict__ unk8, float* __restrict__ scales,
+                                                        int h8, int w8) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int h = h8 / 2, w = w8 / 2;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < h * w; i += 256)
+        a += unk8[((int64_t)b * h8 + 2 * (i / w)) * w8 + 2 * (i % w)] ? 1.f : 0.f;
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) {
+        const float um = a / (float)(h * w), km = 1.f - um;
+        scales[b * 2 + 0] = fminf(fmaxf(sqrtf(um / km), 0.1f), 10.f);
+        scales[b * 2 + 1] = fminf(fmaxf(sqrtf(km / um), 0.1f), 10.f);
+    }
+}
+
+// ------------------------------------------------------------------ guidance patches + per-key vectors
+// g8: [B,h8,w8,64] bf16 (guidance_conv output at os8; os16 grid = even positions).  one wave per key.
+__global__ __launch_bounds__(256) void gca_patches_kernel(const bf16raw* __restrict__ g8, const unsigned char* __restrict__ unk8,
+                                                          const float* __restrict__ scales, bf16raw* __restrict__ G,
+                                                          float* __restrict__ cvec, float* __restrict__ dvec,
+                                                          float* __restrict__ nrm, int B, int h8, int w8, int CG) {
+    const int h = h8 / 2, w = w8 / 2, N = h * w;
+    const int lane = threadIdx.x & 63;
+    const int64_t key = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (key >= (int64_t)B * N) return;
+    const int b = (int)(key / N), j = (int)(key % N), jy = j / w, jx = j % w;
+    float ss = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = refl(jy + t / 3 - 1, h), xx = refl(jx + t % 3 - 1, w);
+        const int64_t src = ((int64_t)b * h8 + 2 * yy) * w8 + 2 * xx;
+        any = any || unk8[src] != 0;
+        for (int c = lane; c < CG; c += 64) {
+            const bf16raw val = g8[src * CG + c];
+            G[(key * 9 + t) * CG + c] = val;
+            const float f = bf2f(val);
+            ss += f * f;
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const float n = sqrtf(ss);
+        const float sc = any ? scales[b * 2] : scales[b * 2 + 1];
+        cvec[key] = sc / fmaxf(n, 1e-4f);
+        dvec[key] = any ? 1e4f : 0.f;
+        nrm[key] = n;
+    }
+}
+
+// ------------------------------------------------------------------ row softmax: fp32 [rows][ld] -> bf16 [rows][ldp]
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ S, bf16raw* __restrict__ P, int ncols,
+                                                          int64_t ld, int64_t ldp) {
+    __shared__ float red[4];
+    const float* s = S + (int64_t)blockIdx.x * ld;
+    bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    float mx = -3.0e38f;
+    for (int j = threadIdx.x; j < ncols; j += 256) mx = fmaxf(mx, s[j]);
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float den = 0.f;
+    for (int j = threadIdx.x; j < ncols; j += 256) den += __expf(s[j] - mx);
+    den = block_sum_256(den, red);
+    const float r = 1.f / den;
+    for (int j = threadIdx.x; j < ldp; j += 256) p[j] = j < ncols ? f2bf(__expf(s[j] - mx) * r) : (bf16raw)0;
+}
+
+// dS'[i][j] = P (dP - sum_j P dP);  T = dS' * c_j  (bf16, padded columns zero)
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const bf16raw* __restrict__ P, const float* __restrict__ dP,
+                                                              const float* __restrict__ cvec, bf16raw* __restrict__ T,
+                                                              int ncols, int64_t ld, int64_t ldp) {
+    __shared__ float red[4];
+    const bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    const float* d = dP + (int64_t)blockIdx.x * ld;
+    bf16raw* t = T + (int64_t)blockIdx.x * ldp;
+    float a = 0.f;
+    for (int j = threadIdx.x; j < ncols; j += 256) a += bf2f(p[j]) * d[j];
+    a = block_sum_256(a, red);
+    for (int j = threadIdx.x; j < ldp; j += 256)
+        t[j] = j < ncols ? f2bf(bf2f(p[j]) * (d[j] - a) * cvec[j]) : (bf16raw)0;
+}
+
+// ------------------------------------------------------------------ value patches V[key][(ky*4+kx)*C + c]
+__global__ __launch_bounds__(256) void gca_value_patches_kernel(const uint4* __restrict__ alpha, uint4* __restrict__ V,
+                                                                int B, int h8, int w8, int C8) {
+    const int h = h8 / 2, w = w8 / 2, N = h * w;
+    const int64_t total = (int64_t)B * N * 16 * C8;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % C8);
+        const int t = (int)((v / C8) % 16);
+        const int64_t key = v / ((int64_t)C8 * 16);
+        const int b = (int)(key / N), j = (int)(key % N);
+        const int yy = refl(2 * (j / w) - 1 + t / 4, h8), xx = refl(2 * (j % w) - 1 + t % 4, w8);
+        V[v] = alpha[(((int64_t)b * h8 + yy) * w8 + xx) * C8 + c];
+    }
+}
+// dalpha[y][x][c] = sum over (key, tap) whose reflected source is (y,x) of dV[key][tap][c]   (dV fp32)
+__global__ __launch_bounds__(256) void gca_value_patches_bwd_kernel(const float* __restrict__ dV, bf16raw* __restrict__ dalpha,
+                                                                    int B, int h8, int w8, int C) {
+    const int h = h8 / 2, w = w8 / 2, N = h * w;
+    const int64_t total = (int64_t)B * h8 * w8 * C;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % C);
+        int64_t t = v / C;
+        const int x = (int)(t % w8); t /= w8;
+        const int y = (int)(t % h8);
+        const int b = (int)(t / h8);
+        float acc = 0.f;
+        for (int jy = max(0, (y - 3) / 2 - 1); jy <= min(h - 1, (y + 3) / 2 + 1); ++jy)
+            for (int ky = 0; ky < 4; ++ky) {
+                if (refl(2 * jy - 1 + ky, h8) != y) continue;
+                for (int jx = max(0, (x - 3) / 2 - 1); jx <= min(w - 1, (x + 3) / 2 + 1); ++jx)
+                    for (int kx = 0; kx < 4; ++kx) {
+                        if (refl(2 * jx - 1 + kx, w8) != x) continue;
+                        acc += dV[(((int64_t)b * N + jy * w + jx) * 16 + ky * 4 + kx) * C + c];
+                    }
+            }
+        dalpha[v] = f2bf(acc);
+    }
+}
+
+// ------------------------------------------------------------------ fold: y = fold(O)/4 and its adjoint
+__global__ __launch_bounds__(256) void gca_fold_kernel(const uint4* __restrict__ O, uint4* __restrict__ Y, int B, int h8, int w8, int C8) {
+    const int h = h8 / 2, w = w8 / 2, N = h * w;
+    const int64_t total = (int64_t)B * h8 * w8 * C8;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % C8);
+        int64_t t = v / C8;
+        const int x = (int)(t % w8); t /= w8;
+        const int y = (int)(t % h8);
+        const int b = (int)(t / h8);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int iy = (y + 1) / 2 - a, ky = y + 1 - 2 * iy;
+            if (iy < 0 || iy >= h || ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ix = (x + 1) / 2 - e, kx = x + 1 - 2 * ix;
+                if (ix < 0 || ix >= w || kx < 0 || kx > 3) continue;
+                unpack8(O[(((int64_t)b * N + iy * w + ix) * 16 + ky * 4 + kx) * C8 + c], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += f[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= 0.25f;
+        Y[v] = pack8(acc);
+    }
+}
+// dO[i][(ky*4+kx)*C + c] = dY[2iy-1+ky][2ix-1+kx][c] / 4  (zero outside)
+__global__ __launch_bounds__(256) void gca_unfold_kernel(const uint4* __restrict__ dY, uint4* __restrict__ dO, int B, int h8, int w8, int C8) {
+    const int h = h8 / 2, w = w8 / 2, N = h * w;
+    const int64_t total = (int64_t)B * N * 16 * C8;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % C8);
+        const int t = (int)((v / C8) % 16);
+        const int64_t key = v / ((int64_t)C8 * 16);
+        const int b = (int)(key / N), i = (int)(key % N);
+        const int yy = 2 * (i / w) - 1 + t / 4, xx = 2 * (i % w) - 1 + t % 4;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (yy >= 0 && yy < h8 && xx >= 0 && xx < w8) {
+            float f[8];
+            unpack8(dY[(((int64_t)b * h8 + yy) * w8 + xx) * C8 + c], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] *= 0.25f;
+            q = pack8(f);
+        }
+        dO[v] = q;
+    }
+}
+
+// ------------------------------------------------------------------ patch gradient -> guidance map gradient
+// dWp[j] = dWq[j] + M'[j] - coef_j G[j],  coef_j = <M'_j, G_j>/n_j^2 (n_j > 1e-4)   [one wave per key, in place in dWq]
+__global__ __launch_bounds__(256) void gca_patch_grad_kernel(float* __restrict__ dWq, const float* __restrict__ Mp,
+                                                             const bf16raw* __restrict__ G, const float* __restrict__ nrm,
+                                                             int64_t keys, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t key = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (key >= keys) return;
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += Mp[key * D + d] * bf2f(G[key * D + d]);
+    dot = wave_sum(dot);
+    const float n = nrm[key];
+    const float coef = n > 1e-4f ? dot / (n * n) : 0.f;
+    for (int d = lane; d < D; d += 64) dWq[key * D + d] += Mp[key * D + d] - coef * bf2f(G[key * D + d]);
+}
+// dg8[b][2y][2x][c] = sum over (key, tap) with reflected source (y,x) of dWp[key][tap*CG + c]; zero at odd positions
+__global__ __launch_bounds__(256) void gca_patches_bwd_kernel(const float* __restrict__ dWp, bf16raw* __restrict__ dg8,
+                                                              int B, int h8, int w8, int CG) {
+    const int h = h8 / 2, w = w8 / 2, N = h * w;
+    const int64_t total = (int64_t)B * h8 * w8 * CG;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(v % CG);
+        int64_t t = v / CG;
+        const int x8 = (int)(t % w8); t /= w8;
+        const int y8 = (int)(t % h8);
+        const int b = (int)(t / h8);
+        float acc = 0.f;
+        if ((y8 & 1) == 0 && (x8 & 1) == 0) {
+            const int y = y8 / 2, x = x8 / 2;
+            for (int jy = max(0, y - 2); jy <= min(h - 1, y + 2); ++jy)
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (refl(jy + ky - 1, h) != y) continue;
+                    for (int jx = max(0, x - 2); jx <= min(w - 1, x + 2); ++jx)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            if (refl(jx + kx - 1, w) != x) continue;
+                            acc += dWp[(((int64_t)b * N + jy * w + jx) * 9 + ky * 3 + kx) * CG + c];
+                        }
+                }
+        }
+        dg8[v] = f2bf(acc);
+    }
+}
+
+static int sgrid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int tcvom_gca_prepare(const void* g8, const uint8_t* unk8, void* G, float* scales, float* cvec, float* dvec,
+                                 float* nrm, int32_t B, int32_t h8, int32_t w8, int32_t CG, void* stream) {
+    TCVOM_CHECK_ARG(g8 && unk8 && G && scales && cvec && dvec && nrm, "gca_prepare: null pointer");
+    TCVOM_CHECK_ARG(h8 % 2 == 0 && w8 % 2 == 0 && h8 >= 4 && w8 >= 4, "gca_prepare: os8 grid %dx%d must be even and >= 4", h8, w8);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gca_scale_kernel, dim3(B), dim3(256), 0, st, unk8, scales, h8, w8);
+    const int64_t keys = (int64_t)B * (h8 / 2) * (w8 / 2);
+    hipLaunchKernelGGL(gca_patches_kernel, dim3(cdiv(keys, 4)), dim3(256), 0, st, (const bf16raw*)g8, unk8, scales,
+                       (bf16raw*)G, cvec, dvec, nrm, B, h8, w8, CG);
+    TCVOM_LAUNCH_CHECK("gca_prepare");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, void* stream) {
+    TCVOM_CHECK_ARG(S && P && rows > 0 && ncols > 0 && ld >= ncols && ldp >= ncols, "row_softmax: bad args");
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, (bf16raw*)P, ncols, ld, ldp);
+    TCVOM_LAUNCH_CHECK("row_softmax");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec, void* T, int32_t rows,
+                                     int32_t ncols, int64_t ld, int64_t ldp, void* stream) {
+    TCVOM_CHECK_ARG(P && dP && cvec && T && rows > 0 && ncols > 0, "row_softmax_bwd: bad args");
+    hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)P, dP, cvec,
+                       (bf16raw*)T, ncols, ld, ldp);
+    TCVOM_LAUNCH_CHECK("row_softmax_bwd");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_value_patches(const void* alpha, void* V, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(alpha && V && C % 8 == 0, "gca_value_patches: bad args");
+    hipLaunchKernelGGL(gca_value_patches_kernel, dim3(sgrid((int64_t)B * h8 * w8 / 4 * 16 * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4*)alpha, (uint4*)V, B, h8, w8, C / 8);
+    TCVOM_LAUNCH_CHECK("gca_value_patches");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_value_patches_bwd(const float* dV, void* dalpha, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(dV && dalpha, "gca_value_patches_bwd: bad args");
+    hipLaunchKernelGGL(gca_value_patches_bwd_kernel, dim3(sgrid((int64_t)B * h8 * w8 * C)), dim3(256), 0,
+                       (hipStream_t)stream, dV, (bf16raw*)dalpha, B, h8, w8, C);
+    TCVOM_LAUNCH_CHECK("gca_value_patches_bwd");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_fold(const void* O, void* Y, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(O && Y && C % 8 == 0, "gca_fold: bad args");
+    hipLaunchKernelGGL(gca_fold_kernel, dim3(sgrid((int64_t)B * h8 * w8 * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)O, (uint4*)Y, B, h8, w8, C / 8);
+    TCVOM_LAUNCH_CHECK("gca_fold");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_unfold(const void* dY, void* dO, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(dY && dO && C % 8 == 0, "gca_unfold: bad args");
+    hipLaunchKernelGGL(gca_unfold_kernel, dim3(sgrid((int64_t)B * h8 * w8 / 4 * 16 * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4*)dY, (uint4*)dO, B, h8, w8, C / 8);
+    TCVOM_LAUNCH_CHECK("gca_unfold");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G, const float* nrm, void* dg8, int32_t B,
+                                     int32_t h8, int32_t w8, int32_t CG, void* stream) {
+    TCVOM_CHECK_ARG(dWq && Mp && G && nrm && dg8, "gca_patches_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t keys = (int64_t)B * (h8 / 2) * (w8 / 2);
+    hipLaunchKernelGGL(gca_patch_grad_kernel, dim3(cdiv(keys, 4)), dim3(256), 0, st, dWq, Mp, (const bf16raw*)G, nrm, keys, 9 * CG);
+    hipLaunchKernelGGL(gca_patches_bwd_kernel, dim3(sgrid((int64_t)B * h8 * w8 * CG)), dim3(256), 0, st, dWq, (bf16raw*)dg8, B, h8, w8, CG);
+    TCVOM_LAUNCH_CHECK("gca_patches_bwd");
+    return TCVOM_OK;
+}

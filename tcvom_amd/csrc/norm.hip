@@ -1,0 +1,292 @@
+// BatchNorm (train-mode batch statistics / eval-mode running statistics) around the igemm
+// convolutions, fused with activation and residual adds.  Replaces nn.BatchNorm2d + ReLU /
+// LeakyReLU(0.2) + `out += identity` of the reference BasicBlocks
+// (models/GCA/encoders/resnet_enc.py:33-49, decoders/resnet_dec.py:43-59) and the
+// conv->ReLU->BN shortcut order of res_gca_enc.py:47-55.  All HBM-bound streaming kernels:
+// 16-byte (8 x bf16) accesses per lane, fp32 math, statistics combined in fp64.
+#include "common.h"
+
+// ---------------------------------------------------------------- statistics finalize
+// partial: [G][2][C] (sum, sumsq).  One block = 32 channels x 8 group slices.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int G, int C, double count, double unbias_count,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var,
+    float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved)
+{
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int g = sl; g < G; g += 8) {
+            a += (double)partial[(int64_t)g * 2 * C + c];
+            b += (double)partial[(int64_t)g * 2 * C + C + c];
+        }
+    }
+    s1[sl][cl] = a;
+    s2[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale_shift[c] = sc;
+        scale_shift[C + c] = beta[c] - (float)mean * sc;
+        saved[c] = (float)mean;
+        saved[C + c] = invstd;
+        if (running_mean) {
+            const double unb = unbias_count > 1.0 ? var * unbias_count / (unbias_count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale_shift, float* __restrict__ saved)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = beta[c] - rm[c] * sc;
+    saved[c] = rm[c];
+    saved[C + c] = invstd;
+}
+
+// ---------------------------------------------------------------- apply: z = act(y*s + b + res1) + res2
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    return act == 1 ? fmaxf(x, 0.f) : (act == 2 ? (x > 0.f ? x : 0.2f * x) : x);
+}
+__device__ __forceinline__ float act_grad(float pre, int act) {
+    return act == 1 ? (pre > 0.f ? 1.f : 0.f) : (act == 2 ? (pre > 0.f ? 1.f : 0.2f) : 1.f);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const uint4* __restrict__ y, const float* __restrict__ scale_shift,
+    const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
+    int64_t nvec, int C8, int C, int act)
+{
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(v % C8) * 8;
+        float f[8], r1[8], r2[8];
+        unpack8(y[v], f);
+        if (res1) unpack8(res1[v], r1);
+        if (res2) unpack8(res2[v], r2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = f[k] * scale_shift[c0 + k] + scale_shift[C + c0 + k];
+            if (res1) x += r1[k];
+            x = act_fwd(x, act);
+            if (res2) x += r2[k];
+            f[k] = x;
+        }
+        z[v] = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------- backward, pass 1: per-channel sums
+// block = 256 threads = RP pixel rows x C8 channel octets (C8 <= 256); partial[block][2][C]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const uint4* __restrict__ dz, const uint4* __restrict__ y, const uint4* __restrict__ res1,
+    const float* __restrict__ scale_shift, const float* __restrict__ saved,
+    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block)
+{
+    extern __shared__ float red[];        // [2][256][8]
+    const int tid = threadIdx.x;
+    const int oct = tid % C8;
+    const int prow = tid / C8;
+    const int RP = 256 / C8;
+    const int c0 = oct * 8;
+    float sg[8], sx[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sg[k] = 0.f; sx[k] = 0.f;
+        sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k];
+        mu[k] = saved[c0 + k]; is[k] = saved[C + c0 + k];
+    }
+    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
+    if (prow < RP) {
+        for (int64_t p = pbeg + prow; p < pend; p += RP) {
+            const int64_t v = p * C8 + oct;
+            float g[8], yy[8], r1[8];
+            unpack8(dz[v], g);
+            unpack8(y[v], yy);
+            if (res1) unpack8(res1[v], r1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float pre = yy[k] * sc[k] + sh[k];
+                if (res1) pre += r1[k];
+                const float gg = g[k] * act_grad(pre, act);
+                sg[k] += gg;
+                sx[k] += gg * (yy[k] - mu[k]) * is[k];
+            }
+        }
+    }
+    float* r_g = red;                 // [256][8]
+    float* r_x = red + 256 * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { r_g[tid * 8 + k] = sg[k]; r_x[tid * 8 + k] = sx[k]; }
+    __syncthreads();
+    if (tid < C8) {
+        float ag[8], ax[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ax[k] = 0.f; }
+        for (int r = 0; r < RP; ++r) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ag[k] += r_g[(r * C8 + tid) * 8 + k];
+                ax[k] += r_x[(r * C8 + tid) * 8 + k];
+            }
+        }
+        float* po = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { po[tid * 8 + k] = ag[k]; po[C + tid * 8 + k] = ax[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int G, int C, double count,
+    const float* __restrict__ gamma, const float* __restrict__ saved,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef)
+{
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int g = sl; g < G; g += 8) {
+            a += (double)partial[(int64_t)g * 2 * C + c];
+            b += (double)partial[(int64_t)g * 2 * C + C + c];
+        }
+    }
+    s1[sl][cl] = a;
+    s2[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        if (dbeta) dbeta[c] = (float)a;
+        if (dgamma) dgamma[c] = (float)b;
+        coef[c] = (float)(a / count);
+        coef[C + c] = (float)(b / count);
+        coef[2 * C + c] = gamma[c] * saved[C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const uint4* __restrict__ dz, const uint4* __restrict__ y, const uint4* __restrict__ res1,
+    const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
+    uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t nvec, int C8, int C, int act, int training, int in_relu)
+{
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(v % C8) * 8;
+        float g[8], yy[8], r1[8], o[8];
+        unpack8(dz[v], g);
+        unpack8(y[v], yy);
+        if (res1) unpack8(res1[v], r1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            float pre = yy[k] * scale_shift[c] + scale_shift[C + c];
+            if (res1) pre += r1[k];
+            const float gg = g[k] * act_grad(pre, act);
+            g[k] = gg;
+            const float xh = (yy[k] - saved[c]) * saved[C + c];
+            o[k] = training ? coef[2 * C + c] * (gg - coef[c] - xh * coef[C + c]) : coef[2 * C + c] * gg;
+            if (in_relu && yy[k] <= 0.f) o[k] = 0.f;
+        }
+        dy[v] = pack8(o);
+        if (dres1) dres1[v] = pack8(g);
+    }
+}
+
+static int stream_grid(int64_t n, int per_block) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* scale_shift, float* saved, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0, "bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, groups, C,
+                       (double)count, (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, running_mean, running_var,
+                       momentum, eps, scale_shift, saved);
+    TCVOM_LAUNCH_CHECK("bn_finalize");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, float* scale_shift, float* saved, void* stream) {
+    TCVOM_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && saved && C > 0, "bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale_shift, saved);
+    TCVOM_LAUNCH_CHECK("bn_eval_coeffs");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
+                              int64_t pixels, int32_t C, int32_t act, void* stream) {
+    TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
+    const int64_t nvec = pixels * (C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, nvec, C / 8, C, act);
+    TCVOM_LAUNCH_CHECK("bn_apply");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
+    const int rows = 256 / (C / 8);
+    int64_t per = (int64_t)rows * 32;               // >= 32 loop iterations per block
+    int64_t g = (pixels + per - 1) / per;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
+                                   const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
+                                   void* stream) {
+    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048,
+                    "bn_bwd_reduce: bad args (C=%d)", C);
+    const int groups = tcvom_bn_bwd_groups(pixels, C);
+    const int rpb = (int)((pixels + groups - 1) / groups);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(groups), dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                       (const uint4*)dz, (const uint4*)y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C,
+                       act, rpb);
+    TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count,
+                                     const float* gamma, const float* saved, float* dgamma, float* dbeta,
+                                     float* coef, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, groups, C,
+                       (double)count, gamma, saved, dgamma, dbeta, coef);
+    TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
+                                  const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, void* stream) {
+    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
+    const int64_t nvec = pixels * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)dz, (const uint4*)y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
+                       (uint4*)dres1, nvec, C / 8, C, act, training, in_relu);
+    TCVOM_LAUNCH_CHECK("bn_bwd_apply");
+    return TCVOM_OK;
+}

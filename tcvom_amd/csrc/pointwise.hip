@@ -1,0 +1,366 @@
+// Small HBM-bound layout / resampling kernels around the conv stack (all NHWC bf16, 16-byte
+// accesses): AvgPool2d(2) of the encoder down-sample path (resnet_enc.py:108-114), nearest x2
+// up-sampling of the decoder identity path (resnet_dec.py:112-118), ReflectionPad2d(1) of the
+// guidance head (res_gca_enc.py:20-33), bias gradients, bf16 matrix transposes, and the final
+// 32->1 3x3 conv + (tanh+1)/2 of the decoder (resnet_dec.py:80, VMN_GCA.py:45-47).
+#include "common.h"
+
+static int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define GRID_STRIDE(v, n) \
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < (n); v += (int64_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- avgpool 2x2 s2 (fwd) / its backward
+__global__ void avgpool2_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t n = (int64_t)N * OH * OW * C8;
+    GRID_STRIDE(v, n) {
+        const int c = (int)(v % C8);
+        int64_t t = v / C8;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int nn = (int)(t / OH);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                unpack8(x[(((int64_t)nn * H + 2 * oh + dy) * W + 2 * ow + dx) * C8 + c], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += f[k];
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= 0.25f;
+        y[v] = pack8(acc);
+    }
+}
+// dx[n,h,w] = scale * dy[n,h/2,w/2]      (avgpool backward: scale .25; nearest-upsample forward: scale 1)
+__global__ void upsample2_kernel(const uint4* __restrict__ y, uint4* __restrict__ x, int N, int H, int W, int C8, float scale) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t n = (int64_t)N * H * W * C8;
+    GRID_STRIDE(v, n) {
+        const int c = (int)(v % C8);
+        int64_t t = v / C8;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int nn = (int)(t / H);
+        uint4 q = y[(((int64_t)nn * OH + h / 2) * OW + w / 2) * C8 + c];
+        if (scale != 1.f) {
+            float f[8];
+            unpack8(q, f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] *= scale;
+            q = pack8(f);
+        }
+        x[v] = q;
+    }
+}
+// y[n,oh,ow] = scale * sum_{2x2} x[...]   (nearest-upsample backward: scale 1)
+__global__ void sumpool2_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, float scale) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t n = (int64_t)N * OH * OW * C8;
+    GRID_STRIDE(v, n) {
+        const int c = (int)(v % C8);
+        int64_t t = v / C8;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const int nn = (int)(t / OH);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                unpack8(x[(((int64_t)nn * H + 2 * oh + dy) * W + 2 * ow + dx) * C8 + c], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += f[k];
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= scale;
+        y[v] = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------- reflection pad 1 (fwd) and its backward
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ void reflect_pad1_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8) {
+    const int PH = H + 2, PW = W + 2;
+    const int64_t n = (int64_t)N * PH * PW * C8;
+    GRID_STRIDE(v, n) {
+        const int c = (int)(v % C8);
+        int64_t t = v / C8;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int nn = (int)(t / PH);
+        y[v] = x[(((int64_t)nn * H + reflect_idx(ph - 1, H)) * W + reflect_idx(pw - 1, W)) * C8 + c];
+    }
+}
+__global__ void reflect_pad1_bwd_kernel(const uint4* __restrict__ dy, uint4* __restrict__ dx, int N, int H, int W, int C8) {
+    const int PH = H + 2, PW = W + 2;
+    const int64_t n = (int64_t)N * H * W * C8;
+    GRID_STRIDE(v, n) {
+        const int c = (int)(v % C8);
+        int64_t t = v / C8;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int nn = (int)(t / H);
+        // padded rows that map to h: h+1 always; 0 if h==1; PH-1 if h==H-2
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + 1;
+        if (h == 1) hs[nh++] = 0;
+        if (h == H - 2) hs[nh++] = PH - 1;
+        ws[nw++] = w + 1;
+        if (w == 1) ws[nw++] = 0;
+        if (w == W - 2) ws[nw++] = PW - 1;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) {
+                unpack8(dy[(((int64_t)nn * PH + hs[a]) * PW + ws[b]) * C8 + c], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += f[k];
+            }
+        dx[v] = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------- z = a + b (+ c)
+__global__ void add_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c,
+                           uint4* __restrict__ z, int64_t nvec) {
+    GRID_STRIDE(v, nvec) {
+        float fa[8], fb[8], fc[8];
+        unpack8(a[v], fa);
+        unpack8(b[v], fb);
+        if (c) unpack8(c[v], fc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fa[k] += fb[k] + (c ? fc[k] : 0.f);
+        z[v] = pack8(fa);
+    }
+}
+
+// ---------------------------------------------------------------- bias gradient: db[k] = sum_p dy[p][k]
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16raw* __restrict__ dy, float* __restrict__ out,
+                                                     int64_t P, int K, int ld, int rows_per_block) {
+    // thread t handles column t % K... generic: each thread walks rows with stride 256/K' ; K <= 256
+    const int col = threadIdx.x % K;
+    const int rsub = threadIdx.x / K;
+    const int RS = 256 / K;
+    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
+    float a = 0.f;
+    if (rsub < RS)
+        for (int64_t p = pbeg + rsub; p < pend; p += RS) a += bf2f(dy[p * ld + col]);
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float s = 0.f;
+        for (int r = 0; r < RS; ++r) s += red[r * K + threadIdx.x];
+        atomicAdd(out + threadIdx.x, s);
+    }
+}
+
+// ---------------------------------------------------------------- bf16 matrix transpose  in[R][ldi] -> out[Cc][ldo]
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16raw* __restrict__ in, bf16raw* __restrict__ out,
+                                                        int R, int Cc, int64_t ldi, int64_t ldo,
+                                                        int64_t in_bstride, int64_t out_bstride) {
+    __shared__ bf16raw tile[64][66];
+    in += blockIdx.z * in_bstride;
+    out += blockIdx.z * out_bstride;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int rr = r0 + r, cc = c0 + tx;
+        tile[r][tx] = (rr < R && cc < Cc) ? in[(int64_t)rr * ldi + cc] : (bf16raw)0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int cc = c0 + c, rr = r0 + tx;
+        if (cc < Cc && rr < ldo) out[(int64_t)cc * ldo + rr] = rr < R ? tile[tx][c] : (bf16raw)0;
+    }
+}
+
+// ---------------------------------------------------------------- final conv 32->1 (3x3, pad 1, bias) + (tanh+1)/2
+// x NHWC bf16 [N,H,W,C]; w fp32 [9][C] (tap-major); alpha fp32 [N,H,W]
+__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16raw* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ alpha,
+                                                            int N, int H, int W, int C) {
+    extern __shared__ float ws[];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int64_t n = (int64_t)N * H * W;
+    const int C8 = C / 8;
+    GRID_STRIDE(p, n) {
+        const int xw = (int)(p % W);
+        const int yh = (int)((p / W) % H);
+        const int nn = (int)(p / ((int64_t)W * H));
+        float acc = bias[0];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = yh + t / 3 - 1, iw = xw + t % 3 - 1;
+            if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+            const uint4* src = reinterpret_cast<const uint4*>(x + (((int64_t)nn * H + ih) * W + iw) * C);
+            for (int c8 = 0; c8 < C8; ++c8) {
+                float f[8];
+                unpack8(src[c8], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += f[k] * ws[t * C + c8 * 8 + k];
+            }
+        }
+        alpha[p] = 0.5f * (tanhf(acc) + 1.f);
+    }
+}
+// dpre = dalpha * 0.5 * (1 - tanh^2) with tanh = 2*alpha-1;  dx[p][c] = sum_t dpre[p - off_t] w[t][c]
+__global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __restrict__ dalpha, const float* __restrict__ alpha,
+                                                                 const float* __restrict__ w, bf16raw* __restrict__ dx,
+                                                                 float* __restrict__ dpre_out, int N, int H, int W, int C) {
+    extern __shared__ float ws[];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int C8 = C / 8;
+    const int64_t n = (int64_t)N * H * W * C8;
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % C8);
+        const int64_t p = v / C8;
+        const int xw = (int)(p % W);
+        const int yh = (int)((p / W) % H);
+        const int nn = (int)(p / ((int64_t)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // output pixel q = p - (t offset):  x[p] contributed to pre[q] with tap t where p = q + off_t
+            const int qh = yh - (t / 3 - 1), qw = xw - (t % 3 - 1);
+            if (qh < 0 || qh >= H || qw < 0 || qw >= W) continue;
+            const int64_t q = ((int64_t)nn * H + qh) * W + qw;
+            const float th = 2.f * alpha[q] - 1.f;
+            const float dp = dalpha[q] * 0.5f * (1.f - th * th);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += dp * ws[t * C + c8 * 8 + k];
+        }
+        *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8(acc);
+        if (c8 == 0 && dpre_out) {
+            const float th = 2.f * alpha[p] - 1.f;
+            dpre_out[p] = dalpha[p] * 0.5f * (1.f - th * th);
+        }
+    }
+}
+// dw[t][c] = sum_p dpre[p] x[p + off_t][c];  db = sum_p dpre[p].   block partials + atomics
+__global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* __restrict__ dpre, const bf16raw* __restrict__ x,
+                                                                   float* __restrict__ dw, float* __restrict__ db,
+                                                                   int N, int H, int W, int C, int rows_per_block) {
+    // thread = (tap-channel column) for columns < 9*C (<= 288 -> loop), pixel loop inside
+    const int64_t P = (int64_t)N * H * W;
+    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
+    for (int col = threadIdx.x; col < 9 * C + 1; col += 256) {
+        float a = 0.f;
+        if (col == 9 * C) {
+            for (int64_t p = pbeg; p < pend; ++p) a += dpre[p];
+            atomicAdd(db, a);
+            continue;
+        }
+        const int t = col / C, c = col % C;
+        const int dh = t / 3 - 1, dwv = t % 3 - 1;
+        for (int64_t p = pbeg; p < pend; ++p) {
+            const int xw = (int)(p % W);
+            const int yh = (int)((p / W) % H);
+            const int ih = yh + dh, iw = xw + dwv;
+            if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+            a += dpre[p] * bf2f(x[(p + (int64_t)dh * W + dwv) * C + c]);
+        }
+        atomicAdd(dw + col, a);
+    }
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(x && y && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "avgpool2: bad args");
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((int64_t)N * H * W * C / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, (uint4*)y, N, H, W, C / 8);
+    TCVOM_LAUNCH_CHECK("avgpool2");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_upsample2(const void* y, void* x, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream) {
+    TCVOM_CHECK_ARG(x && y && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "upsample2: bad args");
+    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)y, (uint4*)x, N, H, W, C / 8, scale);
+    TCVOM_LAUNCH_CHECK("upsample2");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_sumpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream) {
+    TCVOM_CHECK_ARG(x && y && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "sumpool2: bad args");
+    hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for((int64_t)N * H * W * C / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, (uint4*)y, N, H, W, C / 8, scale);
+    TCVOM_LAUNCH_CHECK("sumpool2");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_reflect_pad1(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(x && y && C % 8 == 0 && H >= 2 && W >= 2, "reflect_pad1: bad args");
+    hipLaunchKernelGGL(reflect_pad1_kernel, dim3(grid_for((int64_t)N * (H + 2) * (W + 2) * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4*)x, (uint4*)y, N, H, W, C / 8);
+    TCVOM_LAUNCH_CHECK("reflect_pad1");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_reflect_pad1_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(dx && dy && C % 8 == 0 && H >= 3 && W >= 3, "reflect_pad1_bwd: bad args");
+    hipLaunchKernelGGL(reflect_pad1_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint4*)dy, (uint4*)dx, N, H, W, C / 8);
+    TCVOM_LAUNCH_CHECK("reflect_pad1_bwd");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_add(const void* a, const void* b, const void* c, void* z, int64_t numel, void* stream) {
+    TCVOM_CHECK_ARG(a && b && z && numel % 8 == 0, "add: bad args");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(numel / 8)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a,
+                       (const uint4*)b, (const uint4*)c, (uint4*)z, numel / 8);
+    TCVOM_LAUNCH_CHECK("add");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_colsum(const void* dy, float* out, int64_t P, int32_t K, int32_t ld, void* stream) {
+    TCVOM_CHECK_ARG(dy && out && K >= 1 && K <= 256 && (256 % K == 0 || K == 1), "colsum: K=%d must divide 256", K);
+    int64_t blocks = (P + 4095) / 4096;
+    if (blocks > 1024) blocks = 1024;
+    const int rpb = (int)((P + blocks - 1) / blocks);
+    if (hipMemsetAsync(out, 0, sizeof(float) * K, (hipStream_t)stream) != hipSuccess)
+        return tcvom_fail(TCVOM_ERR_LAUNCH, "colsum: memset failed");
+    hipLaunchKernelGGL(colsum_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)dy, out, P, K, ld, rpb);
+    TCVOM_LAUNCH_CHECK("colsum");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_t Cc, int64_t ldi, int64_t ldo,
+                                    int32_t batch, int64_t in_bstride, int64_t out_bstride, void* stream) {
+    TCVOM_CHECK_ARG(in && out && R > 0 && Cc > 0 && ldi >= Cc && ldo >= R, "transpose_bf16: bad args");
+    dim3 grid(cdiv(Cc, 64), cdiv(ldo, 64), batch > 1 ? batch : 1);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, R, Cc,
+                       ldi, ldo, in_bstride, out_bstride);
+    TCVOM_LAUNCH_CHECK("transpose_bf16");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
+                                   int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(x && w && bias && alpha && C % 8 == 0 && C <= 256, "head_conv_fwd: bad args");
+    hipLaunchKernelGGL(head_conv_fwd_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 9 * C * sizeof(float),
+                       (hipStream_t)stream, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+    TCVOM_LAUNCH_CHECK("head_conv_fwd");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
+                                   float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
+                                   void* stream) {
+    TCVOM_CHECK_ARG(dalpha && alpha && x && w && dx && dpre && dw && db && C % 8 == 0 && C <= 256, "head_conv_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_conv_bwd_data_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(256),
+                       9 * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+    if (hipMemsetAsync(dw, 0, sizeof(float) * 9 * C, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float), st) != hipSuccess)
+        return tcvom_fail(TCVOM_ERR_LAUNCH, "head_conv_bwd: memset failed");
+    const int64_t P = (int64_t)N * H * W;
+    int64_t blocks = (P + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    const int rpb = (int)((P + blocks - 1) / blocks);
+    hipLaunchKernelGGL(head_conv_bwd_weight_kernel, dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H,
+                       W, C, rpb);
+    TCVOM_LAUNCH_CHECK("head_conv_bwd");
+    return TCVOM_OK;
+}

@@ -1,0 +1,263 @@
+// Batched SpectralNorm power iteration + weight packing for ALL conv layers of the net in a
+// handful of launches (the reference runs ~1.2 k tiny mv/div/norm kernels per window:
+// models/GCA/ops.py:25-45,74-80, one power iteration per forward CALL of each wrapped conv).
+//
+// A device-resident table describes every conv weight ("layer"): fp32 master weight in PyTorch
+// layout, optional u/v vectors (SpectralNorm), and where its bf16 packed copies live:
+//     fwd pack  [K][T][Cpad]   (A operand of the forward igemm;   Cpad = max(C, 8))
+//     bwd pack  [C][T][K]      (A operand of the data-gradient igemm; absent for image-fed layers)
+// For ConvTranspose2d weights ([Cin][Kout][R][S], matrix height = Cin, ops.py:30) K means Kout
+// and C means Cin in both packs.
+//
+// Backward: the igemm_tt weight-gradient kernels accumulate dW~ (gradient w.r.t. the normalised,
+// packed weight) into an fp32 arena; sn_backward turns that into the gradient of weight_bar:
+//     dW_bar = dW~/sigma - (<dW~, W_bar>/sigma^2) * u v^T        (u, v constants, ops.py:32-36)
+#include "common.h"
+
+#define SN_WORDS 24
+// layer record (int64 words)
+enum {
+    SN_W = 0, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD,
+    SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL
+};
+// kind bits: 1 = ConvTranspose layout, 2 = plain (no spectral norm)
+
+struct SnScratch {
+    float* tvec;      // [sum wd]      W^T u   (zeroed before each iteration)
+    float* svec;      // [sum h]       W t
+    float* sigma;     // [ncalls][L]
+    float* uhist;     // [ncalls][sum h]
+    float* vhist;     // [ncalls][sum wd]
+    int64_t sum_h, sum_wd;
+    int L;
+};
+
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
+                                                      float* __restrict__ tvec)
+{
+    const int layer = work[blockIdx.x * 2], r0 = work[blockIdx.x * 2 + 1];
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const float* W = reinterpret_cast<const float*>(L[SN_W]);
+    const float* u = reinterpret_cast<const float*>(L[SN_U]);
+    const int h = (int)L[SN_H], wd = (int)L[SN_WD];
+    float* t = tvec + L[SN_T_OFF];
+    __shared__ float us[16];
+    if (threadIdx.x < 16) us[threadIdx.x] = (r0 + threadIdx.x < h) ? u[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const int nr = min(16, h - r0);
+    for (int c = threadIdx.x; c < wd; c += 256) {
+        float a = 0.f;
+        for (int r = 0; r < nr; ++r) a += W[(int64_t)(r0 + r) * wd + c] * us[r];
+        atomicAdd(t + c, a);
+    }
+}
+
+// mode 0: s = W t (t = tvec, train);  mode 1: s = W v (stored v, eval)
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
+                                                     const float* __restrict__ tvec, float* __restrict__ svec, int mode)
+{
+    const int layer = work[blockIdx.x * 2], r0 = work[blockIdx.x * 2 + 1];
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const float* W = reinterpret_cast<const float*>(L[SN_W]);
+    const int h = (int)L[SN_H], wd = (int)L[SN_WD];
+    const float* t = mode == 0 ? tvec + L[SN_T_OFF] : reinterpret_cast<const float*>(L[SN_V]);
+    const int r = r0 + (threadIdx.x >> 6);
+    if (r >= h) return;
+    float a = 0.f;
+    for (int c = threadIdx.x & 63; c < wd; c += 64) a += W[(int64_t)r * wd + c] * t[c];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) svec[L[SN_S_OFF] + r] = a;
+}
+
+// one block per spectral layer
+__global__ __launch_bounds__(256) void sn_finalize_kernel(const int64_t* __restrict__ tab, const int* __restrict__ layers,
+                                                          SnScratch sc, int call, int mode)
+{
+    __shared__ float red[4];
+    const int layer = layers[blockIdx.x];
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    float* u = reinterpret_cast<float*>(L[SN_U]);
+    float* v = reinterpret_cast<float*>(L[SN_V]);
+    const int h = (int)L[SN_H], wd = (int)L[SN_WD];
+    const float* t = sc.tvec + L[SN_T_OFF];
+    const float* s = sc.svec + L[SN_S_OFF];
+    float* uh = sc.uhist + (int64_t)call * sc.sum_h + L[SN_S_OFF];
+    float* vh = sc.vhist + (int64_t)call * sc.sum_wd + L[SN_T_OFF];
+    const float eps = 1e-12f;
+    if (mode == 0) {
+        float a = 0.f;
+        for (int c = threadIdx.x; c < wd; c += 256) a += t[c] * t[c];
+        const float nt = sqrtf(block_sum_256(a, red));
+        float b = 0.f;
+        for (int r = threadIdx.x; r < h; r += 256) b += s[r] * s[r];
+        const float ns_raw = sqrtf(block_sum_256(b, red));
+        const float inv_t = 1.f / (nt + eps);
+        const float ns = ns_raw * inv_t;               // ||W v||
+        const float inv_s = inv_t / (ns + eps);        // u = (s_raw*inv_t)/(ns+eps)
+        for (int c = threadIdx.x; c < wd; c += 256) { const float x = t[c] * inv_t; v[c] = x; vh[c] = x; }
+        for (int r = threadIdx.x; r < h; r += 256) { const float x = s[r] * inv_s; u[r] = x; uh[r] = x; }
+        if (threadIdx.x == 0) sc.sigma[(int64_t)call * sc.L + layer] = ns * ns / (ns + eps);
+    } else {
+        float a = 0.f;
+        for (int r = threadIdx.x; r < h; r += 256) { a += u[r] * s[r]; uh[r] = u[r]; }
+        for (int c = threadIdx.x; c < wd; c += 256) vh[c] = v[c];
+        a = block_sum_256(a, red);
+        if (threadIdx.x == 0) sc.sigma[(int64_t)call * sc.L + layer] = a;
+    }
+}
+
+// pack: one thread per OUTPUT element.  which = 0 fwd pack [K][T][Cpad], 1 bwd pack [C][T][K]
+__global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
+                                                      const float* __restrict__ sigma, int L_total, int call,
+                                                      bf16raw* __restrict__ fwd_arena, bf16raw* __restrict__ bwd_arena,
+                                                      int64_t fwd_call_stride, int64_t bwd_call_stride)
+{
+    const int layer = work[blockIdx.x * 3], which = work[blockIdx.x * 3 + 1];
+    const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * 256;
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const float* W = reinterpret_cast<const float*>(L[SN_W]);
+    const int kind = (int)L[SN_KIND];
+    const int K = (int)L[SN_K], C = (int)L[SN_C], T = (int)L[SN_T], Cp = (int)L[SN_CPAD];
+    const float inv = (kind & 2) ? 1.f : 1.f / sigma[(int64_t)call * L_total + layer];
+    const int64_t idx = base + threadIdx.x;
+    int k, c, t;
+    if (which == 0) {
+        if (idx >= (int64_t)K * T * Cp) return;
+        c = (int)(idx % Cp);
+        t = (int)((idx / Cp) % T);
+        k = (int)(idx / ((int64_t)Cp * T));
+    } else {
+        if (idx >= (int64_t)C * T * K) return;
+        k = (int)(idx % K);
+        t = (int)((idx / K) % T);
+        c = (int)(idx / ((int64_t)K * T));
+    }
+    float val = 0.f;
+    if (c < C) {
+        const int64_t src = (kind & 1) ? ((int64_t)c * K + k) * T + t : ((int64_t)k * C + c) * T + t;
+        val = W[src] * inv;
+    }
+    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + idx] = f2bf(val);
+    else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + idx] = f2bf(val);
+}
+
+// ------------------------------------------------------------------------------ backward
+// inner[call][layer] = sum_e dW~_call[e] * W_bar[e]
+__global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
+                                                           const float* __restrict__ dw_arena, int64_t dw_call_stride,
+                                                           float* __restrict__ inner, int L_total)
+{
+    __shared__ float red[4];
+    const int layer = work[blockIdx.x * 3], call = work[blockIdx.x * 3 + 1];
+    const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * 1024;
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const float* W = reinterpret_cast<const float*>(L[SN_W]);
+    const int kind = (int)L[SN_KIND];
+    const int K = (int)L[SN_K], C = (int)L[SN_C], T = (int)L[SN_T], Cp = (int)L[SN_CPAD];
+    const int64_t numel = L[SN_NUMEL];
+    const float* dw = dw_arena + call * dw_call_stride + L[SN_DW_OFF];
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t e = base + q * 256 + threadIdx.x;
+        if (e < numel) {
+            const int t = (int)(e % T);
+            const int64_t ab = e / T;
+            int k, c;
+            if (kind & 1) { k = (int)(ab % K); c = (int)(ab / K); } else { c = (int)(ab % C); k = (int)(ab / C); }
+            a += dw[((int64_t)k * T + t) * Cp + c] * W[e];
+        }
+    }
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) atomicAdd(inner + (int64_t)call * L_total + layer, a);
+}
+
+// grad[e] = sum_calls dW~[e]/sigma - inner/sigma^2 * u[row] v[col]
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
+                                                           const float* __restrict__ dw_arena, int64_t dw_call_stride,
+                                                           const float* __restrict__ inner, SnScratch sc,
+                                                           const int* __restrict__ ncalls, float* __restrict__ grad_arena)
+{
+    const int layer = work[blockIdx.x * 2];
+    const int64_t e = (int64_t)work[blockIdx.x * 2 + 1] * 256 + threadIdx.x;
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const int64_t numel = L[SN_NUMEL];
+    if (e >= numel) return;
+    const int kind = (int)L[SN_KIND];
+    const int K = (int)L[SN_K], C = (int)L[SN_C], T = (int)L[SN_T], Cp = (int)L[SN_CPAD];
+    const int wd = (int)L[SN_WD];
+    const int t = (int)(e % T);
+    const int64_t ab = e / T;
+    int k, c;
+    if (kind & 1) { k = (int)(ab % K); c = (int)(ab / K); } else { c = (int)(ab % C); k = (int)(ab / C); }
+    const int64_t pidx = ((int64_t)k * T + t) * Cp + c;
+    const int row = (int)(e / wd), col = (int)(e % wd);
+    float g = 0.f;
+    const int nc = ncalls[layer];
+    for (int call = 0; call < nc; ++call) {
+        const float d = dw_arena[call * dw_call_stride + L[SN_DW_OFF] + pidx];
+        if (kind & 2) {
+            g += d;
+        } else {
+            const float sg = sc.sigma[(int64_t)call * sc.L + layer];
+            const float uu = sc.uhist[(int64_t)call * sc.sum_h + L[SN_S_OFF] + row];
+            const float vv = sc.vhist[(int64_t)call * sc.sum_wd + L[SN_T_OFF] + col];
+            g += d / sg - inner[(int64_t)call * sc.L + layer] / (sg * sg) * uu * vv;
+        }
+    }
+    grad_arena[L[SN_GRAD_OFF] + e] = g;
+}
+
+static SnScratch mk_scratch(const tcvom_sn_scratch* s) {
+    SnScratch sc;
+    sc.tvec = s->tvec; sc.svec = s->svec; sc.sigma = s->sigma; sc.uhist = s->uhist; sc.vhist = s->vhist;
+    sc.sum_h = s->sum_h; sc.sum_wd = s->sum_wd; sc.L = s->num_layers;
+    return sc;
+}
+
+extern "C" int tcvom_sn_power_iteration(const int64_t* table, const tcvom_sn_scratch* s,
+                                        const int32_t* work_wtu, int32_t n_wtu, const int32_t* work_wv, int32_t n_wv,
+                                        const int32_t* sn_layers, int32_t n_sn, int32_t call, int32_t training,
+                                        void* stream) {
+    TCVOM_CHECK_ARG(table && s && work_wtu && work_wv && sn_layers, "sn_power_iteration: null pointer");
+    if (n_sn <= 0) return TCVOM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SnScratch sc = mk_scratch(s);
+    if (training) {
+        if (hipMemsetAsync(sc.tvec, 0, sizeof(float) * sc.sum_wd, st) != hipSuccess)
+            return tcvom_fail(TCVOM_ERR_LAUNCH, "sn_power_iteration: memset failed");
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n_wtu), dim3(256), 0, st, table, work_wtu, sc.tvec);
+    }
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(n_wv), dim3(256), 0, st, table, work_wv, sc.tvec, sc.svec, training ? 0 : 1);
+    hipLaunchKernelGGL(sn_finalize_kernel, dim3(n_sn), dim3(256), 0, st, table, sn_layers, sc, call, training ? 0 : 1);
+    TCVOM_LAUNCH_CHECK("sn_power_iteration");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, const int32_t* work_pack, int32_t n_pack,
+                             int32_t call, void* fwd_arena, void* bwd_arena, int64_t fwd_call_stride,
+                             int64_t bwd_call_stride, void* stream) {
+    TCVOM_CHECK_ARG(table && s && work_pack && fwd_arena && n_pack > 0, "sn_pack: bad args");
+    hipLaunchKernelGGL(sn_pack_kernel, dim3(n_pack), dim3(256), 0, (hipStream_t)stream, table, work_pack, s->sigma,
+                       s->num_layers, call, (bf16raw*)fwd_arena, (bf16raw*)bwd_arena, fwd_call_stride, bwd_call_stride);
+    TCVOM_LAUNCH_CHECK("sn_pack");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
+                                 const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
+                                 const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,
+                                 float* inner, int32_t max_calls, float* grad_arena, void* stream) {
+    TCVOM_CHECK_ARG(table && s && work_apply && ncalls && dw_arena && inner && grad_arena, "sn_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    SnScratch sc = mk_scratch(s);
+    if (hipMemsetAsync(inner, 0, sizeof(float) * (size_t)max_calls * sc.L, st) != hipSuccess)
+        return tcvom_fail(TCVOM_ERR_LAUNCH, "sn_backward: memset failed");
+    if (n_inner > 0)
+        hipLaunchKernelGGL(sn_bwd_inner_kernel, dim3(n_inner), dim3(256), 0, st, table, work_inner, dw_arena,
+                           dw_call_stride, inner, sc.L);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(n_apply), dim3(256), 0, st, table, work_apply, dw_arena, dw_call_stride,
+                       inner, sc, ncalls, grad_arena);
+    TCVOM_LAUNCH_CHECK("sn_backward");
+    return TCVOM_OK;
+}

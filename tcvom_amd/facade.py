@@ -1,0 +1,213 @@
+"""Model façade: FullModel / FullModel_VMD / EvalModel with the reference's constructor and
+forward() signatures (models/model.py:15-453), running on libtcvom_hip.so.
+
+    FullModel_VMD(model='vmn_gca', agg_window=7, dilate_kernel=None, eps=0, att_thres=0.3, label_smooth=0.2)
+    .forward(a[B,S,1,H,W], fg[B,S,3,H,W], bg[B,S,3,H,W])      float32 0..255, BGR, H % 32 == W % 32 == 0
+        -> [L_alpha, L_comp, L_grad, L_dt, L_att, scaled_imgs, tris_vis, alphas, comps, scaled_gts, Fs, Bs]
+    .NET                                                      state_dict == the reference checkpoint layout
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import vmn as VMN
+
+TAM_OS = 8
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class _Prep(object):
+    """Outputs of the fused preprocessing kernels for one window."""
+    pass
+
+
+def preprocess_window(a, fg, bg, dilate_kernel, eps):
+    """FullModel.preprocess + make_trimap (models/model.py:54-92) for the 3-channel one-hot trimap."""
+    if not a.is_cuda:
+        raise RuntimeError('tcvom_amd runs on the GPU through libtcvom_hip.so only (no CPU fallback)')
+    B, S, _, H, W = a.shape
+    dev = a.device
+    a, fg, bg = a.float().contiguous(), fg.float().contiguous(), bg.float().contiguous()
+    p = _Prep()
+    p.gts = _f32((B, S, 1, H, W), dev)
+    p.fgs, p.bgs, p.imgs = _f32((B, S, 3, H, W), dev), _f32((B, S, 3, H, W), dev), _f32((B, S, 3, H, W), dev)
+    u8 = lambda: torch.empty((B, S, H, W), dtype=torch.uint8, device=dev)
+    p.unk_raw, tmp, p.unk = u8(), u8(), u8()
+    p.x8 = torch.empty((B, S, H, W, 8), dtype=torch.bfloat16, device=dev)
+    p.trimask = _f32((B, S, 1, H, W), dev)
+    p.tris_vis = _f32((B, S, 1, H, W), dev)
+    L.call('tcvom_preprocess', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
+           L.ptr(p.unk_raw), L.ptr(tmp), L.ptr(p.unk), L.ptr(p.x8), L.ptr(p.trimask), L.ptr(p.tris_vis), B * S, H, W,
+           int(dilate_kernel), float(eps), L.stream_ptr())
+    return p
+
+
+class _WindowLoss(torch.autograd.Function):
+    """L_alpha (masked L1 on interior frames), L_dt (temporal, S >= 5) and L_att (attention BCE), plus the
+    visualisation tensors `alphas` / `comps` — models/model.py:94-127,285-345."""
+
+    @staticmethod
+    def forward(ctx, prep, window, att_thres, label_smooth, S, *tensors):
+        ni = S - 2
+        preds, attb, attf = tensors[:ni], tensors[ni:2 * ni], tensors[2 * ni:3 * ni]
+        dev = preds[0].device
+        st = L.stream_ptr()
+        B, _, H, W = preds[0].shape
+        HW = H * W
+        gts, tm = prep.gts, prep.trimask
+        alphas = torch.zeros((B, S, 1, H, W), dtype=torch.float32, device=dev)
+        comps = torch.zeros((B, S, 3, H, W), dtype=torch.float32, device=dev)
+        losses = torch.zeros(3, dtype=torch.float32, device=dev)          # L_alpha, L_dt, L_att
+        acc = torch.zeros((3, max(S, 1), 2), dtype=torch.float32, device=dev)
+        preds = [p.contiguous() for p in preds]
+        for k in range(ni):
+            c = k + 1
+            L.call('tcvom_masked_l1_fwd', L.ptr(preds[k]), L.ptr(gts[:, c]), L.ptr(tm[:, c]), None, None, None,
+                   L.ptr(prep.fgs[:, c]), L.ptr(prep.bgs[:, c]), L.ptr(alphas[:, c]), L.ptr(comps[:, c]), L.ptr(acc[0, c]),
+                   B, HW, HW, S * HW, S * 3 * HW, st)
+            L.call('tcvom_loss_finalize', L.ptr(acc[0, c]), L.ptr(losses[0:]), 1.0 / ni, 0, float(B * HW), window, 1, st)
+        ndt = S - 3 if S >= 5 else 0
+        for k in range(ndt):
+            c = k + 1
+            L.call('tcvom_masked_l1_fwd', L.ptr(preds[k]), L.ptr(gts[:, c]), L.ptr(tm[:, c]), L.ptr(preds[k + 1]),
+                   L.ptr(gts[:, c + 1]), L.ptr(tm[:, c + 1]), None, None, None, None, L.ptr(acc[1, c]),
+                   B, HW, HW, S * HW, S * 3 * HW, st)
+            L.call('tcvom_loss_finalize', L.ptr(acc[1, c]), L.ptr(losses[1:]), 1.0 / ndt, 0, float(B * HW), window, 1, st)
+        h, w = H // TAM_OS, W // TAM_OS
+        pooled = _f32((B, S, h, w), dev)
+        L.call('tcvom_avgpool8', L.ptr(gts), L.ptr(pooled), B * S, H, W, st)
+        dlog = []
+        for k in range(ni):
+            c = k + 1
+            mask = prep.unk8[c]
+            db, df = torch.empty_like(attb[k]), torch.empty_like(attf[k])
+            L.call('tcvom_att_bce', L.ptr(attb[k].contiguous()), L.ptr(pooled[:, c]), L.ptr(pooled[:, c - 1]), L.ptr(mask),
+                   L.ptr(db), L.ptr(acc[2, c]), B, h, w, window, att_thres, label_smooth, S * h * w, 1, st)
+            L.call('tcvom_att_bce', L.ptr(attf[k].contiguous()), L.ptr(pooled[:, c]), L.ptr(pooled[:, c + 1]), L.ptr(mask),
+                   L.ptr(df), L.ptr(acc[2, c]), B, h, w, window, att_thres, label_smooth, S * h * w, 0, st)
+            L.call('tcvom_loss_finalize', L.ptr(acc[2, c]), L.ptr(losses[2:]), 1.0 / ni, 1, 0.0, window, 1, st)
+            dlog.append((db, df))
+        ctx.prep, ctx.S, ctx.window, ctx.ndt = prep, S, window, ndt
+        ctx.preds, ctx.acc, ctx.dlog = preds, acc, dlog
+        ctx.mark_non_differentiable(alphas, comps)
+        return losses[0], losses[1], losses[2], alphas, comps
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_dt, g_att, _ga, _gc):
+        prep, S, window, acc = ctx.prep, ctx.S, ctx.window, ctx.acc
+        ni = S - 2
+        st = L.stream_ptr()
+        preds = ctx.preds
+        B, _, H, W = preds[0].shape
+        HW = H * W
+        gts, tm = prep.gts, prep.trimask
+        dev = preds[0].device
+        one = lambda g: (g if g is not None else torch.zeros((), device=dev)).reshape(1).float().contiguous()
+        g_alpha, g_dt, g_att = one(g_alpha), one(g_dt), one(g_att)
+        dpreds = [torch.empty_like(p) for p in preds]
+        for k in range(ni):
+            c = k + 1
+            L.call('tcvom_masked_l1_bwd', L.ptr(preds[k]), L.ptr(gts[:, c]), L.ptr(tm[:, c]), None, None, None,
+                   L.ptr(acc[0, c]), L.ptr(g_alpha), 1.0 / ni, L.ptr(dpreds[k]), None, 0, B, HW, HW, S * HW, st)
+        for k in range(ctx.ndt):
+            c = k + 1
+            L.call('tcvom_masked_l1_bwd', L.ptr(preds[k]), L.ptr(gts[:, c]), L.ptr(tm[:, c]), L.ptr(preds[k + 1]),
+                   L.ptr(gts[:, c + 1]), L.ptr(tm[:, c + 1]), L.ptr(acc[1, c]), L.ptr(g_dt), 1.0 / ctx.ndt,
+                   L.ptr(dpreds[k]), L.ptr(dpreds[k + 1]), 1, B, HW, HW, S * HW, st)
+        datt_b, datt_f = [], []
+        for k in range(ni):
+            c = k + 1
+            db, df = ctx.dlog[k]
+            ob, of = torch.empty_like(db), torch.empty_like(df)
+            L.call('tcvom_att_bce_bwd', L.ptr(db), L.ptr(acc[2, c]), L.ptr(g_att), 1.0 / ni, L.ptr(ob), db.numel(), window, st)
+            L.call('tcvom_att_bce_bwd', L.ptr(df), L.ptr(acc[2, c]), L.ptr(g_att), 1.0 / ni, L.ptr(of), df.numel(), window, st)
+            datt_b.append(ob)
+            datt_f.append(of)
+        return (None, None, None, None, None) + tuple(dpreds) + tuple(datt_b) + tuple(datt_f)
+
+
+class FullModel(nn.Module):
+    """Baseline (no TAM) façade — models/model.py:15-246.  Only VMN archs run on the HIP path this round."""
+    ARCH_DICT = {'gca': None, 'dim': None, 'fba': None, 'index': None}
+    TRIMAP_CHANNEL_DICT = {'gca': 3, 'dim': 1, 'index': 1, 'fba': 8}
+    FBA_LOSS_NORMALIZE = True
+    FBA_L_ATT_MULTIPLIER = 1
+
+    def __init__(self, model, dilate_kernel=None, eps=0, **kwargs):
+        super().__init__()
+        self.DILATION_KERNEL = dilate_kernel
+        self.EPS = eps
+        self.IMG_SCALE = 1. / 255
+        self.register_buffer('IMG_MEAN', torch.tensor([0.485, 0.456, 0.406]).reshape([1, 1, 3, 1, 1]).float())
+        self.register_buffer('IMG_STD', torch.tensor([0.229, 0.224, 0.225]).reshape([1, 1, 3, 1, 1]).float())
+        self.model_name = model
+        if model.startswith('vmn'):
+            self.NET = VMN.get_VMN_models(arch=model, **kwargs)
+            self.window = int(kwargs['agg_window'])
+        else:
+            if model not in self.ARCH_DICT:
+                raise KeyError(model)
+            raise NotImplementedError('%s: single-image baselines are not on the MI355X hot path yet (SURVEY.md §8)' % model)
+        self.method = model[model.rfind('_') + 1:]
+        self.TRIMAP_CHANNEL = self.TRIMAP_CHANNEL_DICT[self.method]
+
+    def _dilation(self):
+        if self.DILATION_KERNEL is None:
+            # trimap width 1..51, drawn per call (models/model.py:62-64).  The reference draws one radius per
+            # clip with a host sync; here one host-side draw per window keeps the step sync-free.
+            return int(torch.randint(0, 26, size=()))
+        return int(self.DILATION_KERNEL)
+
+    def preprocess(self, a, fg, bg):
+        p = preprocess_window(a, fg, bg, self._dilation(), self.EPS)
+        tris = p.x8[..., 3:6].permute(0, 1, 4, 2, 3).float()
+        imgs = p.x8[..., 0:3].permute(0, 1, 4, 2, 3).float()
+        return p.imgs, p.fgs, p.bgs, p.gts, tris, p.trimask, imgs
+
+
+class FullModel_VMD(FullModel):
+    """models/model.py:248-357."""
+    TAM_OS = TAM_OS
+
+    def __init__(self, model, att_thres=0.3, label_smooth=0.2, **kwargs):
+        assert model.startswith('vmn'), 'FullModel_VMD only support VMN arch'
+        super().__init__(model, **kwargs)
+        self.att_thres = att_thres
+        self.label_smooth = label_smooth
+
+    def forward(self, a, fg, bg, wb=None, wf=None):
+        B, S = a.shape[:2]
+        assert S >= 3, 'a window needs at least 3 frames'
+        H, W = a.shape[-2:]
+        assert H % 32 == 0 and W % 32 == 0, 'H and W must be multiples of 32 (pred_vmn.py:90)'
+        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS)
+        frames = [prep.x8[:, s].contiguous() for s in range(S)]
+        prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
+        preds, attb, attf = self.NET.run(frames, prep.unk8)
+        ni = S - 2
+        tensors = [preds[c] for c in range(1, S - 1)] + [attb[c] for c in range(1, S - 1)] + [attf[c] for c in range(1, S - 1)]
+        L_alpha, L_dt, L_att, alphas, comps = _WindowLoss.apply(prep, self.window, float(self.att_thres),
+                                                                float(self.label_smooth), S, *tensors)
+        zero = torch.zeros_like(L_alpha)                       # GCA: L_comp = L_grad = 0 (models/model.py:112-114)
+        if S < 5:
+            L_dt = torch.zeros_like(L_att)
+        return [L_alpha, zero, zero.clone(), L_dt, L_att,
+                prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
+
+
+class EvalModel(FullModel):
+    """Inference on image + user trimap (models/model.py:359-453) — next round."""
+
+    def __init__(self, model, agg_window, dilate_kernel):
+        super().__init__(model, dilate_kernel=dilate_kernel, agg_window=agg_window)
+
+    def forward(self, imgs, tris):
+        raise NotImplementedError('EvalModel is scheduled after the training window path (SURVEY.md §8f.1)')
+
+
+def train_step_loss(out):
+    """train_ddp.py:56-61."""
+    return out[0].mean() + out[1].mean() + out[2].mean() + 0.5 * out[3].mean() + 0.25 * out[4].mean()

@@ -1,0 +1,370 @@
+"""Autograd wrappers around the HIP kernels (one torch.autograd.Function per fused op).
+
+PyTorch is used here for device memory (caching allocator), streams and the autograd tape only:
+every forward/backward below is one or more launches from libtcvom_hip.so on the current stream.
+Tensors between ops are NHWC bf16 (`[N,H,W,C]`, contiguous).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .conv_plan import ConvGeometry, dense_desc, dense_tt_desc
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+BF16 = torch.bfloat16
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError('tcvom_amd ops run on the GPU through libtcvom_hip.so only (no CPU fallback); got a %s tensor'
+                           % t.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# =============================================================================================
+# conv (+ bias) (+ ReLU) (+ BatchNorm) (+ residual) (+ activation) (+ residual)
+# =============================================================================================
+class ConvCfg(object):
+    """Static configuration of one conv(+BN) site of the network."""
+
+    def __init__(self, bank, spec, bn=None, act=ACT_NONE, pre_relu=False, unbias_mult=1):
+        self.bank, self.spec, self.bn = bank, spec, bn
+        self.act, self.pre_relu, self.unbias_mult = act, pre_relu, unbias_mult
+        self._geo = {}
+
+    def geometry(self, N, H, W):
+        key = (N, H, W)
+        g = self._geo.get(key)
+        if g is None:
+            g = self._geo[key] = ConvGeometry(self.spec, N, H, W)
+        return g
+
+
+def _launch_conv(descs, x, wptr, out, bias, stats, act, st):
+    goff = 0
+    for d in descs:
+        d.act = act
+        d.stats_group_offset = goff
+        L.call('tcvom_conv_igemm', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), None, None, L.ptr(stats), C.byref(d), st)
+        goff += L.call('tcvom_conv_stats_groups', C.byref(d))
+    return goff
+
+
+def _stats_groups(descs):
+    return sum(L.call('tcvom_conv_stats_groups', C.byref(d)) for d in descs)
+
+
+class _ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, gamma, beta, bias, res1, res2, cfg, training):
+        _need_cuda(x)
+        spec, bank, bn = cfg.spec, cfg.bank, cfg.bn
+        x = _c(x)
+        N, H, W, Cx = x.shape
+        assert Cx == spec.cpad and x.dtype == BF16, 'conv %s: input %s %s, expected %d channels' % (
+            spec.name, tuple(x.shape), x.dtype, spec.cpad)
+        geo = cfg.geometry(N, H, W)
+        call = bank.next_call(spec)
+        st = L.stream_ptr()
+        K = spec.K
+        y = torch.empty((N, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
+        has_bn = bn is not None
+        stats = None
+        if has_bn and training:
+            stats = torch.empty(_stats_groups(geo.fwd) * 2 * K, dtype=torch.float32, device=x.device)
+        _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, ACT_RELU if cfg.pre_relu else ACT_NONE, st)
+        ctx.cfg, ctx.training, ctx.call, ctx.geo = cfg, training, call, geo
+        ctx.has_res1, ctx.has_res2, ctx.has_bias = res1 is not None, res2 is not None, bias is not None
+        if not has_bn:
+            assert res1 is None and res2 is None and cfg.act == ACT_NONE
+            ctx.save_for_backward(x)
+            return y
+        ss = torch.empty(2 * K, dtype=torch.float32, device=x.device)
+        saved = torch.empty(2 * K, dtype=torch.float32, device=x.device)
+        if training:
+            P = geo.out_pixels
+            L.call('tcvom_bn_finalize', L.ptr(stats), stats.numel() // (2 * K), K, P, P * cfg.unbias_mult,
+                   L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                   float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), st)
+            bn.num_batches_tracked += 1
+        else:
+            L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                   float(bn.eps), L.ptr(ss), L.ptr(saved), st)
+        z = torch.empty_like(y)
+        r1 = _c(res1) if res1 is not None else None
+        r2 = _c(res2) if res2 is not None else None
+        L.call('tcvom_bn_apply', L.ptr(y), L.ptr(ss), L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, st)
+        ctx.save_for_backward(x, y, ss, saved, gamma, r1)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        cfg, geo = ctx.cfg, ctx.geo
+        spec, bank = cfg.spec, cfg.bank
+        st = L.stream_ptr()
+        K = spec.K
+        dz = _c(dz)
+        dgamma = dbeta = dbias = dres1 = None
+        if cfg.bn is None:
+            (x,) = ctx.saved_tensors
+            dy = dz
+            if ctx.has_bias:
+                dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
+                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), geo.out_pixels, K, K, st)
+        else:
+            x, y, ss, saved, gamma, r1 = ctx.saved_tensors
+            P = geo.out_pixels
+            groups = L.call('tcvom_bn_bwd_groups', P, K)
+            partial = torch.empty(groups * 2 * K, dtype=torch.float32, device=dz.device)
+            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(partial), P, K, cfg.act, st)
+            dgamma = torch.empty(K, dtype=torch.float32, device=dz.device)
+            dbeta = torch.empty(K, dtype=torch.float32, device=dz.device)
+            coef = torch.empty(3 * K, dtype=torch.float32, device=dz.device)
+            L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), st)
+            dy = torch.empty_like(y)
+            if ctx.has_res1 and ctx.needs_input_grad[5]:
+                dres1 = torch.empty_like(y)
+            L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(coef), L.ptr(dy),
+                   L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, st)
+        dx = None
+        if spec.needs_dgrad and ctx.needs_input_grad[0]:
+            dx = torch.empty((geo.N, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
+            wp = bank.bwd_ptr(spec, ctx.call)
+            for d in geo.dgrad:
+                d.act = 0
+                L.call('tcvom_conv_igemm', L.ptr(dy), wp, L.ptr(dx), None, None, None, None, C.byref(d), st)
+        dwp = bank.dw_ptr(spec, ctx.call)
+        for d in geo.fwd:
+            L.call('tcvom_wgrad_igemm', L.ptr(dy), L.ptr(x), dwp, C.byref(d), K, st)
+        dres2 = dz if ctx.has_res2 else None
+        return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None
+
+
+def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
+    bn = cfg.bn
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    return _ConvBNAct.apply(x, token, gamma, beta, cfg.spec.bias, res1, res2, cfg, training)
+
+
+# =============================================================================================
+# resampling / padding
+# =============================================================================================
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=BF16, device=x.device)
+        L.call('tcvom_avgpool2', L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream_ptr())
+        ctx.shape = (N, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        L.call('tcvom_upsample2', L.ptr(_c(dy)), L.ptr(dx), N, H, W, Cc, 0.25, L.stream_ptr())
+        return dx
+
+
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        y = _c(y)
+        N, h, w, Cc = y.shape
+        x = torch.empty((N, 2 * h, 2 * w, Cc), dtype=BF16, device=y.device)
+        L.call('tcvom_upsample2', L.ptr(y), L.ptr(x), N, 2 * h, 2 * w, Cc, 1.0, L.stream_ptr())
+        ctx.shape = (N, h, w, Cc)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        N, h, w, Cc = ctx.shape
+        dy = torch.empty(ctx.shape, dtype=BF16, device=dx.device)
+        L.call('tcvom_sumpool2', L.ptr(_c(dx)), L.ptr(dy), N, 2 * h, 2 * w, Cc, 1.0, L.stream_ptr())
+        return dy
+
+
+class _ReflectPad1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H + 2, W + 2, Cc), dtype=BF16, device=x.device)
+        L.call('tcvom_reflect_pad1', L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream_ptr())
+        ctx.shape = (N, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        L.call('tcvom_reflect_pad1_bwd', L.ptr(_c(dy)), L.ptr(dx), N, H, W, Cc, L.stream_ptr())
+        return dx
+
+
+avgpool2 = _AvgPool2.apply
+upsample2 = _Upsample2.apply
+reflect_pad1 = _ReflectPad1.apply
+
+
+# =============================================================================================
+# decoder head: conv 3x3 (C -> 1, bias) + (tanh + 1)/2      -> alpha fp32 [N,1,H,W]
+# =============================================================================================
+class _HeadConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        wt = weight.detach().reshape(Cc, 9).t().contiguous()          # [9][C] tap-major
+        alpha = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
+        L.call('tcvom_head_conv_fwd', L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(alpha), N, H, W, Cc, L.stream_ptr())
+        ctx.save_for_backward(x, wt, alpha)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        x, wt, alpha = ctx.saved_tensors
+        N, H, W, Cc = x.shape
+        dalpha = _c(dalpha.float())
+        dx = torch.empty_like(x)
+        dpre = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+        dw = torch.empty((9, Cc), dtype=torch.float32, device=x.device)
+        db = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.call('tcvom_head_conv_bwd', L.ptr(dalpha), L.ptr(alpha), L.ptr(x), L.ptr(wt), L.ptr(dx), L.ptr(dpre), L.ptr(dw),
+               L.ptr(db), N, H, W, Cc, L.stream_ptr())
+        return dx, dw.t().reshape(1, Cc, 3, 3), db
+
+
+head_conv = _HeadConv.apply
+
+
+# =============================================================================================
+# Temporal attention core
+# =============================================================================================
+class _TamAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kb, kf, v, mask_u8, window):
+        q, kb, kf, v = _c(q), _c(kb), _c(kf), _c(v)
+        B, H, W, Cc = q.shape
+        out = torch.empty_like(q)
+        w2 = window * window
+        attb = torch.empty((B, w2, H * W), dtype=torch.float32, device=q.device)
+        attf = torch.empty((B, w2, H * W), dtype=torch.float32, device=q.device)
+        L.call('tcvom_tam_fwd', L.ptr(q), L.ptr(kb), L.ptr(kf), L.ptr(v), L.ptr(mask_u8), L.ptr(out), L.ptr(attb),
+               L.ptr(attf), B, H, W, Cc, window, L.stream_ptr())
+        ctx.save_for_backward(q, kb, kf, mask_u8)
+        ctx.window = window
+        return out, attb, attf
+
+    @staticmethod
+    def backward(ctx, dout, dattb, dattf):
+        q, kb, kf, mask = ctx.saved_tensors
+        B, H, W, Cc = q.shape
+        w2 = ctx.window * ctx.window
+        dout = _c(dout)
+        dq, dkb, dkf = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        pbuf = torch.empty((B, 2, w2, H * W), dtype=torch.float32, device=q.device)
+        dsbuf = torch.empty_like(pbuf)
+        db = _c(dattb) if dattb is not None else None
+        df = _c(dattf) if dattf is not None else None
+        L.call('tcvom_tam_bwd', L.ptr(q), L.ptr(kb), L.ptr(kf), L.ptr(mask), L.ptr(dout), L.ptr(db), L.ptr(df), L.ptr(dq),
+               L.ptr(dkb), L.ptr(dkf), L.ptr(pbuf), L.ptr(dsbuf), B, H, W, Cc, ctx.window, L.stream_ptr())
+        return dq, dkb, dkf, dout, None, None
+
+
+tam_attention = _TamAttention.apply
+
+
+# =============================================================================================
+# Guided contextual attention core:  (g8, alpha, unknown) -> fold(P V)/4
+# =============================================================================================
+def _r32(n):
+    return (n + 31) // 32 * 32
+
+
+class _GcaAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g8, alpha, unk_u8):
+        g8, alpha = _c(g8), _c(alpha)
+        B, h8, w8, CG = g8.shape
+        Ca = alpha.shape[3]
+        dev = g8.device
+        st = L.stream_ptr()
+        N = (h8 // 2) * (w8 // 2)
+        ld = _r32(N)
+        D, DV = 9 * CG, 16 * Ca
+        G = torch.empty((B, N, D), dtype=BF16, device=dev)
+        scales = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        cvec = torch.empty((B, N), dtype=torch.float32, device=dev)
+        dvec = torch.empty((B, N), dtype=torch.float32, device=dev)
+        nrm = torch.empty((B, N), dtype=torch.float32, device=dev)
+        L.call('tcvom_gca_prepare', L.ptr(g8), L.ptr(unk_u8), L.ptr(G), L.ptr(scales), L.ptr(cvec), L.ptr(dvec), L.ptr(nrm),
+               B, h8, w8, CG, st)
+        # S'[i][j] = c_j <G_i, G_j> - d_j [i==j]     (rows m = keys j, columns n = queries i)
+        S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
+        d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
+        L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
+        P = torch.empty((B, N, ld), dtype=BF16, device=dev)
+        L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
+        del S
+        V = torch.empty((B, N, DV), dtype=BF16, device=dev)
+        L.call('tcvom_gca_value_patches', L.ptr(alpha), L.ptr(V), B, h8, w8, Ca, st)
+        Vt = torch.empty((B, DV, ld), dtype=BF16, device=dev)
+        L.call('tcvom_transpose_bf16', L.ptr(V), L.ptr(Vt), N, DV, DV, ld, B, N * DV, DV * ld, st)
+        # O[i][v] = sum_j P[i][j] V[j][v]             (rows m = v, columns n = queries i, reduce j)
+        O = torch.empty((B, N, DV), dtype=BF16, device=dev)
+        d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV)
+        L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
+        y = torch.empty((B, h8, w8, Ca), dtype=BF16, device=dev)
+        L.call('tcvom_gca_fold', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
+        ctx.save_for_backward(G, P, V, cvec, nrm)
+        ctx.dims = (B, h8, w8, CG, Ca, N, ld)
+        ctx.mark_non_differentiable(scales)
+        return y, scales
+
+    @staticmethod
+    def backward(ctx, dy, _dscales):
+        G, P, V, cvec, nrm = ctx.saved_tensors
+        B, h8, w8, CG, Ca, N, ld = ctx.dims
+        D, DV = 9 * CG, 16 * Ca
+        dev = G.device
+        st = L.stream_ptr()
+        dy = _c(dy)
+        dO = torch.empty((B, N, DV), dtype=BF16, device=dev)
+        L.call('tcvom_gca_unfold', L.ptr(dy), L.ptr(dO), B, h8, w8, Ca, st)
+        # dP[i][j] = sum_v dO[i][v] V[j][v]           (rows m = keys j, columns n = queries i)
+        dP = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
+        d = dense_desc(N, N, DV, ld, batch=B, in_bstride=N * DV, w_bstride=N * DV, out_bstride=N * ld, out_fp32=True)
+        L.call('tcvom_conv_igemm', L.ptr(dO), L.ptr(V), L.ptr(dP), None, None, None, None, C.byref(d), st)
+        # T = softmax_bwd(P, dP) * c_j
+        T = torch.empty((B, N, ld), dtype=BF16, device=dev)
+        L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), B * N, N, ld, ld, st)
+        del dP
+        dV = torch.zeros((B, N, DV), dtype=torch.float32, device=dev)
+        Mp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)
+        dWq = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        Gt = torch.empty((B, D, ld), dtype=BF16, device=dev)
+        L.call('tcvom_transpose_bf16', L.ptr(G), L.ptr(Gt), N, D, D, ld, B, N * D, D * ld, st)
+        # dWq[i][d] = sum_j T[i][j] G[j][d]            (rows m = d, columns n = queries i, reduce j)
+        d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
+        L.call('tcvom_conv_igemm', L.ptr(T), L.ptr(Gt), L.ptr(dWq), None, None, None, None, C.byref(d3), st)
+        for b in range(B):
+            # dV[j][v] = sum_i P[i][j] dO[i][v] ;  M'[j][d] = sum_i T[i][j] G[i][d]      (TT GEMMs, reduce over queries i)
+            dtt = dense_tt_desc(N, N, DV)
+            L.call('tcvom_wgrad_igemm', L.ptr(P[b]), L.ptr(dO[b]), L.ptr(dV[b]), C.byref(dtt), ld, st)
+            dtt2 = dense_tt_desc(N, N, D)
+            L.call('tcvom_wgrad_igemm', L.ptr(T[b]), L.ptr(G[b]), L.ptr(Mp[b]), C.byref(dtt2), ld, st)
+        dalpha = torch.empty((B, h8, w8, Ca), dtype=BF16, device=dev)
+        L.call('tcvom_gca_value_patches_bwd', L.ptr(dV), L.ptr(dalpha), B, h8, w8, Ca, st)
+        dg8 = torch.empty((B, h8, w8, CG), dtype=BF16, device=dev)
+        L.call('tcvom_gca_patches_bwd', L.ptr(dWq), L.ptr(Mp), L.ptr(G), L.ptr(nrm), L.ptr(dg8), B, h8, w8, CG, st)
+        return dg8, dalpha, None
+
+
+gca_attention = _GcaAttention.apply

@@ -1,0 +1,133 @@
+"""Video Matting Network on the HIP kernels: per-frame encoder + decoder-front loop, Temporal
+Attention Module, decoder tail.  Mirrors models/VMN/__init__.py:11-29 and VMN_model.py:9-113."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ConvCfg
+from .weights import ConvSpec, WeightBank, bank_token
+
+
+def _to_nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def _to_nchw(t):
+    return t.permute(0, 3, 1, 2).float()
+
+
+class FeatureAggregationModule(nn.Module):
+    """TAM (models/VMN/VMN_model.py:9-68).  forward(x, b, f, mask) -> (feat, attb, attf, mask_small).
+
+    q = query_conv(x), v = value_conv(x), k_b/k_f = key_conv(b / f) (shared key conv); attention over the
+    window x window zero-padded neighbourhood of the adjacent frame at unknown os8 pixels only; the
+    aggregated values are the KEYS; result = v + agg_b + agg_f."""
+
+    def __init__(self, input_chn, reduction, window, bank=None, prefix='fam'):
+        super().__init__()
+        out_chn = input_chn // reduction
+        self.key_conv = nn.Conv2d(input_chn, out_chn, kernel_size=3, padding=1)
+        self.query_conv = nn.Conv2d(input_chn, out_chn, kernel_size=3, padding=1)
+        self.value_conv = nn.Conv2d(input_chn, out_chn, kernel_size=3, padding=1)
+        self.window = int(window)
+        self._own_bank = bank is None
+        bank = bank if bank is not None else WeightBank()
+        object.__setattr__(self, '_bank', bank)
+        self._cfg = {}
+        for n in ('key_conv', 'query_conv', 'value_conv'):
+            conv = getattr(self, n)
+            spec = ConvSpec('%s.%s' % (prefix, n), conv.weight, None, None, conv.bias, False, 1, 1, 'tail')
+            bank.register(spec)
+            self._cfg[n] = ConvCfg(bank, spec)
+
+    def run(self, x, xb, xf, mask_u8, token, training):
+        """NHWC bf16 fast path; mask_u8: uint8 [B,h,w] (unknown at os8)."""
+        q = ops.conv_bn_act(self._cfg['query_conv'], x, token, training)
+        v = ops.conv_bn_act(self._cfg['value_conv'], x, token, training)
+        kb = ops.conv_bn_act(self._cfg['key_conv'], xb, token, training)
+        kf = ops.conv_bn_act(self._cfg['key_conv'], xf, token, training)
+        return ops.tam_attention(q, kb, kf, v, mask_u8, self.window)
+
+    def forward(self, x, b, f, mask):
+        """Reference signature: NCHW fp32 features, mask [B,1,8H,8W] in {0,1}."""
+        assert self._own_bank, 'use .run() inside a network'
+        B, C, H, W = x.shape
+        sh, sw = mask.shape[2] // H, mask.shape[3] // W
+        small = mask[:, :, ::sh, ::sw] != 0                      # nearest down-sampling (VMN_model.py:22)
+        token = bank_token(self._bank, 3, self.training)
+        out, attb, attf = self.run(_to_nhwc(x), _to_nhwc(b), _to_nhwc(f), small[:, 0].to(torch.uint8).contiguous(),
+                                   token, self.training)
+        return _to_nchw(out), attb, attf, small
+
+
+class VMN(nn.Module):
+    """models/VMN/VMN_model.py:70-113."""
+
+    def __init__(self, encoder, decoder, bank, freeze_backbone=False):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.freeze_backbone = freeze_backbone
+        object.__setattr__(self, '_bank', bank)
+
+    def train(self, mode=True):
+        super().train(mode)
+        if self.freeze_backbone:
+            print('Set VMN encoder to eval() mode.')
+            self.encoder.eval()
+        return self
+
+    def run(self, frames_x8, unk_u8):
+        """frames_x8: list of S tensors [B,H,W,8] bf16; unk_u8: list of S uint8 [B,H/8,W/8].
+        Returns (alphas list (None at the ends), attb, attf) for interior frames."""
+        S = len(frames_x8)
+        training = self.training
+        token = bank_token(self._bank, S, training)
+        mids, feats = [None] * S, [None] * S
+        for i in range(S):                                   # per frame, NOT batched over frames (:93-98)
+            emb, mid = self.encoder.run(frames_x8[i], unk_u8[i], token, training)
+            mids[i] = mid
+            feats[i] = self.decoder.run_front(emb, mid, token, training)
+        preds, attb, attf = [None] * S, [None] * S, [None] * S
+        for i in range(1, S - 1):
+            preds[i], attb[i], attf[i] = self.decoder.run_tail(feats[i], feats[i - 1], feats[i + 1], unk_u8[i],
+                                                               mids[i], token, training)
+        return preds, attb, attf
+
+    def forward(self, images, masks, extras=None):
+        """Reference signature: images list[S] of [B,1,6,H,W] fp32, masks tuple[S] of [B,1,1,H,W]
+        -> (preds[S], attb[S], attf[S], small_mask[S])."""
+        S = len(images)
+        frames, unks = [], []
+        for i in range(S):
+            img = images[i].squeeze(1)
+            B, Cc, H, W = img.shape
+            x8 = torch.zeros((B, H, W, 8), dtype=torch.bfloat16, device=img.device)
+            x8[..., :Cc] = img.permute(0, 2, 3, 1).to(torch.bfloat16)
+            frames.append(x8)
+            m = masks[i].squeeze(1)
+            unks.append((m[:, 0, ::8, ::8] != 0).to(torch.uint8).contiguous())
+        preds, attb, attf = self.run(frames, unks)
+        small = [None] * S
+        for i in range(1, S - 1):
+            small[i] = unks[i].bool().unsqueeze(1)
+        preds[0] = torch.zeros_like(preds[1])
+        preds[-1] = torch.zeros_like(preds[-2])
+        return preds, attb, attf, small
+
+
+def build_vmn_gca(agg_window, agg_reduction=1, freeze_backbone=False):
+    from .gca_net import resnet_gca_encoder_29, ResGuidedCxtAtten_FAM_Dec
+    bank = WeightBank()
+    enc = resnet_gca_encoder_29(bank=bank)
+    dec = ResGuidedCxtAtten_FAM_Dec(agg_reduction, agg_window, freeze_backbone=freeze_backbone, bank=bank)
+    return VMN(enc, dec, bank, freeze_backbone=freeze_backbone)
+
+
+def get_VMN_models(arch, agg_window, agg_reduction=1, freeze_backbone=False, **kwargs):
+    """models/VMN/__init__.py:11-29.  Only `vmn_gca` is built on the HIP path in this round."""
+    if arch == 'vmn_gca':
+        return build_vmn_gca(agg_window, agg_reduction, freeze_backbone)
+    if arch in ('vmn_dim', 'vmn_fba', 'vmn_index'):
+        raise NotImplementedError('%s: only the vmn_gca hot path is implemented on MI355X so far (SURVEY.md §8)' % arch)
+    raise ValueError

@@ -1,0 +1,275 @@
+"""WeightBank: every conv weight of the network, normalised + packed for the MFMA kernels.
+
+The reference wraps 70 convs of `vmn_gca` in SpectralNorm (models/GCA/ops.py:12-80), which runs one
+power iteration per forward CALL — ~1.2 k tiny kernels per window.  The power iteration depends only
+on (W_bar, u, v), never on activations, so the bank performs ALL iterations of a window up front
+(S chained iterations for layers used once per frame, S-2 for decoder-tail layers), writes the
+bf16 packed copies the igemm kernels consume, and after the backward pass turns the accumulated
+packed-weight gradients into gradients of `weight_bar` — a handful of launches in total.
+
+State (u, v, weight_bar) stays in ordinary nn.Parameters with the reference's state_dict names.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+SN_WORDS = 24
+(SN_W, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD, SN_FWD_OFF, SN_BWD_OFF,
+ SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL) = range(17)
+
+
+def _r8(n):
+    return (n + 7) // 8 * 8
+
+
+class ConvSpec(object):
+    """Static description of one conv weight registered in the bank."""
+
+    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True):
+        self.name = name
+        self.weight, self.u, self.v, self.bias = weight, u, v, bias
+        self.transposed = transposed
+        shp = tuple(weight.shape)
+        if transposed:                       # ConvTranspose2d weight [Cin][Kout][R][S]
+            self.C, self.K = shp[0], shp[1]
+        else:
+            self.K, self.C = shp[0], shp[1]
+        self.R, self.S = shp[2], shp[3]
+        self.T = self.R * self.S
+        self.stride, self.pad = stride, pad
+        self.spectral = u is not None
+        self.group = group                   # 'frame' (S calls per window) | 'tail' (S-2 calls)
+        self.needs_dgrad = needs_dgrad
+        self.cpad = max(8, _r8(self.C))
+        self.numel = weight.numel()
+        self.h = shp[0]
+        self.wd = self.numel // shp[0]
+        self.layer_id = -1
+
+
+class WeightBank(object):
+    def __init__(self):
+        self.specs = []
+        self._ptr_sig = None
+        self._plans = {}
+        self.max_calls = 0
+
+    # ------------------------------------------------------------------ registration
+    def register(self, spec):
+        spec.layer_id = len(self.specs)
+        self.specs.append(spec)
+        return spec.layer_id
+
+    def weight_params(self):
+        return [s.weight for s in self.specs]
+
+    # ------------------------------------------------------------------ device tables
+    def _signature(self):
+        return tuple((s.weight.data_ptr(), 0 if s.u is None else s.u.data_ptr()) for s in self.specs)
+
+    def _build(self, device):
+        specs = self.specs
+        nl = len(specs)
+        tab = torch.zeros(nl, SN_WORDS, dtype=torch.int64)
+        fwd_off = bwd_off = t_off = s_off = dw_off = g_off = 0
+        for i, s in enumerate(specs):
+            assert s.weight.device == device and s.weight.dtype == torch.float32 and s.weight.is_contiguous()
+            tab[i, SN_W] = s.weight.data_ptr()
+            tab[i, SN_U] = s.u.data_ptr() if s.spectral else 0
+            tab[i, SN_V] = s.v.data_ptr() if s.spectral else 0
+            tab[i, SN_H], tab[i, SN_WD] = s.h, s.wd
+            tab[i, SN_KIND] = (1 if s.transposed else 0) | (0 if s.spectral else 2)
+            tab[i, SN_K], tab[i, SN_C], tab[i, SN_T], tab[i, SN_CPAD] = s.K, s.C, s.T, s.cpad
+            tab[i, SN_FWD_OFF] = fwd_off
+            s.fwd_off = fwd_off
+            fwd_off += s.K * s.T * s.cpad
+            if s.needs_dgrad:
+                tab[i, SN_BWD_OFF] = bwd_off
+                s.bwd_off = bwd_off
+                bwd_off += s.C * s.T * s.K
+            else:
+                tab[i, SN_BWD_OFF] = -1
+                s.bwd_off = -1
+            tab[i, SN_T_OFF], tab[i, SN_S_OFF] = t_off, s_off
+            if s.spectral:
+                t_off += s.wd
+                s_off += s.h
+            tab[i, SN_DW_OFF] = dw_off
+            s.dw_off = dw_off
+            dw_off += s.K * s.T * s.cpad
+            tab[i, SN_GRAD_OFF] = g_off
+            s.grad_off = g_off
+            g_off += s.numel
+            tab[i, SN_NUMEL] = s.numel
+        self.device = device
+        self.table = tab.to(device)
+        self.fwd_stride, self.bwd_stride, self.dw_stride = _r8(fwd_off), _r8(bwd_off), _r8(dw_off)
+        self.sum_wd, self.sum_h, self.grad_numel = max(t_off, 1), max(s_off, 1), g_off
+        i32 = lambda rows: torch.tensor(rows, dtype=torch.int32).reshape(-1).to(device)
+        sn = [s for s in specs if s.spectral]
+        self.sn_ids = i32([s.layer_id for s in sn])
+        self.n_sn = len(sn)
+        wtu = [(s.layer_id, r0) for s in sn for r0 in range(0, s.h, 16)]
+        wv = [(s.layer_id, r0) for s in sn for r0 in range(0, s.h, 4)]
+        self.work_wtu, self.n_wtu = i32(wtu), len(wtu)
+        self.work_wv, self.n_wv = i32(wv), len(wv)
+
+        def pack_rows(sel):
+            rows = []
+            for s in sel:
+                rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad + 255) // 256)]
+                if s.needs_dgrad:
+                    rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
+            return rows
+        rows_all, rows_sn = pack_rows(specs), pack_rows(sn)
+        self.work_pack_all, self.n_pack_all = i32(rows_all), len(rows_all)
+        self.work_pack_sn, self.n_pack_sn = i32(rows_sn), len(rows_sn)
+        app = [(s.layer_id, b) for s in specs for b in range((s.numel + 255) // 256)]
+        self.work_apply, self.n_apply = i32(app), len(app)
+        self.tvec = torch.zeros(self.sum_wd, device=device)
+        self.svec = torch.zeros(self.sum_h, device=device)
+        self._plans = {}
+        self.max_calls = 0
+        self._ptr_sig = self._signature()
+
+    def _ensure_calls(self, ncalls):
+        if ncalls <= self.max_calls:
+            return
+        dev = self.device
+        nl = len(self.specs)
+        self.max_calls = ncalls
+        self.fwd_arena = torch.zeros(ncalls * self.fwd_stride, dtype=torch.bfloat16, device=dev)
+        self.bwd_arena = torch.zeros(max(1, ncalls * self.bwd_stride), dtype=torch.bfloat16, device=dev)
+        self.dw_arena = torch.zeros(ncalls * self.dw_stride, dtype=torch.float32, device=dev)
+        self.sigma = torch.ones(ncalls * nl, device=dev)
+        self.uhist = torch.zeros(ncalls * self.sum_h, device=dev)
+        self.vhist = torch.zeros(ncalls * self.sum_wd, device=dev)
+        self.inner = torch.zeros(ncalls * nl, device=dev)
+        self.scratch = L.SnScratch(self.tvec.data_ptr(), self.svec.data_ptr(), self.sigma.data_ptr(),
+                                   self.uhist.data_ptr(), self.vhist.data_ptr(), self.sum_h, self.sum_wd, nl)
+        self._plans = {}
+
+    def _plan(self, frames, training):
+        key = (frames, training)
+        if key in self._plans:
+            return self._plans[key]
+        calls = {}
+        for s in self.specs:
+            if not s.spectral or not training:
+                calls[s.layer_id] = 1
+            else:
+                calls[s.layer_id] = frames if s.group == 'frame' else max(frames - 2, 1)
+        inner = [(s.layer_id, c, b) for s in self.specs if s.spectral
+                 for c in range(calls[s.layer_id]) for b in range((s.numel + 1023) // 1024)]
+        dev = self.device
+        plan = {
+            'ncalls': calls,
+            'ncalls_dev': torch.tensor([calls[i] for i in range(len(self.specs))], dtype=torch.int32, device=dev),
+            'work_inner': torch.tensor(inner, dtype=torch.int32).reshape(-1).to(dev),
+            'n_inner': len(inner),
+            'iters': max(calls.values()),
+        }
+        self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ per-window work
+    def prepare(self, frames, training):
+        """Run every power iteration of this window and write the packed weights.  Returns the plan."""
+        dev = self.specs[0].weight.device
+        if self._ptr_sig is None or self._ptr_sig != self._signature():
+            self._build(dev)
+        plan = self._plan(frames, training)
+        self._ensure_calls(plan['iters'])
+        plan = self._plan(frames, training)
+        st = L.stream_ptr()
+        sc = C.byref(self.scratch)
+        self.dw_arena.zero_()
+        for call in range(plan['iters']):
+            if training and call > 0:
+                # layers with fewer calls keep iterating harmlessly only if still needed; tail layers
+                # (S-2 calls) must NOT be advanced further than the reference does -> restrict tables
+                ids, n_sn, wtu, n_wtu, wv, n_wv = self._restricted(plan, call)
+            else:
+                ids, n_sn, wtu, n_wtu, wv, n_wv = self.sn_ids, self.n_sn, self.work_wtu, self.n_wtu, self.work_wv, self.n_wv
+            if n_sn > 0:
+                L.call('tcvom_sn_power_iteration', L.ptr(self.table), sc, L.ptr(wtu), n_wtu, L.ptr(wv), n_wv,
+                       L.ptr(ids), n_sn, call, 1 if training else 0, st)
+            if call == 0:
+                wp, npk = self.work_pack_all, self.n_pack_all
+            else:
+                wp, npk = self._restricted_pack(plan, call)
+            if npk > 0:
+                L.call('tcvom_sn_pack', L.ptr(self.table), sc, L.ptr(wp), npk, call, L.ptr(self.fwd_arena),
+                       L.ptr(self.bwd_arena), self.fwd_stride, self.bwd_stride, st)
+        self.current_plan = plan
+        self.call_counter = [0] * len(self.specs)
+        return plan
+
+    def _restricted(self, plan, call):
+        key = ('restrict', call)
+        if key not in plan:
+            sel = [s for s in self.specs if s.spectral and plan['ncalls'][s.layer_id] > call]
+            i32 = lambda rows: torch.tensor(rows, dtype=torch.int32).reshape(-1).to(self.device)
+            wtu = [(s.layer_id, r0) for s in sel for r0 in range(0, s.h, 16)]
+            wv = [(s.layer_id, r0) for s in sel for r0 in range(0, s.h, 4)]
+            plan[key] = (i32([s.layer_id for s in sel]), len(sel), i32(wtu), len(wtu), i32(wv), len(wv))
+        return plan[key]
+
+    def _restricted_pack(self, plan, call):
+        key = ('restrict_pack', call)
+        if key not in plan:
+            rows = []
+            for s in self.specs:
+                if s.spectral and plan['ncalls'][s.layer_id] > call:
+                    rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad + 255) // 256)]
+                    if s.needs_dgrad:
+                        rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
+            plan[key] = (torch.tensor(rows, dtype=torch.int32).reshape(-1).to(self.device), len(rows))
+        return plan[key]
+
+    def next_call(self, spec):
+        """Call slot of this use of `spec` within the current window."""
+        n = self.current_plan['ncalls'][spec.layer_id]
+        c = self.call_counter[spec.layer_id]
+        self.call_counter[spec.layer_id] = c + 1
+        return min(c, n - 1) if n == 1 else c
+
+    def fwd_ptr(self, spec, call):
+        return C.c_void_p(self.fwd_arena.data_ptr() + 2 * (call * self.fwd_stride + spec.fwd_off))
+
+    def bwd_ptr(self, spec, call):
+        return C.c_void_p(self.bwd_arena.data_ptr() + 2 * (call * self.bwd_stride + spec.bwd_off))
+
+    def dw_ptr(self, spec, call):
+        return C.c_void_p(self.dw_arena.data_ptr() + 4 * (call * self.dw_stride + spec.dw_off))
+
+    def backward(self, plan):
+        """dW~ arena -> list of weight_bar gradients (views of one flat fp32 buffer)."""
+        grad = torch.empty(self.grad_numel, dtype=torch.float32, device=self.device)
+        L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), L.ptr(plan['work_inner']), plan['n_inner'],
+               L.ptr(self.work_apply), self.n_apply, L.ptr(plan['ncalls_dev']), L.ptr(self.dw_arena), self.dw_stride,
+               L.ptr(self.inner), self.max_calls, L.ptr(grad), L.stream_ptr())
+        return [grad[s.grad_off:s.grad_off + s.numel].view(s.weight.shape) for s in self.specs]
+
+
+class _BankToken(torch.autograd.Function):
+    """Ties the bank into autograd: forward = prepare (power iterations + packing), output = a scalar
+    token every conv op takes as an input; backward (which therefore runs after every conv's backward
+    has deposited its packed weight gradient) = SpectralNorm backward for all layers at once."""
+
+    @staticmethod
+    def forward(ctx, bank, frames, training, *weights):
+        ctx.bank = bank
+        ctx.plan = bank.prepare(frames, training)
+        return torch.zeros((), device=weights[0].device)
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        grads = ctx.bank.backward(ctx.plan)
+        return (None, None, None) + tuple(grads)
+
+
+def bank_token(bank, frames, training):
+    return _BankToken.apply(bank, frames, training, *bank.weight_params())

@@ -1,0 +1,366 @@
+"""GPU parity tests, op level: every HIP kernel family against the CPU oracle / plain fp32 PyTorch
+math on identical (bf16-rounded) inputs, called through the C ABI (ctypes).
+
+Tolerances: activations are stored in bf16 (8-bit mantissa) with fp32 accumulation, so a single op
+is expected within ~2^-8 relative of an fp32 evaluation of the same bf16 inputs; tolerances are
+stated per test.  Integer/mask outputs must be bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import hu, golden, tam_mask, gca_unknown, TAM_CASES, GCA_CASES, assert_close
+from tcvom_amd.synthetic import formula_tensor, synthetic_window
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def nchw(t):
+    return t.detach().float().cpu().permute(0, 3, 1, 2)
+
+
+def rel_err(got, want):
+    got, want = got.double(), want.double()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+# --------------------------------------------------------------------------------------------- conv engine
+CONV_CASES = [
+    # name, cin, cout, k, stride, pad, transposed, N, H, W
+    ('c3x3_s1_32_64', 32, 64, 3, 1, 1, False, 2, 12, 20),
+    ('c3x3_s2_64_128', 64, 128, 3, 2, 1, False, 1, 16, 24),
+    ('c3x3_s1_128_256', 128, 256, 3, 1, 1, False, 1, 10, 14),
+    ('c1x1_256_128', 256, 128, 1, 1, 0, False, 2, 6, 10),
+    ('c3x3_s2_p0_16_32', 16, 32, 3, 2, 0, False, 1, 18, 26),
+    ('c3x3_s1_32_32_big', 32, 32, 3, 1, 1, False, 1, 40, 72),
+    ('convT_64_64', 64, 64, 4, 2, 1, True, 1, 9, 13),
+    ('convT_512_512', 512, 512, 4, 2, 1, True, 1, 4, 6),
+    ('c3x3_s1_512_256', 512, 256, 3, 1, 1, False, 1, 6, 8),
+]
+
+
+def _mini_bank(cin, cout, k, stride, pad, transposed, spectral, bias=False, tag='t'):
+    from tcvom_amd.weights import WeightBank, ConvSpec
+    shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    w = nn.Parameter(formula_tensor('conv.%s.weight' % tag, shape).to(DEV))
+    u = v = None
+    if spectral:
+        u = nn.Parameter(formula_tensor('conv.%s.weight_u' % tag, (shape[0],)).to(DEV), requires_grad=False)
+        v = nn.Parameter(formula_tensor('conv.%s.weight_v' % tag, (int(np.prod(shape[1:])),)).to(DEV), requires_grad=False)
+    b = nn.Parameter(formula_tensor('conv.%s.bias' % tag, (cout,)).to(DEV)) if bias else None
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, u, v, b, transposed, stride, pad, 'frame')
+    bank.register(spec)
+    return bank, spec
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(case):
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    name, cin, cout, k, stride, pad, transposed, N, H, W = case
+    bank, spec = _mini_bank(cin, cout, k, stride, pad, transposed, spectral=False, bias=True, tag=name)
+    cfg = ops.ConvCfg(bank, spec)
+    x = hu('x.' + name, (N, cin, H, W))
+    xg = nhwc(x).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    y = ops.conv_bn_act(cfg, xg, token, True)
+    # reference on the same bf16-rounded operands
+    xr = bf(x).requires_grad_(True)
+    wr = bf(spec.weight.detach().cpu()).requires_grad_(True)
+    br = spec.bias.detach().cpu().clone().requires_grad_(True)
+    if transposed:
+        yr = F.conv_transpose2d(xr, wr, br, stride, pad)
+    else:
+        yr = F.conv2d(xr, wr, br, stride, pad)
+    assert tuple(nchw(y).shape) == tuple(yr.shape)
+    assert rel_err(nchw(y), yr) < 1.5e-2, 'fwd'                 # bf16 output rounding: 2^-8 = 3.9e-3 of |y|
+    gy = hu('gy.' + name, tuple(yr.shape))
+    (y.float() * nhwc(gy).float()).sum().backward()
+    (yr * bf(gy)).sum().backward()
+    assert rel_err(nchw(xg.grad), xr.grad) < 1.5e-2, 'dgrad'
+    assert rel_err(spec.weight.grad.cpu(), wr.grad) < 1e-2, 'wgrad'
+    assert rel_err(spec.bias.grad.cpu(), br.grad) < 1e-2, 'bias grad'
+
+
+def test_conv_small_cin_padded_channels():
+    """First-layer convs read the 8-channel packed input with 6 (or 3) real channels."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    for cin, stride, pad in ((6, 2, 1), (6, 1, 1), (3, 2, 0)):
+        bank, spec = _mini_bank(cin, 32 if cin == 6 else 16, 3, stride, pad, False, spectral=False, tag='small%d%d' % (cin, stride))
+        spec.needs_dgrad = False
+        cfg = ops.ConvCfg(bank, spec)
+        x = hu('x.small', (1, 8, 20, 28))
+        token = bank_token(bank, 1, True)
+        y = ops.conv_bn_act(cfg, nhwc(x), token, True)
+        wr = bf(spec.weight.detach().cpu()).requires_grad_(True)
+        yr = F.conv2d(bf(x)[:, :cin], wr, None, stride, pad)
+        assert rel_err(nchw(y), yr) < 1.5e-2
+        gy = hu('gy.small', tuple(yr.shape))
+        (y.float() * nhwc(gy).float()).sum().backward()
+        (yr * bf(gy)).sum().backward()
+        assert rel_err(spec.weight.grad.cpu(), wr.grad) < 1e-2
+
+
+@pytest.mark.parametrize('act,pre_relu,res', [(1, False, 'res1'), (2, False, 'both'), (0, True, None), (0, False, None)])
+def test_conv_bn_act_train(act, pre_relu, res):
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    cin, cout, N, H, W = 32, 64, 2, 14, 18
+    bank, spec = _mini_bank(cin, cout, 3, 1, 1, False, spectral=False, tag='bn%d%d' % (act, pre_relu))
+    bn = nn.BatchNorm2d(cout).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(formula_tensor('bn.weight', (cout,)))
+        bn.bias.copy_(formula_tensor('bn.bias', (cout,)))
+    cfg = ops.ConvCfg(bank, spec, bn=bn, act=act, pre_relu=pre_relu)
+    x = hu('x.bn', (N, cin, H, W))
+    r1 = hu('r1.bn', (N, cout, H, W)) if res in ('res1', 'both') else None
+    r2 = hu('r2.bn', (N, cout, H, W)) if res == 'both' else None
+    xg = nhwc(x).requires_grad_(True)
+    r1g = nhwc(r1).requires_grad_(True) if r1 is not None else None
+    r2g = nhwc(r2).requires_grad_(True) if r2 is not None else None
+    token = bank_token(bank, 1, True)
+    z = ops.conv_bn_act(cfg, xg, token, True, res1=r1g, res2=r2g)
+
+    xr = bf(x).requires_grad_(True)
+    wr = bf(spec.weight.detach().cpu()).requires_grad_(True)
+    gam = bn.weight.detach().cpu().clone().requires_grad_(True)
+    bet = bn.bias.detach().cpu().clone().requires_grad_(True)
+    rm, rv = torch.zeros(cout), torch.ones(cout)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    if pre_relu:
+        yr = F.relu(yr)
+    zr = F.batch_norm(yr, rm, rv, gam, bet, True, 0.1, 1e-5)
+    r1r = bf(r1).requires_grad_(True) if r1 is not None else None
+    r2r = bf(r2).requires_grad_(True) if r2 is not None else None
+    if r1r is not None:
+        zr = zr + r1r
+    zr = F.relu(zr) if act == 1 else (F.leaky_relu(zr, 0.2) if act == 2 else zr)
+    if r2r is not None:
+        zr = zr + r2r
+    assert rel_err(nchw(z), zr) < 2e-2, 'fwd'
+    assert_close(bn.running_mean.cpu(), rm, 2e-2, 2e-3, 'running_mean')
+    assert_close(bn.running_var.cpu(), rv, 2e-2, 2e-3, 'running_var')
+    gz = hu('gz.bn', tuple(zr.shape))
+    (z.float() * nhwc(gz).float()).sum().backward()
+    (zr * bf(gz)).sum().backward()
+    assert rel_err(nchw(xg.grad), xr.grad) < 4e-2, 'dx'
+    assert rel_err(bn.weight.grad.cpu(), gam.grad) < 2e-2, 'dgamma'
+    assert rel_err(bn.bias.grad.cpu(), bet.grad) < 2e-2, 'dbeta'
+    assert rel_err(spec.weight.grad.cpu(), wr.grad) < 3e-2, 'dw'
+    if r1r is not None:
+        assert rel_err(nchw(r1g.grad), r1r.grad) < 2e-2, 'dres1'
+    if r2r is not None:
+        assert rel_err(nchw(r2g.grad), r2r.grad) < 2e-2, 'dres2'
+
+
+# --------------------------------------------------------------------------------------------- spectral norm
+@pytest.mark.parametrize('transposed', [False, True])
+def test_spectral_norm_bank(transposed):
+    """Chained per-call power iterations, packed weights and the weight_bar gradient vs the oracle."""
+    import oracle
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    cin, cout, k = (32, 64, 4) if transposed else (32, 64, 3)
+    bank, spec = _mini_bank(cin, cout, k, 2 if transposed else 1, 1, transposed, spectral=True, tag='sn%d' % transposed)
+    cfg = ops.ConvCfg(bank, spec)
+    state = {'m.weight_bar': spec.weight.detach().cpu().clone().requires_grad_(True),
+             'm.weight_u': spec.u.detach().cpu().clone(), 'm.weight_v': spec.v.detach().cpu().clone()}
+    calls = 3
+    token = bank_token(bank, calls, True)
+    xs = [hu('x.sn%d' % c, (1, cin, 8, 10)) for c in range(calls)]
+    gys, ys, yrs = [], [], []
+    for c in range(calls):
+        y = ops.conv_bn_act(cfg, nhwc(xs[c]), token, True)
+        wn = oracle.spectral_weight(state, 'm', True)
+        yr = F.conv_transpose2d(bf(xs[c]), wn, None, 2, 1) if transposed else F.conv2d(bf(xs[c]), wn, None, 1, 1)
+        assert rel_err(nchw(y), yr) < 1.5e-2, 'call %d' % c
+        ys.append(y)
+        yrs.append(yr)
+    assert_close(spec.u.cpu(), state['m.weight_u'], 1e-4, 1e-5, 'u after %d calls' % calls)
+    assert_close(spec.v.cpu(), state['m.weight_v'], 1e-4, 1e-5, 'v after %d calls' % calls)
+    loss = 0
+    lossr = 0
+    for c in range(calls):
+        gy = hu('gy.sn%d' % c, tuple(yrs[c].shape))
+        loss = loss + (ys[c].float() * nhwc(gy).float()).sum()
+        lossr = lossr + (yrs[c] * bf(gy)).sum()
+    loss.backward()
+    lossr.backward()
+    assert rel_err(spec.weight.grad.cpu(), state['m.weight_bar'].grad) < 2e-2, 'weight_bar grad'
+
+
+# --------------------------------------------------------------------------------------------- resampling
+def test_pool_upsample_reflect():
+    from tcvom_amd import ops
+    x = hu('x.pool', (2, 16, 12, 20))
+    xg = nhwc(x).requires_grad_(True)
+    xr = bf(x).requires_grad_(True)
+    for fn, ref in ((ops.avgpool2, lambda t: F.avg_pool2d(t, 2, 2)),
+                    (ops.upsample2, lambda t: F.interpolate(t, scale_factor=2, mode='nearest')),
+                    (ops.reflect_pad1, lambda t: F.pad(t, (1, 1, 1, 1), mode='reflect'))):
+        xg.grad = None
+        xr.grad = None
+        y, yr = fn(xg), ref(xr)
+        assert rel_err(nchw(y), yr) < 1e-2
+        g = hu('g.pool', tuple(yr.shape))
+        (y.float() * nhwc(g).float()).sum().backward()
+        (yr * bf(g)).sum().backward()
+        assert rel_err(nchw(xg.grad), xr.grad) < 1e-2
+
+
+def test_head_conv():
+    from tcvom_amd import ops
+    x = hu('x.head', (2, 32, 12, 20))
+    w = nn.Parameter(formula_tensor('decoder.conv2.weight', (1, 32, 3, 3)).to(DEV))
+    b = nn.Parameter(formula_tensor('decoder.conv2.bias', (1,)).to(DEV))
+    xg = nhwc(x).requires_grad_(True)
+    a = ops.head_conv(xg, w, b)
+    xr = bf(x).requires_grad_(True)
+    wr, br = w.detach().cpu().clone().requires_grad_(True), b.detach().cpu().clone().requires_grad_(True)
+    ar = (torch.tanh(F.conv2d(xr, wr, br, 1, 1)) + 1) / 2
+    assert_close(a.cpu(), ar, 0, 1e-5, 'alpha')
+    g = hu('g.head', tuple(ar.shape))
+    (a * g.to(DEV)).sum().backward()
+    (ar * g).sum().backward()
+    assert rel_err(nchw(xg.grad), xr.grad) < 1e-2
+    assert rel_err(w.grad.cpu(), wr.grad) < 1e-3
+    assert rel_err(b.grad.cpu(), br.grad) < 1e-3
+
+
+# --------------------------------------------------------------------------------------------- TAM
+@pytest.mark.parametrize('name', list(TAM_CASES))
+def test_tam_module_vs_reference_golden(name):
+    """FeatureAggregationModule through its reference signature vs vectors captured from the reference."""
+    from models.VMN.VMN_model import FeatureAggregationModule
+    B, C, H, W, win, kind = TAM_CASES[name]
+    g = golden(name)
+    fam = FeatureAggregationModule(C, 1, win)
+    fam.load_state_dict({k: formula_tensor('decoder.fam.' + k, v.shape) for k, v in fam.state_dict().items()})
+    fam.to(DEV)
+    x, b, f = (hu('tam.' + t, (B, C, H, W)).to(DEV).requires_grad_(True) for t in 'xbf')
+    out, attb, attf, small = fam(x, b, f, tam_mask(kind, B, H, W).to(DEV))
+    assert np.array_equal(small.cpu().numpy().astype(np.uint8), g['small'])
+    scale = float(np.abs(g['out']).max())
+    assert_close(out.cpu(), g['out'], 0, 2e-2 * scale, 'out')        # bf16 features: 2 % of the range
+    lscale = max(float(np.abs(g['attb']).max()), 1e-3)
+    assert_close(attb.cpu(), g['attb'], 0, 2e-2 * lscale, 'attb')
+    assert_close(attf.cpu(), g['attf'], 0, 2e-2 * lscale, 'attf')
+    ((out * hu('tam.gout', out.shape).to(DEV)).sum() + (attb * hu('tam.gattb', attb.shape).to(DEV)).sum()
+     + (attf * hu('tam.gattf', attf.shape).to(DEV)).sum()).backward()
+    for got, key in ((x.grad, 'gx'), (b.grad, 'gb'), (f.grad, 'gf'), (fam.key_conv.weight.grad, 'gkw'),
+                     (fam.query_conv.weight.grad, 'gqw'), (fam.value_conv.bias.grad, 'gvb'), (fam.key_conv.bias.grad, 'gkb')):
+        want = g[key]
+        assert_close(got.cpu(), want, 0, 3e-2 * float(np.abs(want).max()) + 1e-6, key)
+
+
+def test_tam_attention_kernel_tight():
+    """The fused attention kernel alone against the oracle's dense formula on identical bf16 inputs."""
+    import oracle
+    from tcvom_amd import ops
+    B, C, H, W, win = 2, 128, 10, 14, 7
+    q, kb, kf, v = (hu('tamk.' + t, (B, C, H, W)) for t in ('q', 'kb', 'kf', 'v'))
+    mask = (hu('tamk.m', (B, 1, H, W)) > -0.2)
+    args = [nhwc(t).requires_grad_(True) for t in (q, kb, kf, v)]
+    out, attb, attf = ops.tam_attention(*args, mask[:, 0].to(torch.uint8).to(DEV).contiguous(), win)
+    refs = [bf(t).requires_grad_(True) for t in (q, kb, kf, v)]
+    ab, lb = oracle.temporal_attention(refs[0], refs[1], mask, win)
+    af, lf = oracle.temporal_attention(refs[0], refs[2], mask, win)
+    outr = refs[3] + ab + af
+    assert_close(attb.cpu(), lb, 1e-4, 1e-4, 'logits b')
+    assert_close(attf.cpu(), lf, 1e-4, 1e-4, 'logits f')
+    assert rel_err(nchw(out), outr) < 1e-2
+    go, gb, gf = hu('tamk.go', tuple(outr.shape)), hu('tamk.gb', tuple(lb.shape)), hu('tamk.gf', tuple(lf.shape))
+    ((out.float() * nhwc(go).float()).sum() + (attb * gb.to(DEV)).sum() + (attf * gf.to(DEV)).sum()).backward()
+    ((outr * bf(go)).sum() + (lb * gb).sum() + (lf * gf).sum()).backward()
+    for a, r, nm in zip(args, refs, 'q kb kf v'.split()):
+        assert rel_err(nchw(a.grad), r.grad) < 1.5e-2, nm
+
+
+# --------------------------------------------------------------------------------------------- GCA
+@pytest.mark.parametrize('name', list(GCA_CASES))
+def test_gca_module_vs_reference_golden(name):
+    from models.GCA.ops import GuidedCxtAtten
+    B, h, w = 2, 12, 16
+    g = golden(name)
+    mod = GuidedCxtAtten(128, 128)
+    mod.load_state_dict({k: formula_tensor('encoder.gca.' + k, v.shape, v.dtype) for k, v in mod.state_dict().items()})
+    mod.to(DEV).train()
+    f = hu('gca.f', (B, 128, h, w)).to(DEV).requires_grad_(True)
+    al = hu('gca.alpha', (B, 128, h, w)).to(DEV).requires_grad_(True)
+    y, (_, scale) = mod(f, al, gca_unknown(GCA_CASES[name], B, h, w).to(DEV))
+    assert_close(scale.cpu(), g['scale'], 1e-5, 1e-6, 'scale')
+    assert_close(y.cpu(), g['y'], 0, 2e-2 * float(np.abs(g['y']).max()), 'y')
+    (y * hu('gca.gy', y.shape).to(DEV)).sum().backward()
+    for got, key in ((al.grad, 'galpha'), (f.grad, 'gf'), (mod.W[0].weight.grad, 'gW0'), (mod.guidance_conv.weight.grad, 'ggw')):
+        want = g[key]
+        assert_close(got.cpu(), want, 0, 5e-2 * float(np.abs(want).max()) + 1e-6, key)
+    assert_close(mod.W[1].running_mean.cpu(), g['run_mean'], 0, 2e-2 * float(np.abs(g['run_mean']).max()), 'running_mean')
+
+
+# --------------------------------------------------------------------------------------------- facade
+def test_preprocess_and_trimap_bit_exact():
+    from tcvom_amd.facade import preprocess_window
+    g = golden('facade')
+    a, fg, bg = (t.to(DEV) for t in synthetic_window(2, 3, 48, 64, seed=3))
+    for r in (0, 2, 5, 12, 20):
+        p = preprocess_window(a, fg, bg, r, 0.0)
+        tris = p.x8[..., 3:6].permute(0, 1, 4, 2, 3).float().cpu().numpy().astype(np.uint8)
+        assert np.array_equal(tris, g['tris_r%d' % r]), 'one-hot trimap r=%d' % r
+        assert np.array_equal(p.trimask.cpu().numpy().astype(np.uint8), g['trimask_r%d' % r]), 'trimask r=%d' % r
+    assert_close(p.imgs.cpu(), g['scaled_imgs'], 1e-6, 1e-6, 'scaled_imgs')
+    imgs = p.x8[..., 0:3].permute(0, 1, 4, 2, 3).float().cpu()
+    assert_close(imgs, g['imgs'], 8e-3, 8e-3, 'normalised imgs (bf16)')
+    p = preprocess_window(a, fg, bg, 2, 0.3)
+    tris = p.x8[..., 3:6].permute(0, 1, 4, 2, 3).float().cpu().numpy().astype(np.uint8)
+    assert np.array_equal(tris, g['tris_eps'])
+    assert np.array_equal(p.trimask.cpu().numpy().astype(np.uint8), g['trimask_eps'])
+
+
+def test_window_losses_vs_oracle():
+    """_WindowLoss on synthetic predictions/logits vs oracle loss functions (fp32, tight)."""
+    import oracle
+    from tcvom_amd.facade import preprocess_window, _WindowLoss
+    B, S, H, W, win = 2, 5, 32, 64, 7
+    a, fg, bg = synthetic_window(B, S, H, W, seed=1)
+    prep = preprocess_window(a.to(DEV), fg.to(DEV), bg.to(DEV), 3, 0.0)
+    prep.unk8 = [prep.unk[:, s, ::8, ::8].contiguous() for s in range(S)]
+    h, w = H // 8, W // 8
+    preds = [torch.sigmoid(hu('wl.p%d' % c, (B, 1, H, W)) * 3) for c in range(1, S - 1)]
+    attb = [hu('wl.b%d' % c, (B, win * win, h * w)) * 2 for c in range(1, S - 1)]
+    attf = [hu('wl.f%d' % c, (B, win * win, h * w)) * 2 for c in range(1, S - 1)]
+    dp = [t.to(DEV).requires_grad_(True) for t in preds + attb + attf]
+    La, Ld, Lt, alphas, comps = _WindowLoss.apply(prep, win, 0.3, 0.2, S, *dp)
+    (La + 0.5 * Ld + 0.25 * Lt).backward()
+    # oracle
+    sc, fgs, bgs, gts, tris, trimasks, imgs = oracle.preprocess(a, fg, bg, 3)
+    rp = [t.clone().requires_grad_(True) for t in preds + attb + attf]
+    ni = S - 2
+    pr = [None] + rp[:ni] + [None]
+    small = [None] + [trimasks[:, c, :, ::8, ::8].bool() for c in range(1, S - 1)] + [None]
+    refine = [torch.where(trimasks[:, c].bool(), pr[c], gts[:, c]) for c in range(1, S - 1)]
+    La_r = sum(oracle.l1_mask(refine[k], gts[:, k + 1], trimasks[:, k + 1]) for k in range(ni)) / ni
+    al = torch.stack([torch.zeros_like(refine[0])] + refine + [torch.zeros_like(refine[0])], dim=1)
+    Ld_r = oracle.dtssd_loss(al, gts, trimasks)
+    Lt_r = oracle.attention_loss([None] + rp[ni:2 * ni] + [None], [None] + rp[2 * ni:] + [None], small, gts, win)
+    (La_r + 0.5 * Ld_r + 0.25 * Lt_r).backward()
+    assert_close(La.cpu(), La_r, 1e-4, 1e-6, 'L_alpha')
+    assert_close(Ld.cpu(), Ld_r, 1e-4, 1e-6, 'L_dt')
+    assert_close(Lt.cpu(), Lt_r, 1e-4, 1e-6, 'L_att')
+    assert_close(alphas.cpu()[:, 1:-1], al[:, 1:-1].clamp(0, 1), 1e-6, 1e-6, 'alphas')
+    for got, want in zip(dp, rp):
+        assert_close(got.grad.cpu(), want.grad, 1e-3, 1e-9 + 1e-4 * float(want.grad.abs().max()), 'grad')
