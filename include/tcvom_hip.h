@@ -160,8 +160,8 @@ int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, const uint8_t* 
 int tcvom_gca_prepare(const void* g8, const uint8_t* unk8, void* G, float* scales, float* cvec, float* dvec,
                       float* nrm, int32_t B, int32_t h8, int32_t w8, int32_t CG, void* stream);
 int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, void* stream);
-int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec, void* T, int32_t rows,
-                          int32_t ncols, int64_t ld, int64_t ldp, void* stream);
+int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec /*[rows/rows_per_batch][ncols]*/, void* T,
+                          int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, int32_t rows_per_batch, void* stream);
 int tcvom_gca_value_patches(const void* alpha, void* V, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);
 int tcvom_gca_value_patches_bwd(const float* dV, void* dalpha, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);
 int tcvom_gca_fold(const void* O, void* Y, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);

@@ -82,7 +82,7 @@ _PROTOS = {
     'tcvom_tam_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_gca_prepare': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_row_softmax': [vp, vp, i32, i32, i64, i64, vp],
-    'tcvom_row_softmax_bwd': [vp, vp, vp, vp, i32, i32, i64, i64, vp],
+    'tcvom_row_softmax_bwd': [vp, vp, vp, vp, i32, i32, i64, i64, i32, vp],
     'tcvom_gca_value_patches': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_gca_value_patches_bwd': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_gca_fold': [vp, vp, i32, i32, i32, i32, vp],

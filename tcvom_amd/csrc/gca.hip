@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
 // dS'[i][j] = P (dP - sum_j P dP);  T = dS' * c_j  (bf16, padded columns zero)
 __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const bf16raw* __restrict__ P, const float* __restrict__ dP,
                                                               const float* __restrict__ cvec, bf16raw* __restrict__ T,
-                                                              int ncols, int64_t ld, int64_t ldp) {
+                                                              int ncols, int64_t ld, int64_t ldp, int rows_per_batch) {
     __shared__ float red[4];
+    cvec += (int64_t)(blockIdx.x / rows_per_batch) * ncols;      // per-key scales are [B][N]
     const bf16raw* p = P + (int64_t)blockIdx.x * ldp;
     const float* d = dP + (int64_t)blockIdx.x * ld;
     bf16raw* t = T + (int64_t)blockIdx.x * ldp;
@@ -258,10 +259,10 @@ extern "C" int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t 
     return TCVOM_OK;
 }
 extern "C" int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec, void* T, int32_t rows,
-                                     int32_t ncols, int64_t ld, int64_t ldp, void* stream) {
-    TCVOM_CHECK_ARG(P && dP && cvec && T && rows > 0 && ncols > 0, "row_softmax_bwd: bad args");
+                                     int32_t ncols, int64_t ld, int64_t ldp, int32_t rows_per_batch, void* stream) {
+    TCVOM_CHECK_ARG(P && dP && cvec && T && rows > 0 && ncols > 0 && rows_per_batch > 0, "row_softmax_bwd: bad args");
     hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)P, dP, cvec,
-                       (bf16raw*)T, ncols, ld, ldp);
+                       (bf16raw*)T, ncols, ld, ldp, rows_per_batch);
     TCVOM_LAUNCH_CHECK("row_softmax_bwd");
     return TCVOM_OK;
 }

@@ -144,22 +144,25 @@ __global__ void add_kernel(const uint4* __restrict__ a, const uint4* __restrict_
 // ---------------------------------------------------------------- bias gradient: db[k] = sum_p dy[p][k]
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16raw* __restrict__ dy, float* __restrict__ out,
                                                      int64_t P, int K, int ld, int rows_per_block) {
-    // thread t handles column t % K... generic: each thread walks rows with stride 256/K' ; K <= 256
-    const int col = threadIdx.x % K;
-    const int rsub = threadIdx.x / K;
-    const int RS = 256 / K;
+    // columns are processed in chunks of Kc = min(K, 256); within a chunk 256/Kc row slices run concurrently
+    const int Kc = K < 256 ? K : 256;
+    const int RS = 256 / Kc;
+    const int cl = threadIdx.x % Kc, rsub = threadIdx.x / Kc;
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    float a = 0.f;
-    if (rsub < RS)
-        for (int64_t p = pbeg + rsub; p < pend; p += RS) a += bf2f(dy[p * ld + col]);
     __shared__ float red[256];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    if (threadIdx.x < K) {
-        float s = 0.f;
-        for (int r = 0; r < RS; ++r) s += red[r * K + threadIdx.x];
-        atomicAdd(out + threadIdx.x, s);
+    for (int cb = 0; cb < K; cb += Kc) {
+        float a = 0.f;
+        if (rsub < RS && cb + cl < K)
+            for (int64_t p = pbeg + rsub; p < pend; p += RS) a += bf2f(dy[p * ld + cb + cl]);
+        __syncthreads();
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < Kc && cb + threadIdx.x < K) {
+            float s = 0.f;
+            for (int r = 0; r < RS; ++r) s += red[r * Kc + threadIdx.x];
+            atomicAdd(out + cb + threadIdx.x, s);
+        }
     }
 }
 
@@ -319,7 +322,7 @@ extern "C" int tcvom_add(const void* a, const void* b, const void* c, void* z, i
     return TCVOM_OK;
 }
 extern "C" int tcvom_colsum(const void* dy, float* out, int64_t P, int32_t K, int32_t ld, void* stream) {
-    TCVOM_CHECK_ARG(dy && out && K >= 1 && K <= 256 && (256 % K == 0 || K == 1), "colsum: K=%d must divide 256", K);
+    TCVOM_CHECK_ARG(dy && out && K >= 1 && (K >= 256 || 256 % K == 0), "colsum: K=%d must divide 256 or be >= 256", K);
     int64_t blocks = (P + 4095) / 4096;
     if (blocks > 1024) blocks = 1024;
     const int rpb = (int)((P + blocks - 1) / blocks);

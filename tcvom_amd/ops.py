@@ -344,7 +344,7 @@ class _GcaAttention(torch.autograd.Function):
         L.call('tcvom_conv_igemm', L.ptr(dO), L.ptr(V), L.ptr(dP), None, None, None, None, C.byref(d), st)
         # T = softmax_bwd(P, dP) * c_j
         T = torch.empty((B, N, ld), dtype=BF16, device=dev)
-        L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), B * N, N, ld, ld, st)
+        L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), B * N, N, ld, ld, N, st)
         del dP
         dV = torch.zeros((B, N, DV), dtype=torch.float32, device=dev)
         Mp = torch.zeros((B, N, D), dtype=torch.float32, device=dev)

@@ -57,7 +57,7 @@ FULL_GRADS = ('decoder.fam.key_conv.bias', 'decoder.fam.query_conv.bias', 'encod
 
 def assert_close(got, want, rtol, atol, what=''):
     got = torch.as_tensor(np.asarray(got.detach().cpu() if torch.is_tensor(got) else got)).double()
-    want = torch.as_tensor(np.asarray(want)).double()
+    want = torch.as_tensor(np.asarray(want.detach().cpu() if torch.is_tensor(want) else want)).double()
     assert got.shape == want.shape, '%s: shape %s vs %s' % (what, tuple(got.shape), tuple(want.shape))
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
@@ -71,3 +71,22 @@ def vmn_gca_template():
     from tcvom_amd.vmn import build_vmn_gca
     net = build_vmn_gca(agg_window=7)
     return net.state_dict()
+
+
+class Checker(object):
+    """Collects named max-relative-error checks so that one run reports every quantity."""
+
+    def __init__(self):
+        self.rows = []
+
+    def rel(self, name, got, want, tol):
+        got = torch.as_tensor(np.asarray(got.detach().float().cpu() if torch.is_tensor(got) else got)).double()
+        want = torch.as_tensor(np.asarray(want.detach().float().cpu() if torch.is_tensor(want) else want)).double()
+        assert got.shape == want.shape, '%s: shape %s vs %s' % (name, tuple(got.shape), tuple(want.shape))
+        err = float((got - want).abs().max() / (want.abs().max() + 1e-12))
+        self.rows.append((name, err, tol, err <= tol))
+
+    def done(self):
+        msg = ', '.join('%s=%.2e%s' % (n, e, '' if ok else ' (> %.1e!)' % t) for n, e, t, ok in self.rows)
+        print(msg)
+        assert all(ok for _, _, _, ok in self.rows), msg

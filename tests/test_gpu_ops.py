@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from helpers import hu, golden, tam_mask, gca_unknown, TAM_CASES, GCA_CASES, assert_close
+from helpers import hu, golden, tam_mask, gca_unknown, TAM_CASES, GCA_CASES, assert_close, Checker
 from tcvom_amd.synthetic import formula_tensor, synthetic_window
 
 pytestmark = pytest.mark.gpu
@@ -144,7 +144,16 @@ def test_conv_bn_act_train(act, pre_relu, res):
     yr = F.conv2d(xr, wr, None, 1, 1)
     if pre_relu:
         yr = F.relu(yr)
-    zr = F.batch_norm(yr, rm, rv, gam, bet, True, 0.1, 1e-5)
+    # The kernel takes the statistics from the fp32 accumulators but normalises the bf16-stored conv
+    # output; mirror that (straight-through rounding) so that activation masks are decided on identical
+    # values — otherwise a handful of sign flips at pre-activations ~0 dominate a max-error metric.
+    mean = yr.mean((0, 2, 3), keepdim=True)
+    var = yr.var((0, 2, 3), unbiased=False, keepdim=True)
+    n_el = yr.numel() // cout
+    rm = 0.9 * rm + 0.1 * mean.detach().flatten()
+    rv = 0.9 * rv + 0.1 * var.detach().flatten() * n_el / (n_el - 1)
+    yq = yr + (bf(yr) - yr).detach()
+    zr = (yq - mean) / torch.sqrt(var + 1e-5) * gam.view(1, -1, 1, 1) + bet.view(1, -1, 1, 1)
     r1r = bf(r1).requires_grad_(True) if r1 is not None else None
     r2r = bf(r2).requires_grad_(True) if r2 is not None else None
     if r1r is not None:
@@ -152,20 +161,22 @@ def test_conv_bn_act_train(act, pre_relu, res):
     zr = F.relu(zr) if act == 1 else (F.leaky_relu(zr, 0.2) if act == 2 else zr)
     if r2r is not None:
         zr = zr + r2r
-    assert rel_err(nchw(z), zr) < 2e-2, 'fwd'
-    assert_close(bn.running_mean.cpu(), rm, 2e-2, 2e-3, 'running_mean')
-    assert_close(bn.running_var.cpu(), rv, 2e-2, 2e-3, 'running_var')
+    ck = Checker()
+    ck.rel('fwd', nchw(z), zr, 2e-2)
+    ck.rel('running_mean', bn.running_mean, rm, 2e-2)
+    ck.rel('running_var', bn.running_var, rv, 2e-2)
     gz = hu('gz.bn', tuple(zr.shape))
     (z.float() * nhwc(gz).float()).sum().backward()
     (zr * bf(gz)).sum().backward()
-    assert rel_err(nchw(xg.grad), xr.grad) < 4e-2, 'dx'
-    assert rel_err(bn.weight.grad.cpu(), gam.grad) < 2e-2, 'dgamma'
-    assert rel_err(bn.bias.grad.cpu(), bet.grad) < 2e-2, 'dbeta'
-    assert rel_err(spec.weight.grad.cpu(), wr.grad) < 3e-2, 'dw'
+    ck.rel('dx', nchw(xg.grad), xr.grad, 4e-2)
+    ck.rel('dgamma', bn.weight.grad, gam.grad, 2e-2)
+    ck.rel('dbeta', bn.bias.grad, bet.grad, 2e-2)
+    ck.rel('dw', spec.weight.grad, wr.grad, 3e-2)
     if r1r is not None:
-        assert rel_err(nchw(r1g.grad), r1r.grad) < 2e-2, 'dres1'
+        ck.rel('dres1', nchw(r1g.grad), r1r.grad, 2e-2)
     if r2r is not None:
-        assert rel_err(nchw(r2g.grad), r2r.grad) < 2e-2, 'dres2'
+        ck.rel('dres2', nchw(r2g.grad), r2r.grad, 2e-2)
+    ck.done()
 
 
 # --------------------------------------------------------------------------------------------- spectral norm
@@ -303,13 +314,51 @@ def test_gca_module_vs_reference_golden(name):
     f = hu('gca.f', (B, 128, h, w)).to(DEV).requires_grad_(True)
     al = hu('gca.alpha', (B, 128, h, w)).to(DEV).requires_grad_(True)
     y, (_, scale) = mod(f, al, gca_unknown(GCA_CASES[name], B, h, w).to(DEV))
-    assert_close(scale.cpu(), g['scale'], 1e-5, 1e-6, 'scale')
-    assert_close(y.cpu(), g['y'], 0, 2e-2 * float(np.abs(g['y']).max()), 'y')
+    ck = Checker()
+    ck.rel('scale', scale, g['scale'], 1e-5)
+    ck.rel('y', y, g['y'], 2e-2)
     (y * hu('gca.gy', y.shape).to(DEV)).sum().backward()
-    for got, key in ((al.grad, 'galpha'), (f.grad, 'gf'), (mod.W[0].weight.grad, 'gW0'), (mod.guidance_conv.weight.grad, 'ggw')):
-        want = g[key]
-        assert_close(got.cpu(), want, 0, 5e-2 * float(np.abs(want).max()) + 1e-6, key)
-    assert_close(mod.W[1].running_mean.cpu(), g['run_mean'], 0, 2e-2 * float(np.abs(g['run_mean']).max()), 'running_mean')
+    # the guidance gradient goes through a sharply peaked softmax: rounding the guidance features to bf16
+    # perturbs logits of magnitude ~50 by ~0.1, hence the looser bound (the kernel itself is pinned tightly
+    # on identical bf16 inputs in test_gca_attention_kernel_tight)
+    for got, key, tol in ((al.grad, 'galpha', 5e-2), (f.grad, 'gf', 2e-1), (mod.W[0].weight.grad, 'gW0', 5e-2),
+                          (mod.guidance_conv.weight.grad, 'ggw', 2e-1)):
+        ck.rel(key, got, g[key], tol)
+    ck.rel('running_mean', mod.W[1].running_mean, g['run_mean'], 2e-2)
+    ck.done()
+
+
+@pytest.mark.parametrize('B,h8,w8', [(2, 12, 16), (1, 20, 28)])
+def test_gca_attention_kernel_tight(B, h8, w8):
+    """The attention core (patches, scores, softmax, PV, fold) against the oracle's dense formula on
+    IDENTICAL bf16 guidance/value maps (so only accumulation order and the bf16 storage of P differ)."""
+    from oracle.gca_net import _patch_matrix, gca_scales
+    from tcvom_amd import ops
+    CG, Ca = 64, 128
+    g8 = hu('gcak.g', (B, CG, h8, w8)) * 0.35            # |logits| ~ 10: peaked but not degenerate
+    al = hu('gcak.a', (B, Ca, h8, w8))
+    unk = (hu('gcak.u', (B, 1, h8, w8)) > 0.2).float()
+    gg, ag = nhwc(g8).requires_grad_(True), nhwc(al).requires_grad_(True)
+    y, scales = ops.gca_attention(gg, ag, unk[:, 0].to(torch.uint8).to(DEV).contiguous())
+    gr, ar = bf(g8).requires_grad_(True), bf(al).requires_grad_(True)
+    g16, u16 = gr[:, :, ::2, ::2], unk[:, :, ::2, ::2]
+    sc = gca_scales(u16)
+    Wp = _patch_matrix(g16, 3, 1, 1, 1)
+    Kh = Wp / torch.clamp(Wp.pow(2).sum(1, keepdim=True).sqrt(), min=1e-4)
+    mm = (_patch_matrix(u16, 3, 1, 1, 1).mean(1) > 0).float()
+    S = torch.bmm(Kh.transpose(1, 2), Wp) * (sc[:, 0:1] * mm + sc[:, 1:2] * (1 - mm)).unsqueeze(2)
+    P = torch.softmax(S - 1e4 * torch.diag_embed(mm), dim=1)
+    O = torch.bmm(_patch_matrix(ar, 4, 2, 1, 1), P)
+    yr = F.fold(O, (h8, w8), 4, stride=2, padding=1) / 4.0
+    ck = Checker()
+    ck.rel('scales', scales, sc, 1e-5)
+    ck.rel('y', nchw(y), yr, 1.5e-2)
+    gy = hu('gcak.gy', tuple(yr.shape))
+    (y.float() * nhwc(gy).float()).sum().backward()
+    (yr * bf(gy)).sum().backward()
+    ck.rel('dalpha', nchw(ag.grad), ar.grad, 2e-2)
+    ck.rel('dg', nchw(gg.grad), gr.grad, 4e-2)
+    ck.done()
 
 
 # --------------------------------------------------------------------------------------------- facade
