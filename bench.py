@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Headline benchmark: synthetic 1080p (1088x1920) 3-frame windows/s, GCA+TAM, forward + backward
+(L_alpha + 0.5 L_dt + 0.25 L_att, train_ddp.py:56-61) + gradient all-reduce + Adam, bf16 activations.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; each rank trains on its own clip (weak scaling, clips are independent — the only
+data-path collective is the gradient all-reduce over RCCL/xGMI).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work of one window (FlopCounterMode on the reference, 2 flop/MAC)
+GFLOP_FWD_CONV_1080P = 1737.3      # non-GCA convolutions, forward
+GFLOP_FWD_GCA_1080P = 2106.3       # 6 guided-contextual-attention calls, forward (quadratic in pixels)
+GFLOP_WINDOW_1080P = 11179.81      # forward + backward
+MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
+FULL_H, FULL_W = 1088, 1920
+
+
+def window_gflop(H, W):
+    """fwd+bwd GFLOP of one 3-frame window at HxW, scaled from the measured 1088x1920 figures."""
+    r = (H * W) / float(FULL_H * FULL_W)
+    fwd = GFLOP_FWD_CONV_1080P * r + GFLOP_FWD_GCA_1080P * r * r
+    return fwd * (GFLOP_WINDOW_1080P / (GFLOP_FWD_CONV_1080P + GFLOP_FWD_GCA_1080P))
+
+
+def build(device, H, W, seed):
+    from models.model import FullModel_VMD
+    from tcvom_amd.synthetic import formula_tensor, synthetic_window
+    model = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+    model.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in model.NET.state_dict().items()})
+    model = model.to(device).train()
+    a, fg, bg = synthetic_window(1, 3, H, W, seed=seed)
+    return model, a.to(device), fg.to(device), bg.to(device)
+
+
+def igemm_profile(step_fn):
+    """One extra, event-instrumented step: every igemm launch is bracketed by HIP events on the launch
+    stream.  Returns {variant: (launches, total_ms, total_gflop)}."""
+    import tcvom_amd._lib as L
+    rec = []
+    L.PROFILE = rec
+    step_fn()
+    torch.cuda.synchronize()
+    L.PROFILE = None
+    agg = {}
+    for name, desc, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        real_taps = sum(1 for t in range(desc['ntaps']) if desc['tap_w'][t] >= 0)
+        gflop = 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
+        if name == 'tcvom_conv_igemm':
+            var = 'igemm_nt<128,128>' if desc['K'] >= 128 else ('igemm_nt<64,256>' if desc['K'] > 32 else 'igemm_nt<32,256>')
+        else:
+            ncols = desc['ntaps'] * desc['C']
+            var = 'igemm_tt<128,128>' if (desc['K'] >= 128 and ncols >= 128) else ('igemm_tt<64,64>' if desc['K'] > 32 else 'igemm_tt<32,32>')
+        n, t, g = agg.get(var, (0, 0.0, 0.0))
+        agg[var] = (n + 1, t + ms, g + gflop)
+    return agg
+
+
+def cpu_baseline(sample_hw=(544, 960)):
+    """The oracle (pure PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host
+    cores on ONE bounded sample window, scaled to 1080p windows/s by the algorithmic-FLOP ratio."""
+    import oracle
+    from oracle.state_spec import vmn_gca_state_spec
+    from tcvom_amd.synthetic import formula_tensor, synthetic_window
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    H, W = sample_hw
+    state = {k: formula_tensor(k, s, torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
+             for k, s in vmn_gca_state_spec().items()}
+    for k, v in state.items():
+        if v.is_floating_point() and not any(t in k for t in ('weight_u', 'weight_v', 'running_')):
+            v.requires_grad_(True)
+    a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
+    t0 = time.time()
+    out, _ = oracle.window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True)
+    oracle.train_step_loss(out).backward()
+    dt = time.time() - t0
+    ratio = window_gflop(H, W) / window_gflop(FULL_H, FULL_W)
+    return {'value': round(ratio / dt, 6), 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
+            'sample': 'one 3x%dx%d window fwd+bwd in %.1f s on %d threads, scaled to 3x%dx%d by the algorithmic '
+                      'FLOP ratio %.4f' % (H, W, dt, cores, FULL_H, FULL_W, ratio)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--height', type=int, default=FULL_H)
+    ap.add_argument('--width', type=int, default=FULL_W)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group(backend='nccl', init_method='env://')
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
+
+    from tcvom_amd.ddp import GradientAverager, broadcast_module_state
+    from tcvom_amd.facade import train_step_loss
+    from tcvom_amd.optim import FusedAdam
+    H, W = args.height, args.width
+    model, a, fg, bg = build(device, H, W, seed=rank)
+    broadcast_module_state(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4, weight_decay=1e-4)
+    averager = GradientAverager(params)
+
+    def step():
+        out = model(a, fg, bg)
+        loss = train_step_loss(out)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        averager.average()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = torch.tensor([time.time() - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    final_loss = float(loss)
+
+    result = None
+    if rank == 0:
+        win_per_s = world * args.steps / elapsed
+        gflop = window_gflop(H, W)
+        result = {
+            'metric': '1080p 3-frame windows/sec (fwd+bwd) GCA+TAM' if (H, W) == (FULL_H, FULL_W)
+                      else '%dx%d 3-frame windows/sec (fwd+bwd) GCA+TAM' % (H, W),
+            'value': round(win_per_s, 4), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
+                                   '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
+                                   'formula-initialised weights, train mode' % (H, W),
+                       'global_batch_clips': world, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world},
+            'final_loss': round(final_loss, 6),
+            'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5),
+        }
+    # ---- roofline of the dominant kernel (event-instrumented extra step on rank 0's stream)
+    if not args.no_profile:
+        agg = igemm_profile(step)
+        if rank == 0 and agg:
+            dom = max(agg, key=lambda k: agg[k][1])
+            n, ms, gf = agg[dom]
+            tf = gf / ms                                    # GFLOP / ms == TFLOP/s
+            result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': MFMA_PEAK_TFLOPS,
+                                  'unit': 'TFLOP/s', 'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                                  'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
+                                  'algorithmic_gflop_per_launch': round(gf / n, 3),
+                                  'all_igemm': {k: {'launches': v[0], 'ms': round(v[1], 3), 'tflops': round(v[2] / max(v[1], 1e-9), 1)}
+                                                for k, v in sorted(agg.items())}}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

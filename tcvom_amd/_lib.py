@@ -124,9 +124,27 @@ def last_error():
     return (_lib.tcvom_last_error() or b'').decode()
 
 
+PROFILE = None   # bench.py sets this to a list to bracket every igemm launch with HIP events
+
+
+def _profiled(name, args):
+    import torch
+    d = args[7 if name == 'tcvom_conv_igemm' else 3]._obj
+    info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': d.ntaps, 'tap_w': list(d.tap_w), 'batch': d.batch}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = _FNS[name](*args)
+    e1.record()
+    PROFILE.append((name, info, e0, e1))
+    return rc
+
+
 def call(name, *args):
     """Invoke a status-returning entry point; raise TcvomError on failure."""
-    rc = _FNS[name](*args)
+    if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm'):
+        rc = _profiled(name, args)
+    else:
+        rc = _FNS[name](*args)
     if name in _PLAIN:
         return rc
     if rc != 0:

@@ -1,0 +1,56 @@
+"""Multi-tensor Adam on one HIP launch (tcvom_adam_mt) — same update rule as
+`torch.optim.Adam(params, lr, weight_decay=wd)` used by the reference (train_ddp.py:296-297):
+L2 weight decay folded into the gradient, eps 1e-8, betas (0.9, 0.999), bias correction.
+
+Keeps the torch.optim.Optimizer surface (`param_groups[0]['lr']` is what `poly_lr` mutates,
+utils/utils.py:185-188; `state_dict()` round-trips exp_avg / exp_avg_sq / step)."""
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+
+    def _table(self, gi, plist):
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        ent = self._tables.get(gi)
+        if ent is not None and ent[0] == sig:
+            return ent
+        rows, work = [], []
+        for i, p in enumerate(plist):
+            st = self.state[p]
+            rows.append([p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()])
+            work += [(i, b) for b in range((p.numel() + 1023) // 1024)]
+        dev = plist[0].device
+        ent = (sig, torch.tensor(rows, dtype=torch.int64, device=dev),
+               torch.tensor(work, dtype=torch.int32, device=dev).reshape(-1), len(work))
+        self._tables[gi] = ent
+        return ent
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group['params'] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                        and p.grad.dtype == torch.float32):
+                    raise RuntimeError('FusedAdam: parameters and gradients must be contiguous fp32 CUDA tensors')
+            step = self.state[plist[0]]['step'] + 1
+            for p in plist:
+                self.state[p]['step'] = step
+            _, table, work, nblk = self._table(gi, plist)
+            b1, b2 = group['betas']
+            L.call('tcvom_adam_mt', L.ptr(table), L.ptr(work), nblk, float(group['lr']), float(b1), float(b2),
+                   float(group['eps']), float(group['weight_decay']), int(step), float(grad_scale), L.stream_ptr())
+        return loss
