@@ -70,13 +70,15 @@ def igemm_profile(step_fn):
     return agg
 
 
-def cpu_baseline(sample_hw=(544, 960)):
+def cpu_baseline(sample_hw=(384, 640), max_threads=32):
     """The oracle (pure PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host
     cores on ONE bounded sample window, scaled to 1080p windows/s by the algorithmic-FLOP ratio."""
     import oracle
     from oracle.state_spec import vmn_gca_state_spec
     from tcvom_amd.synthetic import formula_tensor, synthetic_window
-    cores = os.cpu_count() or 1
+    # PyTorch's CPU kernels do not scale past a few dozen threads on these shapes (256 threads measured
+    # 768 s for a 544x960 window): use at most `max_threads` and report exactly that many as `cores`
+    cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
     H, W = sample_hw
     state = {k: formula_tensor(k, s, torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
