@@ -86,7 +86,8 @@ int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_con
 int tcvom_bn_finalize(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, float* scale_shift /*[2][C]*/, float* saved /*[2][C] mean,invstd*/,
-                      void* stream);
+                      double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */, void* stream);
+int tcvom_bn_finalize_scratch_doubles(int32_t C);
 int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,

@@ -58,7 +58,8 @@ _PROTOS = {
     'tcvom_conv_igemm': [vp, vp, vp, vp, vp, vp, vp, DP, vp],
     'tcvom_conv_stats_groups': [DP],
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
-    'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp],
+    'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp],
+    'tcvom_bn_finalize_scratch_doubles': [i32],
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
@@ -99,7 +100,7 @@ _PROTOS = {
     'tcvom_abi_version': [],
 }
 # entry points that return a count, not a status
-_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version'}
+_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles'}
 
 EXPORTS = sorted(list(_PROTOS) + ['tcvom_last_error'])
 

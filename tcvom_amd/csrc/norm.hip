@@ -7,9 +7,37 @@
 #include "common.h"
 
 // ---------------------------------------------------------------- statistics finalize
-// partial: [G][2][C] (sum, sumsq).  One block = 32 channels x 8 group slices.
+// stage 1 (only when there are many groups): [G][2][C] fp32 -> [BN_SLICES][2][C] fp64, slice s sums groups
+// g = s, s + BN_SLICES, ...  One block = 32 channels x 8 sub-slices of one slice; grid (C/32, BN_SLICES).
+#define BN_SLICES 64
+__global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __restrict__ partial, int G, int C,
+                                                                double* __restrict__ out) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const int slice = blockIdx.y;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int g = slice + sl * BN_SLICES; g < G; g += 8 * BN_SLICES) {
+            a += (double)partial[(int64_t)g * 2 * C + c];
+            b += (double)partial[(int64_t)g * 2 * C + C + c];
+        }
+    }
+    s1[sl][cl] = a;
+    s2[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        out[(int64_t)slice * 2 * C + c] = a;
+        out[(int64_t)slice * 2 * C + C + c] = b;
+    }
+}
+
+// stage 2 / single stage.  PT = float (raw partials [G][2][C]) or double (stage-1 output).
+template <typename PT>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partial, int G, int C, double count, double unbias_count,
+    const PT* __restrict__ partial, int G, int C, double count, double unbias_count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved)
@@ -218,14 +246,24 @@ static int stream_grid(int64_t n, int per_block) {
 
 extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                 float momentum, float eps, float* scale_shift, float* saved, void* stream) {
+                                 float momentum, float eps, float* scale_shift, float* saved, double* scratch,
+                                 void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0, "bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, groups, C,
-                       (double)count, (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, running_mean, running_var,
-                       momentum, eps, scale_shift, saved);
+    hipStream_t st = (hipStream_t)stream;
+    const double ub = (double)(unbias_count > 0 ? unbias_count : count);
+    if (groups > 8 * BN_SLICES && scratch) {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C,
+                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C,
+                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved);
+    }
     TCVOM_LAUNCH_CHECK("bn_finalize");
     return TCVOM_OK;
 }
+/* doubles of scratch tcvom_bn_finalize needs for C channels */
+extern "C" int tcvom_bn_finalize_scratch_doubles(int32_t C) { return BN_SLICES * 2 * C; }
 
 extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, float* scale_shift, float* saved, void* stream) {

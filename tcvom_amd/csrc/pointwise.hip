@@ -250,31 +250,50 @@ __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __
         }
     }
 }
-// dw[t][c] = sum_p dpre[p] x[p + off_t][c];  db = sum_p dpre[p].   block partials + atomics
+// dw[t][c] = sum_p dpre[p] x[p + off_t][c];  db = sum_p dpre[p].
+// block = 256 threads = (256/C) pixel lanes x C channels; each thread keeps 9 tap accumulators for its channel
+// over the block's pixel chunk; lanes are combined through LDS, then one atomicAdd per (tap, channel) per block.
 __global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* __restrict__ dpre, const bf16raw* __restrict__ x,
                                                                    float* __restrict__ dw, float* __restrict__ db,
                                                                    int N, int H, int W, int C, int rows_per_block) {
-    // thread = (tap-channel column) for columns < 9*C (<= 288 -> loop), pixel loop inside
+    __shared__ float red[9 * 256];
     const int64_t P = (int64_t)N * H * W;
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    for (int col = threadIdx.x; col < 9 * C + 1; col += 256) {
-        float a = 0.f;
-        if (col == 9 * C) {
-            for (int64_t p = pbeg; p < pend; ++p) a += dpre[p];
-            atomicAdd(db, a);
-            continue;
-        }
-        const int t = col / C, c = col % C;
-        const int dh = t / 3 - 1, dwv = t % 3 - 1;
-        for (int64_t p = pbeg; p < pend; ++p) {
+    const int c = threadIdx.x % C, pl = threadIdx.x / C, PL = 256 / C;
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bsum = 0.f;
+    if (pl < PL) {
+        for (int64_t p = pbeg + pl; p < pend; p += PL) {
+            const float dp = dpre[p];
             const int xw = (int)(p % W);
             const int yh = (int)((p / W) % H);
-            const int ih = yh + dh, iw = xw + dwv;
-            if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
-            a += dpre[p] * bf2f(x[(p + (int64_t)dh * W + dwv) * C + c]);
+            if (c == 0) bsum += dp;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ih = yh + t / 3 - 1, iw = xw + t % 3 - 1;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    acc[t] += dp * bf2f(x[(p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * C + c]);
+            }
         }
-        atomicAdd(dw + col, a);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[t * 256 + threadIdx.x] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float s = 0.f;
+            for (int l = 0; l < PL; ++l) s += red[t * 256 + l * C + threadIdx.x];
+            atomicAdd(dw + t * C + threadIdx.x, s);
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int l = 0; l < PL; ++l) s += red[l * C];
+        atomicAdd(db, s);
     }
 }
 
@@ -323,8 +342,8 @@ extern "C" int tcvom_add(const void* a, const void* b, const void* c, void* z, i
 }
 extern "C" int tcvom_colsum(const void* dy, float* out, int64_t P, int32_t K, int32_t ld, void* stream) {
     TCVOM_CHECK_ARG(dy && out && K >= 1 && (K >= 256 || 256 % K == 0), "colsum: K=%d must divide 256 or be >= 256", K);
-    int64_t blocks = (P + 4095) / 4096;
-    if (blocks > 1024) blocks = 1024;
+    int64_t blocks = (P + 63) / 64;
+    if (blocks > 2048) blocks = 2048;
     const int rpb = (int)((P + blocks - 1) / blocks);
     if (hipMemsetAsync(out, 0, sizeof(float) * K, (hipStream_t)stream) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "colsum: memset failed");
@@ -352,7 +371,7 @@ extern "C" int tcvom_head_conv_fwd(const void* x, const float* w, const float* b
 extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
                                    float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
                                    void* stream) {
-    TCVOM_CHECK_ARG(dalpha && alpha && x && w && dx && dpre && dw && db && C % 8 == 0 && C <= 256, "head_conv_bwd: bad args");
+    TCVOM_CHECK_ARG(dalpha && alpha && x && w && dx && dpre && dw && db && C % 8 == 0 && C <= 256 && 256 % C == 0, "head_conv_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(head_conv_bwd_data_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(256),
                        9 * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);

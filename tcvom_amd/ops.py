@@ -87,9 +87,11 @@ class _ConvBNAct(torch.autograd.Function):
         saved = torch.empty(2 * K, dtype=torch.float32, device=x.device)
         if training:
             P = geo.out_pixels
-            L.call('tcvom_bn_finalize', L.ptr(stats), stats.numel() // (2 * K), K, P, P * cfg.unbias_mult,
+            groups = stats.numel() // (2 * K)
+            scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 512 else None
+            L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
                    L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
-                   float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), st)
+                   float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
             bn.num_batches_tracked += 1
         else:
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
