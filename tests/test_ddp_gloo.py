@@ -1,0 +1,59 @@
+"""The N>1 path on CPU: two gloo ranks broadcast module state from rank 0 and average gradients in flat
+buckets exactly like DDP's all-reduce(mean) (train_ddp.py:275-280), including parameters unused on one rank."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tcvom_amd.ddp import GradientAverager, broadcast_module_state, reduce_tensor
+    torch.manual_seed(100 + rank)                           # different init per rank on purpose
+    net = nn.Sequential(nn.Linear(5, 7), nn.BatchNorm1d(7), nn.Linear(7, 3))
+    broadcast_module_state(net)
+    params = [p for p in net.parameters()]
+    flat_state = torch.cat([p.detach().reshape(-1) for p in params] + [b.detach().float().reshape(-1) for b in net.buffers()])
+    for i, p in enumerate(params):
+        p.grad = None if (rank == 1 and i == 0) else torch.full_like(p, float(rank + 1) * (i + 1))
+    GradientAverager(params, bucket_bytes=64).average()     # tiny buckets -> several collectives
+    grads = torch.cat([p.grad.reshape(-1) for p in params])
+    loss = reduce_tensor(torch.tensor(float(rank)))
+    q.put((rank, flat_state, grads, float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_and_broadcast():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, g0, l0), (_, s1, g1, l1) = res
+    assert torch.equal(s0, s1), 'state must equal rank 0 after the broadcast'
+    assert torch.equal(g0, g1), 'averaged gradients must agree on all ranks'
+    net = nn.Sequential(nn.Linear(5, 7), nn.BatchNorm1d(7), nn.Linear(7, 3))
+    expect = []
+    for i, p in enumerate(net.parameters()):
+        r0, r1 = 1.0 * (i + 1), (0.0 if i == 0 else 2.0 * (i + 1))
+        expect.append(torch.full((p.numel(),), (r0 + r1) / 2))
+    assert torch.allclose(g0, torch.cat(expect))
+    assert l0 == l1 == 0.5
