@@ -240,12 +240,26 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     }
 }
 
-static int nt_tile_n(const tcvom_conv_desc* d) { return d->K >= 128 ? 128 : 256; }
+// Tile configuration.  The ResNet layers all have the same FLOP count but very different pixel counts: at
+// os16/os32 (8160 / 2040 pixels at 1080p) a 128x128 tiling yields only 64-128 workgroups for 256 CUs, so those
+// layers switch to 64x64 tiles (4x the workgroups, ~2.5x the co-resident workgroups per CU).
+struct NtCfg { int tm, tn, waves_n; };
+static NtCfg nt_config(const tcvom_conv_desc* d) {
+    const long long P = (long long)d->N * d->PH * d->PW;
+    const int nb = d->batch > 1 ? d->batch : 1;
+    if (d->K >= 128) {
+        const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
+        if (wgs < 512) return {64, 64, 2};
+        return {128, 128, 2};
+    }
+    if (d->K > 32) return {64, 256, 4};
+    return {32, 256, 4};
+}
 
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d) {
-    const int tn = nt_tile_n(d);
+    const NtCfg c = nt_config(d);
     const long long P = (long long)d->N * d->PH * d->PW;
-    return cdiv(P, tn) * (tn / 64);
+    return cdiv(P, c.tn) * c.waves_n;
 }
 
 extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias,
@@ -263,16 +277,16 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
     hipStream_t st = (hipStream_t)stream;
     const bf16raw* ip = (const bf16raw*)in;
     const bf16raw* wp = (const bf16raw*)w;
-    if (d->K >= 128) {
-        dim3 grid(cdiv(P, 128), cdiv(d->K, 128), nb);
+    const NtCfg c = nt_config(d);
+    dim3 grid(cdiv(P, c.tn), cdiv(d->K, c.tm), nb);
+    if (c.tm == 128)
         hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
-    } else if (d->K > 32) {
-        dim3 grid(cdiv(P, 256), cdiv(d->K, 64), nb);
+    else if (c.tm == 64 && c.tn == 64)
+        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
+    else if (c.tm == 64)
         hipLaunchKernelGGL((igemm_nt_kernel<64, 256, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
-    } else {
-        dim3 grid(cdiv(P, 256), 1, nb);
+    else
         hipLaunchKernelGGL((igemm_nt_kernel<32, 256, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
-    }
     TCVOM_LAUNCH_CHECK("conv_igemm");
     return TCVOM_OK;
 }
@@ -462,22 +476,28 @@ extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, cons
     const int ncols = d->ntaps * d->C;
     const bf16raw* a = (const bf16raw*)dy;
     const bf16raw* b = (const bf16raw*)in;
+    // tile: wide-N tiles for the small-channel layers so that dy is re-read ncols/128 (not ncols/32) times
     int tm, tn;
     if (d->K >= 128 && ncols >= 128) { tm = tn = 128; }
-    else if (d->K > 32) { tm = tn = 64; }
-    else { tm = tn = 32; }
+    else if (d->K > 32) { tm = 64; tn = ncols >= 128 ? 128 : 64; }
+    else { tm = 32; tn = ncols >= 128 ? 128 : 32; }
     const int mt = cdiv(d->K, tm), nt = cdiv(ncols, tn);
-    // aim for ~2k workgroups; chunks are multiples of 64 pixels and at least 256
-    long long want = 2048 / ((long long)mt * nt);
+    // pixel chunks: every workgroup ends with tm*tn atomic adds, so chunks must be long enough to amortise
+    // them (>= 512 pixels) while still giving ~3 workgroups per CU
+    long long want = 768 / ((long long)mt * nt);
     if (want < 1) want = 1;
     long long pchunk = ((P + want - 1) / want + 63) / 64 * 64;
-    if (pchunk < 256) pchunk = 256;
+    if (pchunk < 512) pchunk = 512;
     const int chunks = cdiv(P, pchunk);
     dim3 grid(chunks, nt, mt);
     if (tm == 128)
         hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 64, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+    else if (tm == 64 && tn == 128)
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 64, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
     else if (tm == 64)
         hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+    else if (tn == 128)
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
     else
         hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
     TCVOM_LAUNCH_CHECK("wgrad_igemm");
