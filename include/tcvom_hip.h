@@ -51,7 +51,7 @@ typedef struct {
     int32_t OH, OW, K;           /* output tensor dims; K = output channels (multiple of 4) */
     int32_t PH, PW;              /* phase grid */
     int32_t in_step, out_step, out_off_h, out_off_w;
-    int32_t ntaps;               /* ntaps*C must be a multiple of 32 */
+    int32_t ntaps;               /* ntaps*C must be a multiple of 64 */
     int32_t tap_dh[TCVOM_MAX_TAPS], tap_dw[TCVOM_MAX_TAPS];
     int32_t tap_w[TCVOM_MAX_TAPS];   /* weight slot of tap t, -1 = zero tap (padding) */
     int32_t wt;                  /* weight slots: w is [K][wt][C] bf16 */

@@ -9,9 +9,9 @@ from ._lib import ConvDesc, MAX_TAPS
 
 
 def _desc(N, H, W, C, OH, OW, K, PH, PW, in_step, out_step, off_h, off_w, taps, wt, ldo=None):
-    """taps: list of (dh, dw, wslot).  Pads the tap list with zero taps so that ntaps*C % 32 == 0."""
+    """taps: list of (dh, dw, wslot).  Pads the tap list with zero taps so that ntaps*C % 64 == 0."""
     taps = list(taps)
-    while (len(taps) * C) % 32 != 0:
+    while (len(taps) * C) % 64 != 0:
         taps.append((0, 0, -1))
     assert len(taps) <= MAX_TAPS, 'too many taps'
     d = ConvDesc()
@@ -76,7 +76,7 @@ def dense_desc(rows_b, rows_a, kred, ld_out, batch=1, in_bstride=0, w_bstride=0,
                out_fp32=False):
     """Dense GEMM through the conv engine:  out[n][m] = sum_k B[n][k] * A[m][k]
     (B = `in` operand with rows_b rows, A = `w` operand with rows_a rows, both with row length kred)."""
-    assert kred % 32 == 0
+    assert kred % 64 == 0
     d = _desc(1, 1, rows_b, kred, 1, rows_b, rows_a, 1, rows_b, 1, 1, 0, 0, [(0, 0, 0)], 1, ldo=ld_out)
     d.out_fp32 = 1 if out_fp32 else 0
     d.batch = batch

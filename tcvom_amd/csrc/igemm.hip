@@ -10,34 +10,38 @@
 // MFMA roles: rows (M) = output channels, columns (N) = pixels, so that a lane's 4 consecutive
 // accumulator registers are 4 consecutive channels of ONE pixel -> 8-byte NHWC stores, and the
 // BatchNorm statistics of a channel are a reduction across lanes.
-// LDS tiles are [row][32 k + 8 pad] bf16 (80-byte rows): ds_read_b128 of 16 consecutive rows hits
-// 16 distinct 4-bank slots (20*r mod 64), i.e. conflict-free for the MFMA fragment reads.
 #include "common.h"
+#include <mutex>
 
-#define NT_LDS_STRIDE 40   // bf16 elements per LDS row in igemm_nt (32 + 8 pad)
 #define TT_LDS_STRIDE 72   // bf16 elements per LDS row in igemm_tt (64 + 8 pad)
 
+// igemm_nt main loop (v2): 64-deep k-steps, operands DMA'd global->LDS with global_load_lds_dwordx4
+// (no VGPR round trip), 2-slot LDS ring, ONE barrier per k-step:
+//     vmcnt(0); barrier;  issue DMA of step s+1 into the other slot;  16 MFMAs/wave on step s
+// LDS rows are 128 B (64 bf16) and unpadded (the DMA writes 1 KiB = 8 rows per wave-instruction, lane-linear), so
+// bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS 16-byte slot `cpos` of row r holds
+// k-chunk cpos ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows covering all residues mod 16) then touches 16
+// distinct 4-bank quads.  Out-of-image taps and dummy taps read a 16-byte zero page instead of branching.
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(
     const bf16raw* __restrict__ in, const bf16raw* __restrict__ wgt, void* __restrict__ outp,
     const float* __restrict__ bias, const float* __restrict__ mscale, const float* __restrict__ mdiag,
-    float* __restrict__ stats, const tcvom_conv_desc d)
+    float* __restrict__ stats, const bf16raw* __restrict__ zero_page, const tcvom_conv_desc d)
 {
     constexpr int WAVES_N = TN / WN;
     constexpr int WAVES_M = TM / WM;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_IT = (TM * 4 + 255) / 256;
-    constexpr int B_IT = (TN * 4) / 256;
+    constexpr int A_IT = TM / 32;                      // DMA instructions per wave per k-step (8 rows each)
+    constexpr int B_IT = TN / 32;
+    constexpr int SLOT = (TM + TN) * 64;               // bf16 elements per ring slot
 
-    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * (TM + TN) * NT_LDS_STRIDE + 8 * TCVOM_MAX_TAPS];
-    bf16raw* As = lds;                                   // [2][TM][40]
-    bf16raw* Bs = lds + 2 * TM * NT_LDS_STRIDE;          // [2][TN][40]
-    int* taps = reinterpret_cast<int*>(lds + 2 * (TM + TN) * NT_LDS_STRIDE);   // [16][3]
+    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT + 8 * TCVOM_MAX_TAPS];
+    int* taps = reinterpret_cast<int*>(lds + 2 * SLOT);   // [16][3]: input offset, weight offset, validity bit
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     if (d.batch > 1) {
@@ -48,36 +52,49 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
         if (mscale) mscale += z * d.vec_bstride;
         if (mdiag) mdiag += z * d.vec_bstride;
     }
-    if (tid < TCVOM_MAX_TAPS) {
-        taps[tid * 3 + 0] = d.tap_dh[tid];
-        taps[tid * 3 + 1] = d.tap_dw[tid];
-        taps[tid * 3 + 2] = d.tap_w[tid];
-    }
     const int C = d.C, H = d.H, W = d.W, K = d.K, WT = d.wt;
+    if (tid < TCVOM_MAX_TAPS) {
+        const bool ok = tid < d.ntaps && d.tap_w[tid] >= 0;
+        taps[tid * 3 + 0] = (d.tap_dh[tid] * W + d.tap_dw[tid]) * C;
+        taps[tid * 3 + 1] = ok ? d.tap_w[tid] * C : -1;
+        taps[tid * 3 + 2] = ok ? 1 : 0;
+    }
     const int cshift = (d.ntaps == 1) ? 31 : __builtin_ctz(C);
     const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
     const int Ptot = d.N * d.PH * d.PW;
     const int p0 = blockIdx.x * TN;
     const int m0 = blockIdx.y * TM;
 
-    // per-thread pixel rows of the B tile (fixed for the whole reduction loop)
-    int b_ih0[B_IT], b_iw0[B_IT], b_nb[B_IT];
+    // this lane's k-chunk within a 64-deep step (same for all of its DMA instructions, see header comment)
+    const int kc8 = (((lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7)) << 3);
+
+    // per-thread rows: A rows (weights) and B rows (pixels) are fixed for the whole reduction loop
+    int a_off[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = m0 + (it * 4 + wave) * 8 + (lane >> 3);
+        a_off[it] = m < K ? m * WT * C : -1;
+    }
+    int b_off[B_IT];
+    unsigned b_valid[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int row = (tid + it * 256) >> 2;
-        const int p = p0 + row;
+        const int p = p0 + (it * 4 + wave) * 8 + (lane >> 3);
+        b_off[it] = 0;
+        b_valid[it] = 0u;
         if (p < Ptot) {
             const int j = p % d.PW;
             const int t = p / d.PW;
             const int i = t % d.PH;
             const int n = t / d.PH;
-            b_ih0[it] = i * d.in_step;
-            b_iw0[it] = j * d.in_step;
-            b_nb[it] = n * H;
-        } else {
-            b_ih0[it] = -(1 << 28);
-            b_iw0[it] = 0;
-            b_nb[it] = 0;
+            const int ih0 = i * d.in_step, iw0 = j * d.in_step;
+            b_off[it] = ((n * H + ih0) * W + iw0) * C;
+            unsigned msk = 0u;
+            for (int tp = 0; tp < d.ntaps; ++tp) {
+                const int ih = ih0 + d.tap_dh[tp], iw = iw0 + d.tap_dw[tp];
+                if (d.tap_w[tp] >= 0 && ih >= 0 && ih < H && iw >= 0 && iw < W) msk |= 1u << tp;
+            }
+            b_valid[it] = msk;
         }
     }
     __syncthreads();
@@ -90,78 +107,58 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nstage = (d.ntaps * C) >> 5;
-    uint4 areg[A_IT], breg[B_IT];
+    const int nstage = (d.ntaps * C) >> 6;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
 
-#define NT_LOAD_STAGE(s)                                                                        \
-    {                                                                                           \
-        _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                   \
-            const int q = tid + it * 256;                                                       \
-            const int row = q >> 2, kk = (s) * 32 + (q & 3) * 8;                                \
-            uint4 v = make_uint4(0, 0, 0, 0);                                                   \
-            if (TM * 4 >= 256 || q < TM * 4) {                                                  \
-                const int tap = kk >> cshift, c0 = kk & cmask;                                  \
-                const int ws = taps[tap * 3 + 2];                                               \
-                const int m = m0 + row;                                                         \
-                if (ws >= 0 && m < K)                                                           \
-                    v = *reinterpret_cast<const uint4*>(wgt + ((int64_t)m * WT + ws) * C + c0); \
-            }                                                                                   \
-            areg[it] = v;                                                                       \
-        }                                                                                       \
-        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                   \
-            const int q = tid + it * 256;                                                       \
-            const int kk = (s) * 32 + (q & 3) * 8;                                              \
-            const int tap = kk >> cshift, c0 = kk & cmask;                                      \
-            const int ih = b_ih0[it] + taps[tap * 3 + 0], iw = b_iw0[it] + taps[tap * 3 + 1];   \
-            uint4 v = make_uint4(0, 0, 0, 0);                                                   \
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W)                                         \
-                v = *reinterpret_cast<const uint4*>(in + ((int64_t)(b_nb[it] + ih) * W + iw) * C + c0); \
-            breg[it] = v;                                                                       \
-        }                                                                                       \
-    }
-#define NT_STORE_STAGE(buf)                                                                     \
-    {                                                                                           \
-        _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                   \
-            const int q = tid + it * 256;                                                       \
-            if (TM * 4 >= 256 || q < TM * 4)                                                    \
-                *reinterpret_cast<uint4*>(As + ((buf) * TM + (q >> 2)) * NT_LDS_STRIDE + (q & 3) * 8) = areg[it]; \
-        }                                                                                       \
-        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                   \
-            const int q = tid + it * 256;                                                       \
-            *reinterpret_cast<uint4*>(Bs + ((buf) * TN + (q >> 2)) * NT_LDS_STRIDE + (q & 3) * 8) = breg[it]; \
-        }                                                                                       \
+#define NT_ISSUE_STAGE(s, slot)                                                                            \
+    {                                                                                                      \
+        const int kk = (s) * 64 + kc8;                                                                     \
+        const int tap = kk >> cshift, c0 = kk & cmask;                                                     \
+        const int tin = taps[tap * 3 + 0], tw = taps[tap * 3 + 1];                                         \
+        bf16raw* abase = lds + (slot) * SLOT;                                                              \
+        _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                              \
+            const bf16raw* src = (a_off[it] >= 0 && tw >= 0) ? wgt + (a_off[it] + tw + c0) : zero_page;    \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (it * 4 + wave) * 512), 16, 0, 0); \
+        }                                                                                                  \
+        bf16raw* bbase = abase + TM * 64;                                                                  \
+        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                              \
+            const bf16raw* src = ((b_valid[it] >> tap) & 1u) ? in + ((int64_t)b_off[it] + tin + c0) : zero_page; \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + (it * 4 + wave) * 512), 16, 0, 0); \
+        }                                                                                                  \
     }
 
-    NT_LOAD_STAGE(0);
-    NT_STORE_STAGE(0);
-    __syncthreads();
+    // fragment read addressing: row r, k-chunk kch -> byte (r*128 + ((kch ^ ((r>>1)&7)) << 4)); (r>>1)&7 is the
+    // same for every 32-row fragment of this lane because fragment bases are multiples of 16 rows
+    const int a_row = wm * WM + (lane & 31), b_row = wn * WN + (lane & 31);
+    const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;
 
+    NT_ISSUE_STAGE(0, 0);
     for (int s = 0; s < nstage; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstage) NT_LOAD_STAGE(s + 1);
+        const int slot = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nstage) NT_ISSUE_STAGE(s + 1, slot ^ 1);
+        const bf16raw* As = lds + slot * SLOT;
+        const bf16raw* Bs = As + TM * 64;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 4; ++kk) {
             bf16x8_t af[MI], bfr[NI];
-            const int kofs = kk * 16 + (lane >> 5) * 8;
+            const int kch = kk * 2 + (lane >> 5);
 #pragma unroll
             for (int a = 0; a < MI; ++a)
-                af[a] = *reinterpret_cast<const bf16x8_t*>(
-                    As + (buf * TM + wm * WM + a * 32 + (lane & 31)) * NT_LDS_STRIDE + kofs);
+                af[a] = *reinterpret_cast<const bf16x8_t*>(As + (a_row + a * 32) * 64 + ((kch ^ a_swz) << 3));
 #pragma unroll
             for (int b = 0; b < NI; ++b)
-                bfr[b] = *reinterpret_cast<const bf16x8_t*>(
-                    Bs + (buf * TN + wn * WN + b * 32 + (lane & 31)) * NT_LDS_STRIDE + kofs);
+                bfr[b] = *reinterpret_cast<const bf16x8_t*>(Bs + (b_row + b * 32) * 64 + ((kch ^ b_swz) << 3));
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
-        if (s + 1 < nstage) NT_STORE_STAGE(buf ^ 1);
-        __syncthreads();
     }
-#undef NT_LOAD_STAGE
-#undef NT_STORE_STAGE
+#undef NT_ISSUE_STAGE
 
     // ------------------------------------------------------------------ epilogue
     int64_t out_off[NI];
@@ -244,6 +241,23 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
 // os16/os32 (8160 / 2040 pixels at 1080p) a 128x128 tiling yields only 64-128 workgroups for 256 CUs, so those
 // layers switch to 64x64 tiles (4x the workgroups, ~2.5x the co-resident workgroups per CU).
 struct NtCfg { int tm, tn, waves_n; };
+
+// 256 zero bytes per device: the source of every out-of-image / dummy tap (allocated once, on first use —
+// before any graph capture — and never freed; the only allocation the library ever makes)
+static const bf16raw* zero_page_for_current_device() {
+    static const bf16raw* pages[64] = {nullptr};
+    static std::mutex mtx;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(mtx);
+    if (!pages[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = (const bf16raw*)p;
+    }
+    return pages[dev];
+}
 static NtCfg nt_config(const tcvom_conv_desc* d) {
     const long long P = (long long)d->N * d->PH * d->PW;
     const int nb = d->batch > 1 ? d->batch : 1;
@@ -252,8 +266,8 @@ static NtCfg nt_config(const tcvom_conv_desc* d) {
         if (wgs < 512) return {64, 64, 2};
         return {128, 128, 2};
     }
-    if (d->K > 32) return {64, 256, 4};
-    return {32, 256, 4};
+    if (d->K > 32) return {64, 128, 2};
+    return {32, 128, 4};
 }
 
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d) {
@@ -267,7 +281,7 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
                                 const tcvom_conv_desc* d, void* stream) {
     TCVOM_CHECK_ARG(in && w && out && d, "conv_igemm: null pointer");
     TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "conv_igemm: ntaps=%d", d->ntaps);
-    TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 32 == 0, "conv_igemm: ntaps*C=%d not a multiple of 32", d->ntaps * d->C);
+    TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 64 == 0, "conv_igemm: ntaps*C=%d not a multiple of 64", d->ntaps * d->C);
     TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "conv_igemm: C=%d must be a power of two >= 8", d->C);
     TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
     TCVOM_CHECK_ARG(d->C % 8 == 0, "conv_igemm: C=%d must be a multiple of 8", d->C);
@@ -278,15 +292,19 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
     const bf16raw* ip = (const bf16raw*)in;
     const bf16raw* wp = (const bf16raw*)w;
     const NtCfg c = nt_config(d);
+    const bf16raw* zp = zero_page_for_current_device();
+    TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
+    TCVOM_CHECK_ARG((long long)d->N * d->H * d->W * d->C < (1ll << 31) && (long long)d->K * d->wt * d->C < (1ll << 31),
+                    "conv_igemm: operand too large for 32-bit element offsets");
     dim3 grid(cdiv(P, c.tn), cdiv(d->K, c.tm), nb);
     if (c.tm == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     else if (c.tm == 64 && c.tn == 64)
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
+        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     else if (c.tm == 64)
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 256, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
+        hipLaunchKernelGGL((igemm_nt_kernel<64, 128, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     else
-        hipLaunchKernelGGL((igemm_nt_kernel<32, 256, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, *d);
+        hipLaunchKernelGGL((igemm_nt_kernel<32, 128, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     TCVOM_LAUNCH_CHECK("conv_igemm");
     return TCVOM_OK;
 }

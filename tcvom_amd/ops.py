@@ -286,8 +286,8 @@ tam_attention = _TamAttention.apply
 # =============================================================================================
 # Guided contextual attention core:  (g8, alpha, unknown) -> fold(P V)/4
 # =============================================================================================
-def _r32(n):
-    return (n + 31) // 32 * 32
+def _r64(n):
+    return (n + 63) // 64 * 64
 
 
 class _GcaAttention(torch.autograd.Function):
@@ -299,7 +299,7 @@ class _GcaAttention(torch.autograd.Function):
         dev = g8.device
         st = L.stream_ptr()
         N = (h8 // 2) * (w8 // 2)
-        ld = _r32(N)
+        ld = _r64(N)
         D, DV = 9 * CG, 16 * Ca
         G = torch.empty((B, N, D), dtype=BF16, device=dev)
         scales = torch.empty((B, 2), dtype=torch.float32, device=dev)

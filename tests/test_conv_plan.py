@@ -29,7 +29,7 @@ def emulate(descs, x, wpack, out_shape):
                     oh, ow = i * d.out_step + d.out_off_h, j * d.out_step + d.out_off_w
                     out[n, oh, ow, :] = acc
                     written[n, oh, ow] += 1
-        assert (d.ntaps * d.C) % 32 == 0
+        assert (d.ntaps * d.C) % 64 == 0
     assert (written == 1).all(), 'every output pixel must be produced by exactly one phase'
     return out
 
@@ -70,5 +70,5 @@ def test_small_channel_inputs_are_padded_to_eight():
     spec = ConvSpec('stem', w, None, None, None, False, 2, 1, 'frame', needs_dgrad=False)
     geo = ConvGeometry(spec, 1, 8, 8)
     d = geo.fwd[0]
-    assert spec.cpad == 8 and d.C == 8 and d.ntaps == 12 and list(d.tap_w)[9:12] == [-1, -1, -1]
+    assert spec.cpad == 8 and d.C == 8 and d.ntaps == 16 and list(d.tap_w)[9:16] == [-1] * 7
     assert not geo.dgrad
