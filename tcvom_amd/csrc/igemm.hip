@@ -267,7 +267,7 @@ static NtCfg nt_config(const tcvom_conv_desc* d) {
         return {128, 128, 2};
     }
     if (d->K > 32) return {64, 128, 2};
-    return {32, 128, 4};
+    return {32, 256, 4};
 }
 
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d) {
@@ -304,7 +304,7 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
     else if (c.tm == 64)
         hipLaunchKernelGGL((igemm_nt_kernel<64, 128, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     else
-        hipLaunchKernelGGL((igemm_nt_kernel<32, 128, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
+        hipLaunchKernelGGL((igemm_nt_kernel<32, 256, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     TCVOM_LAUNCH_CHECK("conv_igemm");
     return TCVOM_OK;
 }

@@ -97,20 +97,30 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
     return act == 1 ? (pre > 0.f ? 1.f : 0.f) : (act == 2 ? (pre > 0.f ? 1.f : 0.2f) : 1.f);
 }
 
+// A block owns a contiguous pixel range; a thread owns ONE channel octet for the whole range (its 16 scale/shift
+// values live in registers) and walks the pixels with stride 256/C8: every access is a 16-byte load/store and
+// consecutive lanes cover consecutive 16-byte chunks of a pixel row.
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const uint4* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
-    int64_t nvec, int C8, int C, int act)
+    int64_t P, int C8, int C, int act, int rows_per_block)
 {
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(v % C8) * 8;
+    const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
+    if (prow >= RP) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale_shift[oct * 8 + k]; sh[k] = scale_shift[C + oct * 8 + k]; }
+    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
+    for (int64_t p = pbeg + prow; p < pend; p += RP) {
+        const int64_t v = p * C8 + oct;
         float f[8], r1[8], r2[8];
         unpack8(y[v], f);
         if (res1) unpack8(res1[v], r1);
         if (res2) unpack8(res2[v], r2);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float x = f[k] * scale_shift[c0 + k] + scale_shift[C + c0 + k];
+            float x = f[k] * sc[k] + sh[k];
             if (res1) x += r1[k];
             x = act_fwd(x, act);
             if (res2) x += r2[k];
@@ -213,28 +223,48 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
-    uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t nvec, int C8, int C, int act, int training, int in_relu)
+    uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
+    int rows_per_block)
 {
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(v % C8) * 8;
+    const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
+    if (prow >= RP) return;
+    float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], gi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = oct * 8 + k;
+        sc[k] = scale_shift[c]; sh[k] = scale_shift[C + c];
+        mu[k] = saved[c]; is[k] = saved[C + c];
+        c1[k] = training ? coef[c] : 0.f; c2[k] = training ? coef[C + c] : 0.f; gi[k] = coef[2 * C + c];
+    }
+    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
+    for (int64_t p = pbeg + prow; p < pend; p += RP) {
+        const int64_t v = p * C8 + oct;
         float g[8], yy[8], r1[8], o[8];
         unpack8(dz[v], g);
         unpack8(y[v], yy);
         if (res1) unpack8(res1[v], r1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int c = c0 + k;
-            float pre = yy[k] * scale_shift[c] + scale_shift[C + c];
+            float pre = yy[k] * sc[k] + sh[k];
             if (res1) pre += r1[k];
             const float gg = g[k] * act_grad(pre, act);
             g[k] = gg;
-            const float xh = (yy[k] - saved[c]) * saved[C + c];
-            o[k] = training ? coef[2 * C + c] * (gg - coef[c] - xh * coef[C + c]) : coef[2 * C + c] * gg;
+            const float xh = (yy[k] - mu[k]) * is[k];
+            o[k] = gi[k] * (gg - c1[k] - xh * c2[k]);
             if (in_relu && yy[k] <= 0.f) o[k] = 0.f;
         }
         dy[v] = pack8(o);
         if (dres1) dres1[v] = pack8(g);
     }
+}
+
+// pixel rows per block for the streaming BN kernels: ~8 loop iterations per thread, at most 8192 blocks
+static int bn_rows_per_block(int64_t pixels, int C) {
+    const int rp = 256 / (C / 8);
+    int64_t rows = (int64_t)rp * 8;
+    if ((pixels + rows - 1) / rows > 8192) rows = ((pixels + 8191) / 8192 + rp - 1) / rp * rp;
+    return (int)rows;
 }
 
 static int stream_grid(int64_t n, int per_block) {
@@ -277,18 +307,19 @@ extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* 
 extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
                               int64_t pixels, int32_t C, int32_t act, void* stream) {
     TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
-    const int64_t nvec = pixels * (C / 8);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, nvec, C / 8, C, act);
+    TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_apply: C=%d must be a power of two <= 2048", C);
+    const int rpb = bn_rows_per_block(pixels, C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb);
     TCVOM_LAUNCH_CHECK("bn_apply");
     return TCVOM_OK;
 }
 
 extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
     const int rows = 256 / (C / 8);
-    int64_t per = (int64_t)rows * 32;               // >= 32 loop iterations per block
+    int64_t per = (int64_t)rows * 8;                // >= 8 loop iterations per thread
     int64_t g = (pixels + per - 1) / per;
-    if (g > 2048) g = 2048;
+    if (g > 4096) g = 4096;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -321,10 +352,11 @@ extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                                   int32_t C, int32_t act, int32_t training, int32_t in_relu, void* stream) {
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
-    const int64_t nvec = pixels * (C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(nvec, 256)), dim3(256), 0, (hipStream_t)stream,
+    TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_bwd_apply: C=%d must be a power of two <= 2048", C);
+    const int rpb = bn_rows_per_block(pixels, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)dz, (const uint4*)y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                       (uint4*)dres1, nvec, C / 8, C, act, training, in_relu);
+                       (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb);
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
 }
