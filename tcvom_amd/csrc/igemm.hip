@@ -13,7 +13,6 @@
 #include "common.h"
 #include <mutex>
 
-#define TT_LDS_STRIDE 72   // bf16 elements per LDS row in igemm_tt (64 + 8 pad)
 
 // igemm_nt main loop (v2): 64-deep k-steps, operands DMA'd global->LDS with global_load_lds_dwordx4
 // (no VGPR round trip), 2-slot LDS ring, ONE barrier per k-step:
@@ -313,41 +312,49 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
 // igemm_tt: weight gradient / dense TT GEMM.
 //   columns of the B operand are (tap, c) pairs: col = t*C + c  ->  dw[(m*WT + wslot[t])*C + c]
 // =====================================================================================
-__device__ __forceinline__ void transpose8x8_store(const uint4* rows, bf16raw* dst /* &X[ch0][pix0] */) {
-    // rows[p] = 8 channels of pixel p (4 dwords); write 8 LDS rows (one per channel) of 8 pixels.
-    const unsigned* rw = reinterpret_cast<const unsigned*>(rows);   // rw[p*4 + d]
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-        uint4 ev, od;
-        unsigned* e = reinterpret_cast<unsigned*>(&ev);
-        unsigned* o = reinterpret_cast<unsigned*>(&od);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned lo = rw[(2 * q) * 4 + dd], hi = rw[(2 * q + 1) * 4 + dd];
-            e[q] = (lo & 0xffffu) | (hi << 16);
-            o[q] = (lo >> 16) | (hi & 0xffff0000u);
-        }
-        *reinterpret_cast<uint4*>(dst + (2 * dd) * TT_LDS_STRIDE) = ev;
-        *reinterpret_cast<uint4*>(dst + (2 * dd + 1) * TT_LDS_STRIDE) = od;
-    }
+// v2: both operand tiles are DMA'd pixel-major ([64 pixels][channels], global_load_lds_dwordx4, no VGPR staging)
+// and the k-contiguous MFMA fragments are produced by the gfx950 LDS transpose read ds_read_b64_tr_b16
+// (measured semantics, tools/probes/tr_probe.hip: in a 16-lane group lane i loads 4 consecutive bf16 from ITS OWN
+// address; lane l then receives element (l & 3) of the loads of lanes 4e + (l >> 2), e = 0..3).  Pointing lane i
+// at row k0 + (i >> 2), columns c0 + 4 (i & 3) .. +3 of a [k][c] tile gives lane l the 4 k-values of column c0 + l.
+// Bank conflicts between the 4 rows of such a read are removed by XOR-ing the 64-byte column group with the row
+// (source-side swizzle, the DMA destination stays lane-linear).
+template <int TC>
+struct TtTile {                                  // geometry of a [64 pixels][TC columns] bf16 LDS tile
+    static constexpr int LPR = TC / 8;           // 16-byte slots (= DMA lanes) per pixel row
+    static constexpr int RPI = 64 / LPR;         // pixel rows per DMA wave-instruction (1 KiB)
+    static constexpr int NI = 64 / RPI;          // DMA instructions per 64-pixel stage
+    static constexpr int IT = (NI + 3) / 4;      // ... per wave
+    static constexpr int G = (TC * 2) / 64 > 0 ? (TC * 2) / 64 : 1;   // 64-byte column groups per row
+    static constexpr int RPL = 256 / (TC * 2) > 0 ? 256 / (TC * 2) : 1;   // rows per 256-byte bank line
+    __device__ static __forceinline__ int swz(int row) { return (row / RPL) % G; }
+};
+
+__device__ __forceinline__ bf16x8_t tr_read8(const bf16raw* p_lo, const bf16raw* p_hi) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_lo);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 template <int TM, int TN, int WM, int WN, int KS>
 __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const bf16raw* __restrict__ dy, const bf16raw* __restrict__ in, float* __restrict__ dw,
-    const tcvom_conv_desc d, const int ldy, const int pchunk)
+    const bf16raw* __restrict__ zero_page, const tcvom_conv_desc d, const int ldy, const int pchunk)
 {
     constexpr int WAVES_M = TM / WM, WAVES_N = TN / WN;
     static_assert(WAVES_M * WAVES_N * KS == 4, "4 waves per workgroup");
-    static_assert(TM + TN <= 256, "one loader task per thread");
     constexpr int MI = WM / 32, NI = WN / 32;
+    typedef TtTile<TM> TA;
+    typedef TtTile<TN> TB;
+    constexpr int SLOT = 64 * (TM + TN);
 
-    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * (TM + TN) * TT_LDS_STRIDE + 8 * TCVOM_MAX_TAPS];
-    bf16raw* As = lds;                                  // [2][TM][72]
-    bf16raw* Bs = lds + 2 * TM * TT_LDS_STRIDE;         // [2][TN][72]
-    int* taps = reinterpret_cast<int*>(lds + 2 * (TM + TN) * TT_LDS_STRIDE);
+    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT + 8 * TCVOM_MAX_TAPS];
+    int* taps = reinterpret_cast<int*>(lds + 2 * SLOT);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave / (WAVES_M * WAVES_N);
     const int wmn = wave % (WAVES_M * WAVES_N);
     const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
@@ -368,25 +375,46 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const int pend = min(Ptot, pbeg + pchunk);
     const int n0 = blockIdx.y * TN;
     const int m0 = blockIdx.z * TM;
+    const int PW = d.PW, PH = d.PH;
 
-    // loader role of this thread
-    const bool isA = tid < TM;
-    const bool isB = !isA && tid < TM + TN;
-    const int lt = isA ? tid : tid - TM;
-    const int po = lt & 7, co = lt >> 3;
-    int tdh = 0, tdw = 0, c0 = 0;
-    bool colok = false;
-    if (isA) {
-        colok = (m0 + co * 8 + 8) <= ldy;
-    } else if (isB) {
-        const int col = n0 + co * 8;
-        if (col < ncols) {
+    // ---- per-lane DMA state: A = dy tile [64][TM], B = gathered input tile [64][TN]
+    int a_col[TA::IT], a_n[TA::IT], a_i[TA::IT], a_j[TA::IT];
+    bool a_ok[TA::IT];
+#pragma unroll
+    for (int it = 0; it < TA::IT; ++it) {
+        const int ii = it * 4 + wave;
+        const int row = ii * TA::RPI + lane / TA::LPR;
+        const int cs = (lane % TA::LPR) ^ (TA::swz(row) << 2);
+        a_col[it] = m0 + cs * 8;
+        a_ok[it] = ii < TA::NI && (a_col[it] + 8) <= ldy;
+        const int p = pbeg + row;
+        a_j[it] = p % PW;
+        const int t = p / PW;
+        a_i[it] = t % PH;
+        a_n[it] = t / PH;
+    }
+    int b_c0[TB::IT], b_dh[TB::IT], b_dw[TB::IT], b_n[TB::IT], b_i[TB::IT], b_j[TB::IT];
+    bool b_ok[TB::IT];
+#pragma unroll
+    for (int it = 0; it < TB::IT; ++it) {
+        const int ii = it * 4 + wave;
+        const int row = ii * TB::RPI + lane / TB::LPR;
+        const int cs = (lane % TB::LPR) ^ (TB::swz(row) << 2);
+        const int col = n0 + cs * 8;
+        b_ok[it] = false;
+        b_c0[it] = b_dh[it] = b_dw[it] = 0;
+        if (ii < TB::NI && col < ncols) {
             const int tap = col >> cshift;
-            c0 = col & cmask;
-            tdh = taps[tap * 3 + 0];
-            tdw = taps[tap * 3 + 1];
-            colok = taps[tap * 3 + 2] >= 0;
+            b_c0[it] = col & cmask;
+            b_dh[it] = taps[tap * 3 + 0];
+            b_dw[it] = taps[tap * 3 + 1];
+            b_ok[it] = taps[tap * 3 + 2] >= 0;
         }
+        const int p = pbeg + row;
+        b_j[it] = p % PW;
+        const int t = p / PW;
+        b_i[it] = t % PH;
+        b_n[it] = t / PH;
     }
 
     f32x16_t acc[MI][NI];
@@ -397,72 +425,82 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    uint4 rows[8];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     const int nstage = (pend - pbeg + 63) >> 6;
 
-#define TT_LOAD_STAGE(s)                                                                         \
-    {                                                                                            \
-        int p = pbeg + (s) * 64 + po * 8;                                                        \
-        int j = p % d.PW;                                                                        \
-        int tq = p / d.PW;                                                                       \
-        int i = tq % d.PH;                                                                       \
-        int n = tq / d.PH;                                                                       \
-        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp) {                                       \
-            uint4 v = make_uint4(0, 0, 0, 0);                                                    \
-            if (colok && p < pend) {                                                             \
-                if (isA) {                                                                       \
-                    const int64_t off = ((int64_t)(n * d.OH + i * d.out_step + d.out_off_h) * d.OW \
-                                         + j * d.out_step + d.out_off_w) * ldy + m0 + co * 8;    \
-                    v = *reinterpret_cast<const uint4*>(dy + off);                               \
-                } else if (isB) {                                                                \
-                    const int ih = i * d.in_step + tdh, iw = j * d.in_step + tdw;                \
-                    if (ih >= 0 && ih < H && iw >= 0 && iw < W)                                  \
-                        v = *reinterpret_cast<const uint4*>(in + ((int64_t)(n * H + ih) * W + iw) * C + c0); \
-                }                                                                                \
-            }                                                                                    \
-            rows[pp] = v;                                                                        \
-            ++p; ++j;                                                                            \
-            if (j == d.PW) { j = 0; ++i; if (i == d.PH) { i = 0; ++n; } }                        \
-        }                                                                                        \
-    }
-#define TT_STORE_STAGE(buf)                                                                      \
-    {                                                                                            \
-        if (isA) transpose8x8_store(rows, As + ((buf) * TM + co * 8) * TT_LDS_STRIDE + po * 8);  \
-        else if (isB) transpose8x8_store(rows, Bs + ((buf) * TN + co * 8) * TT_LDS_STRIDE + po * 8); \
+    // issue the DMA of stage s (pixels pbeg + 64 s ...) into ring slot `slot`, then advance the pixel counters
+#define TT_ISSUE_STAGE(s, slot)                                                                                  \
+    {                                                                                                            \
+        bf16raw* abase = lds + (slot) * SLOT;                                                                    \
+        _Pragma("unroll") for (int it = 0; it < TA::IT; ++it) {                                                  \
+            const int ii = it * 4 + wave;                                                                        \
+            if (ii < TA::NI) {                                                                                   \
+                const int p = pbeg + (s) * 64 + ii * TA::RPI + lane / TA::LPR;                                   \
+                const bf16raw* src = zero_page;                                                                  \
+                if (a_ok[it] && p < pend)                                                                        \
+                    src = dy + ((int64_t)(a_n[it] * d.OH + a_i[it] * d.out_step + d.out_off_h) * d.OW            \
+                                + a_j[it] * d.out_step + d.out_off_w) * ldy + a_col[it];                         \
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + ii * 512), 16, 0, 0);             \
+                a_j[it] += 64;                                                                                   \
+                while (a_j[it] >= PW) { a_j[it] -= PW; if (++a_i[it] == PH) { a_i[it] = 0; ++a_n[it]; } }        \
+            }                                                                                                    \
+        }                                                                                                        \
+        bf16raw* bbase = abase + 64 * TM;                                                                        \
+        _Pragma("unroll") for (int it = 0; it < TB::IT; ++it) {                                                  \
+            const int ii = it * 4 + wave;                                                                        \
+            if (ii < TB::NI) {                                                                                   \
+                const int p = pbeg + (s) * 64 + ii * TB::RPI + lane / TB::LPR;                                   \
+                const int ih = b_i[it] * d.in_step + b_dh[it], iw = b_j[it] * d.in_step + b_dw[it];              \
+                const bf16raw* src = zero_page;                                                                  \
+                if (b_ok[it] && p < pend && ih >= 0 && ih < H && iw >= 0 && iw < W)                              \
+                    src = in + ((int64_t)(b_n[it] * H + ih) * W + iw) * C + b_c0[it];                            \
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + ii * 512), 16, 0, 0);             \
+                b_j[it] += 64;                                                                                   \
+                while (b_j[it] >= PW) { b_j[it] -= PW; if (++b_i[it] == PH) { b_i[it] = 0; ++b_n[it]; } }        \
+            }                                                                                                    \
+        }                                                                                                        \
     }
 
-    if (nstage > 0) {
-        TT_LOAD_STAGE(0);
-        TT_STORE_STAGE(0);
-    }
-    __syncthreads();
+    // ---- transpose-read addressing (element offsets inside a tile), constant over the reduction loop
+    const int tr_krow = (lane >> 5) * 8 + ((lane & 15) >> 2);          // + ks*16 + h*4
+    const int tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;        // + wave/fragment column base
+
+    if (nstage > 0) TT_ISSUE_STAGE(0, 0);
     for (int s = 0; s < nstage; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstage) TT_LOAD_STAGE(s + 1);
+        const int slot = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < nstage) TT_ISSUE_STAGE(s + 1, slot ^ 1);
+        const bf16raw* As = lds + slot * SLOT;
+        const bf16raw* Bs = As + 64 * TM;
 #pragma unroll
         for (int kq = 0; kq < 4 / KS; ++kq) {
             const int ks = (KS == 1) ? kq : wk;
-            const int kofs = ks * 16 + (lane >> 5) * 8;
             bf16x8_t af[MI], bfr[NI];
+            const int r0 = ks * 16 + tr_krow, r1 = r0 + 4;
 #pragma unroll
-            for (int a = 0; a < MI; ++a)
-                af[a] = *reinterpret_cast<const bf16x8_t*>(
-                    As + (buf * TM + wm * WM + a * 32 + (lane & 31)) * TT_LDS_STRIDE + kofs);
+            for (int a = 0; a < MI; ++a) {
+                const int col = wm * WM + a * 32 + tr_col;
+                const int sl = col >> 3, e = col & 7;
+                af[a] = tr_read8(As + r0 * TM + ((sl ^ (TA::swz(r0) << 2)) << 3) + e,
+                                 As + r1 * TM + ((sl ^ (TA::swz(r1) << 2)) << 3) + e);
+            }
 #pragma unroll
-            for (int b = 0; b < NI; ++b)
-                bfr[b] = *reinterpret_cast<const bf16x8_t*>(
-                    Bs + (buf * TN + wn * WN + b * 32 + (lane & 31)) * TT_LDS_STRIDE + kofs);
+            for (int b = 0; b < NI; ++b) {
+                const int col = wn * WN + b * 32 + tr_col;
+                const int sl = col >> 3, e = col & 7;
+                bfr[b] = tr_read8(Bs + r0 * TN + ((sl ^ (TB::swz(r0) << 2)) << 3) + e,
+                                  Bs + r1 * TN + ((sl ^ (TB::swz(r1) << 2)) << 3) + e);
+            }
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
-        if (s + 1 < nstage) TT_STORE_STAGE(buf ^ 1);
-        __syncthreads();
     }
-#undef TT_LOAD_STAGE
-#undef TT_STORE_STAGE
+#undef TT_ISSUE_STAGE
 
 #pragma unroll
     for (int b = 0; b < NI; ++b) {
@@ -492,6 +530,8 @@ extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, cons
     TCVOM_CHECK_ARG(P > 0 && P < (1ll << 31), "wgrad_igemm: bad pixel count %lld", P);
     hipStream_t st = (hipStream_t)stream;
     const int ncols = d->ntaps * d->C;
+    const bf16raw* zp = zero_page_for_current_device();
+    TCVOM_CHECK_ARG(zp != nullptr, "wgrad_igemm: could not allocate the zero page");
     const bf16raw* a = (const bf16raw*)dy;
     const bf16raw* b = (const bf16raw*)in;
     // tile: wide-N tiles for the small-channel layers so that dy is re-read ncols/128 (not ncols/32) times
@@ -509,15 +549,15 @@ extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, cons
     const int chunks = cdiv(P, pchunk);
     dim3 grid(chunks, nt, mt);
     if (tm == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 64, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
     else if (tm == 64 && tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 64, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
     else if (tm == 64)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
     else if (tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
     else
-        hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, a, b, dw, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
     TCVOM_LAUNCH_CHECK("wgrad_igemm");
     return TCVOM_OK;
 }
