@@ -61,10 +61,26 @@ def igemm_profile(step_fn):
         real_taps = sum(1 for t in range(desc['ntaps']) if desc['tap_w'][t] >= 0)
         gflop = 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
         if name == 'tcvom_conv_igemm':
-            var = 'igemm_nt<128,128>' if desc['K'] >= 128 else ('igemm_nt<64,256>' if desc['K'] > 32 else 'igemm_nt<32,256>')
+            # same selection as nt_config() in tcvom_amd/csrc/igemm.hip
+            if desc['K'] >= 128:
+                nb = max(desc['batch'], 1)
+                cd = lambda a, b: (a + b - 1) // b
+                if cd(desc['P'], 128) * cd(desc['K'], 128) * nb >= 512:
+                    var = 'igemm_nt<128,128,64,64>'
+                elif cd(desc['P'], 64) * cd(desc['K'], 128) * nb >= 400:
+                    var = 'igemm_nt<128,64,64,32>'
+                else:
+                    var = 'igemm_nt<64,64,32,32>'
+            else:
+                var = 'igemm_nt<64,128,32,64>' if desc['K'] > 32 else 'igemm_nt<32,256,32,64>'
         else:
             ncols = desc['ntaps'] * desc['C']
-            var = 'igemm_tt<128,128>' if (desc['K'] >= 128 and ncols >= 128) else ('igemm_tt<64,64>' if desc['K'] > 32 else 'igemm_tt<32,32>')
+            if desc['K'] >= 128 and ncols >= 128:
+                var = 'igemm_tt<128,128,64,64>'
+            elif desc['K'] > 32:
+                var = 'igemm_tt<64,128,32,64>' if ncols >= 128 else 'igemm_tt<64,64,32,32>'
+            else:
+                var = 'igemm_tt<32,128,32,32>' if ncols >= 128 else 'igemm_tt<32,32,32,32>'
         n, t, g = agg.get(var, (0, 0.0, 0.0))
         agg[var] = (n + 1, t + ms, g + gflop)
     return agg
@@ -154,7 +170,7 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     result = None
     if rank == 0:

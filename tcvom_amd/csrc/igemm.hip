@@ -61,7 +61,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     const int cshift = (d.ntaps == 1) ? 31 : __builtin_ctz(C);
     const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
     const int Ptot = d.N * d.PH * d.PW;
-    const int p0 = blockIdx.x * TN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed, speed only); give every XCD a contiguous run
+    // of pixel tiles so that the 3x3 halo rows shared by neighbouring tiles are served by ONE L2 (bijective for any
+    // grid size)
+    int bx;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int p0 = bx * TN;
     const int m0 = blockIdx.y * TM;
 
     // this lane's k-chunk within a 64-deep step (same for all of its DMA instructions, see header comment)
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
                     }
                 }
                 if ((lane & 31) == 0 && mrow < K) {
-                    const int64_t grp = d.stats_group_offset + (int64_t)blockIdx.x * WAVES_N + wn;
+                    const int64_t grp = d.stats_group_offset + (int64_t)bx * WAVES_N + wn;
                     float* sp = stats + grp * 2 * K;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -262,8 +270,9 @@ static NtCfg nt_config(const tcvom_conv_desc* d) {
     const int nb = d->batch > 1 ? d->batch : 1;
     if (d->K >= 128) {
         const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
-        if (wgs < 512) return {64, 64, 2};
-        return {128, 128, 2};
+        if (wgs >= 512) return {128, 128, 2};
+        if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
+        return {64, 64, 2};
     }
     if (d->K > 32) return {64, 128, 2};
     return {32, 256, 4};
@@ -296,8 +305,10 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
     TCVOM_CHECK_ARG((long long)d->N * d->H * d->W * d->C < (1ll << 31) && (long long)d->K * d->wt * d->C < (1ll << 31),
                     "conv_igemm: operand too large for 32-bit element offsets");
     dim3 grid(cdiv(P, c.tn), cdiv(d->K, c.tm), nb);
-    if (c.tm == 128)
+    if (c.tm == 128 && c.tn == 128)
         hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
+    else if (c.tm == 128)
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 64, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     else if (c.tm == 64 && c.tn == 64)
         hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
     else if (c.tm == 64)

@@ -319,7 +319,7 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
     const int rows = 256 / (C / 8);
     int64_t per = (int64_t)rows * 8;                // >= 8 loop iterations per thread
     int64_t g = (pixels + per - 1) / per;
-    if (g > 4096) g = 4096;
+    if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     return (int)g;
 }

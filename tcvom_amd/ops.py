@@ -92,7 +92,7 @@ class _ConvBNAct(torch.autograd.Function):
             L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
                    L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
-            bn.num_batches_tracked += 1
+            bank.pending_bn.append(bn)          # num_batches_tracked is bumped once per window (one foreach launch)
         else:
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), L.ptr(ss), L.ptr(saved), st)

@@ -92,6 +92,7 @@ class VMN(nn.Module):
         for i in range(1, S - 1):
             preds[i], attb[i], attf[i] = self.decoder.run_tail(feats[i], feats[i - 1], feats[i + 1], unk_u8[i],
                                                                mids[i], token, training)
+        self._bank.flush_bn_counters()
         return preds, attb, attf
 
     def forward(self, images, masks, extras=None):

@@ -55,6 +55,22 @@ class WeightBank(object):
         self._ptr_sig = None
         self._plans = {}
         self.max_calls = 0
+        self.pending_bn = []
+
+    def flush_bn_counters(self):
+        """nn.BatchNorm2d.num_batches_tracked += (number of train-mode calls since the last flush), batched."""
+        if not self.pending_bn:
+            return
+        counts = {}
+        for bn in self.pending_bn:
+            counts[id(bn)] = (bn, counts.get(id(bn), (bn, 0))[1] + 1)
+        self.pending_bn = []
+        by_n = {}
+        for bn, n in counts.values():
+            by_n.setdefault(n, []).append(bn.num_batches_tracked)
+        with torch.no_grad():
+            for n, bufs in by_n.items():
+                torch._foreach_add_(bufs, n)
 
     # ------------------------------------------------------------------ registration
     def register(self, spec):
@@ -178,6 +194,7 @@ class WeightBank(object):
     def prepare(self, frames, training):
         """Run every power iteration of this window and write the packed weights.  Returns the plan."""
         dev = self.specs[0].weight.device
+        self.flush_bn_counters()
         if self._ptr_sig is None or self._ptr_sig != self._signature():
             self._build(dev)
         plan = self._plan(frames, training)
