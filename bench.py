@@ -86,7 +86,7 @@ def igemm_profile(step_fn):
     return agg
 
 
-def cpu_baseline(sample_hw=(384, 640), max_threads=32):
+def cpu_baseline(sample_hw=(544, 960), max_threads=32):
     """The oracle (pure PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host
     cores on ONE bounded sample window, scaled to 1080p windows/s by the algorithmic-FLOP ratio."""
     import oracle

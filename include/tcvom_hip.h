@@ -88,6 +88,9 @@ int tcvom_bn_finalize(const float* stats_partial, int32_t groups, int32_t C, int
                       float momentum, float eps, float* scale_shift /*[2][C]*/, float* saved /*[2][C] mean,invstd*/,
                       double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */, void* stream);
 int tcvom_bn_finalize_scratch_doubles(int32_t C);
+/* running_mean/var EMA from the (mean, invstd) a train-mode tcvom_bn_finalize(running_mean=NULL) call saved */
+int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_var, int32_t C, float momentum,
+                        float eps, int64_t unbias_count, void* stream);
 int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,

@@ -60,6 +60,7 @@ _PROTOS = {
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
     'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp],
     'tcvom_bn_finalize_scratch_doubles': [i32],
+    'tcvom_bn_ema_update': [vp, vp, vp, i32, f32, f32, i64, vp],
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, vp],
     'tcvom_bn_bwd_groups': [i64, i32],

@@ -295,6 +295,30 @@ extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C
 /* doubles of scratch tcvom_bn_finalize needs for C channels */
 extern "C" int tcvom_bn_finalize_scratch_doubles(int32_t C) { return BN_SLICES * 2 * C; }
 
+// Deferred running-statistics update (momentum EMA with the unbiased variance), from the (mean, invstd) a train-mode
+// call saved.  Frames of a window run on concurrent streams, so the EMA of the S calls of one BatchNorm is applied
+// afterwards, in call order, instead of inside bn_finalize.
+__global__ void bn_ema_kernel(const float* __restrict__ saved, float* __restrict__ rm, float* __restrict__ rv, int C,
+                              float momentum, float eps, double unbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = saved[c], invstd = saved[C + c];
+    double var = 1.0 / ((double)invstd * (double)invstd) - (double)eps;
+    if (var < 0.0) var = 0.0;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * unbias);
+}
+
+extern "C" int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_var, int32_t C, float momentum,
+                                   float eps, int64_t unbias_count, void* stream) {
+    TCVOM_CHECK_ARG(saved && running_mean && running_var && C > 0 && unbias_count > 0, "bn_ema_update: bad args");
+    const double ub = unbias_count > 1 ? (double)unbias_count / (double)(unbias_count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_ema_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, saved, running_mean, running_var,
+                       C, momentum, eps, ub);
+    TCVOM_LAUNCH_CHECK("bn_ema_update");
+    return TCVOM_OK;
+}
+
 extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, float* scale_shift, float* saved, void* stream) {
     TCVOM_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && saved && C > 0, "bn_eval_coeffs: bad args");

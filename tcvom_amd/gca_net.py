@@ -104,6 +104,7 @@ class GuidedCxtAtten(nn.Module):
         if unknown is None:
             unknown = torch.ones_like(alpha[:, :1])
         y, scales = self.run(to_nhwc(f), to_nhwc(alpha), (unknown[:, 0] != 0).to(torch.uint8).contiguous(), token, training)
+        self._bank.flush_bn_counters()
         return y.permute(0, 3, 1, 2).float(), (None, scales)
 
 

@@ -90,9 +90,11 @@ class _ConvBNAct(torch.autograd.Function):
             groups = stats.numel() // (2 * K)
             scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 512 else None
             L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
-                   L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                   L.ptr(gamma), L.ptr(beta), None, None,
                    float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
-            bank.pending_bn.append(bn)          # num_batches_tracked is bumped once per window (one foreach launch)
+            # running statistics / num_batches_tracked are updated after the window, in call order (frames run on
+            # concurrent streams; the EMA is order dependent)
+            bank.pending_bn.append((bn, saved, P * cfg.unbias_mult))
         else:
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), L.ptr(ss), L.ptr(saved), st)

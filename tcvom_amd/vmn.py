@@ -68,7 +68,9 @@ class VMN(nn.Module):
         self.encoder = encoder
         self.decoder = decoder
         self.freeze_backbone = freeze_backbone
+        self.frame_streams = True
         object.__setattr__(self, '_bank', bank)
+        object.__setattr__(self, '_streams', [])
 
     def train(self, mode=True):
         super().train(mode)
@@ -84,10 +86,27 @@ class VMN(nn.Module):
         training = self.training
         token = bank_token(self._bank, S, training)
         mids, feats = [None] * S, [None] * S
-        for i in range(S):                                   # per frame, NOT batched over frames (:93-98)
-            emb, mid = self.encoder.run(frames_x8[i], unk_u8[i], token, training)
-            mids[i] = mid
-            feats[i] = self.decoder.run_front(emb, mid, token, training)
+        # The encoder + decoder-front of the S frames are independent (VMN_model.py:93-98 loops over them): each frame
+        # runs on its own HIP stream so that the small-grid os16/os32 kernels of different frames overlap; autograd
+        # replays the same streams in backward.  Order-dependent state (BN running statistics) is applied afterwards.
+        main = torch.cuda.current_stream()
+        if self.frame_streams:
+            if len(self._streams) < S:
+                object.__setattr__(self, '_streams', [torch.cuda.Stream() for _ in range(S)])
+            for i in range(S):
+                st = self._streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    emb, mids[i] = self.encoder.run(frames_x8[i], unk_u8[i], token, training)
+                    feats[i] = self.decoder.run_front(emb, mids[i], token, training)
+            for i in range(S):
+                main.wait_stream(self._streams[i])
+                for t in (feats[i], mids[i]['image_fea']) + tuple(mids[i]['shortcut']):
+                    t.record_stream(main)
+        else:
+            for i in range(S):
+                emb, mids[i] = self.encoder.run(frames_x8[i], unk_u8[i], token, training)
+                feats[i] = self.decoder.run_front(emb, mids[i], token, training)
         preds, attb, attf = [None] * S, [None] * S, [None] * S
         for i in range(1, S - 1):
             preds[i], attb[i], attf[i] = self.decoder.run_tail(feats[i], feats[i - 1], feats[i + 1], unk_u8[i],

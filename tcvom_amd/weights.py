@@ -58,13 +58,17 @@ class WeightBank(object):
         self.pending_bn = []
 
     def flush_bn_counters(self):
-        """nn.BatchNorm2d.num_batches_tracked += (number of train-mode calls since the last flush), batched."""
+        """Apply the deferred BatchNorm state updates of the train-mode calls since the last flush, in call order:
+        running_mean/var EMA (one tiny launch per call) and num_batches_tracked (one foreach launch)."""
         if not self.pending_bn:
             return
+        pend, self.pending_bn = self.pending_bn, []
+        st = L.stream_ptr()
         counts = {}
-        for bn in self.pending_bn:
+        for bn, saved, ub in pend:
+            L.call('tcvom_bn_ema_update', L.ptr(saved), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                   bn.num_features, float(bn.momentum), float(bn.eps), int(ub), st)
             counts[id(bn)] = (bn, counts.get(id(bn), (bn, 0))[1] + 1)
-        self.pending_bn = []
         by_n = {}
         for bn, n in counts.values():
             by_n.setdefault(n, []).append(bn.num_batches_tracked)

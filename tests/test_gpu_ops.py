@@ -135,6 +135,7 @@ def test_conv_bn_act_train(act, pre_relu, res):
     r2g = nhwc(r2).requires_grad_(True) if r2 is not None else None
     token = bank_token(bank, 1, True)
     z = ops.conv_bn_act(cfg, xg, token, True, res1=r1g, res2=r2g)
+    bank.flush_bn_counters()            # running statistics are applied after the window (deferred, in call order)
 
     xr = bf(x).requires_grad_(True)
     wr = bf(spec.weight.detach().cpu()).requires_grad_(True)
