@@ -60,10 +60,10 @@ def igemm_profile(step_fn):
         ms = e0.elapsed_time(e1)
         real_taps = sum(1 for t in range(desc['ntaps']) if desc['tap_w'][t] >= 0)
         gflop = 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
-        if name == 'tcvom_conv_igemm':
+        if name.startswith('tcvom_conv_igemm'):
             # same selection as nt_config() in tcvom_amd/csrc/igemm.hip
             if desc['K'] >= 128:
-                nb = max(desc['batch'], 1)
+                nb = max(desc['batch'], 1) * desc.get('phases', 1)
                 cd = lambda a, b: (a + b - 1) // b
                 if cd(desc['P'], 128) * cd(desc['K'], 128) * nb >= 512:
                     var = 'igemm_nt<128,128,64,64>'

@@ -67,8 +67,12 @@ typedef struct {
 int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias,
                      const float* mscale, const float* mdiag, float* stats_partial,
                      const tcvom_conv_desc* d, void* stream);
-/* number of statistics groups one launch of `d` writes (64 output pixels each) */
-int tcvom_conv_stats_groups(const tcvom_conv_desc* d);
+/* The same for up to 4 phases (sub-pixel phases of a ConvTranspose2d / stride-2 data gradient) in ONE launch;
+ * descs[i].stats_group_offset must be i * tcvom_conv_stats_groups(descs, nphase). */
+int tcvom_conv_igemm_phases(const void* in, const void* w, void* out, const float* bias, float* stats_partial,
+                            const tcvom_conv_desc* descs, int32_t nphase, void* stream);
+/* number of statistics groups ONE phase of a launch of `nphase` phases like `d` writes */
+int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase);
 
 /* Weight gradient of the same phase (reduction over pixels, both operands pixel-major):
  *   dw[k][wslot[t]][c] += sum_{n,i,j} dy[n, out pixel(i,j), k] * in[n, i*in_step+dh[t], j*in_step+dw[t], c]
@@ -76,6 +80,8 @@ int tcvom_conv_stats_groups(const tcvom_conv_desc* d);
  * ntaps==1 this is the dense "both operands k-major" GEMM used by the GCA backward. */
 int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_conv_desc* d,
                       int32_t ldy, void* stream);
+int tcvom_wgrad_igemm_phases(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs,
+                             int32_t nphase, int32_t ldy, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm around the convs
  * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks

@@ -56,7 +56,9 @@ SP = C.POINTER(SnScratch)
 # name -> argtypes (all return int except the explicitly listed ones)
 _PROTOS = {
     'tcvom_conv_igemm': [vp, vp, vp, vp, vp, vp, vp, DP, vp],
-    'tcvom_conv_stats_groups': [DP],
+    'tcvom_conv_stats_groups': [DP, i32],
+    'tcvom_conv_igemm_phases': [vp, vp, vp, vp, vp, DP, i32, vp],
+    'tcvom_wgrad_igemm_phases': [vp, vp, vp, DP, i32, i32, vp],
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
     'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp],
     'tcvom_bn_finalize_scratch_doubles': [i32],
@@ -131,8 +133,15 @@ PROFILE = None   # bench.py sets this to a list to bracket every igemm launch wi
 
 def _profiled(name, args):
     import torch
-    d = args[7 if name == 'tcvom_conv_igemm' else 3]._obj
-    info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': d.ntaps, 'tap_w': list(d.tap_w), 'batch': d.batch}
+    if name.endswith('_phases'):
+        arr = args[5 if name == 'tcvom_conv_igemm_phases' else 3]
+        n = args[6 if name == 'tcvom_conv_igemm_phases' else 4]
+        d = arr[0]
+        taps = sum(sum(1 for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0) for i in range(n))
+        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': 1, 'phases': n}
+    else:
+        d = args[7 if name == 'tcvom_conv_igemm' else 3]._obj
+        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': d.ntaps, 'tap_w': list(d.tap_w), 'batch': d.batch, 'phases': 1}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = _FNS[name](*args)
@@ -143,7 +152,7 @@ def _profiled(name, args):
 
 def call(name, *args):
     """Invoke a status-returning entry point; raise TcvomError on failure."""
-    if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm'):
+    if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases'):
         rc = _profiled(name, args)
     else:
         rc = _FNS[name](*args)

@@ -13,6 +13,8 @@
 #include "common.h"
 #include <mutex>
 
+struct TcvomPhases { tcvom_conv_desc d[4]; int n; };
+
 
 // igemm_nt main loop (v2): 64-deep k-steps, operands DMA'd global->LDS with global_load_lds_dwordx4
 // (no VGPR round trip), 2-slot LDS ring, ONE barrier per k-step:
@@ -21,12 +23,17 @@
 // bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS 16-byte slot `cpos` of row r holds
 // k-chunk cpos ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows covering all residues mod 16) then touches 16
 // distinct 4-bank quads.  Out-of-image taps and dummy taps read a 16-byte zero page instead of branching.
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(
     const bf16raw* __restrict__ in, const bf16raw* __restrict__ wgt, void* __restrict__ outp,
     const float* __restrict__ bias, const float* __restrict__ mscale, const float* __restrict__ mdiag,
-    float* __restrict__ stats, const bf16raw* __restrict__ zero_page, const tcvom_conv_desc d)
+    float* __restrict__ stats, const bf16raw* __restrict__ zero_page, const TcvomPhases ps)
 {
+    // up to 4 phases (sub-pixel phases of a transposed conv / stride-2 data gradient) share ONE launch: blockIdx.z
+    // selects the phase, so their small grids fill the chip together
+    const int phase = ps.n > 1 ? blockIdx.z : 0;
+    const tcvom_conv_desc& d = ps.d[phase];
+    const int bz = ps.n > 1 ? 0 : blockIdx.z;
     constexpr int WAVES_N = TN / WN;
     constexpr int WAVES_M = TM / WM;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -35,16 +42,27 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     constexpr int B_IT = TN / 32;
     constexpr int SLOT = (TM + TN) * 64;               // bf16 elements per ring slot
 
-    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT + 8 * TCVOM_MAX_TAPS];
-    int* taps = reinterpret_cast<int*>(lds + 2 * SLOT);   // [16][3]: input offset, weight offset, validity bit
+    static_assert(NST >= 2 && NST <= 4, "2..4 ring slots");
+    __shared__ __attribute__((aligned(16))) bf16raw lds[NST * SLOT + 8 * TCVOM_MAX_TAPS];
+    int* taps = reinterpret_cast<int*>(lds + NST * SLOT);   // [16][3]: input offset, weight offset, validity bit
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    const int Ptot = d.N * d.PH * d.PW;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed, speed only); give every XCD a contiguous run
+    // of pixel tiles so that the 3x3 halo rows shared by neighbouring tiles are served by ONE L2 (bijective for any
+    // grid size)
+    int bx;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    if (bx * TN >= Ptot) return;                       // phases may have fewer tiles than the launch grid
     if (d.batch > 1) {
-        const int64_t z = blockIdx.z;
+        const int64_t z = bz;
         in += z * d.in_bstride;
         wgt += z * d.w_bstride;
         if (bias) bias += z * d.vec_bstride;
@@ -60,15 +78,6 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     }
     const int cshift = (d.ntaps == 1) ? 31 : __builtin_ctz(C);
     const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
-    const int Ptot = d.N * d.PH * d.PW;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed, speed only); give every XCD a contiguous run
-    // of pixel tiles so that the 3x3 halo rows shared by neighbouring tiles are served by ONE L2 (bijective for any
-    // grid size)
-    int bx;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int p0 = bx * TN;
     const int m0 = blockIdx.y * TM;
 
@@ -140,12 +149,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     const int a_row = wm * WM + (lane & 31), b_row = wn * WN + (lane & 31);
     const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;
 
-    NT_ISSUE_STAGE(0, 0);
+    // NST-slot ring: stages s+1 .. s+NST-2 stay in flight across the barrier (counted vmcnt), which hides the DMA
+    // latency for the layers that are latency- rather than throughput-bound (small grids, small K)
+    constexpr int LPS = A_IT + B_IT;                    // DMA instructions per wave per stage
+#pragma unroll
+    for (int ps = 0; ps < NST - 1; ++ps)
+        if (ps < nstage) NT_ISSUE_STAGE(ps, ps);
+    int slot = 0, islot = NST - 1;
     for (int s = 0; s < nstage; ++s) {
-        const int slot = s & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + NST - 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + 1 < nstage) NT_ISSUE_STAGE(s + 1, slot ^ 1);
+        if (s + NST - 1 < nstage) NT_ISSUE_STAGE(s + NST - 1, islot);
         const bf16raw* As = lds + slot * SLOT;
         const bf16raw* Bs = As + TM * 64;
 #pragma unroll
@@ -164,6 +179,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
                 for (int b = 0; b < NI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        islot = islot + 1 == NST ? 0 : islot + 1;
     }
 #undef NT_ISSUE_STAGE
 
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
         const int i = t % d.PH;
         const int n = t / d.PH;
         out_off[b] = ((int64_t)(n * d.OH + i * d.out_step + d.out_off_h) * d.OW + j * d.out_step + d.out_off_w) * d.ldo;
-        if (d.batch > 1) out_off[b] += (int64_t)blockIdx.z * d.out_bstride;
+        if (d.batch > 1) out_off[b] += (int64_t)bz * d.out_bstride;
     }
     const bool do_stats = stats != nullptr;
 #pragma unroll
@@ -265,9 +282,9 @@ static const bf16raw* zero_page_for_current_device() {
     }
     return pages[dev];
 }
-static NtCfg nt_config(const tcvom_conv_desc* d) {
+static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     const long long P = (long long)d->N * d->PH * d->PW;
-    const int nb = d->batch > 1 ? d->batch : 1;
+    const int nb = nphase > 1 ? nphase : (d->batch > 1 ? d->batch : 1);
     if (d->K >= 128) {
         const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
         if (wgs >= 512) return {128, 128, 2};
@@ -278,45 +295,67 @@ static NtCfg nt_config(const tcvom_conv_desc* d) {
     return {32, 256, 4};
 }
 
-extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d) {
-    const NtCfg c = nt_config(d);
+extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
+    const NtCfg c = nt_config(d, nphase);
     const long long P = (long long)d->N * d->PH * d->PW;
     return cdiv(P, c.tn) * c.waves_n;
+}
+
+static int conv_igemm_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale,
+                             const float* mdiag, float* stats_partial, const tcvom_conv_desc* descs, int nphase,
+                             void* stream) {
+    TCVOM_CHECK_ARG(in && w && out && descs, "conv_igemm: null pointer");
+    TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "conv_igemm: %d phases (1..4)", nphase);
+    TcvomPhases ps;
+    ps.n = nphase;
+    long long Pmax = 0;
+    for (int i = 0; i < nphase; ++i) {
+        const tcvom_conv_desc* d = descs + i;
+        TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "conv_igemm: ntaps=%d", d->ntaps);
+        TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 64 == 0, "conv_igemm: ntaps*C=%d not a multiple of 64", d->ntaps * d->C);
+        TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "conv_igemm: C=%d must be a power of two >= 8", d->C);
+        TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
+        TCVOM_CHECK_ARG(d->C % 8 == 0, "conv_igemm: C=%d must be a multiple of 8", d->C);
+        TCVOM_CHECK_ARG(nphase == 1 || (d->batch <= 1 && d->K == descs[0].K), "conv_igemm: phases must share K and be unbatched");
+        const long long P = (long long)d->N * d->PH * d->PW;
+        TCVOM_CHECK_ARG(P > 0 && P < (1ll << 31), "conv_igemm: bad pixel count %lld", P);
+        TCVOM_CHECK_ARG((long long)d->N * d->H * d->W * d->C < (1ll << 31) && (long long)d->K * d->wt * d->C < (1ll << 31),
+                        "conv_igemm: operand too large for 32-bit element offsets");
+        if (P > Pmax) Pmax = P;
+        ps.d[i] = *d;
+    }
+    const tcvom_conv_desc* d0 = descs;
+    const int nb = nphase > 1 ? nphase : (d0->batch > 1 ? d0->batch : 1);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16raw* ip = (const bf16raw*)in;
+    const bf16raw* wp = (const bf16raw*)w;
+    const NtCfg c = nt_config(d0, nphase);
+    const bf16raw* zp = zero_page_for_current_device();
+    TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
+    dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
+    if (c.tm == 128 && c.tn == 128)
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64, 2>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+    else if (c.tm == 128)
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 64, 32, 3>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+    else if (c.tm == 64 && c.tn == 64)
+        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32, 4>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+    else if (c.tm == 64)
+        hipLaunchKernelGGL((igemm_nt_kernel<64, 128, 32, 64, 3>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+    else
+        hipLaunchKernelGGL((igemm_nt_kernel<32, 256, 32, 64, 2>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+    TCVOM_LAUNCH_CHECK("conv_igemm");
+    return TCVOM_OK;
 }
 
 extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias,
                                 const float* mscale, const float* mdiag, float* stats_partial,
                                 const tcvom_conv_desc* d, void* stream) {
-    TCVOM_CHECK_ARG(in && w && out && d, "conv_igemm: null pointer");
-    TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "conv_igemm: ntaps=%d", d->ntaps);
-    TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 64 == 0, "conv_igemm: ntaps*C=%d not a multiple of 64", d->ntaps * d->C);
-    TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "conv_igemm: C=%d must be a power of two >= 8", d->C);
-    TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
-    TCVOM_CHECK_ARG(d->C % 8 == 0, "conv_igemm: C=%d must be a multiple of 8", d->C);
-    const long long P = (long long)d->N * d->PH * d->PW;
-    TCVOM_CHECK_ARG(P > 0 && P < (1ll << 31), "conv_igemm: bad pixel count %lld", P);
-    const int nb = d->batch > 1 ? d->batch : 1;
-    hipStream_t st = (hipStream_t)stream;
-    const bf16raw* ip = (const bf16raw*)in;
-    const bf16raw* wp = (const bf16raw*)w;
-    const NtCfg c = nt_config(d);
-    const bf16raw* zp = zero_page_for_current_device();
-    TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
-    TCVOM_CHECK_ARG((long long)d->N * d->H * d->W * d->C < (1ll << 31) && (long long)d->K * d->wt * d->C < (1ll << 31),
-                    "conv_igemm: operand too large for 32-bit element offsets");
-    dim3 grid(cdiv(P, c.tn), cdiv(d->K, c.tm), nb);
-    if (c.tm == 128 && c.tn == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
-    else if (c.tm == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 64, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
-    else if (c.tm == 64 && c.tn == 64)
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
-    else if (c.tm == 64)
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 128, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
-    else
-        hipLaunchKernelGGL((igemm_nt_kernel<32, 256, 32, 64>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, *d);
-    TCVOM_LAUNCH_CHECK("conv_igemm");
-    return TCVOM_OK;
+    return conv_igemm_launch(in, w, out, bias, mscale, mdiag, stats_partial, d, 1, stream);
+}
+
+extern "C" int tcvom_conv_igemm_phases(const void* in, const void* w, void* out, const float* bias, float* stats_partial,
+                                       const tcvom_conv_desc* descs, int32_t nphase, void* stream) {
+    return conv_igemm_launch(in, w, out, bias, nullptr, nullptr, stats_partial, descs, nphase, stream);
 }
 
 // =====================================================================================
@@ -352,8 +391,12 @@ __device__ __forceinline__ bf16x8_t tr_read8(const bf16raw* p_lo, const bf16raw*
 template <int TM, int TN, int WM, int WN, int KS>
 __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const bf16raw* __restrict__ dy, const bf16raw* __restrict__ in, float* __restrict__ dw,
-    const bf16raw* __restrict__ zero_page, const tcvom_conv_desc d, const int ldy, const int pchunk)
+    const bf16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk, const int chunks_per_phase)
 {
+    const int phase = blockIdx.x / chunks_per_phase;
+    const tcvom_conv_desc& d = ps.d[phase];
+    const int chunk = blockIdx.x - phase * chunks_per_phase;
+    if (chunk * pchunk >= d.N * d.PH * d.PW) return;
     constexpr int WAVES_M = TM / WM, WAVES_N = TN / WN;
     static_assert(WAVES_M * WAVES_N * KS == 4, "4 waves per workgroup");
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -382,7 +425,7 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
     const int ncols = d.ntaps * C;
     const int Ptot = d.N * d.PH * d.PW;
-    const int pbeg = blockIdx.x * pchunk;
+    const int pbeg = chunk * pchunk;
     const int pend = min(Ptot, pbeg + pchunk);
     const int n0 = blockIdx.y * TN;
     const int m0 = blockIdx.z * TM;
@@ -531,14 +574,26 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     }
 }
 
-extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_conv_desc* d,
-                                 int32_t ldy, void* stream) {
-    TCVOM_CHECK_ARG(dy && in && dw && d, "wgrad_igemm: null pointer");
-    TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "wgrad_igemm: ntaps=%d", d->ntaps);
-    TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "wgrad_igemm: C=%d must be a power of two >= 8", d->C);
-    TCVOM_CHECK_ARG(d->C % 8 == 0 && ldy % 8 == 0, "wgrad_igemm: C=%d ldy=%d must be multiples of 8", d->C, ldy);
-    const long long P = (long long)d->N * d->PH * d->PW;
-    TCVOM_CHECK_ARG(P > 0 && P < (1ll << 31), "wgrad_igemm: bad pixel count %lld", P);
+static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs, int nphase,
+                              int32_t ldy, void* stream) {
+    TCVOM_CHECK_ARG(dy && in && dw && descs, "wgrad_igemm: null pointer");
+    TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "wgrad_igemm: %d phases (1..4)", nphase);
+    TcvomPhases ps;
+    ps.n = nphase;
+    long long P = 0;
+    for (int i = 0; i < nphase; ++i) {
+        const tcvom_conv_desc* d = descs + i;
+        TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "wgrad_igemm: ntaps=%d", d->ntaps);
+        TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "wgrad_igemm: C=%d must be a power of two >= 8", d->C);
+        TCVOM_CHECK_ARG(d->C % 8 == 0 && ldy % 8 == 0, "wgrad_igemm: C=%d ldy=%d must be multiples of 8", d->C, ldy);
+        TCVOM_CHECK_ARG(d->K == descs[0].K && d->C == descs[0].C && d->ntaps == descs[0].ntaps,
+                        "wgrad_igemm: phases must share K, C and the tap count");
+        const long long Pi = (long long)d->N * d->PH * d->PW;
+        TCVOM_CHECK_ARG(Pi > 0 && Pi < (1ll << 31), "wgrad_igemm: bad pixel count %lld", Pi);
+        if (Pi > P) P = Pi;
+        ps.d[i] = *d;
+    }
+    const tcvom_conv_desc* d = descs;
     hipStream_t st = (hipStream_t)stream;
     const int ncols = d->ntaps * d->C;
     const bf16raw* zp = zero_page_for_current_device();
@@ -551,24 +606,38 @@ extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, cons
     else if (d->K > 32) { tm = 64; tn = ncols >= 128 ? 128 : 64; }
     else { tm = 32; tn = ncols >= 128 ? 128 : 32; }
     const int mt = cdiv(d->K, tm), nt = cdiv(ncols, tn);
-    // pixel chunks: every workgroup ends with tm*tn atomic adds, so chunks must be long enough to amortise
-    // them (>= 512 pixels) while still giving ~3 workgroups per CU
-    long long want = 768 / ((long long)mt * nt);
+    // pixel chunks: every workgroup ends with tm*tn atomic adds, so chunks must be long enough to amortise them
+    // (>= 512 pixels), and the whole grid should fit in ONE round of co-resident workgroups (LDS-limited occupancy
+    // x 256 CUs): a partial second round costs as much as a full one
+    const int lds_bytes = 2 * 64 * (tm + tn) * 2 + 256;
+    int occ = (160 * 1024) / lds_bytes;
+    if (occ > 4) occ = 4;
+    long long want = (256ll * occ) / ((long long)mt * nt * nphase);
     if (want < 1) want = 1;
     long long pchunk = ((P + want - 1) / want + 63) / 64 * 64;
     if (pchunk < 512) pchunk = 512;
     const int chunks = cdiv(P, pchunk);
-    dim3 grid(chunks, nt, mt);
+    dim3 grid(chunks * nphase, nt, mt);
     if (tm == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else if (tm == 64 && tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else if (tm == 64)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else if (tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else
-        hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, a, b, dw, zp, *d, ldy, (int)pchunk);
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     TCVOM_LAUNCH_CHECK("wgrad_igemm");
     return TCVOM_OK;
+}
+
+extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_conv_desc* d,
+                                 int32_t ldy, void* stream) {
+    return wgrad_igemm_launch(dy, in, dw, d, 1, ldy, stream);
+}
+
+extern "C" int tcvom_wgrad_igemm_phases(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs,
+                                        int32_t nphase, int32_t ldy, void* stream) {
+    return wgrad_igemm_launch(dy, in, dw, descs, nphase, ldy, stream);
 }

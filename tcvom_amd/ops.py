@@ -44,18 +44,29 @@ class ConvCfg(object):
         return g
 
 
+def _phase_array(descs):
+    """ctypes array of the phase descriptors (cached on the list object's first element)."""
+    arr = getattr(descs[0], '_phase_array', None)
+    if arr is None:
+        arr = (L.ConvDesc * len(descs))(*descs)
+        descs[0]._phase_array = arr
+        descs[0]._phase_groups = L.call('tcvom_conv_stats_groups', C.byref(descs[0]), len(descs))
+    return arr
+
+
 def _launch_conv(descs, x, wptr, out, bias, stats, act, st):
-    goff = 0
-    for d in descs:
-        d.act = act
-        d.stats_group_offset = goff
-        L.call('tcvom_conv_igemm', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), None, None, L.ptr(stats), C.byref(d), st)
-        goff += L.call('tcvom_conv_stats_groups', C.byref(d))
-    return goff
+    """All phases of a conv in ONE launch (stride-2 data gradients / ConvTranspose forwards have 4)."""
+    arr = _phase_array(descs)
+    g = descs[0]._phase_groups
+    for i in range(len(descs)):
+        arr[i].act = act
+        arr[i].stats_group_offset = i * g
+    L.call('tcvom_conv_igemm_phases', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), L.ptr(stats), arr, len(descs), st)
 
 
 def _stats_groups(descs):
-    return sum(L.call('tcvom_conv_stats_groups', C.byref(d)) for d in descs)
+    _phase_array(descs)
+    return descs[0]._phase_groups * len(descs)
 
 
 class _ConvBNAct(torch.autograd.Function):
@@ -137,13 +148,9 @@ class _ConvBNAct(torch.autograd.Function):
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
             dx = torch.empty((geo.N, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
-            wp = bank.bwd_ptr(spec, ctx.call)
-            for d in geo.dgrad:
-                d.act = 0
-                L.call('tcvom_conv_igemm', L.ptr(dy), wp, L.ptr(dx), None, None, None, None, C.byref(d), st)
-        dwp = bank.dw_ptr(spec, ctx.call)
-        for d in geo.fwd:
-            L.call('tcvom_wgrad_igemm', L.ptr(dy), L.ptr(x), dwp, C.byref(d), K, st)
+            _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st)
+        L.call('tcvom_wgrad_igemm_phases', L.ptr(dy), L.ptr(x), bank.dw_ptr(spec, ctx.call), _phase_array(geo.fwd),
+               len(geo.fwd), K, st)
         dres2 = dz if ctx.has_res2 else None
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None
 
