@@ -42,6 +42,8 @@ def build(device, H, W, seed):
     model = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
     model.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in model.NET.state_dict().items()})
     model = model.to(device).train()
+    if os.environ.get('TCVOM_FRAME_STREAMS', '1') == '0':      # profiling aid: serialise the frames on one stream
+        model.NET.frame_streams = False
     a, fg, bg = synthetic_window(1, 3, H, W, seed=seed)
     return model, a.to(device), fg.to(device), bg.to(device)
 

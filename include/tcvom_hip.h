@@ -107,7 +107,8 @@ int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const f
                         int32_t act, void* stream);
 /* dgamma/dbeta are WRITTEN (not accumulated); coef is [3][C] scratch consumed by bn_bwd_apply */
 int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, const float* gamma,
-                          const float* saved, float* dgamma, float* dbeta, float* coef, void* stream);
+                          const float* saved, float* dgamma, float* dbeta, float* coef,
+                          double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */, void* stream);
 /* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
  * gradient is additionally masked by y > 0 */
 int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,

@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+template <typename PT>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
-    const float* __restrict__ partial, int G, int C, double count,
+    const PT* __restrict__ partial, int G, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ saved,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef)
 {
@@ -281,7 +282,7 @@ extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C
     TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0, "bn_finalize: bad args");
     hipStream_t st = (hipStream_t)stream;
     const double ub = (double)(unbias_count > 0 ? unbias_count : count);
-    if (groups > 8 * BN_SLICES && scratch) {
+    if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C,
                            (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved);
@@ -343,7 +344,7 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
     const int rows = 256 / (C / 8);
     int64_t per = (int64_t)rows * 8;                // >= 8 loop iterations per thread
     int64_t g = (pixels + per - 1) / per;
-    if (g > 1024) g = 1024;
+    if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -364,10 +365,17 @@ extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* re
 
 extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count,
                                      const float* gamma, const float* saved, float* dgamma, float* dbeta,
-                                     float* coef, void* stream) {
+                                     float* coef, double* scratch, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, groups, C,
-                       (double)count, gamma, saved, dgamma, dbeta, coef);
+    hipStream_t st = (hipStream_t)stream;
+    if (groups > 4 * BN_SLICES && scratch) {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES,
+                           C, (double)count, gamma, saved, dgamma, dbeta, coef);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C,
+                           (double)count, gamma, saved, dgamma, dbeta, coef);
+    }
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
     return TCVOM_OK;
 }

@@ -99,7 +99,7 @@ class _ConvBNAct(torch.autograd.Function):
         if training:
             P = geo.out_pixels
             groups = stats.numel() // (2 * K)
-            scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 512 else None
+            scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
             L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
                    L.ptr(gamma), L.ptr(beta), None, None,
                    float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
@@ -139,7 +139,9 @@ class _ConvBNAct(torch.autograd.Function):
             dgamma = torch.empty(K, dtype=torch.float32, device=dz.device)
             dbeta = torch.empty(K, dtype=torch.float32, device=dz.device)
             coef = torch.empty(3 * K, dtype=torch.float32, device=dz.device)
-            L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), st)
+            scratch = torch.empty(128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
+            L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma), L.ptr(dbeta),
+                   L.ptr(coef), L.ptr(scratch), st)
             dy = torch.empty_like(y)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty_like(y)

@@ -8,7 +8,8 @@ import sys
 import torch
 import torch.nn as nn
 
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tcvom_amd import _lib as L                                      # noqa: E402
 from tcvom_amd.conv_plan import ConvGeometry, dense_desc, dense_tt_desc   # noqa: E402
 from tcvom_amd.weights import ConvSpec, WeightBank                   # noqa: E402
