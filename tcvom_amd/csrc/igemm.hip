@@ -24,7 +24,7 @@ struct TcvomPhases { tcvom_conv_desc d[4]; int n; };
 // k-chunk cpos ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows covering all residues mod 16) then touches 16
 // distinct 4-bank quads.  Out-of-image taps and dummy taps read a 16-byte zero page instead of branching.
 template <int TM, int TN, int WM, int WN, int NST>
-__global__ __launch_bounds__(256) void igemm_nt_kernel(
+__global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const bf16raw* __restrict__ in, const bf16raw* __restrict__ wgt, void* __restrict__ outp,
     const float* __restrict__ bias, const float* __restrict__ mscale, const float* __restrict__ mdiag,
     float* __restrict__ stats, const bf16raw* __restrict__ zero_page, const TcvomPhases ps)
@@ -36,10 +36,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     const int bz = ps.n > 1 ? 0 : blockIdx.z;
     constexpr int WAVES_N = TN / WN;
     constexpr int WAVES_M = TM / WM;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int NW = WAVES_M * WAVES_N;              // 4 or 8 waves per workgroup
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_IT = TM / 32;                      // DMA instructions per wave per k-step (8 rows each)
-    constexpr int B_IT = TN / 32;
+    constexpr int A_IT = TM / (8 * NW);                // DMA instructions per wave per k-step (8 rows each)
+    constexpr int B_IT = TN / (8 * NW);
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the wave count");
     constexpr int SLOT = (TM + TN) * 64;               // bf16 elements per ring slot
 
     static_assert(NST >= 2 && NST <= 4, "2..4 ring slots");
@@ -88,14 +90,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
     int a_off[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + (it * 4 + wave) * 8 + (lane >> 3);
+        const int m = m0 + (it * NW + wave) * 8 + (lane >> 3);
         a_off[it] = m < K ? m * WT * C : -1;
     }
     int b_off[B_IT];
     unsigned b_valid[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int p = p0 + (it * 4 + wave) * 8 + (lane >> 3);
+        const int p = p0 + (it * NW + wave) * 8 + (lane >> 3);
         b_off[it] = 0;
         b_valid[it] = 0u;
         if (p < Ptot) {
@@ -135,12 +137,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(
         bf16raw* abase = lds + (slot) * SLOT;                                                              \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                              \
             const bf16raw* src = (a_off[it] >= 0 && tw >= 0) ? wgt + (a_off[it] + tw + c0) : zero_page;    \
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (it * 4 + wave) * 512), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (it * NW + wave) * 512), 16, 0, 0); \
         }                                                                                                  \
         bf16raw* bbase = abase + TM * 64;                                                                  \
         _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                              \
             const bf16raw* src = ((b_valid[it] >> tap) & 1u) ? in + ((int64_t)b_off[it] + tin + c0) : zero_page; \
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + (it * 4 + wave) * 512), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + (it * NW + wave) * 512), 16, 0, 0); \
         }                                                                                                  \
     }
 
@@ -334,9 +336,9 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
     if (c.tm == 128 && c.tn == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 64, 2>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 32, 2>), grid, dim3(512), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
     else if (c.tm == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 64, 32, 3>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 32, 32, 3>), grid, dim3(512), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
     else if (c.tm == 64 && c.tn == 64)
         hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32, 4>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
     else if (c.tm == 64)
