@@ -289,7 +289,7 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     const int nb = nphase > 1 ? nphase : (d->batch > 1 ? d->batch : 1);
     if (d->K >= 128) {
         const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
-        if (wgs >= 512) return {128, 128, 2};
+        if (wgs >= 512) return {128, 128, 4};
         if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
         return {64, 64, 2};
     }

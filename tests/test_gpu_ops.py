@@ -180,6 +180,41 @@ def test_conv_bn_act_train(act, pre_relu, res):
     ck.done()
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [
+    (64, 128, 3, 1, False, 256, 264),      # >= 512 tiles of 128x128: the 8-wave 128x128 configuration WITH statistics
+    (128, 128, 4, 2, True, 136, 120),      # 4 phases in one launch, 128x128 tiles, statistics per phase
+    (128, 128, 3, 1, False, 136, 240),     # the os8 class at 1080p: 128x64 tiles
+    (32, 32, 3, 1, False, 272, 480),       # the os2/os1 class: 32x256 tiles
+    (256, 256, 3, 1, False, 68, 120),      # the os16 class: 64x64 tiles, 4-slot ring
+])
+def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
+    """Tile configurations are chosen from the problem size, so the production (1080p) configurations need their
+    own cases: forward + batch statistics vs fp32 PyTorch on the same bf16 operands, and gradient sanity."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    tag = 'big%d_%d_%d_%d' % (cin, cout, k, H)
+    bank, spec = _mini_bank(cin, cout, k, stride, 1, transposed, spectral=False, tag=tag)
+    bn = nn.BatchNorm2d(cout).to(DEV)
+    cfg = ops.ConvCfg(bank, spec, bn=bn, act=1)
+    x = hu('x.' + tag, (1, cin, H, W))
+    xg = nhwc(x).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    z = ops.conv_bn_act(cfg, xg, token, True)
+    bank.flush_bn_counters()
+    wr = bf(spec.weight.detach().cpu())
+    yr = F.conv_transpose2d(bf(x), wr, None, stride, 1) if transposed else F.conv2d(bf(x), wr, None, stride, 1)
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    zr = F.relu((bf(yr) - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5))
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.rel('running_mean', bn.running_mean, 0.1 * mean, 2e-2)
+    n_el = yr.numel() // cout
+    ck.rel('running_var', bn.running_var, 0.9 + 0.1 * var * n_el / (n_el - 1), 2e-2)
+    z.float().sum().backward()
+    assert torch.isfinite(xg.grad.float()).all() and torch.isfinite(spec.weight.grad).all()
+    ck.done()
+
+
 # --------------------------------------------------------------------------------------------- spectral norm
 @pytest.mark.parametrize('transposed', [False, True])
 def test_spectral_norm_bank(transposed):
