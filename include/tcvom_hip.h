@@ -45,7 +45,7 @@ int tcvom_abi_version(void);
  * Optional fused epilogue: per-output-channel scale, "diagonal" subtraction
  * (GCA self-mask, ops.py:188), bias, ReLU, BatchNorm partial statistics
  * (sum, sum of squares per channel per 64-pixel group).                       */
-#define TCVOM_MAX_TAPS 16
+#define TCVOM_MAX_TAPS 32
 typedef struct {
     int32_t N, H, W, C;          /* input NHWC; C power of two >= 8 unless ntaps == 1 */
     int32_t OH, OW, K;           /* output tensor dims; K = output channels (multiple of 4) */
@@ -99,12 +99,13 @@ int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_
                         float eps, int64_t unbias_count, void* stream);
 int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
+/* y_fp32 != 0: the conv output y is fp32 (high-precision layers) instead of bf16 */
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
-                   int64_t pixels, int32_t C, int32_t act, void* stream);
+                   int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, void* stream);
 int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
 int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
                         const float* saved, float* partial /*[groups][2][C]*/, int64_t pixels, int32_t C,
-                        int32_t act, void* stream);
+                        int32_t act, int32_t y_fp32, void* stream);
 /* dgamma/dbeta are WRITTEN (not accumulated); coef is [3][C] scratch consumed by bn_bwd_apply */
 int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, const float* gamma,
                           const float* saved, float* dgamma, float* dbeta, float* coef,
@@ -113,7 +114,7 @@ int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64
  * gradient is additionally masked by y > 0 */
 int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
                        const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
-                       int32_t C, int32_t act, int32_t training, int32_t in_relu, void* stream);
+                       int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, void* stream);
 
 /* ------------------------------------------------------------------ batched SpectralNorm + weight packing
  * Replaces SpectralNorm._update_u_v/_noupdate_u_v (models/GCA/ops.py:25-45,74-80) for every wrapped

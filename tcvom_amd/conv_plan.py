@@ -40,11 +40,22 @@ class ConvGeometry(object):
         R, S, st, p = spec.R, spec.S, spec.stride, spec.pad
         K, C, Cp = spec.K, spec.C, spec.cpad
         self.N, self.H, self.W = N, H, W
-        self.fwd, self.dgrad = [], []
+        self.fwd, self.dgrad, self.wgrad = [], [], []
+        hp = getattr(spec, 'hp', False)
+
+        def fwd_desc(*a):
+            # a = (N, H, W, C, OH, OW, K, PH, PW, in_step, out_step, off_h, off_w, taps, wt)
+            self.wgrad.append(_desc(*a))
+            if hp:                      # each tap twice: slot t (bf16 hi part of the weight) and slot wt + t (residual)
+                taps, wt = a[13], a[14]
+                a = a[:13] + (list(taps) + [(dh, dw, wt + ws) for dh, dw, ws in taps], 2 * wt)
+                self.fwd.append(_desc(*a))
+            else:
+                self.fwd.append(self.wgrad[-1])
         if not spec.transposed:
             OH, OW = (H + 2 * p - R) // st + 1, (W + 2 * p - S) // st + 1
             taps = [(r - p, s - p, r * S + s) for r in range(R) for s in range(S)]
-            self.fwd.append(_desc(N, H, W, Cp, OH, OW, K, OH, OW, st, 1, 0, 0, taps, R * S))
+            fwd_desc(N, H, W, Cp, OH, OW, K, OH, OW, st, 1, 0, 0, taps, R * S)
             if spec.needs_dgrad:
                 # dx[n,h,w,c] = sum_{r,s,k} dy[n,(h+p-r)/st,(w+p-s)/st,k] W[k][c][r][s]   (exact divisions only)
                 for ph in range(st):
@@ -63,7 +74,7 @@ class ConvGeometry(object):
                     tp = [((ph + 1 - r) // 2, (pw + 1 - s) // 2, r * 4 + s)
                           for r in range(4) for s in range(4)
                           if (ph + 1 - r) % 2 == 0 and (pw + 1 - s) % 2 == 0]
-                    self.fwd.append(_desc(N, H, W, Cp, OH, OW, K, H, W, 1, 2, ph, pw, tp, 16))
+                    fwd_desc(N, H, W, Cp, OH, OW, K, H, W, 1, 2, ph, pw, tp, 16)
             if spec.needs_dgrad:
                 taps = [(r - 1, s - 1, r * 4 + s) for r in range(4) for s in range(4)]
                 self.dgrad.append(_desc(N, OH, OW, K, H, W, C, H, W, 2, 1, 0, 0, taps, 16))

@@ -89,6 +89,18 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
     saved[C + c] = invstd;
 }
 
+// conv output `y` is bf16, or fp32 for the high-precision layers (YF32)
+template <bool YF32>
+__device__ __forceinline__ void load_y8(const void* __restrict__ y, int64_t v, float* f) {
+    if (YF32) {
+        const float4* p = reinterpret_cast<const float4*>(y) + 2 * v;
+        const float4 a = p[0], b = p[1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+        unpack8(reinterpret_cast<const uint4*>(y)[v], f);
+    }
+}
+
 // ---------------------------------------------------------------- apply: z = act(y*s + b + res1) + res2
 __device__ __forceinline__ float act_fwd(float x, int act) {
     return act == 1 ? fmaxf(x, 0.f) : (act == 2 ? (x > 0.f ? x : 0.2f * x) : x);
@@ -100,8 +112,9 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
 // A block owns a contiguous pixel range; a thread owns ONE channel octet for the whole range (its 16 scale/shift
 // values live in registers) and walks the pixels with stride 256/C8: every access is a 16-byte load/store and
 // consecutive lanes cover consecutive 16-byte chunks of a pixel row.
+template <bool YF32>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
-    const uint4* __restrict__ y, const float* __restrict__ scale_shift,
+    const void* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
     int64_t P, int C8, int C, int act, int rows_per_block)
 {
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     for (int64_t p = pbeg + prow; p < pend; p += RP) {
         const int64_t v = p * C8 + oct;
         float f[8], r1[8], r2[8];
-        unpack8(y[v], f);
+        load_y8<YF32>(y, v, f);
         if (res1) unpack8(res1[v], r1);
         if (res2) unpack8(res2[v], r2);
 #pragma unroll
@@ -132,8 +145,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 
 // ---------------------------------------------------------------- backward, pass 1: per-channel sums
 // block = 256 threads = RP pixel rows x C8 channel octets (C8 <= 256); partial[block][2][C]
+template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const uint4* __restrict__ dz, const uint4* __restrict__ y, const uint4* __restrict__ res1,
+    const uint4* __restrict__ dz, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
     float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block)
 {
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const int64_t v = p * C8 + oct;
             float g[8], yy[8], r1[8];
             unpack8(dz[v], g);
-            unpack8(y[v], yy);
+            load_y8<YF32>(y, v, yy);
             if (res1) unpack8(res1[v], r1);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -221,8 +235,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     }
 }
 
+template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const uint4* __restrict__ dz, const uint4* __restrict__ y, const uint4* __restrict__ res1,
+    const uint4* __restrict__ dz, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
     int rows_per_block)
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const int64_t v = p * C8 + oct;
         float g[8], yy[8], r1[8], o[8];
         unpack8(dz[v], g);
-        unpack8(y[v], yy);
+        load_y8<YF32>(y, v, yy);
         if (res1) unpack8(res1[v], r1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -330,12 +345,16 @@ extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* 
 }
 
 extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
-                              int64_t pixels, int32_t C, int32_t act, void* stream) {
+                              int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, void* stream) {
     TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
     TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_apply: C=%d must be a power of two <= 2048", C);
     const int rpb = bn_rows_per_block(pixels, C);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb);
+    if (y_fp32)
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb);
     TCVOM_LAUNCH_CHECK("bn_apply");
     return TCVOM_OK;
 }
@@ -351,14 +370,17 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
 
 extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
                                    const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
-                                   void* stream) {
+                                   int32_t y_fp32, void* stream) {
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048,
                     "bn_bwd_reduce: bad args (C=%d)", C);
     const int groups = tcvom_bn_bwd_groups(pixels, C);
     const int rpb = (int)((pixels + groups - 1) / groups);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(groups), dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                       (const uint4*)dz, (const uint4*)y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C,
-                       act, rpb);
+    if (y_fp32)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(groups), dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(groups), dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb);
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
 }
@@ -382,13 +404,18 @@ extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32
 
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
-                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, void* stream) {
+                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, void* stream) {
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
     TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_bwd_apply: C=%d must be a power of two <= 2048", C);
     const int rpb = bn_rows_per_block(pixels, C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)dz, (const uint4*)y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                       (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb);
+    if (y_fp32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb);
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
 }

@@ -20,7 +20,7 @@ enum {
     SN_W = 0, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD,
     SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL
 };
-// kind bits: 1 = ConvTranspose layout, 2 = plain (no spectral norm)
+// kind bits: 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual)
 
 struct SnScratch {
     float* tvec;      // [sum wd]      W^T u   (zeroed before each iteration)
@@ -121,11 +121,14 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
     const float inv = (kind & 2) ? 1.f : 1.f / sigma[(int64_t)call * L_total + layer];
     const int64_t idx = base + threadIdx.x;
     int k, c, t;
+    int part = 0;                                  // hp layers (kind & 4): slot t = hi part, slot T + t = bf16 residual
     if (which == 0) {
-        if (idx >= (int64_t)K * T * Cp) return;
+        const int TT = (kind & 4) ? 2 * T : T;
+        if (idx >= (int64_t)K * TT * Cp) return;
         c = (int)(idx % Cp);
-        t = (int)((idx / Cp) % T);
-        k = (int)(idx / ((int64_t)Cp * T));
+        t = (int)((idx / Cp) % TT);
+        k = (int)(idx / ((int64_t)Cp * TT));
+        if (t >= T) { t -= T; part = 1; }
     } else {
         if (idx >= (int64_t)C * T * K) return;
         k = (int)(idx % K);
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
     if (c < C) {
         const int64_t src = (kind & 1) ? ((int64_t)c * K + k) * T + t : ((int64_t)k * C + c) * T + t;
         val = W[src] * inv;
+        if (part) val -= bf2f(f2bf(val));
     }
     if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + idx] = f2bf(val);
     else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + idx] = f2bf(val);

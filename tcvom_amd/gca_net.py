@@ -16,6 +16,7 @@ from .ops import ACT_NONE, ACT_RELU, ACT_LEAKY, ConvCfg
 from .weights import ConvSpec, WeightBank, bank_token
 
 TRIMAP_CHANNEL = 3
+HIGH_PRECISION_STEM = True
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -45,10 +46,10 @@ class SpectralNorm(nn.Module):
         self.module = _ConvParams(tuple(shape))
         self.stride, self.padding, self.transposed = stride, padding, transposed
 
-    def spec(self, name, group, needs_dgrad=True):
+    def spec(self, name, group, needs_dgrad=True, hp=False):
         m = self.module
         return ConvSpec(name, m.weight_bar, m.weight_u, m.weight_v, None, self.transposed, self.stride,
-                        self.padding, group, needs_dgrad)
+                        self.padding, group, needs_dgrad, hp=hp)
 
 
 def _plain_spec(name, conv, group, needs_dgrad=True):
@@ -170,7 +171,11 @@ class ResGuidedCxtAtten(nn.Module):
 
     def _register(self, bank):
         def reg(name, sn, bn, act=ACT_NONE, pre_relu=False, needs_dgrad=True):
-            spec = sn.spec('encoder.' + name, 'frame', needs_dgrad)
+            # High-precision forward for the stem, layer1 and layer2: tests/study_bf16_noise.py shows that >= 99 % of
+            # the bf16 storage noise of the whole window is injected there.  Their packed weights carry a bf16
+            # residual (exact to ~2^-16) and their conv outputs stay fp32 until BatchNorm has been applied.
+            hp = HIGH_PRECISION_STEM and name.split('.')[0] in ('conv1', 'conv2', 'conv3', 'layer1', 'layer2')
+            spec = sn.spec('encoder.' + name, 'frame', needs_dgrad, hp=hp)
             bank.register(spec)
             return ConvCfg(bank, spec, bn=bn, act=act, pre_relu=pre_relu)
         self._stem = [reg('conv1', self.conv1, self.bn1, ACT_RELU, needs_dgrad=False),

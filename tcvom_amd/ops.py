@@ -58,8 +58,10 @@ def _launch_conv(descs, x, wptr, out, bias, stats, act, st):
     """All phases of a conv in ONE launch (stride-2 data gradients / ConvTranspose forwards have 4)."""
     arr = _phase_array(descs)
     g = descs[0]._phase_groups
+    f32 = 1 if out.dtype == torch.float32 else 0
     for i in range(len(descs)):
         arr[i].act = act
+        arr[i].out_fp32 = f32
         arr[i].stats_group_offset = i * g
     L.call('tcvom_conv_igemm_phases', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), L.ptr(stats), arr, len(descs), st)
 
@@ -82,8 +84,10 @@ class _ConvBNAct(torch.autograd.Function):
         call = bank.next_call(spec)
         st = L.stream_ptr()
         K = spec.K
-        y = torch.empty((N, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
         has_bn = bn is not None
+        # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
+        hp = spec.hp and has_bn
+        y = torch.empty((N, geo.OH, geo.OW, K), dtype=torch.float32 if hp else BF16, device=x.device)
         stats = None
         if has_bn and training:
             stats = torch.empty(_stats_groups(geo.fwd) * 2 * K, dtype=torch.float32, device=x.device)
@@ -109,10 +113,10 @@ class _ConvBNAct(torch.autograd.Function):
         else:
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), L.ptr(ss), L.ptr(saved), st)
-        z = torch.empty_like(y)
+        z = torch.empty((N, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
-        L.call('tcvom_bn_apply', L.ptr(y), L.ptr(ss), L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, st)
+        L.call('tcvom_bn_apply', L.ptr(y), L.ptr(ss), L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0, st)
         ctx.save_for_backward(x, y, ss, saved, gamma, r1)
         return z
 
@@ -135,24 +139,25 @@ class _ConvBNAct(torch.autograd.Function):
             P = geo.out_pixels
             groups = L.call('tcvom_bn_bwd_groups', P, K)
             partial = torch.empty(groups * 2 * K, dtype=torch.float32, device=dz.device)
-            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(partial), P, K, cfg.act, st)
+            yf = 1 if y.dtype == torch.float32 else 0
+            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(partial), P, K, cfg.act, yf, st)
             dgamma = torch.empty(K, dtype=torch.float32, device=dz.device)
             dbeta = torch.empty(K, dtype=torch.float32, device=dz.device)
             coef = torch.empty(3 * K, dtype=torch.float32, device=dz.device)
             scratch = torch.empty(128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
             L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma), L.ptr(dbeta),
                    L.ptr(coef), L.ptr(scratch), st)
-            dy = torch.empty_like(y)
+            dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
-                dres1 = torch.empty_like(y)
+                dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)
             L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(coef), L.ptr(dy),
-                   L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, st)
+                   L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, yf, st)
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
             dx = torch.empty((geo.N, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
             _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st)
-        L.call('tcvom_wgrad_igemm_phases', L.ptr(dy), L.ptr(x), bank.dw_ptr(spec, ctx.call), _phase_array(geo.fwd),
-               len(geo.fwd), K, st)
+        L.call('tcvom_wgrad_igemm_phases', L.ptr(dy), L.ptr(x), bank.dw_ptr(spec, ctx.call), _phase_array(geo.wgrad),
+               len(geo.wgrad), K, st)
         dres2 = dz if ctx.has_res2 else None
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None
 

@@ -27,8 +27,9 @@ def _r8(n):
 class ConvSpec(object):
     """Static description of one conv weight registered in the bank."""
 
-    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True):
+    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True, hp=False):
         self.name = name
+        self.hp = hp                         # high-precision forward: packed weight = bf16 hi + bf16 residual (2T slots)
         self.weight, self.u, self.v, self.bias = weight, u, v, bias
         self.transposed = transposed
         shp = tuple(weight.shape)
@@ -100,11 +101,11 @@ class WeightBank(object):
             tab[i, SN_U] = s.u.data_ptr() if s.spectral else 0
             tab[i, SN_V] = s.v.data_ptr() if s.spectral else 0
             tab[i, SN_H], tab[i, SN_WD] = s.h, s.wd
-            tab[i, SN_KIND] = (1 if s.transposed else 0) | (0 if s.spectral else 2)
+            tab[i, SN_KIND] = (1 if s.transposed else 0) | (0 if s.spectral else 2) | (4 if s.hp else 0)
             tab[i, SN_K], tab[i, SN_C], tab[i, SN_T], tab[i, SN_CPAD] = s.K, s.C, s.T, s.cpad
             tab[i, SN_FWD_OFF] = fwd_off
             s.fwd_off = fwd_off
-            fwd_off += s.K * s.T * s.cpad
+            fwd_off += s.K * s.T * s.cpad * (2 if s.hp else 1)
             if s.needs_dgrad:
                 tab[i, SN_BWD_OFF] = bwd_off
                 s.bwd_off = bwd_off
@@ -139,7 +140,7 @@ class WeightBank(object):
         def pack_rows(sel):
             rows = []
             for s in sel:
-                rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad + 255) // 256)]
+                rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad * (2 if s.hp else 1) + 255) // 256)]
                 if s.needs_dgrad:
                     rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
             return rows
@@ -244,7 +245,7 @@ class WeightBank(object):
             rows = []
             for s in self.specs:
                 if s.spectral and plan['ncalls'][s.layer_id] > call:
-                    rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad + 255) // 256)]
+                    rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad * (2 if s.hp else 1) + 255) // 256)]
                     if s.needs_dgrad:
                         rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
             plan[key] = (torch.tensor(rows, dtype=torch.int32).reshape(-1).to(self.device), len(rows))
