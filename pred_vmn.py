@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Inference entry point with the reference's call surface (pred_vmn.py:28-140): --model/--load/--trimap/--agg_window,
+`FullModel_VMD('vmn_' + model, dilate_kernel in {5,12,20}, agg_window)`, eval mode, 3-frame windows at 1088x1920
+(1080 is not a multiple of 32), the 5-loss dict, and the centre-frame `uint8(alpha*255)` crop [:1080, :1920] —
+on the MI355X HIP path with synthetic clips (PNG I/O and the dataset are out of scope).
+
+    python pred_vmn.py --model gca --trimap medium [--load checkpoint.pth.tar] [--clips 2] [--save out_dir]
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from models.model import FullModel_VMD
+from tcvom_amd.synthetic import synthetic_window
+
+DILATE = {'narrow': 5, 'medium': 12, 'wide': 20}          # pred_vmn.py:68-75
+
+
+def forward_pretrain(model, dp):
+    fg, bg, a, idx = dp
+    with torch.no_grad():
+        out = model(a, fg, bg)
+    loss = {k: out[i].sum().item() for i, k in enumerate(('L_alpha', 'L_comp', 'L_grad', 'L_dt', 'L_att'))}
+    loss['L_total'] = sum(loss.values())
+    return [*out[5:], loss, idx]
+
+
+def main(args):
+    device = torch.device('cuda', 0)
+    model = FullModel_VMD(model='vmn_' + args.model, dilate_kernel=DILATE[args.trimap], agg_window=int(args.agg_window))
+    if args.load:
+        missing, unexpected = model.NET.load_state_dict(torch.load(args.load, map_location='cpu'), strict=False)
+        print('Missing keys: ' + str(sorted(missing)))
+        print('Unexpected keys: ' + str(sorted(unexpected)))
+    model = model.to(device).eval()
+    H, W, h, w = 1088, 1920, 1080, 1920
+    totals = {}
+    for clip in range(args.clips):
+        a, fg, bg = (t.to(device) for t in synthetic_window(1, 3, H, W, seed=clip))
+        _, tris, alphas, _, _, _, _, loss, _ = forward_pretrain(model, (fg, bg, a, torch.tensor([clip])))
+        for k, v in loss.items():
+            totals[k] = totals.get(k, 0.0) + v
+        c = 1
+        alpha = np.uint8(alphas[0, c, 0, :h, :w].float().cpu().numpy() * 255)
+        tri = np.uint8(tris[0, c, 0, :h, :w].float().cpu().numpy() * 255)
+        if args.save:
+            os.makedirs(args.save, exist_ok=True)
+            np.save(os.path.join(args.save, 'clip%03d_pred.npy' % clip), alpha)
+            np.save(os.path.join(args.save, 'clip%03d_tri.npy' % clip), tri)
+    for k in sorted(totals):
+        print('%s: %.6f' % (k, totals[k] / args.clips))
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', required=True, choices=['gca'], help='base matting network (HIP path: gca)')
+    ap.add_argument('--load', default=None, help='checkpoint (NET.state_dict layout of the reference)')
+    ap.add_argument('--trimap', required=True, choices=list(DILATE))
+    ap.add_argument('--agg_window', default=7)
+    ap.add_argument('--clips', type=int, default=1)
+    ap.add_argument('--save', default=None)
+    main(ap.parse_args())

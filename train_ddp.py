@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Training entry point with the reference's call surface (train_ddp.py:40-100,178-349): same config keys,
+same model construction, loss composition L_alpha + L_comp + L_grad + 0.5 L_dt + 0.25 L_att, Adam with weight decay,
+poly learning-rate schedule, checkpoint of `model.NET.state_dict()` per epoch — on the MI355X HIP path, one process
+per GPU, gradients averaged over RCCL.
+
+    python train_ddp.py --cfg cfgs/vmd_vmn_gca_synthetic.yaml TRAIN.TOTAL_STEPS 1
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_ddp.py --cfg ...
+
+The reference reads VideoMatting108 from disk (dataset/VMD.py); that data front-end is out of scope,
+so clips here are the synthetic windows of tcvom_amd/synthetic.py with the loader's output contract
+(fg, bg, a, idx: float32 0..255, BGR, [B,S,C,H,W]; dataset/VMD.py:293-301).
+"""
+import argparse
+import logging
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from models.model import FullModel_VMD
+from tcvom_amd.config import get_cfg_defaults
+from tcvom_amd.ddp import GradientAverager, broadcast_module_state, reduce_tensor
+from tcvom_amd.optim import FusedAdam
+from tcvom_amd.synthetic import synthetic_window
+
+
+def poly_lr(optimizer, base_lr, max_iters, cur_iters, power=0.9):
+    """utils/utils.py:185-188."""
+    lr = base_lr * ((1 - float(cur_iters) / max_iters) ** power)
+    optimizer.param_groups[0]['lr'] = lr
+    return lr
+
+
+def const_lr(optimizer, base_lr, max_iters, cur_iters):
+    return base_lr
+
+
+STR_DICT = {'poly': poly_lr, 'const': const_lr}
+
+
+class SyntheticClips(object):
+    """Stands in for DataLoader(VideoMattingDataset(...)): yields (fg, bg, a, idx) batches."""
+
+    def __init__(self, batch, frames, size, steps, seed):
+        self.batch, self.frames, self.size, self.steps, self.seed = batch, frames, size, steps, seed
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            a, fg, bg = synthetic_window(self.batch, self.frames, self.size[0], self.size[1], seed=self.seed + 1000 * i)
+            yield fg, bg, a, torch.arange(self.batch)
+
+
+def train(epoch, loader, base_lr, total_epochs, optimizer, averager, model, adjust_lr, print_freq, rank, device):
+    model.train()
+    steps_per_epoch = len(loader)
+    tic = time.time()
+    for i_iter, (fg, bg, a, _) in enumerate(loader):
+        out = model(a.to(device), fg.to(device), bg.to(device))
+        L_alpha, L_comp, L_grad, L_dt, L_att = (out[k].mean() for k in range(5))
+        loss = L_alpha + L_comp + L_grad + 0.5 * L_dt + 0.25 * L_att          # train_ddp.py:56-61
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        averager.average()
+        optimizer.step()
+        reduced = reduce_tensor(loss.detach())
+        cur = epoch * steps_per_epoch + i_iter
+        lr = adjust_lr(optimizer, base_lr, total_epochs * steps_per_epoch, cur)
+        if i_iter % print_freq == 0 and rank == 0:
+            logging.info('Iter:[%d/%d], Time: %.2f, lr: %.3e, Loss: %.6f, L_alpha: %.4f L_comp: %.4f L_grad: %.4f '
+                         'L_dt: %.4f L_att: %.4f', cur, total_epochs * steps_per_epoch, time.time() - tic, lr,
+                         float(reduced), float(L_alpha), float(L_comp), float(L_grad), float(L_dt), float(L_att))
+            tic = time.time()
+
+
+def main(cfg_name, cfg, steps_per_epoch, frames):
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group(backend='nccl', init_method='env://')
+    if cfg.SYSTEM.RANDOM_SEED > 0:
+        torch.manual_seed(cfg.SYSTEM.RANDOM_SEED + rank)
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format='%(asctime)-15s %(message)s')
+    out_dir = os.path.join(cfg.SYSTEM.OUTDIR, cfg_name + cfg.SYSTEM.EXP_SUFFIX)
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+
+    model = FullModel_VMD(model=cfg.MODEL, agg_window=cfg.AGG_WINDOW)
+    if cfg.TRAIN.LOAD_CKPT:
+        dct = torch.load(cfg.TRAIN.LOAD_CKPT, map_location='cpu')
+        missing, unexpected = model.NET.load_state_dict(dct, strict=False)
+        logging.info('Missing keys: %s', sorted(missing))
+        logging.info('Unexpected keys: %s', sorted(unexpected))
+    model = model.to(device)
+    broadcast_module_state(model)                                  # DDP constructor semantics (train_ddp.py:275-280)
+    params = [p for p in model.parameters() if p.requires_grad]
+    logging.info('=> Total Parameters: %d', sum(p.numel() for p in params))
+    assert cfg.TRAIN.OPTIMIZER == 'adam', 'only Adam (the optimizer of every reference config) is on the HIP path'
+    optimizer = FusedAdam(params, lr=cfg.TRAIN.BASE_LR, weight_decay=cfg.TRAIN.WEIGHT_DECAY)
+    if cfg.TRAIN.LOAD_OPT:
+        optimizer.load_state_dict(torch.load(cfg.TRAIN.LOAD_OPT, map_location='cpu'))
+    averager = GradientAverager(params)
+    adjust_lr = STR_DICT[cfg.TRAIN.LR_STRATEGY]
+    loader = SyntheticClips(cfg.TRAIN.BATCH_SIZE_PER_GPU, frames, tuple(cfg.TRAIN.TRAIN_INPUT_SIZE), steps_per_epoch,
+                            seed=max(cfg.SYSTEM.RANDOM_SEED, 0) + rank)
+    for epoch in range(cfg.TRAIN.TOTAL_STEPS):
+        train(epoch, loader, cfg.TRAIN.BASE_LR, cfg.TRAIN.TOTAL_STEPS, optimizer, averager, model, adjust_lr,
+              cfg.TRAIN.PRINT_FREQ, rank, device)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            weight_fn = os.path.join(out_dir, 'checkpoint_%d.pth.tar' % (epoch + 1))
+            torch.save(model.NET.state_dict(), weight_fn)           # the reference's checkpoint format (train_ddp.py:338)
+            torch.save(optimizer.state_dict(), os.path.join(out_dir, 'optimizer_%d.pth.tar' % (epoch + 1)))
+            logging.info('=> saved %s', weight_fn)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser(description='Train network')
+    ap.add_argument('--cfg', required=True, type=str)
+    ap.add_argument('--local_rank', type=int, default=-1)
+    ap.add_argument('--steps-per-epoch', type=int, default=4, help='synthetic clips per epoch')
+    ap.add_argument('--frames', type=int, default=5, help='sample_length (dataset/VMD.py:28)')
+    ap.add_argument('opts', default=None, nargs=argparse.REMAINDER)
+    args = ap.parse_args()
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(args.cfg)
+    cfg.merge_from_list(args.opts)
+    main(os.path.splitext(os.path.basename(args.cfg))[0], cfg, args.steps_per_epoch, args.frames)
