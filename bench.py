@@ -124,6 +124,8 @@ def main():
     ap.add_argument('--width', type=int, default=FULL_W)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='SyncBatchNorm statistics over ranks, as train_ddp.py:271-273 (adds 2 small all-reduces per BN call)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -136,11 +138,13 @@ def main():
         dist.init_process_group(backend='nccl', init_method='env://')
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
 
-    from tcvom_amd.ddp import GradientAverager, broadcast_module_state
+    from tcvom_amd.ddp import GradientAverager, broadcast_module_state, convert_sync_batchnorm
     from tcvom_amd.facade import train_step_loss
     from tcvom_amd.optim import FusedAdam
     H, W = args.height, args.width
     model, a, fg, bg = build(device, H, W, seed=rank)
+    if args.sync_bn:
+        convert_sync_batchnorm(model)
     broadcast_module_state(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, weight_decay=1e-4)
@@ -187,7 +191,7 @@ def main():
             'config': {'workload': 'GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
                                    '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
                                    'formula-initialised weights, train mode' % (H, W),
-                       'global_batch_clips': world, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world},
+                       'global_batch_clips': world, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn)},
             'final_loss': round(final_loss, 6),
             'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5),
         }

@@ -402,6 +402,76 @@ extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32
     return TCVOM_OK;
 }
 
+// ---------------------------------------------------------------- cross-rank (SyncBatchNorm) statistics
+// The reference converts every BatchNorm to SyncBatchNorm before DDP (train_ddp.py:213): the per-channel sums are
+// added over the ranks before mean / variance (forward) and before the dx coefficients (backward).  The host does
+// the all-reduce (RCCL) on a [2][C] fp64 vector between these calls.
+template <typename PT>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ partial, int G, int C, double* __restrict__ sums) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int g = sl; g < G; g += 8) {
+            a += (double)partial[(int64_t)g * 2 * C + c];
+            b += (double)partial[(int64_t)g * 2 * C + C + c];
+        }
+    }
+    s1[sl][cl] = a;
+    s2[sl][cl] = b;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        sums[c] = a;
+        sums[C + c] = b;
+    }
+}
+
+__global__ void bn_local_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)sums[c];
+    if (dgamma) dgamma[c] = (float)sums[C + c];
+}
+
+extern "C" int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_t C, double* sums, double* scratch, void* stream) {
+    TCVOM_CHECK_ARG(partial && sums && groups > 0 && C > 0, "bn_reduce_sums: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (groups > 4 * BN_SLICES && scratch) {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(bn_sums_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, sums);
+    } else {
+        hipLaunchKernelGGL(bn_sums_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C, sums);
+    }
+    TCVOM_LAUNCH_CHECK("bn_reduce_sums");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t unbias_count, const float* gamma,
+                                      const float* beta, float eps, float* scale_shift, float* saved, void* stream) {
+    TCVOM_CHECK_ARG(sums && gamma && beta && scale_shift && saved && C > 0 && count > 0, "bn_finalize_sums: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, sums, 1, C, (double)count,
+                       (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps,
+                       scale_shift, saved);
+    TCVOM_LAUNCH_CHECK("bn_finalize_sums");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
+                                          const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
+                                          void* stream) {
+    TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0, "bn_bwd_finalize_sums: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, sums_all, 1, C, (double)count, gamma,
+                       saved, (float*)nullptr, (float*)nullptr, coef);
+    // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
+    hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta);
+    TCVOM_LAUNCH_CHECK("bn_bwd_finalize_sums");
+    return TCVOM_OK;
+}
+
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                                   int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, void* stream) {

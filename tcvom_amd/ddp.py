@@ -29,6 +29,18 @@ def broadcast_module_state(module, src=0):
             off += n
 
 
+def convert_sync_batchnorm(module, process_group=None):
+    """`nn.SyncBatchNorm.convert_sync_batchnorm` (train_ddp.py:213) for the HIP network: every BatchNorm of
+    `module` takes its train-mode statistics over the clips of all ranks of `process_group`.  The modules keep
+    their class and state_dict keys; tcvom_amd.ops.conv_bn_act reads the two attributes set here and inserts one
+    [2][C] fp64 all-reduce per BatchNorm call in forward and one in backward."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.sync = True
+            m.sync_group = process_group
+    return module
+
+
 class GradientAverager(object):
     """All-reduce(mean) of the gradients of `params` in flat buckets.  Parameters whose .grad is None on
     this rank (unused in this step: DDP's find_unused_parameters=True case) contribute zeros."""

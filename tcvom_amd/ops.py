@@ -7,6 +7,7 @@ Tensors between ops are NHWC bf16 (`[N,H,W,C]`, contiguous).
 import ctypes as C
 
 import torch
+import torch.distributed as dist
 
 from . import _lib as L
 from .conv_plan import ConvGeometry, dense_desc, dense_tt_desc
@@ -42,6 +43,16 @@ class ConvCfg(object):
         if g is None:
             g = self._geo[key] = ConvGeometry(self.spec, N, H, W)
         return g
+
+
+def _sync_group(bn):
+    """(process group, world size) when `bn` was converted by tcvom_amd.ddp.convert_sync_batchnorm and more than one
+    rank is running, else None."""
+    if not getattr(bn, 'sync', False) or not dist.is_available() or not dist.is_initialized():
+        return None
+    group = getattr(bn, 'sync_group', None)
+    world = dist.get_world_size(group)
+    return (group, world) if world > 1 else None
 
 
 def _phase_array(descs):
@@ -104,9 +115,21 @@ class _ConvBNAct(torch.autograd.Function):
             P = geo.out_pixels
             groups = stats.numel() // (2 * K)
             scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
-            L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
-                   L.ptr(gamma), L.ptr(beta), None, None,
-                   float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
+            sync = _sync_group(bn)
+            if sync is None:
+                L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
+                       L.ptr(gamma), L.ptr(beta), None, None,
+                       float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
+            else:
+                # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size)
+                group, world = sync
+                sums = torch.empty(2 * K, dtype=torch.float64, device=x.device)
+                L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, K, L.ptr(sums), L.ptr(scratch), st)
+                dist.all_reduce(sums, group=group)
+                P = P * world
+                L.call('tcvom_bn_finalize_sums', L.ptr(sums), K, P, P * cfg.unbias_mult, L.ptr(gamma), L.ptr(beta),
+                       float(bn.eps), L.ptr(ss), L.ptr(saved), st)
+            ctx.sync = sync
             # running statistics / num_batches_tracked are updated after the window, in call order (frames run on
             # concurrent streams; the EMA is order dependent)
             bank.pending_bn.append((bn, saved, P * cfg.unbias_mult))
@@ -145,8 +168,18 @@ class _ConvBNAct(torch.autograd.Function):
             dbeta = torch.empty(K, dtype=torch.float32, device=dz.device)
             coef = torch.empty(3 * K, dtype=torch.float32, device=dz.device)
             scratch = torch.empty(128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
-            L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma), L.ptr(dbeta),
-                   L.ptr(coef), L.ptr(scratch), st)
+            sync = ctx.sync if ctx.training else None
+            if sync is None:
+                L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma),
+                       L.ptr(dbeta), L.ptr(coef), L.ptr(scratch), st)
+            else:
+                group, world = sync
+                local = torch.empty(2 * K, dtype=torch.float64, device=dz.device)
+                L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), st)
+                total = local.clone()
+                dist.all_reduce(total, group=group)
+                L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), L.ptr(saved),
+                       L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), st)
             dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)

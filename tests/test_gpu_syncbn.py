@@ -1,0 +1,132 @@
+"""SyncBatchNorm statistic exchange (train_ddp.py:271-273): two ranks holding one clip each must produce what ONE
+process holding both clips produces.  Both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device); the kernels and the [2][C] fp64 all-reduce call sites are the ones the 8-GPU job runs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _block(dev, sync, tag):
+    import torch.nn as nn
+    from tcvom_amd import ops
+    from tcvom_amd.ddp import convert_sync_batchnorm
+    from tcvom_amd.synthetic import formula_tensor
+    from tcvom_amd.weights import ConvSpec, WeightBank
+    Ci, Co = 64, 128
+    w = nn.Parameter((formula_tensor('sync.w', (Co, Ci, 3, 3)) * 0.1).to(dev))
+    bn = nn.BatchNorm2d(Co).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(formula_tensor('sync.gamma', (Co,)) * 0.5 + 1.0)
+        bn.bias.copy_(formula_tensor('sync.beta', (Co,)) * 0.2)
+    if sync:
+        convert_sync_batchnorm(bn)
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, None, None, None, False, 1, 1, 'frame')
+    bank.register(spec)
+    return w, bn, bank, ops.ConvCfg(bank, spec, bn=bn, act=ops.ACT_RELU)
+
+
+def _run(cfg, bank, bn, w, x, dz):
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    token = bank_token(bank, 1, True)
+    x = x.clone().requires_grad_(True)
+    z = ops.conv_bn_act(cfg, x, token, True)
+    bank.flush_bn_counters()
+    z.backward(dz)
+    torch.cuda.synchronize()
+    return (z.detach().float(), x.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+            bn.running_mean.clone(), bn.running_var.clone())
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        from tcvom_amd.synthetic import formula_tensor
+        xs = (formula_tensor('sync.x', (2, 24, 40, 64)) * 2).to(dev)
+        xs[1] = xs[1] * 1.7 + 0.3                      # the two clips have different statistics
+        xs = xs.to(torch.bfloat16)
+        dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(torch.bfloat16)
+        w, bn, bank, cfg = _block(dev, True, 'sync')
+        got = _run(cfg, bank, bn, w, xs[rank:rank + 1].contiguous(), dzs[rank:rank + 1].contiguous())
+        dg = got[2].clone(); db = got[3].clone()
+        dist.all_reduce(dg); dist.all_reduce(db)
+        if rank == 0:
+            w2, bn2, bank2, cfg2 = _block(dev, False, 'nosync')
+            ref = _run(cfg2, bank2, bn2, w2, xs, dzs)
+            res = dict(z=(got[0] - ref[0][0:1]).abs().max().item(), zmax=ref[0].abs().max().item(),
+                       dx=(got[1] - ref[1][0:1]).abs().max().item(), dxmax=ref[1].abs().max().item(),
+                       dg=(dg - ref[2]).abs().max().item(), dgmax=ref[2].abs().max().item(),
+                       db=(db - ref[3]).abs().max().item(), dbmax=ref[3].abs().max().item(),
+                       rm=(got[4] - ref[4]).abs().max().item(), rv=(got[5] - ref[5]).abs().max().item())
+            torch.save(res, out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_match_one_process_batch(tmp_path):
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    print(r)
+    assert r['z'] <= 2e-2 * r['zmax'], r          # one bf16 ulp of the output
+    assert r['dx'] <= 2e-2 * r['dxmax'], r
+    assert r['dg'] <= 2e-3 * r['dgmax'] and r['db'] <= 2e-3 * r['dbmax'], r
+    assert r['rm'] <= 1e-5 and r['rv'] <= 1e-5, r
+
+
+def _window_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        from tcvom_amd.ddp import convert_sync_batchnorm
+        from tcvom_amd.facade import FullModel_VMD
+        from tcvom_amd.synthetic import formula_tensor, synthetic_window
+
+        def make(sync):
+            m = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+            m.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()})
+            m = m.to(dev).train()
+            return convert_sync_batchnorm(m) if sync else m
+        clips = [[t.to(dev) for t in synthetic_window(1, 3, 128, 160, seed=20 + i)] for i in range(2)]
+        m = make(True)
+        a, fg, bg = clips[rank]
+        outs = m(a, fg, bg)
+        alpha = outs[7].detach().float().clone()
+        if rank == 0:
+            m2 = make(False)
+            a2, fg2, bg2 = [torch.cat([clips[0][k], clips[1][k]], 0) for k in range(3)]
+            outs2 = m2(a2, fg2, bg2)
+            ref = outs2[7].detach().float()[0:1]
+            torch.save(dict(mse=((alpha - ref) ** 2).mean().item()), out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_window_forward(tmp_path):
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_window_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    print(r)
+    assert r['mse'] <= 1e-4, r

@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from models.model import FullModel_VMD
 from tcvom_amd.config import get_cfg_defaults
-from tcvom_amd.ddp import GradientAverager, broadcast_module_state, reduce_tensor
+from tcvom_amd.ddp import GradientAverager, broadcast_module_state, convert_sync_batchnorm, reduce_tensor
 from tcvom_amd.optim import FusedAdam
 from tcvom_amd.synthetic import synthetic_window
 
@@ -99,6 +99,8 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
         logging.info('Missing keys: %s', sorted(missing))
         logging.info('Unexpected keys: %s', sorted(unexpected))
     model = model.to(device)
+    if not cfg.MODEL.endswith('fba'):
+        convert_sync_batchnorm(model)                              # train_ddp.py:271-273: SyncBN unless FBA
     broadcast_module_state(model)                                  # DDP constructor semantics (train_ddp.py:275-280)
     params = [p for p in model.parameters() if p.requires_grad]
     logging.info('=> Total Parameters: %d', sum(p.numel() for p in params))
