@@ -23,6 +23,36 @@ struct TcvomPhases { tcvom_conv_desc d[4]; int n; };
 // bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS 16-byte slot `cpos` of row r holds
 // k-chunk cpos ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows covering all residues mod 16) then touches 16
 // distinct 4-bank quads.  Out-of-image taps and dummy taps read a 16-byte zero page instead of branching.
+// p / d and p % d for 0 <= p < 2^24 (exact in fp32): one multiply by the reciprocal and a +-1 fix-up instead of the
+// ~40-instruction integer division sequence; the tile prologues and epilogues do several of these per row.
+__device__ __forceinline__ void divmod24(int p, int dv, float rcp, int& q, int& r) {
+    q = (int)((float)p * rcp);
+    r = p - q * dv;
+    if (r < 0) { r += dv; --q; }
+    else if (r >= dv) { r -= dv; ++q; }
+}
+__device__ __forceinline__ void divmod_any(int p, int dv, float rcp, bool small, int& q, int& r) {
+    if (small) divmod24(p, dv, rcp, q, r);
+    else { q = p / dv; r = p - q * dv; }
+}
+// bits b = 0..15 set where 0 <= x0 + (b - 8) < n
+__device__ __forceinline__ unsigned range_bits16(int x0, int n) {
+    int lo = 8 - x0, hi = n + 7 - x0;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 15 ? 15 : hi;
+    if (hi < lo) return 0u;
+    return ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+
+#ifdef NT_TRACE
+__device__ unsigned long long tcvom_trace_buf[8192];
+extern "C" int tcvom_trace_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tcvom_trace_buf), n * sizeof(unsigned long long));
+}
+#define TRACE(i) if (trace_on && (s) < 256) tcvom_trace_buf[((s) * 4 + (i)) + 4 * 256 * trace_w] = __builtin_readcyclecounter()
+#else
+#define TRACE(i)
+#endif
 template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const bf16raw* __restrict__ in, const bf16raw* __restrict__ wgt, void* __restrict__ outp,
@@ -31,6 +61,9 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 {
     // up to 4 phases (sub-pixel phases of a transposed conv / stride-2 data gradient) share ONE launch: blockIdx.z
     // selects the phase, so their small grids fill the chip together
+#ifdef NT_TRACE
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
     const int phase = ps.n > 1 ? blockIdx.z : 0;
     const tcvom_conv_desc& d = ps.d[phase];
     const int bz = ps.n > 1 ? 0 : blockIdx.z;
@@ -46,7 +79,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 
     static_assert(NST >= 2 && NST <= 4, "2..4 ring slots");
     __shared__ __attribute__((aligned(16))) bf16raw lds[NST * SLOT + 8 * TCVOM_MAX_TAPS];
-    int* taps = reinterpret_cast<int*>(lds + NST * SLOT);   // [16][3]: input offset, weight offset, validity bit
+    int4* taps = reinterpret_cast<int4*>(lds + NST * SLOT);   // per tap: input offset, weight offset (-1: dummy), mask bits
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,15 +106,17 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     }
     const int C = d.C, H = d.H, W = d.W, K = d.K, WT = d.wt;
     if (tid < TCVOM_MAX_TAPS) {
+        const int dh = d.tap_dh[tid], dw = d.tap_dw[tid];
         const bool ok = tid < d.ntaps && d.tap_w[tid] >= 0;
-        taps[tid * 3 + 0] = (d.tap_dh[tid] * W + d.tap_dw[tid]) * C;
-        taps[tid * 3 + 1] = ok ? d.tap_w[tid] * C : -1;
-        taps[tid * 3 + 2] = ok ? 1 : 0;
+        // bit positions of this tap in a row's validity word: rows bit dh+8, columns bit 16+dw+8 (|dh|,|dw| <= 7)
+        taps[tid] = make_int4((dh * W + dw) * C, ok ? d.tap_w[tid] * C : -1, dh + 8, ok ? dw + 8 : 31);
     }
     const int cshift = (d.ntaps == 1) ? 31 : __builtin_ctz(C);
     const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
     const int p0 = bx * TN;
     const int m0 = blockIdx.y * TM;
+    const bool small_p = Ptot < (1 << 24);
+    const float rcp_pw = 1.0f / (float)d.PW, rcp_ph = 1.0f / (float)d.PH;
 
     // this lane's k-chunk within a 64-deep step (same for all of its DMA instructions, see header comment)
     const int kc8 = (((lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7)) << 3);
@@ -93,29 +128,34 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         const int m = m0 + (it * NW + wave) * 8 + (lane >> 3);
         a_off[it] = m < K ? m * WT * C : -1;
     }
+    // b_valid: bit t set when tap t of this pixel row falls inside the image (and is not a dummy tap)
     int b_off[B_IT];
-    unsigned b_valid[B_IT];
+    unsigned b_valid[B_IT], b_hm[B_IT], b_wm[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int p = p0 + (it * NW + wave) * 8 + (lane >> 3);
         b_off[it] = 0;
-        b_valid[it] = 0u;
+        b_valid[it] = b_hm[it] = b_wm[it] = 0u;
         if (p < Ptot) {
-            const int j = p % d.PW;
-            const int t = p / d.PW;
-            const int i = t % d.PH;
-            const int n = t / d.PH;
+            int t, j, n, i;
+            divmod_any(p, d.PW, rcp_pw, small_p, t, j);
+            divmod_any(t, d.PH, rcp_ph, small_p, n, i);
             const int ih0 = i * d.in_step, iw0 = j * d.in_step;
             b_off[it] = ((n * H + ih0) * W + iw0) * C;
-            unsigned msk = 0u;
-            for (int tp = 0; tp < d.ntaps; ++tp) {
-                const int ih = ih0 + d.tap_dh[tp], iw = iw0 + d.tap_dw[tp];
-                if (d.tap_w[tp] >= 0 && ih >= 0 && ih < H && iw >= 0 && iw < W) msk |= 1u << tp;
-            }
-            b_valid[it] = msk;
+            b_hm[it] = range_bits16(ih0, H);
+            b_wm[it] = range_bits16(iw0, W);
         }
     }
     __syncthreads();
+    {
+        const int nt = d.ntaps;
+#pragma unroll 4
+        for (int tp = 0; tp < nt; ++tp) {
+            const int4 tq = taps[tp];
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) b_valid[it] |= (((b_hm[it] >> tq.z) & (b_wm[it] >> tq.w)) & 1u) << tp;
+        }
+    }
 
     f32x16_t acc[MI][NI];
 #pragma unroll
@@ -133,7 +173,8 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     {                                                                                                      \
         const int kk = (s) * 64 + kc8;                                                                     \
         const int tap = kk >> cshift, c0 = kk & cmask;                                                     \
-        const int tin = taps[tap * 3 + 0], tw = taps[tap * 3 + 1];                                         \
+        const int4 tq = taps[tap];                                                                         \
+        const int tin = tq.x, tw = tq.y;                                                                   \
         bf16raw* abase = lds + (slot) * SLOT;                                                              \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                              \
             const bf16raw* src = (a_off[it] >= 0 && tw >= 0) ? wgt + (a_off[it] + tw + c0) : zero_page;    \
@@ -151,18 +192,29 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const int a_row = wm * WM + (lane & 31), b_row = wn * WN + (lane & 31);
     const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;
 
-    // NST-slot ring: stages s+1 .. s+NST-2 stay in flight across the barrier (counted vmcnt), which hides the DMA
-    // latency for the layers that are latency- rather than throughput-bound (small grids, small K)
     constexpr int LPS = A_IT + B_IT;                    // DMA instructions per wave per stage
+    // NST-slot ring: stages s+1 .. s+NST-2 stay in flight across the barrier (counted vmcnt), which hides the
+    // DMA latency for the layers that are latency- rather than throughput-bound (small grids, small K)
 #pragma unroll
     for (int ps = 0; ps < NST - 1; ++ps)
         if (ps < nstage) NT_ISSUE_STAGE(ps, ps);
     int slot = 0, islot = NST - 1;
+#ifdef NT_TRACE
+    const bool trace_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW - 1);
+    const int trace_w = wave == 0 ? 0 : 1;
+#endif
+#ifdef NT_TRACE
+    if (trace_on) { tcvom_trace_buf[4096 + trace_w * 8 + 0] = t_entry; tcvom_trace_buf[4096 + trace_w * 8 + 1] = __builtin_readcyclecounter(); }
+#endif
     for (int s = 0; s < nstage; ++s) {
+        TRACE(0);
         if (s + NST - 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE(1);
         __builtin_amdgcn_s_barrier();
+        TRACE(2);
         if (s + NST - 1 < nstage) NT_ISSUE_STAGE(s + NST - 1, islot);
+        TRACE(3);
         const bf16raw* As = lds + slot * SLOT;
         const bf16raw* Bs = As + TM * 64;
 #pragma unroll
@@ -184,6 +236,9 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         slot = slot + 1 == NST ? 0 : slot + 1;
         islot = islot + 1 == NST ? 0 : islot + 1;
     }
+#ifdef NT_TRACE
+    if (trace_on) tcvom_trace_buf[4096 + trace_w * 8 + 2] = __builtin_readcyclecounter();
+#endif
 #undef NT_ISSUE_STAGE
 
     // ------------------------------------------------------------------ epilogue
@@ -196,10 +251,9 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         pvalid[b] = p < Ptot;
         pglob[b] = p;
         const int pp = pvalid[b] ? p : 0;
-        const int j = pp % d.PW;
-        const int t = pp / d.PW;
-        const int i = t % d.PH;
-        const int n = t / d.PH;
+        int t, j, n, i;
+        divmod_any(pp, d.PW, rcp_pw, small_p, t, j);
+        divmod_any(t, d.PH, rcp_ph, small_p, n, i);
         out_off[b] = ((int64_t)(n * d.OH + i * d.out_step + d.out_off_h) * d.OW + j * d.out_step + d.out_off_w) * d.ldo;
         if (d.batch > 1) out_off[b] += (int64_t)bz * d.out_bstride;
     }
@@ -261,6 +315,12 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
             }
         }
     }
+#ifdef NT_TRACE
+    if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW - 1)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tcvom_trace_buf[4096 + (wave == 0 ? 0 : 1) * 8 + 3] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 // Tile configuration.  The ResNet layers all have the same FLOP count but very different pixel counts: at
@@ -289,6 +349,9 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     const int nb = nphase > 1 ? nphase : (d->batch > 1 ? d->batch : 1);
     if (d->K >= 128) {
         const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
+        // the dense attention GEMMs of GCA (8160 x 8160 x 576 / 8160 x 2048 x 8160 at 1080p): 256x256 tiles halve the
+        // L2->LDS bytes per MFMA, which is what bounds the 128x128 loop (measured 818 -> 1012 TFLOP/s on P.V)
+        if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
         if (wgs >= 512) return {128, 128, 4};
         if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
         return {64, 64, 2};
@@ -314,6 +377,9 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     for (int i = 0; i < nphase; ++i) {
         const tcvom_conv_desc* d = descs + i;
         TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "conv_igemm: ntaps=%d", d->ntaps);
+        for (int t = 0; t < d->ntaps; ++t)
+            TCVOM_CHECK_ARG(d->tap_dh[t] >= -8 && d->tap_dh[t] <= 7 && d->tap_dw[t] >= -8 && d->tap_dw[t] <= 7,
+                            "conv_igemm: tap %d offset (%d,%d) outside [-8,7]", t, d->tap_dh[t], d->tap_dw[t]);
         TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 64 == 0, "conv_igemm: ntaps*C=%d not a multiple of 64", d->ntaps * d->C);
         TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "conv_igemm: C=%d must be a power of two >= 8", d->C);
         TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
@@ -335,16 +401,16 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     const bf16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
-    if (c.tm == 128 && c.tn == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 64, 32, 2>), grid, dim3(512), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
-    else if (c.tm == 128)
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 32, 32, 3>), grid, dim3(512), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
-    else if (c.tm == 64 && c.tn == 64)
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 32, 32, 4>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
-    else if (c.tm == 64)
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 128, 32, 64, 3>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
-    else
-        hipLaunchKernelGGL((igemm_nt_kernel<32, 256, 32, 64, 2>), grid, dim3(256), 0, st, ip, wp, out, bias, mscale, mdiag, stats_partial, zp, ps);
+#define NT_LAUNCH(threads, ...)                                                                                          \
+    hipLaunchKernelGGL((igemm_nt_kernel<__VA_ARGS__>), grid, dim3(threads), 0, st, ip, wp, out, bias, mscale, mdiag,     \
+                       stats_partial, zp, ps)
+    if (c.tm == 256) NT_LAUNCH(512, 256, 256, 128, 64, 2);
+    else if (c.tm == 128 && c.tn == 128) NT_LAUNCH(512, 128, 128, 64, 32, 2);
+    else if (c.tm == 128) NT_LAUNCH(512, 128, 64, 32, 32, 3);
+    else if (c.tm == 64 && c.tn == 64) NT_LAUNCH(256, 64, 64, 32, 32, 4);
+    else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 3);
+    else NT_LAUNCH(256, 32, 256, 32, 64, 2);
+#undef NT_LAUNCH
     TCVOM_LAUNCH_CHECK("conv_igemm");
     return TCVOM_OK;
 }
@@ -432,6 +498,8 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const int n0 = blockIdx.y * TN;
     const int m0 = blockIdx.z * TM;
     const int PW = d.PW, PH = d.PH;
+    const bool small_p = Ptot + 64 * 4 < (1 << 24);     // rows past the chunk end are divided too
+    const float rcp_pw = 1.0f / (float)PW, rcp_ph = 1.0f / (float)PH;
 
     // ---- per-lane DMA state: A = dy tile [64][TM], B = gathered input tile [64][TN]
     int a_col[TA::IT], a_n[TA::IT], a_i[TA::IT], a_j[TA::IT];
@@ -444,10 +512,9 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
         a_col[it] = m0 + cs * 8;
         a_ok[it] = ii < TA::NI && (a_col[it] + 8) <= ldy;
         const int p = pbeg + row;
-        a_j[it] = p % PW;
-        const int t = p / PW;
-        a_i[it] = t % PH;
-        a_n[it] = t / PH;
+        int t;
+        divmod_any(p, PW, rcp_pw, small_p, t, a_j[it]);
+        divmod_any(t, PH, rcp_ph, small_p, a_n[it], a_i[it]);
     }
     int b_c0[TB::IT], b_dh[TB::IT], b_dw[TB::IT], b_n[TB::IT], b_i[TB::IT], b_j[TB::IT];
     bool b_ok[TB::IT];
@@ -467,10 +534,9 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
             b_ok[it] = taps[tap * 3 + 2] >= 0;
         }
         const int p = pbeg + row;
-        b_j[it] = p % PW;
-        const int t = p / PW;
-        b_i[it] = t % PH;
-        b_n[it] = t / PH;
+        int t;
+        divmod_any(p, PW, rcp_pw, small_p, t, b_j[it]);
+        divmod_any(t, PH, rcp_ph, small_p, b_n[it], b_i[it]);
     }
 
     f32x16_t acc[MI][NI];
@@ -570,7 +636,11 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#ifdef TT_SKIP_ATOMICS
+                if (m < K && acc[a][b][r] == 12345.678f) dw[((int64_t)m * d.wt + ws) * C + cc] = 1.f;
+#else
                 if (m < K) atomicAdd(dw + ((int64_t)m * d.wt + ws) * C + cc, acc[a][b][r]);
+#endif
             }
         }
     }

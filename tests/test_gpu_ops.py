@@ -216,6 +216,26 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
 
 
 # --------------------------------------------------------------------------------------------- spectral norm
+@pytest.mark.parametrize('rows_b,rows_a,kred,fp32', [(4100, 4096, 192, True), (4000, 4608, 320, False)])
+def test_dense_gemm_256_tile_config(rows_b, rows_a, kred, fp32):
+    """Dense NT GEMM at sizes that select the 256x256 tile (the GCA score / P.V GEMMs at 1080p), ragged pixel edge,
+    with the per-row scale / diagonal epilogue of the score GEMM."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import dense_desc
+    B = (hu('g256.b', (rows_b, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    A = (hu('g256.a', (rows_a, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    sc = (hu('g256.s', (rows_a,)) + 0.5).to(DEV)
+    ld = (rows_a + 63) // 64 * 64
+    out = torch.zeros(rows_b, ld, device=DEV, dtype=torch.float32 if fp32 else torch.bfloat16)
+    d = dense_desc(rows_b, rows_a, kred, ld, out_fp32=fp32)
+    L.call('tcvom_conv_igemm', L.ptr(B), L.ptr(A), L.ptr(out), None, L.ptr(sc), None, None, C.byref(d), L.stream_ptr())
+    ref = (B.float() @ A.float().t()) * sc[None, :]
+    got = out[:, :rows_a].float()
+    assert rel_err(got.cpu(), ref.cpu()) < (1e-5 if fp32 else 6e-3)
+    assert float(out[:, rows_a:].abs().max()) == 0.0 if ld > rows_a else True
+
+
 @pytest.mark.parametrize('transposed', [False, True])
 def test_spectral_norm_bank(transposed):
     """Chained per-call power iterations, packed weights and the weight_bar gradient vs the oracle."""
