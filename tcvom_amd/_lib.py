@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtcvom_hip.so')
+if os.environ.get('TCVOM_HIP_LIB'):          # kernel A/B work: load an alternative build of the same ABI
+    LIB_PATH = os.environ['TCVOM_HIP_LIB']
 
 MAX_TAPS = 32
 

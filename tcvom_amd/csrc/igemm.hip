@@ -173,8 +173,8 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     {                                                                                                      \
         const int kk = (s) * 64 + kc8;                                                                     \
         const int tap = kk >> cshift, c0 = kk & cmask;                                                     \
-        const int4 tq = taps[tap];                                                                         \
-        const int tin = tq.x, tw = tq.y;                                                                   \
+        const int tin = reinterpret_cast<const int*>(taps)[tap * 4 + 0];                                   \
+        const int tw = reinterpret_cast<const int*>(taps)[tap * 4 + 1];                                    \
         bf16raw* abase = lds + (slot) * SLOT;                                                              \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                              \
             const bf16raw* src = (a_off[it] >= 0 && tw >= 0) ? wgt + (a_off[it] + tw + c0) : zero_page;    \
@@ -295,22 +295,31 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                 }
             }
             if (do_stats) {
+                // 8 sums (4 channels x {sum, sum of squares}) over the 32 pixel lanes: a halving butterfly -- each
+                // exchange keeps half of the values on each side -- needs 4 + 2 + 1 + 1 + 1 = 9 lane exchanges
+                // instead of 8 x 5; lane 4 * idx of each half-wave ends up with value idx
+                const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+                float w4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) {
-                        s1[r] += __shfl_xor(s1[r], o, 64);
-                        s2[r] += __shfl_xor(s2[r], o, 64);
-                    }
+                    const float send = b4 ? s1[r] : s2[r];
+                    const float keep = b4 ? s2[r] : s1[r];
+                    w4[r] = keep + __shfl_xor(send, 16, 64);
                 }
-                if ((lane & 31) == 0 && mrow < K) {
-                    const int64_t grp = d.stats_group_offset + (int64_t)bx * WAVES_N + wn;
-                    float* sp = stats + grp * 2 * K;
+                float w2[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sp[mrow + r] = s1[r];
-                        sp[K + mrow + r] = s2[r];
-                    }
+                for (int r = 0; r < 2; ++r) {
+                    const float send = b3 ? w4[r] : w4[r + 2];
+                    const float keep = b3 ? w4[r + 2] : w4[r];
+                    w2[r] = keep + __shfl_xor(send, 8, 64);
+                }
+                float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
+                w1 += __shfl_xor(w1, 2, 64);
+                w1 += __shfl_xor(w1, 1, 64);
+                if ((lane & 3) == 0 && mrow < K) {
+                    const int idx = (lane >> 2) & 7;                    // b4: sum / sum of squares, (b3, b2): channel
+                    const int64_t grp = d.stats_group_offset + (int64_t)bx * WAVES_N + wn;
+                    stats[grp * 2 * K + (idx >> 2) * K + mrow + (idx & 3)] = w1;
                 }
             }
         }
