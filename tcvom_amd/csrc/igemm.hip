@@ -451,7 +451,8 @@ struct TtTile {                                  // geometry of a [64 pixels][TC
     static constexpr int LPR = TC / 8;           // 16-byte slots (= DMA lanes) per pixel row
     static constexpr int RPI = 64 / LPR;         // pixel rows per DMA wave-instruction (1 KiB)
     static constexpr int NI = 64 / RPI;          // DMA instructions per 64-pixel stage
-    static constexpr int IT = (NI + 3) / 4;      // ... per wave
+    static constexpr int IT4 = (NI + 3) / 4;     // ... per wave of a 4-wave workgroup
+    static constexpr int IT8 = (NI + 7) / 8;     // ... of an 8-wave workgroup
     static constexpr int G = (TC * 2) / 64 > 0 ? (TC * 2) / 64 : 1;   // 64-byte column groups per row
     static constexpr int RPL = 256 / (TC * 2) > 0 ? 256 / (TC * 2) : 1;   // rows per 256-byte bank line
     __device__ static __forceinline__ int swz(int row) { return (row / RPL) % G; }
@@ -466,16 +467,22 @@ __device__ __forceinline__ bf16x8_t tr_read8(const bf16raw* p_lo, const bf16raw*
 }
 
 template <int TM, int TN, int WM, int WN, int KS>
-__global__ __launch_bounds__(256) void igemm_tt_kernel(
+__global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kernel(
     const bf16raw* __restrict__ dy, const bf16raw* __restrict__ in, float* __restrict__ dw,
     const bf16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk, const int chunks_per_phase)
 {
+#ifdef NT_TRACE
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
     const int phase = blockIdx.x / chunks_per_phase;
     const tcvom_conv_desc& d = ps.d[phase];
     const int chunk = blockIdx.x - phase * chunks_per_phase;
     if (chunk * pchunk >= d.N * d.PH * d.PW) return;
     constexpr int WAVES_M = TM / WM, WAVES_N = TN / WN;
-    static_assert(WAVES_M * WAVES_N * KS == 4, "4 waves per workgroup");
+    constexpr int NW = WAVES_M * WAVES_N * KS;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    constexpr int A_IT = NW == 4 ? TtTile<TM>::IT4 : TtTile<TM>::IT8;
+    constexpr int B_IT = NW == 4 ? TtTile<TN>::IT4 : TtTile<TN>::IT8;
     constexpr int MI = WM / 32, NI = WN / 32;
     typedef TtTile<TM> TA;
     typedef TtTile<TN> TB;
@@ -511,11 +518,11 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const float rcp_pw = 1.0f / (float)PW, rcp_ph = 1.0f / (float)PH;
 
     // ---- per-lane DMA state: A = dy tile [64][TM], B = gathered input tile [64][TN]
-    int a_col[TA::IT], a_n[TA::IT], a_i[TA::IT], a_j[TA::IT];
-    bool a_ok[TA::IT];
+    int a_col[A_IT], a_n[A_IT], a_i[A_IT], a_j[A_IT];
+    bool a_ok[A_IT];
 #pragma unroll
-    for (int it = 0; it < TA::IT; ++it) {
-        const int ii = it * 4 + wave;
+    for (int it = 0; it < A_IT; ++it) {
+        const int ii = it * NW + wave;
         const int row = ii * TA::RPI + lane / TA::LPR;
         const int cs = (lane % TA::LPR) ^ (TA::swz(row) << 2);
         a_col[it] = m0 + cs * 8;
@@ -525,11 +532,11 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
         divmod_any(p, PW, rcp_pw, small_p, t, a_j[it]);
         divmod_any(t, PH, rcp_ph, small_p, a_n[it], a_i[it]);
     }
-    int b_c0[TB::IT], b_dh[TB::IT], b_dw[TB::IT], b_n[TB::IT], b_i[TB::IT], b_j[TB::IT];
-    bool b_ok[TB::IT];
+    int b_c0[B_IT], b_dh[B_IT], b_dw[B_IT], b_n[B_IT], b_i[B_IT], b_j[B_IT];
+    bool b_ok[B_IT];
 #pragma unroll
-    for (int it = 0; it < TB::IT; ++it) {
-        const int ii = it * 4 + wave;
+    for (int it = 0; it < B_IT; ++it) {
+        const int ii = it * NW + wave;
         const int row = ii * TB::RPI + lane / TB::LPR;
         const int cs = (lane % TB::LPR) ^ (TB::swz(row) << 2);
         const int col = n0 + cs * 8;
@@ -561,34 +568,48 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const int nstage = (pend - pbeg + 63) >> 6;
 
     // issue the DMA of stage s (pixels pbeg + 64 s ...) into ring slot `slot`, then advance the pixel counters
+    // Pixel counters advance by 64 per stage: one conditional carry when the row is at least 64 pixels wide,
+    // otherwise (tiny images) they are recomputed from the pixel index.  All branch-free, 32-bit element offsets.
+    const bool wide = PW >= 64;
+    const int a_os = d.out_step, a_oh = d.out_off_h, a_ow = d.out_off_w, OHd = d.OH, OWd = d.OW, b_is = d.in_step;
+#define TT_ADVANCE(n_, i_, j_, pnext)                                                                            \
+    if (wide) {                                                                                                  \
+        j_ += 64;                                                                                                \
+        const bool c1 = j_ >= PW;                                                                                \
+        j_ = c1 ? j_ - PW : j_;                                                                                  \
+        i_ += c1 ? 1 : 0;                                                                                        \
+        const bool c2 = i_ >= PH;                                                                                \
+        i_ = c2 ? 0 : i_;                                                                                        \
+        n_ += c2 ? 1 : 0;                                                                                        \
+    } else {                                                                                                     \
+        int t_;                                                                                                  \
+        divmod_any((pnext), PW, rcp_pw, small_p, t_, j_);                                                        \
+        divmod_any(t_, PH, rcp_ph, small_p, n_, i_);                                                             \
+    }
 #define TT_ISSUE_STAGE(s, slot)                                                                                  \
     {                                                                                                            \
         bf16raw* abase = lds + (slot) * SLOT;                                                                    \
-        _Pragma("unroll") for (int it = 0; it < TA::IT; ++it) {                                                  \
-            const int ii = it * 4 + wave;                                                                        \
+        _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                  \
+            const int ii = it * NW + wave;                                                                        \
             if (ii < TA::NI) {                                                                                   \
                 const int p = pbeg + (s) * 64 + ii * TA::RPI + lane / TA::LPR;                                   \
-                const bf16raw* src = zero_page;                                                                  \
-                if (a_ok[it] && p < pend)                                                                        \
-                    src = dy + ((int64_t)(a_n[it] * d.OH + a_i[it] * d.out_step + d.out_off_h) * d.OW            \
-                                + a_j[it] * d.out_step + d.out_off_w) * ldy + a_col[it];                         \
+                const int off = ((a_n[it] * OHd + a_i[it] * a_os + a_oh) * OWd + a_j[it] * a_os + a_ow) * ldy + a_col[it]; \
+                const bf16raw* src = (a_ok[it] && p < pend) ? dy + off : zero_page;                              \
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + ii * 512), 16, 0, 0);             \
-                a_j[it] += 64;                                                                                   \
-                while (a_j[it] >= PW) { a_j[it] -= PW; if (++a_i[it] == PH) { a_i[it] = 0; ++a_n[it]; } }        \
+                TT_ADVANCE(a_n[it], a_i[it], a_j[it], p + 64)                                                    \
             }                                                                                                    \
         }                                                                                                        \
         bf16raw* bbase = abase + 64 * TM;                                                                        \
-        _Pragma("unroll") for (int it = 0; it < TB::IT; ++it) {                                                  \
-            const int ii = it * 4 + wave;                                                                        \
+        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                                  \
+            const int ii = it * NW + wave;                                                                        \
             if (ii < TB::NI) {                                                                                   \
                 const int p = pbeg + (s) * 64 + ii * TB::RPI + lane / TB::LPR;                                   \
-                const int ih = b_i[it] * d.in_step + b_dh[it], iw = b_j[it] * d.in_step + b_dw[it];              \
-                const bf16raw* src = zero_page;                                                                  \
-                if (b_ok[it] && p < pend && ih >= 0 && ih < H && iw >= 0 && iw < W)                              \
-                    src = in + ((int64_t)(b_n[it] * H + ih) * W + iw) * C + b_c0[it];                            \
+                const int ih = b_i[it] * b_is + b_dh[it], iw = b_j[it] * b_is + b_dw[it];                        \
+                const bool okb = b_ok[it] && p < pend && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W; \
+                const int off = ((b_n[it] * H + ih) * W + iw) * C + b_c0[it];                                    \
+                const bf16raw* src = okb ? in + off : zero_page;                                                 \
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + ii * 512), 16, 0, 0);             \
-                b_j[it] += 64;                                                                                   \
-                while (b_j[it] >= PW) { b_j[it] -= PW; if (++b_i[it] == PH) { b_i[it] = 0; ++b_n[it]; } }        \
+                TT_ADVANCE(b_n[it], b_i[it], b_j[it], p + 64)                                                    \
             }                                                                                                    \
         }                                                                                                        \
     }
@@ -598,11 +619,20 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
     const int tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;        // + wave/fragment column base
 
     if (nstage > 0) TT_ISSUE_STAGE(0, 0);
+#ifdef NT_TRACE
+    const bool trace_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW - 1);
+    const int trace_w = wave == 0 ? 0 : 1;
+    if (trace_on) { tcvom_trace_buf[4096 + trace_w * 8 + 0] = t_entry; tcvom_trace_buf[4096 + trace_w * 8 + 1] = __builtin_readcyclecounter(); }
+#endif
     for (int s = 0; s < nstage; ++s) {
         const int slot = s & 1;
+        TRACE(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE(1);
         __builtin_amdgcn_s_barrier();
+        TRACE(2);
         if (s + 1 < nstage) TT_ISSUE_STAGE(s + 1, slot ^ 1);
+        TRACE(3);
         const bf16raw* As = lds + slot * SLOT;
         const bf16raw* Bs = As + 64 * TM;
 #pragma unroll
@@ -632,6 +662,10 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
         }
     }
 #undef TT_ISSUE_STAGE
+#undef TT_ADVANCE
+#ifdef NT_TRACE
+    if (trace_on) tcvom_trace_buf[4096 + trace_w * 8 + 2] = __builtin_readcyclecounter();
+#endif
 
 #pragma unroll
     for (int b = 0; b < NI; ++b) {
@@ -653,6 +687,12 @@ __global__ __launch_bounds__(256) void igemm_tt_kernel(
             }
         }
     }
+#ifdef NT_TRACE
+    if (trace_on) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tcvom_trace_buf[4096 + trace_w * 8 + 3] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs, int nphase,
@@ -671,6 +711,8 @@ static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const t
                         "wgrad_igemm: phases must share K, C and the tap count");
         const long long Pi = (long long)d->N * d->PH * d->PW;
         TCVOM_CHECK_ARG(Pi > 0 && Pi < (1ll << 31), "wgrad_igemm: bad pixel count %lld", Pi);
+        TCVOM_CHECK_ARG((long long)d->N * d->OH * d->OW * ldy < (1ll << 31) && (long long)d->N * d->H * d->W * d->C < (1ll << 31),
+                        "wgrad_igemm: operand too large for 32-bit element offsets");
         if (Pi > P) P = Pi;
         ps.d[i] = *d;
     }
@@ -700,9 +742,9 @@ static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const t
     const int chunks = cdiv(P, pchunk);
     dim3 grid(chunks * nphase, nt, mt);
     if (tm == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 32, 1>), grid, dim3(512), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else if (tm == 64 && tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 64, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 32, 1>), grid, dim3(512), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else if (tm == 64)
         hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
     else if (tn == 128)
