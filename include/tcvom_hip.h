@@ -97,6 +97,11 @@ int tcvom_bn_finalize_scratch_doubles(int32_t C);
 /* running_mean/var EMA from the (mean, invstd) a train-mode tcvom_bn_finalize(running_mean=NULL) call saved */
 int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_var, int32_t C, float momentum,
                         float eps, int64_t unbias_count, void* stream);
+/* every deferred EMA of a window in one launch.  table: nbn rows of 6 int64 {running_mean ptr, running_var ptr,
+ * address of call slot 0's saved (mean, invstd), C, floats between call slots, momentum | eps << 32 (fp32 bits)};
+ * masks[b] bit s = call slot s of BatchNorm b was a train-mode call; unbias[b] = n / (n - 1).  masks / unbias are
+ * HOST arrays (they travel as kernel arguments). */
+int tcvom_bn_ema_multi(const int64_t* table, int32_t nbn, const uint32_t* masks, const float* unbias, void* stream);
 int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
 /* y_fp32 != 0: the conv output y is fp32 (high-precision layers) instead of bf16 */
@@ -106,10 +111,11 @@ int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
 int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
                         const float* saved, float* partial /*[groups][2][C]*/, int64_t pixels, int32_t C,
                         int32_t act, int32_t y_fp32, void* stream);
-/* dgamma/dbeta are WRITTEN (not accumulated); coef is [3][C] scratch consumed by bn_bwd_apply */
+/* dgamma/dbeta are written, or accumulated when `accumulate` is set; coef is [3][C] scratch consumed by bn_bwd_apply */
 int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, const float* gamma,
                           const float* saved, float* dgamma, float* dbeta, float* coef,
-                          double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */, void* stream);
+                          double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
+                          int32_t accumulate /* != 0: atomically ADD into dgamma/dbeta */, void* stream);
 /* SyncBatchNorm (train_ddp.py:213 nn.SyncBatchNorm.convert_sync_batchnorm): the per-channel sums are produced
  * as an fp64 [2][C] vector, the host all-reduces it over the ranks (RCCL), and the *_sums finalizers consume
  * the summed vector with the global pixel count.  dgamma/dbeta come from the LOCAL sums (torch semantics). */
@@ -119,7 +125,7 @@ int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t
                            const float* beta, float eps, float* scale_shift, float* saved, void* stream);
 int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
-                               void* stream);
+                               int32_t accumulate, void* stream);
 /* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
  * gradient is additionally masked by y > 0 */
 int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,

@@ -209,7 +209,7 @@ template <typename PT>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ saved,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef)
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate)
 {
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     if (sl == 0 && c < C) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
-        if (dbeta) dbeta[c] = (float)a;
-        if (dgamma) dgamma[c] = (float)b;
+        // accumulate: the S calls of one BatchNorm (frames on concurrent streams) add into one gradient buffer
+        if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)a); else dbeta[c] = (float)a; }
+        if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)b); else dgamma[c] = (float)b; }
         coef[c] = (float)(a / count);
         coef[C + c] = (float)(b / count);
         coef[2 * C + c] = gamma[c] * saved[C + c];
@@ -335,6 +336,53 @@ extern "C" int tcvom_bn_ema_update(const float* saved, float* running_mean, floa
     return TCVOM_OK;
 }
 
+// All deferred EMAs of a window in ONE launch: block b owns BatchNorm b and applies the EMA of its train-mode calls
+// in call order (bit s of mask[b] = call slot s was a train-mode call).  table row: running_mean ptr, running_var
+// ptr, address of slot 0's (mean, invstd), C, floats between slots, momentum/eps as two packed fp32.
+struct BnEmaArgs { uint32_t mask[256]; float unbias[256]; };
+__global__ __launch_bounds__(128) void bn_ema_multi_kernel(const int64_t* __restrict__ table, const BnEmaArgs args) {
+    const int b = blockIdx.x;
+    const uint32_t mask = args.mask[b];
+    if (!mask) return;
+    const int64_t* row = table + (int64_t)b * 6;
+    float* rm = reinterpret_cast<float*>(row[0]);
+    float* rv = reinterpret_cast<float*>(row[1]);
+    const float* saved0 = reinterpret_cast<const float*>(row[2]);
+    const int C = (int)row[3];
+    const int64_t stride = row[4];
+    const float momentum = __int_as_float((int)(row[5] & 0xffffffffll)), eps = __int_as_float((int)(row[5] >> 32));
+    const double unbias = (double)args.unbias[b];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float m = rm[c], v = rv[c];
+        for (int s = 0; s < 32; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const float* sv = saved0 + s * stride;
+            const float mean = sv[c], invstd = sv[C + c];
+            double var = 1.0 / ((double)invstd * (double)invstd) - (double)eps;
+            if (var < 0.0) var = 0.0;
+            m = (1.f - momentum) * m + momentum * mean;
+            v = (1.f - momentum) * v + momentum * (float)(var * unbias);
+        }
+        rm[c] = m;
+        rv[c] = v;
+    }
+}
+
+extern "C" int tcvom_bn_ema_multi(const int64_t* table, int32_t nbn, const uint32_t* masks, const float* unbias, void* stream) {
+    TCVOM_CHECK_ARG(table && masks && unbias && nbn > 0, "bn_ema_multi: bad args");
+    for (int b0 = 0; b0 < nbn; b0 += 256) {
+        BnEmaArgs a;
+        const int n = nbn - b0 < 256 ? nbn - b0 : 256;
+        for (int i = 0; i < 256; ++i) {
+            a.mask[i] = i < n ? masks[b0 + i] : 0u;
+            a.unbias[i] = i < n ? unbias[b0 + i] : 1.f;
+        }
+        hipLaunchKernelGGL(bn_ema_multi_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, table + (int64_t)b0 * 6, a);
+    }
+    TCVOM_LAUNCH_CHECK("bn_ema_multi");
+    return TCVOM_OK;
+}
+
 extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, float* scale_shift, float* saved, void* stream) {
     TCVOM_CHECK_ARG(gamma && beta && running_mean && running_var && scale_shift && saved && C > 0, "bn_eval_coeffs: bad args");
@@ -387,16 +435,16 @@ extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* re
 
 extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count,
                                      const float* gamma, const float* saved, float* dgamma, float* dbeta,
-                                     float* coef, double* scratch, void* stream) {
+                                     float* coef, double* scratch, int32_t accumulate, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES,
-                           C, (double)count, gamma, saved, dgamma, dbeta, coef);
+                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate);
     } else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C,
-                           (double)count, gamma, saved, dgamma, dbeta, coef);
+                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate);
     }
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
     return TCVOM_OK;
@@ -429,11 +477,12 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ par
     }
 }
 
-__global__ void bn_local_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void bn_local_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (dbeta) dbeta[c] = (float)sums[c];
-    if (dgamma) dgamma[c] = (float)sums[C + c];
+    if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)sums[c]); else dbeta[c] = (float)sums[c]; }
+    if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)sums[C + c]); else dgamma[c] = (float)sums[C + c]; }
 }
 
 extern "C" int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_t C, double* sums, double* scratch, void* stream) {
@@ -461,13 +510,13 @@ extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t cou
 
 extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                           const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
-                                          void* stream) {
+                                          int32_t accumulate, void* stream) {
     TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0, "bn_bwd_finalize_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, sums_all, 1, C, (double)count, gamma,
-                       saved, (float*)nullptr, (float*)nullptr, coef);
+                       saved, (float*)nullptr, (float*)nullptr, coef, 0);
     // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
-    hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate);
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize_sums");
     return TCVOM_OK;
 }

@@ -34,6 +34,8 @@ class ConvCfg(object):
 
     def __init__(self, bank, spec, bn=None, act=ACT_NONE, pre_relu=False, unbias_mult=1):
         self.bank, self.spec, self.bn = bank, spec, bn
+        if bn is not None:
+            bank.register_bn(bn)
         self.act, self.pre_relu, self.unbias_mult = act, pre_relu, unbias_mult
         self._geo = {}
 
@@ -109,38 +111,36 @@ class _ConvBNAct(torch.autograd.Function):
             assert res1 is None and res2 is None and cfg.act == ACT_NONE
             ctx.save_for_backward(x)
             return y
-        ss = torch.empty(2 * K, dtype=torch.float32, device=x.device)
-        saved = torch.empty(2 * K, dtype=torch.float32, device=x.device)
+        P = geo.out_pixels
+        sync = _sync_group(bn) if training else None
+        if sync is not None:
+            P = P * sync[1]
+        ss, saved = (C.c_void_p(a) for a in bank.bn_slot(bn, training, P * cfg.unbias_mult))
         if training:
-            P = geo.out_pixels
             groups = stats.numel() // (2 * K)
             scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
-            sync = _sync_group(bn)
             if sync is None:
+                # running statistics / num_batches_tracked are updated after the window, in call order (frames run
+                # on concurrent streams; the EMA is order dependent): see WeightBank.flush_bn_counters
                 L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
                        L.ptr(gamma), L.ptr(beta), None, None,
-                       float(bn.momentum), float(bn.eps), L.ptr(ss), L.ptr(saved), L.ptr(scratch), st)
+                       float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), st)
             else:
                 # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size)
-                group, world = sync
                 sums = torch.empty(2 * K, dtype=torch.float64, device=x.device)
                 L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, K, L.ptr(sums), L.ptr(scratch), st)
-                dist.all_reduce(sums, group=group)
-                P = P * world
+                dist.all_reduce(sums, group=sync[0])
                 L.call('tcvom_bn_finalize_sums', L.ptr(sums), K, P, P * cfg.unbias_mult, L.ptr(gamma), L.ptr(beta),
-                       float(bn.eps), L.ptr(ss), L.ptr(saved), st)
-            ctx.sync = sync
-            # running statistics / num_batches_tracked are updated after the window, in call order (frames run on
-            # concurrent streams; the EMA is order dependent)
-            bank.pending_bn.append((bn, saved, P * cfg.unbias_mult))
+                       float(bn.eps), ss, saved, st)
         else:
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
-                   float(bn.eps), L.ptr(ss), L.ptr(saved), st)
+                   float(bn.eps), ss, saved, st)
+        ctx.sync, ctx.ss, ctx.saved, ctx.window_id = sync, ss, saved, bank.window_id
         z = torch.empty((N, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
-        L.call('tcvom_bn_apply', L.ptr(y), L.ptr(ss), L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0, st)
-        ctx.save_for_backward(x, y, ss, saved, gamma, r1)
+        L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0, st)
+        ctx.save_for_backward(x, y, gamma, r1)
         return z
 
     @staticmethod
@@ -158,32 +158,36 @@ class _ConvBNAct(torch.autograd.Function):
                 dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
                 L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), geo.out_pixels, K, K, st)
         else:
-            x, y, ss, saved, gamma, r1 = ctx.saved_tensors
+            x, y, gamma, r1 = ctx.saved_tensors
+            if ctx.window_id != bank.window_id:
+                raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not '
+                                   'supported (the per-window BatchNorm / weight arenas were reused)' % spec.name)
+            ss, saved = ctx.ss, ctx.saved
             P = geo.out_pixels
             groups = L.call('tcvom_bn_bwd_groups', P, K)
             partial = torch.empty(groups * 2 * K, dtype=torch.float32, device=dz.device)
             yf = 1 if y.dtype == torch.float32 else 0
-            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(partial), P, K, cfg.act, yf, st)
-            dgamma = torch.empty(K, dtype=torch.float32, device=dz.device)
-            dbeta = torch.empty(K, dtype=torch.float32, device=dz.device)
+            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), P, K, cfg.act, yf, st)
+            # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
+            dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
             coef = torch.empty(3 * K, dtype=torch.float32, device=dz.device)
             scratch = torch.empty(128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
             sync = ctx.sync if ctx.training else None
             if sync is None:
-                L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), L.ptr(saved), L.ptr(dgamma),
-                       L.ptr(dbeta), L.ptr(coef), L.ptr(scratch), st)
+                L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
+                       L.ptr(coef), L.ptr(scratch), 1, st)
             else:
                 group, world = sync
                 local = torch.empty(2 * K, dtype=torch.float64, device=dz.device)
                 L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), st)
                 total = local.clone()
                 dist.all_reduce(total, group=group)
-                L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), L.ptr(saved),
-                       L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), st)
+                L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
+                       dgp, dbp, L.ptr(coef), 1, st)
             dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)
-            L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), L.ptr(ss), L.ptr(saved), L.ptr(coef), L.ptr(dy),
+            L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
                    L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, yf, st)
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:

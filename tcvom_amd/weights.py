@@ -10,6 +10,7 @@ packed-weight gradients into gradients of `weight_bar` — a handful of launches
 State (u, v, weight_bar) stays in ordinary nn.Parameters with the reference's state_dict names.
 """
 import ctypes as C
+import struct
 
 import torch
 
@@ -56,26 +57,97 @@ class WeightBank(object):
         self._ptr_sig = None
         self._plans = {}
         self.max_calls = 0
-        self.pending_bn = []
+        self.bns, self.bn_ch, self._bn_sig, self._bn_cap = [], 0, None, 0
+        self.bn_mask, self.window_id = [], 0
+
+    # ------------------------------------------------------------------ BatchNorm bookkeeping
+    # Every BatchNorm call of a window gets a fixed slot in one arena for its (scale, shift) and (mean, invstd)
+    # vectors, and every BatchNorm one slot in a gradient buffer that the S calls add into atomically: no
+    # per-call allocations, no per-call gradient accumulation kernels, ONE launch for all deferred EMAs.
+    def register_bn(self, bn):
+        idx = getattr(bn, '_tcvom_bank_idx', None)
+        if idx is not None and idx < len(self.bns) and self.bns[idx] is bn:
+            return idx
+        idx = len(self.bns)
+        bn._tcvom_bank_idx, bn._tcvom_ch_off = idx, self.bn_ch
+        self.bns.append(bn)
+        self.bn_ch += bn.num_features
+        self._bn_sig = None
+        return idx
+
+    def _ensure_bn(self, frames, dev):
+        if not self.bns:
+            return
+        cap = max(int(frames), 1)
+        sig = (cap, dev) + tuple(bn.running_mean.data_ptr() for bn in self.bns)
+        if sig != self._bn_sig:
+            self._bn_sig, self._bn_cap = sig, cap
+            self.bn_arena = torch.empty(cap * 4 * self.bn_ch, dtype=torch.float32, device=dev)
+            self.bn_grad = torch.zeros(2 * self.bn_ch, dtype=torch.float32, device=dev)
+            self._bn_arena_ptr, self._bn_grad_ptr = self.bn_arena.data_ptr(), self.bn_grad.data_ptr()
+            rows = []
+            for bn in self.bns:
+                Cn = bn.num_features
+                mom = 0.1 if bn.momentum is None else float(bn.momentum)
+                packed = int.from_bytes(struct.pack('<ff', mom, float(bn.eps)), 'little', signed=True)
+                rows.append([bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                             self._bn_arena_ptr + 4 * (4 * bn._tcvom_ch_off + 2 * Cn), Cn, 4 * self.bn_ch, packed])
+            self.bn_table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        n = len(self.bns)
+        self.bn_calls, self.bn_mask, self.bn_unbias, self.bn_touched = [0] * n, [0] * n, [1.0] * n, [False] * n
+
+    def bn_slot(self, bn, training, unbias_count):
+        """Device addresses of the (scale, shift) and (mean, invstd) vectors of this call of `bn`."""
+        idx = bn._tcvom_bank_idx
+        c = self.bn_calls[idx]
+        if c >= self._bn_cap:
+            raise RuntimeError('BatchNorm called %d times in one window (bank prepared for %d frames)' % (c + 1, self._bn_cap))
+        self.bn_calls[idx] = c + 1
+        if training:
+            self.bn_mask[idx] |= 1 << c
+            self.bn_unbias[idx] = unbias_count / (unbias_count - 1.0) if unbias_count > 1 else 1.0
+        base = self._bn_arena_ptr + 4 * (c * 4 * self.bn_ch + 4 * bn._tcvom_ch_off)
+        return base, base + 8 * bn.num_features
+
+    def bn_grad_ptrs(self, bn):
+        self.bn_touched[bn._tcvom_bank_idx] = True
+        base = self._bn_grad_ptr + 8 * bn._tcvom_ch_off
+        return base, base + 4 * bn.num_features
+
+    def bn_params(self):
+        out = []
+        for bn in self.bns:
+            out += [bn.weight, bn.bias]
+        return out
+
+    def bn_backward(self):
+        """Gradients of (weight, bias) of every BatchNorm that ran a backward in this window (None for the others)."""
+        if not self.bns:
+            return []
+        g = self.bn_grad.clone()
+        out = []
+        for bn, hit in zip(self.bns, self.bn_touched):
+            o, Cn = 2 * bn._tcvom_ch_off, bn.num_features
+            out += [g[o:o + Cn], g[o + Cn:o + 2 * Cn]] if hit else [None, None]
+        return out
 
     def flush_bn_counters(self):
         """Apply the deferred BatchNorm state updates of the train-mode calls since the last flush, in call order:
-        running_mean/var EMA (one tiny launch per call) and num_batches_tracked (one foreach launch)."""
-        if not self.pending_bn:
+        running_mean/var EMA (one launch for all of them) and num_batches_tracked (one foreach launch)."""
+        if not self.bns or not any(self.bn_mask):
             return
-        pend, self.pending_bn = self.pending_bn, []
-        st = L.stream_ptr()
-        counts = {}
-        for bn, saved, ub in pend:
-            L.call('tcvom_bn_ema_update', L.ptr(saved), L.ptr(bn.running_mean), L.ptr(bn.running_var),
-                   bn.num_features, float(bn.momentum), float(bn.eps), int(ub), st)
-            counts[id(bn)] = (bn, counts.get(id(bn), (bn, 0))[1] + 1)
+        n = len(self.bns)
+        masks = (C.c_uint32 * n)(*self.bn_mask)
+        unb = (C.c_float * n)(*self.bn_unbias)
+        L.call('tcvom_bn_ema_multi', L.ptr(self.bn_table), n, C.cast(masks, C.c_void_p), C.cast(unb, C.c_void_p), L.stream_ptr())
         by_n = {}
-        for bn, n in counts.values():
-            by_n.setdefault(n, []).append(bn.num_batches_tracked)
+        for bn, m in zip(self.bns, self.bn_mask):
+            if m:
+                by_n.setdefault(bin(m).count('1'), []).append(bn.num_batches_tracked)
         with torch.no_grad():
-            for n, bufs in by_n.items():
-                torch._foreach_add_(bufs, n)
+            for k, bufs in by_n.items():
+                torch._foreach_add_(bufs, k)
+        self.bn_mask = [0] * n
 
     # ------------------------------------------------------------------ registration
     def register(self, spec):
@@ -208,6 +280,10 @@ class WeightBank(object):
         st = L.stream_ptr()
         sc = C.byref(self.scratch)
         self.dw_arena.zero_()
+        self._ensure_bn(frames, dev)
+        if self.bns and training:
+            self.bn_grad.zero_()
+        self.window_id += 1
         for call in range(plan['iters']):
             if training and call > 0:
                 # layers with fewer calls keep iterating harmlessly only if still needed; tail layers
@@ -290,8 +366,8 @@ class _BankToken(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtoken):
         grads = ctx.bank.backward(ctx.plan)
-        return (None, None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads) + tuple(ctx.bank.bn_backward())
 
 
 def bank_token(bank, frames, training):
-    return _BankToken.apply(bank, frames, training, *bank.weight_params())
+    return _BankToken.apply(bank, frames, training, *(bank.weight_params() + bank.bn_params()))
