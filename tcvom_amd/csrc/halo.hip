@@ -1,0 +1,303 @@
+// Halo-tile direct convolution for the full-resolution, small-channel layers (os1 / os2 of vmn_gca: the shortcut
+// branches res_gca_enc.py:47-55, encoder conv2 resnet_enc.py:72, decoder layer4 resnet_dec.py:86 and their data
+// gradients): stride-1 same-size convs with <= 32 input and 32 output channels and taps within +-1 pixel.
+//
+// These layers are HBM-bound (2M pixels x 32 channels in, the same out, 9 taps of reuse), but the implicit-GEMM
+// kernel re-fetches every input pixel once PER TAP through the L2->LDS DMA path, which then bounds it (measured
+// 190 us against a ~55 us HBM floor for 32->32 at 1088x1920).  Here a workgroup DMAs the (8+2) x (32+2) pixel
+// halo of its 8x32 output tile into LDS ONCE and all taps read it from there; the weights live in LDS for the
+// lifetime of the (persistent) workgroup, the halo of the next tile is in flight while the current one is used.
+//
+//   MFMA 32x32x16 bf16:  A = weights [32 out-channels][16 k],  B = pixels [32 pixels of one tile row][16 k],
+//   k = (tap, channel) in chunks of 16;  wave w owns tile rows 2w, 2w+1.
+// LDS halo image: pixel-major, 16-byte channel chunk c of halo pixel p stored at slot c ^ ((p >> 2) & 3) (C = 32;
+// applied on the DMA source side, the LDS write stays lane-linear) so that the 16 lanes of a ds_read_b128 group --
+// 16 consecutive pixels, 64 B apart -- cover 16 distinct bank groups.  Weight rows are padded by 16 B for the same
+// reason.
+#include "common.h"
+
+#define HALO_TH 8
+#define HALO_TW 32
+#define HALO_HW (HALO_TW + 2)
+#define HALO_HH (HALO_TH + 2)
+#define HALO_PIX (HALO_HW * HALO_HH)          // 340
+#define HALO_MAX_TAPS 18
+
+struct HaloArgs {
+    const bf16raw* in;
+    const bf16raw* wgt;
+    void* out;
+    const float* bias;
+    float* stats;
+    const bf16raw* zero_page;
+    int N, H, W, K, ldo, wt, act, out_fp32, stats_group_offset;
+    int tiles_x, tiles_y, ntiles, tiles_per_wg;
+    int tap_dh[HALO_MAX_TAPS + 2], tap_dw[HALO_MAX_TAPS + 2], tap_w[HALO_MAX_TAPS + 2];   // compacted; tap_w < 0: zero tap
+};
+
+template <int C, int NCH>
+__global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
+    constexpr int CU = C / 8;                           // 16-byte units per pixel
+    constexpr int UNITS = HALO_PIX * CU;
+    constexpr int NDMA = (UNITS + 63) / 64;             // DMA wave-instructions per halo
+    constexpr int DMA_IT = (NDMA + 3) / 4;
+    constexpr int SLOT = NDMA * 512;                    // bf16 elements per halo slot
+    constexpr int WROW = NCH * 16 + 8;                  // padded weight row (elements)
+    constexpr int NTAPS = NCH * 16 / C;
+    extern __shared__ __attribute__((aligned(16))) bf16raw lds[];
+    bf16raw* halo = lds;                                // [2][SLOT]
+    bf16raw* wl = lds + 2 * SLOT;                       // [32][WROW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int H = a.H, W = a.W;
+
+    // XCD-contiguous workgroup order: neighbouring tile runs (which share halo rows) go to one L2
+    int v;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int t_begin = v * a.tiles_per_wg;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
+    if (t_begin >= t_end) return;
+
+    // ---- weights -> LDS, once: wl[k][t*C + c] = wgt[(k*wt + slot(t))*C + c]
+    for (int u = tid; u < 32 * NTAPS * CU; u += 256) {
+        const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
+        const int ws = a.tap_w[t];
+        uint4 val = make_uint4(0u, 0u, 0u, 0u);
+        if (ws >= 0 && k < a.K) val = *reinterpret_cast<const uint4*>(a.wgt + ((int64_t)k * a.wt + ws) * C + cu * 8);
+        *reinterpret_cast<uint4*>(wl + k * WROW + t * C + cu * 8) = val;
+    }
+
+    // ---- per-lane constants
+    // DMA: unit q = (it*4 + wave)*64 + lane -> halo pixel p = q / CU, stored slot q % CU holds chunk slot ^ swz(p)
+    int d_rel[DMA_IT], d_yx[DMA_IT];
+#pragma unroll
+    for (int it = 0; it < DMA_IT; ++it) {
+        const int q = (it * 4 + wave) * 64 + lane;
+        const int p = q / CU, sl = q % CU;
+        const int c16 = (CU == 4) ? (sl ^ ((p >> 2) & 3)) : sl;
+        const int hy = p / HALO_HW, hx = p - hy * HALO_HW;
+        d_rel[it] = ((hy - 1) * W + (hx - 1)) * C + c16 * 8;
+        d_yx[it] = (q < UNITS) ? ((hy << 16) | hx) : -1;
+    }
+    // B fragments: byte offset inside a halo slot for (chunk, tile row j of this wave)
+    int b_addr[NCH][2];
+    int a_addr[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int kk = ch * 16 + half * 8;
+        const int c16 = (kk % C) >> 3;
+        // the two lane halves of a chunk may belong to different taps (C = 8): uniform table reads + select
+        constexpr int dummy = 0;
+        const int tap0 = (ch * 16) / C, tap1 = (ch * 16 + 8) / C;
+        const int dh = half ? a.tap_dh[tap1] : a.tap_dh[tap0], dw = half ? a.tap_dw[tap1] : a.tap_dw[tap0];
+        (void)dummy;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = (2 * wave + j + dh + 1) * HALO_HW + (col + dw + 1);
+            const int sl = (CU == 4) ? (c16 ^ ((p >> 2) & 3)) : c16;
+            b_addr[ch][j] = (p * CU + sl) * 16;
+        }
+        a_addr[ch] = (col * WROW + kk) * 2;
+    }
+    const char* wl_b = reinterpret_cast<const char*>(wl);
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define HALO_ISSUE(tile, slot)                                                                              \
+    {                                                                                                       \
+        const int tx_ = (tile) % a.tiles_x, ty_ = ((tile) / a.tiles_x) % a.tiles_y, n_ = (tile) / (a.tiles_x * a.tiles_y); \
+        const int y0_ = ty_ * HALO_TH, x0_ = tx_ * HALO_TW;                                                 \
+        const int base_ = ((n_ * H + y0_) * W + x0_) * C;                                                   \
+        _Pragma("unroll") for (int it = 0; it < DMA_IT; ++it) {                                             \
+            if ((it * 4 + wave) < NDMA) {                                                                   \
+                const int hy_ = d_yx[it] >> 16, hx_ = d_yx[it] & 0xffff;                                    \
+                const bool ok_ = d_yx[it] >= 0 && (unsigned)(y0_ + hy_ - 1) < (unsigned)H &&                \
+                                 (unsigned)(x0_ + hx_ - 1) < (unsigned)W;                                   \
+                const bf16raw* src_ = ok_ ? a.in + (base_ + d_rel[it]) : a.zero_page;                       \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(halo + (slot) * SLOT + (it * 4 + wave) * 512), 16, 0, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    HALO_ISSUE(t_begin, 0);
+    int slot = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tile + 1 < t_end) HALO_ISSUE(tile + 1, slot ^ 1);
+
+        f32x16_t acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const char* hs = reinterpret_cast<const char*>(halo + slot * SLOT);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(wl_b + a_addr[ch]);
+            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(hs + b_addr[ch][0]);
+            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(hs + b_addr[ch][1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+        }
+
+        // ---- epilogue: bias, ReLU, store, BatchNorm partial statistics (one group per wave and tile)
+        const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
+        const int y0 = ty * HALO_TH + 2 * wave, x = tx * HALO_TW + col;
+        const int64_t o0 = ((int64_t)(n * H + y0) * W + x) * a.ldo;
+        const int64_t o1 = o0 + (int64_t)W * a.ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mrow = 8 * g + 4 * half;
+            float bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bs[r] = mrow + r < a.K ? a.bias[mrow + r] : 0.f;
+            }
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float vv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float xv = acc[j][g * 4 + r] + bs[r];
+                    if (a.act == 1) xv = fmaxf(xv, 0.f);
+                    vv[r] = xv;
+                    s1[r] += xv;
+                    s2[r] += xv * xv;
+                }
+                if (mrow < a.K) {
+                    const int64_t o = (j ? o1 : o0) + mrow;
+                    if (a.out_fp32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(a.out) + o) = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
+                }
+            }
+            if (a.stats) {
+                // halving butterfly over the 32 pixel lanes (see igemm_nt_kernel): lane 4*idx ends with value idx
+                const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+                float w4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4[r] = (b4 ? s2[r] : s1[r]) + __shfl_xor(b4 ? s1[r] : s2[r], 16, 64);
+                float w2[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) w2[r] = (b3 ? w4[r + 2] : w4[r]) + __shfl_xor(b3 ? w4[r] : w4[r + 2], 8, 64);
+                float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
+                w1 += __shfl_xor(w1, 2, 64);
+                w1 += __shfl_xor(w1, 1, 64);
+                if ((lane & 3) == 0 && mrow < a.K) {
+                    const int idx = (lane >> 2) & 7;
+                    const int64_t grp = a.stats_group_offset + (int64_t)tile * 4 + wave;
+                    a.stats[grp * 2 * a.K + (idx >> 2) * a.K + mrow + (idx & 3)] = w1;
+                }
+            }
+        }
+        slot ^= 1;
+    }
+#undef HALO_ISSUE
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct HaloPlan { bool ok; int C, nch, ntaps; int taps[HALO_MAX_TAPS + 2]; };
+
+static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
+    HaloPlan p;
+    p.ok = false;
+    if (nphase != 1 || d->batch > 1) return p;
+    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return p;
+    if (d->PH != d->H || d->PW != d->W || d->OH != d->H || d->OW != d->W) return p;
+    if (d->H % HALO_TH != 0 || d->W % HALO_TW != 0) return p;
+    if (d->K > 32 || d->K % 4 != 0 || (d->C != 8 && d->C != 32)) return p;
+    if ((long long)d->N * d->H * d->W * d->C >= (1ll << 31)) return p;
+    int n = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        if (d->tap_w[t] < 0) continue;
+        if (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1) return p;
+        if (n >= HALO_MAX_TAPS) return p;
+        p.taps[n++] = t;
+    }
+    if (n == 0) return p;
+    const int per = 16 / (d->C < 16 ? d->C : 16);       // taps per 16-deep chunk (C = 8: 2)
+    int padded = (n + per - 1) / per * per;
+    int nch = padded * d->C / 16;
+    // instantiated shapes: C=8 with 9 taps (5 chunks), C=32 with 9 taps (18 chunks) or 18 taps (36 chunks)
+    if (!((d->C == 8 && nch == 5) || (d->C == 32 && (nch == 18 || nch == 36)))) return p;
+    for (int t = n; t < padded; ++t) p.taps[t] = -1;
+    p.ok = true;
+    p.C = d->C;
+    p.nch = nch;
+    p.ntaps = padded;
+    return p;
+}
+
+static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per_wg, size_t* lds_bytes) {
+    const int cu = p.C / 8;
+    const int ndma = (HALO_PIX * cu + 63) / 64;
+    *lds_bytes = (size_t)2 * ndma * 1024 + (size_t)32 * (p.nch * 16 + 8) * 2;
+    int occ = (int)((160 * 1024) / *lds_bytes);
+    if (occ > 4) occ = 4;
+    if (occ < 1) occ = 1;
+    const int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
+    int wgs = 256 * occ;
+    if (wgs > ntiles) wgs = ntiles;
+    *tiles_per_wg = (ntiles + wgs - 1) / wgs;
+    return (ntiles + *tiles_per_wg - 1) / *tiles_per_wg;
+}
+
+// number of statistics groups the halo kernel writes for `d`, or 0 when the shape is not handled here
+int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase) {
+    const HaloPlan p = halo_plan(d, nphase);
+    if (!p.ok) return 0;
+    return d->N * (d->H / HALO_TH) * (d->W / HALO_TW) * 4;
+}
+
+// returns 1 when the conv was launched here, 0 when the caller should use the implicit GEMM, < 0 on error
+int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                         float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream) {
+    if (mscale || mdiag) return 0;
+    const HaloPlan p = halo_plan(d, nphase);
+    if (!p.ok) return 0;
+    HaloArgs a;
+    a.in = (const bf16raw*)in;
+    a.wgt = (const bf16raw*)w;
+    a.out = out;
+    a.bias = bias;
+    a.stats = stats;
+    a.zero_page = zero_page;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.K = d->K; a.ldo = d->ldo; a.wt = d->wt; a.act = d->act; a.out_fp32 = d->out_fp32;
+    a.stats_group_offset = d->stats_group_offset;
+    a.tiles_x = d->W / HALO_TW;
+    a.tiles_y = d->H / HALO_TH;
+    a.ntiles = d->N * a.tiles_x * a.tiles_y;
+    for (int t = 0; t < HALO_MAX_TAPS + 2; ++t) {
+        const int src = t < p.ntaps ? p.taps[t] : -1;
+        a.tap_dh[t] = src >= 0 ? d->tap_dh[src] : 0;
+        a.tap_dw[t] = src >= 0 ? d->tap_dw[src] : 0;
+        a.tap_w[t] = src >= 0 ? d->tap_w[src] : -1;
+    }
+    size_t lds_bytes;
+    const int grid = halo_grid(d, p, &a.tiles_per_wg, &lds_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (p.C == 8) {
+        static bool attr8 = false;
+        if (!attr8) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; }
+        hipLaunchKernelGGL((halo_conv_kernel<8, 5>), dim3(grid), dim3(256), lds_bytes, st, a);
+    } else if (p.nch == 18) {
+        static bool attr18 = false;
+        if (!attr18) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<32, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; }
+        hipLaunchKernelGGL((halo_conv_kernel<32, 18>), dim3(grid), dim3(256), lds_bytes, st, a);
+    } else {
+        static bool attr36 = false;
+        if (!attr36) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<32, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr36 = true; }
+        hipLaunchKernelGGL((halo_conv_kernel<32, 36>), dim3(grid), dim3(256), lds_bytes, st, a);
+    }
+    if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "halo_conv: %s", hipGetErrorString(e));
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "halo_conv: %s", hipGetErrorString(e2));
+    return 1;
+}

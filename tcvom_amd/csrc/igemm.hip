@@ -369,7 +369,14 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     return {32, 256, 4};
 }
 
+// halo.hip: direct conv for the full-resolution small-channel layers
+int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase);
+int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                         float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
+
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
+    const int hg = halo_conv_stats_groups(d, nphase);
+    if (hg > 0) return hg;
     const NtCfg c = nt_config(d, nphase);
     const long long P = (long long)d->N * d->PH * d->PW;
     return cdiv(P, c.tn) * c.waves_n;
@@ -409,6 +416,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     const NtCfg c = nt_config(d0, nphase);
     const bf16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
+    {
+        const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
 #define NT_LAUNCH(threads, ...)                                                                                          \
     hipLaunchKernelGGL((igemm_nt_kernel<__VA_ARGS__>), grid, dim3(threads), 0, st, ip, wp, out, bias, mscale, mdiag,     \

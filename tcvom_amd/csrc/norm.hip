@@ -47,10 +47,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int g = sl; g < G; g += 8) {
+        // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        int g = sl;
+        for (; g + 24 < G; g += 32) {
+            const PT* q = partial + (int64_t)g * 2 * C + c;
+            const PT x0 = q[0], y0 = q[C], x1 = q[16 * C], y1 = q[17 * C], x2 = q[32 * C], y2 = q[33 * C], x3 = q[48 * C], y3 = q[49 * C];
+            a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
+            a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
+        }
+        for (; g < G; g += 8) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
+        a += a1 + a2 + a3;
+        b += b1 + b2 + b3;
     }
     s1[sl][cl] = a;
     s2[sl][cl] = b;
@@ -216,10 +227,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int g = sl; g < G; g += 8) {
+        // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        int g = sl;
+        for (; g + 24 < G; g += 32) {
+            const PT* q = partial + (int64_t)g * 2 * C + c;
+            const PT x0 = q[0], y0 = q[C], x1 = q[16 * C], y1 = q[17 * C], x2 = q[32 * C], y2 = q[33 * C], x3 = q[48 * C], y3 = q[49 * C];
+            a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
+            a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
+        }
+        for (; g < G; g += 8) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
+        a += a1 + a2 + a3;
+        b += b1 + b2 + b3;
     }
     s1[sl][cl] = a;
     s2[sl][cl] = b;
@@ -276,7 +298,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
-// pixel rows per block for the streaming BN kernels: ~8 loop iterations per thread, at most 8192 blocks
+// pixel rows per block for the streaming BN kernels: ~8 loop iterations per thread (fewer iterations / more blocks
+// measured SLOWER: every thread first loads its 16..56 per-channel coefficients), at most 8192 blocks
 static int bn_rows_per_block(int64_t pixels, int C) {
     const int rp = 256 / (C / 8);
     int64_t rows = (int64_t)rp * 8;
@@ -461,10 +484,21 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ par
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int g = sl; g < G; g += 8) {
+        // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        int g = sl;
+        for (; g + 24 < G; g += 32) {
+            const PT* q = partial + (int64_t)g * 2 * C + c;
+            const PT x0 = q[0], y0 = q[C], x1 = q[16 * C], y1 = q[17 * C], x2 = q[32 * C], y2 = q[33 * C], x3 = q[48 * C], y3 = q[49 * C];
+            a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
+            a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
+        }
+        for (; g < G; g += 8) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
+        a += a1 + a2 + a3;
+        b += b1 + b2 + b3;
     }
     s1[sl][cl] = a;
     s2[sl][cl] = b;

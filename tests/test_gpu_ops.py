@@ -215,6 +215,48 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     ck.done()
 
 
+@pytest.mark.parametrize('cin,hp,N,H,W', [(32, False, 2, 16, 64), (32, True, 1, 24, 96), (6, False, 1, 16, 160), (32, False, 1, 72, 96)])
+def test_halo_conv_kernel(cin, hp, N, H, W):
+    """Shapes served by the halo-tile direct conv (stride-1 3x3, <= 32 channels, H % 8 == 0, W % 32 == 0): forward
+    with fused ReLU + batch statistics, data gradient (also through the halo kernel) and weight gradient, against
+    fp32 PyTorch on the same bf16 operands.  hp = bf16 hi + residual weights (18 taps), fp32 conv output."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    cout = 32
+    tag = 'halo%d_%d_%d' % (cin, int(hp), H)
+    w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cout, cin, 3, 3)) * 0.2).to(DEV))
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, None, None, None, False, 1, 1, 'frame', needs_dgrad=cin >= 16, hp=hp)
+    bank.register(spec)
+    bn = nn.BatchNorm2d(cout).to(DEV)
+    cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
+    x = hu('x.' + tag, (N, cin, H, W)) - 0.5
+    xp = F.pad(x, (0, 0, 0, 0, 0, spec.cpad - cin))
+    xg = nhwc(xp).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    z = ops.conv_bn_act(cfg, xg, token, True)
+    bank.flush_bn_counters()
+    xr = bf(x).requires_grad_(True)
+    wf = spec.weight.detach().cpu()
+    wr = (wf if hp else bf(wf)).clone().requires_grad_(True)      # hi + residual reproduces the fp32 weight to ~2^-16
+    yr = F.relu(F.conv2d(xr, wr, None, 1, 1))
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    yq = yr if hp else yr + (bf(yr) - yr).detach()
+    zr = (yq - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.rel('running_mean', bn.running_mean, 0.1 * mean.detach(), 1e-2)
+    n_el = yr.numel() // cout
+    ck.rel('running_var', bn.running_var, 0.9 + 0.1 * var.detach() * n_el / (n_el - 1), 1e-2)
+    gz = hu('gz.' + tag, tuple(zr.shape)) - 0.5
+    (z.float() * nhwc(gz).float()).sum().backward()
+    (zr * bf(gz)).sum().backward()
+    if cin >= 16:
+        ck.rel('dx', nchw(xg.grad)[:, :cin], xr.grad, 4e-2)
+    ck.rel('dw', spec.weight.grad, wr.grad, 3e-2)
+    ck.done()
+
+
 # --------------------------------------------------------------------------------------------- spectral norm
 @pytest.mark.parametrize('rows_b,rows_a,kred,fp32', [(4100, 4096, 192, True), (4000, 4608, 320, False)])
 def test_dense_gemm_256_tile_config(rows_b, rows_a, kred, fp32):
