@@ -199,6 +199,8 @@ int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G, const floa
 
 /* ------------------------------------------------------------------ facade: preprocessing, losses, optimizer
  * (models/model.py:54-127,285-345; utils/loss_func.py:9-22; train_ddp.py:296-297)               */
+/* bg == NULL selects EvalModel.preprocess (models/model.py:360-386): `fg` holds the frames, `a` the user trimaps, no
+ * compositing (imgs = flipped fg / 255) */
 int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
                      float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
                      float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,

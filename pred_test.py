@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Counterpart of the reference's pred_test.py (real-video inference from `<video>/*_rgb.png` + `*_trimap.png`
+folders) on the HIP path: same sample construction (previous / current / next frame with the clip ends mirrored,
+pred_test.py:27-41), reflect padding to multiples of 32 (:47-66), EvalModel forward, crop, uint8(alpha * 255) PNGs.
+
+    python pred_test.py --data <root> --load <NET state_dict .pth> --save <out dir> [--videos v1 v2] [--dilation 5]
+
+PNG I/O uses Pillow (OpenCV is not in this image); frames are converted to the BGR channel order cv2.imread yields.
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from models.model import EvalModel
+
+
+class TestFolder(object):
+    SAMPLE_LENGTH = 3
+
+    def __init__(self, data_root, videos):
+        self.data_root = data_root
+        if not videos:
+            videos = [os.path.basename(f) for f in sorted(glob.glob(os.path.join(data_root, '*'))) if os.path.isdir(f)]
+        self.samples = []
+        for v in sorted(videos):
+            src = sorted(glob.glob(os.path.join(data_root, v, '*_rgb.png')))
+            tri = sorted(glob.glob(os.path.join(data_root, v, '*_trimap.png')))
+            assert len(src) == len(tri) and len(src) >= 2, 'video %s: %d frames, %d trimaps' % (v, len(src), len(tri))
+            frames = list(zip(src, tri))
+            for c in range(len(frames)):
+                p = c + 1 if c == 0 else c - 1
+                n = c - 1 if c == len(frames) - 1 else c + 1
+                self.samples.append((frames[p], frames[c], frames[n]))
+
+    def __len__(self):
+        return len(self.samples)
+
+    @staticmethod
+    def possible_pad(t):
+        H, W = t.shape[-2:]
+        NH, NW = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+        t = t.float()
+        if H == NH and W == NW:
+            return t
+        return F.pad(t.unsqueeze(0), (0, NW - W, 0, NH - H), mode='reflect').squeeze(0)
+
+    def __getitem__(self, idx):
+        from PIL import Image
+        imgs, tris = [], []
+        for rgb, tri in self.samples[idx]:
+            im = np.asarray(Image.open(rgb).convert('RGB'))[..., ::-1].copy()        # BGR, as cv2.imread
+            tr = np.asarray(Image.open(tri).convert('L'))[..., None]
+            imgs.append(self.possible_pad(torch.from_numpy(im).permute(2, 0, 1)))
+            tris.append(self.possible_pad(torch.from_numpy(tr.copy()).permute(2, 0, 1)))
+        return torch.stack(imgs).float(), torch.stack(tris).float(), im.shape[:2]
+
+
+def pred(dataset, indices, device, args):
+    from PIL import Image
+    torch.cuda.set_device(device)
+    c = dataset.SAMPLE_LENGTH // 2
+    model = EvalModel(model=args.model, agg_window=args.agg_window, dilate_kernel=args.dilation)
+    model.NET.load_state_dict(torch.load(args.load, map_location='cpu'), strict=True)
+    model.to(device).eval()
+    out = []
+    for i in range(*indices):
+        imgs, tris, (H, W) = dataset[i]
+        alpha = model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0)).squeeze()[c][:H, :W].cpu().numpy()
+        info = os.path.normpath(dataset.samples[i][c][0]).split(os.sep)
+        outfn = os.path.join(args.save, info[-2], info[-1][:-8] + '_alpha.png')
+        os.makedirs(os.path.dirname(outfn), exist_ok=True)
+        Image.fromarray(np.uint8(alpha * 255)).save(outfn)
+        out.append(outfn)
+    return out
+
+
+def main(args):
+    if args.save is None:
+        args.save = 'test_results/{}'.format(os.path.splitext(args.load)[0])
+    os.makedirs(args.save, exist_ok=True)
+    dataset = TestFolder(args.data, args.videos)
+    return pred(dataset, (0, len(dataset)), torch.device('cuda', args.gpu), args)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--data', required=True)
+    ap.add_argument('--videos', nargs='*', default=[])
+    ap.add_argument('--load', required=True)
+    ap.add_argument('--save', default=None)
+    ap.add_argument('--model', default='vmn_gca')
+    ap.add_argument('--agg_window', type=int, default=7)
+    ap.add_argument('--dilation', type=int, default=None)
+    ap.add_argument('--gpu', type=int, default=0)
+    return ap.parse_args(argv)
+
+
+if __name__ == '__main__':
+    main(parse())

@@ -32,10 +32,14 @@ __global__ void preprocess_kernel(const float* __restrict__ a, const float* __re
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float ff = fg[(f * 3 + (2 - c)) * HW + p] * s;      // BGR -> RGB flip
-            const float bb = bg[(f * 3 + (2 - c)) * HW + p] * s;
             fgs[(f * 3 + c) * HW + p] = ff;
-            bgs[(f * 3 + c) * HW + p] = bb;
-            imgs[(f * 3 + c) * HW + p] = ff * g + bb * (1.f - g);
+            if (bg) {
+                const float bb = bg[(f * 3 + (2 - c)) * HW + p] * s;
+                bgs[(f * 3 + c) * HW + p] = bb;
+                imgs[(f * 3 + c) * HW + p] = ff * g + bb * (1.f - g);
+            } else {                                                  // EvalModel: `fg` is the frame itself, `a` the user trimap
+                imgs[(f * 3 + c) * HW + p] = ff;
+            }
         }
     }
 }
@@ -249,7 +253,8 @@ extern "C" int tcvom_preprocess(const float* a, const float* fg, const float* bg
                                 float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
                                 float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
                                 void* stream) {
-    TCVOM_CHECK_ARG(a && fg && bg && gts && fgs && bgs && imgs && unk_raw && unk_tmp && unk_dil && x8 && trimask && tris_vis,
+    // bg == NULL (then bgs may be NULL too): EvalModel.preprocess (models/model.py:360-386) -- `fg` is the frame, `a` the trimap
+    TCVOM_CHECK_ARG(a && fg && gts && fgs && (bgs || !bg) && imgs && unk_raw && unk_tmp && unk_dil && x8 && trimask && tris_vis,
                     "preprocess: null pointer");
     TCVOM_CHECK_ARG(frames > 0 && H > 0 && W > 0 && dilate_radius >= 0, "preprocess: bad shape");
     hipStream_t st = (hipStream_t)stream;

@@ -30,10 +30,12 @@ def preprocess_window(a, fg, bg, dilate_kernel, eps):
         raise RuntimeError('tcvom_amd runs on the GPU through libtcvom_hip.so only (no CPU fallback)')
     B, S, _, H, W = a.shape
     dev = a.device
-    a, fg, bg = a.float().contiguous(), fg.float().contiguous(), bg.float().contiguous()
+    a, fg = a.float().contiguous(), fg.float().contiguous()
+    bg = bg.float().contiguous() if bg is not None else None      # None: EvalModel (a = user trimap, fg = frame)
     p = _Prep()
     p.gts = _f32((B, S, 1, H, W), dev)
-    p.fgs, p.bgs, p.imgs = _f32((B, S, 3, H, W), dev), _f32((B, S, 3, H, W), dev), _f32((B, S, 3, H, W), dev)
+    p.fgs, p.imgs = _f32((B, S, 3, H, W), dev), _f32((B, S, 3, H, W), dev)
+    p.bgs = _f32((B, S, 3, H, W), dev) if bg is not None else None
     u8 = lambda: torch.empty((B, S, H, W), dtype=torch.uint8, device=dev)
     p.unk_raw, tmp, p.unk = u8(), u8(), u8()
     p.x8 = torch.empty((B, S, H, W, 8), dtype=torch.bfloat16, device=dev)
@@ -199,13 +201,29 @@ class FullModel_VMD(FullModel):
 
 
 class EvalModel(FullModel):
-    """Inference on image + user trimap (models/model.py:359-453) — next round."""
+    """Inference on frames + user trimaps (models/model.py:359-453)."""
 
     def __init__(self, model, agg_window, dilate_kernel):
         super().__init__(model, dilate_kernel=dilate_kernel, agg_window=agg_window)
 
     def forward(self, imgs, tris):
-        raise NotImplementedError('EvalModel is scheduled after the training window path (SURVEY.md §8f.1)')
+        """imgs [B,S,3,H,W] BGR 0..255, tris [B,S,1,H,W] in {0, 128, 255} -> alphas [B,S,1,H,W]: the prediction inside the
+        (optionally dilated) unknown region and the trimap value elsewhere for the interior frames, zeros for the
+        first and last frame (models/model.py:388-424; callers pred_test.py:90-109)."""
+        B, S = imgs.shape[:2]
+        H, W = imgs.shape[-2:]
+        assert self.model_name.startswith('vmn'), 'only the VMN architectures run on the HIP path'
+        assert S >= 3 and H % 32 == 0 and W % 32 == 0, 'pad the frames to multiples of 32 (pred_test.py:47-66)'
+        with torch.no_grad():
+            dil = self.DILATION_KERNEL if self.DILATION_KERNEL is not None else 0
+            prep = preprocess_window(tris, imgs, None, dil, 0.0)
+            frames = [prep.x8[:, s].contiguous() for s in range(S)]
+            prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
+            preds, _attb, _attf = self.NET.run(frames, prep.unk8)
+            alphas = torch.zeros((B, S, 1, H, W), dtype=torch.float32, device=imgs.device)
+            for c in range(1, S - 1):
+                alphas[:, c] = torch.where(prep.trimask[:, c] > 0, preds[c].float(), prep.gts[:, c])
+        return alphas
 
 
 def train_step_loss(out):

@@ -229,6 +229,42 @@ def gen_window():
         save(name, **arrs)
 
 
+EVAL_CASES = {
+    # name: (B, S, H, W, dilate, window)
+    'eval_s3_64x96': (1, 3, 64, 96, 3, 7),
+    'eval_s3_128x160': (1, 3, 128, 160, None, 7),
+}
+
+
+def eval_inputs(B, S, H, W):
+    """Images / user trimaps for EvalModel (pred_test.py:77-88): BGR 0..255 frames and {0,128,255} trimaps derived
+    from the synthetic moving-disk alpha (unknown band = soft edge)."""
+    a, fg, bg = synthetic_window(B, S, H, W, seed=3)
+    al = a / 255.0
+    imgs = torch.round(fg * al + bg * (1 - al))
+    tris = torch.where(a <= 0, torch.zeros_like(a), torch.where(a >= 255, torch.full_like(a, 255.0), torch.full_like(a, 128.0)))
+    return imgs, tris
+
+
+def gen_eval():
+    for name, (B, S, H, W, dil, win) in EVAL_CASES.items():
+        # formula running statistics do not match the formula weights' activations (eval-mode output is NaN), so
+        # both sides first run two train-mode calibration windows (BatchNorm EMA + SpectralNorm u/v), then evaluate
+        fm = ref_model.FullModel_VMD('vmn_gca', agg_window=win, dilate_kernel=12)
+        fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
+        fm.train()
+        with torch.no_grad():
+            for _ in range(2):
+                fm(*synthetic_window(B, S, H, W, seed=0))
+        em = ref_model.EvalModel('vmn_gca', agg_window=win, dilate_kernel=dil)
+        em.NET.load_state_dict(fm.NET.state_dict())
+        em.eval()
+        imgs, tris = eval_inputs(B, S, H, W)
+        with torch.no_grad():
+            alphas = em(imgs, tris)
+        save(name, alphas=alphas, imgs_sum=imgs.sum(), tris_sum=tris.sum())
+
+
 def gen_state_keys():
     sd = ref_model.FullModel_VMD('vmn_gca', agg_window=7).NET.state_dict()
     save('state_keys', keys=np.array(list(sd.keys())),
@@ -247,3 +283,4 @@ if __name__ == '__main__':
     gen_gca()
     gen_facade()
     gen_window()
+    gen_eval()

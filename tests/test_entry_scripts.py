@@ -1,5 +1,7 @@
 """The reference's entry-script call surface: config keys (CPU) and train_ddp.py / pred_vmn.py on the GPU."""
 import os
+
+import numpy as np
 import sys
 
 import pytest
@@ -76,3 +78,48 @@ def test_pred_vmn_runs_at_1080p(capsys):
     pred_vmn.main(argparse.Namespace(model='gca', load=None, trimap='medium', agg_window=7, clips=1, save=None))
     out = capsys.readouterr().out
     assert 'L_alpha' in out and 'L_total' in out
+
+
+@pytest.mark.gpu
+def test_pred_test_folder_inference(tmp_path):
+    """pred_test.py counterpart: a synthetic 4-frame `*_rgb.png` / `*_trimap.png` folder (70x100, so the reflect padding
+    to 96x128 is exercised) -> one alpha PNG per frame, equal to a direct EvalModel call on the padded sample."""
+    from PIL import Image
+    import pred_test
+    from models.model import EvalModel
+    from tcvom_amd.synthetic import formula_tensor, synthetic_window
+    H, W, T = 70, 100, 4
+    a, fg, bg = synthetic_window(1, T, H, W, seed=5)
+    al = a / 255.0
+    imgs = torch.round(fg * al + bg * (1 - al))[0]                 # [T,3,H,W] BGR
+    tris = torch.where(a <= 0, torch.zeros_like(a), torch.where(a >= 255, torch.full_like(a, 255.0), torch.full_like(a, 128.0)))[0]
+    vdir = tmp_path / 'data' / 'clip0'
+    vdir.mkdir(parents=True)
+    for t in range(T):
+        Image.fromarray(imgs[t].permute(1, 2, 0).numpy().astype(np.uint8)[..., ::-1].copy()).save(str(vdir / ('%04d_rgb.png' % t)))
+        Image.fromarray(tris[t, 0].numpy().astype(np.uint8)).save(str(vdir / ('%04d_trimap.png' % t)))
+    from models.model import FullModel_VMD
+    fm = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+    fm.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in fm.NET.state_dict().items()})
+    fm = fm.to('cuda').train()
+    with torch.no_grad():                                          # calibrate the BatchNorm running statistics
+        for _ in range(2):
+            fm(*(t.cuda() for t in synthetic_window(1, 3, 96, 128, seed=0)))
+    em = EvalModel('vmn_gca', agg_window=7, dilate_kernel=2)
+    em.NET.load_state_dict(fm.NET.state_dict())
+    ck = str(tmp_path / 'net.pth')
+    torch.save(em.NET.state_dict(), ck)
+    args = pred_test.parse(['--data', str(tmp_path / 'data'), '--load', ck, '--save', str(tmp_path / 'out'), '--dilation', '2'])
+    outs = pred_test.main(args)
+    assert len(outs) == T and all(os.path.exists(o) for o in outs)
+    ds = pred_test.TestFolder(str(tmp_path / 'data'), [])
+    assert [os.path.basename(s[1][0]) for s in ds.samples] == ['%04d_rgb.png' % t for t in range(T)]
+    assert os.path.basename(ds.samples[0][0][0]) == '0001_rgb.png' and os.path.basename(ds.samples[-1][2][0]) == '0002_rgb.png'
+    x, tr, (h, w) = ds[1]
+    assert tuple(x.shape) == (3, 3, 96, 128) and (h, w) == (H, W)
+    assert torch.equal(x[1, :, :H, :W], imgs[1]) and torch.equal(x[1, :, H:, :W], torch.flip(imgs[1][:, H - 1 - (96 - H):H - 1, :], [1]))
+    em = em.to('cuda').eval()
+    direct = em(x.cuda().unsqueeze(0), tr.cuda().unsqueeze(0)).squeeze()[1][:H, :W].cpu().numpy()
+    got = np.asarray(Image.open(outs[1])).astype(np.float32)
+    assert np.isfinite(direct).all() and 0.0 < direct.mean() < 1.0
+    assert got.shape == (H, W) and np.abs(got - np.uint8(direct * 255).astype(np.float32)).max() <= 1

@@ -215,15 +215,16 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     ck.done()
 
 
-@pytest.mark.parametrize('cin,hp,N,H,W', [(32, False, 2, 16, 64), (32, True, 1, 24, 96), (6, False, 1, 16, 160), (32, False, 1, 72, 96)])
-def test_halo_conv_kernel(cin, hp, N, H, W):
+@pytest.mark.parametrize('cin,cout,hp,N,H,W', [(32, 32, False, 2, 16, 64), (32, 32, True, 1, 24, 96), (6, 32, False, 1, 16, 160),
+                                              (32, 32, False, 1, 72, 96), (64, 64, False, 2, 16, 64), (64, 64, True, 1, 24, 96),
+                                              (64, 32, False, 1, 16, 96), (32, 64, False, 1, 40, 64)])
+def test_halo_conv_kernel(cin, cout, hp, N, H, W):
     """Shapes served by the halo-tile direct conv (stride-1 3x3, <= 32 channels, H % 8 == 0, W % 32 == 0): forward
-    with fused ReLU + batch statistics, data gradient (also through the halo kernel) and weight gradient, against
+    with fused ReLU + batch statistics (64 output channels = two workgroups per tile), data gradient (also through the halo kernel) and weight gradient, against
     fp32 PyTorch on the same bf16 operands.  hp = bf16 hi + residual weights (18 taps), fp32 conv output."""
     from tcvom_amd import ops
     from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
-    cout = 32
-    tag = 'halo%d_%d_%d' % (cin, int(hp), H)
+    tag = 'halo%d_%d_%d_%d' % (cin, cout, int(hp), H)
     w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cout, cin, 3, 3)) * 0.2).to(DEV))
     bank = WeightBank()
     spec = ConvSpec(tag, w, None, None, None, False, 1, 1, 'frame', needs_dgrad=cin >= 16, hp=hp)

@@ -109,3 +109,40 @@ def test_eval_mode_runs_and_is_deterministic():
         o2 = m(a, fg, bg)
     assert torch.equal(o1[7], o2[7])
     assert torch.isfinite(o1[7]).all()
+
+
+def eval_inputs(B, S, H, W):
+    """Same construction as tests/golden/gen_golden.py:eval_inputs."""
+    a, fg, bg = synthetic_window(B, S, H, W, seed=3)
+    al = a / 255.0
+    imgs = torch.round(fg * al + bg * (1 - al))
+    tris = torch.where(a <= 0, torch.zeros_like(a), torch.where(a >= 255, torch.full_like(a, 255.0), torch.full_like(a, 128.0)))
+    return imgs, tris
+
+
+@pytest.mark.parametrize('name,shape', [('eval_s3_64x96', (1, 3, 64, 96, 3, 7)), ('eval_s3_128x160', (1, 3, 128, 160, None, 7))])
+def test_eval_model_vs_reference_golden(name, shape):
+    """EvalModel (frames + user trimaps, eval-mode BatchNorm / SpectralNorm) against the reference's EvalModel.  As in
+    the generator, two train-mode calibration windows first give the running statistics something meaningful."""
+    from models.model import EvalModel
+    B, S, H, W, dil, win = shape
+    g = golden(name)
+    fm = _model(win, 12).train()
+    with torch.no_grad():
+        for _ in range(2):
+            fm(*(t.to(DEV) for t in synthetic_window(B, S, H, W, seed=0)))
+    em = EvalModel('vmn_gca', agg_window=win, dilate_kernel=dil)
+    em.NET.load_state_dict(fm.NET.state_dict())
+    em = em.to(DEV).eval()
+    imgs, tris = eval_inputs(B, S, H, W)
+    assert_close(imgs.sum(), g['imgs_sum'], 0, 0.5, 'imgs')
+    alphas = em(imgs.to(DEV), tris.to(DEV)).cpu().numpy()
+    ref = g['alphas']
+    assert alphas.shape == ref.shape
+    assert np.array_equal(alphas[:, 0], ref[:, 0]) and np.array_equal(alphas[:, -1], ref[:, -1])      # zeros at the clip ends
+    known = (tris.numpy() != 128.0) if dil is None else None
+    if known is not None:
+        assert np.array_equal(alphas[:, 1][known[:, 1]], ref[:, 1][known[:, 1]])                      # trimap passes through
+    mse = float(np.mean((alphas - ref) ** 2))
+    print('%s: alpha MSE vs reference EvalModel %.3e' % (name, mse))
+    assert mse <= 1e-3
