@@ -166,11 +166,13 @@ int tcvom_add(const void* a, const void* b, const void* c, void* z, int64_t nume
 int tcvom_colsum(const void* dy, float* out, int64_t P, int32_t K, int32_t ld, void* stream);
 int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_t Cc, int64_t ldi, int64_t ldo,
                          int32_t batch, int64_t in_bstride, int64_t out_bstride, void* stream);
-/* decoder head: conv2 (3x3, 32->1, bias) + (tanh+1)/2   (resnet_dec.py:80, VMN_GCA.py:45-47); w is fp32 [9][C] */
+/* final conv C -> 1 with the output map fused: ksize 3 / mode 0 = (tanh + 1) / 2 (GCA decoder, resnet_dec.py:139-141),
+ * ksize 5 / mode 1 = clamp(0, 1) (DIM alpha_pred, models/DIM/vggnet.py:76,123).  w is fp32 [ksize*ksize][C]. */
 int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
-                        int32_t W, int32_t C, void* stream);
+                        int32_t W, int32_t C, int32_t ksize, int32_t mode, void* stream);
 int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
-                        float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+                        float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
+                        int32_t ksize, int32_t mode, void* stream);
 
 /* ------------------------------------------------------------------ Temporal Attention Module
  * Replaces FeatureAggregationModule._attention x2 + `v + xb + xf` (models/VMN/VMN_model.py:24-68).
@@ -197,6 +199,35 @@ int tcvom_gca_unfold(const void* dY, void* dO, int32_t B, int32_t h8, int32_t w8
 int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G, const float* nrm, void* dg8, int32_t B,
                           int32_t h8, int32_t w8, int32_t CG, void* stream);
 
+/* ------------------------------------------------------------------ DIM base (models/DIM/vggnet.py, config 1)
+ * MaxPool2d(2, return_indices) / MaxUnpool2d(2) on NHWC bf16: idx holds the position (0..3 = dy*2+dx, first maximum
+ * in scan order as torch) of every pooled element, one byte each.
+ *   maxpool2_idx : x [N,H,W,C] -> y [N,H/2,W/2,C], idx            (vggnet.py:23,80)
+ *   unpool2      : y, idx -> x (zeros elsewhere)                  (vggnet.py:61,104; also the max-pool gradient)
+ *   pick2        : x [N,H,W,C], idx -> y [N,H/2,W/2,C] = x at idx (the unpool gradient)
+ *   relu_bwd     : dy = y > 0 ? dz : 0 for conv+bias+ReLU layers without BatchNorm (vggnet.py:99-118) */
+int tcvom_maxpool2_idx(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_unpool2(const void* y, const uint8_t* idx, void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_pick2(const void* x, const uint8_t* idx, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_relu_bwd(const void* dz, const void* y, void* dy, int64_t numel, void* stream);
+/* im2col / col2im for conv6 (7x7, 512 -> 4096, vggnet.py:56), which runs as unfold + dense GEMM:
+ *   unfold: u[p][t*C + c] = x[p + off_t][c];   fold: dx[q][c] = sum_t du[q - off_t][c*T + t]  (du is c-major) */
+int tcvom_unfold(const void* x, void* u, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ksize, void* stream);
+int tcvom_fold(const void* du, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ksize, void* stream);
+/* DIM losses on one frame (models/model.py:94-127, utils/loss_func.py:9-22,42-59): with refine = mask ? pred : gt,
+ *   acc[0] = sum_c |fg_c refine + bg_c (1 - refine) - img_c| mask       (L_comp numerator; fg/bg/img [B,3,HW] strided)
+ *   acc[2] = sum |sqrt(dx(refine)^2 + dy(refine)^2 + e) - sqrt(dx(gt)^2 + dy(gt)^2 + e)| mask    (L_grad numerator)
+ *   acc[1] = acc[3] = sum [mask > e]    (denominator count; two (sum, count) pairs for tcvom_loss_finalize)
+ * and the gradient w.r.t. pred of  w_comp * L_comp + w_grad * L_grad  given the finished acc.  pred/gt/mask are
+ * [B,HW] planes with batch strides p_stride / frame_stride, fg/bg/img batch stride rgb_stride. */
+int tcvom_dim_losses_fwd(const float* pred, const float* gt, const float* mask, const float* fg, const float* bg,
+                         const float* img, float* comps /*[B,3,HW] or NULL*/, float* acc, int32_t B, int32_t H, int32_t W,
+                         int64_t p_stride, int64_t frame_stride, int64_t rgb_stride, void* stream);
+int tcvom_dim_losses_bwd(const float* pred, const float* gt, const float* mask, const float* fg, const float* bg,
+                         const float* img, const float* acc, const float* g_comp, const float* g_grad, float* dpred,
+                         int32_t accumulate, int32_t B, int32_t H, int32_t W, int64_t p_stride, int64_t frame_stride,
+                         int64_t rgb_stride, void* stream);
+
 /* ------------------------------------------------------------------ facade: preprocessing, losses, optimizer
  * (models/model.py:54-127,285-345; utils/loss_func.py:9-22; train_ddp.py:296-297)               */
 /* bg == NULL selects EvalModel.preprocess (models/model.py:360-386): `fg` holds the frames, `a` the user trimaps, no
@@ -204,6 +235,7 @@ int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G, const floa
 int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
                      float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
                      float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
+                     int32_t tri_channels /* 3: one-hot {bg,unk,fg} (GCA); 1: 128/255-in-unknown plane (DIM, Index) */,
                      void* stream);
 int tcvom_masked_l1_fwd(const float* p1, const float* g1, const float* m1, const float* p2, const float* g2,
                         const float* m2, const float* fgs, const float* bgs, float* alphas, float* comps,

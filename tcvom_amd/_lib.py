@@ -86,8 +86,16 @@ _PROTOS = {
     'tcvom_add': [vp, vp, vp, vp, i64, vp],
     'tcvom_colsum': [vp, vp, i64, i32, i32, vp],
     'tcvom_transpose_bf16': [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp],
-    'tcvom_head_conv_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    'tcvom_head_conv_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_head_conv_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_head_conv_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_maxpool2_idx': [vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_unpool2': [vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_pick2': [vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_relu_bwd': [vp, vp, vp, i64, vp],
+    'tcvom_unfold': [vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_fold': [vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_dim_losses_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp],
+    'tcvom_dim_losses_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
     'tcvom_tam_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_tam_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_gca_prepare': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -98,7 +106,7 @@ _PROTOS = {
     'tcvom_gca_fold': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_gca_unfold': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_gca_patches_bwd': [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    'tcvom_preprocess': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, vp],
+    'tcvom_preprocess': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
     'tcvom_masked_l1_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
     'tcvom_masked_l1_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i64, i64, i64, vp],
     'tcvom_avgpool8': [vp, vp, i64, i32, i32, vp],

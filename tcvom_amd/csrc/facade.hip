@@ -62,7 +62,7 @@ __global__ void dilate_kernel(const unsigned char* __restrict__ in, unsigned cha
 // stage 3: network input x8 [F,H,W,8] bf16 = {norm R,G,B, onehot bg,unk,fg, 0, 0}; trimask fp32; tris_vis fp32
 __global__ void assemble_kernel(const float* __restrict__ gts, const float* __restrict__ imgs, const unsigned char* __restrict__ dil,
                                 uint4* __restrict__ x8, float* __restrict__ trimask, float* __restrict__ tris_vis,
-                                int64_t F, int64_t HW, float eps) {
+                                int64_t F, int64_t HW, float eps, int tri_channels) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
     GRID_STRIDE(v, F * HW) {
         const int64_t f = v / HW, p = v % HW;
@@ -74,14 +74,20 @@ __global__ void assemble_kernel(const float* __restrict__ gts, const float* __re
         float o[8];
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = (imgs[(f * 3 + c) * HW + p] - mean[c]) * istd[c];
-        o[3] = cls == 0 ? 1.f : 0.f;
-        o[4] = cls == 1 ? 1.f : 0.f;
-        o[5] = cls == 2 ? 1.f : 0.f;
+        if (tri_channels == 3) {            // GCA: one-hot {bg, unknown, fg}
+            o[3] = cls == 0 ? 1.f : 0.f;
+            o[4] = cls == 1 ? 1.f : 0.f;
+            o[5] = cls == 2 ? 1.f : 0.f;
+        } else {                            // DIM / Index: one channel, 128/255 in the unknown region (models/model.py:67-69)
+            o[3] = u ? 128.f / 255.f : al;
+            o[4] = 0.f;
+            o[5] = 0.f;
+        }
         o[6] = 0.f;
         o[7] = 0.f;
         x8[v] = pack8(o);
         trimask[v] = u ? 1.f : 0.f;
-        tris_vis[v] = u ? 128.f / 255.f : g;
+        tris_vis[v] = u ? 128.f / 255.f : (tri_channels == 3 ? g : al);
     }
 }
 
@@ -252,17 +258,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ t
 extern "C" int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
                                 float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
                                 float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
-                                void* stream) {
+                                int32_t tri_channels, void* stream) {
     // bg == NULL (then bgs may be NULL too): EvalModel.preprocess (models/model.py:360-386) -- `fg` is the frame, `a` the trimap
     TCVOM_CHECK_ARG(a && fg && gts && fgs && (bgs || !bg) && imgs && unk_raw && unk_tmp && unk_dil && x8 && trimask && tris_vis,
                     "preprocess: null pointer");
     TCVOM_CHECK_ARG(frames > 0 && H > 0 && W > 0 && dilate_radius >= 0, "preprocess: bad shape");
+    TCVOM_CHECK_ARG(tri_channels == 3 || tri_channels == 1, "preprocess: %d trimap channels (3: one-hot, 1: DIM/Index)", tri_channels);
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W;
     hipLaunchKernelGGL(preprocess_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, a, fg, bg, gts, fgs, bgs, imgs, unk_raw, frames, HW, eps);
     hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_raw, unk_tmp, frames, H, W, dilate_radius, 0);
     hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_tmp, unk_dil, frames, H, W, dilate_radius, 1);
-    hipLaunchKernelGGL(assemble_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, gts, imgs, unk_dil, (uint4*)x8, trimask, tris_vis, frames, HW, eps);
+    hipLaunchKernelGGL(assemble_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, gts, imgs, unk_dil, (uint4*)x8, trimask, tris_vis, frames, HW, eps, tri_channels);
     TCVOM_LAUNCH_CHECK("preprocess");
     return TCVOM_OK;
 }

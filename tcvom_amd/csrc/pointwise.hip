@@ -186,13 +186,30 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16raw* __restric
     }
 }
 
-// ---------------------------------------------------------------- final conv 32->1 (3x3, pad 1, bias) + (tanh+1)/2
-// x NHWC bf16 [N,H,W,C]; w fp32 [9][C] (tap-major); alpha fp32 [N,H,W]
+// ---------------------------------------------------------------- final conv C->1 (KS x KS, pad KS/2, bias) + output map
+// MODE 0: alpha = (tanh(pre) + 1) / 2   (GCA decoder head, resnet_dec.py:139-141; KS = 3)
+// MODE 1: alpha = clamp(pre, 0, 1)      (DIM alpha_pred, models/DIM/vggnet.py:76,123; KS = 5)
+// x NHWC bf16 [N,H,W,C]; w fp32 [KS*KS][C] (tap-major); alpha fp32 [N,H,W]
+template <int MODE>
+__device__ __forceinline__ float head_out(float pre) {
+    return MODE == 0 ? 0.5f * (tanhf(pre) + 1.f) : fminf(fmaxf(pre, 0.f), 1.f);
+}
+template <int MODE>
+__device__ __forceinline__ float head_dpre(float dalpha, float alpha) {
+    if (MODE == 0) {
+        const float th = 2.f * alpha - 1.f;
+        return dalpha * 0.5f * (1.f - th * th);
+    }
+    return (alpha > 0.f && alpha < 1.f) ? dalpha : 0.f;
+}
+
+template <int KS, int MODE>
 __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16raw* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ alpha,
                                                             int N, int H, int W, int C) {
+    constexpr int T = KS * KS, R = KS / 2;
     extern __shared__ float ws[];
-    for (int i = threadIdx.x; i < 9 * C; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < T * C; i += 256) ws[i] = w[i];
     __syncthreads();
     const int64_t n = (int64_t)N * H * W;
     const int C8 = C / 8;
@@ -202,8 +219,8 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16raw* __res
         const int nn = (int)(p / ((int64_t)W * H));
         float acc = bias[0];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ih = yh + t / 3 - 1, iw = xw + t % 3 - 1;
+        for (int t = 0; t < T; ++t) {
+            const int ih = yh + t / KS - R, iw = xw + t % KS - R;
             if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
             const uint4* src = reinterpret_cast<const uint4*>(x + (((int64_t)nn * H + ih) * W + iw) * C);
             for (int c8 = 0; c8 < C8; ++c8) {
@@ -213,15 +230,17 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16raw* __res
                 for (int k = 0; k < 8; ++k) acc += f[k] * ws[t * C + c8 * 8 + k];
             }
         }
-        alpha[p] = 0.5f * (tanhf(acc) + 1.f);
+        alpha[p] = head_out<MODE>(acc);
     }
 }
-// dpre = dalpha * 0.5 * (1 - tanh^2) with tanh = 2*alpha-1;  dx[p][c] = sum_t dpre[p - off_t] w[t][c]
+// dx[p][c] = sum_t dpre[p - off_t] w[t][c]
+template <int KS, int MODE>
 __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __restrict__ dalpha, const float* __restrict__ alpha,
                                                                  const float* __restrict__ w, bf16raw* __restrict__ dx,
                                                                  float* __restrict__ dpre_out, int N, int H, int W, int C) {
+    constexpr int T = KS * KS, R = KS / 2;
     extern __shared__ float ws[];
-    for (int i = threadIdx.x; i < 9 * C; i += 256) ws[i] = w[i];
+    for (int i = threadIdx.x; i < T * C; i += 256) ws[i] = w[i];
     __syncthreads();
     const int C8 = C / 8;
     const int64_t n = (int64_t)N * H * W * C8;
@@ -233,35 +252,35 @@ __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __
         const int nn = (int)(p / ((int64_t)W * H));
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < T; ++t) {
             // output pixel q = p - (t offset):  x[p] contributed to pre[q] with tap t where p = q + off_t
-            const int qh = yh - (t / 3 - 1), qw = xw - (t % 3 - 1);
+            const int qh = yh - (t / KS - R), qw = xw - (t % KS - R);
             if (qh < 0 || qh >= H || qw < 0 || qw >= W) continue;
             const int64_t q = ((int64_t)nn * H + qh) * W + qw;
-            const float th = 2.f * alpha[q] - 1.f;
-            const float dp = dalpha[q] * 0.5f * (1.f - th * th);
+            const float dp = head_dpre<MODE>(dalpha[q], alpha[q]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += dp * ws[t * C + c8 * 8 + k];
         }
         *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8(acc);
-        if (c8 == 0 && dpre_out) {
-            const float th = 2.f * alpha[p] - 1.f;
-            dpre_out[p] = dalpha[p] * 0.5f * (1.f - th * th);
-        }
+        if (c8 == 0 && dpre_out) dpre_out[p] = head_dpre<MODE>(dalpha[p], alpha[p]);
     }
 }
 // dw[t][c] = sum_p dpre[p] x[p + off_t][c];  db = sum_p dpre[p].
-// block = 256 threads = (256/C) pixel lanes x C channels; each thread keeps 9 tap accumulators for its channel
+// block = 256 threads = (256/C) pixel lanes x C channels; each thread keeps KS*KS tap accumulators for its channel
 // over the block's pixel chunk; lanes are combined through LDS, then one atomicAdd per (tap, channel) per block.
+template <int KS>
 __global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* __restrict__ dpre, const bf16raw* __restrict__ x,
                                                                    float* __restrict__ dw, float* __restrict__ db,
                                                                    int N, int H, int W, int C, int rows_per_block) {
-    __shared__ float red[9 * 256];
+    constexpr int T = KS * KS, R = KS / 2;
+    __shared__ float red[T * 256];
     const int64_t P = (int64_t)N * H * W;
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     const int c = threadIdx.x % C, pl = threadIdx.x / C, PL = 256 / C;
-    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bsum = 0.f;
+    float acc[T], bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
     if (pl < PL) {
         for (int64_t p = pbeg + pl; p < pend; p += PL) {
             const float dp = dpre[p];
@@ -269,19 +288,19 @@ __global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* 
             const int yh = (int)((p / W) % H);
             if (c == 0) bsum += dp;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ih = yh + t / 3 - 1, iw = xw + t % 3 - 1;
+            for (int t = 0; t < T; ++t) {
+                const int ih = yh + t / KS - R, iw = xw + t % KS - R;
                 if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                    acc[t] += dp * bf2f(x[(p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * C + c]);
+                    acc[t] += dp * bf2f(x[(p + (int64_t)(t / KS - R) * W + (t % KS - R)) * C + c]);
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) red[t * 256 + threadIdx.x] = acc[t];
+    for (int t = 0; t < T; ++t) red[t * 256 + threadIdx.x] = acc[t];
     __syncthreads();
     if (threadIdx.x < C) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < T; ++t) {
             float s = 0.f;
             for (int l = 0; l < PL; ++l) s += red[t * 256 + l * C + threadIdx.x];
             atomicAdd(dw + t * C + threadIdx.x, s);
@@ -361,28 +380,40 @@ extern "C" int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_
     return TCVOM_OK;
 }
 extern "C" int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
-                                   int32_t W, int32_t C, void* stream) {
+                                   int32_t W, int32_t C, int32_t ksize, int32_t mode, void* stream) {
     TCVOM_CHECK_ARG(x && w && bias && alpha && C % 8 == 0 && C <= 256, "head_conv_fwd: bad args");
-    hipLaunchKernelGGL(head_conv_fwd_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 9 * C * sizeof(float),
-                       (hipStream_t)stream, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+    TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && mode == 1), "head_conv_fwd: ksize=%d mode=%d not instantiated", ksize, mode);
+    const dim3 g(grid_for((int64_t)N * H * W));
+    hipStream_t st = (hipStream_t)stream;
+    if (ksize == 3)
+        hipLaunchKernelGGL((head_conv_fwd_kernel<3, 0>), g, dim3(256), 9 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+    else
+        hipLaunchKernelGGL((head_conv_fwd_kernel<5, 1>), g, dim3(256), 25 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
     TCVOM_LAUNCH_CHECK("head_conv_fwd");
     return TCVOM_OK;
 }
 extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
                                    float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
-                                   void* stream) {
+                                   int32_t ksize, int32_t mode, void* stream) {
     TCVOM_CHECK_ARG(dalpha && alpha && x && w && dx && dpre && dw && db && C % 8 == 0 && C <= 256 && 256 % C == 0, "head_conv_bwd: bad args");
+    TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && mode == 1), "head_conv_bwd: ksize=%d mode=%d not instantiated", ksize, mode);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_conv_bwd_data_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(256),
-                       9 * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
-    if (hipMemsetAsync(dw, 0, sizeof(float) * 9 * C, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float), st) != hipSuccess)
+    const int T = ksize * ksize;
+    const dim3 g(grid_for((int64_t)N * H * W * C / 8));
+    if (ksize == 3)
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<3, 0>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+    else
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 1>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+    if (hipMemsetAsync(dw, 0, sizeof(float) * T * C, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float), st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "head_conv_bwd: memset failed");
     const int64_t P = (int64_t)N * H * W;
     int64_t blocks = (P + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
     const int rpb = (int)((P + blocks - 1) / blocks);
-    hipLaunchKernelGGL(head_conv_bwd_weight_kernel, dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H,
-                       W, C, rpb);
+    if (ksize == 3)
+        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<3>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb);
+    else
+        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<5>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb);
     TCVOM_LAUNCH_CHECK("head_conv_bwd");
     return TCVOM_OK;
 }

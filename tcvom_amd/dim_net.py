@@ -1,0 +1,85 @@
+"""Deep Image Matting base (VGG16-BN encoder, max-unpooling decoder) on the HIP kernels.
+
+Mirrors models/DIM/vggnet.py:10-133 (`DeepMatting`, `DIM_VGG`): the module tree only HOLDS the parameters under
+the reference's state_dict names (conv11 .. conv53 + bn*, conv6, dconv6 .. dconv1, alpha_pred); the math runs in
+libtcvom_hip.so through tcvom_amd.ops — NHWC bf16 activations, conv + bias + BatchNorm + ReLU fused blocks, max-pool
+with 2-bit positions, conv6 (7x7, 512 -> 4096) as im2col + dense GEMM, alpha_pred (5x5, 64 -> 1) + clamp fused.
+BASELINE.json config 1 (`pred_single.py`, DIM base without the temporal module).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_RELU, ConvCfg
+from .weights import ConvSpec, WeightBank, bank_token
+
+_ENC = [('11', None, 64), ('12', 64, 64), ('21', 64, 128), ('22', 128, 128), ('31', 128, 256), ('32', 256, 256),
+        ('33', 256, 256), ('41', 256, 512), ('42', 512, 512), ('43', 512, 512), ('51', 512, 512), ('52', 512, 512),
+        ('53', 512, 512)]
+_DEC = [('dconv5', 512, 512), ('dconv4', 512, 256), ('dconv3', 256, 128), ('dconv2', 128, 64), ('dconv1', 64, 64)]
+_STAGES = (('11', '12'), ('21', '22'), ('31', '32', '33'), ('41', '42', '43'), ('51', '52', '53'))
+
+
+class DeepMatting(nn.Module):
+    def __init__(self, input_chn, output_chn=1, build_decoder=True, freeze_bn=False, freeze_dropout=False, alpha_only=True):
+        super().__init__()
+        assert build_decoder and alpha_only and output_chn == 1, 'the decoder-less / feature-returning variants are unused'
+        self.alpha_only, self.input_chn, self.build_decoder = alpha_only, input_chn, build_decoder
+        self.freeze_bn, self.freeze_dropout = freeze_bn, freeze_dropout
+        for tag, cin, cout in _ENC:
+            setattr(self, 'conv' + tag, nn.Conv2d(input_chn if cin is None else cin, cout, kernel_size=3, padding=1))
+            setattr(self, 'bn' + tag, nn.BatchNorm2d(cout))
+        self.conv6 = nn.Conv2d(512, 4096, kernel_size=7, padding=3)
+        self.dconv6 = nn.Conv2d(4096, 512, kernel_size=1, padding=0)
+        for name, cin, cout in _DEC:
+            setattr(self, name, nn.Conv2d(cin, cout, kernel_size=5, padding=2))
+        self.alpha_pred = nn.Conv2d(64, 1, kernel_size=5, padding=2)
+
+        bank = WeightBank()
+        object.__setattr__(self, '_bank', bank)
+        cfgs = {}
+
+        def reg(name, conv, bn=None, needs_dgrad=True):
+            spec = ConvSpec(name, conv.weight, None, None, conv.bias, False, 1, conv.padding[0], 'frame', needs_dgrad)
+            bank.register(spec)
+            cfgs[name] = ConvCfg(bank, spec, bn=bn, act=ACT_RELU) if bn is not None else ConvCfg(bank, spec, pre_relu=True)
+
+        for tag, cin, _ in _ENC:
+            reg('conv' + tag, getattr(self, 'conv' + tag), getattr(self, 'bn' + tag), needs_dgrad=cin is not None)
+        reg('conv6', self.conv6)
+        reg('dconv6', self.dconv6)
+        for name, _, _ in _DEC:
+            reg(name, getattr(self, name))
+        object.__setattr__(self, '_cfgs', cfgs)
+
+    def run(self, x8):
+        """x8: NHWC bf16 [B,H,W,8] = {normalised R,G,B, trimap, 0,0,0,0} -> alpha fp32 [B,1,H,W]."""
+        training = self.training and not self.freeze_bn
+        bank, cfgs = self._bank, self._cfgs
+        token = bank_token(bank, 1, training)
+        x, idx = x8, []
+        for stage in _STAGES:
+            for tag in stage:
+                x = ops.conv_bn_act(cfgs['conv' + tag], x, token, training)
+            x, i = ops.maxpool2_idx(x)
+            idx.append(i)
+        x = ops.conv_unfold_dense(cfgs['conv6'], x, token)
+        x = ops.conv_bn_act(cfgs['dconv6'], x, token, training)
+        for (name, _, _), i in zip(_DEC, reversed(idx)):
+            x = ops.conv_bn_act(cfgs[name], ops.unpool2(x, i), token, training)
+        alpha = ops.head_conv(x, self.alpha_pred.weight, self.alpha_pred.bias, 5, 1)
+        bank.flush_bn_counters()
+        return alpha
+
+    def forward(self, x, **kwargs):
+        """x: NCHW float [B,4,H,W] (normalised RGB + 1-channel trimap), H % 32 == W % 32 == 0 -> alpha [B,1,H,W]."""
+        B, Cx, H, W = x.shape
+        assert Cx == self.input_chn and H % 32 == 0 and W % 32 == 0
+        x8 = torch.zeros((B, H, W, 8), dtype=torch.bfloat16, device=x.device)
+        x8[..., :Cx] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+        return self.run(x8)
+
+
+def DIM_VGG(build_decoder=True, alpha_only=True):
+    """models/DIM/vggnet.py:131-133."""
+    return DeepMatting(input_chn=4, build_decoder=build_decoder, alpha_only=True)

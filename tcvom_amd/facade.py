@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import vmn as VMN
+from .dim_net import DIM_VGG
 
 TAM_OS = 8
 
@@ -24,7 +25,7 @@ class _Prep(object):
     pass
 
 
-def preprocess_window(a, fg, bg, dilate_kernel, eps):
+def preprocess_window(a, fg, bg, dilate_kernel, eps, tri_channels=3):
     """FullModel.preprocess + make_trimap (models/model.py:54-92) for the 3-channel one-hot trimap."""
     if not a.is_cuda:
         raise RuntimeError('tcvom_amd runs on the GPU through libtcvom_hip.so only (no CPU fallback)')
@@ -43,7 +44,7 @@ def preprocess_window(a, fg, bg, dilate_kernel, eps):
     p.tris_vis = _f32((B, S, 1, H, W), dev)
     L.call('tcvom_preprocess', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
            L.ptr(p.unk_raw), L.ptr(tmp), L.ptr(p.unk), L.ptr(p.x8), L.ptr(p.trimask), L.ptr(p.tris_vis), B * S, H, W,
-           int(dilate_kernel), float(eps), L.stream_ptr())
+           int(dilate_kernel), float(eps), int(tri_channels), L.stream_ptr())
     return p
 
 
@@ -131,9 +132,56 @@ class _WindowLoss(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(dpreds) + tuple(datt_b) + tuple(datt_f)
 
 
+class _SingleImageLoss(torch.autograd.Function):
+    """FullModel.single_image_loss for the DIM base on ONE predicted frame c (models/model.py:94-127): L_alpha (masked
+    L1), L_comp (masked L1 of the re-composited image) and L_grad (masked L1 of the gradient magnitude,
+    utils/loss_func.py:42-59), plus the clamped `alphas` / `comps` visualisation tensors."""
+
+    @staticmethod
+    def forward(ctx, prep, c, S, pred):
+        st = L.stream_ptr()
+        pred = pred.contiguous()
+        B, _, H, W = pred.shape
+        HW = H * W
+        dev = pred.device
+        gts, tm = prep.gts, prep.trimask
+        alphas = torch.zeros((B, S, 1, H, W), dtype=torch.float32, device=dev)
+        comps = torch.zeros((B, S, 3, H, W), dtype=torch.float32, device=dev)
+        losses = torch.zeros(3, dtype=torch.float32, device=dev)
+        acc = torch.zeros(6, dtype=torch.float32, device=dev)          # {L1 sum, count | comp sum, count, grad sum, count}
+        L.call('tcvom_masked_l1_fwd', L.ptr(pred), L.ptr(gts[:, c]), L.ptr(tm[:, c]), None, None, None,
+               L.ptr(prep.fgs[:, c]), L.ptr(prep.bgs[:, c]), L.ptr(alphas[:, c]), L.ptr(comps[:, c]), L.ptr(acc[0:]),
+               B, HW, HW, S * HW, S * 3 * HW, st)
+        L.call('tcvom_loss_finalize', L.ptr(acc[0:]), L.ptr(losses[0:]), 1.0, 0, float(B * HW), 1, 0, st)
+        L.call('tcvom_dim_losses_fwd', L.ptr(pred), L.ptr(gts[:, c]), L.ptr(tm[:, c]), L.ptr(prep.fgs[:, c]), L.ptr(prep.bgs[:, c]),
+               L.ptr(prep.imgs[:, c]), None, L.ptr(acc[2:]), B, H, W, HW, S * HW, S * 3 * HW, st)
+        L.call('tcvom_loss_finalize', L.ptr(acc[2:]), L.ptr(losses[1:]), 1.0, 0, float(B * 3 * HW), 1, 0, st)
+        L.call('tcvom_loss_finalize', L.ptr(acc[4:]), L.ptr(losses[2:]), 1.0, 0, float(B * HW), 1, 0, st)
+        ctx.prep, ctx.c, ctx.S, ctx.pred, ctx.acc = prep, c, S, pred, acc
+        ctx.mark_non_differentiable(alphas, comps)
+        return losses[0], losses[1], losses[2], alphas, comps
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_comp, g_grad, _ga, _gc):
+        prep, c, S, pred, acc = ctx.prep, ctx.c, ctx.S, ctx.pred, ctx.acc
+        st = L.stream_ptr()
+        B, _, H, W = pred.shape
+        HW = H * W
+        dev = pred.device
+        one = lambda g: (g if g is not None else torch.zeros((), device=dev)).reshape(1).float().contiguous()
+        g_alpha, g_comp, g_grad = one(g_alpha), one(g_comp), one(g_grad)
+        dpred = torch.empty_like(pred)
+        L.call('tcvom_masked_l1_bwd', L.ptr(pred), L.ptr(prep.gts[:, c]), L.ptr(prep.trimask[:, c]), None, None, None,
+               L.ptr(acc[0:]), L.ptr(g_alpha), 1.0, L.ptr(dpred), None, 0, B, HW, HW, S * HW, st)
+        L.call('tcvom_dim_losses_bwd', L.ptr(pred), L.ptr(prep.gts[:, c]), L.ptr(prep.trimask[:, c]), L.ptr(prep.fgs[:, c]),
+               L.ptr(prep.bgs[:, c]), L.ptr(prep.imgs[:, c]), L.ptr(acc[2:]), L.ptr(g_comp), L.ptr(g_grad), L.ptr(dpred), 1,
+               B, H, W, HW, S * HW, S * 3 * HW, st)
+        return None, None, None, dpred
+
+
 class FullModel(nn.Module):
-    """Baseline (no TAM) façade — models/model.py:15-246.  Only VMN archs run on the HIP path this round."""
-    ARCH_DICT = {'gca': None, 'dim': None, 'fba': None, 'index': None}
+    """Baseline (no TAM) façade — models/model.py:15-246: the DIM base (BASELINE.json config 1) and the VMN archs."""
+    ARCH_DICT = {'gca': None, 'dim': DIM_VGG, 'fba': None, 'index': None}
     TRIMAP_CHANNEL_DICT = {'gca': 3, 'dim': 1, 'index': 1, 'fba': 8}
     FBA_LOSS_NORMALIZE = True
     FBA_L_ATT_MULTIPLIER = 1
@@ -152,7 +200,9 @@ class FullModel(nn.Module):
         else:
             if model not in self.ARCH_DICT:
                 raise KeyError(model)
-            raise NotImplementedError('%s: single-image baselines are not on the MI355X hot path yet (SURVEY.md §8)' % model)
+            if self.ARCH_DICT[model] is None:
+                raise NotImplementedError('%s: this single-image base is not on the MI355X path yet (SURVEY.md §8)' % model)
+            self.NET = self.ARCH_DICT[model]()
         self.method = model[model.rfind('_') + 1:]
         self.TRIMAP_CHANNEL = self.TRIMAP_CHANNEL_DICT[self.method]
 
@@ -164,10 +214,24 @@ class FullModel(nn.Module):
         return int(self.DILATION_KERNEL)
 
     def preprocess(self, a, fg, bg):
-        p = preprocess_window(a, fg, bg, self._dilation(), self.EPS)
-        tris = p.x8[..., 3:6].permute(0, 1, 4, 2, 3).float()
+        p = preprocess_window(a, fg, bg, self._dilation(), self.EPS, self.TRIMAP_CHANNEL)
+        tris = p.x8[..., 3:3 + self.TRIMAP_CHANNEL].permute(0, 1, 4, 2, 3).float()
         imgs = p.x8[..., 0:3].permute(0, 1, 4, 2, 3).float()
         return p.imgs, p.fgs, p.bgs, p.gts, tris, p.trimask, imgs
+
+    def forward(self, a, fg, bg):
+        """models/model.py:199-246 -> [L_alpha, L_comp, L_grad, scaled_imgs, tris_vis, alphas, comps, scaled_gts, Fs, Bs];
+        single-image bases predict only the centre frame of the clip."""
+        B, S = a.shape[:2]
+        H, W = a.shape[-2:]
+        assert H % 32 == 0 and W % 32 == 0, 'H and W must be multiples of 32'
+        if self.model_name.startswith('vmn'):
+            raise NotImplementedError('use FullModel_VMD for the VMN architectures (train_ddp.py:220, pred_vmn.py:76)')
+        c = S // 2
+        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS, self.TRIMAP_CHANNEL)
+        pred = self.NET.run(prep.x8[:, c].contiguous())
+        L_alpha, L_comp, L_grad, alphas, comps = _SingleImageLoss.apply(prep, c, S, pred)
+        return [L_alpha, L_comp, L_grad, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
 
 
 class FullModel_VMD(FullModel):

@@ -109,7 +109,10 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.has_res1, ctx.has_res2, ctx.has_bias = res1 is not None, res2 is not None, bias is not None
         if not has_bn:
             assert res1 is None and res2 is None and cfg.act == ACT_NONE
-            ctx.save_for_backward(x)
+            if cfg.pre_relu:                 # conv + bias + ReLU without BatchNorm (DIM decoder): the mask needs y
+                ctx.save_for_backward(x, y)
+            else:
+                ctx.save_for_backward(x)
             return y
         P = geo.out_pixels
         sync = _sync_group(bn) if training else None
@@ -152,8 +155,13 @@ class _ConvBNAct(torch.autograd.Function):
         dz = _c(dz)
         dgamma = dbeta = dbias = dres1 = None
         if cfg.bn is None:
-            (x,) = ctx.saved_tensors
-            dy = dz
+            if cfg.pre_relu:
+                x, y = ctx.saved_tensors
+                dy = torch.empty_like(dz)
+                L.call('tcvom_relu_bwd', L.ptr(dz), L.ptr(y), L.ptr(dy), dz.numel(), st)
+            else:
+                (x,) = ctx.saved_tensors
+                dy = dz
             if ctx.has_bias:
                 dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
                 L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), geo.out_pixels, K, K, st)
@@ -189,6 +197,11 @@ class _ConvBNAct(torch.autograd.Function):
                 dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)
             L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
                    L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, yf, st)
+            if ctx.has_bias:
+                # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
+                # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
+                dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
+                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P, K, K, st)
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
             dx = torch.empty((geo.N, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
@@ -269,34 +282,142 @@ reflect_pad1 = _ReflectPad1.apply
 
 
 # =============================================================================================
+# DIM base: MaxPool2d(2, return_indices) / MaxUnpool2d(2), and the 7x7 conv6 as unfold + dense GEMM
+# =============================================================================================
+class _MaxPool2Idx(torch.autograd.Function):
+    """F.max_pool2d(x, 2, 2, return_indices=True) on NHWC bf16; idx = uint8 position inside the 2x2 window."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=BF16, device=x.device)
+        idx = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.uint8, device=x.device)
+        L.call('tcvom_maxpool2_idx', L.ptr(x), L.ptr(y), L.ptr(idx), N, H, W, Cc, L.stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, H, W, Cc)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        (idx,) = ctx.saved_tensors
+        N, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        L.call('tcvom_unpool2', L.ptr(_c(dy)), L.ptr(idx), L.ptr(dx), N, H, W, Cc, L.stream_ptr())
+        return dx
+
+
+class _Unpool2(torch.autograd.Function):
+    """F.max_unpool2d(y, idx, 2, 2): every value goes to the position its max-pool partner came from."""
+
+    @staticmethod
+    def forward(ctx, y, idx):
+        y = _c(y)
+        N, h, w, Cc = y.shape
+        x = torch.empty((N, 2 * h, 2 * w, Cc), dtype=BF16, device=y.device)
+        L.call('tcvom_unpool2', L.ptr(y), L.ptr(idx), L.ptr(x), N, 2 * h, 2 * w, Cc, L.stream_ptr())
+        ctx.save_for_backward(idx)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (idx,) = ctx.saved_tensors
+        N, H, W, Cc = dx.shape
+        dy = torch.empty((N, H // 2, W // 2, Cc), dtype=BF16, device=dx.device)
+        L.call('tcvom_pick2', L.ptr(_c(dx)), L.ptr(idx), L.ptr(dy), N, H, W, Cc, L.stream_ptr())
+        return dy, None
+
+
+class _ConvUnfoldDense(torch.autograd.Function):
+    """Large-kernel conv + bias + ReLU as im2col + dense GEMM (DIM conv6: 7x7, 512 -> 4096 at os32, vggnet.py:56,97)."""
+
+    @staticmethod
+    def forward(ctx, x, token, bias, cfg):
+        _need_cuda(x)
+        spec, bank = cfg.spec, cfg.bank
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        assert Cc == spec.cpad == spec.C and spec.R == spec.S and spec.stride == 1 and spec.pad == spec.R // 2
+        call = bank.next_call(spec)
+        st = L.stream_ptr()
+        P, K, kred = N * H * W, spec.K, spec.T * Cc
+        u = torch.empty((P, kred), dtype=BF16, device=x.device)
+        L.call('tcvom_unfold', L.ptr(x), L.ptr(u), N, H, W, Cc, spec.R, st)
+        y = torch.empty((N, H, W, K), dtype=BF16, device=x.device)
+        d = dense_desc(P, K, kred, K)
+        d.act = ACT_RELU
+        L.call('tcvom_conv_igemm', L.ptr(u), bank.fwd_ptr(spec, call), L.ptr(y), L.ptr(bias), None, None, None, C.byref(d), st)
+        ctx.cfg, ctx.call, ctx.shape = cfg, call, (N, H, W, Cc)
+        ctx.save_for_backward(u, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        u, y = ctx.saved_tensors
+        spec, bank = ctx.cfg.spec, ctx.cfg.bank
+        N, H, W, Cc = ctx.shape
+        st = L.stream_ptr()
+        P, K, kred = N * H * W, spec.K, spec.T * Cc
+        dz = _c(dz)
+        dy = torch.empty_like(dz)
+        L.call('tcvom_relu_bwd', L.ptr(dz), L.ptr(y), L.ptr(dy), dz.numel(), st)
+        dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
+        L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P, K, K, st)
+        # du[p][c*T + t] = sum_k dy[p][k] w[k][t][c]: the data-gradient weights are packed [C][T][K]
+        du = torch.empty((P, kred), dtype=BF16, device=dz.device)
+        L.call('tcvom_conv_igemm', L.ptr(dy), bank.bwd_ptr(spec, ctx.call), L.ptr(du), None, None, None, None,
+               C.byref(dense_desc(P, kred, K, kred)), st)
+        dx = torch.empty((N, H, W, Cc), dtype=BF16, device=dz.device)
+        L.call('tcvom_fold', L.ptr(du), L.ptr(dx), N, H, W, Cc, spec.R, st)
+        L.call('tcvom_wgrad_igemm', L.ptr(dy), L.ptr(u), bank.dw_ptr(spec, ctx.call), C.byref(dense_tt_desc(P, K, kred)), K, st)
+        return dx, None, dbias, None
+
+
+def conv_unfold_dense(cfg, x, token):
+    return _ConvUnfoldDense.apply(x, token, cfg.spec.bias, cfg)
+
+
+maxpool2_idx = _MaxPool2Idx.apply
+unpool2 = _Unpool2.apply
+
+
+# =============================================================================================
 # decoder head: conv 3x3 (C -> 1, bias) + (tanh + 1)/2      -> alpha fp32 [N,1,H,W]
 # =============================================================================================
 class _HeadConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, ksize, mode):
         x = _c(x)
         N, H, W, Cc = x.shape
-        wt = weight.detach().reshape(Cc, 9).t().contiguous()          # [9][C] tap-major
+        T = ksize * ksize
+        wt = weight.detach().reshape(Cc, T).t().contiguous()          # [T][C] tap-major
         alpha = torch.empty((N, 1, H, W), dtype=torch.float32, device=x.device)
-        L.call('tcvom_head_conv_fwd', L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(alpha), N, H, W, Cc, L.stream_ptr())
+        L.call('tcvom_head_conv_fwd', L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(alpha), N, H, W, Cc, ksize, mode, L.stream_ptr())
         ctx.save_for_backward(x, wt, alpha)
+        ctx.ksize, ctx.mode = ksize, mode
         return alpha
 
     @staticmethod
     def backward(ctx, dalpha):
         x, wt, alpha = ctx.saved_tensors
         N, H, W, Cc = x.shape
+        T = ctx.ksize * ctx.ksize
         dalpha = _c(dalpha.float())
         dx = torch.empty_like(x)
         dpre = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
-        dw = torch.empty((9, Cc), dtype=torch.float32, device=x.device)
+        dw = torch.empty((T, Cc), dtype=torch.float32, device=x.device)
         db = torch.empty(1, dtype=torch.float32, device=x.device)
         L.call('tcvom_head_conv_bwd', L.ptr(dalpha), L.ptr(alpha), L.ptr(x), L.ptr(wt), L.ptr(dx), L.ptr(dpre), L.ptr(dw),
-               L.ptr(db), N, H, W, Cc, L.stream_ptr())
-        return dx, dw.t().reshape(1, Cc, 3, 3), db
+               L.ptr(db), N, H, W, Cc, ctx.ksize, ctx.mode, L.stream_ptr())
+        return dx, dw.t().reshape(1, Cc, ctx.ksize, ctx.ksize), db, None, None
 
 
-head_conv = _HeadConv.apply
+def head_conv(x, weight, bias, ksize=3, mode=0):
+    """Final conv C -> 1 with its output map: ksize 3 / mode 0 = (tanh + 1) / 2 (GCA), ksize 5 / mode 1 = clamp(0, 1) (DIM)."""
+    return _HeadConv.apply(x, weight, bias, ksize, mode)
+
+
 
 
 # =============================================================================================

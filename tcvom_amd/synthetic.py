@@ -43,6 +43,10 @@ def formula_tensor(key, shape, dtype=torch.float32, salt=0):
         r = 0.1 * r
     elif leaf == 'running_var':
         r = 1.0 + 0.3 * r
+    elif key == 'alpha_pred.bias':                            # DIM head: keep clamp(pred, 0, 1) away from saturation
+        r = 0.5 + 0.0 * r
+    elif key == 'alpha_pred.weight':
+        r = r * np.sqrt(3.0 / (n // shape[0])) * 4.0
     elif leaf == 'bias':
         r = 0.1 * r
     elif len(shape) == 1:                                     # norm-layer scale

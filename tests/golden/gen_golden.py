@@ -17,6 +17,7 @@ import types
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
@@ -265,7 +266,47 @@ def gen_eval():
         save(name, alphas=alphas, imgs_sum=imgs.sum(), tris_sum=tris.sum())
 
 
+DIM_CASES = {
+    # name: (B, S, H, W, dilate)   -- BASELINE.json config 1 is the 512 x 512 single frame
+    'dim_s1_64x64': (2, 1, 64, 64, 3),
+    'dim_s3_96x128': (1, 3, 96, 128, 5),
+    'dim_s1_512x512': (1, 1, 512, 512, 12),
+}
+DIM_FULL_GRADS = ('conv11.weight', 'bn33.weight', 'dconv1.bias', 'alpha_pred.weight', 'dconv6.bias')
+
+
+def gen_dim():
+    for name, (B, S, H, W, dil) in DIM_CASES.items():
+        fm = ref_model.FullModel('dim', dilate_kernel=dil)
+        fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
+        fm.train()
+        a, fg, bg = synthetic_window(B, S, H, W, seed=1)
+        out = fm(a, fg, bg)
+        loss = out[0] + out[1] + out[2]
+        loss.backward()
+        alphas = out[5]
+        arrs = {'losses': torch.stack([o.detach() for o in out[:3]]), 'comps_sum': out[6].sum(), 'tris_sum': out[4].sum(),
+                'alphas': alphas if H <= 128 else F.avg_pool2d(alphas[:, S // 2], 8), 'alphas_sum': alphas.double().sum()}
+        names, norms = [], []
+        for k, p in fm.NET.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        arrs['grad_names'] = np.array(names)
+        arrs['grad_norms'] = np.array(norms)
+        gd = dict(fm.NET.named_parameters())
+        for k in DIM_FULL_GRADS:
+            arrs['grad:' + k] = gd[k].grad
+        post = fm.NET.state_dict()
+        for k in ('bn11.running_mean', 'bn53.running_var', 'bn11.num_batches_tracked'):
+            arrs['state:' + k] = post[k].clone()
+        save(name, **arrs)
+
+
 def gen_state_keys():
+    dsd = ref_model.FullModel('dim').NET.state_dict()
+    save('dim_state_keys', keys=np.array(list(dsd.keys())),
+         shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in dsd.values()]))
     sd = ref_model.FullModel_VMD('vmn_gca', agg_window=7).NET.state_dict()
     save('state_keys', keys=np.array(list(sd.keys())),
          shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]),
@@ -284,3 +325,4 @@ if __name__ == '__main__':
     gen_facade()
     gen_window()
     gen_eval()
+    gen_dim()

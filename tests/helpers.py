@@ -90,3 +90,10 @@ class Checker(object):
         msg = ', '.join('%s=%.2e%s' % (n, e, '' if ok else ' (> %.1e!)' % t) for n, e, t, ok in self.rows)
         print(msg)
         assert all(ok for _, _, _, ok in self.rows), msg
+
+
+def dim_template():
+    """key -> tensor (shape / dtype only) of FullModel('dim').NET.state_dict() — from the product's own module
+    (its key list is checked against the reference in tests/test_oracle_golden.py::test_dim_state_dict_layout)."""
+    from tcvom_amd.dim_net import DIM_VGG
+    return DIM_VGG().state_dict()

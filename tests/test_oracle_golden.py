@@ -158,3 +158,52 @@ def test_window_forward_backward(name):
             ev, _ = oracle.window_forward(state, a, fg, bg, window=win, dilate_kernel=dil, training=False)
         assert_close(ev[7], g['eval_alphas'], 0, 5e-4, 'eval alphas')
         assert_close(torch.stack(list(ev[:5])), g['eval_losses'], 1e-4, 1e-5, 'eval losses')
+
+
+# --------------------------------------------------------------------------------------------- DIM base (config 1)
+DIM_CASES = {'dim_s1_64x64': (2, 1, 64, 64, 3), 'dim_s3_96x128': (1, 3, 96, 128, 5), 'dim_s1_512x512': (1, 1, 512, 512, 12)}
+DIM_FULL_GRADS = ('conv11.weight', 'bn33.weight', 'dconv1.bias', 'alpha_pred.weight', 'dconv6.bias')
+
+
+def dim_formula_state(template, requires_grad=True):
+    state = {k: formula_tensor(k, v.shape, v.dtype) for k, v in template.items()}
+    if requires_grad:
+        for k, v in state.items():
+            if v.is_floating_point() and 'running_' not in k:
+                v.requires_grad_(True)
+    return state
+
+
+@pytest.mark.parametrize('name', ['dim_s1_64x64', 'dim_s3_96x128'])
+def test_dim_full_model_forward_backward(name):
+    """oracle.dim_net against FullModel('dim') of the reference (losses, alpha, gradients, BatchNorm state)."""
+    from oracle import dim_net
+    from helpers import dim_template
+    B, S, H, W, dil = DIM_CASES[name]
+    g = golden(name)
+    state = dim_formula_state(dim_template())
+    a, fg, bg = synthetic_window(B, S, H, W, seed=1)
+    out, _pred = dim_net.full_model_dim_forward(state, a, fg, bg, dilate_kernel=dil, training=True)
+    assert_close(torch.stack([o.detach() for o in out[:3]]), g['losses'], 1e-4, 1e-6, 'losses')
+    assert_close(out[5], g['alphas'], 1e-4, 2e-5, 'alphas')
+    assert_close(out[6].sum(), g['comps_sum'], 1e-5, 1e-2, 'comps')
+    assert_close(out[4].sum(), g['tris_sum'], 1e-6, 1e-3, 'tris')
+    (out[0] + out[1] + out[2]).backward()
+    names = [str(n) for n in g['grad_names']]
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    assert_close(torch.from_numpy(got), g['grad_norms'], 2e-3, 1e-9, 'grad norms')
+    for k in DIM_FULL_GRADS:
+        # fp32 accumulation order differs between two runs of the SAME reference by ~1e-3 of the largest element
+        assert_close(state[k].grad, g['grad:' + k], 5e-3, 1e-2 * float(np.abs(g['grad:' + k]).max()), 'grad ' + k)
+    for k in ('bn11.running_mean', 'bn53.running_var'):
+        assert_close(state[k], g['state:' + k], 1e-4, 1e-6, k)
+    assert int(state['bn11.num_batches_tracked']) == int(g['state:bn11.num_batches_tracked'])
+
+
+def test_dim_state_dict_layout():
+    from helpers import dim_template
+    g = golden('dim_state_keys')
+    sd = dim_template()
+    assert list(sd.keys()) == [str(k) for k in g['keys']]
+    assert [','.join(str(int(d)) for d in v.shape) for v in sd.values()] == [str(s) for s in g['shapes']]
+    assert sum(v.numel() for k, v in sd.items() if 'running_' not in k and 'num_batches' not in k) == 130545345
