@@ -123,3 +123,12 @@ def test_pred_test_folder_inference(tmp_path):
     got = np.asarray(Image.open(outs[1])).astype(np.float32)
     assert np.isfinite(direct).all() and 0.0 < direct.mean() < 1.0
     assert got.shape == (H, W) and np.abs(got - np.uint8(direct * 255).astype(np.float32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_pred_single_dim_config1():
+    """BASELINE.json config 1: pred_single.py, DIM base, one 512 x 512 synthetic frame + trimap (eval mode)."""
+    import pred_single
+    out = pred_single.main(pred_single.parse(['--model', 'dim', '--trimap', 'medium', '--frames', '1']))
+    assert set(out) == {'L_alpha', 'L_comp', 'L_grad', 'L_total', 'mSAD', 'MSE'}
+    assert all(np.isfinite(v) for v in out.values()) and abs(out['L_total'] - out['L_alpha'] - out['L_comp'] - out['L_grad']) < 1e-5
