@@ -27,6 +27,15 @@ GFLOP_FWD_GCA_1080P = 2106.3       # 6 guided-contextual-attention calls, forwar
 GFLOP_WINDOW_1080P = 11179.81      # forward + backward
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 FULL_H, FULL_W = 1088, 1920
+# HBM bytes per launch of the igemm instantiations, from the rocprofv3 PMC passes in profiles/r01_e_hbm_traffic_pmc_final.md
+# (FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script; fetch side doubled per MI355X_MICROARCH.md's gfx950
+# correction; averaged over all launches of the instantiation in a 1080p step).  bench.py cannot run rocprofv3 on itself,
+# so the figure of the kernel that turns out dominant is quoted from that committed measurement.
+PMC_TRAFFIC_BYTES = {
+    'igemm_tt<128,128,64,32,1>': (142.25 + 25.56) * 2 ** 20,
+    'igemm_nt<256,256,128,64,2>': (289.10 + 233.79) * 2 ** 20,
+    'igemm_nt<128,64,32,32,3>': (27.85 + 10.87) * 2 ** 20,
+}
 
 
 def window_gflop(H, W):
@@ -62,33 +71,13 @@ def igemm_profile(step_fn):
         ms = e0.elapsed_time(e1)
         real_taps = sum(1 for t in range(desc['ntaps']) if desc['tap_w'][t] >= 0)
         gflop = 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
-        if name.startswith('tcvom_conv_igemm'):
-            # same selection as nt_config() in tcvom_amd/csrc/igemm.hip
-            if desc['K'] >= 128:
-                nb = max(desc['batch'], 1) * desc.get('phases', 1)
-                cd = lambda a, b: (a + b - 1) // b
-                if cd(desc['P'], 128) * cd(desc['K'], 128) * nb >= 512:
-                    var = 'igemm_nt<128,128,64,64>'
-                elif cd(desc['P'], 64) * cd(desc['K'], 128) * nb >= 400:
-                    var = 'igemm_nt<128,64,64,32>'
-                else:
-                    var = 'igemm_nt<64,64,32,32>'
-            else:
-                var = 'igemm_nt<64,128,32,64>' if desc['K'] > 32 else 'igemm_nt<32,256,32,64>'
-        else:
-            ncols = desc['ntaps'] * desc['C']
-            if desc['K'] >= 128 and ncols >= 128:
-                var = 'igemm_tt<128,128,64,64>'
-            elif desc['K'] > 32:
-                var = 'igemm_tt<64,128,32,64>' if ncols >= 128 else 'igemm_tt<64,64,32,32>'
-            else:
-                var = 'igemm_tt<32,128,32,32>' if ncols >= 128 else 'igemm_tt<32,32,32,32>'
+        var = desc['variant']                       # the instantiation the library selected for this shape
         n, t, g = agg.get(var, (0, 0.0, 0.0))
         agg[var] = (n + 1, t + ms, g + gflop)
     return agg
 
 
-def cpu_baseline(sample_hw=(544, 960), max_threads=32):
+def cpu_baseline(sample_hw=(768, 1344), max_threads=32):
     """The oracle (pure PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host
     cores on ONE bounded sample window, scaled to 1080p windows/s by the algorithmic-FLOP ratio."""
     import oracle
@@ -203,7 +192,8 @@ def main():
             n, ms, gf = agg[dom]
             tf = gf / ms                                    # GFLOP / ms == TFLOP/s
             result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': MFMA_PEAK_TFLOPS,
-                                  'unit': 'TFLOP/s', 'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                                  'unit': 'TFLOP/s', 'frac': round(tf / MFMA_PEAK_TFLOPS, 4),
+                                  'traffic': (round(PMC_TRAFFIC_BYTES[dom]) if (H, W) == (FULL_H, FULL_W) and dom in PMC_TRAFFIC_BYTES else None),
                                   'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
                                   'algorithmic_gflop_per_launch': round(gf / n, 3),
                                   'all_igemm': {k: {'launches': v[0], 'ms': round(v[1], 3), 'tflops': round(v[2] / max(v[1], 1e-9), 1)}

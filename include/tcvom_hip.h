@@ -71,6 +71,9 @@ int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias
  * descs[i].stats_group_offset must be i * tcvom_conv_stats_groups(descs, nphase). */
 int tcvom_conv_igemm_phases(const void* in, const void* w, void* out, const float* bias, float* stats_partial,
                             const tcvom_conv_desc* descs, int32_t nphase, void* stream);
+/* name of the kernel instantiation a launch with these descriptors selects (bench / profile labels) */
+const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase);
+const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d);
 /* number of statistics groups ONE phase of a launch of `nphase` phases like `d` writes */
 int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase);
 

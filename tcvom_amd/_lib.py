@@ -119,7 +119,10 @@ _PROTOS = {
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles'}
 
-EXPORTS = sorted(list(_PROTOS) + ['tcvom_last_error'])
+# entry points that return a string
+_STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}
+
+EXPORTS = sorted(list(_PROTOS) + list(_STRING) + ['tcvom_last_error'])
 
 
 def _bind():
@@ -131,6 +134,14 @@ def _bind():
             raise ImportError('tcvom_amd: %s does not export %s (stale build?)' % (LIB_PATH, name)) from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
+        fns[name] = fn
+    for name, argtypes in _STRING.items():
+        try:
+            fn = getattr(_lib, name)
+        except AttributeError as e:
+            raise ImportError('tcvom_amd: %s does not export %s (stale build?)' % (LIB_PATH, name)) from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p
         fns[name] = fn
     return fns
 
@@ -154,8 +165,13 @@ def _profiled(name, args):
         taps = sum(sum(1 for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0) for i in range(n))
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': 1, 'phases': n}
     else:
+        n = 1
         d = args[7 if name == 'tcvom_conv_igemm' else 3]._obj
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': d.ntaps, 'tap_w': list(d.tap_w), 'batch': d.batch, 'phases': 1}
+    if name.startswith('tcvom_conv_igemm'):
+        info['variant'] = _FNS['tcvom_conv_igemm_variant'](C.byref(d), n).decode()
+    else:
+        info['variant'] = _FNS['tcvom_wgrad_igemm_variant'](C.byref(d)).decode()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = _FNS[name](*args)

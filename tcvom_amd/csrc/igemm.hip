@@ -382,6 +382,18 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
     return cdiv(P, c.tn) * c.waves_n;
 }
 
+// name of the kernel instantiation tcvom_conv_igemm(_phases) launches for this shape (profiling / bench labels)
+extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase) {
+    if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
+    const NtCfg c = nt_config(d, nphase);
+    if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";
+    if (c.tm == 128 && c.tn == 128) return "igemm_nt<128,128,64,32,2>";
+    if (c.tm == 128) return "igemm_nt<128,64,32,32,3>";
+    if (c.tm == 64 && c.tn == 64) return "igemm_nt<64,64,32,32,4>";
+    if (c.tm == 64) return "igemm_nt<64,128,32,64,3>";
+    return "igemm_nt<32,256,32,64,2>";
+}
+
 static int conv_igemm_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale,
                              const float* mdiag, float* stats_partial, const tcvom_conv_desc* descs, int nphase,
                              void* stream) {
@@ -706,6 +718,23 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
 #endif
 }
 
+// tile: wide-N tiles for the small-channel layers so that dy is re-read ncols/128 (not ncols/32) times
+static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
+    const int ncols = d->ntaps * d->C;
+    if (d->K >= 128 && ncols >= 128) { *tm = *tn = 128; }
+    else if (d->K > 32) { *tm = 64; *tn = ncols >= 128 ? 128 : 64; }
+    else { *tm = 32; *tn = ncols >= 128 ? 128 : 32; }
+}
+extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
+    int tm, tn;
+    tt_tile(d, &tm, &tn);
+    if (tm == 128) return "igemm_tt<128,128,64,32,1>";
+    if (tm == 64 && tn == 128) return "igemm_tt<64,128,32,32,1>";
+    if (tm == 64) return "igemm_tt<64,64,32,32,1>";
+    if (tn == 128) return "igemm_tt<32,128,32,32,1>";
+    return "igemm_tt<32,32,32,32,4>";
+}
+
 static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs, int nphase,
                               int32_t ldy, void* stream) {
     TCVOM_CHECK_ARG(dy && in && dw && descs, "wgrad_igemm: null pointer");
@@ -734,11 +763,8 @@ static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const t
     TCVOM_CHECK_ARG(zp != nullptr, "wgrad_igemm: could not allocate the zero page");
     const bf16raw* a = (const bf16raw*)dy;
     const bf16raw* b = (const bf16raw*)in;
-    // tile: wide-N tiles for the small-channel layers so that dy is re-read ncols/128 (not ncols/32) times
     int tm, tn;
-    if (d->K >= 128 && ncols >= 128) { tm = tn = 128; }
-    else if (d->K > 32) { tm = 64; tn = ncols >= 128 ? 128 : 64; }
-    else { tm = 32; tn = ncols >= 128 ? 128 : 32; }
+    tt_tile(d, &tm, &tn);
     const int mt = cdiv(d->K, tm), nt = cdiv(ncols, tn);
     // pixel chunks: every workgroup ends with tm*tn atomic adds, so chunks must be long enough to amortise them
     // (>= 512 pixels), and the whole grid should fit in ONE round of co-resident workgroups (LDS-limited occupancy
