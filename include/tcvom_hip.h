@@ -85,6 +85,10 @@ int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_con
                       int32_t ldy, void* stream);
 int tcvom_wgrad_igemm_phases(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs,
                              int32_t nphase, int32_t ldy, void* stream);
+/* the same for `nbatch` (1..8) problems of identical shape in ONE launch -- the S calls of one layer in a window
+ * (same descriptors; dy / in / dw are HOST arrays of nbatch device pointers) */
+int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, float* const* dw, int32_t nbatch,
+                              const tcvom_conv_desc* descs, int32_t nphase, int32_t ldy, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm around the convs
  * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks

@@ -62,6 +62,7 @@ _PROTOS = {
     'tcvom_conv_igemm_phases': [vp, vp, vp, vp, vp, DP, i32, vp],
     'tcvom_wgrad_igemm_phases': [vp, vp, vp, DP, i32, i32, vp],
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
+    'tcvom_wgrad_igemm_batched': [vp, vp, vp, i32, DP, i32, i32, vp],
     'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp],
     'tcvom_bn_finalize_scratch_doubles': [i32],
     'tcvom_bn_ema_update': [vp, vp, vp, i32, f32, f32, i64, vp],
@@ -158,7 +159,12 @@ PROFILE = None   # bench.py sets this to a list to bracket every igemm launch wi
 
 def _profiled(name, args):
     import torch
-    if name.endswith('_phases'):
+    if name == 'tcvom_wgrad_igemm_batched':
+        arr, n, nb = args[4], args[5], args[3]
+        d = arr[0]
+        taps = sum(sum(1 for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0) for i in range(n))
+        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': nb, 'phases': n}
+    elif name.endswith('_phases'):
         arr = args[5 if name == 'tcvom_conv_igemm_phases' else 3]
         n = args[6 if name == 'tcvom_conv_igemm_phases' else 4]
         d = arr[0]
@@ -182,7 +188,8 @@ def _profiled(name, args):
 
 def call(name, *args):
     """Invoke a status-returning entry point; raise TcvomError on failure."""
-    if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases'):
+    if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
+                                        'tcvom_wgrad_igemm_batched'):
         rc = _profiled(name, args)
     else:
         rc = _FNS[name](*args)

@@ -489,17 +489,34 @@ __device__ __forceinline__ bf16x8_t tr_read8(const bf16raw* p_lo, const bf16raw*
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// up to TT_MAX_BATCH problems of identical shape (the S calls of one layer in a window: same descriptors, different
+// dy / input / dw buffers) share one launch: 3x the workgroups, so the pixel reduction is split 3x less and the
+// atomic epilogue shrinks accordingly
+#define TT_MAX_BATCH 8
+struct TtBatch {
+    const bf16raw* dy[TT_MAX_BATCH];
+    const bf16raw* in[TT_MAX_BATCH];
+    float* dw[TT_MAX_BATCH];
+    int n;
+};
+
 template <int TM, int TN, int WM, int WN, int KS>
 __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kernel(
-    const bf16raw* __restrict__ dy, const bf16raw* __restrict__ in, float* __restrict__ dw,
-    const bf16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk, const int chunks_per_phase)
+    const TtBatch bt, const bf16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk,
+    const int chunks_per_phase)
 {
 #ifdef NT_TRACE
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
-    const int phase = blockIdx.x / chunks_per_phase;
+    const int per_problem = chunks_per_phase * ps.n;
+    const int prob = blockIdx.x / per_problem;
+    const int rem = blockIdx.x - prob * per_problem;
+    const bf16raw* __restrict__ dy = bt.dy[prob];
+    const bf16raw* __restrict__ in = bt.in[prob];
+    float* __restrict__ dw = bt.dw[prob];
+    const int phase = rem / chunks_per_phase;
     const tcvom_conv_desc& d = ps.d[phase];
-    const int chunk = blockIdx.x - phase * chunks_per_phase;
+    const int chunk = rem - phase * chunks_per_phase;
     if (chunk * pchunk >= d.N * d.PH * d.PW) return;
     constexpr int WAVES_M = TM / WM, WAVES_N = TN / WN;
     constexpr int NW = WAVES_M * WAVES_N * KS;
@@ -735,9 +752,19 @@ extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
     return "igemm_tt<32,32,32,32,4>";
 }
 
-static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs, int nphase,
-                              int32_t ldy, void* stream) {
-    TCVOM_CHECK_ARG(dy && in && dw && descs, "wgrad_igemm: null pointer");
+static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch,
+                              const tcvom_conv_desc* descs, int nphase, int32_t ldy, void* stream) {
+    TCVOM_CHECK_ARG(dys && ins && dws && descs, "wgrad_igemm: null pointer");
+    TCVOM_CHECK_ARG(nbatch >= 1 && nbatch <= TT_MAX_BATCH, "wgrad_igemm: batch of %d (1..%d)", nbatch, TT_MAX_BATCH);
+    TtBatch bt;
+    bt.n = nbatch;
+    for (int i = 0; i < TT_MAX_BATCH; ++i) {
+        const int j = i < nbatch ? i : 0;
+        TCVOM_CHECK_ARG(dys[j] && ins[j] && dws[j], "wgrad_igemm: null pointer in batch entry %d", j);
+        bt.dy[i] = (const bf16raw*)dys[j];
+        bt.in[i] = (const bf16raw*)ins[j];
+        bt.dw[i] = dws[j];
+    }
     TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "wgrad_igemm: %d phases (1..4)", nphase);
     TcvomPhases ps;
     ps.n = nphase;
@@ -761,8 +788,6 @@ static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const t
     const int ncols = d->ntaps * d->C;
     const bf16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "wgrad_igemm: could not allocate the zero page");
-    const bf16raw* a = (const bf16raw*)dy;
-    const bf16raw* b = (const bf16raw*)in;
     int tm, tn;
     tt_tile(d, &tm, &tn);
     const int mt = cdiv(d->K, tm), nt = cdiv(ncols, tn);
@@ -772,32 +797,37 @@ static int wgrad_igemm_launch(const void* dy, const void* in, float* dw, const t
     const int lds_bytes = 2 * 64 * (tm + tn) * 2 + 256;
     int occ = (160 * 1024) / lds_bytes;
     if (occ > 4) occ = 4;
-    long long want = (256ll * occ) / ((long long)mt * nt * nphase);
+    long long want = (256ll * occ) / ((long long)mt * nt * nphase * nbatch);
     if (want < 1) want = 1;
     long long pchunk = ((P + want - 1) / want + 63) / 64 * 64;
     if (pchunk < 512) pchunk = 512;
     const int chunks = cdiv(P, pchunk);
-    dim3 grid(chunks * nphase, nt, mt);
+    dim3 grid(chunks * nphase * nbatch, nt, mt);
     if (tm == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 32, 1>), grid, dim3(512), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<128, 128, 64, 32, 1>), grid, dim3(512), 0, st, bt, zp, ps, ldy, (int)pchunk, chunks);
     else if (tm == 64 && tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 32, 1>), grid, dim3(512), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 128, 32, 32, 1>), grid, dim3(512), 0, st, bt, zp, ps, ldy, (int)pchunk, chunks);
     else if (tm == 64)
-        hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, bt, zp, ps, ldy, (int)pchunk, chunks);
     else if (tn == 128)
-        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, bt, zp, ps, ldy, (int)pchunk, chunks);
     else
-        hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, a, b, dw, zp, ps, ldy, (int)pchunk, chunks);
+        hipLaunchKernelGGL((igemm_tt_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, bt, zp, ps, ldy, (int)pchunk, chunks);
     TCVOM_LAUNCH_CHECK("wgrad_igemm");
     return TCVOM_OK;
 }
 
 extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_conv_desc* d,
                                  int32_t ldy, void* stream) {
-    return wgrad_igemm_launch(dy, in, dw, d, 1, ldy, stream);
+    return wgrad_igemm_launch(&dy, &in, &dw, 1, d, 1, ldy, stream);
 }
 
 extern "C" int tcvom_wgrad_igemm_phases(const void* dy, const void* in, float* dw, const tcvom_conv_desc* descs,
                                         int32_t nphase, int32_t ldy, void* stream) {
-    return wgrad_igemm_launch(dy, in, dw, descs, nphase, ldy, stream);
+    return wgrad_igemm_launch(&dy, &in, &dw, 1, descs, nphase, ldy, stream);
+}
+
+extern "C" int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, float* const* dw, int32_t nbatch,
+                                         const tcvom_conv_desc* descs, int32_t nphase, int32_t ldy, void* stream) {
+    return wgrad_igemm_launch(dy, in, dw, nbatch, descs, nphase, ldy, stream);
 }

@@ -206,8 +206,8 @@ class _ConvBNAct(torch.autograd.Function):
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
             dx = torch.empty((geo.N, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
             _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st)
-        L.call('tcvom_wgrad_igemm_phases', L.ptr(dy), L.ptr(x), bank.dw_ptr(spec, ctx.call), _phase_array(geo.wgrad),
-               len(geo.wgrad), K, st)
+        # the weight gradient is deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
+        bank.defer_wgrad(spec, ctx.call, dy, x, geo)
         dres2 = dz if ctx.has_res2 else None
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None
 

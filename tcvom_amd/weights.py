@@ -59,6 +59,7 @@ class WeightBank(object):
         self.max_calls = 0
         self.bns, self.bn_ch, self._bn_sig, self._bn_cap = [], 0, None, 0
         self.bn_mask, self.window_id = [], 0
+        self._deferred = []
 
     # ------------------------------------------------------------------ BatchNorm bookkeeping
     # Every BatchNorm call of a window gets a fixed slot in one arena for its (scale, shift) and (mean, invstd)
@@ -280,6 +281,7 @@ class WeightBank(object):
         st = L.stream_ptr()
         sc = C.byref(self.scratch)
         self.dw_arena.zero_()
+        self._deferred = []
         self._ensure_bn(frames, dev)
         if self.bns and training:
             self.bn_grad.zero_()
@@ -343,8 +345,45 @@ class WeightBank(object):
     def dw_ptr(self, spec, call):
         return C.c_void_p(self.dw_arena.data_ptr() + 4 * (call * self.dw_stride + spec.dw_off))
 
+    # ------------------------------------------------------------------ deferred weight gradients
+    def defer_wgrad(self, spec, call, dy, x, geo):
+        """Queue dW~[call] += dy^T * im2col(x) of one conv call.  All calls of a layer in a window have the same shape,
+        so `run_deferred_wgrads` issues them as one batched launch: 3x the workgroups per launch means the pixel
+        reduction is split 3x less (3x fewer atomic partial sums) and 3x fewer launches."""
+        self._deferred.append((spec, call, dy, x, geo, torch.cuda.current_stream()))
+
+    def run_deferred_wgrads(self):
+        from .ops import _phase_array
+        pend, self._deferred = self._deferred, []
+        if not pend:
+            return
+        cur = torch.cuda.current_stream()
+        for s in {e[5] for e in pend}:
+            if s != cur:
+                cur.wait_stream(s)
+        groups = {}
+        for e in pend:
+            groups.setdefault((e[0].layer_id, id(e[4])), []).append(e)
+        st = L.stream_ptr()
+        for items in groups.values():
+            spec, geo = items[0][0], items[0][4]
+            arr = _phase_array(geo.wgrad)
+            for i in range(0, len(items), 8):
+                part = items[i:i + 8]
+                n = len(part)
+                dys = (C.c_void_p * n)(*[e[2].data_ptr() for e in part])
+                xs = (C.c_void_p * n)(*[e[3].data_ptr() for e in part])
+                dws = (C.c_void_p * n)(*[self.dw_ptr(spec, e[1]).value for e in part])
+                L.call('tcvom_wgrad_igemm_batched', C.cast(dys, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(dws, C.c_void_p), n,
+                       arr, len(geo.wgrad), spec.K, st)
+        for e in pend:
+            if e[5] != cur:                      # allocated on a frame stream, consumed here: keep the blocks alive
+                e[2].record_stream(cur)
+                e[3].record_stream(cur)
+
     def backward(self, plan):
         """dW~ arena -> list of weight_bar gradients (views of one flat fp32 buffer)."""
+        self.run_deferred_wgrads()
         grad = torch.empty(self.grad_numel, dtype=torch.float32, device=self.device)
         L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), L.ptr(plan['work_inner']), plan['n_inner'],
                L.ptr(self.work_apply), self.n_apply, L.ptr(plan['ncalls_dev']), L.ptr(self.dw_arena), self.dw_stride,

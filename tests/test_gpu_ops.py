@@ -215,6 +215,36 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     ck.done()
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [(128, 128, 3, 1, False, 40, 64), (64, 64, 4, 2, True, 20, 24),
+                                                               (32, 64, 3, 2, False, 48, 64)])
+def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
+    """tcvom_wgrad_igemm_batched (the S calls of a layer as one launch, what WeightBank.run_deferred_wgrads issues) must
+    equal S separate tcvom_wgrad_igemm_phases launches up to the fp32 order of the split pixel reduction."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.ops import _phase_array
+    tag = 'bw%d_%d_%d' % (cin, cout, k)
+    bank, spec = _mini_bank(cin, cout, k, stride, 1, transposed, spectral=False, tag=tag)
+    geo = ConvGeometry(spec, 1, H, W)
+    arr = _phase_array(geo.wgrad)
+    S = 3
+    xs = [(hu('x%d.%s' % (i, tag), (1, H, W, spec.cpad))).to(DEV).to(torch.bfloat16) for i in range(S)]
+    dys = [(hu('dy%d.%s' % (i, tag), (1, geo.OH, geo.OW, cout))).to(DEV).to(torch.bfloat16) for i in range(S)]
+    n = spec.K * spec.T * spec.cpad
+    single = torch.zeros(S, n, device=DEV)
+    batched = torch.zeros(S, n, device=DEV)
+    st = L.stream_ptr()
+    for i in range(S):
+        L.call('tcvom_wgrad_igemm_phases', L.ptr(dys[i]), L.ptr(xs[i]), L.ptr(single[i]), arr, len(geo.wgrad), cout, st)
+    vp = lambda ts: C.cast((C.c_void_p * S)(*[t.data_ptr() for t in ts]), C.c_void_p)
+    L.call('tcvom_wgrad_igemm_batched', vp(dys), vp(xs), vp([batched[i] for i in range(S)]), S, arr, len(geo.wgrad), cout, st)
+    torch.cuda.synchronize()
+    assert float(single.abs().max()) > 0
+    assert rel_err(batched.cpu(), single.cpu()) < 2e-5
+    assert not torch.equal(single[0], single[1])
+
+
 @pytest.mark.parametrize('cin,cout,hp,N,H,W', [(32, 32, False, 2, 16, 64), (32, 32, True, 1, 24, 96), (6, 32, False, 1, 16, 160),
                                               (32, 32, False, 1, 72, 96), (64, 64, False, 2, 16, 64), (64, 64, True, 1, 24, 96),
                                               (64, 32, False, 1, 16, 96), (32, 64, False, 1, 40, 64)])
