@@ -177,9 +177,11 @@ int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_t Cc, int64
  * ksize 5 / mode 1 = clamp(0, 1) (DIM alpha_pred, models/DIM/vggnet.py:76,123).  w is fp32 [ksize*ksize][C]. */
 int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t ksize, int32_t mode, void* stream);
+/* dw is [replicas][ksize*ksize][C] and db [replicas] fp32: the per-block partial sums are spread over `replicas`
+ * copies (less atomic contention; ksize 3 only, else 1) which the caller adds up */
 int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
                         float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
-                        int32_t ksize, int32_t mode, void* stream);
+                        int32_t ksize, int32_t mode, int32_t replicas, void* stream);
 
 /* ------------------------------------------------------------------ Temporal Attention Module
  * Replaces FeatureAggregationModule._attention x2 + `v + xb + xf` (models/VMN/VMN_model.py:24-68).

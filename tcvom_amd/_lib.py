@@ -88,7 +88,7 @@ _PROTOS = {
     'tcvom_colsum': [vp, vp, i64, i32, i32, vp],
     'tcvom_transpose_bf16': [vp, vp, i32, i32, i64, i64, i32, i64, i64, vp],
     'tcvom_head_conv_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
-    'tcvom_head_conv_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_head_conv_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_maxpool2_idx': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_unpool2': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_pick2': [vp, vp, vp, i32, i32, i32, i32, vp],

@@ -65,6 +65,55 @@ __global__ __launch_bounds__(256) void gca_patches_kernel(const bf16raw* __restr
 }
 
 // ------------------------------------------------------------------ row softmax: fp32 [rows][ld] -> bf16 [rows][ldp]
+// One block per row.  Fast path (rows up to 8192 columns, 16-byte aligned): a thread owns 8 consecutive columns of each
+// 2048-column chunk, keeps its <= 32 logits in registers (ONE pass over S: 2 x float4 loads per chunk) and writes
+// 8 bf16 per 16-byte store.  The generic path (longer rows / odd strides) re-reads the row from L2.
+template <int NCHUNK>
+__global__ __launch_bounds__(256) void row_softmax_reg_kernel(const float* __restrict__ S, bf16raw* __restrict__ P, int ncols,
+                                                              int64_t ld, int64_t ldp) {
+    __shared__ float red[4];
+    const float* s = S + (int64_t)blockIdx.x * ld;
+    bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    float v[NCHUNK][8];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int j0 = c * 2048 + threadIdx.x * 8;
+        if (j0 + 8 <= ncols) {
+            const float4 a = *reinterpret_cast<const float4*>(s + j0), b = *reinterpret_cast<const float4*>(s + j0 + 4);
+            v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w; v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[c][k] = j0 + k < ncols ? s[j0 + k] : -3.0e38f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, v[c][k]);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[c][k] = __expf(v[c][k] - mx);         // exp(-3e38 - mx) == 0 for the padding
+            den += v[c][k];
+        }
+    den = block_sum_256(den, red);
+    const float r = 1.f / den;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int j0 = c * 2048 + threadIdx.x * 8;
+        if (j0 < ldp) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = v[c][k] * r;
+            *reinterpret_cast<uint4*>(p + j0) = pack8(o);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ S, bf16raw* __restrict__ P, int ncols,
                                                           int64_t ld, int64_t ldp) {
     __shared__ float red[4];
@@ -85,6 +134,57 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
 }
 
 // dS'[i][j] = P (dP - sum_j P dP);  T = dS' * c_j  (bf16, padded columns zero)
+template <int NCHUNK>
+__global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const bf16raw* __restrict__ P, const float* __restrict__ dP,
+                                                                  const float* __restrict__ cvec, bf16raw* __restrict__ T,
+                                                                  int ncols, int64_t ld, int64_t ldp, int rows_per_batch) {
+    __shared__ float red[4];
+    cvec += (int64_t)(blockIdx.x / rows_per_batch) * ncols;      // per-key scales are [B][N]
+    const bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    const float* d = dP + (int64_t)blockIdx.x * ld;
+    bf16raw* t = T + (int64_t)blockIdx.x * ldp;
+    const bool cvec4 = (ncols & 3) == 0 && (((uintptr_t)cvec) & 15) == 0;
+    // pass 1 keeps P * (the row's probabilities) and dP in registers as w = P and g = dP; only 8 + 8 live values per
+    // chunk are needed twice, so the products are stored: pd = P*dP (for the sum) and the second pass needs P and dP
+    float pv[NCHUNK][8], dv[NCHUNK][8];
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int j0 = c * 2048 + threadIdx.x * 8;
+        if (j0 + 8 <= ncols) {
+            unpack8(*reinterpret_cast<const uint4*>(p + j0), pv[c]);
+            const float4 x = *reinterpret_cast<const float4*>(d + j0), y = *reinterpret_cast<const float4*>(d + j0 + 4);
+            dv[c][0] = x.x; dv[c][1] = x.y; dv[c][2] = x.z; dv[c][3] = x.w; dv[c][4] = y.x; dv[c][5] = y.y; dv[c][6] = y.z; dv[c][7] = y.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pv[c][k] = j0 + k < ncols ? bf2f(p[j0 + k]) : 0.f;
+                dv[c][k] = j0 + k < ncols ? d[j0 + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += pv[c][k] * dv[c][k];
+    }
+    a = block_sum_256(a, red);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int j0 = c * 2048 + threadIdx.x * 8;
+        if (j0 < ldp) {
+            float cv[8];
+            if (cvec4 && j0 + 8 <= ncols) {
+                const float4 x = *reinterpret_cast<const float4*>(cvec + j0), y = *reinterpret_cast<const float4*>(cvec + j0 + 4);
+                cv[0] = x.x; cv[1] = x.y; cv[2] = x.z; cv[3] = x.w; cv[4] = y.x; cv[5] = y.y; cv[6] = y.z; cv[7] = y.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cv[k] = j0 + k < ncols ? cvec[j0 + k] : 0.f;
+            }
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = pv[c][k] * (dv[c][k] - a) * cv[k];       // pv == 0 beyond ncols
+            *reinterpret_cast<uint4*>(t + j0) = pack8(o);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const bf16raw* __restrict__ P, const float* __restrict__ dP,
                                                               const float* __restrict__ cvec, bf16raw* __restrict__ T,
                                                               int ncols, int64_t ld, int64_t ldp, int rows_per_batch) {
@@ -254,15 +354,27 @@ extern "C" int tcvom_gca_prepare(const void* g8, const uint8_t* unk8, void* G, f
 }
 extern "C" int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, void* stream) {
     TCVOM_CHECK_ARG(S && P && rows > 0 && ncols > 0 && ld >= ncols && ldp >= ncols, "row_softmax: bad args");
-    hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, (bf16raw*)P, ncols, ld, ldp);
+    const bool fast = ldp <= 8192 && ld % 4 == 0 && ldp % 8 == 0 && ((uintptr_t)S % 16 == 0) && ((uintptr_t)P % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (fast && ldp <= 2048) hipLaunchKernelGGL(row_softmax_reg_kernel<1>, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
+    else if (fast && ldp <= 4096) hipLaunchKernelGGL(row_softmax_reg_kernel<2>, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
+    else if (fast) hipLaunchKernelGGL(row_softmax_reg_kernel<4>, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
+    else hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
     TCVOM_LAUNCH_CHECK("row_softmax");
     return TCVOM_OK;
 }
 extern "C" int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec, void* T, int32_t rows,
                                      int32_t ncols, int64_t ld, int64_t ldp, int32_t rows_per_batch, void* stream) {
     TCVOM_CHECK_ARG(P && dP && cvec && T && rows > 0 && ncols > 0 && rows_per_batch > 0, "row_softmax_bwd: bad args");
-    hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)P, dP, cvec,
-                       (bf16raw*)T, ncols, ld, ldp, rows_per_batch);
+    const bool fast = ldp <= 8192 && ld % 4 == 0 && ldp % 8 == 0 && ((uintptr_t)dP % 16 == 0) && ((uintptr_t)P % 16 == 0) &&
+                      ((uintptr_t)T % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+#define SM_BWD_ARGS (const bf16raw*)P, dP, cvec, (bf16raw*)T, ncols, ld, ldp, rows_per_batch
+    if (fast && ldp <= 2048) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<1>, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
+    else if (fast && ldp <= 4096) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<2>, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
+    else if (fast) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<4>, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
+    else hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
+#undef SM_BWD_ARGS
     TCVOM_LAUNCH_CHECK("row_softmax_bwd");
     return TCVOM_OK;
 }

@@ -406,10 +406,13 @@ class _HeadConv(torch.autograd.Function):
         dalpha = _c(dalpha.float())
         dx = torch.empty_like(x)
         dpre = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
-        dw = torch.empty((T, Cc), dtype=torch.float32, device=x.device)
-        db = torch.empty(1, dtype=torch.float32, device=x.device)
+        reps = 16 if ctx.ksize == 3 else 1                      # replicas of dw: 16x less atomic contention
+        dw = torch.empty((reps, T, Cc), dtype=torch.float32, device=x.device)
+        db = torch.empty(reps, dtype=torch.float32, device=x.device)
         L.call('tcvom_head_conv_bwd', L.ptr(dalpha), L.ptr(alpha), L.ptr(x), L.ptr(wt), L.ptr(dx), L.ptr(dpre), L.ptr(dw),
-               L.ptr(db), N, H, W, Cc, ctx.ksize, ctx.mode, L.stream_ptr())
+               L.ptr(db), N, H, W, Cc, ctx.ksize, ctx.mode, reps, L.stream_ptr())
+        dw = dw.sum(0) if reps > 1 else dw[0]
+        db = db.sum(0, keepdim=True)
         return dx, dw.t().reshape(1, Cc, ctx.ksize, ctx.ksize), db, None, None
 
 

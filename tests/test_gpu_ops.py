@@ -289,6 +289,31 @@ def test_halo_conv_kernel(cin, cout, hp, N, H, W):
 
 
 # --------------------------------------------------------------------------------------------- spectral norm
+@pytest.mark.parametrize('ncols', [8160, 2040, 3000, 250])
+def test_row_softmax_kernels(ncols):
+    """GCA attention softmax forward / backward rows at the 1080p length (8160 keys: 4 register chunks) and shorter / ragged
+    ones, against fp32 PyTorch."""
+    from tcvom_amd import _lib as L
+    rows = 37
+    ld = (ncols + 63) // 64 * 64
+    S = (hu('sm.s%d' % ncols, (rows, ld)) * 6).to(DEV)
+    P = torch.empty(rows, ld, dtype=torch.bfloat16, device=DEV)
+    st = L.stream_ptr()
+    L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), rows, ncols, ld, ld, st)
+    ref = torch.softmax(S[:, :ncols].float(), dim=1)
+    assert rel_err(P[:, :ncols].float().cpu(), ref.cpu()) < 5e-3
+    assert float(P[:, ncols:].float().abs().max()) == 0.0 if ld > ncols else True
+    dP = hu('sm.dp%d' % ncols, (rows, ld)).to(DEV)
+    cvec = (hu('sm.c%d' % ncols, (ncols,)) + 1.5).to(DEV)
+    T = torch.empty(rows, ld, dtype=torch.bfloat16, device=DEV)
+    L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), rows, ncols, ld, ld, rows, st)
+    Pf = P[:, :ncols].float()
+    a = (Pf * dP[:, :ncols]).sum(1, keepdim=True)
+    tref = Pf * (dP[:, :ncols] - a) * cvec[None, :]
+    assert rel_err(T[:, :ncols].float().cpu(), tref.cpu()) < 1e-2
+    assert float(T[:, ncols:].float().abs().max()) == 0.0 if ld > ncols else True
+
+
 @pytest.mark.parametrize('rows_b,rows_a,kred,fp32', [(4100, 4096, 192, True), (4000, 4608, 320, False)])
 def test_dense_gemm_256_tile_config(rows_b, rows_a, kred, fp32):
     """Dense NT GEMM at sizes that select the 256x256 tile (the GCA score / P.V GEMMs at 1080p), ragged pixel edge,
