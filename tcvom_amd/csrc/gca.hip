@@ -215,27 +215,29 @@ __global__ __launch_bounds__(256) void gca_value_patches_kernel(const uint4* __r
     }
 }
 // dalpha[y][x][c] = sum over (key, tap) whose reflected source is (y,x) of dV[key][tap][c]   (dV fp32)
-__global__ __launch_bounds__(256) void gca_value_patches_bwd_kernel(const float* __restrict__ dV, bf16raw* __restrict__ dalpha,
-                                                                    int B, int h8, int w8, int C) {
+__global__ __launch_bounds__(256) void gca_value_patches_bwd_kernel(const float4* __restrict__ dV, uint2* __restrict__ dalpha,
+                                                                    int B, int h8, int w8, int C4) {
+    // one thread = one pixel x 4 channels (16-byte loads of the fp32 patch gradients, 8-byte bf16 store)
     const int h = h8 / 2, w = w8 / 2, N = h * w;
-    const int64_t total = (int64_t)B * h8 * w8 * C;
+    const int64_t total = (int64_t)B * h8 * w8 * C4;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(v % C);
-        int64_t t = v / C;
+        const int c = (int)(v % C4);
+        int64_t t = v / C4;
         const int x = (int)(t % w8); t /= w8;
         const int y = (int)(t % h8);
         const int b = (int)(t / h8);
-        float acc = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int jy = max(0, (y - 3) / 2 - 1); jy <= min(h - 1, (y + 3) / 2 + 1); ++jy)
             for (int ky = 0; ky < 4; ++ky) {
                 if (refl(2 * jy - 1 + ky, h8) != y) continue;
                 for (int jx = max(0, (x - 3) / 2 - 1); jx <= min(w - 1, (x + 3) / 2 + 1); ++jx)
                     for (int kx = 0; kx < 4; ++kx) {
                         if (refl(2 * jx - 1 + kx, w8) != x) continue;
-                        acc += dV[(((int64_t)b * N + jy * w + jx) * 16 + ky * 4 + kx) * C + c];
+                        const float4 g = dV[(((int64_t)b * N + jy * w + jx) * 16 + ky * 4 + kx) * C4 + c];
+                        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                     }
             }
-        dalpha[v] = f2bf(acc);
+        dalpha[v] = make_uint2(pack2bf(acc.x, acc.y), pack2bf(acc.z, acc.w));
     }
 }
 
@@ -386,9 +388,9 @@ extern "C" int tcvom_gca_value_patches(const void* alpha, void* V, int32_t B, in
     return TCVOM_OK;
 }
 extern "C" int tcvom_gca_value_patches_bwd(const float* dV, void* dalpha, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
-    TCVOM_CHECK_ARG(dV && dalpha, "gca_value_patches_bwd: bad args");
-    hipLaunchKernelGGL(gca_value_patches_bwd_kernel, dim3(sgrid((int64_t)B * h8 * w8 * C)), dim3(256), 0,
-                       (hipStream_t)stream, dV, (bf16raw*)dalpha, B, h8, w8, C);
+    TCVOM_CHECK_ARG(dV && dalpha && C % 4 == 0, "gca_value_patches_bwd: bad args");
+    hipLaunchKernelGGL(gca_value_patches_bwd_kernel, dim3(sgrid((int64_t)B * h8 * w8 * C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)dV, (uint2*)dalpha, B, h8, w8, C / 4);
     TCVOM_LAUNCH_CHECK("gca_value_patches_bwd");
     return TCVOM_OK;
 }
