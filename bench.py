@@ -53,6 +53,8 @@ def build(device, H, W, seed):
     model = model.to(device).train()
     if os.environ.get('TCVOM_FRAME_STREAMS', '1') == '0':      # profiling aid: serialise the frames on one stream
         model.NET.frame_streams = False
+    if os.environ.get('TCVOM_BATCHED_FRAMES', '1') == '0':     # A/B aid: frame-by-frame launches instead of frame-batched ones
+        model.NET.batched_frames = False
     a, fg, bg = synthetic_window(1, 3, H, W, seed=seed)
     return model, a.to(device), fg.to(device), bg.to(device)
 

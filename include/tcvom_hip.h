@@ -59,8 +59,12 @@ typedef struct {
     int32_t act;                 /* 0 none, 1 ReLU (before store and statistics) */
     int32_t out_fp32;            /* store fp32 instead of bf16 */
     int32_t stats_group_offset;  /* first statistics group written by this launch */
-    int32_t batch;               /* >1: blockIdx.z batches with the strides below (dense GEMM use) */
+    int32_t batch;               /* >1: `batch` independent problems with the strides below: the dense GEMMs of GCA,
+                                    and the S frames of a window through one conv layer (N samples per frame, own
+                                    SpectralNorm'd weight copy per frame) */
     int64_t in_bstride, w_bstride, out_bstride, vec_bstride;
+    int64_t stats_bstride;       /* statistics groups between batch elements (frame f writes groups
+                                    stats_group_offset + f*stats_bstride + ...) */
 } tcvom_conv_desc;
 
 /* stats_partial: [groups][2][K] fp32 or NULL; mscale/mdiag/bias: [K] fp32 or NULL. */
@@ -99,7 +103,12 @@ int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, floa
 int tcvom_bn_finalize(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, float* scale_shift /*[2][C]*/, float* saved /*[2][C] mean,invstd*/,
-                      double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */, void* stream);
+                      double* scratch /* nframes * tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
+                      int32_t nframes, int64_t slot_stride, void* stream);
+/* nframes / slot_stride (above and below): a frame-batched call normalises `nframes` groups of `pixels` pixels each
+ * (the S frames of a window in one launch; statistics stay per frame, as in the reference's per-frame encoder calls).
+ * partial is then [nframes][groups][2][C], and frame f uses the vectors at scale_shift + f*slot_stride,
+ * saved + f*slot_stride and coef + f*3*C.  nframes = 1, slot_stride = 0 is the plain call. */
 int tcvom_bn_finalize_scratch_doubles(int32_t C);
 /* running_mean/var EMA from the (mean, invstd) a train-mode tcvom_bn_finalize(running_mean=NULL) call saved */
 int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_var, int32_t C, float momentum,
@@ -113,16 +122,18 @@ int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
 /* y_fp32 != 0: the conv output y is fp32 (high-precision layers) instead of bf16 */
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
-                   int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, void* stream);
+                   int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
+                   void* stream);
 int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
 int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
-                        const float* saved, float* partial /*[groups][2][C]*/, int64_t pixels, int32_t C,
-                        int32_t act, int32_t y_fp32, void* stream);
+                        const float* saved, float* partial /*[nframes][groups][2][C]*/, int64_t pixels, int32_t C,
+                        int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream);
 /* dgamma/dbeta are written, or accumulated when `accumulate` is set; coef is [3][C] scratch consumed by bn_bwd_apply */
 int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, const float* gamma,
-                          const float* saved, float* dgamma, float* dbeta, float* coef,
-                          double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
-                          int32_t accumulate /* != 0: atomically ADD into dgamma/dbeta */, void* stream);
+                          const float* saved, float* dgamma, float* dbeta, float* coef /*[nframes][3][C]*/,
+                          double* scratch /* nframes * tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
+                          int32_t accumulate /* != 0: atomically ADD into dgamma/dbeta (required when nframes > 1) */,
+                          int32_t nframes, int64_t slot_stride, void* stream);
 /* SyncBatchNorm (train_ddp.py:213 nn.SyncBatchNorm.convert_sync_batchnorm): the per-channel sums are produced
  * as an fp64 [2][C] vector, the host all-reduces it over the ranks (RCCL), and the *_sums finalizers consume
  * the summed vector with the global pixel count.  dgamma/dbeta come from the LOCAL sums (torch semantics). */
@@ -137,7 +148,8 @@ int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local,
  * gradient is additionally masked by y > 0 */
 int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
                        const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
-                       int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, void* stream);
+                       int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                       int64_t slot_stride, void* stream);
 
 /* ------------------------------------------------------------------ batched SpectralNorm + weight packing
  * Replaces SpectralNorm._update_u_v/_noupdate_u_v (models/GCA/ops.py:25-45,74-80) for every wrapped

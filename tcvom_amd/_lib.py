@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ('wt', C.c_int32), ('ldo', C.c_int32), ('act', C.c_int32), ('out_fp32', C.c_int32),
         ('stats_group_offset', C.c_int32), ('batch', C.c_int32),
         ('in_bstride', C.c_int64), ('w_bstride', C.c_int64), ('out_bstride', C.c_int64), ('vec_bstride', C.c_int64),
+        ('stats_bstride', C.c_int64),
     ]
 
 
@@ -63,19 +64,19 @@ _PROTOS = {
     'tcvom_wgrad_igemm_phases': [vp, vp, vp, DP, i32, i32, vp],
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
     'tcvom_wgrad_igemm_batched': [vp, vp, vp, i32, DP, i32, i32, vp],
-    'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp],
+    'tcvom_bn_finalize': [vp, i32, i32, i64, i64, vp, vp, vp, vp, f32, f32, vp, vp, vp, i32, i64, vp],
     'tcvom_bn_finalize_scratch_doubles': [i32],
     'tcvom_bn_ema_update': [vp, vp, vp, i32, f32, f32, i64, vp],
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
-    'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
+    'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
-    'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
-    'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, vp],
+    'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     'tcvom_bn_ema_multi': [vp, i32, vp, vp, vp],
     'tcvom_bn_reduce_sums': [vp, i32, i32, vp, vp, vp],
     'tcvom_bn_finalize_sums': [vp, i32, i64, i64, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_bwd_finalize_sums': [vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, vp],
-    'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
+    'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
     'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, vp],

@@ -32,6 +32,8 @@ struct HaloArgs {
     const bf16raw* zero_page;
     int N, H, W, K, ldo, wt, act, out_fp32, stats_group_offset;
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
+    int spf;                     // samples per frame (weights change every spf samples: w_bstride elements further)
+    long long w_bstride;
     int tap_dh[HALO_MAX_TAPS + 2], tap_dw[HALO_MAX_TAPS + 2], tap_w[HALO_MAX_TAPS + 2];   // compacted; tap_w < 0: zero tap
 };
 
@@ -63,14 +65,21 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
 
-    // ---- weights -> LDS, once: wl[k][t*C + c] = wgt[(k*wt + slot(t))*C + c]
-    for (int u = tid; u < 32 * NTAPS * CU; u += 256) {
-        const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
-        const int ws = a.tap_w[t];
-        uint4 val = make_uint4(0u, 0u, 0u, 0u);
-        if (ws >= 0 && k < a.K) val = *reinterpret_cast<const uint4*>(a.wgt + ((int64_t)k * a.wt + ws) * C + cu * 8);
-        *reinterpret_cast<uint4*>(wl + k * WROW + t * C + cu * 8) = val;
-    }
+    // ---- weights -> LDS: wl[k][t*C + c] = wgt[frame][(k*wt + slot(t))*C + c].  Once per workgroup, and again whenever
+    // its tile run crosses into the next FRAME of a frame-batched call (every frame has its own SpectralNorm'd copy).
+    const int tiles_per_frame = a.spf * a.tiles_x * a.tiles_y;
+    auto load_weights = [&](int frame) {
+        const bf16raw* wsrc = a.wgt + (int64_t)frame * a.w_bstride;
+        for (int u = tid; u < 32 * NTAPS * CU; u += 256) {
+            const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
+            const int ws = a.tap_w[t];
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (ws >= 0 && k < a.K) val = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)k * a.wt + ws) * C + cu * 8);
+            *reinterpret_cast<uint4*>(wl + k * WROW + t * C + cu * 8) = val;
+        }
+    };
+    int cur_frame = t_begin / tiles_per_frame;
+    load_weights(cur_frame);
 
     // ---- per-lane constants
     // DMA: unit q = (it*4 + wave)*64 + lane -> halo pixel p = q / CU, stored slot q % CU holds chunk slot ^ swz(p)
@@ -130,6 +139,12 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tile + 1 < t_end) HALO_ISSUE(tile + 1, slot ^ 1);
+        if (tile / tiles_per_frame != cur_frame) {      // uniform: every wave has finished the previous frame's last tile
+            cur_frame = tile / tiles_per_frame;
+            load_weights(cur_frame);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
 
         f32x16_t acc[2];
 #pragma unroll
@@ -207,12 +222,16 @@ struct HaloPlan { bool ok; int C, nch, ntaps; int taps[HALO_MAX_TAPS + 2]; };
 static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     HaloPlan p;
     p.ok = false;
-    if (nphase != 1 || d->batch > 1) return p;
+    if (nphase != 1) return p;
+    if (d->batch > 1) {           // frame-batched call: frames must be contiguous sample groups
+        if (d->in_bstride != (long long)d->N * d->H * d->W * d->C || d->out_bstride != (long long)d->N * d->H * d->W * d->ldo) return p;
+        if (d->vec_bstride != 0) return p;
+    }
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return p;
     if (d->PH != d->H || d->PW != d->W || d->OH != d->H || d->OW != d->W) return p;
     if (d->H % HALO_TH != 0 || d->W % HALO_TW != 0) return p;
     if (d->K > 32 || d->K % 4 != 0 || (d->C != 8 && d->C != 32)) return p;
-    if ((long long)d->N * d->H * d->W * d->C >= (1ll << 31)) return p;
+    if ((long long)d->N * (d->batch > 1 ? d->batch : 1) * d->H * d->W * d->C >= (1ll << 31)) return p;
     int n = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         if (d->tap_w[t] < 0) continue;
@@ -241,7 +260,7 @@ static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per
     int occ = (int)((160 * 1024) / *lds_bytes);
     if (occ > 4) occ = 4;
     if (occ < 1) occ = 1;
-    const int ntiles = d->N * (d->H / HALO_TH) * (d->W / HALO_TW);
+    const int ntiles = d->N * (d->batch > 1 ? d->batch : 1) * (d->H / HALO_TH) * (d->W / HALO_TW);
     int wgs = 256 * occ;
     if (wgs > ntiles) wgs = ntiles;
     *tiles_per_wg = (ntiles + wgs - 1) / wgs;
@@ -252,7 +271,7 @@ static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase) {
     const HaloPlan p = halo_plan(d, nphase);
     if (!p.ok) return 0;
-    return d->N * (d->H / HALO_TH) * (d->W / HALO_TW) * 4;
+    return d->N * (d->H / HALO_TH) * (d->W / HALO_TW) * 4;     // per batch element (frame), like the igemm count
 }
 
 // returns 1 when the conv was launched here, 0 when the caller should use the implicit GEMM, < 0 on error
@@ -272,7 +291,15 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
     a.stats_group_offset = d->stats_group_offset;
     a.tiles_x = d->W / HALO_TW;
     a.tiles_y = d->H / HALO_TH;
-    a.ntiles = d->N * a.tiles_x * a.tiles_y;
+    const int nb = d->batch > 1 ? d->batch : 1;
+    a.N = d->N * nb;
+    a.spf = d->N;
+    a.w_bstride = nb > 1 ? d->w_bstride : 0;
+    a.ntiles = a.N * a.tiles_x * a.tiles_y;
+    // statistics groups are tile-major == frame-major, so frame f starts at f * (groups per frame): the caller's
+    // stats_bstride must be exactly that
+    if (stats && nb > 1 && d->stats_bstride != (long long)d->N * a.tiles_x * a.tiles_y * 4)
+        return tcvom_fail(TCVOM_ERR_ARG, "halo_conv: stats_bstride %lld != groups per frame", (long long)d->stats_bstride);
     for (int t = 0; t < HALO_MAX_TAPS + 2; ++t) {
         const int src = t < p.ntaps ? p.taps[t] : -1;
         a.tap_dh[t] = src >= 0 ? d->tap_dh[src] : 0;

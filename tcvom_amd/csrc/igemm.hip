@@ -64,9 +64,10 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 #ifdef NT_TRACE
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
-    const int phase = ps.n > 1 ? blockIdx.z : 0;
+    const int bcount = ps.d[0].batch > 1 ? ps.d[0].batch : 1;        // blockIdx.z = phase * batch + batch element
+    const int phase = ps.n > 1 ? blockIdx.z / bcount : 0;
     const tcvom_conv_desc& d = ps.d[phase];
-    const int bz = ps.n > 1 ? 0 : blockIdx.z;
+    const int bz = ps.n > 1 ? blockIdx.z - phase * bcount : blockIdx.z;
     constexpr int WAVES_N = TN / WN;
     constexpr int WAVES_M = TM / WM;
     constexpr int NW = WAVES_M * WAVES_N;              // 4 or 8 waves per workgroup
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                 w1 += __shfl_xor(w1, 1, 64);
                 if ((lane & 3) == 0 && mrow < K) {
                     const int idx = (lane >> 2) & 7;                    // b4: sum / sum of squares, (b3, b2): channel
-                    const int64_t grp = d.stats_group_offset + (int64_t)bx * WAVES_N + wn;
+                    const int64_t grp = d.stats_group_offset + bz * d.stats_bstride + (int64_t)bx * WAVES_N + wn;
                     stats[grp * 2 * K + (idx >> 2) * K + mrow + (idx & 3)] = w1;
                 }
             }
@@ -355,7 +356,7 @@ static const bf16raw* zero_page_for_current_device() {
 }
 static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     const long long P = (long long)d->N * d->PH * d->PW;
-    const int nb = nphase > 1 ? nphase : (d->batch > 1 ? d->batch : 1);
+    const int nb = nphase * (d->batch > 1 ? d->batch : 1);
     if (d->K >= 128) {
         const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
         // the dense attention GEMMs of GCA (8160 x 8160 x 576 / 8160 x 2048 x 8160 at 1080p): 256x256 tiles halve the
@@ -412,7 +413,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "conv_igemm: C=%d must be a power of two >= 8", d->C);
         TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
         TCVOM_CHECK_ARG(d->C % 8 == 0, "conv_igemm: C=%d must be a multiple of 8", d->C);
-        TCVOM_CHECK_ARG(nphase == 1 || (d->batch <= 1 && d->K == descs[0].K), "conv_igemm: phases must share K and be unbatched");
+        TCVOM_CHECK_ARG(nphase == 1 || (d->batch == descs[0].batch && d->K == descs[0].K), "conv_igemm: phases must share K and the batch count");
         const long long P = (long long)d->N * d->PH * d->PW;
         TCVOM_CHECK_ARG(P > 0 && P < (1ll << 31), "conv_igemm: bad pixel count %lld", P);
         TCVOM_CHECK_ARG((long long)d->N * d->H * d->W * d->C < (1ll << 31) && (long long)d->K * d->wt * d->C < (1ll << 31),
@@ -421,7 +422,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         ps.d[i] = *d;
     }
     const tcvom_conv_desc* d0 = descs;
-    const int nb = nphase > 1 ? nphase : (d0->batch > 1 ? d0->batch : 1);
+    const int nb = nphase * (d0->batch > 1 ? d0->batch : 1);
     hipStream_t st = (hipStream_t)stream;
     const bf16raw* ip = (const bf16raw*)in;
     const bf16raw* wp = (const bf16raw*)w;

@@ -16,6 +16,8 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __r
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     const int slice = blockIdx.y;
+    partial += (int64_t)blockIdx.z * G * 2 * C;                     // frame (BatchNorm statistics group) of a batched call
+    out += (int64_t)blockIdx.z * BN_SLICES * 2 * C;
     double a = 0.0, b = 0.0;
     if (c < C) {
         for (int g = slice + sl * BN_SLICES; g < G; g += 8 * BN_SLICES) {
@@ -40,11 +42,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count, double unbias_count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
-    float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved)
+    float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved, int64_t slot_stride)
 {
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    partial += (int64_t)blockIdx.y * G * 2 * C;                     // frame of a batched call
+    scale_shift += blockIdx.y * slot_stride;
+    saved += blockIdx.y * slot_stride;
     double a = 0.0, b = 0.0;
     if (c < C) {
         // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
@@ -127,17 +132,20 @@ template <bool YF32>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const void* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
-    int64_t P, int C8, int C, int act, int rows_per_block)
+    int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride)
 {
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
+    // blockIdx.y = frame of a batched call: P pixels per frame, own (scale, shift) vector
+    scale_shift += blockIdx.y * slot_stride;
+    const int64_t fo = (int64_t)blockIdx.y * P * C8;
     float sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = scale_shift[oct * 8 + k]; sh[k] = scale_shift[C + oct * 8 + k]; }
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     for (int64_t p = pbeg + prow; p < pend; p += RP) {
-        const int64_t v = p * C8 + oct;
+        const int64_t v = fo + p * C8 + oct;
         float f[8], r1[8], r2[8];
         load_y8<YF32>(y, v, f);
         if (res1) unpack8(res1[v], r1);
@@ -160,10 +168,14 @@ template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint4* __restrict__ dz, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
-    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block)
+    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride)
 {
     extern __shared__ float red[];        // [2][256][8]
     const int tid = threadIdx.x;
+    scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
+    saved += blockIdx.y * slot_stride;
+    partial += (int64_t)blockIdx.y * gridDim.x * 2 * C;
+    const int64_t fo = (int64_t)blockIdx.y * P * C8;
     const int oct = tid % C8;
     const int prow = tid / C8;
     const int RP = 256 / C8;
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     if (prow < RP) {
         for (int64_t p = pbeg + prow; p < pend; p += RP) {
-            const int64_t v = p * C8 + oct;
+            const int64_t v = fo + p * C8 + oct;
             float g[8], yy[8], r1[8];
             unpack8(dz[v], g);
             load_y8<YF32>(y, v, yy);
@@ -220,11 +232,14 @@ template <typename PT>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ saved,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate)
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate, int64_t slot_stride)
 {
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    partial += (int64_t)blockIdx.y * G * 2 * C;                     // frame of a batched call
+    saved += blockIdx.y * slot_stride;
+    coef += (int64_t)blockIdx.y * 3 * C;
     double a = 0.0, b = 0.0;
     if (c < C) {
         // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
@@ -263,10 +278,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint4* __restrict__ dz, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
-    int rows_per_block)
+    int rows_per_block, int64_t slot_stride)
 {
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
+    scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
+    saved += blockIdx.y * slot_stride;
+    coef += (int64_t)blockIdx.y * 3 * C;
+    const int64_t fo = (int64_t)blockIdx.y * P * C8;
     float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], gi[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     for (int64_t p = pbeg + prow; p < pend; p += RP) {
-        const int64_t v = p * C8 + oct;
+        const int64_t v = fo + p * C8 + oct;
         float g[8], yy[8], r1[8], o[8];
         unpack8(dz[v], g);
         load_y8<YF32>(y, v, yy);
@@ -317,17 +336,19 @@ static int stream_grid(int64_t n, int per_block) {
 extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  float momentum, float eps, float* scale_shift, float* saved, double* scratch,
-                                 void* stream) {
+                                 int32_t nframes, int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0, "bn_finalize: bad args");
+    TCVOM_CHECK_ARG(nframes >= 1 && (nframes == 1 || (!running_mean && !running_var)), "bn_finalize: running statistics of a batched call are updated by tcvom_bn_ema_multi");
     hipStream_t st = (hipStream_t)stream;
     const double ub = (double)(unbias_count > 0 ? unbias_count : count);
     if (groups > 4 * BN_SLICES && scratch) {
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C,
-                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved);
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
+        // the second stage reads nframes blocks of BN_SLICES double partials
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C,
+                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride);
     } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C,
-                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved);
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, partial, groups, C,
+                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("bn_finalize");
     return TCVOM_OK;
@@ -416,16 +437,18 @@ extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* 
 }
 
 extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
-                              int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, void* stream) {
-    TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
+                              int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
+                              void* stream) {
+    TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0 && nframes >= 1, "bn_apply: bad args (C=%d)", C);
     TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_apply: C=%d must be a power of two <= 2048", C);
     const int rpb = bn_rows_per_block(pixels, C);
+    const dim3 grid(cdiv(pixels, rpb), nframes);
     if (y_fp32)
-        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
-                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb);
+        hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
-                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb);
+        hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_apply");
     return TCVOM_OK;
 }
@@ -441,33 +464,36 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
 
 extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
                                    const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
-                                   int32_t y_fp32, void* stream) {
-    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048,
+                                   int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && nframes >= 1,
                     "bn_bwd_reduce: bad args (C=%d)", C);
     const int groups = tcvom_bn_bwd_groups(pixels, C);
     const int rpb = (int)((pixels + groups - 1) / groups);
+    const dim3 grid(groups, nframes);
     if (y_fp32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(groups), dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(groups), dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
 }
 
 extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count,
                                      const float* gamma, const float* saved, float* dgamma, float* dbeta,
-                                     float* coef, double* scratch, int32_t accumulate, void* stream) {
-    TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+                                     float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
+                                     void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize: bad args");
+    TCVOM_CHECK_ARG(nframes == 1 || accumulate, "bn_bwd_finalize: the frames of a batched call must ACCUMULATE dgamma/dbeta");
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES,
-                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate);
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES,
+                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
     } else {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C,
-                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, partial, groups, C,
+                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
     return TCVOM_OK;
@@ -537,7 +563,7 @@ extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t cou
     TCVOM_CHECK_ARG(sums && gamma && beta && scale_shift && saved && C > 0 && count > 0, "bn_finalize_sums: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, sums, 1, C, (double)count,
                        (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps,
-                       scale_shift, saved);
+                       scale_shift, saved, (int64_t)0);
     TCVOM_LAUNCH_CHECK("bn_finalize_sums");
     return TCVOM_OK;
 }
@@ -548,7 +574,7 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
     TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0, "bn_bwd_finalize_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, sums_all, 1, C, (double)count, gamma,
-                       saved, (float*)nullptr, (float*)nullptr, coef, 0);
+                       saved, (float*)nullptr, (float*)nullptr, coef, 0, (int64_t)0);
     // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
     hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate);
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize_sums");
@@ -557,18 +583,20 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
 
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
-                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, void* stream) {
-    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
+                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                                  int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0 && nframes >= 1, "bn_bwd_apply: bad args");
     TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_bwd_apply: C=%d must be a power of two <= 2048", C);
     const int rpb = bn_rows_per_block(pixels, C);
+    const dim3 grid(cdiv(pixels, rpb), nframes);
     if (y_fp32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(cdiv(pixels, rpb)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
 }

@@ -63,49 +63,78 @@ def _phase_array(descs):
     if arr is None:
         arr = (L.ConvDesc * len(descs))(*descs)
         descs[0]._phase_array = arr
-        descs[0]._phase_groups = L.call('tcvom_conv_stats_groups', C.byref(descs[0]), len(descs))
+        descs[0]._phase_groups = {}
     return arr
 
 
-def _launch_conv(descs, x, wptr, out, bias, stats, act, st):
-    """All phases of a conv in ONE launch (stride-2 data gradients / ConvTranspose forwards have 4)."""
+def _set_frames(arr, n, nf, w_stride):
+    """Frame-batched launch: the S frames of a window go through a layer in ONE launch, as `batch` independent problems
+    of N = B samples each with their own weight copy (w_stride elements apart; 0 = shared)."""
+    for i in range(n):
+        d = arr[i]
+        d.batch = nf
+        if nf > 1:
+            d.in_bstride = d.N * d.H * d.W * d.C
+            d.out_bstride = d.N * d.OH * d.OW * d.ldo
+            d.w_bstride = w_stride
+            d.vec_bstride = 0
+
+
+def _stats_groups(descs, nf=1):
+    """Statistics groups ONE frame of a launch of these phases writes (depends on the tile the library picks, which
+    depends on the total workgroup count, hence on nf)."""
     arr = _phase_array(descs)
-    g = descs[0]._phase_groups
+    cache = descs[0]._phase_groups
+    if nf not in cache:
+        _set_frames(arr, len(descs), nf, 0)
+        cache[nf] = L.call('tcvom_conv_stats_groups', C.byref(arr[0]), len(descs)) * len(descs)
+    return cache[nf]
+
+
+def _launch_conv(descs, x, wptr, out, bias, stats, act, st, nf=1, w_stride=0):
+    """All phases of a conv in ONE launch (stride-2 data gradients / ConvTranspose forwards have 4), for nf frames."""
+    arr = _phase_array(descs)
+    n = len(descs)
+    gf = _stats_groups(descs, nf)                  # groups per frame (all phases)
+    _set_frames(arr, n, nf, w_stride)
     f32 = 1 if out.dtype == torch.float32 else 0
-    for i in range(len(descs)):
+    for i in range(n):
         arr[i].act = act
         arr[i].out_fp32 = f32
-        arr[i].stats_group_offset = i * g
-    L.call('tcvom_conv_igemm_phases', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), L.ptr(stats), arr, len(descs), st)
-
-
-def _stats_groups(descs):
-    _phase_array(descs)
-    return descs[0]._phase_groups * len(descs)
+        arr[i].stats_group_offset = i * (gf // n)
+        arr[i].stats_bstride = gf
+    L.call('tcvom_conv_igemm_phases', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), L.ptr(stats), arr, n, st)
 
 
 class _ConvBNAct(torch.autograd.Function):
+    """conv (+bias) (+ReLU) (+BatchNorm) (+residual) (+activation) (+residual) of one layer, for `bank.frames_per_op`
+    frames at once: x is [nf*B, H, W, C] frame-major; every frame has its own SpectralNorm call slot (weight copy) and
+    its own BatchNorm statistics, exactly as in the reference's per-frame encoder calls (VMN_model.py:93-98)."""
+
     @staticmethod
     def forward(ctx, x, token, gamma, beta, bias, res1, res2, cfg, training):
         _need_cuda(x)
         spec, bank, bn = cfg.spec, cfg.bank, cfg.bn
         x = _c(x)
-        N, H, W, Cx = x.shape
+        NT, H, W, Cx = x.shape
         assert Cx == spec.cpad and x.dtype == BF16, 'conv %s: input %s %s, expected %d channels' % (
             spec.name, tuple(x.shape), x.dtype, spec.cpad)
+        nf = bank.frames_per_op
+        assert NT % nf == 0
+        N = NT // nf
         geo = cfg.geometry(N, H, W)
-        call = bank.next_call(spec)
+        call, wsf, wsb = bank.next_calls(spec, nf)
         st = L.stream_ptr()
         K = spec.K
         has_bn = bn is not None
         # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
         hp = spec.hp and has_bn
-        y = torch.empty((N, geo.OH, geo.OW, K), dtype=torch.float32 if hp else BF16, device=x.device)
+        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=torch.float32 if hp else BF16, device=x.device)
         stats = None
         if has_bn and training:
-            stats = torch.empty(_stats_groups(geo.fwd) * 2 * K, dtype=torch.float32, device=x.device)
-        _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, ACT_RELU if cfg.pre_relu else ACT_NONE, st)
-        ctx.cfg, ctx.training, ctx.call, ctx.geo = cfg, training, call, geo
+            stats = torch.empty(nf * _stats_groups(geo.fwd, nf) * 2 * K, dtype=torch.float32, device=x.device)
+        _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, ACT_RELU if cfg.pre_relu else ACT_NONE, st, nf, wsf)
+        ctx.cfg, ctx.training, ctx.call, ctx.geo, ctx.nf, ctx.wsb = cfg, training, call, geo, nf, wsb
         ctx.has_res1, ctx.has_res2, ctx.has_bias = res1 is not None, res2 is not None, bias is not None
         if not has_bn:
             assert res1 is None and res2 is None and cfg.act == ACT_NONE
@@ -114,20 +143,22 @@ class _ConvBNAct(torch.autograd.Function):
             else:
                 ctx.save_for_backward(x)
             return y
-        P = geo.out_pixels
+        P = geo.out_pixels                   # pixels of ONE frame
         sync = _sync_group(bn) if training else None
         if sync is not None:
+            assert nf == 1, 'SyncBatchNorm runs frame by frame (VMN.run switches the frame batching off)'
             P = P * sync[1]
-        ss, saved = (C.c_void_p(a) for a in bank.bn_slot(bn, training, P * cfg.unbias_mult))
+        ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training, P * cfg.unbias_mult)
+        ss, saved = C.c_void_p(ss_i), C.c_void_p(saved_i)
         if training:
-            groups = stats.numel() // (2 * K)
-            scratch = torch.empty(128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
+            groups = stats.numel() // (2 * K * nf)
+            scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
             if sync is None:
-                # running statistics / num_batches_tracked are updated after the window, in call order (frames run
-                # on concurrent streams; the EMA is order dependent): see WeightBank.flush_bn_counters
+                # running statistics / num_batches_tracked are updated after the window, in call order: see
+                # WeightBank.flush_bn_counters
                 L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
                        L.ptr(gamma), L.ptr(beta), None, None,
-                       float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), st)
+                       float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
             else:
                 # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size)
                 sums = torch.empty(2 * K, dtype=torch.float64, device=x.device)
@@ -136,24 +167,27 @@ class _ConvBNAct(torch.autograd.Function):
                 L.call('tcvom_bn_finalize_sums', L.ptr(sums), K, P, P * cfg.unbias_mult, L.ptr(gamma), L.ptr(beta),
                        float(bn.eps), ss, saved, st)
         else:
+            slot_stride = 0                  # eval: one (scale, shift) for all frames
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), ss, saved, st)
-        ctx.sync, ctx.ss, ctx.saved, ctx.window_id = sync, ss, saved, bank.window_id
-        z = torch.empty((N, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
+        ctx.sync, ctx.ss, ctx.saved, ctx.window_id, ctx.slot_stride = sync, ss, saved, bank.window_id, slot_stride
+        z = torch.empty((NT, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
-        L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0, st)
+        L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0,
+               nf, slot_stride, st)
         ctx.save_for_backward(x, y, gamma, r1)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        cfg, geo = ctx.cfg, ctx.geo
+        cfg, geo, nf = ctx.cfg, ctx.geo, ctx.nf
         spec, bank = cfg.spec, cfg.bank
         st = L.stream_ptr()
         K = spec.K
         dz = _c(dz)
         dgamma = dbeta = dbias = dres1 = None
+        P = geo.out_pixels
         if cfg.bn is None:
             if cfg.pre_relu:
                 x, y = ctx.saved_tensors
@@ -164,26 +198,25 @@ class _ConvBNAct(torch.autograd.Function):
                 dy = dz
             if ctx.has_bias:
                 dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
-                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), geo.out_pixels, K, K, st)
+                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P * nf, K, K, st)
         else:
             x, y, gamma, r1 = ctx.saved_tensors
             if ctx.window_id != bank.window_id:
                 raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not '
                                    'supported (the per-window BatchNorm / weight arenas were reused)' % spec.name)
-            ss, saved = ctx.ss, ctx.saved
-            P = geo.out_pixels
+            ss, saved, stride = ctx.ss, ctx.saved, ctx.slot_stride
             groups = L.call('tcvom_bn_bwd_groups', P, K)
-            partial = torch.empty(groups * 2 * K, dtype=torch.float32, device=dz.device)
+            partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
             yf = 1 if y.dtype == torch.float32 else 0
-            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), P, K, cfg.act, yf, st)
+            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, st)
             # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
             dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
-            coef = torch.empty(3 * K, dtype=torch.float32, device=dz.device)
-            scratch = torch.empty(128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
+            coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
+            scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
             sync = ctx.sync if ctx.training else None
             if sync is None:
                 L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
-                       L.ptr(coef), L.ptr(scratch), 1, st)
+                       L.ptr(coef), L.ptr(scratch), 1, nf, stride, st)
             else:
                 group, world = sync
                 local = torch.empty(2 * K, dtype=torch.float64, device=dz.device)
@@ -196,18 +229,18 @@ class _ConvBNAct(torch.autograd.Function):
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)
             L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
-                   L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, yf, st)
+                   L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
             if ctx.has_bias:
                 # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
                 # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
                 dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
-                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P, K, K, st)
+                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P * nf, K, K, st)
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
-            dx = torch.empty((geo.N, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
-            _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st)
-        # the weight gradient is deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
-        bank.defer_wgrad(spec, ctx.call, dy, x, geo)
+            dx = torch.empty((geo.N * nf, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
+            _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st, nf, ctx.wsb)
+        # the weight gradients are deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
+        bank.defer_wgrad(spec, ctx.call, dy, x, geo, nf)
         dres2 = dz if ctx.has_res2 else None
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None
 

@@ -69,6 +69,7 @@ class VMN(nn.Module):
         self.decoder = decoder
         self.freeze_backbone = freeze_backbone
         self.frame_streams = True
+        self.batched_frames = True          # push the S frames through every layer together (one launch per layer)
         object.__setattr__(self, '_bank', bank)
         object.__setattr__(self, '_streams', [])
 
@@ -85,6 +86,10 @@ class VMN(nn.Module):
         S = len(frames_x8)
         training = self.training
         token = bank_token(self._bank, S, training)
+        sync_bn = training and any(getattr(bn, 'sync', False) for bn in self._bank.bns) and \
+            torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if self.batched_frames and not sync_bn:
+            return self._run_batched(frames_x8, unk_u8, token, training)
         mids, feats = [None] * S, [None] * S
         # The encoder + decoder-front of the S frames are independent (VMN_model.py:93-98 loops over them): each frame
         # runs on its own HIP stream so that the small-grid os16/os32 kernels of different frames overlap; autograd
@@ -112,6 +117,33 @@ class VMN(nn.Module):
             preds[i], attb[i], attf[i] = self.decoder.run_tail(feats[i], feats[i - 1], feats[i + 1], unk_u8[i],
                                                                mids[i], token, training)
         self._bank.flush_bn_counters()
+        return preds, attb, attf
+
+    def _run_batched(self, frames_x8, unk_u8, token, training):
+        """The S frames as ONE frame-major batch [S*B, ...]: every encoder / decoder-front layer is a single launch for
+        all frames (each frame keeps its own SpectralNorm call slot and BatchNorm statistics, ops._ConvBNAct), the
+        decoder tail a single launch for the S-2 interior frames.  3x fewer, 3x larger launches than frame-by-frame."""
+        S = len(frames_x8)
+        B = frames_x8[0].shape[0]
+        bank = self._bank
+        X = torch.cat(frames_x8, 0) if S > 1 else frames_x8[0]
+        U = torch.cat(unk_u8, 0) if S > 1 else unk_u8[0]
+        try:
+            bank.frames_per_op = S
+            emb, mid = self.encoder.run(X, U, token, training)
+            feat = self.decoder.run_front(emb, mid, token, training)
+            bank.frames_per_op = S - 2
+            lo, hi = B, (S - 1) * B                               # the interior frames 1 .. S-2
+            mid_c = {'shortcut': tuple(t[lo:hi] for t in mid['shortcut']), 'image_fea': mid['image_fea'][lo:hi],
+                     'unknown': U[lo:hi]}
+            pred, ab, af = self.decoder.run_tail(feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B], U[lo:hi], mid_c, token, training)
+        finally:
+            bank.frames_per_op = 1
+        preds, attb, attf = [None] * S, [None] * S, [None] * S
+        for i in range(1, S - 1):
+            sl = slice((i - 1) * B, i * B)
+            preds[i], attb[i], attf[i] = pred[sl], ab[sl], af[sl]
+        bank.flush_bn_counters()
         return preds, attb, attf
 
     def forward(self, images, masks, extras=None):

@@ -59,6 +59,7 @@ class WeightBank(object):
         self.max_calls = 0
         self.bns, self.bn_ch, self._bn_sig, self._bn_cap = [], 0, None, 0
         self.bn_mask, self.window_id = [], 0
+        self.frames_per_op = 1              # >1 while VMN.run pushes the S frames of a window through the layers together
         self._deferred = []
 
     # ------------------------------------------------------------------ BatchNorm bookkeeping
@@ -97,18 +98,22 @@ class WeightBank(object):
         n = len(self.bns)
         self.bn_calls, self.bn_mask, self.bn_unbias, self.bn_touched = [0] * n, [0] * n, [1.0] * n, [False] * n
 
-    def bn_slot(self, bn, training, unbias_count):
-        """Device addresses of the (scale, shift) and (mean, invstd) vectors of this call of `bn`."""
+    def bn_slots(self, bn, nf, training, unbias_count):
+        """Device addresses of the (scale, shift) and (mean, invstd) vectors of the next `nf` calls (frames) of `bn`
+        and the float stride between consecutive calls' vectors."""
         idx = bn._tcvom_bank_idx
         c = self.bn_calls[idx]
-        if c >= self._bn_cap:
-            raise RuntimeError('BatchNorm called %d times in one window (bank prepared for %d frames)' % (c + 1, self._bn_cap))
-        self.bn_calls[idx] = c + 1
+        if c + nf > self._bn_cap:
+            raise RuntimeError('BatchNorm called %d times in one window (bank prepared for %d frames)' % (c + nf, self._bn_cap))
+        self.bn_calls[idx] = c + nf
         if training:
-            self.bn_mask[idx] |= 1 << c
+            self.bn_mask[idx] |= ((1 << nf) - 1) << c
             self.bn_unbias[idx] = unbias_count / (unbias_count - 1.0) if unbias_count > 1 else 1.0
         base = self._bn_arena_ptr + 4 * (c * 4 * self.bn_ch + 4 * bn._tcvom_ch_off)
-        return base, base + 8 * bn.num_features
+        return base, base + 8 * bn.num_features, 4 * self.bn_ch
+
+    def bn_slot(self, bn, training, unbias_count):
+        return self.bn_slots(bn, 1, training, unbias_count)[:2]
 
     def bn_grad_ptrs(self, bn):
         self.bn_touched[bn._tcvom_bank_idx] = True
@@ -331,10 +336,19 @@ class WeightBank(object):
 
     def next_call(self, spec):
         """Call slot of this use of `spec` within the current window."""
+        return self.next_calls(spec, 1)[0]
+
+    def next_calls(self, spec, nf):
+        """`nf` consecutive call slots (the frames of a frame-batched op): (first slot, element stride between the
+        frames' forward weight copies, ... data-gradient copies); strides are 0 when all frames share one copy
+        (eval mode, layers without SpectralNorm)."""
         n = self.current_plan['ncalls'][spec.layer_id]
         c = self.call_counter[spec.layer_id]
-        self.call_counter[spec.layer_id] = c + 1
-        return min(c, n - 1) if n == 1 else c
+        self.call_counter[spec.layer_id] = c + nf
+        if n == 1:
+            return 0, 0, 0
+        assert c + nf <= n, 'layer %s: call %d of %d in this window' % (spec.name, c + nf, n)
+        return c, (self.fwd_stride if nf > 1 else 0), (self.bwd_stride if nf > 1 else 0)
 
     def fwd_ptr(self, spec, call):
         return C.c_void_p(self.fwd_arena.data_ptr() + 2 * (call * self.fwd_stride + spec.fwd_off))
@@ -346,11 +360,15 @@ class WeightBank(object):
         return C.c_void_p(self.dw_arena.data_ptr() + 4 * (call * self.dw_stride + spec.dw_off))
 
     # ------------------------------------------------------------------ deferred weight gradients
-    def defer_wgrad(self, spec, call, dy, x, geo):
-        """Queue dW~[call] += dy^T * im2col(x) of one conv call.  All calls of a layer in a window have the same shape,
-        so `run_deferred_wgrads` issues them as one batched launch: 3x the workgroups per launch means the pixel
-        reduction is split 3x less (3x fewer atomic partial sums) and 3x fewer launches."""
-        self._deferred.append((spec, call, dy, x, geo, torch.cuda.current_stream()))
+    def defer_wgrad(self, spec, call, dy, x, geo, nf=1):
+        """Queue dW~[call + f] += dy_f^T * im2col(x_f) for the nf frames of a conv call.  All calls of a layer in a
+        window have the same shape, so `run_deferred_wgrads` issues them as one batched launch: 3x the workgroups per
+        launch means the pixel reduction is split 3x less (3x fewer atomic partial sums) and 3x fewer launches."""
+        n = self.current_plan['ncalls'][spec.layer_id]
+        st = torch.cuda.current_stream()
+        dyb, xb = dy.numel() // nf * dy.element_size(), x.numel() // nf * x.element_size()
+        for f in range(nf):
+            self._deferred.append((spec, (call + f) if n > 1 else 0, dy, x, geo, st, f * dyb, f * xb))
 
     def run_deferred_wgrads(self):
         from .ops import _phase_array
@@ -371,8 +389,8 @@ class WeightBank(object):
             for i in range(0, len(items), 8):
                 part = items[i:i + 8]
                 n = len(part)
-                dys = (C.c_void_p * n)(*[e[2].data_ptr() for e in part])
-                xs = (C.c_void_p * n)(*[e[3].data_ptr() for e in part])
+                dys = (C.c_void_p * n)(*[e[2].data_ptr() + e[6] for e in part])
+                xs = (C.c_void_p * n)(*[e[3].data_ptr() + e[7] for e in part])
                 dws = (C.c_void_p * n)(*[self.dw_ptr(spec, e[1]).value for e in part])
                 L.call('tcvom_wgrad_igemm_batched', C.cast(dys, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(dws, C.c_void_p), n,
                        arr, len(geo.wgrad), spec.K, st)
