@@ -215,6 +215,67 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     ck.done()
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W,hp', [(64, 128, 3, 2, False, 24, 40, False), (128, 64, 4, 2, True, 12, 20, False),
+                                                                  (32, 32, 3, 1, False, 16, 64, True), (256, 256, 1, 1, False, 10, 12, False)])
+def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, transposed, H, W, hp):
+    """Three frames through a SpectralNorm'd conv + BatchNorm + ReLU as ONE frame-batched op (bank.frames_per_op = 3: per-frame
+    weight slot, per-frame batch statistics, batched data gradient, deferred batched weight gradient) must equal three
+    frame-by-frame ops on the same bank state: outputs and input gradients bit for bit (same kernels, same tiles may differ
+    -> compared to bf16 precision), parameter gradients and running statistics to fp32 summation order."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    S, B = 3, 2
+    pad = 0 if k == 1 else 1
+
+    def run(batched):
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        tag = 'fb%d_%d_%d' % (cin, cout, k)
+        w = nn.Parameter(formula_tensor('conv.%s.weight' % tag, shape).to(DEV))
+        u = nn.Parameter(formula_tensor('conv.%s.weight_u' % tag, (shape[0],)).to(DEV), requires_grad=False)
+        v = nn.Parameter(formula_tensor('conv.%s.weight_v' % tag, (int(np.prod(shape[1:])),)).to(DEV), requires_grad=False)
+        bank = WeightBank()
+        spec = ConvSpec(tag, w, u, v, None, transposed, stride, pad, 'frame', hp=hp)
+        bank.register(spec)
+        bn = nn.BatchNorm2d(cout).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(formula_tensor('bn.weight', (cout,)))
+            bn.bias.copy_(formula_tensor('bn.bias', (cout,)))
+        cfg = ops.ConvCfg(bank, spec, bn=bn, act=1)
+        xs = [nhwc(hu('x%d.%s' % (f, tag), (B, cin, H, W)) * (1.0 + 0.5 * f)) for f in range(S)]
+        token = bank_token(bank, S, True)
+        if batched:
+            xg = torch.cat(xs, 0).requires_grad_(True)
+            bank.frames_per_op = S
+            z = ops.conv_bn_act(cfg, xg, token, True)
+            bank.frames_per_op = 1
+            zs = [z[f * B:(f + 1) * B] for f in range(S)]
+        else:
+            xl = [t.clone().requires_grad_(True) for t in xs]
+            zs = [ops.conv_bn_act(cfg, t, token, True) for t in xl]
+        bank.flush_bn_counters()
+        gz = [nhwc(hu('gz%d.%s' % (f, tag), (B, cout, zs[0].shape[1], zs[0].shape[2]))) for f in range(S)]
+        sum((a.float() * g.float()).sum() for a, g in zip(zs, gz)).backward()
+        torch.cuda.synchronize()
+        dx = [xg.grad[f * B:(f + 1) * B] for f in range(S)] if batched else [t.grad for t in xl]
+        return ([t.detach().float().cpu() for t in zs], [t.float().cpu() for t in dx], w.grad.cpu(), bn.weight.grad.cpu(),
+                bn.bias.grad.cpu(), bn.running_mean.cpu(), bn.running_var.cpu(), u.detach().cpu().clone(), int(bn.num_batches_tracked))
+
+    a, b = run(True), run(False)
+    ck = Checker()
+    for f in range(S):
+        ck.rel('z[%d]' % f, a[0][f], b[0][f], 1e-2)
+        ck.rel('dx[%d]' % f, a[1][f], b[1][f], 2e-2)
+    ck.rel('dw', a[2], b[2], 1e-2)
+    ck.rel('dgamma', a[3], b[3], 1e-2)
+    ck.rel('dbeta', a[4], b[4], 1e-2)
+    ck.rel('running_mean', a[5], b[5], 2e-4)          # different tile -> different fp32 order of the partial sums
+    ck.rel('running_var', a[6], b[6], 2e-4)
+    ck.rel('u', a[7], b[7], 1e-6)
+    ck.done()
+    assert a[8] == b[8] == S
+    assert not torch.allclose(a[0][0], a[0][1])
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [(128, 128, 3, 1, False, 40, 64), (64, 64, 4, 2, True, 20, 24),
                                                                (32, 64, 3, 2, False, 48, 64)])
 def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
