@@ -27,14 +27,14 @@ GFLOP_FWD_GCA_1080P = 2106.3       # 6 guided-contextual-attention calls, forwar
 GFLOP_WINDOW_1080P = 11179.81      # forward + backward
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 FULL_H, FULL_W = 1088, 1920
-# HBM bytes per launch of the igemm instantiations, from the rocprofv3 PMC passes in profiles/r01_e_hbm_traffic_pmc_final.md
+# HBM bytes per launch of the igemm instantiations, from the rocprofv3 PMC passes in profiles/r01_g_hbm_traffic_pmc_batched.md
 # (FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script; fetch side doubled per MI355X_MICROARCH.md's gfx950
 # correction; averaged over all launches of the instantiation in a 1080p step).  bench.py cannot run rocprofv3 on itself,
 # so the figure of the kernel that turns out dominant is quoted from that committed measurement.
 PMC_TRAFFIC_BYTES = {
-    'igemm_tt<128,128,64,32,1>': (142.25 + 25.56) * 2 ** 20,
-    'igemm_nt<256,256,128,64,2>': (289.10 + 233.79) * 2 ** 20,
-    'igemm_nt<128,64,32,32,3>': (27.85 + 10.87) * 2 ** 20,
+    'igemm_tt<128,128,64,32,1>': (310.74 + 29.26) * 2 ** 20,
+    'igemm_nt<256,256,128,64,2>': (664.34 + 576.68) * 2 ** 20,
+    'igemm_nt<128,128,64,32,2>': (77.40 + 39.20) * 2 ** 20,
 }
 
 
