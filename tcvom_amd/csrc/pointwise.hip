@@ -186,6 +186,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16raw* __restric
     }
 }
 
+// 16-byte variant (ldi, ldo multiples of 8, 16-byte aligned bases): 64x64 tiles, uint4 global loads and stores, the
+// transposition happens in the LDS read (8 two-byte reads per output chunk).  2.5 -> ~5 TB/s on the 134 MB attention
+// matrices of the GCA backward.
+__global__ __launch_bounds__(256) void transpose_v8_kernel(const bf16raw* __restrict__ in, bf16raw* __restrict__ out,
+                                                           int R, int Cc, int64_t ldi, int64_t ldo,
+                                                           int64_t in_bstride, int64_t out_bstride) {
+    __shared__ bf16raw tile[64][72];
+    in += blockIdx.z * in_bstride;
+    out += blockIdx.z * out_bstride;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t8 = threadIdx.x & 7, tr = threadIdx.x >> 3;           // 8 chunks x 32 rows per pass
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = tr + 32 * i, rr = r0 + r, cc = c0 + t8 * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (rr < R && cc + 8 <= Cc) v = *reinterpret_cast<const uint4*>(in + (int64_t)rr * ldi + cc);
+        else if (rr < R && cc < Cc) {
+            bf16raw tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tmp[k] = cc + k < Cc ? in[(int64_t)rr * ldi + cc + k] : (bf16raw)0;
+            v = *reinterpret_cast<uint4*>(tmp);
+        }
+        *reinterpret_cast<uint4*>(&tile[r][t8 * 8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tr + 32 * i, cc = c0 + c, rr = r0 + t8 * 8;      // output row cc, output columns rr .. rr+7
+        if (cc < Cc && rr < ldo) {
+            bf16raw tmp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tmp[k] = tile[t8 * 8 + k][c];    // rows >= R were loaded as zeros
+            *reinterpret_cast<uint4*>(out + (int64_t)cc * ldo + rr) = *reinterpret_cast<uint4*>(tmp);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- final conv C->1 (KS x KS, pad KS/2, bias) + output map
 // MODE 0: alpha = (tanh(pre) + 1) / 2   (GCA decoder head, resnet_dec.py:139-141; KS = 3)
 // MODE 1: alpha = clamp(pre, 0, 1)      (DIM alpha_pred, models/DIM/vggnet.py:76,123; KS = 5)
@@ -434,8 +471,14 @@ extern "C" int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_
                                     int32_t batch, int64_t in_bstride, int64_t out_bstride, void* stream) {
     TCVOM_CHECK_ARG(in && out && R > 0 && Cc > 0 && ldi >= Cc && ldo >= R, "transpose_bf16: bad args");
     dim3 grid(cdiv(Cc, 64), cdiv(ldo, 64), batch > 1 ? batch : 1);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, R, Cc,
-                       ldi, ldo, in_bstride, out_bstride);
+    const bool v8 = ldi % 8 == 0 && ldo % 8 == 0 && in_bstride % 8 == 0 && out_bstride % 8 == 0 &&
+                    ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    if (v8)
+        hipLaunchKernelGGL(transpose_v8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, R, Cc,
+                           ldi, ldo, in_bstride, out_bstride);
+    else
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, R, Cc,
+                           ldi, ldo, in_bstride, out_bstride);
     TCVOM_LAUNCH_CHECK("transpose_bf16");
     return TCVOM_OK;
 }

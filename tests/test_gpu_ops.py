@@ -350,6 +350,19 @@ def test_halo_conv_kernel(cin, cout, hp, N, H, W):
 
 
 # --------------------------------------------------------------------------------------------- spectral norm
+@pytest.mark.parametrize('R,Cc,ldi,ldo,batch', [(200, 130, 136, 256, 2), (70, 64, 64, 72, 1), (33, 50, 50, 35, 3), (4100, 576, 576, 4160, 1)])
+def test_transpose_bf16(R, Cc, ldi, ldo, batch):
+    """in [batch][R][ldi] (first Cc columns) -> out [batch][Cc][ldo] (columns >= R zero): the 16-byte kernel (aligned strides)
+    and the scalar fallback (odd strides), bit exact."""
+    from tcvom_amd import _lib as L
+    x = hu('tr.x', (batch, R, ldi)).to(DEV).to(torch.bfloat16)
+    out = torch.full((batch, Cc, ldo), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.call('tcvom_transpose_bf16', L.ptr(x), L.ptr(out), R, Cc, ldi, ldo, batch, R * ldi, Cc * ldo, L.stream_ptr())
+    ref = torch.zeros((batch, Cc, ldo), dtype=torch.bfloat16, device=DEV)
+    ref[:, :, :R] = x[:, :, :Cc].transpose(1, 2)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize('ncols', [8160, 2040, 3000, 250])
 def test_row_softmax_kernels(ncols):
     """GCA attention softmax forward / backward rows at the 1080p length (8160 keys: 4 register chunks) and shorter / ragged
