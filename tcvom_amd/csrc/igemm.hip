@@ -4,8 +4,13 @@
 //              (conv fwd, data-gradient via re-packed weights, transposed-conv phases, 1x1,
 //               and with ntaps==1 a dense  C^T[n][m] = sum_k A[m][k] B[n][k]  GEMM)
 //   igemm_tt : dw[k][tap][c] += sum_pixel dy[pixel][k] * in[gather(pixel,tap)][c]
-//              (weight gradient; both operands are pixel-major, so 8x8 blocks are transposed
-//               in registers on their way to LDS; with ntaps==1 a dense "TT" GEMM)
+//              (weight gradient; both operands are pixel-major: tiles are DMA'd as they lie and the
+//               k-contiguous MFMA fragments come from the LDS transpose read ds_read_b64_tr_b16;
+//               with ntaps==1 a dense "TT" GEMM; up to 8 same-shape problems per launch)
+//   Descriptors with batch > 1 run `batch` independent problems per launch (the dense GEMMs of GCA, and
+//   the S frames of a window through one layer with a per-frame weight copy); up to 4 phase descriptors
+//   (sub-pixel phases of a ConvTranspose / stride-2 data gradient) share a launch as well.  Shapes served
+//   by the halo-tile direct conv (halo.hip) are dispatched from conv_igemm_launch.
 //
 // MFMA roles: rows (M) = output channels, columns (N) = pixels, so that a lane's 4 consecutive
 // accumulator registers are 4 consecutive channels of ONE pixel -> 8-byte NHWC stores, and the
@@ -16,9 +21,9 @@
 struct TcvomPhases { tcvom_conv_desc d[4]; int n; };
 
 
-// igemm_nt main loop (v2): 64-deep k-steps, operands DMA'd global->LDS with global_load_lds_dwordx4
-// (no VGPR round trip), 2-slot LDS ring, ONE barrier per k-step:
-//     vmcnt(0); barrier;  issue DMA of step s+1 into the other slot;  16 MFMAs/wave on step s
+// igemm_nt main loop: 64-deep k-steps, operands DMA'd global->LDS with global_load_lds_dwordx4
+// (no VGPR round trip), NST-slot LDS ring (2..4), ONE barrier per k-step:
+//     vmcnt(stages still in flight); barrier;  issue DMA of step s+NST-1;  MFMAs on step s
 // LDS rows are 128 B (64 bf16) and unpadded (the DMA writes 1 KiB = 8 rows per wave-instruction, lane-linear), so
 // bank conflicts are removed by an XOR swizzle applied on the SOURCE side: LDS 16-byte slot `cpos` of row r holds
 // k-chunk cpos ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows covering all residues mod 16) then touches 16
