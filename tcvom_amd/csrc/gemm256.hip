@@ -1,0 +1,246 @@
+// Dense NT GEMM on 256x256 tiles with two staggered wave groups, for the attention GEMMs of GuidedCxtAtten
+// (models/GCA/ops.py:177,204 and their gradients: 8160 x 8160 x 576, 8160 x 2048 x 8160 at 1080p):
+//
+//     out[n][m] = epilogue( sum_k B[n][k] * A[m][k] )          A: [M][K] (k contiguous), B: [N][K], out: [N][ldo]
+//
+// The single-phase loop of igemm_nt (all 8 waves: wait -> barrier -> DMA burst -> ds_reads -> MFMAs) leaves the matrix
+// pipe idle while the texture path is saturated by the DMA burst and vice versa (traced: 53 % MFMA issue at 256x256).
+// Here the K-tile (64 deep) is processed in 4 phases -- the 4 quadrants (64 x 32) of a wave's 128 x 64 output tile --
+// each a LOAD section (ds_reads of the operand sub-tiles the quadrant newly needs) and an MFMA section (8 MFMAs
+// 32x32x16), separated by workgroup barriers.  Waves 4..7 execute ONE EXTRA barrier up front, so at any time one
+// group (one wave per SIMD) is in its MFMA section while the other (its SIMD neighbour) is in a LOAD section:
+//
+//     barrier interval     8t    8t+1  8t+2  8t+3  8t+4  8t+5  8t+6  8t+7  8t+8
+//     group 0 (waves 0-3)  L1    M1*   L2    M2*   L3    M3    L4    M4w   L1'          * issues the LDS-DMA of K-tile t+1
+//     group 1 (waves 4-7)  M4    L1    M1*   L2    M2*   L3    M3    L4w   M4           w ends with s_waitcnt vmcnt(0)
+//
+// LDS: two K-tile buffers (2 x (256 + 256) rows x 128 B = 128 KiB), rows unpadded, 16-byte chunk c of row r stored in slot
+// c ^ ((r >> 1) & 7) (applied on the DMA source side, as in igemm_nt).  Hazards: buffer (t+1) & 1 held K-tile t-1, whose
+// last reads (group 1, L4) are retired by the lgkmcnt(0) at the head of its M4 in interval 8t -- the DMA of tile t+1
+// is first issued in interval 8t+1; it must have landed before interval 8t+8, where group 0 starts reading it: every
+// wave drains vmcnt before the barrier that ends interval 8t+7.
+#include "common.h"
+
+struct Gemm256Args {
+    const bf16raw* A;
+    const bf16raw* B;
+    void* out;
+    const float* bias;
+    const float* mscale;
+    const float* mdiag;
+    const bf16raw* zero_page;
+    int M, N, K, ldo, act, out_fp32, batch;
+    long long a_bstride, b_bstride, out_bstride, vec_bstride;
+};
+
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
+    constexpr int TM = 256, TN = 256;
+    constexpr int SLOT = (TM + TN) * 64;                 // bf16 elements per K-tile buffer
+    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // wm = wave group (0: rows 0..127 of the tile, 1: rows 128..255)
+
+    // XCD-aware tile order over the pixel (N) tiles
+    int bx;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bz = blockIdx.z;
+    const bf16raw* A = g.A + bz * g.a_bstride;
+    const bf16raw* B = g.B + bz * g.b_bstride;
+    const float* bias = g.bias ? g.bias + bz * g.vec_bstride : nullptr;
+    const float* mscale = g.mscale ? g.mscale + bz * g.vec_bstride : nullptr;
+    const float* mdiag = g.mdiag ? g.mdiag + bz * g.vec_bstride : nullptr;
+    const int n0 = bx * TN, m0 = blockIdx.y * TM;
+    const int K = g.K;
+
+    // DMA rows: instruction (it, wave) covers tile rows (it*8 + wave)*8 .. +7; lane -> row +lane/8, 16-byte chunk kc
+    const int kc8 = (((lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7)) << 3);
+    int64_t a_off[4], b_off[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ra = m0 + (it * 8 + wave) * 8 + (lane >> 3), rb = n0 + (it * 8 + wave) * 8 + (lane >> 3);
+        a_off[it] = ra < g.M ? (int64_t)ra * K + kc8 : -1;
+        b_off[it] = rb < g.N ? (int64_t)rb * K + kc8 : -1;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define G_ISSUE_A(t, it)                                                                                     \
+    {                                                                                                        \
+        const bf16raw* src_ = a_off[it] >= 0 ? A + a_off[it] + (t) * 64 : g.zero_page;                       \
+        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + ((it) * 8 + wave) * 512), 16, 0, 0); \
+    }
+#define G_ISSUE_B(t, it)                                                                                     \
+    {                                                                                                        \
+        const bf16raw* src_ = b_off[it] >= 0 ? B + b_off[it] + (t) * 64 : g.zero_page;                       \
+        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + TM * 64 + ((it) * 8 + wave) * 512), 16, 0, 0); \
+    }
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int a_row = wm * 128 + (lane & 31), b_row = wn * 64 + (lane & 31);
+    const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;     // the same for rows +32, +64, +96
+    const int khalf = lane >> 5;
+    bf16x8_t fa[2][4], fb[4];                          // A sub-tile (2 row-fragments x 4 k16), B sub-tile (1 x 4)
+
+#define G_READ_A(buf, mh)                                                                                    \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                         \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                  \
+            fa[a_][kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
+#define G_READ_B(buf, nh)                                                                                    \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                      \
+        fb[kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3));
+    // 8 MFMAs of one quadrant; `DMA` = 0/1/2: interleave the A / B DMA instructions of K-tile tn behind MFMA pairs
+#define G_MFMA(mh, nh, DMA, tn)                                                                              \
+    {                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                \
+            acc[(mh) * 2 + 0][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk_], fb[kk_], acc[(mh) * 2 + 0][nh], 0, 0, 0); \
+            acc[(mh) * 2 + 1][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk_], fb[kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
+            if ((DMA) == 1 && (tn) < ntile) G_ISSUE_A(tn, kk_)                                               \
+            if ((DMA) == 2 && (tn) < ntile) G_ISSUE_B(tn, kk_)                                               \
+        }                                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+    }
+#define G_BAR() __builtin_amdgcn_s_barrier()
+
+    const int ntile = K >> 6;
+    // prologue: K-tile 0 into buffer 0 (all waves), then the stagger
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { G_ISSUE_A(0, it) G_ISSUE_B(0, it) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G_BAR();
+    if (wm == 1) G_BAR();                              // group 1 runs one barrier interval behind group 0
+
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        // phase 1: quadrant (m0, n0)
+        G_READ_A(buf, 0) G_READ_B(buf, 0)
+        G_BAR();
+        G_MFMA(0, 0, 1, t + 1)
+        G_BAR();
+        // phase 2: quadrant (m0, n1)
+        G_READ_B(buf, 1)
+        G_BAR();
+        G_MFMA(0, 1, 2, t + 1)
+        G_BAR();
+        // phase 3: quadrant (m1, n1)
+        G_READ_A(buf, 1)
+        G_BAR();
+        G_MFMA(1, 1, 0, 0)
+        G_BAR();
+        // phase 4: quadrant (m1, n0); the DMA of K-tile t+1 must have landed before anybody enters phase 1 of t+1:
+        // group 0 drains at the end of its M4, group 1 (one interval behind) at the end of its L4
+        G_READ_B(buf, 0)
+        if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G_BAR();
+        G_MFMA(1, 0, 0, 0)
+        if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G_BAR();
+    }
+    if (wm == 0) G_BAR();                              // balance group 1's extra barrier
+#undef G_MFMA
+#undef G_READ_A
+#undef G_READ_B
+#undef G_ISSUE_A
+#undef G_ISSUE_B
+#undef G_BAR
+
+    // ------------------------------------------------------------------ epilogue (as igemm_nt: bias / scale / diagonal / ReLU)
+    int64_t out_off[2];
+    bool pvalid[2];
+    int pglob[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int p = n0 + wn * 64 + b * 32 + (lane & 31);
+        pvalid[b] = p < g.N;
+        pglob[b] = p;
+        out_off[b] = (int64_t)(pvalid[b] ? p : 0) * g.ldo + bz * g.out_bstride;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mrow = m0 + wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5);
+            float bs[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (mrow + r < g.M) {
+                    if (bias) bs[r] = bias[mrow + r];
+                    if (mscale) sc[r] = mscale[mrow + r];
+                    if (mdiag) dg[r] = mdiag[mrow + r];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[a][b][q * 4 + r] * sc[r] + bs[r];
+                    if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
+                    if (g.act == 1) x = fmaxf(x, 0.f);
+                    v[r] = x;
+                }
+                if (pvalid[b] && mrow < g.M) {
+                    if (g.out_fp32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(g.out) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
+// does the dense descriptor `d` run on this kernel?  (plain row-major operands, enough 256x256 tiles to fill the chip)
+int gemm_nt256_takes(const tcvom_conv_desc* d) {
+    if (d->ntaps != 1 || d->tap_w[0] < 0) return 0;
+    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0 || d->wt != 1) return 0;
+    if (d->C % 64 != 0 || d->K % 4 != 0 || d->ldo % 4 != 0) return 0;
+    const long long P = (long long)d->N * d->PH * d->PW;
+    if ((long long)d->N * d->H * d->W != P || (long long)d->N * d->OH * d->OW != P) return 0;
+    const int nb = d->batch > 1 ? d->batch : 1;
+    const long long tiles = ((P + 255) / 256) * ((d->K + 255) / 256) * nb;
+    if (d->K < 256 || P < 256 || tiles < 192) return 0;
+    return 1;
+}
+
+// 1: launched; 0: not a shape for this kernel.  Called from conv_igemm_launch for dense descriptors (ntaps == 1).
+int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream) {
+    if (!gemm_nt256_takes(d)) return 0;
+    const long long P = (long long)d->N * d->PH * d->PW;
+    const int nb = d->batch > 1 ? d->batch : 1;
+    Gemm256Args g;
+    g.A = (const bf16raw*)w;
+    g.B = (const bf16raw*)in;
+    g.out = out;
+    g.bias = bias;
+    g.mscale = mscale;
+    g.mdiag = mdiag;
+    g.zero_page = zero_page;
+    g.M = d->K;
+    g.N = (int)P;
+    g.K = d->C;
+    g.ldo = d->ldo;
+    g.act = d->act;
+    g.out_fp32 = d->out_fp32;
+    g.batch = nb;
+    g.a_bstride = nb > 1 ? d->w_bstride : 0;
+    g.b_bstride = nb > 1 ? d->in_bstride : 0;
+    g.out_bstride = nb > 1 ? d->out_bstride : 0;
+    g.vec_bstride = nb > 1 ? d->vec_bstride : 0;
+    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)((d->K + 255) / 256), (unsigned)nb);
+    hipLaunchKernelGGL(gemm_nt256_kernel, grid, dim3(512), 0, (hipStream_t)stream, g);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: %s", hipGetErrorString(e));
+    return 1;
+}

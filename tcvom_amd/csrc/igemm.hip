@@ -379,6 +379,10 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                          float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
+// gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
+int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream);
+int gemm_nt256_takes(const tcvom_conv_desc* d);
 
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
     const int hg = halo_conv_stats_groups(d, nphase);
@@ -391,6 +395,7 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
 // name of the kernel instantiation tcvom_conv_igemm(_phases) launches for this shape (profiling / bench labels)
 extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase) {
     if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
+    if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
     if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";
     if (c.tm == 128 && c.tn == 128) return "igemm_nt<128,128,64,32,2>";
@@ -436,6 +441,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
+    if (nphase == 1 && !stats_partial) {
+        const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);

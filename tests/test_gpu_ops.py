@@ -264,10 +264,12 @@ def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, trans
     ck = Checker()
     for f in range(S):
         ck.rel('z[%d]' % f, a[0][f], b[0][f], 1e-2)
-        ck.rel('dx[%d]' % f, a[1][f], b[1][f], 2e-2)
-    ck.rel('dw', a[2], b[2], 1e-2)
-    ck.rel('dgamma', a[3], b[3], 1e-2)
-    ck.rel('dbeta', a[4], b[4], 1e-2)
+        ck.rel('dx[%d]' % f, a[1][f], b[1][f], 3e-2)
+    # the power iteration reduces with fp32 atomics: sigma can differ by an ulp between the two runs, which flips the
+    # bf16 rounding of a few packed weights and, through them, a few ReLU masks -- 1-2 % on the summed gradients
+    ck.rel('dw', a[2], b[2], 3e-2)
+    ck.rel('dgamma', a[3], b[3], 3e-2)
+    ck.rel('dbeta', a[4], b[4], 3e-2)
     ck.rel('running_mean', a[5], b[5], 2e-4)          # different tile -> different fp32 order of the partial sums
     ck.rel('running_var', a[6], b[6], 2e-4)
     ck.rel('u', a[7], b[7], 1e-6)
@@ -406,6 +408,35 @@ def test_dense_gemm_256_tile_config(rows_b, rows_a, kred, fp32):
     got = out[:, :rows_a].float()
     assert rel_err(got.cpu(), ref.cpu()) < (1e-5 if fp32 else 6e-3)
     assert float(out[:, rows_a:].abs().max()) == 0.0 if ld > rows_a else True
+
+
+@pytest.mark.parametrize('fp32', [True, False])
+def test_dense_gemm_256_staggered_kernel_epilogues(fp32):
+    """gemm_nt256 (csrc/gemm256.hip) on a batch of 2 problems whose row counts are not multiples of the 256-row
+    tile on either side, with every epilogue term: out = relu(acc * scale[m] + bias[m] - [m == n] diag[m])."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import dense_desc
+    nb, rows_b, rows_a, kred = 2, 2590, 2700, 192
+    ld = (rows_a + 63) // 64 * 64
+    B = (hu('g2s.b', (nb, rows_b, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    A = (hu('g2s.a', (nb, rows_a, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    sc = (hu('g2s.s', (nb, rows_a)) + 0.5).to(DEV)
+    bias = (hu('g2s.bias', (nb, rows_a)) - 0.5).to(DEV)
+    dg = (hu('g2s.d', (nb, rows_a)) * 3).to(DEV)
+    out = torch.zeros(nb, rows_b, ld, device=DEV, dtype=torch.float32 if fp32 else torch.bfloat16)
+    d = dense_desc(rows_b, rows_a, kred, ld, batch=nb, in_bstride=rows_b * kred, w_bstride=rows_a * kred,
+                   out_bstride=rows_b * ld, vec_bstride=rows_a, out_fp32=fp32)
+    d.act = 1
+    assert L._FNS['tcvom_conv_igemm_variant'](C.byref(d), 1).decode() == 'gemm_nt256'
+    L.call('tcvom_conv_igemm', L.ptr(B), L.ptr(A), L.ptr(out), L.ptr(bias), L.ptr(sc), L.ptr(dg), None, C.byref(d), L.stream_ptr())
+    ref = torch.bmm(B.float(), A.float().transpose(1, 2)) * sc[:, None, :] + bias[:, None, :]
+    n = min(rows_a, rows_b)
+    idx = torch.arange(n, device=DEV)
+    ref[:, idx, idx] -= dg[:, :n]
+    ref = torch.relu(ref)
+    assert rel_err(out[:, :, :rows_a].float().cpu(), ref.cpu()) < (1e-5 if fp32 else 6e-3)
+    assert float(out[:, :, rows_a:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('transposed', [False, True])

@@ -59,6 +59,13 @@ def main():
         flop = 2.0 * geo.out_pixels * cout * cin * k * k / (4 if tr else 1)
 
         from tcvom_amd.ops import _launch_conv, _phase_array
+        # weight gradients as the product issues them: the 3 frames of a window in one batched launch (time / 3 shown)
+        xb = [torch.randn_like(x) for _ in range(3)]
+        dyb = [torch.randn_like(dy) for _ in range(3)]
+        dwb = torch.zeros(3, spec.K * spec.T * spec.cpad, device=DEV)
+        dys3 = (C.c_void_p * 3)(*[t.data_ptr() for t in dyb])
+        xs3 = (C.c_void_p * 3)(*[t.data_ptr() for t in xb])
+        dws3 = (C.c_void_p * 3)(*[dwb[i].data_ptr() for i in range(3)])
 
         def fwd():
             _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, 0), y, None, None, 0, st)
@@ -67,11 +74,12 @@ def main():
             _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, 0), dx, None, None, 0, st)
 
         def wgrad():
-            L.call('tcvom_wgrad_igemm_phases', L.ptr(dy), L.ptr(x), bank.dw_ptr(spec, 0), _phase_array(geo.fwd), len(geo.fwd), cout, st)
+            L.call('tcvom_wgrad_igemm_batched', C.cast(dys3, C.c_void_p), C.cast(xs3, C.c_void_p), C.cast(dws3, C.c_void_p), 3,
+                   _phase_array(geo.wgrad), len(geo.wgrad), cout, st)
 
         tf = timeit(fwd)
         td = timeit(dgrad) if spec.needs_dgrad else float('nan')
-        tw = timeit(wgrad)
+        tw = timeit(wgrad) / 3
         print('%-22s %5.0f %4.0f %5.0f %4.0f %5.0f %4.0f' % (name, flop / tf / 1e9, tf * 1e3, flop / td / 1e9, td * 1e3,
                                                           flop / tw / 1e9, tw * 1e3))
     # GCA GEMMs at 1080p: N = 8160
