@@ -42,21 +42,47 @@ def convert_sync_batchnorm(module, process_group=None):
 
 
 class GradientAverager(object):
-    """All-reduce(mean) of the gradients of `params` in flat buckets.  Parameters whose .grad is None on
-    this rank (unused in this step: DDP's find_unused_parameters=True case) contribute zeros."""
+    """All-reduce(mean) of the gradients of `params` (DDP's reduction, train_ddp.py:275-280).  Parameters whose
+    .grad is None on this rank (unused in this step: DDP's find_unused_parameters=True case) contribute zeros.
+
+    The weight bank hands autograd views of ONE flat fp32 buffer (WeightBank.backward) and the BatchNorm arenas do
+    the same, so most of the 25.6 M gradient elements already sit in a few contiguous spans: those are all-reduced
+    IN PLACE (no pack / unpack copies, no per-parameter kernels).  Whatever is left (biases, stray tensors) is
+    packed into flat buckets of `bucket_bytes`.  With RCCL the mean is taken by the collective (ReduceOp.AVG)."""
+
+    MIN_SPAN = 1 << 14           # elements; shorter runs are cheaper packed together than as their own collective
 
     def __init__(self, params, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
-        self.buckets, cur, size = [], [], 0
-        for p in self.params:
-            nbytes = p.numel() * p.element_size()
-            if cur and size + nbytes > bucket_bytes:
-                self.buckets.append(cur)
-                cur, size = [], 0
-            cur.append(p)
-            size += nbytes
-        if cur:
-            self.buckets.append(cur)
+        self.bucket_bytes = bucket_bytes
+        self.last_plan = None    # (elements reduced in place, number of spans, elements packed, number of buckets)
+
+    @staticmethod
+    def plan(grads, min_span):
+        """Split `grads` into (spans, rest): a span is (tensor list, storage, first element, element count) of
+        contiguous gradients lying back to back in one storage."""
+        keyed = {}
+        rest = []
+        for g in grads:
+            if g.is_contiguous() and g.numel() > 0:
+                keyed.setdefault((g.untyped_storage().data_ptr(), g.dtype, g.device), []).append(g)
+            else:
+                rest.append(g)
+        spans = []
+        for gs in keyed.values():
+            gs.sort(key=lambda t: t.storage_offset())
+            run = [gs[0]]
+            for g in gs[1:] + [None]:
+                if g is not None and g.storage_offset() == run[-1].storage_offset() + run[-1].numel():
+                    run.append(g)
+                    continue
+                n = run[-1].storage_offset() + run[-1].numel() - run[0].storage_offset()
+                if n >= min_span:
+                    spans.append((run, run[0].untyped_storage(), run[0].storage_offset(), n))
+                else:
+                    rest.extend(run)
+                run = [g]
+        return spans, rest
 
     def average(self):
         if not (dist.is_available() and dist.is_initialized()):
@@ -64,23 +90,36 @@ class GradientAverager(object):
         ws = dist.get_world_size()
         if ws < 2:
             return
+        avg = dist.get_backend() == 'nccl'
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        missing = [p for p in self.params if p.grad is None]
+        for p in missing:
+            p.grad = torch.zeros_like(p)
+        spans, rest = self.plan([p.grad for p in self.params], self.MIN_SPAN)
         works = []
-        for bucket in self.buckets:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            works.append((bucket, flat, dist.all_reduce(flat, async_op=True)))
-        for bucket, flat, work in works:
+        for run, storage, first, n in spans:
+            flat = run[0].new_empty(0).set_(storage, first, (n,))
+            works.append((flat, None, dist.all_reduce(flat, op=op, async_op=True)))
+        buckets, cur, size = [], [], 0
+        for g in rest:
+            nbytes = g.numel() * g.element_size()
+            if cur and (size + nbytes > self.bucket_bytes or g.dtype != cur[0].dtype):
+                buckets.append(cur)
+                cur, size = [], 0
+            cur.append(g)
+            size += nbytes
+        if cur:
+            buckets.append(cur)
+        for bucket in buckets:
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            works.append((flat, bucket, dist.all_reduce(flat, op=op, async_op=True)))
+        for flat, bucket, work in works:
             work.wait()
-            flat.div_(ws)
-            off = 0
-            for p in bucket:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += n
+            if not avg:
+                flat.div_(ws)
+            if bucket is not None:
+                torch._foreach_copy_(bucket, [t.view_as(g) for t, g in zip(flat.split([g.numel() for g in bucket]), bucket)])
+        self.last_plan = (sum(s[3] for s in spans), len(spans), sum(g.numel() for g in rest), len(buckets))
 
 
 def reduce_tensor(inp):

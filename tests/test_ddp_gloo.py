@@ -31,7 +31,15 @@ def _worker(rank, world, port, q):
     GradientAverager(params, bucket_bytes=64).average()     # tiny buckets -> several collectives
     grads = torch.cat([p.grad.reshape(-1) for p in params])
     loss = reduce_tensor(torch.tensor(float(rank)))
-    q.put((rank, flat_state, grads, float(loss)))
+    # gradients that are views of one flat buffer (what WeightBank.backward hands to autograd): reduced in place
+    ps = [nn.Parameter(torch.zeros(n)) for n in (6, 10, 4, 3)]
+    arena = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    ps[0].grad, ps[1].grad, ps[2].grad = arena[2:8], arena[8:18], arena[18:22]      # one run of 20 elements
+    ps[3].grad = arena[30:33]                                                         # short run -> packed bucket
+    av = GradientAverager(ps)
+    av.MIN_SPAN = 8
+    av.average()
+    q.put((rank, flat_state, grads, float(loss), arena.clone(), av.last_plan, [p.grad.data_ptr() - arena.data_ptr() for p in ps]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,7 +55,15 @@ def test_two_rank_gradient_average_and_broadcast():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, s0, g0, l0), (_, s1, g1, l1) = res
+    (_, s0, g0, l0, a0, plan0, offs0), (_, s1, g1, l1, a1, plan1, offs1) = res
+    base = torch.arange(40, dtype=torch.float32)
+    for arena, scale in ((a0, 1.0), (a1, 2.0)):
+        want = base * scale                               # outside the gradient views: untouched, rank-specific
+        want[2:22] = base[2:22] * 1.5
+        want[30:33] = base[30:33] * 1.5
+        assert torch.equal(arena, want)
+    assert plan0 == plan1 == (20, 1, 3, 1)
+    assert offs0 == offs1 == [8, 32, 72, 120]            # .grad still aliases the arena: no copies were made
     assert torch.equal(s0, s1), 'state must equal rank 0 after the broadcast'
     assert torch.equal(g0, g1), 'averaged gradients must agree on all ranks'
     net = nn.Sequential(nn.Linear(5, 7), nn.BatchNorm1d(7), nn.Linear(7, 3))
