@@ -15,6 +15,9 @@ formula-initialised weights/inputs and stores inputs' parameters + outputs in
 this package against those vectors.  The reference ships no tests or golden
 vectors of its own.
 
+`oracle.dim_net` (DIM base, config 1) and `oracle.fba_net` (FBA base + TAM, config 5) are imported explicitly
+by their tests; both are pinned the same way (tests/golden/dim_*.npz, fba_*.npz).
+
 Everything operates on a flat ``state`` dict that uses exactly the key layout
 of the reference's ``FullModel_VMD(...).NET.state_dict()`` (584 tensors for
 ``vmn_gca``) so identical weights can be fed to reference, oracle and product.

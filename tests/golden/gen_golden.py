@@ -303,6 +303,71 @@ def gen_dim():
         save(name, **arrs)
 
 
+# ----------------------------------------------------------------------------- FBA + TAM (BASELINE config 5)
+FBA_CASES = {
+    # name: (B, S, H, W, dilate_kernel)
+    'fba_s3_64x64': (1, 3, 64, 64, 3),
+    'fba_s5_64x96': (1, 5, 64, 96, 5),
+}
+FBA_FULL_GRADS = ('decoder.conv_up4.4.weight', 'decoder.conv_up4.4.bias', 'decoder.fam.query_conv.bias', 'encoder.bn1.weight',
+                  'decoder.conv_up3.1.weight', 'decoder.ppm.0.1.bias')
+
+
+def gen_fba():
+    for name, (B, S, H, W, dil) in FBA_CASES.items():
+        fm = ref_model.FullModel_VMD('vmn_fba', agg_window=7, dilate_kernel=dil)
+        fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
+        fm.train()
+        a, fg, bg = synthetic_window(B, S, H, W, seed=2)
+        out = fm(a, fg, bg)
+        loss = out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]        # train_ddp.py:56-61
+        loss.backward()
+        tris = fm.preprocess(a, fg, bg)[4]
+        arrs = {'losses': torch.stack([o.detach() for o in out[:5]]), 'alphas': out[7], 'comps': out[8], 'Fs': out[10],
+                'Bs': out[11], 'tris': tris.half(), 'tris_vis_sum': out[6].double().sum()}
+        names, norms = [], []
+        for k, p in fm.NET.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+        arrs['grad_names'] = np.array(names)
+        arrs['grad_norms'] = np.array(norms)
+        gd = dict(fm.NET.named_parameters())
+        for k in FBA_FULL_GRADS:
+            arrs['grad:' + k] = gd[k].grad
+        save(name, **arrs)
+    # op level: the FBA-only losses and the fusion, values and input gradients
+    x = (hu('fbaops.x', (2, 3, 64, 96)) * 0.5 + 0.5).requires_grad_(True)
+    y = (hu('fbaops.y', (2, 3, 64, 96)) * 0.5 + 0.5).requires_grad_(True)
+    al = (hu('fbaops.a', (2, 1, 64, 96)) * 0.6 + 0.5).clamp(0, 1).requires_grad_(True)
+    arrs = {}
+    lap = ref_loss.LapLoss()
+    for tag, fn in (('lap_norm', lambda: lap(x, y, normalize=True)), ('lap_sum', lambda: lap(x, y, normalize=False)),
+                    ('excl_norm', lambda: ref_loss.exclusion_loss(x, y, level=3, normalize=True)),
+                    ('excl_sum', lambda: ref_loss.exclusion_loss(x, y, level=3, normalize=False)),
+                    ('l1grad_norm', lambda: ref_loss.L1_grad(x, y, normalize=True)),
+                    ('l1grad_sum', lambda: ref_loss.L1_grad(x, y, normalize=False))):
+        x.grad = y.grad = None
+        v = fn()
+        v.backward()
+        arrs[tag] = v.detach()
+        for nm, g in ((':dx', x.grad), (':dy', y.grad)):              # every 3rd row / column + the L1 norm of all of it
+            arrs[tag + nm] = g[:, :, ::3, ::3].clone()
+            arrs[tag + nm + ':abs_sum'] = g.double().abs().sum()
+    import models.FBA.models as ref_fba
+    img = hu('fbaops.img', (2, 3, 64, 96)) * 0.5 + 0.5
+    x.grad = y.grad = None
+    fa, fF, fB = ref_fba.fba_fusion(al, img, x, y)
+    (fa.sum() + 2 * fF.sum() + 3 * fB.sum()).backward()
+    sub = lambda t: t[:, :, ::3, ::3]
+    arrs.update({'fusion:alpha': sub(fa), 'fusion:F': sub(fF), 'fusion:B': sub(fB), 'fusion:dalpha': sub(al.grad),
+                 'fusion:dF': sub(x.grad), 'fusion:dB': sub(y.grad),
+                 'fusion:sums': torch.stack([t.double().sum() for t in (fa, fF, fB, al.grad, x.grad, y.grad)])})
+    save('fba_ops', **arrs)
+    sd = ref_model.FullModel_VMD('vmn_fba', agg_window=7).NET.state_dict()
+    save('fba_state_keys', keys=np.array(list(sd.keys())),
+         shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))
+
+
 def gen_state_keys():
     dsd = ref_model.FullModel('dim').NET.state_dict()
     save('dim_state_keys', keys=np.array(list(dsd.keys())),
@@ -318,11 +383,7 @@ def gen_state_keys():
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    gen_state_keys()
-    gen_sn()
-    gen_tam()
-    gen_gca()
-    gen_facade()
-    gen_window()
-    gen_eval()
-    gen_dim()
+    only = sys.argv[1:]                                   # e.g. `python gen_golden.py fba dim`; default: everything
+    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba):
+        if not only or fn.__name__[4:] in only:
+            fn()

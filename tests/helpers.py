@@ -97,3 +97,24 @@ def dim_template():
     (its key list is checked against the reference in tests/test_oracle_golden.py::test_dim_state_dict_layout)."""
     from tcvom_amd.dim_net import DIM_VGG
     return DIM_VGG().state_dict()
+
+
+FBA_CASES = {
+    # name: (B, S, H, W, dilate_kernel)  -- tests/golden/gen_golden.py:FBA_CASES
+    'fba_s3_64x64': (1, 3, 64, 64, 3),
+    'fba_s5_64x96': (1, 5, 64, 96, 5),
+}
+FBA_FULL_GRADS = ('decoder.conv_up4.4.weight', 'decoder.conv_up4.4.bias', 'decoder.fam.query_conv.bias', 'encoder.bn1.weight',
+                  'decoder.conv_up3.1.weight', 'decoder.ppm.0.1.bias')
+
+
+def fba_formula_state(requires_grad=True):
+    """Formula-initialised state of FullModel_VMD('vmn_fba').NET: keys / shapes from the reference's own state_dict
+    (tests/golden/fba_state_keys.npz)."""
+    from tcvom_amd.synthetic import formula_tensor
+    g = golden('fba_state_keys')
+    state = {}
+    for k, shp in zip(g['keys'], g['shapes']):
+        shape = tuple(int(d) for d in str(shp).split(',')) if str(shp) else ()
+        state[str(k)] = formula_tensor(str(k), shape).requires_grad_(requires_grad)
+    return state

@@ -207,3 +207,72 @@ def test_dim_state_dict_layout():
     assert list(sd.keys()) == [str(k) for k in g['keys']]
     assert [','.join(str(int(d)) for d in v.shape) for v in sd.values()] == [str(s) for s in g['shapes']]
     assert sum(v.numel() for k, v in sd.items() if 'running_' not in k and 'num_batches' not in k) == 130545345
+
+
+# ----------------------------------------------------------------------------- FBA + TAM (config 5)
+@pytest.mark.parametrize('name', ['fba_s3_64x64', 'fba_s5_64x96'])
+def test_fba_window_forward_backward(name):
+    """oracle.fba_net against FullModel_VMD('vmn_fba') of the reference: the 5 losses, alpha / F / B, the 8-channel trimap
+    and the parameter gradients of the train_ddp.py loss."""
+    from oracle import fba_net
+    from helpers import FBA_CASES, FBA_FULL_GRADS, fba_formula_state
+    B, S, H, W, dil = FBA_CASES[name]
+    g = golden(name)
+    state = fba_formula_state()
+    a, fg, bg = synthetic_window(B, S, H, W, seed=2)
+    out, extra = fba_net.fba_window_forward(state, a, fg, bg, window=7, dilate_kernel=dil)
+    assert_close(torch.stack([o.detach() for o in out[:5]]), g['losses'], 2e-5, 1e-6, 'losses')
+    assert float(g['losses'][3]) > 0 if S >= 5 else float(g['losses'][3]) == 0
+    for i, k in ((7, 'alphas'), (8, 'comps'), (10, 'Fs'), (11, 'Bs')):
+        assert_close(out[i], g[k], 1e-4, 2e-4, k)
+    assert_close(extra['tris'], g['tris'].astype(np.float32), 2e-3, 1e-3, 'tris')          # stored as fp16
+    assert_close(out[6].double().sum(), g['tris_vis_sum'], 1e-6, 1e-3, 'tris_vis')
+    (out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]).backward()
+    names = [str(n) for n in g['grad_names']]
+    assert names == [k for k in state if state[k].grad is not None] and len(names) == 203
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    want = g['grad_norms']
+    # 50 layers of ReLU / clamp masks over an 8x8 os8 grid: a last-bit difference in the forward pass flips a mask and
+    # moves individual deep-layer gradients by several % (two fp32 evaluations of the same formulas); the gradient
+    # as a whole is tight
+    assert np.all(np.abs(got - want) <= 0.25 * want + 1e-7), np.max(np.abs(got - want) / (want + 1e-12))
+    assert abs(np.linalg.norm(got) - np.linalg.norm(want)) <= 2e-2 * np.linalg.norm(want)
+    for k in FBA_FULL_GRADS:
+        ref = g['grad:' + k]
+        assert_close(state[k].grad, ref, 5e-2, 5e-2 * float(np.abs(ref).max()), 'grad ' + k)
+
+
+def test_fba_losses_and_fusion():
+    """LapLoss, exclusion_loss, L1_grad (normalised and summed) and fba_fusion against the reference functions."""
+    from oracle import fba_net
+    g = golden('fba_ops')
+    x = (hu('fbaops.x', (2, 3, 64, 96)) * 0.5 + 0.5).requires_grad_(True)
+    y = (hu('fbaops.y', (2, 3, 64, 96)) * 0.5 + 0.5).requires_grad_(True)
+    al = (hu('fbaops.a', (2, 1, 64, 96)) * 0.6 + 0.5).clamp(0, 1).requires_grad_(True)
+    img = hu('fbaops.img', (2, 3, 64, 96)) * 0.5 + 0.5
+    fns = {'lap': fba_net.lap_loss, 'excl': lambda p, q, n: fba_net.exclusion_loss(p, q, 3, normalize=n), 'l1grad': fba_net.l1_grad}
+    for tag, fn in fns.items():
+        for mode, norm in (('norm', True), ('sum', False)):
+            x.grad = y.grad = None
+            v = fn(x, y, norm)
+            v.backward()
+            key = '%s_%s' % (tag, mode)
+            assert_close(v, g[key], 2e-5, 1e-7, key)
+            for nm, t in ((':dx', x.grad), (':dy', y.grad)):
+                ref = g[key + nm]
+                assert_close(t[:, :, ::3, ::3], ref, 1e-3, 1e-4 * float(np.abs(ref).max()) + 1e-9, key + nm)
+                assert_close(t.double().abs().sum(), g[key + nm + ':abs_sum'], 1e-4, 1e-9, key + nm + ' L1')
+    x.grad = y.grad = None
+    fa, fF, fB = fba_net.fba_fusion(al, img, x, y)
+    (fa.sum() + 2 * fF.sum() + 3 * fB.sum()).backward()
+    sub = lambda t: t[:, :, ::3, ::3]
+    for k, t in (('alpha', fa), ('F', fF), ('B', fB), ('dalpha', al.grad), ('dF', x.grad), ('dB', y.grad)):
+        assert_close(sub(t), g['fusion:' + k], 1e-4, 1e-5, 'fusion ' + k)
+    assert_close(torch.stack([t.double().sum() for t in (fa, fF, fB, al.grad, x.grad, y.grad)]), g['fusion:sums'], 1e-5, 1e-3, 'fusion sums')
+
+
+def test_fba_state_dict_layout():
+    g = golden('fba_state_keys')
+    assert len(g['keys']) == 203
+    n = sum(int(np.prod([int(d) for d in str(s).split(',')])) for s in g['shapes'])
+    assert n == 36463271
