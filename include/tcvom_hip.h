@@ -97,7 +97,7 @@ int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, floa
 /* ------------------------------------------------------------------ BatchNorm around the convs
  * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks
  * (models/GCA/encoders/resnet_enc.py:33-49, decoders/resnet_dec.py:43-59).
- * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).   z = act(y*scale + shift + res1) + res2          */
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 LeakyReLU(0.01).   z = act(y*scale + shift + res1) + res2          */
 /* unbias_count: element count used for the unbiased running_var correction (0 = count); differs from
  * count when the statistics were taken before a nearest x2 up-sampling (resnet_dec.py:112-118) */
 int tcvom_bn_finalize(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
@@ -134,6 +134,15 @@ int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64
                           double* scratch /* nframes * tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
                           int32_t accumulate /* != 0: atomically ADD into dgamma/dbeta (required when nframes > 1) */,
                           int32_t nframes, int64_t slot_stride, void* stream);
+/* GroupNorm (FBA base, models/FBA/layers_WS.py:26-27, nn.GroupNorm(32, C)) on the same partial sums: one sample per
+ * "frame"; count = pixels of one sample.  The (scale, shift) / (mean, invstd) / coef vectors it writes drive
+ * tcvom_bn_apply / tcvom_bn_bwd_reduce / tcvom_bn_bwd_apply unchanged.  dgamma / dbeta are ADDED to (atomics). */
+int tcvom_gn_finalize(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int32_t num_groups,
+                      const float* gamma, const float* beta, float eps, float* scale_shift, float* saved,
+                      double* scratch, int32_t nframes, int64_t slot_stride, void* stream);
+int tcvom_gn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int32_t num_groups,
+                          const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
+                          double* scratch, int32_t nframes, int64_t slot_stride, void* stream);
 /* SyncBatchNorm (train_ddp.py:213 nn.SyncBatchNorm.convert_sync_batchnorm): the per-channel sums are produced
  * as an fp64 [2][C] vector, the host all-reduces it over the ranks (RCCL), and the *_sums finalizers consume
  * the summed vector with the global pixel count.  dgamma/dbeta come from the LOCAL sums (torch semantics). */
@@ -230,7 +239,7 @@ int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G, const floa
 int tcvom_maxpool2_idx(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int tcvom_unpool2(const void* y, const uint8_t* idx, void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int tcvom_pick2(const void* x, const uint8_t* idx, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
-int tcvom_relu_bwd(const void* dz, const void* y, void* dy, int64_t numel, void* stream);
+int tcvom_relu_bwd(const void* dz, const void* y, void* dy, int64_t numel, float negative_slope /* 0: ReLU */, void* stream);
 /* im2col / col2im for conv6 (7x7, 512 -> 4096, vggnet.py:56), which runs as unfold + dense GEMM:
  *   unfold: u[p][t*C + c] = x[p + off_t][c];   fold: dx[q][c] = sum_t du[q - off_t][c*T + t]  (du is c-major) */
 int tcvom_unfold(const void* x, void* u, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ksize, void* stream);
@@ -274,6 +283,48 @@ int tcvom_loss_finalize(const float* acc, float* out, float weight, int32_t deno
                         int32_t window, int32_t accumulate, void* stream);
 int tcvom_adam_mt(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ FBA base (config 5: FullModel_VMD('vmn_fba'))
+ * Weight standardisation (models/FBA/layers_WS.py:13-23) lives in the weight table of tcvom_sn_pack: layers with kind
+ * bit 8 are packed as (w - mean_row) / (std_row + 1e-5); tcvom_ws_stats fills the per-row statistics (float4 per output
+ * channel at table word 17), tcvom_ws_backward turns the gradient w.r.t. the standardised weight (already in the
+ * parameter's layout inside grad_arena) into the gradient w.r.t. the raw weight, in place.  work_rows: (layer, row) pairs.
+ * Kind bit 16 marks the 7x7 stride-2 stem, packed as a 4x4 stride-1 kernel over the 2x2 space-to-depth input. */
+int tcvom_ws_stats(const int64_t* table, const int32_t* work_rows, int32_t n_rows, void* stream);
+int tcvom_ws_backward(const int64_t* table, const int32_t* work_rows, int32_t n_rows, float* grad_arena, void* stream);
+/* nn.MaxPool2d(3, 2, 1) (models/FBA/resnet_GN_WS.py:101) on NHWC bf16; idx = uint8 position of the maximum in its window */
+int tcvom_maxpool3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int tcvom_maxpool3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* pyramid pooling (models/VMN/VMN_FBA.py:23-31): nn.AdaptiveAvgPool2d(s) -> fp32 [N][s][s][C]; the backward sums the
+ * gradients of up to 4 scales (dout / scales are HOST arrays) into dx (NHWC bf16) */
+int tcvom_adaptive_avgpool(const void* x, float* out, int32_t N, int32_t h, int32_t w, int32_t C, int32_t s, void* stream);
+int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N,
+                               int32_t h, int32_t w, int32_t C, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) between channel slices of NHWC bf16 tensors (pixel strides ld_*,
+ * first channel c_*): any size ratio forward; backward for the exact x2 case (gather, bf16 out) and for small sources
+ * such as the s x s pooled maps (fp32 out) */
+int tcvom_bilinear(const void* src, void* dst, int32_t N, int32_t hs, int32_t ws, int32_t hd, int32_t wd, int32_t C,
+                   int32_t ld_src, int32_t c_src, int32_t ld_dst, int32_t c_dst, void* stream);
+int tcvom_bilinear_up2_bwd(const void* ddst, void* dsrc, int32_t N, int32_t hs, int32_t ws, int32_t C, int32_t ld_dst,
+                           int32_t c_dst, void* stream);
+int tcvom_bilinear_small_bwd(const void* ddst, float* dsrc, int32_t N, int32_t hs, int32_t ws, int32_t hd, int32_t wd,
+                             int32_t C, int32_t ld_dst, int32_t c_dst, void* stream);
+/* last decoder step (models/VMN/VMN_FBA.py:50-57): 1x1 conv 16 -> 7 (w [7][16], b [7] fp32), alpha = clamp, F / B =
+ * sigmoid, fba_fusion (models/FBA/models.py:246-255).  x NHWC bf16 [N][HW][16]; img fp32 [N][3][HW] (image stride
+ * img_stride); pred fp32 [N][7][HW] (stride pred_stride).  Backward: dw [replicas][7][16] and db [replicas][7] are
+ * added to atomically (caller zeroes them and sums the replicas). */
+int tcvom_fba_head_fwd(const void* x, const float* w, const float* b, const float* img, float* pred, int32_t N, int64_t HW,
+                       int64_t img_stride, int64_t pred_stride, void* stream);
+int tcvom_fba_head_bwd(const void* x, const float* w, const float* b, const float* img, const float* dpred, void* dx,
+                       float* dw, float* db, int32_t replicas, int32_t N, int64_t HW, int64_t img_stride,
+                       int64_t pred_stride, void* stream);
+/* network input of the FBA base from the outputs of tcvom_preprocess (gts, dilated unknown mask, scaled RGB images):
+ * make_trimap with 8 channels (models/model.py:71-77) incl. trimap_transform (utils/utils.py:12-39; exact Euclidean
+ * distance transform, the reference calls cv2.distanceTransform on the host).  x2: bf16 [frames][H/2][W/2][64], the 2x2
+ * space-to-depth form of cat(normalised RGB, 6 click maps, bg, fg) (16 channels per sub-pixel, 11 used); extras: bf16
+ * [frames][H][W][8] = (normalised RGB, RGB, bg, fg); tris (optional): fp32 [frames][8][H][W]; edt_scratch: frames*2*H*W floats */
+int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const float* imgs, void* x2, void* extras, float* tris,
+                    float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,21 @@ _PROTOS = {
     'tcvom_maxpool2_idx': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_unpool2': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_pick2': [vp, vp, vp, i32, i32, i32, i32, vp],
-    'tcvom_relu_bwd': [vp, vp, vp, i64, vp],
+    'tcvom_relu_bwd': [vp, vp, vp, i64, f32, vp],
+    'tcvom_gn_finalize': [vp, i32, i32, i64, i32, vp, vp, f32, vp, vp, vp, i32, i64, vp],
+    'tcvom_gn_bwd_finalize': [vp, i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, i32, i64, vp],
+    'tcvom_ws_stats': [vp, vp, i32, vp],
+    'tcvom_ws_backward': [vp, vp, i32, vp, vp],
+    'tcvom_maxpool3s2': [vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_maxpool3s2_bwd': [vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_adaptive_avgpool': [vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_adaptive_avgpool_bwd': [vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    'tcvom_bilinear': [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_bilinear_up2_bwd': [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_bilinear_small_bwd': [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_fba_head_fwd': [vp, vp, vp, vp, vp, i32, i64, i64, i64, vp],
+    'tcvom_fba_head_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, vp],
+    'tcvom_fba_input': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, vp],
     'tcvom_unfold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_fold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_dim_losses_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp],

@@ -39,6 +39,18 @@ class ConvGeometry(object):
     def __init__(self, spec, N, H, W):
         R, S, st, p = spec.R, spec.S, spec.stride, spec.pad
         K, C, Cp = spec.K, spec.C, spec.cpad
+        dil = getattr(spec, 'dilation', 1)
+        assert dil == 1 or st == 1, 'dilated convs are stride 1 (ResnetDilated, models/FBA/models.py:203-217)'
+        if getattr(spec, 'stem', False):
+            # 7x7 stride-2 pad-3 stem on the 2x2 space-to-depth input [N][H][W][64] (H, W = half resolution): a 4x4
+            # stride-1 kernel with taps (a, b) in -2..1; weight slot (a + 2) * 4 + (b + 2) (csrc/spectral.hip kind 16)
+            self.N, self.H, self.W = N, H, W
+            taps = [(a, b, (a + 2) * 4 + (b + 2)) for a in range(-2, 2) for b in range(-2, 2)]
+            d = _desc(N, H, W, Cp, H, W, K, H, W, 1, 1, 0, 0, taps, 16)
+            self.fwd, self.wgrad, self.dgrad = [d], [d], []
+            self.OH, self.OW, self.K, self.C = H, W, K, C
+            self.out_pixels = self.in_pixels = N * H * W
+            return
         self.N, self.H, self.W = N, H, W
         self.fwd, self.dgrad, self.wgrad = [], [], []
         hp = getattr(spec, 'hp', False)
@@ -54,18 +66,19 @@ class ConvGeometry(object):
                 self.fwd.append(self.wgrad[-1])
         if not spec.transposed:
             OH, OW = (H + 2 * p - R) // st + 1, (W + 2 * p - S) // st + 1
-            taps = [(r - p, s - p, r * S + s) for r in range(R) for s in range(S)]
+            OH, OW = (H + 2 * p - dil * (R - 1) - 1) // st + 1, (W + 2 * p - dil * (S - 1) - 1) // st + 1
+            taps = [(r * dil - p, s * dil - p, r * S + s) for r in range(R) for s in range(S)]
             fwd_desc(N, H, W, Cp, OH, OW, K, OH, OW, st, 1, 0, 0, taps, R * S)
             if spec.needs_dgrad:
                 # dx[n,h,w,c] = sum_{r,s,k} dy[n,(h+p-r)/st,(w+p-s)/st,k] W[k][c][r][s]   (exact divisions only)
                 for ph in range(st):
                     for pw in range(st):
                         PH, PW = (H - ph + st - 1) // st, (W - pw + st - 1) // st
-                        tp = [((ph + p - r) // st, (pw + p - s) // st, r * S + s)
+                        tp = [((ph + p - r * dil) // st, (pw + p - s * dil) // st, r * S + s)
                               for r in range(R) for s in range(S)
-                              if (ph + p - r) % st == 0 and (pw + p - s) % st == 0]
+                              if (ph + p - r * dil) % st == 0 and (pw + p - s * dil) % st == 0]
                         assert tp, 'phase without taps'
-                        self.dgrad.append(_desc(N, OH, OW, K, H, W, C, PH, PW, 1, st, ph, pw, tp, R * S))
+                        self.dgrad.append(_desc(N, OH, OW, K, H, W, C, PH, PW, 1, st, ph, pw, tp, R * S, ldo=Cp if Cp > 8 else None))
         else:
             assert R == 4 and S == 4 and st == 2 and p == 1, 'only ConvTranspose2d(k=4, s=2, p=1)'
             OH, OW = 2 * H, 2 * W

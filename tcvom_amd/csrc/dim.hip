@@ -99,13 +99,13 @@ __global__ void pick2_kernel(const uint4* __restrict__ x, const uint2* __restric
         y[v] = pack8(o);
     }
 }
-__global__ void relu_bwd_kernel(const uint4* __restrict__ dz, const uint4* __restrict__ y, uint4* __restrict__ dy, int64_t n8) {
+__global__ void relu_bwd_kernel(const uint4* __restrict__ dz, const uint4* __restrict__ y, uint4* __restrict__ dy, int64_t n8, float slope) {
     GRID_STRIDE(v, n8) {
         float g[8], a[8];
         unpack8(dz[v], g);
         unpack8(y[v], a);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+        for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.f ? g[k] : slope * g[k];
         dy[v] = pack8(g);
     }
 }
@@ -279,9 +279,10 @@ extern "C" int tcvom_pick2(const void* x, const uint8_t* idx, void* y, int32_t N
     TCVOM_LAUNCH_CHECK("pick2");
     return TCVOM_OK;
 }
-extern "C" int tcvom_relu_bwd(const void* dz, const void* y, void* dy, int64_t numel, void* stream) {
+extern "C" int tcvom_relu_bwd(const void* dz, const void* y, void* dy, int64_t numel, float negative_slope, void* stream) {
     TCVOM_CHECK_ARG(dz && y && dy && numel > 0 && numel % 8 == 0, "relu_bwd: bad args");
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(dgrid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (const uint4*)dz, (const uint4*)y, (uint4*)dy, numel / 8);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(dgrid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (const uint4*)dz, (const uint4*)y, (uint4*)dy, numel / 8,
+                       negative_slope);
     TCVOM_LAUNCH_CHECK("relu_bwd");
     return TCVOM_OK;
 }

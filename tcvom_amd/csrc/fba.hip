@@ -1,0 +1,570 @@
+// Kernels of the FBA base (BASELINE config 5: FullModel_VMD('vmn_fba')) that the conv / norm engine does not cover:
+//   * MaxPool2d(3, 2, 1) of the ResNet stem                          models/FBA/resnet_GN_WS.py:101
+//   * pyramid pooling: AdaptiveAvgPool2d(1, 2, 3, 6) and the bilinear resize back    models/VMN/VMN_FBA.py:23-31
+//   * bilinear x2 up-sampling (align_corners=False) into a slice of a concat buffer   models/VMN/VMN_FBA.py:37-48
+//   * the 1x1 head + clamp / sigmoid + fba_fusion                      models/VMN/VMN_FBA.py:50-57, models/FBA/models.py:246-255
+//   * the 11-channel network input: trimap_transform (exact Euclidean distance transform + Gaussian "clicks")
+//     utils/utils.py:12-39, models/model.py:71-77, written directly in the 2x2 space-to-depth layout of the stem
+// Activations are NHWC bf16; losses-side tensors are NCHW fp32 like the rest of the facade.
+#include "common.h"
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+static int dgrid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------ MaxPool2d(3, 2, 1)
+// idx = position (0..8) of the FIRST maximum inside the window in row-major scan order (PyTorch's choice)
+__global__ void maxpool3s2_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, uint8_t* __restrict__ idx, int64_t n,
+                                  int H, int W, int OH, int OW, int C8) {
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % C8);
+        int64_t t = v / C8;
+        const int j = (int)(t % OW); t /= OW;
+        const int i = (int)(t % OH);
+        const int64_t nb = t / OH;
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        for (int r = 0; r < 3; ++r) {
+            const int h = 2 * i - 1 + r;
+            if (h < 0 || h >= H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int w = 2 * j - 1 + s;
+                if (w < 0 || w >= W) continue;
+                float f[8];
+                unpack8(x[((nb * H + h) * W + w) * C8 + c8], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (f[k] > best[k]) { best[k] = f[k]; bi[k] = r * 3 + s; }
+            }
+        }
+        y[v] = pack8(best);
+        uint8_t* ip = idx + v * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ip[k] = (uint8_t)bi[k];
+    }
+}
+// gather form of the backward: every input pixel collects from the (at most 4) windows that contain it
+__global__ void maxpool3s2_bwd_kernel(const uint4* __restrict__ dy, const uint8_t* __restrict__ idx, uint4* __restrict__ dx,
+                                      int64_t n, int H, int W, int OH, int OW, int C8) {
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % C8);
+        int64_t t = v / C8;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int64_t nb = t / H;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = h / 2; i <= (h + 1) / 2; ++i) {
+            if (i >= OH) continue;
+            const int r = h - (2 * i - 1);
+            for (int j = w / 2; j <= (w + 1) / 2; ++j) {
+                if (j >= OW) continue;
+                const int pos = r * 3 + (w - (2 * j - 1));
+                const int64_t o = ((nb * OH + i) * OW + j) * C8 + c8;
+                float g[8];
+                unpack8(dy[o], g);
+                const uint8_t* ip = idx + o * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (ip[k] == pos) acc[k] += g[k];
+            }
+        }
+        dx[v] = pack8(acc);
+    }
+}
+
+extern "C" int tcvom_maxpool3s2(const void* x, void* y, uint8_t* idx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(x && y && idx && N > 0 && H > 1 && W > 1 && C % 8 == 0, "maxpool3s2: bad args");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int64_t n = (int64_t)N * OH * OW * (C / 8);
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, idx, n, H, W, OH, OW, C / 8);
+    TCVOM_LAUNCH_CHECK("maxpool3s2");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_maxpool3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(dy && dx && idx && N > 0 && H > 1 && W > 1 && C % 8 == 0, "maxpool3s2_bwd: bad args");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int64_t n = (int64_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const uint4*)dy, idx, (uint4*)dx, n, H, W, OH, OW, C / 8);
+    TCVOM_LAUNCH_CHECK("maxpool3s2_bwd");
+    return TCVOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ adaptive average pooling
+// AdaptiveAvgPool2d(s): bin b covers rows floor(b*h/s) .. ceil((b+1)*h/s) - 1 (bins overlap when s does not divide h)
+__device__ __forceinline__ int bin_lo(int b, int n, int s) { return (b * n) / s; }
+__device__ __forceinline__ int bin_hi(int b, int n, int s) { return ((b + 1) * n + s - 1) / s; }
+
+// grid (N*s*s, row splits); block = 256 threads = C8 channel octets x 256/C8 pixel lanes; out fp32 [N][s][s][C], zeroed
+__global__ __launch_bounds__(256) void adaptive_pool_kernel(const uint4* __restrict__ x, float* __restrict__ out, int h, int w, int C8, int s) {
+    const int bin = blockIdx.x % (s * s), nb = blockIdx.x / (s * s);
+    const int bi = bin / s, bj = bin % s;
+    const int h0 = bin_lo(bi, h, s), h1 = bin_hi(bi, h, s), w0 = bin_lo(bj, w, s), w1 = bin_hi(bj, w, s);
+    const int lanes = 256 / C8, c8 = threadIdx.x % C8, pl = threadIdx.x / C8;
+    const int bw = w1 - w0;
+    const int64_t npix = (int64_t)(h1 - h0) * bw;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t p = (int64_t)blockIdx.y * lanes + pl; p < npix; p += (int64_t)gridDim.y * lanes) {
+        const int yy = h0 + (int)(p / bw), xx = w0 + (int)(p % bw);
+        float f[8];
+        unpack8(x[(((int64_t)nb * h + yy) * w + xx) * C8 + c8], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += f[k];
+    }
+    const float inv = 1.f / (float)npix;
+    float* o = out + ((int64_t)blockIdx.x * C8 + c8) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(o + k, acc[k] * inv);
+}
+// dx = sum over the scales of dout_s[bin] / |bin| for every bin that contains the pixel
+struct PoolGrads { const float* d[4]; int s[4]; int n; };
+__global__ void adaptive_pool_bwd_kernel(PoolGrads pg, uint4* __restrict__ dx, int64_t n, int h, int w, int C8) {
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % C8);
+        int64_t t = v / C8;
+        const int xx = (int)(t % w); t /= w;
+        const int yy = (int)(t % h);
+        const int64_t nb = t / h;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < pg.n; ++q) {
+            const int s = pg.s[q];
+            for (int bi = 0; bi < s; ++bi) {
+                const int h0 = bin_lo(bi, h, s), h1 = bin_hi(bi, h, s);
+                if (yy < h0 || yy >= h1) continue;
+                for (int bj = 0; bj < s; ++bj) {
+                    const int w0 = bin_lo(bj, w, s), w1 = bin_hi(bj, w, s);
+                    if (xx < w0 || xx >= w1) continue;
+                    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+                    const float* g = pg.d[q] + (((nb * s + bi) * s + bj) * C8 + c8) * 8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += g[k] * inv;
+                }
+            }
+        }
+        dx[v] = pack8(acc);
+    }
+}
+
+extern "C" int tcvom_adaptive_avgpool(const void* x, float* out, int32_t N, int32_t h, int32_t w, int32_t C, int32_t s, void* stream) {
+    TCVOM_CHECK_ARG(x && out && N > 0 && h >= s && w >= s && s >= 1 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, "adaptive_avgpool: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * s * s * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "adaptive_avgpool: memset failed");
+    const int64_t npix = (int64_t)((h + s - 1) / s + 1) * ((w + s - 1) / s + 1);
+    int split = (int)((npix * (C / 8) + 256 * 64 - 1) / (256 * 64));
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    hipLaunchKernelGGL(adaptive_pool_kernel, dim3(N * s * s, split), dim3(256), 0, st, (const uint4*)x, out, h, w, C / 8, s);
+    TCVOM_LAUNCH_CHECK("adaptive_avgpool");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N, int32_t h,
+                                          int32_t w, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(dout && scales && dx && nscales >= 1 && nscales <= 4 && N > 0 && C % 8 == 0, "adaptive_avgpool_bwd: bad args");
+    PoolGrads pg;
+    pg.n = nscales;
+    for (int i = 0; i < 4; ++i) { pg.d[i] = dout[i < nscales ? i : 0]; pg.s[i] = scales[i < nscales ? i : 0]; }
+    const int64_t n = (int64_t)N * h * w * (C / 8);
+    hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, pg, (uint4*)dx, n, h, w, C / 8);
+    TCVOM_LAUNCH_CHECK("adaptive_avgpool_bwd");
+    return TCVOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ bilinear resize
+// F.interpolate(mode='bilinear', align_corners=False): source coordinate max(0, (dst + 0.5) * in/out - 0.5)
+struct Lerp { int i0, i1; float l; };
+__device__ __forceinline__ Lerp lerp_of(int d, float scale, int n_in) {
+    float s = ((float)d + 0.5f) * scale - 0.5f;
+    if (s < 0.f) s = 0.f;
+    Lerp r;
+    r.i0 = (int)s;
+    if (r.i0 > n_in - 1) r.i0 = n_in - 1;
+    r.i1 = r.i0 + 1 < n_in ? r.i0 + 1 : n_in - 1;
+    r.l = s - (float)r.i0;
+    return r;
+}
+// weight of source index `i` in destination index d
+__device__ __forceinline__ float lerp_weight(int d, int i, float scale, int n_in) {
+    const Lerp r = lerp_of(d, scale, n_in);
+    return (r.i0 == i ? 1.f - r.l : 0.f) + (r.i1 == i ? r.l : 0.f);
+}
+
+// src [N][hs][ws][ld_src] (channels c_src..+C) -> dst [N][hd][wd][ld_dst] (channels c_dst..+C)
+__global__ void bilinear_kernel(const bf16raw* __restrict__ src, bf16raw* __restrict__ dst, int64_t n, int hs, int ws, int hd, int wd,
+                                int C8, int ld_src, int c_src, int ld_dst, int c_dst, float sh, float sw) {
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % C8);
+        int64_t t = v / C8;
+        const int X = (int)(t % wd); t /= wd;
+        const int Y = (int)(t % hd);
+        const int64_t nb = t / hd;
+        const Lerp ly = lerp_of(Y, sh, hs), lx = lerp_of(X, sw, ws);
+        const bf16raw* sb = src + nb * hs * ws * ld_src + c_src + c8 * 8;
+        float a[8], b[8], c[8], d[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i0 * ws + lx.i0) * ld_src), a);
+        unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i0 * ws + lx.i1) * ld_src), b);
+        unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i1 * ws + lx.i0) * ld_src), c);
+        unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i1 * ws + lx.i1) * ld_src), d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            o[k] = (1.f - ly.l) * ((1.f - lx.l) * a[k] + lx.l * b[k]) + ly.l * ((1.f - lx.l) * c[k] + lx.l * d[k]);
+        *reinterpret_cast<uint4*>(dst + ((nb * hd + Y) * wd + X) * ld_dst + c_dst + c8 * 8) = pack8(o);
+    }
+}
+// gather form of the x2 backward: source pixel (i, j) collects from destination rows 2i-2 .. 2i+2 (weights from lerp_weight,
+// which reproduces the border clamping of the forward)
+__global__ void bilinear_up2_bwd_kernel(const bf16raw* __restrict__ ddst, bf16raw* __restrict__ dsrc, int64_t n, int hs, int ws, int C8,
+                                        int ld_dst, int c_dst) {
+    const int hd = 2 * hs, wd = 2 * ws;
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % C8);
+        int64_t t = v / C8;
+        const int j = (int)(t % ws); t /= ws;
+        const int i = (int)(t % hs);
+        const int64_t nb = t / hs;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int Y = 2 * i - 2; Y <= 2 * i + 2; ++Y) {
+            if (Y < 0 || Y >= hd) continue;
+            const float wy = lerp_weight(Y, i, 0.5f, hs);
+            if (wy == 0.f) continue;
+            for (int X = 2 * j - 2; X <= 2 * j + 2; ++X) {
+                if (X < 0 || X >= wd) continue;
+                const float wgt = wy * lerp_weight(X, j, 0.5f, ws);
+                if (wgt == 0.f) continue;
+                float g[8];
+                unpack8(*reinterpret_cast<const uint4*>(ddst + ((nb * hd + Y) * wd + X) * ld_dst + c_dst + c8 * 8), g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += wgt * g[k];
+            }
+        }
+        *reinterpret_cast<uint4*>(dsrc + v * 8) = pack8(acc);
+    }
+}
+// backward onto a SMALL source (the s x s pyramid-pooling maps): grid (N*hs*ws, row splits); a block walks the destination
+// rows that touch its source pixel and adds its partial sum to dsrc (fp32 [N][hs][ws][C], zeroed)
+__global__ __launch_bounds__(256) void bilinear_small_bwd_kernel(const bf16raw* __restrict__ ddst, float* __restrict__ dsrc, int hs, int ws,
+                                                                 int hd, int wd, int C8, int ld_dst, int c_dst, float sh, float sw) {
+    const int sp = blockIdx.x % (hs * ws), nb = blockIdx.x / (hs * ws);
+    const int i = sp / ws, j = sp % ws;
+    const int lanes = 256 / C8, c8 = threadIdx.x % C8, pl = threadIdx.x / C8;
+    // destination rows / columns whose two source taps can include i / j
+    int y0 = (int)floorf(((float)i - 1.f + 0.5f) / sh - 0.5f) - 1, y1 = (int)ceilf(((float)i + 1.f + 0.5f) / sh - 0.5f) + 1;
+    int x0 = (int)floorf(((float)j - 1.f + 0.5f) / sw - 0.5f) - 1, x1 = (int)ceilf(((float)j + 1.f + 0.5f) / sw - 0.5f) + 1;
+    if (y0 < 0) y0 = 0;
+    if (x0 < 0) x0 = 0;
+    if (y1 > hd - 1) y1 = hd - 1;
+    if (x1 > wd - 1) x1 = wd - 1;
+    const int bw = x1 - x0 + 1;
+    const int64_t npix = (int64_t)(y1 - y0 + 1) * bw;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t p = (int64_t)blockIdx.y * lanes + pl; p < npix; p += (int64_t)gridDim.y * lanes) {
+        const int Y = y0 + (int)(p / bw), X = x0 + (int)(p % bw);
+        const float wgt = lerp_weight(Y, i, sh, hs) * lerp_weight(X, j, sw, ws);
+        if (wgt == 0.f) continue;
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(ddst + (((int64_t)nb * hd + Y) * wd + X) * ld_dst + c_dst + c8 * 8), g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += wgt * g[k];
+    }
+    float* o = dsrc + ((int64_t)blockIdx.x * C8 + c8) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(o + k, acc[k]);
+}
+
+extern "C" int tcvom_bilinear(const void* src, void* dst, int32_t N, int32_t hs, int32_t ws, int32_t hd, int32_t wd, int32_t C,
+                              int32_t ld_src, int32_t c_src, int32_t ld_dst, int32_t c_dst, void* stream) {
+    TCVOM_CHECK_ARG(src && dst && N > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0 && C % 8 == 0, "bilinear: bad args");
+    TCVOM_CHECK_ARG(ld_src % 8 == 0 && c_src % 8 == 0 && ld_dst % 8 == 0 && c_dst % 8 == 0 && c_src + C <= ld_src && c_dst + C <= ld_dst, "bilinear: bad channel slices");
+    const int64_t n = (int64_t)N * hd * wd * (C / 8);
+    hipLaunchKernelGGL(bilinear_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)src, (bf16raw*)dst, n, hs, ws, hd, wd,
+                       C / 8, ld_src, c_src, ld_dst, c_dst, (float)hs / (float)hd, (float)ws / (float)wd);
+    TCVOM_LAUNCH_CHECK("bilinear");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_bilinear_up2_bwd(const void* ddst, void* dsrc, int32_t N, int32_t hs, int32_t ws, int32_t C, int32_t ld_dst, int32_t c_dst,
+                                      void* stream) {
+    TCVOM_CHECK_ARG(ddst && dsrc && N > 0 && hs > 0 && ws > 0 && C % 8 == 0 && ld_dst % 8 == 0 && c_dst % 8 == 0 && c_dst + C <= ld_dst, "bilinear_up2_bwd: bad args");
+    const int64_t n = (int64_t)N * hs * ws * (C / 8);
+    hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)ddst, (bf16raw*)dsrc, n, hs, ws,
+                       C / 8, ld_dst, c_dst);
+    TCVOM_LAUNCH_CHECK("bilinear_up2_bwd");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_bilinear_small_bwd(const void* ddst, float* dsrc, int32_t N, int32_t hs, int32_t ws, int32_t hd, int32_t wd, int32_t C,
+                                        int32_t ld_dst, int32_t c_dst, void* stream) {
+    TCVOM_CHECK_ARG(ddst && dsrc && N > 0 && hs > 0 && ws > 0 && hd >= hs && wd >= ws && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, "bilinear_small_bwd: bad args");
+    TCVOM_CHECK_ARG(ld_dst % 8 == 0 && c_dst % 8 == 0 && c_dst + C <= ld_dst, "bilinear_small_bwd: bad channel slice");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dsrc, 0, sizeof(float) * (size_t)N * hs * ws * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "bilinear_small_bwd: memset failed");
+    const int64_t npix = (int64_t)(2 * hd / hs + 4) * (2 * wd / ws + 4);
+    int split = (int)((npix * (C / 8) + 256 * 64 - 1) / (256 * 64));
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    hipLaunchKernelGGL(bilinear_small_bwd_kernel, dim3(N * hs * ws, split), dim3(256), 0, st, (const bf16raw*)ddst, dsrc, hs, ws, hd, wd, C / 8,
+                       ld_dst, c_dst, (float)hs / (float)hd, (float)ws / (float)wd);
+    TCVOM_LAUNCH_CHECK("bilinear_small_bwd");
+    return TCVOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ head: 1x1 conv 16 -> 7, clamp / sigmoid, fusion
+struct FbaPix { float o[7], a, F0[3], B0[3], F1[3], B1[3], Fc[3], Bc[3], num, den, r; };
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+__device__ __forceinline__ float in01(float x) { return (x >= 0.f && x <= 1.f) ? 1.f : 0.f; }      // torch.clamp passes the gradient at the bounds
+
+__device__ __forceinline__ void fba_pixel(const float* x16, const float* wb /* [7][16] + [7] */, const float* I, FbaPix& p) {
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        float a = wb[112 + m];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a += wb[m * 16 + c] * x16[c];
+        p.o[m] = a;
+    }
+    const float a = clamp01(p.o[0]);
+    p.a = a;
+    float num = a * 0.1f, den = 0.1f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p.F0[c] = sigmoidf(p.o[1 + c]);
+        p.B0[c] = sigmoidf(p.o[4 + c]);
+        p.F1[c] = a * I[c] + (1.f - a * a) * p.F0[c] - a * (1.f - a) * p.B0[c];
+        p.B1[c] = (1.f - a) * I[c] + (2.f * a - a * a) * p.B0[c] - a * (1.f - a) * p.F1[c];
+        p.Fc[c] = clamp01(p.F1[c]);
+        p.Bc[c] = clamp01(p.B1[c]);
+        const float D = p.Fc[c] - p.Bc[c];
+        num += (I[c] - p.Bc[c]) * D;
+        den += D * D;
+    }
+    p.num = num; p.den = den; p.r = num / den;
+}
+
+// x [N][HW][16] bf16; img fp32 [N][3][HW] with image stride img_stride; pred fp32 [N][7][HW] with stride pred_stride
+__global__ void fba_head_fwd_kernel(const uint4* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ img,
+                                    float* __restrict__ pred, int64_t n, int64_t HW, int64_t img_stride, int64_t pred_stride) {
+    __shared__ float wb[119];
+    if (threadIdx.x < 112) wb[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < 7) wb[112 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    GRID_STRIDE(v, n) {
+        const int64_t nb = v / HW, p = v % HW;
+        float x16[16], I[3];
+        unpack8(x[v * 2], x16);
+        unpack8(x[v * 2 + 1], x16 + 8);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I[c] = img[nb * img_stride + c * HW + p];
+        FbaPix px;
+        fba_pixel(x16, wb, I, px);
+        float* o = pred + nb * pred_stride + p;
+        o[0] = clamp01(px.r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[(1 + c) * HW] = px.Fc[c]; o[(4 + c) * HW] = px.Bc[c]; }
+    }
+}
+// dpred fp32 [N][7][HW] -> dx bf16 [N][HW][16], dw [replicas][7][16], db [replicas][7] (atomic, zeroed by the caller)
+__global__ __launch_bounds__(256) void fba_head_bwd_kernel(const uint4* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* __restrict__ img, const float* __restrict__ dpred, uint4* __restrict__ dx,
+                                                           float* __restrict__ dw, float* __restrict__ db, int64_t n, int64_t HW,
+                                                           int64_t img_stride, int64_t pred_stride, int replicas) {
+    __shared__ float wb[119];
+    __shared__ float red[4][119];
+    if (threadIdx.x < 112) wb[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x < 7) wb[112 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    float gw[112], gb[7];
+#pragma unroll
+    for (int i = 0; i < 112; ++i) gw[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gb[i] = 0.f;
+    GRID_STRIDE(v, n) {
+        const int64_t nb = v / HW, p = v % HW;
+        float x16[16], I[3];
+        unpack8(x[v * 2], x16);
+        unpack8(x[v * 2 + 1], x16 + 8);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) I[c] = img[nb * img_stride + c * HW + p];
+        FbaPix px;
+        fba_pixel(x16, wb, I, px);
+        const float* g = dpred + nb * pred_stride + p;
+        const float a = px.a;
+        const float g_r = g[0] * in01(px.r);
+        const float g_num = g_r / px.den, g_den = -g_r * px.num / (px.den * px.den);
+        float g_a = g_num * 0.1f, go[7];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float D = px.Fc[c] - px.Bc[c];
+            const float gFc = g[(1 + c) * HW] + g_num * (I[c] - px.Bc[c]) + g_den * 2.f * D;
+            const float gBc = g[(4 + c) * HW] + g_num * (-D - (I[c] - px.Bc[c])) - g_den * 2.f * D;
+            float gF1 = gFc * in01(px.F1[c]);
+            const float gB1 = gBc * in01(px.B1[c]);
+            g_a += gB1 * (-I[c] + (2.f - 2.f * a) * px.B0[c] - (1.f - 2.f * a) * px.F1[c]);
+            float gB0 = gB1 * (2.f * a - a * a);
+            gF1 += gB1 * (-a * (1.f - a));
+            g_a += gF1 * (I[c] - 2.f * a * px.F0[c] - (1.f - 2.f * a) * px.B0[c]);
+            const float gF0 = gF1 * (1.f - a * a);
+            gB0 += gF1 * (-a * (1.f - a));
+            go[1 + c] = gF0 * px.F0[c] * (1.f - px.F0[c]);
+            go[4 + c] = gB0 * px.B0[c] * (1.f - px.B0[c]);
+        }
+        go[0] = g_a * in01(px.o[0]);
+        float d16[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) s += wb[m * 16 + c] * go[m];
+            d16[c] = s;
+        }
+        dx[v * 2] = pack8(d16);
+        dx[v * 2 + 1] = pack8(d16 + 8);
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            gb[m] += go[m];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) gw[m * 16 + c] += go[m] * x16[c];
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 112; ++i) { const float s = wave_sum(gw[i]); if ((threadIdx.x & 63) == 0) red[wave][i] = s; }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const float s = wave_sum(gb[i]); if ((threadIdx.x & 63) == 0) red[wave][112 + i] = s; }
+    __syncthreads();
+    if (threadIdx.x < 119) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const int rep = blockIdx.x % replicas;
+        if (threadIdx.x < 112) atomicAdd(dw + rep * 112 + threadIdx.x, s);
+        else atomicAdd(db + rep * 7 + (threadIdx.x - 112), s);
+    }
+}
+
+extern "C" int tcvom_fba_head_fwd(const void* x, const float* w, const float* b, const float* img, float* pred, int32_t N, int64_t HW,
+                                  int64_t img_stride, int64_t pred_stride, void* stream) {
+    TCVOM_CHECK_ARG(x && w && b && img && pred && N > 0 && HW > 0, "fba_head_fwd: bad args");
+    const int64_t n = (int64_t)N * HW;
+    hipLaunchKernelGGL(fba_head_fwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, w, b, img, pred, n, HW, img_stride, pred_stride);
+    TCVOM_LAUNCH_CHECK("fba_head_fwd");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_fba_head_bwd(const void* x, const float* w, const float* b, const float* img, const float* dpred, void* dx, float* dw,
+                                  float* db, int32_t replicas, int32_t N, int64_t HW, int64_t img_stride, int64_t pred_stride, void* stream) {
+    TCVOM_CHECK_ARG(x && w && b && img && dpred && dx && dw && db && N > 0 && HW > 0 && replicas >= 1, "fba_head_bwd: bad args");
+    const int64_t n = (int64_t)N * HW;
+    int grid = dgrid(n);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(fba_head_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, w, b, img, dpred, (uint4*)dx, dw, db,
+                       n, HW, img_stride, pred_stride, replicas);
+    TCVOM_LAUNCH_CHECK("fba_head_bwd");
+    return TCVOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ network input: 8-channel trimap + image
+// class maps (models/model.py:71-75): tri1 = dilated unknown ? 255 : alpha (after the eps snapping); bg = (tri1 == 0), fg = (tri1 == 1).
+// trimap_transform (utils/utils.py:25-39): d = Euclidean distance to the nearest pixel of the class (exact two-pass EDT),
+// clicks = exp(-d^2 / (2 (s * 320)^2)), s = 0.02, 0.08, 0.16.  No pixel of the class in the frame -> d = inf -> 0.
+#define EDT_INF 1.0e30f
+__device__ __forceinline__ int fba_class(float alpha, uint8_t dil, float eps) {   // 0 bg, 1 fg, 2 neither
+    if (dil) return 2;
+    float a = alpha < eps ? 0.f : alpha;
+    a = a > 1.f - eps ? 1.f : a;
+    return a == 0.f ? 0 : (a == 1.f ? 1 : 2);
+}
+// pass 1: per column, squared vertical distance to the nearest class pixel; g2 [frames][2][H][W]
+__global__ void edt_columns_kernel(const float* __restrict__ gts, const uint8_t* __restrict__ dil, float* __restrict__ g2, int64_t n, int H, int W, float eps) {
+    GRID_STRIDE(v, n) {
+        const int w = (int)(v % W);
+        const int k = (int)((v / W) % 2);
+        const int64_t f = v / (2 * W);
+        const float* a = gts + f * H * W + w;
+        const uint8_t* d = dil + f * H * W + w;
+        float* o = g2 + ((f * 2 + k) * H) * W + w;
+        float dist = EDT_INF;
+        for (int h = 0; h < H; ++h) {
+            dist = fba_class(a[(int64_t)h * W], d[(int64_t)h * W], eps) == k ? 0.f : (dist < EDT_INF ? dist + 1.f : EDT_INF);
+            o[(int64_t)h * W] = dist;
+        }
+        dist = EDT_INF;
+        for (int h = H - 1; h >= 0; --h) {
+            const float up = o[(int64_t)h * W];
+            dist = up == 0.f ? 0.f : (dist < EDT_INF ? dist + 1.f : EDT_INF);
+            const float m = fminf(up, dist);
+            o[(int64_t)h * W] = m < EDT_INF ? m * m : EDT_INF;
+        }
+    }
+}
+// pass 2: one block per (frame, class, row): d2[x] = min_x' (x - x')^2 + g2[x'], then the three click maps, written into the
+// space-to-depth network input x2 [frames][H/2][W/2][64] (channel 16 * (2 (h&1) + (w&1)) + 3 + 3 k + sigma) and, optionally, tris
+__global__ __launch_bounds__(256) void edt_rows_kernel(const float* __restrict__ g2, bf16raw* __restrict__ x2, float* __restrict__ tris, int H, int W) {
+    extern __shared__ float row[];
+    const int h = blockIdx.x % H, k = (blockIdx.x / H) % 2;
+    const int64_t f = blockIdx.x / (2 * H);
+    const float* g = g2 + ((f * 2 + k) * H + h) * W;
+    for (int x = threadIdx.x; x < W; x += 256) row[x] = g[x];
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        float best = row[x];
+        // outward scan, stopping once the horizontal distance alone exceeds the best value of every lane of the wave
+        for (int d = 1; d < W; ++d) {
+            const float dd = (float)d * (float)d;
+            if (__all(dd >= best)) break;
+            if (x - d >= 0) best = fminf(best, dd + row[x - d]);
+            if (x + d < W) best = fminf(best, dd + row[x + d]);
+        }
+        const int sub = (h & 1) * 2 + (x & 1);
+        bf16raw* o = x2 + (((f * (H / 2) + h / 2) * (W / 2) + x / 2) * 64) + sub * 16 + 3 + 3 * k;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float sg = (s == 0 ? 0.02f : (s == 1 ? 0.08f : 0.16f)) * 320.f;
+            const float c = best < EDT_INF ? __expf(-best / (2.f * sg * sg)) : 0.f;
+            o[s] = f2bf(c);
+            if (tris) tris[((f * 8 + 3 * k + s) * H + h) * W + x] = c;
+        }
+    }
+}
+// pass 3: image and indicator channels.  x2 channels 0..2 (normalised RGB), 9 (bg), 10 (fg) of every sub-pixel; extras
+// [frames][H][W][8] = (normalised RGB, RGB, bg, fg) for the last decoder stage; imgs fp32 [frames][3][H][W] (scaled RGB)
+__global__ void fba_input_kernel(const float* __restrict__ gts, const uint8_t* __restrict__ dil, const float* __restrict__ imgs, bf16raw* __restrict__ x2,
+                                 uint4* __restrict__ extras, float* __restrict__ tris, int64_t n, int H, int W, float eps) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+    GRID_STRIDE(v, n) {
+        const int w = (int)(v % W);
+        const int h = (int)((v / W) % H);
+        const int64_t f = v / ((int64_t)H * W);
+        const int cls = fba_class(gts[v], dil[v], eps);
+        float e[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float px = imgs[(f * 3 + c) * H * W + (int64_t)h * W + w];
+            e[c] = (px - mean[c]) * istd[c];
+            e[3 + c] = px;
+        }
+        e[6] = cls == 0 ? 1.f : 0.f;
+        e[7] = cls == 1 ? 1.f : 0.f;
+        extras[v] = pack8(e);
+        bf16raw* o = x2 + (((f * (H / 2) + h / 2) * (W / 2) + w / 2) * 64) + ((h & 1) * 2 + (w & 1)) * 16;
+        o[0] = f2bf(e[0]); o[1] = f2bf(e[1]); o[2] = f2bf(e[2]);
+        o[9] = f2bf(e[6]); o[10] = f2bf(e[7]);
+        if (tris) {
+            tris[((f * 8 + 6) * H + h) * W + w] = e[6];
+            tris[((f * 8 + 7) * H + h) * W + w] = e[7];
+        }
+    }
+}
+
+extern "C" int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const float* imgs, void* x2, void* extras, float* tris,
+                               float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream) {
+    TCVOM_CHECK_ARG(gts && unk_dil && imgs && x2 && extras && edt_scratch && frames > 0 && H % 2 == 0 && W % 2 == 0 && W <= 8192, "fba_input: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(x2, 0, sizeof(bf16raw) * (size_t)frames * (H / 2) * (W / 2) * 64, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "fba_input: memset failed");
+    const int64_t ncol = frames * 2 * W;
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(dgrid(ncol)), dim3(256), 0, st, gts, unk_dil, edt_scratch, ncol, H, W, eps);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)(frames * 2 * H)), dim3(256), sizeof(float) * W, st, edt_scratch, (bf16raw*)x2, tris, H, W);
+    const int64_t n = frames * (int64_t)H * W;
+    hipLaunchKernelGGL(fba_input_kernel, dim3(dgrid(n)), dim3(256), 0, st, gts, unk_dil, imgs, (bf16raw*)x2, (uint4*)extras, tris, n, H, W, eps);
+    TCVOM_LAUNCH_CHECK("fba_input");
+    return TCVOM_OK;
+}

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[a][b][q * 4 + r] * sc[r] + bs[r];
                     if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
-                    if (g.act == 1) x = fmaxf(x, 0.f);
+                    if (g.act == 1) x = fmaxf(x, 0.f); else if (g.act == 3) x = x > 0.f ? x : 0.01f * x;
                     v[r] = x;
                 }
                 if (pvalid[b] && mrow < g.M) {

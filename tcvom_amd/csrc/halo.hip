@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float xv = acc[j][g * 4 + r] + bs[r];
-                    if (a.act == 1) xv = fmaxf(xv, 0.f);
+                    if (a.act == 1) xv = fmaxf(xv, 0.f); else if (a.act == 3) xv = xv > 0.f ? xv : 0.01f * xv;
                     vv[r] = xv;
                     s1[r] += xv;
                     s2[r] += xv * xv;

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[a][b][g * 4 + r] * sc[r] + bs[r];
                     if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
-                    if (d.act == 1) x = fmaxf(x, 0.f);
+                    if (d.act == 1) x = fmaxf(x, 0.f); else if (d.act == 3) x = x > 0.f ? x : 0.01f * x;
                     v[r] = x;
                     if (pvalid[b]) { s1[r] += x; s2[r] += x * x; }
                 }

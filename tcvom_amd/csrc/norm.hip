@@ -119,10 +119,10 @@ __device__ __forceinline__ void load_y8(const void* __restrict__ y, int64_t v, f
 
 // ---------------------------------------------------------------- apply: z = act(y*s + b + res1) + res2
 __device__ __forceinline__ float act_fwd(float x, int act) {
-    return act == 1 ? fmaxf(x, 0.f) : (act == 2 ? (x > 0.f ? x : 0.2f * x) : x);
+    return act == 1 ? fmaxf(x, 0.f) : (act == 2 ? (x > 0.f ? x : 0.2f * x) : (act == 3 ? (x > 0.f ? x : 0.01f * x) : x));
 }
 __device__ __forceinline__ float act_grad(float pre, int act) {
-    return act == 1 ? (pre > 0.f ? 1.f : 0.f) : (act == 2 ? (pre > 0.f ? 1.f : 0.2f) : 1.f);
+    return act == 1 ? (pre > 0.f ? 1.f : 0.f) : (act == 2 ? (pre > 0.f ? 1.f : 0.2f) : (act == 3 ? (pre > 0.f ? 1.f : 0.01f) : 1.f));
 }
 
 // A block owns a contiguous pixel range; a thread owns ONE channel octet for the whole range (its 16 scale/shift
@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         // accumulate: the S calls of one BatchNorm (frames on concurrent streams) add into one gradient buffer
         if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)a); else dbeta[c] = (float)a; }
         if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)b); else dgamma[c] = (float)b; }
-        coef[c] = (float)(a / count);
-        coef[C + c] = (float)(b / count);
-        coef[2 * C + c] = gamma[c] * saved[C + c];
+        // dy = gi * g - c1 - xhat * c2   (bn_bwd_apply); the same form serves GroupNorm (gn_bwd_finalize_kernel)
+        const float gi = gamma[c] * saved[C + c];
+        coef[c] = (float)(a / count) * gi;
+        coef[C + c] = (float)(b / count) * gi;
+        coef[2 * C + c] = gi;
     }
 }
 
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             const float gg = g[k] * act_grad(pre, act);
             g[k] = gg;
             const float xh = (yy[k] - mu[k]) * is[k];
-            o[k] = gi[k] * (gg - c1[k] - xh * c2[k]);
+            o[k] = gi[k] * gg - c1[k] - xh * c2[k];
             if (in_relu && yy[k] <= 0.f) o[k] = 0.f;
         }
         dy[v] = pack8(o);
@@ -496,6 +498,132 @@ extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32
                            (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
+    return TCVOM_OK;
+}
+
+// ---------------------------------------------------------------- GroupNorm (FBA base: models/FBA/layers_WS.py:26-27)
+// The conv epilogue's per-channel (sum, sum of squares) partials of ONE sample are combined over the channels of
+// a group; the per-channel (scale, shift) / (mean, invstd) vectors then drive the same apply kernels as BatchNorm.
+// One block per sample ("frame" of a batched call).
+template <typename PT>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const PT* __restrict__ partial, int G, int C, int ngroups, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale_shift, float* __restrict__ saved, int64_t slot_stride) {
+    __shared__ double cs[2048], cq[2048];
+    __shared__ float gm[64], gr[64];
+    partial += (int64_t)blockIdx.x * G * 2 * C;
+    scale_shift += blockIdx.x * slot_stride;
+    saved += blockIdx.x * slot_stride;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int g = 0; g < G; ++g) {
+            a += (double)partial[(int64_t)g * 2 * C + c];
+            b += (double)partial[(int64_t)g * 2 * C + C + c];
+        }
+        cs[c] = a;
+        cq[c] = b;
+    }
+    __syncthreads();
+    const int cpg = C / ngroups;
+    if ((int)threadIdx.x < ngroups) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < cpg; ++j) { a += cs[threadIdx.x * cpg + j]; b += cq[threadIdx.x * cpg + j]; }
+        const double m = count * cpg, mean = a / m;
+        double var = b / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gm[threadIdx.x] = (float)mean;
+        gr[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = gamma[c] * gr[g];
+        scale_shift[c] = sc;
+        scale_shift[C + c] = beta[c] - gm[g] * sc;
+        saved[c] = gm[g];
+        saved[C + c] = gr[g];
+    }
+}
+
+// partial: per-channel (sum g, sum g * xhat) of bn_bwd_reduce.  dx = rstd * (gamma * g - G1/m - xhat * G2/m) with the
+// group sums G1 = sum_c gamma_c S1_c, G2 = sum_c gamma_c S2_c, m = pixels * channels per group.
+template <typename PT>
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const PT* __restrict__ partial, int G, int C, int ngroups, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ saved,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef, int64_t slot_stride) {
+    __shared__ double cs[2048], cq[2048];
+    __shared__ float g1[64], g2[64];
+    partial += (int64_t)blockIdx.x * G * 2 * C;
+    saved += blockIdx.x * slot_stride;
+    coef += (int64_t)blockIdx.x * 3 * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int g = 0; g < G; ++g) {
+            a += (double)partial[(int64_t)g * 2 * C + c];
+            b += (double)partial[(int64_t)g * 2 * C + C + c];
+        }
+        cs[c] = a;
+        cq[c] = b;
+        if (dbeta) atomicAdd(dbeta + c, (float)a);
+        if (dgamma) atomicAdd(dgamma + c, (float)b);
+    }
+    __syncthreads();
+    const int cpg = C / ngroups;
+    if ((int)threadIdx.x < ngroups) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+            const double gmm = (double)gamma[threadIdx.x * cpg + j];
+            a += gmm * cs[threadIdx.x * cpg + j];
+            b += gmm * cq[threadIdx.x * cpg + j];
+        }
+        const double m = count * cpg;
+        g1[threadIdx.x] = (float)(a / m);
+        g2[threadIdx.x] = (float)(b / m);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float rstd = saved[C + c];
+        coef[c] = rstd * g1[g];
+        coef[C + c] = rstd * g2[g];
+        coef[2 * C + c] = gamma[c] * rstd;
+    }
+}
+
+extern "C" int tcvom_gn_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int32_t num_groups,
+                                 const float* gamma, const float* beta, float eps, float* scale_shift, float* saved,
+                                 double* scratch, int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && count > 0 && nframes >= 1, "gn_finalize: bad args");
+    TCVOM_CHECK_ARG(C > 0 && C <= 2048 && num_groups > 0 && num_groups <= 64 && C % num_groups == 0, "gn_finalize: C=%d groups=%d", C, num_groups);
+    hipStream_t st = (hipStream_t)stream;
+    if (groups > 4 * BN_SLICES && scratch) {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(gn_finalize_kernel<double>, dim3(nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, num_groups,
+                           (double)count, gamma, beta, eps, scale_shift, saved, slot_stride);
+    } else {
+        hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(nframes), dim3(256), 0, st, partial, groups, C, num_groups, (double)count,
+                           gamma, beta, eps, scale_shift, saved, slot_stride);
+    }
+    TCVOM_LAUNCH_CHECK("gn_finalize");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_gn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int32_t num_groups,
+                                     const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
+                                     double* scratch, int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && count > 0 && nframes >= 1, "gn_bwd_finalize: bad args");
+    TCVOM_CHECK_ARG(C > 0 && C <= 2048 && num_groups > 0 && num_groups <= 64 && C % num_groups == 0, "gn_bwd_finalize: C=%d groups=%d", C, num_groups);
+    hipStream_t st = (hipStream_t)stream;
+    if (groups > 4 * BN_SLICES && scratch) {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel<double>, dim3(nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, num_groups,
+                           (double)count, gamma, saved, dgamma, dbeta, coef, slot_stride);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel<float>, dim3(nframes), dim3(256), 0, st, partial, groups, C, num_groups, (double)count,
+                           gamma, saved, dgamma, dbeta, coef, slot_stride);
+    }
+    TCVOM_LAUNCH_CHECK("gn_bwd_finalize");
     return TCVOM_OK;
 }
 

@@ -18,9 +18,27 @@
 // layer record (int64 words)
 enum {
     SN_W = 0, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD,
-    SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL
+    SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS
 };
-// kind bits: 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual)
+// kind bits: 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual),
+//            8 = weight-standardised (FBA base, models/FBA/layers_WS.py:13-23): packed value = (w - mean_row) * inv_row
+//                with the row statistics at SN_WS_STATS (float4 per output channel: mean, 1/(std + 1e-5), std, unused),
+//           16 = 7x7 stride-2 stem in space-to-depth form: the packed weight is the 4x4 stride-1 kernel over the 2x2
+//                space-to-depth input (T = 16 taps (a, b) in -2..1, Cpad = 64 channels (2p + q) * 16 + c); tap
+//                (a, b), sub-pixel (p, q) holds w[k][c][2a + p + 3][2b + q + 3] (zero outside the 7x7 window)
+
+// 7x7 stem: packed (t, c') -> element offset inside row k of the [C][7][7] kernel, or -1
+__device__ __forceinline__ int stem_src(int t, int cp, int C) {
+    const int a = (t >> 2) - 2, b = (t & 3) - 2, sub = cp >> 4, ch = cp & 15;
+    const int u = 2 * a + (sub >> 1) + 3, v = 2 * b + (sub & 1) + 3;
+    return (ch < C && u >= 0 && u < 7 && v >= 0 && v < 7) ? (ch * 7 + u) * 7 + v : -1;
+}
+// ... and back: element (ch, u, v) -> packed (t, c') as t * 64 + c'
+__device__ __forceinline__ int stem_dst(int ch, int u, int v) {
+    const int uu = u - 3, vv = v - 3;
+    const int a = (uu - (uu & 1)) / 2, p = uu & 1, b = (vv - (vv & 1)) / 2, q = vv & 1;
+    return ((a + 2) * 4 + (b + 2)) * 64 + (p * 2 + q) * 16 + ch;
+}
 
 struct SnScratch {
     float* tvec;      // [sum wd]      W^T u   (zeroed before each iteration)
@@ -136,9 +154,19 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
         c = (int)(idx / ((int64_t)K * T));
     }
     float val = 0.f;
-    if (c < C) {
+    if (kind & 16) {                               // 7x7 stem, space-to-depth taps (forward pack only)
+        const int so = stem_src(t, c, C);
+        if (so >= 0) {
+            const float4 ws = reinterpret_cast<const float4*>(L[SN_WS_STATS])[k];
+            val = (W[(int64_t)k * C * 49 + so] - ws.x) * ws.y;
+        }
+    } else if (c < C) {
         const int64_t src = (kind & 1) ? ((int64_t)c * K + k) * T + t : ((int64_t)k * C + c) * T + t;
         val = W[src] * inv;
+        if (kind & 8) {
+            const float4 ws = reinterpret_cast<const float4*>(L[SN_WS_STATS])[k];
+            val = (W[src] - ws.x) * ws.y;
+        }
         if (part) val -= bf2f(f2bf(val));
     }
     if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + idx] = f2bf(val);
@@ -194,8 +222,12 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
     const int64_t ab = e / T;
     int k, c;
     if (kind & 1) { k = (int)(ab % K); c = (int)(ab / K); } else { c = (int)(ab % C); k = (int)(ab / C); }
-    const int64_t pidx = ((int64_t)k * T + t) * Cp + c;
+    int64_t pidx = ((int64_t)k * T + t) * Cp + c;
     const int row = (int)(e / wd), col = (int)(e % wd);
+    if (kind & 16) {                               // [K][C][7][7] element -> its slot in the [K][16][64] packed gradient
+        const int v = col % 7, u = (col / 7) % 7, ch = col / 49;
+        pidx = (int64_t)row * 16 * 64 + stem_dst(ch, u, v);
+    }
     float g = 0.f;
     const int nc = ncalls[layer];
     for (int call = 0; call < nc; ++call) {
@@ -210,6 +242,63 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
         }
     }
     grad_arena[L[SN_GRAD_OFF] + e] = g;
+}
+
+// ------------------------------------------------------------------------------ weight standardisation
+// one block per (layer, output channel): mean, unbiased variance over the wd = C*R*S elements of the row
+__global__ __launch_bounds__(256) void ws_stats_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work) {
+    __shared__ float red[4];
+    const int layer = work[blockIdx.x * 2], row = work[blockIdx.x * 2 + 1];
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const int wd = (int)L[SN_WD];
+    const float* w = reinterpret_cast<const float*>(L[SN_W]) + (int64_t)row * wd;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < wd; i += 256) a += w[i];
+    const float mean = block_sum_256(a, red) / (float)wd;
+    __syncthreads();
+    float b = 0.f;
+    for (int i = threadIdx.x; i < wd; i += 256) { const float d = w[i] - mean; b += d * d; }
+    const float var = block_sum_256(b, red) / (float)(wd - 1);
+    if (threadIdx.x == 0) {
+        const float sd = sqrtf(var + 1e-12f);
+        reinterpret_cast<float4*>(L[SN_WS_STATS])[row] = make_float4(mean, 1.f / (sd + 1e-5f), sd, 0.f);
+    }
+}
+
+// grad (w.r.t. the standardised weight, already in the parameter's layout) -> grad w.r.t. the raw weight, in place:
+//   w^ = (w - mu) / s,  s = sd + 1e-5,  sd = sqrt(var_unbiased + 1e-12)
+//   dw_i = (g_i - mean(g)) / s  -  (w_i - mu) * <g, w - mu> / (s^2 * sd * (n - 1))
+__global__ __launch_bounds__(256) void ws_backward_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
+                                                          float* __restrict__ grad_arena) {
+    __shared__ float red[4];
+    const int layer = work[blockIdx.x * 2], row = work[blockIdx.x * 2 + 1];
+    const int64_t* L = tab + (int64_t)layer * SN_WORDS;
+    const int wd = (int)L[SN_WD];
+    const float* w = reinterpret_cast<const float*>(L[SN_W]) + (int64_t)row * wd;
+    float* g = grad_arena + L[SN_GRAD_OFF] + (int64_t)row * wd;
+    const float4 ws = reinterpret_cast<const float4*>(L[SN_WS_STATS])[row];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < wd; i += 256) { a += g[i]; b += g[i] * (w[i] - ws.x); }
+    const float gsum = block_sum_256(a, red);
+    __syncthreads();
+    const float gdot = block_sum_256(b, red);
+    const float gmean = gsum / (float)wd;
+    const float k2 = gdot * ws.y * ws.y / (ws.z * (float)(wd - 1));
+    for (int i = threadIdx.x; i < wd; i += 256) g[i] = (g[i] - gmean) * ws.y - (w[i] - ws.x) * k2;
+}
+
+extern "C" int tcvom_ws_stats(const int64_t* table, const int32_t* work_rows, int32_t n_rows, void* stream) {
+    TCVOM_CHECK_ARG(table && work_rows && n_rows > 0, "ws_stats: bad args");
+    hipLaunchKernelGGL(ws_stats_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, table, work_rows);
+    TCVOM_LAUNCH_CHECK("ws_stats");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_ws_backward(const int64_t* table, const int32_t* work_rows, int32_t n_rows, float* grad_arena, void* stream) {
+    TCVOM_CHECK_ARG(table && work_rows && n_rows > 0 && grad_arena, "ws_backward: bad args");
+    hipLaunchKernelGGL(ws_backward_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, table, work_rows, grad_arena);
+    TCVOM_LAUNCH_CHECK("ws_backward");
+    return TCVOM_OK;
 }
 
 static SnScratch mk_scratch(const tcvom_sn_scratch* s) {

@@ -250,6 +250,8 @@ class FullModel_VMD(FullModel):
         H, W = a.shape[-2:]
         assert H % 32 == 0 and W % 32 == 0, 'H and W must be multiples of 32 (pred_vmn.py:90)'
         prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS)
+        if self.method == 'fba':
+            return self._forward_fba(prep, B, S, H, W)
         frames = [prep.x8[:, s].contiguous() for s in range(S)]
         prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
         preds, attb, attf = self.NET.run(frames, prep.unk8)
@@ -262,6 +264,39 @@ class FullModel_VMD(FullModel):
             L_dt = torch.zeros_like(L_att)
         return [L_alpha, zero, zero.clone(), L_dt, L_att,
                 prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
+
+
+    def _forward_fba(self, prep, B, S, H, W):
+        """FBA base (config 5): 8-channel trimap with the distance-transform click maps (models/model.py:71-77), network
+        output (alpha, F, B) per interior frame, fba_single_image_loss + L_att (+ L_dt on alpha, F and B for S >= 5)."""
+        from . import fba_losses as FL
+        x2, extras, _tris = fba_network_input(prep, self.EPS)
+        unk_small = prep.unk[:, :, ::TAM_OS, ::TAM_OS].contiguous()
+        pred, attb, attf = self.NET.run(x2, extras, prep.imgs, unk_small)
+        norm = self.FBA_LOSS_NORMALIZE
+        L1, L2, L3, alphas, comps, Fs, Bs = FL.fba_single_image_loss(pred, prep.trimask, prep.gts, prep.fgs, prep.bgs, prep.imgs, norm)
+        L_att = FL.attention_loss(attb, attf, unk_small, prep.gts, self.window, float(self.att_thres), float(self.label_smooth), TAM_OS)
+        L_att = L_att * self.FBA_L_ATT_MULTIPLIER
+        if S >= 5:
+            L_dt = FL.dtssd(alphas, prep.gts, prep.trimask, norm) + 0.25 * (FL.dtssd(Fs, prep.fgs, prep.trimask, norm) +
+                                                                           FL.dtssd(Bs, prep.bgs, prep.trimask, norm))
+        else:
+            L_dt = torch.zeros_like(L_att)
+        return [L1, L2, L3, L_dt, L_att, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, Fs, Bs]
+
+
+def fba_network_input(prep, eps, want_tris=False):
+    """tcvom_fba_input on the outputs of preprocess_window: (x2 bf16 [B,S,H/2,W/2,64] space-to-depth network input, extras
+    bf16 [B,S,H,W,8], tris fp32 [B,S,8,H,W] or None)."""
+    B, S, _, H, W = prep.gts.shape
+    dev = prep.gts.device
+    x2 = torch.empty((B, S, H // 2, W // 2, 64), dtype=torch.bfloat16, device=dev)
+    extras = torch.empty((B, S, H, W, 8), dtype=torch.bfloat16, device=dev)
+    tris = torch.empty((B, S, 8, H, W), dtype=torch.float32, device=dev) if want_tris else None
+    scratch = torch.empty((B * S, 2, H, W), dtype=torch.float32, device=dev)
+    L.call('tcvom_fba_input', L.ptr(prep.gts), L.ptr(prep.unk), L.ptr(prep.imgs), L.ptr(x2), L.ptr(extras), L.ptr(tris),
+           L.ptr(scratch), B * S, H, W, float(eps), L.stream_ptr())
+    return x2, extras, tris
 
 
 class EvalModel(FullModel):

@@ -12,7 +12,7 @@ import torch.distributed as dist
 from . import _lib as L
 from .conv_plan import ConvGeometry, dense_desc, dense_tt_desc
 
-ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_LEAKY01 = 0, 1, 2, 3        # LeakyReLU(0.2) (GCA decoder) / nn.LeakyReLU() default 0.01 (FBA)
 BF16 = torch.bfloat16
 
 
@@ -32,11 +32,16 @@ def _c(t):
 class ConvCfg(object):
     """Static configuration of one conv(+BN) site of the network."""
 
-    def __init__(self, bank, spec, bn=None, act=ACT_NONE, pre_relu=False, unbias_mult=1):
+    def __init__(self, bank, spec, bn=None, act=ACT_NONE, pre_relu=False, unbias_mult=1, pre_slope=0.0):
+        """bn: nn.BatchNorm2d, nn.GroupNorm (FBA base: statistics per sample, no running state) or None.
+        pre_relu: activation fused into the conv epilogue BEFORE the norm (or the layer's only activation when there is
+        no norm): ReLU, or LeakyReLU(pre_slope) for pre_slope == 0.01."""
         self.bank, self.spec, self.bn = bank, spec, bn
         if bn is not None:
             bank.register_bn(bn)
-        self.act, self.pre_relu, self.unbias_mult = act, pre_relu, unbias_mult
+        assert pre_slope in (0.0, 0.01)
+        self.act, self.pre_relu, self.unbias_mult, self.pre_slope = act, pre_relu, unbias_mult, pre_slope
+        self.group_norm = isinstance(bn, torch.nn.GroupNorm)
         self._geo = {}
 
     def geometry(self, N, H, W):
@@ -131,9 +136,13 @@ class _ConvBNAct(torch.autograd.Function):
         hp = spec.hp and has_bn
         y = torch.empty((NT, geo.OH, geo.OW, K), dtype=torch.float32 if hp else BF16, device=x.device)
         stats = None
-        if has_bn and training:
+        gn = cfg.group_norm
+        if gn:
+            assert N == 1 and not hp, 'GroupNorm: one sample per frame slot (VMN.run flattens the batch into frames)'
+        if has_bn and (training or gn):
             stats = torch.empty(nf * _stats_groups(geo.fwd, nf) * 2 * K, dtype=torch.float32, device=x.device)
-        _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, ACT_RELU if cfg.pre_relu else ACT_NONE, st, nf, wsf)
+        pre_act = (ACT_LEAKY01 if cfg.pre_slope else ACT_RELU) if cfg.pre_relu else ACT_NONE
+        _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, pre_act, st, nf, wsf)
         ctx.cfg, ctx.training, ctx.call, ctx.geo, ctx.nf, ctx.wsb = cfg, training, call, geo, nf, wsb
         ctx.has_res1, ctx.has_res2, ctx.has_bias = res1 is not None, res2 is not None, bias is not None
         if not has_bn:
@@ -148,9 +157,15 @@ class _ConvBNAct(torch.autograd.Function):
         if sync is not None:
             assert nf == 1, 'SyncBatchNorm runs frame by frame (VMN.run switches the frame batching off)'
             P = P * sync[1]
-        ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training, P * cfg.unbias_mult)
+        ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training and not gn, P * cfg.unbias_mult)
         ss, saved = C.c_void_p(ss_i), C.c_void_p(saved_i)
-        if training:
+        if gn:
+            # GroupNorm: per-sample statistics in train AND eval mode, no running state
+            groups = stats.numel() // (2 * K * nf)
+            scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
+            L.call('tcvom_gn_finalize', L.ptr(stats), groups, K, P, bn.num_groups, L.ptr(gamma), L.ptr(beta), float(bn.eps),
+                   ss, saved, L.ptr(scratch), nf, slot_stride, st)
+        elif training:
             groups = stats.numel() // (2 * K * nf)
             scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
             if sync is None:
@@ -192,7 +207,7 @@ class _ConvBNAct(torch.autograd.Function):
             if cfg.pre_relu:
                 x, y = ctx.saved_tensors
                 dy = torch.empty_like(dz)
-                L.call('tcvom_relu_bwd', L.ptr(dz), L.ptr(y), L.ptr(dy), dz.numel(), st)
+                L.call('tcvom_relu_bwd', L.ptr(dz), L.ptr(y), L.ptr(dy), dz.numel(), float(cfg.pre_slope), st)
             else:
                 (x,) = ctx.saved_tensors
                 dy = dz
@@ -214,7 +229,10 @@ class _ConvBNAct(torch.autograd.Function):
             coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
             scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
             sync = ctx.sync if ctx.training else None
-            if sync is None:
+            if cfg.group_norm:
+                L.call('tcvom_gn_bwd_finalize', L.ptr(partial), groups, K, P, cfg.bn.num_groups, L.ptr(gamma), saved, dgp, dbp,
+                       L.ptr(coef), L.ptr(scratch), nf, stride, st)
+            elif sync is None:
                 L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
                        L.ptr(coef), L.ptr(scratch), 1, nf, stride, st)
             else:
@@ -229,7 +247,7 @@ class _ConvBNAct(torch.autograd.Function):
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)
             L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
-                   L.ptr(dres1), P, K, cfg.act, 1 if ctx.training else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
+                   L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
             if ctx.has_bias:
                 # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
                 # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
@@ -237,7 +255,10 @@ class _ConvBNAct(torch.autograd.Function):
                 L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P * nf, K, K, st)
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
-            dx = torch.empty((geo.N * nf, geo.H, geo.W, spec.C), dtype=BF16, device=dz.device)
+            # zero-padded concat inputs (spec.cpad > spec.C): the gradient keeps the padded layout, zeros in the padding
+            cx = spec.cpad if spec.cpad > 8 else spec.C
+            alloc = torch.zeros if cx != spec.C else torch.empty
+            dx = alloc((geo.N * nf, geo.H, geo.W, cx), dtype=BF16, device=dz.device)
             _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st, nf, ctx.wsb)
         # the weight gradients are deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
         bank.defer_wgrad(spec, ctx.call, dy, x, geo, nf)
@@ -394,7 +415,7 @@ class _ConvUnfoldDense(torch.autograd.Function):
         P, K, kred = N * H * W, spec.K, spec.T * Cc
         dz = _c(dz)
         dy = torch.empty_like(dz)
-        L.call('tcvom_relu_bwd', L.ptr(dz), L.ptr(y), L.ptr(dy), dz.numel(), st)
+        L.call('tcvom_relu_bwd', L.ptr(dz), L.ptr(y), L.ptr(dy), dz.numel(), 0.0, st)
         dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
         L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P, K, K, st)
         # du[p][c*T + t] = sum_k dy[p][k] w[k][t][c]: the data-gradient weights are packed [C][T][K]
@@ -454,6 +475,176 @@ def head_conv(x, weight, bias, ksize=3, mode=0):
     return _HeadConv.apply(x, weight, bias, ksize, mode)
 
 
+
+
+# =============================================================================================
+# FBA base: MaxPool2d(3, 2, 1), pyramid pooling, bilinear up-sampling into concat buffers, fused head
+# =============================================================================================
+class _MaxPool3S2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) (models/FBA/resnet_GN_WS.py:101) on NHWC bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, OH, OW, Cc), dtype=BF16, device=x.device)
+        idx = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x.device)
+        L.call('tcvom_maxpool3s2', L.ptr(x), L.ptr(y), L.ptr(idx), N, H, W, Cc, L.stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        L.call('tcvom_maxpool3s2_bwd', L.ptr(_c(dy)), L.ptr(idx), L.ptr(dx), N, H, W, Cc, L.stream_ptr())
+        return dx
+
+
+class _PyramidPool(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(s) for every s of `scales` in one op (models/VMN/VMN_FBA.py:26-30): x [N,h,w,C] bf16 ->
+    tuple of [N,s,s,C] bf16.  The backward adds the gradients of all scales in one pass over x."""
+
+    @staticmethod
+    def forward(ctx, x, scales):
+        x = _c(x)
+        N, h, w, Cc = x.shape
+        st = L.stream_ptr()
+        outs = []
+        for s in scales:
+            o = torch.empty((N, s, s, Cc), dtype=torch.float32, device=x.device)
+            L.call('tcvom_adaptive_avgpool', L.ptr(x), L.ptr(o), N, h, w, Cc, s, st)
+            outs.append(o.to(BF16))
+        ctx.shape, ctx.scales = (N, h, w, Cc), tuple(scales)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        N, h, w, Cc = ctx.shape
+        gs = [_c(d).float() for d in douts]
+        n = len(gs)
+        ptrs = (C.c_void_p * n)(*[g.data_ptr() for g in gs])
+        sc = (C.c_int32 * n)(*ctx.scales)
+        dx = torch.empty(ctx.shape, dtype=BF16, device=gs[0].device)
+        L.call('tcvom_adaptive_avgpool_bwd', C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, L.ptr(dx), N, h, w, Cc, L.stream_ptr())
+        return dx, None
+
+
+class _PyramidConcat(torch.autograd.Function):
+    """cat(conv5, bilinear(pooled_s -> h x w) for every scale) zero-padded to `cpad` channels (VMN_FBA.py:25-31)."""
+
+    @staticmethod
+    def forward(ctx, cpad, x, *maps):
+        x = _c(x)
+        N, h, w, Cx = x.shape
+        st = L.stream_ptr()
+        buf = torch.zeros((N, h, w, cpad), dtype=BF16, device=x.device)
+        buf[..., :Cx].copy_(x)
+        off = Cx
+        shapes = []
+        for m in maps:
+            m = _c(m)
+            _, hs, ws, Cm = m.shape
+            L.call('tcvom_bilinear', L.ptr(m), L.ptr(buf), N, hs, ws, h, w, Cm, Cm, 0, cpad, off, st)
+            shapes.append((hs, ws, Cm, off))
+            off += Cm
+        assert off <= cpad
+        ctx.geo = (N, h, w, Cx, cpad, shapes)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        N, h, w, Cx, cpad, shapes = ctx.geo
+        dbuf = _c(dbuf)
+        st = L.stream_ptr()
+        dx = dbuf[..., :Cx].contiguous()
+        dmaps = []
+        for hs, ws, Cm, off in shapes:
+            d = torch.empty((N, hs, ws, Cm), dtype=torch.float32, device=dbuf.device)
+            L.call('tcvom_bilinear_small_bwd', L.ptr(dbuf), L.ptr(d), N, hs, ws, h, w, Cm, cpad, off, st)
+            dmaps.append(d.to(BF16))
+        return (None, dx) + tuple(dmaps)
+
+
+class _Up2Concat(torch.autograd.Function):
+    """cat(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), skip) zero-padded to `cpad` channels
+    (models/VMN/VMN_FBA.py:37-48): the up-sampling writes straight into its slice of the concat buffer."""
+
+    @staticmethod
+    def forward(ctx, cpad, x, skip):
+        x, skip = _c(x), _c(skip)
+        N, h, w, Cx = x.shape
+        Cs = skip.shape[3]
+        assert skip.shape[:3] == (N, 2 * h, 2 * w) and Cx + Cs <= cpad and Cx % 8 == 0
+        buf = torch.empty((N, 2 * h, 2 * w, cpad), dtype=BF16, device=x.device)
+        L.call('tcvom_bilinear', L.ptr(x), L.ptr(buf), N, h, w, 2 * h, 2 * w, Cx, Cx, 0, cpad, 0, L.stream_ptr())
+        buf[..., Cx:Cx + Cs].copy_(skip)
+        if Cx + Cs < cpad:
+            buf[..., Cx + Cs:].zero_()
+        ctx.geo = (N, h, w, Cx, Cs, cpad)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        N, h, w, Cx, Cs, cpad = ctx.geo
+        dbuf = _c(dbuf)
+        dx = torch.empty((N, h, w, Cx), dtype=BF16, device=dbuf.device)
+        L.call('tcvom_bilinear_up2_bwd', L.ptr(dbuf), L.ptr(dx), N, h, w, Cx, cpad, 0, L.stream_ptr())
+        dskip = dbuf[..., Cx:Cx + Cs].contiguous() if ctx.needs_input_grad[2] else None
+        return None, dx, dskip
+
+
+class _FbaHead(torch.autograd.Function):
+    """conv_up4[4] (1x1, 16 -> 7) + clamp / sigmoid + fba_fusion (models/VMN/VMN_FBA.py:50-57): x [N,H,W,16] bf16,
+    img fp32 [N,3,H,W] (a view with image stride img.stride(0)) -> pred fp32 [N,7,H,W] = (alpha, F, B)."""
+    REPLICAS = 16
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, img):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        assert Cc == 16 and weight.numel() == 7 * 16 and img.shape == (N, 3, H, W) and img.stride()[1:] == (H * W, W, 1)
+        w2 = weight.detach().reshape(7, 16).contiguous().float()
+        pred = torch.empty((N, 7, H, W), dtype=torch.float32, device=x.device)
+        L.call('tcvom_fba_head_fwd', L.ptr(x), L.ptr(w2), L.ptr(bias), L.ptr(img), L.ptr(pred), N, H * W, img.stride(0), 7 * H * W,
+               L.stream_ptr())
+        ctx.save_for_backward(x, w2, bias, img)
+        ctx.wshape = weight.shape
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        x, w2, bias, img = ctx.saved_tensors
+        N, H, W, _ = x.shape
+        dpred = _c(dpred)
+        R = _FbaHead.REPLICAS
+        dx = torch.empty_like(x)
+        dw = torch.zeros((R, 7, 16), dtype=torch.float32, device=x.device)
+        db = torch.zeros((R, 7), dtype=torch.float32, device=x.device)
+        L.call('tcvom_fba_head_bwd', L.ptr(x), L.ptr(w2), L.ptr(bias), L.ptr(img), L.ptr(dpred), L.ptr(dx), L.ptr(dw), L.ptr(db), R, N,
+               H * W, img.stride(0), 7 * H * W, L.stream_ptr())
+        return dx, dw.sum(0).reshape(ctx.wshape), db.sum(0), None
+
+
+maxpool3s2 = _MaxPool3S2.apply
+
+
+def pyramid_pool(x, scales):
+    return _PyramidPool.apply(x, tuple(scales))
+
+
+def pyramid_concat(cpad, x, maps):
+    return _PyramidConcat.apply(cpad, x, *maps)
+
+
+def up2_concat(cpad, x, skip):
+    return _Up2Concat.apply(cpad, x, skip)
+
+
+fba_head = _FbaHead.apply
 
 
 # =============================================================================================

@@ -177,9 +177,12 @@ def build_vmn_gca(agg_window, agg_reduction=1, freeze_backbone=False):
 
 
 def get_VMN_models(arch, agg_window, agg_reduction=1, freeze_backbone=False, **kwargs):
-    """models/VMN/__init__.py:11-29.  Only `vmn_gca` is built on the HIP path in this round."""
+    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4) and `vmn_fba` (config 5) run on the HIP path."""
     if arch == 'vmn_gca':
         return build_vmn_gca(agg_window, agg_reduction, freeze_backbone)
-    if arch in ('vmn_dim', 'vmn_fba', 'vmn_index'):
+    if arch == 'vmn_fba':
+        from .fba_net import build_vmn_fba
+        return build_vmn_fba(agg_window, agg_reduction, freeze_backbone)
+    if arch in ('vmn_dim', 'vmn_index'):
         raise NotImplementedError('%s: only the vmn_gca hot path is implemented on MI355X so far (SURVEY.md §8)' % arch)
     raise ValueError

@@ -18,18 +18,27 @@ from . import _lib as L
 
 SN_WORDS = 24
 (SN_W, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD, SN_FWD_OFF, SN_BWD_OFF,
- SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL) = range(17)
+ SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS) = range(18)
 
 
 def _r8(n):
     return (n + 7) // 8 * 8
 
 
+def _nch(norm):
+    """Channels of a BatchNorm2d / GroupNorm."""
+    return norm.num_features if hasattr(norm, 'num_features') else norm.num_channels
+
+
 class ConvSpec(object):
     """Static description of one conv weight registered in the bank."""
 
-    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True, hp=False):
+    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True, hp=False,
+                 dilation=1, ws=False, stem=False, cpad=None):
+        """ws: weight-standardised conv of the FBA base (models/FBA/layers_WS.py:13-23).  stem: the 7x7 stride-2 pad-3
+        input conv of its ResNet, run as a 4x4 stride-1 conv over the 2x2 space-to-depth input (16 taps x 64 channels)."""
         self.name = name
+        self.dilation, self.ws, self.stem = dilation, ws, stem
         self.hp = hp                         # high-precision forward: packed weight = bf16 hi + bf16 residual (2T slots)
         self.weight, self.u, self.v, self.bias = weight, u, v, bias
         self.transposed = transposed
@@ -44,7 +53,13 @@ class ConvSpec(object):
         self.spectral = u is not None
         self.group = group                   # 'frame' (S calls per window) | 'tail' (S-2 calls)
         self.needs_dgrad = needs_dgrad
-        self.cpad = max(8, _r8(self.C))
+        # cpad: channels of the (zero-padded) input buffer; the engine wants a power of two for multi-tap convs, so the
+        # concat inputs of the FBA decoder (3072, 320, 72 channels) are padded to 4096 / 512 / 128
+        self.cpad = max(8, _r8(self.C)) if cpad is None else int(cpad)
+        assert self.cpad >= self.C and self.cpad % 8 == 0
+        if stem:
+            assert shp[2:] == (7, 7) and stride == 2 and pad == 3 and self.C <= 16 and not transposed and not needs_dgrad
+            self.T, self.cpad = 16, 64          # packed geometry; C / R / S keep the parameter's shape
         self.numel = weight.numel()
         self.h = shp[0]
         self.wd = self.numel // shp[0]
@@ -73,7 +88,7 @@ class WeightBank(object):
         idx = len(self.bns)
         bn._tcvom_bank_idx, bn._tcvom_ch_off = idx, self.bn_ch
         self.bns.append(bn)
-        self.bn_ch += bn.num_features
+        self.bn_ch += _nch(bn)
         self._bn_sig = None
         return idx
 
@@ -81,7 +96,7 @@ class WeightBank(object):
         if not self.bns:
             return
         cap = max(int(frames), 1)
-        sig = (cap, dev) + tuple(bn.running_mean.data_ptr() for bn in self.bns)
+        sig = (cap, dev) + tuple((bn.weight.data_ptr(), bn.running_mean.data_ptr() if hasattr(bn, 'running_mean') else 0) for bn in self.bns)
         if sig != self._bn_sig:
             self._bn_sig, self._bn_cap = sig, cap
             self.bn_arena = torch.empty(cap * 4 * self.bn_ch, dtype=torch.float32, device=dev)
@@ -89,9 +104,12 @@ class WeightBank(object):
             self._bn_arena_ptr, self._bn_grad_ptr = self.bn_arena.data_ptr(), self.bn_grad.data_ptr()
             rows = []
             for bn in self.bns:
-                Cn = bn.num_features
-                mom = 0.1 if bn.momentum is None else float(bn.momentum)
+                Cn = _nch(bn)
+                mom = 0.1 if getattr(bn, 'momentum', None) is None else float(bn.momentum)
                 packed = int.from_bytes(struct.pack('<ff', mom, float(bn.eps)), 'little', signed=True)
+                if not hasattr(bn, 'running_mean'):           # GroupNorm: never part of an EMA launch (mask stays 0)
+                    rows.append([0, 0, 0, Cn, 4 * self.bn_ch, packed])
+                    continue
                 rows.append([bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                              self._bn_arena_ptr + 4 * (4 * bn._tcvom_ch_off + 2 * Cn), Cn, 4 * self.bn_ch, packed])
             self.bn_table = torch.tensor(rows, dtype=torch.int64).to(dev)
@@ -110,7 +128,7 @@ class WeightBank(object):
             self.bn_mask[idx] |= ((1 << nf) - 1) << c
             self.bn_unbias[idx] = unbias_count / (unbias_count - 1.0) if unbias_count > 1 else 1.0
         base = self._bn_arena_ptr + 4 * (c * 4 * self.bn_ch + 4 * bn._tcvom_ch_off)
-        return base, base + 8 * bn.num_features, 4 * self.bn_ch
+        return base, base + 8 * _nch(bn), 4 * self.bn_ch
 
     def bn_slot(self, bn, training, unbias_count):
         return self.bn_slots(bn, 1, training, unbias_count)[:2]
@@ -118,7 +136,7 @@ class WeightBank(object):
     def bn_grad_ptrs(self, bn):
         self.bn_touched[bn._tcvom_bank_idx] = True
         base = self._bn_grad_ptr + 8 * bn._tcvom_ch_off
-        return base, base + 4 * bn.num_features
+        return base, base + 4 * _nch(bn)
 
     def bn_params(self):
         out = []
@@ -133,7 +151,7 @@ class WeightBank(object):
         g = self.bn_grad.clone()
         out = []
         for bn, hit in zip(self.bns, self.bn_touched):
-            o, Cn = 2 * bn._tcvom_ch_off, bn.num_features
+            o, Cn = 2 * bn._tcvom_ch_off, _nch(bn)
             out += [g[o:o + Cn], g[o + Cn:o + 2 * Cn]] if hit else [None, None]
         return out
 
@@ -179,7 +197,9 @@ class WeightBank(object):
             tab[i, SN_U] = s.u.data_ptr() if s.spectral else 0
             tab[i, SN_V] = s.v.data_ptr() if s.spectral else 0
             tab[i, SN_H], tab[i, SN_WD] = s.h, s.wd
-            tab[i, SN_KIND] = (1 if s.transposed else 0) | (0 if s.spectral else 2) | (4 if s.hp else 0)
+            tab[i, SN_KIND] = ((1 if s.transposed else 0) | (0 if s.spectral else 2) | (4 if s.hp else 0) |
+                               (8 if s.ws else 0) | (16 if s.stem else 0))
+            assert not (s.ws and (s.spectral or s.transposed or s.hp)) and (s.ws or not s.stem)
             tab[i, SN_K], tab[i, SN_C], tab[i, SN_T], tab[i, SN_CPAD] = s.K, s.C, s.T, s.cpad
             tab[i, SN_FWD_OFF] = fwd_off
             s.fwd_off = fwd_off
@@ -202,6 +222,15 @@ class WeightBank(object):
             s.grad_off = g_off
             g_off += s.numel
             tab[i, SN_NUMEL] = s.numel
+        ws = [s for s in specs if s.ws]
+        self.ws_stats = torch.zeros(max(1, 4 * sum(s.h for s in ws)), dtype=torch.float32, device=device)
+        off = 0
+        for s in ws:
+            tab[s.layer_id, SN_WS_STATS] = self.ws_stats.data_ptr() + 4 * off
+            off += 4 * s.h
+        rows = [(s.layer_id, r) for s in ws for r in range(s.h)]
+        self.work_ws = torch.tensor(rows, dtype=torch.int32).reshape(-1).to(device) if rows else None
+        self.n_ws = len(rows)
         self.device = device
         self.table = tab.to(device)
         self.fwd_stride, self.bwd_stride, self.dw_stride = _r8(fwd_off), _r8(bwd_off), _r8(dw_off)
@@ -291,6 +320,8 @@ class WeightBank(object):
         if self.bns and training:
             self.bn_grad.zero_()
         self.window_id += 1
+        if self.n_ws:
+            L.call('tcvom_ws_stats', L.ptr(self.table), L.ptr(self.work_ws), self.n_ws, st)
         for call in range(plan['iters']):
             if training and call > 0:
                 # layers with fewer calls keep iterating harmlessly only if still needed; tail layers
@@ -406,6 +437,8 @@ class WeightBank(object):
         L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), L.ptr(plan['work_inner']), plan['n_inner'],
                L.ptr(self.work_apply), self.n_apply, L.ptr(plan['ncalls_dev']), L.ptr(self.dw_arena), self.dw_stride,
                L.ptr(self.inner), self.max_calls, L.ptr(grad), L.stream_ptr())
+        if self.n_ws:
+            L.call('tcvom_ws_backward', L.ptr(self.table), L.ptr(self.work_ws), self.n_ws, L.ptr(grad), L.stream_ptr())
         return [grad[s.grad_off:s.grad_off + s.numel].view(s.weight.shape) for s in self.specs]
 
 

@@ -86,6 +86,15 @@ class Checker(object):
         err = float((got - want).abs().max() / (want.abs().max() + 1e-12))
         self.rows.append((name, err, tol, err <= tol))
 
+    def l2(self, name, got, want, tol):
+        """relative L2 error: for element-wise quantities behind an activation mask, where a single rounding-induced
+        mask flip is a large LOCAL error but a negligible part of the tensor"""
+        got = torch.as_tensor(np.asarray(got.detach().float().cpu() if torch.is_tensor(got) else got)).double()
+        want = torch.as_tensor(np.asarray(want.detach().float().cpu() if torch.is_tensor(want) else want)).double()
+        assert got.shape == want.shape, '%s: shape %s vs %s' % (name, tuple(got.shape), tuple(want.shape))
+        err = float((got - want).norm() / (want.norm() + 1e-12))
+        self.rows.append((name + '(L2)', err, tol, err <= tol))
+
     def done(self):
         msg = ', '.join('%s=%.2e%s' % (n, e, '' if ok else ' (> %.1e!)' % t) for n, e, t, ok in self.rows)
         print(msg)

@@ -1,0 +1,296 @@
+"""GPU parity tests of the FBA base + TAM (BASELINE.json config 5) on the HIP path: the FBA-only kernels against PyTorch /
+the CPU oracle, and FullModel_VMD('vmn_fba') against vectors captured from the reference
+(tests/golden/gen_golden.py:gen_fba)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from helpers import hu, golden, assert_close, Checker, FBA_CASES, FBA_FULL_GRADS
+from tcvom_amd.synthetic import formula_tensor, synthetic_window
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def nchw(t):
+    return t.detach().permute(0, 3, 1, 2).float().cpu()
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def test_maxpool_3x3_stride2_bit_exact():
+    """nn.MaxPool2d(3, 2, 1) and its gradient: selections on bf16 values, bit-identical to PyTorch (first maximum wins)."""
+    from tcvom_amd import ops
+    x = bf((hu('fba.pool.x', (2, 16, 12, 20)) * 4).round() / 4)
+    xg = nhwc(x).requires_grad_(True)
+    y = ops.maxpool3s2(xg)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(nchw(y), yr.detach())
+    gy = bf(hu('fba.pool.gy', tuple(yr.shape)))
+    y.backward(nhwc(gy))
+    yr.backward(gy)
+    assert_close(nchw(xg.grad), bf(xr.grad), 1e-2, 1e-2, 'maxpool3s2 dx')       # up to 4 bf16 terms summed in fp32, rounded once
+
+
+@pytest.mark.parametrize('h,w', [(12, 18), (17, 30)])
+def test_pyramid_pooling_and_concat(h, w):
+    """AdaptiveAvgPool2d(1, 2, 3, 6) -> (identity instead of the conv) -> bilinear back to h x w -> concat, fwd + bwd."""
+    from tcvom_amd import ops
+    N, Cc = 2, 64
+    x = bf(hu('fba.ppm.x', (N, Cc, h, w)))
+    xg = nhwc(x).requires_grad_(True)
+    pooled = ops.pyramid_pool(xg, (1, 2, 3, 6))
+    buf = ops.pyramid_concat(512, xg, pooled)
+    xr = x.clone().requires_grad_(True)
+    parts = [xr] + [F.interpolate(bf(F.adaptive_avg_pool2d(xr, s)), (h, w), mode='bilinear', align_corners=False) for s in (1, 2, 3, 6)]
+    ref = torch.cat(parts, 1)
+    for i, s in enumerate((1, 2, 3, 6)):
+        assert_close(nchw(pooled[i]), F.adaptive_avg_pool2d(x, s), 1e-2, 1e-2, 'pool %d' % s)
+    got = nchw(buf)
+    assert_close(got[:, :5 * Cc], ref.detach(), 1e-2, 1e-2, 'concat')
+    assert float(got[:, 5 * Cc:].abs().max()) == 0.0
+    g = bf(hu('fba.ppm.g', (N, 512, h, w)))
+    buf.backward(nhwc(g))
+    ref.backward(g[:, :5 * Cc])
+    assert_close(nchw(xg.grad), xr.grad, 2e-2, 2e-2 * float(xr.grad.abs().max()), 'dx')
+
+
+def test_bilinear_up2_concat():
+    from tcvom_amd import ops
+    N, Cx, Cs, h, w = 2, 32, 16, 9, 14
+    x, skip = bf(hu('fba.up.x', (N, Cx, h, w))), bf(hu('fba.up.s', (N, Cs, 2 * h, 2 * w)))
+    xg, sg = nhwc(x).requires_grad_(True), nhwc(skip).requires_grad_(True)
+    buf = ops.up2_concat(64, xg, sg)
+    xr, sr = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    ref = torch.cat([F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False), sr], 1)
+    got = nchw(buf)
+    assert_close(got[:, :Cx + Cs], ref.detach(), 1e-2, 1e-2, 'up2 concat')
+    assert float(got[:, Cx + Cs:].abs().max()) == 0.0
+    g = bf(hu('fba.up.g', (N, 64, 2 * h, 2 * w)))
+    buf.backward(nhwc(g))
+    ref.backward(g[:, :Cx + Cs])
+    assert_close(nchw(xg.grad), xr.grad, 1e-2, 1e-2 * float(xr.grad.abs().max()), 'dx')
+    assert torch.equal(nchw(sg.grad), sr.grad)
+
+
+def test_head_fusion_forward_backward():
+    """1x1 conv 16 -> 7 + clamp / sigmoid + fba_fusion against the oracle's fusion under torch autograd."""
+    from oracle import fba_net
+    from tcvom_amd import ops
+    N, H, W = 2, 12, 20
+    x = bf(hu('fba.head.x', (N, 16, H, W)))
+    w = (hu('fba.head.w', (7, 16, 1, 1)) * 1.5).to(DEV).requires_grad_(True)
+    b = torch.tensor([0.5, 0.1, -0.2, 0.3, 0.0, 0.2, -0.1]).to(DEV).requires_grad_(True)
+    img = (hu('fba.head.img', (N, 3, H, W)) * 0.5 + 0.5).to(DEV)
+    xg = nhwc(x).requires_grad_(True)
+    pred = ops.fba_head(xg, w, b, img)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.detach().cpu().clone().requires_grad_(True), b.detach().cpu().clone().requires_grad_(True)
+    o = F.conv2d(xr, wr, br)
+    a, Fg, Bg = fba_net.fba_fusion(o[:, :1].clamp(0, 1), img.cpu(), torch.sigmoid(o[:, 1:4]), torch.sigmoid(o[:, 4:7]))
+    ref = torch.cat([a, Fg, Bg], 1)
+    assert_close(pred, ref, 1e-4, 1e-5, 'pred')
+    frac_mid = float(((ref[:, 0] > 0) & (ref[:, 0] < 1)).float().mean())
+    assert frac_mid > 0.3, 'test data must exercise the unclamped branch (%.2f)' % frac_mid
+    g = hu('fba.head.g', tuple(ref.shape))
+    pred.backward(g.to(DEV))
+    ref.backward(g)
+    ck = Checker()
+    ck.rel('dx', nchw(xg.grad), xr.grad, 1e-2)
+    ck.rel('dw', w.grad, wr.grad, 1e-4)
+    ck.rel('db', b.grad, br.grad, 1e-4)
+    ck.done()
+
+
+@pytest.mark.parametrize('H,W,dil', [(64, 96, 5), (32, 64, 0)])
+def test_trimap_transform_input(H, W, dil):
+    """8-channel trimap (exact Euclidean distance transform + Gaussian click maps) and the space-to-depth network input
+    against the oracle's make_trimap8 (scipy EDT)."""
+    from oracle import fba_net
+    from tcvom_amd.facade import preprocess_window, fba_network_input
+    B, S = 1, 3
+    a, fg, bg = synthetic_window(B, S, H, W, seed=3)
+    prep = preprocess_window(a.to(DEV), fg.to(DEV), bg.to(DEV), dil, 0.0)
+    x2, extras, tris = fba_network_input(prep, 0.0, want_tris=True)
+    want, _ = fba_net.make_trimap8(a / 255.0, dil)
+    assert_close(tris[:, :, 6:], want[:, :, 6:], 0, 0, 'indicator channels')
+    assert_close(tris[:, :, :6], want[:, :, :6], 1e-4, 1e-6, 'click maps')
+    assert float(want[:, :, :6].max()) > 0.5 and float(want[:, :, :6].min()) < 0.5
+    # network input: channel c of pixel (2i+p, 2j+q) sits at x2[..., i, j, 16*(2p+q) + c]
+    imgs = prep.imgs.cpu()
+    mean = torch.tensor([0.485, 0.456, 0.406]).reshape(1, 1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).reshape(1, 1, 3, 1, 1)
+    full = torch.cat([(imgs - mean) / std, tris.cpu()], 2)                       # [B,S,11,H,W]
+    x2c = x2.float().cpu().reshape(B, S, H // 2, W // 2, 2, 2, 16)             # (.., i, j, p, q, c)
+    got = x2c.permute(0, 1, 6, 2, 4, 3, 5).reshape(B, S, 16, H, W)
+    assert_close(got[:, :, :11], bf(full), 1e-2, 1e-2, 'space-to-depth input')
+    assert float(got[:, :, 11:].abs().max()) == 0.0
+    ex = extras.float().cpu().permute(0, 1, 4, 2, 3)
+    assert_close(ex[:, :, 0:3], bf((imgs - mean) / std), 1e-2, 1e-2, 'extras: normalised image')
+    assert_close(ex[:, :, 3:6], bf(imgs), 1e-2, 1e-2, 'extras: image')
+    assert torch.equal(ex[:, :, 6:8], want[:, :, 6:8])
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,dil,act,res', [(64, 64, 3, 1, 2, 0, False), (128, 64, 1, 1, 1, 0, True), (64, 128, 3, 2, 1, 0, False),
+                                                             (96, 64, 3, 1, 1, 0, False), (64, 64, 3, 1, 4, 1, True), (64, 64, 3, 1, 1, 3, False)])
+def test_ws_conv_groupnorm_block(cin, cout, k, stride, dil, act, res):
+    """Weight-standardised conv (+bias) + GroupNorm(32) + ReLU / LeakyReLU(0.01) (+ residual before the activation), three
+    samples in one launch with per-sample statistics, against oracle.fba_net.ws_conv + F.group_norm: outputs, input
+    gradient, and the gradients of the RAW weight (through the standardisation), bias, gamma and beta."""
+    from oracle import fba_net
+    from tcvom_amd import ops
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    NF, H, W = 3, 12, 20
+    tag = 'fbacg%d_%d_%d_%d' % (cin, cout, k, dil)
+    cpad = 128 if cin == 96 else None                                          # a zero-padded concat input
+    pad = dil if k == 3 else 0
+    w = nn.Parameter((formula_tensor('%s.weight' % tag, (cout, cin, k, k)) * 3 + 0.02).to(DEV))
+    b = nn.Parameter(formula_tensor('%s.bias' % tag, (cout,)).to(DEV))
+    gn = nn.GroupNorm(32, cout).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(formula_tensor('gn.weight', (cout,)))
+        gn.bias.copy_(formula_tensor('gn.bias', (cout,)))
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, None, None, b, False, stride, pad, 'frame', dilation=dil, ws=True, cpad=cpad)
+    bank.register(spec)
+    cfg = ops.ConvCfg(bank, spec, bn=gn, act=act)
+    x = bf(hu('x.' + tag, (NF, cin, H, W)) * torch.tensor([1.0, 2.0, 0.5]).reshape(3, 1, 1, 1))
+    xin = x if cpad is None else torch.cat([x, torch.zeros(NF, cpad - cin, H, W)], 1)
+    xg = nhwc(xin).requires_grad_(True)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = bf(hu('r.' + tag, (NF, cout, OH, OW))) if res else None
+    rg = nhwc(r).requires_grad_(True) if res else None
+    token = bank_token(bank, NF, True)
+    bank.frames_per_op = NF
+    z = ops.conv_bn_act(cfg, xg, token, True, res1=rg)
+    bank.frames_per_op = 1
+    state = {'c.weight': w.detach().cpu().clone().requires_grad_(True), 'c.bias': b.detach().cpu().clone().requires_grad_(True),
+             'n.weight': gn.weight.detach().cpu().clone().requires_grad_(True), 'n.bias': gn.bias.detach().cpu().clone().requires_grad_(True)}
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    y = fba_net.group_norm(state, 'n', fba_net.ws_conv(state, 'c', xr, stride, pad, dil))
+    if res:
+        y = y + rr
+    zr = y if act == 0 else (F.relu(y) if act == 1 else F.leaky_relu(y, 0.01))
+    # a mostly positive upstream gradient: the parameter gradients are then sums WITHOUT cancellation, so the few
+    # activation-mask flips that bf16 rounding of the conv output causes (|pre-activation| ~ 1e-3) stay negligible
+    g = bf(hu('g.' + tag, tuple(zr.shape)) * 0.5 + 0.75)
+    z.backward(nhwc(g))
+    zr.backward(g)
+    # without an activation every quantity is a smooth function of the bf16-rounded tensors (tight bounds); behind a
+    # ReLU / LeakyReLU about 0.04 % of the masks flip (|pre-activation| below the bf16 rounding of the conv output),
+    # each an O(1) local change: ~2.5 % of the L2 norm of the masked gradient and of everything computed from it
+    t = 1.5e-2 if act == 0 else 1e-1
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.l2('dx', nchw(xg.grad)[:, :cin], xr.grad, t)
+    ck.l2('dw', w.grad, state['c.weight'].grad, t)
+    ck.rel('dbias', b.grad, state['c.bias'].grad, 2 * t)
+    ck.rel('dgamma', gn.weight.grad, state['n.weight'].grad, t)
+    ck.rel('dbeta', gn.bias.grad, state['n.bias'].grad, t)
+    if res:
+        ck.l2('dres', nchw(rg.grad), rr.grad, t)
+    ck.done()
+    if cpad is not None:
+        assert float(nchw(xg.grad)[:, cin:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('act', [0, 1])
+def test_stem_7x7_space_to_depth(act):
+    """The 11-channel 7x7 stride-2 stem as a 4x4 conv over the space-to-depth input: output and weight gradient."""
+    from oracle import fba_net
+    from tcvom_amd import ops
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    NF, H, W = 2, 24, 40
+    w = nn.Parameter((formula_tensor('stem.weight', (64, 11, 7, 7)) * 2).to(DEV))
+    gn = nn.GroupNorm(32, 64).to(DEV)
+    bank = WeightBank()
+    spec = ConvSpec('stem', w, None, None, None, False, 2, 3, 'frame', needs_dgrad=False, ws=True, stem=True)
+    bank.register(spec)
+    cfg = ops.ConvCfg(bank, spec, bn=gn, act=act)
+    x = bf(hu('x.stem', (NF, 11, H, W)))
+    x16 = torch.cat([x, torch.zeros(NF, 5, H, W)], 1)
+    x2 = x16.reshape(NF, 16, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(NF, H // 2, W // 2, 64)
+    token = bank_token(bank, NF, True)
+    bank.frames_per_op = NF
+    z = ops.conv_bn_act(cfg, x2.contiguous().to(torch.bfloat16).to(DEV), token, True)
+    bank.frames_per_op = 1
+    state = {'c.weight': w.detach().cpu().clone().requires_grad_(True), 'n.weight': gn.weight.detach().cpu().clone(),
+             'n.bias': gn.bias.detach().cpu().clone()}
+    zr = fba_net.group_norm(state, 'n', fba_net.ws_conv(state, 'c', x, 2, 3))
+    zr = F.relu(zr) if act else zr
+    g = bf(hu('g.stem', tuple(zr.shape)) * 0.5 + 0.75)
+    z.backward(nhwc(g))
+    zr.backward(g)
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.l2('dw', w.grad, state['c.weight'].grad, 1.5e-2 if act == 0 else 1e-1)
+    ck.done()
+
+
+def _build(name, dil, S):
+    from tcvom_amd.facade import FullModel_VMD
+    fm = FullModel_VMD('vmn_fba', agg_window=7, dilate_kernel=dil)
+    sd = fm.NET.state_dict()
+    fm.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in sd.items()})
+    return fm.to(DEV).train()
+
+
+def test_state_dict_layout_matches_reference():
+    from tcvom_amd.facade import FullModel_VMD
+    g = golden('fba_state_keys')
+    sd = FullModel_VMD('vmn_fba', agg_window=7).NET.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['keys']]
+    assert [','.join(str(int(d)) for d in v.shape) for v in sd.values()] == [str(s) for s in g['shapes']]
+
+
+@pytest.mark.parametrize('name', list(FBA_CASES))
+def test_window_against_reference_golden(name):
+    """FullModel_VMD('vmn_fba') forward + backward of the train_ddp.py loss against the reference's outputs on the same
+    formula weights and synthetic clip.  bf16 activations through ~60 conv layers: losses to 3 %, alpha MSE <= 1e-4
+    (BASELINE.json tolerance), gradients by norm."""
+    B, S, H, W, dil = FBA_CASES[name]
+    g = golden(name)
+    fm = _build(name, dil, S)
+    a, fg, bg = synthetic_window(B, S, H, W, seed=2)
+    out = fm(a.to(DEV), fg.to(DEV), bg.to(DEV))
+    losses = torch.stack([o.detach().float().cpu() for o in out[:5]])
+    want = torch.from_numpy(g['losses'])
+    print('losses', losses.tolist(), want.tolist())
+    (out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]).backward()
+    ck = Checker()
+    for i, nm in enumerate(('L_alpha_comp', 'L_lap', 'L_grad', 'L_dt', 'L_att')):
+        if float(want[i]) != 0:
+            ck.rel(nm, losses[i], want[i], 5e-2)
+        else:
+            assert float(losses[i]) == 0
+    mse = float(((out[7].cpu() - torch.from_numpy(g['alphas'])) ** 2).mean())
+    assert mse <= 1e-4, 'alpha MSE %.3e' % mse
+    for i, k in ((8, 'comps'), (10, 'Fs'), (11, 'Bs')):
+        m = float(((out[i].cpu() - torch.from_numpy(g[k])) ** 2).mean())
+        assert m <= 2e-4, '%s MSE %.3e' % (k, m)
+    names = [str(n) for n in g['grad_names']]
+    params = dict(fm.NET.named_parameters())
+    assert all(params[n].grad is not None for n in names), [n for n in names if params[n].grad is None][:5]
+    got = np.array([float(params[n].grad.double().norm()) for n in names])
+    wn = g['grad_norms']
+    cos_like = abs(np.linalg.norm(got) - np.linalg.norm(wn)) / np.linalg.norm(wn)
+    print('grad norm total rel diff %.3f; worst per-parameter %.3f' % (cos_like, np.max(np.abs(got - wn) / (wn + 1e-9))))
+    ck.rel('grad norm (all parameters)', torch.tensor(np.linalg.norm(got)), torch.tensor(np.linalg.norm(wn)), 0.15)
+    for k in FBA_FULL_GRADS:
+        ref = torch.from_numpy(g['grad:' + k])
+        gk = params[k].grad.float().cpu()
+        cs = float((gk * ref).sum() / (gk.norm() * ref.norm() + 1e-30))
+        # encoder.bn1 sits below all 60 layers: its gradient is the most rounding-sensitive quantity of the step
+        tol = 0.25 if k.startswith('encoder.') else 0.05
+        ck.rows.append(('cos ' + k, 1 - cs, tol, 1 - cs <= tol))
+    ck.done()

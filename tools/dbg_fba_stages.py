@@ -1,0 +1,44 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+from helpers import fba_formula_state
+from oracle import fba_net as O
+from tcvom_amd.facade import FullModel_VMD, preprocess_window, fba_network_input
+from tcvom_amd.synthetic import formula_tensor, synthetic_window
+from tcvom_amd.weights import bank_token
+DEV = 'cuda'
+B, S, H, W, dil = 1, 3, 64, 64, 3
+a, fg, bg = synthetic_window(B, S, H, W, seed=2)
+state = fba_formula_state(False)
+out, ex = O.fba_window_forward(state, a, fg, bg, window=7, dilate_kernel=dil)
+fm = FullModel_VMD('vmn_fba', agg_window=7, dilate_kernel=dil)
+fm.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in fm.NET.state_dict().items()})
+fm = fm.to(DEV).train()
+prep = preprocess_window(a.to(DEV), fg.to(DEV), bg.to(DEV), dil, 0.0)
+x2, extras, _ = fba_network_input(prep, 0.0)
+net = fm.NET
+bank = net._bank
+F_ = B * S
+token = bank_token(bank, F_, True)
+fmj = lambda t: t.transpose(0, 1).reshape((S * B,) + tuple(t.shape[2:]))
+bank.frames_per_op = F_
+with torch.no_grad():
+    outs = net.encoder.run(fmj(x2), token, True)
+    feat = net.decoder.run_feature(outs[-1], token, True)
+bank.frames_per_op = 1
+def rel(got, want):
+    got = got.permute(0, 3, 1, 2).float().cpu()
+    return float((got - want).norm() / want.norm())
+names = ['os2', 'os4', 'os8a', 'os8b', 'os8c']
+for i, n in enumerate(names):
+    want = torch.cat([ex['conv_outs'][s][i + 1] for s in range(S)], 0)
+    print('%-6s rel L2 err %.4f' % (n, rel(outs[i], want)))
+want = torch.cat(ex['features'], 0)
+print('feat   rel L2 err %.4f' % rel(feat, want))
+res = fm(a.to(DEV), fg.to(DEV), bg.to(DEV))
+pr = ex['preds'][:, 1]
+al = res[7][:, 1].cpu()
+m = ex['trimasks'][:, 1] > 0
+print('alpha(refined) rms err in unknown', float(((al - out[7][:, 1])[m] ** 2).mean().sqrt()), 'n unknown', int(m.sum()), 'of', m.numel())
+print('alpha MSE all', float(((res[7].cpu() - out[7]) ** 2).mean()))
