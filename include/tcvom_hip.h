@@ -322,7 +322,8 @@ int tcvom_fba_head_bwd(const void* x, const float* w, const float* b, const floa
  * make_trimap with 8 channels (models/model.py:71-77) incl. trimap_transform (utils/utils.py:12-39; exact Euclidean
  * distance transform, the reference calls cv2.distanceTransform on the host).  x2: bf16 [frames][H/2][W/2][64], the 2x2
  * space-to-depth form of cat(normalised RGB, 6 click maps, bg, fg) (16 channels per sub-pixel, 11 used); extras: bf16
- * [frames][H][W][8] = (normalised RGB, RGB, bg, fg); tris (optional): fp32 [frames][8][H][W]; edt_scratch: frames*2*H*W floats */
+ * [frames][H][W][8] = (normalised RGB, RGB, bg, fg); tris (optional): fp32 [frames][8][H][W]; edt_scratch: frames*2*H*W floats.
+ * unk_dil == NULL: EvalModel.preprocess (models/model.py:380-385), the classes come from the user trimap `gts` alone */
 int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const float* imgs, void* x2, void* extras, float* tris,
                     float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream);
 

@@ -484,7 +484,7 @@ __global__ void edt_columns_kernel(const float* __restrict__ gts, const uint8_t*
         float* o = g2 + ((f * 2 + k) * H) * W + w;
         float dist = EDT_INF;
         for (int h = 0; h < H; ++h) {
-            dist = fba_class(a[(int64_t)h * W], d[(int64_t)h * W], eps) == k ? 0.f : (dist < EDT_INF ? dist + 1.f : EDT_INF);
+            dist = fba_class(a[(int64_t)h * W], dil ? d[(int64_t)h * W] : (uint8_t)0, eps) == k ? 0.f : (dist < EDT_INF ? dist + 1.f : EDT_INF);
             o[(int64_t)h * W] = dist;
         }
         dist = EDT_INF;
@@ -534,7 +534,7 @@ __global__ void fba_input_kernel(const float* __restrict__ gts, const uint8_t* _
         const int w = (int)(v % W);
         const int h = (int)((v / W) % H);
         const int64_t f = v / ((int64_t)H * W);
-        const int cls = fba_class(gts[v], dil[v], eps);
+        const int cls = fba_class(gts[v], dil ? dil[v] : (uint8_t)0, eps);
         float e[8];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -557,7 +557,7 @@ __global__ void fba_input_kernel(const float* __restrict__ gts, const uint8_t* _
 
 extern "C" int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const float* imgs, void* x2, void* extras, float* tris,
                                float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream) {
-    TCVOM_CHECK_ARG(gts && unk_dil && imgs && x2 && extras && edt_scratch && frames > 0 && H % 2 == 0 && W % 2 == 0 && W <= 8192, "fba_input: bad args");
+    TCVOM_CHECK_ARG(gts && imgs && x2 && extras && edt_scratch && frames > 0 && H % 2 == 0 && W % 2 == 0 && W <= 8192, "fba_input: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(x2, 0, sizeof(bf16raw) * (size_t)frames * (H / 2) * (W / 2) * 64, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "fba_input: memset failed");
     const int64_t ncol = frames * 2 * W;

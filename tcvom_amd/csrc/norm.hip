@@ -505,88 +505,97 @@ extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32
 // The conv epilogue's per-channel (sum, sum of squares) partials of ONE sample are combined over the channels of
 // a group; the per-channel (scale, shift) / (mean, invstd) vectors then drive the same apply kernels as BatchNorm.
 // One block per sample ("frame" of a batched call).
+// One block per (group, sample): thread t sums channel (t % cpg) of the group over the partial slices t / cpg, ...
+// (cpg = channels per group: 2 .. 64, a power of two here), then the block combines the group.
 template <typename PT>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const PT* __restrict__ partial, int G, int C, int ngroups, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float* __restrict__ scale_shift, float* __restrict__ saved, int64_t slot_stride) {
-    __shared__ double cs[2048], cq[2048];
-    __shared__ float gm[64], gr[64];
-    partial += (int64_t)blockIdx.x * G * 2 * C;
-    scale_shift += blockIdx.x * slot_stride;
-    saved += blockIdx.x * slot_stride;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double a = 0.0, b = 0.0;
-        for (int g = 0; g < G; ++g) {
+    __shared__ double ra[256], rb[256];
+    const int grp = blockIdx.x, frame = blockIdx.y;
+    const int cpg = C / ngroups;
+    partial += (int64_t)frame * G * 2 * C;
+    scale_shift += frame * slot_stride;
+    saved += frame * slot_stride;
+    const int lanes = 256 / cpg > 0 ? 256 / cpg : 1;       // slice lanes per channel (cpg <= 256)
+    double a = 0.0, b = 0.0;
+    for (int cc = threadIdx.x % cpg; cc < cpg; cc += 256) {
+        const int c = grp * cpg + cc;
+        for (int g = threadIdx.x / cpg; g < G; g += lanes) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
-        cs[c] = a;
-        cq[c] = b;
     }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
     __syncthreads();
-    const int cpg = C / ngroups;
-    if ((int)threadIdx.x < ngroups) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < cpg; ++j) { a += cs[threadIdx.x * cpg + j]; b += cq[threadIdx.x * cpg + j]; }
-        const double m = count * cpg, mean = a / m;
-        double var = b / m - mean * mean;
-        if (var < 0.0) var = 0.0;
-        gm[threadIdx.x] = (float)mean;
-        gr[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { ra[threadIdx.x] += ra[threadIdx.x + o]; rb[threadIdx.x] += rb[threadIdx.x + o]; }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int g = c / cpg;
-        const float sc = gamma[c] * gr[g];
+    const double m = count * cpg, mean = ra[0] / m;
+    double var = rb[0] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float gm = (float)mean, gr = (float)(1.0 / sqrt(var + (double)eps));
+    for (int cc = threadIdx.x; cc < cpg; cc += 256) {
+        const int c = grp * cpg + cc;
+        const float sc = gamma[c] * gr;
         scale_shift[c] = sc;
-        scale_shift[C + c] = beta[c] - gm[g] * sc;
-        saved[c] = gm[g];
-        saved[C + c] = gr[g];
+        scale_shift[C + c] = beta[c] - gm * sc;
+        saved[c] = gm;
+        saved[C + c] = gr;
     }
 }
 
 // partial: per-channel (sum g, sum g * xhat) of bn_bwd_reduce.  dx = rstd * (gamma * g - G1/m - xhat * G2/m) with the
-// group sums G1 = sum_c gamma_c S1_c, G2 = sum_c gamma_c S2_c, m = pixels * channels per group.
+// group sums G1 = sum_c gamma_c S1_c, G2 = sum_c gamma_c S2_c, m = pixels * channels per group.  One block per (group, sample).
 template <typename PT>
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const PT* __restrict__ partial, int G, int C, int ngroups, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ saved,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef, int64_t slot_stride) {
-    __shared__ double cs[2048], cq[2048];
-    __shared__ float g1[64], g2[64];
-    partial += (int64_t)blockIdx.x * G * 2 * C;
-    saved += blockIdx.x * slot_stride;
-    coef += (int64_t)blockIdx.x * 3 * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double a = 0.0, b = 0.0;
-        for (int g = 0; g < G; ++g) {
+    __shared__ double ra[256], rb[256];
+    __shared__ double cs[256], cq[256];                    // per-channel totals of the group (cpg <= 256)
+    const int grp = blockIdx.x, frame = blockIdx.y;
+    const int cpg = C / ngroups;
+    partial += (int64_t)frame * G * 2 * C;
+    saved += frame * slot_stride;
+    coef += (int64_t)frame * 3 * C;
+    const int lanes = 256 / cpg > 0 ? 256 / cpg : 1;
+    const int cc0 = threadIdx.x % cpg, l0 = threadIdx.x / cpg;
+    double a = 0.0, b = 0.0;
+    if (l0 < lanes) {
+        const int c = grp * cpg + cc0;
+        for (int g = l0; g < G; g += lanes) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
-        cs[c] = a;
-        cq[c] = b;
-        if (dbeta) atomicAdd(dbeta + c, (float)a);
-        if (dgamma) atomicAdd(dgamma + c, (float)b);
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {                          // channel totals: sum over the slice lanes
+        double sa = 0.0, sb = 0.0;
+        for (int l = 0; l < lanes; ++l) { sa += ra[l * cpg + threadIdx.x]; sb += rb[l * cpg + threadIdx.x]; }
+        cs[threadIdx.x] = sa;
+        cq[threadIdx.x] = sb;
+        const int c = grp * cpg + threadIdx.x;
+        if (dbeta) atomicAdd(dbeta + c, (float)sa);
+        if (dgamma) atomicAdd(dgamma + c, (float)sb);
     }
     __syncthreads();
-    const int cpg = C / ngroups;
-    if ((int)threadIdx.x < ngroups) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < cpg; ++j) {
-            const double gmm = (double)gamma[threadIdx.x * cpg + j];
-            a += gmm * cs[threadIdx.x * cpg + j];
-            b += gmm * cq[threadIdx.x * cpg + j];
-        }
-        const double m = count * cpg;
-        g1[threadIdx.x] = (float)(a / m);
-        g2[threadIdx.x] = (float)(b / m);
+    double g1 = 0.0, g2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+        const double gmm = (double)gamma[grp * cpg + j];
+        g1 += gmm * cs[j];
+        g2 += gmm * cq[j];
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int g = c / cpg;
+    const double m = count * cpg;
+    if ((int)threadIdx.x < cpg) {
+        const int c = grp * cpg + threadIdx.x;
         const float rstd = saved[C + c];
-        coef[c] = rstd * g1[g];
-        coef[C + c] = rstd * g2[g];
+        coef[c] = rstd * (float)(g1 / m);
+        coef[C + c] = rstd * (float)(g2 / m);
         coef[2 * C + c] = gamma[c] * rstd;
     }
 }
@@ -595,14 +604,14 @@ extern "C" int tcvom_gn_finalize(const float* partial, int32_t groups, int32_t C
                                  const float* gamma, const float* beta, float eps, float* scale_shift, float* saved,
                                  double* scratch, int32_t nframes, int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && count > 0 && nframes >= 1, "gn_finalize: bad args");
-    TCVOM_CHECK_ARG(C > 0 && C <= 2048 && num_groups > 0 && num_groups <= 64 && C % num_groups == 0, "gn_finalize: C=%d groups=%d", C, num_groups);
+    TCVOM_CHECK_ARG(C > 0 && num_groups > 0 && C % num_groups == 0 && C / num_groups <= 256 && 256 % (C / num_groups) == 0, "gn_finalize: C=%d groups=%d", C, num_groups);
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(gn_finalize_kernel<double>, dim3(nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, num_groups,
+        hipLaunchKernelGGL(gn_finalize_kernel<double>, dim3(num_groups, nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, num_groups,
                            (double)count, gamma, beta, eps, scale_shift, saved, slot_stride);
     } else {
-        hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(nframes), dim3(256), 0, st, partial, groups, C, num_groups, (double)count,
+        hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(num_groups, nframes), dim3(256), 0, st, partial, groups, C, num_groups, (double)count,
                            gamma, beta, eps, scale_shift, saved, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("gn_finalize");
@@ -613,14 +622,14 @@ extern "C" int tcvom_gn_bwd_finalize(const float* partial, int32_t groups, int32
                                      const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
                                      double* scratch, int32_t nframes, int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && count > 0 && nframes >= 1, "gn_bwd_finalize: bad args");
-    TCVOM_CHECK_ARG(C > 0 && C <= 2048 && num_groups > 0 && num_groups <= 64 && C % num_groups == 0, "gn_bwd_finalize: C=%d groups=%d", C, num_groups);
+    TCVOM_CHECK_ARG(C > 0 && num_groups > 0 && C % num_groups == 0 && C / num_groups <= 256 && 256 % (C / num_groups) == 0, "gn_bwd_finalize: C=%d groups=%d", C, num_groups);
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel<double>, dim3(nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, num_groups,
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel<double>, dim3(num_groups, nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, num_groups,
                            (double)count, gamma, saved, dgamma, dbeta, coef, slot_stride);
     } else {
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel<float>, dim3(nframes), dim3(256), 0, st, partial, groups, C, num_groups, (double)count,
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel<float>, dim3(num_groups, nframes), dim3(256), 0, st, partial, groups, C, num_groups, (double)count,
                            gamma, saved, dgamma, dbeta, coef, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("gn_bwd_finalize");

@@ -285,16 +285,17 @@ class FullModel_VMD(FullModel):
         return [L1, L2, L3, L_dt, L_att, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, Fs, Bs]
 
 
-def fba_network_input(prep, eps, want_tris=False):
+def fba_network_input(prep, eps, want_tris=False, use_dilated=True):
     """tcvom_fba_input on the outputs of preprocess_window: (x2 bf16 [B,S,H/2,W/2,64] space-to-depth network input, extras
-    bf16 [B,S,H,W,8], tris fp32 [B,S,8,H,W] or None)."""
+    bf16 [B,S,H,W,8], tris fp32 [B,S,8,H,W] or None).  use_dilated=False: EvalModel, where the bg / fg classes are read
+    from the user trimap itself (models/model.py:380-385) and the dilation only widens the blend / TAM mask."""
     B, S, _, H, W = prep.gts.shape
     dev = prep.gts.device
     x2 = torch.empty((B, S, H // 2, W // 2, 64), dtype=torch.bfloat16, device=dev)
     extras = torch.empty((B, S, H, W, 8), dtype=torch.bfloat16, device=dev)
     tris = torch.empty((B, S, 8, H, W), dtype=torch.float32, device=dev) if want_tris else None
     scratch = torch.empty((B * S, 2, H, W), dtype=torch.float32, device=dev)
-    L.call('tcvom_fba_input', L.ptr(prep.gts), L.ptr(prep.unk), L.ptr(prep.imgs), L.ptr(x2), L.ptr(extras), L.ptr(tris),
+    L.call('tcvom_fba_input', L.ptr(prep.gts), L.ptr(prep.unk) if use_dilated else None, L.ptr(prep.imgs), L.ptr(x2), L.ptr(extras), L.ptr(tris),
            L.ptr(scratch), B * S, H, W, float(eps), L.stream_ptr())
     return x2, extras, tris
 
@@ -316,6 +317,8 @@ class EvalModel(FullModel):
         with torch.no_grad():
             dil = self.DILATION_KERNEL if self.DILATION_KERNEL is not None else 0
             prep = preprocess_window(tris, imgs, None, dil, 0.0)
+            if self.method == 'fba':
+                return self._forward_fba_eval(prep, B, S, H, W)
             frames = [prep.x8[:, s].contiguous() for s in range(S)]
             prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
             preds, _attb, _attf = self.NET.run(frames, prep.unk8)
@@ -323,6 +326,24 @@ class EvalModel(FullModel):
             for c in range(1, S - 1):
                 alphas[:, c] = torch.where(prep.trimask[:, c] > 0, preds[c].float(), prep.gts[:, c])
         return alphas
+
+
+    def _forward_fba_eval(self, prep, B, S, H, W):
+        """FBA: (alphas, Fs, Bs) -- prediction inside the unknown region, trimap value / image elsewhere (:425-453)."""
+        x2, extras, _ = fba_network_input(prep, 0.0, use_dilated=False)
+        unk_small = prep.unk[:, :, ::TAM_OS, ::TAM_OS].contiguous()
+        pred, _ab, _af = self.NET.run(x2, extras, prep.imgs, unk_small)
+        dev = pred.device
+        alphas = torch.zeros((B, S, 1, H, W), dtype=torch.float32, device=dev)
+        Fs = torch.zeros((B, S, 3, H, W), dtype=torch.float32, device=dev)
+        Bs = torch.zeros((B, S, 3, H, W), dtype=torch.float32, device=dev)
+        for c in range(1, S - 1):
+            m = prep.trimask[:, c] > 0
+            p = pred[:, c - 1]
+            alphas[:, c] = torch.where(m, p[:, :1], prep.gts[:, c])
+            Fs[:, c] = torch.where(m, p[:, 1:4], prep.imgs[:, c])
+            Bs[:, c] = torch.where(m, p[:, 4:7], prep.imgs[:, c])
+        return alphas, Fs, Bs
 
 
 def train_step_loss(out):

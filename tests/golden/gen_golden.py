@@ -363,6 +363,14 @@ def gen_fba():
                  'fusion:dF': sub(x.grad), 'fusion:dB': sub(y.grad),
                  'fusion:sums': torch.stack([t.double().sum() for t in (fa, fF, fB, al.grad, x.grad, y.grad)])})
     save('fba_ops', **arrs)
+    # EvalModel('vmn_fba') on frames + user trimaps (pred_test.py path): (alphas, Fs, Bs)
+    em = ref_model.EvalModel('vmn_fba', agg_window=7, dilate_kernel=3)
+    em.NET.load_state_dict(formula_state_dict(em.NET.state_dict()))
+    em.eval()
+    imgs, tris = eval_inputs(1, 3, 64, 96)
+    with torch.no_grad():
+        al, Fs, Bs = em(imgs, tris)
+    save('fba_eval_s3_64x96', alphas=al, Fs=Fs, Bs=Bs)
     sd = ref_model.FullModel_VMD('vmn_fba', agg_window=7).NET.state_dict()
     save('fba_state_keys', keys=np.array(list(sd.keys())),
          shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))

@@ -294,3 +294,23 @@ def test_window_against_reference_golden(name):
         tol = 0.25 if k.startswith('encoder.') else 0.05
         ck.rows.append(('cos ' + k, 1 - cs, tol, 1 - cs <= tol))
     ck.done()
+
+
+def test_eval_model_against_reference_golden():
+    """EvalModel('vmn_fba') (frames + user trimaps -> alphas, Fs, Bs; models/model.py:388-453) against the reference."""
+    from tcvom_amd.facade import EvalModel
+    g = golden('fba_eval_s3_64x96')
+    em = EvalModel('vmn_fba', agg_window=7, dilate_kernel=3)
+    em.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in em.NET.state_dict().items()})
+    em = em.to(DEV).eval()
+    a, fg, bg = synthetic_window(1, 3, 64, 96, seed=3)                  # tests/golden/gen_golden.py:eval_inputs
+    al = a / 255.0
+    imgs = torch.round(fg * al + bg * (1 - al))
+    tris = torch.where(a <= 0, torch.zeros_like(a), torch.where(a >= 255, torch.full_like(a, 255.0), torch.full_like(a, 128.0)))
+    alphas, Fs, Bs = em(imgs.to(DEV), tris.to(DEV))
+    for nm, got in (('alphas', alphas), ('Fs', Fs), ('Bs', Bs)):
+        want = torch.from_numpy(g[nm])
+        assert got.shape == want.shape
+        mse = float(((got.cpu() - want) ** 2).mean())
+        assert mse <= 1e-4, '%s MSE %.3e' % (nm, mse)
+    assert float(alphas[:, 0].abs().max()) == 0 and float(alphas[:, -1].abs().max()) == 0
