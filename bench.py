@@ -31,10 +31,10 @@ FULL_H, FULL_W = 1088, 1920
 # (FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script; fetch side doubled per MI355X_MICROARCH.md's gfx950
 # correction; averaged over all launches of the instantiation in a 1080p step).  bench.py cannot run rocprofv3 on itself,
 # so the figure of the kernel that turns out dominant is quoted from that committed measurement.
-PMC_TRAFFIC_BYTES = {
-    'igemm_tt<128,128,64,32,1>': (310.74 + 29.26) * 2 ** 20,
-    'igemm_nt<256,256,128,64,2>': (664.34 + 576.68) * 2 ** 20,
-    'igemm_nt<128,128,64,32,2>': (77.40 + 39.20) * 2 ** 20,
+PMC_TRAFFIC_BYTES = {                                                   # profiles/r01_h_hbm_traffic_pmc.md
+    'gemm_nt256': (901.47 + 452.69) * 2 ** 20,
+    'igemm_tt<128,128,64,32,1>': (212.53 + 25.20) * 2 ** 20,
+    'igemm_nt<128,128,64,32,2>': (41.45 + 41.31) * 2 ** 20,
 }
 
 
