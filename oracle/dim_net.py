@@ -7,7 +7,8 @@ Follows:  models/DIM/vggnet.py:10-128 (DeepMatting.forward: VGG16-BN encoder wit
           dconv6 1x1, five max-unpool + 5x5 conv stages, alpha_pred 5x5 + clamp(0, 1))
           models/model.py:54-92,94-127,199-246 (make_trimap with one channel, single_image_loss, FullModel.forward)
           utils/loss_func.py:9-22,42-59 (L1_mask, get_gradient, L1_grad)
-Pinned by tests/golden/dim_*.npz (generated from the reference itself by tests/golden/gen_golden.py).
+          models/VMN/VMN_DIM.py:6-136 (vmn_dim: the same network split around the TAM at os8)
+Pinned by tests/golden/dim_*.npz and vmn_dim_*.npz (generated from the reference itself by tests/golden/gen_golden.py).
 """
 import torch
 import torch.nn.functional as F
@@ -81,3 +82,57 @@ def full_model_dim_forward(state, a, fg, bg, dilate_kernel=12, training=True, ep
     alphas[:, c] = refine.detach().clamp(0, 1)
     comps[:, c] = comp.detach().clamp(0, 1)
     return [L_alpha, L_comp, L_grad, simgs, tris, alphas, comps, gts, fgs, bgs], pred
+
+
+# ----------------------------------------------------------------------------- vmn_dim (models/VMN/VMN_DIM.py)
+def vmn_dim_window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True, att_thres=0.3, label_smooth=0.2, eps=0.0):
+    """FullModel_VMD('vmn_dim').forward -> the reference's 12-item list (models/model.py:258-357 with the non-GCA branch
+    of single_image_loss: L_alpha, L_comp, L_grad on the interior frames)."""
+    from .tam import tam_forward
+    from .window import attention_loss, dtssd_loss
+    mean = torch.tensor([0.485, 0.456, 0.406]).reshape(1, 1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).reshape(1, 1, 3, 1, 1)
+    B, S = a.shape[:2]
+    gts = a / 255.0
+    fgs, bgs = fg.flip([2]) / 255.0, bg.flip([2]) / 255.0
+    simgs = fgs * gts + bgs * (1.0 - gts)
+    tris, trimasks = make_trimap1(gts, dilate_kernel, eps)
+    x = torch.cat([(simgs - mean) / std, tris], dim=2)
+    conv = lambda name, t, pad: F.conv2d(t, state[name + '.weight'], state[name + '.bias'], 1, pad)
+    idxs, feats = [None] * S, [None] * S
+    for s in range(S):                                               # DIMEncoder + DIMDecoder(extract_feature=True)
+        t, idx = x[:, s], []
+        for stage in _STAGES:
+            for tag in stage:
+                t = F.relu(batch_norm(state, 'encoder.bn' + tag, conv('encoder.conv' + tag, t, 1), training))
+            t, i = F.max_pool2d(t, (2, 2), stride=2, return_indices=True)
+            idx.append(i)
+        t = F.relu(conv('encoder.conv6', t, 3))
+        t = F.relu(conv('decoder.dconv6', t, 0))
+        t = F.relu(conv('decoder.dconv5', F.max_unpool2d(t, idx[4], (2, 2), stride=2), 2))
+        feats[s] = F.relu(conv('decoder.dconv4', F.max_unpool2d(t, idx[3], (2, 2), stride=2), 2))
+        idxs[s] = idx
+    preds, attb, attf, small = [None] * S, [None] * S, [None] * S, [None] * S
+    for s in range(1, S - 1):
+        t, attb[s], attf[s], small[s] = tam_forward(state, 'decoder.fam', feats[s], feats[s - 1], feats[s + 1], trimasks[:, s], window)
+        for name, i in (('dconv3', 2), ('dconv2', 1), ('dconv1', 0)):
+            t = F.relu(conv('decoder.' + name, F.max_unpool2d(t, idxs[s][i], (2, 2), stride=2), 2))
+        preds[s] = conv('decoder.alpha_pred', t, 2).clamp(0, 1)
+    La, Lc, Lg = [], [], []
+    alphas, comps = [None] * S, [None] * S
+    for c in range(1, S - 1):
+        m = trimasks[:, c].float()
+        refine = torch.where(m.bool(), preds[c], gts[:, c])
+        comp = fgs[:, c] * refine + bgs[:, c] * (1.0 - refine)
+        alphas[c], comps[c] = refine, comp
+        La.append(l1_mask(refine, gts[:, c], m))
+        Lc.append(l1_mask(comp, simgs[:, c], m))
+        Lg.append(l1_grad(refine, gts[:, c], m))
+    n = float(len(La))
+    alphas[0] = alphas[-1] = torch.zeros_like(alphas[1])
+    comps[0] = comps[-1] = torch.zeros_like(comps[1])
+    alphas = torch.stack(alphas, dim=1).clamp(0, 1)
+    comps = torch.stack(comps, dim=1).clamp(0, 1)
+    L_att = attention_loss(attb, attf, small, gts, window, att_thres, label_smooth)
+    L_dt = dtssd_loss(alphas, gts, trimasks)
+    return [sum(La) / n, sum(Lc) / n, sum(Lg) / n, L_dt, L_att, simgs, tris, alphas, comps, gts, fgs, bgs]

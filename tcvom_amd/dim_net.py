@@ -83,3 +83,91 @@ class DeepMatting(nn.Module):
 def DIM_VGG(build_decoder=True, alpha_only=True):
     """models/DIM/vggnet.py:131-133."""
     return DeepMatting(input_chn=4, build_decoder=build_decoder, alpha_only=True)
+
+
+# =============================================================================================
+# vmn_dim: the DIM base split around the Temporal Attention Module (models/VMN/VMN_DIM.py)
+# =============================================================================================
+class DIMEncoder(nn.Module):
+    """models/VMN/VMN_DIM.py:6-82: VGG16-BN stages with pooling indices + conv6 (7x7, 512 -> 4096) + ReLU."""
+
+    def __init__(self, input_chn, bank=None):
+        super().__init__()
+        for tag, cin, cout in _ENC:
+            setattr(self, 'conv' + tag, nn.Conv2d(input_chn if cin is None else cin, cout, kernel_size=3, padding=1))
+            setattr(self, 'bn' + tag, nn.BatchNorm2d(cout))
+        self.conv6 = nn.Conv2d(512, 4096, kernel_size=7, padding=3)
+        cfgs = {}
+        for tag, cin, _ in _ENC:
+            conv = getattr(self, 'conv' + tag)
+            spec = ConvSpec('encoder.conv' + tag, conv.weight, None, None, conv.bias, False, 1, 1, 'frame', cin is not None)
+            bank.register(spec)
+            cfgs['conv' + tag] = ConvCfg(bank, spec, bn=getattr(self, 'bn' + tag), act=ACT_RELU)
+        spec = ConvSpec('encoder.conv6', self.conv6.weight, None, None, self.conv6.bias, False, 1, 3, 'frame')
+        bank.register(spec)
+        cfgs['conv6'] = ConvCfg(bank, spec, pre_relu=True)
+        object.__setattr__(self, '_cfgs', cfgs)
+
+    def run(self, x8, unk_u8, token, training):
+        """x8 [F*B,H,W,8] bf16 (normalised RGB + 1-channel trimap) -> (x6 [.., H/32, W/32, 4096], {'idx': 5 index maps})."""
+        cf = self._cfgs
+        x, idx = x8, []
+        for stage in _STAGES:
+            for tag in stage:
+                x = ops.conv_bn_act(cf['conv' + tag], x, token, training)
+            x, i = ops.maxpool2_idx(x)
+            idx.append(i)
+        return ops.conv_unfold_dense(cf['conv6'], x, token), {'idx': tuple(idx)}
+
+
+class DIMDecoder(nn.Module):
+    """models/VMN/VMN_DIM.py:84-136: dconv6, five max-unpool + 5x5 conv stages, alpha_pred; the TAM sits at os8 (256 ch)."""
+
+    def __init__(self, reduction, window, freeze_backbone, bank=None):
+        super().__init__()
+        from .vmn import FeatureAggregationModule
+        self.freeze_backbone = freeze_backbone
+        self.dconv6 = nn.Conv2d(4096, 512, kernel_size=1, padding=0)
+        for name, cin, cout in _DEC:
+            setattr(self, name, nn.Conv2d(cin, cout, kernel_size=5, padding=2))
+        self.alpha_pred = nn.Conv2d(64, 1, kernel_size=5, padding=2)
+        cfgs = {}
+        for name, group in (('dconv6', 'frame'), ('dconv5', 'frame'), ('dconv4', 'frame'), ('dconv3', 'tail'), ('dconv2', 'tail'),
+                            ('dconv1', 'tail')):
+            conv = getattr(self, name)
+            spec = ConvSpec('decoder.' + name, conv.weight, None, None, conv.bias, False, 1, conv.padding[0], group)
+            bank.register(spec)
+            cfgs[name] = ConvCfg(bank, spec, pre_relu=True)
+        object.__setattr__(self, '_cfgs', cfgs)
+        self.fam = FeatureAggregationModule(256, reduction, window, bank=bank, prefix='decoder.fam')
+
+    def train(self, mode=True):
+        super().train(mode)
+        if self.freeze_backbone:
+            print('Set DIM decoder feature extraction part in eval() mode.')
+            self.dconv6.eval()
+            self.dconv5.eval()
+            self.dconv4.eval()
+        return self
+
+    def run_front(self, x6, mid, token, training):
+        cf, idx = self._cfgs, mid['idx']
+        x = ops.conv_bn_act(cf['dconv6'], x6, token, training)
+        x = ops.conv_bn_act(cf['dconv5'], ops.unpool2(x, idx[4]), token, training)
+        return ops.conv_bn_act(cf['dconv4'], ops.unpool2(x, idx[3]), token, training)
+
+    def run_tail(self, x, xb, xf, mask_u8, mid, token, training):
+        cf, idx = self._cfgs, mid['idx']
+        x, attb, attf = self.fam.run(x, xb, xf, mask_u8.contiguous(), token, training)
+        for name, i in (('dconv3', idx[2]), ('dconv2', idx[1]), ('dconv1', idx[0])):
+            x = ops.conv_bn_act(cf[name], ops.unpool2(x, i.contiguous()), token, training)
+        return ops.head_conv(x, self.alpha_pred.weight, self.alpha_pred.bias, 5, 1), attb, attf
+
+
+def build_vmn_dim(agg_window, agg_reduction=1, freeze_backbone=False):
+    """models/VMN/__init__.py:15-17: VMN(DIMEncoder(4), DIMDecoder(...))."""
+    from .vmn import VMN
+    bank = WeightBank()
+    enc = DIMEncoder(4, bank=bank)
+    dec = DIMDecoder(agg_reduction, agg_window, freeze_backbone, bank=bank)
+    return VMN(enc, dec, bank, freeze_backbone=freeze_backbone)

@@ -249,7 +249,7 @@ class FullModel_VMD(FullModel):
         assert S >= 3, 'a window needs at least 3 frames'
         H, W = a.shape[-2:]
         assert H % 32 == 0 and W % 32 == 0, 'H and W must be multiples of 32 (pred_vmn.py:90)'
-        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS)
+        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
         if self.method == 'fba':
             return self._forward_fba(prep, B, S, H, W)
         frames = [prep.x8[:, s].contiguous() for s in range(S)]
@@ -259,9 +259,15 @@ class FullModel_VMD(FullModel):
         tensors = [preds[c] for c in range(1, S - 1)] + [attb[c] for c in range(1, S - 1)] + [attf[c] for c in range(1, S - 1)]
         L_alpha, L_dt, L_att, alphas, comps = _WindowLoss.apply(prep, self.window, float(self.att_thres),
                                                                 float(self.label_smooth), S, *tensors)
-        zero = torch.zeros_like(L_alpha)                       # GCA: L_comp = L_grad = 0 (models/model.py:112-114)
         if S < 5:
             L_dt = torch.zeros_like(L_att)
+        if self.method != 'gca':
+            # DIM / Index bases also train on the composition and gradient losses of the interior frames (:110-118)
+            per = [_SingleImageLoss.apply(prep, c, S, preds[c]) for c in range(1, S - 1)]
+            L_comp = sum(p[1] for p in per) / float(ni)
+            L_grad = sum(p[2] for p in per) / float(ni)
+            return [L_alpha, L_comp, L_grad, L_dt, L_att, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
+        zero = torch.zeros_like(L_alpha)                       # GCA: L_comp = L_grad = 0 (models/model.py:112-114)
         return [L_alpha, zero, zero.clone(), L_dt, L_att,
                 prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
 
@@ -316,7 +322,7 @@ class EvalModel(FullModel):
         assert S >= 3 and H % 32 == 0 and W % 32 == 0, 'pad the frames to multiples of 32 (pred_test.py:47-66)'
         with torch.no_grad():
             dil = self.DILATION_KERNEL if self.DILATION_KERNEL is not None else 0
-            prep = preprocess_window(tris, imgs, None, dil, 0.0)
+            prep = preprocess_window(tris, imgs, None, dil, 0.0, 1 if self.TRIMAP_CHANNEL == 1 else 3)
             if self.method == 'fba':
                 return self._forward_fba_eval(prep, B, S, H, W)
             frames = [prep.x8[:, s].contiguous() for s in range(S)]

@@ -43,9 +43,9 @@ def formula_tensor(key, shape, dtype=torch.float32, salt=0):
         r = 0.1 * r
     elif leaf == 'running_var':
         r = 1.0 + 0.3 * r
-    elif key == 'alpha_pred.bias':                            # DIM head: keep clamp(pred, 0, 1) away from saturation
+    elif key.endswith('alpha_pred.bias'):                            # DIM head: keep clamp(pred, 0, 1) away from saturation
         r = 0.5 + 0.0 * r
-    elif key == 'alpha_pred.weight':
+    elif key.endswith('alpha_pred.weight'):
         r = r * np.sqrt(3.0 / (n // shape[0])) * 4.0
     elif key == 'decoder.conv_up4.4.bias':                    # FBA head (alpha, F, B): alpha = clamp(out[0], 0, 1) mid-range
         r = np.where(np.arange(n) == 0, 0.5, 0.1 * r)

@@ -60,6 +60,14 @@ class FeatureAggregationModule(nn.Module):
         return _to_nchw(out), attb, attf, small
 
 
+def _mid_tensors(mid):
+    """Every tensor an encoder handed to the decoder (skip features, pooling indices ...)."""
+    out = []
+    for v in mid.values():
+        out += [t for t in v if torch.is_tensor(t)] if isinstance(v, (tuple, list)) else ([v] if torch.is_tensor(v) else [])
+    return out
+
+
 class VMN(nn.Module):
     """models/VMN/VMN_model.py:70-113."""
 
@@ -106,7 +114,7 @@ class VMN(nn.Module):
                     feats[i] = self.decoder.run_front(emb, mids[i], token, training)
             for i in range(S):
                 main.wait_stream(self._streams[i])
-                for t in (feats[i], mids[i]['image_fea']) + tuple(mids[i]['shortcut']):
+                for t in [feats[i]] + _mid_tensors(mids[i]):
                     t.record_stream(main)
         else:
             for i in range(S):
@@ -134,8 +142,9 @@ class VMN(nn.Module):
             feat = self.decoder.run_front(emb, mid, token, training)
             bank.frames_per_op = S - 2
             lo, hi = B, (S - 1) * B                               # the interior frames 1 .. S-2
-            mid_c = {'shortcut': tuple(t[lo:hi] for t in mid['shortcut']), 'image_fea': mid['image_fea'][lo:hi],
-                     'unknown': U[lo:hi]}
+            mid_c = {k: (tuple(t[lo:hi] for t in v) if isinstance(v, (tuple, list)) else v[lo:hi]) for k, v in mid.items()
+                     if k != 'unknown'}
+            mid_c['unknown'] = U[lo:hi]
             pred, ab, af = self.decoder.run_tail(feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B], U[lo:hi], mid_c, token, training)
         finally:
             bank.frames_per_op = 1
@@ -177,12 +186,15 @@ def build_vmn_gca(agg_window, agg_reduction=1, freeze_backbone=False):
 
 
 def get_VMN_models(arch, agg_window, agg_reduction=1, freeze_backbone=False, **kwargs):
-    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4) and `vmn_fba` (config 5) run on the HIP path."""
+    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4), `vmn_fba` (config 5) and `vmn_dim` run on the HIP path."""
     if arch == 'vmn_gca':
         return build_vmn_gca(agg_window, agg_reduction, freeze_backbone)
     if arch == 'vmn_fba':
         from .fba_net import build_vmn_fba
         return build_vmn_fba(agg_window, agg_reduction, freeze_backbone)
-    if arch in ('vmn_dim', 'vmn_index'):
+    if arch == 'vmn_dim':
+        from .dim_net import build_vmn_dim
+        return build_vmn_dim(agg_window, agg_reduction, freeze_backbone)
+    if arch in ('vmn_index',):
         raise NotImplementedError('%s: only the vmn_gca hot path is implemented on MI355X so far (SURVEY.md §8)' % arch)
     raise ValueError

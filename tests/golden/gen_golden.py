@@ -376,6 +376,38 @@ def gen_fba():
          shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))
 
 
+VMN_DIM_CASES = {'vmn_dim_s3_64x64': (1, 3, 64, 64, 3), 'vmn_dim_s5_64x96': (1, 5, 64, 96, 5)}
+VMN_DIM_FULL_GRADS = ('encoder.conv11.weight', 'encoder.bn33.weight', 'decoder.dconv1.bias', 'decoder.alpha_pred.weight',
+                      'decoder.fam.key_conv.bias')
+
+
+def gen_vmn_dim():
+    for name, (B, S, H, W, dil) in VMN_DIM_CASES.items():
+        fm = ref_model.FullModel_VMD('vmn_dim', agg_window=7, dilate_kernel=dil)
+        fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
+        fm.train()
+        a, fg, bg = synthetic_window(B, S, H, W, seed=4)
+        out = fm(a, fg, bg)
+        (out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]).backward()
+        arrs = {'losses': torch.stack([o.detach() for o in out[:5]]), 'alphas': out[7], 'comps_sum': out[8].double().sum()}
+        names, norms = [], []
+        for k, p in fm.NET.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        arrs['grad_names'], arrs['grad_norms'] = np.array(names), np.array(norms)
+        gd = dict(fm.NET.named_parameters())
+        for k in VMN_DIM_FULL_GRADS:
+            arrs['grad:' + k] = gd[k].grad
+        post = fm.NET.state_dict()
+        for k in ('encoder.bn11.running_mean', 'encoder.bn53.running_var', 'encoder.bn11.num_batches_tracked'):
+            arrs['state:' + k] = post[k].clone()
+        save(name, **arrs)
+    sd = ref_model.FullModel_VMD('vmn_dim', agg_window=7).NET.state_dict()
+    save('vmn_dim_state_keys', keys=np.array(list(sd.keys())),
+         shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))
+
+
 def gen_state_keys():
     dsd = ref_model.FullModel('dim').NET.state_dict()
     save('dim_state_keys', keys=np.array(list(dsd.keys())),
@@ -392,6 +424,6 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]                                   # e.g. `python gen_golden.py fba dim`; default: everything
-    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba):
+    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim):
         if not only or fn.__name__[4:] in only:
             fn()

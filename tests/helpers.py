@@ -127,3 +127,21 @@ def fba_formula_state(requires_grad=True):
         shape = tuple(int(d) for d in str(shp).split(',')) if str(shp) else ()
         state[str(k)] = formula_tensor(str(k), shape).requires_grad_(requires_grad)
     return state
+
+
+VMN_DIM_CASES = {'vmn_dim_s3_64x64': (1, 3, 64, 64, 3), 'vmn_dim_s5_64x96': (1, 5, 64, 96, 5)}
+VMN_DIM_FULL_GRADS = ('encoder.conv11.weight', 'encoder.bn33.weight', 'decoder.dconv1.bias', 'decoder.alpha_pred.weight',
+                      'decoder.fam.key_conv.bias')
+
+
+def golden_formula_state(name, requires_grad=True):
+    """Formula-initialised state from a key / shape list captured from the reference (tests/golden/<name>.npz)."""
+    from tcvom_amd.synthetic import formula_tensor
+    g = golden(name)
+    state = {}
+    for k, shp in zip(g['keys'], g['shapes']):
+        shape = tuple(int(d) for d in str(shp).split(',')) if str(shp) else ()
+        t = formula_tensor(str(k), shape)
+        buf = str(k).rsplit('.', 1)[-1] in ('running_mean', 'running_var', 'num_batches_tracked')
+        state[str(k)] = t.requires_grad_(requires_grad) if (t.dtype.is_floating_point and not buf) else t
+    return state

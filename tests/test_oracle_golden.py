@@ -276,3 +276,28 @@ def test_fba_state_dict_layout():
     assert len(g['keys']) == 203
     n = sum(int(np.prod([int(d) for d in str(s).split(',')])) for s in g['shapes'])
     assert n == 36463271
+
+
+# ----------------------------------------------------------------------------- vmn_dim (DIM base + TAM)
+@pytest.mark.parametrize('name', ['vmn_dim_s3_64x64', 'vmn_dim_s5_64x96'])
+def test_vmn_dim_window_forward_backward(name):
+    """oracle.dim_net.vmn_dim_window_forward against FullModel_VMD('vmn_dim') of the reference."""
+    from oracle import dim_net
+    from helpers import VMN_DIM_CASES, VMN_DIM_FULL_GRADS, golden_formula_state
+    B, S, H, W, dil = VMN_DIM_CASES[name]
+    g = golden(name)
+    state = golden_formula_state('vmn_dim_state_keys')
+    assert len(state) == len(golden('vmn_dim_state_keys')['keys'])
+    a, fg, bg = synthetic_window(B, S, H, W, seed=4)
+    out = dim_net.vmn_dim_window_forward(state, a, fg, bg, window=7, dilate_kernel=dil, training=True)
+    assert_close(torch.stack([o.detach() for o in out[:5]]), g['losses'], 1e-4, 1e-6, 'losses')
+    assert_close(out[7], g['alphas'], 1e-4, 5e-5, 'alphas')
+    assert_close(out[8].double().sum(), g['comps_sum'], 1e-5, 1e-2, 'comps')
+    (out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]).backward()
+    names = [str(n) for n in g['grad_names']]
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    assert_close(torch.from_numpy(got), g['grad_norms'], 5e-3, 1e-9, 'grad norms')
+    for k in VMN_DIM_FULL_GRADS:
+        assert_close(state[k].grad, g['grad:' + k], 5e-3, 1e-2 * float(np.abs(g['grad:' + k]).max()), 'grad ' + k)
+    for k in ('encoder.bn11.running_mean', 'encoder.bn53.running_var'):
+        assert_close(state[k], g['state:' + k], 1e-4, 1e-6, k)
