@@ -327,6 +327,15 @@ int tcvom_fba_head_bwd(const void* x, const float* w, const float* b, const floa
 int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const float* imgs, void* x2, void* extras, float* tris,
                     float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream);
 
+/* ------------------------------------------------------------------ evaluation metrics (calc_metric.py:22-46)
+ * One frame, one launch: a / g predicted and ground-truth alpha (fp32 [H][W], 0..1), tri the uint8 trimap (unknown =
+ * neither 0 nor 255), ha / hg the adjacent frame (or NULL), flow fp32 [2][H][W] (x then y displacement, NaN = invalid;
+ * or NULL).  acc: double[8], zeroed by the caller, receives {unknown pixel count, sum |a-g|, sum (a-g)^2,
+ * sum ((a-ha)-(g-hg))^2, MESSDdt sum |(a-g)-(pa-pg)|, sum |(a-g)^2-(pa-pg)^2|, valid flow pixels} where pa / pg are ha / hg
+ * warped by the flow (utils/utils.py:70-123: bilinear, align_corners=True, zeros outside). */
+int tcvom_matting_metrics(const float* a, const float* g, const uint8_t* tri, const float* ha, const float* hg,
+                          const float* flow, double* acc, int32_t H, int32_t W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,7 @@ _PROTOS = {
     'tcvom_fba_head_fwd': [vp, vp, vp, vp, vp, i32, i64, i64, i64, vp],
     'tcvom_fba_head_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, vp],
     'tcvom_fba_input': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, vp],
+    'tcvom_matting_metrics': [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     'tcvom_unfold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_fold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_dim_losses_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp],

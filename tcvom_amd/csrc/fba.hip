@@ -568,3 +568,68 @@ extern "C" int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const f
     TCVOM_LAUNCH_CHECK("fba_input");
     return TCVOM_OK;
 }
+
+// ------------------------------------------------------------------------------------------ evaluation metrics (calc_metric.py:22-46)
+// One pass over a frame: SAD / MSE / SSDA sums over the unknown region of the trimap, dtSSD against the adjacent frame and the
+// flow-warped MESSDdt (utils/utils.py:88-123: bilinear grid_sample, align_corners=True, zero padding).  acc (double[8], zeroed
+// by the caller): 0 unknown pixels, 1 sum |a-g|, 2 sum (a-g)^2, 3 sum ((a-ha)-(g-hg))^2, 4 sum |(a-g)-(pa-pg)|,
+// 5 sum |(a-g)^2-(pa-pg)^2|, 6 pixels with valid flow inside the unknown region.
+__device__ __forceinline__ float sample_zero(const float* __restrict__ im, int H, int W, float x, float y) {
+    const float x0f = floorf(x), y0f = floorf(y);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float lx = x - x0f, ly = y - y0f;
+    float v = 0.f;
+    if (y0 >= 0 && y0 < H) {
+        if (x0 >= 0 && x0 < W) v += (1.f - ly) * (1.f - lx) * im[(int64_t)y0 * W + x0];
+        if (x0 + 1 >= 0 && x0 + 1 < W) v += (1.f - ly) * lx * im[(int64_t)y0 * W + x0 + 1];
+    }
+    if (y0 + 1 >= 0 && y0 + 1 < H) {
+        if (x0 >= 0 && x0 < W) v += ly * (1.f - lx) * im[(int64_t)(y0 + 1) * W + x0];
+        if (x0 + 1 >= 0 && x0 + 1 < W) v += ly * lx * im[(int64_t)(y0 + 1) * W + x0 + 1];
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void matting_metrics_kernel(const float* __restrict__ a, const float* __restrict__ g, const uint8_t* __restrict__ tri,
+                                                              const float* __restrict__ ha, const float* __restrict__ hg,
+                                                              const float* __restrict__ flow, double* __restrict__ acc, int H, int W) {
+    __shared__ float red[4];
+    float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t n = (int64_t)H * W;
+    GRID_STRIDE(v, n) {
+        const uint8_t t = tri[v];
+        if (t == 0 || t == 255) continue;
+        const float d = a[v] - g[v];
+        s[0] += 1.f;
+        s[1] += fabsf(d);
+        s[2] += d * d;
+        if (ha) {
+            const float dd = (a[v] - ha[v]) - (g[v] - hg[v]);
+            s[3] += dd * dd;
+        }
+        if (flow) {
+            const float fx = flow[v], fy = flow[n + v];
+            if (fx == fx && fy == fy) {                                  // NaN marks an invalid flow vector
+                const int y = (int)(v / W), x = (int)(v % W);
+                const float e = sample_zero(ha, H, W, (float)x + fx, (float)y + fy) - sample_zero(hg, H, W, (float)x + fx, (float)y + fy);
+                s[4] += fabsf(d - e);
+                s[5] += fabsf(d * d - e * e);
+                s[6] += 1.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float r = block_sum_256(s[i], red);
+        if (threadIdx.x == 0 && r != 0.f) atomicAdd(acc + i, (double)r);
+    }
+}
+
+extern "C" int tcvom_matting_metrics(const float* a, const float* g, const uint8_t* tri, const float* ha, const float* hg, const float* flow,
+                                     double* acc, int32_t H, int32_t W, void* stream) {
+    TCVOM_CHECK_ARG(a && g && tri && acc && H > 0 && W > 0 && (!flow || (ha && hg)) && ((ha == nullptr) == (hg == nullptr)), "matting_metrics: bad args");
+    int grid = dgrid((int64_t)H * W);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(matting_metrics_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, g, tri, ha, hg, flow, acc, H, W);
+    TCVOM_LAUNCH_CHECK("matting_metrics");
+    return TCVOM_OK;
+}

@@ -408,6 +408,33 @@ def gen_vmn_dim():
          shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))
 
 
+def metric_inputs(H=48, W=64):
+    """alpha / gt of two adjacent frames, a trimap and a smooth optical flow with an invalid (NaN) patch."""
+    a = (hu('metric.a', (H, W)) * 0.5 + 0.5).numpy().astype(np.float32)
+    g = np.clip(a + hu('metric.g', (H, W)).numpy() * 0.1, 0, 1).astype(np.float32)
+    ha = np.clip(a + hu('metric.ha', (H, W)).numpy() * 0.2, 0, 1).astype(np.float32)
+    hg = np.clip(g + hu('metric.hg', (H, W)).numpy() * 0.2, 0, 1).astype(np.float32)
+    u = hu('metric.tri', (H, W)).numpy()
+    tri = np.where(u < -0.3, 0, np.where(u > 0.4, 255, 128)).astype(np.uint8)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    flow = np.stack([3.0 * np.sin(ys / 7.0) + 2.5, -2.0 * np.cos(xs / 9.0) - 1.25], -1).astype(np.float32)
+    flow[5:12, 20:31] = np.nan
+    flow[0, :] = np.array([-4.5, -3.25], dtype=np.float32)              # samples that fall outside the image
+    return a, g, tri, ha, hg, flow
+
+
+def gen_metrics():
+    sys.path.insert(0, REF)
+    sys.modules.pop('utils', None)
+    import calc_metric as cm
+    sys.path.remove(REF)
+    a, g, tri, ha, hg, flow = metric_inputs()
+    m = (tri > 0) * (tri < 255)
+    fix, org, valid = cm.MESSDdt(a, g, m, ha, hg, torch.from_numpy(flow.copy()))
+    save('metrics', sad=cm.SAD(a, g, m), mse=cm.MSE(a, g, m), ssda=cm.SSDA(a, g, m), dtssd=cm.dtSSD(a, g, m, ha, hg),
+         messd=np.array([fix, org, valid], dtype=np.float64), pixels=int(m.sum()))
+
+
 def gen_state_keys():
     dsd = ref_model.FullModel('dim').NET.state_dict()
     save('dim_state_keys', keys=np.array(list(dsd.keys())),
@@ -424,6 +451,6 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]                                   # e.g. `python gen_golden.py fba dim`; default: everything
-    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim):
+    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_metrics):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -145,3 +145,18 @@ def golden_formula_state(name, requires_grad=True):
         buf = str(k).rsplit('.', 1)[-1] in ('running_mean', 'running_var', 'num_batches_tracked')
         state[str(k)] = t.requires_grad_(requires_grad) if (t.dtype.is_floating_point and not buf) else t
     return state
+
+
+def metric_inputs(H=48, W=64):
+    """tests/golden/gen_golden.py:metric_inputs."""
+    a = (hu('metric.a', (H, W)) * 0.5 + 0.5).numpy().astype(np.float32)
+    g = np.clip(a + hu('metric.g', (H, W)).numpy() * 0.1, 0, 1).astype(np.float32)
+    ha = np.clip(a + hu('metric.ha', (H, W)).numpy() * 0.2, 0, 1).astype(np.float32)
+    hg = np.clip(g + hu('metric.hg', (H, W)).numpy() * 0.2, 0, 1).astype(np.float32)
+    u = hu('metric.tri', (H, W)).numpy()
+    tri = np.where(u < -0.3, 0, np.where(u > 0.4, 255, 128)).astype(np.uint8)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    flow = np.stack([3.0 * np.sin(ys / 7.0) + 2.5, -2.0 * np.cos(xs / 9.0) - 1.25], -1).astype(np.float32)
+    flow[5:12, 20:31] = np.nan
+    flow[0, :] = np.array([-4.5, -3.25], dtype=np.float32)
+    return a, g, tri, ha, hg, flow

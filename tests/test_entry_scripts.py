@@ -132,3 +132,57 @@ def test_pred_single_dim_config1():
     out = pred_single.main(pred_single.parse(['--model', 'dim', '--trimap', 'medium', '--frames', '1']))
     assert set(out) == {'L_alpha', 'L_comp', 'L_grad', 'L_total', 'mSAD', 'MSE'}
     assert all(np.isfinite(v) for v in out.values()) and abs(out['L_total'] - out['L_alpha'] - out['L_comp'] - out['L_grad']) < 1e-5
+
+
+@pytest.mark.gpu
+def test_calc_metric_folder(tmp_path):
+    """calc_metric.py counterpart on a synthetic prediction folder (2 videos x 3 frames of _pred / _tri PNGs, FG_done RGBA
+    ground truth, frame_corr.json): the per-frame and averaged SAD / MSE / SSDA / dtSSD equal the oracle's numpy values."""
+    import json
+    from PIL import Image
+    import calc_metric
+    from oracle import metrics as om
+    from helpers import hu
+    H, W = 40, 56
+    pred, data = tmp_path / 'pred', tmp_path / 'data'
+    frames, arrays = {}, {}
+    for v in ('vidA', 'vidB'):
+        (pred / v).mkdir(parents=True)
+        (data / 'FG_done' / v).mkdir(parents=True)
+        for t in range(3):
+            fn = '%s/%04d' % (v, t)
+            a = np.uint8((hu('cm.a.' + fn, (H, W)).numpy() * 0.5 + 0.5) * 255)
+            g = np.uint8(np.clip(a.astype(np.float32) + hu('cm.g.' + fn, (H, W)).numpy() * 30, 0, 255))
+            u = hu('cm.t.' + fn, (H, W)).numpy()
+            tri = np.where(u < -0.3, 0, np.where(u > 0.4, 255, 128)).astype(np.uint8)
+            Image.fromarray(a).save(str(pred / (fn + '_pred.png')))
+            Image.fromarray(tri).save(str(pred / (fn + '_tri.png')))
+            Image.fromarray(np.dstack([g, g, g, g])).save(str(data / 'FG_done' / (fn + '.png')))
+            frames[fn + '.png'] = []
+            arrays[fn] = (np.float32(a / 255.0), np.float32(g / 255.0), tri)
+    with open(str(data / 'frame_corr.json'), 'w') as f:
+        json.dump(frames, f)
+    out = str(tmp_path / 'metric.json')
+    calc_metric.main(argparse_ns(pred=str(pred), data=str(data), output=out, vis=False, n_threads=None))
+    res = json.load(open(out))
+    assert sorted(res['all'].keys()) == ['vidA', 'vidB']
+    for v in ('vidA', 'vidB'):
+        sad = []
+        for t in range(3):
+            fn = '%s/%04d' % (v, t)
+            a, g, tri = arrays[fn]
+            nxt = arrays.get('%s/%04d' % (v, t + 1))
+            want = om.frame_metrics(a, g, tri, *(nxt[:2] if nxt else (None, None)))
+            got = res['all'][v]['all'][fn]
+            assert got['pixel_count'] == want['pixels']
+            for k, wk in (('mSAD', 'SAD'), ('MSE', 'MSE'), ('SSDA', 'SSDA')):
+                assert abs(got[k] - want[wk]) <= 1e-5 * want[wk]
+            assert abs(got['dtSSD'] - want.get('dtSSD', 0.0)) <= 1e-5 * max(want.get('dtSSD', 0.0), 1e-9)
+            sad.append(want['SAD'])
+        assert abs(res['all'][v]['avg']['mSAD'] - np.mean(sad)) <= 1e-5
+    assert abs(res['avg']['mSAD'] - np.mean([res['all'][v]['avg']['mSAD'] for v in ('vidA', 'vidB')])) <= 1e-9
+
+
+def argparse_ns(**kw):
+    import argparse
+    return argparse.Namespace(**kw)

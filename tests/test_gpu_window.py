@@ -146,3 +146,20 @@ def test_eval_model_vs_reference_golden(name, shape):
     mse = float(np.mean((alphas - ref) ** 2))
     print('%s: alpha MSE vs reference EvalModel %.3e' % (name, mse))
     assert mse <= 1e-3
+
+
+def test_evaluation_metrics_on_device():
+    """tcvom_amd.metrics.frame_metrics (one fused kernel) against the values of calc_metric.py's own functions."""
+    from helpers import metric_inputs
+    from tcvom_amd.metrics import frame_metrics
+    g = golden('metrics')
+    a, gt, tri, ha, hg, flow = (torch.from_numpy(t).to('cuda') for t in metric_inputs())
+    out = frame_metrics(a, gt, tri, ha, hg, flow)
+    assert out['pixels'] == int(g['pixels'])
+    for k, ref in (('SAD', 'sad'), ('MSE', 'mse'), ('SSDA', 'ssda'), ('dtSSD', 'dtssd')):
+        assert abs(out[k] - float(g[ref])) <= 1e-5 * abs(float(g[ref])), (k, out[k], float(g[ref]))
+    fix, org, valid = out['MESSDdt']
+    assert valid == int(g['messd'][2])
+    assert abs(fix - g['messd'][0]) <= 1e-4 * g['messd'][0] and abs(org - g['messd'][1]) <= 1e-4 * g['messd'][1]
+    only = frame_metrics(a, gt, tri)
+    assert only['SAD'] == out['SAD'] and 'dtSSD' not in only

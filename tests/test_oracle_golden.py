@@ -301,3 +301,18 @@ def test_vmn_dim_window_forward_backward(name):
         assert_close(state[k].grad, g['grad:' + k], 5e-3, 1e-2 * float(np.abs(g['grad:' + k]).max()), 'grad ' + k)
     for k in ('encoder.bn11.running_mean', 'encoder.bn53.running_var'):
         assert_close(state[k], g['state:' + k], 1e-4, 1e-6, k)
+
+
+def test_evaluation_metrics():
+    """oracle.metrics against calc_metric.py's SAD / MSE / SSDA / dtSSD / MESSDdt (values from the reference functions)."""
+    from oracle import metrics
+    from helpers import metric_inputs
+    g = golden('metrics')
+    a, gt, tri, ha, hg, flow = metric_inputs()
+    out = metrics.frame_metrics(a, gt, tri, ha, hg, flow)
+    assert out['pixels'] == int(g['pixels'])
+    for k, ref in (('SAD', 'sad'), ('MSE', 'mse'), ('SSDA', 'ssda'), ('dtSSD', 'dtssd')):
+        assert abs(out[k] - float(g[ref])) <= 2e-6 * abs(float(g[ref])) + 1e-9, (k, out[k], float(g[ref]))
+    fix, org, valid = out['MESSDdt']
+    assert valid == int(g['messd'][2]) and valid < out['pixels']
+    assert abs(fix - g['messd'][0]) <= 1e-4 * g['messd'][0] and abs(org - g['messd'][1]) <= 1e-4 * g['messd'][1]
