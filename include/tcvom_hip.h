@@ -327,6 +327,39 @@ int tcvom_fba_head_bwd(const void* x, const float* w, const float* b, const floa
 int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const float* imgs, void* x2, void* extras, float* tris,
                     float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream);
 
+/* ------------------------------------------------------------------ FBA losses (models/model.py:129-197, utils/loss_func.py)
+ * One interior frame of B samples, all tensors fp32 NCHW; *_stride = elements between consecutive samples of a tensor
+ * that is a [:, c] slice of a [B, S, ...] window tensor.
+ * point_fwd: refine / F / B selection by the unknown mask, the visualisation slices (alphas, comps, Fs, Bs), d0 [B][7][HW] =
+ * (refine - gt, F - fg, B - bg), fb [B][6][HW] = (F, B), and acc[0..5] += sum |refine-gt|, |F gt + B (1-gt) - img|,
+ * |fg refine + bg (1-refine) - img|, |F-fg|, |B-bg|, |grad-magnitude(refine) - grad-magnitude(gt)| (L1_mask / L1_grad sums).
+ * point_bwd: dpred from coef[0..5] = d loss / d acc[i] plus the gradients w.r.t. d0 / fb of the two losses below. */
+int tcvom_fba_point_fwd(const float* pred, const float* gt, const float* mask, const float* fg, const float* bg, const float* img,
+                        int64_t pred_stride, int64_t frame_stride, int64_t rgb_stride, float* d0, float* fb, float* alphas,
+                        float* comps, float* Fs, float* Bs, float* acc, int32_t B, int32_t H, int32_t W, void* stream);
+int tcvom_fba_point_bwd(const float* pred, const float* gt, const float* mask, const float* fg, const float* bg, const float* img,
+                        int64_t pred_stride, int64_t frame_stride, int64_t rgb_stride, const float* coef, const float* g_d0,
+                        const float* g_fb, float* dpred, int32_t B, int32_t H, int32_t W, void* stream);
+/* exclusion_loss (utils/loss_func.py:63-90) on one pyramid level lvl [B][6][h][w] = (F, B): excl_abs: sums[0..3] += sum |gx F|,
+ * |gx B|, |gy F|, |gy B|; excl_terms mode 0: out [B][2] += per-sample sum f(gF) f(a gB) in x / y (f(u) = (2 sigmoid(u) - 1)^2,
+ * a = 2 mean|gF| / (mean|gB| + eps)); mode 1: out[0..1] += d L / d a given wts [B][2] = d L / d terms; excl_bwd: gradient w.r.t. the
+ * level (+ 0.25 x the next level's gradient through the 2x2 average pooling). */
+int tcvom_excl_abs(const float* lvl, float* sums, int32_t B, int32_t h, int32_t w, void* stream);
+int tcvom_excl_terms(const float* lvl, const float* sums, const float* wts, float* out, int32_t mode, int32_t B, int32_t h,
+                     int32_t w, void* stream);
+int tcvom_avgpool2_f32(const float* x, float* y, int64_t planes, int32_t h, int32_t w, void* stream);
+int tcvom_excl_bwd(const float* lvl, const float* sums, const float* wts, const float* dsum, const float* dcoarse, float* dlvl,
+                   int32_t B, int32_t h, int32_t w, void* stream);
+/* LapLoss (utils/loss_func.py:101-158) on the 7-channel difference image (the pyramid is linear): lap_down = reflect-padded 5x5
+ * Gaussian + even sub-sampling; lap_resid: residual against the zero-interleaved, 4x Gaussian up-sampling, acc[c] += sum |resid|
+ * per channel c = plane % 7, sgn = sign(resid); lap_bwd_coarse / lap_bwd_fine: the transposed operators, level by level. */
+int tcvom_lap_down(const float* cur, float* down, int64_t planes, int32_t h, int32_t w, void* stream);
+int tcvom_lap_resid(const float* cur, const float* down, int8_t* sgn, float* acc, int64_t planes, int32_t h, int32_t w, void* stream);
+int tcvom_lap_bwd_coarse(const int8_t* sgn, const float* coef, const float* gnext, float* r, int64_t planes, int32_t h, int32_t w,
+                         void* stream);
+int tcvom_lap_bwd_fine(const int8_t* sgn, const float* coef, const float* r, float* g, int64_t planes, int32_t h, int32_t w,
+                       void* stream);
+
 /* ------------------------------------------------------------------ evaluation metrics (calc_metric.py:22-46)
  * One frame, one launch: a / g predicted and ground-truth alpha (fp32 [H][W], 0..1), tri the uint8 trimap (unknown =
  * neither 0 nor 255), ha / hg the adjacent frame (or NULL), flow fp32 [2][H][W] (x then y displacement, NaN = invalid;

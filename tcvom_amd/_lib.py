@@ -109,6 +109,16 @@ _PROTOS = {
     'tcvom_fba_head_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, vp],
     'tcvom_fba_input': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32, vp],
     'tcvom_matting_metrics': [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    'tcvom_fba_point_fwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    'tcvom_fba_point_bwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, i32, i32, i32, vp],
+    'tcvom_excl_abs': [vp, vp, i32, i32, i32, vp],
+    'tcvom_excl_terms': [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_avgpool2_f32': [vp, vp, i64, i32, i32, vp],
+    'tcvom_excl_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    'tcvom_lap_down': [vp, vp, i64, i32, i32, vp],
+    'tcvom_lap_resid': [vp, vp, vp, vp, i64, i32, i32, vp],
+    'tcvom_lap_bwd_coarse': [vp, vp, vp, vp, i64, i32, i32, vp],
+    'tcvom_lap_bwd_fine': [vp, vp, vp, vp, i64, i32, i32, vp],
     'tcvom_unfold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_fold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_dim_losses_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp],

@@ -284,8 +284,15 @@ class FullModel_VMD(FullModel):
         L_att = FL.attention_loss(attb, attf, unk_small, prep.gts, self.window, float(self.att_thres), float(self.label_smooth), TAM_OS)
         L_att = L_att * self.FBA_L_ATT_MULTIPLIER
         if S >= 5:
-            L_dt = FL.dtssd(alphas, prep.gts, prep.trimask, norm) + 0.25 * (FL.dtssd(Fs, prep.fgs, prep.trimask, norm) +
-                                                                           FL.dtssd(Bs, prep.bgs, prep.trimask, norm))
+            # L_dt needs alphas / Fs / Bs as differentiable functions of the prediction (the loss kernels write them as
+            # plain outputs): rebuild the interior frames with the same selection
+            m = prep.trimask[:, 1:S - 1] > 0
+            ends = lambda t: torch.cat([torch.zeros_like(t[:, :1]), t, torch.zeros_like(t[:, :1])], dim=1)
+            al = ends(torch.where(m, pred[:, :, :1], prep.gts[:, 1:S - 1]))
+            cF = ends(torch.where(m, pred[:, :, 1:4], prep.fgs[:, 1:S - 1]))
+            cB = ends(torch.where(m, pred[:, :, 4:7], prep.bgs[:, 1:S - 1]))
+            L_dt = FL.dtssd(al, prep.gts, prep.trimask, norm) + 0.25 * (FL.dtssd(cF, prep.fgs, prep.trimask, norm) +
+                                                                       FL.dtssd(cB, prep.bgs, prep.trimask, norm))
         else:
             L_dt = torch.zeros_like(L_att)
         return [L1, L2, L3, L_dt, L_att, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, Fs, Bs]

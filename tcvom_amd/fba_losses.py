@@ -1,106 +1,134 @@
 """Losses of the FBA base (models/model.py:129-197,285-345; utils/loss_func.py:9-158) on the GPU.
 
-First version: these are fp32 tensor expressions on device tensors (ATen element-wise / reduction kernels with
-autograd), not yet fused HIP kernels like the GCA / DIM losses of tcvom_amd.facade — about 1.5 k small launches
-per window.  DESIGN.md lists them as the next FBA item to move into libtcvom_hip.so.  The 5x5 Gaussian of the
-Laplacian pyramid is applied as two separable 5-tap passes over shifted views (no library convolution).
+`fba_single_image_loss` runs one `_FbaFrameLoss` per interior frame: the L1 family + L1_grad in one kernel, the exclusion
+loss as 3 levels x (reduction, per-sample terms), the Laplacian loss of alpha, F and B as ONE 7-channel pyramid of the
+difference image (the pyramid is linear) -- csrc/fba_loss.hip; ~40 launches forward, ~30 backward per frame, no host
+sync.  The handful of scalars in between (means, fourth roots, weights) are tiny device-side tensor expressions.
+`attention_loss` / `dtssd` (L_att, L_dt) are small tensor expressions on os8 / masked tensors.
 """
+import ctypes as C
+
 import torch
 import torch.nn.functional as F
 
-_G5 = (1.0 / 16, 4.0 / 16, 6.0 / 16, 4.0 / 16, 1.0 / 16)
+from . import _lib as L
+
+EPS = 1.001e-5
+LAP_LEVELS, EXCL_LEVELS = 5, 3
 
 
-def _l1(x, y, normalize):
-    d = (x - y).abs()
-    return d.mean() if normalize else d.sum()
+class _FbaFrameLoss(torch.autograd.Function):
+    """fba_single_image_loss for ONE interior frame c (models/model.py:142-175, normalize=True):
+    (pred [B,7,H,W]) -> L_alpha_comp, L_lap, L_grad; writes the alphas / comps / Fs / Bs slices of the window tensors."""
 
+    @staticmethod
+    def forward(ctx, pred, gts, trimask, fgs, bgs, imgs, c, alphas, comps, Fs, Bs):
+        B, S, _, H, W = gts.shape
+        assert H % 32 == 0 and W % 32 == 0, 'the 5-level Laplacian pyramid needs H, W multiples of 32'
+        dev = pred.device
+        st = L.stream_ptr()
+        HW = H * W
+        pred = pred.contiguous()
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        d0, fb = f32(B, 7, H, W), f32(B, 6, H, W)
+        acc = torch.zeros(6 + LAP_LEVELS * 7 + EXCL_LEVELS * (4 + 2 * B), dtype=torch.float32, device=dev)
+        frame = (L.ptr(pred), L.ptr(gts[:, c]), L.ptr(trimask[:, c]), L.ptr(fgs[:, c]), L.ptr(bgs[:, c]), L.ptr(imgs[:, c]),
+                 7 * HW, S * HW, S * 3 * HW)
+        L.call('tcvom_fba_point_fwd', *frame, L.ptr(d0), L.ptr(fb), L.ptr(alphas[:, c]), L.ptr(comps[:, c]), L.ptr(Fs[:, c]),
+               L.ptr(Bs[:, c]), L.ptr(acc), B, H, W, st)
+        # exclusion loss: 3 levels of (F, B)
+        lv, ex = [fb], []
+        off = 6 + LAP_LEVELS * 7
+        for l in range(EXCL_LEVELS):
+            h, w = H >> l, W >> l
+            sums, terms = acc[off:off + 4], acc[off + 4:off + 4 + 2 * B]
+            off += 4 + 2 * B
+            L.call('tcvom_excl_abs', L.ptr(lv[l]), L.ptr(sums), B, h, w, st)
+            L.call('tcvom_excl_terms', L.ptr(lv[l]), L.ptr(sums), None, L.ptr(terms), 0, B, h, w, st)
+            ex.append((sums, terms.view(B, 2), 3.0 * h * w))
+            if l + 1 < EXCL_LEVELS:
+                nxt = f32(B, 6, h // 2, w // 2)
+                L.call('tcvom_avgpool2_f32', L.ptr(lv[l]), L.ptr(nxt), B * 6, h, w, st)
+                lv.append(nxt)
+        excl = sum(((t / n + EPS) ** 0.25).mean(0).sum() for _, t, n in ex) / float(EXCL_LEVELS)
+        # Laplacian loss: one pyramid of d0 = (refine - gt, F - fg, B - bg)
+        cur, sgns = d0, []
+        for l in range(LAP_LEVELS):
+            h, w = H >> l, W >> l
+            down = f32(B, 7, h // 2, w // 2)
+            sg = torch.empty((B, 7, h, w), dtype=torch.int8, device=dev)
+            L.call('tcvom_lap_down', L.ptr(cur), L.ptr(down), B * 7, h, w, st)
+            L.call('tcvom_lap_resid', L.ptr(cur), L.ptr(down), L.ptr(sg), L.ptr(acc[6 + 7 * l:]), B * 7, h, w, st)
+            sgns.append(sg)
+            cur = down
+        n1, n3 = float(B * HW), float(3 * B * HW)
+        lap_w = torch.tensor([1.0 / n1] + [0.25 / n3] * 6, dtype=torch.float32, device=dev)
+        lap_acc = acc[6:6 + 7 * LAP_LEVELS].view(LAP_LEVELS, 7)
+        pw = torch.tensor([float(2 ** l) for l in range(LAP_LEVELS)], dtype=torch.float32, device=dev)
+        L_lap = (lap_acc * lap_w[None, :] * pw[:, None]).sum()
+        L_ac = acc[0] / n1 + acc[1] / n3 + 0.25 * (acc[2] / n3 + acc[3] / n3 + acc[4] / n3)
+        L_grad = acc[5] / n1 + 0.25 * excl
+        ctx.frame_tensors = (pred, gts, trimask, fgs, bgs, imgs)
+        ctx.c, ctx.lv, ctx.ex, ctx.sgns, ctx.lap_w, ctx.pw = c, lv, ex, sgns, lap_w, pw
+        ctx.mark_non_differentiable(alphas, comps, Fs, Bs)
+        return L_ac, L_lap, L_grad
 
-def _gradient(im):
-    dy = F.pad(im[:, :, 1:, :] - im[:, :, :-1, :], (0, 0, 0, 1))
-    dx = F.pad(im[:, :, :, 1:] - im[:, :, :, :-1], (0, 1, 0, 0))
-    return dx, dy
-
-
-def l1_grad(pred, gt, normalize, epsilon=1.001e-5):
-    """utils/loss_func.py:49-58 (no mask)."""
-    fx, fy = _gradient(pred)
-    tx, ty = _gradient(gt)
-    return _l1(torch.sqrt(fx * fx + fy * fy + epsilon), torch.sqrt(tx * tx + ty * ty + epsilon), normalize)
-
-
-def exclusion_loss(img1, img2, level=3, epsilon=1.001e-5, normalize=True):
-    """utils/loss_func.py:63-90."""
-    lx, ly = [], []
-    for _ in range(level):
-        gx1, gy1 = _gradient(img1)
-        gx2, gy2 = _gradient(img2)
-        ax = 2.0 * gx1.abs().mean() / (gx2.abs().mean() + epsilon)
-        ay = 2.0 * gy1.abs().mean() / (gy2.abs().mean() + epsilon)
-        sx1, sy1 = torch.sigmoid(gx1) * 2 - 1, torch.sigmoid(gy1) * 2 - 1
-        sx2, sy2 = torch.sigmoid(gx2 * ax) * 2 - 1, torch.sigmoid(gy2 * ay) * 2 - 1
-        lx.append((((sx1 * sx1) * (sx2 * sx2)).mean(dim=(1, 2, 3)) + epsilon) ** 0.25)
-        ly.append((((sy1 * sy1) * (sy2 * sy2)).mean(dim=(1, 2, 3)) + epsilon) ** 0.25)
-        img1 = F.avg_pool2d(img1, 2, 2)
-        img2 = F.avg_pool2d(img2, 2, 2)
-    red = torch.mean if normalize else torch.sum
-    return red(sum(lx) / float(level)) + red(sum(ly) / float(level))
-
-
-def _gauss5(img, scale=1.0):
-    """5x5 binomial filter with reflect padding (LapLoss.conv_gauss), separable."""
-    x = F.pad(img, (2, 2, 2, 2), mode='reflect')
-    H, W = img.shape[-2:]
-    v = sum(_G5[k] * x[:, :, k:k + H, :] for k in range(5))
-    return sum((_G5[k] * scale) * v[:, :, :, k:k + W] for k in range(5))
-
-
-def laplacian_pyramid(img, levels=5):
-    """utils/loss_func.py:114-147."""
-    cur, pyr = img, []
-    for _ in range(levels):
-        down = _gauss5(cur)[:, :, ::2, ::2]
-        up = torch.zeros((down.shape[0], down.shape[1], down.shape[2] * 2, down.shape[3] * 2), dtype=img.dtype, device=img.device)
-        up[:, :, ::2, ::2] = down
-        pyr.append(cur - _gauss5(up, 4.0))
-        cur = down
-    return pyr
-
-
-def lap_loss(img, tgt, normalize):
-    """LapLoss.forward (utils/loss_func.py:149-158, no mask)."""
-    with torch.no_grad():
-        pt = laplacian_pyramid(tgt)
-    loss = sum((2 ** lvl) * (a - b).abs().sum() for lvl, (a, b) in enumerate(zip(laplacian_pyramid(img), pt)))
-    return loss / float(tgt.numel()) if normalize else loss
+    @staticmethod
+    def backward(ctx, g_ac, g_lap, g_grad):
+        pred, gts, trimask, fgs, bgs, imgs = ctx.frame_tensors
+        c = ctx.c
+        B, S, _, H, W = gts.shape
+        HW = H * W
+        dev = pred.device
+        st = L.stream_ptr()
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        g_ac = zero if g_ac is None else g_ac.float()
+        g_lap = zero if g_lap is None else g_lap.float()
+        g_grad = zero if g_grad is None else g_grad.float()
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        n1, n3 = float(B * HW), float(3 * B * HW)
+        coef = torch.stack([g_ac / n1, g_ac / n3, 0.25 * g_ac / n3, 0.25 * g_ac / n3, 0.25 * g_ac / n3, g_grad / n1]).contiguous()
+        # exclusion: d L / d terms, then level by level from the coarsest
+        dl = None
+        for l in reversed(range(EXCL_LEVELS)):
+            sums, terms, n = ctx.ex[l]
+            h, w = H >> l, W >> l
+            wts = (g_grad * (0.25 / float(EXCL_LEVELS) / float(B)) * 0.25 * (terms / n + EPS) ** (-0.75) / n).contiguous()
+            dsum = torch.zeros(2, dtype=torch.float32, device=dev)
+            L.call('tcvom_excl_terms', L.ptr(ctx.lv[l]), L.ptr(sums), L.ptr(wts), L.ptr(dsum), 1, B, h, w, st)
+            cur = f32(B, 6, h, w)
+            L.call('tcvom_excl_bwd', L.ptr(ctx.lv[l]), L.ptr(sums), L.ptr(wts), L.ptr(dsum), L.ptr(dl), L.ptr(cur), B, h, w, st)
+            dl = cur
+        # Laplacian: g_l = s_l + D^T (g_{l+1} - U^T s_l), from the top level down
+        g = None
+        for l in reversed(range(LAP_LEVELS)):
+            h, w = H >> l, W >> l
+            cf = (g_lap * ctx.pw[l] * ctx.lap_w).contiguous()
+            r = f32(B, 7, h // 2, w // 2)
+            L.call('tcvom_lap_bwd_coarse', L.ptr(ctx.sgns[l]), L.ptr(cf), L.ptr(g), L.ptr(r), B * 7, h, w, st)
+            g = f32(B, 7, h, w)
+            L.call('tcvom_lap_bwd_fine', L.ptr(ctx.sgns[l]), L.ptr(cf), L.ptr(r), L.ptr(g), B * 7, h, w, st)
+        dpred = torch.empty_like(pred)
+        L.call('tcvom_fba_point_bwd', L.ptr(pred), L.ptr(gts[:, c]), L.ptr(trimask[:, c]), L.ptr(fgs[:, c]), L.ptr(bgs[:, c]),
+               L.ptr(imgs[:, c]), 7 * HW, S * HW, S * 3 * HW, L.ptr(coef), L.ptr(g), L.ptr(dl), L.ptr(dpred), B, H, W, st)
+        return (dpred,) + (None,) * 10
 
 
 def fba_single_image_loss(preds, trimasks, gts, fgs, bgs, imgs, normalize=True):
     """models/model.py:129-197 for the interior frames.  preds [B,S-2,7,H,W] (interior frames only); the other tensors
     [B,S,*,H,W].  -> L_alpha_comp, L_lap, L_grad, alphas, comps, Fs, Bs ([B,S,*,H,W], zeros at the ends)."""
+    assert normalize, 'FullModel.FBA_LOSS_NORMALIZE is True in the reference (models/model.py:28); the summed variant is not built'
     B, S = gts.shape[:2]
+    alphas = torch.zeros_like(gts)
+    comps, Fs, Bs = torch.zeros_like(fgs), torch.zeros_like(fgs), torch.zeros_like(fgs)
     La, Ll, Lg = [], [], []
-    zero1, zero3 = torch.zeros_like(gts[:, 0]), torch.zeros_like(fgs[:, 0])
-    alphas, comps, Fs, Bs = [zero1] * S, [zero3] * S, [zero3] * S, [zero3] * S
     for c in range(1, S - 1):
-        gt, img, fg, bg = gts[:, c], imgs[:, c], fgs[:, c], bgs[:, c]
-        m = trimasks[:, c] > 0
-        p = preds[:, c - 1]
-        refine = torch.where(m, p[:, :1], gt)
-        cF = torch.where(m, p[:, 1:4], fg)
-        cB = torch.where(m, p[:, 4:7], bg)
-        alphas[c], Fs[c], Bs[c] = refine, cF, cB
-        comps[c] = cF * refine + cB * (1.0 - refine)
-        L_a1 = _l1(refine, gt, normalize)
-        L_ac = _l1(cF * gt + cB * (1.0 - gt), img, normalize)
-        L_FBc = _l1(fg * refine + bg * (1.0 - refine), img, normalize)
-        L_FB1 = _l1(cF, fg, normalize) + _l1(cB, bg, normalize)
-        La.append(L_a1 + L_ac + 0.25 * (L_FBc + L_FB1))
-        Lg.append(l1_grad(refine, gt, normalize) + 0.25 * exclusion_loss(cF, cB, 3, normalize=normalize))
-        Ll.append(lap_loss(refine, gt, normalize) + 0.25 * (lap_loss(cF, fg, normalize) + lap_loss(cB, bg, normalize)))
+        a, l, g = _FbaFrameLoss.apply(preds[:, c - 1], gts, trimasks, fgs, bgs, imgs, c, alphas, comps, Fs, Bs)
+        La.append(a)
+        Ll.append(l)
+        Lg.append(g)
     n = float(len(La))
-    st = lambda lst: torch.stack(lst, dim=1)
-    return sum(La) / n, sum(Ll) / n, sum(Lg) / n, st(alphas), st(comps), st(Fs), st(Bs)
+    return sum(La) / n, sum(Ll) / n, sum(Lg) / n, alphas, comps, Fs, Bs
 
 
 def attention_loss(attb, attf, unk_small, gts, window, att_thres, label_smooth, os=8):

@@ -314,3 +314,38 @@ def test_eval_model_against_reference_golden():
         mse = float(((got.cpu() - want) ** 2).mean())
         assert mse <= 1e-4, '%s MSE %.3e' % (nm, mse)
     assert float(alphas[:, 0].abs().max()) == 0 and float(alphas[:, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 64, 96), (1, 64, 64), (1, 96, 160)])
+def test_frame_loss_kernels_against_oracle(B, H, W):
+    """The fused FBA loss kernels (L1 family + L1_grad, 3-level exclusion loss, 7-channel Laplacian pyramid) for one interior
+    frame: the three losses, the visualisation slices and d loss / d pred against oracle.fba_net.fba_single_image_loss
+    under torch autograd (fp32 both sides)."""
+    from oracle import fba_net
+    from tcvom_amd import fba_losses as FL
+    S = 3
+    tag = 'fl%d_%d' % (B, H)
+    u = lambda n, shape: hu('%s.%s' % (tag, n), shape) * 0.5 + 0.5
+    gts, fgs, bgs = u('gt', (B, S, 1, H, W)), u('fg', (B, S, 3, H, W)), u('bg', (B, S, 3, H, W))
+    imgs = fgs * gts + bgs * (1 - gts)
+    tm = (hu(tag + '.m', (B, S, 1, H // 8, W // 8)) > -0.2).float().repeat_interleave(8, 3).repeat_interleave(8, 4)
+    pred = u('pred', (B, 1, 7, H, W))
+    pg = pred.to(DEV).requires_grad_(True)
+    dev = lambda t: t.to(DEV)
+    out = FL.fba_single_image_loss(pg, dev(tm), dev(gts), dev(fgs), dev(bgs), dev(imgs))
+    pr = pred.clone().requires_grad_(True)
+    full = torch.cat([torch.zeros_like(pr), pr, torch.zeros_like(pr)], 1)
+    ref = fba_net.fba_single_image_loss(full, tm, gts, fgs, bgs, imgs, True)
+    wts = (1.0, 0.7, 1.3)
+    sum(w * o for w, o in zip(wts, out[:3])).backward()
+    sum(w * o for w, o in zip(wts, ref[:3])).backward()
+    ck = Checker()
+    for i, nm in enumerate(('L_alpha_comp', 'L_lap', 'L_grad')):
+        ck.rel(nm, out[i], ref[i], 2e-5)
+    for i, nm in ((3, 'alphas'), (4, 'comps'), (5, 'Fs'), (6, 'Bs')):
+        ck.rel(nm, out[i], ref[i], 1e-6)
+    # |x| kinks: a handful of residuals of the pyramids sit within rounding of zero, where the two evaluations may pick
+    # different subgradients -- compared in L2
+    ck.l2('dpred', pg.grad, pr.grad, 2e-3)
+    ck.done()
+    assert float(pg.grad.abs().max()) > 0
