@@ -33,6 +33,13 @@ struct Gemm256Args {
     long long a_bstride, b_bstride, out_bstride, vec_bstride;
 };
 
+#ifdef G256_TRACE
+__device__ unsigned long long g256_trace[512];
+extern "C" int tcvom_trace256_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g256_trace), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -1;
+}
+#endif
+
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     constexpr int TM = 256, TN = 256;
     constexpr int SLOT = (TM + TN) * 64;                 // bf16 elements per K-tile buffer
@@ -112,7 +119,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         }                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                       \
     }
+#ifdef G256_TRACE                                      // tools/g256_trace.py: (arrive, leave) cycle stamps of every barrier
+    const bool trace_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 4);
+    int trace_i = 0;
+#define G_BAR()                                                                                              \
+    {                                                                                                        \
+        if (trace_on && trace_i < 250) g256_trace[(wave >> 2) * 256 + trace_i++] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        if (trace_on && trace_i < 250) g256_trace[(wave >> 2) * 256 + trace_i++] = __builtin_readcyclecounter(); \
+    }
+#else
 #define G_BAR() __builtin_amdgcn_s_barrier()
+#endif
 
     const int ntile = K >> 6;
     // prologue: K-tile 0 into buffer 0 (all waves), then the stagger
