@@ -67,14 +67,41 @@ def pred(dataset, indices, device, args):
     model.NET.load_state_dict(torch.load(args.load, map_location='cpu'), strict=True)
     model.to(device).eval()
     out = []
-    for i in range(*indices):
-        imgs, tris, (H, W) = dataset[i]
-        alpha = model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0)).squeeze()[c][:H, :W].cpu().numpy()
+
+    def save(i, alpha):
         info = os.path.normpath(dataset.samples[i][c][0]).split(os.sep)
         outfn = os.path.join(args.save, info[-2], info[-1][:-8] + '_alpha.png')
         os.makedirs(os.path.dirname(outfn), exist_ok=True)
         Image.fromarray(np.uint8(alpha * 255)).save(outfn)
         out.append(outfn)
+
+    first, last = indices
+    if args.model == 'vmn_gca' and not args.per_sample:
+        # whole clips: every frame goes through the encoder once and its features serve the three windows containing
+        # it (EvalModel.forward_video) -- same outputs as the per-sample loop below at a third of the encoder work
+        i = first
+        while i < last:
+            vid = os.path.dirname(dataset.samples[i][c][0])
+            j = i
+            while j < last and os.path.dirname(dataset.samples[j][c][0]) == vid:
+                j += 1
+            whole = (i == 0 or os.path.dirname(dataset.samples[i - 1][c][0]) != vid) and \
+                    (j == len(dataset) or os.path.dirname(dataset.samples[j][c][0]) != vid)
+            if whole and j - i >= 2:
+                frames = [dataset[k] for k in range(i, j)]
+                H, W = frames[0][2]
+                alphas = model.forward_video(torch.stack([f[0][c] for f in frames]), torch.stack([f[1][c] for f in frames]))
+                for k in range(i, j):
+                    save(k, alphas[k - i, 0, :H, :W].cpu().numpy())
+            else:                                       # a clip split across workers: per-sample windows
+                for k in range(i, j):
+                    imgs, tris, (H, W) = dataset[k]
+                    save(k, model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0)).squeeze()[c][:H, :W].cpu().numpy())
+            i = j
+        return out
+    for i in range(first, last):
+        imgs, tris, (H, W) = dataset[i]
+        save(i, model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0)).squeeze()[c][:H, :W].cpu().numpy())
     return out
 
 
@@ -96,6 +123,7 @@ def parse(argv=None):
     ap.add_argument('--agg_window', type=int, default=7)
     ap.add_argument('--dilation', type=int, default=None)
     ap.add_argument('--gpu', type=int, default=0)
+    ap.add_argument('--per_sample', action='store_true', help='one EvalModel call per 3-frame sample (the reference loop) instead of whole clips with cached features')
     return ap.parse_args(argv)
 
 

@@ -341,6 +341,48 @@ class EvalModel(FullModel):
         return alphas
 
 
+    def forward_video(self, imgs, tris, chunk=4):
+        """A whole clip at once: imgs [T,3,H,W] BGR 0..255, tris [T,1,H,W] in {0,128,255} -> alphas
+        [T,1,H,W], frame c predicted from (c-1, c, c+1) with the clip ends mirrored exactly as pred_test.py:27-41 builds
+        its samples.  In eval mode the encoder + decoder-front output of a frame does not depend on its window
+        (BatchNorm running statistics, stored SpectralNorm u / v), so it is computed ONCE per frame (`chunk` frames per
+        launch) and shared by the three windows that contain the frame: a third of the encoder work of per-sample calls."""
+        from .weights import bank_token
+        assert self.method == 'gca' and not self.training, 'feature caching: vmn_gca in eval mode'
+        T, _, H, W = imgs.shape
+        assert T >= 2 and chunk >= 2 and H % 32 == 0 and W % 32 == 0
+        net, bank = self.NET, self.NET._bank
+        dev = self.IMG_MEAN.device                                  # the clip may stay on the host: chunks are uploaded
+        dil = self.DILATION_KERNEL if self.DILATION_KERNEL is not None else 0
+        alphas = torch.zeros((T, 1, H, W), dtype=torch.float32, device=dev)
+        feats, mids, unk8, trimask, gts = {}, {}, {}, {}, {}
+        with torch.no_grad():
+            for c in range(T):
+                p = c + 1 if c == 0 else c - 1
+                n = c - 1 if c == T - 1 else c + 1
+                if max(p, n) not in feats:                              # next chunk of frames through encoder + front
+                    lo = max(feats) + 1 if feats else 0
+                    hi = min(T, lo + chunk)
+                    prep = preprocess_window(tris[lo:hi].unsqueeze(0).to(dev), imgs[lo:hi].unsqueeze(0).to(dev), None, dil, 0.0)
+                    X = prep.x8[0].contiguous()
+                    U = prep.unk[0, :, ::TAM_OS, ::TAM_OS].contiguous()
+                    token = bank_token(bank, hi - lo, False)
+                    emb, mid = net.encoder.run(X, U, token, False)
+                    feat = net.decoder.run_front(emb, mid, token, False)
+                    for k, i in enumerate(range(lo, hi)):
+                        feats[i] = feat[k:k + 1]
+                        mids[i] = {key: (tuple(t[k:k + 1] for t in v) if isinstance(v, (tuple, list)) else v[k:k + 1])
+                                   for key, v in mid.items() if key != 'unknown'}
+                        mids[i]['unknown'] = U[k:k + 1]
+                        unk8[i], trimask[i], gts[i] = U[k:k + 1], prep.trimask[0, k], prep.gts[0, k]
+                token = bank_token(bank, 1, False)
+                pred, _ab, _af = net.decoder.run_tail(feats[c], feats[p], feats[n], unk8[c], mids[c], token, False)
+                alphas[c] = torch.where(trimask[c] > 0, pred[0].float(), gts[c])
+                for i in [i for i in feats if i < c - 1]:               # frames no later window needs
+                    for d in (feats, mids, unk8, trimask, gts):
+                        d.pop(i, None)
+        return alphas
+
     def _forward_fba_eval(self, prep, B, S, H, W):
         """FBA: (alphas, Fs, Bs) -- prediction inside the unknown region, trimap value / image elsewhere (:425-453)."""
         x2, extras, _ = fba_network_input(prep, 0.0, use_dilated=False)
