@@ -42,6 +42,9 @@ class TcvomError(RuntimeError):
 
 
 def _load():
+    # torch first: its bundled HIP runtime must be the one this library binds to (loading the library before torch
+    # would resolve libamdhip64 from /opt/rocm and leave two runtimes in the process, the second one without a device)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'tcvom_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
