@@ -32,20 +32,24 @@ def test_poly_lr_matches_reference_formula():
 
 
 @pytest.mark.gpu
-def test_train_ddp_two_steps_and_checkpoint(tmp_path):
+@pytest.mark.parametrize('arch,nkeys', [('vmn_gca', 584), ('vmn_fba', 203), ('vmn_dim', 113)])
+def test_train_ddp_two_steps_and_checkpoint(tmp_path, arch, nkeys):
+    """train_ddp.py counterpart for every VMN architecture on the HIP path: two optimizer steps on 5-frame synthetic
+    clips (L_dt active), checkpoint with the reference's state_dict layout that loads back strictly."""
     sys.path.insert(0, REPO)
     import train_ddp
     from tcvom_amd.config import get_cfg_defaults
     cfg = get_cfg_defaults()
     cfg.merge_from_file(os.path.join(REPO, 'cfgs', 'vmd_vmn_gca_synthetic.yaml'))
-    cfg.merge_from_list(['TRAIN.TRAIN_INPUT_SIZE', '(128, 160)', 'SYSTEM.OUTDIR', str(tmp_path), 'TRAIN.TOTAL_STEPS', '1'])
-    train_ddp.main('vmd_vmn_gca_synthetic', cfg, steps_per_epoch=2, frames=5)
-    ck = os.path.join(str(tmp_path), 'vmd_vmn_gca_synthetic_agg7_synthetic', 'checkpoint_1.pth.tar')
+    cfg.merge_from_list(['TRAIN.TRAIN_INPUT_SIZE', '(128, 160)', 'SYSTEM.OUTDIR', str(tmp_path), 'TRAIN.TOTAL_STEPS', '1',
+                         'MODEL', arch])
+    train_ddp.main('vmd_%s_synthetic' % arch, cfg, steps_per_epoch=2, frames=5)
+    ck = os.path.join(str(tmp_path), 'vmd_%s_synthetic_agg7_synthetic' % arch, 'checkpoint_1.pth.tar')
     sd = torch.load(ck, map_location='cpu')
-    assert len(sd) == 584 and all(torch.isfinite(v.float()).all() for v in sd.values())
+    assert len(sd) == nkeys and all(torch.isfinite(v.float()).all() for v in sd.values())
     # the checkpoint loads back through the reference's loading code path
     from models.model import FullModel_VMD
-    m = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+    m = FullModel_VMD(arch, agg_window=7, dilate_kernel=12)
     missing, unexpected = m.NET.load_state_dict(sd, strict=False)
     assert not missing and not unexpected
 
