@@ -123,10 +123,14 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # TCVOM_DIST_BACKEND=gloo: dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices; RCCL
+    # refuses that).  The driver's multi-GPU runs use the default: one rank per GPU over RCCL.
+    backend = os.environ.get('TCVOM_DIST_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group(backend='nccl', init_method='env://')
+        dist.init_process_group(backend=backend, init_method='env://')
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
 
     from tcvom_amd.ddp import GradientAverager, broadcast_module_state, convert_sync_batchnorm

@@ -198,3 +198,27 @@ def test_calc_metric_folder(tmp_path):
 def argparse_ns(**kw):
     import argparse
     return argparse.Namespace(**kw)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_dry_run():
+    """bench.py's N > 1 path end to end (rendezvous, state broadcast, in-place gradient all-reduce, max-over-ranks timing,
+    one JSON line from rank 0) with two ranks sharing this GPU over gloo (RCCL wants one GPU per rank)."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TCVOM_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--height', '128', '--width', '160', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch_clips'] == 2 and res['value'] > 0 and res['scaling'] == 'weak'
+    assert np.isfinite(res['final_loss'])
