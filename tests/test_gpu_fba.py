@@ -349,3 +349,25 @@ def test_frame_loss_kernels_against_oracle(B, H, W):
     ck.l2('dpred', pg.grad, pr.grad, 2e-3)
     ck.done()
     assert float(pg.grad.abs().max()) > 0
+
+
+def test_window_batch_of_two_against_oracle():
+    """B = 2 clips in one window (every sample is its own GroupNorm statistics slot): losses and alpha against the CPU oracle."""
+    from oracle import fba_net
+    from helpers import fba_formula_state
+    B, S, H, W, dil = 2, 3, 64, 64, 3
+    fm = _build('b2', dil, S)
+    a, fg, bg = synthetic_window(B, S, H, W, seed=7)
+    out = fm(a.to(DEV), fg.to(DEV), bg.to(DEV))
+    (out[0] + out[1] + out[2] + 0.25 * out[4]).backward()
+    with torch.no_grad():
+        ref, _ = fba_net.fba_window_forward(fba_formula_state(False), a, fg, bg, window=7, dilate_kernel=dil)
+    ck = Checker()
+    for i, nm in ((0, 'L_alpha_comp'), (1, 'L_lap'), (2, 'L_grad'), (4, 'L_att')):
+        ck.rel(nm, out[i], ref[i], 2e-2)
+    ck.done()
+    for i, nm in ((7, 'alphas'), (10, 'Fs'), (11, 'Bs')):
+        mse = float(((out[i].cpu() - ref[i]) ** 2).mean())
+        assert mse <= 1e-4, '%s MSE %.3e' % (nm, mse)
+    assert not torch.allclose(out[7][0], out[7][1])
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fm.NET.parameters())
