@@ -68,6 +68,10 @@ def pred(dataset, indices, device, args):
     model.to(device).eval()
     out = []
 
+    def run_sample(imgs, tris):
+        res = model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0))
+        return (res[0] if isinstance(res, tuple) else res).squeeze()         # FBA returns (alphas, Fs, Bs)
+
     def save(i, alpha):
         info = os.path.normpath(dataset.samples[i][c][0]).split(os.sep)
         outfn = os.path.join(args.save, info[-2], info[-1][:-8] + '_alpha.png')
@@ -96,12 +100,12 @@ def pred(dataset, indices, device, args):
             else:                                       # a clip split across workers: per-sample windows
                 for k in range(i, j):
                     imgs, tris, (H, W) = dataset[k]
-                    save(k, model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0)).squeeze()[c][:H, :W].cpu().numpy())
+                    save(k, run_sample(imgs, tris)[c][:H, :W].cpu().numpy())
             i = j
         return out
     for i in range(first, last):
         imgs, tris, (H, W) = dataset[i]
-        save(i, model(imgs.to(device).unsqueeze(0), tris.to(device).unsqueeze(0)).squeeze()[c][:H, :W].cpu().numpy())
+        save(i, run_sample(imgs, tris)[c][:H, :W].cpu().numpy())
     return out
 
 
