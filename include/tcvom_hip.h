@@ -207,13 +207,16 @@ int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, 
 /* ------------------------------------------------------------------ Temporal Attention Module
  * Replaces FeatureAggregationModule._attention x2 + `v + xb + xf` (models/VMN/VMN_model.py:24-68).
  * q,kb,kf,v,out: NHWC bf16 [B,H,W,C]; mask uint8 [B,H,W]; attb/attf fp32 [B,window^2,H*W].      */
+/* worklist: int32 [B*H*W + 1] device scratch; tam_fwd fills it with the number and the flat indices of the unknown pixels
+ * (the attention runs on those only; the other pixels get out = v and zero logits) and tam_bwd reads it back */
 int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, const void* v, const uint8_t* mask,
-                  void* out, float* attb, float* attf, int32_t B, int32_t H, int32_t W, int32_t C,
+                  void* out, float* attb, float* attf, int32_t* worklist, int32_t B, int32_t H, int32_t W, int32_t C,
                   int32_t window, void* stream);
 /* pbuf, dsbuf: fp32 scratch [B][2][window^2][H*W]; dattb/dattf may be NULL */
 int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, const uint8_t* mask, const void* dout,
                   const float* dattb, const float* dattf, void* dq, void* dkb, void* dkf,
-                  float* pbuf, float* dsbuf, int32_t B, int32_t H, int32_t W, int32_t C, int32_t window, void* stream);
+                  float* pbuf, float* dsbuf, const int32_t* worklist, int32_t B, int32_t H, int32_t W, int32_t C,
+                  int32_t window, void* stream);
 
 /* ------------------------------------------------------------------ Guided Contextual Attention pieces
  * (models/GCA/ops.py:106-229); the two N x N GEMMs go through tcvom_conv_igemm / tcvom_wgrad_igemm. */

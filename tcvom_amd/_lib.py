@@ -126,8 +126,8 @@ _PROTOS = {
     'tcvom_fold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_dim_losses_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, vp],
     'tcvom_dim_losses_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, vp],
-    'tcvom_tam_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
-    'tcvom_tam_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_tam_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_tam_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_gca_prepare': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_row_softmax': [vp, vp, i32, i32, i64, i64, vp],
     'tcvom_row_softmax_bwd': [vp, vp, vp, vp, i32, i32, i64, i64, i32, vp],

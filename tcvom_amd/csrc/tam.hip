@@ -19,19 +19,23 @@ template <int WIN, int NP>
 __global__ __launch_bounds__(256) void tam_fwd_kernel(
     const unsigned* __restrict__ q, const unsigned* __restrict__ kb, const unsigned* __restrict__ kf,
     const unsigned* __restrict__ v, const unsigned char* __restrict__ mask,
-    unsigned* __restrict__ out, float* __restrict__ attb, float* __restrict__ attf,
+    unsigned* __restrict__ out, float* __restrict__ attb, float* __restrict__ attf, const int* __restrict__ worklist,
     int B, int H, int W, int C, float inv_sqrt_c)
 {
     constexpr int W2 = WIN * WIN, R = WIN / 2;
     const int lane = threadIdx.x & 63;
     const int64_t N = (int64_t)H * W;
-    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= B * N) return;
+    const int CP = C / 2;                       // channel pairs per pixel
+    // one wave per UNKNOWN pixel, taken from the compacted work list (known pixels: out = v and zero logits, done by the
+    // launcher with a copy and a memset).  The kernel keeps 49 key slices + logits + probabilities in registers
+    // (256 VGPRs, one wave per SIMD), so it must not be launched over the >95 % known pixels of a typical trimap.
+    const int nwork = worklist[0];
+    for (int wi = blockIdx.x * 4 + (threadIdx.x >> 6); wi < nwork; wi += gridDim.x * 4) {
+    const int64_t pix = worklist[1 + wi];
     const int b = (int)(pix / N);
     const int64_t u = pix % N;
     const int y = (int)(u / W), x = (int)(u % W);
-    const int CP = C / 2;                       // channel pairs per pixel
-    const bool unknown = mask[pix] != 0;
+    const bool unknown = true;
 
     float o[NP][2];
     unsigned qq[NP];
@@ -47,10 +51,8 @@ __global__ __launch_bounds__(256) void tam_fwd_kernel(
     for (int dir = 0; dir < 2; ++dir) {
         const unsigned* __restrict__ k = dir == 0 ? kb : kf;
         float* __restrict__ att = dir == 0 ? attb : attf;
-        if (!unknown) {
-            for (int j = lane; j < W2; j += 64) att[((int64_t)b * W2 + j) * N + u] = 0.f;
-            continue;
-        }
+        if (!unknown) continue;                 // the logit maps are zero-filled by the launcher (one memset instead of
+                                                // 2 x 49 scattered 4-byte stores per known pixel)
         unsigned kk[W2][NP];
         float lg[W2];
 #pragma unroll
@@ -94,6 +96,13 @@ __global__ __launch_bounds__(256) void tam_fwd_kernel(
         const int cp = lane + 64 * i;
         if (cp < CP) out[pix * CP + cp] = pack2bf(o[i][0], o[i][1]);
     }
+    }
+}
+
+// worklist[0] = number of unknown pixels, worklist[1..] = their flat indices (any order); worklist[0] zeroed by the launcher
+__global__ void tam_compact_kernel(const unsigned char* __restrict__ mask, int* __restrict__ worklist, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i] != 0) worklist[1 + atomicAdd(worklist, 1)] = (int)i;
 }
 
 // Backward pass A (per query pixel): recompute p; dp_j = <dout, k_j>; ds = p*(dp - sum p dp) + datt;
@@ -103,19 +112,20 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
     const unsigned* __restrict__ q, const unsigned* __restrict__ kb, const unsigned* __restrict__ kf,
     const unsigned char* __restrict__ mask, const unsigned* __restrict__ dout,
     const float* __restrict__ dattb, const float* __restrict__ dattf,
-    unsigned* __restrict__ dq, float* __restrict__ pbuf, float* __restrict__ dsbuf,
+    unsigned* __restrict__ dq, float* __restrict__ pbuf, float* __restrict__ dsbuf, const int* __restrict__ worklist,
     int B, int H, int W, int C, float inv_sqrt_c)
 {
     constexpr int W2 = WIN * WIN, R = WIN / 2;
     const int lane = threadIdx.x & 63;
     const int64_t N = (int64_t)H * W;
-    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= B * N) return;
+    const int CP = C / 2;
+    const int nwork = worklist[0];                 // unknown pixels only (dq of the others is zero-filled by the launcher)
+    for (int wi = blockIdx.x * 4 + (threadIdx.x >> 6); wi < nwork; wi += gridDim.x * 4) {
+    const int64_t pix = worklist[1 + wi];
     const int b = (int)(pix / N);
     const int64_t u = pix % N;
     const int y = (int)(u / W), x = (int)(u % W);
-    const int CP = C / 2;
-    const bool unknown = mask[pix] != 0;
+    const bool unknown = true;
     float dqa[NP][2];
     unsigned qq[NP], go[NP];
 #pragma unroll
@@ -131,10 +141,7 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
         const float* __restrict__ datt = dir == 0 ? dattb : dattf;
         float* __restrict__ pb = pbuf + ((int64_t)(b * 2 + dir) * W2) * N;
         float* __restrict__ db = dsbuf + ((int64_t)(b * 2 + dir) * W2) * N;
-        if (!unknown) {
-            for (int j = lane; j < W2; j += 64) { pb[(int64_t)j * N + u] = 0.f; db[(int64_t)j * N + u] = 0.f; }
-            continue;
-        }
+        if (!unknown) continue;                 // pass B reads p / ds of unknown query pixels only
         unsigned kk[W2][NP];
         float lg[W2], dp[W2];
 #pragma unroll
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
     for (int i = 0; i < NP; ++i) {
         const int cp = lane + 64 * i;
         if (cp < CP) dq[pix * CP + cp] = pack2bf(dqa[i][0], dqa[i][1]);
+    }
     }
 }
 
@@ -232,6 +240,120 @@ __global__ __launch_bounds__(256) void tam_bwd_key_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------ LDS-tiled kernels (C <= 128)
+// A workgroup owns an 8 x 8 pixel tile; tiles without unknown pixels exit at once.  The (8+6) x (8+6) key halos of BOTH
+// directions and the query tile are staged in LDS (zero rows outside the image).  One wave per unknown pixel:
+//   phase A  lane j (< 49) owns neighbour j: logit_j = <q, k_j> with v_dot2_f32_bf16 over 16-byte chunks; lane j starts at
+//            chunk j so that the 16 lanes of an LDS read group hit 16 different banks although all key rows start on bank 0;
+//            the softmax is then TWO wave reductions (the one-wave-per-pixel kernel above needs 49, one per neighbour)
+//   phase B  lane = channel pair: out = v + sum_j p_j k_j, p_j broadcast with v_readlane, key rows read conflict-free
+#define TT_TH 8
+#define TT_TW 8
+typedef __attribute__((ext_vector_type(2))) __bf16 tam_bf2;
+__device__ __forceinline__ float tam_dot8(const uint4 a, const uint4 b, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.x), __builtin_bit_cast(tam_bf2, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.y), __builtin_bit_cast(tam_bf2, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.z), __builtin_bit_cast(tam_bf2, b.z), acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.w), __builtin_bit_cast(tam_bf2, b.w), acc, false);
+}
+__device__ __forceinline__ float tam_lane(float v, int j) {
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
+}
+
+// MODE 0: forward (out, logits).  MODE 1: backward pass A (dq, p and ds / sqrt(C) for pass B); `g` = dout, datt* may be NULL.
+template <int WIN, int MODE>
+__global__ __launch_bounds__(256) void tam_tiled_kernel(
+    const uint4* __restrict__ q, const uint4* __restrict__ kb, const uint4* __restrict__ kf, const unsigned* __restrict__ v,
+    const uint4* __restrict__ g, const unsigned char* __restrict__ mask, unsigned* __restrict__ out,
+    float* __restrict__ att0, float* __restrict__ att1, const float* __restrict__ datt0, const float* __restrict__ datt1,
+    int H, int W, int C, float inv_sqrt_c)
+{
+    constexpr int W2 = WIN * WIN, R = WIN / 2, HH = TT_TH + 2 * R, HW = TT_TW + 2 * R, NT = TT_TH * TT_TW;
+    __shared__ uint4 halo[2 * HH * HW * 16];           // both directions, up to 16 chunks (128 channels) per key pixel
+    __shared__ uint4 qt[NT * 16];
+    __shared__ uint4 gt[MODE == 1 ? NT * 16 : 1];
+    __shared__ int list[NT];
+    __shared__ int cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C8 = C >> 3, CP = C >> 1;
+    const int b = blockIdx.z, ty0 = blockIdx.y * TT_TH, tx0 = blockIdx.x * TT_TW;
+    const int64_t N = (int64_t)H * W;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    if (tid < NT) {
+        const int y = ty0 + tid / TT_TW, x = tx0 + tid % TT_TW;
+        if (y < H && x < W && mask[b * N + (int64_t)y * W + x] != 0) list[atomicAdd(&cnt, 1)] = tid;
+    }
+    __syncthreads();
+    const int nu = cnt;
+    if (nu == 0) return;
+    for (int idx = tid; idx < 2 * HH * HW * C8; idx += 256) {
+        const int d = idx / (HH * HW * C8), rem = idx - d * (HH * HW * C8);
+        const int r = rem / C8, c = rem - r * C8;
+        const int y = ty0 + r / HW - R, x = tx0 + r % HW - R;
+        uint4 val = make_uint4(0u, 0u, 0u, 0u);
+        if (y >= 0 && y < H && x >= 0 && x < W) val = (d == 0 ? kb : kf)[(b * N + (int64_t)y * W + x) * C8 + c];
+        halo[(d * HH * HW + r) * C8 + c] = val;
+    }
+    for (int idx = tid; idx < NT * C8; idx += 256) {
+        const int p = idx / C8, c = idx - p * C8;
+        const int y = ty0 + p / TT_TW, x = tx0 + p % TT_TW;
+        const bool in = y < H && x < W;
+        qt[idx] = in ? q[(b * N + (int64_t)y * W + x) * C8 + c] : make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == 1) gt[idx] = in ? g[(b * N + (int64_t)y * W + x) * C8 + c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int j = lane < W2 ? lane : W2 - 1;            // idle lanes shadow the last neighbour
+    for (int li = wave; li < nu; li += 4) {
+        const int t = list[li];
+        const int py = t / TT_TW, px = t % TT_TW;
+        const int64_t u = (int64_t)(ty0 + py) * W + tx0 + px;
+        const int64_t pix = b * N + u;
+        float o0 = 0.f, o1 = 0.f;
+        if (MODE == 0 && lane < CP) { const unsigned vv = v[pix * CP + lane]; o0 = bflo(vv); o1 = bfhi(vv); }
+#pragma unroll 1
+        for (int dir = 0; dir < 2; ++dir) {
+            const uint4* hl = halo + dir * HH * HW * C8;
+            const int rj = ((py + j / WIN) * HW + px + j % WIN) * C8;
+            float lg = 0.f, dp = 0.f;
+            for (int sidx = 0; sidx < C8; ++sidx) {
+                int c = sidx + lane;
+                c = c >= C8 ? c % C8 : c;
+                const uint4 kv = hl[rj + c];
+                lg = tam_dot8(qt[t * C8 + c], kv, lg);
+                if (MODE == 1) dp = tam_dot8(gt[t * C8 + c], kv, dp);
+            }
+            lg *= inv_sqrt_c;
+            const float mx = wave_max(lane < W2 ? lg : -3.0e38f);
+            const float e = lane < W2 ? __expf(lg - mx) : 0.f;
+            const float p = e / wave_sum(e);
+            float wgt;                                  // weight of neighbour j in phase B
+            if (MODE == 0) {
+                wgt = p;
+                if (lane < W2) (dir == 0 ? att0 : att1)[((int64_t)b * W2 + lane) * N + u] = lg;
+            } else {
+                const float dot = wave_sum(lane < W2 ? p * dp : 0.f);
+                const float* datt = dir == 0 ? datt0 : datt1;
+                const float da = (datt && lane < W2) ? datt[((int64_t)b * W2 + lane) * N + u] : 0.f;
+                wgt = (p * (dp - dot) + da) * inv_sqrt_c;
+                if (lane < W2) {                        // p and ds / sqrt(C) for pass B: [b][dir][j][u]
+                    att0[(((int64_t)b * 2 + dir) * W2 + lane) * N + u] = p;
+                    att1[(((int64_t)b * 2 + dir) * W2 + lane) * N + u] = wgt;
+                }
+            }
+            const unsigned* hp = reinterpret_cast<const unsigned*>(hl) + (py * HW + px) * CP + (lane < CP ? lane : 0);
+#pragma unroll
+            for (int jj = 0; jj < W2; ++jj) {
+                const float pj = tam_lane(wgt, jj);
+                const unsigned kv = hp[((jj / WIN) * HW + jj % WIN) * CP];
+                o0 += pj * bflo(kv);
+                o1 += pj * bfhi(kv);
+            }
+        }
+        if (lane < CP) out[pix * CP + lane] = pack2bf(o0, o1);
+    }
+}
+
 #define TAM_DISPATCH(KERNEL, GRID, ...)                                                                        \
     do {                                                                                                       \
         const int np = C <= 128 ? 1 : 2;                                                                       \
@@ -252,32 +374,62 @@ static int tam_check(int B, int H, int W, int C, int window) {
     return TCVOM_OK;
 }
 
+// the heavy per-unknown-pixel kernels run on a fixed grid and walk the work list
+static int tam_heavy_grid(int64_t pixels) {
+    int64_t b = (pixels + 3) / 4;
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
 extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, const void* v, const uint8_t* mask,
-                             void* out, float* attb, float* attf, int32_t B, int32_t H, int32_t W, int32_t C,
-                             int32_t window, void* stream) {
-    TCVOM_CHECK_ARG(q && kb && kf && v && mask && out && attb && attf, "tam_fwd: null pointer");
+                             void* out, float* attb, float* attf, int32_t* worklist, int32_t B, int32_t H, int32_t W,
+                             int32_t C, int32_t window, void* stream) {
+    TCVOM_CHECK_ARG(q && kb && kf && v && mask && out && attb && attf && worklist, "tam_fwd: null pointer");
     if (int e = tam_check(B, H, W, C, window)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(cdiv((int64_t)B * H * W, 4));
+    const int64_t n = (int64_t)B * H * W;
+    TCVOM_CHECK_ARG(n < (1ll << 31), "tam_fwd: too many pixels");
     const float isc = 1.0f / sqrtf((float)C);
+    const size_t att_bytes = sizeof(float) * (size_t)n * window * window;
+    if (hipMemsetAsync(attb, 0, att_bytes, st) != hipSuccess || hipMemsetAsync(attf, 0, att_bytes, st) != hipSuccess ||
+        hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
+        hipMemcpyAsync(out, v, sizeof(bf16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_fwd: memset / copy failed");
+    if (window == 7 && C <= 128 && C % 8 == 0) {
+        const dim3 tg(cdiv(W, TT_TW), cdiv(H, TT_TH), B);
+        hipLaunchKernelGGL((tam_tiled_kernel<7, 0>), tg, dim3(256), 0, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
+                           (const unsigned*)v, (const uint4*)nullptr, mask, (unsigned*)out, attb, attf, (const float*)nullptr,
+                           (const float*)nullptr, H, W, C, isc);
+        TCVOM_LAUNCH_CHECK("tam_fwd");
+        return TCVOM_OK;
+    }
+    hipLaunchKernelGGL(tam_compact_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, mask, worklist, n);
+    const dim3 grid(tam_heavy_grid(n));
     TAM_DISPATCH(tam_fwd_kernel, grid, (const unsigned*)q, (const unsigned*)kb, (const unsigned*)kf, (const unsigned*)v,
-                 mask, (unsigned*)out, attb, attf, B, H, W, C, isc);
+                 mask, (unsigned*)out, attb, attf, (const int*)worklist, B, H, W, C, isc);
     TCVOM_LAUNCH_CHECK("tam_fwd");
     return TCVOM_OK;
 }
 
 extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, const uint8_t* mask, const void* dout,
                              const float* dattb, const float* dattf, void* dq, void* dkb, void* dkf,
-                             float* pbuf, float* dsbuf, int32_t B, int32_t H, int32_t W, int32_t C, int32_t window,
-                             void* stream) {
-    TCVOM_CHECK_ARG(q && kb && kf && mask && dout && dq && dkb && dkf && pbuf && dsbuf, "tam_bwd: null pointer");
+                             float* pbuf, float* dsbuf, const int32_t* worklist, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t window, void* stream) {
+    TCVOM_CHECK_ARG(q && kb && kf && mask && dout && dq && dkb && dkf && pbuf && dsbuf && worklist, "tam_bwd: null pointer");
     if (int e = tam_check(B, H, W, C, window)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(cdiv((int64_t)B * H * W, 4));
-    const dim3 grid2(cdiv((int64_t)B * H * W, 4), 2);
+    const int64_t n = (int64_t)B * H * W;
+    const dim3 grid(tam_heavy_grid(n));
+    const dim3 grid2(cdiv(n, 4), 2);
     const float isc = 1.0f / sqrtf((float)C);
-    TAM_DISPATCH(tam_bwd_query_kernel, grid, (const unsigned*)q, (const unsigned*)kb, (const unsigned*)kf, mask,
-                 (const unsigned*)dout, dattb, dattf, (unsigned*)dq, pbuf, dsbuf, B, H, W, C, isc);
+    if (hipMemsetAsync(dq, 0, sizeof(bf16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
+    if (window == 7 && C <= 128 && C % 8 == 0) {
+        const dim3 tg(cdiv(W, TT_TW), cdiv(H, TT_TH), B);
+        hipLaunchKernelGGL((tam_tiled_kernel<7, 1>), tg, dim3(256), 0, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
+                           (const unsigned*)nullptr, (const uint4*)dout, mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, C, isc);
+    } else {
+        TAM_DISPATCH(tam_bwd_query_kernel, grid, (const unsigned*)q, (const unsigned*)kb, (const unsigned*)kf, mask,
+                     (const unsigned*)dout, dattb, dattf, (unsigned*)dq, pbuf, dsbuf, (const int*)worklist, B, H, W, C, isc);
+    }
     TAM_DISPATCH(tam_bwd_key_kernel, grid2, (const unsigned*)q, mask, (const unsigned*)dout, pbuf, dsbuf,
                  (unsigned*)dkb, (unsigned*)dkf, B, H, W, C);
     TCVOM_LAUNCH_CHECK("tam_bwd");

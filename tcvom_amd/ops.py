@@ -659,15 +659,16 @@ class _TamAttention(torch.autograd.Function):
         w2 = window * window
         attb = torch.empty((B, w2, H * W), dtype=torch.float32, device=q.device)
         attf = torch.empty((B, w2, H * W), dtype=torch.float32, device=q.device)
+        work = torch.empty(B * H * W + 1, dtype=torch.int32, device=q.device)      # compacted list of the unknown pixels
         L.call('tcvom_tam_fwd', L.ptr(q), L.ptr(kb), L.ptr(kf), L.ptr(v), L.ptr(mask_u8), L.ptr(out), L.ptr(attb),
-               L.ptr(attf), B, H, W, Cc, window, L.stream_ptr())
-        ctx.save_for_backward(q, kb, kf, mask_u8)
+               L.ptr(attf), L.ptr(work), B, H, W, Cc, window, L.stream_ptr())
+        ctx.save_for_backward(q, kb, kf, mask_u8, work)
         ctx.window = window
         return out, attb, attf
 
     @staticmethod
     def backward(ctx, dout, dattb, dattf):
-        q, kb, kf, mask = ctx.saved_tensors
+        q, kb, kf, mask, work = ctx.saved_tensors
         B, H, W, Cc = q.shape
         w2 = ctx.window * ctx.window
         dout = _c(dout)
@@ -677,7 +678,7 @@ class _TamAttention(torch.autograd.Function):
         db = _c(dattb) if dattb is not None else None
         df = _c(dattf) if dattf is not None else None
         L.call('tcvom_tam_bwd', L.ptr(q), L.ptr(kb), L.ptr(kf), L.ptr(mask), L.ptr(dout), L.ptr(db), L.ptr(df), L.ptr(dq),
-               L.ptr(dkb), L.ptr(dkf), L.ptr(pbuf), L.ptr(dsbuf), B, H, W, Cc, ctx.window, L.stream_ptr())
+               L.ptr(dkb), L.ptr(dkf), L.ptr(pbuf), L.ptr(dsbuf), L.ptr(work), B, H, W, Cc, ctx.window, L.stream_ptr())
         return dq, dkb, dkf, dout, None, None
 
 
