@@ -9,9 +9,11 @@
 //       out_u    = v_u + sum_j p_j kb_{u+d_j} + sum_j p'_j kf_{u+d_j}      (values are the keys)
 //   known pixels: out_u = v_u, logits 0.
 //
-// One wave (64 lanes) per pixel; a lane owns channel pairs {lane + 64*i}; the w*w neighbour key
-// slices stay in registers between the logit and the aggregation pass, so each key element is
-// fetched once per (pixel, direction) — from L2, since neighbouring pixels share 42/49 of them.
+// window 7 (the configuration of every entry script): LDS-tiled kernels, see tam_tiled_kernel below -- tiles without unknown
+// pixels exit at once, key halos of both directions + queries staged in LDS, one wave per unknown pixel with one lane per
+// neighbour for the logits (v_dot2_f32_bf16) and one lane per channel pair for the aggregation.
+// Other windows (1, 3, 5): one wave (64 lanes) per unknown pixel taken from a compacted work list; a lane owns channel pairs
+// {lane + 64*i}; the w*w neighbour key slices stay in registers between the logit and the aggregation pass.
 // HBM-bound: algorithmic traffic = read q, v, kb, kf + write out + 2 logit maps.
 #include "common.h"
 
@@ -247,8 +249,6 @@ __global__ __launch_bounds__(256) void tam_bwd_key_kernel(
 //            chunk j so that the 16 lanes of an LDS read group hit 16 different banks although all key rows start on bank 0;
 //            the softmax is then TWO wave reductions (the one-wave-per-pixel kernel above needs 49, one per neighbour)
 //   phase B  lane = channel pair: out = v + sum_j p_j k_j, p_j broadcast with v_readlane, key rows read conflict-free
-#define TT_TH 8
-#define TT_TW 8
 typedef __attribute__((ext_vector_type(2))) __bf16 tam_bf2;
 __device__ __forceinline__ float tam_dot8(const uint4 a, const uint4 b, float acc) {
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.x), __builtin_bit_cast(tam_bf2, b.x), acc, false);
@@ -261,27 +261,29 @@ __device__ __forceinline__ float tam_lane(float v, int j) {
 }
 
 // MODE 0: forward (out, logits).  MODE 1: backward pass A (dq, p and ds / sqrt(C) for pass B); `g` = dout, datt* may be NULL.
-template <int WIN, int MODE>
+// TH x TW = pixel tile, C8MAX = 16-byte chunks per pixel the LDS arrays are sized for (16: C <= 128, tiles 8x8;
+// 32: C <= 256 as in the FBA / DIM bases, tiles 4x8 forward and 4x4 backward so that everything stays below 160 KiB).
+template <int WIN, int MODE, int TH, int TW, int C8MAX>
 __global__ __launch_bounds__(256) void tam_tiled_kernel(
     const uint4* __restrict__ q, const uint4* __restrict__ kb, const uint4* __restrict__ kf, const unsigned* __restrict__ v,
     const uint4* __restrict__ g, const unsigned char* __restrict__ mask, unsigned* __restrict__ out,
     float* __restrict__ att0, float* __restrict__ att1, const float* __restrict__ datt0, const float* __restrict__ datt1,
     int H, int W, int C, float inv_sqrt_c)
 {
-    constexpr int W2 = WIN * WIN, R = WIN / 2, HH = TT_TH + 2 * R, HW = TT_TW + 2 * R, NT = TT_TH * TT_TW;
-    __shared__ uint4 halo[2 * HH * HW * 16];           // both directions, up to 16 chunks (128 channels) per key pixel
-    __shared__ uint4 qt[NT * 16];
-    __shared__ uint4 gt[MODE == 1 ? NT * 16 : 1];
+    constexpr int W2 = WIN * WIN, R = WIN / 2, HH = TH + 2 * R, HW = TW + 2 * R, NT = TH * TW, NP = C8MAX / 16;
+    __shared__ uint4 halo[2 * HH * HW * C8MAX];        // both directions
+    __shared__ uint4 qt[NT * C8MAX];
+    __shared__ uint4 gt[MODE == 1 ? NT * C8MAX : 1];
     __shared__ int list[NT];
     __shared__ int cnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C8 = C >> 3, CP = C >> 1;
-    const int b = blockIdx.z, ty0 = blockIdx.y * TT_TH, tx0 = blockIdx.x * TT_TW;
+    const int b = blockIdx.z, ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
     const int64_t N = (int64_t)H * W;
     if (tid == 0) cnt = 0;
     __syncthreads();
     if (tid < NT) {
-        const int y = ty0 + tid / TT_TW, x = tx0 + tid % TT_TW;
+        const int y = ty0 + tid / TW, x = tx0 + tid % TW;
         if (y < H && x < W && mask[b * N + (int64_t)y * W + x] != 0) list[atomicAdd(&cnt, 1)] = tid;
     }
     __syncthreads();
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
     }
     for (int idx = tid; idx < NT * C8; idx += 256) {
         const int p = idx / C8, c = idx - p * C8;
-        const int y = ty0 + p / TT_TW, x = tx0 + p % TT_TW;
+        const int y = ty0 + p / TW, x = tx0 + p % TW;
         const bool in = y < H && x < W;
         qt[idx] = in ? q[(b * N + (int64_t)y * W + x) * C8 + c] : make_uint4(0u, 0u, 0u, 0u);
         if (MODE == 1) gt[idx] = in ? g[(b * N + (int64_t)y * W + x) * C8 + c] : make_uint4(0u, 0u, 0u, 0u);
@@ -306,11 +308,16 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
     const int j = lane < W2 ? lane : W2 - 1;            // idle lanes shadow the last neighbour
     for (int li = wave; li < nu; li += 4) {
         const int t = list[li];
-        const int py = t / TT_TW, px = t % TT_TW;
+        const int py = t / TW, px = t % TW;
         const int64_t u = (int64_t)(ty0 + py) * W + tx0 + px;
         const int64_t pix = b * N + u;
-        float o0 = 0.f, o1 = 0.f;
-        if (MODE == 0 && lane < CP) { const unsigned vv = v[pix * CP + lane]; o0 = bflo(vv); o1 = bfhi(vv); }
+        float o[NP][2];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            o[i][0] = o[i][1] = 0.f;
+            const int cp = lane + 64 * i;
+            if (MODE == 0 && cp < CP) { const unsigned vv = v[pix * CP + cp]; o[i][0] = bflo(vv); o[i][1] = bfhi(vv); }
+        }
 #pragma unroll 1
         for (int dir = 0; dir < 2; ++dir) {
             const uint4* hl = halo + dir * HH * HW * C8;
@@ -341,16 +348,24 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
                     att1[(((int64_t)b * 2 + dir) * W2 + lane) * N + u] = wgt;
                 }
             }
-            const unsigned* hp = reinterpret_cast<const unsigned*>(hl) + (py * HW + px) * CP + (lane < CP ? lane : 0);
+            const unsigned* hp = reinterpret_cast<const unsigned*>(hl) + (py * HW + px) * CP;
 #pragma unroll
             for (int jj = 0; jj < W2; ++jj) {
                 const float pj = tam_lane(wgt, jj);
-                const unsigned kv = hp[((jj / WIN) * HW + jj % WIN) * CP];
-                o0 += pj * bflo(kv);
-                o1 += pj * bfhi(kv);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int cp = lane + 64 * i;
+                    const unsigned kv = hp[((jj / WIN) * HW + jj % WIN) * CP + (cp < CP ? cp : 0)];
+                    o[i][0] += pj * bflo(kv);
+                    o[i][1] += pj * bfhi(kv);
+                }
             }
         }
-        if (lane < CP) out[pix * CP + lane] = pack2bf(o0, o1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int cp = lane + 64 * i;
+            if (cp < CP) out[pix * CP + cp] = pack2bf(o[i][0], o[i][1]);
+        }
     }
 }
 
@@ -394,11 +409,13 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
         hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
         hipMemcpyAsync(out, v, sizeof(bf16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_fwd: memset / copy failed");
-    if (window == 7 && C <= 128 && C % 8 == 0) {
-        const dim3 tg(cdiv(W, TT_TW), cdiv(H, TT_TH), B);
-        hipLaunchKernelGGL((tam_tiled_kernel<7, 0>), tg, dim3(256), 0, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
-                           (const unsigned*)v, (const uint4*)nullptr, mask, (unsigned*)out, attb, attf, (const float*)nullptr,
-                           (const float*)nullptr, H, W, C, isc);
+    if (window == 7 && C % 8 == 0) {
+#define TAM_TILED_FWD(TH, TW, CM)                                                                                     \
+        hipLaunchKernelGGL((tam_tiled_kernel<7, 0, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(256), 0, st,   \
+                           (const uint4*)q, (const uint4*)kb, (const uint4*)kf, (const unsigned*)v, (const uint4*)nullptr, \
+                           mask, (unsigned*)out, attb, attf, (const float*)nullptr, (const float*)nullptr, H, W, C, isc)
+        if (C <= 128) TAM_TILED_FWD(8, 8, 16); else TAM_TILED_FWD(4, 8, 32);
+#undef TAM_TILED_FWD
         TCVOM_LAUNCH_CHECK("tam_fwd");
         return TCVOM_OK;
     }
@@ -422,10 +439,13 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
     const dim3 grid2(cdiv(n, 4), 2);
     const float isc = 1.0f / sqrtf((float)C);
     if (hipMemsetAsync(dq, 0, sizeof(bf16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
-    if (window == 7 && C <= 128 && C % 8 == 0) {
-        const dim3 tg(cdiv(W, TT_TW), cdiv(H, TT_TH), B);
-        hipLaunchKernelGGL((tam_tiled_kernel<7, 1>), tg, dim3(256), 0, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
-                           (const unsigned*)nullptr, (const uint4*)dout, mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, C, isc);
+    if (window == 7 && C % 8 == 0) {
+#define TAM_TILED_BWD(TH, TW, CM)                                                                                     \
+        hipLaunchKernelGGL((tam_tiled_kernel<7, 1, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(256), 0, st,   \
+                           (const uint4*)q, (const uint4*)kb, (const uint4*)kf, (const unsigned*)nullptr, (const uint4*)dout, \
+                           mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, C, isc)
+        if (C <= 128) TAM_TILED_BWD(8, 8, 16); else TAM_TILED_BWD(4, 4, 32);
+#undef TAM_TILED_BWD
     } else {
         TAM_DISPATCH(tam_bwd_query_kernel, grid, (const unsigned*)q, (const unsigned*)kb, (const unsigned*)kf, mask,
                      (const unsigned*)dout, dattb, dattf, (unsigned*)dq, pbuf, dsbuf, (const int*)worklist, B, H, W, C, isc);
