@@ -75,11 +75,12 @@ def test_adam_step_matches_torch_adam():
 
 
 @pytest.mark.gpu
-def test_pred_vmn_runs_at_1080p(capsys):
+@pytest.mark.parametrize('base', ['gca', 'fba', 'dim'])
+def test_pred_vmn_runs_at_1080p(capsys, base):
     sys.path.insert(0, REPO)
     import pred_vmn
     import argparse
-    pred_vmn.main(argparse.Namespace(model='gca', load=None, trimap='medium', agg_window=7, clips=1, save=None))
+    pred_vmn.main(argparse.Namespace(model=base, load=None, trimap='medium', agg_window=7, clips=1, save=None))
     out = capsys.readouterr().out
     assert 'L_alpha' in out and 'L_total' in out
 
