@@ -310,3 +310,31 @@ def fba_window_forward(state, a, fg, bg, window=7, dilate_kernel=12, reduction=1
     out = [L1, L2, L3, L_dt, L_att, simgs, tris_vis, alphas, comps, gts, Fs, Bs]
     return out, {'preds': preds, 'attb': attb, 'attf': attf, 'small_mask': small, 'features': feats, 'tris': tris,
                  'trimasks': trimasks, 'imgs': imgs, 'conv_outs': conv_outs}
+
+
+def fba_single_forward(state, a, fg, bg, dilate_kernel=12, eps=0.0, normalize=True):
+    """FullModel('fba').forward (models/model.py:199-246 with MattingModule, models/FBA/models.py:18-32): the FBA base WITHOUT
+    the temporal module on the centre frame -> [L_alpha_comp, L_lap, L_grad, imgs, tris_vis, alphas, comps, gts, Fs, Bs]."""
+    B, S = a.shape[:2]
+    c = S // 2
+    with torch.no_grad():
+        gts = a / 255.0
+        fgs, bgs = fg.flip([2]) / 255.0, bg.flip([2]) / 255.0
+        simgs = fgs * gts + bgs * (1.0 - gts)
+        tris, trimasks = make_trimap8(gts, dilate_kernel, eps)
+        mean = torch.tensor(IMG_MEAN).reshape(1, 1, 3, 1, 1)
+        std = torch.tensor(IMG_STD).reshape(1, 1, 3, 1, 1)
+        imgs = (simgs - mean) / std
+    conv_out = encoder(state, torch.cat([imgs[:, c], tris[:, c]], dim=1))
+    pred = decoder_tail(state, decoder_feature(state, conv_out), conv_out, simgs[:, c], tris[:, c, -2:])
+    preds = [torch.zeros_like(pred)] * S
+    preds[c] = pred
+    # fba_single_image_loss with start = c, end = c + 1: the same per-frame terms as the window loss on frame c only
+    lo = torch.stack([torch.zeros_like(pred), pred, torch.zeros_like(pred)], dim=1)
+    pick = lambda t: torch.stack([t[:, c]] * 3, dim=1)
+    L1, L2, L3, al, co, Fs_, Bs_ = fba_single_image_loss(lo, pick(trimasks), pick(gts), pick(fgs), pick(bgs), pick(simgs), normalize)
+    alphas, comps, Fs, Bs = torch.zeros_like(gts), torch.zeros_like(fgs), torch.zeros_like(fgs), torch.zeros_like(fgs)
+    alphas[:, c], comps[:, c], Fs[:, c], Bs[:, c] = al[:, 1].detach(), co[:, 1].detach(), Fs_[:, 1].detach(), Bs_[:, 1].detach()
+    with torch.no_grad():
+        tris_vis = torch.where(trimasks.bool(), torch.full_like(gts, 128.0 / 255.0), gts)
+    return [L1, L2, L3, simgs, tris_vis, alphas, comps, gts, Fs, Bs]

@@ -156,3 +156,23 @@ def window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True,
 def train_step_loss(out):
     """train_ddp.py:56-61."""
     return out[0].mean() + out[1].mean() + out[2].mean() + 0.5 * out[3].mean() + 0.25 * out[4].mean()
+
+
+def single_gca_forward(state, a, fg, bg, dilate_kernel=12, training=True, eps=0.0):
+    """FullModel('gca').forward (models/model.py:199-246 with models/GCA/generators.py): the GCA base WITHOUT the temporal
+    module on the centre frame -> [L_alpha, 0, 0, imgs, tris_vis, alphas, comps, gts, fgs, bgs]."""
+    scaled_imgs, fgs, bgs, gts, tris, trimasks, imgs = preprocess(a, fg, bg, dilate_kernel, eps)
+    S = a.shape[1]
+    c = S // 2
+    emb, mid = encoder_frame(state, torch.cat([imgs[:, c], tris[:, c]], dim=1), training)
+    pred = decoder_tail(state, decoder_front(state, emb, mid, training), mid, training)
+    unk = trimasks[:, c]
+    refine = torch.where(unk.bool(), pred, gts[:, c])
+    L_alpha = l1_mask(refine, gts[:, c], unk)
+    alphas, comps = torch.zeros_like(gts), torch.zeros_like(fgs)
+    alphas[:, c] = refine.detach().clamp(0, 1)
+    comps[:, c] = (fgs[:, c] * refine + bgs[:, c] * (1.0 - refine)).detach().clamp(0, 1)
+    zero = torch.zeros_like(L_alpha)
+    with torch.no_grad():
+        tris_vis = torch.where(trimasks.bool(), torch.full_like(gts, 128.0 / 255.0), gts)
+    return [L_alpha, zero, zero.clone(), scaled_imgs, tris_vis, alphas, comps, gts, fgs, bgs]

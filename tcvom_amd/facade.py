@@ -12,6 +12,8 @@ import torch.nn as nn
 from . import _lib as L
 from . import vmn as VMN
 from .dim_net import DIM_VGG
+from .fba_net import FBA
+from .gca_net import GCA
 
 TAM_OS = 8
 
@@ -181,7 +183,7 @@ class _SingleImageLoss(torch.autograd.Function):
 
 class FullModel(nn.Module):
     """Baseline (no TAM) façade — models/model.py:15-246: the DIM base (BASELINE.json config 1) and the VMN archs."""
-    ARCH_DICT = {'gca': None, 'dim': DIM_VGG, 'fba': None, 'index': None}
+    ARCH_DICT = {'gca': GCA, 'dim': DIM_VGG, 'fba': FBA, 'index': None}
     TRIMAP_CHANNEL_DICT = {'gca': 3, 'dim': 1, 'index': 1, 'fba': 8}
     FBA_LOSS_NORMALIZE = True
     FBA_L_ATT_MULTIPLIER = 1
@@ -205,6 +207,7 @@ class FullModel(nn.Module):
             self.NET = self.ARCH_DICT[model]()
         self.method = model[model.rfind('_') + 1:]
         self.TRIMAP_CHANNEL = self.TRIMAP_CHANNEL_DICT[self.method]
+        self.att_thres, self.label_smooth = 0.3, 0.2          # FullModel_VMD's defaults (its forward serves VMN archs here too)
 
     def _dilation(self):
         if self.DILATION_KERNEL is None:
@@ -226,9 +229,25 @@ class FullModel(nn.Module):
         H, W = a.shape[-2:]
         assert H % 32 == 0 and W % 32 == 0, 'H and W must be multiples of 32'
         if self.model_name.startswith('vmn'):
-            raise NotImplementedError('use FullModel_VMD for the VMN architectures (train_ddp.py:220, pred_vmn.py:76)')
+            # a VMN architecture through the baseline façade: the single-image losses of the interior frames only (:214-218)
+            out = FullModel_VMD.forward(self, a, fg, bg)
+            return out[:3] + out[5:]
         c = S // 2
-        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS, self.TRIMAP_CHANNEL)
+        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
+        if self.method == 'fba':
+            from . import fba_losses as FL
+            x2, extras, _ = fba_network_input(prep, self.EPS)
+            pred = self.NET.run(x2[:, c].contiguous(), extras[:, c].contiguous(), prep.imgs[:, c].contiguous())
+            # the loss kernels take the window tensors and a frame index: predict "frame c of a clip whose interior is c"
+            alphas = torch.zeros_like(prep.gts)
+            comps, Fs, Bs = torch.zeros_like(prep.fgs), torch.zeros_like(prep.fgs), torch.zeros_like(prep.fgs)
+            L1, L2, L3 = FL._FbaFrameLoss.apply(pred, prep.gts, prep.trimask, prep.fgs, prep.bgs, prep.imgs, c, alphas, comps, Fs, Bs)
+            return [L1, L2, L3, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, Fs, Bs]
+        if self.method == 'gca':
+            pred = self.NET.run(prep.x8[:, c].contiguous(), prep.unk[:, c, ::TAM_OS, ::TAM_OS].contiguous())
+            L_alpha, _lc, _lg, alphas, comps = _SingleImageLoss.apply(prep, c, S, pred)
+            zero = torch.zeros_like(L_alpha)                   # GCA: alpha loss only (models/model.py:110-114)
+            return [L_alpha, zero, zero.clone(), prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
         pred = self.NET.run(prep.x8[:, c].contiguous())
         L_alpha, L_comp, L_grad, alphas, comps = _SingleImageLoss.apply(prep, c, S, pred)
         return [L_alpha, L_comp, L_grad, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]

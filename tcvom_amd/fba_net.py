@@ -109,7 +109,7 @@ class ResnetDilated(nn.Module):
 class vmn_fba_decoder(nn.Module):
     """models/VMN/VMN_FBA.py:6-59 over fba_decoder (models/FBA/models.py:258-324, batch_norm=False)."""
 
-    def __init__(self, reduction, window, freeze_backbone=False, batch_norm=False, bank=None):
+    def __init__(self, reduction, window, freeze_backbone=False, batch_norm=False, bank=None, with_fam=True):
         super().__init__()
         assert not batch_norm and bank is not None
         self.batch_norm = batch_norm
@@ -143,7 +143,8 @@ class vmn_fba_decoder(nn.Module):
         reg('decoder.conv_up4.0', self.conv_up4[0], None, 'tail', ws=False, cpad=128)
         reg('decoder.conv_up4.2', self.conv_up4[2], None, 'tail', ws=False)
         object.__setattr__(self, '_cfgs', cfgs)
-        self.fam = FeatureAggregationModule(256, reduction, window, bank=bank, prefix='decoder.fam')
+        if with_fam:                                # without: the single-image fba_decoder (models/FBA/models.py:258-353)
+            self.fam = FeatureAggregationModule(256, reduction, window, bank=bank, prefix='decoder.fam')
 
     def train(self, mode=True):
         super().train(mode)
@@ -165,14 +166,17 @@ class vmn_fba_decoder(nn.Module):
         """extract_feature=False (VMN_FBA.py:35-59) for the interior frames: TAM, three up-sampling stages, head.
         os4 / os2: conv_out[-4] / conv_out[-5]; extras: [F, H, W, 8] bf16 (normalised RGB, RGB, bg, fg); img: fp32
         [F, 3, H, W] view of the scaled images -> (pred fp32 [F, 7, H, W], attb, attf)."""
-        cf = self._cfgs
         x, attb, attf = self.fam.run(x, xb, xf, mask_u8, token, training)
+        return self.run_tail_single(x, os4, os2, extras, img, token, training), attb, attf
+
+    def run_tail_single(self, x, os4, os2, extras, img, token, training):
+        """The three up-sampling stages and the fused head (models/FBA/models.py:326-353) -> pred fp32 [F, 7, H, W]."""
+        cf = self._cfgs
         x = ops.conv_bn_act(cf['decoder.conv_up2.0'], ops.up2_concat(512, x, os4), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up3.0'], ops.up2_concat(512, x, os2), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up4.0'], ops.up2_concat(128, x, extras), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up4.2'], x, token, training)
-        pred = ops.fba_head(x, self.conv_up4[4].weight, self.conv_up4[4].bias, img)
-        return pred, attb, attf
+        return ops.fba_head(x, self.conv_up4[4].weight, self.conv_up4[4].bias, img)
 
 
 class VMN_FBA(nn.Module):
@@ -232,3 +236,31 @@ def build_vmn_fba(agg_window, agg_reduction=1, freeze_backbone=False):
     enc = ResnetDilated(bank)
     dec = vmn_fba_decoder(agg_reduction, agg_window, freeze_backbone=freeze_backbone, bank=bank)
     return VMN_FBA(enc, dec, bank, freeze_backbone=freeze_backbone)
+
+
+class MattingModule(nn.Module):
+    """models/FBA/models.py:18-32: the single-image FBA network (FullModel('fba')), no temporal module."""
+
+    def __init__(self):
+        super().__init__()
+        bank = WeightBank()
+        object.__setattr__(self, '_bank', bank)
+        self.encoder = ResnetDilated(bank)
+        self.decoder = vmn_fba_decoder(1, 1, bank=bank, with_fam=False)
+
+    def run(self, x2, extras, img):
+        """x2 [B,H/2,W/2,64] bf16 space-to-depth input, extras [B,H,W,8] bf16, img fp32 [B,3,H,W] -> pred fp32 [B,7,H,W]."""
+        bank, training = self._bank, self.training
+        F = x2.shape[0]
+        token = bank_token(bank, F, training)
+        try:
+            bank.frames_per_op = F
+            outs = self.encoder.run(x2, token, training)
+            feat = self.decoder.run_feature(outs[-1], token, training)
+            return self.decoder.run_tail_single(feat, outs[1], outs[0], extras, img, token, training)
+        finally:
+            bank.frames_per_op = 1
+
+
+def FBA():
+    return MattingModule()

@@ -259,7 +259,7 @@ class ResGuidedCxtAtten_FAM_Dec(nn.Module):
     """VMN decoder for GCA (models/VMN/VMN_GCA.py:8-48 over resnet_dec.py:62-144), split at os8:
     front = layer1, layer2, gca (per frame);  tail = TAM, layer3, layer4, conv1/bn1, conv2 (interior frames)."""
 
-    def __init__(self, reduction, window, layers=(2, 3, 3, 2), freeze_backbone=False, bank=None):
+    def __init__(self, reduction, window, layers=(2, 3, 3, 2), freeze_backbone=False, bank=None, with_fam=True):
         super().__init__()
         assert reduction == 1, 'agg_reduction != 1 is inconsistent in the reference (SURVEY.md App. B 16)'
         from .vmn import FeatureAggregationModule
@@ -279,7 +279,8 @@ class ResGuidedCxtAtten_FAM_Dec(nn.Module):
             if isinstance(m, DecBasicBlock):
                 nn.init.constant_(m.bn2.weight, 0)
         self.gca = GuidedCxtAtten(128, 128, bank=bank, prefix='decoder.gca')
-        self.fam = FeatureAggregationModule(128, reduction, window, bank=bank, prefix='decoder.fam')
+        if with_fam:                            # without: the single-image decoder res_gca_decoder_22 (decoders/res_gca_dec.py)
+            self.fam = FeatureAggregationModule(128, reduction, window, bank=bank, prefix='decoder.fam')
         self._register(bank)
 
     def _make_layer(self, planes, blocks):
@@ -331,12 +332,16 @@ class ResGuidedCxtAtten_FAM_Dec(nn.Module):
 
     def run_tail(self, x, xb, xf, mask_u8, mid, token, training):
         """extract_feature=False branch (VMN_GCA.py:35-47): alpha fp32 [B,1,H,W], attb, attf."""
-        fea1, fea2, fea3, fea4, fea5 = mid['shortcut']
         x, attb, attf = self.fam.run(x, xb, xf, mask_u8, token, training)
+        return self.run_tail_single(x, mid, token, training), attb, attf
+
+    def run_tail_single(self, x, mid, token, training):
+        """layer3, layer4, conv1/bn1, conv2 + (tanh + 1) / 2 (resnet_dec.py:105-120): alpha fp32 [B,1,H,W]."""
+        fea1, fea2, fea3, fea4, fea5 = mid['shortcut']
         x = self._run_layer(self._layers[2], x, token, training, fea3)
         x = self._run_layer(self._layers[3], x, token, training, fea2)
         x = ops.conv_bn_act(self._out, x, token, training, res2=fea1)
-        return ops.head_conv(x, self.conv2.weight, self.conv2.bias), attb, attf
+        return ops.head_conv(x, self.conv2.weight, self.conv2.bias)
 
     def train(self, mode=True):
         super().train(mode)
@@ -346,3 +351,31 @@ class ResGuidedCxtAtten_FAM_Dec(nn.Module):
             self.layer2.eval()
             self.gca.eval()
         return self
+
+
+class Generator(nn.Module):
+    """models/GCA/generators.py:8-41: the single-image GCA matting network (FullModel('gca')): resnet_gca_encoder_29 +
+    res_gca_decoder_22, no temporal module."""
+
+    def __init__(self, encoder='resnet_gca_encoder_29', decoder='res_gca_decoder_22', alpha_only=True):
+        super().__init__()
+        assert encoder == 'resnet_gca_encoder_29' and decoder == 'res_gca_decoder_22' and alpha_only
+        self.alpha_only = alpha_only
+        bank = WeightBank()
+        object.__setattr__(self, '_bank', bank)
+        self.encoder = resnet_gca_encoder_29(bank=bank)
+        self.decoder = ResGuidedCxtAtten_FAM_Dec(1, 1, bank=bank, with_fam=False)
+
+    def run(self, x8, unk_u8):
+        """x8 [B,H,W,8] bf16 (normalised RGB + one-hot trimap), unk_u8 uint8 [B,H/8,W/8] -> alpha fp32 [B,1,H,W]."""
+        training = self.training
+        token = bank_token(self._bank, 1, training)
+        emb, mid = self.encoder.run(x8, unk_u8, token, training)
+        x = self.decoder.run_front(emb, mid, token, training)
+        alpha = self.decoder.run_tail_single(x, mid, token, training)
+        self._bank.flush_bn_counters()
+        return alpha
+
+
+def GCA(encoder='resnet_gca_encoder_29', decoder='res_gca_decoder_22', alpha_only=True):
+    return Generator(encoder, decoder, alpha_only)

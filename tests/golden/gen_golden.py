@@ -435,6 +435,31 @@ def gen_metrics():
          messd=np.array([fix, org, valid], dtype=np.float64), pixels=int(m.sum()))
 
 
+SINGLE_CASES = {'gca_single_s1_128x160': ('gca', 1, 1, 128, 160, 5), 'fba_single_s3_64x64': ('fba', 1, 3, 64, 64, 3)}
+
+
+def gen_single():
+    """FullModel('gca') / FullModel('fba'): the single-image bases without the temporal module (models/model.py:199-246)."""
+    for name, (arch, B, S, H, W, dil) in SINGLE_CASES.items():
+        fm = ref_model.FullModel(arch, dilate_kernel=dil)
+        fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
+        fm.train()
+        a, fg, bg = synthetic_window(B, S, H, W, seed=6)
+        out = fm(a, fg, bg)
+        (out[0] + out[1] + out[2]).backward()
+        arrs = {'losses': torch.stack([o.detach() for o in out[:3]]), 'alphas': out[5], 'comps_sum': out[6].double().sum()}
+        names, norms = [], []
+        for k, p in fm.NET.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        arrs['grad_names'], arrs['grad_norms'] = np.array(names), np.array(norms)
+        sd = fm.NET.state_dict()
+        arrs['keys'] = np.array(list(sd.keys()))
+        arrs['shapes'] = np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()])
+        save(name, **arrs)
+
+
 def gen_state_keys():
     dsd = ref_model.FullModel('dim').NET.state_dict()
     save('dim_state_keys', keys=np.array(list(dsd.keys())),
@@ -451,6 +476,6 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]                                   # e.g. `python gen_golden.py fba dim`; default: everything
-    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_metrics):
+    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_metrics, gen_single):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -166,3 +166,54 @@ def test_evaluation_metrics_on_device():
     assert abs(fix - g['messd'][0]) <= 1e-4 * g['messd'][0] and abs(org - g['messd'][1]) <= 1e-4 * g['messd'][1]
     only = frame_metrics(a, gt, tri)
     assert only['SAD'] == out['SAD'] and 'dtSSD' not in only
+
+
+@pytest.mark.parametrize('name,arch,shape', [('gca_single_s1_128x160', 'gca', (1, 1, 128, 160, 5)), ('fba_single_s3_64x64', 'fba', (1, 3, 64, 64, 3))])
+def test_single_image_bases_vs_reference_golden(name, arch, shape):
+    """FullModel('gca') / FullModel('fba'): the single-image bases without the temporal module (models/model.py:199-246),
+    state_dict layout, losses, centre-frame alpha and gradient norm against the reference."""
+    from tcvom_amd.facade import FullModel
+    from tcvom_amd.synthetic import formula_tensor
+    B, S, H, W, dil = shape
+    g = golden(name)
+    m = FullModel(arch, dilate_kernel=dil)
+    sd = m.NET.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['keys']]
+    assert [','.join(str(int(d)) for d in v.shape) for v in sd.values()] == [str(s) for s in g['shapes']]
+    m.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in sd.items()})
+    m = m.to(DEV).train()
+    a, fg, bg = (t.to(DEV) for t in synthetic_window(B, S, H, W, seed=6))
+    out = m(a, fg, bg)
+    assert len(out) == 10
+    (out[0] + out[1] + out[2]).backward()
+    losses = torch.stack([o.detach().float().cpu() for o in out[:3]])
+    mse = float(((out[5].float().cpu() - torch.from_numpy(g['alphas'])) ** 2).mean())
+    print('%s: alpha MSE %.3e, losses %s vs %s' % (name, mse, losses.tolist(), g['losses'].tolist()))
+    assert mse <= (1e-4 if arch == 'fba' else 1e-3)       # GCA at 128x160: small BatchNorms, see test_window_vs_reference_golden
+    assert_close(losses, g['losses'], 3e-2, 1e-3, 'losses')
+    params = dict(m.NET.named_parameters())
+    names = [str(n) for n in g['grad_names']]
+    assert all(params[n].grad is not None for n in names)
+    got = np.linalg.norm([float(params[n].grad.double().norm()) for n in names])
+    want = np.linalg.norm(g['grad_norms'])
+    assert abs(got - want) <= 0.25 * want, (got, want)
+
+
+def test_baseline_facade_accepts_vmn_architectures():
+    """FullModel('vmn_gca', ...) (models/model.py:199-246 with a VMN arch): the 10-item list with the single-image losses of
+    the interior frames; equals the first three losses and the visualisation tensors of FullModel_VMD on the same weights."""
+    from tcvom_amd.facade import FullModel, FullModel_VMD
+    from tcvom_amd.synthetic import formula_tensor
+    a, fg, bg = (t.to(DEV) for t in synthetic_window(1, 3, 128, 160, seed=0))
+    outs = []
+    for cls in (FullModel, FullModel_VMD):
+        m = cls('vmn_gca', agg_window=7, dilate_kernel=12)
+        m.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()})
+        with torch.no_grad():
+            outs.append(m.to(DEV).train()(a, fg, bg))
+    base, vmd = outs
+    assert len(base) == 10 and len(vmd) == 12
+    for i in range(3):
+        assert_close(base[i].cpu(), vmd[i].cpu(), 1e-3, 1e-5, 'loss %d' % i)
+    # two runs differ by the order of fp32 atomic sums (SpectralNorm sigma, statistics): compare like the golden tests do
+    assert float(((base[5] - vmd[7]) ** 2).mean()) <= 1e-4

@@ -316,3 +316,49 @@ def test_evaluation_metrics():
     fix, org, valid = out['MESSDdt']
     assert valid == int(g['messd'][2]) and valid < out['pixels']
     assert abs(fix - g['messd'][0]) <= 1e-4 * g['messd'][0] and abs(org - g['messd'][1]) <= 1e-4 * g['messd'][1]
+
+
+# ----------------------------------------------------------------------------- single-image bases without the temporal module
+def _state_from(g):
+    state = {}
+    for k, shp in zip(g['keys'], g['shapes']):
+        shape = tuple(int(d) for d in str(shp).split(',')) if str(shp) else ()
+        t = formula_tensor(str(k), shape, torch.int64 if str(k).endswith('num_batches_tracked') else torch.float32)
+        buf = str(k).rsplit('.', 1)[-1] in ('running_mean', 'running_var', 'num_batches_tracked')
+        state[str(k)] = t if buf else t.requires_grad_(True)
+    return state
+
+
+def test_single_image_gca_base():
+    """oracle.window.single_gca_forward against FullModel('gca') of the reference (no TAM: 578 state tensors)."""
+    from oracle.window import single_gca_forward
+    g = golden('gca_single_s1_128x160')
+    state = _state_from(g)
+    assert len(state) == 578 and not any('.fam.' in k for k in state)
+    a, fg, bg = synthetic_window(1, 1, 128, 160, seed=6)
+    out = single_gca_forward(state, a, fg, bg, dilate_kernel=5, training=True)
+    assert_close(torch.stack([o.detach() for o in out[:3]]), g['losses'], 1e-4, 1e-6, 'losses')
+    assert_close(out[5], g['alphas'], 1e-4, 5e-5, 'alphas')
+    assert_close(out[6].double().sum(), g['comps_sum'], 1e-5, 1e-2, 'comps')
+    out[0].backward()
+    names = [str(n) for n in g['grad_names']]
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    want = g['grad_norms']
+    assert abs(np.linalg.norm(got) - np.linalg.norm(want)) <= 0.05 * np.linalg.norm(want)
+
+
+def test_single_image_fba_base():
+    """oracle.fba_net.fba_single_forward against FullModel('fba') of the reference (no TAM: 197 state tensors)."""
+    from oracle import fba_net
+    g = golden('fba_single_s3_64x64')
+    state = _state_from(g)
+    assert len(state) == 197
+    a, fg, bg = synthetic_window(1, 3, 64, 64, seed=6)
+    out = fba_net.fba_single_forward(state, a, fg, bg, dilate_kernel=3)
+    assert_close(torch.stack([o.detach() for o in out[:3]]), g['losses'], 2e-5, 1e-6, 'losses')
+    assert_close(out[5], g['alphas'], 1e-4, 2e-4, 'alphas')
+    (out[0] + out[1] + out[2]).backward()
+    names = [str(n) for n in g['grad_names']]
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    want = g['grad_norms']
+    assert abs(np.linalg.norm(got) - np.linalg.norm(want)) <= 0.02 * np.linalg.norm(want)
