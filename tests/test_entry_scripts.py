@@ -139,10 +139,12 @@ def test_pred_test_folder_inference(tmp_path):
 
 
 @pytest.mark.gpu
-def test_pred_single_dim_config1():
-    """BASELINE.json config 1: pred_single.py, DIM base, one 512 x 512 synthetic frame + trimap (eval mode)."""
+@pytest.mark.parametrize('base', ['dim', 'gca', 'fba'])
+def test_pred_single_dim_config1(base):
+    """BASELINE.json config 1: pred_single.py, DIM base, one 512 x 512 synthetic frame + trimap (eval mode); the GCA and FBA
+    single-image bases run through the same script."""
     import pred_single
-    out = pred_single.main(pred_single.parse(['--model', 'dim', '--trimap', 'medium', '--frames', '1']))
+    out = pred_single.main(pred_single.parse(['--model', base, '--trimap', 'medium', '--frames', '1']))
     assert set(out) == {'L_alpha', 'L_comp', 'L_grad', 'L_total', 'mSAD', 'MSE'}
     assert all(np.isfinite(v) for v in out.values()) and abs(out['L_total'] - out['L_alpha'] - out['L_comp'] - out['L_grad']) < 1e-5
 
