@@ -14,6 +14,7 @@
 // applied on the DMA source side, the LDS write stays lane-linear) so that the 16 lanes of a ds_read_b128 group --
 // 16 consecutive pixels, 64 B apart -- cover 16 distinct bank groups.  Weight rows are padded by 16 B for the same
 // reason.
+#include <cstdlib>
 #include "common.h"
 
 #define HALO_TH 8
@@ -327,4 +328,155 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "halo_conv: %s", hipGetErrorString(e2));
     return 1;
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient, halo form
+// dW[k][tap][c] += sum_p dy[p][k] * x[p + tap][c] for the same layers (32 -> 32 channels, taps within +-1): the implicit-GEMM
+// TT kernel streams x once per TAP and dy once per column tile through L2 -> LDS; here a persistent workgroup DMAs the x halo
+// and the dy tile of an 8x32 pixel tile ONCE (38 KB), forms all 9 tap products from LDS and keeps the 9 [32 x 32]
+// accumulators in registers over its whole tile run: HBM traffic = x + dy once.
+//   MFMA 32x32x16: A = dy^T [32 out-ch][16 pixels], B = x^T(tap) [32 in-ch][16 pixels]; the reduction runs over pixels, both
+//   operands are pixel-major in LDS and are read with ds_read_b64_tr_b16 (a 32-lane group reads 4 whole 64-byte pixels).
+//   Wave w owns tile rows 2w, 2w+1 (4 k-steps of 16 pixels per tile).  At the end every wave adds its accumulators to
+//   dw with fp32 atomics (once per workgroup; summing the waves in LDS first measured slower: the tail is not atomic-bound).
+struct HaloWgArgs {
+    const bf16raw* dy[8];
+    const bf16raw* in[8];
+    float* dw[8];
+    const bf16raw* zero_page;
+    int N, H, W, wt;
+    int tiles_x, tiles_y, ntiles, tiles_per_wg;
+    int tap_dh[9], tap_dw[9], tap_w[9];
+    int ntaps;
+};
+
+__device__ __forceinline__ bf16x8_t halo_tr_read8(const bf16raw* p_lo, const bf16raw* p_hi) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_lo);
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_wgrad_kernel(const HaloWgArgs a) {
+    constexpr int C = 32, XU = HALO_PIX * 4, YU = HALO_TH * HALO_TW * 4;         // 16-byte units of the x halo / the dy tile
+    constexpr int XI = (XU + 63) / 64, YI = YU / 64;                              // DMA wave-instructions: 22 and 16
+    constexpr int SLOT = (XI + YI) * 512;                                         // bf16 elements per tile buffer
+    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int prob = blockIdx.y;
+    const bf16raw* __restrict__ dy = a.dy[prob];
+    const bf16raw* __restrict__ in = a.in[prob];
+    const int H = a.H, W = a.W;
+    const int t_begin = blockIdx.x * a.tiles_per_wg;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
+    if (t_begin >= t_end) return;
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#define HWG_ISSUE(tile, slot)                                                                                \
+    {                                                                                                        \
+        const int tx_ = (tile) % a.tiles_x, ty_ = ((tile) / a.tiles_x) % a.tiles_y, n_ = (tile) / (a.tiles_x * a.tiles_y); \
+        const int y0_ = ty_ * HALO_TH, x0_ = tx_ * HALO_TW;                                                  \
+        for (int ii = wave; ii < XI + YI; ii += 4) {                                                         \
+            const bf16raw* src_;                                                                             \
+            if (ii < XI) {                                                                                   \
+                const int q_ = ii * 64 + lane, p_ = q_ >> 2, hy_ = p_ / HALO_HW, hx_ = p_ - hy_ * HALO_HW;   \
+                const int y_ = y0_ + hy_ - 1, x_ = x0_ + hx_ - 1;                                            \
+                const bool ok_ = q_ < XU && (unsigned)y_ < (unsigned)H && (unsigned)x_ < (unsigned)W;        \
+                src_ = ok_ ? in + ((int64_t)(n_ * H + y_) * W + x_) * C + (q_ & 3) * 8 : a.zero_page;        \
+            } else {                                                                                         \
+                const int q_ = (ii - XI) * 64 + lane, p_ = q_ >> 2;                                          \
+                src_ = dy + ((int64_t)(n_ * H + y0_ + p_ / HALO_TW) * W + x0_ + p_ % HALO_TW) * C + (q_ & 3) * 8; \
+            }                                                                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + (slot) * SLOT + ii * 512), 16, 0, 0); \
+        }                                                                                                    \
+    }
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // transposing reads: lane -> pixel (lane >> 5) * 8 + ((lane & 15) >> 2) (+4 for the second half), channel group
+    const int tr_p = (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    int tap_off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap_off[t] = t < a.ntaps ? ((a.tap_dh[t] + 1) * HALO_HW + a.tap_dw[t] + 1) * C : 0;
+
+    HWG_ISSUE(t_begin, 0);
+    int slot = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tile + 1 < t_end) HWG_ISSUE(tile + 1, slot ^ 1);
+        const bf16raw* xs = lds + slot * SLOT;
+        const bf16raw* ys = xs + XI * 512;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = 2 * wave + (ks >> 1), x0 = (ks & 1) * 16;
+            const bf16raw* yp = ys + (row * HALO_TW + x0 + tr_p) * C + tr_c;
+            const bf16x8_t af = halo_tr_read8(yp, yp + 4 * C);
+            const bf16raw* xp = xs + (row * HALO_HW + x0 + tr_p) * C + tr_c;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t < a.ntaps) {
+                    const bf16x8_t bfr = halo_tr_read8(xp + tap_off[t], xp + tap_off[t] + 4 * C);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        slot ^= 1;
+    }
+#undef HWG_ISSUE
+    // ---- accumulators -> dw[(k * wt + slot(t)) * C + c]: rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31
+    float* __restrict__ dw = a.dw[prob];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t >= a.ntaps || a.tap_w[t] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            atomicAdd(dw + ((int64_t)k * a.wt + a.tap_w[t]) * C + (lane & 31), acc[t][r]);
+        }
+    }
+}
+
+// 1: launched, 0: not a shape for this kernel, -1: launch error
+int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
+                          int nphase, int ldy, const bf16raw* zero_page, void* stream) {
+    static const bool disabled = getenv("TCVOM_NO_HALO_WGRAD") != nullptr;      // A/B switch for tools/igemm_bench.py
+    if (disabled) return 0;
+    if (nphase != 1 || nbatch < 1 || nbatch > 8 || d->C != 32 || d->K != 32 || ldy != 32 || (d->batch > 1)) return 0;
+    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return 0;
+    if (d->H != d->OH || d->W != d->OW || d->PH != d->H || d->PW != d->W || d->H % HALO_TH != 0 || d->W % HALO_TW != 0) return 0;
+    HaloWgArgs a;
+    int nt = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        if (d->tap_w[t] < 0) continue;
+        if (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1 || nt >= 9) return 0;
+        a.tap_dh[nt] = d->tap_dh[t]; a.tap_dw[nt] = d->tap_dw[t]; a.tap_w[nt] = d->tap_w[t];
+        ++nt;
+    }
+    if (nt == 0) return 0;
+    for (int t = nt; t < 9; ++t) { a.tap_dh[t] = a.tap_dw[t] = 0; a.tap_w[t] = -1; }
+    a.ntaps = nt;
+    for (int i = 0; i < 8; ++i) {
+        const int j = i < nbatch ? i : 0;
+        a.dy[i] = (const bf16raw*)dys[j]; a.in[i] = (const bf16raw*)ins[j]; a.dw[i] = dws[j];
+    }
+    a.zero_page = zero_page;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.wt = d->wt;
+    a.tiles_x = d->W / HALO_TW; a.tiles_y = d->H / HALO_TH;
+    a.ntiles = d->N * a.tiles_x * a.tiles_y;
+    if ((long long)d->N * d->H * d->W * 32 >= (1ll << 31)) return 0;
+    int wgs = 512 / nbatch;                               // two co-resident workgroups per CU over all problems
+    if (wgs < 1) wgs = 1;
+    if (wgs > a.ntiles) wgs = a.ntiles;
+    a.tiles_per_wg = (a.ntiles + wgs - 1) / wgs;
+    wgs = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    hipLaunchKernelGGL(halo_wgrad_kernel, dim3(wgs, nbatch), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 1 : -1;
 }

@@ -383,6 +383,9 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                           const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream);
 int gemm_nt256_takes(const tcvom_conv_desc* d);
+// halo.hip: weight gradient of the 32 -> 32 channel full-resolution layers from LDS-resident x halo / dy tiles
+int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
+                          int nphase, int ldy, const bf16raw* zero_page, void* stream);
 
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
     const int hg = halo_conv_stats_groups(d, nphase);
@@ -758,6 +761,13 @@ static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
     else { *tm = 32; *tn = ncols >= 128 ? 128 : 32; }
 }
 extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
+    if (d->C == 32 && d->K == 32 && d->in_step == 1 && d->out_step == 1 && d->H == d->OH && d->W == d->OW && d->H % 8 == 0 && d->W % 32 == 0 &&
+        d->batch <= 1) {
+        bool ok = true;
+        for (int t = 0; t < d->ntaps; ++t)
+            if (d->tap_w[t] >= 0 && (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1)) ok = false;
+        if (ok) return "halo_wgrad<32>";
+    }
     int tm, tn;
     tt_tile(d, &tm, &tn);
     if (tm == 128) return "igemm_tt<128,128,64,32,1>";
@@ -803,6 +813,10 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     const int ncols = d->ntaps * d->C;
     const bf16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "wgrad_igemm: could not allocate the zero page");
+    {
+        const int r = halo_wgrad_try_launch(dys, ins, dws, nbatch, descs, nphase, ldy, zp, stream);
+        if (r != 0) return r < 0 ? tcvom_fail(TCVOM_ERR_LAUNCH, "wgrad_igemm: halo launch failed") : TCVOM_OK;
+    }
     int tm, tn;
     tt_tile(d, &tm, &tn);
     const int mt = cdiv(d->K, tm), nt = cdiv(ncols, tn);

@@ -279,7 +279,7 @@ def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, trans
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [(128, 128, 3, 1, False, 40, 64), (64, 64, 4, 2, True, 20, 24),
-                                                               (32, 64, 3, 2, False, 48, 64)])
+                                                               (32, 64, 3, 2, False, 48, 64), (32, 32, 3, 1, False, 48, 64)])
 def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
     """tcvom_wgrad_igemm_batched (the S calls of a layer as one launch, what WeightBank.run_deferred_wgrads issues) must
     equal S separate tcvom_wgrad_igemm_phases launches up to the fp32 order of the split pixel reduction."""
