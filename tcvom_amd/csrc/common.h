@@ -64,3 +64,31 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- gfx950 LDS transposing reads (ds_read_b64_tr_b16) issued as inline asm
+// The compiler treats the ds_read_tr builtin as a possible reader of what an in-flight global_load_lds writes and puts
+// s_waitcnt vmcnt(0) in front of the first one: the next stage's DMA then never overlaps this stage's MFMAs.  The reduction
+// loop therefore issues the transposing reads as inline asm (invisible to the waitcnt pass) and counts lgkmcnt itself:
+// tr_issue (2 x ds_read_b64_tr_b16), one s_waitcnt lgkmcnt(0), tr_fence per fragment (an empty asm the MFMA depends on, so
+// that it cannot be scheduled above the wait).
+typedef __attribute__((ext_vector_type(2))) unsigned int tr_u32x2_t;
+struct TrFrag { tr_u32x2_t lo, hi; };
+__device__ __forceinline__ void tr_issue(TrFrag& f, const bf16raw* p_lo, const bf16raw* p_hi) {
+    typedef __attribute__((address_space(3))) const void* lp_t;
+    const unsigned a_lo = (unsigned)(uintptr_t)(lp_t)p_lo, a_hi = (unsigned)(uintptr_t)(lp_t)p_hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a_lo));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a_hi));
+}
+__device__ __forceinline__ void tr_fence(TrFrag& f) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }
+__device__ __forceinline__ bf16x8_t tr_value(const TrFrag& f) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// the same with the k-step / row displacement as an immediate: lo at addr + OFF, hi (k rows + 4) at addr + OFF + HI bytes
+template <int OFF, int HI>
+__device__ __forceinline__ void tr_issue_imm(TrFrag& f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(OFF + HI));
+}
+

@@ -337,8 +337,9 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
 // accumulators in registers over its whole tile run: HBM traffic = x + dy once.
 //   MFMA 32x32x16: A = dy^T [32 out-ch][16 pixels], B = x^T(tap) [32 in-ch][16 pixels]; the reduction runs over pixels, both
 //   operands are pixel-major in LDS and are read with ds_read_b64_tr_b16 (a 32-lane group reads 4 whole 64-byte pixels).
-//   Wave w owns tile rows 2w, 2w+1 (4 k-steps of 16 pixels per tile).  At the end every wave adds its accumulators to
-//   dw with fp32 atomics (once per workgroup; summing the waves in LDS first measured slower: the tail is not atomic-bound).
+//   The reads are inline asm (common.h: the builtin form makes the compiler drain the next tile's DMA first).
+//   Wave w owns tile rows 2w, 2w+1 (4 k-steps of 16 pixels per tile).  At the end the 4 waves' accumulators are summed
+//   through LDS and added to dw with fp32 atomics, once per workgroup.
 struct HaloWgArgs {
     const bf16raw* dy[8];
     const bf16raw* in[8];
@@ -349,14 +350,6 @@ struct HaloWgArgs {
     int tap_dh[9], tap_dw[9], tap_w[9];
     int ntaps;
 };
-
-__device__ __forceinline__ bf16x8_t halo_tr_read8(const bf16raw* p_lo, const bf16raw* p_hi) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_lo);
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_hi);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_wgrad_kernel(const HaloWgArgs a) {
     constexpr int C = 32, XU = HALO_PIX * 4, YU = HALO_TH * HALO_TW * 4;         // 16-byte units of the x halo / the dy tile
@@ -399,12 +392,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // transposing reads: lane -> pixel (lane >> 5) * 8 + ((lane & 15) >> 2) (+4 for the second half), channel group
+    // transposing reads: lane -> pixel (lane >> 5) * 8 + ((lane & 15) >> 2) (+4 for the hi half: +256 bytes), channels
+    // ((lane >> 4) & 1) * 16 + (lane & 3) * 4 ..+3.  Byte addresses inside a tile buffer; the k-step moves them by immediates.
     const int tr_p = (lane >> 5) * 8 + ((lane & 15) >> 2);
     const int tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-    int tap_off[9];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const unsigned y_rel = XI * 1024 + ((2 * wave * HALO_TW + tr_p) * C + tr_c) * 2;
+    unsigned x_rel[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tap_off[t] = t < a.ntaps ? ((a.tap_dh[t] + 1) * HALO_HW + a.tap_dw[t] + 1) * C : 0;
+    for (int t = 0; t < 9; ++t)
+        x_rel[t] = (((2 * wave + a.tap_dh[t] + 1) * HALO_HW + a.tap_dw[t] + 1 + tr_p) * C + tr_c) * 2;
+    constexpr int XROW = HALO_HW * C * 2, YROW = HALO_TW * C * 2, HALF = 16 * C * 2, HI = 4 * C * 2;
+
+    // k-step ks = tile row 2 wave + (ks >> 1), pixels (ks & 1) * 16 ..+15.  The 9 taps of a k-step are read in two groups
+    // (taps 0-4, taps 5-8) so that the reads of one group are in flight under the MFMAs of the other.
+    TrFrag fy[2], fx[9];
+#define HWG_READ_Y(ks, set) tr_issue_imm<((ks) >> 1) * YROW + ((ks) & 1) * HALF, HI>(fy[set], ya)
+#define HWG_READ_X(ks, t) tr_issue_imm<((ks) >> 1) * XROW + ((ks) & 1) * HALF, HI>(fx[t], xa[t])
+#define HWG_STEP(ks)                                                                                          \
+    {                                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        tr_fence(fy[(ks) & 1]);                                                                               \
+        _Pragma("unroll") for (int t = 0; t < 5; ++t) tr_fence(fx[t]);                                        \
+        _Pragma("unroll") for (int t = 5; t < 9; ++t) HWG_READ_X(ks, t);                                      \
+        _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                         \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+        _Pragma("unroll") for (int t = 5; t < 9; ++t) tr_fence(fx[t]);                                        \
+        if ((ks) < 3) {                                                                                       \
+            HWG_READ_Y((ks) + 1, ((ks) + 1) & 1);                                                             \
+            _Pragma("unroll") for (int t = 0; t < 5; ++t) HWG_READ_X((ks) + 1, t);                            \
+        }                                                                                                     \
+        _Pragma("unroll") for (int t = 5; t < 9; ++t)                                                         \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
+    }
 
     HWG_ISSUE(t_begin, 0);
     int slot = 0;
@@ -412,30 +433,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tile + 1 < t_end) HWG_ISSUE(tile + 1, slot ^ 1);
-        const bf16raw* xs = lds + slot * SLOT;
-        const bf16raw* ys = xs + XI * 512;
+        const unsigned sb = lds0 + slot * (SLOT * 2);
+        const unsigned ya = sb + y_rel;
+        unsigned xa[9];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int row = 2 * wave + (ks >> 1), x0 = (ks & 1) * 16;
-            const bf16raw* yp = ys + (row * HALO_TW + x0 + tr_p) * C + tr_c;
-            const bf16x8_t af = halo_tr_read8(yp, yp + 4 * C);
-            const bf16raw* xp = xs + (row * HALO_HW + x0 + tr_p) * C + tr_c;
+        for (int t = 0; t < 9; ++t) xa[t] = sb + x_rel[t];
+        HWG_READ_Y(0, 0);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t < a.ntaps) {
-                    const bf16x8_t bfr = halo_tr_read8(xp + tap_off[t], xp + tap_off[t] + 4 * C);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
-                }
-            }
-        }
+        for (int t = 0; t < 5; ++t) HWG_READ_X(0, t);
+        HWG_STEP(0)
+        HWG_STEP(1)
+        HWG_STEP(2)
+        HWG_STEP(3)
         slot ^= 1;
     }
 #undef HWG_ISSUE
+#undef HWG_STEP
+#undef HWG_READ_X
+#undef HWG_READ_Y
     // ---- accumulators -> dw[(k * wt + slot(t)) * C + c]: rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31
+    // The sum over the 4 waves is formed in LDS with plain stores / loads (waves 2, 3 -> waves 0, 1 -> wave 0; LDS float
+    // atomics measured far slower), then wave 0 alone issues the fp32 global atomics: 4x fewer than one set per wave, and
+    // they were the tail of the kernel (all workgroups finish together and hit the same 36 KB of dw).
     float* __restrict__ dw = a.dw[prob];
+    __builtin_amdgcn_s_barrier();                         // every wave is done with the tile buffers
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);       // [2 regions][9 taps][4 quads][64 lanes] float4 = 2 x 36 KB
+    static_assert(2 * 9 * 4 * 64 * 16 <= 2 * SLOT * 2, "reduction buffers must fit the tile buffers");
+#define HWG_PUT(region)                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                        \
+            red[(((region) * 9 + t) * 4 + q) * 64 + lane] =                                                  \
+                f32x4_t{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+#define HWG_GET(region)                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+            const f32x4_t v = red[(((region) * 9 + t) * 4 + q) * 64 + lane];                                 \
+            acc[t][4 * q] += v[0]; acc[t][4 * q + 1] += v[1]; acc[t][4 * q + 2] += v[2]; acc[t][4 * q + 3] += v[3]; \
+        }
+    if (wave >= 2) HWG_PUT(wave - 2)
+    __syncthreads();
+    if (wave < 2) HWG_GET(wave)
+    __syncthreads();
+    if (wave == 1) HWG_PUT(0)
+    __syncthreads();
+    if (wave != 0) return;
+    HWG_GET(0)
+#undef HWG_PUT
+#undef HWG_GET
+    // accumulator rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31 -> dw[(k * wt + slot(t)) * C + c]
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        if (t >= a.ntaps || a.tap_w[t] < 0) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -460,8 +507,7 @@ int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float*
         a.tap_dh[nt] = d->tap_dh[t]; a.tap_dw[nt] = d->tap_dw[t]; a.tap_w[nt] = d->tap_w[t];
         ++nt;
     }
-    if (nt == 0) return 0;
-    for (int t = nt; t < 9; ++t) { a.tap_dh[t] = a.tap_dw[t] = 0; a.tap_w[t] = -1; }
+    if (nt != 9) return 0;                                  // the kernel is written for the full 3x3 stencil
     a.ntaps = nt;
     for (int i = 0; i < 8; ++i) {
         const int j = i < nbatch ? i : 0;

@@ -693,31 +693,43 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
         TRACE(3);
         const bf16raw* As = lds + slot * SLOT;
         const bf16raw* Bs = As + 64 * TM;
+        // fragments of k-step kq + 1 are requested before the MFMAs of k-step kq (two register sets)
+        TrFrag fa[2][MI], fb[2][NI];
+        constexpr int NKQ = 4 / KS;
+#define TT_READ(set, kq)                                                                                         \
+        {                                                                                                        \
+            const int ks_ = (KS == 1) ? (kq) : wk;                                                               \
+            const int r0 = ks_ * 16 + tr_krow, r1 = r0 + 4;                                                      \
+            _Pragma("unroll") for (int a = 0; a < MI; ++a) {                                                     \
+                const int col = wm * WM + a * 32 + tr_col;                                                       \
+                const int sl = col >> 3, e = col & 7;                                                            \
+                tr_issue(fa[set][a], As + r0 * TM + ((sl ^ (TA::swz(r0) << 2)) << 3) + e,                        \
+                         As + r1 * TM + ((sl ^ (TA::swz(r1) << 2)) << 3) + e);                                   \
+            }                                                                                                    \
+            _Pragma("unroll") for (int b = 0; b < NI; ++b) {                                                     \
+                const int col = wn * WN + b * 32 + tr_col;                                                       \
+                const int sl = col >> 3, e = col & 7;                                                            \
+                tr_issue(fb[set][b], Bs + r0 * TN + ((sl ^ (TB::swz(r0) << 2)) << 3) + e,                        \
+                         Bs + r1 * TN + ((sl ^ (TB::swz(r1) << 2)) << 3) + e);                                   \
+            }                                                                                                    \
+        }
+        TT_READ(0, 0)
 #pragma unroll
-        for (int kq = 0; kq < 4 / KS; ++kq) {
-            const int ks = (KS == 1) ? kq : wk;
-            bf16x8_t af[MI], bfr[NI];
-            const int r0 = ks * 16 + tr_krow, r1 = r0 + 4;
+        for (int kq = 0; kq < NKQ; ++kq) {
+            const int set = kq & 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int a = 0; a < MI; ++a) {
-                const int col = wm * WM + a * 32 + tr_col;
-                const int sl = col >> 3, e = col & 7;
-                af[a] = tr_read8(As + r0 * TM + ((sl ^ (TA::swz(r0) << 2)) << 3) + e,
-                                 As + r1 * TM + ((sl ^ (TA::swz(r1) << 2)) << 3) + e);
-            }
+            for (int a = 0; a < MI; ++a) tr_fence(fa[set][a]);
 #pragma unroll
-            for (int b = 0; b < NI; ++b) {
-                const int col = wn * WN + b * 32 + tr_col;
-                const int sl = col >> 3, e = col & 7;
-                bfr[b] = tr_read8(Bs + r0 * TN + ((sl ^ (TB::swz(r0) << 2)) << 3) + e,
-                                  Bs + r1 * TN + ((sl ^ (TB::swz(r1) << 2)) << 3) + e);
-            }
+            for (int b = 0; b < NI; ++b) tr_fence(fb[set][b]);
+            if (kq + 1 < NKQ) TT_READ(set ^ 1, kq + 1)
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fa[set][a]), tr_value(fb[set][b]), acc[a][b], 0, 0, 0);
         }
+#undef TT_READ
     }
 #undef TT_ISSUE_STAGE
 #undef TT_ADVANCE
