@@ -496,7 +496,7 @@ int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float*
                           int nphase, int ldy, const bf16raw* zero_page, void* stream) {
     static const bool disabled = getenv("TCVOM_NO_HALO_WGRAD") != nullptr;      // A/B switch for tools/igemm_bench.py
     if (disabled) return 0;
-    if (nphase != 1 || nbatch < 1 || nbatch > 8 || d->C != 32 || d->K != 32 || ldy != 32 || (d->batch > 1)) return 0;
+    if (nphase != 1 || nbatch < 1 || nbatch > 8 || d->C != 32 || d->K != 32 || ldy != 32) return 0;   // (d->batch is a forward-only field)
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return 0;
     if (d->H != d->OH || d->W != d->OW || d->PH != d->H || d->PW != d->W || d->H % HALO_TH != 0 || d->W % HALO_TW != 0) return 0;
     HaloWgArgs a;

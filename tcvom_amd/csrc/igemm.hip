@@ -773,8 +773,7 @@ static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
     else { *tm = 32; *tn = ncols >= 128 ? 128 : 32; }
 }
 extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
-    if (d->C == 32 && d->K == 32 && d->in_step == 1 && d->out_step == 1 && d->H == d->OH && d->W == d->OW && d->H % 8 == 0 && d->W % 32 == 0 &&
-        d->batch <= 1) {
+    if (d->C == 32 && d->K == 32 && d->in_step == 1 && d->out_step == 1 && d->H == d->OH && d->W == d->OW && d->H % 8 == 0 && d->W % 32 == 0) {
         bool ok = true;
         for (int t = 0; t < d->ntaps; ++t)
             if (d->tap_w[t] >= 0 && (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1)) ok = false;
