@@ -372,6 +372,24 @@ int tcvom_lap_bwd_fine(const int8_t* sgn, const float* coef, const float* r, flo
 int tcvom_matting_metrics(const float* a, const float* g, const uint8_t* tri, const float* ha, const float* hg,
                           const float* flow, double* acc, int32_t H, int32_t W, void* stream);
 
+/* ------------------------------------------------------------------ data front-end (dataset/VMD.py)
+ * The loader decodes PNGs into uint8 frames; everything after the decode runs on the device, S frames per launch.
+ * tcvom_crop_resize_u8 = img_crop_and_resize (VMD.py:62-66): src uint8 [S][Hs][Ws][Cs] (HWC as decoded), crop window
+ * rows ph..ph+nh-1 / columns pw..pw+nw-1, bilinear resize to Ho x Wo with align_corners=True, floor(x + 0.5); the nc
+ * output planes take source channels chan[0..nc-1] (e.g. {2,1,0} turns RGB into the reference's BGR, {3} is the alpha of
+ * an RGBA foreground).  dst fp32 [S][nc][Ho][Wo].  nh == Ho && nw == Wo is a plain crop + uint8 -> float conversion.
+ * form selects which of ATen's two CPU bilinear kernels is reproduced bit for bit: 0 = the generic one (alpha planes; images in a
+ * multi-threaded process), 1 = the channels-last one (3-channel images inside a DataLoader worker, which runs with one thread).
+ * tcvom_count_unknown: counts[s] = #{0 < alpha < 255} of frame s of a fp32 [S][n] alpha (shape_aug's crop acceptance test,
+ * VMD.py:146-150).  tcvom_pad_bottom_right = possible_pad (VMD.py:187-200): fp32 [S][C][H][W] -> [S][C][Ho][Wo], border
+ * filled with value[c] (NULL = 0). */
+int tcvom_crop_resize_u8(const void* src, float* dst, int32_t S, int32_t Hs, int32_t Ws, int32_t Cs, const int32_t* chan,
+                         int32_t nc, int32_t ph, int32_t pw, int32_t nh, int32_t nw, int32_t Ho, int32_t Wo, int32_t form,
+                         void* stream);
+int tcvom_count_unknown(const float* alpha, int32_t S, int64_t n, int32_t* counts, void* stream);
+int tcvom_pad_bottom_right(const float* src, float* dst, int32_t S, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                           const float* value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

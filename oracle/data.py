@@ -1,0 +1,113 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): CPU restatement of the reference's loader math, dataset/VMD.py, for
+the no_flow path — file-list neighbourhoods (`parse`, VMD.py:167-181), `img_crop_and_resize` (VMD.py:62-66),
+`possible_pad` (VMD.py:187-200), the crop search of `shape_aug` (VMD.py:131-152) and `__getitem__` (VMD.py:202-301)
+without the imgaug colour / JPEG augmentation.
+
+Parity status: the reference module imports cv2 and imgaug, neither of which exists in this image, so it cannot be
+executed here: this restatement is pinned by construction only — every numeric step is the SAME torch call the
+reference makes (`F.interpolate(..., mode='bilinear', align_corners=True)`, `torch.floor(x + 0.5)`, `F.pad`) on the same
+uint8 pixel values (PIL decodes RGB(A); cv2 would give BGR(A), the channel order is swapped back below).
+"""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+IMG_PADDING_VALUE = [103.53, 116.28, 123.675]
+
+
+def parse(frame_corr, video_names, length):
+    samples = []
+    for v in video_names:
+        v = v.strip()
+        fns = [k for k in sorted(frame_corr.keys()) if os.path.dirname(k) == v]
+        for i in range(len(fns)):
+            sample = [None] * length
+            c = length // 2
+            sample[c] = fns[i]
+            for j in range(length // 2):
+                sample[c - j - 1] = fns[i - j - 1] if i - j - 1 >= 0 else fns[-(i - j - 1)]
+                sample[c + j + 1] = fns[i + j + 1] if i + j + 1 < len(fns) else fns[len(fns) - (i + j + 1) - 2]
+            samples.append(sample)
+    return samples
+
+
+def img_crop_and_resize(img, image_shape, ph, pw, nsize=None, threads=1):
+    """img: float32 numpy [H, W, C] -> [1, C, h, w].  `threads`: ATen rounds 3-channel images differently when the process has
+    one thread (channels-last kernel) than when it has several (generic kernel); the reference's loader runs inside DataLoader
+    workers, which torch pins to one thread, hence the default."""
+    img2 = img[ph:ph + nsize[0], pw:pw + nsize[1]] if nsize is not None else img
+    img2 = torch.from_numpy(img2).permute(2, 0, 1).unsqueeze(0)
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        return torch.floor(F.interpolate(img2, list(image_shape), mode='bilinear', align_corners=True) + 0.5)
+    finally:
+        torch.set_num_threads(before)
+
+
+def possible_pad(t, image_shape, padvalue=0):
+    H, W = t.shape[-2:]
+    if H == image_shape[0] and W == image_shape[1]:
+        return t
+    assert H <= image_shape[0] and W <= image_shape[1]
+    ph, pw = image_shape[0] - H, image_shape[1] - W
+    if isinstance(padvalue, (int, float)):
+        return F.pad(t, (0, pw, 0, ph), value=padvalue)
+    mask = F.pad(torch.zeros(H, W), (0, pw, 0, ph), value=1).bool()
+    t = F.pad(t, (0, pw, 0, ph), value=0)
+    t[:, mask] = torch.tensor(padvalue, dtype=t.dtype).unsqueeze(-1)
+    return t
+
+
+def shape_aug(fg, bg, a, image_shape, video_shape, scales=(1.0, 1.25, 1.5, 1.75, 2.0)):
+    H, W = video_shape
+    length = len(fg)
+    pa = [None] * length
+    good = False
+    while not good:
+        scale = random.choice(list(scales))
+        nsize = (int(image_shape[0] * scale), int(image_shape[1] * scale))
+        ph = random.randint(0, H - nsize[0] - 1)
+        pw = random.randint(0, W - nsize[1] - 1)
+        good = True
+        for i in range(length):
+            pa[i] = img_crop_and_resize(a[i], image_shape, ph, pw, nsize).squeeze(0)
+            if torch.sum((pa[i] > 0) * (pa[i] < 255)).item() < 1:
+                good = False
+                break
+    pfg = [img_crop_and_resize(fg[i], image_shape, ph, pw, nsize).squeeze(0) for i in range(length)]
+    pbg = [img_crop_and_resize(bg[i], image_shape, ph, pw, nsize).squeeze(0) for i in range(length)]
+    return pfg, pbg, pa
+
+
+def get_item(root, frame_corr, sample, mode, image_shape, video_shape, precomputed=False):
+    """The (fg, bg, a) of one sample; `sample` = list of frame names; consumes python `random` like the reference."""
+    from PIL import Image
+    if mode == 'train' and random.random() > 0.5:
+        sample = sample[::-1]
+    fg, bg, a = [], [], []
+    for fn in sample:
+        with Image.open(os.path.join(root, 'FG_done', fn)) as im:
+            f = np.asarray(im.convert('RGBA'))
+        bgp = os.path.join(root, 'BG_done', frame_corr[fn])
+        if not os.path.exists(bgp):
+            bgp = os.path.splitext(bgp)[0] + '.png'
+        with Image.open(bgp) as im:
+            b = np.asarray(im.convert('RGB'))
+        fg.append(np.float32(f[..., [2, 1, 0]]))          # cv2 channel order
+        bg.append(np.float32(b[..., [2, 1, 0]]))
+        a.append(np.float32(f[..., 3:]))
+    if mode == 'train':
+        fg, bg, a = shape_aug(fg, bg, a, image_shape, video_shape)
+    elif precomputed:
+        fg = [possible_pad(torch.from_numpy(x).permute(2, 0, 1), image_shape, IMG_PADDING_VALUE) for x in fg]
+        bg = [possible_pad(torch.from_numpy(x).permute(2, 0, 1), image_shape, IMG_PADDING_VALUE) for x in bg]
+        a = [possible_pad(torch.from_numpy(x).permute(2, 0, 1), image_shape) for x in a]
+    else:
+        fg = [img_crop_and_resize(x, image_shape, 0, 0).squeeze(0) for x in fg]
+        bg = [img_crop_and_resize(x, image_shape, 0, 0).squeeze(0) for x in bg]
+        a = [img_crop_and_resize(x, image_shape, 0, 0).squeeze(0) for x in a]
+    return torch.stack(fg).float(), torch.stack(bg).float(), torch.stack(a).float()

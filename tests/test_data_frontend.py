@@ -1,0 +1,130 @@
+"""Data front-end (dataset/VMD.py): file-list logic on the CPU; the crop / resize / pad kernels and the whole
+`VideoMattingDataset` against the oracle's restatement of the reference loader on the GPU (bit exact: integer pixel values)."""
+import io
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data as odata
+
+
+def _write_clips(root, videos, nframes, H, W, seed=0):
+    """Synthetic VideoMatting108-style tree: FG_done/<v>/<k>.png (RGBA), BG_done/<b>/<k>.png, frame_corr.json, *_videos.txt."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    corr = {}
+    for v in videos:
+        os.makedirs(os.path.join(root, 'FG_done', v), exist_ok=True)
+        os.makedirs(os.path.join(root, 'BG_done', 'bg_' + v), exist_ok=True)
+        yy, xx = np.mgrid[0:H, 0:W]
+        for k in range(nframes):
+            rgb = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+            cx, cy = W * (0.4 + 0.03 * k), H * 0.5
+            d = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+            alpha = np.clip((min(H, W) * 0.3 - d) * 12 + 128, 0, 255).astype(np.uint8)      # soft disc: fg, unknown ring, bg
+            Image.fromarray(np.dstack([rgb, alpha]), 'RGBA').save(os.path.join(root, 'FG_done', v, '%04d.png' % k))
+            Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8), 'RGB').save(
+                os.path.join(root, 'BG_done', 'bg_' + v, '%04d.png' % k))
+            # the table names a .jpg background: the loader falls back to .png (VMD.py:229-231)
+            corr['%s/%04d.png' % (v, k)] = 'bg_%s/%04d.jpg' % (v, k)
+    with open(os.path.join(root, 'frame_corr.json'), 'w') as f:
+        json.dump(corr, f)
+    for mode in ('train', 'val'):
+        with open(os.path.join(root, '%s_videos.txt' % mode), 'w') as f:
+            f.write('\n'.join(videos) + '\n')
+    return corr
+
+
+def test_parse_neighbourhoods(tmp_path):
+    from tcvom_amd.data import VideoMattingDataset
+    root = str(tmp_path)
+    corr = _write_clips(root, ['va', 'vb'], 4, 8, 8)
+    ds = VideoMattingDataset(root, [8, 8], False, 'val', no_flow=True, sample_length=5)
+    assert len(ds) == 8
+    want = odata.parse(corr, ['va', 'vb'], 5)
+    assert ds.samples == want
+    f = ['va/%04d.png' % k for k in range(4)]
+    assert ds.samples[0] == [f[2], f[1], f[0], f[1], f[2]]          # mirrored at the start of the clip
+    assert ds.samples[3] == [f[1], f[2], f[3], f[2], f[1]]          # ... and at its end
+    ds3 = VideoMattingDataset(root, [8, 8], True, 'val', no_flow=True, sample_length=3)
+    assert ds3.image_shape == [9, 9] and ds3.samples == odata.parse(corr, ['va', 'vb'], 3)
+    raw = ds.load_raw(5)
+    assert raw['fg'].shape == (5, 8, 8, 4) and raw['bg'].shape == (5, 8, 8, 3) and raw['fg'].dtype == torch.uint8
+    with pytest.raises(NotImplementedError):
+        VideoMattingDataset(root, [8, 8], False, 'val', no_flow=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Hs,Ws,ph,pw,nh,nw,Ho,Wo', [(96, 128, 0, 0, 96, 128, 96, 128), (96, 128, 5, 9, 64, 64, 32, 32),
+                                                    (96, 128, 10, 20, 40, 40, 33, 33), (270, 480, 3, 7, 200, 200, 161, 161),
+                                                    (96, 128, 0, 0, 96, 128, 64, 80), (50, 70, 1, 2, 48, 60, 96, 128)])
+def test_crop_resize_kernel_bit_exact(Hs, Ws, ph, pw, nh, nw, Ho, Wo):
+    from tcvom_amd.data import VideoMattingDataset as DS
+    g = torch.Generator().manual_seed(Hs * 7 + Ho)
+    src = torch.randint(0, 256, (3, Hs, Ws, 4), generator=g, dtype=torch.uint8)
+    got = DS._crop_resize(src.cuda(), [2, 1, 0], ph, pw, nh, nw, Ho, Wo, 1).cpu()         # as in a DataLoader worker (1 thread)
+    got_mt = DS._crop_resize(src.cuda(), [2, 1, 0], ph, pw, nh, nw, Ho, Wo, 0).cpu()      # as in a multi-threaded process
+    got_a = DS._crop_resize(src.cuda(), [3], ph, pw, nh, nw, Ho, Wo, 0).cpu()
+    for s in range(3):
+        img = np.float32(src[s].numpy())
+        want = odata.img_crop_and_resize(img[..., [2, 1, 0]], (Ho, Wo), ph, pw, (nh, nw))[0]
+        want_a = odata.img_crop_and_resize(img[..., 3:], (Ho, Wo), ph, pw, (nh, nw))[0]
+        assert torch.equal(got[s], want), 'frame %d: %d pixels differ' % (s, int((got[s] != want).sum()))
+        assert torch.equal(got_a[s], want_a)
+        if (os.cpu_count() or 1) >= 2:
+            want_mt = odata.img_crop_and_resize(img[..., [2, 1, 0]], (Ho, Wo), ph, pw, (nh, nw), threads=2)[0]
+            assert torch.equal(got_mt[s], want_mt)
+
+
+@pytest.mark.gpu
+def test_count_unknown_and_pad():
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.data import VideoMattingDataset as DS
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(0, 256, (4, 1, 37, 53), generator=g).float()
+    a[1] = 255.0
+    a[2] = 0.0
+    ad = a.cuda()
+    counts = torch.full((4,), -1, dtype=torch.int32, device='cuda')
+    L.call('tcvom_count_unknown', L.ptr(ad), 4, 37 * 53, L.ptr(counts), L.stream_ptr())
+    want = [int(((a[s] > 0) & (a[s] < 255)).sum()) for s in range(4)]
+    assert counts.tolist() == want and want[1] == 0 and want[2] == 0
+    t = torch.rand(2, 3, 20, 30, generator=g) * 255
+    got = DS._pad(t.cuda(), 32, 32, odata.IMG_PADDING_VALUE).cpu()
+    for s in range(2):
+        assert torch.equal(got[s], odata.possible_pad(t[s].clone(), (32, 32), odata.IMG_PADDING_VALUE))
+    got0 = DS._pad(t[:, :1].contiguous().cuda(), 20, 31, None).cpu()
+    assert torch.equal(got0[1], odata.possible_pad(t[1, :1].clone(), (20, 31)))
+    assert DS._pad(ad, 37, 53, None) is ad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,precomputed,shape', [('train', False, [32, 32]), ('val', False, [64, 96]), ('val', True, [128, 160])])
+def test_dataset_equals_reference_loader_math(tmp_path, mode, precomputed, shape):
+    from tcvom_amd.data import VideoMattingDataset
+
+    class Small(VideoMattingDataset):
+        VIDEO_SHAPE = (96, 128)
+    root = str(tmp_path)
+    corr = _write_clips(root, ['va', 'vb'], 6, 96, 128, seed=5)
+    ds = Small(root, shape, False, mode, no_flow=True, precomputed_val=root if precomputed else None, sample_length=5)
+    for idx in (0, 4, 11):
+        random.seed(100 + idx)
+        fg, bg, a, i = ds[idx]
+        random.seed(100 + idx)
+        wfg, wbg, wa = odata.get_item(root, corr, ds.samples[idx], mode, shape, (96, 128), precomputed)
+        assert int(i) == idx and fg.is_cuda and fg.dtype == torch.float32
+        assert tuple(fg.shape) == (5, 3, shape[0], shape[1]) and tuple(a.shape) == (5, 1, shape[0], shape[1])
+        assert torch.equal(fg.cpu(), wfg) and torch.equal(bg.cpu(), wbg) and torch.equal(a.cpu(), wa)
+        if mode == 'train':
+            assert all(int(((a[s] > 0) & (a[s] < 255)).sum()) >= 1 for s in range(5))
+    # decode in a worker-safe view, finish on the device
+    raw = ds.raw_view()[1] if mode != 'train' else None
+    if raw is not None:
+        fg2, _, _, _ = ds.transform(raw)
+        assert torch.equal(fg2, ds[1][0])

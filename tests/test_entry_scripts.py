@@ -55,6 +55,43 @@ def test_train_ddp_two_steps_and_checkpoint(tmp_path, arch, nkeys):
 
 
 @pytest.mark.gpu
+def test_train_ddp_from_a_clip_directory(tmp_path):
+    """DATASET.PATH set: train_ddp.py reads a VideoMatting108-style tree (1080p RGBA foregrounds, backgrounds, frame_corr.json,
+    train_videos.txt) through dataset.VMD.VideoMattingDataset with PNG-decoding worker processes, and trains on it."""
+    import json
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, REPO)
+    import train_ddp
+    from tcvom_amd.config import get_cfg_defaults
+    root = os.path.join(str(tmp_path), 'vm108')
+    H, W = 1080, 1920
+    yy, xx = np.mgrid[0:H, 0:W]
+    corr = {}
+    os.makedirs(os.path.join(root, 'FG_done', 'clip0'))
+    os.makedirs(os.path.join(root, 'BG_done', 'bg0'))
+    for k in range(3):
+        rgb = np.dstack([(xx + 40 * k) % 256, (yy * 2) % 256, (xx + yy) % 256]).astype(np.uint8)
+        d = np.sqrt((xx - (900 + 30 * k)) ** 2 + (yy - 540) ** 2)
+        alpha = np.clip((420 - d) * 2 + 128, 0, 255).astype(np.uint8)
+        Image.fromarray(np.dstack([rgb, alpha]), 'RGBA').save(os.path.join(root, 'FG_done', 'clip0', '%04d.png' % k), compress_level=1)
+        Image.fromarray(np.dstack([yy % 256, xx % 256, (xx * 3) % 256]).astype(np.uint8), 'RGB').save(
+            os.path.join(root, 'BG_done', 'bg0', '%04d.png' % k), compress_level=1)
+        corr['clip0/%04d.png' % k] = 'bg0/%04d.png' % k
+    with open(os.path.join(root, 'frame_corr.json'), 'w') as f:
+        json.dump(corr, f)
+    with open(os.path.join(root, 'train_videos.txt'), 'w') as f:
+        f.write('clip0\n')
+    cfg = get_cfg_defaults()
+    cfg.merge_from_file(os.path.join(REPO, 'cfgs', 'vmd_vmn_gca_synthetic.yaml'))
+    cfg.merge_from_list(['TRAIN.TRAIN_INPUT_SIZE', '(128, 128)', 'SYSTEM.OUTDIR', str(tmp_path), 'TRAIN.TOTAL_STEPS', '1',
+                         'DATASET.PATH', root, 'SYSTEM.NUM_WORKERS', '2'])
+    train_ddp.main('vmd_vmn_gca_disk', cfg, steps_per_epoch=0, frames=5)
+    sd = torch.load(os.path.join(str(tmp_path), 'vmd_vmn_gca_disk_agg7_synthetic', 'checkpoint_1.pth.tar'), map_location='cpu')
+    assert len(sd) == 584 and all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+@pytest.mark.gpu
 def test_adam_step_matches_torch_adam():
     """FusedAdam (one HIP launch) vs torch.optim.Adam on the same gradients, two steps, weight decay on."""
     from tcvom_amd.optim import FusedAdam
@@ -83,6 +120,46 @@ def test_pred_vmn_runs_at_1080p(capsys, base):
     pred_vmn.main(argparse.Namespace(model=base, load=None, trimap='medium', agg_window=7, clips=1, save=None))
     out = capsys.readouterr().out
     assert 'L_alpha' in out and 'L_total' in out
+
+
+@pytest.mark.gpu
+def test_pred_vmn_from_a_precomputed_validation_tree(tmp_path, capsys):
+    """pred_vmn.py --data: 1080p RGBA / RGB PNG clips -> dataset.VMD (val, precomputed, padded to 1088) -> one
+    `_pred.png` and `_tri.png` per frame, cropped back to 1080x1920 (pred_vmn.py:120-134)."""
+    import argparse
+    import json
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, REPO)
+    import pred_vmn
+    root = os.path.join(str(tmp_path), 'val')
+    H, W = 1080, 1920
+    yy, xx = np.mgrid[0:H, 0:W]
+    os.makedirs(os.path.join(root, 'FG_done', 'clipA'))
+    os.makedirs(os.path.join(root, 'BG_done', 'bgA'))
+    corr = {}
+    for k in range(2):
+        rgb = np.dstack([(xx + 25 * k) % 256, yy % 256, (xx // 2 + yy) % 256]).astype(np.uint8)
+        d = np.sqrt((xx - (960 + 20 * k)) ** 2 + (yy - 540) ** 2)
+        alpha = np.clip((400 - d) * 3 + 128, 0, 255).astype(np.uint8)
+        Image.fromarray(np.dstack([rgb, alpha]), 'RGBA').save(os.path.join(root, 'FG_done', 'clipA', '%04d.png' % k), compress_level=1)
+        Image.fromarray(np.dstack([yy % 256, (xx * 2) % 256, xx % 256]).astype(np.uint8), 'RGB').save(
+            os.path.join(root, 'BG_done', 'bgA', '%04d.png' % k), compress_level=1)
+        corr['clipA/%04d.png' % k] = 'bgA/%04d.png' % k
+    with open(os.path.join(root, 'frame_corr.json'), 'w') as f:
+        json.dump(corr, f)
+    with open(os.path.join(root, 'val_videos.txt'), 'w') as f:
+        f.write('clipA\n')
+    out = os.path.join(str(tmp_path), 'out')
+    pred_vmn.main(argparse.Namespace(model='gca', load=None, trimap='medium', agg_window=7, clips=1, save=out, data=root, subset=False,
+                                     n_threads=2))
+    assert 'L_alpha' in capsys.readouterr().out
+    for k in range(2):
+        for suffix in ('_pred.png', '_tri.png'):
+            im = np.asarray(Image.open(os.path.join(out, 'clipA', '%04d%s' % (k, suffix))))
+            assert im.shape == (H, W) and im.dtype == np.uint8
+        tri = np.asarray(Image.open(os.path.join(out, 'clipA', '%04d_tri.png' % k)))
+        assert set(np.unique(tri).tolist()) <= {0, 127, 128, 255} and (tri == 255).any() and (tri == 0).any()
 
 
 @pytest.mark.gpu

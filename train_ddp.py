@@ -7,8 +7,9 @@ per GPU, gradients averaged over RCCL.
     python train_ddp.py --cfg cfgs/vmd_vmn_gca_synthetic.yaml TRAIN.TOTAL_STEPS 1
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_ddp.py --cfg ...
 
-The reference reads VideoMatting108 from disk (dataset/VMD.py); that data front-end is out of scope,
-so clips here are the synthetic windows of tcvom_amd/synthetic.py with the loader's output contract
+With `DATASET.PATH` set the clips come from a VideoMatting108-style tree through `dataset.VMD.VideoMattingDataset`
+(tcvom_amd/data.py: PNG decode in loader workers, crop / resize on the device; train_ddp.py:224-240 of the reference);
+with `DATASET.PATH ''` they are the synthetic windows of tcvom_amd/synthetic.py with the same output contract
 (fg, bg, a, idx: float32 0..255, BGR, [B,S,C,H,W]; dataset/VMD.py:293-301).
 """
 import argparse
@@ -53,6 +54,33 @@ class SyntheticClips(object):
         for i in range(self.steps):
             a, fg, bg = synthetic_window(self.batch, self.frames, self.size[0], self.size[1], seed=self.seed + 1000 * i)
             yield fg, bg, a, torch.arange(self.batch)
+
+
+class DiskClips(object):
+    """DataLoader(VideoMattingDataset, sampler=DistributedSampler) of train_ddp.py:232-240: every rank takes its stride of a
+    per-epoch permutation (drop_last), worker processes decode the PNGs, the training process finishes the clips on its GPU."""
+
+    def __init__(self, dataset, batch, rank, world, workers, seed):
+        self.ds, self.batch, self.rank, self.world, self.workers, self.seed = dataset, batch, rank, world, workers, seed
+        self.epoch = 0
+
+    def __len__(self):
+        return (len(self.ds) // self.world) // self.batch
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)
+        self.epoch += 1
+        perm = torch.randperm(len(self.ds), generator=g).tolist()
+        mine = perm[self.rank::self.world][:len(self) * self.batch]
+        raws = torch.utils.data.DataLoader(torch.utils.data.Subset(self.ds.raw_view(), mine), batch_size=None, shuffle=False,
+                                           num_workers=self.workers)
+        buf = []
+        for raw in raws:
+            buf.append(self.ds.transform(raw))
+            if len(buf) == self.batch:
+                yield tuple(torch.stack([b[k] for b in buf]) for k in range(4))
+                buf = []
 
 
 def train(epoch, loader, base_lr, total_epochs, optimizer, averager, model, adjust_lr, print_freq, rank, device):
@@ -110,8 +138,16 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
         optimizer.load_state_dict(torch.load(cfg.TRAIN.LOAD_OPT, map_location='cpu'))
     averager = GradientAverager(params)
     adjust_lr = STR_DICT[cfg.TRAIN.LR_STRATEGY]
-    loader = SyntheticClips(cfg.TRAIN.BATCH_SIZE_PER_GPU, frames, tuple(cfg.TRAIN.TRAIN_INPUT_SIZE), steps_per_epoch,
-                            seed=max(cfg.SYSTEM.RANDOM_SEED, 0) + rank)
+    if cfg.DATASET.PATH:
+        from dataset.VMD import VideoMattingDataset
+        train_dataset = VideoMattingDataset(data_root=cfg.DATASET.PATH, image_shape=cfg.TRAIN.TRAIN_INPUT_SIZE, mode='train',
+                                            use_subset=cfg.DATASET.SUBSET, plus1=cfg.MODEL.startswith('vmn_res'), no_flow=True,
+                                            sample_length=frames, device=device)
+        loader = DiskClips(train_dataset, cfg.TRAIN.BATCH_SIZE_PER_GPU, rank, world, cfg.SYSTEM.NUM_WORKERS,
+                           seed=max(cfg.SYSTEM.RANDOM_SEED, 0))
+    else:
+        loader = SyntheticClips(cfg.TRAIN.BATCH_SIZE_PER_GPU, frames, tuple(cfg.TRAIN.TRAIN_INPUT_SIZE), steps_per_epoch,
+                                seed=max(cfg.SYSTEM.RANDOM_SEED, 0) + rank)
     for epoch in range(cfg.TRAIN.TOTAL_STEPS):
         train(epoch, loader, cfg.TRAIN.BASE_LR, cfg.TRAIN.TOTAL_STEPS, optimizer, averager, model, adjust_lr,
               cfg.TRAIN.PRINT_FREQ, rank, device)
