@@ -18,20 +18,28 @@ import torch.nn.functional as F
 IMG_PADDING_VALUE = [103.53, 116.28, 123.675]
 
 
+def _mirrored(i, n):
+    """Frame index i of an n-frame clip with the clip reflected about its first / last frame (no repeated end frame)."""
+    if i < 0:
+        return -i
+    if i >= n:
+        return 2 * (n - 1) - i
+    return i
+
+
 def parse(frame_corr, video_names, length):
-    samples = []
+    """VMD.py:167-181: one sample per frame, the frame in the middle and length // 2 neighbours per side; neighbours beyond the
+    ends of the clip are the mirrored frames."""
+    frames = {}
+    for name in sorted(frame_corr):
+        frames.setdefault(os.path.dirname(name), []).append(name)
+    half = length // 2
+    out = []
     for v in video_names:
-        v = v.strip()
-        fns = [k for k in sorted(frame_corr.keys()) if os.path.dirname(k) == v]
-        for i in range(len(fns)):
-            sample = [None] * length
-            c = length // 2
-            sample[c] = fns[i]
-            for j in range(length // 2):
-                sample[c - j - 1] = fns[i - j - 1] if i - j - 1 >= 0 else fns[-(i - j - 1)]
-                sample[c + j + 1] = fns[i + j + 1] if i + j + 1 < len(fns) else fns[len(fns) - (i + j + 1) - 2]
-            samples.append(sample)
-    return samples
+        clip = frames.get(v.strip(), [])
+        for centre in range(len(clip)):
+            out.append([clip[_mirrored(centre + off, len(clip))] for off in range(-half, length - half)])
+    return out
 
 
 def img_crop_and_resize(img, image_shape, ph, pw, nsize=None, threads=1):
@@ -49,37 +57,32 @@ def img_crop_and_resize(img, image_shape, ph, pw, nsize=None, threads=1):
 
 
 def possible_pad(t, image_shape, padvalue=0):
-    H, W = t.shape[-2:]
-    if H == image_shape[0] and W == image_shape[1]:
+    """VMD.py:187-200: grow [C, H, W] to image_shape at the bottom / right; the new pixels get padvalue (scalar or per channel)."""
+    C, H, W = t.shape[-3:]
+    Ho, Wo = image_shape
+    if (H, W) == (Ho, Wo):
         return t
-    assert H <= image_shape[0] and W <= image_shape[1]
-    ph, pw = image_shape[0] - H, image_shape[1] - W
-    if isinstance(padvalue, (int, float)):
-        return F.pad(t, (0, pw, 0, ph), value=padvalue)
-    mask = F.pad(torch.zeros(H, W), (0, pw, 0, ph), value=1).bool()
-    t = F.pad(t, (0, pw, 0, ph), value=0)
-    t[:, mask] = torch.tensor(padvalue, dtype=t.dtype).unsqueeze(-1)
-    return t
+    assert H <= Ho and W <= Wo
+    fill = torch.as_tensor(padvalue, dtype=t.dtype).reshape(-1, 1, 1).expand(C, Ho, Wo)
+    out = fill.clone()
+    out[:, :H, :W] = t
+    return out
 
 
 def shape_aug(fg, bg, a, image_shape, video_shape, scales=(1.0, 1.25, 1.5, 1.75, 2.0)):
+    """VMD.py:131-152: draw (scale, top, left) with python `random` until EVERY frame's resized alpha keeps an unknown pixel
+    (0 < a < 255); the reference stops resizing a candidate at its first frame without one, which draws nothing further."""
     H, W = video_shape
-    length = len(fg)
-    pa = [None] * length
-    good = False
-    while not good:
-        scale = random.choice(list(scales))
-        nsize = (int(image_shape[0] * scale), int(image_shape[1] * scale))
-        ph = random.randint(0, H - nsize[0] - 1)
-        pw = random.randint(0, W - nsize[1] - 1)
-        good = True
-        for i in range(length):
-            pa[i] = img_crop_and_resize(a[i], image_shape, ph, pw, nsize).squeeze(0)
-            if torch.sum((pa[i] > 0) * (pa[i] < 255)).item() < 1:
-                good = False
-                break
-    pfg = [img_crop_and_resize(fg[i], image_shape, ph, pw, nsize).squeeze(0) for i in range(length)]
-    pbg = [img_crop_and_resize(bg[i], image_shape, ph, pw, nsize).squeeze(0) for i in range(length)]
+    while True:
+        s = random.choice(list(scales))
+        n = (int(image_shape[0] * s), int(image_shape[1] * s))
+        top = random.randint(0, H - n[0] - 1)
+        left = random.randint(0, W - n[1] - 1)
+        pa = [img_crop_and_resize(x, image_shape, top, left, n).squeeze(0) for x in a]
+        if all(int(((p > 0) & (p < 255)).sum()) >= 1 for p in pa):
+            break
+    pfg = [img_crop_and_resize(x, image_shape, top, left, n).squeeze(0) for x in fg]
+    pbg = [img_crop_and_resize(x, image_shape, top, left, n).squeeze(0) for x in bg]
     return pfg, pbg, pa
 
 
