@@ -64,5 +64,5 @@ def get_cfg_defaults():
     c.TRAIN = CfgNode(LOAD_CKPT='', LOAD_OPT='', FREEZE_BACKBONE=False, BATCH_SIZE_PER_GPU=1, VAL_BATCH_SIZE_PER_GPU=1,
                       BASE_LR=5e-4, LR_STRATEGY='const', WEIGHT_DECAY=1e-4, TRAIN_INPUT_SIZE=(512, 512),
                       VAL_INPUT_SIZE=(512, 512), MIN_EDGE_LENGTH=1088, OPTIMIZER='adam', TOTAL_STEPS=50, PRINT_FREQ=10,
-                      IMAGE_FREQ=500)
+                      IMAGE_FREQ=500, VAL_START_EPOCH=15)       # VAL_START_EPOCH: train_ddp.py:323 hard-codes 15
     return c

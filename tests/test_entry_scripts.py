@@ -80,15 +80,21 @@ def test_train_ddp_from_a_clip_directory(tmp_path):
         corr['clip0/%04d.png' % k] = 'bg0/%04d.png' % k
     with open(os.path.join(root, 'frame_corr.json'), 'w') as f:
         json.dump(corr, f)
-    with open(os.path.join(root, 'train_videos.txt'), 'w') as f:
-        f.write('clip0\n')
+    for name in ('train_videos.txt', 'val_videos.txt'):
+        with open(os.path.join(root, name), 'w') as f:
+            f.write('clip0\n')
     cfg = get_cfg_defaults()
     cfg.merge_from_file(os.path.join(REPO, 'cfgs', 'vmd_vmn_gca_synthetic.yaml'))
     cfg.merge_from_list(['TRAIN.TRAIN_INPUT_SIZE', '(128, 128)', 'SYSTEM.OUTDIR', str(tmp_path), 'TRAIN.TOTAL_STEPS', '1',
-                         'DATASET.PATH', root, 'SYSTEM.NUM_WORKERS', '2'])
+                         'DATASET.PATH', root, 'SYSTEM.NUM_WORKERS', '2', 'TRAIN.VAL_INPUT_SIZE', '(128, 224)',
+                         'TRAIN.VAL_START_EPOCH', '0'])
     train_ddp.main('vmd_vmn_gca_disk', cfg, steps_per_epoch=0, frames=5)
-    sd = torch.load(os.path.join(str(tmp_path), 'vmd_vmn_gca_disk_agg7_synthetic', 'checkpoint_1.pth.tar'), map_location='cpu')
+    out_dir = os.path.join(str(tmp_path), 'vmd_vmn_gca_disk_agg7_synthetic')
+    sd = torch.load(os.path.join(out_dir, 'checkpoint_1.pth.tar'), map_location='cpu')
     assert len(sd) == 584 and all(torch.isfinite(v.float()).all() for v in sd.values())
+    # the validation pass (3-frame samples, losses + the 8-bit temporal indicator) ran and kept the epoch as best.pth
+    best = torch.load(os.path.join(out_dir, 'best.pth'), map_location='cpu')
+    assert best.keys() == sd.keys() and all(torch.equal(best[k], sd[k]) for k in sd)
 
 
 @pytest.mark.gpu

@@ -15,6 +15,7 @@ with `DATASET.PATH ''` they are the synthetic windows of tcvom_amd/synthetic.py 
 import argparse
 import logging
 import os
+import shutil
 import time
 
 import torch
@@ -105,6 +106,54 @@ def train(epoch, loader, base_lr, total_epochs, optimizer, averager, model, adju
             tic = time.time()
 
 
+def validate(dataset, model, rank, world, workers):
+    """train_ddp.py:102-166: mean of L_alpha + L_comp + L_grad over the 3-frame validation samples plus, on rank 0, the
+    temporal indicator mean_unknown |(a_t - a_t+1) - (g_t - g_t+1)| over consecutive centre-frame predictions.  The reference
+    round-trips (pred, unknown mask, gt) through 8-bit PNGs in /dev/shm; here the same 8-bit triplets stay in memory."""
+    model.eval()
+    c = dataset.sample_length // 2
+    mine = list(range(len(dataset)))[rank::world]
+    raws = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset.raw_view(), mine), batch_size=None, shuffle=False,
+                                       num_workers=workers)
+    total, count, store = 0.0, 0, {}
+    with torch.no_grad():
+        for raw in raws:
+            fg, bg, a, idx = dataset.transform(raw)
+            out = model(a[None], fg[None], bg[None])
+            loss = out[0].mean() + out[1].mean() + out[2].mean()
+            total += float(loss)
+            count += 1
+            tri = out[6][0, c, 0].float() * 255
+            store[dataset.samples[int(idx)][c]] = (torch.floor(out[7][0, c, 0].float() * 255).to(torch.uint8).cpu(),     # np.uint8(alpha * 255)
+                                                   ((tri > 0) & (tri < 255)).cpu(), a[c, 0].to(torch.uint8).cpu())
+    model.train()
+    if world > 1:                                   # ranks may hold one sample more or less: one reduction of (sum, count)
+        acc = torch.tensor([total, float(count)], dtype=torch.float64, device=next(model.parameters()).device)
+        dist.all_reduce(acc)
+        total, count = float(acc[0]), int(acc[1])
+    val_loss = total / max(count, 1)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, store)
+        store = {k: v for part in parts for k, v in part.items()}
+    if rank == 0:
+        logging.info('Validation loss: %.6f', val_loss)
+        res = 0.0
+        for sample in dataset.samples:
+            pa, m, g = store[sample[c]]
+            ha, _, hg = store[sample[c + 1]]
+            if not bool(m.any()):
+                continue
+            d = (pa.float() - ha.float()) / 255.0 - (g.float() - hg.float()) / 255.0
+            res += float(d[m].abs().mean())
+        res /= float(len(dataset.samples))
+        logging.info('Average L_dt: %.6f', res)
+        val_loss += res
+    if world > 1:
+        dist.barrier()
+    return val_loss
+
+
 def main(cfg_name, cfg, steps_per_epoch, frames):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -138,6 +187,7 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
         optimizer.load_state_dict(torch.load(cfg.TRAIN.LOAD_OPT, map_location='cpu'))
     averager = GradientAverager(params)
     adjust_lr = STR_DICT[cfg.TRAIN.LR_STRATEGY]
+    test_dataset, best_loss = None, 1e+8
     if cfg.DATASET.PATH:
         from dataset.VMD import VideoMattingDataset
         train_dataset = VideoMattingDataset(data_root=cfg.DATASET.PATH, image_shape=cfg.TRAIN.TRAIN_INPUT_SIZE, mode='train',
@@ -145,6 +195,10 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
                                             sample_length=frames, device=device)
         loader = DiskClips(train_dataset, cfg.TRAIN.BATCH_SIZE_PER_GPU, rank, world, cfg.SYSTEM.NUM_WORKERS,
                            seed=max(cfg.SYSTEM.RANDOM_SEED, 0))
+        if os.path.exists(os.path.join(cfg.DATASET.PATH, 'val_videos_subset.txt' if cfg.DATASET.SUBSET else 'val_videos.txt')):
+            test_dataset = VideoMattingDataset(data_root=cfg.DATASET.PATH, image_shape=cfg.TRAIN.VAL_INPUT_SIZE, mode='val',
+                                               use_subset=cfg.DATASET.SUBSET, plus1=cfg.MODEL.startswith('vmn_res'), no_flow=True,
+                                               sample_length=3, device=device)          # train_ddp.py:242-250
     else:
         loader = SyntheticClips(cfg.TRAIN.BATCH_SIZE_PER_GPU, frames, tuple(cfg.TRAIN.TRAIN_INPUT_SIZE), steps_per_epoch,
                                 seed=max(cfg.SYSTEM.RANDOM_SEED, 0) + rank)
@@ -153,11 +207,18 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
               cfg.TRAIN.PRINT_FREQ, rank, device)
         if world > 1:
             dist.barrier()
+        val_loss = best_loss
+        if test_dataset is not None and epoch >= cfg.TRAIN.VAL_START_EPOCH:
+            val_loss = validate(test_dataset, model, rank, world, cfg.SYSTEM.NUM_WORKERS)
         if rank == 0:
             weight_fn = os.path.join(out_dir, 'checkpoint_%d.pth.tar' % (epoch + 1))
             torch.save(model.NET.state_dict(), weight_fn)           # the reference's checkpoint format (train_ddp.py:338)
             torch.save(optimizer.state_dict(), os.path.join(out_dir, 'optimizer_%d.pth.tar' % (epoch + 1)))
             logging.info('=> saved %s', weight_fn)
+            if val_loss < best_loss:                                # train_ddp.py:340-343
+                best_loss = val_loss
+                shutil.copyfile(weight_fn, os.path.join(out_dir, 'best.pth'))
+                logging.info('=> new minimum loss. copy to best.pth')
     if world > 1:
         dist.destroy_process_group()
 
