@@ -27,14 +27,14 @@ GFLOP_FWD_GCA_1080P = 2106.3       # 6 guided-contextual-attention calls, forwar
 GFLOP_WINDOW_1080P = 11179.81      # forward + backward
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 FULL_H, FULL_W = 1088, 1920
-# HBM bytes per launch of the igemm instantiations, from the rocprofv3 PMC passes in profiles/r01_g_hbm_traffic_pmc_batched.md
+# HBM bytes per launch of the igemm instantiations, from the rocprofv3 PMC passes in profiles/r01_k_hbm_traffic_pmc.md
 # (FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script; fetch side doubled per MI355X_MICROARCH.md's gfx950
 # correction; averaged over all launches of the instantiation in a 1080p step).  bench.py cannot run rocprofv3 on itself,
 # so the figure of the kernel that turns out dominant is quoted from that committed measurement.
-PMC_TRAFFIC_BYTES = {                                                   # profiles/r01_h_hbm_traffic_pmc.md
-    'gemm_nt256': (901.47 + 452.69) * 2 ** 20,
-    'igemm_tt<128,128,64,32,1>': (212.53 + 25.20) * 2 ** 20,
-    'igemm_nt<128,128,64,32,2>': (41.45 + 41.31) * 2 ** 20,
+PMC_TRAFFIC_BYTES = {                                                   # profiles/r01_k_hbm_traffic_pmc.md
+    'gemm_nt256': (871.10 + 380.03) * 2 ** 20,
+    'igemm_tt<128,128,64,32,1>': (157.05 + 26.17) * 2 ** 20,
+    'igemm_nt<128,128,64,32,2>': (41.54 + 41.08) * 2 ** 20,
 }
 
 
