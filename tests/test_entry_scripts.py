@@ -128,23 +128,17 @@ def test_pred_vmn_runs_at_1080p(capsys, base):
     assert 'L_alpha' in out and 'L_total' in out
 
 
-@pytest.mark.gpu
-def test_pred_vmn_from_a_precomputed_validation_tree(tmp_path, capsys):
-    """pred_vmn.py --data: 1080p RGBA / RGB PNG clips -> dataset.VMD (val, precomputed, padded to 1088) -> one
-    `_pred.png` and `_tri.png` per frame, cropped back to 1080x1920 (pred_vmn.py:120-134)."""
-    import argparse
+def _write_val_tree(root, nframes=2):
+    """1080p RGBA foregrounds / RGB backgrounds of one clip + frame_corr.json + val_videos.txt (VideoMatting108 layout)."""
     import json
     import numpy as np
     from PIL import Image
-    sys.path.insert(0, REPO)
-    import pred_vmn
-    root = os.path.join(str(tmp_path), 'val')
     H, W = 1080, 1920
     yy, xx = np.mgrid[0:H, 0:W]
     os.makedirs(os.path.join(root, 'FG_done', 'clipA'))
     os.makedirs(os.path.join(root, 'BG_done', 'bgA'))
     corr = {}
-    for k in range(2):
+    for k in range(nframes):
         rgb = np.dstack([(xx + 25 * k) % 256, yy % 256, (xx // 2 + yy) % 256]).astype(np.uint8)
         d = np.sqrt((xx - (960 + 20 * k)) ** 2 + (yy - 540) ** 2)
         alpha = np.clip((400 - d) * 3 + 128, 0, 255).astype(np.uint8)
@@ -156,6 +150,21 @@ def test_pred_vmn_from_a_precomputed_validation_tree(tmp_path, capsys):
         json.dump(corr, f)
     with open(os.path.join(root, 'val_videos.txt'), 'w') as f:
         f.write('clipA\n')
+    return H, W
+
+
+@pytest.mark.gpu
+def test_pred_vmn_from_a_precomputed_validation_tree(tmp_path, capsys):
+    """pred_vmn.py --data: 1080p RGBA / RGB PNG clips -> dataset.VMD (val, precomputed, padded to 1088) -> one
+    `_pred.png` and `_tri.png` per frame, cropped back to 1080x1920 (pred_vmn.py:120-134)."""
+    import argparse
+    import json
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, REPO)
+    import pred_vmn
+    root = os.path.join(str(tmp_path), 'val')
+    H, W = _write_val_tree(root, 2)
     out = os.path.join(str(tmp_path), 'out')
     pred_vmn.main(argparse.Namespace(model='gca', load=None, trimap='medium', agg_window=7, clips=1, save=out, data=root, subset=False,
                                      n_threads=2))
@@ -230,6 +239,22 @@ def test_pred_single_dim_config1(base):
     out = pred_single.main(pred_single.parse(['--model', base, '--trimap', 'medium', '--frames', '1']))
     assert set(out) == {'L_alpha', 'L_comp', 'L_grad', 'L_total', 'mSAD', 'MSE'}
     assert all(np.isfinite(v) for v in out.values()) and abs(out['L_total'] - out['L_alpha'] - out['L_comp'] - out['L_grad']) < 1e-5
+
+
+@pytest.mark.gpu
+def test_pred_single_from_a_precomputed_validation_tree(tmp_path):
+    """pred_single.py --data (the `vmd` branch of the reference script): single-image GCA over the 3-frame validation samples,
+    centre frame scored over the unknown band on rows :1080, PNGs written."""
+    from PIL import Image
+    import pred_single
+    root = os.path.join(str(tmp_path), 'val')
+    H, W = _write_val_tree(root, 2)
+    out_dir = os.path.join(str(tmp_path), 'out')
+    out = pred_single.main(pred_single.parse(['--model', 'gca', '--trimap', 'narrow', '--data', root, '--save', out_dir, '--n_threads', '2']))
+    assert set(out) == {'L_alpha', 'L_comp', 'L_grad', 'L_total', 'mSAD', 'MSE'} and all(np.isfinite(v) for v in out.values())
+    assert out['mSAD'] > 0
+    for k in range(2):
+        assert np.asarray(Image.open(os.path.join(out_dir, 'clipA', '%04d_pred.png' % k))).shape == (H, W)
 
 
 @pytest.mark.gpu
