@@ -57,6 +57,9 @@ extern "C" int tcvom_trace_read(unsigned long long* host, int n) {
 #define TRACE(i) if (trace_on && (s) < 256) tcvom_trace_buf[((s) * 4 + (i)) + 4 * 256 * trace_w] = __builtin_readcyclecounter()
 #else
 #define TRACE(i)
+#ifndef NT_DBG
+#define NT_DBG 0            // kernel study builds only: 1 = no LDS reads / MFMAs, 2 = no DMA, 3 = no epilogue
+#endif
 #endif
 template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
@@ -201,9 +204,11 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     constexpr int LPS = A_IT + B_IT;                    // DMA instructions per wave per stage
     // NST-slot ring: stages s+1 .. s+NST-2 stay in flight across the barrier (counted vmcnt), which hides the
     // DMA latency for the layers that are latency- rather than throughput-bound (small grids, small K)
+#if NT_DBG != 2
 #pragma unroll
     for (int ps = 0; ps < NST - 1; ++ps)
         if (ps < nstage) NT_ISSUE_STAGE(ps, ps);
+#endif
     int slot = 0, islot = NST - 1;
 #ifdef NT_TRACE
     const bool trace_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW - 1);
@@ -219,12 +224,16 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         TRACE(1);
         __builtin_amdgcn_s_barrier();
         TRACE(2);
+#if NT_DBG != 2
         if (s + NST - 1 < nstage) NT_ISSUE_STAGE(s + NST - 1, islot);
+#endif
         TRACE(3);
         const bf16raw* As = lds + slot * SLOT;
         const bf16raw* Bs = As + TM * 64;
+#if NT_DBG != 1
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+#endif
+        for (int kk = 0; kk < (NT_DBG == 1 ? 0 : 4); ++kk) {
             bf16x8_t af[MI], bfr[NI];
             const int kch = kk * 2 + (lane >> 5);
 #pragma unroll
@@ -247,6 +256,9 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 #endif
 #undef NT_ISSUE_STAGE
 
+#if NT_DBG == 3
+    if (acc[0][0][0] != 123.25f && acc[MI - 1][NI - 1][15] != 7.f && acc[0][NI - 1][3] != 1.f && acc[MI - 1][0][9] != 2.f) return;
+#endif
     // ------------------------------------------------------------------ epilogue
     int64_t out_off[NI];
     bool pvalid[NI];
