@@ -124,12 +124,84 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(const int64_t* __restr
     }
 }
 
-// pack: one thread per OUTPUT element.  which = 0 fwd pack [K][T][Cpad], 1 bwd pack [C][T][K]
+// Tiled pack (work rows with which = 2 / 3): a block takes a 32 (k) x 64 (c) x T tile of one layer, reads it in the
+// weight's own order (contiguous runs of 64 T or 32 T floats), keeps the scaled bf16 values in LDS and writes the forward
+// pack [K][T][Cpad] (128-byte runs) and, for which = 3, the data-gradient pack [C][T][K] (64-byte runs) from there.  The
+// one-thread-per-output form below reads the fp32 weights with a stride of T floats (forward pack) or C T floats (backward
+// pack): 793 MiB fetched per call for 102 MB of weights (profiles/r01_k_hbm_traffic_pmc.md), 208 us per call.
+constexpr int SNP_TK = 32, SNP_TC = 64, SNP_RB = 16;
+constexpr int SNP_SLOTS = 18;                    // T <= 9 with the hi + residual pair, or T <= 16 alone
+constexpr int SNP_ROW = SNP_TC * SNP_SLOTS + 2;  // LDS row of one k: [c][slot], +2 elements: consecutive k rows are 32 T + 1 banks apart
+
+template <int TC>                                // TC = compile-time tap count (9, 16, 1) or 0: read it from the table
+__device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int which, int tile, float inv, int call,
+                                             bf16raw* __restrict__ fwd_arena, bf16raw* __restrict__ bwd_arena,
+                                             int64_t fwd_call_stride, int64_t bwd_call_stride, bf16raw* __restrict__ lds) {
+    const float* __restrict__ W = reinterpret_cast<const float*>(L[SN_W]);
+    const int kind = (int)L[SN_KIND];
+    const int K = (int)L[SN_K], C = (int)L[SN_C], T = TC ? TC : (int)L[SN_T], Cp = (int)L[SN_CPAD];
+    const bool hp = kind & 4, transposed = kind & 1, ws = kind & 8;
+    const int TT = hp ? 2 * T : T;               // slots per (k, c)   (all divisions below are by T, 2 T or constants:
+                                                 // with a runtime T the integer divisions WERE the kernel, ~250 VALU ops / element)
+    const int rp = SNP_TC * TT + 2;              // row pitch of this layer (<= SNP_ROW)
+    const int nct = (Cp + SNP_TC - 1) / SNP_TC;
+    const int k0 = (tile / nct) * SNP_TK, c0 = (tile % nct) * SNP_TC;
+    const int nk = min(SNP_TK, K - k0), nc = min(SNP_TC, C - c0);        // nc <= 0: a tile of padding channels only
+    const float4* wstat = reinterpret_cast<const float4*>(L[SN_WS_STATS]);
+    const int tid = threadIdx.x;
+    // ---- read: rows are k (runs of nc * T floats) or, for ConvTranspose weights [c][k][t], c (runs of nk * T floats);
+    // LDS element (kl, cl, slot) at kl * rp + cl * TT + slot: consecutive source elements land on consecutive addresses
+    const int nrow = transposed ? nc : nk, run = (transposed ? nk : nc) * T;
+    const int64_t row_stride = transposed ? (int64_t)K * T : (int64_t)C * T;
+    const float* __restrict__ Wt = W + (transposed ? ((int64_t)c0 * K + k0) * T : ((int64_t)k0 * C + c0) * T);
+    // SNP_RB rows per pass: their loads are independent and in flight together (the kernel is latency-bound otherwise)
+    for (int r0 = 0; r0 < nrow; r0 += SNP_RB) {
+        for (int e = tid; e < run; e += 256) {
+            const int q = e / T, t = e - q * T;
+            float w[SNP_RB];
+#pragma unroll
+            for (int u = 0; u < SNP_RB; ++u) w[u] = r0 + u < nrow ? Wt[(r0 + u) * row_stride + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < SNP_RB; ++u) {
+                if (r0 + u >= nrow) break;
+                const int r = r0 + u;
+                const int kl = transposed ? q : r, cl = transposed ? r : q;
+                float val = w[u] * inv;
+                if (ws) { const float4 st = wstat[k0 + kl]; val = (w[u] - st.x) * st.y; }
+                const bf16raw hi = f2bf(val);
+                bf16raw* dst = lds + kl * rp + cl * TT + t;
+                dst[0] = hi;
+                if (hp) dst[T] = f2bf(val - bf2f(hi));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- forward pack: [K][TT][Cp], channels c0 .. c0 + 63 of every (k, slot) row of the tile; padding channels are zero
+    bf16raw* __restrict__ fdst = fwd_arena + call * fwd_call_stride + L[SN_FWD_OFF];
+    const int ncp = min(SNP_TC, Cp - c0);
+    for (int e = tid; e < nk * TT * SNP_TC; e += 256) {
+        const int cl = e % SNP_TC, row = e / SNP_TC;
+        int kl, slot;
+        if (hp) { kl = row / (2 * T); slot = row - kl * (2 * T); } else { kl = row / T; slot = row - kl * T; }
+        if (cl < ncp) fdst[((int64_t)(k0 + kl) * TT + slot) * Cp + c0 + cl] = cl < nc ? lds[kl * rp + cl * TT + slot] : (bf16raw)0;
+    }
+    // ---- data-gradient pack: [C][T][K], output channels k0 .. k0 + 31 of every (c, t) row
+    if (which == 3 && nc > 0) {
+        bf16raw* __restrict__ bdst = bwd_arena + call * bwd_call_stride + L[SN_BWD_OFF];
+        for (int e = tid; e < nc * T * SNP_TK; e += 256) {
+            const int kl = e % SNP_TK, row = e / SNP_TK, t = row % T, cl = row / T;
+            if (kl < nk) bdst[((int64_t)(c0 + cl) * T + t) * K + k0 + kl] = lds[kl * rp + cl * TT + t];
+        }
+    }
+}
+
+// pack: one thread per OUTPUT element.  which = 0 fwd pack [K][T][Cpad], 1 bwd pack [C][T][K]; 2 / 3: tiled (above)
 __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
                                                       const float* __restrict__ sigma, int L_total, int call,
                                                       bf16raw* __restrict__ fwd_arena, bf16raw* __restrict__ bwd_arena,
                                                       int64_t fwd_call_stride, int64_t bwd_call_stride)
 {
+    __shared__ bf16raw tile_lds[SNP_TK * SNP_ROW];
     const int layer = work[blockIdx.x * 3], which = work[blockIdx.x * 3 + 1];
     const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * 256;
     const int64_t* L = tab + (int64_t)layer * SN_WORDS;
@@ -137,6 +209,14 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
     const int kind = (int)L[SN_KIND];
     const int K = (int)L[SN_K], C = (int)L[SN_C], T = (int)L[SN_T], Cp = (int)L[SN_CPAD];
     const float inv = (kind & 2) ? 1.f : 1.f / sigma[(int64_t)call * L_total + layer];
+    if (which >= 2) {
+        const int tile = work[blockIdx.x * 3 + 2];
+        if (T == 9) sn_pack_tile<9>(L, which, tile, inv, call, fwd_arena, bwd_arena, fwd_call_stride, bwd_call_stride, tile_lds);
+        else if (T == 16) sn_pack_tile<16>(L, which, tile, inv, call, fwd_arena, bwd_arena, fwd_call_stride, bwd_call_stride, tile_lds);
+        else if (T == 1) sn_pack_tile<1>(L, which, tile, inv, call, fwd_arena, bwd_arena, fwd_call_stride, bwd_call_stride, tile_lds);
+        else sn_pack_tile<0>(L, which, tile, inv, call, fwd_arena, bwd_arena, fwd_call_stride, bwd_call_stride, tile_lds);
+        return;
+    }
     const int64_t idx = base + threadIdx.x;
     int k, c, t;
     int part = 0;                                  // hp layers (kind & 4): slot t = hi part, slot T + t = bf16 residual

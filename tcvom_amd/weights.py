@@ -10,12 +10,14 @@ packed-weight gradients into gradients of `weight_bar` — a handful of launches
 State (u, v, weight_bar) stays in ordinary nn.Parameters with the reference's state_dict names.
 """
 import ctypes as C
+import os
 import struct
 
 import torch
 
 from . import _lib as L
 
+TILED_PACK = os.environ.get('TCVOM_SN_PACK_TILED', '1') != '0'      # 0: one thread per packed element (A/B, tests)
 SN_WORDS = 24
 (SN_W, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD, SN_FWD_OFF, SN_BWD_OFF,
  SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS) = range(18)
@@ -244,14 +246,7 @@ class WeightBank(object):
         self.work_wtu, self.n_wtu = i32(wtu), len(wtu)
         self.work_wv, self.n_wv = i32(wv), len(wv)
 
-        def pack_rows(sel):
-            rows = []
-            for s in sel:
-                rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad * (2 if s.hp else 1) + 255) // 256)]
-                if s.needs_dgrad:
-                    rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
-            return rows
-        rows_all, rows_sn = pack_rows(specs), pack_rows(sn)
+        rows_all, rows_sn = self._pack_rows(specs), self._pack_rows(sn)
         self.work_pack_all, self.n_pack_all = i32(rows_all), len(rows_all)
         self.work_pack_sn, self.n_pack_sn = i32(rows_sn), len(rows_sn)
         app = [(s.layer_id, b) for s in specs for b in range((s.numel + 255) // 256)]
@@ -356,14 +351,25 @@ class WeightBank(object):
     def _restricted_pack(self, plan, call):
         key = ('restrict_pack', call)
         if key not in plan:
-            rows = []
-            for s in self.specs:
-                if s.spectral and plan['ncalls'][s.layer_id] > call:
-                    rows += [(s.layer_id, 0, b) for b in range((s.K * s.T * s.cpad * (2 if s.hp else 1) + 255) // 256)]
-                    if s.needs_dgrad:
-                        rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
+            rows = self._pack_rows([s for s in self.specs if s.spectral and plan['ncalls'][s.layer_id] > call])
             plan[key] = (torch.tensor(rows, dtype=torch.int32).reshape(-1).to(self.device), len(rows))
         return plan[key]
+
+    @staticmethod
+    def _pack_rows(sel):
+        """Work list of tcvom_sn_pack: (layer, which, block) triples."""
+        rows = []
+        for s in sel:
+            slots = s.T * (2 if s.hp else 1)
+            if TILED_PACK and not getattr(s, 'stem', False) and slots <= 18:
+                # csrc/spectral.hip sn_pack_tile: 32 (k) x 64 (c) tiles, which = 3 also writes the data-gradient pack
+                ntile = ((s.K + 31) // 32) * ((s.cpad + 63) // 64)
+                rows += [(s.layer_id, 3 if s.needs_dgrad else 2, b) for b in range(ntile)]
+                continue
+            rows += [(s.layer_id, 0, b) for b in range((s.K * slots * s.cpad + 255) // 256)]
+            if s.needs_dgrad:
+                rows += [(s.layer_id, 1, b) for b in range((s.C * s.T * s.K + 255) // 256)]
+        return rows
 
     def next_call(self, spec):
         """Call slot of this use of `spec` within the current window."""

@@ -352,6 +352,48 @@ def test_halo_conv_kernel(cin, cout, hp, N, H, W):
 
 
 # --------------------------------------------------------------------------------------------- spectral norm
+def test_tiled_weight_pack_equals_elementwise_pack(monkeypatch):
+    """The tiled pack (32 x 64 x T tiles through LDS, csrc/spectral.hip sn_pack_tile) must write the same bytes as the
+    one-thread-per-element pack for every layer kind: plain / SpectralNorm / ConvTranspose [cin][cout] order / hi + residual
+    (hp) / weight-standardised, padded channels (6 -> 8, 72 -> 128), K below and off the tile size, no data-gradient pack."""
+    from tcvom_amd import weights as Wm
+    from tcvom_amd.weights import WeightBank, ConvSpec, bank_token
+
+    def build():
+        bank = WeightBank()
+        specs = []
+
+        def add(tag, shape, transposed=False, spectral=False, **kw):
+            w = nn.Parameter(formula_tensor('pk.%s.weight' % tag, shape).to(DEV))
+            u = v = None
+            if spectral:
+                u = nn.Parameter(formula_tensor('pk.%s.u' % tag, (shape[0],)).to(DEV), requires_grad=False)
+                v = nn.Parameter(formula_tensor('pk.%s.v' % tag, (int(np.prod(shape[1:])),)).to(DEV), requires_grad=False)
+            s = ConvSpec(tag, w, u, v, None, transposed, 2 if transposed else 1, 1, 'frame', **kw)
+            bank.register(s)
+            specs.append(s)
+        add('plain', (48, 32, 3, 3))
+        add('sn', (64, 64, 3, 3), spectral=True)
+        add('sn_small_k', (20, 6, 3, 3), spectral=True, needs_dgrad=False)
+        add('convT', (96, 40, 4, 4), transposed=True, spectral=True)
+        add('hp', (32, 32, 3, 3), spectral=True, hp=True)
+        add('ws', (64, 128, 1, 1), ws=True)
+        add('ws3', (36, 72, 3, 3), ws=True, cpad=128)
+        bank_token(bank, 1, True)
+        torch.cuda.synchronize()
+        return bank, specs
+
+    monkeypatch.setattr(Wm, 'TILED_PACK', False)
+    ref, specs = build()
+    assert int(ref.work_pack_all.view(-1, 3)[:, 1].max()) <= 1
+    monkeypatch.setattr(Wm, 'TILED_PACK', True)
+    got, _ = build()
+    assert int(got.work_pack_all.view(-1, 3)[:, 1].min()) >= 2
+    assert torch.equal(got.fwd_arena.view(torch.int16), ref.fwd_arena.view(torch.int16))
+    assert torch.equal(got.bwd_arena.view(torch.int16), ref.bwd_arena.view(torch.int16))
+    assert float(ref.fwd_arena.float().abs().sum()) > 0 and float(ref.bwd_arena.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize('R,Cc,ldi,ldo,batch', [(200, 130, 136, 256, 2), (70, 64, 64, 72, 1), (33, 50, 50, 35, 3), (4100, 576, 576, 4160, 1)])
 def test_transpose_bf16(R, Cc, ldi, ldo, batch):
     """in [batch][R][ldi] (first Cc columns) -> out [batch][Cc][ldo] (columns >= R zero): the 16-byte kernel (aligned strides)
