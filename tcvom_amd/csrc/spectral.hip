@@ -254,14 +254,28 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------ backward
-// inner[call][layer] = sum_e dW~_call[e] * W_bar[e]
+// weight-order element e -> (k, c, t) in 32-bit arithmetic, the tap count a compile-time constant for the usual shapes
+__device__ __forceinline__ void sn_split(unsigned e, int kind, int K, int C, int T, int& k, int& c, int& t) {
+    unsigned ab;
+    if (T == 9) { ab = e / 9u; t = (int)(e - ab * 9u); }
+    else if (T == 16) { ab = e >> 4; t = (int)(e & 15u); }
+    else if (T == 1) { ab = e; t = 0; }
+    else { ab = e / (unsigned)T; t = (int)(e - ab * (unsigned)T); }
+    if (kind & 1) { c = (int)(ab / (unsigned)K); k = (int)(ab - (unsigned)c * (unsigned)K); }
+    else { k = (int)(ab / (unsigned)C); c = (int)(ab - (unsigned)k * (unsigned)C); }
+}
+
+// inner[call][layer] = sum_e dW~_call[e] * W_bar[e].  SN_INNER_BLOCK elements per block: every block ends with ONE atomic on
+// its layer's scalar, and same-address atomics serialise at ~0.14 us each (halo weight gradient): with 1024 elements
+// per block a 512x512x3x3 layer queued 2304 of them per call and the kernel took 350 us.
+constexpr int SN_INNER_BLOCK = 8192;
 __global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
                                                            const float* __restrict__ dw_arena, int64_t dw_call_stride,
                                                            float* __restrict__ inner, int L_total)
 {
     __shared__ float red[4];
     const int layer = work[blockIdx.x * 3], call = work[blockIdx.x * 3 + 1];
-    const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * 1024;
+    const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * SN_INNER_BLOCK;
     const int64_t* L = tab + (int64_t)layer * SN_WORDS;
     const float* W = reinterpret_cast<const float*>(L[SN_W]);
     const int kind = (int)L[SN_KIND];
@@ -269,14 +283,12 @@ __global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const int64_t* __rest
     const int64_t numel = L[SN_NUMEL];
     const float* dw = dw_arena + call * dw_call_stride + L[SN_DW_OFF];
     float a = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+#pragma unroll 8
+    for (int q = 0; q < SN_INNER_BLOCK / 256; ++q) {
         const int64_t e = base + q * 256 + threadIdx.x;
         if (e < numel) {
-            const int t = (int)(e % T);
-            const int64_t ab = e / T;
-            int k, c;
-            if (kind & 1) { k = (int)(ab % K); c = (int)(ab / K); } else { c = (int)(ab % C); k = (int)(ab / C); }
+            int k, c, t;
+            sn_split((unsigned)e, kind, K, C, T, k, c, t);
             a += dw[((int64_t)k * T + t) * Cp + c] * W[e];
         }
     }
@@ -298,12 +310,16 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
     const int kind = (int)L[SN_KIND];
     const int K = (int)L[SN_K], C = (int)L[SN_C], T = (int)L[SN_T], Cp = (int)L[SN_CPAD];
     const int wd = (int)L[SN_WD];
-    const int t = (int)(e % T);
-    const int64_t ab = e / T;
-    int k, c;
-    if (kind & 1) { k = (int)(ab % K); c = (int)(ab / K); } else { c = (int)(ab % C); k = (int)(ab / C); }
+    int k, c, t, row, col;
+    if (kind & 16) {                               // stem: T is the packed tap count (16), the parameter is [K][C][7][7]
+        row = (int)((unsigned)e / (unsigned)wd); col = (int)((unsigned)e - (unsigned)row * (unsigned)wd);
+        k = row; c = t = 0;
+    } else {
+        sn_split((unsigned)e, kind, K, C, T, k, c, t);
+        // the SpectralNorm matrix is weight.view(shape[0], -1): rows are k ([K][C][T]) or, for ConvTranspose, c ([C][K][T])
+        if (kind & 1) { row = c; col = k * T + t; } else { row = k; col = c * T + t; }
+    }
     int64_t pidx = ((int64_t)k * T + t) * Cp + c;
-    const int row = (int)(e / wd), col = (int)(e % wd);
     if (kind & 16) {                               // [K][C][7][7] element -> its slot in the [K][16][64] packed gradient
         const int v = col % 7, u = (col / 7) % 7, ch = col / 49;
         pidx = (int64_t)row * 16 * 64 + stem_dst(ch, u, v);

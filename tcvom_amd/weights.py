@@ -285,7 +285,7 @@ class WeightBank(object):
             else:
                 calls[s.layer_id] = frames if s.group == 'frame' else max(frames - 2, 1)
         inner = [(s.layer_id, c, b) for s in self.specs if s.spectral
-                 for c in range(calls[s.layer_id]) for b in range((s.numel + 1023) // 1024)]
+                 for c in range(calls[s.layer_id]) for b in range((s.numel + 8191) // 8192)]      # SN_INNER_BLOCK of csrc/spectral.hip
         dev = self.device
         plan = {
             'ncalls': calls,
