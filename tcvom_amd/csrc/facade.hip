@@ -306,7 +306,10 @@ extern "C" int tcvom_att_bce(const float* logits, const float* cg, const float* 
     TCVOM_CHECK_ARG(logits && cg && adj && mask && acc, "att_bce: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (zero_acc && hipMemsetAsync(acc, 0, 2 * sizeof(float), st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "att_bce: memset");
-    hipLaunchKernelGGL(att_bce_kernel, dim3(sgrid((int64_t)B * window * window * h * w)), dim3(256), 0, st, logits, cg, adj, mask, dlogit, acc, B, h, w, window, thres, smooth, g_bstride);
+    // every block ends with two atomics on the same two floats: a few hundred blocks, not 4096 (same-address atomics serialise)
+    int grid = sgrid((int64_t)B * window * window * h * w);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(att_bce_kernel, dim3(grid), dim3(256), 0, st, logits, cg, adj, mask, dlogit, acc, B, h, w, window, thres, smooth, g_bstride);
     TCVOM_LAUNCH_CHECK("att_bce");
     return TCVOM_OK;
 }
