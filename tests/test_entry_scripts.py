@@ -54,6 +54,58 @@ def test_train_ddp_two_steps_and_checkpoint(tmp_path, arch, nkeys):
     assert not missing and not unexpected
 
 
+def test_disk_clip_sharding_matches_a_distributed_sampler():
+    """train_ddp.DiskClips (the DataLoader + DistributedSampler pair of train_ddp.py:232-240): per epoch every rank takes its
+    stride of ONE shared permutation, ranks are disjoint, drop_last per rank, and the permutation changes with the epoch."""
+    sys.path.insert(0, REPO)
+    import train_ddp
+
+    class FakeDataset(object):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def raw_view(self):
+            ds = self
+
+            class View(torch.utils.data.Dataset):
+                def __len__(self):
+                    return ds.n
+
+                def __getitem__(self, i):
+                    return {'idx': i}
+            return View()
+
+        def transform(self, raw):
+            i = int(raw['idx'])
+            return torch.full((2, 1), float(i)), torch.zeros(2, 1), torch.zeros(2, 1), torch.tensor(i)
+
+    ds, world, batch = FakeDataset(23), 3, 2
+    loaders = [train_ddp.DiskClips(ds, batch, r, world, 0, seed=5) for r in range(world)]
+    assert all(len(ld) == (23 // world) // batch == 3 for ld in loaders)
+    epochs = []
+    for _ in range(2):
+        seen = []
+        for ld in loaders:
+            idxs = []
+            for fg, bg, a, idx in ld:
+                assert tuple(fg.shape) == (batch, 2, 1) and tuple(idx.shape) == (batch,)
+                assert torch.equal(fg[:, 0, 0], idx.float())
+                idxs += idx.tolist()
+            assert len(idxs) == 6
+            seen.append(idxs)
+        flat = [i for s in seen for i in s]
+        assert len(set(flat)) == len(flat) == 18 and all(0 <= i < 23 for i in flat)
+        epochs.append(seen)
+    assert epochs[0] != epochs[1]
+    g = torch.Generator()
+    g.manual_seed(5)
+    perm = torch.randperm(23, generator=g).tolist()
+    assert epochs[0][1] == perm[1::3][:6]
+
+
 @pytest.mark.gpu
 def test_train_ddp_from_a_clip_directory(tmp_path):
     """DATASET.PATH set: train_ddp.py reads a VideoMatting108-style tree (1080p RGBA foregrounds, backgrounds, frame_corr.json,
