@@ -130,7 +130,8 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group(backend=backend, init_method='env://')
+        # device_id: RCCL binds this rank's communicator to its GPU up front (no guessing in barrier())
+        dist.init_process_group(backend=backend, init_method='env://', **({'device_id': device} if backend == 'nccl' else {}))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
 
     from tcvom_amd.ddp import GradientAverager, broadcast_module_state, convert_sync_batchnorm

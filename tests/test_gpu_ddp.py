@@ -1,0 +1,55 @@
+"""The N > 1 gradient exchange on the REAL backend: a one-rank RCCL group on the GPU box runs exactly the collectives the
+driver's 2 / 4 / 8-GPU bench runs issue (in-place ReduceOp.AVG all-reduce over spans of the flat gradient arena + bucketed
+stragglers, SyncBatchNorm statistic all-reduce, parameter broadcast).  The two-rank semantics are covered on CPU over gloo
+(tests/test_ddp_gloo.py); this one checks that RCCL accepts the calls."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.gpu
+def test_rccl_gradient_average_and_sync_bn_on_one_rank():
+    from tcvom_amd.ddp import GradientAverager, broadcast_module_state, reduce_tensor
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(_free_port())
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend='nccl', init_method='env://', world_size=1, rank=0, device_id=dev)      # as bench.py / train_ddp.py
+    try:
+        # gradients laid out like WeightBank.backward's arena: views of one flat buffer (-> in-place span all-reduce) + strays
+        arena = torch.arange(3 * 70000, dtype=torch.float32, device=dev) / 1000.0
+        params = [torch.nn.Parameter(torch.zeros(70000, device=dev)) for _ in range(3)] + \
+                 [torch.nn.Parameter(torch.zeros(17, device=dev)), torch.nn.Parameter(torch.zeros(5, 3, device=dev))]
+        for i in range(3):
+            params[i].grad = arena[i * 70000:(i + 1) * 70000]
+        params[3].grad = torch.full((17,), 2.5, device=dev)
+        params[4].grad = None                                      # a parameter without a gradient this step
+        want = [None if p.grad is None else p.grad.clone() for p in params]
+        av = GradientAverager(params)
+        av.average(force=True)
+        torch.cuda.synchronize()
+        numel_spans, nspans, numel_rest, nbuckets = av.last_plan
+        assert nspans >= 1 and numel_spans == 3 * 70000 and nbuckets >= 1
+        for p, w in zip(params, want):
+            assert torch.equal(p.grad, torch.zeros_like(p) if w is None else w)       # AVG over one rank = identity
+        assert params[0].grad.data_ptr() == arena.data_ptr()                           # reduced in place
+        assert float(reduce_tensor(torch.tensor(3.0, device=dev))) == 3.0
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4)).to(dev)
+        broadcast_module_state(m)
+        t = torch.ones(8, device=dev)
+        dist.all_reduce(t)
+        dist.barrier()
+        assert float(t.sum()) == 8.0
+    finally:
+        dist.destroy_process_group()

@@ -161,7 +161,7 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group(backend='nccl', init_method='env://')
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
     if cfg.SYSTEM.RANDOM_SEED > 0:
         torch.manual_seed(cfg.SYSTEM.RANDOM_SEED + rank)
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format='%(asctime)-15s %(message)s')
