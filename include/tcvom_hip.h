@@ -80,6 +80,10 @@ const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase);
 const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d);
 /* number of statistics groups ONE phase of a launch of `nphase` phases like `d` writes */
 int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase);
+/* profiling aid: with the environment variable TCVOM_CONV_TRACE set, the weight-stationary conv kernel records up to 64
+ * shader-clock stamps of one workgroup of its latest launch (entry, halo issued, weights loaded, end, then per tile:
+ * barrier passed, next halo issued, MFMAs done, halo landed); this copies the first n to the HOST array (synchronises). */
+int tcvom_conv_trace_read(uint64_t* host, int32_t n);
 
 /* Weight gradient of the same phase (reduction over pixels, both operands pixel-major):
  *   dw[k][wslot[t]][c] += sum_{n,i,j} dy[n, out pixel(i,j), k] * in[n, i*in_step+dh[t], j*in_step+dw[t], c]

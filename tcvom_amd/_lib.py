@@ -148,6 +148,7 @@ _PROTOS = {
     'tcvom_loss_finalize': [vp, vp, f32, i32, f32, i32, i32, vp],
     'tcvom_adam_mt': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp],
     'tcvom_abi_version': [],
+    'tcvom_conv_trace_read': [vp, i32],
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles'}

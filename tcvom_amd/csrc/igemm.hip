@@ -391,6 +391,10 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                          float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
+// wsconv.hip: weight-stationary 3x3 conv for the 64 / 128-channel stride-1 layers
+int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase);
+int wsconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                      float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
 // gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                           const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream);
@@ -402,6 +406,8 @@ int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float*
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
     const int hg = halo_conv_stats_groups(d, nphase);
     if (hg > 0) return hg;
+    const int wg = wsconv_stats_groups(d, nphase);
+    if (wg > 0) return wg;
     const NtCfg c = nt_config(d, nphase);
     const long long P = (long long)d->N * d->PH * d->PW;
     return cdiv(P, c.tn) * c.waves_n;
@@ -410,6 +416,7 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
 // name of the kernel instantiation tcvom_conv_igemm(_phases) launches for this shape (profiling / bench labels)
 extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase) {
     if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
+    if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? "wsconv<64>" : "wsconv<128>";
     if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
     if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";
@@ -456,6 +463,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
+    {
+        const int r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     if (nphase == 1 && !stats_partial) {

@@ -77,11 +77,27 @@ def main():
             L.call('tcvom_wgrad_igemm_batched', C.cast(dys3, C.c_void_p), C.cast(xs3, C.c_void_p), C.cast(dws3, C.c_void_p), 3,
                    _phase_array(geo.wgrad), len(geo.wgrad), cout, st)
 
+        # the same layer as the product runs it: the 3 frames of a window in ONE frame-batched launch (time / 3 shown)
+        x3 = torch.randn(3, H, W, spec.cpad, device=DEV).to(torch.bfloat16)
+        y3 = torch.empty(3, geo.OH, geo.OW, cout, device=DEV, dtype=torch.bfloat16)
+        dy3 = torch.randn_like(y3)
+        dx3 = torch.empty(3, H, W, max(cin, 8), device=DEV, dtype=torch.bfloat16)
+
+        def fwd3():
+            _launch_conv(geo.fwd, x3, bank.fwd_ptr(spec, 0), y3, None, None, 0, st, 3, 0)
+
+        def dgrad3():
+            _launch_conv(geo.dgrad, dy3, bank.bwd_ptr(spec, 0), dx3, None, None, 0, st, 3, 0)
+
         tf = timeit(fwd)
         td = timeit(dgrad) if spec.needs_dgrad else float('nan')
         tw = timeit(wgrad) / 3
-        print('%-22s %5.0f %4.0f %5.0f %4.0f %5.0f %4.0f' % (name, flop / tf / 1e9, tf * 1e3, flop / td / 1e9, td * 1e3,
-                                                          flop / tw / 1e9, tw * 1e3))
+        tf3 = timeit(fwd3) / 3
+        td3 = timeit(dgrad3) / 3 if spec.needs_dgrad else float('nan')
+        print('%-22s %5.0f %4.0f %5.0f %4.0f %5.0f %4.0f | 3-frame launch: fwd %5.0f %4.0f dgrad %5.0f %4.0f  [%s]' % (
+            name, flop / tf / 1e9, tf * 1e3, flop / td / 1e9, td * 1e3, flop / tw / 1e9, tw * 1e3,
+            flop / tf3 / 1e9, tf3 * 1e3, flop / td3 / 1e9, td3 * 1e3,
+            L._FNS['tcvom_conv_igemm_variant'](C.byref(_phase_array(geo.fwd)[0]), len(geo.fwd)).decode()))
     # GCA GEMMs at 1080p: N = 8160
     N, D, DV = 8160, 576, 2048
     ld = (N + 63) // 64 * 64
