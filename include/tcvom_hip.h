@@ -62,6 +62,10 @@ typedef struct {
     int32_t batch;               /* >1: `batch` independent problems with the strides below: the dense GEMMs of GCA,
                                     and the S frames of a window through one conv layer (N samples per frame, own
                                     SpectralNorm'd weight copy per frame) */
+    int32_t w_layout;            /* 0: w is [K][wt][C].  1: "fragment-major" (stride-1 3x3 layers with C == K in {64, 128}
+                                    only, served by the weight-stationary kernel): element (k, slot, c) at
+                                    ((((k/32)*wt + slot)*(C/16) + c/16)*64 + ((c/8)&1)*32 + k%32)*8 + c%8, i.e. every
+                                    32 x 16 MFMA A fragment is one contiguous 1 KiB block in lane order */
     int64_t in_bstride, w_bstride, out_bstride, vec_bstride;
     int64_t stats_bstride;       /* statistics groups between batch elements (frame f writes groups
                                     stats_group_offset + f*stats_bstride + ...) */

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtcvom_hip.so')
+LIB_PATH = os.environ.get('TCVOM_LIB') or os.path.join(_HERE, 'lib', 'libtcvom_hip.so')      # TCVOM_LIB: a study build of the same library (kernel ablations)
 if os.environ.get('TCVOM_HIP_LIB'):          # kernel A/B work: load an alternative build of the same ABI
     LIB_PATH = os.environ['TCVOM_HIP_LIB']
 
@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ('ntaps', C.c_int32),
         ('tap_dh', C.c_int32 * MAX_TAPS), ('tap_dw', C.c_int32 * MAX_TAPS), ('tap_w', C.c_int32 * MAX_TAPS),
         ('wt', C.c_int32), ('ldo', C.c_int32), ('act', C.c_int32), ('out_fp32', C.c_int32),
-        ('stats_group_offset', C.c_int32), ('batch', C.c_int32),
+        ('stats_group_offset', C.c_int32), ('batch', C.c_int32), ('w_layout', C.c_int32),
         ('in_bstride', C.c_int64), ('w_bstride', C.c_int64), ('out_bstride', C.c_int64), ('vec_bstride', C.c_int64),
         ('stats_bstride', C.c_int64),
     ]

@@ -30,6 +30,7 @@ def _desc(N, H, W, C, OH, OW, K, PH, PW, in_step, out_step, off_h, off_w, taps, 
     d.out_fp32 = 0
     d.stats_group_offset = 0
     d.batch = 1
+    d.w_layout = 0
     return d
 
 
@@ -94,6 +95,9 @@ class ConvGeometry(object):
         self.OH, self.OW, self.K, self.C = OH, OW, K, C
         self.out_pixels = N * OH * OW
         self.in_pixels = N * H * W
+        if getattr(spec, 'frag', False):        # packed fragment-major by the WeightBank (weights.py: ConvSpec.frag)
+            for d in self.fwd + self.dgrad:
+                d.w_layout = 1
 
 
 def dense_desc(rows_b, rows_a, kred, ld_out, batch=1, in_bstride=0, w_bstride=0, out_bstride=0, vec_bstride=0,

@@ -469,6 +469,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         const int r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
+    TCVOM_CHECK_ARG(d0->w_layout == 0, "conv_igemm: fragment-major weights (w_layout = 1) are only served by the weight-stationary kernel");
     if (nphase == 1 && !stats_partial) {
         const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;

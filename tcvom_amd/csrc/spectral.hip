@@ -20,7 +20,7 @@ enum {
     SN_W = 0, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD,
     SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS
 };
-// kind bits: 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual),
+// kind bits: 32 = fragment-major packs (sn_frag_index), 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual),
 //            8 = weight-standardised (FBA base, models/FBA/layers_WS.py:13-23): packed value = (w - mean_row) * inv_row
 //                with the row statistics at SN_WS_STATS (float4 per output channel: mean, 1/(std + 1e-5), std, unused),
 //           16 = 7x7 stride-2 stem in space-to-depth form: the packed weight is the 4x4 stride-1 kernel over the 2x2
@@ -129,6 +129,12 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(const int64_t* __restr
 // pack [K][T][Cpad] (128-byte runs) and, for which = 3, the data-gradient pack [C][T][K] (64-byte runs) from there.  The
 // one-thread-per-output form below reads the fp32 weights with a stride of T floats (forward pack) or C T floats (backward
 // pack): 793 MiB fetched per call for 102 MB of weights (profiles/r01_k_hbm_traffic_pmc.md), 208 us per call.
+// kind bit 32: "fragment-major" packs for the weight-stationary conv (csrc/wsconv.hip, tcvom_conv_desc.w_layout = 1): element
+// (row, slot, col) -- (k, t, c) of the forward pack, (c, t, k) of the data-gradient pack -- goes to the position below, so
+// that every 32 x 16 MFMA A fragment is one contiguous 1 KiB block in lane order
+__device__ __forceinline__ int64_t sn_frag_index(int row, int slot, int col, int T, int ncols) {
+    return ((((int64_t)(row >> 5) * T + slot) * (ncols >> 4) + (col >> 4)) * 64 + ((col >> 3) & 1) * 32 + (row & 31)) * 8 + (col & 7);
+}
 constexpr int SNP_TK = 32, SNP_TC = 64, SNP_RB = 16;
 constexpr int SNP_SLOTS = 18;                    // T <= 9 with the hi + residual pair, or T <= 16 alone
 constexpr int SNP_ROW = SNP_TC * SNP_SLOTS + 2;  // LDS row of one k: [c][slot], +2 elements: consecutive k rows are 32 T + 1 banks apart
@@ -183,14 +189,20 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
         const int cl = e % SNP_TC, row = e / SNP_TC;
         int kl, slot;
         if (hp) { kl = row / (2 * T); slot = row - kl * (2 * T); } else { kl = row / T; slot = row - kl * T; }
-        if (cl < ncp) fdst[((int64_t)(k0 + kl) * TT + slot) * Cp + c0 + cl] = cl < nc ? lds[kl * rp + cl * TT + slot] : (bf16raw)0;
+        if (cl < ncp) {
+            const int64_t di = (kind & 32) ? sn_frag_index(k0 + kl, slot, c0 + cl, TT, Cp) : ((int64_t)(k0 + kl) * TT + slot) * Cp + c0 + cl;
+            fdst[di] = cl < nc ? lds[kl * rp + cl * TT + slot] : (bf16raw)0;
+        }
     }
     // ---- data-gradient pack: [C][T][K], output channels k0 .. k0 + 31 of every (c, t) row
     if (which == 3 && nc > 0) {
         bf16raw* __restrict__ bdst = bwd_arena + call * bwd_call_stride + L[SN_BWD_OFF];
         for (int e = tid; e < nc * T * SNP_TK; e += 256) {
             const int kl = e % SNP_TK, row = e / SNP_TK, t = row % T, cl = row / T;
-            if (kl < nk) bdst[((int64_t)(c0 + cl) * T + t) * K + k0 + kl] = lds[kl * rp + cl * TT + t];
+            if (kl < nk) {
+                const int64_t di = (kind & 32) ? sn_frag_index(c0 + cl, t, k0 + kl, T, K) : ((int64_t)(c0 + cl) * T + t) * K + k0 + kl;
+                bdst[di] = lds[kl * rp + cl * TT + t];
+            }
         }
     }
 }
@@ -249,8 +261,10 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
         }
         if (part) val -= bf2f(f2bf(val));
     }
-    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + idx] = f2bf(val);
-    else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + idx] = f2bf(val);
+    int64_t di = idx;
+    if (kind & 32) di = which == 0 ? sn_frag_index(k, t, c, T, Cp) : sn_frag_index(c, t, k, T, K);
+    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + di] = f2bf(val);
+    else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + di] = f2bf(val);
 }
 
 // ------------------------------------------------------------------------------ backward

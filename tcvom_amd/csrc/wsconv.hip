@@ -45,13 +45,14 @@ struct WsArgs {
     float* stats;
     const bf16raw* zero_page;
     int H, W, K, ldo, wt, act;
-    unsigned out_bytes, stats_bytes;
+    unsigned in_bytes, out_bytes, stats_bytes;
     int tiles_x, tiles_y, tiles_per_frame, tiles_per_wg, wgs_per_frame;
     int spf;                      // samples per frame (every frame has its own weight copy, w_bstride elements apart)
     long long w_bstride;
     int stats_group_offset;
     long long stats_bstride;
     int wslot[9];                 // weight slot of the canonical tap t = (dh + 1) * 3 + (dw + 1)
+    int w_frag;                   // weights are fragment-major (tcvom_conv_desc.w_layout = 1)
     unsigned long long* trace;    // NULL, or 64 cycle stamps of workgroup 8 / wave 0 (tcvom_conv_trace_read, env TCVOM_CONV_TRACE)
 };
 #define WS_STAMP(i) if (tracing) a.trace[i] = __builtin_readcyclecounter()
@@ -68,10 +69,11 @@ struct WsCfg {
     static constexpr int DUMPB = 1024;                          // where the DMA instructions past NDMA of the last round land
     static constexpr int NCC = C / 16;                          // 16-channel chunks per tap
     static constexpr int NS = 9 * NCC;                          // k-steps (A fragments held by a wave)
-    static constexpr int PF = 1;                                // B fragments are requested PF k-steps ahead of their MFMAs
+    static constexpr int PF = 2;                                // B fragments are requested PF k-steps ahead of their MFMAs
     // schedule of the work that rides on the MFMA stream of a tile: the halo DMA of the NEXT tile (DPS instructions per
     // k-step from step 0) and the epilogue of the PREVIOUS tile (NQ pieces spread over steps E0 .. E1 - 1)
-    static constexpr int DPS = (DMA_IT * 6 + NS - 1) / NS;      // DMA done within the first sixth of the steps
+    static constexpr int DPS = 1;                               // one DMA instruction per k-step from step 0
+    static_assert(DMA_IT <= NS / 2, "the halo DMA must be issued in the first half of the k-steps");
     static constexpr int E0 = (DMA_IT + DPS - 1) / DPS;
     static constexpr int E1 = NS - NS / 8;                      // the last stores get an eighth of the tile to complete
     // C = 128 (no registers to spare): the channel sums are reduced and stored per TILE by an extra piece per channel group
@@ -92,7 +94,14 @@ struct WsCfg {
         return s >= E0 && s < E1 ? n : 0;
     }
     static constexpr int er(int s) { return OLDS && s >= 0 ? frag_pieces_at(s + 1) : 0; }   // reads issued in step s
-    static_assert(PF == 1, "the lgkmcnt bookkeeping below assumes a prefetch distance of one k-step");
+    static constexpr int nb(int s) { return s >= 0 && s < NS ? NI : 0; }                    // B reads OF k-step s
+    // LDS operations issued after the B reads of k-step s (issued in step s - PF) and before the wait at the TOP of step s:
+    // the epilogue fetches of steps s - PF .. s - 1 and the B reads of k-steps s + 1 .. s + PF - 1
+    static constexpr int later_than_b(int s) {
+        int n = 0;
+        for (int u = s - PF; u < s; ++u) n += er(u) + (u > s - PF ? nb(u + PF) : 0);
+        return n;
+    }
     static_assert(MF * PS == 4 && FH * FW == 32 && (C == 64 || C == 128), "unsupported configuration");
     static_assert(HW % 2 == 0, "halo rows must hold an even number of pixels (bank parity of 128-byte pixels)");
 };
@@ -110,6 +119,8 @@ struct WsCtx {
     // next tile (halo DMA)
     bool has_next;
     int nn, ny0, nx0, nslot;      // sample, halo origin (tile origin - 1), buffer
+    int dhy, dhx, dsl;            // halo pixel / 16-byte slot of this lane's unit in the DMA instruction being issued
+    __amdgpu_buffer_rsrc_t irsrc; // the input as a raw buffer: out-of-image units use an out-of-range offset and load zeros
     // previous tile (epilogue)
     bool has_prev;
     int ptile, py0, pgx;          // tile index inside the frame, first row of this wave's fragments, this lane's column
@@ -119,21 +130,40 @@ struct WsCtx {
     __device__ WsCtx(const WsArgs& a_) : a(a_) {}
 };
 
-// ---- halo DMA instruction IT of this wave: unit u = (IT*4 + wave)*64 + lane -> halo pixel p = u / CU, LDS slot u % CU
+// ---- halo DMA instruction IT of this wave: unit u = (IT*4 + wave)*64 + lane -> halo pixel p = u / CU, LDS slot u % CU.
+// Branch-free (a branch would end the scheduling region of the MFMAs it rides behind): buffer_load ... lds with an
+// out-of-range offset for the units outside the image (they load zeros).  From one instruction to the next the pixel moves
+// on by 256 / CU, the slot stays: (hy, hx) are carried instead of divided out again.
 template <class G, int IT>
 __device__ __forceinline__ void ws_dma_piece(WsCtx<G>& c) {
-    int ln = c.lane;
-    asm volatile("" : "+v"(ln));          // opaque: no hoisting of the address arithmetic out of the tile loop (registers)
+    constexpr int STEP = 256 / G::CU;
+    static_assert(256 % G::CU == 0 && STEP <= G::HW, "one row wrap per DMA instruction at most");
+    if constexpr (IT == 0) {
+        int ln = c.lane;
+        asm volatile("" : "+v"(ln));      // opaque: no hoisting of this arithmetic out of the tile loop (registers)
+        const int u = c.wave * 64 + ln, p = u / G::CU;
+        c.dsl = u % G::CU;
+        c.dhy = p / G::HW;
+        c.dhx = p - c.dhy * G::HW;
+    } else {
+        c.dhx += STEP;
+        const bool wrap = c.dhx >= G::HW;
+        c.dhx = wrap ? c.dhx - G::HW : c.dhx;
+        c.dhy += wrap ? 1 : 0;
+    }
     const int j = IT * 4 + c.wave;
-    const int u = j * 64 + ln, p = u / G::CU, sl = u % G::CU;
-    const int hy = p / G::HW, hx = p - hy * G::HW;
-    const int f = G::CU >= 16 ? (hx & 15) : ((hx >> 1) & 7);
-    const int y = c.ny0 + hy, x = c.nx0 + hx;
-    const bool ok = p < G::HPIX && (unsigned)y < (unsigned)c.a.H && (unsigned)x < (unsigned)c.a.W;
-    const bf16raw* src = ok ? c.a.in + (((c.nn * c.a.H + y) * c.a.W + x) * G::C + ((sl ^ f) << 3)) : c.a.zero_page;
-    // (the last round has 4 * DMA_IT - NDMA instructions too many: they fetch the zero page into a dump area, branch-free)
+    const int f = G::CU >= 16 ? (c.dhx & 15) : ((c.dhx >> 1) & 7);
+    const int y = c.ny0 + c.dhy, x = c.nx0 + c.dhx;
+    bool ok = (unsigned)y < (unsigned)c.a.H && (unsigned)x < (unsigned)c.a.W;
+    if constexpr (((IT * 4 + 3) * 64 + 63) / G::CU >= G::HPIX) ok = ok && c.dhy < G::HH;     // padding units of the last rounds
+    const unsigned off = (unsigned)((((c.nn * c.a.H + y) * c.a.W + x) * G::C + ((c.dsl ^ f) << 3)) * 2);
+    // (the last round has 4 * DMA_IT - NDMA instructions too many: they land in a dump area)
     char* dst = (IT * 4 + 3 < G::NDMA || j < G::NDMA) ? c.lds + c.nslot * G::SLOTB + j * 1024 : c.lds + 2 * G::SLOTB;
-    __builtin_amdgcn_global_load_lds((ws_gptr_t)src, (ws_lptr_t)dst, 16, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)        // (the host pass of hipcc has no such builtin)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.irsrc, (ws_lptr_t)dst, 16, (int)(ok ? off : 0xffffffffu), 0, 0, 0);
+#else
+    (void)dst; (void)ok; (void)off;
+#endif
 }
 template <class G, int IT, int N>
 __device__ __forceinline__ void ws_dma_pieces(WsCtx<G>& c) {
@@ -143,7 +173,9 @@ __device__ __forceinline__ void ws_dma_pieces(WsCtx<G>& c) {
     }
 }
 
-#define WS_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, false))
+// (mov_dpp: no `old` operand -- lanes a row mask disables hold garbage afterwards, here rows 0 and 2 of the last level, unused;
+// with an `old` of 0 the compiler kept v_mov 0 + v_mov_dpp + v_add instead of one v_add_f32_dpp)
+#define WS_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
 
 // ---- epilogue piece Q of the previous tile.  Q = g * (NI + 1) + j: j < NI: activation, store and channel sums of the 4
 // channels mf*32 + 8g + 4*half ..+3 of fragment j; j == NI: the BatchNorm partial statistics of group g.  VALU / VMEM only (no
@@ -151,13 +183,37 @@ __device__ __forceinline__ void ws_dma_pieces(WsCtx<G>& c) {
 // 8 sums over the 32 pixel lanes of each half wave with DPP adds (VALU rate, no LDS): within quads, half rows, rows, then
 // row 0 -> row 1 / row 2 -> row 3 (row_bcast15): lanes 16..31 and 48..63 hold the totals
 __device__ __forceinline__ void ws_reduce8(float (&t)[8]) {
+    // level by level: 8 independent adds per level (a dependent DPP chain pays 2 wait states per link)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        t[r] += WS_DPP(t[r], 0xB1, 0xF);       // quad_perm [1,0,3,2]
-        t[r] += WS_DPP(t[r], 0x4E, 0xF);       // quad_perm [2,3,0,1]
-        t[r] += WS_DPP(t[r], 0x141, 0xF);      // row_half_mirror
-        t[r] += WS_DPP(t[r], 0x140, 0xF);      // row_mirror
-        t[r] += WS_DPP(t[r], 0x142, 0xA);      // row_bcast15 into rows 1 and 3
+    for (int r = 0; r < 8; ++r) t[r] += WS_DPP(t[r], 0xB1, 0xF);       // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += WS_DPP(t[r], 0x4E, 0xF);       // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += WS_DPP(t[r], 0x141, 0xF);      // row_half_mirror
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += WS_DPP(t[r], 0x140, 0xF);      // row_mirror
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += WS_DPP(t[r], 0x142, 0xA);      // row_bcast15 into rows 1 and 3
+}
+// end of a tile's k-steps (the only exposed VALU work per tile): activation, and zeros for the pixels of a border tile that
+// lie outside the image (their sums must not count); both only where needed (wave-uniform branches)
+template <class G>
+__device__ __forceinline__ void ws_finish_tile(WsCtx<G>& c, f32x16_t (&acc)[G::NI], int y0, int x0) {
+    const WsArgs& a = c.a;
+    if (a.act != 0) {
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = fmaxf(acc[i][r], acc[i][r] * c.slope);
+    }
+    if (y0 + G::TH > a.H || x0 + G::TW > a.W) {
+        const bool xin = x0 + c.fx < a.W;
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) {
+            const bool in = xin && y0 + (c.ps * G::NI + i) * G::FH + c.fy < a.H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = in ? acc[i][r] : 0.f;
+        }
     }
 }
 template <class G, int Q>
@@ -166,20 +222,17 @@ __device__ __forceinline__ void ws_epi_piece(WsCtx<G>& c, const f32x4_t vals) {
     constexpr int g = Q / G::NQG, j = Q % G::NQG, sg = G::SPT ? 0 : g;
     const WsArgs& a = c.a;
     if constexpr (j < G::NI) {
+        // (activation and the zeroing of out-of-image pixels happened at the hand-off: ws_finish_tile)
         const int gy = c.py0 + j * G::FH + c.fy;
         const bool pv = gy < a.H && c.pgx < a.W;
-        float vv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float xv = fmaxf(vals[r], vals[r] * c.slope);
-            vv[r] = xv;
-            const float xm = pv ? xv : 0.f;
-            c.s1[sg][r] += xm;
-            c.s2[sg][r] = fmaf(xm, xm, c.s2[sg][r]);
+            c.s1[sg][r] += vals[r];
+            c.s2[sg][r] = fmaf(vals[r], vals[r], c.s2[sg][r]);
         }
         const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * 2) + 16u * g : 0xffffffffu;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3])}, c.orsrc, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2bf(vals[0], vals[1]), pack2bf(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
     } else {
         float t[8];
 #pragma unroll
@@ -273,40 +326,64 @@ __device__ __forceinline__ void ws_prefetch(u32x4_t (&bq)[G::PF + 1][G::NI], con
 }
 // k-steps S .. NS-1: reads of step S + PF, this step's share of the next halo's DMA and of the previous tile's epilogue,
 // counted wait for the reads of step S, NI MFMAs; the order is pinned
+template <class G, int S, int I0, int I1>
+__device__ __forceinline__ void ws_read_some(u32x4_t (&bq)[G::PF + 1][G::NI], unsigned ad) {
+    if constexpr (I0 < I1 && I0 < G::NI) {
+        constexpr int t = S / G::NCC;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[S % (G::PF + 1)][I0]) : "v"(ad), "n"(((I0 * G::FH + t / 3) * G::HW + t % 3) * G::PIXB));
+        ws_read_some<G, S, I0 + 1, I1>(bq, ad);
+    }
+}
+// One k-step.  An in-order wave stalls in front of every MFMA but the first of a back-to-back group until the matrix pipe is
+// free, so everything else has to sit BETWEEN the MFMAs: the B reads of k-step S + PF go behind MFMAs 0 and 1, this step's
+// DMA instruction or epilogue piece shares a scheduling region with the remaining MFMAs (group barriers ask for an MFMA /
+// VALU alternation).  lgkmcnt is counted by hand (the reads are inline asm).
 template <class G, int S>
 __device__ __forceinline__ void ws_step(WsCtx<G>& c, const bf16x8_t (&wr)[G::NS], f32x16_t (&acc)[G::NI], u32x4_t (&bq)[G::PF + 1][G::NI],
                                         const unsigned (&bbase)[3], unsigned lb) {
-    constexpr int set = S % (G::PF + 1);
-    constexpr int nb_next = S + 1 < G::NS ? G::NI : 0;          // B reads issued in this step (for k-step S + 1)
-    if constexpr (S + 1 < G::NS) ws_read_step<G, S + 1>(bq, bbase, lb);
-    if constexpr (G::er(S) > 0) ws_epi_fetch<G, S + 1, 0>(c);   // unconditional: the counts below rely on it
-    // LDS operations issued after the B reads of k-step S: the epilogue fetch of step S - 1, then the two groups above
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::er(S - 1) + nb_next + G::er(S)) : "memory");
+    constexpr int set = S % (G::PF + 1), NI = G::NI, SN = S + G::PF;
+    constexpr bool rd = SN < G::NS;
+    static_assert(NI == 4, "issue pattern written for 4 fragments per wave");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::later_than_b(S)) : "memory");
 #pragma unroll
-    for (int i = 0; i < G::NI; ++i) asm volatile("" : "+v"(bq[set][i]));
-#pragma unroll
-    for (int i = 0; i < G::NI; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][i]), acc[i], 0, 0, 0);
-    // An in-order wave waits 32 cycles in front of every MFMA but the first, so work placed BEHIND the NI MFMAs overlaps only
-    // the last one (measured: k-steps + DMA issue + epilogue = the plain sum).  The DMA issue and epilogue pieces of this
-    // step therefore share a scheduling region with the MFMAs, and the group barriers below ask for an MFMA / <= 7 VALU
-    // alternation (the matrix pipe hides about that many single-issue instructions per MFMA).
-    constexpr bool has_dma = S * G::DPS < G::DMA_IT;
-    constexpr bool has_epi = S >= G::E0 && S < G::E1;
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bq[set][i]));
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][0]), acc[0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned ad = 0;
+    if constexpr (rd) {
+        constexpr int t = SN / G::NCC, cc = SN % G::NCC;
+        unsigned b = bbase[t % 3];
+        asm volatile("" : "+v"(b));       // opaque: the 3 * NCC address variants are recomputed (2 VALU) instead of held in registers
+        ad = (b ^ (unsigned)(cc << 5)) + lb;
+        ws_read_some<G, SN, 0, 2>(bq, ad);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][1]), acc[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (rd) ws_read_some<G, SN, 2, 4>(bq, ad);
+    if constexpr (G::er(S) > 0) ws_epi_fetch<G, S + 1, 0>(c);   // unconditional: the counts rely on it
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WS_ABL
+#define WS_ABL 0            // kernel study builds only: 1 = no DMA pieces, 2 = no epilogue pieces, 3 = neither (wrong results)
+#endif
+    constexpr bool has_dma = S * G::DPS < G::DMA_IT && !(WS_ABL & 1);
+    constexpr bool has_epi = S >= G::E0 && S < G::E1 && !(WS_ABL & 2);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][2]), acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][3]), acc[3], 0, 0, 0);
     if constexpr (has_dma) ws_dma_pieces<G, S * G::DPS, G::DPS>(c);      // without a next tile: zeros into the idle buffer
     if constexpr (has_epi) {
         if constexpr (G::er(S - 1) > 0) {                       // the float4 requested in step S - 1
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(nb_next + G::er(S)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::nb(SN) + G::er(S)) : "memory");
             asm volatile("" : "+v"(c.ereg));
         }
         ws_epi_pieces<G, S, 0>(c);                              // without a previous tile: every store is out of range
     }
     if constexpr (has_dma || has_epi) {
-#pragma unroll
-        for (int i = 0; i < G::NI; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x6, 7, 0);        // up to 7 VALU / SALU
-        }
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        // MFMA 2
+        __builtin_amdgcn_sched_group_barrier(0x6, 8, 0);        // up to 8 VALU / SALU
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        // MFMA 3
+        __builtin_amdgcn_sched_group_barrier(0x6, 8, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S + 1 < G::NS) ws_step<G, S + 1>(c, wr, acc, bq, bbase, lb);
@@ -358,6 +435,8 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
     }
     c.slope = a.act == 1 ? 0.f : (a.act == 3 ? 0.01f : 1.f);
     c.orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+    c.irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16raw*>(a.in), 0, a.in_bytes, 0x00020000);
+    c.dhy = c.dhx = c.dsl = 0;
     c.srsrc = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, a.stats ? a.stats_bytes : 0, 0x00020000);
     c.pgx = 0x7fffffff;
     c.py0 = 0; c.ptile = 0; c.pbase = 0;
@@ -402,7 +481,9 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
 #pragma unroll
             for (int cc = 0; cc < NCC; ++cc) {
                 bf16x8_t v = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
-                if (m < K && ws >= 0)
+                if (a.w_frag) {               // one contiguous 1 KiB block per fragment
+                    if (ws >= 0) v = *reinterpret_cast<const bf16x8_t*>(wsrc + ((((int64_t)c.mf * a.wt + ws) * NCC + cc) * 64 + c.lane) * 8);
+                } else if (m < K && ws >= 0)
                     v = *reinterpret_cast<const bf16x8_t*>(wsrc + ((int64_t)m * a.wt + ws) * C + cc * 16 + c.half * 8);
                 wr[t * NCC + cc] = v;
             }
@@ -455,6 +536,7 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
         ws_prefetch<G, 0>(bq, bbase, lb);
         ws_step<G, 0>(c, wr, acc, bq, bbase, lb);
         WS_STAMP(5 + (tile - t_begin) * 4);
+        ws_finish_tile<G>(c, acc, ((tile % txy) / a.tiles_x) * TH, ((tile % txy) % a.tiles_x) * TW);
         if (tile + 1 == t_end) {                    // the last tile's epilogue has no MFMAs to hide behind
             WS_SET_PREV(tile)
             ws_epi_all<G, 0>(c, acc);
@@ -533,8 +615,10 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     p.C = d->C;
     p.th = 8;
     p.tw = d->C == 64 ? 32 : 16;
-    // tiny images (the 64 x 64 golden windows) would leave most of a tile masked: the implicit GEMM serves them
-    if (d->H < p.th / 2 || d->W < p.tw / 2) return p;
+    // tiny images (the 64 x 64 golden windows) would leave most of a tile masked: the implicit GEMM serves them -- unless
+    // the weights are packed for this kernel
+    if (d->w_layout == 0 && (d->H < p.th / 2 || d->W < p.tw / 2)) return p;
+    if (d->w_layout != 0 && (d->w_layout != 1 || d->wt != 9)) return p;
     p.ok = true;
     return p;
 }
@@ -584,7 +668,9 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     a.stats_group_offset = d->stats_group_offset;
     a.stats_bstride = nb > 1 ? d->stats_bstride : 0;
     a.out_bytes = (unsigned)((long long)d->N * nb * d->H * d->W * d->ldo * 2);
+    a.in_bytes = (unsigned)((long long)d->N * nb * d->H * d->W * d->C * 2);
     for (int t = 0; t < 9; ++t) a.wslot[t] = p.wslot[t];
+    a.w_frag = d->w_layout == 1;
     a.trace = ws_trace_buffer();
     ws_grid(d, p, &a.tiles_per_frame, &a.tiles_per_wg, &a.wgs_per_frame);
     const long long gpf = p.C == 128 ? a.tiles_per_frame : (long long)a.wgs_per_frame * ws_ps(p);

@@ -18,6 +18,7 @@ import torch
 from . import _lib as L
 
 TILED_PACK = os.environ.get('TCVOM_SN_PACK_TILED', '1') != '0'      # 0: one thread per packed element (A/B, tests)
+WS_FRAG = os.environ.get('TCVOM_NO_WSCONV') is None                 # the same switch that disables the kernel in the library
 SN_WORDS = 24
 (SN_W, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD, SN_FWD_OFF, SN_BWD_OFF,
  SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS) = range(18)
@@ -62,6 +63,10 @@ class ConvSpec(object):
         if stem:
             assert shp[2:] == (7, 7) and stride == 2 and pad == 3 and self.C <= 16 and not transposed and not needs_dgrad
             self.T, self.cpad = 16, 64          # packed geometry; C / R / S keep the parameter's shape
+        # fragment-major packed weights for the weight-stationary conv kernel (csrc/wsconv.hip): stride-1 3x3 layers with
+        # C == K in {64, 128}; its persistent workgroups then load their 288 KB of A fragments as contiguous 1 KiB blocks
+        self.frag = (WS_FRAG and not transposed and not hp and not stem and shp[2:] == (3, 3) and stride == 1 and pad == 1 and
+                     dilation == 1 and self.C == self.K and self.C in (64, 128) and self.cpad == self.C)
         self.numel = weight.numel()
         self.h = shp[0]
         self.wd = self.numel // shp[0]
@@ -200,7 +205,7 @@ class WeightBank(object):
             tab[i, SN_V] = s.v.data_ptr() if s.spectral else 0
             tab[i, SN_H], tab[i, SN_WD] = s.h, s.wd
             tab[i, SN_KIND] = ((1 if s.transposed else 0) | (0 if s.spectral else 2) | (4 if s.hp else 0) |
-                               (8 if s.ws else 0) | (16 if s.stem else 0))
+                               (8 if s.ws else 0) | (16 if s.stem else 0) | (32 if s.frag else 0))
             assert not (s.ws and (s.spectral or s.transposed or s.hp)) and (s.ws or not s.stem)
             tab[i, SN_K], tab[i, SN_C], tab[i, SN_T], tab[i, SN_CPAD] = s.K, s.C, s.T, s.cpad
             tab[i, SN_FWD_OFF] = fwd_off

@@ -41,6 +41,6 @@ def test_abi_version_and_error_channel():
 
 def test_struct_layout_matches_header():
     import tcvom_amd._lib as L
-    # 13 + 1 + 3*MAX_TAPS + 6 int32 fields, then 5 int64 (8-byte aligned)
-    n_i32 = 14 + 3 * L.MAX_TAPS + 6
+    # 13 + 1 + 3*MAX_TAPS + 7 int32 fields, then 5 int64 (8-byte aligned)
+    n_i32 = 14 + 3 * L.MAX_TAPS + 7
     assert ctypes.sizeof(L.ConvDesc) == ((n_i32 * 4 + 7) // 8) * 8 + 5 * 8
