@@ -149,6 +149,9 @@ _PROTOS = {
     'tcvom_adam_mt': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp],
     'tcvom_abi_version': [],
     'tcvom_conv_trace_read': [vp, i32],
+    'tcvom_gca_dp_softmax_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
+    'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
+    'tcvom_gca_fold_f32': [vp, vp, i32, i32, i32, i32, vp],
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles'}

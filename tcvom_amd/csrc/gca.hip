@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void gca_value_patches_bwd_kernel(const float4
 }
 
 // ------------------------------------------------------------------ fold: y = fold(O)/4 and its adjoint
+template <bool F32>                              // F32: O is fp32 (the backward's <dO, O> row sums want the unrounded P V)
 __global__ __launch_bounds__(256) void gca_fold_kernel(const uint4* __restrict__ O, uint4* __restrict__ Y, int B, int h8, int w8, int C8) {
     const int h = h8 / 2, w = w8 / 2, N = h * w;
     const int64_t total = (int64_t)B * h8 * w8 * C8;
@@ -260,7 +261,11 @@ __global__ __launch_bounds__(256) void gca_fold_kernel(const uint4* __restrict__
             for (int e = 0; e < 2; ++e) {
                 const int ix = (x + 1) / 2 - e, kx = x + 1 - 2 * ix;
                 if (ix < 0 || ix >= w || kx < 0 || kx > 3) continue;
-                unpack8(O[(((int64_t)b * N + iy * w + ix) * 16 + ky * 4 + kx) * C8 + c], f);
+                const int64_t oi = (((int64_t)b * N + iy * w + ix) * 16 + ky * 4 + kx) * C8 + c;
+                if (F32) {
+                    const float4 lo = reinterpret_cast<const float4*>(O)[2 * oi], hi = reinterpret_cast<const float4*>(O)[2 * oi + 1];
+                    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+                } else unpack8(O[oi], f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += f[k];
             }
@@ -380,6 +385,35 @@ extern "C" int tcvom_row_softmax_bwd(const void* P, const float* dP, const float
     TCVOM_LAUNCH_CHECK("row_softmax_bwd");
     return TCVOM_OK;
 }
+// delta[r] = <a[r], b[r]> over `cols` bf16 columns (one wave per row): the row sums sum_j P dP of the softmax backward
+// as <dO_i, O_i>, which needs no N x N operand
+template <bool BF32>                             // BF32: b is fp32
+__global__ __launch_bounds__(256) void rowdot_bf16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, float* __restrict__ out,
+                                                          int64_t rows, int cols8) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int c = lane; c < cols8; c += 64) {
+        float x[8], y[8];
+        unpack8(a[r * cols8 + c], x);
+        if (BF32) {
+            const float4 lo = reinterpret_cast<const float4*>(b)[2 * (r * cols8 + c)], hi = reinterpret_cast<const float4*>(b)[2 * (r * cols8 + c) + 1];
+            y[0] = lo.x; y[1] = lo.y; y[2] = lo.z; y[3] = lo.w; y[4] = hi.x; y[5] = hi.y; y[6] = hi.z; y[7] = hi.w;
+        } else unpack8(b[r * cols8 + c], y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += x[k] * y[k];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[r] = acc;
+}
+extern "C" int tcvom_rowdot_bf16(const void* a, const void* b, int32_t b_fp32, float* out, int64_t rows, int32_t cols, void* stream) {
+    TCVOM_CHECK_ARG(a && b && out && rows > 0 && cols > 0 && cols % 8 == 0, "rowdot_bf16: bad args");
+    if (b_fp32) hipLaunchKernelGGL(rowdot_bf16_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, out, rows, cols / 8);
+    else hipLaunchKernelGGL(rowdot_bf16_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b, out, rows, cols / 8);
+    TCVOM_LAUNCH_CHECK("rowdot_bf16");
+    return TCVOM_OK;
+}
 extern "C" int tcvom_gca_value_patches(const void* alpha, void* V, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
     TCVOM_CHECK_ARG(alpha && V && C % 8 == 0, "gca_value_patches: bad args");
     hipLaunchKernelGGL(gca_value_patches_kernel, dim3(sgrid((int64_t)B * h8 * w8 / 4 * 16 * C / 8)), dim3(256), 0,
@@ -396,9 +430,16 @@ extern "C" int tcvom_gca_value_patches_bwd(const float* dV, void* dalpha, int32_
 }
 extern "C" int tcvom_gca_fold(const void* O, void* Y, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
     TCVOM_CHECK_ARG(O && Y && C % 8 == 0, "gca_fold: bad args");
-    hipLaunchKernelGGL(gca_fold_kernel, dim3(sgrid((int64_t)B * h8 * w8 * C / 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gca_fold_kernel<false>, dim3(sgrid((int64_t)B * h8 * w8 * C / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)O, (uint4*)Y, B, h8, w8, C / 8);
     TCVOM_LAUNCH_CHECK("gca_fold");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_fold_f32(const float* O, void* Y, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(O && Y && C % 8 == 0, "gca_fold_f32: bad args");
+    hipLaunchKernelGGL(gca_fold_kernel<true>, dim3(sgrid((int64_t)B * h8 * w8 * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)O, (uint4*)Y, B, h8, w8, C / 8);
+    TCVOM_LAUNCH_CHECK("gca_fold_f32");
     return TCVOM_OK;
 }
 extern "C" int tcvom_gca_unfold(const void* dY, void* dO, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream) {

@@ -31,6 +31,10 @@ struct Gemm256Args {
     const bf16raw* zero_page;
     int M, N, K, ldo, act, out_fp32, batch;
     long long a_bstride, b_bstride, out_bstride, vec_bstride;
+    // fused softmax backward (GuidedCxtAtten, tcvom_gca_dp_softmax_bwd): out = bf16( P * (acc - delta[n]) * mscale[m] ), zeros
+    // in the padding columns M <= m < ldo.  P has the layout of `out`, delta is [batch][N].
+    const bf16raw* P;
+    const float* delta;
 };
 
 #ifdef G256_TRACE
@@ -185,6 +189,32 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         pglob[b] = p;
         out_off[b] = (int64_t)(pvalid[b] ? p : 0) * g.ldo + bz * g.out_bstride;
     }
+    if (g.P) {
+        float dl[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) dl[b] = pvalid[b] ? g.delta[(int64_t)bz * g.N + pglob[b]] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mrow = m0 + wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5);
+                float sc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (mrow < g.M) { const float4 c4 = *reinterpret_cast<const float4*>(mscale + mrow); sc[0] = c4.x; sc[1] = c4.y; sc[2] = c4.z; sc[3] = c4.w; }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (!pvalid[b] || mrow >= g.ldo) continue;
+                    uint2 o = make_uint2(0u, 0u);
+                    if (mrow < g.M) {
+                        const uint2 pp = *reinterpret_cast<const uint2*>(g.P + out_off[b] + mrow);
+                        o.x = pack2bf(bflo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], bfhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
+                        o.y = pack2bf(bflo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], bfhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
+                    }
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(g.out) + out_off[b] + mrow) = o;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -256,9 +286,42 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.b_bstride = nb > 1 ? d->in_bstride : 0;
     g.out_bstride = nb > 1 ? d->out_bstride : 0;
     g.vec_bstride = nb > 1 ? d->vec_bstride : 0;
+    g.P = nullptr;
+    g.delta = nullptr;
     const dim3 grid((unsigned)((P + 255) / 256), (unsigned)((d->K + 255) / 256), (unsigned)nb);
     hipLaunchKernelGGL(gemm_nt256_kernel, grid, dim3(512), 0, (hipStream_t)stream, g);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: %s", hipGetErrorString(e));
     return 1;
+}
+
+// ---- GuidedCxtAtten backward, fused: T[b][i][j] = P[b][i][j] * (sum_v dO[b][i][v] V[b][j][v] - delta[b][i]) * c[b][j] (bf16,
+// zero in the padding columns N <= j < ld), delta[b][i] = sum_j P dP = <dO[b][i], O[b][i]>.  Replaces the fp32 dP GEMM
+// (800 MB written and read back per 3-frame launch at 1080p) + tcvom_row_softmax_bwd of models/GCA/ops.py:190's backward.
+extern const bf16raw* tcvom_zero_page(void);
+extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const void* P, const float* delta, const float* cvec, void* T,
+                                        int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(dO && V && P && delta && cvec && T, "gca_dp_softmax_bwd: null pointer");
+    TCVOM_CHECK_ARG(N > 0 && N % 4 == 0 && DV % 64 == 0 && ld >= N && ld % 4 == 0 && batch >= 1, "gca_dp_softmax_bwd: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
+    TCVOM_CHECK_ARG(((uintptr_t)cvec % 16) == 0 && ((uintptr_t)P % 8) == 0 && ((uintptr_t)T % 8) == 0, "gca_dp_softmax_bwd: alignment");
+    Gemm256Args g;
+    g.A = (const bf16raw*)V;          // rows m = keys j
+    g.B = (const bf16raw*)dO;         // columns n = queries i
+    g.out = T;
+    g.bias = nullptr;
+    g.mscale = cvec;
+    g.mdiag = nullptr;
+    g.zero_page = tcvom_zero_page();
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_dp_softmax_bwd: could not allocate the zero page");
+    g.M = N; g.N = N; g.K = DV; g.ldo = (int)ld; g.act = 0; g.out_fp32 = 0; g.batch = batch;
+    g.a_bstride = (long long)N * DV;
+    g.b_bstride = (long long)N * DV;
+    g.out_bstride = (long long)N * ld;
+    g.vec_bstride = N;
+    g.P = (const bf16raw*)P;
+    g.delta = delta;
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL(gemm_nt256_kernel, grid, dim3(512), 0, (hipStream_t)stream, g);
+    TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
+    return TCVOM_OK;
 }

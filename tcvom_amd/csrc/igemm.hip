@@ -371,6 +371,7 @@ static const bf16raw* zero_page_for_current_device() {
     }
     return pages[dev];
 }
+const bf16raw* tcvom_zero_page(void) { return zero_page_for_current_device(); }
 static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     const long long P = (long long)d->N * d->PH * d->PW;
     const int nb = nphase * (d->batch > 1 ? d->batch : 1);

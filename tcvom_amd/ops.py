@@ -722,19 +722,21 @@ class _GcaAttention(torch.autograd.Function):
         Vt = torch.empty((B, DV, ld), dtype=BF16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(V), L.ptr(Vt), N, DV, DV, ld, B, N * DV, DV * ld, st)
         # O[i][v] = sum_j P[i][j] V[j][v]             (rows m = v, columns n = queries i, reduce j)
-        O = torch.empty((B, N, DV), dtype=BF16, device=dev)
-        d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV)
+        # (fp32: the backward forms sum_j P dP as <dO_i, O_i>; with a peaked softmax dP[i][i] - <dO_i, O_i> cancels to ~0 and
+        # a bf16-rounded O would leave its rounding error as the gradient)
+        O = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
+        d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
         L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
         y = torch.empty((B, h8, w8, Ca), dtype=BF16, device=dev)
-        L.call('tcvom_gca_fold', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
-        ctx.save_for_backward(G, P, V, cvec, nrm)
+        L.call('tcvom_gca_fold_f32', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
+        ctx.save_for_backward(G, P, V, cvec, nrm, O)
         ctx.dims = (B, h8, w8, CG, Ca, N, ld)
         ctx.mark_non_differentiable(scales)
         return y, scales
 
     @staticmethod
     def backward(ctx, dy, _dscales):
-        G, P, V, cvec, nrm = ctx.saved_tensors
+        G, P, V, cvec, nrm, O = ctx.saved_tensors
         B, h8, w8, CG, Ca, N, ld = ctx.dims
         D, DV = 9 * CG, 16 * Ca
         dev = G.device
@@ -742,14 +744,12 @@ class _GcaAttention(torch.autograd.Function):
         dy = _c(dy)
         dO = torch.empty((B, N, DV), dtype=BF16, device=dev)
         L.call('tcvom_gca_unfold', L.ptr(dy), L.ptr(dO), B, h8, w8, Ca, st)
-        # dP[i][j] = sum_v dO[i][v] V[j][v]           (rows m = keys j, columns n = queries i)
-        dP = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
-        d = dense_desc(N, N, DV, ld, batch=B, in_bstride=N * DV, w_bstride=N * DV, out_bstride=N * ld, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(dO), L.ptr(V), L.ptr(dP), None, None, None, None, C.byref(d), st)
-        # T = softmax_bwd(P, dP) * c_j
+        # T = softmax_bwd(P, dP) * c_j with dP[i][j] = sum_v dO[i][v] V[j][v]: ONE GEMM whose epilogue applies the softmax
+        # backward (the row sums sum_j P dP are <dO_i, O_i>): no fp32 N x N dP matrix, no separate softmax-backward pass
+        delta = torch.empty((B, N), dtype=torch.float32, device=dev)
+        L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
         T = torch.empty((B, N, ld), dtype=BF16, device=dev)
-        L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), B * N, N, ld, ld, N, st)
-        del dP
+        L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), N, DV, ld, B, st)
         # dV[j][v] = sum_i P[i][j] dO[i][v]: as an NT GEMM on the transposed operands (Pt = P^T, dOt = dO^T) it runs on the
         # 256x256 tiles at ~1 PFLOP/s; the pixel-major TT form (atomics, transposing LDS reads) measured 437 us against
         # 270 + 80 us of transposes here

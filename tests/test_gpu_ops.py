@@ -478,6 +478,39 @@ def test_transpose_bf16(R, Cc, ldi, ldo, batch):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize('B,N,DV', [(2, 80, 256), (1, 1020, 2048), (3, 264, 512)])
+def test_gca_fused_softmax_backward_gemm(B, N, DV):
+    """tcvom_gca_dp_softmax_bwd (dP GEMM with the softmax backward in its epilogue, row sums from <dO, O>) against the
+    unfused formula in fp32 on the same bf16 operands; padding columns N..ld must come out zero."""
+    from tcvom_amd import _lib as L
+    ld = (N + 63) // 64 * 64
+    tag = 'fsb%d_%d' % (N, DV)
+    st = L.stream_ptr()
+    Pf = torch.softmax(hu('p.' + tag, (B, N, N)) * 8, dim=2)
+    P = torch.zeros(B, N, ld)
+    P[:, :, :N] = Pf
+    P = P.to(torch.bfloat16).to(DEV)
+    V = (hu('v.' + tag, (B, N, DV)) - 0.5).to(torch.bfloat16).to(DEV)
+    dO = (hu('do.' + tag, (B, N, DV)) - 0.5).to(torch.bfloat16).to(DEV)
+    cvec = (hu('c.' + tag, (B, N)) + 0.5).to(DEV)
+    Pq, Vq, dOq = P[:, :, :N].float(), V.float(), dO.float()
+    O = torch.bmm(Pq, Vq).contiguous()                            # what the forward saves (fp32)
+    delta = torch.empty(B, N, device=DEV)
+    L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
+    assert rel_err(delta.cpu(), (dOq * O).sum(2).cpu()) < 1e-5
+    Ob = O.to(torch.bfloat16)
+    L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(Ob), 0, L.ptr(delta), B * N, DV, st)
+    assert rel_err(delta.cpu(), (dOq * Ob.float()).sum(2).cpu()) < 1e-5
+    L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
+    T = torch.full((B, N, ld), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), N, DV, ld, B, st)
+    dP = torch.bmm(dOq, Vq.transpose(1, 2))
+    ref = Pq * (dP - (Pq * dP).sum(2, keepdim=True)) * cvec[:, None, :]
+    assert rel_err(T[:, :, :N].float().cpu(), ref.cpu()) < 1.5e-2
+    if ld > N:
+        assert float(T[:, :, N:].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('ncols', [8160, 2040, 3000, 250])
 def test_row_softmax_kernels(ncols):
     """GCA attention softmax forward / backward rows at the 1080p length (8160 keys: 4 register chunks) and shorter / ragged
@@ -695,6 +728,12 @@ def test_gca_module_vs_reference_golden(name):
     # on identical bf16 inputs in test_gca_attention_kernel_tight)
     for got, key, tol in ((al.grad, 'galpha', 5e-2), (f.grad, 'gf', 2e-1), (mod.W[0].weight.grad, 'gW0', 5e-2),
                           (mod.guidance_conv.weight.grad, 'ggw', 2e-1)):
+        if float(np.abs(g[key]).max()) < 1e-20:
+            # all-known case: the softmax saturates to exact one-hot rows in fp32, the reference's guidance gradient is
+            # exactly 0 (1e-33).  The fused backward forms sum_j P dP as <dO_i, O_i>, so dP[i][i] - delta_i cancels only
+            # to fp32 summation-order noise: bound it in absolute terms against the O(1) value gradient
+            assert float(got.abs().max()) <= 1e-4 * float(np.abs(g['galpha']).max()), key
+            continue
         ck.rel(key, got, g[key], tol)
     ck.rel('running_mean', mod.W[1].running_mean, g['run_mean'], 2e-2)
     ck.done()
