@@ -44,6 +44,9 @@ extern "C" int tcvom_trace256_read(unsigned long long* host) {
 }
 #endif
 
+// EPI: 0 = fp32 output, 1 = bf16 output, 2 = fused softmax backward (one instantiation each: a single kernel with all three
+// epilogues spilled registers in the main loop)
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     constexpr int TM = 256, TN = 256;
     constexpr int SLOT = (TM + TN) * 64;                 // bf16 elements per K-tile buffer
@@ -178,73 +181,100 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #undef G_ISSUE_B
 #undef G_BAR
 
-    // ------------------------------------------------------------------ epilogue (as igemm_nt: bias / scale / diagonal / ReLU)
-    int64_t out_off[2];
-    bool pvalid[2];
+    // ------------------------------------------------------------------ epilogue
+    // A lane holds 4 consecutive m of ONE row n, its 32 neighbours 32 different rows.
+    __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): nothing of the main loop is in flight
+    __builtin_amdgcn_s_barrier();
     int pglob[2];
+    bool pvalid[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int p = n0 + wn * 64 + b * 32 + (lane & 31);
-        pvalid[b] = p < g.N;
-        pglob[b] = p;
-        out_off[b] = (int64_t)(pvalid[b] ? p : 0) * g.ldo + bz * g.out_bstride;
+        pglob[b] = n0 + wn * 64 + b * 32 + (lane & 31);
+        pvalid[b] = pglob[b] < g.N;
     }
-    if (g.P) {
+    char* lb = reinterpret_cast<char*>(lds);
+    const int64_t obase = (int64_t)bz * g.out_bstride;
+    if constexpr (EPI == 2) {
+        // ---- fused softmax backward: T = P * (acc - delta[n]) * c[m] in bf16; tile = 256 rows x 512 bytes, IN PLACE over the
+        // P tile: 16-byte chunk c of row r at position c ^ (r & 15)
+        const bf16raw* Pb = g.P + obase;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = (it * 8 + wave) * 2 + (lane >> 5), cp = lane & 31, c = cp ^ (r & 15);
+            const bool ok = n0 + r < g.N && m0 + c * 8 < g.ldo;
+            const bf16raw* src = ok ? Pb + (int64_t)(n0 + r) * g.ldo + m0 + c * 8 : g.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lb + (it * 8 + wave) * 1024), 16, 0, 0);
+        }
         float dl[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) dl[b] = pvalid[b] ? g.delta[(int64_t)bz * g.N + pglob[b]] : 0.f;
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int mrow = m0 + wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5);
+                const int ml = wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5), mrow = m0 + ml;
                 float sc[4] = {0.f, 0.f, 0.f, 0.f};
                 if (mrow < g.M) { const float4 c4 = *reinterpret_cast<const float4*>(mscale + mrow); sc[0] = c4.x; sc[1] = c4.y; sc[2] = c4.z; sc[3] = c4.w; }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if (!pvalid[b] || mrow >= g.ldo) continue;
-                    uint2 o = make_uint2(0u, 0u);
-                    if (mrow < g.M) {
-                        const uint2 pp = *reinterpret_cast<const uint2*>(g.P + out_off[b] + mrow);
-                        o.x = pack2bf(bflo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], bfhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
-                        o.y = pack2bf(bflo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], bfhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
-                    }
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(g.out) + out_off[b] + mrow) = o;
+                    const int r = wn * 64 + b * 32 + (lane & 31);
+                    uint2* cell = reinterpret_cast<uint2*>(lb + r * 512 + (((ml >> 3) ^ (r & 15)) << 4) + (ml & 4) * 2);
+                    const uint2 pp = *cell;
+                    uint2 o;                           // (padding columns M <= m < ldo: sc = 0 -> zeros)
+                    o.x = pack2bf(bflo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], bfhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
+                    o.y = pack2bf(bflo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], bfhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
+                    *cell = o;
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        bf16raw* Tb = reinterpret_cast<bf16raw*>(g.out) + obase;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = (it * 8 + wave) * 2 + (lane >> 5), cp = lane & 31, c = cp ^ (r & 15);
+            const uint4 v = *reinterpret_cast<const uint4*>(lb + r * 512 + cp * 16);
+            if (n0 + r < g.N && m0 + c * 8 < g.ldo) *reinterpret_cast<uint4*>(Tb + (int64_t)(n0 + r) * g.ldo + m0 + c * 8) = v;
+        }
         return;
-    }
+    } else {
+    // ---- plain epilogue (bias / scale / diagonal / activation), stored straight from the registers.  (Staging the fp32 tile
+    // through LDS in two 128-row halves for whole-row stores was built and measured slower: S = G G^T 124 -> 157 us per frame.)
+    constexpr bool F32 = EPI == 0;
+    int64_t out_off[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) out_off[b] = (int64_t)(pvalid[b] ? pglob[b] : 0) * g.ldo + obase;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int mrow = m0 + wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5);
-            float bs[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (mrow + r < g.M) {
-                    if (bias) bs[r] = bias[mrow + r];
-                    if (mscale) sc[r] = mscale[mrow + r];
-                    if (mdiag) dg[r] = mdiag[mrow + r];
-                }
+            float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = bs;
+            if (mrow < g.M) {                         // M % 4 == 0: a lane's 4 rows are valid together
+                if (bias) bs = *reinterpret_cast<const float4*>(bias + mrow);
+                if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
+                if (mdiag) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
             }
+            const float bsv[4] = {bs.x, bs.y, bs.z, bs.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[a][b][q * 4 + r] * sc[r] + bs[r];
+                    float x = acc[a][b][q * 4 + r] * sc[r] + bsv[r];
                     if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
                     if (g.act == 1) x = fmaxf(x, 0.f); else if (g.act == 3) x = x > 0.f ? x : 0.01f * x;
                     v[r] = x;
                 }
                 if (pvalid[b] && mrow < g.M) {
-                    if (g.out_fp32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
                     else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(g.out) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                 }
             }
         }
+    }
     }
 }
 
@@ -289,7 +319,8 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.P = nullptr;
     g.delta = nullptr;
     const dim3 grid((unsigned)((P + 255) / 256), (unsigned)((d->K + 255) / 256), (unsigned)nb);
-    hipLaunchKernelGGL(gemm_nt256_kernel, grid, dim3(512), 0, (hipStream_t)stream, g);
+    if (g.out_fp32) hipLaunchKernelGGL(gemm_nt256_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gemm_nt256_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, g);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: %s", hipGetErrorString(e));
     return 1;
@@ -321,7 +352,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.P = (const bf16raw*)P;
     g.delta = delta;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
-    hipLaunchKernelGGL(gemm_nt256_kernel, grid, dim3(512), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gemm_nt256_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
     return TCVOM_OK;
 }

@@ -113,6 +113,18 @@ def main():
     t1 = timeit(lambda: L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, None, None, None, C.byref(d1), st))
     t2 = timeit(lambda: L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st))
     t3 = timeit(lambda: L.call('tcvom_wgrad_igemm', L.ptr(P), L.ptr(O), L.ptr(dV), C.byref(d3), ld, st))
+    # the softmax backward: unfused (fp32 dP GEMM + row pass) vs fused epilogue
+    V = torch.randn(N, DV, device=DEV).to(torch.bfloat16)
+    dO = torch.randn(N, DV, device=DEV).to(torch.bfloat16)
+    dP = torch.empty(N, ld, device=DEV)
+    cvec = torch.rand(N, device=DEV) + 0.5
+    delta = torch.randn(N, device=DEV)
+    T = torch.empty(N, ld, device=DEV, dtype=torch.bfloat16)
+    d4 = dense_desc(N, N, DV, ld, out_fp32=True)
+    t4 = timeit(lambda: L.call('tcvom_conv_igemm', L.ptr(dO), L.ptr(V), L.ptr(dP), None, None, None, None, C.byref(d4), st))
+    t5 = timeit(lambda: L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), N, N, ld, ld, N, st))
+    t6 = timeit(lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), N, DV, ld, 1, st))
+    print('GCA dP fp32 %5.0f us + softmax bwd %5.0f us | fused %5.0f us' % (t4 * 1e3, t5 * 1e3, t6 * 1e3))
     print('GCA S=GG^T  %5.0f TF %5.0f us | O=PV %5.0f TF %5.0f us | dV=P^T dO %5.0f TF %5.0f us' % (
         2.0 * N * N * D / t1 / 1e9, t1 * 1e3, 2.0 * N * N * DV / t2 / 1e9, t2 * 1e3, 2.0 * N * N * DV / t3 / 1e9, t3 * 1e3))
 
