@@ -41,10 +41,16 @@ def test_window_vs_reference_golden(name):
     mse_unk = float(np.mean((alphas[um] - ref[um]) ** 2)) if um.any() else 0.0
     print('%s: alpha MSE %.3e (unknown-only %.3e), losses %s vs %s' % (
         name, mse, mse_unk, [float(x) for x in out[:5]], g['losses'].tolist()))
-    # These small goldens have 8..80 elements per channel in the os32 BatchNorms: bf16 storage noise
-    # (2^-9 per layer) is amplified by the ill-conditioned statistics, so the bound here is 1e-3; the
-    # north-star bound (<= 1e-4 on unknown pixels) is asserted on realistically sized windows below.
-    assert mse <= 1e-3 and mse_unk <= 1e-3, 'alpha MSE vs reference'
+    # The 64-pixel-high goldens have 8..24 elements per channel in the os32 BatchNorms: bf16 storage noise (2^-9 per layer)
+    # is amplified by the ill-conditioned statistics -- an all-bf16-storage pipeline emulated in the fp32 oracle reaches only
+    # 3e-4 on the unknown pixels there (tests/test_bf16_noise_floor.py) -- so those two are bounded at 1e-3.  From 128 x 160
+    # upwards the north-star bound holds against the REFERENCE golden: whole-frame MSE <= 1e-4 (measured 4.3e-5; unknown-only
+    # 9.6e-5 against an emulated all-bf16 floor of 1.9e-4, asserted at 2e-4); test_window_north_star_parity asserts the
+    # unknown-only bound at 544 x 960 and at the benchmark size.
+    if H * W >= 128 * 160:
+        assert mse <= 1e-4 and mse_unk <= 2e-4, 'alpha MSE vs reference'
+    else:
+        assert mse <= 1e-3 and mse_unk <= 1e-3, 'alpha MSE vs reference'
     assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), g['losses'], 3e-2, 1e-3, 'losses')
     assert_close(out[8].sum().cpu(), g['comps_sum'], 1e-2, 1.0, 'comps')
     assert_close(out[6].sum().cpu(), g['tris_vis_sum'], 1e-5, 1e-2, 'tris_vis')
@@ -97,6 +103,93 @@ def test_window_large_vs_oracle():
     # (and a fortiori over the whole frame)
     assert mse <= 1e-4 and mse_unk <= 1e-4
     assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), torch.stack(list(ro[:5])), 3e-2, 1e-3, 'losses')
+
+
+def _oracle_state(requires_grad=False):
+    from oracle.state_spec import vmn_gca_state_spec
+    state = {k: formula_tensor(k, s, torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
+             for k, s in vmn_gca_state_spec().items()}
+    if requires_grad:
+        for k, v in state.items():
+            if v.is_floating_point() and not any(t in k for t in ('weight_u', 'weight_v', 'running_')):
+                v.requires_grad_(True)
+    return state
+
+
+@pytest.mark.parametrize('H,W', [(544, 960), (1088, 1920)])
+def test_window_north_star_parity(H, W):
+    """BASELINE.json north star at the benchmark geometry (config 3: one 3 x 1088 x 1920 window, train mode, dilate_kernel 12)
+    and at half of it: forward + losses of the HIP path against the fp32 CPU oracle on identical inputs and formula
+    weights.  Bound: alpha MSE over the unknown region (calc_metric.py:25) <= 1e-4; the dtSSD-style delta
+    (calc_metric.py:31-34 applied to neighbouring columns, the window has one predicted frame) is reported."""
+    import os
+    import time
+    import oracle
+    B, S, dil, win = 1, 3, 12, 7
+    m = _model(win, dil).train()
+    a, fg, bg = synthetic_window(B, S, H, W, seed=0)
+    with torch.no_grad():
+        out = m(a.to(DEV), fg.to(DEV), bg.to(DEV))
+    torch.cuda.synchronize()
+    al = out[7].float().cpu()
+    losses = [float(x) for x in out[:5]]
+    del out, m
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    with torch.no_grad():
+        ro, _ = oracle.window_forward(_oracle_state(), a, fg, bg, window=win, dilate_kernel=dil, training=True)
+    rl = ro[7]
+    um = ro[6].isclose(torch.tensor(128.0 / 255.0))
+    d = al - rl
+    mse, mse_unk = float((d ** 2).mean()), float((d[um] ** 2).mean())
+    d_a, d_r = al[:, 1] - al[:, 1].roll(1, -1), rl[:, 1] - rl[:, 1].roll(1, -1)
+    dtssd_delta = float(torch.sqrt(((d_a - d_r)[um[:, 1]] ** 2).mean()))
+    print('%dx%d: alpha MSE %.3e (unknown-only %.3e, %d unknown pixels), dtSSD-style delta %.3e, max |d| %.3e; losses %s vs %s; oracle %.0f s'
+          % (H, W, mse, mse_unk, int(um.sum()), dtssd_delta, float(d.abs().max()), losses, [float(x) for x in ro[:5]], time.time() - t0))
+    assert mse <= 1e-4 and mse_unk <= 1e-4
+    assert_close(torch.tensor(losses), torch.stack(list(ro[:5])), 3e-2, 1e-3, 'losses')
+
+
+def test_gradient_fidelity_vs_oracle():
+    """Backward parity of the whole window beyond gradient NORMS: cosine similarity of every parameter gradient of the HIP path
+    (bf16 activations) against the fp32 CPU oracle at 256 x 320, norm-weighted per module group.  The backward map of this
+    60-layer train-mode-BatchNorm net with random weights amplifies last-bit noise (two identical HIP runs differ by the fp32
+    order of their atomic partial sums only and already reach just 0.76..1.0 against each other), so the
+    bounds are set from that measured floor: decoder groups >= 0.8 (measured 0.89..1.0), encoder groups >= 0.6 (0.67..0.95), the
+    concatenated gradient of the whole network >= 0.7 (0.79); op-level gradients are pinned tightly in test_gpu_ops.py."""
+    import os
+    import oracle
+    from tcvom_amd.facade import train_step_loss
+    H, W = 256, 320
+    m = _model(7, 12).train()
+    a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
+    train_step_loss(m(a.to(DEV), fg.to(DEV), bg.to(DEV))).backward()
+    torch.cuda.synchronize()
+    g = {k: p.grad.double().cpu() for k, p in m.NET.named_parameters() if p.grad is not None}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    state = _oracle_state(requires_grad=True)
+    out, _ = oracle.window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True)
+    oracle.train_step_loss(out).backward()
+    go = {k: v.grad.double() for k, v in state.items() if getattr(v, 'grad', None) is not None}
+    cos = lambda x, y: float((x * y).sum() / (x.norm() * y.norm() + 1e-300))
+    groups = {}
+    for k in g:
+        if k in go and float(go[k].norm()) > 0:
+            groups.setdefault('.'.join(k.split('.')[:2]), []).append(k)
+    rows = []
+    for top, ks in sorted(groups.items()):
+        w = [float(go[k].norm()) for k in ks]
+        c = [cos(g[k], go[k]) for k in ks]
+        rows.append((top, sum(ci * wi for ci, wi in zip(c, w)) / sum(w), min(c), len(ks)))
+    print('\n'.join('%-30s weighted cos %.3f  min %.3f  (%d tensors)' % r for r in rows))
+    dec = [r[1] for r in rows if r[0].startswith('decoder.')]
+    enc = [r[1] for r in rows if r[0].startswith('encoder.')]
+    assert min(dec) >= 0.8, 'decoder gradient direction'
+    assert min(enc) >= 0.6, 'encoder gradient direction'
+    tot_h = torch.cat([g[k].flatten() for ks in groups.values() for k in ks])
+    tot_o = torch.cat([go[k].flatten() for ks in groups.values() for k in ks])
+    assert cos(tot_h, tot_o) >= 0.7, 'whole-network gradient direction'       # measured 0.79
 
 
 def test_eval_mode_runs_and_is_deterministic():
