@@ -14,9 +14,12 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
 
-    def _table(self, gi, plist):
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
-        ent = self._tables.get(gi)
+    def _table(self, key, plist):
+        # the kernel writes through the cached pointers: exp_avg / exp_avg_sq are part of the signature, so that a
+        # load_state_dict() (which replaces them) rebuilds the table
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr())
+                    for p in plist)
+        ent = self._tables.get(key)
         if ent is not None and ent[0] == sig:
             return ent
         rows, work = [], []
@@ -27,8 +30,15 @@ class FusedAdam(torch.optim.Optimizer):
         dev = plist[0].device
         ent = (sig, torch.tensor(rows, dtype=torch.int64, device=dev),
                torch.tensor(work, dtype=torch.int32, device=dev).reshape(-1), len(work))
-        self._tables[gi] = ent
+        self._tables[key] = ent
         return ent
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+        for st in self.state.values():                      # torch stores `step` as a tensor in newer checkpoints
+            if torch.is_tensor(st.get('step')):
+                st['step'] = int(st['step'].item())
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -37,6 +47,7 @@ class FusedAdam(torch.optim.Optimizer):
             plist = [p for p in group['params'] if p.grad is not None]
             if not plist:
                 continue
+            by_step = {}
             for p in plist:
                 st = self.state[p]
                 if not st:
@@ -46,11 +57,13 @@ class FusedAdam(torch.optim.Optimizer):
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
                         and p.grad.dtype == torch.float32):
                     raise RuntimeError('FusedAdam: parameters and gradients must be contiguous fp32 CUDA tensors')
-            step = self.state[plist[0]]['step'] + 1
-            for p in plist:
-                self.state[p]['step'] = step
-            _, table, work, nblk = self._table(gi, plist)
+                # the bias correction uses each parameter's OWN step count (torch.optim.Adam): a parameter that receives its
+                # first gradient later than the others (find_unused_parameters) runs in its own launch
+                st['step'] = int(st['step']) + 1
+                by_step.setdefault(st['step'], []).append(p)
             b1, b2 = group['betas']
-            L.call('tcvom_adam_mt', L.ptr(table), L.ptr(work), nblk, float(group['lr']), float(b1), float(b2),
-                   float(group['eps']), float(group['weight_decay']), int(step), float(grad_scale), L.stream_ptr())
+            for step, ps in by_step.items():
+                _, table, work, nblk = self._table((gi, len(by_step) > 1 and step), ps)
+                L.call('tcvom_adam_mt', L.ptr(table), L.ptr(work), nblk, float(group['lr']), float(b1), float(b2),
+                       float(group['eps']), float(group['weight_decay']), int(step), float(grad_scale), L.stream_ptr())
         return loss

@@ -80,6 +80,11 @@ class VMN(nn.Module):
         self.batched_frames = True          # push the S frames through every layer together (one launch per layer)
         object.__setattr__(self, '_bank', bank)
         object.__setattr__(self, '_streams', [])
+        if freeze_backbone:
+            # VMN_model.py:77-103 + VMN_GCA.py:18-24: encoder and decoder front (the per-frame feature extraction) run in eval
+            # mode under no_grad inside a training window: BatchNorm uses (and keeps) its running statistics, SpectralNorm
+            # takes sigma from the stored u, v without iterating, no gradient reaches them
+            bank.frozen_groups = {'frame'}
 
     def train(self, mode=True):
         super().train(mode)
@@ -96,8 +101,19 @@ class VMN(nn.Module):
         token = bank_token(self._bank, S, training)
         sync_bn = training and any(getattr(bn, 'sync', False) for bn in self._bank.bns) and \
             torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        front_training = training and not self.freeze_backbone
         if self.batched_frames and not sync_bn:
-            return self._run_batched(frames_x8, unk_u8, token, training)
+            return self._run_batched(frames_x8, unk_u8, token, training, front_training)
+        if self.freeze_backbone:
+            with torch.no_grad():
+                fronts = [self._front(frames_x8[i], unk_u8[i], token, front_training) for i in range(S)]
+            mids, feats = [f[0] for f in fronts], [f[1] for f in fronts]
+            preds, attb, attf = [None] * S, [None] * S, [None] * S
+            for i in range(1, S - 1):
+                preds[i], attb[i], attf[i] = self.decoder.run_tail(feats[i], feats[i - 1], feats[i + 1], unk_u8[i],
+                                                                   mids[i], token, training)
+            self._bank.flush_bn_counters()
+            return preds, attb, attf
         mids, feats = [None] * S, [None] * S
         # The encoder + decoder-front of the S frames are independent (VMN_model.py:93-98 loops over them): each frame
         # runs on its own HIP stream so that the small-grid os16/os32 kernels of different frames overlap; autograd
@@ -127,7 +143,11 @@ class VMN(nn.Module):
         self._bank.flush_bn_counters()
         return preds, attb, attf
 
-    def _run_batched(self, frames_x8, unk_u8, token, training):
+    def _front(self, x8, unk, token, training):
+        emb, mid = self.encoder.run(x8, unk, token, training)
+        return mid, self.decoder.run_front(emb, mid, token, training)
+
+    def _run_batched(self, frames_x8, unk_u8, token, training, front_training=None):
         """The S frames as ONE frame-major batch [S*B, ...]: every encoder / decoder-front layer is a single launch for
         all frames (each frame keeps its own SpectralNorm call slot and BatchNorm statistics, ops._ConvBNAct), the
         decoder tail a single launch for the S-2 interior frames.  3x fewer, 3x larger launches than frame-by-frame."""
@@ -136,10 +156,14 @@ class VMN(nn.Module):
         bank = self._bank
         X = torch.cat(frames_x8, 0) if S > 1 else frames_x8[0]
         U = torch.cat(unk_u8, 0) if S > 1 else unk_u8[0]
+        front_training = training if front_training is None else front_training
         try:
             bank.frames_per_op = S
-            emb, mid = self.encoder.run(X, U, token, training)
-            feat = self.decoder.run_front(emb, mid, token, training)
+            if self.freeze_backbone:
+                with torch.no_grad():
+                    mid, feat = self._front(X, U, token, front_training)
+            else:
+                mid, feat = self._front(X, U, token, front_training)
             bank.frames_per_op = S - 2
             lo, hi = B, (S - 1) * B                               # the interior frames 1 .. S-2
             mid_c = {k: (tuple(t[lo:hi] for t in v) if isinstance(v, (tuple, list)) else v[lo:hi]) for k, v in mid.items()

@@ -81,6 +81,7 @@ class WeightBank(object):
         self.max_calls = 0
         self.bns, self.bn_ch, self._bn_sig, self._bn_cap = [], 0, None, 0
         self.bn_mask, self.window_id = [], 0
+        self.frozen_groups = set()          # spec groups run in eval mode inside a training window (VMN freeze_backbone: {'frame'})
         self.frames_per_op = 1              # >1 while VMN.run pushes the S frames of a window through the layers together
         self._deferred = []
 
@@ -280,13 +281,13 @@ class WeightBank(object):
         self._plans = {}
 
     def _plan(self, frames, training):
-        key = (frames, training)
+        key = (frames, training, frozenset(self.frozen_groups))
         if key in self._plans:
             return self._plans[key]
         calls = {}
         for s in self.specs:
-            if not s.spectral or not training:
-                calls[s.layer_id] = 1
+            if not s.spectral or not training or s.group in self.frozen_groups:
+                calls[s.layer_id] = 1           # eval mode (also a frozen backbone in a training window): no iteration, one copy
             else:
                 calls[s.layer_id] = frames if s.group == 'frame' else max(frames - 2, 1)
         inner = [(s.layer_id, c, b) for s in self.specs if s.spectral
@@ -326,12 +327,18 @@ class WeightBank(object):
             if training and call > 0:
                 # layers with fewer calls keep iterating harmlessly only if still needed; tail layers
                 # (S-2 calls) must NOT be advanced further than the reference does -> restrict tables
-                ids, n_sn, wtu, n_wtu, wv, n_wv = self._restricted(plan, call)
+                runs = [(self._restricted(plan, call), 1)]
+            elif training and self.frozen_groups:
+                # frozen backbone (VMN_model.py:77-103: encoder.eval() under no_grad): its SpectralNorm layers take sigma
+                # from the stored u, v without iterating, the others iterate
+                frozen = lambda s: s.group in self.frozen_groups
+                runs = [(self._subset(plan, 'trainable', lambda s: not frozen(s)), 1), (self._subset(plan, 'frozen', frozen), 0)]
             else:
-                ids, n_sn, wtu, n_wtu, wv, n_wv = self.sn_ids, self.n_sn, self.work_wtu, self.n_wtu, self.work_wv, self.n_wv
-            if n_sn > 0:
-                L.call('tcvom_sn_power_iteration', L.ptr(self.table), sc, L.ptr(wtu), n_wtu, L.ptr(wv), n_wv,
-                       L.ptr(ids), n_sn, call, 1 if training else 0, st)
+                runs = [((self.sn_ids, self.n_sn, self.work_wtu, self.n_wtu, self.work_wv, self.n_wv), 1 if training else 0)]
+            for (ids, n_sn, wtu, n_wtu, wv, n_wv), flag in runs:
+                if n_sn > 0:
+                    L.call('tcvom_sn_power_iteration', L.ptr(self.table), sc, L.ptr(wtu), n_wtu, L.ptr(wv), n_wv,
+                           L.ptr(ids), n_sn, call, flag, st)
             if call == 0:
                 wp, npk = self.work_pack_all, self.n_pack_all
             else:
@@ -342,6 +349,16 @@ class WeightBank(object):
         self.current_plan = plan
         self.call_counter = [0] * len(self.specs)
         return plan
+
+    def _subset(self, plan, key, pred):
+        """Power-iteration work tables of the SpectralNorm layers selected by `pred` (cached in the plan)."""
+        if key not in plan:
+            sel = [s for s in self.specs if s.spectral and pred(s)]
+            i32 = lambda rows: torch.tensor(rows, dtype=torch.int32).reshape(-1).to(self.device)
+            wtu = [(s.layer_id, r0) for s in sel for r0 in range(0, s.h, 16)]
+            wv = [(s.layer_id, r0) for s in sel for r0 in range(0, s.h, 4)]
+            plan[key] = (i32([s.layer_id for s in sel]), len(sel), i32(wtu), len(wtu), i32(wv), len(wv))
+        return plan[key]
 
     def _restricted(self, plan, call):
         key = ('restrict', call)

@@ -107,6 +107,33 @@ def test_disk_clip_sharding_matches_a_distributed_sampler():
 
 
 @pytest.mark.gpu
+def test_train_ddp_resume_continues_at_the_saved_epoch(tmp_path):
+    """TRAIN.LOAD_OPT = .../optimizer_<N>.pth.tar resumes at epoch N (train_ddp.py:300-304,316): the run does not start over at
+    epoch 0 -- it writes checkpoint_<N+1> only, continues the poly learning rate and keeps the Adam moments."""
+    sys.path.insert(0, REPO)
+    import train_ddp
+    from tcvom_amd.config import get_cfg_defaults
+
+    def cfg_for(total, extra=()):
+        cfg = get_cfg_defaults()
+        cfg.merge_from_file(os.path.join(REPO, 'cfgs', 'vmd_vmn_gca_synthetic.yaml'))
+        cfg.merge_from_list(['TRAIN.TRAIN_INPUT_SIZE', '(64, 64)', 'SYSTEM.OUTDIR', str(tmp_path), 'TRAIN.TOTAL_STEPS', str(total)] + list(extra))
+        return cfg
+    train_ddp.main('resume_a', cfg_for(3), steps_per_epoch=1, frames=3)
+    out_a = os.path.join(str(tmp_path), 'resume_a_agg7_synthetic')
+    assert all(os.path.exists(os.path.join(out_a, 'checkpoint_%d.pth.tar' % e)) for e in (1, 2, 3))
+    opt2 = os.path.join(out_a, 'optimizer_2.pth.tar')
+    lr2 = torch.load(opt2, map_location='cpu')['param_groups'][0]['lr']
+    train_ddp.main('resume_b', cfg_for(3, ['TRAIN.LOAD_CKPT', os.path.join(out_a, 'checkpoint_2.pth.tar'), 'TRAIN.LOAD_OPT', opt2]),
+                   steps_per_epoch=1, frames=3)
+    out_b = os.path.join(str(tmp_path), 'resume_b_agg7_synthetic')
+    assert sorted(f for f in os.listdir(out_b) if f.startswith('checkpoint_')) == ['checkpoint_3.pth.tar']
+    lr3a = torch.load(os.path.join(out_a, 'optimizer_3.pth.tar'), map_location='cpu')['param_groups'][0]['lr']
+    lr3b = torch.load(os.path.join(out_b, 'optimizer_3.pth.tar'), map_location='cpu')['param_groups'][0]['lr']
+    assert lr3b == lr3a and lr3b < lr2, 'the poly schedule continues from epoch 2'
+
+
+@pytest.mark.gpu
 def test_train_ddp_from_a_clip_directory(tmp_path):
     """DATASET.PATH set: train_ddp.py reads a VideoMatting108-style tree (1080p RGBA foregrounds, backgrounds, frame_corr.json,
     train_videos.txt) through dataset.VMD.VideoMattingDataset with PNG-decoding worker processes, and trains on it."""
@@ -165,6 +192,32 @@ def test_adam_step_matches_torch_adam():
             a.grad, b.grad = g.clone(), g.clone()
         o1.step()
         o2.step()
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    # a parameter that gets its first gradient later keeps its OWN step count (bias correction), as in torch.optim.Adam
+    p1.append(torch.nn.Parameter(torch.randn(33, device='cuda')))
+    p2.append(torch.nn.Parameter(p1[-1].detach().clone()))
+    o1.add_param_group({'params': [p1[-1]]})
+    o2.add_param_group({'params': [p2[-1]]})
+    o1.param_groups[0]['params'].append(o1.param_groups.pop()['params'][0])      # same group: two step counts in one group
+    for step in range(2):
+        for a, b in zip(p1, p2):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert o1.state[p1[0]]['step'] == 4 and o1.state[p1[-1]]['step'] == 2
+    # load_state_dict replaces exp_avg / exp_avg_sq: the cached pointer table must follow
+    sd = o1.state_dict()
+    o3 = FusedAdam(p1, lr=1e-3, weight_decay=1e-4)
+    o3.load_state_dict(sd)
+    for a, b in zip(p1, p2):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    o3.step()
+    o2.step()
     for a, b in zip(p1, p2):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
 

@@ -15,6 +15,7 @@ with `DATASET.PATH ''` they are the synthetic windows of tcvom_amd/synthetic.py 
 import argparse
 import logging
 import os
+import random
 import shutil
 import time
 
@@ -162,7 +163,8 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
     device = torch.device('cuda', local_rank)
     if world > 1:
         dist.init_process_group(backend='nccl', init_method='env://', device_id=device)
-    if cfg.SYSTEM.RANDOM_SEED > 0:
+    if cfg.SYSTEM.RANDOM_SEED > 0:                                 # train_ddp.py:192-197 (the crop search of the loader uses `random`)
+        random.seed(cfg.SYSTEM.RANDOM_SEED + rank)
         torch.manual_seed(cfg.SYSTEM.RANDOM_SEED + rank)
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format='%(asctime)-15s %(message)s')
     out_dir = os.path.join(cfg.SYSTEM.OUTDIR, cfg_name + cfg.SYSTEM.EXP_SUFFIX)
@@ -183,8 +185,12 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
     logging.info('=> Total Parameters: %d', sum(p.numel() for p in params))
     assert cfg.TRAIN.OPTIMIZER == 'adam', 'only Adam (the optimizer of every reference config) is on the HIP path'
     optimizer = FusedAdam(params, lr=cfg.TRAIN.BASE_LR, weight_decay=cfg.TRAIN.WEIGHT_DECAY)
+    start_step = 0
     if cfg.TRAIN.LOAD_OPT:
+        # resume (train_ddp.py:300-304): the epoch to continue from is parsed from 'optimizer_<N>.pth.tar', so that the poly
+        # learning rate, the epoch shuffle, the checkpoint numbering and the validation delay pick up where the run stopped
         optimizer.load_state_dict(torch.load(cfg.TRAIN.LOAD_OPT, map_location='cpu'))
+        start_step = int(os.path.basename(cfg.TRAIN.LOAD_OPT).split('_')[-1][:-8])
     averager = GradientAverager(params)
     adjust_lr = STR_DICT[cfg.TRAIN.LR_STRATEGY]
     test_dataset, best_loss = None, 1e+8
@@ -202,7 +208,9 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
     else:
         loader = SyntheticClips(cfg.TRAIN.BATCH_SIZE_PER_GPU, frames, tuple(cfg.TRAIN.TRAIN_INPUT_SIZE), steps_per_epoch,
                                 seed=max(cfg.SYSTEM.RANDOM_SEED, 0) + rank)
-    for epoch in range(cfg.TRAIN.TOTAL_STEPS):
+    if hasattr(loader, 'epoch'):
+        loader.epoch = start_step                                  # DistributedSampler.set_epoch(epoch) (train_ddp.py:317-318)
+    for epoch in range(start_step, cfg.TRAIN.TOTAL_STEPS):
         train(epoch, loader, cfg.TRAIN.BASE_LR, cfg.TRAIN.TOTAL_STEPS, optimizer, averager, model, adjust_lr,
               cfg.TRAIN.PRINT_FREQ, rank, device)
         if world > 1:
