@@ -48,15 +48,20 @@ class TestFolder(object):
             return t
         return F.pad(t.unsqueeze(0), (0, NW - W, 0, NH - H), mode='reflect').squeeze(0)
 
-    def __getitem__(self, idx):
+    def _frame(self, rgb, tri):
         from PIL import Image
-        imgs, tris = [], []
-        for rgb, tri in self.samples[idx]:
-            im = np.asarray(Image.open(rgb).convert('RGB'))[..., ::-1].copy()        # BGR, as cv2.imread
-            tr = np.asarray(Image.open(tri).convert('L'))[..., None]
-            imgs.append(self.possible_pad(torch.from_numpy(im).permute(2, 0, 1)))
-            tris.append(self.possible_pad(torch.from_numpy(tr.copy()).permute(2, 0, 1)))
-        return torch.stack(imgs).float(), torch.stack(tris).float(), im.shape[:2]
+        im = np.asarray(Image.open(rgb).convert('RGB'))[..., ::-1].copy()            # BGR, as cv2.imread
+        tr = np.asarray(Image.open(tri).convert('L'))[..., None]
+        return (self.possible_pad(torch.from_numpy(im).permute(2, 0, 1)), self.possible_pad(torch.from_numpy(tr.copy()).permute(2, 0, 1)),
+                im.shape[:2])
+
+    def centre(self, idx):
+        """Only the centre frame of sample idx (the whole-clip path needs every frame once, not three times)."""
+        return self._frame(*self.samples[idx][self.SAMPLE_LENGTH // 2])
+
+    def __getitem__(self, idx):
+        frames = [self._frame(rgb, tri) for rgb, tri in self.samples[idx]]
+        return torch.stack([f[0] for f in frames]).float(), torch.stack([f[1] for f in frames]).float(), frames[-1][2]
 
 
 def pred(dataset, indices, device, args):
@@ -92,9 +97,9 @@ def pred(dataset, indices, device, args):
             whole = (i == 0 or os.path.dirname(dataset.samples[i - 1][c][0]) != vid) and \
                     (j == len(dataset) or os.path.dirname(dataset.samples[j][c][0]) != vid)
             if whole and j - i >= 2:
-                frames = [dataset[k] for k in range(i, j)]
+                frames = [dataset.centre(k) for k in range(i, j)]     # one decode per frame
                 H, W = frames[0][2]
-                alphas = model.forward_video(torch.stack([f[0][c] for f in frames]), torch.stack([f[1][c] for f in frames]))
+                alphas = model.forward_video(torch.stack([f[0] for f in frames]), torch.stack([f[1] for f in frames]))
                 for k in range(i, j):
                     save(k, alphas[k - i, 0, :H, :W].cpu().numpy())
             else:                                       # a clip split across workers: per-sample windows

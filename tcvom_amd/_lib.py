@@ -152,9 +152,12 @@ _PROTOS = {
     'tcvom_gca_dp_softmax_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
     'tcvom_gca_fold_f32': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_wgrad_ws_multi': [vp, vp, vp, i32, DP, i32, vp],
+    'tcvom_wgrad_ws_max_problems': [],
 }
 # entry points that return a count, not a status
-_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles'}
+_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles',
+          'tcvom_wgrad_ws_max_problems'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}
@@ -195,7 +198,10 @@ PROFILE = None   # bench.py sets this to a list to bracket every igemm launch wi
 
 def _profiled(name, args):
     import torch
-    if name == 'tcvom_wgrad_igemm_batched':
+    if name == 'tcvom_wgrad_ws_multi':
+        d, n, nb = args[4][0], 1, args[3]
+        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': 9, 'tap_w': [0] * 9, 'batch': nb, 'phases': 1}
+    elif name == 'tcvom_wgrad_igemm_batched':
         arr, n, nb = args[4], args[5], args[3]
         d = arr[0]
         taps = sum(sum(1 for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0) for i in range(n))
@@ -225,7 +231,7 @@ def _profiled(name, args):
 def call(name, *args):
     """Invoke a status-returning entry point; raise TcvomError on failure."""
     if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
-                                        'tcvom_wgrad_igemm_batched'):
+                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi'):
         rc = _profiled(name, args)
     else:
         rc = _FNS[name](*args)

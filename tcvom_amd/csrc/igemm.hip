@@ -403,6 +403,10 @@ int gemm_nt256_takes(const tcvom_conv_desc* d);
 // halo.hip: weight gradient of the 32 -> 32 channel full-resolution layers from LDS-resident x halo / dy tiles
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
                           int nphase, int ldy, const bf16raw* zero_page, void* stream);
+// wgradws.hip: accumulator-stationary weight gradient of the stride-1 3x3 layers with 64 / 128-multiple channel counts
+int wgradws_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
+                       int nphase, int ldy, void* stream);
+const char* wgradws_variant(const tcvom_conv_desc* d, int ldy);
 
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
     const int hg = halo_conv_stats_groups(d, nphase);
@@ -804,6 +808,7 @@ extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
             if (d->tap_w[t] >= 0 && (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1)) ok = false;
         if (ok) return "halo_wgrad<32>";
     }
+    if (const char* v = wgradws_variant(d, d->K)) return v;
     int tm, tn;
     tt_tile(d, &tm, &tn);
     if (tm == 128) return "igemm_tt<128,128,64,32,1>";
@@ -852,6 +857,10 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     {
         const int r = halo_wgrad_try_launch(dys, ins, dws, nbatch, descs, nphase, ldy, zp, stream);
         if (r != 0) return r < 0 ? tcvom_fail(TCVOM_ERR_LAUNCH, "wgrad_igemm: halo launch failed") : TCVOM_OK;
+    }
+    {
+        const int r = wgradws_try_launch(dys, ins, dws, nbatch, descs, nphase, ldy, stream);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     int tm, tn;
     tt_tile(d, &tm, &tn);

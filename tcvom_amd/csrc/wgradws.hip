@@ -1,0 +1,372 @@
+// Accumulator-stationary weight gradient of the stride-1 3x3 convolutions (the BasicBlock / shortcut / TAM layers of
+// resnet_enc.py:33-49, resnet_dec.py:43-59, res_gca_enc.py:47-55 at os4 .. os32):
+//     dw[k][slot(t)][c] += sum_p dy[p][k] * x[p + t][c],      t = the 9 taps, C and K multiples of 64.
+//
+// Why: the implicit-GEMM TT kernel (igemm.hip) gives every workgroup ONE 128 x 128 block of dw, i.e. one tap: the dy tile is
+// DMA'd once per tap and x once per output-channel tile (measured 3.3x the algorithmic bytes through L2 -> LDS, 71 us for the
+// three frames of an os8 layer against ~13 us of MFMA time).  Here a persistent workgroup owns a [64 k][9 taps][CWIN c] block of
+// dw in REGISTERS (CWIN/16 waves x 9 accumulator tiles of 32 x 32 = 144 AGPRs each: wave = (k fragment, c fragment), one tile per
+// tap; 8 waves = 2 per SIMD for CWIN = 128), walks over pixel tiles and
+// DMAs, per tile, the x halo of its CWIN input channels and the dy tile of its 64 output channels ONCE; all 9 taps read their
+// operands from that halo.  dw is added to global memory once per workgroup, at the end (fp32 atomics: the workgroups of one
+// [k][c] block split the pixels).
+//
+//   MFMA 32x32x16 bf16: A = dy^T [32 k][16 pixels], B = x^T(tap) [32 c][16 pixels]; the reduction runs over pixels, both
+//   operands are pixel-major in LDS and are read with ds_read_b64_tr_b16 (layout as in halo.hip: halo_wgrad_kernel).
+// LDS images: pixel-major; the 64-byte channel group g of pixel p sits at group position g ^ s(p) (applied on the DMA source
+// side), s = hx & 3 for 256-byte pixels and (hx >> 1) & 1 for 128-byte pixels, so that the 4 consecutive pixels a 32-lane
+// group of a transposing read touches lie in distinct banks.
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void* wg_lptr_t;
+#ifndef WG_ABL
+#define WG_ABL 0          // kernel ablations for timing (1: no atomics, 2: no DMA inside the tile loop); 0 in the product
+#endif
+
+#define WG_MAX_PROBLEMS 112                // 3 pointer arrays of this length stay inside the 4 KiB kernel-argument segment
+struct WgArgs {
+    const bf16raw* dy[WG_MAX_PROBLEMS];
+    const bf16raw* in[WG_MAX_PROBLEMS];
+    float* dw[WG_MAX_PROBLEMS];
+    int N, H, W, C, K, wt;
+    int tiles_x, tiles_y, ntiles;          // pixel tiles of one problem (N * tiles_y * tiles_x)
+    int kgroups, cgroups;                  // K / 64, C / CWIN: the (k, c) blocks of dw
+    int total, per_wg;                     // length of the (problem, block, tile) sequence and the run of one workgroup
+    unsigned dy_bytes, in_bytes;
+    int wslot[9];                          // dw slot of the canonical tap t = (dh + 1) * 3 + (dw + 1)
+};
+
+template <int CWIN_, int TW_>
+struct WgCfg {
+    static constexpr int NW = CWIN_ / 16;                           // waves: (2 k fragments) x (CWIN / 32 c fragments), 9 tap tiles each
+    static constexpr int CWIN = CWIN_, TW = TW_, TH = 8, HW = TW + 2, HH = TH + 2;
+    static constexpr int XPB = CWIN * 2, YPB = 128;                 // bytes per pixel of the x halo / the dy tile (64 k)
+    static constexpr int XB = (HH * HW * XPB + 1023) / 1024 * 1024, YB = TH * TW * YPB;   // bytes of the two images (x padded to 1 KiB)
+    static constexpr int XU = XB / 16, YU = YB / 16;                // 16-byte DMA units
+    static constexpr int NDMA = (XU + YU + 63) / 64;                // DMA wave-instructions per tile (x units first, then dy)
+    static constexpr int DMA_IT = (NDMA + NW - 1) / NW;
+    static constexpr int SLOTB = NDMA * 1024;
+    static constexpr int NB = 9;                              // accumulator tiles (= MFMAs per k-step) per wave
+    static constexpr int NKS = TH * TW / 16;                        // k-steps (16 pixels) per tile
+    static constexpr int NG = NKS * NB;                             // MFMAs per tile and wave
+    static constexpr int D = 3;                                     // B fragments are requested D MFMAs ahead
+    static constexpr int AISSUE = 2;                                // the A fragment of k-step s + 1 is requested before MFMA AISSUE of step s
+    static_assert(XU % 64 == 0 && YU % 64 == 0, "a DMA wave-instruction covers one image");
+    static_assert(AISSUE + D < NB, "the A fragment must be older than the first B fragment of its k-step");
+    // LDS operations (2 per fragment) issued after the reads of B fragment g and before MFMA g
+    static constexpr bool a_at(int u) { return u >= 0 && u % NB == AISSUE && u / NB + 1 < NKS; }
+    static constexpr int later_than(int g) {
+        int n = 0;
+        for (int u = g - D; u <= g; ++u) n += (a_at(u) ? 2 : 0) + (u > g - D && u + D < NG ? 2 : 0);
+        return n;
+    }
+};
+
+// B fragment g = (k-step s, tile j = cf * 9 + t): pixels (row r + dh + 1, x0 + dw + 1 + q) of the halo, channels of fragment cf
+template <class G, int g>
+__device__ __forceinline__ void wg_read_b(TrFrag& f, const unsigned (&xb)[3]) {
+    constexpr int s = g / G::NB, t = g % G::NB;
+    constexpr int r = s / (G::TW / 16), xo = (s % (G::TW / 16)) * 16;
+    constexpr int off = ((r + t / 3) * G::HW + xo + t % 3) * G::XPB;
+    const unsigned ad = xb[t % 3];
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(ad), "n"(off));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(ad), "n"(off + 4 * G::XPB));
+}
+// A fragment of k-step s: pixels (row r, x0 + q) of the dy tile
+template <class G, int s>
+__device__ __forceinline__ void wg_read_a(TrFrag& f, unsigned ya) {
+    constexpr int r = s / (G::TW / 16), xo = (s % (G::TW / 16)) * 16;
+    constexpr int off = (r * G::TW + xo) * G::YPB;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(ya), "n"(off));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(ya), "n"(off + 4 * G::YPB));
+}
+
+struct WgDma {                   // per-wave state of the tile being fetched
+    int ym, xm;                  // tile origin (y0, x0); the x halo starts one pixel up / left
+    unsigned xbase, ybase;       // byte offset of halo pixel (0, 0) channel cbase / of tile pixel (0, 0) channel kbase
+    int slot;
+    __amdgpu_buffer_rsrc_t xr, yr;
+};
+// The (lane, instruction) -> (pixel, 16-byte chunk) map of the DMA does not depend on the tile: rel[IT] = byte offset of the
+// unit relative to the image's first pixel, pk[IT] = (row << 16 | column) inside the image for the bounds test (row 0x7fff:
+// padding unit, never loaded).  Unit u = (IT*NW + wave)*64 + lane; units [0, XU) are the x halo, then the dy tile.
+template <class G>
+__device__ __forceinline__ void wg_dma_map(const WgArgs& a, int wave, int lane, unsigned (&rel)[G::DMA_IT], unsigned (&pk)[G::DMA_IT]) {
+#pragma unroll
+    for (int it = 0; it < G::DMA_IT; ++it) {
+        const int u = (it * G::NW + wave) * 64 + lane;
+        if (u < G::XU) {
+            // x halo: pixel p = u / (XPB/16), LDS position sl holds chunk c = ((sl >> 2) ^ s(hx)) << 2 | (sl & 3)
+            constexpr int UX = G::XPB / 16;
+            const int p = u / UX, sl = u % UX;
+            const int hy = p / G::HW, hx = p - hy * G::HW;
+            const int sw = UX >= 16 ? (hx & 3) : ((hx >> 1) & 1);
+            const int c = (((sl >> 2) ^ sw) << 2) | (sl & 3);
+            rel[it] = (unsigned)(((hy * a.W + hx) * a.C + c * 8) * 2);
+            pk[it] = p < G::HH * G::HW ? (unsigned)(hy << 16 | hx) : 0x7fff0000u;
+        } else {
+            // dy tile: pixel q = v / 8, LDS position sy holds chunk ((sy >> 2) ^ ((q >> 1) & 1)) << 2 | (sy & 3)
+            const int v = u - G::XU, q = v >> 3, sy = v & 7;
+            const int ty = q / G::TW, tx = q - ty * G::TW;
+            const int cy = (((sy >> 2) ^ ((q >> 1) & 1)) << 2) | (sy & 3);
+            rel[it] = (unsigned)(((ty * a.W + tx) * a.K + cy * 8) * 2);
+            pk[it] = v < G::YU ? (unsigned)(ty << 16 | tx) : 0x7fff0000u;
+        }
+    }
+}
+// DMA instruction IT of this wave.  Branch-free: buffer_load ... lds with an out-of-range offset (loads zeros) outside the image.
+template <class G, int IT>
+__device__ __forceinline__ void wg_dma_piece(const WgArgs& a, const WgDma& d, char* lds, int wave, const unsigned (&rel)[G::DMA_IT],
+                                             const unsigned (&pk)[G::DMA_IT]) {
+    const int j = IT * G::NW + wave;
+    const bool is_x = (IT * G::NW + G::NW - 1) * 64 + 63 < G::XU ? true : IT * G::NW * 64 >= G::XU ? false : j * 64 < G::XU;   // wave-uniform
+    const int y = (is_x ? d.ym - 1 : d.ym) + (int)(pk[IT] >> 16), x = (is_x ? d.xm - 1 : d.xm) + (int)(pk[IT] & 0xffff);
+    const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const unsigned off = (is_x ? d.xbase : d.ybase) + rel[IT];
+    char* dst = (IT * G::NW + G::NW - 1 < G::NDMA || j < G::NDMA) ? lds + d.slot * G::SLOTB + j * 1024 : lds + 2 * G::SLOTB;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_x ? d.xr : d.yr, (wg_lptr_t)dst, 16, (int)(ok ? off : 0xffffffffu), 0, 0, 0);
+#else
+    (void)dst; (void)ok; (void)off;
+#endif
+}
+template <class G, int IT>
+__device__ __forceinline__ void wg_dma_all(const WgArgs& a, const WgDma& d, char* lds, int wave, const unsigned (&rel)[G::DMA_IT],
+                                           const unsigned (&pk)[G::DMA_IT]) {
+    if constexpr (IT < G::DMA_IT) {
+        wg_dma_piece<G, IT>(a, d, lds, wave, rel, pk);
+        wg_dma_all<G, IT + 1>(a, d, lds, wave, rel, pk);
+    }
+}
+
+// MFMAs g .. NG-1 of a tile: request B fragment g + D (and, at the scheduled position, the next k-step's A fragment), wait for
+// fragment g, multiply.  The order is pinned; the DMA instructions of the NEXT tile ride behind every PER-th MFMA from the start.
+template <class G, int g>
+__device__ __forceinline__ void wg_mfma(const WgArgs& a, const WgDma& d, char* lds, int wave, f32x16_t (&acc)[G::NB],
+                                        TrFrag (&fa)[2], TrFrag (&fb)[G::D + 1], const unsigned (&xb)[3], unsigned ya,
+                                        const unsigned (&rel)[G::DMA_IT], const unsigned (&pk)[G::DMA_IT]) {
+    constexpr int s = g / G::NB, j = g % G::NB;
+    if constexpr (g + G::D < G::NG) wg_read_b<G, g + G::D>(fb[(g + G::D) % (G::D + 1)], xb);
+    if constexpr (G::a_at(g)) wg_read_a<G, s + 1>(fa[(s + 1) & 1], ya);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::later_than(g)) : "memory");
+    tr_fence(fb[g % (G::D + 1)]);
+    if constexpr (j == 0) tr_fence(fa[s & 1]);
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fa[s & 1]), tr_value(fb[g % (G::D + 1)]), acc[j], 0, 0, 0);
+    constexpr int PER = G::NG / G::DMA_IT >= 6 ? 6 : 4;
+#if WG_ABL != 2
+    if constexpr (g % PER == PER - 1 && g / PER < G::DMA_IT) wg_dma_piece<G, g / PER>(a, d, lds, wave, rel, pk);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (g + 1 < G::NG) wg_mfma<G, g + 1>(a, d, lds, wave, acc, fa, fb, xb, ya, rel, pk);
+}
+template <class G, int g>
+__device__ __forceinline__ void wg_prefetch(TrFrag (&fb)[G::D + 1], const unsigned (&xb)[3]) {
+    if constexpr (g < G::D) {
+        wg_read_b<G, g>(fb[g % (G::D + 1)], xb);
+        wg_prefetch<G, g + 1>(fb, xb);
+    }
+}
+
+template <int CWIN, int TW>
+__global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
+    typedef WgCfg<CWIN, TW> G;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];     // [2][SLOTB] (x halo, dy tile), 1 KiB dump area
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kf = wave & 1, cf = wave >> 1;                         // this wave's 32 k rows and 32 c columns of the block
+    // The launch is the flat sequence q = (problem * blocks + block) * ntiles + tile; this workgroup owns [q_begin, q_end) and
+    // flushes its accumulators whenever q crosses into another (problem, block).
+    const int q_begin = blockIdx.x * a.per_wg, q_end = min(a.total, q_begin + a.per_wg);
+    if (q_begin >= q_end) return;
+    const int txy = a.tiles_x * a.tiles_y, blocks = a.kgroups * a.cgroups;
+
+    unsigned rel[G::DMA_IT], pk[G::DMA_IT];
+    wg_dma_map<G>(a, wave, lane, rel, pk);
+    WgDma d;
+    // (q >= q_end: an origin below the image, every unit loads zeros into the free buffer -- keeps the loop branch-free)
+#define WG_SET(q_, slot_)                                                                                     \
+    {                                                                                                         \
+        const int qq_ = min((q_), a.total - 1), item_ = qq_ / a.ntiles, tl_ = qq_ - item_ * a.ntiles;          \
+        const int prob_ = item_ / blocks, blk_ = item_ - prob_ * blocks;                                      \
+        const int kg_ = blk_ / a.cgroups, cg_ = blk_ - kg_ * a.cgroups;                                       \
+        const int n_ = tl_ / txy, r_ = tl_ - n_ * txy;                                                        \
+        d.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16raw*>(a.in[prob_]), 0, a.in_bytes, 0x00020000); \
+        d.yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16raw*>(a.dy[prob_]), 0, a.dy_bytes, 0x00020000); \
+        d.ym = (q_) < q_end ? (r_ / a.tiles_x) * G::TH : (1 << 20);                                           \
+        d.xm = (r_ % a.tiles_x) * TW;                                                                         \
+        d.xbase = (unsigned)((((n_ * a.H + d.ym - 1) * a.W + d.xm - 1) * a.C + cg_ * CWIN) * 2);              \
+        d.ybase = (unsigned)((((n_ * a.H + d.ym) * a.W + d.xm) * a.K + kg_ * 64) * 2);                        \
+        d.slot = (slot_);                                                                                     \
+    }
+    WG_SET(q_begin, 0)
+    wg_dma_all<G, 0>(a, d, lds, wave, rel, pk);
+
+    f32x16_t acc[G::NB];
+#pragma unroll
+    for (int j = 0; j < G::NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // transposing-read lane addressing (halo.hip): lane -> pixel (lane >> 5) * 8 + ((lane & 15) >> 2) (+4 for the hi half), channels
+    // ((lane >> 4) & 1) * 16 + (lane & 3) * 4 ..+3 of its 32-channel fragment
+    const int tr_p = (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(wg_lptr_t)lds;
+    // x: halo pixel (0, q + dwi) + this wave's first c fragment; the 64-byte group g of a pixel sits at g ^ s(hx)
+    unsigned xrel[3];
+#pragma unroll
+    for (int dwi = 0; dwi < 3; ++dwi) {
+        const int hx = tr_p + dwi;
+        const int sw = CWIN >= 128 ? (hx & 3) : ((hx >> 1) & 1);
+        xrel[dwi] = (unsigned)(tr_p * G::XPB + ((cf ^ sw) << 6) + tr_c * 2);
+    }
+    const unsigned yrel = (unsigned)(G::XB + tr_p * G::YPB + ((kf ^ ((tr_p >> 1) & 1)) << 6) + tr_c * 2);
+
+    // dw[(k * wt + slot(t)) * C + c] += acc: rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31
+    auto flush = [&](int item) {
+        const int prob = item / blocks, blk = item - prob * blocks;
+        const int kg = blk / a.cgroups, cg = blk - kg * a.cgroups;
+        float* __restrict__ dw = a.dw[prob];
+        const int kb = kg * 64 + kf * 32 + 4 * (lane >> 5);
+        const int c = cg * CWIN + cf * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < G::NB; ++j) {
+            const int ws = a.wslot[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb + (r & 3) + 8 * (r >> 2);
+#if WG_ABL == 1
+                if (acc[j][r] == 1.2345f)
+#endif
+                atomicAdd(dw + ((int64_t)k * a.wt + ws) * a.C + c, acc[j][r]);
+                acc[j][r] = 0.f;
+            }
+        }
+    };
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the first tile has landed (compiler-visible)
+    int slot = 0, item = q_begin / a.ntiles;
+    int next_change = (item + 1) * a.ntiles;                          // first q of the next (problem, block)
+    for (int q = q_begin; q < q_end; ++q) {
+        if (q == next_change) {                                       // (wave-uniform, a few times per workgroup)
+            flush(item);
+            ++item;
+            next_change += a.ntiles;
+        }
+        __builtin_amdgcn_s_barrier();                                 // tile landed for every wave; the other buffer is free
+        WG_SET(q + 1, slot ^ 1)
+        const unsigned sb = lds0 + slot * G::SLOTB;
+        unsigned xb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xb[k] = sb + xrel[k];
+        const unsigned ya = sb + yrel;
+        TrFrag fa[2], fb[G::D + 1];
+        wg_read_a<G, 0>(fa[0], ya);
+        wg_prefetch<G, 0>(fb, xb);
+        wg_mfma<G, 0>(a, d, lds, wave, acc, fa, fb, xb, ya, rel, pk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile has landed (this wave's part)
+        slot ^= 1;
+    }
+#undef WG_SET
+    flush(item);
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot) {
+    static const bool disabled = getenv("TCVOM_NO_WGRADWS") != nullptr;     // A/B switch
+    if (disabled) return false;
+    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return false;
+    if (d->H != d->OH || d->W != d->OW || d->PH != d->H || d->PW != d->W) return false;
+    const int C = d->C, K = d->K;
+    if (ldy != K || K % 64 != 0 || !(C == 64 || C % 128 == 0)) return false;
+    if (d->H < 4 || d->W < 8) return false;
+    int slots[9];
+    for (int t = 0; t < 9; ++t) slots[t] = -1;
+    int n = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        if (d->tap_w[t] < 0) continue;
+        const int dh = d->tap_dh[t], dw_ = d->tap_dw[t];
+        if (dh < -1 || dh > 1 || dw_ < -1 || dw_ > 1) return false;
+        const int c = (dh + 1) * 3 + (dw_ + 1);
+        if (slots[c] >= 0) return false;
+        slots[c] = d->tap_w[t];
+        ++n;
+    }
+    if (n != 9) return false;
+    const long long in_b = (long long)d->N * d->H * d->W * C * 2, dy_b = (long long)d->N * d->H * d->W * K * 2;
+    if (in_b >= (1ll << 31) || dy_b >= (1ll << 31)) return false;
+    if (wslot) for (int t = 0; t < 9; ++t) wslot[t] = slots[t];
+    return true;
+}
+
+// 1: launched, 0: not a shape for this kernel, < 0: error.  `nprob` problems of identical geometry (the calls of one layer in a
+// window, or of several layers of the same shape): the more problems, the fewer workgroups share a (problem, block) and the fewer
+// atomic partial sums -- weights.py: WeightBank.run_deferred_wgrads groups the deferred weight gradients by geometry.
+int wgradws_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nprob, const tcvom_conv_desc* d,
+                       int nphase, int ldy, void* stream) {
+    WgArgs a;
+    if (nphase != 1 || nprob < 1 || nprob > WG_MAX_PROBLEMS || !wgradws_takes(d, ldy, a.wslot)) return 0;
+    const int C = d->C, K = d->K;
+    for (int i = 0; i < WG_MAX_PROBLEMS; ++i) {
+        const int j = i < nprob ? i : 0;
+        a.dy[i] = (const bf16raw*)dys[j]; a.in[i] = (const bf16raw*)ins[j]; a.dw[i] = dws[j];
+    }
+    const int cwin = C == 64 ? 64 : 128, tw = C == 64 ? 32 : 16;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = C; a.K = K; a.wt = d->wt;
+    a.tiles_x = cdiv(d->W, tw);
+    a.tiles_y = cdiv(d->H, 8);
+    a.ntiles = d->N * a.tiles_x * a.tiles_y;
+    a.kgroups = K / 64;
+    a.cgroups = C / cwin;
+    a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * C * 2);
+    a.dy_bytes = (unsigned)((long long)d->N * d->H * d->W * K * 2);
+    const long long total = (long long)nprob * a.kgroups * a.cgroups * a.ntiles;
+    if (total >= (1ll << 31)) return 0;
+    a.total = (int)total;
+    // one persistent workgroup per CU; a run shorter than 2 tiles is all pipeline fill
+    int wgs = 256;
+    if (total < 2ll * wgs) wgs = (int)((total + 1) / 2);
+    a.per_wg = cdiv(total, wgs);
+    const dim3 grid(cdiv(total, a.per_wg));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (cwin == 64) {
+        auto kern = wgrad_ws_kernel<64, 32>;
+        constexpr size_t lds_bytes = 2 * WgCfg<64, 32>::SLOTB + 1024;
+        static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+        static bool attr = false;
+        if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    } else {
+        auto kern = wgrad_ws_kernel<128, 16>;
+        constexpr size_t lds_bytes = 2 * WgCfg<128, 16>::SLOTB + 1024;
+        static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+        static bool attr = false;
+        if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, st, a);
+    }
+    if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "wgrad_ws: %s", hipGetErrorString(e));
+    const hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "wgrad_ws: %s", hipGetErrorString(e2));
+    return 1;
+}
+
+// C ABI: the weight gradients of up to WG_MAX_PROBLEMS convolutions of ONE geometry in one launch (declared in tcvom_hip.h)
+extern "C" int tcvom_wgrad_ws_multi(const void* const* dy, const void* const* in, float* const* dw, int32_t nprob,
+                                    const tcvom_conv_desc* d, int32_t ldy, void* stream) {
+    TCVOM_CHECK_ARG(dy && in && dw && d, "wgrad_ws_multi: null pointer");
+    TCVOM_CHECK_ARG(nprob >= 1 && nprob <= WG_MAX_PROBLEMS, "wgrad_ws_multi: %d problems (1..%d)", nprob, WG_MAX_PROBLEMS);
+    for (int i = 0; i < nprob; ++i) TCVOM_CHECK_ARG(dy[i] && in[i] && dw[i], "wgrad_ws_multi: null pointer in problem %d", i);
+    const int r = wgradws_try_launch(dy, in, dw, nprob, d, 1, ldy, stream);
+    TCVOM_CHECK_ARG(r != 0, "wgrad_ws_multi: not a stride-1 3x3 convolution with C = 64 or a multiple of 128 and K a multiple of 64");
+    return r < 0 ? r : TCVOM_OK;
+}
+extern "C" int32_t tcvom_wgrad_ws_max_problems(void) { return WG_MAX_PROBLEMS; }
+
+// name for profiles / bench labels
+const char* wgradws_variant(const tcvom_conv_desc* d, int ldy) {
+    if (!wgradws_takes(d, ldy, nullptr)) return nullptr;
+    return d->C == 64 ? "wgrad_ws<64>" : "wgrad_ws<128>";
+}

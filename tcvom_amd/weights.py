@@ -73,6 +73,29 @@ class ConvSpec(object):
         self.layer_id = -1
 
 
+_WS_CAP = []
+
+
+def _wgrad_ws_cap():
+    if not _WS_CAP:
+        _WS_CAP.append(int(L.call('tcvom_wgrad_ws_max_problems')))
+    return _WS_CAP[0]
+
+
+def _wgrad_ws_key(geo):
+    """Geometry signature of a layer whose weight gradient runs on the accumulator-stationary kernel, else None (cached
+    on the geometry object)."""
+    key = getattr(geo, '_ws_key', False)
+    if key is False:
+        key = None
+        if len(geo.wgrad) == 1:
+            d = geo.wgrad[0]
+            if L._FNS['tcvom_wgrad_igemm_variant'](C.byref(d)).startswith(b'wgrad_ws'):
+                key = (d.N, d.H, d.W, d.C, d.K, d.wt, tuple((d.tap_dh[t], d.tap_dw[t], d.tap_w[t]) for t in range(d.ntaps)))
+        geo._ws_key = key
+    return key
+
+
 class WeightBank(object):
     def __init__(self):
         self.specs = []
@@ -438,10 +461,29 @@ class WeightBank(object):
         for s in {e[5] for e in pend}:
             if s != cur:
                 cur.wait_stream(s)
-        groups = {}
+        # Layers of one geometry share launches of the accumulator-stationary kernel (csrc/wgradws.hip): with every call of every
+        # such layer in one launch a block of dw is owned by one or two workgroups instead of ~40.  Other shapes: the calls of
+        # a layer as one batched launch.
+        groups, multi = {}, {}
         for e in pend:
-            groups.setdefault((e[0].layer_id, id(e[4])), []).append(e)
+            geo = e[4]
+            key = _wgrad_ws_key(geo)
+            if key is not None:
+                multi.setdefault(key, []).append(e)
+            else:
+                groups.setdefault((e[0].layer_id, id(geo)), []).append(e)
         st = L.stream_ptr()
+        cap = _wgrad_ws_cap()
+        for items in multi.values():
+            arr = _phase_array(items[0][4].wgrad)
+            for i in range(0, len(items), cap):
+                part = items[i:i + cap]
+                n = len(part)
+                dys = (C.c_void_p * n)(*[e[2].data_ptr() + e[6] for e in part])
+                xs = (C.c_void_p * n)(*[e[3].data_ptr() + e[7] for e in part])
+                dws = (C.c_void_p * n)(*[self.dw_ptr(e[0], e[1]).value for e in part])
+                L.call('tcvom_wgrad_ws_multi', C.cast(dys, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(dws, C.c_void_p), n,
+                       arr, items[0][0].K, st)
         for items in groups.values():
             spec, geo = items[0][0], items[0][4]
             arr = _phase_array(geo.wgrad)

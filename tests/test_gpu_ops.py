@@ -309,6 +309,41 @@ def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
     assert not torch.equal(single[0], single[1])
 
 
+@pytest.mark.parametrize('cin,cout,N,H,W,S', [(64, 64, 2, 20, 40, 1), (64, 64, 1, 33, 70, 3), (128, 128, 1, 17, 30, 3),
+                                              (128, 128, 2, 40, 64, 1), (256, 128, 1, 9, 16, 2), (128, 256, 1, 24, 20, 1),
+                                              (512, 512, 1, 6, 10, 3), (64, 128, 1, 16, 32, 1), (128, 128, 1, 17, 30, 20),
+                                              (64, 64, 1, 16, 32, 40), (256, 256, 1, 9, 12, 112)])
+def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
+    """Accumulator-stationary weight gradient (csrc/wgradws.hip; stride-1 3x3, C = 64 or a multiple of 128, K a multiple
+    of 64): ragged tiles, several samples, several problems per launch, every (k, c) block split -- against
+    torch.nn.grad.conv2d_weight in fp32 on the same bf16 operands."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.ops import _phase_array
+    tag = 'wgws%d_%d_%d' % (cin, cout, H)
+    bank, spec = _mini_bank(cin, cout, 3, 1, 1, False, spectral=False, tag=tag)
+    geo = ConvGeometry(spec, N, H, W)
+    assert L._FNS['tcvom_wgrad_igemm_variant'](C.byref(_phase_array(geo.wgrad)[0])).decode().startswith('wgrad_ws')
+    xs = [hu('x%d.%s' % (i, tag), (N, H, W, cin)).to(DEV).to(torch.bfloat16) for i in range(S)]
+    dys = [hu('dy%d.%s' % (i, tag), (N, H, W, cout)).to(DEV).to(torch.bfloat16) for i in range(S)]
+    dw = torch.zeros(S, cout, 9, cin, device=DEV)
+    vp = lambda ts: C.cast((C.c_void_p * S)(*[t.data_ptr() for t in ts]), C.c_void_p)
+    for _ in range(2):                                   # accumulates: two launches = twice the gradient
+        if S <= 8:
+            L.call('tcvom_wgrad_igemm_batched', vp(dys), vp(xs), vp([dw[i] for i in range(S)]), S, _phase_array(geo.wgrad),
+                   len(geo.wgrad), cout, L.stream_ptr())
+        else:                                            # many problems of one geometry: WeightBank.run_deferred_wgrads
+            L.call('tcvom_wgrad_ws_multi', vp(dys), vp(xs), vp([dw[i] for i in range(S)]), S, _phase_array(geo.wgrad),
+                   cout, L.stream_ptr())
+    torch.cuda.synchronize()
+    for i in range(S):
+        ref = torch.nn.grad.conv2d_weight(xs[i].float().cpu().permute(0, 3, 1, 2), (cout, cin, 3, 3),
+                                          dys[i].float().cpu().permute(0, 3, 1, 2), padding=1)
+        got = dw[i].cpu().view(cout, 3, 3, cin).permute(0, 3, 1, 2) / 2
+        assert rel_err(got, ref) < 1e-5, 'problem %d' % i
+
+
 @pytest.mark.parametrize('cin,cout,hp,N,H,W', [(32, 32, False, 2, 16, 64), (32, 32, True, 1, 24, 96), (6, 32, False, 1, 16, 160),
                                               (32, 32, False, 1, 72, 96), (64, 64, False, 2, 16, 64), (64, 64, True, 1, 24, 96),
                                               (64, 32, False, 1, 16, 96), (32, 64, False, 1, 40, 64)])

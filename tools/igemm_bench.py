@@ -89,13 +89,24 @@ def main():
         def dgrad3():
             _launch_conv(geo.dgrad, dy3, bank.bwd_ptr(spec, 0), dx3, None, None, 0, st, 3, 0)
 
+        # eligible shapes: 24 problems (8 layers x 3 frames) of the accumulator-stationary kernel in one launch
+        tm = float('nan')
+        if L._FNS['tcvom_wgrad_igemm_variant'](C.byref(_phase_array(geo.wgrad)[0])).startswith(b'wgrad_ws'):
+            NP = 24
+            dwm = torch.zeros(NP, spec.K * spec.T * spec.cpad, device=DEV)
+            dysm = (C.c_void_p * NP)(*[dyb[i % 3].data_ptr() for i in range(NP)])
+            xsm = (C.c_void_p * NP)(*[xb[i % 3].data_ptr() for i in range(NP)])
+            dwsm = (C.c_void_p * NP)(*[dwm[i].data_ptr() for i in range(NP)])
+            tm = timeit(lambda: L.call('tcvom_wgrad_ws_multi', C.cast(dysm, C.c_void_p), C.cast(xsm, C.c_void_p),
+                                       C.cast(dwsm, C.c_void_p), NP, _phase_array(geo.wgrad), cout, st)) / NP
+
         tf = timeit(fwd)
         td = timeit(dgrad) if spec.needs_dgrad else float('nan')
         tw = timeit(wgrad) / 3
         tf3 = timeit(fwd3) / 3
         td3 = timeit(dgrad3) / 3 if spec.needs_dgrad else float('nan')
-        print('%-22s %5.0f %4.0f %5.0f %4.0f %5.0f %4.0f | 3-frame launch: fwd %5.0f %4.0f dgrad %5.0f %4.0f  [%s]' % (
-            name, flop / tf / 1e9, tf * 1e3, flop / td / 1e9, td * 1e3, flop / tw / 1e9, tw * 1e3,
+        print('%-22s %5.0f %4.0f %5.0f %4.0f %5.0f %4.0f (x24: %4.0f %4.0f) | 3-frame launch: fwd %5.0f %4.0f dgrad %5.0f %4.0f  [%s]' % (
+            name, flop / tf / 1e9, tf * 1e3, flop / td / 1e9, td * 1e3, flop / tw / 1e9, tw * 1e3, flop / tm / 1e9, tm * 1e3,
             flop / tf3 / 1e9, tf3 * 1e3, flop / td3 / 1e9, td3 * 1e3,
             L._FNS['tcvom_conv_igemm_variant'](C.byref(_phase_array(geo.fwd)[0]), len(geo.fwd)).decode()))
     # GCA GEMMs at 1080p: N = 8160

@@ -134,9 +134,9 @@ def validate(dataset, model, rank, world, workers):
         total, count = float(acc[0]), int(acc[1])
     val_loss = total / max(count, 1)
     if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, store)
-        store = {k: v for part in parts for k, v in part.items()}
+        parts = [None] * world if rank == 0 else None       # only rank 0 evaluates the temporal indicator
+        dist.gather_object(store, parts, dst=0)
+        store = {k: v for part in parts for k, v in part.items()} if rank == 0 else {}
     if rank == 0:
         logging.info('Validation loss: %.6f', val_loss)
         res = 0.0
