@@ -13,6 +13,7 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        self.table_rebuilds = 0        # diagnostic: how often the pointer table had to be rebuilt
 
     def _table(self, key, plist):
         # the kernel writes through the cached pointers: exp_avg / exp_avg_sq are part of the signature, so that a
@@ -22,14 +23,25 @@ class FusedAdam(torch.optim.Optimizer):
         ent = self._tables.get(key)
         if ent is not None and ent[0] == sig:
             return ent
-        rows, work = [], []
-        for i, p in enumerate(plist):
-            st = self.state[p]
-            rows.append([p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()])
-            work += [(i, b) for b in range((p.numel() + 1023) // 1024)]
+        # The gradient buffers may move between steps (they are views of a buffer the bank allocates per backward), so a
+        # rebuild must not stall the stream: the block list depends on the sizes only and is cached on the device; the
+        # pointer rows go up from pinned memory without a host synchronisation.
+        rows = [[p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr(),
+                 p.numel()] for p in plist]
         dev = plist[0].device
-        ent = (sig, torch.tensor(rows, dtype=torch.int64, device=dev),
-               torch.tensor(work, dtype=torch.int32, device=dev).reshape(-1), len(work))
+        wkey = ('work', dev, tuple(p.numel() for p in plist))
+        went = self._tables.get(wkey)
+        if went is None:
+            counts = torch.tensor([(p.numel() + 1023) // 1024 for p in plist], dtype=torch.int64)
+            idx = torch.repeat_interleave(torch.arange(len(plist), dtype=torch.int64), counts)
+            first = torch.cumsum(counts, 0) - counts
+            blk = torch.arange(int(counts.sum()), dtype=torch.int64) - first[idx]
+            work = torch.stack([idx, blk], 1).to(torch.int32).reshape(-1)
+            went = (work.to(dev), int(counts.sum()))
+            self._tables[wkey] = went
+        self.table_rebuilds += 1
+        host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        ent = (sig, host.to(dev, non_blocking=True), went[0], went[1])
         self._tables[key] = ent
         return ent
 

@@ -16,7 +16,7 @@ for _ in range(5): step()
 t1 = time.time()
 torch.cuda.synchronize()
 t2 = time.time()
-print('host enqueue %.1f ms/step, total %.1f ms/step' % ((t1-t0)*200, (t2-t0)*200))
+print('host enqueue %.1f ms/step, total %.1f ms/step; adam table rebuilds %d in 7 steps' % ((t1-t0)*200, (t2-t0)*200, opt.table_rebuilds))
 # forward-only / backward-only host split
 torch.cuda.synchronize(); t0=time.time(); out = model(a,fg,bg); loss = train_step_loss(out); t1=time.time(); torch.cuda.synchronize(); t2=time.time()
 print('fwd host %.1f ms, fwd total %.1f ms' % ((t1-t0)*1e3, (t2-t0)*1e3))
