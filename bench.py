@@ -27,15 +27,33 @@ GFLOP_FWD_GCA_1080P = 2106.3       # 6 guided-contextual-attention calls, forwar
 GFLOP_WINDOW_1080P = 11179.81      # forward + backward
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 FULL_H, FULL_W = 1088, 1920
-# HBM bytes per launch of the igemm instantiations, from the rocprofv3 PMC passes in profiles/r01_k_hbm_traffic_pmc.md
-# (FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this script; fetch side doubled per MI355X_MICROARCH.md's gfx950
-# correction; averaged over all launches of the instantiation in a 1080p step).  bench.py cannot run rocprofv3 on itself,
-# so the figure of the kernel that turns out dominant is quoted from that committed measurement.
-PMC_TRAFFIC_BYTES = {                                                   # profiles/r01_k_hbm_traffic_pmc.md
-    'gemm_nt256': (871.10 + 380.03) * 2 ** 20,
-    'igemm_tt<128,128,64,32,1>': (157.05 + 26.17) * 2 ** 20,
-    'igemm_nt<128,128,64,32,2>': (41.54 + 41.08) * 2 ** 20,
-}
+PROFILE_DIR = os.path.join(ROOT, 'profiles')
+
+
+def profile_traffic(variant):
+    """HBM bytes per launch of the kernel behind `variant`, read from the newest committed PMC summary
+    (profiles/r*_hbm_traffic_pmc.md: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes of this script, fetch
+    side doubled per MI355X_MICROARCH.md's gfx950 correction, averaged over the launches of that kernel in a 1080p
+    step).  bench.py cannot run rocprofv3 on itself; returns (bytes or None, file name or None)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(PROFILE_DIR, 'r*_hbm_traffic_pmc*.md')))
+    if not files:
+        return None, None
+    m = re.match(r'(\w+?)(<.*>)?$', variant)
+    base, targs = m.group(1), (m.group(2) or '')
+    if base == 'gemm_nt256':
+        key = 'gemm_nt256_kernel<0>'
+    else:
+        key = base + '_kernel' + (targs[:-1].replace(',', ', ') if targs else '')    # the table truncates long names
+    for line in open(files[-1]):
+        if line.startswith('| `') and key in line.replace('void ', ''):
+            cols = [c.strip() for c in line.split('|')]
+            try:
+                return (float(cols[3]) + float(cols[4])) * 2 ** 20, os.path.basename(files[-1])
+            except (ValueError, IndexError):
+                return None, os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
 
 
 def window_gflop(H, W):
@@ -79,31 +97,44 @@ def igemm_profile(step_fn):
     return agg
 
 
-def cpu_baseline(sample_hw=(768, 1344), max_threads=32):
-    """The oracle (pure PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host
-    cores on ONE bounded sample window, scaled to 1080p windows/s by the algorithmic-FLOP ratio."""
+def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
+    """The oracle (pure PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host cores on the
+    SAME 3x1088x1920 window as the GPU line: one small warm-up window (thread pool, allocator), then `reps` timed
+    forward+backward passes, median reported.  `cores` is the thread count actually used: PyTorch's CPU kernels get
+    SLOWER on these shapes beyond ~32 threads (measured on the 256-logical-core MI355X host: 19-21 s per window at 32
+    threads, 30 s at 64, 55 s at 128 -- tools/cpu_oracle_time.py), so 32 is the best the port does on this box."""
+    import statistics
     import oracle
     from oracle.state_spec import vmn_gca_state_spec
     from tcvom_amd.synthetic import formula_tensor, synthetic_window
-    # PyTorch's CPU kernels do not scale past a few dozen threads on these shapes (256 threads measured
-    # 768 s for a 544x960 window): use at most `max_threads` and report exactly that many as `cores`
-    cores = min(os.cpu_count() or 1, max_threads)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, threads)
     torch.set_num_threads(cores)
-    H, W = sample_hw
     state = {k: formula_tensor(k, s, torch.int64 if k.endswith('num_batches_tracked') else torch.float32)
              for k, s in vmn_gca_state_spec().items()}
     for k, v in state.items():
         if v.is_floating_point() and not any(t in k for t in ('weight_u', 'weight_v', 'running_')):
             v.requires_grad_(True)
-    a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
-    t0 = time.time()
-    out, _ = oracle.window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True)
-    oracle.train_step_loss(out).backward()
-    dt = time.time() - t0
+
+    def one(H, W):
+        a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
+        t0 = time.time()
+        out, _ = oracle.window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True)
+        oracle.train_step_loss(out).backward()
+        for v in state.values():
+            v.grad = None
+        return time.time() - t0
+
+    one(256, 448)                                            # warm-up, not timed
+    H, W = sample_hw
+    times = sorted(one(H, W) for _ in range(reps))
+    dt = statistics.median(times)
     ratio = window_gflop(H, W) / window_gflop(FULL_H, FULL_W)
-    return {'value': round(ratio / dt, 6), 'unit': 'windows/s', 'cores': cores, 'kind': 'port',
-            'sample': 'one 3x%dx%d window fwd+bwd in %.1f s on %d threads, scaled to 3x%dx%d by the algorithmic '
-                      'FLOP ratio %.4f' % (H, W, dt, cores, FULL_H, FULL_W, ratio)}
+    return {'value': round(ratio / dt, 6), 'unit': 'windows/s', 'cores': cores, 'host_logical_cores': host_cores, 'kind': 'port',
+            'sample': 'median of %d fwd+bwd passes over one 3x%dx%d window after a 3x256x448 warm-up: %s s on %d threads '
+                      '(more threads measured slower, tools/cpu_oracle_time.py)%s'
+                      % (reps, H, W, '/'.join('%.1f' % t for t in times), cores,
+                         '' if (H, W) == (FULL_H, FULL_W) else ', scaled to 3x%dx%d by the algorithmic FLOP ratio %.4f' % (FULL_H, FULL_W, ratio))}
 
 
 def main():
@@ -198,9 +229,11 @@ def main():
             dom = max(agg, key=lambda k: agg[k][1])
             n, ms, gf = agg[dom]
             tf = gf / ms                                    # GFLOP / ms == TFLOP/s
+            traffic, tsrc = profile_traffic(dom)
             result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': MFMA_PEAK_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': round(tf / MFMA_PEAK_TFLOPS, 4),
-                                  'traffic': (round(PMC_TRAFFIC_BYTES[dom]) if (H, W) == (FULL_H, FULL_W) and dom in PMC_TRAFFIC_BYTES else None),
+                                  'traffic': (round(traffic) if traffic is not None and (H, W) == (FULL_H, FULL_W) else None),
+                                  'traffic_source': tsrc,
                                   'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
                                   'algorithmic_gflop_per_launch': round(gf / n, 3),
                                   'all_igemm': {k: {'launches': v[0], 'ms': round(v[1], 3), 'tflops': round(v[2] / max(v[1], 1e-9), 1)}
@@ -209,7 +242,7 @@ def main():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline()
+            result['cpu_baseline'] = cpu_baseline((H, W))
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
