@@ -165,7 +165,7 @@ def main():
         dist.init_process_group(backend=backend, init_method='env://', **({'device_id': device} if backend == 'nccl' else {}))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
 
-    from tcvom_amd.ddp import GradientAverager, broadcast_module_state, convert_sync_batchnorm
+    from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm
     from tcvom_amd.facade import train_step_loss
     from tcvom_amd.optim import FusedAdam
     H, W = args.height, args.width
@@ -175,7 +175,8 @@ def main():
     broadcast_module_state(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, weight_decay=1e-4)
-    averager = GradientAverager(params)
+    # the banks finish the flat gradient in layer ranges; each range's all-reduce starts while the next still computes
+    averager = GradientAverager(params, banks=banks_of(model))
 
     def step():
         out = model(a, fg, bg)
@@ -220,6 +221,9 @@ def main():
                                    'formula-initialised weights, train mode' % (H, W),
                        'global_batch_clips': world, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn)},
             'final_loss': round(final_loss, 6),
+            'dist': {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,
+                     'grad_spans_overlapped_with_backward': averager.early_spans,
+                     'grad_allreduce_plan': averager.last_plan},
             'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5),
         }
     # ---- roofline of the dominant kernel (event-instrumented extra step on rank 0's stream)

@@ -161,15 +161,20 @@ int tcvom_gn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64
                           const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
                           double* scratch, int32_t nframes, int64_t slot_stride, void* stream);
 /* SyncBatchNorm (train_ddp.py:213 nn.SyncBatchNorm.convert_sync_batchnorm): the per-channel sums are produced
- * as an fp64 [2][C] vector, the host all-reduces it over the ranks (RCCL), and the *_sums finalizers consume
- * the summed vector with the global pixel count.  dgamma/dbeta come from the LOCAL sums (torch semantics). */
-int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_t C, double* sums /*[2][C]*/,
-                         double* scratch /* tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */, void* stream);
+ * as an fp64 [nframes][2][C] vector (the frames of a frame-batched call are separate calls of the BatchNorm and keep
+ * separate statistics), the host all-reduces it over the ranks in ONE collective (RCCL), and the *_sums finalizers
+ * consume the summed vector with the global pixel count of one frame.  scale_shift / saved of frame f sit
+ * f * slot_stride floats further, coef [nframes][3][C].  dgamma/dbeta come from the LOCAL sums (torch semantics),
+ * summed over the frames. */
+int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_t C, double* sums /*[nframes][2][C]*/,
+                         double* scratch /* nframes * tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
+                         int32_t nframes, void* stream);
 int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t unbias_count, const float* gamma,
-                           const float* beta, float eps, float* scale_shift, float* saved, void* stream);
+                           const float* beta, float eps, float* scale_shift, float* saved, int32_t nframes,
+                           int64_t slot_stride, void* stream);
 int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
-                               int32_t accumulate, void* stream);
+                               int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream);
 /* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
  * gradient is additionally masked by y > 0 */
 int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,

@@ -645,6 +645,8 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ par
     __shared__ double s1[8][32], s2[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    partial += (int64_t)blockIdx.y * G * 2 * C;                     // frame of a batched call: sums[frame][2][C]
+    sums += (int64_t)blockIdx.y * 2 * C;
     double a = 0.0, b = 0.0;
     if (c < C) {
         // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
@@ -675,45 +677,49 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ par
 }
 
 __global__ void bn_local_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                      int accumulate) {
+                                      int accumulate, int nframes) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)sums[c]); else dbeta[c] = (float)sums[c]; }
-    if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)sums[C + c]); else dgamma[c] = (float)sums[C + c]; }
+    double a = 0.0, b = 0.0;                                        // the frames of a batched call are calls of ONE BatchNorm
+    for (int f = 0; f < nframes; ++f) { a += sums[(int64_t)f * 2 * C + c]; b += sums[(int64_t)f * 2 * C + C + c]; }
+    if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)a); else dbeta[c] = (float)a; }
+    if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)b); else dgamma[c] = (float)b; }
 }
 
-extern "C" int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_t C, double* sums, double* scratch, void* stream) {
-    TCVOM_CHECK_ARG(partial && sums && groups > 0 && C > 0, "bn_reduce_sums: bad args");
+extern "C" int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_t C, double* sums, double* scratch,
+                                    int32_t nframes, void* stream) {
+    TCVOM_CHECK_ARG(partial && sums && groups > 0 && C > 0 && nframes >= 1, "bn_reduce_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(bn_sums_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, sums);
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(bn_sums_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, sums);
     } else {
-        hipLaunchKernelGGL(bn_sums_kernel<float>, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, groups, C, sums);
+        hipLaunchKernelGGL(bn_sums_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, partial, groups, C, sums);
     }
     TCVOM_LAUNCH_CHECK("bn_reduce_sums");
     return TCVOM_OK;
 }
 
 extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t unbias_count, const float* gamma,
-                                      const float* beta, float eps, float* scale_shift, float* saved, void* stream) {
-    TCVOM_CHECK_ARG(sums && gamma && beta && scale_shift && saved && C > 0 && count > 0, "bn_finalize_sums: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, sums, 1, C, (double)count,
+                                      const float* beta, float eps, float* scale_shift, float* saved, int32_t nframes,
+                                      int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(sums && gamma && beta && scale_shift && saved && C > 0 && count > 0 && nframes >= 1, "bn_finalize_sums: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, (hipStream_t)stream, sums, 1, C, (double)count,
                        (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps,
-                       scale_shift, saved, (int64_t)0);
+                       scale_shift, saved, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_finalize_sums");
     return TCVOM_OK;
 }
 
 extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                           const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
-                                          int32_t accumulate, void* stream) {
-    TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0, "bn_bwd_finalize_sums: bad args");
+                                          int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32)), dim3(256), 0, st, sums_all, 1, C, (double)count, gamma,
-                       saved, (float*)nullptr, (float*)nullptr, coef, 0, (int64_t)0);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, sums_all, 1, C, (double)count, gamma,
+                       saved, (float*)nullptr, (float*)nullptr, coef, 0, slot_stride);
     // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
-    hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate, nframes);
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize_sums");
     return TCVOM_OK;
 }

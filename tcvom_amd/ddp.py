@@ -52,10 +52,34 @@ class GradientAverager(object):
 
     MIN_SPAN = 1 << 14           # elements; shorter runs are cheaper packed together than as their own collective
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=64 << 20, banks=(), force=False):
+        """banks: the WeightBanks of the model (`tcvom_amd.weights.banks_of(model)`).  Their backward finishes the flat
+        gradient in WeightBank.GRAD_CHUNKS layer ranges and calls back after each: the all-reduce of a finished span is
+        started right there, on RCCL's stream, while the weight-gradient kernels of the next range still run -- DDP's
+        overlap of bucket reductions with the tail of backward.  `average()` then only waits for those and reduces the
+        small remainder (BatchNorm arena, biases).  force: also in a one-rank group (tests)."""
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self.last_plan = None    # (elements reduced in place, number of spans, elements packed, number of buckets)
+        self.force = force
+        self._early = []         # [(flat view, work, storage ptr, first element, count)] started from the bank hooks
+        self.early_spans = 0     # diagnostic: spans started before backward returned, last step
+        for bank in banks:
+            bank.grad_span_hook = self._on_span
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
+
+    def _on_span(self, flat, lo, hi):
+        """WeightBank.backward finished flat[lo:hi] (fp32, final values of this step).  Only valid when no parameter
+        still holds an older .grad that autograd would add these values to (zero_grad(set_to_none=True) each step, as
+        bench.py / train_ddp.py do): otherwise the span is left to average()."""
+        if not self._active() or hi <= lo:
+            return
+        avg = dist.get_backend() == 'nccl'
+        view = flat[lo:hi]
+        work = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
+        self._early.append((view, work, flat.untyped_storage().data_ptr(), flat.storage_offset() + lo, hi - lo))
 
     @staticmethod
     def plan(grads, min_span):
@@ -86,18 +110,34 @@ class GradientAverager(object):
 
     def average(self, force=False):
         """force: run the collectives even in a one-rank group (tests/test_gpu_ddp.py drives the RCCL code path on one GPU)."""
+        early, self._early = self._early, []
+        self.early_spans = len(early)
         if not (dist.is_available() and dist.is_initialized()):
             return
         ws = dist.get_world_size()
-        if ws < 2 and not force:
+        if ws < 2 and not (force or self.force):
             return
         avg = dist.get_backend() == 'nccl'
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         missing = [p for p in self.params if p.grad is None]
         for p in missing:
             p.grad = torch.zeros_like(p)
-        spans, rest = self.plan([p.grad for p in self.params], self.MIN_SPAN)
-        works = []
+
+        def covered(g):          # already being reduced by a span started from the bank hook
+            if not early or not g.is_contiguous():
+                return False
+            sp, off = g.untyped_storage().data_ptr(), g.storage_offset()
+            return any(sp == e[2] and e[3] <= off and off + g.numel() <= e[3] + e[4] for e in early)
+        grads = [p.grad for p in self.params]
+        if early:
+            # a parameter that kept an older .grad got `old += new` from autograd AFTER the early all-reduce of `new` was
+            # started: its .grad is not a view of the reduced buffer any more and would silently stay rank-local
+            done = [g for g in grads if covered(g)]
+            assert sum(g.numel() for g in done) == sum(e[4] for e in early), \
+                'early gradient spans need zero_grad(set_to_none=True) before every backward'
+            grads = [g for g in grads if not covered(g)]
+        spans, rest = self.plan(grads, self.MIN_SPAN)
+        works = [(e[0], None, e[1]) for e in early]
         for run, storage, first, n in spans:
             flat = run[0].new_empty(0).set_(storage, first, (n,))
             works.append((flat, None, dist.all_reduce(flat, op=op, async_op=True)))
@@ -120,7 +160,20 @@ class GradientAverager(object):
                 flat.div_(ws)
             if bucket is not None:
                 torch._foreach_copy_(bucket, [t.view_as(g) for t, g in zip(flat.split([g.numel() for g in bucket]), bucket)])
-        self.last_plan = (sum(s[3] for s in spans), len(spans), sum(g.numel() for g in rest), len(buckets))
+        self.last_plan = (sum(s[3] for s in spans) + sum(e[4] for e in early), len(spans) + len(early),
+                          sum(g.numel() for g in rest), len(buckets))
+
+
+def banks_of(module):
+    """The WeightBanks behind a HIP network (each owns one flat gradient buffer): for GradientAverager(banks=...)."""
+    from .weights import WeightBank
+    seen, out = set(), []
+    for m in module.modules():
+        for v in vars(m).values():
+            if isinstance(v, WeightBank) and id(v) not in seen:
+                seen.add(id(v))
+                out.append(v)
+    return out
 
 
 def reduce_tensor(inp):

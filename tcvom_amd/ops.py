@@ -155,7 +155,6 @@ class _ConvBNAct(torch.autograd.Function):
         P = geo.out_pixels                   # pixels of ONE frame
         sync = _sync_group(bn) if training else None
         if sync is not None:
-            assert nf == 1, 'SyncBatchNorm runs frame by frame (VMN.run switches the frame batching off)'
             P = P * sync[1]
         ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training and not gn, P * cfg.unbias_mult)
         ss, saved = C.c_void_p(ss_i), C.c_void_p(saved_i)
@@ -175,12 +174,13 @@ class _ConvBNAct(torch.autograd.Function):
                        L.ptr(gamma), L.ptr(beta), None, None,
                        float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
             else:
-                # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size)
-                sums = torch.empty(2 * K, dtype=torch.float64, device=x.device)
-                L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, K, L.ptr(sums), L.ptr(scratch), st)
+                # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size); the nf
+                # frames of a frame-batched call keep separate statistics and share ONE collective
+                sums = torch.empty(nf * 2 * K, dtype=torch.float64, device=x.device)
+                L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, K, L.ptr(sums), L.ptr(scratch), nf, st)
                 dist.all_reduce(sums, group=sync[0])
                 L.call('tcvom_bn_finalize_sums', L.ptr(sums), K, P, P * cfg.unbias_mult, L.ptr(gamma), L.ptr(beta),
-                       float(bn.eps), ss, saved, st)
+                       float(bn.eps), ss, saved, nf, slot_stride, st)
         else:
             slot_stride = 0                  # eval: one (scale, shift) for all frames
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
@@ -237,12 +237,12 @@ class _ConvBNAct(torch.autograd.Function):
                        L.ptr(coef), L.ptr(scratch), 1, nf, stride, st)
             else:
                 group, world = sync
-                local = torch.empty(2 * K, dtype=torch.float64, device=dz.device)
-                L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), st)
+                local = torch.empty(nf * 2 * K, dtype=torch.float64, device=dz.device)
+                L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), nf, st)
                 total = local.clone()
                 dist.all_reduce(total, group=group)
                 L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
-                       dgp, dbp, L.ptr(coef), 1, st)
+                       dgp, dbp, L.ptr(coef), 1, nf, stride, st)
             dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)

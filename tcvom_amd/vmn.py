@@ -99,10 +99,8 @@ class VMN(nn.Module):
         S = len(frames_x8)
         training = self.training
         token = bank_token(self._bank, S, training)
-        sync_bn = training and any(getattr(bn, 'sync', False) for bn in self._bank.bns) and \
-            torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         front_training = training and not self.freeze_backbone
-        if self.batched_frames and not sync_bn:
+        if self.batched_frames:
             return self._run_batched(frames_x8, unk_u8, token, training, front_training)
         if self.freeze_backbone:
             with torch.no_grad():

@@ -107,6 +107,7 @@ class WeightBank(object):
         self.frozen_groups = set()          # spec groups run in eval mode inside a training window (VMN freeze_backbone: {'frame'})
         self.frames_per_op = 1              # >1 while VMN.run pushes the S frames of a window through the layers together
         self._deferred = []
+        self.grad_span_hook = None        # callable(flat_grad, lo, hi): a finished span of the flat gradient (ddp.py)
 
     # ------------------------------------------------------------------ BatchNorm bookkeeping
     # Every BatchNorm call of a window gets a fixed slot in one arena for its (scale, shift) and (mean, invstd)
@@ -261,6 +262,7 @@ class WeightBank(object):
             off += 4 * s.h
         rows = [(s.layer_id, r) for s in ws for r in range(s.h)]
         self.work_ws = torch.tensor(rows, dtype=torch.int32).reshape(-1).to(device) if rows else None
+        self._ws_rows = rows
         self.n_ws = len(rows)
         self.device = device
         self.table = tab.to(device)
@@ -452,9 +454,15 @@ class WeightBank(object):
         for f in range(nf):
             self._deferred.append((spec, (call + f) if n > 1 else 0, dy, x, geo, st, f * dyb, f * xb))
 
-    def run_deferred_wgrads(self):
+    def run_deferred_wgrads(self, layers=None):
+        """Issue the queued weight-gradient launches; `layers` = (lo, hi): only those of layer ids lo <= id < hi (the
+        chunked bank backward), the others stay queued."""
         from .ops import _phase_array
-        pend, self._deferred = self._deferred, []
+        if layers is None:
+            pend, self._deferred = self._deferred, []
+        else:
+            pend = [e for e in self._deferred if layers[0] <= e[0].layer_id < layers[1]]
+            self._deferred = [e for e in self._deferred if not (layers[0] <= e[0].layer_id < layers[1])]
         if not pend:
             return
         cur = torch.cuda.current_stream()
@@ -500,15 +508,63 @@ class WeightBank(object):
                 e[2].record_stream(cur)
                 e[3].record_stream(cur)
 
+    GRAD_CHUNKS = 4          # spans of the flat gradient handed to `grad_span_hook` as they complete
+
+    def _chunks(self, plan):
+        """Layer ranges of ~equal gradient size, each with its slice of the sn_backward work lists (both lists are in
+        layer order): [(layer lo, layer hi, grad lo, grad hi, inner row lo, n, apply row lo, n)]."""
+        ck = plan.get('chunks')
+        if ck is not None:
+            return ck
+        specs = self.specs
+        n = max(1, min(self.GRAD_CHUNKS, len(specs)))
+        target = self.grad_numel / float(n)
+        bounds, acc = [0], 0
+        for i, sp in enumerate(specs):
+            acc += sp.numel
+            if len(bounds) < n and acc >= target * len(bounds) and i + 1 < len(specs):
+                bounds.append(i + 1)
+        bounds.append(len(specs))
+        calls = plan['ncalls']
+        inner_rows = lambda sp: calls[sp.layer_id] * ((sp.numel + 8191) // 8192) if sp.spectral else 0
+        apply_rows = lambda sp: (sp.numel + 255) // 256
+        ck, i0, a0 = [], 0, 0
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            ni = sum(inner_rows(sp) for sp in specs[lo:hi])
+            na = sum(apply_rows(sp) for sp in specs[lo:hi])
+            ck.append((lo, hi, specs[lo].grad_off, specs[hi - 1].grad_off + specs[hi - 1].numel, i0, ni, a0, na))
+            i0 += ni
+            a0 += na
+        assert i0 == plan['n_inner'] and a0 == self.n_apply
+        plan['chunks'] = ck
+        return ck
+
     def backward(self, plan):
-        """dW~ arena -> list of weight_bar gradients (views of one flat fp32 buffer)."""
-        self.run_deferred_wgrads()
+        """dW~ arena -> list of weight_bar gradients (views of one flat fp32 buffer).
+
+        Runs in GRAD_CHUNKS layer ranges: the deferred weight-gradient launches of a range, its SpectralNorm backward,
+        then `grad_span_hook(flat, lo, hi)` -- tcvom_amd.ddp.GradientAverager starts the all-reduce of that span of the
+        flat buffer there, so the collective of one range overlaps the weight-gradient kernels of the next
+        (DDP's bucketed overlap, train_ddp.py:275-280)."""
         grad = torch.empty(self.grad_numel, dtype=torch.float32, device=self.device)
-        L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), L.ptr(plan['work_inner']), plan['n_inner'],
-               L.ptr(self.work_apply), self.n_apply, L.ptr(plan['ncalls_dev']), L.ptr(self.dw_arena), self.dw_stride,
-               L.ptr(self.inner), self.max_calls, L.ptr(grad), L.stream_ptr())
-        if self.n_ws:
-            L.call('tcvom_ws_backward', L.ptr(self.table), L.ptr(self.work_ws), self.n_ws, L.ptr(grad), L.stream_ptr())
+        st = L.stream_ptr()
+        hook = self.grad_span_hook
+        chunks = self._chunks(plan) if hook is not None else [(0, len(self.specs), 0, self.grad_numel, 0, plan['n_inner'], 0, self.n_apply)]
+        for lo, hi, g0, g1, i0, ni, a0, na in chunks:
+            self.run_deferred_wgrads(None if len(chunks) == 1 else (lo, hi))
+            wi = C.c_void_p(plan['work_inner'].data_ptr() + 12 * i0) if ni else None
+            wa = C.c_void_p(self.work_apply.data_ptr() + 8 * a0)
+            L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), wi, ni, wa, na, L.ptr(plan['ncalls_dev']),
+                   L.ptr(self.dw_arena), self.dw_stride, L.ptr(self.inner), self.max_calls, L.ptr(grad), st)
+            if self.n_ws:
+                rows = [(i, r) for i, r in self._ws_rows if lo <= i < hi]
+                if rows:
+                    w0 = self._ws_rows.index(rows[0])
+                    L.call('tcvom_ws_backward', L.ptr(self.table), C.c_void_p(self.work_ws.data_ptr() + 8 * w0), len(rows),
+                           L.ptr(grad), st)
+            if hook is not None:
+                hook(grad, g0, g1)
+        self.run_deferred_wgrads()                     # (nothing left unless a layer id fell outside the ranges)
         return [grad[s.grad_off:s.grad_off + s.numel].view(s.weight.shape) for s in self.specs]
 
 

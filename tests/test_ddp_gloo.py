@@ -73,3 +73,78 @@ def test_two_rank_gradient_average_and_broadcast():
         expect.append(torch.full((p.numel(),), (r0 + r1) / 2))
     assert torch.allclose(g0, torch.cat(expect))
     assert l0 == l1 == 0.5
+
+
+def _overlap_worker(rank, world, port, q):
+    """The overlapped path: the bank calls back per finished span of its flat gradient (here a stand-in with the same
+    contract as WeightBank.backward), the all-reduce of a span starts inside the callback, average() waits and reduces
+    the remainder."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tcvom_amd.ddp import GradientAverager
+
+    class Bank(object):
+        grad_span_hook = None
+
+    bank = Bank()
+    sizes = [50000, 30000, 20000, 40000, 10000]                   # five "layers", handed over in 3 spans
+    ps = [nn.Parameter(torch.zeros(n)) for n in sizes] + [nn.Parameter(torch.zeros(7))]
+    av = GradientAverager(ps, banks=[bank])
+    assert bank.grad_span_hook is not None
+    results = []
+    for step in range(2):
+        for p in ps:
+            p.grad = None                                          # zero_grad(set_to_none=True)
+        flat = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1) + step
+        started = []
+        for lo, hi in ((0, 80000), (80000, 100000), (100000, 150000)):
+            bank.grad_span_hook(flat, lo, hi)                      # "backward" finished this span
+            started.append(len(av._early))
+        off = 0
+        for p, n in zip(ps, sizes):
+            p.grad = flat[off:off + n]
+            off += n
+        ps[5].grad = torch.full((7,), float(rank + 1))
+        av.average()
+        results.append((started, av.early_spans, av.last_plan, flat.clone(), ps[5].grad.clone(),
+                        [p.grad.data_ptr() - flat.data_ptr() for p in ps[:5]]))
+    # a parameter that kept its old .grad: autograd would have ADDED the new values after the early all-reduce started
+    for p in ps:
+        p.grad = None
+    flat = torch.ones(sum(sizes))
+    bank.grad_span_hook(flat, 0, 150000)
+    off = 0
+    for p, n in zip(ps, sizes):
+        p.grad = flat[off:off + n]
+        off += n
+    ps[1].grad = ps[1].grad + 1.0                                  # not a view of the reduced buffer any more
+    try:
+        av.average()
+        stale = 'no error'
+    except AssertionError as e:
+        stale = str(e)
+    q.put((rank, results, stale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_gradient_spans():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    base = torch.arange(150000, dtype=torch.float32)
+    for rank, results, stale in res:
+        assert 'set_to_none' in stale
+        for step, (started, early, plan, flat, small, offs) in enumerate(results):
+            assert started == [1, 2, 3] and early == 3             # one collective per span, started before average()
+            assert plan == (150000, 3, 7, 1)                       # 3 early spans in place + one packed bucket
+            assert torch.equal(flat, base * 1.5 + step)            # mean of (x + step, 2x + step)
+            assert torch.equal(small, torch.full((7,), 1.5))
+            assert offs == [0, 200000, 320000, 400000, 560000]     # .grad still aliases the flat buffer

@@ -437,4 +437,5 @@ def test_bench_two_ranks_dry_run():
     assert len(lines) == 1, out.stdout[-2000:]
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['global_batch_clips'] == 2 and res['value'] > 0 and res['scaling'] == 'weak'
+    assert res['dist']['world_size'] == 2 and res['dist']['grad_spans_overlapped_with_backward'] >= 3, res['dist']
     assert np.isfinite(res['final_loss'])

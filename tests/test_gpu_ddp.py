@@ -45,6 +45,39 @@ def test_rccl_gradient_average_and_sync_bn_on_one_rank():
             assert torch.equal(p.grad, torch.zeros_like(p) if w is None else w)       # AVG over one rank = identity
         assert params[0].grad.data_ptr() == arena.data_ptr()                           # reduced in place
         assert float(reduce_tensor(torch.tensor(3.0, device=dev))) == 3.0
+        # the overlapped path on a real network: the bank hands over its flat gradient in >= 3 spans, each all-reduced
+        # (RCCL, in place) from inside backward; the result equals the plain backward
+        from tcvom_amd.ddp import banks_of
+        from tcvom_amd.facade import FullModel_VMD, train_step_loss
+        from tcvom_amd.synthetic import formula_tensor, synthetic_window
+        a, fg, bg = [t.to(dev) for t in synthetic_window(1, 3, 128, 160, seed=3)]
+        model = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+        model.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in model.NET.state_dict().items()})
+        model = model.to(dev).train()
+        ps = [p for p in model.parameters() if p.requires_grad]
+        banks = banks_of(model)
+        assert len(banks) == 1
+        bank = banks[0]
+        av2 = GradientAverager(ps, banks=banks, force=True)
+        train_step_loss(model(a, fg, bg)).backward()
+        spans = [(e[3], e[4]) for e in av2._early]
+        av2.average()
+        torch.cuda.synchronize()
+        assert av2.early_spans >= 3 and av2.last_plan[1] >= 3, (av2.early_spans, av2.last_plan)
+        assert spans[0][0] == 0 and sum(n for _, n in spans) == bank.grad_numel                    # the spans tile the flat gradient
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        assert not bank._deferred                                                                   # every weight gradient was issued
+        assert all(bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0 for p in ps if p.grad is not None)
+        # the layer-range form of the SpectralNorm backward equals the single-launch form (same dW~ arena; the inner products
+        # <dW~, u v^T> are accumulated with fp32 atomics, hence not bit for bit; the
+        # whole-network gradients of two passes are not comparable at this size: their atomics reorder and the 4x5-pixel
+        # BatchNorms amplify that)
+        plan = bank.current_plan
+        chunked = torch.cat([g.reshape(-1) for g in bank.backward(plan)])
+        bank.grad_span_hook = None
+        whole = torch.cat([g.reshape(-1) for g in bank.backward(plan)])
+        torch.cuda.synchronize()
+        assert float((chunked - whole).abs().max()) <= 1e-5 * float(whole.abs().max())
         m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4)).to(dev)
         broadcast_module_state(m)
         t = torch.ones(8, device=dev)

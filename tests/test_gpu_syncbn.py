@@ -110,9 +110,14 @@ def _window_worker(rank, world, port, out):
             return convert_sync_batchnorm(m) if sync else m
         clips = [[t.to(dev) for t in synthetic_window(1, 3, 128, 160, seed=20 + i)] for i in range(2)]
         m = make(True)
-        a, fg, bg = clips[rank]
+        assert m.NET.batched_frames                       # SyncBatchNorm keeps the frame-batched launches: the statistics of
+        a, fg, bg = clips[rank]                            # the 3 frames of a layer travel in ONE [3][2][C] all-reduce
         outs = m(a, fg, bg)
         alpha = outs[7].detach().float().clone()
+        from tcvom_amd.facade import train_step_loss
+        train_step_loss(outs).backward()                   # the backward collectives pair up on the two ranks as well
+        gnorm = torch.stack([p.grad.float().norm() for p in m.parameters() if p.grad is not None])
+        assert bool(torch.isfinite(gnorm).all()) and float(gnorm.max()) > 0
         if rank == 0:
             m2 = make(False)
             a2, fg2, bg2 = [torch.cat([clips[0][k], clips[1][k]], 0) for k in range(3)]

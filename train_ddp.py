@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 from models.model import FullModel_VMD
 from tcvom_amd.config import get_cfg_defaults
-from tcvom_amd.ddp import GradientAverager, broadcast_module_state, convert_sync_batchnorm, reduce_tensor
+from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm, reduce_tensor
 from tcvom_amd.optim import FusedAdam
 from tcvom_amd.synthetic import synthetic_window
 
@@ -191,7 +191,7 @@ def main(cfg_name, cfg, steps_per_epoch, frames):
         # learning rate, the epoch shuffle, the checkpoint numbering and the validation delay pick up where the run stopped
         optimizer.load_state_dict(torch.load(cfg.TRAIN.LOAD_OPT, map_location='cpu'))
         start_step = int(os.path.basename(cfg.TRAIN.LOAD_OPT).split('_')[-1][:-8])
-    averager = GradientAverager(params)
+    averager = GradientAverager(params, banks=banks_of(model))      # gradient spans all-reduced as the bank finishes them
     adjust_lr = STR_DICT[cfg.TRAIN.LR_STRATEGY]
     test_dataset, best_loss = None, 1e+8
     if cfg.DATASET.PATH:
