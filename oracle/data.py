@@ -3,10 +3,13 @@ the no_flow path — file-list neighbourhoods (`parse`, VMD.py:167-181), `img_cr
 `possible_pad` (VMD.py:187-200), the crop search of `shape_aug` (VMD.py:131-152) and `__getitem__` (VMD.py:202-301)
 without the imgaug colour / JPEG augmentation.
 
-Parity status: the reference module imports cv2 and imgaug, neither of which exists in this image, so it cannot be
-executed here: this restatement is pinned by construction only — every numeric step is the SAME torch call the
-reference makes (`F.interpolate(..., mode='bilinear', align_corners=True)`, `torch.floor(x + 0.5)`, `F.pad`) on the same
-uint8 pixel values (PIL decodes RGB(A); cv2 would give BGR(A), the channel order is swapped back below).
+Parity status: PINNED.  tests/golden/gen_data_golden.py imports the reference module in the build container behind import-time
+stubs of cv2 (imread through PIL, channels swapped to BGR(A)) and imgaug (identity augmenters) and stores what its parse /
+img_crop_and_resize / possible_pad / shape_aug / __getitem__ return on a tiny synthetic clip tree (tests/golden/data_loader.npz);
+tests/test_oracle_golden.py::test_data_loader_golden replays the same inputs through this file: bit exact, including the
+position of python's `random` after the crop search.  Every numeric step is the SAME torch call the reference makes
+(`F.interpolate(..., mode='bilinear', align_corners=True)`, `torch.floor(x + 0.5)`, `F.pad`) on the same uint8 pixel values
+(PIL decodes RGB(A); cv2 would give BGR(A), the channel order is swapped back below).
 """
 import os
 import random

@@ -64,8 +64,9 @@ class GradientAverager(object):
         self.force = force
         self._early = []         # [(flat view, work, storage ptr, first element, count)] started from the bank hooks
         self.early_spans = 0     # diagnostic: spans started before backward returned, last step
-        for bank in banks:
-            bank.grad_span_hook = self._on_span
+        if self._active():       # (a one-process run keeps the bank's single-launch backward)
+            for bank in banks:
+                bank.grad_span_hook = self._on_span
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)

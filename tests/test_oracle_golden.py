@@ -362,3 +362,60 @@ def test_single_image_fba_base():
     got = np.array([float(state[n].grad.double().norm()) for n in names])
     want = g['grad_norms']
     assert abs(np.linalg.norm(got) - np.linalg.norm(want)) <= 0.02 * np.linalg.norm(want)
+
+
+def test_data_loader_golden(tmp_path):
+    """oracle/data.py against the REFERENCE loader's outputs (tests/golden/gen_data_golden.py imports dataset/VMD.py behind
+    cv2 / imgaug stubs and calls parse, img_crop_and_resize, possible_pad, shape_aug and __getitem__ on a tiny clip tree).
+    Integer pixel values: bit exact, including where python's `random` stands after the crop search."""
+    import json
+    import os
+    import random
+    import sys
+    from oracle import data as odata
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    try:
+        import gen_data_golden as gen          # only its constants and write_tree(): the reference import lives in main()
+    finally:
+        sys.path.pop(0)
+    g = golden('data_loader')
+    fg, bg = g['fg'], g['bg']
+    root = str(tmp_path)
+    corr = gen.write_tree(root, gen.VIDEOS, fg, bg)
+    for length in (3, 5):
+        want = json.loads(bytes(g['parse_%d' % length]).decode())
+        assert odata.parse(corr, gen.VIDEOS, length) == want
+    assert list(g['plus1_shape']) == [gen.CROP[0] + 1, gen.CROP[1] + 1]
+    img = np.float32(fg[0, 1][..., [2, 1, 0]])
+    alpha = np.float32(fg[0, 1][..., 3:])
+    for i, (ph, pw, nh, nw) in enumerate(g['resize_cases'].tolist()):
+        n = None if nh < 0 else (nh, nw)
+        assert np.array_equal(odata.img_crop_and_resize(img, gen.CROP, ph, pw, n).numpy(), g['resize_img_%d' % i])
+        assert np.array_equal(odata.img_crop_and_resize(alpha, gen.CROP, ph, pw, n).numpy(), g['resize_a_%d' % i])
+    t3 = torch.from_numpy(img).permute(2, 0, 1)
+    t1 = torch.from_numpy(alpha).permute(2, 0, 1)
+    assert np.array_equal(odata.possible_pad(t3, gen.PAD_SHAPE, odata.IMG_PADDING_VALUE).numpy(), g['pad_img'])
+    assert np.array_equal(odata.possible_pad(t1, gen.PAD_SHAPE).numpy(), g['pad_a'])
+    f3 = [np.float32(fg[1, k][..., [2, 1, 0]]) for k in range(3)]
+    b3 = [np.float32(bg[1, k][..., ::-1]) for k in range(3)]
+    a3 = [np.float32(fg[1, k][..., 3:]) for k in range(3)]
+    for s in gen.SEEDS:
+        random.seed(s)
+        pfg, pbg, pa = odata.shape_aug(f3, b3, a3, gen.CROP, (gen.H, gen.W))
+        assert np.array_equal(torch.stack(pfg).numpy(), g['aug_fg_%d' % s])
+        assert np.array_equal(torch.stack(pbg).numpy(), g['aug_bg_%d' % s])
+        assert np.array_equal(torch.stack(pa).numpy(), g['aug_a_%d' % s])
+        assert random.random() == float(g['aug_next_random_%d' % s][0])       # the same draws were consumed
+    samples = odata.parse(corr, gen.VIDEOS, 3)
+    for idx in (0, 5):
+        got = odata.get_item(root, corr, samples[idx], 'val', gen.VAL_SHAPE, (gen.H, gen.W))
+        for t, k in zip(got, ('fg', 'bg', 'a')):
+            assert np.array_equal(t.numpy(), g['val_%d_%s' % (idx, k)]), (idx, k)
+        got = odata.get_item(root, corr, samples[idx], 'val', gen.PAD_SHAPE, (gen.H, gen.W), precomputed=True)
+        for t, k in zip(got, ('fg', 'bg', 'a')):
+            assert np.array_equal(t.numpy(), g['pad_%d_%s' % (idx, k)]), (idx, k)
+    for s in gen.SEEDS:
+        random.seed(s)
+        got = odata.get_item(root, corr, samples[3], 'train', gen.CROP, (gen.H, gen.W))
+        for t, k in zip(got, ('fg', 'bg', 'a')):
+            assert np.array_equal(t.numpy(), g['train_%d_%s' % (s, k)]), (s, k)
