@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_FWD_CONV_1080P = 1737.3      # non-GCA convolutions, forward
 GFLOP_FWD_GCA_1080P = 2106.3       # 6 guided-contextual-attention calls, forward (quadratic in pixels)
 GFLOP_WINDOW_1080P = 11179.81      # forward + backward
+GFLOP_WINDOW_FBA_1080P = 21200.0   # BASELINE config 5 (FBA+TAM): 2663 GFLOP fwd+bwd at 384x672 x 7.96 pixels
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 FULL_H, FULL_W = 1088, 1920
 PROFILE_DIR = os.path.join(ROOT, 'profiles')
@@ -56,22 +57,24 @@ def profile_traffic(variant):
     return None, os.path.basename(files[-1])
 
 
-def window_gflop(H, W):
+def window_gflop(H, W, config='gca'):
     """fwd+bwd GFLOP of one 3-frame window at HxW, scaled from the measured 1088x1920 figures."""
     r = (H * W) / float(FULL_H * FULL_W)
+    if config == 'fba':
+        return GFLOP_WINDOW_FBA_1080P * r          # no attention term quadratic in the pixels
     fwd = GFLOP_FWD_CONV_1080P * r + GFLOP_FWD_GCA_1080P * r * r
     return fwd * (GFLOP_WINDOW_1080P / (GFLOP_FWD_CONV_1080P + GFLOP_FWD_GCA_1080P))
 
 
-def build(device, H, W, seed):
+def build(device, H, W, seed, config='gca'):
     from models.model import FullModel_VMD
     from tcvom_amd.synthetic import formula_tensor, synthetic_window
-    model = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+    model = FullModel_VMD('vmn_fba' if config == 'fba' else 'vmn_gca', agg_window=7, dilate_kernel=12)
     model.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in model.NET.state_dict().items()})
     model = model.to(device).train()
-    if os.environ.get('TCVOM_FRAME_STREAMS', '1') == '0':      # profiling aid: serialise the frames on one stream
+    if os.environ.get('TCVOM_FRAME_STREAMS', '1') == '0' and hasattr(model.NET, 'frame_streams'):      # profiling aid
         model.NET.frame_streams = False
-    if os.environ.get('TCVOM_BATCHED_FRAMES', '1') == '0':     # A/B aid: frame-by-frame launches instead of frame-batched ones
+    if os.environ.get('TCVOM_BATCHED_FRAMES', '1') == '0' and hasattr(model.NET, 'batched_frames'):    # A/B aid
         model.NET.batched_frames = False
     a, fg, bg = synthetic_window(1, 3, H, W, seed=seed)
     return model, a.to(device), fg.to(device), bg.to(device)
@@ -95,6 +98,40 @@ def igemm_profile(step_fn):
         n, t, g = agg.get(var, (0, 0.0, 0.0))
         agg[var] = (n + 1, t + ms, g + gflop)
     return agg
+
+
+def cpu_baseline_fba(sample_hw=(544, 960), threads=32):
+    """Config 5 (FBA+TAM): the oracle's fba_window_forward + backward on a BOUNDED sample (one 3x544x960 window after a
+    small warm-up; the ResNet-50 GN+WS trunk at os8 makes a full 1080p pass minutes long on the host), scaled to
+    3x1088x1920 by the pixel ratio (the FBA path has no term quadratic in the pixels)."""
+    import oracle.fba_net as fba
+    from tcvom_amd.synthetic import formula_tensor, synthetic_window
+    import numpy as np
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, threads)
+    torch.set_num_threads(cores)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'fba_state_keys.npz'))
+    state = {}
+    for k, shp in zip(g['keys'], g['shapes']):
+        shape = tuple(int(d) for d in str(shp).split(',')) if str(shp) else ()
+        state[str(k)] = formula_tensor(str(k), shape).requires_grad_(True)
+
+    def one(H, W):
+        a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
+        t0 = time.time()
+        out, _ = fba.fba_window_forward(state, a, fg, bg, window=7, dilate_kernel=12)
+        (out[0].mean() + out[1].mean() + out[2].mean() + 0.5 * out[3].mean() + 0.25 * out[4].mean()).backward()
+        for v in state.values():
+            v.grad = None
+        return time.time() - t0
+
+    one(128, 160)
+    H, W = sample_hw
+    dt = one(H, W)
+    ratio = window_gflop(H, W, 'fba') / window_gflop(FULL_H, FULL_W, 'fba')
+    return {'value': round(ratio / dt, 6), 'unit': 'windows/s', 'cores': cores, 'host_logical_cores': host_cores, 'kind': 'port',
+            'sample': 'one fwd+bwd pass over a 3x%dx%d window in %.1f s on %d threads after a 3x128x160 warm-up, scaled to '
+                      '3x%dx%d by the pixel ratio %.4f' % (H, W, dt, cores, FULL_H, FULL_W, ratio)}
 
 
 def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
@@ -144,6 +181,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--height', type=int, default=FULL_H)
     ap.add_argument('--width', type=int, default=FULL_W)
+    ap.add_argument('--config', choices=('gca', 'fba'), default='gca',
+                    help='gca: the headline GCA+TAM window (BASELINE.json configs[2]); fba: FBA+TAM (configs[4], the heaviest base)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--sync-bn', action='store_true',
@@ -169,7 +208,8 @@ def main():
     from tcvom_amd.facade import train_step_loss
     from tcvom_amd.optim import FusedAdam
     H, W = args.height, args.width
-    model, a, fg, bg = build(device, H, W, seed=rank)
+    model, a, fg, bg = build(device, H, W, seed=rank, config=args.config)
+    base = 'FBA+TAM' if args.config == 'fba' else 'GCA+TAM'
     if args.sync_bn:
         convert_sync_batchnorm(model)
     broadcast_module_state(model)
@@ -209,16 +249,20 @@ def main():
     result = None
     if rank == 0:
         win_per_s = world * args.steps / elapsed
-        gflop = window_gflop(H, W)
+        gflop = window_gflop(H, W, args.config)
         result = {
-            'metric': '1080p 3-frame windows/sec (fwd+bwd) GCA+TAM' if (H, W) == (FULL_H, FULL_W)
-                      else '%dx%d 3-frame windows/sec (fwd+bwd) GCA+TAM' % (H, W),
+            'metric': '1080p 3-frame windows/sec (fwd+bwd) %s' % base if (H, W) == (FULL_H, FULL_W)
+                      else '%dx%d 3-frame windows/sec (fwd+bwd) %s' % (H, W, base),
             'value': round(win_per_s, 4), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
-                                   '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
-                                   'formula-initialised weights, train mode' % (H, W),
+            'config': {'workload': ('GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
+                                    '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
+                                    'formula-initialised weights, train mode' % (H, W)) if args.config == 'gca' else
+                                   ('FBA+TAM (vmn_fba: ResNet-50 GN+WS dilated os8, PPM, 7-channel head, 11-channel input with the '
+                                    '2-scale trimap channels) fwd+bwd+grad-allreduce+Adam, L_alpha_comp+L_lap+L_grad+0.5L_dt+0.25L_att, '
+                                    'one 3-frame %dx%d window per GPU per step, formula-initialised weights, train mode; BASELINE '
+                                    'config 5 names fp16: the engine computes in bf16 (same MFMA rate, no loss scaling needed)' % (H, W)),
                        'global_batch_clips': world, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn)},
             'final_loss': round(final_loss, 6),
             'dist': {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,
@@ -246,7 +290,7 @@ def main():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline((H, W))
+            result['cpu_baseline'] = cpu_baseline((H, W)) if args.config == 'gca' else cpu_baseline_fba()
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -47,7 +47,7 @@ int tcvom_abi_version(void);
  * (sum, sum of squares per channel per 64-pixel group).                       */
 #define TCVOM_MAX_TAPS 32
 typedef struct {
-    int32_t N, H, W, C;          /* input NHWC; C power of two >= 8 unless ntaps == 1 */
+    int32_t N, H, W, C;          /* input NHWC; C a multiple of 8 (ntaps * C a multiple of 64) */
     int32_t OH, OW, K;           /* output tensor dims; K = output channels (multiple of 4) */
     int32_t PH, PW;              /* phase grid */
     int32_t in_step, out_step, out_off_h, out_off_w;

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         // bit positions of this tap in a row's validity word: rows bit dh+8, columns bit 16+dw+8 (|dh|,|dw| <= 7)
         taps[tid] = make_int4((dh * W + dw) * C, ok ? d.tap_w[tid] * C : -1, dh + 8, ok ? dw + 8 : 31);
     }
-    const int cshift = (d.ntaps == 1) ? 31 : __builtin_ctz(C);
-    const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
+    // tap = kk / C through a multiply-high (exact for kk < 2^32 / C; one tap: magic 0 -> tap 0): C is any multiple of 8
+    const unsigned cmagic = (d.ntaps == 1) ? 0u : (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
     const int p0 = bx * TN;
     const int m0 = blockIdx.y * TM;
     const bool small_p = Ptot < (1 << 24);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 #define NT_ISSUE_STAGE(s, slot)                                                                            \
     {                                                                                                      \
         const int kk = (s) * 64 + kc8;                                                                     \
-        const int tap = kk >> cshift, c0 = kk & cmask;                                                     \
+        const int tap = (int)__umulhi((unsigned)kk, cmagic), c0 = kk - tap * C;                            \
         const int tin = reinterpret_cast<const int*>(taps)[tap * 4 + 0];                                   \
         const int tw = reinterpret_cast<const int*>(taps)[tap * 4 + 1];                                    \
         bf16raw* abase = lds + (slot) * SLOT;                                                              \
@@ -447,7 +447,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
             TCVOM_CHECK_ARG(d->tap_dh[t] >= -8 && d->tap_dh[t] <= 7 && d->tap_dw[t] >= -8 && d->tap_dw[t] <= 7,
                             "conv_igemm: tap %d offset (%d,%d) outside [-8,7]", t, d->tap_dh[t], d->tap_dw[t]);
         TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 64 == 0, "conv_igemm: ntaps*C=%d not a multiple of 64", d->ntaps * d->C);
-        TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "conv_igemm: C=%d must be a power of two >= 8", d->C);
+        TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && d->C % 8 == 0 && d->C <= 32768), "conv_igemm: C=%d must be a multiple of 8 (8..32768)", d->C);
         TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
         TCVOM_CHECK_ARG(d->C % 8 == 0, "conv_igemm: C=%d must be a multiple of 8", d->C);
         TCVOM_CHECK_ARG(nphase == 1 || (d->batch == descs[0].batch && d->K == descs[0].K), "conv_igemm: phases must share K and the batch count");
@@ -592,8 +592,8 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
     __syncthreads();
 
     const int C = d.C, H = d.H, W = d.W, K = d.K;
-    const int cshift = (d.ntaps == 1) ? 31 : __builtin_ctz(C);
-    const int cmask = (d.ntaps == 1) ? 0x7fffffff : (C - 1);
+    // tap = kk / C through a multiply-high (exact for kk < 2^32 / C; one tap: magic 0 -> tap 0): C is any multiple of 8
+    const unsigned cmagic = (d.ntaps == 1) ? 0u : (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
     const int ncols = d.ntaps * C;
     const int Ptot = d.N * d.PH * d.PW;
     const int pbeg = chunk * pchunk;
@@ -630,8 +630,8 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
         b_ok[it] = false;
         b_c0[it] = b_dh[it] = b_dw[it] = 0;
         if (ii < TB::NI && col < ncols) {
-            const int tap = col >> cshift;
-            b_c0[it] = col & cmask;
+            const int tap = (int)__umulhi((unsigned)col, cmagic);
+            b_c0[it] = col - tap * C;
             b_dh[it] = taps[tap * 3 + 0];
             b_dw[it] = taps[tap * 3 + 1];
             b_ok[it] = taps[tap * 3 + 2] >= 0;
@@ -770,7 +770,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
     for (int b = 0; b < NI; ++b) {
         const int col = n0 + wn * WN + b * 32 + (lane & 31);
         if (col >= ncols) continue;
-        const int tap = col >> cshift, cc = col & cmask;
+        const int tap = (int)__umulhi((unsigned)col, cmagic), cc = col - tap * C;
         const int ws = taps[tap * 3 + 2];
         if (ws < 0) continue;
 #pragma unroll
@@ -838,7 +838,7 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     for (int i = 0; i < nphase; ++i) {
         const tcvom_conv_desc* d = descs + i;
         TCVOM_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= TCVOM_MAX_TAPS, "wgrad_igemm: ntaps=%d", d->ntaps);
-        TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && (d->C & (d->C - 1)) == 0), "wgrad_igemm: C=%d must be a power of two >= 8", d->C);
+        TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && d->C % 8 == 0 && d->C <= 32768), "wgrad_igemm: C=%d must be a multiple of 8 (8..32768)", d->C);
         TCVOM_CHECK_ARG(d->C % 8 == 0 && ldy % 8 == 0, "wgrad_igemm: C=%d ldy=%d must be multiples of 8", d->C, ldy);
         TCVOM_CHECK_ARG(d->K == descs[0].K && d->C == descs[0].C && d->ntaps == descs[0].ntaps,
                         "wgrad_igemm: phases must share K, C and the tap count");

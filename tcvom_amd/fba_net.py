@@ -11,7 +11,8 @@ The module tree only HOLDS the parameters; the math runs in libtcvom_hip.so thro
     per-sample group statistics combined from the conv epilogue's channel sums (csrc/norm.hip gn_*),
   * every frame (and batch sample) of a window goes through a layer in ONE launch (frames_per_op),
   * the 7x7 stride-2 stem runs as a 4x4 conv over the 2x2 space-to-depth input that tcvom_fba_input writes,
-  * the concat inputs of the decoder (3072 / 320 / 72 channels) are zero-padded to 4096 / 512 / 128 channels.
+  * the concat inputs of the decoder keep their 3072 / 320 channels (the conv engine takes any multiple of 8); only the 72-channel
+    input of conv_up4 is zero-padded to 128 (9 taps x 128 and the 16 zero-padded taps 72 channels would need are the same work).
 """
 import torch
 import torch.nn as nn
@@ -136,10 +137,10 @@ class vmn_fba_decoder(nn.Module):
 
         for i in range(4):
             reg('decoder.ppm.%d.1' % i, self.ppm[i][1], self.ppm[i][2], 'frame')
-        reg('decoder.conv_up1.0', self.conv_up1[0], self.conv_up1[1], 'frame', cpad=4096)
+        reg('decoder.conv_up1.0', self.conv_up1[0], self.conv_up1[1], 'frame')
         reg('decoder.conv_up1.3', self.conv_up1[3], self.conv_up1[4], 'frame')
         reg('decoder.conv_up2.0', self.conv_up2[0], self.conv_up2[1], 'tail')
-        reg('decoder.conv_up3.0', self.conv_up3[0], self.conv_up3[1], 'tail', cpad=512)
+        reg('decoder.conv_up3.0', self.conv_up3[0], self.conv_up3[1], 'tail')
         reg('decoder.conv_up4.0', self.conv_up4[0], None, 'tail', ws=False, cpad=128)
         reg('decoder.conv_up4.2', self.conv_up4[2], None, 'tail', ws=False)
         object.__setattr__(self, '_cfgs', cfgs)
@@ -158,7 +159,7 @@ class vmn_fba_decoder(nn.Module):
         cf = self._cfgs
         pooled = ops.pyramid_pool(conv5, PPM_SCALES)
         maps = [ops.conv_bn_act(cf['decoder.ppm.%d.1' % i], pooled[i], token, training) for i in range(4)]
-        x = ops.pyramid_concat(4096, conv5, maps)
+        x = ops.pyramid_concat(3072, conv5, maps)
         x = ops.conv_bn_act(cf['decoder.conv_up1.0'], x, token, training)
         return ops.conv_bn_act(cf['decoder.conv_up1.3'], x, token, training)
 
@@ -173,7 +174,7 @@ class vmn_fba_decoder(nn.Module):
         """The three up-sampling stages and the fused head (models/FBA/models.py:326-353) -> pred fp32 [F, 7, H, W]."""
         cf = self._cfgs
         x = ops.conv_bn_act(cf['decoder.conv_up2.0'], ops.up2_concat(512, x, os4), token, training)
-        x = ops.conv_bn_act(cf['decoder.conv_up3.0'], ops.up2_concat(512, x, os2), token, training)
+        x = ops.conv_bn_act(cf['decoder.conv_up3.0'], ops.up2_concat(320, x, os2), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up4.0'], ops.up2_concat(128, x, extras), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up4.2'], x, token, training)
         return ops.fba_head(x, self.conv_up4[4].weight, self.conv_up4[4].bias, img)

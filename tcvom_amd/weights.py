@@ -56,8 +56,7 @@ class ConvSpec(object):
         self.spectral = u is not None
         self.group = group                   # 'frame' (S calls per window) | 'tail' (S-2 calls)
         self.needs_dgrad = needs_dgrad
-        # cpad: channels of the (zero-padded) input buffer; the engine wants a power of two for multi-tap convs, so the
-        # concat inputs of the FBA decoder (3072, 320, 72 channels) are padded to 4096 / 512 / 128
+        # cpad: channels of the (zero-padded) input buffer: a multiple of 8 (16-byte channel chunks)
         self.cpad = max(8, _r8(self.C)) if cpad is None else int(cpad)
         assert self.cpad >= self.C and self.cpad % 8 == 0
         if stem:

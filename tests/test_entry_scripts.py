@@ -439,3 +439,19 @@ def test_bench_two_ranks_dry_run():
     assert res['n_gpus'] == 2 and res['config']['global_batch_clips'] == 2 and res['value'] > 0 and res['scaling'] == 'weak'
     assert res['dist']['world_size'] == 2 and res['dist']['grad_spans_overlapped_with_backward'] >= 3, res['dist']
     assert np.isfinite(res['final_loss'])
+
+
+@pytest.mark.gpu
+def test_bench_fba_config_line():
+    """`bench.py --config fba` (BASELINE.json config 5) prints the same one-line JSON contract as the headline run."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--config', 'fba', '--steps', '2', '--warmup', '1', '--height', '128',
+           '--width', '160', '--no-cpu-baseline']
+    out = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert 'FBA+TAM' in res['metric'] and res['unit'] == 'windows/s' and res['value'] > 0 and res['n_gpus'] == 1
+    assert res['roofline']['bound'] == 'mfma' and res['roofline']['achieved'] > 0 and 'all_igemm' in res['roofline']

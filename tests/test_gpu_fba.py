@@ -371,3 +371,31 @@ def test_window_batch_of_two_against_oracle():
         assert mse <= 1e-4, '%s MSE %.3e' % (nm, mse)
     assert not torch.allclose(out[7][0], out[7][1])
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fm.NET.parameters())
+
+
+def test_window_1080p_forward_backward():
+    """BASELINE.json config 5 at its stated size: FBA+TAM forward + backward over one 3-frame 1088x1920 window (the goldens pin
+    the arithmetic at 64..96 pixels; this one exercises the full-size launch geometry: 2048-channel os8 trunk, the 3072-channel
+    pyramid concat, 32-bit offsets).  Size-independent properties: alpha in [0, 1] and equal to the ground truth on the known
+    pixels the fusion clamps, F / B in [0, 1], finite losses, a finite non-zero gradient for every parameter, and the same
+    result (to rounding) when the window is run twice."""
+    from tcvom_amd.facade import train_step_loss
+    fm = _build('full', 12, 3)
+    a, fg, bg = [t.to(DEV) for t in synthetic_window(1, 3, 1088, 1920, seed=5)]
+    out = fm(a, fg, bg)
+    loss = train_step_loss(out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and float(loss) > 0
+    for i in (7, 10, 11):                                   # alphas, Fs, Bs
+        t = out[i]
+        assert bool(torch.isfinite(t).all()) and float(t.min()) >= 0.0 and float(t.max()) <= 1.0
+    grads = [p.grad for p in fm.NET.parameters()]
+    assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads)
+    assert sum(float(g.abs().sum()) > 0 for g in grads) >= 0.95 * len(grads)
+    first = out[7].detach().clone()
+    with torch.no_grad():
+        again = fm(a, fg, bg)[7]
+    # GroupNorm has no running statistics and weight standardisation no power iteration: a second pass is the same function,
+    # up to the summation order of the fp32 atomics in the pyramid pooling (a flipped bf16 rounding moves single pixels)
+    assert float((again - first).abs().mean()) <= 1e-4 and float((again - first).abs().max()) <= 0.1
