@@ -125,6 +125,29 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
     return act == 1 ? (pre > 0.f ? 1.f : 0.f) : (act == 2 ? (pre > 0.f ? 1.f : 0.2f) : (act == 3 ? (pre > 0.f ? 1.f : 0.01f) : 1.f));
 }
 
+// negative-side slope of the activation (1 = none): act(x) = x > 0 ? x : slope * x, act'(x) = x > 0 ? 1 : slope -- branch-free
+__device__ __forceinline__ float act_slope(int act) { return act == 1 ? 0.f : (act == 2 ? 0.2f : (act == 3 ? 0.01f : 1.f)); }
+// 8 consecutive per-channel coefficients as two 16-byte loads (the vectors are 32-byte aligned: C and the slot strides are
+// multiples of 8 floats); all loads of a thread's coefficient set are issued before the first one is waited for
+__device__ __forceinline__ void load_coef8(const float* __restrict__ p, float* f) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <bool YF32> struct YRaw { uint4 a; };
+template <> struct YRaw<true> { float4 a, b; };
+template <bool YF32>
+__device__ __forceinline__ YRaw<YF32> load_yraw(const void* __restrict__ y, int64_t v) {
+    YRaw<YF32> r;
+    if constexpr (YF32) { const float4* p = reinterpret_cast<const float4*>(y) + 2 * v; r.a = p[0]; r.b = p[1]; }
+    else r.a = reinterpret_cast<const uint4*>(y)[v];
+    return r;
+}
+template <bool YF32>
+__device__ __forceinline__ void unpack_yraw(const YRaw<YF32>& r, float* f) {
+    if constexpr (YF32) { f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w; }
+    else unpack8(r.a, f);
+}
+
 // A block owns a contiguous pixel range; a thread owns ONE channel octet for the whole range (its 16 scale/shift
 // values live in registers) and walks the pixels with stride 256/C8: every access is a 16-byte load/store and
 // consecutive lanes cover consecutive 16-byte chunks of a pixel row.
@@ -140,25 +163,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     scale_shift += blockIdx.y * slot_stride;
     const int64_t fo = (int64_t)blockIdx.y * P * C8;
     float sc[8], sh[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = scale_shift[oct * 8 + k]; sh[k] = scale_shift[C + oct * 8 + k]; }
+    load_coef8(scale_shift + oct * 8, sc);
+    load_coef8(scale_shift + C + oct * 8, sh);
+    const float slope = act_slope(act);
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    for (int64_t p = pbeg + prow; p < pend; p += RP) {
-        const int64_t v = fo + p * C8 + oct;
+    // two-deep software pipeline: the loads of pixel row p + RP are in flight while row p is computed and stored
+    int64_t p = pbeg + prow;
+    if (p >= pend) return;
+    int64_t v = fo + p * C8 + oct;
+    YRaw<YF32> yr = load_yraw<YF32>(y, v);
+    uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0}, q2 = res2 ? res2[v] : uint4{0, 0, 0, 0};
+    while (true) {
+        const int64_t pn = p + RP;
+        const bool more = pn < pend;
+        const int64_t vn = fo + (more ? pn : p) * C8 + oct;
+        const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
+        const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0}, n2 = res2 ? res2[vn] : uint4{0, 0, 0, 0};
         float f[8], r1[8], r2[8];
-        load_y8<YF32>(y, v, f);
-        if (res1) unpack8(res1[v], r1);
-        if (res2) unpack8(res2[v], r2);
+        unpack_yraw<YF32>(yr, f);
+        unpack8(q1, r1);
+        unpack8(q2, r2);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float x = f[k] * sc[k] + sh[k];
-            if (res1) x += r1[k];
-            x = act_fwd(x, act);
-            if (res2) x += r2[k];
-            f[k] = x;
+            float x = f[k] * sc[k] + sh[k] + r1[k];
+            x = x > 0.f ? x : slope * x;
+            f[k] = x + r2[k];
         }
         z[v] = pack8(f);
+        if (!more) break;
+        p = pn; v = vn; yr = yn; q1 = n1; q2 = n2;
     }
 }
 
@@ -182,28 +216,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const int c0 = oct * 8;
     float sg[8], sx[8], sc[8], sh[8], mu[8], is[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        sg[k] = 0.f; sx[k] = 0.f;
-        sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k];
-        mu[k] = saved[c0 + k]; is[k] = saved[C + c0 + k];
-    }
+    for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sx[k] = 0.f; }
+    load_coef8(scale_shift + c0, sc);
+    load_coef8(scale_shift + C + c0, sh);
+    load_coef8(saved + c0, mu);
+    load_coef8(saved + C + c0, is);
+    const float slope = act_slope(act);
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    if (prow < RP) {
-        for (int64_t p = pbeg + prow; p < pend; p += RP) {
-            const int64_t v = fo + p * C8 + oct;
+    if (prow < RP && pbeg + prow < pend) {
+        // two-deep software pipeline (see bn_apply_kernel)
+        int64_t p = pbeg + prow;
+        int64_t v = fo + p * C8 + oct;
+        uint4 qg = dz[v];
+        YRaw<YF32> yr = load_yraw<YF32>(y, v);
+        uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
+        while (true) {
+            const int64_t pn = p + RP;
+            const bool more = pn < pend;
+            const int64_t vn = fo + (more ? pn : p) * C8 + oct;
+            const uint4 ng = dz[vn];
+            const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
+            const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
             float g[8], yy[8], r1[8];
-            unpack8(dz[v], g);
-            load_y8<YF32>(y, v, yy);
-            if (res1) unpack8(res1[v], r1);
+            unpack8(qg, g);
+            unpack_yraw<YF32>(yr, yy);
+            unpack8(q1, r1);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float pre = yy[k] * sc[k] + sh[k];
-                if (res1) pre += r1[k];
-                const float gg = g[k] * act_grad(pre, act);
+                const float pre = yy[k] * sc[k] + sh[k] + r1[k];
+                const float gg = g[k] * (pre > 0.f ? 1.f : slope);
                 sg[k] += gg;
                 sx[k] += gg * (yy[k] - mu[k]) * is[k];
             }
+            if (!more) break;
+            p = pn; qg = ng; yr = yn; q1 = n1;
         }
     }
     float* r_g = red;                 // [256][8]
@@ -289,26 +336,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     coef += (int64_t)blockIdx.y * 3 * C;
     const int64_t fo = (int64_t)blockIdx.y * P * C8;
     float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], gi[8];
+    load_coef8(scale_shift + oct * 8, sc);
+    load_coef8(scale_shift + C + oct * 8, sh);
+    load_coef8(saved + oct * 8, mu);
+    load_coef8(saved + C + oct * 8, is);
+    load_coef8(coef + oct * 8, c1);
+    load_coef8(coef + C + oct * 8, c2);
+    load_coef8(coef + 2 * C + oct * 8, gi);
+    if (!training) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = oct * 8 + k;
-        sc[k] = scale_shift[c]; sh[k] = scale_shift[C + c];
-        mu[k] = saved[c]; is[k] = saved[C + c];
-        c1[k] = training ? coef[c] : 0.f; c2[k] = training ? coef[C + c] : 0.f; gi[k] = coef[2 * C + c];
+        for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; }
     }
+    const float slope = act_slope(act);
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    for (int64_t p = pbeg + prow; p < pend; p += RP) {
-        const int64_t v = fo + p * C8 + oct;
+    int64_t p = pbeg + prow;
+    if (p >= pend) return;
+    // two-deep software pipeline (see bn_apply_kernel)
+    int64_t v = fo + p * C8 + oct;
+    uint4 qg = dz[v];
+    YRaw<YF32> yr = load_yraw<YF32>(y, v);
+    uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
+    while (true) {
+        const int64_t pn = p + RP;
+        const bool more = pn < pend;
+        const int64_t vn = fo + (more ? pn : p) * C8 + oct;
+        const uint4 ng = dz[vn];
+        const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
+        const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
         float g[8], yy[8], r1[8], o[8];
-        unpack8(dz[v], g);
-        load_y8<YF32>(y, v, yy);
-        if (res1) unpack8(res1[v], r1);
+        unpack8(qg, g);
+        unpack_yraw<YF32>(yr, yy);
+        unpack8(q1, r1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float pre = yy[k] * sc[k] + sh[k];
-            if (res1) pre += r1[k];
-            const float gg = g[k] * act_grad(pre, act);
+            const float pre = yy[k] * sc[k] + sh[k] + r1[k];
+            const float gg = g[k] * (pre > 0.f ? 1.f : slope);
             g[k] = gg;
             const float xh = (yy[k] - mu[k]) * is[k];
             o[k] = gi[k] * gg - c1[k] - xh * c2[k];
@@ -316,6 +379,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         }
         dy[v] = pack8(o);
         if (dres1) dres1[v] = pack8(g);
+        if (!more) break;
+        p = pn; v = vn; qg = ng; yr = yn; q1 = n1;
     }
 }
 
