@@ -10,6 +10,7 @@
 // stage 1 (only when there are many groups): [G][2][C] fp32 -> [BN_SLICES][2][C] fp64, slice s sums groups
 // g = s, s + BN_SLICES, ...  One block = 32 channels x 8 sub-slices of one slice; grid (C/32, BN_SLICES).
 #define BN_SLICES 64
+#define FIN_SL 32           // sub-slices (of 32 channels each) per block of the finalize kernels: 1024 threads, 4 load chains each
 __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __restrict__ partial, int G, int C,
                                                                 double* __restrict__ out) {
     __shared__ double s1[8][32], s2[8][32];
@@ -20,10 +21,22 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __r
     out += (int64_t)blockIdx.z * BN_SLICES * 2 * C;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int g = slice + sl * BN_SLICES; g < G; g += 8 * BN_SLICES) {
+        // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
+        const int64_t st = (int64_t)8 * BN_SLICES * 2 * C;
+        int g = slice + sl * BN_SLICES;
+        for (; g + 24 * BN_SLICES < G; g += 32 * BN_SLICES) {
+            const float* q = partial + (int64_t)g * 2 * C + c;
+            const float x0 = q[0], y0 = q[C], x1 = q[st], y1 = q[st + C], x2 = q[2 * st], y2 = q[2 * st + C], x3 = q[3 * st], y3 = q[3 * st + C];
+            a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
+            a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
+        }
+        for (; g < G; g += 8 * BN_SLICES) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
+        a += a1 + a2 + a3;
+        b += b1 + b2 + b3;
     }
     s1[sl][cl] = a;
     s2[sl][cl] = b;
@@ -38,13 +51,13 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __r
 
 // stage 2 / single stage.  PT = float (raw partials [G][2][C]) or double (stage-1 output).
 template <typename PT>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+__global__ __launch_bounds__(FIN_SL * 32) void bn_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count, double unbias_count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved, int64_t slot_stride)
 {
-    __shared__ double s1[8][32], s2[8][32];
+    __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     partial += (int64_t)blockIdx.y * G * 2 * C;                     // frame of a batched call
@@ -55,13 +68,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
         double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
         int g = sl;
-        for (; g + 24 < G; g += 32) {
+        for (; g + 3 * FIN_SL < G; g += 4 * FIN_SL) {
             const PT* q = partial + (int64_t)g * 2 * C + c;
-            const PT x0 = q[0], y0 = q[C], x1 = q[16 * C], y1 = q[17 * C], x2 = q[32 * C], y2 = q[33 * C], x3 = q[48 * C], y3 = q[49 * C];
+            const PT x0 = q[0], y0 = q[C], x1 = q[2 * FIN_SL * C], y1 = q[(2 * FIN_SL + 1) * C], x2 = q[4 * FIN_SL * C], y2 = q[(4 * FIN_SL + 1) * C],
+                     x3 = q[6 * FIN_SL * C], y3 = q[(6 * FIN_SL + 1) * C];
             a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
             a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
         }
-        for (; g < G; g += 8) {
+        for (; g < G; g += FIN_SL) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
@@ -73,7 +87,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     __syncthreads();
     if (sl == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -276,12 +290,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 }
 
 template <typename PT>
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ saved,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate, int64_t slot_stride)
 {
-    __shared__ double s1[8][32], s2[8][32];
+    __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     partial += (int64_t)blockIdx.y * G * 2 * C;                     // frame of a batched call
@@ -292,13 +306,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
         double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
         int g = sl;
-        for (; g + 24 < G; g += 32) {
+        for (; g + 3 * FIN_SL < G; g += 4 * FIN_SL) {
             const PT* q = partial + (int64_t)g * 2 * C + c;
-            const PT x0 = q[0], y0 = q[C], x1 = q[16 * C], y1 = q[17 * C], x2 = q[32 * C], y2 = q[33 * C], x3 = q[48 * C], y3 = q[49 * C];
+            const PT x0 = q[0], y0 = q[C], x1 = q[2 * FIN_SL * C], y1 = q[(2 * FIN_SL + 1) * C], x2 = q[4 * FIN_SL * C], y2 = q[(4 * FIN_SL + 1) * C],
+                     x3 = q[6 * FIN_SL * C], y3 = q[(6 * FIN_SL + 1) * C];
             a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
             a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
         }
-        for (; g < G; g += 8) {
+        for (; g < G; g += FIN_SL) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     __syncthreads();
     if (sl == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
         // accumulate: the S calls of one BatchNorm (frames on concurrent streams) add into one gradient buffer
         if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)a); else dbeta[c] = (float)a; }
         if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)b); else dgamma[c] = (float)b; }
@@ -411,10 +426,10 @@ extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
         // the second stage reads nframes blocks of BN_SLICES double partials
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C,
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES, C,
                            (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride);
     } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, partial, groups, C,
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C,
                            (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("bn_finalize");
@@ -556,10 +571,10 @@ extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES,
                            C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
     } else {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, partial, groups, C,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C,
                            (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
     }
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
@@ -706,8 +721,8 @@ extern "C" int tcvom_gn_bwd_finalize(const float* partial, int32_t groups, int32
 // added over the ranks before mean / variance (forward) and before the dx coefficients (backward).  The host does
 // the all-reduce (RCCL) on a [2][C] fp64 vector between these calls.
 template <typename PT>
-__global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ partial, int G, int C, double* __restrict__ sums) {
-    __shared__ double s1[8][32], s2[8][32];
+__global__ __launch_bounds__(FIN_SL * 32) void bn_sums_kernel(const PT* __restrict__ partial, int G, int C, double* __restrict__ sums) {
+    __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     partial += (int64_t)blockIdx.y * G * 2 * C;                     // frame of a batched call: sums[frame][2][C]
@@ -717,13 +732,14 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ par
         // 4 independent chains so that the (L2-latency-bound) loads of consecutive groups overlap
         double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, a3 = 0.0, b3 = 0.0;
         int g = sl;
-        for (; g + 24 < G; g += 32) {
+        for (; g + 3 * FIN_SL < G; g += 4 * FIN_SL) {
             const PT* q = partial + (int64_t)g * 2 * C + c;
-            const PT x0 = q[0], y0 = q[C], x1 = q[16 * C], y1 = q[17 * C], x2 = q[32 * C], y2 = q[33 * C], x3 = q[48 * C], y3 = q[49 * C];
+            const PT x0 = q[0], y0 = q[C], x1 = q[2 * FIN_SL * C], y1 = q[(2 * FIN_SL + 1) * C], x2 = q[4 * FIN_SL * C], y2 = q[(4 * FIN_SL + 1) * C],
+                     x3 = q[6 * FIN_SL * C], y3 = q[(6 * FIN_SL + 1) * C];
             a += (double)x0; b += (double)y0; a1 += (double)x1; b1 += (double)y1;
             a2 += (double)x2; b2 += (double)y2; a3 += (double)x3; b3 += (double)y3;
         }
-        for (; g < G; g += 8) {
+        for (; g < G; g += FIN_SL) {
             a += (double)partial[(int64_t)g * 2 * C + c];
             b += (double)partial[(int64_t)g * 2 * C + C + c];
         }
@@ -735,7 +751,7 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const PT* __restrict__ par
     __syncthreads();
     if (sl == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+        for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
         sums[c] = a;
         sums[C + c] = b;
     }
@@ -757,9 +773,9 @@ extern "C" int tcvom_bn_reduce_sums(const float* partial, int32_t groups, int32_
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(bn_sums_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, (const double*)scratch, BN_SLICES, C, sums);
+        hipLaunchKernelGGL(bn_sums_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES, C, sums);
     } else {
-        hipLaunchKernelGGL(bn_sums_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, partial, groups, C, sums);
+        hipLaunchKernelGGL(bn_sums_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C, sums);
     }
     TCVOM_LAUNCH_CHECK("bn_reduce_sums");
     return TCVOM_OK;
@@ -769,7 +785,7 @@ extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t cou
                                       const float* beta, float eps, float* scale_shift, float* saved, int32_t nframes,
                                       int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(sums && gamma && beta && scale_shift && saved && C > 0 && count > 0 && nframes >= 1, "bn_finalize_sums: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, (hipStream_t)stream, sums, 1, C, (double)count,
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, (hipStream_t)stream, sums, 1, C, (double)count,
                        (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps,
                        scale_shift, saved, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_finalize_sums");
@@ -781,7 +797,7 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
                                           int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(256), 0, st, sums_all, 1, C, (double)count, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, sums_all, 1, C, (double)count, gamma,
                        saved, (float*)nullptr, (float*)nullptr, coef, 0, slot_stride);
     // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
     hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate, nframes);
