@@ -19,6 +19,7 @@
 // last reads (group 1, L4) are retired by the lgkmcnt(0) at the head of its M4 in interval 8t -- the DMA of tile t+1
 // is first issued in interval 8t+1; it must have landed before interval 8t+8, where group 0 starts reading it: every
 // wave drains vmcnt before the barrier that ends interval 8t+7.
+#include <cstdlib>
 #include "common.h"
 
 struct Gemm256Args {
@@ -46,9 +47,12 @@ extern "C" int tcvom_trace256_read(unsigned long long* host) {
 
 // EPI: 0 = fp32 output, 1 = bf16 output, 2 = fused softmax backward (one instantiation each: a single kernel with all three
 // epilogues spilled registers in the main loop)
-template <int EPI>
+template <int EPI, int MF>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
-    constexpr int TM = 256, TN = 256;
+    // MF = 32-row A fragments per wave: 4 -> 256 x 256 tiles; 3 -> 192 (A rows) x 256 tiles for M = 576 (the d(query) / d(key)
+    // GEMMs of GuidedCxtAtten: 3 x 192 instead of 3 x 256 with a quarter of the MFMAs multiplying padding).  The quadrant
+    // (m1, *) then holds one fragment: phases 3 and 4 issue 4 MFMAs instead of 8.
+    constexpr int TM = MF * 64, TN = 256, HM = TM / 2, A_IT = TM / 64;
     constexpr int SLOT = (TM + TN) * 64;                 // bf16 elements per K-tile buffer
     __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT];
 
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int ra = m0 + (it * 8 + wave) * 8 + (lane >> 3), rb = n0 + (it * 8 + wave) * 8 + (lane >> 3);
-        a_off[it] = ra < g.M ? (int64_t)ra * K + kc8 : -1;
+        a_off[it] = (it < A_IT && ra < g.M) ? (int64_t)ra * K + kc8 : -1;
         b_off[it] = rb < g.N ? (int64_t)rb * K + kc8 : -1;
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -93,21 +97,21 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + TM * 64 + ((it) * 8 + wave) * 512), 16, 0, 0); \
     }
 
-    f32x16_t acc[4][2];
+    f32x16_t acc[MF][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MF; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int a_row = wm * 128 + (lane & 31), b_row = wn * 64 + (lane & 31);
+    const int a_row = wm * HM + (lane & 31), b_row = wn * 64 + (lane & 31);
     const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;     // the same for rows +32, +64, +96
     const int khalf = lane >> 5;
     bf16x8_t fa[2][4], fb[4];                          // A sub-tile (2 row-fragments x 4 k16), B sub-tile (1 x 4)
 
 #define G_READ_A(buf, mh)                                                                                    \
-    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                         \
+    _Pragma("unroll") for (int a_ = 0; a_ < ((mh) * 2 + 1 < MF ? 2 : 1); ++a_)                               \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                  \
             fa[a_][kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
 #define G_READ_B(buf, nh)                                                                                    \
@@ -120,8 +124,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                \
             acc[(mh) * 2 + 0][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk_], fb[kk_], acc[(mh) * 2 + 0][nh], 0, 0, 0); \
-            acc[(mh) * 2 + 1][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk_], fb[kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
-            if ((DMA) == 1 && (tn) < ntile) G_ISSUE_A(tn, kk_)                                               \
+            if constexpr ((mh) * 2 + 1 < MF)                                                                 \
+                acc[(mh) * 2 + 1][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk_], fb[kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
+            if ((DMA) == 1 && kk_ < A_IT && (tn) < ntile) G_ISSUE_A(tn, kk_)                                 \
             if ((DMA) == 2 && (tn) < ntile) G_ISSUE_B(tn, kk_)                                               \
         }                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                       \
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int ntile = K >> 6;
     // prologue: K-tile 0 into buffer 0 (all waves), then the stagger
 #pragma unroll
-    for (int it = 0; it < 4; ++it) { G_ISSUE_A(0, it) G_ISSUE_B(0, it) }
+    for (int it = 0; it < 4; ++it) { if (it < A_IT) G_ISSUE_A(0, it) G_ISSUE_B(0, it) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G_BAR();
     if (wm == 1) G_BAR();                              // group 1 runs one barrier interval behind group 0
@@ -211,10 +216,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < MF; ++a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ml = wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5), mrow = m0 + ml;
+                const int ml = wm * HM + a * 32 + 8 * q + 4 * (lane >> 5), mrow = m0 + ml;
                 float sc[4] = {0.f, 0.f, 0.f, 0.f};
                 if (mrow < g.M) { const float4 c4 = *reinterpret_cast<const float4*>(mscale + mrow); sc[0] = c4.x; sc[1] = c4.y; sc[2] = c4.z; sc[3] = c4.w; }
 #pragma unroll
@@ -247,10 +252,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) out_off[b] = (int64_t)(pvalid[b] ? pglob[b] : 0) * g.ldo + obase;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < MF; ++a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int mrow = m0 + wm * 128 + a * 32 + 8 * q + 4 * (lane >> 5);
+            const int mrow = m0 + wm * HM + a * 32 + 8 * q + 4 * (lane >> 5);
             float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = bs;
             if (mrow < g.M) {                         // M % 4 == 0: a lane's 4 rows are valid together
                 if (bias) bs = *reinterpret_cast<const float4*>(bias + mrow);
@@ -318,9 +323,17 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.vec_bstride = nb > 1 ? d->vec_bstride : 0;
     g.P = nullptr;
     g.delta = nullptr;
-    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)((d->K + 255) / 256), (unsigned)nb);
-    if (g.out_fp32) hipLaunchKernelGGL(gemm_nt256_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_nt256_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, g);
+    // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
+    static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
+    const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
+    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)cdiv(d->K, m192 ? 192 : 256), (unsigned)nb);
+    if (m192) {
+        if (g.out_fp32) hipLaunchKernelGGL((gemm_nt256_kernel<0, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_nt256_kernel<1, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    } else {
+        if (g.out_fp32) hipLaunchKernelGGL((gemm_nt256_kernel<0, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_nt256_kernel<1, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: %s", hipGetErrorString(e));
     return 1;
@@ -352,7 +365,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.P = (const bf16raw*)P;
     g.delta = delta;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
-    hipLaunchKernelGGL(gemm_nt256_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
     return TCVOM_OK;
 }
