@@ -324,13 +324,14 @@ def test_pred_test_folder_inference(tmp_path):
     direct = em(x.cuda().unsqueeze(0), tr.cuda().unsqueeze(0)).squeeze()[1][:H, :W].cpu().numpy()
     got = np.asarray(Image.open(outs[1])).astype(np.float32)
     assert np.isfinite(direct).all() and 0.0 < direct.mean() < 1.0
-    # the clip path (features computed once per frame) vs the per-sample window: same math, different launch shapes
-    assert got.shape == (H, W) and np.abs(got - np.uint8(direct * 255).astype(np.float32)).mean() <= 0.5
+    # the clip path (features computed once per frame, 4 frames per launch) vs the per-sample window: the same per-frame math --
+    # every frame's tiles are computed by the same instructions whatever the frame batch, so the PNGs are identical
+    assert got.shape == (H, W) and np.abs(got - np.uint8(direct * 255).astype(np.float32)).max() <= 1
     args2 = pred_test.parse(['--data', str(tmp_path / 'data'), '--load', ck, '--save', str(tmp_path / 'out2'), '--dilation', '2', '--per_sample'])
     outs2 = pred_test.main(args2)
     for a_fn, b_fn in zip(outs, outs2):
         pa, pb = np.asarray(Image.open(a_fn)).astype(np.float32), np.asarray(Image.open(b_fn)).astype(np.float32)
-        assert np.abs(pa - pb).mean() <= 0.5 and np.abs(pa - pb).max() <= 16, (np.abs(pa - pb).mean(), np.abs(pa - pb).max())
+        assert np.array_equal(pa, pb), (np.abs(pa - pb).mean(), np.abs(pa - pb).max())
     got2 = np.asarray(Image.open(outs2[1])).astype(np.float32)
     assert np.abs(got2 - np.uint8(direct * 255).astype(np.float32)).max() <= 1
 
