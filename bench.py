@@ -139,7 +139,7 @@ def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
     SAME 3x1088x1920 window as the GPU line: one small warm-up window (thread pool, allocator), then `reps` timed
     forward+backward passes, median reported.  `cores` is the thread count actually used: PyTorch's CPU kernels get
     SLOWER on these shapes beyond ~32 threads (measured on the 256-logical-core MI355X host: 19-21 s per window at 32
-    threads, 30 s at 64, 55 s at 128 -- tools/cpu_oracle_time.py), so 32 is the best the port does on this box."""
+    threads, 30 s at 64, 55 s at 128 -- tests/cpu_oracle_time.py), so 32 is the best the port does on this box."""
     import statistics
     import oracle
     from oracle.state_spec import vmn_gca_state_spec
@@ -169,7 +169,7 @@ def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
     ratio = window_gflop(H, W) / window_gflop(FULL_H, FULL_W)
     return {'value': round(ratio / dt, 6), 'unit': 'windows/s', 'cores': cores, 'host_logical_cores': host_cores, 'kind': 'port',
             'sample': 'median of %d fwd+bwd passes over one 3x%dx%d window after a 3x256x448 warm-up: %s s on %d threads '
-                      '(more threads measured slower, tools/cpu_oracle_time.py)%s'
+                      '(more threads measured slower, tests/cpu_oracle_time.py)%s'
                       % (reps, H, W, '/'.join('%.1f' % t for t in times), cores,
                          '' if (H, W) == (FULL_H, FULL_W) else ', scaled to 3x%dx%d by the algorithmic FLOP ratio %.4f' % (FULL_H, FULL_W, ratio))}
 
