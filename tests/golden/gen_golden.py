@@ -408,6 +408,44 @@ def gen_vmn_dim():
          shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))
 
 
+VMN_INDEX_CASES = {'vmn_index_s3_64x96': (2, 3, 64, 96, 3), 'vmn_index_s3_128x128': (2, 3, 128, 128, 5)}
+VMN_INDEX_FULL_GRADS = ('encoder.layer0.0.weight', 'encoder.layer3.1.conv.3.weight', 'encoder.index2.indexnet3.3.weight',
+                        'encoder.dconv_pp.aspp3.atrous_conv.0.weight', 'decoder.decoder_layer2.dconv.0.weight',
+                        'decoder.pred.1.weight', 'decoder.fam.key_conv.bias')
+
+
+def gen_vmn_index():
+    """FullModel_VMD('vmn_index') (IndexNet base + TAM), train mode, B = 2 (the image-pooling branch of the ASPP has a BatchNorm
+    over [B, 256, 1, 1]: PyTorch refuses B = 1 in train mode).  The ASPP's Dropout(0.5) is put in eval mode: its mask comes from
+    torch's global RNG, which no other implementation can replay; everything else runs in train mode."""
+    for name, (B, S, H, W, dil) in VMN_INDEX_CASES.items():
+        fm = ref_model.FullModel_VMD('vmn_index', agg_window=7, dilate_kernel=dil)
+        fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
+        fm.train()
+        fm.NET.encoder.dconv_pp.dropout.eval()
+        a, fg, bg = synthetic_window(B, S, H, W, seed=6)
+        out = fm(a, fg, bg)
+        (out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]).backward()
+        arrs = {'losses': torch.stack([o.detach() for o in out[:5]]), 'alphas': out[7], 'comps_sum': out[8].double().sum()}
+        names, norms = [], []
+        for k, p in fm.NET.named_parameters():
+            if p.grad is not None:
+                names.append(k)
+                norms.append(float(p.grad.double().norm()))
+        arrs['grad_names'], arrs['grad_norms'] = np.array(names), np.array(norms)
+        gd = dict(fm.NET.named_parameters())
+        for k in VMN_INDEX_FULL_GRADS:
+            arrs['grad:' + k] = gd[k].grad
+        post = fm.NET.state_dict()
+        for k in ('encoder.layer0.1.running_mean', 'encoder.layer2.0.conv.4.running_var', 'encoder.index0.indexnet1.1.running_mean',
+                  'decoder.decoder_layer0.dconv.1.running_var', 'encoder.layer0.1.num_batches_tracked'):
+            arrs['state:' + k] = post[k].clone()
+        save(name, **arrs)
+    sd = ref_model.FullModel_VMD('vmn_index', agg_window=7).NET.state_dict()
+    save('vmn_index_state_keys', keys=np.array(list(sd.keys())),
+         shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in sd.values()]))
+
+
 def metric_inputs(H=48, W=64):
     """alpha / gt of two adjacent frames, a trimap and a smooth optical flow with an invalid (NaN) patch."""
     a = (hu('metric.a', (H, W)) * 0.5 + 0.5).numpy().astype(np.float32)
@@ -476,6 +514,6 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]                                   # e.g. `python gen_golden.py fba dim`; default: everything
-    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_metrics, gen_single):
+    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_vmn_index, gen_metrics, gen_single):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -134,6 +134,12 @@ VMN_DIM_FULL_GRADS = ('encoder.conv11.weight', 'encoder.bn33.weight', 'decoder.d
                       'decoder.fam.key_conv.bias')
 
 
+VMN_INDEX_CASES = {'vmn_index_s3_64x96': (2, 3, 64, 96, 3), 'vmn_index_s3_128x128': (2, 3, 128, 128, 5)}
+VMN_INDEX_FULL_GRADS = ('encoder.layer0.0.weight', 'encoder.layer3.1.conv.3.weight', 'encoder.index2.indexnet3.3.weight',
+                        'encoder.dconv_pp.aspp3.atrous_conv.0.weight', 'decoder.decoder_layer2.dconv.0.weight',
+                        'decoder.pred.1.weight', 'decoder.fam.key_conv.bias')
+
+
 def golden_formula_state(name, requires_grad=True):
     """Formula-initialised state from a key / shape list captured from the reference (tests/golden/<name>.npz)."""
     from tcvom_amd.synthetic import formula_tensor

@@ -303,6 +303,42 @@ def test_vmn_dim_window_forward_backward(name):
         assert_close(state[k], g['state:' + k], 1e-4, 1e-6, k)
 
 
+# ----------------------------------------------------------------------------- vmn_index (IndexNet base + TAM)
+@pytest.mark.parametrize('name', ['vmn_index_s3_64x96', 'vmn_index_s3_128x128'])
+def test_vmn_index_window_forward_backward(name):
+    """oracle.index_net.vmn_index_window_forward against FullModel_VMD('vmn_index') of the reference (train mode, the ASPP
+    dropout off on both sides: its mask comes from torch's global RNG).  The oracle runs in fp64 here: through BatchNorms over
+    2 x 2x3 .. 4x4 pixels at os32 two fp32 evaluations of the same graph differ by 1-5 % in single gradient elements (the fp32
+    oracle does, against this fp64 run as much as against the reference), while the fp64 run reproduces the reference's fp32
+    numbers to ~1e-5: that is the tighter pin of the algorithm."""
+    from oracle import index_net
+    from helpers import VMN_INDEX_CASES, VMN_INDEX_FULL_GRADS, golden_formula_state
+    B, S, H, W, dil = VMN_INDEX_CASES[name]
+    g = golden(name)
+    base = golden_formula_state('vmn_index_state_keys')
+    assert len(base) == len(golden('vmn_index_state_keys')['keys'])
+    torch.set_default_dtype(torch.float64)
+    try:
+        state = {k: (v.detach().double().requires_grad_('running_' not in k) if v.is_floating_point() else v) for k, v in base.items()}
+        a, fg, bg = [t.double() for t in synthetic_window(B, S, H, W, seed=6)]
+        out, _ = index_net.vmn_index_window_forward(state, a, fg, bg, window=7, dilate_kernel=dil, training=True)
+        (out[0] + out[1] + out[2] + 0.5 * out[3] + 0.25 * out[4]).backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert_close(torch.stack([o.detach() for o in out[:5]]).float(), g['losses'], 1e-4, 1e-6, 'losses')
+    assert_close(out[7].float(), g['alphas'], 1e-4, 5e-5, 'alphas')
+    assert_close(out[8].double().sum(), g['comps_sum'], 1e-5, 1e-2, 'comps')
+    names = [str(n) for n in g['grad_names']]
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    # (the REFERENCE's fp32 gradients carry that noise: ~1 % of the norms at 128x128, less at 64x96)
+    assert_close(torch.from_numpy(got), g['grad_norms'], 2e-2, 1e-5, 'grad norms')
+    for k in VMN_INDEX_FULL_GRADS:
+        assert_close(state[k].grad.float(), g['grad:' + k], 2e-2, 3e-2 * float(np.abs(g['grad:' + k]).max()), 'grad ' + k)
+    for k in ('encoder.layer0.1.running_mean', 'encoder.layer2.0.conv.4.running_var', 'encoder.index0.indexnet1.1.running_mean',
+              'decoder.decoder_layer0.dconv.1.running_var'):
+        assert_close(state[k].float(), g['state:' + k], 1e-4, 1e-6, k)
+
+
 def test_evaluation_metrics():
     """oracle.metrics against calc_metric.py's SAD / MSE / SSDA / dtSSD / MESSDdt (values from the reference functions)."""
     from oracle import metrics
