@@ -111,10 +111,24 @@ int tcvom_wgrad_ws_multi(const void* const* dy, const void* const* in, float* co
                          const tcvom_conv_desc* d, int32_t ldy, void* stream);
 int32_t tcvom_wgrad_ws_max_problems(void);
 
+/* ------------------------------------------------------------------ depthwise 3x3 (IndexNet / MobileNetV2 blocks)
+ * Replaces nn.Conv2d(C, C, 3, 1, padding, dilation, groups=C, bias=False) of models/Index/net.py:38-61 (InvertedResidual, run
+ * unpadded on the `fixed_padding` input) and models/Index/hlaspp.py:38-46 (ASPP branches, padding = dilation).
+ * x [nframes][N][H][W][C] bf16 NHWC, w fp32 [9][C] tap-major (16-byte aligned), y [nframes][N][OH][OW][C] bf16 with
+ * OH = H + 2 pad - 2 dilation.  stats (or NULL): [nframes][tcvom_dw3x3_stats_groups(N*OH*OW, C)][2][C] fp32 partial (sum, sum of
+ * squares) of y per channel for the BatchNorm that follows (the layout tcvom_bn_finalize consumes).  flip != 0: taps reversed
+ * (the data gradient: tcvom_dw3x3(dy, w, dx, NULL, N, OH, OW, C, dilation, 2 * dilation - pad, 1, ...)).
+ * tcvom_dw3x3_wgrad: dw [9][C] fp32 = sum over all frames and pixels of dy * shifted x (overwritten). */
+int tcvom_dw3x3_stats_groups(int64_t out_pixels, int32_t C);
+int tcvom_dw3x3(const void* x, const float* w, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C,
+                int32_t dilation, int32_t pad, int32_t flip, int32_t nframes, void* stream);
+int tcvom_dw3x3_wgrad(const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t C,
+                      int32_t dilation, int32_t pad, int32_t nframes, void* stream);
+
 /* ------------------------------------------------------------------ BatchNorm around the convs
  * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks
  * (models/GCA/encoders/resnet_enc.py:33-49, decoders/resnet_dec.py:43-59).
- * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 LeakyReLU(0.01).   z = act(y*scale + shift + res1) + res2          */
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 LeakyReLU(0.01), 4 ReLU6.   z = act(y*scale + shift + res1) + res2   */
 /* unbias_count: element count used for the unbiased running_var correction (0 = count); differs from
  * count when the statistics were taken before a nearest x2 up-sampling (resnet_dec.py:112-118) */
 int tcvom_bn_finalize(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,

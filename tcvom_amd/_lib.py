@@ -153,11 +153,14 @@ _PROTOS = {
     'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
     'tcvom_gca_fold_f32': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_multi': [vp, vp, vp, i32, DP, i32, vp],
+    'tcvom_dw3x3_stats_groups': [i64, i32],
+    'tcvom_dw3x3': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    'tcvom_dw3x3_wgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_max_problems': [],
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles',
-          'tcvom_wgrad_ws_max_problems'}
+          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}

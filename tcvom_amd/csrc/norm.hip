@@ -140,7 +140,10 @@ __device__ __forceinline__ float act_grad(float pre, int act) {
 }
 
 // negative-side slope of the activation (1 = none): act(x) = x > 0 ? x : slope * x, act'(x) = x > 0 ? 1 : slope -- branch-free
-__device__ __forceinline__ float act_slope(int act) { return act == 1 ? 0.f : (act == 2 ? 0.2f : (act == 3 ? 0.01f : 1.f)); }
+// act 4 = ReLU6 (IndexNet / MobileNetV2 blocks): slope 0 below, capped at 6 above (gradient 0 at and beyond both ends, like
+// torch's hardtanh backward)
+__device__ __forceinline__ float act_slope(int act) { return (act == 1 || act == 4) ? 0.f : (act == 2 ? 0.2f : (act == 3 ? 0.01f : 1.f)); }
+__device__ __forceinline__ float act_cap(int act) { return act == 4 ? 6.f : __builtin_inff(); }
 // 8 consecutive per-channel coefficients as two 16-byte loads (the vectors are 32-byte aligned: C and the slot strides are
 // multiples of 8 floats); all loads of a thread's coefficient set are issued before the first one is waited for
 __device__ __forceinline__ void load_coef8(const float* __restrict__ p, float* f) {
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     float sc[8], sh[8];
     load_coef8(scale_shift + oct * 8, sc);
     load_coef8(scale_shift + C + oct * 8, sh);
-    const float slope = act_slope(act);
+    const float slope = act_slope(act), cap = act_cap(act);
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     // two-deep software pipeline: the loads of pixel row p + RP are in flight while row p is computed and stored
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float x = f[k] * sc[k] + sh[k] + r1[k];
-            x = x > 0.f ? x : slope * x;
+            x = fminf(x > 0.f ? x : slope * x, cap);
             f[k] = x + r2[k];
         }
         z[v] = pack8(f);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     load_coef8(scale_shift + C + c0, sh);
     load_coef8(saved + c0, mu);
     load_coef8(saved + C + c0, is);
-    const float slope = act_slope(act);
+    const float slope = act_slope(act), cap = act_cap(act);
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     if (prow < RP && pbeg + prow < pend) {
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-                const float gg = g[k] * (pre > 0.f ? 1.f : slope);
+                const float gg = g[k] * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
                 sg[k] += gg;
                 sx[k] += gg * (yy[k] - mu[k]) * is[k];
             }
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) { c1[k] = 0.f; c2[k] = 0.f; }
     }
-    const float slope = act_slope(act);
+    const float slope = act_slope(act), cap = act_cap(act);
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     int64_t p = pbeg + prow;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-            const float gg = g[k] * (pre > 0.f ? 1.f : slope);
+            const float gg = g[k] * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
             g[k] = gg;
             const float xh = (yy[k] - mu[k]) * is[k];
             o[k] = gi[k] * gg - c1[k] - xh * c2[k];
@@ -522,7 +525,7 @@ extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const voi
                               int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                               void* stream) {
     TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0 && nframes >= 1, "bn_apply: bad args (C=%d)", C);
-    TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_apply: C=%d must be a power of two <= 2048", C);
+    TCVOM_CHECK_ARG(C <= 2048, "bn_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
     if (y_fp32)
@@ -810,7 +813,7 @@ extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res
                                   int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                                   int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0 && nframes >= 1, "bn_bwd_apply: bad args");
-    TCVOM_CHECK_ARG(C <= 2048 && 256 % (C / 8) == 0, "bn_bwd_apply: C=%d must be a power of two <= 2048", C);
+    TCVOM_CHECK_ARG(C <= 2048, "bn_bwd_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
     if (y_fp32)

@@ -226,10 +226,11 @@ __global__ __launch_bounds__(256) void transpose_v8_kernel(const bf16raw* __rest
 // ---------------------------------------------------------------- final conv C->1 (KS x KS, pad KS/2, bias) + output map
 // MODE 0: alpha = (tanh(pre) + 1) / 2   (GCA decoder head, resnet_dec.py:139-141; KS = 3)
 // MODE 1: alpha = clamp(pre, 0, 1)      (DIM alpha_pred, models/DIM/vggnet.py:76,123; KS = 5)
+// MODE 2: alpha = pre                   (IndexNet pred[0][0] 32 -> 1, models/Index/net.py:16-22; KS = 5; BN + ReLU6 follow)
 // x NHWC bf16 [N,H,W,C]; w fp32 [KS*KS][C] (tap-major); alpha fp32 [N,H,W]
 template <int MODE>
 __device__ __forceinline__ float head_out(float pre) {
-    return MODE == 0 ? 0.5f * (tanhf(pre) + 1.f) : fminf(fmaxf(pre, 0.f), 1.f);
+    return MODE == 0 ? 0.5f * (tanhf(pre) + 1.f) : (MODE == 1 ? fminf(fmaxf(pre, 0.f), 1.f) : pre);
 }
 template <int MODE>
 __device__ __forceinline__ float head_dpre(float dalpha, float alpha) {
@@ -237,6 +238,7 @@ __device__ __forceinline__ float head_dpre(float dalpha, float alpha) {
         const float th = 2.f * alpha - 1.f;
         return dalpha * 0.5f * (1.f - th * th);
     }
+    if (MODE == 2) return dalpha;
     return (alpha > 0.f && alpha < 1.f) ? dalpha : 0.f;
 }
 
@@ -485,13 +487,15 @@ extern "C" int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_
 extern "C" int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
                                    int32_t W, int32_t C, int32_t ksize, int32_t mode, void* stream) {
     TCVOM_CHECK_ARG(x && w && bias && alpha && C % 8 == 0 && C <= 256, "head_conv_fwd: bad args");
-    TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && mode == 1), "head_conv_fwd: ksize=%d mode=%d not instantiated", ksize, mode);
+    TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && (mode == 1 || mode == 2)), "head_conv_fwd: ksize=%d mode=%d not instantiated", ksize, mode);
     const dim3 g(grid_for((int64_t)N * H * W));
     hipStream_t st = (hipStream_t)stream;
     if (ksize == 3)
         hipLaunchKernelGGL((head_conv_fwd_kernel<3, 0>), g, dim3(256), 9 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL((head_conv_fwd_kernel<5, 1>), g, dim3(256), 25 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+    else
+        hipLaunchKernelGGL((head_conv_fwd_kernel<5, 2>), g, dim3(256), 25 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
     TCVOM_LAUNCH_CHECK("head_conv_fwd");
     return TCVOM_OK;
 }
@@ -500,14 +504,16 @@ extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, cons
                                    int32_t ksize, int32_t mode, int32_t replicas, void* stream) {
     TCVOM_CHECK_ARG(dalpha && alpha && x && w && dx && dpre && dw && db && C % 8 == 0 && C <= 256 && 256 % C == 0, "head_conv_bwd: bad args");
     TCVOM_CHECK_ARG(replicas >= 1 && (ksize == 3 || replicas == 1), "head_conv_bwd: replicas=%d (only the 3x3 kernel spreads dw)", replicas);
-    TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && mode == 1), "head_conv_bwd: ksize=%d mode=%d not instantiated", ksize, mode);
+    TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && (mode == 1 || mode == 2)), "head_conv_bwd: ksize=%d mode=%d not instantiated", ksize, mode);
     hipStream_t st = (hipStream_t)stream;
     const int T = ksize * ksize;
     const dim3 g(grid_for((int64_t)N * H * W * C / 8));
     if (ksize == 3)
         hipLaunchKernelGGL((head_conv_bwd_data_kernel<3, 0>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 1>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+    else
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 2>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
     if (hipMemsetAsync(dw, 0, sizeof(float) * T * C * replicas, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * replicas, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "head_conv_bwd: memset failed");
     const int64_t P = (int64_t)N * H * W;

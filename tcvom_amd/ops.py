@@ -13,6 +13,7 @@ from . import _lib as L
 from .conv_plan import ConvGeometry, dense_desc, dense_tt_desc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_LEAKY01 = 0, 1, 2, 3        # LeakyReLU(0.2) (GCA decoder) / nn.LeakyReLU() default 0.01 (FBA)
+ACT_RELU6 = 4                                                  # IndexNet / MobileNetV2 blocks
 BF16 = torch.bfloat16
 
 
@@ -264,6 +265,97 @@ class _ConvBNAct(torch.autograd.Function):
         bank.defer_wgrad(spec, ctx.call, dy, x, geo, nf)
         dres2 = dz if ctx.has_res2 else None
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None
+
+
+# =============================================================================================
+# Depthwise 3x3 + BatchNorm + ReLU6 (IndexNet base: models/Index/net.py:38-61, hlaspp.py:38-46)
+# =============================================================================================
+class DwCfg(object):
+    """One depthwise 3x3 conv + BatchNorm (+ activation) site: weight [C, 1, 3, 3] fp32 (read by the kernel as it is -- 9 C
+    values, not worth a packed copy), stride 1."""
+
+    def __init__(self, bank, weight, bn, dilation=1, pad=0, act=ACT_RELU6):
+        self.bank, self.weight, self.bn, self.dilation, self.pad, self.act = bank, weight, bn, int(dilation), int(pad), act
+        bank.register_bn(bn)
+
+
+class _DwBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, weight, gamma, beta, cfg, training):
+        _need_cuda(x)
+        bank, bn = cfg.bank, cfg.bn
+        x = _c(x)
+        NT, H, W, Cc = x.shape
+        assert x.dtype == BF16 and tuple(weight.shape) == (Cc, 1, 3, 3)
+        assert _sync_group(bn) is None or not training, 'SyncBatchNorm on the depthwise layers is not wired'
+        nf = bank.frames_per_op
+        assert NT % nf == 0
+        N = NT // nf
+        d, p = cfg.dilation, cfg.pad
+        OH, OW = H + 2 * p - 2 * d, W + 2 * p - 2 * d
+        st = L.stream_ptr()
+        wt = weight.detach().reshape(Cc, 9).t().contiguous().float()          # [9][C] tap-major
+        y = torch.empty((NT, OH, OW, Cc), dtype=BF16, device=x.device)
+        P = N * OH * OW
+        stats, groups = None, 0
+        if training:
+            groups = L.call('tcvom_dw3x3_stats_groups', P, Cc)
+            stats = torch.empty(nf * groups * 2 * Cc, dtype=torch.float32, device=x.device)
+        L.call('tcvom_dw3x3', L.ptr(x), L.ptr(wt), L.ptr(y), L.ptr(stats), N, H, W, Cc, d, p, 0, nf, st)
+        ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training, P)
+        ss, saved = C.c_void_p(ss_i), C.c_void_p(saved_i)
+        if training:
+            scratch = torch.empty(nf * 128 * Cc, dtype=torch.float64, device=x.device) if groups > 256 else None
+            L.call('tcvom_bn_finalize', L.ptr(stats), groups, Cc, P, P, L.ptr(gamma), L.ptr(beta), None, None,
+                   float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
+        else:
+            slot_stride = 0
+            L.call('tcvom_bn_eval_coeffs', Cc, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                   float(bn.eps), ss, saved, st)
+        z = torch.empty_like(y)
+        L.call('tcvom_bn_apply', L.ptr(y), ss, None, None, L.ptr(z), P, Cc, cfg.act, 0, nf, slot_stride, st)
+        ctx.cfg, ctx.training, ctx.nf, ctx.dims = cfg, training, nf, (N, H, W, OH, OW, Cc)
+        ctx.ss, ctx.saved, ctx.slot_stride, ctx.window_id = ss, saved, slot_stride, bank.window_id
+        ctx.save_for_backward(x, y, gamma, wt)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        cfg, nf = ctx.cfg, ctx.nf
+        bank = cfg.bank
+        x, y, gamma, wt = ctx.saved_tensors
+        N, H, W, OH, OW, Cc = ctx.dims
+        if ctx.window_id != bank.window_id:
+            raise RuntimeError('depthwise conv: backward of a window after a newer forward of the same network is not supported')
+        st = L.stream_ptr()
+        dz = _c(dz)
+        P = N * OH * OW
+        ss, saved, stride = ctx.ss, ctx.saved, ctx.slot_stride
+        groups = L.call('tcvom_bn_bwd_groups', P, Cc)
+        partial = torch.empty(nf * groups * 2 * Cc, dtype=torch.float32, device=dz.device)
+        L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), None, ss, saved, L.ptr(partial), P, Cc, cfg.act, 0, nf, stride, st)
+        dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
+        coef = torch.empty(nf * 3 * Cc, dtype=torch.float32, device=dz.device)
+        scratch = torch.empty(nf * 128 * Cc, dtype=torch.float64, device=dz.device) if groups > 256 else None
+        L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, Cc, P, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef), L.ptr(scratch),
+               1, nf, stride, st)
+        dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
+        L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), None, ss, saved, L.ptr(coef), L.ptr(dy), None, P, Cc, cfg.act,
+               1 if ctx.training else 0, 0, 0, nf, stride, st)
+        d, p = cfg.dilation, cfg.pad
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=BF16, device=dz.device)
+            L.call('tcvom_dw3x3', L.ptr(dy), L.ptr(wt), L.ptr(dx), None, N, OH, OW, Cc, d, 2 * d - p, 1, nf, st)
+        dw = torch.empty((9, Cc), dtype=torch.float32, device=dz.device)
+        L.call('tcvom_dw3x3_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), N, H, W, Cc, d, p, nf, st)
+        return dx, None, dw.t().reshape(Cc, 1, 3, 3), None, None, None, None
+
+
+def dw_bn_act(cfg, x, token, training):
+    """Depthwise 3x3 (cfg.dilation, cfg.pad) + BatchNorm + cfg.act on NHWC bf16; the BatchNorm parameter gradients travel
+    through the bank like those of conv_bn_act."""
+    return _DwBNAct.apply(x, token, cfg.weight, cfg.bn.weight, cfg.bn.bias, cfg, training)
 
 
 def conv_bn_act(cfg, x, token, training, res1=None, res2=None):

@@ -208,7 +208,7 @@ def build_vmn_gca(agg_window, agg_reduction=1, freeze_backbone=False):
 
 
 def get_VMN_models(arch, agg_window, agg_reduction=1, freeze_backbone=False, **kwargs):
-    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4), `vmn_fba` (config 5) and `vmn_dim` run on the HIP path."""
+    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4), `vmn_fba` (config 5), `vmn_dim` and `vmn_index` run on the HIP path."""
     if arch == 'vmn_gca':
         return build_vmn_gca(agg_window, agg_reduction, freeze_backbone)
     if arch == 'vmn_fba':
@@ -217,6 +217,7 @@ def get_VMN_models(arch, agg_window, agg_reduction=1, freeze_backbone=False, **k
     if arch == 'vmn_dim':
         from .dim_net import build_vmn_dim
         return build_vmn_dim(agg_window, agg_reduction, freeze_backbone)
-    if arch in ('vmn_index',):
-        raise NotImplementedError('%s: only the vmn_gca hot path is implemented on MI355X so far (SURVEY.md §8)' % arch)
+    if arch == 'vmn_index':
+        from .index_net import build_vmn_index
+        return build_vmn_index(agg_window, agg_reduction, freeze_backbone)
     raise ValueError
