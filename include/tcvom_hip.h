@@ -125,6 +125,23 @@ int tcvom_dw3x3(const void* x, const float* w, void* y, float* stats, int32_t N,
 int tcvom_dw3x3_wgrad(const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t C,
                       int32_t dilation, int32_t pad, int32_t nframes, void* stream);
 
+/* ------------------------------------------------------------------ IndexNet element-wise stages (csrc/indexnet.hip)
+ * tcvom_index_pool_*: DepthwiseM2OIndexBlock's sigmoid / softmax-over-the-four-branches / pixel shuffle fused with the encoder's
+ * indexed pooling (models/Index/hlindex.py:149-168, models/Index/net.py:203-205).  x1..x4 [N][h2][w2][C] bf16 (branch k = sub-pixel
+ * (k / 2, k % 2) of a 2x2 cell), l [N][2 h2][2 w2][C] -> xe = idx_en * l and idx_de = sigmoid(x) at full resolution, pooled =
+ * 4 * avg_pool2d(xe) at half resolution.  Backward: gradients of (xe, pooled, idx_de) (each may be NULL = zero) -> dx1..dx4, dl.
+ * tcvom_index_up_*: IndexedUpsamlping's conv input (models/Index/hldecoder.py:128-133): out [N][H][W][C1 + C2] =
+ * concat(idx * nearest_x2(enc), low) with enc [N][H/2][W/2][C1], idx [N][H][W][C1]; idx == NULL: enc is [N][H][W][C1] (plain concat). */
+int tcvom_index_pool_fwd(const void* x1, const void* x2, const void* x3, const void* x4, const void* l, void* xe, void* pooled,
+                         void* idx_de, int32_t N, int32_t h2, int32_t w2, int32_t C, void* stream);
+int tcvom_index_pool_bwd(const void* x1, const void* x2, const void* x3, const void* x4, const void* l, const void* dxe,
+                         const void* dpooled, const void* dde, void* dx1, void* dx2, void* dx3, void* dx4, void* dl,
+                         int32_t N, int32_t h2, int32_t w2, int32_t C, void* stream);
+int tcvom_index_up_fwd(const void* enc, const void* idx, const void* low, void* out, int32_t N, int32_t H, int32_t W,
+                       int32_t C1, int32_t C2, void* stream);
+int tcvom_index_up_bwd(const void* dout, const void* enc, const void* idx, void* denc, void* didx, void* dlow, int32_t N,
+                       int32_t H, int32_t W, int32_t C1, int32_t C2, void* stream);
+
 /* ------------------------------------------------------------------ BatchNorm around the convs
  * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks
  * (models/GCA/encoders/resnet_enc.py:33-49, decoders/resnet_dec.py:43-59).

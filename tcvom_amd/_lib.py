@@ -153,6 +153,10 @@ _PROTOS = {
     'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
     'tcvom_gca_fold_f32': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_multi': [vp, vp, vp, i32, DP, i32, vp],
+    'tcvom_index_pool_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_index_pool_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_index_up_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_index_up_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_dw3x3_stats_groups': [i64, i32],
     'tcvom_dw3x3': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_dw3x3_wgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

@@ -10,8 +10,10 @@ tests/golden/vmn_index_state_keys.npz); the modules only hold parameters, the wo
   * the conv engine for the 1x1 / 4x4 stride-2 / 5x5 / 3x3 convs (any C % 8 == 0) with BatchNorm + ReLU6 in the BN kernels,
   * `ops.dw_bn_act` (csrc/depthwise.hip) for the depthwise 3x3 convs,
   * `ops.head_conv` for pred[0][0] (32 -> 1),
-  * small tensor expressions for the index normalisation / pooling / indexed up-sampling and the 1-channel tail of `pred`
-    (first version: element-wise torch ops on NHWC tensors; they are bandwidth-trivial next to the convs).
+  * `ops.index_pool` / `ops.index_up` (csrc/indexnet.hip) for the index normalisation + indexed pooling and the indexed up-sampling
+    + concat, each with an analytic backward kernel,
+  * small tensor expressions for what is left: the image-pooling branch of the ASPP ([N, 320] vectors), the zero ring of
+    `fixed_padding`, the ASPP concat and dropout, and the 1-channel tail of `pred` (BatchNorm(1) + ReLU6 + 5x5 conv on a fp32 map).
 `fixed_padding` (net.py:63-69) pads the BLOCK INPUT, so the 1x1 expand conv and its BatchNorm see the zero ring (it enters the
 batch statistics, and after BN + ReLU6 the ring is relu6(shift), not zero): the padded tensor is materialised here as well.
 """
@@ -101,17 +103,9 @@ class DepthwiseM2OIndexBlock(nn.Module):
         ys = []
         for k in range(1, 5):
             t = ops.conv_bn_act(cf['%s.indexnet%d.0' % (self._name, k)], x, token, training)
-            ys.append(ops.conv_bn_act(cf['%s.indexnet%d.3' % (self._name, k)], t, token, training).float())
-        N, h2, w2, Cc = ys[0].shape
-        y = torch.sigmoid(torch.stack(ys, 0))                         # [4, N, h2, w2, C], branch k -> sub-pixel (k // 2, k % 2)
-        z = torch.softmax(y, 0)
-
-        def shuffle(t):
-            return t.reshape(2, 2, N, h2, w2, Cc).permute(2, 3, 0, 4, 1, 5).reshape(N, 2 * h2, 2 * w2, Cc)
-        idx_en, idx_de = shuffle(z), shuffle(y).to(BF16)
-        xe = (idx_en * x.float())
-        pooled = xe.reshape(N, h2, 2, w2, 2, Cc).sum((2, 4))
-        return xe.to(BF16), pooled.to(BF16), idx_de
+            ys.append(ops.conv_bn_act(cf['%s.indexnet%d.3' % (self._name, k)], t, token, training))
+        # sigmoid, softmax over the four branches, pixel shuffle, idx_en * x and the 2x2 sum in one kernel (csrc/indexnet.hip)
+        return ops.index_pool(ys[0], ys[1], ys[2], ys[3], x)
 
 
 class _ASPPModule(nn.Module):
@@ -240,11 +234,8 @@ class IndexedUpsamlping(nn.Module):
 
 
 def _indexed_cat(l_encode, l_low, indices):
-    """hldecoder.py:128-133 on NHWC: indices * nearest x2 of l_encode, concatenated with l_low."""
-    if indices is not None:
-        up = l_encode.repeat_interleave(2, 1).repeat_interleave(2, 2)
-        l_encode = (indices.float() * up.float()).to(BF16)
-    return torch.cat((l_encode, l_low), -1)
+    """hldecoder.py:128-133 on NHWC: indices * nearest x2 of l_encode, concatenated with l_low (csrc/indexnet.hip)."""
+    return ops.index_up(l_encode, indices, l_low)
 
 
 class IndexMattingDecoder_VMN(nn.Module):

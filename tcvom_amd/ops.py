@@ -358,6 +358,65 @@ def dw_bn_act(cfg, x, token, training):
     return _DwBNAct.apply(x, token, cfg.weight, cfg.bn.weight, cfg.bn.bias, cfg, training)
 
 
+class _IndexPool(torch.autograd.Function):
+    """x1..x4 [N, h2, w2, C], l [N, 2 h2, 2 w2, C] -> (idx_en * l, 4 * avg_pool2d(idx_en * l), idx_de) (csrc/indexnet.hip)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, x3, x4, l):
+        x1, x2, x3, x4, l = _c(x1), _c(x2), _c(x3), _c(x4), _c(l)
+        N, h2, w2, Cc = x1.shape
+        assert tuple(l.shape) == (N, 2 * h2, 2 * w2, Cc) and l.dtype == BF16
+        xe, de = torch.empty_like(l), torch.empty_like(l)
+        pooled = torch.empty_like(x1)
+        L.call('tcvom_index_pool_fwd', L.ptr(x1), L.ptr(x2), L.ptr(x3), L.ptr(x4), L.ptr(l), L.ptr(xe), L.ptr(pooled), L.ptr(de),
+               N, h2, w2, Cc, L.stream_ptr())
+        ctx.save_for_backward(x1, x2, x3, x4, l)
+        return xe, pooled, de
+
+    @staticmethod
+    def backward(ctx, dxe, dpooled, dde):
+        x1, x2, x3, x4, l = ctx.saved_tensors
+        N, h2, w2, Cc = x1.shape
+        g = [None if t is None else _c(t) for t in (dxe, dpooled, dde)]
+        dxs = [torch.empty_like(x1) for _ in range(4)]
+        dl = torch.empty_like(l)
+        L.call('tcvom_index_pool_bwd', L.ptr(x1), L.ptr(x2), L.ptr(x3), L.ptr(x4), L.ptr(l), L.ptr(g[0]), L.ptr(g[1]), L.ptr(g[2]),
+               L.ptr(dxs[0]), L.ptr(dxs[1]), L.ptr(dxs[2]), L.ptr(dxs[3]), L.ptr(dl), N, h2, w2, Cc, L.stream_ptr())
+        return dxs[0], dxs[1], dxs[2], dxs[3], dl
+
+
+class _IndexUp(torch.autograd.Function):
+    """concat(idx * nearest_x2(enc), low) along the channels (idx None: concat(enc, low)) (csrc/indexnet.hip)."""
+
+    @staticmethod
+    def forward(ctx, enc, idx, low):
+        enc, low = _c(enc), _c(low)
+        idx = _c(idx) if idx is not None else None
+        N, H, W, C2 = low.shape
+        C1 = enc.shape[3]
+        out = torch.empty((N, H, W, C1 + C2), dtype=BF16, device=low.device)
+        L.call('tcvom_index_up_fwd', L.ptr(enc), L.ptr(idx), L.ptr(low), L.ptr(out), N, H, W, C1, C2, L.stream_ptr())
+        ctx.save_for_backward(enc, idx)
+        ctx.dims = (N, H, W, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc, idx = ctx.saved_tensors
+        N, H, W, C1, C2 = ctx.dims
+        dout = _c(dout)
+        denc = torch.empty_like(enc)
+        didx = torch.empty_like(idx) if idx is not None else None
+        dlow = torch.empty((N, H, W, C2), dtype=BF16, device=dout.device)
+        L.call('tcvom_index_up_bwd', L.ptr(dout), L.ptr(enc), L.ptr(idx), L.ptr(denc), L.ptr(didx), L.ptr(dlow), N, H, W, C1, C2,
+               L.stream_ptr())
+        return denc, didx, dlow
+
+
+index_pool = _IndexPool.apply
+index_up = _IndexUp.apply
+
+
 def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
     bn = cfg.bn
     gamma = bn.weight if bn is not None else None
