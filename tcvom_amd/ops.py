@@ -287,7 +287,7 @@ class _DwBNAct(torch.autograd.Function):
         x = _c(x)
         NT, H, W, Cc = x.shape
         assert x.dtype == BF16 and tuple(weight.shape) == (Cc, 1, 3, 3)
-        assert _sync_group(bn) is None or not training, 'SyncBatchNorm on the depthwise layers is not wired'
+        sync = _sync_group(bn) if training else None
         nf = bank.frames_per_op
         assert NT % nf == 0
         N = NT // nf
@@ -302,12 +302,20 @@ class _DwBNAct(torch.autograd.Function):
             groups = L.call('tcvom_dw3x3_stats_groups', P, Cc)
             stats = torch.empty(nf * groups * 2 * Cc, dtype=torch.float32, device=x.device)
         L.call('tcvom_dw3x3', L.ptr(x), L.ptr(wt), L.ptr(y), L.ptr(stats), N, H, W, Cc, d, p, 0, nf, st)
-        ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training, P)
+        Pg = P * (sync[1] if sync is not None else 1)                  # SyncBatchNorm: statistics over the clips of all ranks
+        ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training, Pg)
         ss, saved = C.c_void_p(ss_i), C.c_void_p(saved_i)
         if training:
             scratch = torch.empty(nf * 128 * Cc, dtype=torch.float64, device=x.device) if groups > 256 else None
-            L.call('tcvom_bn_finalize', L.ptr(stats), groups, Cc, P, P, L.ptr(gamma), L.ptr(beta), None, None,
-                   float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
+            if sync is None:
+                L.call('tcvom_bn_finalize', L.ptr(stats), groups, Cc, P, P, L.ptr(gamma), L.ptr(beta), None, None,
+                       float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
+            else:
+                sums = torch.empty(nf * 2 * Cc, dtype=torch.float64, device=x.device)
+                L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, Cc, L.ptr(sums), L.ptr(scratch), nf, st)
+                dist.all_reduce(sums, group=sync[0])
+                L.call('tcvom_bn_finalize_sums', L.ptr(sums), Cc, Pg, Pg, L.ptr(gamma), L.ptr(beta), float(bn.eps), ss, saved, nf,
+                       slot_stride, st)
         else:
             slot_stride = 0
             L.call('tcvom_bn_eval_coeffs', Cc, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
@@ -315,7 +323,7 @@ class _DwBNAct(torch.autograd.Function):
         z = torch.empty_like(y)
         L.call('tcvom_bn_apply', L.ptr(y), ss, None, None, L.ptr(z), P, Cc, cfg.act, 0, nf, slot_stride, st)
         ctx.cfg, ctx.training, ctx.nf, ctx.dims = cfg, training, nf, (N, H, W, OH, OW, Cc)
-        ctx.ss, ctx.saved, ctx.slot_stride, ctx.window_id = ss, saved, slot_stride, bank.window_id
+        ctx.ss, ctx.saved, ctx.slot_stride, ctx.window_id, ctx.sync = ss, saved, slot_stride, bank.window_id, sync
         ctx.save_for_backward(x, y, gamma, wt)
         return z
 
@@ -337,8 +345,17 @@ class _DwBNAct(torch.autograd.Function):
         dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
         coef = torch.empty(nf * 3 * Cc, dtype=torch.float32, device=dz.device)
         scratch = torch.empty(nf * 128 * Cc, dtype=torch.float64, device=dz.device) if groups > 256 else None
-        L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, Cc, P, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef), L.ptr(scratch),
-               1, nf, stride, st)
+        if ctx.sync is None or not ctx.training:
+            L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, Cc, P, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef), L.ptr(scratch),
+                   1, nf, stride, st)
+        else:
+            group, world = ctx.sync
+            local = torch.empty(nf * 2 * Cc, dtype=torch.float64, device=dz.device)
+            L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, Cc, L.ptr(local), L.ptr(scratch), nf, st)
+            total = local.clone()
+            dist.all_reduce(total, group=group)
+            L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), Cc, P * world, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef),
+                   1, nf, stride, st)
         dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
         L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), None, ss, saved, L.ptr(coef), L.ptr(dy), None, P, Cc, cfg.act,
                1 if ctx.training else 0, 0, 0, nf, stride, st)

@@ -32,7 +32,7 @@ def test_poly_lr_matches_reference_formula():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('arch,nkeys', [('vmn_gca', 584), ('vmn_fba', 203), ('vmn_dim', 113)])
+@pytest.mark.parametrize('arch,nkeys', [('vmn_gca', 584), ('vmn_fba', 203), ('vmn_dim', 113), ('vmn_index', 555)])
 def test_train_ddp_two_steps_and_checkpoint(tmp_path, arch, nkeys):
     """train_ddp.py counterpart for every VMN architecture on the HIP path: two optimizer steps on 5-frame synthetic
     clips (L_dt active), checkpoint with the reference's state_dict layout that loads back strictly."""
@@ -42,7 +42,7 @@ def test_train_ddp_two_steps_and_checkpoint(tmp_path, arch, nkeys):
     cfg = get_cfg_defaults()
     cfg.merge_from_file(os.path.join(REPO, 'cfgs', 'vmd_vmn_gca_synthetic.yaml'))
     cfg.merge_from_list(['TRAIN.TRAIN_INPUT_SIZE', '(128, 160)', 'SYSTEM.OUTDIR', str(tmp_path), 'TRAIN.TOTAL_STEPS', '1',
-                         'MODEL', arch])
+                         'MODEL', arch] + (['TRAIN.BATCH_SIZE_PER_GPU', '2'] if arch == 'vmn_index' else []))   # (IndexNet: B >= 2 in train mode)
     train_ddp.main('vmd_%s_synthetic' % arch, cfg, steps_per_epoch=2, frames=5)
     ck = os.path.join(str(tmp_path), 'vmd_%s_synthetic_agg7_synthetic' % arch, 'checkpoint_1.pth.tar')
     sd = torch.load(ck, map_location='cpu')
