@@ -281,9 +281,11 @@ int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec /*[r
 /* The same backward without the N x N fp32 dP matrix: one MFMA GEMM whose epilogue applies the softmax backward,
  *   T[b][i][j] = P[b][i][j] * (sum_v dO[b][i][v] V[b][j][v] - delta[b][i]) * cvec[b][j]   (bf16 [batch][N][ld], zero for j >= N),
  * with delta[b][i] = sum_j P dP = <dO[b][i], O[b][i]> from tcvom_rowdot_bf16 (O = the forward's P V, kept in fp32: for a
- * peaked softmax dP[i][i] - delta[i] cancels to zero and a bf16 O would leave its rounding error instead).  dO, V: bf16 [batch][N][DV]. */
+ * peaked softmax dP[i][i] - delta[i] cancels to zero and a bf16 O would leave its rounding error instead).  dO, V: bf16 [batch][N][DV].
+ * Tt, Pt (both or neither; need ld % 256 == 0): bf16 [batch][ld][ld] transposed copies Tt[b][j][i] = T[b][i][j], Pt[b][j][i] =
+ * P[b][i][j], written by the same epilogue -- the operands of the dV = P^T dO and M' = T^T G GEMMs. */
 int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const void* P, const float* delta, const float* cvec, void* T,
-                             int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream);
+                             void* Tt, void* Pt, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream);
 /* out[r] = <a[r], b[r]> over `cols` columns (cols % 8 == 0); a is bf16, b is bf16 or (b_fp32 != 0) fp32 */
 int tcvom_rowdot_bf16(const void* a, const void* b, int32_t b_fp32, float* out, int64_t rows, int32_t cols, void* stream);
 int tcvom_gca_value_patches(const void* alpha, void* V, int32_t B, int32_t h8, int32_t w8, int32_t C, void* stream);

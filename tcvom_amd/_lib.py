@@ -149,7 +149,7 @@ _PROTOS = {
     'tcvom_adam_mt': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp],
     'tcvom_abi_version': [],
     'tcvom_conv_trace_read': [vp, i32],
-    'tcvom_gca_dp_softmax_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
+    'tcvom_gca_dp_softmax_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
     'tcvom_gca_fold_f32': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_multi': [vp, vp, vp, i32, DP, i32, vp],

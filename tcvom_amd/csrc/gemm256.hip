@@ -36,6 +36,11 @@ struct Gemm256Args {
     // in the padding columns M <= m < ldo.  P has the layout of `out`, delta is [batch][N].
     const bf16raw* P;
     const float* delta;
+    // optional transposed copies written by the same epilogue: Tt[b][m][n] = out[b][n][m], Pt[b][m][n] = P[b][n][m] ([ldt][ldt] per
+    // batch entry): the operands of the dV = P^T dO and M' = T^T G GEMMs, which otherwise cost two N x N transpose passes
+    bf16raw* Tt;
+    bf16raw* Pt;
+    int ldt;
 };
 
 #ifdef G256_TRACE
@@ -231,6 +236,31 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     o.x = pack2bf(bflo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], bfhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
                     o.y = pack2bf(bflo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], bfhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
                     *cell = o;
+                    if (g.Tt) {
+                        // A lane holds 4 consecutive m of ONE n; its neighbour (lane ^ 1) the same m of n + 1.  After one pair
+                        // exchange the even lane owns (n, n + 1) of rows m, m + 2 and the odd lane of rows m + 1, m + 3: 4-byte
+                        // stores whose 32 lanes cover 2 x 64 contiguous bytes of two rows.
+                        const int odd = lane & 1;
+                        const int nn = pglob[b] - odd, mr = mrow + odd;
+                        const bool okt = nn < g.ldt && mr + 2 < g.ldt + 2 && mr < g.ldt;
+                        const int64_t tb = (int64_t)bz * g.ldt * g.ldt + (int64_t)mr * g.ldt + nn;
+                        {
+                            const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)o.x, 0xB1, 0xf, 0xf, true);
+                            const unsigned py = (unsigned)__builtin_amdgcn_mov_dpp((int)o.y, 0xB1, 0xf, 0xf, true);
+                            const unsigned v0 = odd ? ((px >> 16) | (o.x & 0xffff0000u)) : ((o.x & 0xffffu) | (px << 16));
+                            const unsigned v1 = odd ? ((py >> 16) | (o.y & 0xffff0000u)) : ((o.y & 0xffffu) | (py << 16));
+                            if (okt) *reinterpret_cast<unsigned*>(g.Tt + tb) = v0;
+                            if (okt && mr + 2 < g.ldt) *reinterpret_cast<unsigned*>(g.Tt + tb + 2 * (int64_t)g.ldt) = v1;
+                        }
+                        {
+                            const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)pp.x, 0xB1, 0xf, 0xf, true);
+                            const unsigned py = (unsigned)__builtin_amdgcn_mov_dpp((int)pp.y, 0xB1, 0xf, 0xf, true);
+                            const unsigned v0 = odd ? ((px >> 16) | (pp.x & 0xffff0000u)) : ((pp.x & 0xffffu) | (px << 16));
+                            const unsigned v1 = odd ? ((py >> 16) | (pp.y & 0xffff0000u)) : ((pp.y & 0xffffu) | (py << 16));
+                            if (okt) *reinterpret_cast<unsigned*>(g.Pt + tb) = v0;
+                            if (okt && mr + 2 < g.ldt) *reinterpret_cast<unsigned*>(g.Pt + tb + 2 * (int64_t)g.ldt) = v1;
+                        }
+                    }
                 }
             }
         }
@@ -323,6 +353,7 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.vec_bstride = nb > 1 ? d->vec_bstride : 0;
     g.P = nullptr;
     g.delta = nullptr;
+    g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
@@ -344,7 +375,7 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
 // (800 MB written and read back per 3-frame launch at 1080p) + tcvom_row_softmax_bwd of models/GCA/ops.py:190's backward.
 extern const bf16raw* tcvom_zero_page(void);
 extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const void* P, const float* delta, const float* cvec, void* T,
-                                        int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
+                                        void* Tt, void* Pt, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
     TCVOM_CHECK_ARG(dO && V && P && delta && cvec && T, "gca_dp_softmax_bwd: null pointer");
     TCVOM_CHECK_ARG(N > 0 && N % 4 == 0 && DV % 64 == 0 && ld >= N && ld % 4 == 0 && batch >= 1, "gca_dp_softmax_bwd: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
     TCVOM_CHECK_ARG(((uintptr_t)cvec % 16) == 0 && ((uintptr_t)P % 8) == 0 && ((uintptr_t)T % 8) == 0, "gca_dp_softmax_bwd: alignment");
@@ -364,6 +395,8 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.vec_bstride = N;
     g.P = (const bf16raw*)P;
     g.delta = delta;
+    TCVOM_CHECK_ARG((Tt == nullptr) == (Pt == nullptr) && (!Tt || ld % 256 == 0), "gca_dp_softmax_bwd: the transposed copies come together and need ld %% 256 == 0");
+    g.Tt = (bf16raw*)Tt; g.Pt = (bf16raw*)Pt; g.ldt = (int)ld;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");

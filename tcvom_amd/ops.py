@@ -917,12 +917,18 @@ class _GcaAttention(torch.autograd.Function):
         delta = torch.empty((B, N), dtype=torch.float32, device=dev)
         L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
         T = torch.empty((B, N, ld), dtype=BF16, device=dev)
-        L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), N, DV, ld, B, st)
+        # the same epilogue also writes the transposed copies P^T and T^T that the dV and M' GEMMs read (when the padded row length
+        # is a whole number of 256-wide tiles; otherwise two transpose passes)
+        fused_t = ld % 256 == 0
+        Pt = torch.empty((B, ld, ld), dtype=BF16, device=dev)
+        Tt = torch.empty((B, ld, ld), dtype=BF16, device=dev)
+        L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T),
+               L.ptr(Tt) if fused_t else None, L.ptr(Pt) if fused_t else None, N, DV, ld, B, st)
         # dV[j][v] = sum_i P[i][j] dO[i][v]: as an NT GEMM on the transposed operands (Pt = P^T, dOt = dO^T) it runs on the
         # 256x256 tiles at ~1 PFLOP/s; the pixel-major TT form (atomics, transposing LDS reads) measured 437 us against
         # 270 + 80 us of transposes here
-        Pt = torch.empty((B, ld, ld), dtype=BF16, device=dev)
-        L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Pt), N, ld, ld, ld, B, N * ld, ld * ld, st)
+        if not fused_t:
+            L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Pt), N, ld, ld, ld, B, N * ld, ld * ld, st)
         dOt = torch.empty((B, DV, ld), dtype=BF16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(dO), L.ptr(dOt), N, DV, DV, ld, B, N * DV, DV * ld, st)
         dV = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
@@ -937,8 +943,8 @@ class _GcaAttention(torch.autograd.Function):
         L.call('tcvom_conv_igemm', L.ptr(T), L.ptr(Gt), L.ptr(dWq), None, None, None, None, C.byref(d3), st)
         # M'[j][d] = sum_i T[i][j] G[i][d]: like dV, an NT GEMM on the transposed operand (Tt = T^T) on the 256x256 tiles
         # instead of the pixel-major TT form (320 workgroups, one long reduction each); measured -0.1 ms per step
-        Tt = torch.empty((B, ld, ld), dtype=BF16, device=dev)
-        L.call('tcvom_transpose_bf16', L.ptr(T), L.ptr(Tt), N, ld, ld, ld, B, N * ld, ld * ld, st)
+        if not fused_t:
+            L.call('tcvom_transpose_bf16', L.ptr(T), L.ptr(Tt), N, ld, ld, ld, B, N * ld, ld * ld, st)
         Mp = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         d5 = dense_desc(N, D, ld, D, batch=B, in_bstride=ld * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
         L.call('tcvom_conv_igemm', L.ptr(Tt), L.ptr(Gt), L.ptr(Mp), None, None, None, None, C.byref(d5), st)

@@ -513,7 +513,7 @@ def test_transpose_bf16(R, Cc, ldi, ldo, batch):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize('B,N,DV', [(2, 80, 256), (1, 1020, 2048), (3, 264, 512)])
+@pytest.mark.parametrize('B,N,DV', [(2, 80, 256), (1, 1020, 2048), (3, 264, 512), (2, 500, 256)])
 def test_gca_fused_softmax_backward_gemm(B, N, DV):
     """tcvom_gca_dp_softmax_bwd (dP GEMM with the softmax backward in its epilogue, row sums from <dO, O>) against the
     unfused formula in fp32 on the same bf16 operands; padding columns N..ld must come out zero."""
@@ -538,12 +538,22 @@ def test_gca_fused_softmax_backward_gemm(B, N, DV):
     assert rel_err(delta.cpu(), (dOq * Ob.float()).sum(2).cpu()) < 1e-5
     L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
     T = torch.full((B, N, ld), float('nan'), dtype=torch.bfloat16, device=DEV)
-    L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), N, DV, ld, B, st)
+    fused_t = ld % 256 == 0                                  # (1020 -> 1024, 500 -> 512: the epilogue also writes T^T and P^T)
+    Tt = torch.full((B, ld, ld), float('nan'), dtype=torch.bfloat16, device=DEV) if fused_t else None
+    Pt = torch.full((B, ld, ld), float('nan'), dtype=torch.bfloat16, device=DEV) if fused_t else None
+    L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), L.ptr(Tt), L.ptr(Pt),
+           N, DV, ld, B, st)
     dP = torch.bmm(dOq, Vq.transpose(1, 2))
     ref = Pq * (dP - (Pq * dP).sum(2, keepdim=True)) * cvec[:, None, :]
     assert rel_err(T[:, :, :N].float().cpu(), ref.cpu()) < 1.5e-2
     if ld > N:
         assert float(T[:, :, N:].float().abs().max()) == 0.0
+    if fused_t:
+        want_t = torch.zeros(B, ld, ld, dtype=torch.bfloat16, device=DEV)
+        want_t[:, :, :N] = T.transpose(1, 2)
+        want_p = torch.zeros(B, ld, ld, dtype=torch.bfloat16, device=DEV)
+        want_p[:, :, :N] = P.transpose(1, 2)
+        assert torch.equal(Tt, want_t) and torch.equal(Pt, want_p)          # exact transposes, zero padding rows / columns
 
 
 @pytest.mark.parametrize('ncols', [8160, 2040, 3000, 250])

@@ -134,8 +134,12 @@ def main():
     d4 = dense_desc(N, N, DV, ld, out_fp32=True)
     t4 = timeit(lambda: L.call('tcvom_conv_igemm', L.ptr(dO), L.ptr(V), L.ptr(dP), None, None, None, None, C.byref(d4), st))
     t5 = timeit(lambda: L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), N, N, ld, ld, N, st))
-    t6 = timeit(lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), N, DV, ld, 1, st))
-    print('GCA dP fp32 %5.0f us + softmax bwd %5.0f us | fused %5.0f us' % (t4 * 1e3, t5 * 1e3, t6 * 1e3))
+    t6 = timeit(lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), None, None, N, DV, ld, 1, st))
+    Ttb = torch.empty(ld, ld, device=DEV, dtype=torch.bfloat16)
+    Ptb = torch.empty(ld, ld, device=DEV, dtype=torch.bfloat16)
+    t7 = timeit(lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), L.ptr(Ttb), L.ptr(Ptb), N, DV, ld, 1, st))
+    t8 = timeit(lambda: L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Ptb), N, ld, ld, ld, 1, N * ld, ld * ld, st))
+    print('GCA dP fp32 %5.0f us + softmax bwd %5.0f us | fused %5.0f us | fused + T^T, P^T %5.0f us (one N x N transpose pass: %5.0f us)' % (t4 * 1e3, t5 * 1e3, t6 * 1e3, t7 * 1e3, t8 * 1e3))
     print('GCA S=GG^T  %5.0f TF %5.0f us | O=PV %5.0f TF %5.0f us | dV=P^T dO %5.0f TF %5.0f us' % (
         2.0 * N * N * D / t1 / 1e9, t1 * 1e3, 2.0 * N * N * DV / t2 / 1e9, t2 * 1e3, 2.0 * N * N * DV / t3 / 1e9, t3 * 1e3))
 
