@@ -177,3 +177,30 @@ def vmn_index_window_forward(state, a, fg, bg, window=7, dilate_kernel=12, train
     L_att = attention_loss(attb, attf, small, gts, window, att_thres, label_smooth)
     L_dt = dtssd_loss(alphas, gts, trimasks)
     return [sum(La) / n, sum(Lc) / n, sum(Lg) / n, L_dt, L_att, simgs, tris, alphas, comps, gts, fgs, bgs], preds
+
+
+def index_single_forward(state, a, fg, bg, dilate_kernel=12, training=True, eps=0.0, dropout=False):
+    """FullModel('index').forward (models/model.py:199-246; IndexMatting of net.py:284-293 = encoder + IndexMattingDecoder,
+    net.py:252-280, no TAM): the centre frame of the clip -> the reference's 10-item list."""
+    mean = torch.tensor([0.485, 0.456, 0.406]).reshape(1, 1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).reshape(1, 1, 3, 1, 1)
+    S = a.shape[1]
+    c = S // 2
+    gts = a / 255.0
+    fgs, bgs = fg.flip([2]) / 255.0, bg.flip([2]) / 255.0
+    simgs = fgs * gts + bgs * (1.0 - gts)
+    tris, trimasks = make_trimap1(gts, dilate_kernel, eps)
+    x = torch.cat([(simgs - mean) / std, tris], dim=2)[:, c]
+    inputs = encoder(state, x, training, dropout)
+    pred = decoder_tail(state, decoder_front(state, inputs, training), inputs, training)
+    m = trimasks[:, c].float()
+    refine = torch.where(m.bool(), pred, gts[:, c])
+    comp = fgs[:, c] * refine + bgs[:, c] * (1.0 - refine)
+    L_alpha = l1_mask(refine, gts[:, c], m)
+    L_comp = l1_mask(comp, simgs[:, c], m)
+    L_grad = l1_grad(refine, gts[:, c], m)
+    alphas = torch.zeros_like(gts)
+    comps = torch.zeros_like(fgs)
+    alphas[:, c] = refine.detach().clamp(0, 1)
+    comps[:, c] = comp.detach().clamp(0, 1)
+    return [L_alpha, L_comp, L_grad, simgs, tris, alphas, comps, gts, fgs, bgs], pred

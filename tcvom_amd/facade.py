@@ -12,6 +12,7 @@ import torch.nn as nn
 from . import _lib as L
 from . import vmn as VMN
 from .dim_net import DIM_VGG
+from .index_net import IndexMatting
 from .fba_net import FBA
 from .gca_net import GCA
 
@@ -183,7 +184,7 @@ class _SingleImageLoss(torch.autograd.Function):
 
 class FullModel(nn.Module):
     """Baseline (no TAM) façade — models/model.py:15-246: the DIM base (BASELINE.json config 1) and the VMN archs."""
-    ARCH_DICT = {'gca': GCA, 'dim': DIM_VGG, 'fba': FBA, 'index': None}
+    ARCH_DICT = {'gca': GCA, 'dim': DIM_VGG, 'fba': FBA, 'index': IndexMatting}
     TRIMAP_CHANNEL_DICT = {'gca': 3, 'dim': 1, 'index': 1, 'fba': 8}
     FBA_LOSS_NORMALIZE = True
     FBA_L_ATT_MULTIPLIER = 1

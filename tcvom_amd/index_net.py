@@ -239,9 +239,9 @@ def _indexed_cat(l_encode, l_low, indices):
 
 
 class IndexMattingDecoder_VMN(nn.Module):
-    """models/VMN/VMN_Index.py:7-28."""
+    """models/VMN/VMN_Index.py:7-28; with_fam=False: the single-image IndexMattingDecoder (models/Index/net.py:252-280)."""
 
-    def __init__(self, reduction, window, freeze_backbone=False, bank=None):
+    def __init__(self, reduction, window, freeze_backbone=False, bank=None, with_fam=True):
         super().__init__()
         from .vmn import FeatureAggregationModule
         self.freeze_backbone = freeze_backbone
@@ -255,7 +255,9 @@ class IndexMattingDecoder_VMN(nn.Module):
             reg.conv('decoder.decoder_layer%d.dconv.0' % i, seq[0], seq[1], ACT_RELU6)
             cfgs.update(reg.cfgs)
         object.__setattr__(self, '_cfgs', cfgs)
-        self.fam = FeatureAggregationModule(32, reduction, window, bank=bank, prefix='decoder.fam')
+        object.__setattr__(self, '_bank', bank)
+        if with_fam:
+            self.fam = FeatureAggregationModule(32, reduction, window, bank=bank, prefix='decoder.fam')
         self.register_buffer('_zero_bias', torch.zeros(1), persistent=False)
 
     def _up(self, i, l, low, idx, token, training):
@@ -272,6 +274,11 @@ class IndexMattingDecoder_VMN(nn.Module):
         l3, l2, l1, l0 = mid['skip'][3:]
         idx3, idx2, idx0 = mid['idx'][2:]
         x, attb, attf = self.fam.run(x, xb, xf, mask_u8.contiguous(), token, training)
+        return self.run_tail_single(x, mid, token, training), attb, attf
+
+    def run_tail_single(self, x, mid, token, training):
+        l3, l2, l1, l0 = mid['skip'][3:]
+        idx3, idx2, idx0 = mid['idx'][2:]
         l = self._up(3, x, l3, idx3, token, training)
         l = self._up(2, l, l2, idx2, token, training)
         l = self._up(1, l, l1, None, token, training)
@@ -279,7 +286,7 @@ class IndexMattingDecoder_VMN(nn.Module):
         # pred: 5x5 conv 32 -> 1 (HIP), then BatchNorm over ONE channel + ReLU6 + 5x5 conv 1 -> 1 on a [N, 1, H, W] fp32 map
         conv0, bn, conv1 = self.pred[0][0], self.pred[0][1], self.pred[1]
         p = ops.head_conv(l, conv0.weight, self._zero_bias, 5, 2)
-        nf = self.fam._bank.frames_per_op
+        nf = self._bank.frames_per_op
         N = p.shape[0]
         if training:                                                   # the frames of a frame-batched call: separate BatchNorm calls
             outs = [F.batch_norm(p[f * (N // nf):(f + 1) * (N // nf)], bn.running_mean, bn.running_var, bn.weight, bn.bias, True,
@@ -289,7 +296,7 @@ class IndexMattingDecoder_VMN(nn.Module):
             p = torch.cat(outs, 0) if nf > 1 else outs[0]
         else:
             p = F.batch_norm(p, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
-        return F.conv2d(F.relu6(p), conv1.weight, None, 1, 2), attb, attf
+        return F.conv2d(F.relu6(p), conv1.weight, None, 1, 2)
 
 
 def build_vmn_index(agg_window, agg_reduction=1, freeze_backbone=False):
@@ -299,3 +306,24 @@ def build_vmn_index(agg_window, agg_reduction=1, freeze_backbone=False):
     enc = IndexMattingEncoder(bank=bank)
     dec = IndexMattingDecoder_VMN(agg_reduction, agg_window, freeze_backbone, bank=bank)
     return VMN(enc, dec, bank, freeze_backbone=freeze_backbone)
+
+
+class IndexMatting(nn.Module):
+    """The single-image base (models/Index/net.py:284-293): IndexMattingEncoder + IndexMattingDecoder, no temporal module."""
+
+    def __init__(self):
+        super().__init__()
+        bank = WeightBank()
+        object.__setattr__(self, '_bank', bank)
+        self.encoder = IndexMattingEncoder(bank=bank)
+        self.decoder = IndexMattingDecoder_VMN(1, 1, bank=bank, with_fam=False)
+
+    def run(self, x8):
+        """x8 [B, H, W, 8] bf16 (normalised RGB + 1-channel trimap) -> raw alpha prediction [B, 1, H, W] fp32."""
+        from .weights import bank_token
+        training = self.training
+        token = bank_token(self._bank, 1, training)
+        l, mid = self.encoder.run(x8, None, token, training)
+        pred = self.decoder.run_tail_single(self.decoder.run_front(l, mid, token, training), mid, token, training)
+        self._bank.flush_bn_counters()
+        return pred

@@ -473,7 +473,8 @@ def gen_metrics():
          messd=np.array([fix, org, valid], dtype=np.float64), pixels=int(m.sum()))
 
 
-SINGLE_CASES = {'gca_single_s1_128x160': ('gca', 1, 1, 128, 160, 5), 'fba_single_s3_64x64': ('fba', 1, 3, 64, 64, 3)}
+SINGLE_CASES = {'gca_single_s1_128x160': ('gca', 1, 1, 128, 160, 5), 'fba_single_s3_64x64': ('fba', 1, 3, 64, 64, 3),
+                'index_single_s3_64x96': ('index', 2, 3, 64, 96, 3)}      # IndexNet: B = 2 (image-pooling BatchNorm), ASPP dropout off
 
 
 def gen_single():
@@ -482,6 +483,8 @@ def gen_single():
         fm = ref_model.FullModel(arch, dilate_kernel=dil)
         fm.NET.load_state_dict(formula_state_dict(fm.NET.state_dict()))
         fm.train()
+        if arch == 'index':
+            fm.NET.encoder.dconv_pp.dropout.eval()
         a, fg, bg = synthetic_window(B, S, H, W, seed=6)
         out = fm(a, fg, bg)
         (out[0] + out[1] + out[2]).backward()

@@ -297,3 +297,46 @@ def test_dropout_is_active_in_train_mode():
         o1 = fm(a, fg, bg)[7]
         o2 = fm(a, fg, bg)[7]
     assert float((o1 - o2).abs().max()) > 0
+
+
+def test_single_image_base_against_reference_golden():
+    """FullModel('index') (IndexNet without the TAM, models/model.py:199-246) against the reference: state_dict layout, losses,
+    alphas."""
+    from tcvom_amd.facade import FullModel
+    g = golden('index_single_s3_64x96')
+    fm = FullModel('index', dilate_kernel=3)
+    sd = fm.NET.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['keys']]
+    assert [','.join(str(int(d)) for d in v.shape) for v in sd.values()] == [str(s) for s in g['shapes']]
+    fm.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in sd.items()})
+    fm = fm.to(DEV).train()
+    fm.NET.encoder.dconv_pp.dropout.eval()
+    a, fg, bg = synthetic_window(2, 3, 64, 96, seed=6)
+    out = fm(a.to(DEV), fg.to(DEV), bg.to(DEV))
+    (out[0] + out[1] + out[2]).backward()
+    ck = Checker()
+    for i, nm in enumerate(('L_alpha', 'L_comp', 'L_grad')):
+        ck.rel(nm, out[i].detach().cpu(), torch.tensor(g['losses'][i]), 5e-2)
+    ck.done()
+    mse = float(((out[5].cpu() - torch.from_numpy(g['alphas'])) ** 2).mean())
+    assert mse <= 1e-3, 'alpha MSE %.3e' % mse
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in fm.NET.parameters())
+
+
+def test_eval_model_runs_vmn_index():
+    """EvalModel('vmn_index') (models/model.py:359-424): eval-mode inference on one clip per call (B = 1 is fine without batch
+    statistics), prediction inside the unknown region, trimap value elsewhere."""
+    from tcvom_amd.facade import EvalModel
+    em = EvalModel('vmn_index', agg_window=7, dilate_kernel=2)
+    em.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in em.NET.state_dict().items()})
+    em = em.to(DEV).eval()
+    a, fg, bg = synthetic_window(1, 3, 96, 128, seed=5)
+    al = a / 255.0
+    imgs = torch.round(fg * al + bg * (1 - al))
+    tris = torch.where(a <= 0, torch.zeros_like(a), torch.where(a >= 255, torch.full_like(a, 255.0), torch.full_like(a, 128.0)))
+    out = em(imgs.to(DEV), tris.to(DEV))
+    assert tuple(out.shape) == (1, 3, 1, 96, 128) and bool(torch.isfinite(out).all())
+    known = (tris[:, 1] != 128).to(DEV)
+    # outside the (dilated) unknown band the output is the trimap value
+    far = known & (torch.nn.functional.max_pool2d((tris[:, 1] == 128).float(), 5, 1, 2).to(DEV) == 0)
+    assert torch.equal(out[:, 1][far], (tris[:, 1].to(DEV) / 255.0)[far])

@@ -400,6 +400,29 @@ def test_single_image_fba_base():
     assert abs(np.linalg.norm(got) - np.linalg.norm(want)) <= 0.02 * np.linalg.norm(want)
 
 
+def test_single_image_index_base():
+    """oracle.index_net.index_single_forward against FullModel('index') of the reference (IndexNet without the TAM; B = 2, ASPP
+    dropout off); fp64 as in test_vmn_index_window_forward_backward."""
+    from oracle import index_net
+    g = golden('index_single_s3_64x96')
+    base = _state_from(g)
+    assert len(base) == 549 and not any('.fam.' in k for k in base)
+    torch.set_default_dtype(torch.float64)
+    try:
+        state = {k: (v.detach().double().requires_grad_('running_' not in k) if v.is_floating_point() else v) for k, v in base.items()}
+        a, fg, bg = [t.double() for t in synthetic_window(2, 3, 64, 96, seed=6)]
+        out, _ = index_net.index_single_forward(state, a, fg, bg, dilate_kernel=3, training=True)
+        (out[0] + out[1] + out[2]).backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert_close(torch.stack([o.detach() for o in out[:3]]).float(), g['losses'], 1e-4, 1e-6, 'losses')
+    assert_close(out[5].float(), g['alphas'], 1e-4, 5e-5, 'alphas')
+    assert_close(out[6].double().sum(), g['comps_sum'], 1e-5, 1e-2, 'comps')
+    names = [str(n) for n in g['grad_names']]
+    got = np.array([float(state[n].grad.double().norm()) for n in names])
+    assert_close(torch.from_numpy(got), g['grad_norms'], 2e-2, 1e-5, 'grad norms')
+
+
 def test_data_loader_golden(tmp_path):
     """oracle/data.py against the REFERENCE loader's outputs (tests/golden/gen_data_golden.py imports dataset/VMD.py behind
     cv2 / imgaug stubs and calls parse, img_crop_and_resize, possible_pad, shape_aug and __getitem__ on a tiny clip tree).
