@@ -105,7 +105,7 @@ def predict_directory(model, args, device, totals):
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument('--model', required=True, choices=['dim', 'gca', 'fba'], help='single-image base on the HIP path')
+    ap.add_argument('--model', required=True, choices=['dim', 'gca', 'fba', 'index'], help='single-image base on the HIP path')
     ap.add_argument('--load', default=None, help='checkpoint (NET.state_dict layout of the reference)')
     ap.add_argument('--trimap', required=True, choices=list(DILATE))
     ap.add_argument('--agg_window', default=7)

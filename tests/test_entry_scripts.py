@@ -337,7 +337,7 @@ def test_pred_test_folder_inference(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('base', ['dim', 'gca', 'fba'])
+@pytest.mark.parametrize('base', ['dim', 'gca', 'fba', 'index'])
 def test_pred_single_dim_config1(base):
     """BASELINE.json config 1: pred_single.py, DIM base, one 512 x 512 synthetic frame + trimap (eval mode); the GCA and FBA
     single-image bases run through the same script."""
