@@ -44,7 +44,7 @@ def profile_traffic(variant):
     m = re.match(r'(\w+?)(<.*>)?$', variant)
     base, targs = m.group(1), (m.group(2) or '')
     if base == 'gemm_nt256':
-        key = 'gemm_nt256_kernel<0>'
+        key = 'gemm_nt256_kernel<0'                    # <0, 4>: fp32-output 256x256 tiles, the bulk of the profiled launches
     else:
         key = base + '_kernel' + (targs[:-1].replace(',', ', ') if targs else '')    # the table truncates long names
     for line in open(files[-1]):
