@@ -15,6 +15,7 @@
 // MFMA roles: rows (M) = output channels, columns (N) = pixels, so that a lane's 4 consecutive
 // accumulator registers are 4 consecutive channels of ONE pixel -> 8-byte NHWC stores, and the
 // BatchNorm statistics of a channel are a reduction across lanes.
+#include <cstdlib>
 #include "common.h"
 #include <mutex>
 
@@ -379,8 +380,11 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         const long long wgs = (long long)cdiv(P, 128) * cdiv(d->K, 128) * nb;
         // the dense attention GEMMs of GCA (8160 x 8160 x 576 / 8160 x 2048 x 8160 at 1080p): 256x256 tiles halve the
         // L2->LDS bytes per MFMA, which is what bounds the 128x128 loop (measured 818 -> 1012 TFLOP/s on P.V)
+        // 128x128 tiles from 256 workgroups on (3-frame launches of the os16 / os32 layers: 16 vs 18 us per frame in isolation, the
+        // step barely moves: 30.02 -> 29.85 ms); TCVOM_NT_T128 = study knob
+        static const int t128 = getenv("TCVOM_NT_T128") ? atoi(getenv("TCVOM_NT_T128")) : 256;
         if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
-        if (wgs >= 512) return {128, 128, 4};
+        if (wgs >= t128) return {128, 128, 4};
         if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
         return {64, 64, 2};
     }
