@@ -285,7 +285,14 @@ def main():
                                   'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
                                   'algorithmic_gflop_per_launch': round(gf / n, 3),
                                   'all_igemm': {k: {'launches': v[0], 'ms': round(v[1], 3), 'tflops': round(v[2] / max(v[1], 1e-9), 1)}
-                                                for k, v in sorted(agg.items())}}
+                                                for k, v in sorted(agg.items())},
+                                  # every conv / GEMM launch of the step (MFMA kernels of all families) and the implicit-GEMM
+                                  # family alone (what is left on igemm_nt / igemm_tt: small-K, strided, 1x1, high-precision layers)
+                                  'aggregate': {name: {'ms': round(sum(v[1] for k, v in agg.items() if sel(k)), 3),
+                                                       'tflops': round(sum(v[2] for k, v in agg.items() if sel(k)) /
+                                                                       max(sum(v[1] for k, v in agg.items() if sel(k)), 1e-9), 1)}
+                                                for name, sel in (('all_conv_gemm', lambda k: True),
+                                                                  ('igemm_nt_tt', lambda k: k.startswith('igemm_')))}}
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -211,14 +211,17 @@ def _profiled(name, args):
     elif name == 'tcvom_wgrad_igemm_batched':
         arr, n, nb = args[4], args[5], args[3]
         d = arr[0]
-        taps = sum(sum(1 for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0) for i in range(n))
+        # algorithmic taps: distinct offsets (the hi + residual weight pair of a high-precision layer is ONE tap of the layer)
+        taps = sum(len({(arr[i].tap_dh[t], arr[i].tap_dw[t]) for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0}) for i in range(n))
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': nb, 'phases': n}
     elif name.endswith('_phases'):
         arr = args[5 if name == 'tcvom_conv_igemm_phases' else 3]
         n = args[6 if name == 'tcvom_conv_igemm_phases' else 4]
         d = arr[0]
-        taps = sum(sum(1 for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0) for i in range(n))
-        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': 1, 'phases': n}
+        # algorithmic taps: distinct offsets (the hi + residual weight pair of a high-precision layer is ONE tap of the layer)
+        taps = sum(len({(arr[i].tap_dh[t], arr[i].tap_dw[t]) for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0}) for i in range(n))
+        # (frame-batched launches: `batch` frames of P pixels each, ops._set_frames)
+        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': max(int(d.batch), 1), 'phases': n}
     else:
         n = 1
         d = args[7 if name == 'tcvom_conv_igemm' else 3]._obj
