@@ -90,13 +90,19 @@ def igemm_profile(step_fn):
     torch.cuda.synchronize()
     L.PROFILE = None
     agg = {}
+    tam = {}
     for name, desc, e0, e1 in rec:
         ms = e0.elapsed_time(e1)
+        if 'bytes' in desc:                          # Temporal Attention Module launches: an HBM-bound kernel family
+            n, t, b = tam.get(desc['variant'], (0, 0.0, 0))
+            tam[desc['variant']] = (n + 1, t + ms, b + desc['bytes'])
+            continue
         real_taps = sum(1 for t in range(desc['ntaps']) if desc['tap_w'][t] >= 0)
         gflop = 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
         var = desc['variant']                       # the instantiation the library selected for this shape
         n, t, g = agg.get(var, (0, 0.0, 0.0))
         agg[var] = (n + 1, t + ms, g + gflop)
+    igemm_profile.tam = tam
     return agg
 
 
@@ -288,6 +294,10 @@ def main():
                                                 for k, v in sorted(agg.items())},
                                   # every conv / GEMM launch of the step (MFMA kernels of all families) and the implicit-GEMM
                                   # family alone (what is left on igemm_nt / igemm_tt: small-K, strided, 1x1, high-precision layers)
+                                  # the Temporal Attention Module against the HBM roofline (algorithmic bytes / event time)
+                                  'tam': {k: {'launches': v[0], 'ms': round(v[1], 4), 'GBps': round(v[2] / max(v[1], 1e-9) / 1e6, 1),
+                                              'frac_of_8TBps': round(v[2] / max(v[1], 1e-9) / 1e6 / 8000.0, 4)}
+                                          for k, v in sorted(getattr(igemm_profile, 'tam', {}).items())},
                                   'aggregate': {name: {'ms': round(sum(v[1] for k, v in agg.items() if sel(k)), 3),
                                                        'tflops': round(sum(v[2] for k, v in agg.items() if sel(k)) /
                                                                        max(sum(v[1] for k, v in agg.items() if sel(k)), 1e-9), 1)}

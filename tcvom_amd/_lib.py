@@ -238,9 +238,30 @@ def _profiled(name, args):
     return rc
 
 
+def _profiled_tam(name, args):
+    """The Temporal Attention Module launches, bracketed by HIP events; `bytes` = algorithmic HBM bytes of the call: q, v (or dout),
+    k_b, k_f read and out (or dq, dk_b, dk_f) written once as bf16 [B, H, W, C], the unknown mask once, plus the 2 x w^2 fp32
+    attention logits of every pixel (forward: written; backward: their gradients read, p / ds scratch written and read)."""
+    import torch
+    if name == 'tcvom_tam_fwd':
+        B, H, W, Cc, win = args[9:14]
+        nbytes = 5 * B * H * W * Cc * 2 + B * H * W + 2 * win * win * B * H * W * 4
+    else:
+        B, H, W, Cc, win = args[13:18]
+        nbytes = 7 * B * H * W * Cc * 2 + B * H * W + 2 * win * win * B * H * W * 4 * 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = _FNS[name](*args)
+    e1.record()
+    PROFILE.append((name, {'variant': name[6:], 'bytes': nbytes, 'P': 0, 'K': 0, 'C': 0, 'ntaps': 0, 'tap_w': [], 'batch': 1}, e0, e1))
+    return rc
+
+
 def call(name, *args):
     """Invoke a status-returning entry point; raise TcvomError on failure."""
-    if PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
+    if PROFILE is not None and name in ('tcvom_tam_fwd', 'tcvom_tam_bwd'):
+        rc = _profiled_tam(name, args)
+    elif PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
                                         'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi'):
         rc = _profiled(name, args)
     else:
