@@ -173,7 +173,10 @@ int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, co
                    int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                    void* stream);
 int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
-int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
+/* dz2 (or NULL): a second addend of the incoming gradient, bf16 like dz -- the skip-branch gradient of a residual block
+ * (`out += identity`, resnet_enc.py:45-47: the block input feeds conv1 AND the residual add), summed in fp32 on the fly
+ * instead of by a separate element-wise pass */
+int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                         const float* saved, float* partial /*[nframes][groups][2][C]*/, int64_t pixels, int32_t C,
                         int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream);
 /* dgamma/dbeta are written, or accumulated when `accumulate` is set; coef is [3][C] scratch consumed by bn_bwd_apply */
@@ -208,7 +211,7 @@ int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local,
                                int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream);
 /* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
  * gradient is additionally masked by y > 0 */
-int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
+int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                        const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                        int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                        int64_t slot_stride, void* stream);

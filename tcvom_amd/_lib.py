@@ -73,13 +73,13 @@ _PROTOS = {
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
-    'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     'tcvom_bn_ema_multi': [vp, i32, vp, vp, vp],
     'tcvom_bn_reduce_sums': [vp, i32, i32, vp, vp, i32, vp],
     'tcvom_bn_finalize_sums': [vp, i32, i64, i64, vp, vp, f32, vp, vp, i32, i64, vp],
     'tcvom_bn_bwd_finalize_sums': [vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i64, vp],
-    'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
     'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, vp],

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 // block = 256 threads = RP pixel rows x C8 channel octets (C8 <= 256); partial[block][2][C]
 template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const uint4* __restrict__ dz, const void* __restrict__ y, const uint4* __restrict__ res1,
+    const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
     float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride)
 {
@@ -245,29 +245,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         // two-deep software pipeline (see bn_apply_kernel)
         int64_t p = pbeg + prow;
         int64_t v = fo + p * C8 + oct;
-        uint4 qg = dz[v];
+        uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
         YRaw<YF32> yr = load_yraw<YF32>(y, v);
         uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
         while (true) {
             const int64_t pn = p + RP;
             const bool more = pn < pend;
             const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-            const uint4 ng = dz[vn];
+            const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
             const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
             const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
-            float g[8], yy[8], r1[8];
+            float g[8], g2[8], yy[8], r1[8];
             unpack8(qg, g);
+            unpack8(qh, g2);
             unpack_yraw<YF32>(yr, yy);
             unpack8(q1, r1);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-                const float gg = g[k] * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
+                const float gg = (g[k] + g2[k]) * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
                 sg[k] += gg;
                 sx[k] += gg * (yy[k] - mu[k]) * is[k];
             }
             if (!more) break;
-            p = pn; qg = ng; yr = yn; q1 = n1;
+            p = pn; qg = ng; qh = nh; yr = yn; q1 = n1;
         }
     }
     float* r_g = red;                 // [256][8]
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
 
 template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const uint4* __restrict__ dz, const void* __restrict__ y, const uint4* __restrict__ res1,
+    const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
     int rows_per_block, int64_t slot_stride)
@@ -372,24 +373,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (p >= pend) return;
     // two-deep software pipeline (see bn_apply_kernel)
     int64_t v = fo + p * C8 + oct;
-    uint4 qg = dz[v];
+    uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
     YRaw<YF32> yr = load_yraw<YF32>(y, v);
     uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
     while (true) {
         const int64_t pn = p + RP;
         const bool more = pn < pend;
         const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-        const uint4 ng = dz[vn];
+        const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
         const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
         const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
-        float g[8], yy[8], r1[8], o[8];
+        float g[8], g2[8], yy[8], r1[8], o[8];
         unpack8(qg, g);
+        unpack8(qh, g2);
         unpack_yraw<YF32>(yr, yy);
         unpack8(q1, r1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-            const float gg = g[k] * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
+            const float gg = (g[k] + g2[k]) * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
             g[k] = gg;
             const float xh = (yy[k] - mu[k]) * is[k];
             o[k] = gi[k] * gg - c1[k] - xh * c2[k];
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         dy[v] = pack8(o);
         if (dres1) dres1[v] = pack8(g);
         if (!more) break;
-        p = pn; v = vn; qg = ng; yr = yn; q1 = n1;
+        p = pn; v = vn; qg = ng; qh = nh; yr = yn; q1 = n1;
     }
 }
 
@@ -547,7 +549,7 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
     return (int)g;
 }
 
-extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* res1, const float* scale_shift,
+extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                    const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
                                    int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && nframes >= 1,
@@ -557,10 +559,10 @@ extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* y, const void* re
     const dim3 grid(groups, nframes);
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
 }
@@ -808,7 +810,7 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
     return TCVOM_OK;
 }
 
-extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res1, const float* scale_shift,
+extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                                   int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                                   int64_t slot_stride, void* stream) {
@@ -818,11 +820,11 @@ extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* y, const void* res
     const dim3 grid(cdiv(pixels, rpb), nframes);
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
                            (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)dz, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
                            (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride);
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;

@@ -96,6 +96,55 @@ def test_conv_fwd_bwd(case):
     assert rel_err(spec.bias.grad.cpu(), br.grad) < 1e-2, 'bias grad'
 
 
+def test_residual_gradient_goes_through_the_producers_batchnorm_backward():
+    """A BasicBlock-shaped graph: z0 = act(BN(conv0(x))) + skip;  o = act(BN(conv1(z0)));  z1 = act(BN(conv2(o)) + z0).  z0 feeds conv1
+    AND the residual add: the second op deposits d(res1) on z0's list instead of returning it, and the op that produced z0 reads it as
+    the second addend `dz2` of its BatchNorm backward (ops.conv_bn_act).  Every gradient -- x, skip (which must see the WHOLE gradient
+    of z0), the three weights -- against fp32 PyTorch autograd on the same bf16-rounded operands."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    Cc, N, H, W = 64, 2, 16, 24
+    bank = WeightBank()
+    ws, bns, cfgs = [], [], []
+    for i in range(3):
+        w = nn.Parameter((formula_tensor('dep.w%d' % i, (Cc, Cc, 3, 3))).to(DEV))
+        bn = nn.BatchNorm2d(Cc).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(hu('dep.g%d' % i, (Cc,)) * 0.3 + 1.0)
+            bn.bias.copy_(hu('dep.b%d' % i, (Cc,)) * 0.3)
+        spec = ConvSpec('dep%d' % i, w, None, None, None, False, 1, 1, 'frame')
+        bank.register(spec)
+        ws.append(w); bns.append(bn); cfgs.append(ops.ConvCfg(bank, spec, bn=bn, act=ops.ACT_RELU))
+    x, skip, gz = hu('dep.x', (N, Cc, H, W)), hu('dep.s', (N, Cc, H, W)), hu('dep.gz', (N, Cc, H, W))
+    xg, sg = nhwc(x).requires_grad_(True), nhwc(skip).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    z0 = ops.conv_bn_act(cfgs[0], xg, token, True, res2=sg)
+    assert getattr(z0, '_tcvom_grad_stash', None) is not None
+    o = ops.conv_bn_act(cfgs[1], z0, token, True)
+    z1 = ops.conv_bn_act(cfgs[2], o, token, True, res1=z0)
+    (z1.float() * nhwc(gz).float()).sum().backward()
+    assert len(z0._tcvom_grad_stash) == 0                          # deposited by op 2, consumed by op 0
+
+    def rb(t):                                                     # bf16 storage points of the HIP path, straight-through gradient
+        return t + (bf(t.detach()) - t.detach())
+    xr, sr = bf(x).requires_grad_(True), bf(skip).requires_grad_(True)
+    wr = [bf(w.detach().cpu()).requires_grad_(True) for w in ws]
+    bnp = [(b.weight.detach().cpu(), b.bias.detach().cpu(), b.eps) for b in bns]
+    conv = lambda t, i: rb(F.conv2d(t, wr[i], None, 1, 1))
+    norm = lambda t, i: F.batch_norm(t, None, None, bnp[i][0], bnp[i][1], True, 0.1, bnp[i][2])
+    z0r = rb(F.relu(norm(conv(xr, 0), 0)) + sr)
+    orf = rb(F.relu(norm(conv(z0r, 1), 1)))
+    z1r = F.relu(norm(conv(orf, 2), 2) + z0r)
+    (z1r * bf(gz)).sum().backward()
+    l2 = lambda got, want: float((got.double() - want.double()).norm() / (want.double().norm() + 1e-12))
+    assert l2(nchw(z1), z1r.detach()) < 1e-2, 'forward'
+    # (bf16 activations flip a few ReLU masks against the fp32 graph: percent-level L2 differences; a lost deposit would be ~50 %)
+    assert l2(nchw(sg.grad), sr.grad) < 6e-2, 'skip gradient (autograd part + deposited part)'
+    assert l2(nchw(xg.grad), xr.grad) < 6e-2, 'input gradient'
+    for i in range(3):
+        assert l2(ws[i].grad.cpu(), wr[i].grad) < 6e-2, 'weight gradient %d' % i
+
+
 def test_conv_small_cin_padded_channels():
     """First-layer convs read the 8-channel packed input with 6 (or 3) real channels."""
     from tcvom_amd import ops

@@ -47,9 +47,9 @@ def main():
         nbytes = y.numel() * 2
         for res in (None, r1):
             t1 = timeit(lambda: L.call('tcvom_bn_apply', L.ptr(y), L.ptr(ss), L.ptr(res), None, L.ptr(z), P, K, 1, 0, nf, 2 * K, st))
-            t2 = timeit(lambda: L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(y), L.ptr(res), L.ptr(ss), L.ptr(saved), L.ptr(partial),
+            t2 = timeit(lambda: L.call('tcvom_bn_bwd_reduce', L.ptr(dz), None, L.ptr(y), L.ptr(res), L.ptr(ss), L.ptr(saved), L.ptr(partial),
                                        P, K, 1, 0, nf, 2 * K, st))
-            t3 = timeit(lambda: L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(y), L.ptr(res), L.ptr(ss), L.ptr(saved), L.ptr(coef),
+            t3 = timeit(lambda: L.call('tcvom_bn_bwd_apply', L.ptr(dz), None, L.ptr(y), L.ptr(res), L.ptr(ss), L.ptr(saved), L.ptr(coef),
                                        L.ptr(dy), L.ptr(dres) if res is not None else None, P, K, 1, 1, 0, 0, nf, 2 * K, st))
             n = 1 if res is not None else 0
             print('%-10s %12.1f (%6.0f) %12.1f (%6.0f) %12.1f (%6.0f)   %s' % (
