@@ -57,6 +57,7 @@ class _WindowLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prep, window, att_thres, label_smooth, S, *tensors):
+        ctx.set_materialize_grads(False)         # no zero tensors for the visualisation outputs / unused losses in backward
         ni = S - 2
         preds, attb, attf = tensors[:ni], tensors[ni:2 * ni], tensors[2 * ni:3 * ni]
         dev = preds[0].device
@@ -142,6 +143,7 @@ class _SingleImageLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prep, c, S, pred):
+        ctx.set_materialize_grads(False)
         st = L.stream_ptr()
         pred = pred.contiguous()
         B, _, H, W = pred.shape

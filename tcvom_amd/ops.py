@@ -856,6 +856,7 @@ fba_head = _FbaHead.apply
 class _TamAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, kb, kf, v, mask_u8, window):
+        ctx.set_materialize_grads(False)         # the attention maps may not reach the loss: no zero tensors for them
         q, kb, kf, v = _c(q), _c(kb), _c(kf), _c(v)
         B, H, W, Cc = q.shape
         out = torch.empty_like(q)
@@ -874,7 +875,9 @@ class _TamAttention(torch.autograd.Function):
         q, kb, kf, mask, work = ctx.saved_tensors
         B, H, W, Cc = q.shape
         w2 = ctx.window * ctx.window
-        dout = _c(dout)
+        if dout is None and dattb is None and dattf is None:
+            return (None,) * 6
+        dout = _c(dout) if dout is not None else torch.zeros_like(q)
         dq, dkb, dkf = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         pbuf = torch.empty((B, 2, w2, H * W), dtype=torch.float32, device=q.device)
         dsbuf = torch.empty_like(pbuf)
