@@ -84,7 +84,7 @@ def predict_directory(model, args, device, padded, frame):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--model', required=True, choices=['gca', 'fba', 'dim'], help='base matting network (HIP path: gca, fba, dim)')
+    ap.add_argument('--model', required=True, choices=['gca', 'fba', 'dim', 'index'], help='base matting network (HIP path: gca, fba, dim, index)')
     ap.add_argument('--load', default=None, help='checkpoint (NET.state_dict layout of the reference)')
     ap.add_argument('--trimap', required=True, choices=list(DILATE))
     ap.add_argument('--agg_window', default=7)
