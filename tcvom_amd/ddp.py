@@ -63,6 +63,7 @@ class GradientAverager(object):
         self.last_plan = None    # (elements reduced in place, number of spans, elements packed, number of buckets)
         self.force = force
         self._early = []         # [(flat view, work, storage ptr, first element, count)] started from the bank hooks
+        self._early_ok = True
         self.early_spans = 0     # diagnostic: spans started before backward returned, last step
         if self._active():       # (a one-process run keeps the bank's single-launch backward)
             for bank in banks:
@@ -72,10 +73,15 @@ class GradientAverager(object):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
 
     def _on_span(self, flat, lo, hi):
-        """WeightBank.backward finished flat[lo:hi] (fp32, final values of this step).  Only valid when no parameter
-        still holds an older .grad that autograd would add these values to (zero_grad(set_to_none=True) each step, as
-        bench.py / train_ddp.py do): otherwise the span is left to average()."""
+        """WeightBank.backward finished flat[lo:hi] (fp32, final values of this step).  Only valid when no parameter still holds
+        an older .grad that autograd would ADD these values to after the all-reduce of the new ones has started
+        (zero_grad(set_to_none=True) each step, as bench.py / train_ddp.py do): checked at the first span of a backward,
+        otherwise the spans are left to average()."""
         if not self._active() or hi <= lo:
+            return
+        if not self._early:
+            self._early_ok = all(p.grad is None for p in self.params)
+        if not self._early_ok:
             return
         avg = dist.get_backend() == 'nccl'
         view = flat[lo:hi]
@@ -131,11 +137,8 @@ class GradientAverager(object):
             return any(sp == e[2] and e[3] <= off and off + g.numel() <= e[3] + e[4] for e in early)
         grads = [p.grad for p in self.params]
         if early:
-            # a parameter that kept an older .grad got `old += new` from autograd AFTER the early all-reduce of `new` was
-            # started: its .grad is not a view of the reduced buffer any more and would silently stay rank-local
-            done = [g for g in grads if covered(g)]
-            assert sum(g.numel() for g in done) == sum(e[4] for e in early), \
-                'early gradient spans need zero_grad(set_to_none=True) before every backward'
+            # (parameters of the bank that do not require a gradient -- a frozen backbone -- leave holes in the spans: reduced
+            #  along with the rest, harmless)
             grads = [g for g in grads if not covered(g)]
         spans, rest = self.plan(grads, self.MIN_SPAN)
         works = [(e[0], None, e[1]) for e in early]

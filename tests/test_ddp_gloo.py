@@ -108,21 +108,21 @@ def _overlap_worker(rank, world, port, q):
         av.average()
         results.append((started, av.early_spans, av.last_plan, flat.clone(), ps[5].grad.clone(),
                         [p.grad.data_ptr() - flat.data_ptr() for p in ps[:5]]))
-    # a parameter that kept its old .grad: autograd would have ADDED the new values after the early all-reduce started
+    # a parameter that kept its old .grad: autograd would ADD the new values to it after the early all-reduce had started, so no
+    # span may start early in such a backward; average() then reduces everything itself
     for p in ps:
         p.grad = None
-    flat = torch.ones(sum(sizes))
+    ps[1].grad = torch.full((sizes[1],), 7.0)                      # left over from an earlier step (no zero_grad)
+    flat = torch.ones(sum(sizes)) * (rank + 1)
     bank.grad_span_hook(flat, 0, 150000)
+    stale = len(av._early)
     off = 0
     for p, n in zip(ps, sizes):
-        p.grad = flat[off:off + n]
+        p.grad = (p.grad + flat[off:off + n]) if p.grad is not None else flat[off:off + n]      # what AccumulateGrad does
         off += n
-    ps[1].grad = ps[1].grad + 1.0                                  # not a view of the reduced buffer any more
-    try:
-        av.average()
-        stale = 'no error'
-    except AssertionError as e:
-        stale = str(e)
+    ps[5].grad = torch.full((7,), float(rank + 1))
+    av.average()
+    stale = (stale, av.early_spans, float(ps[1].grad[0]), float(ps[0].grad[0]))
     q.put((rank, results, stale))
     dist.barrier()
     dist.destroy_process_group()
@@ -141,7 +141,7 @@ def test_two_rank_overlapped_gradient_spans():
         assert p.exitcode == 0
     base = torch.arange(150000, dtype=torch.float32)
     for rank, results, stale in res:
-        assert 'set_to_none' in stale
+        assert stale == (0, 0, 8.5, 1.5)                           # nothing started early; mean of (7 + 1, 7 + 2) and of (1, 2)
         for step, (started, early, plan, flat, small, offs) in enumerate(results):
             assert started == [1, 2, 3] and early == 3             # one collective per span, started before average()
             assert plan == (150000, 3, 7, 1)                       # 3 early spans in place + one packed bucket
