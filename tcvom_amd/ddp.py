@@ -64,6 +64,9 @@ class GradientAverager(object):
         self.force = force
         self._early = []         # [(flat view, work, storage ptr, first element, count)] started from the bank hooks
         self._early_ok = True
+        # the parameters whose gradients ARE the bank's flat buffer (assigned by autograd after the bank's backward returns;
+        # other leaves -- BatchNorm scales, biases -- legitimately have their .grad by then)
+        self._bank_params = [p for bank in banks for p in bank.weight_params()]
         self.early_spans = 0     # diagnostic: spans started before backward returned, last step
         if self._active():       # (a one-process run keeps the bank's single-launch backward)
             for bank in banks:
@@ -80,7 +83,7 @@ class GradientAverager(object):
         if not self._active() or hi <= lo:
             return
         if not self._early:
-            self._early_ok = all(p.grad is None for p in self.params)
+            self._early_ok = all(p.grad is None for p in self._bank_params)
         if not self._early_ok:
             return
         avg = dist.get_backend() == 'nccl'
