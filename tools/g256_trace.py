@@ -3,7 +3,7 @@
 the GCA P.V shape: per section of the 4-phase K-tile, the wave's own work and its wait at the closing barrier.
 Needs a library built with -DG256_TRACE:
     make -C tcvom_amd/csrc FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value -DG256_TRACE"
-    TCVOM_HIP_LIB=<that .so> python tools/g256_trace.py"""
+    TCVOM_LIB=<that .so> python tools/g256_trace.py"""
 import ctypes as C
 import os
 import sys
