@@ -69,14 +69,14 @@ def window_gflop(H, W, config='gca'):
 def build(device, H, W, seed, config='gca'):
     from models.model import FullModel_VMD
     from tcvom_amd.synthetic import formula_tensor, synthetic_window
-    model = FullModel_VMD('vmn_fba' if config == 'fba' else 'vmn_gca', agg_window=7, dilate_kernel=12)
+    model = FullModel_VMD({'fba': 'vmn_fba', 'index': 'vmn_index'}.get(config, 'vmn_gca'), agg_window=7, dilate_kernel=12)
     model.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in model.NET.state_dict().items()})
     model = model.to(device).train()
     if os.environ.get('TCVOM_FRAME_STREAMS', '1') == '0' and hasattr(model.NET, 'frame_streams'):      # profiling aid
         model.NET.frame_streams = False
     if os.environ.get('TCVOM_BATCHED_FRAMES', '1') == '0' and hasattr(model.NET, 'batched_frames'):    # A/B aid
         model.NET.batched_frames = False
-    a, fg, bg = synthetic_window(1, 3, H, W, seed=seed)
+    a, fg, bg = synthetic_window(2 if config == 'index' else 1, 3, H, W, seed=seed)
     return model, a.to(device), fg.to(device), bg.to(device)
 
 
@@ -187,8 +187,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--height', type=int, default=FULL_H)
     ap.add_argument('--width', type=int, default=FULL_W)
-    ap.add_argument('--config', choices=('gca', 'fba'), default='gca',
-                    help='gca: the headline GCA+TAM window (BASELINE.json configs[2]); fba: FBA+TAM (configs[4], the heaviest base)')
+    ap.add_argument('--config', choices=('gca', 'fba', 'index'), default='gca',
+                    help='gca: the headline GCA+TAM window (BASELINE.json configs[2]); fba: FBA+TAM (configs[4], the heaviest base); '
+                         'index: IndexNet+TAM (not a BASELINE config; 2 clips per step: its ASPP has a BatchNorm over the batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--sync-bn', action='store_true',
@@ -215,7 +216,8 @@ def main():
     from tcvom_amd.optim import FusedAdam
     H, W = args.height, args.width
     model, a, fg, bg = build(device, H, W, seed=rank, config=args.config)
-    base = 'FBA+TAM' if args.config == 'fba' else 'GCA+TAM'
+    base = {'fba': 'FBA+TAM', 'index': 'IndexNet+TAM'}.get(args.config, 'GCA+TAM')
+    clips = 2 if args.config == 'index' else 1
     if args.sync_bn:
         convert_sync_batchnorm(model)
     broadcast_module_state(model)
@@ -254,8 +256,8 @@ def main():
 
     result = None
     if rank == 0:
-        win_per_s = world * args.steps / elapsed
-        gflop = window_gflop(H, W, args.config)
+        win_per_s = world * clips * args.steps / elapsed
+        gflop = window_gflop(H, W, args.config) if args.config != 'index' else None      # (no FLOP count taken for IndexNet)
         result = {
             'metric': '1080p 3-frame windows/sec (fwd+bwd) %s' % base if (H, W) == (FULL_H, FULL_W)
                       else '%dx%d 3-frame windows/sec (fwd+bwd) %s' % (H, W, base),
@@ -265,16 +267,19 @@ def main():
             'config': {'workload': ('GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
                                     '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
                                     'formula-initialised weights, train mode' % (H, W)) if args.config == 'gca' else
+                                   ('IndexNet+TAM (vmn_index: MobileNetV2 encoder with learned index blocks, ASPP, indexed up-sampling decoder) '
+                                    'fwd+bwd+grad-allreduce+Adam, L_alpha+L_comp+L_grad+0.5L_dt+0.25L_att, two 3-frame %dx%d windows per GPU per '
+                                    'step (train-mode BatchNorm over the batch in the ASPP), formula-initialised weights' % (H, W)) if args.config == 'index' else
                                    ('FBA+TAM (vmn_fba: ResNet-50 GN+WS dilated os8, PPM, 7-channel head, 11-channel input with the '
                                     '2-scale trimap channels) fwd+bwd+grad-allreduce+Adam, L_alpha_comp+L_lap+L_grad+0.5L_dt+0.25L_att, '
                                     'one 3-frame %dx%d window per GPU per step, formula-initialised weights, train mode; BASELINE '
                                     'config 5 names fp16: the engine computes in bf16 (same MFMA rate, no loss scaling needed)' % (H, W)),
-                       'global_batch_clips': world, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn)},
+                       'global_batch_clips': world * clips, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn)},
             'final_loss': round(final_loss, 6),
             'dist': {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,
                      'grad_spans_overlapped_with_backward': averager.early_spans,
                      'grad_allreduce_plan': averager.last_plan},
-            'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5),
+            'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5) if gflop is not None else None,
         }
     # ---- roofline of the dominant kernel (event-instrumented extra step on rank 0's stream)
     if not args.no_profile:
@@ -307,7 +312,8 @@ def main():
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline((H, W)) if args.config == 'gca' else cpu_baseline_fba()
+            if args.config != 'index':                      # (no CPU line for the extra IndexNet configuration)
+                result['cpu_baseline'] = cpu_baseline((H, W)) if args.config == 'gca' else cpu_baseline_fba()
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

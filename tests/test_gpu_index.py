@@ -340,3 +340,23 @@ def test_eval_model_runs_vmn_index():
     # outside the (dilated) unknown band the output is the trimap value
     far = known & (torch.nn.functional.max_pool2d((tris[:, 1] == 128).float(), 5, 1, 2).to(DEV) == 0)
     assert torch.equal(out[:, 1][far], (tris[:, 1].to(DEV) / 255.0)[far])
+
+
+def test_window_1080p_forward_backward():
+    """vmn_index at the north-star frame size: two 3-frame 1088x1920 clips forward + backward (the goldens pin the arithmetic at
+    64..128 pixels, the oracle comparison at 256x320; this exercises the full-size launch geometry: 960-channel depthwise layers at
+    os16, 5x5 decoder convs at os1, index blocks from os1 down).  Finite losses, alpha of the interior frame in [0, 1] after the
+    clamp, a finite gradient for every parameter."""
+    from tcvom_amd.facade import train_step_loss
+    fm = _build(12)
+    a, fg, bg = [t.to(DEV) for t in synthetic_window(2, 3, 1088, 1920, seed=5)]
+    out = fm(a, fg, bg)
+    loss = train_step_loss(out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and float(loss) > 0
+    al = out[7][:, 1]
+    assert bool(torch.isfinite(al).all()) and float(al.min()) >= 0.0 and float(al.max()) <= 1.0
+    grads = [p.grad for p in fm.NET.parameters()]
+    assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads)
+    assert sum(float(g.abs().sum()) > 0 for g in grads) >= 0.95 * len(grads)
