@@ -141,6 +141,10 @@ int tcvom_index_up_fwd(const void* enc, const void* idx, const void* low, void* 
                        int32_t C1, int32_t C2, void* stream);
 int tcvom_index_up_bwd(const void* dout, const void* enc, const void* idx, void* denc, void* didx, void* dlow, int32_t N,
                        int32_t H, int32_t W, int32_t C1, int32_t C2, void* stream);
+/* pred[1] of the IndexNet decoder: nn.Conv2d(1, 1, 5, padding=2, bias=False) (models/Index/net.py:21) on a fp32 [N][H][W] map,
+ * w fp32 [25]; flip != 0: reversed taps (data gradient); _wgrad: dw[25] = sum dy * shifted x (overwritten). */
+int tcvom_conv5x5_c1(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t flip, void* stream);
+int tcvom_conv5x5_c1_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm around the convs
  * Replaces nn.BatchNorm2d (+ReLU / LeakyReLU(0.2) / residual add) of the BasicBlocks

@@ -157,6 +157,8 @@ _PROTOS = {
     'tcvom_index_pool_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_index_up_fwd': [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_index_up_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_conv5x5_c1': [vp, vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_conv5x5_c1_wgrad': [vp, vp, vp, i32, i32, i32, vp],
     'tcvom_dw3x3_stats_groups': [i64, i32],
     'tcvom_dw3x3': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_dw3x3_wgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],

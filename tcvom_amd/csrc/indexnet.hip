@@ -231,3 +231,69 @@ extern "C" int tcvom_index_up_bwd(const void* dout, const void* enc, const void*
     TCVOM_LAUNCH_CHECK("index_up_bwd");
     return TCVOM_OK;
 }
+
+// ---------------------------------------------------------------- pred[1]: nn.Conv2d(1, 1, 5, padding=2, bias=False) on a fp32 map
+// (models/Index/net.py:21; the last layer of the decoder: its input is the ONE-channel output of pred[0] = conv + BN + ReLU6).
+// x, y: fp32 [N][H][W]; w: fp32 [25].  flip: taps reversed (the data gradient).  One thread per output pixel; the 25 inputs of
+// neighbouring threads overlap in L1.
+__global__ __launch_bounds__(256) void conv5x5_c1_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                         int64_t pixels, int H, int W, int flip) {
+    float wt[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) wt[t] = w[flip ? 24 - t : t];
+    GRID_STRIDE(p, pixels) {
+        const int xw = (int)(p % W);
+        const int yh = (int)((p / W) % H);
+        const int64_t base = p - (int64_t)yh * W - xw;               // first pixel of the sample
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const int ih = yh + t / 5 - 2, iw = xw + t % 5 - 2;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) acc += wt[t] * x[base + (int64_t)ih * W + iw];
+        }
+        y[p] = acc;
+    }
+}
+// dw[t] += sum_p dy[p] * x[p + off_t]: per-thread accumulators, wave + block reduction, one atomic per tap and block
+__global__ __launch_bounds__(256) void conv5x5_c1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               float* __restrict__ dw, int64_t pixels, int H, int W) {
+    __shared__ float red[4];
+    float acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+    GRID_STRIDE(p, pixels) {
+        const int xw = (int)(p % W);
+        const int yh = (int)((p / W) % H);
+        const int64_t base = p - (int64_t)yh * W - xw;
+        const float g = dy[p];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const int ih = yh + t / 5 - 2, iw = xw + t % 5 - 2;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) acc[t] += g * x[base + (int64_t)ih * W + iw];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        const float s = block_sum_256(acc[t], red);
+        if (threadIdx.x == 0) atomicAdd(dw + t, s);
+    }
+}
+
+extern "C" int tcvom_conv5x5_c1(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t flip, void* stream) {
+    TCVOM_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0, "conv5x5_c1: bad args");
+    const int64_t pixels = (int64_t)N * H * W;
+    hipLaunchKernelGGL(conv5x5_c1_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream, x, w, y, pixels, H, W, flip);
+    TCVOM_LAUNCH_CHECK("conv5x5_c1");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_conv5x5_c1_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W, void* stream) {
+    TCVOM_CHECK_ARG(dy && x && dw && N > 0 && H > 0 && W > 0, "conv5x5_c1_wgrad: bad args");
+    const int64_t pixels = (int64_t)N * H * W;
+    if (hipMemsetAsync(dw, 0, 25 * sizeof(float), (hipStream_t)stream) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "conv5x5_c1_wgrad: memset");
+    int blocks = grid_for(pixels);
+    if (blocks > 1024) blocks = 1024;                                 // 25 atomics per block
+    hipLaunchKernelGGL(conv5x5_c1_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dw, pixels, H, W);
+    TCVOM_LAUNCH_CHECK("conv5x5_c1_wgrad");
+    return TCVOM_OK;
+}

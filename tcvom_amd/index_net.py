@@ -288,15 +288,23 @@ class IndexMattingDecoder_VMN(nn.Module):
         p = ops.head_conv(l, conv0.weight, self._zero_bias, 5, 2)
         nf = self._bank.frames_per_op
         N = p.shape[0]
-        if training:                                                   # the frames of a frame-batched call: separate BatchNorm calls
-            outs = [F.batch_norm(p[f * (N // nf):(f + 1) * (N // nf)], bn.running_mean, bn.running_var, bn.weight, bn.bias, True,
-                                 0.1 if bn.momentum is None else bn.momentum, bn.eps) for f in range(nf)]
+        # BatchNorm over ONE channel as tensor expressions (a library BatchNorm kernel runs a single-channel map on one
+        # workgroup); the frames of a frame-batched call are separate BatchNorm calls
+        if training:
+            pf = p.reshape(nf, -1)
+            var, mean = torch.var_mean(pf, dim=1, unbiased=False, keepdim=True)
+            p = ((pf - mean) * torch.rsqrt(var + bn.eps)).reshape(p.shape)
             with torch.no_grad():
+                m = 0.1 if bn.momentum is None else bn.momentum
+                cnt = pf.shape[1]
+                for f in range(nf):                                    # running statistics: one EMA step per call, in call order
+                    bn.running_mean.mul_(1 - m).add_(m * mean[f])
+                    bn.running_var.mul_(1 - m).add_(m * var[f] * (cnt / (cnt - 1.0)))
                 bn.num_batches_tracked += nf
-            p = torch.cat(outs, 0) if nf > 1 else outs[0]
         else:
-            p = F.batch_norm(p, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
-        return F.conv2d(F.relu6(p), conv1.weight, None, 1, 2)
+            p = (p - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps)
+        p = p * bn.weight + bn.bias
+        return ops.conv5x5_c1(F.relu6(p), conv1.weight)
 
 
 def build_vmn_index(agg_window, agg_reduction=1, freeze_backbone=False):

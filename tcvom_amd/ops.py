@@ -456,6 +456,32 @@ class _IndexUp(torch.autograd.Function):
         return denc, didx, dlow
 
 
+class _Conv5x5C1(torch.autograd.Function):
+    """nn.Conv2d(1, 1, 5, padding=2, bias=False) on a fp32 [N, 1, H, W] map (the last layer of the IndexNet decoder)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _c(x.float())
+        N, _, H, W = x.shape
+        w = _c(weight.detach().float().reshape(25))
+        y = torch.empty_like(x)
+        L.call('tcvom_conv5x5_c1', L.ptr(x), L.ptr(w), L.ptr(y), N, H, W, 0, L.stream_ptr())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, _, H, W = x.shape
+        dy = _c(dy.float())
+        dx = torch.empty_like(x)
+        L.call('tcvom_conv5x5_c1', L.ptr(dy), L.ptr(w), L.ptr(dx), N, H, W, 1, L.stream_ptr())
+        dw = torch.empty(25, dtype=torch.float32, device=x.device)
+        L.call('tcvom_conv5x5_c1_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), N, H, W, L.stream_ptr())
+        return dx, dw.reshape(1, 1, 5, 5)
+
+
+conv5x5_c1 = _Conv5x5C1.apply
 index_pool = _IndexPool.apply
 index_up = _IndexUp.apply
 
