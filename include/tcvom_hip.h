@@ -79,6 +79,11 @@ int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias
  * descs[i].stats_group_offset must be i * tcvom_conv_stats_groups(descs, nphase). */
 int tcvom_conv_igemm_phases(const void* in, const void* w, void* out, const float* bias, float* stats_partial,
                             const tcvom_conv_desc* descs, int32_t nphase, void* stream);
+/* Two dense products against ONE weight operand (out1 = in1 x w^T, out2 = in2 x w^T, both described by `desc`: ntaps = 1;
+ * in2's batch stride is in2_bstride instead of desc->in_bstride) in one launch where the 256-tile GEMM takes the shape, else as two launches.  Replaces the two `torch.matmul`s autograd
+ * runs for d(query) and d(key) of models/GCA/ops.py:177's F.conv2d (same correlation weights, two gradient operands). */
+int tcvom_gemm_pair(const void* in1, const void* in2, const void* w, void* out1, void* out2,
+                    const tcvom_conv_desc* desc, int64_t in2_bstride, void* stream);
 /* name of the kernel instantiation a launch with these descriptors selects (bench / profile labels) */
 const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase);
 const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d);
@@ -259,7 +264,7 @@ int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_t Cc, int64
 int tcvom_head_conv_fwd(const void* x, const float* w, const float* bias, float* alpha, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t ksize, int32_t mode, void* stream);
 /* dw is [replicas][ksize*ksize][C] and db [replicas] fp32: the per-block partial sums are spread over `replicas`
- * copies (less atomic contention; ksize 3 only, else 1) which the caller adds up */
+ * copies (1..64; less atomic contention) which the caller adds up */
 int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, const void* x, const float* w, void* dx,
                         float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
                         int32_t ksize, int32_t mode, int32_t replicas, void* stream);

@@ -64,6 +64,7 @@ _PROTOS = {
     'tcvom_conv_igemm': [vp, vp, vp, vp, vp, vp, vp, DP, vp],
     'tcvom_conv_stats_groups': [DP, i32],
     'tcvom_conv_igemm_phases': [vp, vp, vp, vp, vp, DP, i32, vp],
+    'tcvom_gemm_pair': [vp, vp, vp, vp, vp, DP, i64, vp],
     'tcvom_wgrad_igemm_phases': [vp, vp, vp, DP, i32, i32, vp],
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
     'tcvom_wgrad_igemm_batched': [vp, vp, vp, i32, DP, i32, i32, vp],
@@ -224,11 +225,15 @@ def _profiled(name, args):
         taps = sum(len({(arr[i].tap_dh[t], arr[i].tap_dw[t]) for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0}) for i in range(n))
         # (frame-batched launches: `batch` frames of P pixels each, ops._set_frames)
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': max(int(d.batch), 1), 'phases': n}
+    elif name == 'tcvom_gemm_pair':
+        n = 1
+        d = args[5]._obj
+        info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': 1, 'tap_w': [0], 'batch': 2 * max(int(d.batch), 1), 'phases': 1}
     else:
         n = 1
         d = args[7 if name == 'tcvom_conv_igemm' else 3]._obj
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': d.ntaps, 'tap_w': list(d.tap_w), 'batch': d.batch, 'phases': 1}
-    if name.startswith('tcvom_conv_igemm'):
+    if name.startswith('tcvom_conv_igemm') or name == 'tcvom_gemm_pair':
         info['variant'] = _FNS['tcvom_conv_igemm_variant'](C.byref(d), n).decode()
     else:
         info['variant'] = _FNS['tcvom_wgrad_igemm_variant'](C.byref(d)).decode()
@@ -264,7 +269,7 @@ def call(name, *args):
     if PROFILE is not None and name in ('tcvom_tam_fwd', 'tcvom_tam_bwd'):
         rc = _profiled_tam(name, args)
     elif PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
-                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi'):
+                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi', 'tcvom_gemm_pair'):
         rc = _profiled(name, args)
     else:
         rc = _FNS[name](*args)

@@ -41,8 +41,16 @@ struct Gemm256Args {
     bf16raw* Tt;
     bf16raw* Pt;
     int ldt;
+    // paired launch (gemm_nt256_pair): grid z in [batch, 2 batch) multiplies the SAME A with B2 into out2
+    const bf16raw* B2;
+    void* out2;
+    long long b2_bstride;
 };
 
+#ifndef G256_DMA_MFMA
+#define G256_DMA_MFMA 1       // 1: the LDS-DMA instructions ride behind MFMA pairs; 0: in the LOAD sections of phases 2 / 3, as in the
+                              // guide's 8-phase template -- measured 6-8 % SLOWER here (O = P V 792 -> 852 us per 3-frame launch)
+#endif
 #ifdef G256_TRACE
 __device__ unsigned long long g256_trace[512];
 extern "C" int tcvom_trace256_read(unsigned long long* host) {
@@ -71,9 +79,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int bz = blockIdx.z;
+    const bool second = (int)blockIdx.z >= g.batch;
+    const int bz = second ? blockIdx.z - g.batch : blockIdx.z;
     const bf16raw* A = g.A + bz * g.a_bstride;
-    const bf16raw* B = g.B + bz * g.b_bstride;
+    const bf16raw* B = second ? g.B2 + bz * g.b2_bstride : g.B + bz * g.b_bstride;
+    void* const gout = second ? g.out2 : g.out;
     const float* bias = g.bias ? g.bias + bz * g.vec_bstride : nullptr;
     const float* mscale = g.mscale ? g.mscale + bz * g.vec_bstride : nullptr;
     const float* mdiag = g.mdiag ? g.mdiag + bz * g.vec_bstride : nullptr;
@@ -162,14 +172,26 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         // phase 1: quadrant (m0, n0)
         G_READ_A(buf, 0) G_READ_B(buf, 0)
         G_BAR();
-        G_MFMA(0, 0, 1, t + 1)
+        G_MFMA(0, 0, G256_DMA_MFMA ? 1 : 0, t + 1)
         G_BAR();
         // phase 2: quadrant (m0, n1)
+#if !G256_DMA_MFMA
+        if (t + 1 < ntile) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) G_ISSUE_A(t + 1, it)
+        }
+#endif
         G_READ_B(buf, 1)
         G_BAR();
-        G_MFMA(0, 1, 2, t + 1)
+        G_MFMA(0, 1, G256_DMA_MFMA ? 2 : 0, t + 1)
         G_BAR();
         // phase 3: quadrant (m1, n1)
+#if !G256_DMA_MFMA
+        if (t + 1 < ntile) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) G_ISSUE_B(t + 1, it)
+        }
+#endif
         G_READ_A(buf, 1)
         G_BAR();
         G_MFMA(1, 1, 0, 0)
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         }
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
-        bf16raw* Tb = reinterpret_cast<bf16raw*>(g.out) + obase;
+        bf16raw* Tb = reinterpret_cast<bf16raw*>(gout) + obase;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int r = (it * 8 + wave) * 2 + (lane >> 5), cp = lane & 31, c = cp ^ (r & 15);
@@ -304,8 +326,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     v[r] = x;
                 }
                 if (pvalid[b] && mrow < g.M) {
-                    if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(g.out) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(gout) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(gout) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                 }
             }
         }
@@ -327,8 +349,10 @@ int gemm_nt256_takes(const tcvom_conv_desc* d) {
 }
 
 // 1: launched; 0: not a shape for this kernel.  Called from conv_igemm_launch for dense descriptors (ntaps == 1).
+// in2 / out2 non-null: paired launch, the second product in2 x w -> out2 rides in grid z (same descriptor).
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream) {
+                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream, const void* in2, void* out2,
+                          long long in2_bstride) {
     if (!gemm_nt256_takes(d)) return 0;
     const long long P = (long long)d->N * d->PH * d->PW;
     const int nb = d->batch > 1 ? d->batch : 1;
@@ -354,10 +378,11 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.P = nullptr;
     g.delta = nullptr;
     g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
+    g.B2 = (const bf16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
-    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)cdiv(d->K, m192 ? 192 : 256), (unsigned)nb);
+    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)cdiv(d->K, m192 ? 192 : 256), (unsigned)(in2 ? 2 * nb : nb));
     if (m192) {
         if (g.out_fp32) hipLaunchKernelGGL((gemm_nt256_kernel<0, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_nt256_kernel<1, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
@@ -397,6 +422,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.delta = delta;
     TCVOM_CHECK_ARG((Tt == nullptr) == (Pt == nullptr) && (!Tt || ld % 256 == 0), "gca_dp_softmax_bwd: the transposed copies come together and need ld %% 256 == 0");
     g.Tt = (bf16raw*)Tt; g.Pt = (bf16raw*)Pt; g.ldt = (int)ld;
+    g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");

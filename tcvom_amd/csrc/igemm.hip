@@ -402,7 +402,8 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
                       float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
 // gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream);
+                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream, const void* in2, void* out2,
+                          long long in2_bstride);
 int gemm_nt256_takes(const tcvom_conv_desc* d);
 // halo.hip: weight gradient of the 32 -> 32 channel full-resolution layers from LDS-resident x halo / dy tiles
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
@@ -480,7 +481,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     }
     TCVOM_CHECK_ARG(d0->w_layout == 0, "conv_igemm: fragment-major weights (w_layout = 1) are only served by the weight-stationary kernel");
     if (nphase == 1 && !stats_partial) {
-        const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream);
+        const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream, nullptr, nullptr, 0);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
@@ -496,6 +497,26 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
 #undef NT_LAUNCH
     TCVOM_LAUNCH_CHECK("conv_igemm");
     return TCVOM_OK;
+}
+
+// Two dense products against the same weight operand, out1 = in1 x w^T and out2 = in2 x w^T (one descriptor), in ONE launch
+// where the 256-tile GEMM takes the shape: the d(query) / d(key) GEMMs of GuidedCxtAtten's backward (M = 576, K = 8192, 3 frames)
+// are 288 workgroups each -- 1.125 rounds on 256 CUs, i.e. two rounds of time; together 576 = 2.25 -> three rounds for both.
+extern "C" int tcvom_gemm_pair(const void* in1, const void* in2, const void* w, void* out1, void* out2,
+                               const tcvom_conv_desc* desc, int64_t in2_bstride, void* stream) {
+    TCVOM_CHECK_ARG(in1 && in2 && w && out1 && out2 && desc, "gemm_pair: null pointer");
+    if (gemm_nt256_takes(desc)) {
+        const bf16raw* zp = zero_page_for_current_device();
+        TCVOM_CHECK_ARG(zp != nullptr, "gemm_pair: could not allocate the zero page");
+        TCVOM_CHECK_ARG(desc->w_layout == 0, "gemm_pair: plain weight layout only");
+        const int r = gemm_nt256_try_launch(in1, w, out1, nullptr, nullptr, nullptr, desc, zp, stream, in2, out2, in2_bstride);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
+    const int r1 = conv_igemm_launch(in1, w, out1, nullptr, nullptr, nullptr, nullptr, desc, 1, stream);
+    if (r1 != TCVOM_OK) return r1;
+    tcvom_conv_desc d2 = *desc;
+    d2.in_bstride = in2_bstride;
+    return conv_igemm_launch(in2, w, out2, nullptr, nullptr, nullptr, nullptr, &d2, 1, stream);
 }
 
 extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias,

@@ -305,72 +305,25 @@ __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __
     }
 }
 // dw[t][c] = sum_p dpre[p] x[p + off_t][c];  db = sum_p dpre[p].
-// block = 256 threads = (256/C) pixel lanes x C channels; each thread keeps KS*KS tap accumulators for its channel
-// over the block's pixel chunk; lanes are combined through LDS, then one atomicAdd per (tap, channel) per block.
+// Input-stationary: x is read ONCE (16 bytes = 8 channels per thread and pixel) and multiplied with the KS*KS
+// neighbouring dpre values (fp32 scalars, L1/L2-resident); KS*KS*8 accumulators per thread, pixel lanes combined
+// through LDS, one atomicAdd per (tap, channel) and block, spread over `replicas` copies of dw that the caller sums
+// (2048 blocks onto ONE copy measured ~500 us of pure atomic serialisation).  A tap-stationary version that re-read x
+// once per tap took 505 us (3x3, 64 channels) and 4.0 ms (5x5, 32 channels) at 1088x1920 against ~60 us for one pass.
 template <int KS>
 __global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* __restrict__ dpre, const bf16raw* __restrict__ x,
                                                                    float* __restrict__ dw, float* __restrict__ db,
-                                                                   int N, int H, int W, int C, int rows_per_block) {
+                                                                   int N, int H, int W, int C, int rows_per_block, int replicas) {
     constexpr int T = KS * KS, R = KS / 2;
-    __shared__ float red[T * 256];
-    const int64_t P = (int64_t)N * H * W;
-    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    const int c = threadIdx.x % C, pl = threadIdx.x / C, PL = 256 / C;
-    float acc[T], bsum = 0.f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
-    if (pl < PL) {
-        for (int64_t p = pbeg + pl; p < pend; p += PL) {
-            const float dp = dpre[p];
-            const int xw = (int)(p % W);
-            const int yh = (int)((p / W) % H);
-            if (c == 0) bsum += dp;
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int ih = yh + t / KS - R, iw = xw + t % KS - R;
-                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                    acc[t] += dp * bf2f(x[(p + (int64_t)(t / KS - R) * W + (t % KS - R)) * C + c]);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) red[t * 256 + threadIdx.x] = acc[t];
-    __syncthreads();
-    if (threadIdx.x < C) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            float s = 0.f;
-            for (int l = 0; l < PL; ++l) s += red[t * 256 + l * C + threadIdx.x];
-            atomicAdd(dw + t * C + threadIdx.x, s);
-        }
-    }
-    __syncthreads();
-    red[threadIdx.x] = bsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int l = 0; l < PL; ++l) s += red[l * C];
-        atomicAdd(db, s);
-    }
-}
-
-// 3x3 variant, input-stationary: x is read ONCE (16 bytes = 8 channels per thread and pixel) and multiplied with the 9
-// neighbouring dpre values (fp32 scalars, L1/L2-resident); 72 accumulators per thread, pixel lanes combined through
-// LDS, one atomicAdd per (tap, channel) and block.  The generic kernel above re-reads x once per tap (9x the traffic:
-// 505 us at 1088x1920 against ~60 us for one pass).
-__global__ __launch_bounds__(256) void head_conv3_bwd_weight_kernel(const float* __restrict__ dpre, const bf16raw* __restrict__ x,
-                                                                    float* __restrict__ dw, float* __restrict__ db,
-                                                                    int N, int H, int W, int C, int rows_per_block, int replicas) {
-    __shared__ float red[256 * 9];
+    __shared__ float red[256 * T];
     const int C8 = C / 8;
     const int64_t P = (int64_t)N * H * W;
     const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
     const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, PL = 256 / C8;
-    float acc[9][8];
+    float acc[T][8];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
     float bsum = 0.f;
@@ -381,28 +334,27 @@ __global__ __launch_bounds__(256) void head_conv3_bwd_weight_kernel(const float*
         unpack8(*reinterpret_cast<const uint4*>(x + q * C + c8 * 8), f);
         if (c8 == 0) bsum += dpre[q];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < T; ++t) {
             // x[q] is tap t of the output pixel o = q - off_t
-            const int oh = yh - (t / 3 - 1), ow = xw - (t % 3 - 1);
+            const int oh = yh - (t / KS - R), ow = xw - (t % KS - R);
             if (oh < 0 || oh >= H || ow < 0 || ow >= W) continue;
-            const float dp = dpre[q - (int64_t)(t / 3 - 1) * W - (t % 3 - 1)];
+            const float dp = dpre[q - (int64_t)(t / KS - R) * W - (t % KS - R)];
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[t][k] += dp * f[k];
         }
     }
-    // combine the PL pixel lanes: for every k, red[t][thread]; then thread (c8, k) of lane 0.. sums
+    // combine the PL pixel lanes: for every k, red[t][thread]; then thread i < T*C8 sums (t = i / C8, c8' = i % C8)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 9; ++t) red[t * 256 + threadIdx.x] = acc[t][k];
+        for (int t = 0; t < T; ++t) red[t * 256 + threadIdx.x] = acc[t][k];
         __syncthreads();
-        // 9 * C8 outputs for this k: thread i < 9*C8 handles (t = i / C8, c8' = i % C8)
-        if (threadIdx.x < 9 * C8) {
-            const int t = threadIdx.x / C8, cc = threadIdx.x % C8;
+        for (int i = threadIdx.x; i < T * C8; i += 256) {
+            const int t = i / C8, cc = i % C8;
             float sacc = 0.f;
             for (int l = 0; l < PL; ++l) sacc += red[t * 256 + l * C8 + cc];
-            atomicAdd(dw + (int64_t)(blockIdx.x % replicas) * 9 * C + t * C + cc * 8 + k, sacc);
+            atomicAdd(dw + (int64_t)(blockIdx.x % replicas) * T * C + t * C + cc * 8 + k, sacc);
         }
     }
     __syncthreads();
@@ -503,7 +455,7 @@ extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, cons
                                    float* dpre, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C,
                                    int32_t ksize, int32_t mode, int32_t replicas, void* stream) {
     TCVOM_CHECK_ARG(dalpha && alpha && x && w && dx && dpre && dw && db && C % 8 == 0 && C <= 256 && 256 % C == 0, "head_conv_bwd: bad args");
-    TCVOM_CHECK_ARG(replicas >= 1 && (ksize == 3 || replicas == 1), "head_conv_bwd: replicas=%d (only the 3x3 kernel spreads dw)", replicas);
+    TCVOM_CHECK_ARG(replicas >= 1 && replicas <= 64, "head_conv_bwd: replicas=%d outside 1..64", replicas);
     TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && (mode == 1 || mode == 2)), "head_conv_bwd: ksize=%d mode=%d not instantiated", ksize, mode);
     hipStream_t st = (hipStream_t)stream;
     const int T = ksize * ksize;
@@ -517,15 +469,14 @@ extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, cons
     if (hipMemsetAsync(dw, 0, sizeof(float) * T * C * replicas, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * replicas, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "head_conv_bwd: memset failed");
     const int64_t P = (int64_t)N * H * W;
-    // every block ends with T*C atomicAdds onto the SAME addresses (2048 blocks measured ~500 us of pure atomic
-    // serialisation): the 3x3 kernel spreads them over `replicas` copies of dw that the caller sums
+    // every block ends with T*C atomicAdds; `replicas` copies of dw (summed by the caller) keep them from serialising
     int64_t blocks = (P + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
     const int rpb = (int)((P + blocks - 1) / blocks);
     if (ksize == 3)
-        hipLaunchKernelGGL(head_conv3_bwd_weight_kernel, dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb, replicas);
+        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<3>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb, replicas);
     else
-        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<5>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb);
+        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<5>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb, replicas);
     TCVOM_LAUNCH_CHECK("head_conv_bwd");
     return TCVOM_OK;
 }

@@ -689,7 +689,7 @@ class _HeadConv(torch.autograd.Function):
         dalpha = _c(dalpha.float())
         dx = torch.empty_like(x)
         dpre = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
-        reps = 16 if ctx.ksize == 3 else 1                      # replicas of dw: 16x less atomic contention
+        reps = 16                                               # replicas of dw: 16x less atomic contention
         dw = torch.empty((reps, T, Cc), dtype=torch.float32, device=x.device)
         db = torch.empty(reps, dtype=torch.float32, device=x.device)
         L.call('tcvom_head_conv_bwd', L.ptr(dalpha), L.ptr(alpha), L.ptr(x), L.ptr(wt), L.ptr(dx), L.ptr(dpre), L.ptr(dw),
@@ -1003,15 +1003,15 @@ class _GcaAttention(torch.autograd.Function):
         Gt = torch.empty((B, D, ld), dtype=BF16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(G), L.ptr(Gt), N, D, D, ld, B, N * D, D * ld, st)
         # dWq[i][d] = sum_j T[i][j] G[j][d]            (rows m = d, columns n = queries i, reduce j)
-        d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(T), L.ptr(Gt), L.ptr(dWq), None, None, None, None, C.byref(d3), st)
-        # M'[j][d] = sum_i T[i][j] G[i][d]: like dV, an NT GEMM on the transposed operand (Tt = T^T) on the 256x256 tiles
-        # instead of the pixel-major TT form (320 workgroups, one long reduction each); measured -0.1 ms per step
+        # M'[j][d]  = sum_i T[i][j] G[i][d]: like dV, an NT GEMM on the transposed operand (Tt = T^T) on the 256-pixel tiles
+        # instead of the pixel-major TT form (320 workgroups, one long reduction each); measured -0.1 ms per step.
+        # Both share the weight operand Gt and go out as ONE launch (tcvom_gemm_pair: 2 x 288 workgroups fill 2.25 rounds of the
+        # 256 CUs instead of 2 x 1.125)
         if not fused_t:
             L.call('tcvom_transpose_bf16', L.ptr(T), L.ptr(Tt), N, ld, ld, ld, B, N * ld, ld * ld, st)
         Mp = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-        d5 = dense_desc(N, D, ld, D, batch=B, in_bstride=ld * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(Tt), L.ptr(Gt), L.ptr(Mp), None, None, None, None, C.byref(d5), st)
+        d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
+        L.call('tcvom_gemm_pair', L.ptr(T), L.ptr(Tt), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), C.byref(d3), ld * ld, st)
         del Tt
         dalpha = torch.empty((B, h8, w8, Ca), dtype=BF16, device=dev)
         L.call('tcvom_gca_value_patches_bwd', L.ptr(dV), L.ptr(dalpha), B, h8, w8, Ca, st)

@@ -679,6 +679,31 @@ def test_dense_gemm_256_staggered_kernel_epilogues(fp32):
     assert float(out[:, :, rows_a:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('rows_a,rows_b', [(576, 5700), (64, 300)])
+def test_dense_gemm_pair_one_launch(rows_a, rows_b):
+    """tcvom_gemm_pair: two products against the same weight operand (the d(query) / d(key) GEMMs of the attention scores,
+    576 rows on 192-row tiles), with different batch strides of the two inputs, against float matmuls; the small case takes
+    the two-launch fallback."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import dense_desc
+    nb, kred = 3, 512 if rows_a == 576 else 128
+    pad = rows_b + 10                                         # rows of in2's per-batch allocation
+    W_ = (hu('gp.w', (nb, rows_a, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    X1 = (hu('gp.x1', (nb, rows_b, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    X2 = (hu('gp.x2', (nb, pad, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    o1 = torch.full((nb, rows_b, rows_a), 7.0, device=DEV)
+    o2 = torch.full((nb, rows_b, rows_a), 7.0, device=DEV)
+    d = dense_desc(rows_b, rows_a, kred, rows_a, batch=nb, in_bstride=rows_b * kred, w_bstride=rows_a * kred,
+                   out_bstride=rows_b * rows_a, out_fp32=True)
+    assert (L._FNS['tcvom_conv_igemm_variant'](C.byref(d), 1).decode() == 'gemm_nt256') == (rows_a == 576)
+    L.call('tcvom_gemm_pair', L.ptr(X1), L.ptr(X2), L.ptr(W_), L.ptr(o1), L.ptr(o2), C.byref(d), pad * kred, L.stream_ptr())
+    r1 = torch.bmm(X1.float(), W_.float().transpose(1, 2))
+    r2 = torch.bmm(X2[:, :rows_b].float(), W_.float().transpose(1, 2))
+    assert rel_err(o1.cpu(), r1.cpu()) < 1e-5
+    assert rel_err(o2.cpu(), r2.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize('transposed', [False, True])
 def test_spectral_norm_bank(transposed):
     """Chained per-call power iterations, packed weights and the weight_bar gradient vs the oracle."""
