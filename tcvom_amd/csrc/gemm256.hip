@@ -47,10 +47,14 @@ struct Gemm256Args {
     long long b2_bstride;
 };
 
-#ifndef G256_DMA_MFMA
-#define G256_DMA_MFMA 1       // 1: the LDS-DMA instructions ride behind MFMA pairs; 0: in the LOAD sections of phases 2 / 3, as in the
-                              // guide's 8-phase template -- measured 6-8 % SLOWER here (O = P V 792 -> 852 us per 3-frame launch)
+#ifndef G256_PHASES
+#define G256_PHASES 2         // barrier phases per K-tile (2 or 4), see the main loop
 #endif
+// (An L2 prefetch of K-tile t+2 -- one 4-byte LDS-DMA per lane and K-tile into a dump area, i.e. one cache line per tile row --
+// measured 8 % SLOWER: 772 -> 833 us; the one-K-tile prefetch distance is not what separates the 3-frame launch, 259 us per
+// round of workgroups, from the one-frame launch whose operands stay in the 256 MB Infinity Cache, 224 us.)
+// (Issuing the LDS-DMA instructions in the LOAD sections of the four-phase loop, as the guide's 8-phase template does, instead of
+// behind MFMA pairs measured 6-8 % SLOWER here: O = P V 792 -> 852 us per 3-frame launch.)
 #ifdef G256_TRACE
 __device__ unsigned long long g256_trace[512];
 extern "C" int tcvom_trace256_read(unsigned long long* host) {
@@ -90,12 +94,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int n0 = bx * TN, m0 = blockIdx.y * TM;
     const int K = g.K;
 
-    // DMA rows: instruction (it, wave) covers tile rows (it*8 + wave)*8 .. +7; lane -> row +lane/8, 16-byte chunk kc
+    // DMA pieces (8 rows x 128 bytes per wave-instruction; lane -> row +lane/8, 16-byte chunk kc): B piece (it, wave) covers tile
+    // rows (it*8 + wave)*8 .. +7; the A rows are split by wave group -- group wm fetches the HM rows its own waves multiply
+    // (piece s of wave w: rows wm*HM + (s*4 + (w & 3))*8 ..), so a group's A pieces are needed one barrier interval later than B
     const int kc8 = (((lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7)) << 3);
+    const int a_piece = wm * (HM / 8) + (wave & 3);                    // + s*4
     int64_t a_off[4], b_off[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int ra = m0 + (it * 8 + wave) * 8 + (lane >> 3), rb = n0 + (it * 8 + wave) * 8 + (lane >> 3);
+        const int ra = m0 + (a_piece + it * 4) * 8 + (lane >> 3), rb = n0 + (it * 8 + wave) * 8 + (lane >> 3);
         a_off[it] = (it < A_IT && ra < g.M) ? (int64_t)ra * K + kc8 : -1;
         b_off[it] = rb < g.N ? (int64_t)rb * K + kc8 : -1;
     }
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #define G_ISSUE_A(t, it)                                                                                     \
     {                                                                                                        \
         const bf16raw* src_ = a_off[it] >= 0 ? A + a_off[it] + (t) * 64 : g.zero_page;                       \
-        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + ((it) * 8 + wave) * 512), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + (a_piece + (it) * 4) * 512), 16, 0, 0); \
     }
 #define G_ISSUE_B(t, it)                                                                                     \
     {                                                                                                        \
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int a_row = wm * HM + (lane & 31), b_row = wn * 64 + (lane & 31);
     const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;     // the same for rows +32, +64, +96
     const int khalf = lane >> 5;
-    bf16x8_t fa[2][4], fb[4];                          // A sub-tile (2 row-fragments x 4 k16), B sub-tile (1 x 4)
+    bf16x8_t fa[2][4], fb[2][4];                       // A sub-tile (2 row-fragments x 4 k16), both B sub-tiles (1 x 4 each)
 
 #define G_READ_A(buf, mh)                                                                                    \
     _Pragma("unroll") for (int a_ = 0; a_ < ((mh) * 2 + 1 < MF ? 2 : 1); ++a_)                               \
@@ -131,24 +138,27 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             fa[a_][kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
 #define G_READ_B(buf, nh)                                                                                    \
     _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                      \
-        fb[kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3));
+        fb[nh][kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3));
     // 8 MFMAs of one quadrant; `DMA` = 0/1/2: interleave the A / B DMA instructions of K-tile tn behind MFMA pairs
 #define G_MFMA(mh, nh, DMA, tn)                                                                              \
     {                                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                \
-            acc[(mh) * 2 + 0][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk_], fb[kk_], acc[(mh) * 2 + 0][nh], 0, 0, 0); \
+            acc[(mh) * 2 + 0][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk_], fb[nh][kk_], acc[(mh) * 2 + 0][nh], 0, 0, 0); \
             if constexpr ((mh) * 2 + 1 < MF)                                                                 \
-                acc[(mh) * 2 + 1][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk_], fb[kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
+                acc[(mh) * 2 + 1][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk_], fb[nh][kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
             if ((DMA) == 1 && kk_ < A_IT && (tn) < ntile) G_ISSUE_A(tn, kk_)                                 \
             if ((DMA) == 2 && (tn) < ntile) G_ISSUE_B(tn, kk_)                                               \
         }                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                       \
     }
+#define G_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #ifdef G256_TRACE                                      // tools/g256_trace.py: (arrive, leave) cycle stamps of every barrier
     const bool trace_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 4);
     int trace_i = 0;
+    // slots 254 / 255 of a group's block: shader-clock cycles and 100 MHz reference ticks of the whole main loop (their ratio is
+    // the clock the CU actually ran at)
+    const unsigned long long trace_c0 = __builtin_readcyclecounter(), trace_r0 = __builtin_amdgcn_s_memrealtime();
 #define G_BAR()                                                                                              \
     {                                                                                                        \
         if (trace_on && trace_i < 250) g256_trace[(wave >> 2) * 256 + trace_i++] = __builtin_readcyclecounter(); \
@@ -167,33 +177,52 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     G_BAR();
     if (wm == 1) G_BAR();                              // group 1 runs one barrier interval behind group 0
 
+#if G256_PHASES == 2
+    // Two phases per K-tile: A = quadrants (m0, n0), (m0, n1) (16 MFMAs, loads A-m0 and all of B), B = (m1, n1), (m1, n0) (loads
+    // A-m1 only): half the barriers of the four-phase loop and 24 instead of 28 ds_reads per K-tile.
+    //     barrier interval     4t    4t+1   4t+2   4t+3   4t+4
+    //     group 0              LA    MA*    LB     MBw    LA'            * issues the LDS-DMA of K-tile t+1 (B pieces first)
+    //     group 1              MB    LA     MA*    LBv    MBw            v vmcnt(A_IT): its B pieces have landed;  w vmcnt(0)
+    // Buffer (t+1) & 1 held K-tile t-1, whose last reads (group 1, LB) retire at the head of its MB in interval 4t; the first DMA
+    // into it is issued in 4t+1.  Group 0 reads tile t+1 from 4t+4 on (A rows of group 0, all B rows): group 0's pieces are
+    // drained at the end of 4t+3, group 1's B pieces too (they were issued first: vmcnt(A_IT) leaves only its own A pieces in
+    // flight); group 1's A rows are read by group 1 alone, from 4t+5 on, and are drained at the end of its MB (4t+4).
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        G_READ_A(buf, 0) G_READ_B(buf, 0) G_READ_B(buf, 1)
+        G_BAR();
+        G_WAIT_LDS();
+        G_MFMA(0, 0, 2, t + 1)
+        G_MFMA(0, 1, 1, t + 1)
+        G_BAR();
+        G_READ_A(buf, 1)
+        if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");
+        G_BAR();
+        G_WAIT_LDS();
+        G_MFMA(1, 1, 0, 0)
+        G_MFMA(1, 0, 0, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G_BAR();
+    }
+#else
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         // phase 1: quadrant (m0, n0)
         G_READ_A(buf, 0) G_READ_B(buf, 0)
         G_BAR();
-        G_MFMA(0, 0, G256_DMA_MFMA ? 1 : 0, t + 1)
+        G_WAIT_LDS();
+        G_MFMA(0, 0, 1, t + 1)
         G_BAR();
         // phase 2: quadrant (m0, n1)
-#if !G256_DMA_MFMA
-        if (t + 1 < ntile) {
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) G_ISSUE_A(t + 1, it)
-        }
-#endif
         G_READ_B(buf, 1)
         G_BAR();
-        G_MFMA(0, 1, G256_DMA_MFMA ? 2 : 0, t + 1)
+        G_WAIT_LDS();
+        G_MFMA(0, 1, 2, t + 1)
         G_BAR();
         // phase 3: quadrant (m1, n1)
-#if !G256_DMA_MFMA
-        if (t + 1 < ntile) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) G_ISSUE_B(t + 1, it)
-        }
-#endif
         G_READ_A(buf, 1)
         G_BAR();
+        G_WAIT_LDS();
         G_MFMA(1, 1, 0, 0)
         G_BAR();
         // phase 4: quadrant (m1, n0); the DMA of K-tile t+1 must have landed before anybody enters phase 1 of t+1:
@@ -201,17 +230,26 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         G_READ_B(buf, 0)
         if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G_BAR();
+        G_WAIT_LDS();
         G_MFMA(1, 0, 0, 0)
         if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G_BAR();
     }
+#endif
     if (wm == 0) G_BAR();                              // balance group 1's extra barrier
+#ifdef G256_TRACE
+    if (trace_on) {
+        g256_trace[(wave >> 2) * 256 + 254] = __builtin_readcyclecounter() - trace_c0;
+        g256_trace[(wave >> 2) * 256 + 255] = __builtin_amdgcn_s_memrealtime() - trace_r0;
+    }
+#endif
 #undef G_MFMA
 #undef G_READ_A
 #undef G_READ_B
 #undef G_ISSUE_A
 #undef G_ISSUE_B
 #undef G_BAR
+#undef G_WAIT_LDS
 
     // ------------------------------------------------------------------ epilogue
     // A lane holds 4 consecutive m of ONE row n, its 32 neighbours 32 different rows.

@@ -505,7 +505,8 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
 extern "C" int tcvom_gemm_pair(const void* in1, const void* in2, const void* w, void* out1, void* out2,
                                const tcvom_conv_desc* desc, int64_t in2_bstride, void* stream) {
     TCVOM_CHECK_ARG(in1 && in2 && w && out1 && out2 && desc, "gemm_pair: null pointer");
-    if (gemm_nt256_takes(desc)) {
+    static const bool unpaired = getenv("TCVOM_NO_GEMM_PAIR") != nullptr;          // A/B switch
+    if (!unpaired && gemm_nt256_takes(desc)) {
         const bf16raw* zp = zero_page_for_current_device();
         TCVOM_CHECK_ARG(zp != nullptr, "gemm_pair: could not allocate the zero page");
         TCVOM_CHECK_ARG(desc->w_layout == 0, "gemm_pair: plain weight layout only");

@@ -60,6 +60,9 @@ def main():
          lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T),
                         L.ptr(Tt), L.ptr(Pt2), N, DV, ld, B, st)),
     ]
+    d2one = dense_desc(N, DV, ld, DV, out_fp32=True)
+    rows.insert(2, ('O = P V, one frame', 2.0 * N * N * DV,
+                    lambda: L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2one), st)))
     dW2 = torch.empty(B, N, D, device=DEV)
     rows.append(('dWq, M\' in one launch', 4.0 * B * N * N * D,
                  lambda: L.call('tcvom_gemm_pair', L.ptr(P), L.ptr(Pt), L.ptr(Gt), L.ptr(dW), L.ptr(dW2), C.byref(d3), ld * ld, st)))
