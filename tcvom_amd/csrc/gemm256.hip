@@ -47,6 +47,9 @@ struct Gemm256Args {
     long long b2_bstride;
 };
 
+#ifndef G256_STAGED_EPI
+#define G256_STAGED_EPI 1     // 1: the plain epilogue of the 256-row tiles goes through per-wave LDS regions (whole-row stores)
+#endif
 #ifndef G256_PHASES
 #define G256_PHASES 2         // barrier phases per K-tile (2 or 4), see the main loop
 #endif
@@ -335,9 +338,77 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         }
         return;
     } else {
-    // ---- plain epilogue (bias / scale / diagonal / activation), stored straight from the registers.  (Staging the fp32 tile
-    // through LDS in two 128-row halves for whole-row stores was built and measured slower: S = G G^T 124 -> 157 us per frame.)
+    // ---- plain epilogue (bias / scale / diagonal / activation)
     constexpr bool F32 = EPI == 0;
+    if constexpr (MF == 4 && G256_STAGED_EPI) {
+        // Each wave turns its own 64 (n) x 128 (m) tile through a private LDS region, 32 rows at a time, so that the global stores
+        // are whole rows: a lane's MFMA results are 4 consecutive m of ONE row n and its 32 neighbours sit in 32 different rows --
+        // stored straight from the registers that is 32 segments of 32 bytes (fp32) / 8 bytes (bf16) per instruction, and the
+        // GEMMs with a short reduction (the 1x1 convs of the FBA bottlenecks: 4 .. 8 K-tiles; S = G G^T: 9) spend more time
+        // there than in their main loop.  No barrier: a wave only reads what it wrote (LDS operations of a wave execute in order).
+        // Row r of the region holds 512 (fp32) / 256 (bf16) bytes; its 16-byte chunk c sits at position c ^ (r & 31) / c ^ (r & 15)
+        // (conflict-free ds_write_b128 / ds_write_b64 for the MFMA layout, plain rows for the ds_read_b128 that feed the stores).
+        char* wl = lb + wave * (F32 ? 16384 : 8192);
+        const int nl = lane & 31, h = lane >> 5;
+        const bool al16 = F32 || ((g.ldo & 7) == 0 && (g.out_bstride & 7) == 0 && ((uintptr_t)gout & 15) == 0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int a = 0; a < MF; ++a) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mrow = m0 + wm * HM + a * 32 + 8 * q + 4 * h;
+                    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = bs;
+                    if (mrow < g.M) {                         // M % 4 == 0: a lane's 4 rows are valid together
+                        if (bias) bs = *reinterpret_cast<const float4*>(bias + mrow);
+                        if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
+                        if (mdiag) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
+                    }
+                    const float bsv[4] = {bs.x, bs.y, bs.z, bs.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[a][b][q * 4 + r] * sc[r] + bsv[r];
+                        if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
+                        if (g.act == 1) x = fmaxf(x, 0.f); else if (g.act == 3) x = x > 0.f ? x : 0.01f * x;
+                        v[r] = x;
+                    }
+                    if constexpr (F32)
+                        *reinterpret_cast<float4*>(wl + nl * 512 + (((a * 8 + 2 * q + h) ^ nl) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+                    else
+                        *reinterpret_cast<uint2*>(wl + nl * 256 + (((a * 4 + q) ^ (nl & 15)) << 4) + h * 8) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+            }
+            const int nbase = n0 + wn * 64 + b * 32, mbase = m0 + wm * HM;
+            if constexpr (F32) {
+                float* o = reinterpret_cast<float*>(gout) + obase;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = i * 2 + h, c = nl ^ row;                     // (row < 32: row & 31 == row)
+                    const float4 t = *reinterpret_cast<const float4*>(wl + row * 512 + nl * 16);
+                    const int n = nbase + row, m = mbase + c * 4;
+                    if (n < g.N && m < g.M) *reinterpret_cast<float4*>(o + (int64_t)n * g.ldo + m) = t;
+                }
+            } else {
+                bf16raw* o = reinterpret_cast<bf16raw*>(gout) + obase;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = i * 4 + (lane >> 4), pc = lane & 15, c = pc ^ (row & 15);
+                    const uint4 t = *reinterpret_cast<const uint4*>(wl + row * 256 + pc * 16);
+                    const int n = nbase + row, m = mbase + c * 8;
+                    if (n < g.N && m < g.M) {
+                        bf16raw* dst = o + (int64_t)n * g.ldo + m;
+                        if (al16 && m + 8 <= g.M) *reinterpret_cast<uint4*>(dst) = t;
+                        else {
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(t.x, t.y);
+                            if (m + 8 <= g.M) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(t.z, t.w);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+    // stored straight from the registers (the 192-row tiles)
     int64_t out_off[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) out_off[b] = (int64_t)(pvalid[b] ? pglob[b] : 0) * g.ldo + obase;
@@ -369,6 +440,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                 }
             }
         }
+    }
     }
     }
 }

@@ -60,6 +60,14 @@ def main():
          lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T),
                         L.ptr(Tt), L.ptr(Pt2), N, DV, ld, B, st)),
     ]
+    # the 1x1 convs of the FBA bottlenecks (bf16 output, 3 frames per launch): rows = pixels, weights [K][C]
+    for pix, kout, cin in ((32640, 2048, 512), (32640, 1024, 256), (130560, 256, 64), (32640, 512, 2048)):
+        x = rnd(B, pix, cin)
+        w = rnd(kout, cin)
+        y = torch.empty(B, pix, kout, device=DEV, dtype=BF)
+        dd = dense_desc(pix, kout, cin, kout, batch=B, in_bstride=pix * cin, w_bstride=0, out_bstride=pix * kout)
+        rows.append(('1x1 conv %d px %d -> %d' % (pix, cin, kout), 2.0 * B * pix * kout * cin,
+                     (lambda x=x, w=w, y=y, dd=dd: L.call('tcvom_conv_igemm', L.ptr(x), L.ptr(w), L.ptr(y), None, None, None, None, C.byref(dd), st))))
     d2one = dense_desc(N, DV, ld, DV, out_fp32=True)
     rows.insert(2, ('O = P V, one frame', 2.0 * N * N * DV,
                     lambda: L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2one), st)))
