@@ -58,9 +58,9 @@ extern "C" int tcvom_trace_read(unsigned long long* host, int n) {
 #define TRACE(i) if (trace_on && (s) < 256) tcvom_trace_buf[((s) * 4 + (i)) + 4 * 256 * trace_w] = __builtin_readcyclecounter()
 #else
 #define TRACE(i)
+#endif
 #ifndef NT_DBG
 #define NT_DBG 0            // kernel study builds only: 1 = no LDS reads / MFMAs, 2 = no DMA, 3 = no epilogue
-#endif
 #endif
 template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
