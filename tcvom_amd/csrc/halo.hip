@@ -32,16 +32,21 @@ struct HaloArgs {
     float* stats;
     const bf16raw* zero_page;
     int N, H, W, K, ldo, wt, act, out_fp32, stats_group_offset;
+    int org;                     // 1: taps 0..2 on an input that carries its own (reflection) padding ring -- the tile origin moves by (1, 1)
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
     int spf;                     // samples per frame (weights change every spf samples: w_bstride elements further)
     long long w_bstride;
     int tap_dh[HALO_MAX_TAPS + 2], tap_dw[HALO_MAX_TAPS + 2], tap_w[HALO_MAX_TAPS + 2];   // compacted; tap_w < 0: zero tap
 };
 
-template <int C, int NCH>
+// S = input stride (1, or 2: the stride-2 3x3 convs on the 8-channel full-resolution inputs, resnet_enc.py:68 conv1 and the
+// guidance head res_gca_enc.py:20-28): the output tile stays 8 x 32 pixels, its halo covers (S*8 + 2) x (S*32 + 2) input pixels.
+template <int C, int NCH, int S>
 __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
     constexpr int CU = C / 8;                           // 16-byte units per pixel
-    constexpr int UNITS = HALO_PIX * CU;
+    constexpr int HW_ = S * HALO_TW + 2, HH_ = S * HALO_TH + 2, PIX_ = HW_ * HH_;
+    static_assert(S == 1 || CU == 1, "the strided form is instantiated for 8-channel inputs only (no chunk swizzle)");
+    constexpr int UNITS = PIX_ * CU;
     constexpr int NDMA = (UNITS + 63) / 64;             // DMA wave-instructions per halo
     constexpr int DMA_IT = (NDMA + 3) / 4;
     constexpr int SLOT = NDMA * 512;                    // bf16 elements per halo slot
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
-    const int H = a.H, W = a.W;
+    const int H = a.H, W = a.W, OH = (H - 2 * a.org) / S, OW = (W - 2 * a.org) / S;
 
     // XCD-contiguous workgroup order: neighbouring tile runs (which share halo rows) go to one L2
     int v;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         const int q = (it * 4 + wave) * 64 + lane;
         const int p = q / CU, sl = q % CU;
         const int c16 = (CU == 4) ? (sl ^ ((p >> 2) & 3)) : sl;
-        const int hy = p / HALO_HW, hx = p - hy * HALO_HW;
+        const int hy = p / HW_, hx = p - hy * HW_;
         d_rel[it] = ((hy - 1) * W + (hx - 1)) * C + c16 * 8;
         d_yx[it] = (q < UNITS) ? ((hy << 16) | hx) : -1;
     }
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         (void)dummy;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = (2 * wave + j + dh + 1) * HALO_HW + (col + dw + 1);
+            const int p = (S * (2 * wave + j) + dh + 1) * HW_ + (S * col + dw + 1);
             const int sl = (CU == 4) ? (c16 ^ ((p >> 2) & 3)) : c16;
             b_addr[ch][j] = (p * CU + sl) * 16;
         }
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
 #define HALO_ISSUE(tile, slot)                                                                              \
     {                                                                                                       \
         const int tx_ = (tile) % a.tiles_x, ty_ = ((tile) / a.tiles_x) % a.tiles_y, n_ = (tile) / (a.tiles_x * a.tiles_y); \
-        const int y0_ = ty_ * HALO_TH, x0_ = tx_ * HALO_TW;                                                 \
+        const int y0_ = S * ty_ * HALO_TH + a.org, x0_ = S * tx_ * HALO_TW + a.org;   /* input coordinates of the tile origin */ \
         const int base_ = ((n_ * H + y0_) * W + x0_) * C;                                                   \
         _Pragma("unroll") for (int it = 0; it < DMA_IT; ++it) {                                             \
             if ((it * 4 + wave) < NDMA) {                                                                   \
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         // ---- epilogue: bias, ReLU, store, BatchNorm partial statistics (one group per wave and tile)
         const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
         const int y0 = ty * HALO_TH + 2 * wave, x = tx * HALO_TW + col;
-        const int64_t o0 = ((int64_t)(n * H + y0) * W + x) * a.ldo;
-        const int64_t o1 = o0 + (int64_t)W * a.ldo;
+        const int64_t o0 = ((int64_t)(n * OH + y0) * OW + x) * a.ldo;
+        const int64_t o1 = o0 + (int64_t)OW * a.ldo;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int mrow = 8 * g + 4 * half;
@@ -218,25 +223,31 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-struct HaloPlan { bool ok; int C, nch, ntaps; int taps[HALO_MAX_TAPS + 2]; };
+struct HaloPlan { bool ok; int C, nch, ntaps, S, org; int taps[HALO_MAX_TAPS + 2]; };
 
 static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     HaloPlan p;
     p.ok = false;
     if (nphase != 1) return p;
     if (d->batch > 1) {           // frame-batched call: frames must be contiguous sample groups
-        if (d->in_bstride != (long long)d->N * d->H * d->W * d->C || d->out_bstride != (long long)d->N * d->H * d->W * d->ldo) return p;
+        if (d->in_bstride != (long long)d->N * d->H * d->W * d->C || d->out_bstride != (long long)d->N * d->OH * d->OW * d->ldo) return p;
         if (d->vec_bstride != 0) return p;
     }
-    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return p;
-    if (d->PH != d->H || d->PW != d->W || d->OH != d->H || d->OW != d->W) return p;
-    if (d->H % HALO_TH != 0 || d->W % HALO_TW != 0) return p;
+    const int S = d->in_step;
+    static const bool no_strided = getenv("TCVOM_NO_HALO_S2") != nullptr;          // A/B switch
+    if ((S != 1 && !(S == 2 && d->C == 8 && !no_strided)) || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return p;
+    // org = 1: every tap in 0..2 on an input with its own padding ring (ReflectionPad2d(1) + Conv2d(padding=0), res_gca_enc.py:20-28)
+    int org = d->ntaps > 0 ? 1 : 0;
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->tap_w[t] >= 0 && (d->tap_dh[t] < 0 || d->tap_dw[t] < 0)) org = 0;
+    if (d->PH != d->OH || d->PW != d->OW || d->OH * S != d->H - 2 * org || d->OW * S != d->W - 2 * org) return p;
+    if (d->OH % HALO_TH != 0 || d->OW % HALO_TW != 0) return p;
     if (d->K > 32 || d->K % 4 != 0 || (d->C != 8 && d->C != 32)) return p;
     if ((long long)d->N * (d->batch > 1 ? d->batch : 1) * d->H * d->W * d->C >= (1ll << 31)) return p;
     int n = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         if (d->tap_w[t] < 0) continue;
-        if (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1) return p;
+        if (d->tap_dh[t] - org < -1 || d->tap_dh[t] - org > 1 || d->tap_dw[t] - org < -1 || d->tap_dw[t] - org > 1) return p;
         if (n >= HALO_MAX_TAPS) return p;
         p.taps[n++] = t;
     }
@@ -244,24 +255,27 @@ static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     const int per = 16 / (d->C < 16 ? d->C : 16);       // taps per 16-deep chunk (C = 8: 2)
     int padded = (n + per - 1) / per * per;
     int nch = padded * d->C / 16;
-    // instantiated shapes: C=8 with 9 taps (5 chunks), C=32 with 9 taps (18 chunks) or 18 taps (36 chunks)
-    if (!((d->C == 8 && nch == 5) || (d->C == 32 && (nch == 18 || nch == 36)))) return p;
+    // instantiated shapes: C=8 with 9 taps (5 chunks; stride 2 also with the 18 taps = 9 chunks of a high-precision layer),
+    // C=32 with 9 taps (18 chunks) or 18 taps (36 chunks)
+    if (!((d->C == 8 && (nch == 5 || (S == 2 && nch == 9))) || (d->C == 32 && (nch == 18 || nch == 36)))) return p;
     for (int t = n; t < padded; ++t) p.taps[t] = -1;
     p.ok = true;
     p.C = d->C;
     p.nch = nch;
     p.ntaps = padded;
+    p.S = S;
+    p.org = org;
     return p;
 }
 
 static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per_wg, size_t* lds_bytes) {
     const int cu = p.C / 8;
-    const int ndma = (HALO_PIX * cu + 63) / 64;
+    const int ndma = ((p.S * HALO_TW + 2) * (p.S * HALO_TH + 2) * cu + 63) / 64;
     *lds_bytes = (size_t)2 * ndma * 1024 + (size_t)32 * (p.nch * 16 + 8) * 2;
     int occ = (int)((160 * 1024) / *lds_bytes);
     if (occ > 4) occ = 4;
     if (occ < 1) occ = 1;
-    const int ntiles = d->N * (d->batch > 1 ? d->batch : 1) * (d->H / HALO_TH) * (d->W / HALO_TW);
+    const int ntiles = d->N * (d->batch > 1 ? d->batch : 1) * (d->OH / HALO_TH) * (d->OW / HALO_TW);
     int wgs = 256 * occ;
     if (wgs > ntiles) wgs = ntiles;
     *tiles_per_wg = (ntiles + wgs - 1) / wgs;
@@ -272,7 +286,7 @@ static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase) {
     const HaloPlan p = halo_plan(d, nphase);
     if (!p.ok) return 0;
-    return d->N * (d->H / HALO_TH) * (d->W / HALO_TW) * 4;     // per batch element (frame), like the igemm count
+    return d->N * (d->OH / HALO_TH) * (d->OW / HALO_TW) * 4;   // per batch element (frame), like the igemm count
 }
 
 // returns 1 when the conv was launched here, 0 when the caller should use the implicit GEMM, < 0 on error
@@ -290,8 +304,9 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
     a.zero_page = zero_page;
     a.N = d->N; a.H = d->H; a.W = d->W; a.K = d->K; a.ldo = d->ldo; a.wt = d->wt; a.act = d->act; a.out_fp32 = d->out_fp32;
     a.stats_group_offset = d->stats_group_offset;
-    a.tiles_x = d->W / HALO_TW;
-    a.tiles_y = d->H / HALO_TH;
+    a.org = p.org;
+    a.tiles_x = d->OW / HALO_TW;
+    a.tiles_y = d->OH / HALO_TH;
     const int nb = d->batch > 1 ? d->batch : 1;
     a.N = d->N * nb;
     a.spf = d->N;
@@ -303,27 +318,26 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
         return tcvom_fail(TCVOM_ERR_ARG, "halo_conv: stats_bstride %lld != groups per frame", (long long)d->stats_bstride);
     for (int t = 0; t < HALO_MAX_TAPS + 2; ++t) {
         const int src = t < p.ntaps ? p.taps[t] : -1;
-        a.tap_dh[t] = src >= 0 ? d->tap_dh[src] : 0;
-        a.tap_dw[t] = src >= 0 ? d->tap_dw[src] : 0;
+        a.tap_dh[t] = src >= 0 ? d->tap_dh[src] - p.org : 0;
+        a.tap_dw[t] = src >= 0 ? d->tap_dw[src] - p.org : 0;
         a.tap_w[t] = src >= 0 ? d->tap_w[src] : -1;
     }
     size_t lds_bytes;
     const int grid = halo_grid(d, p, &a.tiles_per_wg, &lds_bytes);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    if (p.C == 8) {
-        static bool attr8 = false;
-        if (!attr8) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr8 = true; }
-        hipLaunchKernelGGL((halo_conv_kernel<8, 5>), dim3(grid), dim3(256), lds_bytes, st, a);
-    } else if (p.nch == 18) {
-        static bool attr18 = false;
-        if (!attr18) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<32, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr18 = true; }
-        hipLaunchKernelGGL((halo_conv_kernel<32, 18>), dim3(grid), dim3(256), lds_bytes, st, a);
-    } else {
-        static bool attr36 = false;
-        if (!attr36) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<32, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr36 = true; }
-        hipLaunchKernelGGL((halo_conv_kernel<32, 36>), dim3(grid), dim3(256), lds_bytes, st, a);
+#define HALO_LAUNCH(...)                                                                                    \
+    {                                                                                                       \
+        static bool attr_ = false;                                                                          \
+        if (!attr_) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        hipLaunchKernelGGL((halo_conv_kernel<__VA_ARGS__>), dim3(grid), dim3(256), lds_bytes, st, a);        \
     }
+    if (p.S == 2 && p.nch == 5) HALO_LAUNCH(8, 5, 2)
+    else if (p.S == 2) HALO_LAUNCH(8, 9, 2)
+    else if (p.C == 8) HALO_LAUNCH(8, 5, 1)
+    else if (p.nch == 18) HALO_LAUNCH(32, 18, 1)
+    else HALO_LAUNCH(32, 36, 1)
+#undef HALO_LAUNCH
     if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "halo_conv: %s", hipGetErrorString(e));
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "halo_conv: %s", hipGetErrorString(e2));

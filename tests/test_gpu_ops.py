@@ -397,15 +397,32 @@ def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
                                               (32, 32, False, 1, 72, 96), (64, 64, False, 2, 16, 64), (64, 64, True, 1, 24, 96),
                                               (64, 32, False, 1, 16, 96), (32, 64, False, 1, 40, 64)])
 def test_halo_conv_kernel(cin, cout, hp, N, H, W):
+    _halo_conv_case(cin, cout, hp, N, H, W, 1)
+
+
+@pytest.mark.parametrize('cin,cout,hp,N,H,W', [(6, 32, False, 2, 32, 128), (6, 32, True, 1, 48, 192), (3, 16, False, 1, 16, 64)])
+def test_halo_conv_kernel_stride2(cin, cout, hp, N, H, W):
+    """The stride-2 3x3 convs on the 8-channel full-resolution inputs (encoder conv1, guidance head; out % (8, 32) == 0) take the
+    halo kernel too: forward with fused ReLU + batch statistics and the weight gradient against fp32 PyTorch."""
+    _halo_conv_case(cin, cout, hp, N, H, W, 2)
+
+
+def test_halo_conv_kernel_stride2_on_a_reflection_padded_input():
+    """ReflectionPad2d(1) + Conv2d(3 -> 16, stride 2, padding 0) of the guidance head (res_gca_enc.py:20-28): taps 0..2 on an
+    input that carries its own ring."""
+    _halo_conv_case(3, 16, False, 2, 34, 130, 2, pad=0)
+
+
+def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
     """Shapes served by the halo-tile direct conv (stride-1 3x3, <= 32 channels, H % 8 == 0, W % 32 == 0): forward
     with fused ReLU + batch statistics (64 output channels = two workgroups per tile), data gradient (also through the halo kernel) and weight gradient, against
     fp32 PyTorch on the same bf16 operands.  hp = bf16 hi + residual weights (18 taps), fp32 conv output."""
     from tcvom_amd import ops
     from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
-    tag = 'halo%d_%d_%d_%d' % (cin, cout, int(hp), H)
+    tag = 'halo%d_%d_%d_%d_s%d_p%d' % (cin, cout, int(hp), H, stride, pad)
     w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cout, cin, 3, 3)) * 0.2).to(DEV))
     bank = WeightBank()
-    spec = ConvSpec(tag, w, None, None, None, False, 1, 1, 'frame', needs_dgrad=cin >= 16, hp=hp)
+    spec = ConvSpec(tag, w, None, None, None, False, stride, pad, 'frame', needs_dgrad=cin >= 16, hp=hp)
     bank.register(spec)
     bn = nn.BatchNorm2d(cout).to(DEV)
     cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
@@ -413,12 +430,18 @@ def test_halo_conv_kernel(cin, cout, hp, N, H, W):
     xp = F.pad(x, (0, 0, 0, 0, 0, spec.cpad - cin))
     xg = nhwc(xp).requires_grad_(True)
     token = bank_token(bank, 1, True)
+    if stride == 2:
+        import ctypes as C
+        from tcvom_amd import _lib as L
+        from tcvom_amd.conv_plan import ConvGeometry
+        geo = ConvGeometry(spec, N, H, W)
+        assert L._FNS['tcvom_conv_igemm_variant'](C.byref(geo.fwd[0]), len(geo.fwd)).decode() == 'halo_conv<8>'
     z = ops.conv_bn_act(cfg, xg, token, True)
     bank.flush_bn_counters()
     xr = bf(x).requires_grad_(True)
     wf = spec.weight.detach().cpu()
     wr = (wf if hp else bf(wf)).clone().requires_grad_(True)      # hi + residual reproduces the fp32 weight to ~2^-16
-    yr = F.relu(F.conv2d(xr, wr, None, 1, 1))
+    yr = F.relu(F.conv2d(xr, wr, None, stride, pad))
     mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
     yq = yr if hp else yr + (bf(yr) - yr).detach()
     zr = (yq - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
