@@ -15,8 +15,12 @@
 // 16 consecutive pixels, 64 B apart -- cover 16 distinct bank groups.  Weight rows are padded by 16 B for the same
 // reason.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
+#ifndef HALO_ABL
+#define HALO_ABL 0          // kernel ablations for timing (1: no output stores, 2: no statistics); 0 in the product
+#endif
 #define HALO_TH 8
 #define HALO_TW 32
 #define HALO_HW (HALO_TW + 2)
@@ -34,10 +38,51 @@ struct HaloArgs {
     int N, H, W, K, ldo, wt, act, out_fp32, stats_group_offset;
     int org;                     // 1: taps 0..2 on an input that carries its own (reflection) padding ring -- the tile origin moves by (1, 1)
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
+    int wgs_per_frame;           // a workgroup stays inside ONE frame: tiles [f*tpf + w*tiles_per_wg, ..) of frame f = v / wgs_per_frame
+    long long stats_bstride;     // statistics groups between frames; a frame has wgs_per_frame * 4 groups (workgroup, wave)
     int spf;                     // samples per frame (weights change every spf samples: w_bstride elements further)
     long long w_bstride;
     int tap_dh[HALO_MAX_TAPS + 2], tap_dw[HALO_MAX_TAPS + 2], tap_w[HALO_MAX_TAPS + 2];   // compacted; tap_w < 0: zero tap
 };
+
+#ifdef HALO_TRACE                      // tools/halo_trace.py: cycle stamps of workgroup 8 / wave 0, 5 per tile
+__device__ unsigned long long halo_trace_buf[1024];
+extern "C" int tcvom_halo_trace_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(halo_trace_buf), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -1;
+}
+#define HALO_STAMP(i) if (tracing && tix < 200) halo_trace_buf[tix * 5 + (i)] = __builtin_readcyclecounter()
+#else
+#define HALO_STAMP(i)
+#endif
+// 8 sums over the 32 pixel lanes of each half wave: within quads, half rows, rows, then row 0 -> row 1 / row 2 -> row 3
+// (row_bcast15): lanes 16..31 and 48..63 hold the totals.  (mov_dpp without `old`: one v_add_f32_dpp per step.)
+#define HALO_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
+__device__ __forceinline__ void halo_reduce8(float (&t)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += HALO_DPP(t[r], 0xB1, 0xF);      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += HALO_DPP(t[r], 0x4E, 0xF);      // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += HALO_DPP(t[r], 0x141, 0xF);     // row_half_mirror
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += HALO_DPP(t[r], 0x140, 0xF);     // row_mirror
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += HALO_DPP(t[r], 0x142, 0xA);     // row_bcast15 into rows 1 and 3
+}
+// LDS fragment reads the compiler does not see (see the MFMA section of halo_conv_kernel)
+#define HALO_PF 3
+typedef __attribute__((ext_vector_type(4))) unsigned int halo_u32x4_t;
+struct HaloFrag { halo_u32x4_t v; };
+__device__ __forceinline__ void halo_read(HaloFrag& f, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(addr)); }
+__device__ __forceinline__ void halo_fence(HaloFrag& f) { asm volatile("" : "+v"(f.v)); }
+__device__ __forceinline__ bf16x8_t halo_value(const HaloFrag& f) { return __builtin_bit_cast(bf16x8_t, f.v); }
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // S = input stride (1, or 2: the stride-2 3x3 convs on the 8-channel full-resolution inputs, resnet_enc.py:68 conv1 and the
 // guidance head res_gca_enc.py:20-28): the output tile stays 8 x 32 pixels, its halo covers (S*8 + 2) x (S*32 + 2) input pixels.
@@ -67,14 +112,14 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int t_begin = v * a.tiles_per_wg;
-    const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
-    if (t_begin >= t_end) return;
-
-    // ---- weights -> LDS: wl[k][t*C + c] = wgt[frame][(k*wt + slot(t))*C + c].  Once per workgroup, and again whenever
-    // its tile run crosses into the next FRAME of a frame-batched call (every frame has its own SpectralNorm'd copy).
     const int tiles_per_frame = a.spf * a.tiles_x * a.tiles_y;
-    auto load_weights = [&](int frame) {
+    const int frame = v / a.wgs_per_frame, wslot = v - frame * a.wgs_per_frame;
+    const int t_begin = frame * tiles_per_frame + wslot * a.tiles_per_wg;
+    const int t_end = min((frame + 1) * tiles_per_frame, t_begin + a.tiles_per_wg);      // (may be empty: the statistics are still written)
+
+    // ---- weights -> LDS, once per workgroup: wl[k][t*C + c] = wgt[frame][(k*wt + slot(t))*C + c]  (every frame of a
+    // frame-batched call has its own SpectralNorm'd copy)
+    {
         const bf16raw* wsrc = a.wgt + (int64_t)frame * a.w_bstride;
         for (int u = tid; u < 32 * NTAPS * CU; u += 256) {
             const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
@@ -83,9 +128,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
             if (ws >= 0 && k < a.K) val = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)k * a.wt + ws) * C + cu * 8);
             *reinterpret_cast<uint4*>(wl + k * WROW + t * C + cu * 8) = val;
         }
-    };
-    int cur_frame = t_begin / tiles_per_frame;
-    load_weights(cur_frame);
+    }
 
     // ---- per-lane constants
     // DMA: unit q = (it*4 + wave)*64 + lane -> halo pixel p = q / CU, stored slot q % CU holds chunk slot ^ swz(p)
@@ -119,7 +162,8 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         }
         a_addr[ch] = (col * WROW + kk) * 2;
     }
-    const char* wl_b = reinterpret_cast<const char*>(wl);
+    typedef __attribute__((address_space(3))) void* halo_lptr_t;
+    const unsigned halo_lds = (unsigned)(uintptr_t)(halo_lptr_t)halo, wl_lds = (unsigned)(uintptr_t)(halo_lptr_t)wl;
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -139,87 +183,135 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
         }                                                                                                   \
     }
 
-    HALO_ISSUE(t_begin, 0);
+    // epilogue constants: this lane's 16 bias values (channels 8 g + 4 half + r) and the activation slope
+    float bsv[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bsv[g][r] = (a.bias && 8 * g + 4 * half + r < a.K) ? a.bias[8 * g + 4 * half + r] : 0.f;
+    const float slope = a.act == 1 ? 0.f : a.act == 3 ? 0.01f : 1.f;
+
+    if (t_begin < t_end) HALO_ISSUE(t_begin, 0);
     int slot = 0;
+    // channel sums of this wave over its whole tile run: [group g][channel r] of channels 8 g + 4 half + r
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[g][r] = 0.f; s2[g][r] = 0.f; }
+#ifdef HALO_TRACE
+    const bool tracing = blockIdx.x == 8 && tid == 0;
+#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
+#ifdef HALO_TRACE
+        const int tix = tile - t_begin;
+#endif
+        HALO_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        HALO_STAMP(1);
         if (tile + 1 < t_end) HALO_ISSUE(tile + 1, slot ^ 1);
-        if (tile / tiles_per_frame != cur_frame) {      // uniform: every wave has finished the previous frame's last tile
-            cur_frame = tile / tiles_per_frame;
-            load_weights(cur_frame);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-
+        HALO_STAMP(2);
+#if HALO_ABL == 3
+        if (a.K != 12345) { slot ^= 1; continue; }
+#endif
         f32x16_t acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        const char* hs = reinterpret_cast<const char*>(halo + slot * SLOT);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(wl_b + a_addr[ch]);
-            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(hs + b_addr[ch][0]);
-            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(hs + b_addr[ch][1]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
-        }
+        // The fragment reads are inline asm with hand-counted lgkmcnt waits, HALO_PF chunks ahead of their MFMAs.  As plain LDS
+        // loads the compiler (a) waited for lgkmcnt(0) in front of every MFMA pair -- 2 x NCH exposed LDS latencies per tile -- and
+        // (b) put s_waitcnt vmcnt(0) in front of the first read, because the halo DMA of the NEXT tile issued above might alias
+        // what the loads read: the tile then waited for the DMA it should have overlapped (measured at 1088x1920, 32 -> 32
+        // channels, 3 frames: 260 us per launch, of which 100 us is the DMA loop alone and 160 us this section + epilogue).
+        const unsigned hs = halo_lds + (unsigned)slot * (SLOT * 2);
+        HaloFrag fa[HALO_PF + 1], fb[HALO_PF + 1][2];
+        static_for<0, (HALO_PF < NCH ? HALO_PF : NCH)>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            halo_read(fa[c], wl_lds + a_addr[c]);
+            halo_read(fb[c][0], hs + b_addr[c][0]);
+            halo_read(fb[c][1], hs + b_addr[c][1]);
+        });
+        static_for<0, NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            if constexpr (c + HALO_PF < NCH) {
+                constexpr int n = (c + HALO_PF) % (HALO_PF + 1);
+                halo_read(fa[n], wl_lds + a_addr[c + HALO_PF]);
+                halo_read(fb[n][0], hs + b_addr[c + HALO_PF][0]);
+                halo_read(fb[n][1], hs + b_addr[c + HALO_PF][1]);
+            }
+            constexpr int ahead = (NCH - 1 - c < HALO_PF ? NCH - 1 - c : HALO_PF) * 3;      // reads issued after chunk c's
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ahead) : "memory");
+            constexpr int k = c % (HALO_PF + 1);
+            halo_fence(fa[k]); halo_fence(fb[k][0]); halo_fence(fb[k][1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(halo_value(fa[k]), halo_value(fb[k][0]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(halo_value(fa[k]), halo_value(fb[k][1]), acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        HALO_STAMP(3);
 
-        // ---- epilogue: bias, ReLU, store, BatchNorm partial statistics (one group per wave and tile)
+        // ---- epilogue: bias, activation, store, running channel sums.  Straight-line code:
+        // the activation as max(x, slope * x), the bias in registers, one wave-uniform branch on the output type for the whole
+        // tile (per-element `if (act == ..)` / `if (bias)` / `if (out_fp32)` made this 1500 instructions = 6.7 k of the 12 k
+        // cycles of a tile).
         const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
         const int y0 = ty * HALO_TH + 2 * wave, x = tx * HALO_TW + col;
-        const int64_t o0 = ((int64_t)(n * OH + y0) * OW + x) * a.ldo;
-        const int64_t o1 = o0 + (int64_t)OW * a.ldo;
+        const int64_t o0 = ((int64_t)(n * OH + y0) * OW + x) * a.ldo + 4 * half;
+        const int64_t ostep = (int64_t)OW * a.ldo;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int mrow = 8 * g + 4 * half;
-            float bs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bs[r] = mrow + r < a.K ? a.bias[mrow + r] : 0.f;
-            }
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float vv[4];
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float xv = acc[j][g * 4 + r] + bs[r];
-                    if (a.act == 1) xv = fmaxf(xv, 0.f); else if (a.act == 3) xv = xv > 0.f ? xv : 0.01f * xv;
-                    vv[r] = xv;
-                    s1[r] += xv;
-                    s2[r] += xv * xv;
-                }
-                if (mrow < a.K) {
-                    const int64_t o = (j ? o1 : o0) + mrow;
-                    if (a.out_fp32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(a.out) + o) = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
-                }
-            }
-            if (a.stats) {
-                // halving butterfly over the 32 pixel lanes (see igemm_nt_kernel): lane 4*idx ends with value idx
-                const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-                float w4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w4[r] = (b4 ? s2[r] : s1[r]) + __shfl_xor(b4 ? s1[r] : s2[r], 16, 64);
-                float w2[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) w2[r] = (b3 ? w4[r + 2] : w4[r]) + __shfl_xor(b3 ? w4[r] : w4[r + 2], 8, 64);
-                float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
-                w1 += __shfl_xor(w1, 2, 64);
-                w1 += __shfl_xor(w1, 1, 64);
-                if ((lane & 3) == 0 && mrow < a.K) {
-                    const int idx = (lane >> 2) & 7;
-                    const int64_t grp = a.stats_group_offset + (int64_t)tile * 4 + wave;
-                    a.stats[grp * 2 * a.K + (idx >> 2) * a.K + mrow + (idx & 3)] = w1;
+                    float xv = acc[j][g * 4 + r] + bsv[g][r];
+                    xv = fmaxf(xv, xv * slope);
+                    acc[j][g * 4 + r] = xv;
+                    s1[g][r] += xv;
+                    s2[g][r] += xv * xv;
                 }
             }
         }
+#if HALO_ABL != 1
+        if (a.out_fp32) {
+            float* op = reinterpret_cast<float*>(a.out) + o0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (8 * g + 4 * half < a.K)
+                        *reinterpret_cast<float4*>(op + j * ostep + 8 * g) = make_float4(acc[j][g * 4], acc[j][g * 4 + 1], acc[j][g * 4 + 2], acc[j][g * 4 + 3]);
+        } else {
+            bf16raw* op = reinterpret_cast<bf16raw*>(a.out) + o0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (8 * g + 4 * half < a.K)
+                        *reinterpret_cast<uint2*>(op + j * ostep + 8 * g) = make_uint2(pack2bf(acc[j][g * 4], acc[j][g * 4 + 1]), pack2bf(acc[j][g * 4 + 2], acc[j][g * 4 + 3]));
+        }
+#endif
+        HALO_STAMP(4);
         slot ^= 1;
     }
 #undef HALO_ISSUE
+    if (a.stats && HALO_ABL != 2) {
+        // BatchNorm partial statistics: ONE group per (workgroup, wave) and frame -- the sums ride in registers over the tile run
+        // and cross the 32 pixel lanes of each half wave once, with DPP adds (per tile that reduction was 256 of the epilogue's
+        // 600 instructions)
+        const int64_t grp = a.stats_group_offset + (int64_t)frame * a.stats_bstride + wslot * 4 + wave;
+        float* sp = a.stats + grp * 2 * a.K + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float t8[8] = {s1[g][0], s1[g][1], s1[g][2], s1[g][3], s2[g][0], s2[g][1], s2[g][2], s2[g][3]};
+            halo_reduce8(t8);
+            if ((lane & 31) == 16 && 8 * g + 4 * half < a.K) {
+                *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(t8[0], t8[1], t8[2], t8[3]);
+                *reinterpret_cast<float4*>(sp + a.K + 8 * g) = make_float4(t8[4], t8[5], t8[6], t8[7]);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -268,25 +360,33 @@ static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     return p;
 }
 
-static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per_wg, size_t* lds_bytes) {
+static int halo_grid(const tcvom_conv_desc* d, const HaloPlan& p, int* tiles_per_wg, int* wgs_per_frame, size_t* lds_bytes) {
     const int cu = p.C / 8;
     const int ndma = ((p.S * HALO_TW + 2) * (p.S * HALO_TH + 2) * cu + 63) / 64;
     *lds_bytes = (size_t)2 * ndma * 1024 + (size_t)32 * (p.nch * 16 + 8) * 2;
     int occ = (int)((160 * 1024) / *lds_bytes);
     if (occ > 4) occ = 4;
     if (occ < 1) occ = 1;
-    const int ntiles = d->N * (d->batch > 1 ? d->batch : 1) * (d->OH / HALO_TH) * (d->OW / HALO_TW);
-    int wgs = 256 * occ;
-    if (wgs > ntiles) wgs = ntiles;
-    *tiles_per_wg = (ntiles + wgs - 1) / wgs;
-    return (ntiles + *tiles_per_wg - 1) / *tiles_per_wg;
+    // persistent workgroups, every frame the same number (a workgroup never crosses into another frame: its weights and its
+    // statistics group belong to one)
+    const int nb = d->batch > 1 ? d->batch : 1;
+    const int tpf = d->N * (d->OH / HALO_TH) * (d->OW / HALO_TW);
+    int wpf = 256 * occ / nb;
+    if (wpf < 1) wpf = 1;
+    if (wpf > tpf) wpf = tpf;
+    *tiles_per_wg = (tpf + wpf - 1) / wpf;
+    *wgs_per_frame = (tpf + *tiles_per_wg - 1) / *tiles_per_wg;
+    return *wgs_per_frame * nb;
 }
 
 // number of statistics groups the halo kernel writes for `d`, or 0 when the shape is not handled here
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase) {
     const HaloPlan p = halo_plan(d, nphase);
     if (!p.ok) return 0;
-    return d->N * (d->OH / HALO_TH) * (d->OW / HALO_TW) * 4;   // per batch element (frame), like the igemm count
+    int tpw, wpf;
+    size_t lds;
+    halo_grid(d, p, &tpw, &wpf, &lds);
+    return wpf * 4;                                            // per batch element (frame): one per (workgroup, wave)
 }
 
 // returns 1 when the conv was launched here, 0 when the caller should use the implicit GEMM, < 0 on error
@@ -312,10 +412,6 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
     a.spf = d->N;
     a.w_bstride = nb > 1 ? d->w_bstride : 0;
     a.ntiles = a.N * a.tiles_x * a.tiles_y;
-    // statistics groups are tile-major == frame-major, so frame f starts at f * (groups per frame): the caller's
-    // stats_bstride must be exactly that
-    if (stats && nb > 1 && d->stats_bstride != (long long)d->N * a.tiles_x * a.tiles_y * 4)
-        return tcvom_fail(TCVOM_ERR_ARG, "halo_conv: stats_bstride %lld != groups per frame", (long long)d->stats_bstride);
     for (int t = 0; t < HALO_MAX_TAPS + 2; ++t) {
         const int src = t < p.ntaps ? p.taps[t] : -1;
         a.tap_dh[t] = src >= 0 ? d->tap_dh[src] - p.org : 0;
@@ -323,7 +419,10 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
         a.tap_w[t] = src >= 0 ? d->tap_w[src] : -1;
     }
     size_t lds_bytes;
-    const int grid = halo_grid(d, p, &a.tiles_per_wg, &lds_bytes);
+    const int grid = halo_grid(d, p, &a.tiles_per_wg, &a.wgs_per_frame, &lds_bytes);
+    a.stats_bstride = nb > 1 ? d->stats_bstride : 0;
+    if (stats && nb > 1 && d->stats_bstride < (long long)a.wgs_per_frame * 4)
+        return tcvom_fail(TCVOM_ERR_ARG, "halo_conv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
 #define HALO_LAUNCH(...)                                                                                    \
