@@ -36,3 +36,7 @@ for name, cin, cout, H, W in SHAPES:
         per = np.diff(steps[:n, 0])
         print('%s wave%d: prologue %d  loop %d (%d steps, median period %d)  epilogue %d  total %d cycles' % (
             name, wv, e[1] - e[0], e[2] - e[1], n, np.median(per) if len(per) else 0, e[3] - e[2], e[3] - e[0]))
+        if n > 2:
+            t = steps[:n]
+            print('    per step: wait vmcnt %d  barrier %d  dma issue %d  reads + mfma %d' % (
+                np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2] - t[:, 1]), np.median(t[:, 3] - t[:, 2]), np.median(t[1:, 0] - t[:-1, 3])))
