@@ -1,7 +1,7 @@
 """Host time of each segment of the training step in a free-running loop (no synchronisation): a segment whose host time is far
 above its enqueue cost is where the host waits for the GPU."""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from tcvom_amd.facade import train_step_loss
 from tcvom_amd.optim import FusedAdam
