@@ -16,6 +16,7 @@
 // accumulator registers are 4 consecutive channels of ONE pixel -> 8-byte NHWC stores, and the
 // BatchNorm statistics of a channel are a reduction across lanes.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include <mutex>
 
@@ -62,6 +63,22 @@ extern "C" int tcvom_trace_read(unsigned long long* host, int n) {
 #ifndef NT_DBG
 #define NT_DBG 0            // kernel study builds only: 1 = no LDS reads / MFMAs, 2 = no DMA, 3 = no epilogue
 #endif
+// 8 sums over the 32 pixel lanes of each half wave with DPP adds: within quads, half rows, rows, then row 0 -> row 1 / row 2 -> row 3
+// (row_bcast15): lanes 16..31 and 48..63 hold the totals
+#define NT_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
+__device__ __forceinline__ void nt_reduce8(float (&t)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0xB1, 0xF);      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x4E, 0xF);      // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x141, 0xF);     // row_half_mirror
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x140, 0xF);     // row_mirror
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x142, 0xA);     // row_bcast15 into rows 1 and 3
+}
+
 template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const bf16raw* __restrict__ in, const bf16raw* __restrict__ wgt, void* __restrict__ outp,
@@ -276,72 +293,68 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         out_off[b] = ((int64_t)(n * d.OH + i * d.out_step + d.out_off_h) * d.OW + j * d.out_step + d.out_off_w) * d.ldo;
         if (d.batch > 1) out_off[b] += (int64_t)bz * d.out_bstride;
     }
+    // Straight-line form: the activation as max(x, slope * x); the per-row vectors as 16-byte loads (K % 4 == 0: a lane's 4 rows
+    // are valid together); the diagonal term and the output type decided once per tile, not per element; the 8 channel sums of a
+    // row group cross the 32 pixel lanes with DPP adds.  (With per-element `if (act == ..)`, `if (mdiag ..)`, scalar coefficient
+    // loads and a ds_bpermute butterfly per group this took 6.3 k cycles per workgroup -- a quarter of an os16 layer's workgroup.)
     const bool do_stats = stats != nullptr;
+    const float slope = d.act == 1 ? 0.f : d.act == 3 ? 0.01f : 1.f;
+    const bool vec_ok = (((uintptr_t)bias | (uintptr_t)mscale | (uintptr_t)mdiag) & 15) == 0;     // 16-byte loads of the row vectors
+    const int64_t sgrp = do_stats ? d.stats_group_offset + bz * d.stats_bstride + (int64_t)bx * WAVES_N + wn : 0;
+    auto emit = [&](auto diag_, auto f32_) {
+        constexpr bool DIAG = decltype(diag_)::value, F32 = decltype(f32_)::value;
 #pragma unroll
-    for (int a = 0; a < MI; ++a) {
+        for (int a = 0; a < MI; ++a) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int mrow = m0 + wm * WM + a * 32 + 8 * g + 4 * (lane >> 5);   // first of 4 rows
-            float bs[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (mrow + r < K) {
-                    if (bias) bs[r] = bias[mrow + r];
-                    if (mscale) sc[r] = mscale[mrow + r];
-                    if (mdiag) dg[r] = mdiag[mrow + r];
-                }
-            }
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < NI; ++b) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[a][b][g * 4 + r] * sc[r] + bs[r];
-                    if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
-                    if (d.act == 1) x = fmaxf(x, 0.f); else if (d.act == 3) x = x > 0.f ? x : 0.01f * x;
-                    v[r] = x;
-                    if (pvalid[b]) { s1[r] += x; s2[r] += x * x; }
-                }
-                if (pvalid[b] && mrow < K) {
-                    if (d.out_fp32) {
-                        float* o = reinterpret_cast<float*>(outp) + out_off[b] + mrow;
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            for (int g = 0; g < 4; ++g) {
+                const int mrow = m0 + wm * WM + a * 32 + 8 * g + 4 * (lane >> 5);   // first of 4 rows
+                float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = bs4;
+                if (mrow < K) {
+                    if (vec_ok) {
+                        if (bias) bs4 = *reinterpret_cast<const float4*>(bias + mrow);
+                        if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
+                        if (DIAG) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
                     } else {
-                        bf16raw* o = reinterpret_cast<bf16raw*>(outp) + out_off[b] + mrow;
-                        *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                        if (bias) bs4 = make_float4(bias[mrow], bias[mrow + 1], bias[mrow + 2], bias[mrow + 3]);
+                        if (mscale) sc4 = make_float4(mscale[mrow], mscale[mrow + 1], mscale[mrow + 2], mscale[mrow + 3]);
+                        if (DIAG) dg4 = make_float4(mdiag[mrow], mdiag[mrow + 1], mdiag[mrow + 2], mdiag[mrow + 3]);
+                    }
+                }
+                const float bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
+                float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < NI; ++b) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[a][b][g * 4 + r] * sc[r] + bs[r];
+                        if (DIAG) x -= (mrow + r) == pglob[b] ? dg[r] : 0.f;
+                        x = fmaxf(x, x * slope);
+                        v[r] = x;
+                        const float xs = pvalid[b] ? x : 0.f;
+                        t8[r] += xs;
+                        t8[4 + r] = fmaf(xs, xs, t8[4 + r]);
+                    }
+                    if (pvalid[b] && mrow < K) {
+                        if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
+                        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(outp) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    }
+                }
+                if (do_stats) {
+                    nt_reduce8(t8);                      // lanes 16..31 / 48..63 hold the totals of the two lane halves
+                    if ((lane & 31) == 16 && mrow < K) {
+                        float* sp = stats + sgrp * 2 * K + mrow;
+                        *reinterpret_cast<float4*>(sp) = make_float4(t8[0], t8[1], t8[2], t8[3]);
+                        *reinterpret_cast<float4*>(sp + K) = make_float4(t8[4], t8[5], t8[6], t8[7]);
                     }
                 }
             }
-            if (do_stats) {
-                // 8 sums (4 channels x {sum, sum of squares}) over the 32 pixel lanes: a halving butterfly -- each
-                // exchange keeps half of the values on each side -- needs 4 + 2 + 1 + 1 + 1 = 9 lane exchanges
-                // instead of 8 x 5; lane 4 * idx of each half-wave ends up with value idx
-                const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-                float w4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float send = b4 ? s1[r] : s2[r];
-                    const float keep = b4 ? s2[r] : s1[r];
-                    w4[r] = keep + __shfl_xor(send, 16, 64);
-                }
-                float w2[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float send = b3 ? w4[r] : w4[r + 2];
-                    const float keep = b3 ? w4[r + 2] : w4[r];
-                    w2[r] = keep + __shfl_xor(send, 8, 64);
-                }
-                float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 4, 64);
-                w1 += __shfl_xor(w1, 2, 64);
-                w1 += __shfl_xor(w1, 1, 64);
-                if ((lane & 3) == 0 && mrow < K) {
-                    const int idx = (lane >> 2) & 7;                    // b4: sum / sum of squares, (b3, b2): channel
-                    const int64_t grp = d.stats_group_offset + bz * d.stats_bstride + (int64_t)bx * WAVES_N + wn;
-                    stats[grp * 2 * K + (idx >> 2) * K + mrow + (idx & 3)] = w1;
-                }
-            }
         }
+    };
+    if (mdiag) {
+        if (d.out_fp32) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{});
+    } else {
+        if (d.out_fp32) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{});
     }
 #ifdef NT_TRACE
     if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW - 1)) {
