@@ -20,6 +20,7 @@
 // is first issued in interval 8t+1; it must have landed before interval 8t+8, where group 0 starts reading it: every
 // wave drains vmcnt before the barrier that ends interval 8t+7.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 struct Gemm256Args {
@@ -351,6 +352,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         char* wl = lb + wave * (F32 ? 16384 : 8192);
         const int nl = lane & 31, h = lane >> 5;
         const bool al16 = F32 || ((g.ldo & 7) == 0 && (g.out_bstride & 7) == 0 && ((uintptr_t)gout & 15) == 0);
+        const float slope = g.act == 1 ? 0.f : g.act == 3 ? 0.01f : 1.f;          // activation as max(x, slope * x)
+        // (the diagonal term is decided once per tile, not per element: `if (mdiag && ..)` / `if (act == ..)` inside the 128-value
+        // loops were scalar branches)
+        auto emit = [&](auto diag_) {
+        constexpr bool DIAG = decltype(diag_)::value;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -362,16 +368,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     if (mrow < g.M) {                         // M % 4 == 0: a lane's 4 rows are valid together
                         if (bias) bs = *reinterpret_cast<const float4*>(bias + mrow);
                         if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
-                        if (mdiag) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
+                        if (DIAG) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
                     }
                     const float bsv[4] = {bs.x, bs.y, bs.z, bs.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float x = acc[a][b][q * 4 + r] * sc[r] + bsv[r];
-                        if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
-                        if (g.act == 1) x = fmaxf(x, 0.f); else if (g.act == 3) x = x > 0.f ? x : 0.01f * x;
-                        v[r] = x;
+                        if (DIAG) x -= (mrow + r) == pglob[b] ? dg[r] : 0.f;
+                        v[r] = fmaxf(x, x * slope);
                     }
                     if constexpr (F32)
                         *reinterpret_cast<float4*>(wl + nl * 512 + (((a * 8 + 2 * q + h) ^ nl) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
@@ -407,8 +412,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                 }
             }
         }
+        };
+        if (mdiag) emit(std::true_type{}); else emit(std::false_type{});
     } else {
     // stored straight from the registers (the 192-row tiles)
+    const float slope3 = g.act == 1 ? 0.f : g.act == 3 ? 0.01f : 1.f;
     int64_t out_off[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) out_off[b] = (int64_t)(pvalid[b] ? pglob[b] : 0) * g.ldo + obase;
@@ -431,8 +439,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                 for (int r = 0; r < 4; ++r) {
                     float x = acc[a][b][q * 4 + r] * sc[r] + bsv[r];
                     if (mdiag && (mrow + r) == pglob[b]) x -= dg[r];
-                    if (g.act == 1) x = fmaxf(x, 0.f); else if (g.act == 3) x = x > 0.f ? x : 0.01f * x;
-                    v[r] = x;
+                    v[r] = fmaxf(x, x * slope3);
                 }
                 if (pvalid[b] && mrow < g.M) {
                     if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(gout) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
