@@ -47,11 +47,12 @@ int tcvom_abi_version(void);
  * (sum, sum of squares per channel per 64-pixel group).                       */
 #define TCVOM_MAX_TAPS 32
 typedef struct {
-    int32_t N, H, W, C;          /* input NHWC; C a multiple of 8 (ntaps * C a multiple of 64) */
+    int32_t N, H, W, C;          /* input NHWC; C a multiple of 8 */
     int32_t OH, OW, K;           /* output tensor dims; K = output channels (multiple of 4) */
     int32_t PH, PW;              /* phase grid */
     int32_t in_step, out_step, out_off_h, out_off_w;
-    int32_t ntaps;               /* ntaps*C must be a multiple of 64 */
+    int32_t ntaps;               /* the reduction runs over ntaps*C elements in 64-deep steps; a partial last step ends in zero-tap
+                                    slots past the list: ((ntaps*C + 63) / 64 * 64 - 1) / C must stay below TCVOM_MAX_TAPS */
     int32_t tap_dh[TCVOM_MAX_TAPS], tap_dw[TCVOM_MAX_TAPS];
     int32_t tap_w[TCVOM_MAX_TAPS];   /* weight slot of tap t, -1 = zero tap (padding) */
     int32_t wt;                  /* weight slots: w is [K][wt][C] bf16 */

@@ -9,11 +9,11 @@ from ._lib import ConvDesc, MAX_TAPS
 
 
 def _desc(N, H, W, C, OH, OW, K, PH, PW, in_step, out_step, off_h, off_w, taps, wt, ldo=None):
-    """taps: list of (dh, dw, wslot).  Pads the tap list with zero taps so that ntaps*C % 64 == 0."""
+    """taps: list of (dh, dw, wslot).  The reduction runs over ntaps*C elements in 64-deep steps; the tail of the last step
+    falls into tap slots past the list, which the kernels treat as zero taps (igemm_nt_kernel: `taps` table) -- a 1x1 conv
+    over 24 channels is ONE step, not the 8 zero-padded taps (192 elements) that made ntaps*C a multiple of 64."""
     taps = list(taps)
-    while (len(taps) * C) % 64 != 0:
-        taps.append((0, 0, -1))
-    assert len(taps) <= MAX_TAPS, 'too many taps'
+    assert ((len(taps) * C + 63) // 64 * 64 - 1) // C < MAX_TAPS, 'too many taps'
     d = ConvDesc()
     d.N, d.H, d.W, d.C = N, H, W, C
     d.OH, d.OW, d.K = OH, OW, K

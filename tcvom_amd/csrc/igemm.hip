@@ -139,7 +139,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         taps[tid] = make_int4((dh * W + dw) * C, ok ? d.tap_w[tid] * C : -1, dh + 8, ok ? dw + 8 : 31);
     }
     // tap = kk / C through a multiply-high (exact for kk < 2^32 / C; one tap: magic 0 -> tap 0): C is any multiple of 8
-    const unsigned cmagic = (d.ntaps == 1) ? 0u : (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
+    const unsigned cmagic = (d.ntaps == 1 && (C & 63) == 0) ? 0u : (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
     const int p0 = bx * TN;
     const int m0 = blockIdx.y * TM;
     const bool small_p = Ptot < (1 << 24);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nstage = (d.ntaps * C) >> 6;
+    const int nstage = (d.ntaps * C + 63) >> 6;          // (a partial last step ends in zero-tap slots)
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -464,7 +464,8 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         for (int t = 0; t < d->ntaps; ++t)
             TCVOM_CHECK_ARG(d->tap_dh[t] >= -8 && d->tap_dh[t] <= 7 && d->tap_dw[t] >= -8 && d->tap_dw[t] <= 7,
                             "conv_igemm: tap %d offset (%d,%d) outside [-8,7]", t, d->tap_dh[t], d->tap_dw[t]);
-        TCVOM_CHECK_ARG(((long long)d->ntaps * d->C) % 64 == 0, "conv_igemm: ntaps*C=%d not a multiple of 64", d->ntaps * d->C);
+        // (the last 64-deep step may reach past the tap list: those slots count as zero taps and must exist in the table)
+        TCVOM_CHECK_ARG((((long long)d->ntaps * d->C + 63) / 64 * 64 - 1) / d->C < TCVOM_MAX_TAPS, "conv_igemm: ntaps*C=%d needs tap slots past the table", d->ntaps * d->C);
         TCVOM_CHECK_ARG(d->ntaps == 1 || (d->C >= 8 && d->C % 8 == 0 && d->C <= 32768), "conv_igemm: C=%d must be a multiple of 8 (8..32768)", d->C);
         TCVOM_CHECK_ARG(d->K % 4 == 0 && d->ldo % 4 == 0, "conv_igemm: K=%d ldo=%d must be multiples of 4", d->K, d->ldo);
         TCVOM_CHECK_ARG(d->C % 8 == 0, "conv_igemm: C=%d must be a multiple of 8", d->C);
@@ -632,7 +633,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
 
     const int C = d.C, H = d.H, W = d.W, K = d.K;
     // tap = kk / C through a multiply-high (exact for kk < 2^32 / C; one tap: magic 0 -> tap 0): C is any multiple of 8
-    const unsigned cmagic = (d.ntaps == 1) ? 0u : (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
+    const unsigned cmagic = (d.ntaps == 1 && (C & 63) == 0) ? 0u : (unsigned)((0x100000000ull + (unsigned)C - 1) / (unsigned)C);
     const int ncols = d.ntaps * C;
     const int Ptot = d.N * d.PH * d.PW;
     const int pbeg = chunk * pchunk;
