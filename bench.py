@@ -192,8 +192,12 @@ def main():
                          'index: IndexNet+TAM (not a BASELINE config; 2 clips per step: its ASPP has a BatchNorm over the batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--sync-bn', action='store_true',
-                    help='SyncBatchNorm statistics over ranks, as train_ddp.py:271-273 (adds 2 small all-reduces per BN call)')
+    ap.add_argument('--sync-bn', dest='sync_bn', action='store_true', default=None,
+                    help='SyncBatchNorm statistics over the ranks, as train_ddp.py:271-273 converts every non-FBA model: the DEFAULT '
+                         'for --gpus > 1 (gca / index).  The [frames][2][C] sums are exchanged inside the BatchNorm finalize kernels '
+                         'through hipIpc peer mailboxes (TCVOM_SYNCBN=rccl: one all-reduce per BatchNorm call instead).  With '
+                         '--gpus 1 the exchange runs against a one-rank loop-back mailbox (its cost on one GPU)')
+    ap.add_argument('--no-sync-bn', dest='sync_bn', action='store_false', help='per-rank BatchNorm statistics (the A/B of --sync-bn)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -211,15 +215,21 @@ def main():
         dist.init_process_group(backend=backend, init_method='env://', **({'device_id': device} if backend == 'nccl' else {}))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
 
-    from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm
+    from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm, sync_batchnorm_info
     from tcvom_amd.facade import train_step_loss
     from tcvom_amd.optim import FusedAdam
     H, W = args.height, args.width
     model, a, fg, bg = build(device, H, W, seed=rank, config=args.config)
     base = {'fba': 'FBA+TAM', 'index': 'IndexNet+TAM'}.get(args.config, 'GCA+TAM')
     clips = 2 if args.config == 'index' else 1
-    if args.sync_bn:
-        convert_sync_batchnorm(model)
+    # train_ddp.py:271-273: every model but FBA (GroupNorm) trains with SyncBatchNorm under DDP
+    sync_bn = (world > 1 and args.config != 'fba') if args.sync_bn is None else bool(args.sync_bn)
+    if sync_bn:
+        if world > 1:
+            convert_sync_batchnorm(model)
+        else:
+            from tcvom_amd.mailbox import PeerMailbox
+            convert_sync_batchnorm(model, mailbox=PeerMailbox(loopback=True))
     broadcast_module_state(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = FusedAdam(params, lr=1e-4, weight_decay=1e-4)
@@ -244,10 +254,12 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    sync_transport, sync_n0 = sync_batchnorm_info(model)
     t0 = time.time()
     for _ in range(args.steps):
         loss = step()
     fence()
+    sync_n1 = sync_batchnorm_info(model)[1]
     elapsed = torch.tensor([time.time() - t0], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -274,9 +286,11 @@ def main():
                                     '2-scale trimap channels) fwd+bwd+grad-allreduce+Adam, L_alpha_comp+L_lap+L_grad+0.5L_dt+0.25L_att, '
                                     'one 3-frame %dx%d window per GPU per step, formula-initialised weights, train mode; BASELINE '
                                     'config 5 names fp16: the engine computes in bf16 (same MFMA rate, no loss scaling needed)' % (H, W)),
-                       'global_batch_clips': world * clips, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn)},
+                       'global_batch_clips': world * clips, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(sync_bn)},
             'final_loss': round(final_loss, 6),
             'dist': {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,
+                     'sync_bn_transport': sync_transport,            # 'mailbox': in-kernel peer exchange; 'allreduce': one collective per BN call
+                     'sync_bn_exchanges_per_step': (sync_n1 - sync_n0) // args.steps if sync_n1 is not None else None,
                      'grad_spans_overlapped_with_backward': averager.early_spans,
                      'grad_allreduce_plan': averager.last_plan},
             'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5) if gflop is not None else None,

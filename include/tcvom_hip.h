@@ -219,6 +219,38 @@ int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t
 int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
                                int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream);
+/* SyncBatchNorm WITHOUT a collective call (replaces the all_gather / all_reduce pairs nn.SyncBatchNorm issues per BatchNorm call
+ * under train_ddp.py:271-280): every rank owns a mailbox of uncached device memory mapped into its peers
+ * through hipIpc; the finalize kernel pushes its local fp64 sums into every peer's mailbox over xGMI as self-validating 8-byte
+ * granules {32 data bits, 32-bit tag = seq}, polls its own mailbox for the `world` contributions and adds them in rank order
+ * (bit-identical on all ranks).  Same launches as tcvom_bn_finalize / tcvom_bn_bwd_finalize; `count` is the pixel count of one
+ * frame over ALL ranks.  Calls of one mailbox must be enqueued on ONE stream, in the same order and with consecutive `seq`
+ * values on every rank.  A peer that never arrives does not hang the device: after timeout_ticks the kernel stores seq into
+ * *status and carries on with partial sums (the host raises).
+ * mailbox bytes = ring * world * capacity * 16. */
+typedef struct {
+    const void* peers;        /* DEVICE array of `world` pointers: base of rank r's mailbox as mapped in this process */
+    int32_t world, rank;      /* world <= 32 */
+    uint32_t seq;             /* tag of this exchange, != 0 */
+    int32_t ring;             /* ring slots (>= 2); slot = seq % ring */
+    int64_t capacity;         /* doubles per (slot, sender): nframes * 2 * C must fit */
+    int64_t timeout_ticks;    /* 100 MHz ticks a poll may spin (0: 30 s) */
+    int32_t* status;          /* device-visible word (pinned host memory), or NULL */
+} tcvom_bn_sync;
+int tcvom_bn_finalize_sync(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
+                           const float* gamma, const float* beta, float eps, float* scale_shift, float* saved,
+                           double* scratch, int32_t nframes, int64_t slot_stride, const tcvom_bn_sync* sync, void* stream);
+int tcvom_bn_bwd_finalize_sync(const float* partial, int32_t groups, int32_t C, int64_t count,
+                               const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
+                               double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
+                               const tcvom_bn_sync* sync, void* stream);
+/* The mailbox memory: the only entry points that own memory (uncached + hipIpc-exportable, which the caller's allocator cannot
+ * provide).  alloc: zero-filled, *handle64 = the 64-byte hipIpc handle to hand to the peers (all zero if the runtime cannot
+ * export: a one-rank mailbox still works).  open / close: map / unmap a peer's mailbox.  These four synchronise the device. */
+int tcvom_mbox_alloc(int64_t bytes, void** ptr, void* handle64);
+int tcvom_mbox_open(const void* handle64, void** ptr);
+int tcvom_mbox_close(void* ptr);
+int tcvom_mbox_free(void* ptr);
 /* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
  * gradient is additionally masked by y > 0 */
 int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,

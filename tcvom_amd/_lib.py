@@ -37,6 +37,12 @@ class SnScratch(C.Structure):
                 ('vhist', C.c_void_p), ('sum_h', C.c_int64), ('sum_wd', C.c_int64), ('num_layers', C.c_int32)]
 
 
+class BnSync(C.Structure):
+    """struct tcvom_bn_sync: one in-kernel SyncBatchNorm exchange (tcvom_amd/mailbox.py fills it)."""
+    _fields_ = [('peers', C.c_void_p), ('world', C.c_int32), ('rank', C.c_int32), ('seq', C.c_uint32), ('ring', C.c_int32),
+                ('capacity', C.c_int64), ('timeout_ticks', C.c_int64), ('status', C.c_void_p)]
+
+
 class TcvomError(RuntimeError):
     pass
 
@@ -58,6 +64,7 @@ _lib.tcvom_last_error.restype = C.c_char_p
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 DP = C.POINTER(ConvDesc)
 SP = C.POINTER(SnScratch)
+YP = C.POINTER(BnSync)
 
 # name -> argtypes (all return int except the explicitly listed ones)
 _PROTOS = {
@@ -81,6 +88,12 @@ _PROTOS = {
     'tcvom_bn_finalize_sums': [vp, i32, i64, i64, vp, vp, f32, vp, vp, i32, i64, vp],
     'tcvom_bn_bwd_finalize_sums': [vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_finalize_sync': [vp, i32, i32, i64, i64, vp, vp, f32, vp, vp, vp, i32, i64, YP, vp],
+    'tcvom_bn_bwd_finalize_sync': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, YP, vp],
+    'tcvom_mbox_alloc': [i64, C.POINTER(C.c_void_p), vp],
+    'tcvom_mbox_open': [vp, C.POINTER(C.c_void_p)],
+    'tcvom_mbox_close': [vp],
+    'tcvom_mbox_free': [vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
     'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, vp],

@@ -49,13 +49,82 @@ __global__ __launch_bounds__(256) void bn_partial_reduce_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------- SyncBatchNorm: in-kernel peer exchange
+// train_ddp.py:271-273 converts every BatchNorm to SyncBatchNorm: the per-channel (sum, sum of squares) -- and in backward
+// (sum dy, sum dy * xhat) -- are added over the ranks before they are used.  Instead of a collective per BatchNorm call (the
+// reference: all_gather / all_reduce of <= 4 KB, ~370 per step), every rank owns a MAILBOX (uncached device memory, mapped into
+// the peers through hipIpc): ring slot (seq % ring), one region per sender.  The finalize kernel PUSHES its local sums into the
+// region [slot][my rank] of every peer over xGMI and then PULLS the `world` regions of its own mailbox.  A value travels as two
+// 8-byte granules {32 data bits, 32-bit tag = seq}: each granule is one naturally aligned store, so a reader that sees the tag
+// sees the data -- no fence, no flag, no ordering between granules (the LL protocol of the collective libraries).  Every rank adds
+// the `world` contributions in rank order: bit-identical statistics on all ranks.  A slot is rewritten `ring` exchanges later;
+// a rank can be at most one exchange ahead of the slowest reader of its pushes (it needs that reader's push to finish its own
+// exchange), so ring >= 2 suffices on one stream.
+struct BnSync {
+    const unsigned long long* const* peers;   // device table [world]: base of rank r's mailbox as mapped in this process; NULL = no exchange
+    int world, rank;
+    unsigned int seq;                          // tag of this exchange (never 0: fresh mailboxes are zero)
+    long long slot_off;                        // granule offset of the ring slot: (seq % ring) * world * cap2
+    long long cap2;                            // granules per (slot, sender) = 2 * capacity in doubles
+    long long timeout;                         // wall_clock64() ticks (100 MHz) a pull may spin before it gives up
+    int* status;                               // set to seq when a pull timed out (host-visible: pinned memory)
+};
+
+// Threads (sl, cl) of a FIN_SL x 32 block; on entry the sl == 0 threads hold the LOCAL sums (a, b) of channel c of `frame`;
+// on return they hold the sums over all ranks.  Every thread of the block must call it (barriers inside).
+__device__ __forceinline__ void bn_sync_exchange(const BnSync& sy, double (*s1)[32], double (*s2)[32], int sl, int cl, int c, int C,
+                                                 int frame, double& a, double& b) {
+    if (sl == 0) { s1[0][cl] = a; s2[0][cl] = b; }
+    __syncthreads();
+    const bool active = sl < sy.world && c < C;
+    const long long ia = ((long long)(frame * 2) * C + c) * 2, ib = ((long long)(frame * 2 + 1) * C + c) * 2;
+    double pa = 0.0, pb = 0.0;
+    if (active) {
+        const unsigned long long ua = (unsigned long long)__double_as_longlong(s1[0][cl]), ub = (unsigned long long)__double_as_longlong(s2[0][cl]);
+        const unsigned long long tag = (unsigned long long)sy.seq << 32;
+        unsigned long long* dst = const_cast<unsigned long long*>(sy.peers[sl]) + sy.slot_off + (long long)sy.rank * sy.cap2;
+        __hip_atomic_store(dst + ia, tag | (ua & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + ia + 1, tag | (ua >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + ib, tag | (ub & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + ib + 1, tag | (ub >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();                                               // s1[0] / s2[0] have been read: the pulls may overwrite them
+    if (active) {
+        unsigned long long* src = const_cast<unsigned long long*>(sy.peers[sy.rank]) + sy.slot_off + (long long)sl * sy.cap2;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned long long g0 = __hip_atomic_load(src + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long g1 = __hip_atomic_load(src + ia + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long g2 = __hip_atomic_load(src + ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long g3 = __hip_atomic_load(src + ib + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(g0 >> 32) == sy.seq && (unsigned)(g1 >> 32) == sy.seq && (unsigned)(g2 >> 32) == sy.seq && (unsigned)(g3 >> 32) == sy.seq) {
+                pa = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
+                pb = __longlong_as_double((long long)((g2 & 0xffffffffull) | (g3 << 32)));
+                break;
+            }
+            if (wall_clock64() - t0 > sy.timeout) {                // a peer never arrived: report, do not hang the device
+                if (sy.status) __hip_atomic_store(sy.status, (int)sy.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    if (sl < FIN_SL) { s1[sl][cl] = pa; s2[sl][cl] = pb; }
+    __syncthreads();
+    if (sl == 0) {
+        a = 0.0; b = 0.0;
+        for (int k = 0; k < sy.world; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+    }
+}
+
 // stage 2 / single stage.  PT = float (raw partials [G][2][C]) or double (stage-1 output).
 template <typename PT>
 __global__ __launch_bounds__(FIN_SL * 32) void bn_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count, double unbias_count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
-    float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved, int64_t slot_stride)
+    float momentum, float eps, float* __restrict__ scale_shift, float* __restrict__ saved, int64_t slot_stride, const BnSync sy)
 {
     __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -88,6 +157,9 @@ __global__ __launch_bounds__(FIN_SL * 32) void bn_finalize_kernel(
     if (sl == 0 && c < C) {
 #pragma unroll
         for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
+    }
+    if (sy.peers) bn_sync_exchange(sy, s1, s2, sl, cl, c, C, blockIdx.y, a, b);      // SyncBatchNorm: sums over the ranks (block-uniform branch)
+    if (sl == 0 && c < C) {
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -297,7 +369,7 @@ template <typename PT>
 __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ saved,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate, int64_t slot_stride)
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate, int64_t slot_stride, const BnSync sy)
 {
     __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -331,8 +403,12 @@ __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
 #pragma unroll
         for (int k = 1; k < FIN_SL; ++k) { a += s1[k][cl]; b += s2[k][cl]; }
         // accumulate: the S calls of one BatchNorm (frames on concurrent streams) add into one gradient buffer
+        // (SyncBatchNorm: gamma / beta gradients stay the LOCAL sums -- torch semantics; the gradient all-reduce averages them)
         if (dbeta) { if (accumulate) atomicAdd(dbeta + c, (float)a); else dbeta[c] = (float)a; }
         if (dgamma) { if (accumulate) atomicAdd(dgamma + c, (float)b); else dgamma[c] = (float)b; }
+    }
+    if (sy.peers) bn_sync_exchange(sy, s1, s2, sl, cl, c, C, blockIdx.y, a, b);      // the dx coefficients use the sums over the ranks
+    if (sl == 0 && c < C) {
         // dy = gi * g - c1 - xhat * c2   (bn_bwd_apply); the same form serves GroupNorm (gn_bwd_finalize_kernel)
         const float gi = gamma[c] * saved[C + c];
         coef[c] = (float)(a / count) * gi;
@@ -420,25 +496,67 @@ static int stream_grid(int64_t n, int per_block) {
     return (int)b;
 }
 
-extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
-                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                 float momentum, float eps, float* scale_shift, float* saved, double* scratch,
-                                 int32_t nframes, int64_t slot_stride, void* stream) {
-    TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0, "bn_finalize: bad args");
-    TCVOM_CHECK_ARG(nframes >= 1 && (nframes == 1 || (!running_mean && !running_var)), "bn_finalize: running statistics of a batched call are updated by tcvom_bn_ema_multi");
+static const BnSync kNoSync = {nullptr, 1, 0, 0u, 0, 0, 0, nullptr};
+
+// host view of tcvom_bn_sync -> kernel argument
+static int make_sync(const tcvom_bn_sync* s, int32_t C, int32_t nframes, BnSync* out, const char* who) {
+    if (!s) { *out = kNoSync; return TCVOM_OK; }
+    TCVOM_CHECK_ARG(s->peers && s->world >= 1 && s->world <= FIN_SL && s->rank >= 0 && s->rank < s->world && s->seq != 0 && s->ring >= 2,
+                    "%s: bad tcvom_bn_sync (world %d, rank %d, seq %u, ring %d; at most %d ranks)", who, s->world, s->rank, s->seq, s->ring, FIN_SL);
+    TCVOM_CHECK_ARG((int64_t)nframes * 2 * C <= s->capacity, "%s: %d frames x 2 x %d channels exceed the mailbox capacity of %lld doubles",
+                    who, nframes, C, (long long)s->capacity);
+    out->peers = (const unsigned long long* const*)s->peers;
+    out->world = s->world;
+    out->rank = s->rank;
+    out->seq = s->seq;
+    out->cap2 = 2 * s->capacity;
+    out->slot_off = (long long)(s->seq % (uint32_t)s->ring) * s->world * out->cap2;
+    out->timeout = s->timeout_ticks > 0 ? s->timeout_ticks : 3000000000ll;      // default 30 s
+    out->status = s->status;
+    return TCVOM_OK;
+}
+
+static int bn_finalize_impl(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, float* scale_shift, float* saved, double* scratch,
+                            int32_t nframes, int64_t slot_stride, const BnSync& sy, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const double ub = (double)(unbias_count > 0 ? unbias_count : count);
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
         // the second stage reads nframes blocks of BN_SLICES double partials
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES, C,
-                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride);
+                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride, sy);
     } else {
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C,
-                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride);
+                           (double)count, ub, gamma, beta, running_mean, running_var, momentum, eps, scale_shift, saved, slot_stride, sy);
     }
     TCVOM_LAUNCH_CHECK("bn_finalize");
     return TCVOM_OK;
+}
+
+extern "C" int tcvom_bn_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* scale_shift, float* saved, double* scratch,
+                                 int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0, "bn_finalize: bad args");
+    TCVOM_CHECK_ARG(nframes >= 1 && (nframes == 1 || (!running_mean && !running_var)), "bn_finalize: running statistics of a batched call are updated by tcvom_bn_ema_multi");
+    return bn_finalize_impl(partial, groups, C, count, unbias_count, gamma, beta, running_mean, running_var, momentum, eps, scale_shift,
+                            saved, scratch, nframes, slot_stride, kNoSync, stream);
+}
+
+// SyncBatchNorm forward: the local partial sums are combined, exchanged with the peers INSIDE the finalize kernel (bn_sync_exchange)
+// and finalised with the global count: the same launches as tcvom_bn_finalize, no collective call, no host involvement.
+extern "C" int tcvom_bn_finalize_sync(const float* partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
+                                      const float* gamma, const float* beta, float eps, float* scale_shift, float* saved,
+                                      double* scratch, int32_t nframes, int64_t slot_stride, const tcvom_bn_sync* sync, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && beta && scale_shift && saved && groups > 0 && C > 0 && count > 0 && nframes >= 1 && sync,
+                    "bn_finalize_sync: bad args");
+    BnSync sy;
+    const int rc = make_sync(sync, C, nframes, &sy, "bn_finalize_sync");
+    if (rc != TCVOM_OK) return rc;
+    return bn_finalize_impl(partial, groups, C, count, unbias_count, gamma, beta, nullptr, nullptr, 0.f, eps, scale_shift, saved, scratch,
+                            nframes, slot_stride, sy, stream);
 }
 /* doubles of scratch tcvom_bn_finalize needs for C channels */
 extern "C" int tcvom_bn_finalize_scratch_doubles(int32_t C) { return BN_SLICES * 2 * C; }
@@ -567,23 +685,44 @@ extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* 
     return TCVOM_OK;
 }
 
+static int bn_bwd_finalize_impl(const float* partial, int32_t groups, int32_t C, int64_t count,
+                                const float* gamma, const float* saved, float* dgamma, float* dbeta,
+                                float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
+                                const BnSync& sy, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (groups > 4 * BN_SLICES && scratch) {
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES,
+                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride, sy);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C,
+                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride, sy);
+    }
+    TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
+    return TCVOM_OK;
+}
+
 extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count,
                                      const float* gamma, const float* saved, float* dgamma, float* dbeta,
                                      float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
                                      void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize: bad args");
     TCVOM_CHECK_ARG(nframes == 1 || accumulate, "bn_bwd_finalize: the frames of a batched call must ACCUMULATE dgamma/dbeta");
-    hipStream_t st = (hipStream_t)stream;
-    if (groups > 4 * BN_SLICES && scratch) {
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES,
-                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
-    } else {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C,
-                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride);
-    }
-    TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
-    return TCVOM_OK;
+    return bn_bwd_finalize_impl(partial, groups, C, count, gamma, saved, dgamma, dbeta, coef, scratch, accumulate, nframes, slot_stride,
+                                kNoSync, stream);
+}
+
+// SyncBatchNorm backward: (sum dy, sum dy * xhat) exchanged inside the finalize kernel; dgamma / dbeta from the LOCAL sums.
+extern "C" int tcvom_bn_bwd_finalize_sync(const float* partial, int32_t groups, int32_t C, int64_t count,
+                                          const float* gamma, const float* saved, float* dgamma, float* dbeta,
+                                          float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
+                                          const tcvom_bn_sync* sync, void* stream) {
+    TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0 && nframes >= 1 && sync, "bn_bwd_finalize_sync: bad args");
+    TCVOM_CHECK_ARG(nframes == 1 || accumulate, "bn_bwd_finalize_sync: the frames of a batched call must ACCUMULATE dgamma/dbeta");
+    BnSync sy;
+    const int rc = make_sync(sync, C, nframes, &sy, "bn_bwd_finalize_sync");
+    if (rc != TCVOM_OK) return rc;
+    return bn_bwd_finalize_impl(partial, groups, C, count, gamma, saved, dgamma, dbeta, coef, scratch, accumulate, nframes, slot_stride, sy, stream);
 }
 
 // ---------------------------------------------------------------- GroupNorm (FBA base: models/FBA/layers_WS.py:26-27)
@@ -792,7 +931,7 @@ extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t cou
     TCVOM_CHECK_ARG(sums && gamma && beta && scale_shift && saved && C > 0 && count > 0 && nframes >= 1, "bn_finalize_sums: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, (hipStream_t)stream, sums, 1, C, (double)count,
                        (double)(unbias_count > 0 ? unbias_count : count), gamma, beta, (float*)nullptr, (float*)nullptr, 0.f, eps,
-                       scale_shift, saved, slot_stride);
+                       scale_shift, saved, slot_stride, kNoSync);
     TCVOM_LAUNCH_CHECK("bn_finalize_sums");
     return TCVOM_OK;
 }
@@ -803,7 +942,7 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
     TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, sums_all, 1, C, (double)count, gamma,
-                       saved, (float*)nullptr, (float*)nullptr, coef, 0, slot_stride);
+                       saved, (float*)nullptr, (float*)nullptr, coef, 0, slot_stride, kNoSync);
     // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
     hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate, nframes);
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize_sums");

@@ -29,16 +29,40 @@ def broadcast_module_state(module, src=0):
             off += n
 
 
-def convert_sync_batchnorm(module, process_group=None):
-    """`nn.SyncBatchNorm.convert_sync_batchnorm` (train_ddp.py:213) for the HIP network: every BatchNorm of
-    `module` takes its train-mode statistics over the clips of all ranks of `process_group`.  The modules keep
-    their class and state_dict keys; tcvom_amd.ops.conv_bn_act reads the two attributes set here and inserts one
-    [2][C] fp64 all-reduce per BatchNorm call in forward and one in backward."""
+def convert_sync_batchnorm(module, process_group=None, mailbox='auto'):
+    """`nn.SyncBatchNorm.convert_sync_batchnorm` (train_ddp.py:271-273) for the HIP network: every BatchNorm of `module` takes
+    its train-mode statistics over the clips of all ranks of `process_group`.  The modules keep their class and state_dict
+    keys; tcvom_amd.ops.conv_bn_act reads the attributes set here.
+
+    mailbox: 'auto' -- the ranks of one node exchange the [frames][2][C] fp64 sums INSIDE the BatchNorm finalize kernels
+    through hipIpc-mapped peer mailboxes (tcvom_amd/mailbox.py; a collective call: every rank must convert); None -- one
+    all-reduce of the process group per BatchNorm call, forward and backward (what remains when the ranks span nodes or
+    TCVOM_SYNCBN=rccl); or a PeerMailbox (a one-rank loop-back mailbox measures the exchange on one GPU)."""
+    mb = None
+    if mailbox == 'auto':
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1 and torch.cuda.is_available():
+            from .mailbox import mailbox_for
+            mb = mailbox_for(process_group)
+    else:
+        mb = mailbox
     for m in module.modules():
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
             m.sync = True
             m.sync_group = process_group
+            m.sync_mailbox = mb
     return module
+
+
+def sync_batchnorm_info(module):
+    """(transport, exchanges issued so far) of a converted module: 'mailbox' / 'allreduce' / None."""
+    for m in module.modules():
+        if getattr(m, 'sync', False):
+            mb = getattr(m, 'sync_mailbox', None)
+            if mb is not None:
+                return ('mailbox', mb.exchanges)
+            from .ops import SYNC_ALLREDUCES
+            return ('allreduce', SYNC_ALLREDUCES[0])
+    return (None, None)
 
 
 class GradientAverager(object):

@@ -53,14 +53,30 @@ class ConvCfg(object):
         return g
 
 
+SYNC_ALLREDUCES = [0]          # diagnostic: SyncBatchNorm all-reduce calls issued by the fallback transport
+
+
+class _Sync(tuple):
+    """(process group, world size, PeerMailbox or None) of a SyncBatchNorm call."""
+    group = property(lambda self: self[0])
+    world = property(lambda self: self[1])
+    mailbox = property(lambda self: self[2])
+
+
 def _sync_group(bn):
-    """(process group, world size) when `bn` was converted by tcvom_amd.ddp.convert_sync_batchnorm and more than one
-    rank is running, else None."""
-    if not getattr(bn, 'sync', False) or not dist.is_available() or not dist.is_initialized():
+    """_Sync when `bn` was converted by tcvom_amd.ddp.convert_sync_batchnorm and more than one rank is running (or the module
+    carries a one-rank loop-back mailbox: bench.py --sync-bn on one GPU, tests), else None.  With a mailbox the statistics are
+    exchanged inside the finalize kernels (tcvom_amd/mailbox.py); without one through an all-reduce of the process group."""
+    if not getattr(bn, 'sync', False):
+        return None
+    mb = getattr(bn, 'sync_mailbox', None)
+    if mb is not None and mb.group is None and mb.world == 1:
+        return _Sync((None, 1, mb))
+    if not dist.is_available() or not dist.is_initialized():
         return None
     group = getattr(bn, 'sync_group', None)
     world = dist.get_world_size(group)
-    return (group, world) if world > 1 else None
+    return _Sync((group, world, mb)) if world > 1 else None
 
 
 def _phase_array(descs):
@@ -180,11 +196,17 @@ class _ConvBNAct(torch.autograd.Function):
                 L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
                        L.ptr(gamma), L.ptr(beta), None, None,
                        float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
+            elif sync.mailbox is not None and sync.mailbox.fits(nf, K):
+                # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size), exchanged
+                # INSIDE the finalize kernel through the peer mailbox: same launches as the local path, no collective call
+                L.call('tcvom_bn_finalize_sync', L.ptr(stats), groups, K, P, P * cfg.unbias_mult, L.ptr(gamma), L.ptr(beta),
+                       float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, sync.mailbox.next(), st)
             else:
-                # SyncBatchNorm: statistics over the clips of ALL ranks (every rank holds the same crop size); the nf
-                # frames of a frame-batched call keep separate statistics and share ONE collective
+                # fallback (ranks on several nodes, TCVOM_SYNCBN=rccl): the nf frames of a frame-batched call keep separate
+                # statistics and share ONE all-reduce
                 sums = torch.empty(nf * 2 * K, dtype=torch.float64, device=x.device)
                 L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, K, L.ptr(sums), L.ptr(scratch), nf, st)
+                SYNC_ALLREDUCES[0] += 1
                 dist.all_reduce(sums, group=sync[0])
                 L.call('tcvom_bn_finalize_sums', L.ptr(sums), K, P, P * cfg.unbias_mult, L.ptr(gamma), L.ptr(beta),
                        float(bn.eps), ss, saved, nf, slot_stride, st)
@@ -253,11 +275,15 @@ class _ConvBNAct(torch.autograd.Function):
             elif sync is None:
                 L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
                        L.ptr(coef), L.ptr(scratch), 1, nf, stride, st)
+            elif sync.mailbox is not None and sync.mailbox.fits(nf, K):
+                L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, K, P * sync.world, L.ptr(gamma), saved, dgp, dbp,
+                       L.ptr(coef), L.ptr(scratch), 1, nf, stride, sync.mailbox.next(), st)
             else:
-                group, world = sync
+                group, world = sync.group, sync.world
                 local = torch.empty(nf * 2 * K, dtype=torch.float64, device=dz.device)
                 L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), nf, st)
                 total = local.clone()
+                SYNC_ALLREDUCES[0] += 1
                 dist.all_reduce(total, group=group)
                 L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
                        dgp, dbp, L.ptr(coef), 1, nf, stride, st)
@@ -336,9 +362,13 @@ class _DwBNAct(torch.autograd.Function):
             if sync is None:
                 L.call('tcvom_bn_finalize', L.ptr(stats), groups, Cc, P, P, L.ptr(gamma), L.ptr(beta), None, None,
                        float(bn.momentum), float(bn.eps), ss, saved, L.ptr(scratch), nf, slot_stride, st)
+            elif sync.mailbox is not None and sync.mailbox.fits(nf, Cc):
+                L.call('tcvom_bn_finalize_sync', L.ptr(stats), groups, Cc, Pg, Pg, L.ptr(gamma), L.ptr(beta), float(bn.eps), ss, saved,
+                       L.ptr(scratch), nf, slot_stride, sync.mailbox.next(), st)
             else:
                 sums = torch.empty(nf * 2 * Cc, dtype=torch.float64, device=x.device)
                 L.call('tcvom_bn_reduce_sums', L.ptr(stats), groups, Cc, L.ptr(sums), L.ptr(scratch), nf, st)
+                SYNC_ALLREDUCES[0] += 1
                 dist.all_reduce(sums, group=sync[0])
                 L.call('tcvom_bn_finalize_sums', L.ptr(sums), Cc, Pg, Pg, L.ptr(gamma), L.ptr(beta), float(bn.eps), ss, saved, nf,
                        slot_stride, st)
@@ -374,11 +404,15 @@ class _DwBNAct(torch.autograd.Function):
         if ctx.sync is None or not ctx.training:
             L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, Cc, P, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef), L.ptr(scratch),
                    1, nf, stride, st)
+        elif ctx.sync.mailbox is not None and ctx.sync.mailbox.fits(nf, Cc):
+            L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, Cc, P * ctx.sync.world, L.ptr(gamma), saved, dgp, dbp,
+                   L.ptr(coef), L.ptr(scratch), 1, nf, stride, ctx.sync.mailbox.next(), st)
         else:
-            group, world = ctx.sync
+            group, world = ctx.sync.group, ctx.sync.world
             local = torch.empty(nf * 2 * Cc, dtype=torch.float64, device=dz.device)
             L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, Cc, L.ptr(local), L.ptr(scratch), nf, st)
             total = local.clone()
+            SYNC_ALLREDUCES[0] += 1
             dist.all_reduce(total, group=group)
             L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), Cc, P * world, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef),
                    1, nf, stride, st)

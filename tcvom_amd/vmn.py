@@ -117,7 +117,8 @@ class VMN(nn.Module):
         # runs on its own HIP stream so that the small-grid os16/os32 kernels of different frames overlap; autograd
         # replays the same streams in backward.  Order-dependent state (BN running statistics) is applied afterwards.
         main = torch.cuda.current_stream()
-        if self.frame_streams:
+        # (SyncBatchNorm: the mailbox exchanges of a rank must run in ONE stream order -- tcvom_amd/mailbox.py)
+        if self.frame_streams and not any(getattr(m, 'sync', False) for m in self.modules()):
             if len(self._streams) < S:
                 object.__setattr__(self, '_streams', [torch.cuda.Stream() for _ in range(S)])
             for i in range(S):

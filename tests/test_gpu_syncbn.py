@@ -1,6 +1,8 @@
 """SyncBatchNorm statistic exchange (train_ddp.py:271-273): two ranks holding one clip each must produce what ONE
-process holding both clips produces.  Both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
-device); the kernels and the [2][C] fp64 all-reduce call sites are the ones the 8-GPU job runs."""
+process holding both clips produces.  Both ranks share cuda:0 (RCCL refuses two ranks on one device; the process group
+is gloo and only carries the hipIpc handles).  Two transports, both the code the 8-GPU job runs: 'mailbox' -- the sums
+travel through hipIpc-mapped peer mailboxes INSIDE the BatchNorm finalize kernels (tcvom_amd/mailbox.py, the default) --
+and 'rccl' -- one [frames][2][C] fp64 all-reduce per BatchNorm call (the fallback across nodes)."""
 import os
 import socket
 
@@ -53,8 +55,8 @@ def _run(cfg, bank, bn, w, x, dz):
             bn.running_mean.clone(), bn.running_var.clone())
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+def _worker(rank, world, port, out, transport):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TCVOM_SYNCBN=transport, TCVOM_MBOX_TIMEOUT_S='20')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         dev = torch.device('cuda:0')
@@ -65,7 +67,11 @@ def _worker(rank, world, port, out):
         xs = xs.to(torch.bfloat16)
         dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(torch.bfloat16)
         w, bn, bank, cfg = _block(dev, True, 'sync')
+        assert (bn.sync_mailbox is not None) == (transport == 'mailbox')
         got = _run(cfg, bank, bn, w, xs[rank:rank + 1].contiguous(), dzs[rank:rank + 1].contiguous())
+        if bn.sync_mailbox is not None:
+            assert bn.sync_mailbox.exchanges == 2 and bn.sync_mailbox.world == 2      # one exchange forward, one backward
+            bn.sync_mailbox.check()
         dg = got[2].clone(); db = got[3].clone()
         dist.all_reduce(dg); dist.all_reduce(db)
         if rank == 0:
@@ -82,19 +88,21 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sync_batchnorm_two_ranks_match_one_process_batch(tmp_path):
+@pytest.mark.parametrize('transport', ['mailbox', 'rccl'])
+def test_sync_batchnorm_two_ranks_match_one_process_batch(tmp_path, transport):
     out = str(tmp_path / 'res.pt')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, transport), nprocs=2, join=True)
     r = torch.load(out)
-    print(r)
-    assert r['z'] <= 2e-2 * r['zmax'], r          # one bf16 ulp of the output
-    assert r['dx'] <= 2e-2 * r['dxmax'], r
+    print(transport, r)
+    # the fp64 sums of the two ranks add up to the one-process sums to the last fp64 bits: the fp32 (mean, invstd) and with them
+    # the bf16 outputs and input gradients of the two-rank run EQUAL the batch-of-2 run
+    assert r['z'] == 0.0 and r['dx'] <= 1e-2 * r['dxmax'], r
     assert r['dg'] <= 2e-3 * r['dgmax'] and r['db'] <= 2e-3 * r['dbmax'], r
     assert r['rm'] <= 1e-5 and r['rv'] <= 1e-5, r
 
 
-def _window_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+def _window_worker(rank, world, port, out, transport):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TCVOM_SYNCBN=transport, TCVOM_MBOX_TIMEOUT_S='20')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         dev = torch.device('cuda:0')
@@ -118,6 +126,11 @@ def _window_worker(rank, world, port, out):
         train_step_loss(outs).backward()                   # the backward collectives pair up on the two ranks as well
         gnorm = torch.stack([p.grad.float().norm() for p in m.parameters() if p.grad is not None])
         assert bool(torch.isfinite(gnorm).all()) and float(gnorm.max()) > 0
+        from tcvom_amd.ddp import sync_batchnorm_info
+        kind, n = sync_batchnorm_info(m)
+        assert kind == ('mailbox' if transport == 'mailbox' else 'allreduce') and n > 100, (kind, n)
+        if kind == 'mailbox':
+            next(b for b in m.modules() if getattr(b, 'sync', False)).sync_mailbox.check()
         if rank == 0:
             m2 = make(False)
             a2, fg2, bg2 = [torch.cat([clips[0][k], clips[1][k]], 0) for k in range(3)]
@@ -129,9 +142,71 @@ def _window_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sync_batchnorm_window_forward(tmp_path):
+@pytest.mark.parametrize('transport', ['mailbox', 'rccl'])
+def test_sync_batchnorm_window_forward(tmp_path, transport):
     out = str(tmp_path / 'res.pt')
-    mp.spawn(_window_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_window_worker, args=(2, _free_port(), out, transport), nprocs=2, join=True)
     r = torch.load(out)
     print(r)
     assert r['mse'] <= 1e-4, r
+
+
+def test_sync_batchnorm_loopback_mailbox_equals_local_statistics():
+    """A one-rank mailbox (what `bench.py --gpus 1 --sync-bn` measures): the sums make the round trip through the uncached
+    mailbox memory inside the finalize kernels and come back unchanged -- outputs and gradients equal the plain BatchNorm's bit
+    for bit, over several calls (ring slots are reused from the 5th exchange on)."""
+    from tcvom_amd.ddp import convert_sync_batchnorm
+    from tcvom_amd.mailbox import PeerMailbox
+    from tcvom_amd.synthetic import formula_tensor
+    dev = torch.device('cuda:0')
+    xs = (formula_tensor('sync.x', (2, 24, 40, 64)) * 2).to(dev).to(torch.bfloat16)
+    dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(torch.bfloat16)
+    w, bn, bank, cfg = _block(dev, False, 'loop.sync')
+    mb = PeerMailbox(loopback=True, timeout_s=5)
+    convert_sync_batchnorm(bn, mailbox=mb)
+    w2, bn2, bank2, cfg2 = _block(dev, False, 'loop.local')
+    for it in range(6):
+        got = _run(cfg, bank, bn, w, xs, dzs)
+        ref = _run(cfg2, bank2, bn2, w2, xs, dzs)
+        for g, r in zip(got, ref):
+            assert torch.equal(g, r), it
+        bn.weight.grad = bn.bias.grad = bn2.weight.grad = bn2.bias.grad = None
+    assert mb.exchanges == 12
+    mb.check()
+    mb.close()
+
+
+def test_sync_batchnorm_mailbox_timeout_is_reported_not_hung():
+    """A peer that never arrives: the polling kernel gives up after the timeout, stores the exchange number into the pinned
+    status word and terminates; the host raises MailboxTimeout at the next check (no device hang)."""
+    import time
+    from tcvom_amd.ddp import convert_sync_batchnorm
+    from tcvom_amd.mailbox import MailboxTimeout, PeerMailbox
+    from tcvom_amd.synthetic import formula_tensor
+    dev = torch.device('cuda:0')
+    xs = (formula_tensor('sync.x', (1, 24, 40, 64)) * 2).to(dev).to(torch.bfloat16)
+    dzs = formula_tensor('sync.dz', (1, 24, 40, 128)).to(dev).to(torch.bfloat16)
+    w, bn, bank, cfg = _block(dev, False, 'timeout')
+    # pretend to be rank 0 of 2 whose peer is silent: both table entries point at the own mailbox (sized for one sender: the
+    # second sender region is ring slot memory nobody writes with this tag)
+    mb2 = PeerMailbox(loopback=True, timeout_s=0.25, capacity=4096)
+    mb2._sync.world = 2
+    mb2.world = 2
+    mb2._sync.capacity = 1024                       # [ring 4][2 senders][1024] fits the 4 x 1 x 4096 allocation
+    mb2.capacity = 1024
+    mb2.table = torch.tensor([mb2._ptr.value, mb2._ptr.value], dtype=torch.int64, device=dev)
+    mb2._sync.peers = mb2.table.data_ptr()
+    convert_sync_batchnorm(bn, mailbox=mb2)
+    bn.sync_group = None
+    import tcvom_amd.ops as ops
+    real = ops._sync_group
+    ops._sync_group = lambda b: ops._Sync((None, 2, b.sync_mailbox)) if getattr(b, 'sync', False) else None
+    try:
+        t0 = time.time()
+        _run(cfg, bank, bn, w, xs, dzs)
+        assert time.time() - t0 < 10.0
+        with pytest.raises(MailboxTimeout):
+            mb2.check()
+    finally:
+        ops._sync_group = real
+        mb2.close()
