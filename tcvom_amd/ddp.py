@@ -90,24 +90,35 @@ class GradientAverager(object):
         self._early_ok = True
         # the parameters whose gradients ARE the bank's flat buffer (assigned by autograd after the bank's backward returns;
         # other leaves -- BatchNorm scales, biases -- legitimately have their .grad by then)
-        self._bank_params = [p for bank in banks for p in bank.weight_params()]
+        self._bank_params = {id(bank): bank.weight_params() for bank in banks}
         self.early_spans = 0     # diagnostic: spans started before backward returned, last step
         if self._active():       # (a one-process run keeps the bank's single-launch backward)
+            import functools
             for bank in banks:
-                bank.grad_span_hook = self._on_span
+                bank.grad_span_hook = functools.partial(self._on_span, id(bank))
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
 
-    def _on_span(self, flat, lo, hi):
-        """WeightBank.backward finished flat[lo:hi] (fp32, final values of this step).  Only valid when no parameter still holds
-        an older .grad that autograd would ADD these values to after the all-reduce of the new ones has started
-        (zero_grad(set_to_none=True) each step, as bench.py / train_ddp.py do): checked at the first span of a backward,
-        otherwise the spans are left to average()."""
+    def _on_span(self, bank_id, flat, lo, hi):
+        """WeightBank.backward finished flat[lo:hi] (fp32, final values of this step).  Only valid when no parameter of that bank
+        still holds an older .grad that autograd would ADD these values to after the all-reduce of the new ones has started
+        (zero_grad(set_to_none=True) each step, as bench.py / train_ddp.py do).  Checked at the FIRST span of every bank backward
+        (lo == 0): a second backward before average() (gradient accumulation) finds the .grad of the first and then (a) starts
+        nothing early and (b) waits for the spans the first backward started and forgets them -- autograd is about to accumulate
+        into those buffers, and average() reduces the sums again (an all-reduce(mean) of already averaged values is the identity,
+        so the first backward's share stays correct)."""
         if not self._active() or hi <= lo:
             return
-        if not self._early:
-            self._early_ok = all(p.grad is None for p in self._bank_params)
+        if lo == 0:
+            ok = all(p.grad is None for p in self._bank_params.get(bank_id, ()))
+            if not ok and self._early:
+                for e in self._early:
+                    e[1].wait()
+                    if dist.get_backend() != 'nccl':           # (gloo sums; RCCL's ReduceOp.AVG already divided)
+                        e[0].div_(dist.get_world_size())
+                self._early = []
+            self._early_ok = ok
         if not self._early_ok:
             return
         avg = dist.get_backend() == 'nccl'

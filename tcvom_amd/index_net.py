@@ -119,6 +119,41 @@ class _ASPPModule(nn.Module):
                                              nn.Conv2d(inp, planes, 1, 1, 0, bias=False), nn.BatchNorm2d(planes), nn.ReLU6(inplace=True))
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """Sum over the ranks of a process group, differentiable: every rank's loss depends on the total, so the gradient with
+    respect to a rank's addend is the sum of the ranks' gradients with respect to the total (nn.SyncBatchNorm's backward
+    all-reduce of sum_dy / sum_dy_xmu, written once for any statistic)."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        ctx.group = group
+        out = t.clone()
+        torch.distributed.all_reduce(out, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        torch.distributed.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+def _sync_batchnorm_expr(xf, bn, sync):
+    """Train-mode SyncBatchNorm of xf [nf, count, C] (fp32; normalised over dim 1 of ALL ranks; the nf frames are separate
+    calls) as tensor expressions -- the two tiny BatchNorms of IndexNet that do not run through the bank's kernels
+    (train_ddp.py:271-273 converts every BatchNorm).  Returns (normalised xf, mean [nf, C], biased var [nf, C], global count)."""
+    nf, cnt, Cc = xf.shape
+    x64 = xf.double()
+    sums = torch.stack([x64.sum(1), (x64 * x64).sum(1)], 1)            # [nf, 2, C]
+    total = _AllReduceSum.apply(sums, sync.group)
+    n = cnt * sync.world
+    mean = total[:, 0] / n
+    var = (total[:, 1] / n - mean * mean).clamp_min(0.0)
+    out = (x64 - mean.unsqueeze(1)) * torch.rsqrt(var.unsqueeze(1) + bn.eps)
+    return out.float(), mean.detach().float(), var.detach().float(), n
+
+
+
 class ASPP(nn.Module):
     """hlaspp.py:87-142, output_stride 32."""
 
@@ -152,18 +187,24 @@ class ASPP(nn.Module):
         g = x.float().mean((1, 2)) @ conv.weight.reshape(conv.weight.shape[0], Cc).t()          # [N, 256]
         if training:
             B = N // nf
-            if B < 2:
+            sync = ops._sync_group(bn)
+            Bg = B * (sync.world if sync is not None else 1)           # SyncBatchNorm: the clips of all ranks
+            if Bg < 2:
                 raise ValueError('Expected more than 1 value per channel when training (the ASPP image-pooling BatchNorm sees '
                                  '[B, 256, 1, 1]: vmn_index needs at least 2 clips per step in train mode, as in the reference)')
             gf = g.reshape(nf, B, -1)
-            mean = gf.mean(1, keepdim=True)
-            var = gf.var(1, unbiased=False, keepdim=True)
-            out = ((gf - mean) / torch.sqrt(var + bn.eps)).reshape(N, -1)
+            if sync is not None:
+                out, mean, var, _ = _sync_batchnorm_expr(gf, bn, sync)
+                out, mean, var = out.reshape(N, -1), mean.unsqueeze(1), var.unsqueeze(1)
+            else:
+                mean = gf.mean(1, keepdim=True)
+                var = gf.var(1, unbiased=False, keepdim=True)
+                out = ((gf - mean) / torch.sqrt(var + bn.eps)).reshape(N, -1)
             with torch.no_grad():
                 m = 0.1 if bn.momentum is None else bn.momentum
                 for f in range(nf):                                   # running statistics: one EMA step per call, in call order
                     bn.running_mean.mul_(1 - m).add_(m * mean[f, 0])
-                    bn.running_var.mul_(1 - m).add_(m * var[f, 0] * (B / (B - 1.0)))
+                    bn.running_var.mul_(1 - m).add_(m * var[f, 0] * (Bg / (Bg - 1.0)))
                 bn.num_batches_tracked += nf
         else:
             out = (g - bn.running_mean) / torch.sqrt(bn.running_var + bn.eps)
@@ -292,11 +333,16 @@ class IndexMattingDecoder_VMN(nn.Module):
         # workgroup); the frames of a frame-batched call are separate BatchNorm calls
         if training:
             pf = p.reshape(nf, -1)
-            var, mean = torch.var_mean(pf, dim=1, unbiased=False, keepdim=True)
-            p = ((pf - mean) * torch.rsqrt(var + bn.eps)).reshape(p.shape)
+            sync = ops._sync_group(bn)
+            cnt = pf.shape[1]
+            if sync is not None:
+                pn, mean, var, cnt = _sync_batchnorm_expr(pf.unsqueeze(2), bn, sync)
+                p = pn.reshape(p.shape)
+            else:
+                var, mean = torch.var_mean(pf, dim=1, unbiased=False, keepdim=True)
+                p = ((pf - mean) * torch.rsqrt(var + bn.eps)).reshape(p.shape)
             with torch.no_grad():
                 m = 0.1 if bn.momentum is None else bn.momentum
-                cnt = pf.shape[1]
                 for f in range(nf):                                    # running statistics: one EMA step per call, in call order
                     bn.running_mean.mul_(1 - m).add_(m * mean[f])
                     bn.running_var.mul_(1 - m).add_(m * var[f] * (cnt / (cnt - 1.0)))

@@ -74,8 +74,12 @@ class FusedAdam(torch.optim.Optimizer):
                 st['step'] = int(st['step']) + 1
                 by_step.setdefault(st['step'], []).append(p)
             b1, b2 = group['betas']
+            if len(self._tables) > 64:                      # step groups come and go: no unbounded cache of pointer tables
+                self._tables = {k: v for k, v in self._tables.items() if k[0] == 'work'}
             for step, ps in by_step.items():
-                _, table, work, nblk = self._table((gi, len(by_step) > 1 and step), ps)
+                # several step groups: keyed by the parameter set (stable from step to step), not by the step count
+                key = (gi, False) if len(by_step) == 1 else (gi, tuple(id(p) for p in ps))
+                _, table, work, nblk = self._table(key, ps)
                 L.call('tcvom_adam_mt', L.ptr(table), L.ptr(work), nblk, float(group['lr']), float(b1), float(b2),
                        float(group['eps']), float(group['weight_decay']), int(step), float(grad_scale), L.stream_ptr())
         return loss

@@ -564,7 +564,11 @@ class WeightBank(object):
             if hook is not None:
                 hook(grad, g0, g1)
         self.run_deferred_wgrads()                     # (nothing left unless a layer id fell outside the ranges)
-        return [grad[s.grad_off:s.grad_off + s.numel].view(s.weight.shape) for s in self.specs]
+        # a frozen backbone (VMN freeze_backbone: the 'frame' group runs under no_grad) gets NO gradient, as in the reference --
+        # not zeros: Adam folds weight_decay * p into the gradient and would move the "frozen" weights (holes in the flat
+        # buffer; GradientAverager reduces across them)
+        frozen = self.frozen_groups
+        return [None if s.group in frozen else grad[s.grad_off:s.grad_off + s.numel].view(s.weight.shape) for s in self.specs]
 
 
 class _BankToken(torch.autograd.Function):

@@ -439,6 +439,9 @@ def test_bench_two_ranks_dry_run():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['global_batch_clips'] == 2 and res['value'] > 0 and res['scaling'] == 'weak'
     assert res['dist']['world_size'] == 2 and res['dist']['grad_spans_overlapped_with_backward'] >= 3, res['dist']
+    # N > 1 runs train_ddp.py's semantics: SyncBatchNorm, exchanged through the peer mailboxes (72 BatchNorms forward + backward)
+    assert res['config']['sync_bn'] is True and res['dist']['sync_bn_transport'] == 'mailbox', res['dist']
+    assert res['dist']['sync_bn_exchanges_per_step'] == 144, res['dist']
     assert np.isfinite(res['final_loss'])
 
 

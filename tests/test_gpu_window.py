@@ -220,9 +220,22 @@ def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
     front = lambda k: k.startswith('encoder.') or k.startswith(('decoder.layer1.', 'decoder.layer2.', 'decoder.gca.'))
     for k, p in m.NET.named_parameters():
         if front(k):
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, 'frozen parameter %s has a gradient' % k
+            assert p.grad is None, 'frozen parameter %s has a gradient (the reference leaves it None: Adam skips it)' % k
         elif p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    # an optimizer step with weight decay (train_ddp.py:296-297: Adam(weight_decay=1e-4)) must not move the frozen backbone
+    from tcvom_amd.optim import FusedAdam
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=1e-1)
+    opt.step()
+    torch.cuda.synchronize()
+    moved = 0
+    for k, p in m.NET.named_parameters():
+        if front(k):
+            assert torch.equal(p.detach(), before[k]), 'frozen parameter %s moved in optimizer.step()' % k
+        elif p.requires_grad:
+            moved += int(not torch.equal(p.detach(), before[k]))
+    assert moved > 0
+    m.NET.load_state_dict(before)
     changed_tail = 0
     for k in before:
         if front(k):
