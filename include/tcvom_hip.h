@@ -33,6 +33,9 @@ extern "C" {
 
 const char* tcvom_last_error(void);
 int tcvom_abi_version(void);
+/* The 16-bit storage type of this build: 0 = bf16 (libtcvom_hip.so), 1 = IEEE fp16 (libtcvom_hip_f16.so; same sources, same
+ * ABI).  Wherever this header says "bf16" for an activation or a packed weight, read "the build's 16-bit type". */
+int tcvom_act_dtype(void);
 
 /* ------------------------------------------------------------------ implicit-GEMM convolution
  * One "phase" of a (possibly transposed) convolution on bf16 MFMA:

@@ -8,7 +8,18 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('TCVOM_LIB') or os.path.join(_HERE, 'lib', 'libtcvom_hip.so')      # TCVOM_LIB: a study build of the same library (kernel ablations)
+# The 16-bit storage type of activations and packed weights: one build of the library per type, same ABI (csrc/common.h).
+#   TCVOM_DTYPE=fp16  libtcvom_hip_f16.so  IEEE fp16: 3 more mantissa bits than bf16 at the same MFMA rate -- the alpha-matte error of
+#                     16-bit storage falls ~35x (tests/test_bf16_noise_floor.py), the doubled-tap high-precision stem is not needed;
+#                     the backward runs under an internal loss scale (ops.LOSS_SCALE).  BASELINE config 5 names this dtype.
+#   TCVOM_DTYPE=bf16  libtcvom_hip.so      bf16: fp32's exponent range, no loss scale.
+DTYPE_NAME = os.environ.get('TCVOM_DTYPE', 'bf16').lower()
+if DTYPE_NAME in ('f16', 'half', 'float16'):
+    DTYPE_NAME = 'fp16'
+if DTYPE_NAME not in ('bf16', 'fp16'):
+    raise ImportError('TCVOM_DTYPE must be bf16 or fp16, got %r' % DTYPE_NAME)
+_DEFAULT_LIB = os.path.join(_HERE, 'lib', 'libtcvom_hip_f16.so' if DTYPE_NAME == 'fp16' else 'libtcvom_hip.so')
+LIB_PATH = os.environ.get('TCVOM_LIB') or _DEFAULT_LIB      # TCVOM_LIB: a study build of the same library (kernel ablations)
 if os.environ.get('TCVOM_HIP_LIB'):          # kernel A/B work: load an alternative build of the same ABI
     LIB_PATH = os.environ['TCVOM_HIP_LIB']
 
@@ -162,6 +173,7 @@ _PROTOS = {
     'tcvom_loss_finalize': [vp, vp, f32, i32, f32, i32, i32, vp],
     'tcvom_adam_mt': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp],
     'tcvom_abi_version': [],
+    'tcvom_act_dtype': [],
     'tcvom_conv_trace_read': [vp, i32],
     'tcvom_gca_dp_softmax_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
@@ -179,7 +191,7 @@ _PROTOS = {
     'tcvom_wgrad_ws_max_problems': [],
 }
 # entry points that return a count, not a status
-_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_bn_finalize_scratch_doubles',
+_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
           'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups'}
 
 # entry points that return a string
@@ -210,6 +222,17 @@ def _bind():
 
 
 _FNS = _bind()
+
+
+def _act_dtype():
+    import torch
+    kind = _FNS['tcvom_act_dtype']()
+    if kind != (1 if DTYPE_NAME == 'fp16' else 0):
+        raise ImportError('tcvom_amd: %s stores %s but TCVOM_DTYPE=%s was asked for' % (LIB_PATH, 'fp16' if kind else 'bf16', DTYPE_NAME))
+    return torch.float16 if kind else torch.bfloat16
+
+
+ACT_DTYPE = _act_dtype()         # torch dtype of every activation / packed-weight tensor handed to the library
 
 
 def last_error():

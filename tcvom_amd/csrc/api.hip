@@ -14,3 +14,11 @@ int tcvom_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* tcvom_last_error(void) { return g_tcvom_err; }
 extern "C" int tcvom_abi_version(void) { return 1; }
+// the 16-bit storage type this build computes in: 0 = bf16 (libtcvom_hip.so), 1 = IEEE fp16 (libtcvom_hip_f16.so)
+extern "C" int tcvom_act_dtype(void) {
+#ifdef TCVOM_F16
+    return 1;
+#else
+    return 0;
+#endif
+}

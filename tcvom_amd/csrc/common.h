@@ -5,9 +5,24 @@
 #include <stdio.h>
 #include "../../include/tcvom_hip.h"
 
-typedef unsigned short bf16raw;  // bf16 bit pattern
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// ---- the 16-bit storage type of activations and packed weights ("h16" below)
+// One library per type, same ABI: libtcvom_hip.so stores bf16 (8 exponent / 7 mantissa bits), libtcvom_hip_f16.so (built with
+// -DTCVOM_F16) stores IEEE fp16 (5 / 10).  Same MFMA rate (v_mfma_f32_32x32x16_{bf16,f16}), same bytes; fp32 accumulation,
+// statistics, softmax and losses in both.  fp16's three extra mantissa bits lower the storage-rounding floor of the alpha matte
+// ~35x (tests/test_bf16_noise_floor.py); its narrow exponent is why the fp16 build runs the backward under a loss scale
+// (tcvom_amd/ops.py: LOSS_SCALE).  tcvom_act_dtype() tells the caller which one it loaded.
+typedef unsigned short h16raw;  // bit pattern of one stored element
+#ifdef TCVOM_F16
+typedef _Float16 act_t;
+#define mfma16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define dot2_h16 __builtin_amdgcn_fdot2
+#else
+typedef __bf16 act_t;
+#define mfma16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define dot2_h16 __builtin_amdgcn_fdot2_f32_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) act_t h16x8_t;
+typedef __attribute__((ext_vector_type(2))) act_t h16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -20,26 +35,42 @@ int tcvom_fail(int code, const char* fmt, ...);
     do { hipError_t e_ = hipGetLastError(); \
          if (e_ != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); } while (0)
 
-// ---- bf16 <-> f32 ----
-__device__ __forceinline__ float bf2f(bf16raw h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ unsigned pack2bf(float a, float b) {
-    bf16x2_t v = {(__bf16)a, (__bf16)b};           // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950
+// ---- h16 <-> f32 ----
+#ifdef TCVOM_F16
+__device__ __forceinline__ float h2f(h16raw h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float hlo(unsigned u) { return (float)__builtin_bit_cast(h16x2_t, u).x; }
+__device__ __forceinline__ float hhi(unsigned u) { return (float)__builtin_bit_cast(h16x2_t, u).y; }
+// RNE with saturation to the largest finite value (65504): an overflow must not turn into inf / NaN downstream
+__device__ __forceinline__ float h16_clamp(float a) { return __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); }      // one v_med3_f32
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+    h16x2_t v = {(act_t)h16_clamp(a), (act_t)h16_clamp(b)};
     return __builtin_bit_cast(unsigned, v);
 }
-__device__ __forceinline__ bf16raw f2bf(float a) {
-    __bf16 v = (__bf16)a;
-    return __builtin_bit_cast(bf16raw, v);
+__device__ __forceinline__ h16raw f2h(float a) {
+    act_t v = (act_t)h16_clamp(a);
+    return __builtin_bit_cast(h16raw, v);
 }
+#else
+__device__ __forceinline__ float h2f(h16raw h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float hlo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+    h16x2_t v = {(act_t)a, (act_t)b};           // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ h16raw f2h(float a) {
+    act_t v = (act_t)a;
+    return __builtin_bit_cast(h16raw, v);
+}
+#endif
 __device__ __forceinline__ void unpack8(const uint4& q, float* f) {
-    f[0] = bflo(q.x); f[1] = bfhi(q.x); f[2] = bflo(q.y); f[3] = bfhi(q.y);
-    f[4] = bflo(q.z); f[5] = bfhi(q.z); f[6] = bflo(q.w); f[7] = bfhi(q.w);
+    f[0] = hlo(q.x); f[1] = hhi(q.x); f[2] = hlo(q.y); f[3] = hhi(q.y);
+    f[4] = hlo(q.z); f[5] = hhi(q.z); f[6] = hlo(q.w); f[7] = hhi(q.w);
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
     uint4 q;
-    q.x = pack2bf(f[0], f[1]); q.y = pack2bf(f[2], f[3]);
-    q.z = pack2bf(f[4], f[5]); q.w = pack2bf(f[6], f[7]);
+    q.x = pack2h(f[0], f[1]); q.y = pack2h(f[2], f[3]);
+    q.z = pack2h(f[4], f[5]); q.w = pack2h(f[6], f[7]);
     return q;
 }
 
@@ -73,17 +104,17 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // that it cannot be scheduled above the wait).
 typedef __attribute__((ext_vector_type(2))) unsigned int tr_u32x2_t;
 struct TrFrag { tr_u32x2_t lo, hi; };
-__device__ __forceinline__ void tr_issue(TrFrag& f, const bf16raw* p_lo, const bf16raw* p_hi) {
+__device__ __forceinline__ void tr_issue(TrFrag& f, const h16raw* p_lo, const h16raw* p_hi) {
     typedef __attribute__((address_space(3))) const void* lp_t;
     const unsigned a_lo = (unsigned)(uintptr_t)(lp_t)p_lo, a_hi = (unsigned)(uintptr_t)(lp_t)p_hi;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a_lo));
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a_hi));
 }
 __device__ __forceinline__ void tr_fence(TrFrag& f) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }
-__device__ __forceinline__ bf16x8_t tr_value(const TrFrag& f) {
+__device__ __forceinline__ h16x8_t tr_value(const TrFrag& f) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     const u32x4_t v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3);
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
 // the same with the k-step / row displacement as an immediate: lo at addr + OFF, hi (k rows + 4) at addr + OFF + HI bytes
 template <int OFF, int HI>

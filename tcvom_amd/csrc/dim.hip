@@ -128,7 +128,7 @@ __global__ void unfold_kernel(const uint4* __restrict__ x, uint4* __restrict__ u
         u[v] = val;
     }
 }
-__global__ void fold_kernel(const bf16raw* __restrict__ du, bf16raw* __restrict__ dx, int64_t n, int H, int W, int C, int KS) {
+__global__ void fold_kernel(const h16raw* __restrict__ du, h16raw* __restrict__ dx, int64_t n, int H, int W, int C, int KS) {
     const int T = KS * KS, R = KS / 2;
     GRID_STRIDE(v, n) {
         const int c = (int)(v % C);
@@ -139,9 +139,9 @@ __global__ void fold_kernel(const bf16raw* __restrict__ du, bf16raw* __restrict_
             const int ph = yh - (t / KS - R), pw = xw - (t % KS - R);
             if (ph < 0 || ph >= H || pw < 0 || pw >= W) continue;
             const int64_t p = q - (int64_t)(t / KS - R) * W - (t % KS - R);
-            acc += bf2f(du[p * ((int64_t)C * T) + (int64_t)c * T + t]);
+            acc += h2f(du[p * ((int64_t)C * T) + (int64_t)c * T + t]);
         }
-        dx[v] = f2bf(acc);
+        dx[v] = f2h(acc);
     }
 }
 
@@ -296,7 +296,7 @@ extern "C" int tcvom_unfold(const void* x, void* u, int32_t N, int32_t H, int32_
 extern "C" int tcvom_fold(const void* du, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t ksize, void* stream) {
     TCVOM_CHECK_ARG(du && dx && N > 0 && H > 0 && W > 0 && C > 0 && ksize % 2 == 1, "fold: bad args");
     const int64_t n = (int64_t)N * H * W * C;
-    hipLaunchKernelGGL(fold_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)du, (bf16raw*)dx, n, H, W, C, ksize);
+    hipLaunchKernelGGL(fold_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const h16raw*)du, (h16raw*)dx, n, H, W, C, ksize);
     TCVOM_LAUNCH_CHECK("fold");
     return TCVOM_OK;
 }

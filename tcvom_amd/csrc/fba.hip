@@ -195,7 +195,7 @@ __device__ __forceinline__ float lerp_weight(int d, int i, float scale, int n_in
 }
 
 // src [N][hs][ws][ld_src] (channels c_src..+C) -> dst [N][hd][wd][ld_dst] (channels c_dst..+C)
-__global__ void bilinear_kernel(const bf16raw* __restrict__ src, bf16raw* __restrict__ dst, int64_t n, int hs, int ws, int hd, int wd,
+__global__ void bilinear_kernel(const h16raw* __restrict__ src, h16raw* __restrict__ dst, int64_t n, int hs, int ws, int hd, int wd,
                                 int C8, int ld_src, int c_src, int ld_dst, int c_dst, float sh, float sw) {
     GRID_STRIDE(v, n) {
         const int c8 = (int)(v % C8);
@@ -204,7 +204,7 @@ __global__ void bilinear_kernel(const bf16raw* __restrict__ src, bf16raw* __rest
         const int Y = (int)(t % hd);
         const int64_t nb = t / hd;
         const Lerp ly = lerp_of(Y, sh, hs), lx = lerp_of(X, sw, ws);
-        const bf16raw* sb = src + nb * hs * ws * ld_src + c_src + c8 * 8;
+        const h16raw* sb = src + nb * hs * ws * ld_src + c_src + c8 * 8;
         float a[8], b[8], c[8], d[8], o[8];
         unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i0 * ws + lx.i0) * ld_src), a);
         unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i0 * ws + lx.i1) * ld_src), b);
@@ -218,7 +218,7 @@ __global__ void bilinear_kernel(const bf16raw* __restrict__ src, bf16raw* __rest
 }
 // gather form of the x2 backward: source pixel (i, j) collects from destination rows 2i-2 .. 2i+2 (weights from lerp_weight,
 // which reproduces the border clamping of the forward)
-__global__ void bilinear_up2_bwd_kernel(const bf16raw* __restrict__ ddst, bf16raw* __restrict__ dsrc, int64_t n, int hs, int ws, int C8,
+__global__ void bilinear_up2_bwd_kernel(const h16raw* __restrict__ ddst, h16raw* __restrict__ dsrc, int64_t n, int hs, int ws, int C8,
                                         int ld_dst, int c_dst) {
     const int hd = 2 * hs, wd = 2 * ws;
     GRID_STRIDE(v, n) {
@@ -247,7 +247,7 @@ __global__ void bilinear_up2_bwd_kernel(const bf16raw* __restrict__ ddst, bf16ra
 }
 // backward onto a SMALL source (the s x s pyramid-pooling maps): grid (N*hs*ws, row splits); a block walks the destination
 // rows that touch its source pixel and adds its partial sum to dsrc (fp32 [N][hs][ws][C], zeroed)
-__global__ __launch_bounds__(256) void bilinear_small_bwd_kernel(const bf16raw* __restrict__ ddst, float* __restrict__ dsrc, int hs, int ws,
+__global__ __launch_bounds__(256) void bilinear_small_bwd_kernel(const h16raw* __restrict__ ddst, float* __restrict__ dsrc, int hs, int ws,
                                                                  int hd, int wd, int C8, int ld_dst, int c_dst, float sh, float sw) {
     const int sp = blockIdx.x % (hs * ws), nb = blockIdx.x / (hs * ws);
     const int i = sp / ws, j = sp % ws;
@@ -281,7 +281,7 @@ extern "C" int tcvom_bilinear(const void* src, void* dst, int32_t N, int32_t hs,
     TCVOM_CHECK_ARG(src && dst && N > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0 && C % 8 == 0, "bilinear: bad args");
     TCVOM_CHECK_ARG(ld_src % 8 == 0 && c_src % 8 == 0 && ld_dst % 8 == 0 && c_dst % 8 == 0 && c_src + C <= ld_src && c_dst + C <= ld_dst, "bilinear: bad channel slices");
     const int64_t n = (int64_t)N * hd * wd * (C / 8);
-    hipLaunchKernelGGL(bilinear_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)src, (bf16raw*)dst, n, hs, ws, hd, wd,
+    hipLaunchKernelGGL(bilinear_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const h16raw*)src, (h16raw*)dst, n, hs, ws, hd, wd,
                        C / 8, ld_src, c_src, ld_dst, c_dst, (float)hs / (float)hd, (float)ws / (float)wd);
     TCVOM_LAUNCH_CHECK("bilinear");
     return TCVOM_OK;
@@ -290,7 +290,7 @@ extern "C" int tcvom_bilinear_up2_bwd(const void* ddst, void* dsrc, int32_t N, i
                                       void* stream) {
     TCVOM_CHECK_ARG(ddst && dsrc && N > 0 && hs > 0 && ws > 0 && C % 8 == 0 && ld_dst % 8 == 0 && c_dst % 8 == 0 && c_dst + C <= ld_dst, "bilinear_up2_bwd: bad args");
     const int64_t n = (int64_t)N * hs * ws * (C / 8);
-    hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)ddst, (bf16raw*)dsrc, n, hs, ws,
+    hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const h16raw*)ddst, (h16raw*)dsrc, n, hs, ws,
                        C / 8, ld_dst, c_dst);
     TCVOM_LAUNCH_CHECK("bilinear_up2_bwd");
     return TCVOM_OK;
@@ -305,7 +305,7 @@ extern "C" int tcvom_bilinear_small_bwd(const void* ddst, float* dsrc, int32_t N
     int split = (int)((npix * (C / 8) + 256 * 64 - 1) / (256 * 64));
     if (split > 64) split = 64;
     if (split < 1) split = 1;
-    hipLaunchKernelGGL(bilinear_small_bwd_kernel, dim3(N * hs * ws, split), dim3(256), 0, st, (const bf16raw*)ddst, dsrc, hs, ws, hd, wd, C / 8,
+    hipLaunchKernelGGL(bilinear_small_bwd_kernel, dim3(N * hs * ws, split), dim3(256), 0, st, (const h16raw*)ddst, dsrc, hs, ws, hd, wd, C / 8,
                        ld_dst, c_dst, (float)hs / (float)hd, (float)ws / (float)wd);
     TCVOM_LAUNCH_CHECK("bilinear_small_bwd");
     return TCVOM_OK;
@@ -498,7 +498,7 @@ __global__ void edt_columns_kernel(const float* __restrict__ gts, const uint8_t*
 }
 // pass 2: one block per (frame, class, row): d2[x] = min_x' (x - x')^2 + g2[x'], then the three click maps, written into the
 // space-to-depth network input x2 [frames][H/2][W/2][64] (channel 16 * (2 (h&1) + (w&1)) + 3 + 3 k + sigma) and, optionally, tris
-__global__ __launch_bounds__(256) void edt_rows_kernel(const float* __restrict__ g2, bf16raw* __restrict__ x2, float* __restrict__ tris, int H, int W) {
+__global__ __launch_bounds__(256) void edt_rows_kernel(const float* __restrict__ g2, h16raw* __restrict__ x2, float* __restrict__ tris, int H, int W) {
     extern __shared__ float row[];
     const int h = blockIdx.x % H, k = (blockIdx.x / H) % 2;
     const int64_t f = blockIdx.x / (2 * H);
@@ -515,19 +515,19 @@ __global__ __launch_bounds__(256) void edt_rows_kernel(const float* __restrict__
             if (x + d < W) best = fminf(best, dd + row[x + d]);
         }
         const int sub = (h & 1) * 2 + (x & 1);
-        bf16raw* o = x2 + (((f * (H / 2) + h / 2) * (W / 2) + x / 2) * 64) + sub * 16 + 3 + 3 * k;
+        h16raw* o = x2 + (((f * (H / 2) + h / 2) * (W / 2) + x / 2) * 64) + sub * 16 + 3 + 3 * k;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const float sg = (s == 0 ? 0.02f : (s == 1 ? 0.08f : 0.16f)) * 320.f;
             const float c = best < EDT_INF ? __expf(-best / (2.f * sg * sg)) : 0.f;
-            o[s] = f2bf(c);
+            o[s] = f2h(c);
             if (tris) tris[((f * 8 + 3 * k + s) * H + h) * W + x] = c;
         }
     }
 }
 // pass 3: image and indicator channels.  x2 channels 0..2 (normalised RGB), 9 (bg), 10 (fg) of every sub-pixel; extras
 // [frames][H][W][8] = (normalised RGB, RGB, bg, fg) for the last decoder stage; imgs fp32 [frames][3][H][W] (scaled RGB)
-__global__ void fba_input_kernel(const float* __restrict__ gts, const uint8_t* __restrict__ dil, const float* __restrict__ imgs, bf16raw* __restrict__ x2,
+__global__ void fba_input_kernel(const float* __restrict__ gts, const uint8_t* __restrict__ dil, const float* __restrict__ imgs, h16raw* __restrict__ x2,
                                  uint4* __restrict__ extras, float* __restrict__ tris, int64_t n, int H, int W, float eps) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
     GRID_STRIDE(v, n) {
@@ -545,9 +545,9 @@ __global__ void fba_input_kernel(const float* __restrict__ gts, const uint8_t* _
         e[6] = cls == 0 ? 1.f : 0.f;
         e[7] = cls == 1 ? 1.f : 0.f;
         extras[v] = pack8(e);
-        bf16raw* o = x2 + (((f * (H / 2) + h / 2) * (W / 2) + w / 2) * 64) + ((h & 1) * 2 + (w & 1)) * 16;
-        o[0] = f2bf(e[0]); o[1] = f2bf(e[1]); o[2] = f2bf(e[2]);
-        o[9] = f2bf(e[6]); o[10] = f2bf(e[7]);
+        h16raw* o = x2 + (((f * (H / 2) + h / 2) * (W / 2) + w / 2) * 64) + ((h & 1) * 2 + (w & 1)) * 16;
+        o[0] = f2h(e[0]); o[1] = f2h(e[1]); o[2] = f2h(e[2]);
+        o[9] = f2h(e[6]); o[10] = f2h(e[7]);
         if (tris) {
             tris[((f * 8 + 6) * H + h) * W + w] = e[6];
             tris[((f * 8 + 7) * H + h) * W + w] = e[7];
@@ -559,12 +559,12 @@ extern "C" int tcvom_fba_input(const float* gts, const uint8_t* unk_dil, const f
                                float* edt_scratch, int64_t frames, int32_t H, int32_t W, float eps, void* stream) {
     TCVOM_CHECK_ARG(gts && imgs && x2 && extras && edt_scratch && frames > 0 && H % 2 == 0 && W % 2 == 0 && W <= 8192, "fba_input: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(x2, 0, sizeof(bf16raw) * (size_t)frames * (H / 2) * (W / 2) * 64, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "fba_input: memset failed");
+    if (hipMemsetAsync(x2, 0, sizeof(h16raw) * (size_t)frames * (H / 2) * (W / 2) * 64, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "fba_input: memset failed");
     const int64_t ncol = frames * 2 * W;
     hipLaunchKernelGGL(edt_columns_kernel, dim3(dgrid(ncol)), dim3(256), 0, st, gts, unk_dil, edt_scratch, ncol, H, W, eps);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)(frames * 2 * H)), dim3(256), sizeof(float) * W, st, edt_scratch, (bf16raw*)x2, tris, H, W);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((unsigned)(frames * 2 * H)), dim3(256), sizeof(float) * W, st, edt_scratch, (h16raw*)x2, tris, H, W);
     const int64_t n = frames * (int64_t)H * W;
-    hipLaunchKernelGGL(fba_input_kernel, dim3(dgrid(n)), dim3(256), 0, st, gts, unk_dil, imgs, (bf16raw*)x2, (uint4*)extras, tris, n, H, W, eps);
+    hipLaunchKernelGGL(fba_input_kernel, dim3(dgrid(n)), dim3(256), 0, st, gts, unk_dil, imgs, (h16raw*)x2, (uint4*)extras, tris, n, H, W, eps);
     TCVOM_LAUNCH_CHECK("fba_input");
     return TCVOM_OK;
 }

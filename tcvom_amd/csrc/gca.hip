@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void gca_scale_kernel(const unsigned char* __r
 
 // ------------------------------------------------------------------ guidance patches + per-key vectors
 // g8: [B,h8,w8,64] bf16 (guidance_conv output at os8; os16 grid = even positions).  one wave per key.
-__global__ __launch_bounds__(256) void gca_patches_kernel(const bf16raw* __restrict__ g8, const unsigned char* __restrict__ unk8,
-                                                          const float* __restrict__ scales, bf16raw* __restrict__ G,
+__global__ __launch_bounds__(256) void gca_patches_kernel(const h16raw* __restrict__ g8, const unsigned char* __restrict__ unk8,
+                                                          const float* __restrict__ scales, h16raw* __restrict__ G,
                                                           float* __restrict__ cvec, float* __restrict__ dvec,
                                                           float* __restrict__ nrm, int B, int h8, int w8, int CG) {
     const int h = h8 / 2, w = w8 / 2, N = h * w;
@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256) void gca_patches_kernel(const bf16raw* __restr
         const int64_t src = ((int64_t)b * h8 + 2 * yy) * w8 + 2 * xx;
         any = any || unk8[src] != 0;
         for (int c = lane; c < CG; c += 64) {
-            const bf16raw val = g8[src * CG + c];
+            const h16raw val = g8[src * CG + c];
             G[(key * 9 + t) * CG + c] = val;
-            const float f = bf2f(val);
+            const float f = h2f(val);
             ss += f * f;
         }
     }
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256) void gca_patches_kernel(const bf16raw* __restr
 // 2048-column chunk, keeps its <= 32 logits in registers (ONE pass over S: 2 x float4 loads per chunk) and writes
 // 8 bf16 per 16-byte store.  The generic path (longer rows / odd strides) re-reads the row from L2.
 template <int NCHUNK>
-__global__ __launch_bounds__(256) void row_softmax_reg_kernel(const float* __restrict__ S, bf16raw* __restrict__ P, int ncols,
+__global__ __launch_bounds__(256) void row_softmax_reg_kernel(const float* __restrict__ S, h16raw* __restrict__ P, int ncols,
                                                               int64_t ld, int64_t ldp) {
     __shared__ float red[4];
     const float* s = S + (int64_t)blockIdx.x * ld;
-    bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    h16raw* p = P + (int64_t)blockIdx.x * ldp;
     float v[NCHUNK][8];
     float mx = -3.0e38f;
 #pragma unroll
@@ -114,11 +114,11 @@ __global__ __launch_bounds__(256) void row_softmax_reg_kernel(const float* __res
         }
     }
 }
-__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ S, bf16raw* __restrict__ P, int ncols,
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ S, h16raw* __restrict__ P, int ncols,
                                                           int64_t ld, int64_t ldp) {
     __shared__ float red[4];
     const float* s = S + (int64_t)blockIdx.x * ld;
-    bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    h16raw* p = P + (int64_t)blockIdx.x * ldp;
     float mx = -3.0e38f;
     for (int j = threadIdx.x; j < ncols; j += 256) mx = fmaxf(mx, s[j]);
     mx = wave_max(mx);
@@ -130,19 +130,19 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
     for (int j = threadIdx.x; j < ncols; j += 256) den += __expf(s[j] - mx);
     den = block_sum_256(den, red);
     const float r = 1.f / den;
-    for (int j = threadIdx.x; j < ldp; j += 256) p[j] = j < ncols ? f2bf(__expf(s[j] - mx) * r) : (bf16raw)0;
+    for (int j = threadIdx.x; j < ldp; j += 256) p[j] = j < ncols ? f2h(__expf(s[j] - mx) * r) : (h16raw)0;
 }
 
 // dS'[i][j] = P (dP - sum_j P dP);  T = dS' * c_j  (bf16, padded columns zero)
 template <int NCHUNK>
-__global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const bf16raw* __restrict__ P, const float* __restrict__ dP,
-                                                                  const float* __restrict__ cvec, bf16raw* __restrict__ T,
+__global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const h16raw* __restrict__ P, const float* __restrict__ dP,
+                                                                  const float* __restrict__ cvec, h16raw* __restrict__ T,
                                                                   int ncols, int64_t ld, int64_t ldp, int rows_per_batch) {
     __shared__ float red[4];
     cvec += (int64_t)(blockIdx.x / rows_per_batch) * ncols;      // per-key scales are [B][N]
-    const bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    const h16raw* p = P + (int64_t)blockIdx.x * ldp;
     const float* d = dP + (int64_t)blockIdx.x * ld;
-    bf16raw* t = T + (int64_t)blockIdx.x * ldp;
+    h16raw* t = T + (int64_t)blockIdx.x * ldp;
     const bool cvec4 = (ncols & 3) == 0 && (((uintptr_t)cvec) & 15) == 0;
     // pass 1 keeps P * (the row's probabilities) and dP in registers as w = P and g = dP; only 8 + 8 live values per
     // chunk are needed twice, so the products are stored: pd = P*dP (for the sum) and the second pass needs P and dP
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const bf16raw*
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                pv[c][k] = j0 + k < ncols ? bf2f(p[j0 + k]) : 0.f;
+                pv[c][k] = j0 + k < ncols ? h2f(p[j0 + k]) : 0.f;
                 dv[c][k] = j0 + k < ncols ? d[j0 + k] : 0.f;
             }
         }
@@ -185,19 +185,19 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const bf16raw*
         }
     }
 }
-__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const bf16raw* __restrict__ P, const float* __restrict__ dP,
-                                                              const float* __restrict__ cvec, bf16raw* __restrict__ T,
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const h16raw* __restrict__ P, const float* __restrict__ dP,
+                                                              const float* __restrict__ cvec, h16raw* __restrict__ T,
                                                               int ncols, int64_t ld, int64_t ldp, int rows_per_batch) {
     __shared__ float red[4];
     cvec += (int64_t)(blockIdx.x / rows_per_batch) * ncols;      // per-key scales are [B][N]
-    const bf16raw* p = P + (int64_t)blockIdx.x * ldp;
+    const h16raw* p = P + (int64_t)blockIdx.x * ldp;
     const float* d = dP + (int64_t)blockIdx.x * ld;
-    bf16raw* t = T + (int64_t)blockIdx.x * ldp;
+    h16raw* t = T + (int64_t)blockIdx.x * ldp;
     float a = 0.f;
-    for (int j = threadIdx.x; j < ncols; j += 256) a += bf2f(p[j]) * d[j];
+    for (int j = threadIdx.x; j < ncols; j += 256) a += h2f(p[j]) * d[j];
     a = block_sum_256(a, red);
     for (int j = threadIdx.x; j < ldp; j += 256)
-        t[j] = j < ncols ? f2bf(bf2f(p[j]) * (d[j] - a) * cvec[j]) : (bf16raw)0;
+        t[j] = j < ncols ? f2h(h2f(p[j]) * (d[j] - a) * cvec[j]) : (h16raw)0;
 }
 
 // ------------------------------------------------------------------ value patches V[key][(ky*4+kx)*C + c]
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void gca_value_patches_bwd_kernel(const float4
                         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                     }
             }
-        dalpha[v] = make_uint2(pack2bf(acc.x, acc.y), pack2bf(acc.z, acc.w));
+        dalpha[v] = make_uint2(pack2h(acc.x, acc.y), pack2h(acc.z, acc.w));
     }
 }
 
@@ -300,20 +300,20 @@ __global__ __launch_bounds__(256) void gca_unfold_kernel(const uint4* __restrict
 // ------------------------------------------------------------------ patch gradient -> guidance map gradient
 // dWp[j] = dWq[j] + M'[j] - coef_j G[j],  coef_j = <M'_j, G_j>/n_j^2 (n_j > 1e-4)   [one wave per key, in place in dWq]
 __global__ __launch_bounds__(256) void gca_patch_grad_kernel(float* __restrict__ dWq, const float* __restrict__ Mp,
-                                                             const bf16raw* __restrict__ G, const float* __restrict__ nrm,
+                                                             const h16raw* __restrict__ G, const float* __restrict__ nrm,
                                                              int64_t keys, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t key = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (key >= keys) return;
     float dot = 0.f;
-    for (int d = lane; d < D; d += 64) dot += Mp[key * D + d] * bf2f(G[key * D + d]);
+    for (int d = lane; d < D; d += 64) dot += Mp[key * D + d] * h2f(G[key * D + d]);
     dot = wave_sum(dot);
     const float n = nrm[key];
     const float coef = n > 1e-4f ? dot / (n * n) : 0.f;
-    for (int d = lane; d < D; d += 64) dWq[key * D + d] += Mp[key * D + d] - coef * bf2f(G[key * D + d]);
+    for (int d = lane; d < D; d += 64) dWq[key * D + d] += Mp[key * D + d] - coef * h2f(G[key * D + d]);
 }
 // dg8[b][2y][2x][c] = sum over (key, tap) with reflected source (y,x) of dWp[key][tap*CG + c]; zero at odd positions
-__global__ __launch_bounds__(256) void gca_patches_bwd_kernel(const float* __restrict__ dWp, bf16raw* __restrict__ dg8,
+__global__ __launch_bounds__(256) void gca_patches_bwd_kernel(const float* __restrict__ dWp, h16raw* __restrict__ dg8,
                                                               int B, int h8, int w8, int CG) {
     const int h = h8 / 2, w = w8 / 2, N = h * w;
     const int64_t total = (int64_t)B * h8 * w8 * CG;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void gca_patches_bwd_kernel(const float* __res
                         }
                 }
         }
-        dg8[v] = f2bf(acc);
+        dg8[v] = f2h(acc);
     }
 }
 
@@ -354,8 +354,8 @@ extern "C" int tcvom_gca_prepare(const void* g8, const uint8_t* unk8, void* G, f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gca_scale_kernel, dim3(B), dim3(256), 0, st, unk8, scales, h8, w8);
     const int64_t keys = (int64_t)B * (h8 / 2) * (w8 / 2);
-    hipLaunchKernelGGL(gca_patches_kernel, dim3(cdiv(keys, 4)), dim3(256), 0, st, (const bf16raw*)g8, unk8, scales,
-                       (bf16raw*)G, cvec, dvec, nrm, B, h8, w8, CG);
+    hipLaunchKernelGGL(gca_patches_kernel, dim3(cdiv(keys, 4)), dim3(256), 0, st, (const h16raw*)g8, unk8, scales,
+                       (h16raw*)G, cvec, dvec, nrm, B, h8, w8, CG);
     TCVOM_LAUNCH_CHECK("gca_prepare");
     return TCVOM_OK;
 }
@@ -363,10 +363,10 @@ extern "C" int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t 
     TCVOM_CHECK_ARG(S && P && rows > 0 && ncols > 0 && ld >= ncols && ldp >= ncols, "row_softmax: bad args");
     const bool fast = ldp <= 8192 && ld % 4 == 0 && ldp % 8 == 0 && ((uintptr_t)S % 16 == 0) && ((uintptr_t)P % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (fast && ldp <= 2048) hipLaunchKernelGGL(row_softmax_reg_kernel<1>, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
-    else if (fast && ldp <= 4096) hipLaunchKernelGGL(row_softmax_reg_kernel<2>, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
-    else if (fast) hipLaunchKernelGGL(row_softmax_reg_kernel<4>, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
-    else hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(256), 0, st, S, (bf16raw*)P, ncols, ld, ldp);
+    if (fast && ldp <= 2048) hipLaunchKernelGGL(row_softmax_reg_kernel<1>, dim3(rows), dim3(256), 0, st, S, (h16raw*)P, ncols, ld, ldp);
+    else if (fast && ldp <= 4096) hipLaunchKernelGGL(row_softmax_reg_kernel<2>, dim3(rows), dim3(256), 0, st, S, (h16raw*)P, ncols, ld, ldp);
+    else if (fast) hipLaunchKernelGGL(row_softmax_reg_kernel<4>, dim3(rows), dim3(256), 0, st, S, (h16raw*)P, ncols, ld, ldp);
+    else hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(256), 0, st, S, (h16raw*)P, ncols, ld, ldp);
     TCVOM_LAUNCH_CHECK("row_softmax");
     return TCVOM_OK;
 }
@@ -376,7 +376,7 @@ extern "C" int tcvom_row_softmax_bwd(const void* P, const float* dP, const float
     const bool fast = ldp <= 8192 && ld % 4 == 0 && ldp % 8 == 0 && ((uintptr_t)dP % 16 == 0) && ((uintptr_t)P % 16 == 0) &&
                       ((uintptr_t)T % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-#define SM_BWD_ARGS (const bf16raw*)P, dP, cvec, (bf16raw*)T, ncols, ld, ldp, rows_per_batch
+#define SM_BWD_ARGS (const h16raw*)P, dP, cvec, (h16raw*)T, ncols, ld, ldp, rows_per_batch
     if (fast && ldp <= 2048) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<1>, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
     else if (fast && ldp <= 4096) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<2>, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
     else if (fast) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<4>, dim3(rows), dim3(256), 0, st, SM_BWD_ARGS);
@@ -454,8 +454,8 @@ extern "C" int tcvom_gca_patches_bwd(float* dWq, const float* Mp, const void* G,
     TCVOM_CHECK_ARG(dWq && Mp && G && nrm && dg8, "gca_patches_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int64_t keys = (int64_t)B * (h8 / 2) * (w8 / 2);
-    hipLaunchKernelGGL(gca_patch_grad_kernel, dim3(cdiv(keys, 4)), dim3(256), 0, st, dWq, Mp, (const bf16raw*)G, nrm, keys, 9 * CG);
-    hipLaunchKernelGGL(gca_patches_bwd_kernel, dim3(sgrid((int64_t)B * h8 * w8 * CG)), dim3(256), 0, st, dWq, (bf16raw*)dg8, B, h8, w8, CG);
+    hipLaunchKernelGGL(gca_patch_grad_kernel, dim3(cdiv(keys, 4)), dim3(256), 0, st, dWq, Mp, (const h16raw*)G, nrm, keys, 9 * CG);
+    hipLaunchKernelGGL(gca_patches_bwd_kernel, dim3(sgrid((int64_t)B * h8 * w8 * CG)), dim3(256), 0, st, dWq, (h16raw*)dg8, B, h8, w8, CG);
     TCVOM_LAUNCH_CHECK("gca_patches_bwd");
     return TCVOM_OK;
 }

@@ -24,26 +24,26 @@
 #include "common.h"
 
 struct Gemm256Args {
-    const bf16raw* A;
-    const bf16raw* B;
+    const h16raw* A;
+    const h16raw* B;
     void* out;
     const float* bias;
     const float* mscale;
     const float* mdiag;
-    const bf16raw* zero_page;
+    const h16raw* zero_page;
     int M, N, K, ldo, act, out_fp32, batch;
     long long a_bstride, b_bstride, out_bstride, vec_bstride;
     // fused softmax backward (GuidedCxtAtten, tcvom_gca_dp_softmax_bwd): out = bf16( P * (acc - delta[n]) * mscale[m] ), zeros
     // in the padding columns M <= m < ldo.  P has the layout of `out`, delta is [batch][N].
-    const bf16raw* P;
+    const h16raw* P;
     const float* delta;
     // optional transposed copies written by the same epilogue: Tt[b][m][n] = out[b][n][m], Pt[b][m][n] = P[b][n][m] ([ldt][ldt] per
     // batch entry): the operands of the dV = P^T dO and M' = T^T G GEMMs, which otherwise cost two N x N transpose passes
-    bf16raw* Tt;
-    bf16raw* Pt;
+    h16raw* Tt;
+    h16raw* Pt;
     int ldt;
     // paired launch (gemm_nt256_pair): grid z in [batch, 2 batch) multiplies the SAME A with B2 into out2
-    const bf16raw* B2;
+    const h16raw* B2;
     void* out2;
     long long b2_bstride;
 };
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     // (m1, *) then holds one fragment: phases 3 and 4 issue 4 MFMAs instead of 8.
     constexpr int TM = MF * 64, TN = 256, HM = TM / 2, A_IT = TM / 64;
     constexpr int SLOT = (TM + TN) * 64;                 // bf16 elements per K-tile buffer
-    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT];
+    __shared__ __attribute__((aligned(16))) h16raw lds[2 * SLOT];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     }
     const bool second = (int)blockIdx.z >= g.batch;
     const int bz = second ? blockIdx.z - g.batch : blockIdx.z;
-    const bf16raw* A = g.A + bz * g.a_bstride;
-    const bf16raw* B = second ? g.B2 + bz * g.b2_bstride : g.B + bz * g.b_bstride;
+    const h16raw* A = g.A + bz * g.a_bstride;
+    const h16raw* B = second ? g.B2 + bz * g.b2_bstride : g.B + bz * g.b_bstride;
     void* const gout = second ? g.out2 : g.out;
     const float* bias = g.bias ? g.bias + bz * g.vec_bstride : nullptr;
     const float* mscale = g.mscale ? g.mscale + bz * g.vec_bstride : nullptr;
@@ -114,12 +114,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     typedef __attribute__((address_space(3))) void* lptr_t;
 #define G_ISSUE_A(t, it)                                                                                     \
     {                                                                                                        \
-        const bf16raw* src_ = a_off[it] >= 0 ? A + a_off[it] + (t) * 64 : g.zero_page;                       \
+        const h16raw* src_ = a_off[it] >= 0 ? A + a_off[it] + (t) * 64 : g.zero_page;                       \
         __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + (a_piece + (it) * 4) * 512), 16, 0, 0); \
     }
 #define G_ISSUE_B(t, it)                                                                                     \
     {                                                                                                        \
-        const bf16raw* src_ = b_off[it] >= 0 ? B + b_off[it] + (t) * 64 : g.zero_page;                       \
+        const h16raw* src_ = b_off[it] >= 0 ? B + b_off[it] + (t) * 64 : g.zero_page;                       \
         __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + TM * 64 + ((it) * 8 + wave) * 512), 16, 0, 0); \
     }
 
@@ -134,23 +134,23 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int a_row = wm * HM + (lane & 31), b_row = wn * 64 + (lane & 31);
     const int a_swz = (a_row >> 1) & 7, b_swz = (b_row >> 1) & 7;     // the same for rows +32, +64, +96
     const int khalf = lane >> 5;
-    bf16x8_t fa[2][4], fb[2][4];                       // A sub-tile (2 row-fragments x 4 k16), both B sub-tiles (1 x 4 each)
+    h16x8_t fa[2][4], fb[2][4];                       // A sub-tile (2 row-fragments x 4 k16), both B sub-tiles (1 x 4 each)
 
 #define G_READ_A(buf, mh)                                                                                    \
     _Pragma("unroll") for (int a_ = 0; a_ < ((mh) * 2 + 1 < MF ? 2 : 1); ++a_)                               \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                  \
-            fa[a_][kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
+            fa[a_][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
 #define G_READ_B(buf, nh)                                                                                    \
     _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                      \
-        fb[nh][kk_] = *reinterpret_cast<const bf16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3));
+        fb[nh][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3));
     // 8 MFMAs of one quadrant; `DMA` = 0/1/2: interleave the A / B DMA instructions of K-tile tn behind MFMA pairs
 #define G_MFMA(mh, nh, DMA, tn)                                                                              \
     {                                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                \
-            acc[(mh) * 2 + 0][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk_], fb[nh][kk_], acc[(mh) * 2 + 0][nh], 0, 0, 0); \
+            acc[(mh) * 2 + 0][nh] = mfma16(fa[0][kk_], fb[nh][kk_], acc[(mh) * 2 + 0][nh], 0, 0, 0); \
             if constexpr ((mh) * 2 + 1 < MF)                                                                 \
-                acc[(mh) * 2 + 1][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk_], fb[nh][kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
+                acc[(mh) * 2 + 1][nh] = mfma16(fa[1][kk_], fb[nh][kk_], acc[(mh) * 2 + 1][nh], 0, 0, 0); \
             if ((DMA) == 1 && kk_ < A_IT && (tn) < ntile) G_ISSUE_A(tn, kk_)                                 \
             if ((DMA) == 2 && (tn) < ntile) G_ISSUE_B(tn, kk_)                                               \
         }                                                                                                    \
@@ -271,12 +271,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     if constexpr (EPI == 2) {
         // ---- fused softmax backward: T = P * (acc - delta[n]) * c[m] in bf16; tile = 256 rows x 512 bytes, IN PLACE over the
         // P tile: 16-byte chunk c of row r at position c ^ (r & 15)
-        const bf16raw* Pb = g.P + obase;
+        const h16raw* Pb = g.P + obase;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int r = (it * 8 + wave) * 2 + (lane >> 5), cp = lane & 31, c = cp ^ (r & 15);
             const bool ok = n0 + r < g.N && m0 + c * 8 < g.ldo;
-            const bf16raw* src = ok ? Pb + (int64_t)(n0 + r) * g.ldo + m0 + c * 8 : g.zero_page;
+            const h16raw* src = ok ? Pb + (int64_t)(n0 + r) * g.ldo + m0 + c * 8 : g.zero_page;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lb + (it * 8 + wave) * 1024), 16, 0, 0);
         }
         float dl[2];
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     uint2* cell = reinterpret_cast<uint2*>(lb + r * 512 + (((ml >> 3) ^ (r & 15)) << 4) + (ml & 4) * 2);
                     const uint2 pp = *cell;
                     uint2 o;                           // (padding columns M <= m < ldo: sc = 0 -> zeros)
-                    o.x = pack2bf(bflo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], bfhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
-                    o.y = pack2bf(bflo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], bfhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
+                    o.x = pack2h(hlo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], hhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
+                    o.y = pack2h(hlo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], hhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
                     *cell = o;
                     if (g.Tt) {
                         // A lane holds 4 consecutive m of ONE n; its neighbour (lane ^ 1) the same m of n + 1.  After one pair
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         }
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
-        bf16raw* Tb = reinterpret_cast<bf16raw*>(gout) + obase;
+        h16raw* Tb = reinterpret_cast<h16raw*>(gout) + obase;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int r = (it * 8 + wave) * 2 + (lane >> 5), cp = lane & 31, c = cp ^ (r & 15);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     if constexpr (F32)
                         *reinterpret_cast<float4*>(wl + nl * 512 + (((a * 8 + 2 * q + h) ^ nl) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
                     else
-                        *reinterpret_cast<uint2*>(wl + nl * 256 + (((a * 4 + q) ^ (nl & 15)) << 4) + h * 8) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(wl + nl * 256 + (((a * 4 + q) ^ (nl & 15)) << 4) + h * 8) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
                 }
             }
             const int nbase = n0 + wn * 64 + b * 32, mbase = m0 + wm * HM;
@@ -395,14 +395,14 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     if (n < g.N && m < g.M) *reinterpret_cast<float4*>(o + (int64_t)n * g.ldo + m) = t;
                 }
             } else {
-                bf16raw* o = reinterpret_cast<bf16raw*>(gout) + obase;
+                h16raw* o = reinterpret_cast<h16raw*>(gout) + obase;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = i * 4 + (lane >> 4), pc = lane & 15, c = pc ^ (row & 15);
                     const uint4 t = *reinterpret_cast<const uint4*>(wl + row * 256 + pc * 16);
                     const int n = nbase + row, m = mbase + c * 8;
                     if (n < g.N && m < g.M) {
-                        bf16raw* dst = o + (int64_t)n * g.ldo + m;
+                        h16raw* dst = o + (int64_t)n * g.ldo + m;
                         if (al16 && m + 8 <= g.M) *reinterpret_cast<uint4*>(dst) = t;
                         else {
                             *reinterpret_cast<uint2*>(dst) = make_uint2(t.x, t.y);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                 }
                 if (pvalid[b] && mrow < g.M) {
                     if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(gout) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(gout) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<h16raw*>(gout) + out_off[b] + mrow) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
                 }
             }
         }
@@ -468,14 +468,14 @@ int gemm_nt256_takes(const tcvom_conv_desc* d) {
 // 1: launched; 0: not a shape for this kernel.  Called from conv_igemm_launch for dense descriptors (ntaps == 1).
 // in2 / out2 non-null: paired launch, the second product in2 x w -> out2 rides in grid z (same descriptor).
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream, const void* in2, void* out2,
+                          const tcvom_conv_desc* d, const h16raw* zero_page, void* stream, const void* in2, void* out2,
                           long long in2_bstride) {
     if (!gemm_nt256_takes(d)) return 0;
     const long long P = (long long)d->N * d->PH * d->PW;
     const int nb = d->batch > 1 ? d->batch : 1;
     Gemm256Args g;
-    g.A = (const bf16raw*)w;
-    g.B = (const bf16raw*)in;
+    g.A = (const h16raw*)w;
+    g.B = (const h16raw*)in;
     g.out = out;
     g.bias = bias;
     g.mscale = mscale;
@@ -495,7 +495,7 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.P = nullptr;
     g.delta = nullptr;
     g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
-    g.B2 = (const bf16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
+    g.B2 = (const h16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
@@ -515,15 +515,15 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
 // ---- GuidedCxtAtten backward, fused: T[b][i][j] = P[b][i][j] * (sum_v dO[b][i][v] V[b][j][v] - delta[b][i]) * c[b][j] (bf16,
 // zero in the padding columns N <= j < ld), delta[b][i] = sum_j P dP = <dO[b][i], O[b][i]>.  Replaces the fp32 dP GEMM
 // (800 MB written and read back per 3-frame launch at 1080p) + tcvom_row_softmax_bwd of models/GCA/ops.py:190's backward.
-extern const bf16raw* tcvom_zero_page(void);
+extern const h16raw* tcvom_zero_page(void);
 extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const void* P, const float* delta, const float* cvec, void* T,
                                         void* Tt, void* Pt, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
     TCVOM_CHECK_ARG(dO && V && P && delta && cvec && T, "gca_dp_softmax_bwd: null pointer");
     TCVOM_CHECK_ARG(N > 0 && N % 4 == 0 && DV % 64 == 0 && ld >= N && ld % 4 == 0 && batch >= 1, "gca_dp_softmax_bwd: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
     TCVOM_CHECK_ARG(((uintptr_t)cvec % 16) == 0 && ((uintptr_t)P % 8) == 0 && ((uintptr_t)T % 8) == 0, "gca_dp_softmax_bwd: alignment");
     Gemm256Args g;
-    g.A = (const bf16raw*)V;          // rows m = keys j
-    g.B = (const bf16raw*)dO;         // columns n = queries i
+    g.A = (const h16raw*)V;          // rows m = keys j
+    g.B = (const h16raw*)dO;         // columns n = queries i
     g.out = T;
     g.bias = nullptr;
     g.mscale = cvec;
@@ -535,10 +535,10 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.b_bstride = (long long)N * DV;
     g.out_bstride = (long long)N * ld;
     g.vec_bstride = N;
-    g.P = (const bf16raw*)P;
+    g.P = (const h16raw*)P;
     g.delta = delta;
     TCVOM_CHECK_ARG((Tt == nullptr) == (Pt == nullptr) && (!Tt || ld % 256 == 0), "gca_dp_softmax_bwd: the transposed copies come together and need ld %% 256 == 0");
-    g.Tt = (bf16raw*)Tt; g.Pt = (bf16raw*)Pt; g.ldt = (int)ld;
+    g.Tt = (h16raw*)Tt; g.Pt = (h16raw*)Pt; g.ldt = (int)ld;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);

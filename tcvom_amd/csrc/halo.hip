@@ -29,12 +29,12 @@
 #define HALO_MAX_TAPS 18
 
 struct HaloArgs {
-    const bf16raw* in;
-    const bf16raw* wgt;
+    const h16raw* in;
+    const h16raw* wgt;
     void* out;
     const float* bias;
     float* stats;
-    const bf16raw* zero_page;
+    const h16raw* zero_page;
     int N, H, W, K, ldo, wt, act, out_fp32, stats_group_offset;
     int org;                     // 1: taps 0..2 on an input that carries its own (reflection) padding ring -- the tile origin moves by (1, 1)
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
@@ -75,7 +75,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int halo_u32x4_t;
 struct HaloFrag { halo_u32x4_t v; };
 __device__ __forceinline__ void halo_read(HaloFrag& f, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(addr)); }
 __device__ __forceinline__ void halo_fence(HaloFrag& f) { asm volatile("" : "+v"(f.v)); }
-__device__ __forceinline__ bf16x8_t halo_value(const HaloFrag& f) { return __builtin_bit_cast(bf16x8_t, f.v); }
+__device__ __forceinline__ h16x8_t halo_value(const HaloFrag& f) { return __builtin_bit_cast(h16x8_t, f.v); }
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) {
@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
     constexpr int SLOT = NDMA * 512;                    // bf16 elements per halo slot
     constexpr int WROW = NCH * 16 + 8;                  // padded weight row (elements)
     constexpr int NTAPS = NCH * 16 / C;
-    extern __shared__ __attribute__((aligned(16))) bf16raw lds[];
-    bf16raw* halo = lds;                                // [2][SLOT]
-    bf16raw* wl = lds + 2 * SLOT;                       // [32][WROW]
+    extern __shared__ __attribute__((aligned(16))) h16raw lds[];
+    h16raw* halo = lds;                                // [2][SLOT]
+    h16raw* wl = lds + 2 * SLOT;                       // [32][WROW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
     // ---- weights -> LDS, once per workgroup: wl[k][t*C + c] = wgt[frame][(k*wt + slot(t))*C + c]  (every frame of a
     // frame-batched call has its own SpectralNorm'd copy)
     {
-        const bf16raw* wsrc = a.wgt + (int64_t)frame * a.w_bstride;
+        const h16raw* wsrc = a.wgt + (int64_t)frame * a.w_bstride;
         for (int u = tid; u < 32 * NTAPS * CU; u += 256) {
             const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
             const int ws = a.tap_w[t];
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ahead) : "memory");
             constexpr int k = c % (HALO_PF + 1);
             halo_fence(fa[k]); halo_fence(fb[k][0]); halo_fence(fb[k][1]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(halo_value(fa[k]), halo_value(fb[k][0]), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(halo_value(fa[k]), halo_value(fb[k][1]), acc[1], 0, 0, 0);
+            acc[0] = mfma16(halo_value(fa[k]), halo_value(fb[k][0]), acc[0], 0, 0, 0);
+            acc[1] = mfma16(halo_value(fa[k]), halo_value(fb[k][1]), acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
         HALO_STAMP(3);
@@ -304,13 +304,13 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
                     if (8 * g + 4 * half < a.K)
                         *reinterpret_cast<float4*>(op + j * ostep + 8 * g) = make_float4(acc[j][g * 4], acc[j][g * 4 + 1], acc[j][g * 4 + 2], acc[j][g * 4 + 3]);
         } else {
-            bf16raw* op = reinterpret_cast<bf16raw*>(a.out) + o0;
+            h16raw* op = reinterpret_cast<h16raw*>(a.out) + o0;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (8 * g + 4 * half < a.K)
-                        *reinterpret_cast<uint2*>(op + j * ostep + 8 * g) = make_uint2(pack2bf(acc[j][g * 4], acc[j][g * 4 + 1]), pack2bf(acc[j][g * 4 + 2], acc[j][g * 4 + 3]));
+                        *reinterpret_cast<uint2*>(op + j * ostep + 8 * g) = make_uint2(pack2h(acc[j][g * 4], acc[j][g * 4 + 1]), pack2h(acc[j][g * 4 + 2], acc[j][g * 4 + 3]));
         }
 #endif
         HALO_STAMP(4);
@@ -413,13 +413,13 @@ int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase) {
 
 // returns 1 when the conv was launched here, 0 when the caller should use the implicit GEMM, < 0 on error
 int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                         float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream) {
+                         float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream) {
     if (mscale || mdiag) return 0;
     const HaloPlan p = halo_plan(d, nphase);
     if (!p.ok) return 0;
     HaloArgs a;
-    a.in = (const bf16raw*)in;
-    a.wgt = (const bf16raw*)w;
+    a.in = (const h16raw*)in;
+    a.wgt = (const h16raw*)w;
     a.out = out;
     a.bias = bias;
     a.stats = stats;
@@ -476,10 +476,10 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
 //   Wave w owns tile rows 2w, 2w+1 (4 k-steps of 16 pixels per tile).  At the end the 4 waves' accumulators are summed
 //   through LDS and added to dw with fp32 atomics, once per workgroup.
 struct HaloWgArgs {
-    const bf16raw* dy[8];
-    const bf16raw* in[8];
+    const h16raw* dy[8];
+    const h16raw* in[8];
     float* dw[8];
-    const bf16raw* zero_page;
+    const h16raw* zero_page;
     int N, H, W, wt;
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
     int tap_dh[9], tap_dw[9], tap_w[9];
@@ -490,12 +490,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int C = 32, XU = HALO_PIX * 4, YU = HALO_TH * HALO_TW * 4;         // 16-byte units of the x halo / the dy tile
     constexpr int XI = (XU + 63) / 64, YI = YU / 64;                              // DMA wave-instructions: 22 and 16
     constexpr int SLOT = (XI + YI) * 512;                                         // bf16 elements per tile buffer
-    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT];
+    __shared__ __attribute__((aligned(16))) h16raw lds[2 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int prob = blockIdx.y;
-    const bf16raw* __restrict__ dy = a.dy[prob];
-    const bf16raw* __restrict__ in = a.in[prob];
+    const h16raw* __restrict__ dy = a.dy[prob];
+    const h16raw* __restrict__ in = a.in[prob];
     const int H = a.H, W = a.W;
     const int t_begin = blockIdx.x * a.tiles_per_wg;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tx_ = (tile) % a.tiles_x, ty_ = ((tile) / a.tiles_x) % a.tiles_y, n_ = (tile) / (a.tiles_x * a.tiles_y); \
         const int y0_ = ty_ * HALO_TH, x0_ = tx_ * HALO_TW;                                                  \
         for (int ii = wave; ii < XI + YI; ii += 4) {                                                         \
-            const bf16raw* src_;                                                                             \
+            const h16raw* src_;                                                                             \
             if (ii < XI) {                                                                                   \
                 const int q_ = ii * 64 + lane, p_ = q_ >> 2, hy_ = p_ / HALO_HW, hx_ = p_ - hy_ * HALO_HW;   \
                 const int y_ = y0_ + hy_ - 1, x_ = x0_ + hx_ - 1;                                            \
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         _Pragma("unroll") for (int t = 0; t < 5; ++t) tr_fence(fx[t]);                                        \
         _Pragma("unroll") for (int t = 5; t < 9; ++t) HWG_READ_X(ks, t);                                      \
         _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                         \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
+            acc[t] = mfma16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
         _Pragma("unroll") for (int t = 5; t < 9; ++t) tr_fence(fx[t]);                                        \
         if ((ks) < 3) {                                                                                       \
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             _Pragma("unroll") for (int t = 0; t < 5; ++t) HWG_READ_X((ks) + 1, t);                            \
         }                                                                                                     \
         _Pragma("unroll") for (int t = 5; t < 9; ++t)                                                         \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
+            acc[t] = mfma16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
     }
 
     HWG_ISSUE(t_begin, 0);
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // 1: launched, 0: not a shape for this kernel, -1: launch error
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
-                          int nphase, int ldy, const bf16raw* zero_page, void* stream) {
+                          int nphase, int ldy, const h16raw* zero_page, void* stream) {
     static const bool disabled = getenv("TCVOM_NO_HALO_WGRAD") != nullptr;      // A/B switch for tools/igemm_bench.py
     if (disabled) return 0;
     if (nphase != 1 || nbatch < 1 || nbatch > 8 || d->C != 32 || d->K != 32 || ldy != 32) return 0;   // (d->batch is a forward-only field)
@@ -646,7 +646,7 @@ int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float*
     a.ntaps = nt;
     for (int i = 0; i < 8; ++i) {
         const int j = i < nbatch ? i : 0;
-        a.dy[i] = (const bf16raw*)dys[j]; a.in[i] = (const bf16raw*)ins[j]; a.dw[i] = dws[j];
+        a.dy[i] = (const h16raw*)dys[j]; a.in[i] = (const h16raw*)ins[j]; a.dw[i] = dws[j];
     }
     a.zero_page = zero_page;
     a.N = d->N; a.H = d->H; a.W = d->W; a.wt = d->wt;

@@ -81,9 +81,9 @@ __device__ __forceinline__ void nt_reduce8(float (&t)[8]) {
 
 template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
-    const bf16raw* __restrict__ in, const bf16raw* __restrict__ wgt, void* __restrict__ outp,
+    const h16raw* __restrict__ in, const h16raw* __restrict__ wgt, void* __restrict__ outp,
     const float* __restrict__ bias, const float* __restrict__ mscale, const float* __restrict__ mdiag,
-    float* __restrict__ stats, const bf16raw* __restrict__ zero_page, const TcvomPhases ps)
+    float* __restrict__ stats, const h16raw* __restrict__ zero_page, const TcvomPhases ps)
 {
     // up to 4 phases (sub-pixel phases of a transposed conv / stride-2 data gradient) share ONE launch: blockIdx.z
     // selects the phase, so their small grids fill the chip together
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     constexpr int SLOT = (TM + TN) * 64;               // bf16 elements per ring slot
 
     static_assert(NST >= 2 && NST <= 4, "2..4 ring slots");
-    __shared__ __attribute__((aligned(16))) bf16raw lds[NST * SLOT + 8 * TCVOM_MAX_TAPS];
+    __shared__ __attribute__((aligned(16))) h16raw lds[NST * SLOT + 8 * TCVOM_MAX_TAPS];
     int4* taps = reinterpret_cast<int4*>(lds + NST * SLOT);   // per tap: input offset, weight offset (-1: dummy), mask bits
 
     const int tid = threadIdx.x;
@@ -202,14 +202,14 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         const int tap = (int)__umulhi((unsigned)kk, cmagic), c0 = kk - tap * C;                            \
         const int tin = reinterpret_cast<const int*>(taps)[tap * 4 + 0];                                   \
         const int tw = reinterpret_cast<const int*>(taps)[tap * 4 + 1];                                    \
-        bf16raw* abase = lds + (slot) * SLOT;                                                              \
+        h16raw* abase = lds + (slot) * SLOT;                                                              \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                              \
-            const bf16raw* src = (a_off[it] >= 0 && tw >= 0) ? wgt + (a_off[it] + tw + c0) : zero_page;    \
+            const h16raw* src = (a_off[it] >= 0 && tw >= 0) ? wgt + (a_off[it] + tw + c0) : zero_page;    \
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (it * NW + wave) * 512), 16, 0, 0); \
         }                                                                                                  \
-        bf16raw* bbase = abase + TM * 64;                                                                  \
+        h16raw* bbase = abase + TM * 64;                                                                  \
         _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                              \
-            const bf16raw* src = ((b_valid[it] >> tap) & 1u) ? in + ((int64_t)b_off[it] + tin + c0) : zero_page; \
+            const h16raw* src = ((b_valid[it] >> tap) & 1u) ? in + ((int64_t)b_off[it] + tin + c0) : zero_page; \
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + (it * NW + wave) * 512), 16, 0, 0); \
         }                                                                                                  \
     }
@@ -246,25 +246,25 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         if (s + NST - 1 < nstage) NT_ISSUE_STAGE(s + NST - 1, islot);
 #endif
         TRACE(3);
-        const bf16raw* As = lds + slot * SLOT;
-        const bf16raw* Bs = As + TM * 64;
+        const h16raw* As = lds + slot * SLOT;
+        const h16raw* Bs = As + TM * 64;
 #if NT_DBG != 1
 #pragma unroll
 #endif
         for (int kk = 0; kk < (NT_DBG == 1 ? 0 : 4); ++kk) {
-            bf16x8_t af[MI], bfr[NI];
+            h16x8_t af[MI], bfr[NI];
             const int kch = kk * 2 + (lane >> 5);
 #pragma unroll
             for (int a = 0; a < MI; ++a)
-                af[a] = *reinterpret_cast<const bf16x8_t*>(As + (a_row + a * 32) * 64 + ((kch ^ a_swz) << 3));
+                af[a] = *reinterpret_cast<const h16x8_t*>(As + (a_row + a * 32) * 64 + ((kch ^ a_swz) << 3));
 #pragma unroll
             for (int b = 0; b < NI; ++b)
-                bfr[b] = *reinterpret_cast<const bf16x8_t*>(Bs + (b_row + b * 32) * 64 + ((kch ^ b_swz) << 3));
+                bfr[b] = *reinterpret_cast<const h16x8_t*>(Bs + (b_row + b * 32) * 64 + ((kch ^ b_swz) << 3));
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = mfma16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
         slot = slot + 1 == NST ? 0 : slot + 1;
         islot = islot + 1 == NST ? 0 : islot + 1;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                     }
                     if (pvalid[b] && mrow < K) {
                         if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
-                        else *reinterpret_cast<uint2*>(reinterpret_cast<bf16raw*>(outp) + out_off[b] + mrow) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                        else *reinterpret_cast<uint2*>(reinterpret_cast<h16raw*>(outp) + out_off[b] + mrow) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
                     }
                 }
                 if (do_stats) {
@@ -371,8 +371,8 @@ struct NtCfg { int tm, tn, waves_n; };
 
 // 256 zero bytes per device: the source of every out-of-image / dummy tap (allocated once, on first use —
 // before any graph capture — and never freed; the only allocation the library ever makes)
-static const bf16raw* zero_page_for_current_device() {
-    static const bf16raw* pages[64] = {nullptr};
+static const h16raw* zero_page_for_current_device() {
+    static const h16raw* pages[64] = {nullptr};
     static std::mutex mtx;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -381,11 +381,11 @@ static const bf16raw* zero_page_for_current_device() {
         void* p = nullptr;
         if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
         if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-        pages[dev] = (const bf16raw*)p;
+        pages[dev] = (const h16raw*)p;
     }
     return pages[dev];
 }
-const bf16raw* tcvom_zero_page(void) { return zero_page_for_current_device(); }
+const h16raw* tcvom_zero_page(void) { return zero_page_for_current_device(); }
 static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
     const long long P = (long long)d->N * d->PH * d->PW;
     const int nb = nphase * (d->batch > 1 ? d->batch : 1);
@@ -408,19 +408,19 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
 // halo.hip: direct conv for the full-resolution small-channel layers
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                         float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
+                         float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream);
 // wsconv.hip: weight-stationary 3x3 conv for the 64 / 128-channel stride-1 layers
 int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int wsconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                      float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream);
+                      float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream);
 // gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                          const tcvom_conv_desc* d, const bf16raw* zero_page, void* stream, const void* in2, void* out2,
+                          const tcvom_conv_desc* d, const h16raw* zero_page, void* stream, const void* in2, void* out2,
                           long long in2_bstride);
 int gemm_nt256_takes(const tcvom_conv_desc* d);
 // halo.hip: weight gradient of the 32 -> 32 channel full-resolution layers from LDS-resident x halo / dy tiles
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
-                          int nphase, int ldy, const bf16raw* zero_page, void* stream);
+                          int nphase, int ldy, const h16raw* zero_page, void* stream);
 // wgradws.hip: accumulator-stationary weight gradient of the stride-1 3x3 layers with 64 / 128-multiple channel counts
 int wgradws_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
                        int nphase, int ldy, void* stream);
@@ -480,10 +480,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     const tcvom_conv_desc* d0 = descs;
     const int nb = nphase * (d0->batch > 1 ? d0->batch : 1);
     hipStream_t st = (hipStream_t)stream;
-    const bf16raw* ip = (const bf16raw*)in;
-    const bf16raw* wp = (const bf16raw*)w;
+    const h16raw* ip = (const h16raw*)in;
+    const h16raw* wp = (const h16raw*)w;
     const NtCfg c = nt_config(d0, nphase);
-    const bf16raw* zp = zero_page_for_current_device();
+    const h16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
@@ -521,7 +521,7 @@ extern "C" int tcvom_gemm_pair(const void* in1, const void* in2, const void* w, 
     TCVOM_CHECK_ARG(in1 && in2 && w && out1 && out2 && desc, "gemm_pair: null pointer");
     static const bool unpaired = getenv("TCVOM_NO_GEMM_PAIR") != nullptr;          // A/B switch
     if (!unpaired && gemm_nt256_takes(desc)) {
-        const bf16raw* zp = zero_page_for_current_device();
+        const h16raw* zp = zero_page_for_current_device();
         TCVOM_CHECK_ARG(zp != nullptr, "gemm_pair: could not allocate the zero page");
         TCVOM_CHECK_ARG(desc->w_layout == 0, "gemm_pair: plain weight layout only");
         const int r = gemm_nt256_try_launch(in1, w, out1, nullptr, nullptr, nullptr, desc, zp, stream, in2, out2, in2_bstride);
@@ -568,28 +568,20 @@ struct TtTile {                                  // geometry of a [64 pixels][TC
     __device__ static __forceinline__ int swz(int row) { return (row / RPL) % G; }
 };
 
-__device__ __forceinline__ bf16x8_t tr_read8(const bf16raw* p_lo, const bf16raw* p_hi) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-    typedef __attribute__((address_space(3))) bf16x4_t* lp_t;
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_lo);
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp_t)p_hi);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
 // up to TT_MAX_BATCH problems of identical shape (the S calls of one layer in a window: same descriptors, different
 // dy / input / dw buffers) share one launch: 3x the workgroups, so the pixel reduction is split 3x less and the
 // atomic epilogue shrinks accordingly
 #define TT_MAX_BATCH 8
 struct TtBatch {
-    const bf16raw* dy[TT_MAX_BATCH];
-    const bf16raw* in[TT_MAX_BATCH];
+    const h16raw* dy[TT_MAX_BATCH];
+    const h16raw* in[TT_MAX_BATCH];
     float* dw[TT_MAX_BATCH];
     int n;
 };
 
 template <int TM, int TN, int WM, int WN, int KS>
 __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kernel(
-    const TtBatch bt, const bf16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk,
+    const TtBatch bt, const h16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk,
     const int chunks_per_phase)
 {
 #ifdef NT_TRACE
@@ -598,8 +590,8 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
     const int per_problem = chunks_per_phase * ps.n;
     const int prob = blockIdx.x / per_problem;
     const int rem = blockIdx.x - prob * per_problem;
-    const bf16raw* __restrict__ dy = bt.dy[prob];
-    const bf16raw* __restrict__ in = bt.in[prob];
+    const h16raw* __restrict__ dy = bt.dy[prob];
+    const h16raw* __restrict__ in = bt.in[prob];
     float* __restrict__ dw = bt.dw[prob];
     const int phase = rem / chunks_per_phase;
     const tcvom_conv_desc& d = ps.d[phase];
@@ -615,7 +607,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
     typedef TtTile<TN> TB;
     constexpr int SLOT = 64 * (TM + TN);
 
-    __shared__ __attribute__((aligned(16))) bf16raw lds[2 * SLOT + 8 * TCVOM_MAX_TAPS];
+    __shared__ __attribute__((aligned(16))) h16raw lds[2 * SLOT + 8 * TCVOM_MAX_TAPS];
     int* taps = reinterpret_cast<int*>(lds + 2 * SLOT);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -715,18 +707,18 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
     }
 #define TT_ISSUE_STAGE(s, slot)                                                                                  \
     {                                                                                                            \
-        bf16raw* abase = lds + (slot) * SLOT;                                                                    \
+        h16raw* abase = lds + (slot) * SLOT;                                                                    \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                  \
             const int ii = it * NW + wave;                                                                        \
             if (ii < TA::NI) {                                                                                   \
                 const int p = pbeg + (s) * 64 + ii * TA::RPI + lane / TA::LPR;                                   \
                 const int off = ((a_n[it] * OHd + a_i[it] * a_os + a_oh) * OWd + a_j[it] * a_os + a_ow) * ldy + a_col[it]; \
-                const bf16raw* src = (a_ok[it] && p < pend) ? dy + off : zero_page;                              \
+                const h16raw* src = (a_ok[it] && p < pend) ? dy + off : zero_page;                              \
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + ii * 512), 16, 0, 0);             \
                 TT_ADVANCE(a_n[it], a_i[it], a_j[it], p + 64)                                                    \
             }                                                                                                    \
         }                                                                                                        \
-        bf16raw* bbase = abase + 64 * TM;                                                                        \
+        h16raw* bbase = abase + 64 * TM;                                                                        \
         _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                                  \
             const int ii = it * NW + wave;                                                                        \
             if (ii < TB::NI) {                                                                                   \
@@ -734,7 +726,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
                 const int ih = b_i[it] * b_is + b_dh[it], iw = b_j[it] * b_is + b_dw[it];                        \
                 const bool okb = b_ok[it] && p < pend && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W; \
                 const int off = ((b_n[it] * H + ih) * W + iw) * C + b_c0[it];                                    \
-                const bf16raw* src = okb ? in + off : zero_page;                                                 \
+                const h16raw* src = okb ? in + off : zero_page;                                                 \
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + ii * 512), 16, 0, 0);             \
                 TT_ADVANCE(b_n[it], b_i[it], b_j[it], p + 64)                                                    \
             }                                                                                                    \
@@ -760,8 +752,8 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
         TRACE(2);
         if (s + 1 < nstage) TT_ISSUE_STAGE(s + 1, slot ^ 1);
         TRACE(3);
-        const bf16raw* As = lds + slot * SLOT;
-        const bf16raw* Bs = As + 64 * TM;
+        const h16raw* As = lds + slot * SLOT;
+        const h16raw* Bs = As + 64 * TM;
         // fragments of k-step kq + 1 are requested before the MFMAs of k-step kq (two register sets)
         TrFrag fa[2][MI], fb[2][NI];
         constexpr int NKQ = 4 / KS;
@@ -796,7 +788,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
             for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fa[set][a]), tr_value(fb[set][b]), acc[a][b], 0, 0, 0);
+                    acc[a][b] = mfma16(tr_value(fa[set][a]), tr_value(fb[set][b]), acc[a][b], 0, 0, 0);
         }
 #undef TT_READ
     }
@@ -867,8 +859,8 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     for (int i = 0; i < TT_MAX_BATCH; ++i) {
         const int j = i < nbatch ? i : 0;
         TCVOM_CHECK_ARG(dys[j] && ins[j] && dws[j], "wgrad_igemm: null pointer in batch entry %d", j);
-        bt.dy[i] = (const bf16raw*)dys[j];
-        bt.in[i] = (const bf16raw*)ins[j];
+        bt.dy[i] = (const h16raw*)dys[j];
+        bt.in[i] = (const h16raw*)ins[j];
         bt.dw[i] = dws[j];
     }
     TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "wgrad_igemm: %d phases (1..4)", nphase);
@@ -892,7 +884,7 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     const tcvom_conv_desc* d = descs;
     hipStream_t st = (hipStream_t)stream;
     const int ncols = d->ntaps * d->C;
-    const bf16raw* zp = zero_page_for_current_device();
+    const h16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "wgrad_igemm: could not allocate the zero page");
     {
         const int r = halo_wgrad_try_launch(dys, ins, dws, nbatch, descs, nphase, ldy, zp, stream);

@@ -142,7 +142,7 @@ __global__ void add_kernel(const uint4* __restrict__ a, const uint4* __restrict_
 }
 
 // ---------------------------------------------------------------- bias gradient: db[k] = sum_p dy[p][k]
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16raw* __restrict__ dy, float* __restrict__ out,
+__global__ __launch_bounds__(256) void colsum_kernel(const h16raw* __restrict__ dy, float* __restrict__ out,
                                                      int64_t P, int K, int ld, int rows_per_block) {
     // columns are processed in chunks of Kc = min(K, 256); within a chunk 256/Kc row slices run concurrently
     const int Kc = K < 256 ? K : 256;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16raw* __restrict__
     for (int cb = 0; cb < K; cb += Kc) {
         float a = 0.f;
         if (rsub < RS && cb + cl < K)
-            for (int64_t p = pbeg + rsub; p < pend; p += RS) a += bf2f(dy[p * ld + cb + cl]);
+            for (int64_t p = pbeg + rsub; p < pend; p += RS) a += h2f(dy[p * ld + cb + cl]);
         __syncthreads();
         red[threadIdx.x] = a;
         __syncthreads();
@@ -167,32 +167,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16raw* __restrict__
 }
 
 // ---------------------------------------------------------------- bf16 matrix transpose  in[R][ldi] -> out[Cc][ldo]
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16raw* __restrict__ in, bf16raw* __restrict__ out,
+__global__ __launch_bounds__(256) void transpose_kernel(const h16raw* __restrict__ in, h16raw* __restrict__ out,
                                                         int R, int Cc, int64_t ldi, int64_t ldo,
                                                         int64_t in_bstride, int64_t out_bstride) {
-    __shared__ bf16raw tile[64][66];
+    __shared__ h16raw tile[64][66];
     in += blockIdx.z * in_bstride;
     out += blockIdx.z * out_bstride;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
         const int rr = r0 + r, cc = c0 + tx;
-        tile[r][tx] = (rr < R && cc < Cc) ? in[(int64_t)rr * ldi + cc] : (bf16raw)0;
+        tile[r][tx] = (rr < R && cc < Cc) ? in[(int64_t)rr * ldi + cc] : (h16raw)0;
     }
     __syncthreads();
     for (int c = ty; c < 64; c += 4) {
         const int cc = c0 + c, rr = r0 + tx;
-        if (cc < Cc && rr < ldo) out[(int64_t)cc * ldo + rr] = rr < R ? tile[tx][c] : (bf16raw)0;
+        if (cc < Cc && rr < ldo) out[(int64_t)cc * ldo + rr] = rr < R ? tile[tx][c] : (h16raw)0;
     }
 }
 
 // 16-byte variant (ldi, ldo multiples of 8, 16-byte aligned bases): 64x64 tiles, uint4 global loads and stores, the
 // transposition happens in the LDS read (8 two-byte reads per output chunk).  2.5 -> ~5 TB/s on the 134 MB attention
 // matrices of the GCA backward.
-__global__ __launch_bounds__(256) void transpose_v8_kernel(const bf16raw* __restrict__ in, bf16raw* __restrict__ out,
+__global__ __launch_bounds__(256) void transpose_v8_kernel(const h16raw* __restrict__ in, h16raw* __restrict__ out,
                                                            int R, int Cc, int64_t ldi, int64_t ldo,
                                                            int64_t in_bstride, int64_t out_bstride) {
-    __shared__ bf16raw tile[64][72];
+    __shared__ h16raw tile[64][72];
     in += blockIdx.z * in_bstride;
     out += blockIdx.z * out_bstride;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void transpose_v8_kernel(const bf16raw* __rest
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (rr < R && cc + 8 <= Cc) v = *reinterpret_cast<const uint4*>(in + (int64_t)rr * ldi + cc);
         else if (rr < R && cc < Cc) {
-            bf16raw tmp[8];
+            h16raw tmp[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tmp[k] = cc + k < Cc ? in[(int64_t)rr * ldi + cc + k] : (bf16raw)0;
+            for (int k = 0; k < 8; ++k) tmp[k] = cc + k < Cc ? in[(int64_t)rr * ldi + cc + k] : (h16raw)0;
             v = *reinterpret_cast<uint4*>(tmp);
         }
         *reinterpret_cast<uint4*>(&tile[r][t8 * 8]) = v;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void transpose_v8_kernel(const bf16raw* __rest
     for (int i = 0; i < 2; ++i) {
         const int c = tr + 32 * i, cc = c0 + c, rr = r0 + t8 * 8;      // output row cc, output columns rr .. rr+7
         if (cc < Cc && rr < ldo) {
-            bf16raw tmp[8];
+            h16raw tmp[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) tmp[k] = tile[t8 * 8 + k][c];    // rows >= R were loaded as zeros
             *reinterpret_cast<uint4*>(out + (int64_t)cc * ldo + rr) = *reinterpret_cast<uint4*>(tmp);
@@ -243,7 +243,7 @@ __device__ __forceinline__ float head_dpre(float dalpha, float alpha) {
 }
 
 template <int KS, int MODE>
-__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16raw* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const h16raw* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ alpha,
                                                             int N, int H, int W, int C) {
     constexpr int T = KS * KS, R = KS / 2;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16raw* __res
 // dx[p][c] = sum_t dpre[p - off_t] w[t][c]
 template <int KS, int MODE>
 __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __restrict__ dalpha, const float* __restrict__ alpha,
-                                                                 const float* __restrict__ w, bf16raw* __restrict__ dx,
+                                                                 const float* __restrict__ w, h16raw* __restrict__ dx,
                                                                  float* __restrict__ dpre_out, int N, int H, int W, int C) {
     constexpr int T = KS * KS, R = KS / 2;
     extern __shared__ float ws[];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __
 // (2048 blocks onto ONE copy measured ~500 us of pure atomic serialisation).  A tap-stationary version that re-read x
 // once per tap took 505 us (3x3, 64 channels) and 4.0 ms (5x5, 32 channels) at 1088x1920 against ~60 us for one pass.
 template <int KS>
-__global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* __restrict__ dpre, const bf16raw* __restrict__ x,
+__global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* __restrict__ dpre, const h16raw* __restrict__ x,
                                                                    float* __restrict__ dw, float* __restrict__ db,
                                                                    int N, int H, int W, int C, int rows_per_block, int replicas) {
     constexpr int T = KS * KS, R = KS / 2;
@@ -417,7 +417,7 @@ extern "C" int tcvom_colsum(const void* dy, float* out, int64_t P, int32_t K, in
     const int rpb = (int)((P + blocks - 1) / blocks);
     if (hipMemsetAsync(out, 0, sizeof(float) * K, (hipStream_t)stream) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "colsum: memset failed");
-    hipLaunchKernelGGL(colsum_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16raw*)dy, out, P, K, ld, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const h16raw*)dy, out, P, K, ld, rpb);
     TCVOM_LAUNCH_CHECK("colsum");
     return TCVOM_OK;
 }
@@ -428,10 +428,10 @@ extern "C" int tcvom_transpose_bf16(const void* in, void* out, int32_t R, int32_
     const bool v8 = ldi % 8 == 0 && ldo % 8 == 0 && in_bstride % 8 == 0 && out_bstride % 8 == 0 &&
                     ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
     if (v8)
-        hipLaunchKernelGGL(transpose_v8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, R, Cc,
+        hipLaunchKernelGGL(transpose_v8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const h16raw*)in, (h16raw*)out, R, Cc,
                            ldi, ldo, in_bstride, out_bstride);
     else
-        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16raw*)in, (bf16raw*)out, R, Cc,
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const h16raw*)in, (h16raw*)out, R, Cc,
                            ldi, ldo, in_bstride, out_bstride);
     TCVOM_LAUNCH_CHECK("transpose_bf16");
     return TCVOM_OK;
@@ -443,11 +443,11 @@ extern "C" int tcvom_head_conv_fwd(const void* x, const float* w, const float* b
     const dim3 g(grid_for((int64_t)N * H * W));
     hipStream_t st = (hipStream_t)stream;
     if (ksize == 3)
-        hipLaunchKernelGGL((head_conv_fwd_kernel<3, 0>), g, dim3(256), 9 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_fwd_kernel<3, 0>), g, dim3(256), 9 * C * sizeof(float), st, (const h16raw*)x, w, bias, alpha, N, H, W, C);
     else if (mode == 1)
-        hipLaunchKernelGGL((head_conv_fwd_kernel<5, 1>), g, dim3(256), 25 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_fwd_kernel<5, 1>), g, dim3(256), 25 * C * sizeof(float), st, (const h16raw*)x, w, bias, alpha, N, H, W, C);
     else
-        hipLaunchKernelGGL((head_conv_fwd_kernel<5, 2>), g, dim3(256), 25 * C * sizeof(float), st, (const bf16raw*)x, w, bias, alpha, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_fwd_kernel<5, 2>), g, dim3(256), 25 * C * sizeof(float), st, (const h16raw*)x, w, bias, alpha, N, H, W, C);
     TCVOM_LAUNCH_CHECK("head_conv_fwd");
     return TCVOM_OK;
 }
@@ -461,11 +461,11 @@ extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, cons
     const int T = ksize * ksize;
     const dim3 g(grid_for((int64_t)N * H * W * C / 8));
     if (ksize == 3)
-        hipLaunchKernelGGL((head_conv_bwd_data_kernel<3, 0>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<3, 0>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (h16raw*)dx, dpre, N, H, W, C);
     else if (mode == 1)
-        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 1>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 1>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (h16raw*)dx, dpre, N, H, W, C);
     else
-        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 2>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (bf16raw*)dx, dpre, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 2>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (h16raw*)dx, dpre, N, H, W, C);
     if (hipMemsetAsync(dw, 0, sizeof(float) * T * C * replicas, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * replicas, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "head_conv_bwd: memset failed");
     const int64_t P = (int64_t)N * H * W;
@@ -474,9 +474,9 @@ extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, cons
     if (blocks > 2048) blocks = 2048;
     const int rpb = (int)((P + blocks - 1) / blocks);
     if (ksize == 3)
-        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<3>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb, replicas);
+        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<3>), dim3((int)blocks), dim3(256), 0, st, dpre, (const h16raw*)x, dw, db, N, H, W, C, rpb, replicas);
     else
-        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<5>), dim3((int)blocks), dim3(256), 0, st, dpre, (const bf16raw*)x, dw, db, N, H, W, C, rpb, replicas);
+        hipLaunchKernelGGL((head_conv_bwd_weight_kernel<5>), dim3((int)blocks), dim3(256), 0, st, dpre, (const h16raw*)x, dw, db, N, H, W, C, rpb, replicas);
     TCVOM_LAUNCH_CHECK("head_conv_bwd");
     return TCVOM_OK;
 }

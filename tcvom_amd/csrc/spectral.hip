@@ -141,8 +141,8 @@ constexpr int SNP_ROW = SNP_TC * SNP_SLOTS + 2;  // LDS row of one k: [c][slot],
 
 template <int TC>                                // TC = compile-time tap count (9, 16, 1) or 0: read it from the table
 __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int which, int tile, float inv, int call,
-                                             bf16raw* __restrict__ fwd_arena, bf16raw* __restrict__ bwd_arena,
-                                             int64_t fwd_call_stride, int64_t bwd_call_stride, bf16raw* __restrict__ lds) {
+                                             h16raw* __restrict__ fwd_arena, h16raw* __restrict__ bwd_arena,
+                                             int64_t fwd_call_stride, int64_t bwd_call_stride, h16raw* __restrict__ lds) {
     const float* __restrict__ W = reinterpret_cast<const float*>(L[SN_W]);
     const int kind = (int)L[SN_KIND];
     const int K = (int)L[SN_K], C = (int)L[SN_C], T = TC ? TC : (int)L[SN_T], Cp = (int)L[SN_CPAD];
@@ -174,16 +174,16 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
                 const int kl = transposed ? q : r, cl = transposed ? r : q;
                 float val = w[u] * inv;
                 if (ws) { const float4 st = wstat[k0 + kl]; val = (w[u] - st.x) * st.y; }
-                const bf16raw hi = f2bf(val);
-                bf16raw* dst = lds + kl * rp + cl * TT + t;
+                const h16raw hi = f2h(val);
+                h16raw* dst = lds + kl * rp + cl * TT + t;
                 dst[0] = hi;
-                if (hp) dst[T] = f2bf(val - bf2f(hi));
+                if (hp) dst[T] = f2h(val - h2f(hi));
             }
         }
     }
     __syncthreads();
     // ---- forward pack: [K][TT][Cp], channels c0 .. c0 + 63 of every (k, slot) row of the tile; padding channels are zero
-    bf16raw* __restrict__ fdst = fwd_arena + call * fwd_call_stride + L[SN_FWD_OFF];
+    h16raw* __restrict__ fdst = fwd_arena + call * fwd_call_stride + L[SN_FWD_OFF];
     const int ncp = min(SNP_TC, Cp - c0);
     for (int e = tid; e < nk * TT * SNP_TC; e += 256) {
         const int cl = e % SNP_TC, row = e / SNP_TC;
@@ -191,12 +191,12 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
         if (hp) { kl = row / (2 * T); slot = row - kl * (2 * T); } else { kl = row / T; slot = row - kl * T; }
         if (cl < ncp) {
             const int64_t di = (kind & 32) ? sn_frag_index(k0 + kl, slot, c0 + cl, TT, Cp) : ((int64_t)(k0 + kl) * TT + slot) * Cp + c0 + cl;
-            fdst[di] = cl < nc ? lds[kl * rp + cl * TT + slot] : (bf16raw)0;
+            fdst[di] = cl < nc ? lds[kl * rp + cl * TT + slot] : (h16raw)0;
         }
     }
     // ---- data-gradient pack: [C][T][K], output channels k0 .. k0 + 31 of every (c, t) row
     if (which == 3 && nc > 0) {
-        bf16raw* __restrict__ bdst = bwd_arena + call * bwd_call_stride + L[SN_BWD_OFF];
+        h16raw* __restrict__ bdst = bwd_arena + call * bwd_call_stride + L[SN_BWD_OFF];
         for (int e = tid; e < nc * T * SNP_TK; e += 256) {
             const int kl = e % SNP_TK, row = e / SNP_TK, t = row % T, cl = row / T;
             if (kl < nk) {
@@ -210,10 +210,10 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
 // pack: one thread per OUTPUT element.  which = 0 fwd pack [K][T][Cpad], 1 bwd pack [C][T][K]; 2 / 3: tiled (above)
 __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
                                                       const float* __restrict__ sigma, int L_total, int call,
-                                                      bf16raw* __restrict__ fwd_arena, bf16raw* __restrict__ bwd_arena,
+                                                      h16raw* __restrict__ fwd_arena, h16raw* __restrict__ bwd_arena,
                                                       int64_t fwd_call_stride, int64_t bwd_call_stride)
 {
-    __shared__ bf16raw tile_lds[SNP_TK * SNP_ROW];
+    __shared__ h16raw tile_lds[SNP_TK * SNP_ROW];
     const int layer = work[blockIdx.x * 3], which = work[blockIdx.x * 3 + 1];
     const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * 256;
     const int64_t* L = tab + (int64_t)layer * SN_WORDS;
@@ -259,12 +259,12 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
             const float4 ws = reinterpret_cast<const float4*>(L[SN_WS_STATS])[k];
             val = (W[src] - ws.x) * ws.y;
         }
-        if (part) val -= bf2f(f2bf(val));
+        if (part) val -= h2f(f2h(val));
     }
     int64_t di = idx;
     if (kind & 32) di = which == 0 ? sn_frag_index(k, t, c, T, Cp) : sn_frag_index(c, t, k, T, K);
-    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + di] = f2bf(val);
-    else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + di] = f2bf(val);
+    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + di] = f2h(val);
+    else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + di] = f2h(val);
 }
 
 // ------------------------------------------------------------------------------ backward
@@ -462,7 +462,7 @@ extern "C" int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, co
                              int64_t bwd_call_stride, void* stream) {
     TCVOM_CHECK_ARG(table && s && work_pack && fwd_arena && n_pack > 0, "sn_pack: bad args");
     hipLaunchKernelGGL(sn_pack_kernel, dim3(n_pack), dim3(256), 0, (hipStream_t)stream, table, work_pack, s->sigma,
-                       s->num_layers, call, (bf16raw*)fwd_arena, (bf16raw*)bwd_arena, fwd_call_stride, bwd_call_stride);
+                       s->num_layers, call, (h16raw*)fwd_arena, (h16raw*)bwd_arena, fwd_call_stride, bwd_call_stride);
     TCVOM_LAUNCH_CHECK("sn_pack");
     return TCVOM_OK;
 }

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void tam_fwd_kernel(
     for (int i = 0; i < NP; ++i) {
         const int cp = lane + 64 * i;
         const unsigned vv = cp < CP ? v[pix * CP + cp] : 0u;
-        o[i][0] = bflo(vv);
-        o[i][1] = bfhi(vv);
+        o[i][0] = hlo(vv);
+        o[i][1] = hhi(vv);
         qq[i] = (cp < CP && unknown) ? q[pix * CP + cp] : 0u;
     }
 #pragma unroll 1
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void tam_fwd_kernel(
                 const int cp = lane + 64 * i;
                 const unsigned w = (ok && cp < CP) ? k[(((int64_t)b * H + yy) * W + xx) * CP + cp] : 0u;
                 kk[j][i] = w;
-                part += bflo(qq[i]) * bflo(w) + bfhi(qq[i]) * bfhi(w);
+                part += hlo(qq[i]) * hlo(w) + hhi(qq[i]) * hhi(w);
             }
             lg[j] = wave_sum(part) * inv_sqrt_c;
         }
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void tam_fwd_kernel(
             const float p = pj[j] * rden;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                o[i][0] += p * bflo(kk[j][i]);
-                o[i][1] += p * bfhi(kk[j][i]);
+                o[i][0] += p * hlo(kk[j][i]);
+                o[i][1] += p * hhi(kk[j][i]);
             }
         }
         // every lane holds all logits: lane j stores logit j (strided by N in memory)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void tam_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int cp = lane + 64 * i;
-        if (cp < CP) out[pix * CP + cp] = pack2bf(o[i][0], o[i][1]);
+        if (cp < CP) out[pix * CP + cp] = pack2h(o[i][0], o[i][1]);
     }
     }
 }
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
                 const int cp = lane + 64 * i;
                 const unsigned w = (ok && cp < CP) ? k[(((int64_t)b * H + yy) * W + xx) * CP + cp] : 0u;
                 kk[j][i] = w;
-                part += bflo(qq[i]) * bflo(w) + bfhi(qq[i]) * bfhi(w);
-                part2 += bflo(go[i]) * bflo(w) + bfhi(go[i]) * bfhi(w);
+                part += hlo(qq[i]) * hlo(w) + hhi(qq[i]) * hhi(w);
+                part2 += hlo(go[i]) * hlo(w) + hhi(go[i]) * hhi(w);
             }
             lg[j] = wave_sum(part) * inv_sqrt_c;
             dp[j] = wave_sum(part2);
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
             const float dss = ds * inv_sqrt_c;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                dqa[i][0] += dss * bflo(kk[j][i]);
-                dqa[i][1] += dss * bfhi(kk[j][i]);
+                dqa[i][0] += dss * hlo(kk[j][i]);
+                dqa[i][1] += dss * hhi(kk[j][i]);
             }
             if (lane == (j & 63)) { pb[(int64_t)j * N + u] = lg[j]; db[(int64_t)j * N + u] = dss; }
         }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int cp = lane + 64 * i;
-        if (cp < CP) dq[pix * CP + cp] = pack2bf(dqa[i][0], dqa[i][1]);
+        if (cp < CP) dq[pix * CP + cp] = pack2h(dqa[i][0], dqa[i][1]);
     }
     }
 }
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void tam_bwd_key_kernel(
             if (cp < CP) {
                 const unsigned g = dout[((int64_t)b * N + u) * CP + cp];
                 const unsigned qv = q[((int64_t)b * N + u) * CP + cp];
-                acc[i][0] += p * bflo(g) + ds * bflo(qv);
-                acc[i][1] += p * bfhi(g) + ds * bfhi(qv);
+                acc[i][0] += p * hlo(g) + ds * hlo(qv);
+                acc[i][1] += p * hhi(g) + ds * hhi(qv);
             }
         }
     }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void tam_bwd_key_kernel(
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int cp = lane + 64 * i;
-        if (cp < CP) dk[pix * CP + cp] = pack2bf(acc[i][0], acc[i][1]);
+        if (cp < CP) dk[pix * CP + cp] = pack2h(acc[i][0], acc[i][1]);
     }
 }
 
@@ -249,12 +249,12 @@ __global__ __launch_bounds__(256) void tam_bwd_key_kernel(
 //            chunk j so that the 16 lanes of an LDS read group hit 16 different banks although all key rows start on bank 0;
 //            the softmax is then TWO wave reductions (the one-wave-per-pixel kernel above needs 49, one per neighbour)
 //   phase B  lane = channel pair: out = v + sum_j p_j k_j, p_j broadcast with v_readlane, key rows read conflict-free
-typedef __attribute__((ext_vector_type(2))) __bf16 tam_bf2;
+typedef __attribute__((ext_vector_type(2))) act_t tam_h2;
 __device__ __forceinline__ float tam_dot8(const uint4 a, const uint4 b, float acc) {
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.x), __builtin_bit_cast(tam_bf2, b.x), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.y), __builtin_bit_cast(tam_bf2, b.y), acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.z), __builtin_bit_cast(tam_bf2, b.z), acc, false);
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tam_bf2, a.w), __builtin_bit_cast(tam_bf2, b.w), acc, false);
+    acc = dot2_h16(__builtin_bit_cast(tam_h2, a.x), __builtin_bit_cast(tam_h2, b.x), acc, false);
+    acc = dot2_h16(__builtin_bit_cast(tam_h2, a.y), __builtin_bit_cast(tam_h2, b.y), acc, false);
+    acc = dot2_h16(__builtin_bit_cast(tam_h2, a.z), __builtin_bit_cast(tam_h2, b.z), acc, false);
+    return dot2_h16(__builtin_bit_cast(tam_h2, a.w), __builtin_bit_cast(tam_h2, b.w), acc, false);
 }
 __device__ __forceinline__ float tam_lane(float v, int j) {
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
         for (int i = 0; i < NP; ++i) {
             o[i][0] = o[i][1] = 0.f;
             const int cp = lane + 64 * i;
-            if (MODE == 0 && cp < CP) { const unsigned vv = v[pix * CP + cp]; o[i][0] = bflo(vv); o[i][1] = bfhi(vv); }
+            if (MODE == 0 && cp < CP) { const unsigned vv = v[pix * CP + cp]; o[i][0] = hlo(vv); o[i][1] = hhi(vv); }
         }
 #pragma unroll 1
         for (int dir = 0; dir < 2; ++dir) {
@@ -356,15 +356,15 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
                 for (int i = 0; i < NP; ++i) {
                     const int cp = lane + 64 * i;
                     const unsigned kv = hp[((jj / WIN) * HW + jj % WIN) * CP + (cp < CP ? cp : 0)];
-                    o[i][0] += pj * bflo(kv);
-                    o[i][1] += pj * bfhi(kv);
+                    o[i][0] += pj * hlo(kv);
+                    o[i][1] += pj * hhi(kv);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int cp = lane + 64 * i;
-            if (cp < CP) out[pix * CP + cp] = pack2bf(o[i][0], o[i][1]);
+            if (cp < CP) out[pix * CP + cp] = pack2h(o[i][0], o[i][1]);
         }
     }
 }
@@ -407,7 +407,7 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
     const size_t att_bytes = sizeof(float) * (size_t)n * window * window;
     if (hipMemsetAsync(attb, 0, att_bytes, st) != hipSuccess || hipMemsetAsync(attf, 0, att_bytes, st) != hipSuccess ||
         hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
-        hipMemcpyAsync(out, v, sizeof(bf16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        hipMemcpyAsync(out, v, sizeof(h16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_fwd: memset / copy failed");
     if (window == 7 && C % 8 == 0) {
 #define TAM_TILED_FWD(TH, TW, CM)                                                                                     \
@@ -438,7 +438,7 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
     const dim3 grid(tam_heavy_grid(n));
     const dim3 grid2(cdiv(n, 4), 2);
     const float isc = 1.0f / sqrtf((float)C);
-    if (hipMemsetAsync(dq, 0, sizeof(bf16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
+    if (hipMemsetAsync(dq, 0, sizeof(h16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
     if (window == 7 && C % 8 == 0) {
 #define TAM_TILED_BWD(TH, TW, CM)                                                                                     \
         hipLaunchKernelGGL((tam_tiled_kernel<7, 1, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(256), 0, st,   \

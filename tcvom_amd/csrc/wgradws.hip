@@ -27,8 +27,8 @@ typedef __attribute__((address_space(3))) void* wg_lptr_t;
 
 #define WG_MAX_PROBLEMS 112                // 3 pointer arrays of this length stay inside the 4 KiB kernel-argument segment
 struct WgArgs {
-    const bf16raw* dy[WG_MAX_PROBLEMS];
-    const bf16raw* in[WG_MAX_PROBLEMS];
+    const h16raw* dy[WG_MAX_PROBLEMS];
+    const h16raw* in[WG_MAX_PROBLEMS];
     float* dw[WG_MAX_PROBLEMS];
     int N, H, W, C, K, wt;
     int tiles_x, tiles_y, ntiles;          // pixel tiles of one problem (N * tiles_y * tiles_x)
@@ -153,7 +153,7 @@ __device__ __forceinline__ void wg_mfma(const WgArgs& a, const WgDma& d, char* l
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(G::later_than(g)) : "memory");
     tr_fence(fb[g % (G::D + 1)]);
     if constexpr (j == 0) tr_fence(fa[s & 1]);
-    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_value(fa[s & 1]), tr_value(fb[g % (G::D + 1)]), acc[j], 0, 0, 0);
+    acc[j] = mfma16(tr_value(fa[s & 1]), tr_value(fb[g % (G::D + 1)]), acc[j], 0, 0, 0);
     constexpr int PER = G::NG / G::DMA_IT >= 6 ? 6 : 4;
 #if WG_ABL != 2
     if constexpr (g % PER == PER - 1 && g / PER < G::DMA_IT) wg_dma_piece<G, g / PER>(a, d, lds, wave, rel, pk);
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
         const int prob_ = item_ / blocks, blk_ = item_ - prob_ * blocks;                                      \
         const int kg_ = blk_ / a.cgroups, cg_ = blk_ - kg_ * a.cgroups;                                       \
         const int n_ = tl_ / txy, r_ = tl_ - n_ * txy;                                                        \
-        d.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16raw*>(a.in[prob_]), 0, a.in_bytes, 0x00020000); \
-        d.yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16raw*>(a.dy[prob_]), 0, a.dy_bytes, 0x00020000); \
+        d.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.in[prob_]), 0, a.in_bytes, 0x00020000); \
+        d.yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.dy[prob_]), 0, a.dy_bytes, 0x00020000); \
         d.ym = (q_) < q_end ? (r_ / a.tiles_x) * G::TH : (1 << 20);                                           \
         d.xm = (r_ % a.tiles_x) * TW;                                                                         \
         d.xbase = (unsigned)((((n_ * a.H + d.ym - 1) * a.W + d.xm - 1) * a.C + cg_ * CWIN) * 2);              \
@@ -311,7 +311,7 @@ int wgradws_try_launch(const void* const* dys, const void* const* ins, float* co
     const int C = d->C, K = d->K;
     for (int i = 0; i < WG_MAX_PROBLEMS; ++i) {
         const int j = i < nprob ? i : 0;
-        a.dy[i] = (const bf16raw*)dys[j]; a.in[i] = (const bf16raw*)ins[j]; a.dw[i] = dws[j];
+        a.dy[i] = (const h16raw*)dys[j]; a.in[i] = (const h16raw*)ins[j]; a.dw[i] = dws[j];
     }
     const int cwin = C == 64 ? 64 : 128, tw = C == 64 ? 32 : 16;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = C; a.K = K; a.wt = d->wt;

@@ -38,12 +38,12 @@ typedef const __attribute__((address_space(1))) void* ws_gptr_t;
 typedef __attribute__((address_space(3))) void* ws_lptr_t;
 
 struct WsArgs {
-    const bf16raw* in;
-    const bf16raw* wgt;
+    const h16raw* in;
+    const h16raw* wgt;
     void* out;
     const float* bias;
     float* stats;
-    const bf16raw* zero_page;
+    const h16raw* zero_page;
     int H, W, K, ldo, wt, act;
     unsigned in_bytes, out_bytes, stats_bytes;
     int tiles_x, tiles_y, tiles_per_frame, tiles_per_wg, wgs_per_frame;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void ws_epi_piece(WsCtx<G>& c, const f32x4_t vals) {
         }
         const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * 2) + 16u * g : 0xffffffffu;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2bf(vals[0], vals[1]), pack2bf(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2h(vals[0], vals[1]), pack2h(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
     } else {
         float t[8];
 #pragma unroll
@@ -339,7 +339,7 @@ __device__ __forceinline__ void ws_read_some(u32x4_t (&bq)[G::PF + 1][G::NI], un
 // DMA instruction or epilogue piece shares a scheduling region with the remaining MFMAs (group barriers ask for an MFMA /
 // VALU alternation).  lgkmcnt is counted by hand (the reads are inline asm).
 template <class G, int S>
-__device__ __forceinline__ void ws_step(WsCtx<G>& c, const bf16x8_t (&wr)[G::NS], f32x16_t (&acc)[G::NI], u32x4_t (&bq)[G::PF + 1][G::NI],
+__device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS], f32x16_t (&acc)[G::NI], u32x4_t (&bq)[G::PF + 1][G::NI],
                                         const unsigned (&bbase)[3], unsigned lb) {
     constexpr int set = S % (G::PF + 1), NI = G::NI, SN = S + G::PF;
     constexpr bool rd = SN < G::NS;
@@ -348,7 +348,7 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const bf16x8_t (&wr)[G::NS]
 #pragma unroll
     for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bq[set][i]));
     __builtin_amdgcn_sched_barrier(0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][0]), acc[0], 0, 0, 0);
+    acc[0] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][0]), acc[0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     unsigned ad = 0;
     if constexpr (rd) {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const bf16x8_t (&wr)[G::NS]
         ws_read_some<G, SN, 0, 2>(bq, ad);
     }
     __builtin_amdgcn_sched_barrier(0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][1]), acc[1], 0, 0, 0);
+    acc[1] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][1]), acc[1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (rd) ws_read_some<G, SN, 2, 4>(bq, ad);
     if constexpr (G::er(S) > 0) ws_epi_fetch<G, S + 1, 0>(c);   // unconditional: the counts rely on it
@@ -369,8 +369,8 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const bf16x8_t (&wr)[G::NS]
 #endif
     constexpr bool has_dma = S * G::DPS < G::DMA_IT && !(WS_ABL & 1);
     constexpr bool has_epi = S >= G::E0 && S < G::E1 && !(WS_ABL & 2);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][2]), acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[S], __builtin_bit_cast(bf16x8_t, bq[set][3]), acc[3], 0, 0, 0);
+    acc[2] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][2]), acc[2], 0, 0, 0);
+    acc[3] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][3]), acc[3], 0, 0, 0);
     if constexpr (has_dma) ws_dma_pieces<G, S * G::DPS, G::DPS>(c);      // without a next tile: zeros into the idle buffer
     if constexpr (has_epi) {
         if constexpr (G::er(S - 1) > 0) {                       // the float4 requested in step S - 1
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
     }
     c.slope = a.act == 1 ? 0.f : (a.act == 3 ? 0.01f : 1.f);
     c.orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
-    c.irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16raw*>(a.in), 0, a.in_bytes, 0x00020000);
+    c.irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.in), 0, a.in_bytes, 0x00020000);
     c.dhy = c.dhx = c.dsl = 0;
     c.srsrc = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, a.stats ? a.stats_bytes : 0, 0x00020000);
     c.pgx = 0x7fffffff;
@@ -471,20 +471,20 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
     WS_STAMP(1);
 
     // ---- weights -> registers: A fragment of k-step s = t*NCC + cc: rows mf*32 + col, channels cc*16 + half*8 ..+7 of tap t
-    bf16x8_t wr[NS];
+    h16x8_t wr[NS];
     {
-        const bf16raw* wsrc = a.wgt + (int64_t)c.frame * a.w_bstride;
+        const h16raw* wsrc = a.wgt + (int64_t)c.frame * a.w_bstride;
         const int m = c.mf * 32 + col;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int ws = a.wslot[t];
 #pragma unroll
             for (int cc = 0; cc < NCC; ++cc) {
-                bf16x8_t v = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
+                h16x8_t v = __builtin_bit_cast(h16x8_t, u32x4_t{0u, 0u, 0u, 0u});
                 if (a.w_frag) {               // one contiguous 1 KiB block per fragment
-                    if (ws >= 0) v = *reinterpret_cast<const bf16x8_t*>(wsrc + ((((int64_t)c.mf * a.wt + ws) * NCC + cc) * 64 + c.lane) * 8);
+                    if (ws >= 0) v = *reinterpret_cast<const h16x8_t*>(wsrc + ((((int64_t)c.mf * a.wt + ws) * NCC + cc) * 64 + c.lane) * 8);
                 } else if (m < K && ws >= 0)
-                    v = *reinterpret_cast<const bf16x8_t*>(wsrc + ((int64_t)m * a.wt + ws) * C + cc * 16 + c.half * 8);
+                    v = *reinterpret_cast<const h16x8_t*>(wsrc + ((int64_t)m * a.wt + ws) * C + cc * 16 + c.half * 8);
                 wr[t * NCC + cc] = v;
             }
         }
@@ -648,13 +648,13 @@ int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase) {
 
 // returns 1 when the conv was launched here, 0 when the caller should use another kernel, < 0 on error
 int wsconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
-                      float* stats, const tcvom_conv_desc* d, int nphase, const bf16raw* zero_page, void* stream) {
+                      float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream) {
     if (mscale || mdiag) return 0;
     const WsPlan p = ws_plan(d, nphase);
     if (!p.ok) return 0;
     WsArgs a;
-    a.in = (const bf16raw*)in;
-    a.wgt = (const bf16raw*)w;
+    a.in = (const h16raw*)in;
+    a.wgt = (const h16raw*)w;
     a.out = out;
     a.bias = bias;
     a.stats = stats;

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ACT_RELU, ConvCfg
+from .ops import ACT_RELU, ConvCfg, H16
 from .weights import ConvSpec, WeightBank, bank_token
 
 _ENC = [('11', None, 64), ('12', 64, 64), ('21', 64, 128), ('22', 128, 128), ('31', 128, 256), ('32', 256, 256),
@@ -67,7 +67,7 @@ class DeepMatting(nn.Module):
         x = ops.conv_bn_act(cfgs['dconv6'], x, token, training)
         for (name, _, _), i in zip(_DEC, reversed(idx)):
             x = ops.conv_bn_act(cfgs[name], ops.unpool2(x, i), token, training)
-        alpha = ops.head_conv(x, self.alpha_pred.weight, self.alpha_pred.bias, 5, 1)
+        alpha = ops.head_conv(x, ops.param_in(self.alpha_pred.weight, self._bank), ops.param_in(self.alpha_pred.bias, self._bank), 5, 1)
         bank.flush_bn_counters()
         return alpha
 
@@ -75,8 +75,8 @@ class DeepMatting(nn.Module):
         """x: NCHW float [B,4,H,W] (normalised RGB + 1-channel trimap), H % 32 == W % 32 == 0 -> alpha [B,1,H,W]."""
         B, Cx, H, W = x.shape
         assert Cx == self.input_chn and H % 32 == 0 and W % 32 == 0
-        x8 = torch.zeros((B, H, W, 8), dtype=torch.bfloat16, device=x.device)
-        x8[..., :Cx] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+        x8 = torch.zeros((B, H, W, 8), dtype=H16, device=x.device)
+        x8[..., :Cx] = x.permute(0, 2, 3, 1).to(H16)
         return self.run(x8)
 
 
@@ -127,6 +127,7 @@ class DIMDecoder(nn.Module):
         super().__init__()
         from .vmn import FeatureAggregationModule
         self.freeze_backbone = freeze_backbone
+        object.__setattr__(self, '_bank', bank)
         self.dconv6 = nn.Conv2d(4096, 512, kernel_size=1, padding=0)
         for name, cin, cout in _DEC:
             setattr(self, name, nn.Conv2d(cin, cout, kernel_size=5, padding=2))
@@ -161,7 +162,7 @@ class DIMDecoder(nn.Module):
         x, attb, attf = self.fam.run(x, xb, xf, mask_u8.contiguous(), token, training)
         for name, i in (('dconv3', idx[2]), ('dconv2', idx[1]), ('dconv1', idx[0])):
             x = ops.conv_bn_act(cf[name], ops.unpool2(x, i.contiguous()), token, training)
-        return ops.head_conv(x, self.alpha_pred.weight, self.alpha_pred.bias, 5, 1), attb, attf
+        return ops.head_conv(x, ops.param_in(self.alpha_pred.weight, self._bank), ops.param_in(self.alpha_pred.bias, self._bank), 5, 1), attb, attf
 
 
 def build_vmn_dim(agg_window, agg_reduction=1, freeze_backbone=False):

@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import ops
+from ._lib import ACT_DTYPE as H16
 from . import vmn as VMN
 from .dim_net import DIM_VGG
 from .index_net import IndexMatting
@@ -42,7 +44,7 @@ def preprocess_window(a, fg, bg, dilate_kernel, eps, tri_channels=3):
     p.bgs = _f32((B, S, 3, H, W), dev) if bg is not None else None
     u8 = lambda: torch.empty((B, S, H, W), dtype=torch.uint8, device=dev)
     p.unk_raw, tmp, p.unk = u8(), u8(), u8()
-    p.x8 = torch.empty((B, S, H, W, 8), dtype=torch.bfloat16, device=dev)
+    p.x8 = torch.empty((B, S, H, W, 8), dtype=H16, device=dev)
     p.trimask = _f32((B, S, 1, H, W), dev)
     p.tris_vis = _f32((B, S, 1, H, W), dev)
     L.call('tcvom_preprocess', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
@@ -208,6 +210,9 @@ class FullModel(nn.Module):
             if self.ARCH_DICT[model] is None:
                 raise NotImplementedError('%s: this single-image base is not on the MI355X path yet (SURVEY.md §8)' % model)
             self.NET = self.ARCH_DICT[model]()
+        from .ddp import banks_of
+        for bank in banks_of(self.NET):                        # fp16 build: the network's backward runs under a loss scale (ops.py)
+            bank.loss_scale = ops.LOSS_SCALE
         self.method = model[model.rfind('_') + 1:]
         self.TRIMAP_CHANNEL = self.TRIMAP_CHANNEL_DICT[self.method]
         self.att_thres, self.label_smooth = 0.3, 0.2          # FullModel_VMD's defaults (its forward serves VMN archs here too)
@@ -240,18 +245,18 @@ class FullModel(nn.Module):
         if self.method == 'fba':
             from . import fba_losses as FL
             x2, extras, _ = fba_network_input(prep, self.EPS)
-            pred = self.NET.run(x2[:, c].contiguous(), extras[:, c].contiguous(), prep.imgs[:, c].contiguous())
+            pred = ops.enter_backward(self.NET.run(x2[:, c].contiguous(), extras[:, c].contiguous(), prep.imgs[:, c].contiguous()), self.NET._bank)
             # the loss kernels take the window tensors and a frame index: predict "frame c of a clip whose interior is c"
             alphas = torch.zeros_like(prep.gts)
             comps, Fs, Bs = torch.zeros_like(prep.fgs), torch.zeros_like(prep.fgs), torch.zeros_like(prep.fgs)
             L1, L2, L3 = FL._FbaFrameLoss.apply(pred, prep.gts, prep.trimask, prep.fgs, prep.bgs, prep.imgs, c, alphas, comps, Fs, Bs)
             return [L1, L2, L3, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, Fs, Bs]
         if self.method == 'gca':
-            pred = self.NET.run(prep.x8[:, c].contiguous(), prep.unk[:, c, ::TAM_OS, ::TAM_OS].contiguous())
+            pred = ops.enter_backward(self.NET.run(prep.x8[:, c].contiguous(), prep.unk[:, c, ::TAM_OS, ::TAM_OS].contiguous()), self.NET._bank)
             L_alpha, _lc, _lg, alphas, comps = _SingleImageLoss.apply(prep, c, S, pred)
             zero = torch.zeros_like(L_alpha)                   # GCA: alpha loss only (models/model.py:110-114)
             return [L_alpha, zero, zero.clone(), prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
-        pred = self.NET.run(prep.x8[:, c].contiguous())
+        pred = ops.enter_backward(self.NET.run(prep.x8[:, c].contiguous()), self.NET._bank)
         L_alpha, L_comp, L_grad, alphas, comps = _SingleImageLoss.apply(prep, c, S, pred)
         return [L_alpha, L_comp, L_grad, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
 
@@ -276,7 +281,8 @@ class FullModel_VMD(FullModel):
             return self._forward_fba(prep, B, S, H, W)
         frames = [prep.x8[:, s].contiguous() for s in range(S)]
         prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
-        preds, attb, attf = self.NET.run(frames, prep.unk8)
+        # (fp16 build: the gradients the loss kernels send back into the network are scaled here -- ops.LOSS_SCALE)
+        preds, attb, attf = ops.enter_backward(self.NET.run(frames, prep.unk8), self.NET._bank)
         ni = S - 2
         tensors = [preds[c] for c in range(1, S - 1)] + [attb[c] for c in range(1, S - 1)] + [attf[c] for c in range(1, S - 1)]
         L_alpha, L_dt, L_att, alphas, comps = _WindowLoss.apply(prep, self.window, float(self.att_thres),
@@ -300,7 +306,7 @@ class FullModel_VMD(FullModel):
         from . import fba_losses as FL
         x2, extras, _tris = fba_network_input(prep, self.EPS)
         unk_small = prep.unk[:, :, ::TAM_OS, ::TAM_OS].contiguous()
-        pred, attb, attf = self.NET.run(x2, extras, prep.imgs, unk_small)
+        pred, attb, attf = ops.enter_backward(self.NET.run(x2, extras, prep.imgs, unk_small), self.NET._bank)
         norm = self.FBA_LOSS_NORMALIZE
         L1, L2, L3, alphas, comps, Fs, Bs = FL.fba_single_image_loss(pred, prep.trimask, prep.gts, prep.fgs, prep.bgs, prep.imgs, norm)
         L_att = FL.attention_loss(attb, attf, unk_small, prep.gts, self.window, float(self.att_thres), float(self.label_smooth), TAM_OS)
@@ -326,8 +332,8 @@ def fba_network_input(prep, eps, want_tris=False, use_dilated=True):
     from the user trimap itself (models/model.py:380-385) and the dilation only widens the blend / TAM mask."""
     B, S, _, H, W = prep.gts.shape
     dev = prep.gts.device
-    x2 = torch.empty((B, S, H // 2, W // 2, 64), dtype=torch.bfloat16, device=dev)
-    extras = torch.empty((B, S, H, W, 8), dtype=torch.bfloat16, device=dev)
+    x2 = torch.empty((B, S, H // 2, W // 2, 64), dtype=H16, device=dev)
+    extras = torch.empty((B, S, H, W, 8), dtype=H16, device=dev)
     tris = torch.empty((B, S, 8, H, W), dtype=torch.float32, device=dev) if want_tris else None
     scratch = torch.empty((B * S, 2, H, W), dtype=torch.float32, device=dev)
     L.call('tcvom_fba_input', L.ptr(prep.gts), L.ptr(prep.unk) if use_dilated else None, L.ptr(prep.imgs), L.ptr(x2), L.ptr(extras), L.ptr(tris),

@@ -113,6 +113,7 @@ class vmn_fba_decoder(nn.Module):
     def __init__(self, reduction, window, freeze_backbone=False, batch_norm=False, bank=None, with_fam=True):
         super().__init__()
         assert not batch_norm and bank is not None
+        object.__setattr__(self, '_bank', bank)
         self.batch_norm = batch_norm
         self.freeze_backbone = freeze_backbone
         self.ppm = nn.ModuleList([nn.Sequential(nn.AdaptiveAvgPool2d(s), nn.Conv2d(2048, 256, 1, bias=True), _gn(256), nn.LeakyReLU())
@@ -177,7 +178,7 @@ class vmn_fba_decoder(nn.Module):
         x = ops.conv_bn_act(cf['decoder.conv_up3.0'], ops.up2_concat(320, x, os2), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up4.0'], ops.up2_concat(128, x, extras), token, training)
         x = ops.conv_bn_act(cf['decoder.conv_up4.2'], x, token, training)
-        return ops.fba_head(x, self.conv_up4[4].weight, self.conv_up4[4].bias, img)
+        return ops.fba_head(x, ops.param_in(self.conv_up4[4].weight, self._bank), ops.param_in(self.conv_up4[4].bias, self._bank), img)
 
 
 class VMN_FBA(nn.Module):

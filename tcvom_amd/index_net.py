@@ -28,7 +28,7 @@ from .weights import ConvSpec, WeightBank
 # expand_ratio, input channels, output channels, blocks (net.py:108-116)
 SETTINGS = ((1, 32, 16, 1), (6, 16, 24, 2), (6, 24, 32, 3), (6, 32, 64, 4), (6, 64, 96, 3), (6, 96, 160, 3), (6, 160, 320, 1))
 ASPP_DILATIONS = (1, 2, 4, 8)
-BF16 = torch.bfloat16
+H16 = ops.H16
 
 
 def _conv_bn(inp, oup, k):
@@ -178,13 +178,15 @@ class ASPP(nn.Module):
         b = self.bottleneck_conv
         reg.conv(name + '.bottleneck_conv.0', b[0], b[1], ACT_RELU6)
         self._name = name
+        object.__setattr__(self, '_bank', reg.bank)
 
     def _image_pool(self, x, nf, training):
         """AdaptiveAvgPool2d(1) + 1x1 conv + BatchNorm over the B samples of each frame + ReLU6 on [N, 320] vectors (a few KB:
         tensor expressions).  The nf frames of a frame-batched call are separate BatchNorm calls."""
         conv, bn = self.global_avg_pool[1], self.global_avg_pool[2]
+        bank = self._bank
         N, h, w, Cc = x.shape
-        g = x.float().mean((1, 2)) @ conv.weight.reshape(conv.weight.shape[0], Cc).t()          # [N, 256]
+        g = x.float().mean((1, 2)) @ ops.param_in(conv.weight, bank).reshape(conv.weight.shape[0], Cc).t()          # [N, 256]
         if training:
             B = N // nf
             sync = ops._sync_group(bn)
@@ -208,8 +210,8 @@ class ASPP(nn.Module):
                 bn.num_batches_tracked += nf
         else:
             out = (g - bn.running_mean) / torch.sqrt(bn.running_var + bn.eps)
-        out = F.relu6(out * bn.weight + bn.bias)
-        return out.to(BF16).reshape(N, 1, 1, -1).expand(N, h, w, out.shape[1])
+        out = F.relu6(out * ops.param_in(bn.weight, bank) + ops.param_in(bn.bias, bank))
+        return out.to(H16).reshape(N, 1, 1, -1).expand(N, h, w, out.shape[1])
 
     def run(self, cf, x, token, training, nf):
         n = self._name
@@ -326,7 +328,7 @@ class IndexMattingDecoder_VMN(nn.Module):
         l = self._up(0, l, l0, idx0, token, training)
         # pred: 5x5 conv 32 -> 1 (HIP), then BatchNorm over ONE channel + ReLU6 + 5x5 conv 1 -> 1 on a [N, 1, H, W] fp32 map
         conv0, bn, conv1 = self.pred[0][0], self.pred[0][1], self.pred[1]
-        p = ops.head_conv(l, conv0.weight, self._zero_bias, 5, 2)
+        p = ops.head_conv(l, ops.param_in(conv0.weight, self._bank), self._zero_bias, 5, 2)
         nf = self._bank.frames_per_op
         N = p.shape[0]
         # BatchNorm over ONE channel as tensor expressions (a library BatchNorm kernel runs a single-channel map on one
@@ -349,8 +351,8 @@ class IndexMattingDecoder_VMN(nn.Module):
                 bn.num_batches_tracked += nf
         else:
             p = (p - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps)
-        p = p * bn.weight + bn.bias
-        return ops.conv5x5_c1(F.relu6(p), conv1.weight)
+        p = p * ops.param_in(bn.weight, self._bank) + ops.param_in(bn.bias, self._bank)
+        return ops.conv5x5_c1(F.relu6(p), ops.param_in(conv1.weight, self._bank))
 
 
 def build_vmn_index(agg_window, agg_reduction=1, freeze_backbone=False):

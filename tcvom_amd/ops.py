@@ -14,7 +14,64 @@ from .conv_plan import ConvGeometry, dense_desc, dense_tt_desc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_LEAKY01 = 0, 1, 2, 3        # LeakyReLU(0.2) (GCA decoder) / nn.LeakyReLU() default 0.01 (FBA)
 ACT_RELU6 = 4                                                  # IndexNet / MobileNetV2 blocks
-BF16 = torch.bfloat16
+H16 = L.ACT_DTYPE            # torch.bfloat16 or torch.float16: the 16-bit storage type of the loaded library
+
+
+# ---- loss scale of the fp16 build
+# fp16 has 5 exponent bits: activation GRADIENTS (1e-5 .. 1e-9 at 1080p: the losses are means over ~1e5 unknown pixels) would fall
+# into its denormals.  A network built by the facade in the fp16 build therefore runs its whole backward under a constant scale,
+# invisibly to the caller: the gradients entering the network (d loss / d prediction, d loss / d attention logits: fp32 tensors
+# produced by the loss kernels) are multiplied by `bank.loss_scale` (`enter_backward`), and every parameter gradient leaving it
+# is multiplied by its inverse -- the bank's flat weight gradient and BatchNorm arena (weights.py), the bias gradients of the
+# conv ops below (they know their bank), and the parameters that enter through plain tensor expressions or bank-less ops
+# (`param_in` at the call site) -- so .grad holds the same values as in the bf16 build and in the reference.  With the formula
+# weights the per-layer gradient maxima sit at 1e-5 .. 4e-3: 2^16 puts them at 1 .. 300, far from both ends of fp16 (65504 /
+# 6e-5); the 16-bit conversions saturate instead of producing inf (csrc/common.h).  A WeightBank starts with loss_scale 1:
+# ops called directly (tests, tools) are not scaled.  bf16 (8 exponent bits) needs none.
+import os as _os
+LOSS_SCALE = float(_os.environ.get('TCVOM_LOSS_SCALE', '65536' if L.DTYPE_NAME == 'fp16' else '1'))
+
+
+class _ScaleGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, s):
+        ctx.s = s
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def scale_grad(t, s):
+    """Identity whose backward multiplies the gradient by s."""
+    if t is None or s == 1.0 or not torch.is_tensor(t) or not t.requires_grad:
+        return t
+    return _ScaleGrad.apply(t, s)
+
+
+def enter_backward(outs, bank):
+    """Network outputs on their way to the loss kernels: the gradients coming back are scaled by bank.loss_scale."""
+    s = bank.loss_scale
+    if s == 1.0:
+        return outs
+    if isinstance(outs, (list, tuple)):
+        return type(outs)(enter_backward(o, bank) for o in outs)
+    return scale_grad(outs, s)
+
+
+def param_in(p, bank):
+    """A parameter that enters the network through a tensor expression or a bank-less op (head convs): its gradient is
+    unscaled on the way out."""
+    return scale_grad(p, 1.0 / bank.loss_scale)
+
+
+def _unscale_(bank, *grads):
+    """Parameter gradients computed by an op inside the scaled backward, on their way out (in place)."""
+    if bank.loss_scale != 1.0:
+        for g in grads:
+            if g is not None:
+                g.mul_(1.0 / bank.loss_scale)
 
 
 def _need_cuda(t):
@@ -145,7 +202,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.set_materialize_grads(False)             # every consumer may have deposited: then autograd hands over None
         x = _c(x)
         NT, H, W, Cx = x.shape
-        assert Cx == spec.cpad and x.dtype == BF16, 'conv %s: input %s %s, expected %d channels' % (
+        assert Cx == spec.cpad and x.dtype == H16, 'conv %s: input %s %s, expected %d channels' % (
             spec.name, tuple(x.shape), x.dtype, spec.cpad)
         nf = bank.frames_per_op
         assert NT % nf == 0
@@ -157,7 +214,7 @@ class _ConvBNAct(torch.autograd.Function):
         has_bn = bn is not None
         # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
         hp = spec.hp and has_bn
-        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=torch.float32 if hp else BF16, device=x.device)
+        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=torch.float32 if hp else H16, device=x.device)
         stats = None
         gn = cfg.group_norm
         if gn:
@@ -215,7 +272,7 @@ class _ConvBNAct(torch.autograd.Function):
             L.call('tcvom_bn_eval_coeffs', K, L.ptr(gamma), L.ptr(beta), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                    float(bn.eps), ss, saved, st)
         ctx.sync, ctx.ss, ctx.saved, ctx.window_id, ctx.slot_stride = sync, ss, saved, bank.window_id, slot_stride
-        z = torch.empty((NT, geo.OH, geo.OW, K), dtype=BF16, device=x.device)
+        z = torch.empty((NT, geo.OH, geo.OW, K), dtype=H16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
         L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0,
@@ -287,9 +344,9 @@ class _ConvBNAct(torch.autograd.Function):
                 dist.all_reduce(total, group=group)
                 L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
                        dgp, dbp, L.ptr(coef), 1, nf, stride, st)
-            dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
+            dy = torch.empty(y.shape, dtype=H16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
-                dres1 = torch.empty(y.shape, dtype=BF16, device=dz.device)
+                dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
             L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
                    L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
             if ctx.has_bias:
@@ -302,7 +359,7 @@ class _ConvBNAct(torch.autograd.Function):
             # zero-padded concat inputs (spec.cpad > spec.C): the gradient keeps the padded layout, zeros in the padding
             cx = spec.cpad if spec.cpad > 8 else spec.C
             alloc = torch.zeros if cx != spec.C else torch.empty
-            dx = alloc((geo.N * nf, geo.H, geo.W, cx), dtype=BF16, device=dz.device)
+            dx = alloc((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dz.device)
             _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st, nf, ctx.wsb)
         # the weight gradients are deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
         bank.defer_wgrad(spec, ctx.call, dy, x, geo, nf)
@@ -316,6 +373,7 @@ class _ConvBNAct(torch.autograd.Function):
         if dx is not None and ctx.x_stash is not None and dx.shape == x.shape:
             ctx.x_stash.append(dx)                         # likewise the data gradient, when the input came from such an op
             dx = None
+        _unscale_(bank, dbias)
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None, None
 
 
@@ -338,7 +396,7 @@ class _DwBNAct(torch.autograd.Function):
         bank, bn = cfg.bank, cfg.bn
         x = _c(x)
         NT, H, W, Cc = x.shape
-        assert x.dtype == BF16 and tuple(weight.shape) == (Cc, 1, 3, 3)
+        assert x.dtype == H16 and tuple(weight.shape) == (Cc, 1, 3, 3)
         sync = _sync_group(bn) if training else None
         nf = bank.frames_per_op
         assert NT % nf == 0
@@ -347,7 +405,7 @@ class _DwBNAct(torch.autograd.Function):
         OH, OW = H + 2 * p - 2 * d, W + 2 * p - 2 * d
         st = L.stream_ptr()
         wt = weight.detach().reshape(Cc, 9).t().contiguous().float()          # [9][C] tap-major
-        y = torch.empty((NT, OH, OW, Cc), dtype=BF16, device=x.device)
+        y = torch.empty((NT, OH, OW, Cc), dtype=H16, device=x.device)
         P = N * OH * OW
         stats, groups = None, 0
         if training:
@@ -416,16 +474,17 @@ class _DwBNAct(torch.autograd.Function):
             dist.all_reduce(total, group=group)
             L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), Cc, P * world, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef),
                    1, nf, stride, st)
-        dy = torch.empty(y.shape, dtype=BF16, device=dz.device)
+        dy = torch.empty(y.shape, dtype=H16, device=dz.device)
         L.call('tcvom_bn_bwd_apply', L.ptr(dz), None, L.ptr(y), None, ss, saved, L.ptr(coef), L.ptr(dy), None, P, Cc, cfg.act,
                1 if ctx.training else 0, 0, 0, nf, stride, st)
         d, p = cfg.dilation, cfg.pad
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(x.shape, dtype=BF16, device=dz.device)
+            dx = torch.empty(x.shape, dtype=H16, device=dz.device)
             L.call('tcvom_dw3x3', L.ptr(dy), L.ptr(wt), L.ptr(dx), None, N, OH, OW, Cc, d, 2 * d - p, 1, nf, st)
         dw = torch.empty((9, Cc), dtype=torch.float32, device=dz.device)
         L.call('tcvom_dw3x3_wgrad', L.ptr(dy), L.ptr(x), L.ptr(dw), N, H, W, Cc, d, p, nf, st)
+        _unscale_(bank, dw)
         return dx, None, dw.t().reshape(Cc, 1, 3, 3), None, None, None, None
 
 
@@ -442,7 +501,7 @@ class _IndexPool(torch.autograd.Function):
     def forward(ctx, x1, x2, x3, x4, l):
         x1, x2, x3, x4, l = _c(x1), _c(x2), _c(x3), _c(x4), _c(l)
         N, h2, w2, Cc = x1.shape
-        assert tuple(l.shape) == (N, 2 * h2, 2 * w2, Cc) and l.dtype == BF16
+        assert tuple(l.shape) == (N, 2 * h2, 2 * w2, Cc) and l.dtype == H16
         xe, de = torch.empty_like(l), torch.empty_like(l)
         pooled = torch.empty_like(x1)
         L.call('tcvom_index_pool_fwd', L.ptr(x1), L.ptr(x2), L.ptr(x3), L.ptr(x4), L.ptr(l), L.ptr(xe), L.ptr(pooled), L.ptr(de),
@@ -471,7 +530,7 @@ class _IndexUp(torch.autograd.Function):
         idx = _c(idx) if idx is not None else None
         N, H, W, C2 = low.shape
         C1 = enc.shape[3]
-        out = torch.empty((N, H, W, C1 + C2), dtype=BF16, device=low.device)
+        out = torch.empty((N, H, W, C1 + C2), dtype=H16, device=low.device)
         L.call('tcvom_index_up_fwd', L.ptr(enc), L.ptr(idx), L.ptr(low), L.ptr(out), N, H, W, C1, C2, L.stream_ptr())
         ctx.save_for_backward(enc, idx)
         ctx.dims = (N, H, W, C1, C2)
@@ -484,7 +543,7 @@ class _IndexUp(torch.autograd.Function):
         dout = _c(dout)
         denc = torch.empty_like(enc)
         didx = torch.empty_like(idx) if idx is not None else None
-        dlow = torch.empty((N, H, W, C2), dtype=BF16, device=dout.device)
+        dlow = torch.empty((N, H, W, C2), dtype=H16, device=dout.device)
         L.call('tcvom_index_up_bwd', L.ptr(dout), L.ptr(enc), L.ptr(idx), L.ptr(denc), L.ptr(didx), L.ptr(dlow), N, H, W, C1, C2,
                L.stream_ptr())
         return denc, didx, dlow
@@ -544,7 +603,7 @@ class _AvgPool2(torch.autograd.Function):
     def forward(ctx, x):
         x = _c(x)
         N, H, W, Cc = x.shape
-        y = torch.empty((N, H // 2, W // 2, Cc), dtype=BF16, device=x.device)
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=H16, device=x.device)
         L.call('tcvom_avgpool2', L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream_ptr())
         ctx.shape = (N, H, W, Cc)
         return y
@@ -552,7 +611,7 @@ class _AvgPool2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         N, H, W, Cc = ctx.shape
-        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        dx = torch.empty(ctx.shape, dtype=H16, device=dy.device)
         L.call('tcvom_upsample2', L.ptr(_c(dy)), L.ptr(dx), N, H, W, Cc, 0.25, L.stream_ptr())
         return dx
 
@@ -562,7 +621,7 @@ class _Upsample2(torch.autograd.Function):
     def forward(ctx, y):
         y = _c(y)
         N, h, w, Cc = y.shape
-        x = torch.empty((N, 2 * h, 2 * w, Cc), dtype=BF16, device=y.device)
+        x = torch.empty((N, 2 * h, 2 * w, Cc), dtype=H16, device=y.device)
         L.call('tcvom_upsample2', L.ptr(y), L.ptr(x), N, 2 * h, 2 * w, Cc, 1.0, L.stream_ptr())
         ctx.shape = (N, h, w, Cc)
         return x
@@ -570,7 +629,7 @@ class _Upsample2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx):
         N, h, w, Cc = ctx.shape
-        dy = torch.empty(ctx.shape, dtype=BF16, device=dx.device)
+        dy = torch.empty(ctx.shape, dtype=H16, device=dx.device)
         L.call('tcvom_sumpool2', L.ptr(_c(dx)), L.ptr(dy), N, 2 * h, 2 * w, Cc, 1.0, L.stream_ptr())
         return dy
 
@@ -580,7 +639,7 @@ class _ReflectPad1(torch.autograd.Function):
     def forward(ctx, x):
         x = _c(x)
         N, H, W, Cc = x.shape
-        y = torch.empty((N, H + 2, W + 2, Cc), dtype=BF16, device=x.device)
+        y = torch.empty((N, H + 2, W + 2, Cc), dtype=H16, device=x.device)
         L.call('tcvom_reflect_pad1', L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream_ptr())
         ctx.shape = (N, H, W, Cc)
         return y
@@ -588,7 +647,7 @@ class _ReflectPad1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         N, H, W, Cc = ctx.shape
-        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        dx = torch.empty(ctx.shape, dtype=H16, device=dy.device)
         L.call('tcvom_reflect_pad1_bwd', L.ptr(_c(dy)), L.ptr(dx), N, H, W, Cc, L.stream_ptr())
         return dx
 
@@ -608,7 +667,7 @@ class _MaxPool2Idx(torch.autograd.Function):
     def forward(ctx, x):
         x = _c(x)
         N, H, W, Cc = x.shape
-        y = torch.empty((N, H // 2, W // 2, Cc), dtype=BF16, device=x.device)
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=H16, device=x.device)
         idx = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.uint8, device=x.device)
         L.call('tcvom_maxpool2_idx', L.ptr(x), L.ptr(y), L.ptr(idx), N, H, W, Cc, L.stream_ptr())
         ctx.save_for_backward(idx)
@@ -620,7 +679,7 @@ class _MaxPool2Idx(torch.autograd.Function):
     def backward(ctx, dy, _didx):
         (idx,) = ctx.saved_tensors
         N, H, W, Cc = ctx.shape
-        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        dx = torch.empty(ctx.shape, dtype=H16, device=dy.device)
         L.call('tcvom_unpool2', L.ptr(_c(dy)), L.ptr(idx), L.ptr(dx), N, H, W, Cc, L.stream_ptr())
         return dx
 
@@ -632,7 +691,7 @@ class _Unpool2(torch.autograd.Function):
     def forward(ctx, y, idx):
         y = _c(y)
         N, h, w, Cc = y.shape
-        x = torch.empty((N, 2 * h, 2 * w, Cc), dtype=BF16, device=y.device)
+        x = torch.empty((N, 2 * h, 2 * w, Cc), dtype=H16, device=y.device)
         L.call('tcvom_unpool2', L.ptr(y), L.ptr(idx), L.ptr(x), N, 2 * h, 2 * w, Cc, L.stream_ptr())
         ctx.save_for_backward(idx)
         return x
@@ -641,7 +700,7 @@ class _Unpool2(torch.autograd.Function):
     def backward(ctx, dx):
         (idx,) = ctx.saved_tensors
         N, H, W, Cc = dx.shape
-        dy = torch.empty((N, H // 2, W // 2, Cc), dtype=BF16, device=dx.device)
+        dy = torch.empty((N, H // 2, W // 2, Cc), dtype=H16, device=dx.device)
         L.call('tcvom_pick2', L.ptr(_c(dx)), L.ptr(idx), L.ptr(dy), N, H, W, Cc, L.stream_ptr())
         return dy, None
 
@@ -659,9 +718,9 @@ class _ConvUnfoldDense(torch.autograd.Function):
         call = bank.next_call(spec)
         st = L.stream_ptr()
         P, K, kred = N * H * W, spec.K, spec.T * Cc
-        u = torch.empty((P, kred), dtype=BF16, device=x.device)
+        u = torch.empty((P, kred), dtype=H16, device=x.device)
         L.call('tcvom_unfold', L.ptr(x), L.ptr(u), N, H, W, Cc, spec.R, st)
-        y = torch.empty((N, H, W, K), dtype=BF16, device=x.device)
+        y = torch.empty((N, H, W, K), dtype=H16, device=x.device)
         d = dense_desc(P, K, kred, K)
         d.act = ACT_RELU
         L.call('tcvom_conv_igemm', L.ptr(u), bank.fwd_ptr(spec, call), L.ptr(y), L.ptr(bias), None, None, None, C.byref(d), st)
@@ -682,12 +741,13 @@ class _ConvUnfoldDense(torch.autograd.Function):
         dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
         L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P, K, K, st)
         # du[p][c*T + t] = sum_k dy[p][k] w[k][t][c]: the data-gradient weights are packed [C][T][K]
-        du = torch.empty((P, kred), dtype=BF16, device=dz.device)
+        du = torch.empty((P, kred), dtype=H16, device=dz.device)
         L.call('tcvom_conv_igemm', L.ptr(dy), bank.bwd_ptr(spec, ctx.call), L.ptr(du), None, None, None, None,
                C.byref(dense_desc(P, kred, K, kred)), st)
-        dx = torch.empty((N, H, W, Cc), dtype=BF16, device=dz.device)
+        dx = torch.empty((N, H, W, Cc), dtype=H16, device=dz.device)
         L.call('tcvom_fold', L.ptr(du), L.ptr(dx), N, H, W, Cc, spec.R, st)
         L.call('tcvom_wgrad_igemm', L.ptr(dy), L.ptr(u), bank.dw_ptr(spec, ctx.call), C.byref(dense_tt_desc(P, K, kred)), K, st)
+        _unscale_(bank, dbias)
         return dx, None, dbias, None
 
 
@@ -751,7 +811,7 @@ class _MaxPool3S2(torch.autograd.Function):
         x = _c(x)
         N, H, W, Cc = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty((N, OH, OW, Cc), dtype=BF16, device=x.device)
+        y = torch.empty((N, OH, OW, Cc), dtype=H16, device=x.device)
         idx = torch.empty((N, OH, OW, Cc), dtype=torch.uint8, device=x.device)
         L.call('tcvom_maxpool3s2', L.ptr(x), L.ptr(y), L.ptr(idx), N, H, W, Cc, L.stream_ptr())
         ctx.save_for_backward(idx)
@@ -762,7 +822,7 @@ class _MaxPool3S2(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         N, H, W, Cc = ctx.shape
-        dx = torch.empty(ctx.shape, dtype=BF16, device=dy.device)
+        dx = torch.empty(ctx.shape, dtype=H16, device=dy.device)
         L.call('tcvom_maxpool3s2_bwd', L.ptr(_c(dy)), L.ptr(idx), L.ptr(dx), N, H, W, Cc, L.stream_ptr())
         return dx
 
@@ -780,7 +840,7 @@ class _PyramidPool(torch.autograd.Function):
         for s in scales:
             o = torch.empty((N, s, s, Cc), dtype=torch.float32, device=x.device)
             L.call('tcvom_adaptive_avgpool', L.ptr(x), L.ptr(o), N, h, w, Cc, s, st)
-            outs.append(o.to(BF16))
+            outs.append(o.to(H16))
         ctx.shape, ctx.scales = (N, h, w, Cc), tuple(scales)
         return tuple(outs)
 
@@ -791,7 +851,7 @@ class _PyramidPool(torch.autograd.Function):
         n = len(gs)
         ptrs = (C.c_void_p * n)(*[g.data_ptr() for g in gs])
         sc = (C.c_int32 * n)(*ctx.scales)
-        dx = torch.empty(ctx.shape, dtype=BF16, device=gs[0].device)
+        dx = torch.empty(ctx.shape, dtype=H16, device=gs[0].device)
         L.call('tcvom_adaptive_avgpool_bwd', C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, L.ptr(dx), N, h, w, Cc, L.stream_ptr())
         return dx, None
 
@@ -804,7 +864,7 @@ class _PyramidConcat(torch.autograd.Function):
         x = _c(x)
         N, h, w, Cx = x.shape
         st = L.stream_ptr()
-        buf = torch.zeros((N, h, w, cpad), dtype=BF16, device=x.device)
+        buf = torch.zeros((N, h, w, cpad), dtype=H16, device=x.device)
         buf[..., :Cx].copy_(x)
         off = Cx
         shapes = []
@@ -828,7 +888,7 @@ class _PyramidConcat(torch.autograd.Function):
         for hs, ws, Cm, off in shapes:
             d = torch.empty((N, hs, ws, Cm), dtype=torch.float32, device=dbuf.device)
             L.call('tcvom_bilinear_small_bwd', L.ptr(dbuf), L.ptr(d), N, hs, ws, h, w, Cm, cpad, off, st)
-            dmaps.append(d.to(BF16))
+            dmaps.append(d.to(H16))
         return (None, dx) + tuple(dmaps)
 
 
@@ -842,7 +902,7 @@ class _Up2Concat(torch.autograd.Function):
         N, h, w, Cx = x.shape
         Cs = skip.shape[3]
         assert skip.shape[:3] == (N, 2 * h, 2 * w) and Cx + Cs <= cpad and Cx % 8 == 0
-        buf = torch.empty((N, 2 * h, 2 * w, cpad), dtype=BF16, device=x.device)
+        buf = torch.empty((N, 2 * h, 2 * w, cpad), dtype=H16, device=x.device)
         L.call('tcvom_bilinear', L.ptr(x), L.ptr(buf), N, h, w, 2 * h, 2 * w, Cx, Cx, 0, cpad, 0, L.stream_ptr())
         buf[..., Cx:Cx + Cs].copy_(skip)
         if Cx + Cs < cpad:
@@ -854,7 +914,7 @@ class _Up2Concat(torch.autograd.Function):
     def backward(ctx, dbuf):
         N, h, w, Cx, Cs, cpad = ctx.geo
         dbuf = _c(dbuf)
-        dx = torch.empty((N, h, w, Cx), dtype=BF16, device=dbuf.device)
+        dx = torch.empty((N, h, w, Cx), dtype=H16, device=dbuf.device)
         L.call('tcvom_bilinear_up2_bwd', L.ptr(dbuf), L.ptr(dx), N, h, w, Cx, cpad, 0, L.stream_ptr())
         dskip = dbuf[..., Cx:Cx + Cs].contiguous() if ctx.needs_input_grad[2] else None
         return None, dx, dskip
@@ -958,6 +1018,11 @@ def _r64(n):
     return (n + 63) // 64 * 64
 
 
+# study knob: run the attention GEMM chains frame by frame when a frame's probability matrix fits the Infinity Cache
+GCA_CHAIN = _os.environ.get('TCVOM_GCA_CHAIN', '0') == '1'
+GCA_CHAIN_BYTES = 200 << 20
+
+
 class _GcaAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g8, alpha, unk_u8):
@@ -969,7 +1034,7 @@ class _GcaAttention(torch.autograd.Function):
         N = (h8 // 2) * (w8 // 2)
         ld = _r64(N)
         D, DV = 9 * CG, 16 * Ca
-        G = torch.empty((B, N, D), dtype=BF16, device=dev)
+        G = torch.empty((B, N, D), dtype=H16, device=dev)
         scales = torch.empty((B, 2), dtype=torch.float32, device=dev)
         cvec = torch.empty((B, N), dtype=torch.float32, device=dev)
         dvec = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -977,23 +1042,37 @@ class _GcaAttention(torch.autograd.Function):
         L.call('tcvom_gca_prepare', L.ptr(g8), L.ptr(unk_u8), L.ptr(G), L.ptr(scales), L.ptr(cvec), L.ptr(dvec), L.ptr(nrm),
                B, h8, w8, CG, st)
         # S'[i][j] = c_j <G_i, G_j> - d_j [i==j]     (rows m = keys j, columns n = queries i)
-        S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
-        d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
-        P = torch.empty((B, N, ld), dtype=BF16, device=dev)
-        L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
-        del S
-        V = torch.empty((B, N, DV), dtype=BF16, device=dev)
+        V = torch.empty((B, N, DV), dtype=H16, device=dev)
         L.call('tcvom_gca_value_patches', L.ptr(alpha), L.ptr(V), B, h8, w8, Ca, st)
-        Vt = torch.empty((B, DV, ld), dtype=BF16, device=dev)
+        Vt = torch.empty((B, DV, ld), dtype=H16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(V), L.ptr(Vt), N, DV, DV, ld, B, N * DV, DV * ld, st)
+        P = torch.empty((B, N, ld), dtype=H16, device=dev)
         # O[i][v] = sum_j P[i][j] V[j][v]             (rows m = v, columns n = queries i, reduce j)
         # (fp32: the backward forms sum_j P dP as <dO_i, O_i>; with a peaked softmax dP[i][i] - <dO_i, O_i> cancels to ~0 and
         # a bf16-rounded O would leave its rounding error as the gradient)
         O = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
-        d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
-        y = torch.empty((B, h8, w8, Ca), dtype=BF16, device=dev)
+        if GCA_CHAIN and B > 1 and N * ld * 2 <= GCA_CHAIN_BYTES:
+            # Frame by frame: scores -> softmax -> P V of ONE frame back to back, so that the frame's P (N x ld 16-bit, 133 MB at
+            # 1080p) is still in the 256 MB Infinity Cache when the P V GEMM reads it (with all frames per launch the softmax of
+            # the last frame has evicted the first frame's P long before its GEMM runs).  The per-frame launches still fill
+            # the chip (1024 / 256 tiles of 256 x 256)
+            S = torch.empty((N, ld), dtype=torch.float32, device=dev)
+            d = dense_desc(N, N, D, ld, out_fp32=True)
+            d2 = dense_desc(N, DV, ld, DV, out_fp32=True)
+            for b in range(B):
+                L.call('tcvom_conv_igemm', L.ptr(G[b]), L.ptr(G[b]), L.ptr(S), None, L.ptr(cvec[b]), L.ptr(dvec[b]), None, C.byref(d), st)
+                L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P[b]), N, N, ld, ld, st)
+                L.call('tcvom_conv_igemm', L.ptr(P[b]), L.ptr(Vt[b]), L.ptr(O[b]), None, None, None, None, C.byref(d2), st)
+            del S
+        else:
+            S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
+            d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
+            L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
+            L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
+            del S
+            d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
+            L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
+        y = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_fold_f32', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
         ctx.save_for_backward(G, P, V, cvec, nrm, O)
         ctx.dims = (B, h8, w8, CG, Ca, N, ld)
@@ -1008,18 +1087,18 @@ class _GcaAttention(torch.autograd.Function):
         dev = G.device
         st = L.stream_ptr()
         dy = _c(dy)
-        dO = torch.empty((B, N, DV), dtype=BF16, device=dev)
+        dO = torch.empty((B, N, DV), dtype=H16, device=dev)
         L.call('tcvom_gca_unfold', L.ptr(dy), L.ptr(dO), B, h8, w8, Ca, st)
         # T = softmax_bwd(P, dP) * c_j with dP[i][j] = sum_v dO[i][v] V[j][v]: ONE GEMM whose epilogue applies the softmax
         # backward (the row sums sum_j P dP are <dO_i, O_i>): no fp32 N x N dP matrix, no separate softmax-backward pass
         delta = torch.empty((B, N), dtype=torch.float32, device=dev)
         L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
-        T = torch.empty((B, N, ld), dtype=BF16, device=dev)
+        T = torch.empty((B, N, ld), dtype=H16, device=dev)
         # the same epilogue also writes the transposed copies P^T and T^T that the dV and M' GEMMs read (when the padded row length
         # is a whole number of 256-wide tiles; otherwise two transpose passes)
         fused_t = ld % 256 == 0
-        Pt = torch.empty((B, ld, ld), dtype=BF16, device=dev)
-        Tt = torch.empty((B, ld, ld), dtype=BF16, device=dev)
+        Pt = torch.empty((B, ld, ld), dtype=H16, device=dev)
+        Tt = torch.empty((B, ld, ld), dtype=H16, device=dev)
         L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T),
                L.ptr(Tt) if fused_t else None, L.ptr(Pt) if fused_t else None, N, DV, ld, B, st)
         # dV[j][v] = sum_i P[i][j] dO[i][v]: as an NT GEMM on the transposed operands (Pt = P^T, dOt = dO^T) it runs on the
@@ -1027,14 +1106,14 @@ class _GcaAttention(torch.autograd.Function):
         # 270 + 80 us of transposes here
         if not fused_t:
             L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Pt), N, ld, ld, ld, B, N * ld, ld * ld, st)
-        dOt = torch.empty((B, DV, ld), dtype=BF16, device=dev)
+        dOt = torch.empty((B, DV, ld), dtype=H16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(dO), L.ptr(dOt), N, DV, DV, ld, B, N * DV, DV * ld, st)
         dV = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
         d4 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=ld * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
         L.call('tcvom_conv_igemm', L.ptr(Pt), L.ptr(dOt), L.ptr(dV), None, None, None, None, C.byref(d4), st)
         del Pt, dOt
         dWq = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-        Gt = torch.empty((B, D, ld), dtype=BF16, device=dev)
+        Gt = torch.empty((B, D, ld), dtype=H16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(G), L.ptr(Gt), N, D, D, ld, B, N * D, D * ld, st)
         # dWq[i][d] = sum_j T[i][j] G[j][d]            (rows m = d, columns n = queries i, reduce j)
         # M'[j][d]  = sum_i T[i][j] G[i][d]: like dV, an NT GEMM on the transposed operand (Tt = T^T) on the 256-pixel tiles
@@ -1047,9 +1126,9 @@ class _GcaAttention(torch.autograd.Function):
         d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
         L.call('tcvom_gemm_pair', L.ptr(T), L.ptr(Tt), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), C.byref(d3), ld * ld, st)
         del Tt
-        dalpha = torch.empty((B, h8, w8, Ca), dtype=BF16, device=dev)
+        dalpha = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_value_patches_bwd', L.ptr(dV), L.ptr(dalpha), B, h8, w8, Ca, st)
-        dg8 = torch.empty((B, h8, w8, CG), dtype=BF16, device=dev)
+        dg8 = torch.empty((B, h8, w8, CG), dtype=H16, device=dev)
         L.call('tcvom_gca_patches_bwd', L.ptr(dWq), L.ptr(Mp), L.ptr(G), L.ptr(nrm), L.ptr(dg8), B, h8, w8, CG, st)
         return dg8, dalpha, None
 

@@ -4,12 +4,12 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ConvCfg
+from .ops import ConvCfg, H16
 from .weights import ConvSpec, WeightBank, bank_token
 
 
 def _to_nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    return t.permute(0, 2, 3, 1).contiguous().to(H16)
 
 
 def _to_nchw(t):
@@ -186,8 +186,8 @@ class VMN(nn.Module):
         for i in range(S):
             img = images[i].squeeze(1)
             B, Cc, H, W = img.shape
-            x8 = torch.zeros((B, H, W, 8), dtype=torch.bfloat16, device=img.device)
-            x8[..., :Cc] = img.permute(0, 2, 3, 1).to(torch.bfloat16)
+            x8 = torch.zeros((B, H, W, 8), dtype=H16, device=img.device)
+            x8[..., :Cc] = img.permute(0, 2, 3, 1).to(H16)
             frames.append(x8)
             m = masks[i].squeeze(1)
             unks.append((m[:, 0, ::8, ::8] != 0).to(torch.uint8).contiguous())

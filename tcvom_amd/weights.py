@@ -16,6 +16,7 @@ import struct
 import torch
 
 from . import _lib as L
+from ._lib import ACT_DTYPE as H16
 
 TILED_PACK = os.environ.get('TCVOM_SN_PACK_TILED', '1') != '0'      # 0: one thread per packed element (A/B, tests)
 WS_FRAG = os.environ.get('TCVOM_NO_WSCONV') is None                 # the same switch that disables the kernel in the library
@@ -107,6 +108,7 @@ class WeightBank(object):
         self.frames_per_op = 1              # >1 while VMN.run pushes the S frames of a window through the layers together
         self._deferred = []
         self.grad_span_hook = None        # callable(flat_grad, lo, hi): a finished span of the flat gradient (ddp.py)
+        self.loss_scale = 1.0             # the facade sets ops.LOSS_SCALE on the banks of an fp16 network (ops.py)
 
     # ------------------------------------------------------------------ BatchNorm bookkeeping
     # Every BatchNorm call of a window gets a fixed slot in one arena for its (scale, shift) and (mean, invstd)
@@ -179,7 +181,8 @@ class WeightBank(object):
         """Gradients of (weight, bias) of every BatchNorm that ran a backward in this window (None for the others)."""
         if not self.bns:
             return []
-        g = self.bn_grad.clone()
+        inv = 1.0 / self.loss_scale
+        g = self.bn_grad.clone() if inv == 1.0 else self.bn_grad * inv      # (fp16 build: the backward ran under the loss scale)
         out = []
         for bn, hit in zip(self.bns, self.bn_touched):
             o, Cn = 2 * bn._tcvom_ch_off, _nch(bn)
@@ -293,8 +296,8 @@ class WeightBank(object):
         dev = self.device
         nl = len(self.specs)
         self.max_calls = ncalls
-        self.fwd_arena = torch.zeros(ncalls * self.fwd_stride, dtype=torch.bfloat16, device=dev)
-        self.bwd_arena = torch.zeros(max(1, ncalls * self.bwd_stride), dtype=torch.bfloat16, device=dev)
+        self.fwd_arena = torch.zeros(ncalls * self.fwd_stride, dtype=H16, device=dev)
+        self.bwd_arena = torch.zeros(max(1, ncalls * self.bwd_stride), dtype=H16, device=dev)
         self.dw_arena = torch.zeros(ncalls * self.dw_stride, dtype=torch.float32, device=dev)
         self.sigma = torch.ones(ncalls * nl, device=dev)
         self.uhist = torch.zeros(ncalls * self.sum_h, device=dev)
@@ -548,6 +551,7 @@ class WeightBank(object):
         grad = torch.empty(self.grad_numel, dtype=torch.float32, device=self.device)
         st = L.stream_ptr()
         hook = self.grad_span_hook
+        inv = 1.0 / self.loss_scale
         chunks = self._chunks(plan) if hook is not None else [(0, len(self.specs), 0, self.grad_numel, 0, plan['n_inner'], 0, self.n_apply)]
         for lo, hi, g0, g1, i0, ni, a0, na in chunks:
             self.run_deferred_wgrads(None if len(chunks) == 1 else (lo, hi))
@@ -561,6 +565,8 @@ class WeightBank(object):
                     w0 = self._ws_rows.index(rows[0])
                     L.call('tcvom_ws_backward', L.ptr(self.table), C.c_void_p(self.work_ws.data_ptr() + 8 * w0), len(rows),
                            L.ptr(grad), st)
+            if inv != 1.0:                                 # (fp16 build: the backward ran under the loss scale, ops.py)
+                grad[g0:g1].mul_(inv)
             if hook is not None:
                 hook(grad, g0, g1)
         self.run_deferred_wgrads()                     # (nothing left unless a layer id fell outside the ranges)

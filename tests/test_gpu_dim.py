@@ -3,6 +3,8 @@ PyTorch, and FullModel('dim') vs vectors captured from the reference (tests/gold
 import numpy as np
 import pytest
 import torch
+
+from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of the loaded build (bf16 / fp16)
 import torch.nn.functional as F
 
 from helpers import hu, golden, assert_close, Checker
@@ -15,7 +17,7 @@ DIM_FULL_GRADS = ('conv11.weight', 'bn33.weight', 'dconv1.bias', 'alpha_pred.wei
 
 
 def nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    return t.permute(0, 2, 3, 1).contiguous().to(H16).to(DEV)
 
 
 def nchw(t):
@@ -27,7 +29,7 @@ def test_maxpool_indices_and_unpool_bit_exact():
     so everything must be bit-identical to PyTorch on the same bf16 data (ties broken towards the first position)."""
     from tcvom_amd import ops
     x = (hu('dim.pool.x', (2, 16, 12, 20)) * 4).round() / 4            # coarse values: plenty of exact ties
-    xb = x.to(torch.bfloat16).float()
+    xb = x.to(H16).float()
     xg = nhwc(x).requires_grad_(True)
     y, idx = ops.maxpool2_idx(xg)
     yr, ir = F.max_pool2d(xb, 2, 2, return_indices=True)
@@ -35,18 +37,18 @@ def test_maxpool_indices_and_unpool_bit_exact():
     W = 20
     pos = ((ir // W) % 2) * 2 + (ir % W) % 2                            # flat input index -> position inside the window
     assert torch.equal(idx.permute(0, 3, 1, 2).cpu().long(), pos)
-    gy = hu('dim.pool.gy', tuple(yr.shape)).to(torch.bfloat16).float()
+    gy = hu('dim.pool.gy', tuple(yr.shape)).to(H16).float()
     y.backward(nhwc(gy))
     xr = xb.clone().requires_grad_(True)
     F.max_pool2d(xr, 2, 2).backward(gy)
     assert torch.equal(nchw(xg.grad), xr.grad)
-    z = hu('dim.unpool.z', tuple(yr.shape)).to(torch.bfloat16).float()
+    z = hu('dim.unpool.z', tuple(yr.shape)).to(H16).float()
     zg = nhwc(z).requires_grad_(True)
     up = ops.unpool2(zg, idx)
     zr = z.clone().requires_grad_(True)
     upr = F.max_unpool2d(zr, ir, 2, 2)
     assert torch.equal(nchw(up), upr)
-    gu = hu('dim.unpool.g', tuple(upr.shape)).to(torch.bfloat16).float()
+    gu = hu('dim.unpool.g', tuple(upr.shape)).to(H16).float()
     up.backward(nhwc(gu))
     upr.backward(gu)
     assert torch.equal(nchw(zg.grad), zr.grad)
@@ -61,7 +63,7 @@ def test_head_conv_5x5_clamp():
     xg = nhwc(x).requires_grad_(True)
     wg, bg_ = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
     a = ops.head_conv(xg, wg, bg_, 5, 1)
-    xr = x.to(torch.bfloat16).float().requires_grad_(True)
+    xr = x.to(H16).float().requires_grad_(True)
     wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ar = F.conv2d(xr, wr, br, 1, 2).clamp(0, 1)
     assert 0.05 < float(((ar > 0) & (ar < 1)).float().mean()) < 0.95          # both clamp branches are exercised
@@ -94,15 +96,15 @@ def test_conv6_as_unfold_dense():
     xg = nhwc(x).requires_grad_(True)
     token = bank_token(bank, 1, True)
     y = ops.conv_unfold_dense(cfg, xg, token)
-    xr = x.to(torch.bfloat16).float().requires_grad_(True)
-    wr = conv.weight.detach().cpu().to(torch.bfloat16).float().requires_grad_(True)
+    xr = x.to(H16).float().requires_grad_(True)
+    wr = conv.weight.detach().cpu().to(H16).float().requires_grad_(True)
     br = conv.bias.detach().cpu().clone().requires_grad_(True)
     yr = F.relu(F.conv2d(xr, wr, br, 1, 3))
     ck = Checker()
     ck.rel('y', nchw(y), yr, 1e-2)
     g = hu('dim.c6.g', tuple(yr.shape))
     (y.float() * nhwc(g).float()).sum().backward()
-    (yr * g.to(torch.bfloat16).float()).sum().backward()
+    (yr * g.to(H16).float()).sum().backward()
     ck.rel('dx', nchw(xg.grad), xr.grad, 3e-2)
     ck.rel('dw', conv.weight.grad.cpu(), wr.grad, 2e-2)
     ck.rel('db', conv.bias.grad.cpu(), br.grad, 2e-2)
@@ -136,7 +138,7 @@ def test_dim_losses_vs_oracle():
     assert_close(pg.grad.cpu(), pr.grad, 1e-3, 1e-7, 'dpred')
     assert_close(alphas[:, c].cpu(), refine.detach().clamp(0, 1), 1e-6, 1e-6, 'alphas')
     assert_close(comps[:, c].cpu(), comp.detach().clamp(0, 1), 1e-5, 1e-5, 'comps')
-    assert_close(prep.x8[..., 3].float().cpu(), tris[:, :, 0].to(torch.bfloat16).float(), 0, 0, 'trimap channel')
+    assert_close(prep.x8[..., 3].float().cpu(), tris[:, :, 0].to(H16).float(), 0, 0, 'trimap channel')
     assert float(alphas[:, 0].abs().max()) == 0.0 and float(comps[:, -1].abs().max()) == 0.0
 
 

@@ -4,6 +4,8 @@ the CPU oracle, and FullModel_VMD('vmn_fba') against vectors captured from the r
 import numpy as np
 import pytest
 import torch
+
+from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of the loaded build (bf16 / fp16)
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -15,7 +17,7 @@ DEV = 'cuda'
 
 
 def nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    return t.permute(0, 2, 3, 1).contiguous().to(H16).to(DEV)
 
 
 def nchw(t):
@@ -23,7 +25,7 @@ def nchw(t):
 
 
 def bf(t):
-    return t.to(torch.bfloat16).float()
+    return t.to(H16).float()
 
 
 def test_maxpool_3x3_stride2_bit_exact():
@@ -222,7 +224,7 @@ def test_stem_7x7_space_to_depth(act):
     x2 = x16.reshape(NF, 16, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(NF, H // 2, W // 2, 64)
     token = bank_token(bank, NF, True)
     bank.frames_per_op = NF
-    z = ops.conv_bn_act(cfg, x2.contiguous().to(torch.bfloat16).to(DEV), token, True)
+    z = ops.conv_bn_act(cfg, x2.contiguous().to(H16).to(DEV), token, True)
     bank.frames_per_op = 1
     state = {'c.weight': w.detach().cpu().clone().requires_grad_(True), 'n.weight': gn.weight.detach().cpu().clone(),
              'n.bias': gn.bias.detach().cpu().clone()}

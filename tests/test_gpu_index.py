@@ -4,6 +4,8 @@ from the reference (tests/golden/gen_golden.py: gen_vmn_index) and against the C
 import numpy as np
 import pytest
 import torch
+
+from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of the loaded build (bf16 / fp16)
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -15,7 +17,7 @@ DEV = 'cuda'
 
 
 def nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    return t.permute(0, 2, 3, 1).contiguous().to(H16).to(DEV)
 
 
 def nchw(t):
@@ -23,7 +25,7 @@ def nchw(t):
 
 
 def bf(t):
-    return t.to(torch.bfloat16).float()
+    return t.to(H16).float()
 
 
 def rel(got, want):
@@ -202,7 +204,7 @@ def test_modules_against_oracle():
                 check(k, params[k].grad, state[k].grad)
                 state[k].grad = None
         net.zero_grad()
-    to_dev = lambda t: t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    to_dev = lambda t: t.permute(0, 2, 3, 1).contiguous().to(H16).to(DEV)
     # ASPP (dilated depthwise branches, image pooling, bottleneck)
     x, gz = hu('m.x7', (2, 320, 4, 4)) * 1.5 + 0.5, hu('m.gz7', (2, 160, 4, 4))
     xg = to_dev(x).requires_grad_(True)

@@ -10,6 +10,8 @@ import math
 import numpy as np
 import pytest
 import torch
+
+from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of the loaded build (bf16 / fp16)
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -21,11 +23,11 @@ DEV = 'cuda'
 
 
 def bf(t):
-    return t.to(torch.bfloat16).float()
+    return t.to(H16).float()
 
 
 def nhwc(t):
-    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    return t.permute(0, 2, 3, 1).contiguous().to(H16).to(DEV)
 
 
 def nchw(t):
@@ -342,8 +344,8 @@ def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
     geo = ConvGeometry(spec, 1, H, W)
     arr = _phase_array(geo.wgrad)
     S = 3
-    xs = [(hu('x%d.%s' % (i, tag), (1, H, W, spec.cpad))).to(DEV).to(torch.bfloat16) for i in range(S)]
-    dys = [(hu('dy%d.%s' % (i, tag), (1, geo.OH, geo.OW, cout))).to(DEV).to(torch.bfloat16) for i in range(S)]
+    xs = [(hu('x%d.%s' % (i, tag), (1, H, W, spec.cpad))).to(DEV).to(H16) for i in range(S)]
+    dys = [(hu('dy%d.%s' % (i, tag), (1, geo.OH, geo.OW, cout))).to(DEV).to(H16) for i in range(S)]
     n = spec.K * spec.T * spec.cpad
     single = torch.zeros(S, n, device=DEV)
     batched = torch.zeros(S, n, device=DEV)
@@ -374,8 +376,8 @@ def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
     bank, spec = _mini_bank(cin, cout, 3, 1, 1, False, spectral=False, tag=tag)
     geo = ConvGeometry(spec, N, H, W)
     assert L._FNS['tcvom_wgrad_igemm_variant'](C.byref(_phase_array(geo.wgrad)[0])).decode().startswith('wgrad_ws')
-    xs = [hu('x%d.%s' % (i, tag), (N, H, W, cin)).to(DEV).to(torch.bfloat16) for i in range(S)]
-    dys = [hu('dy%d.%s' % (i, tag), (N, H, W, cout)).to(DEV).to(torch.bfloat16) for i in range(S)]
+    xs = [hu('x%d.%s' % (i, tag), (N, H, W, cin)).to(DEV).to(H16) for i in range(S)]
+    dys = [hu('dy%d.%s' % (i, tag), (N, H, W, cout)).to(DEV).to(H16) for i in range(S)]
     dw = torch.zeros(S, cout, 9, cin, device=DEV)
     vp = lambda ts: C.cast((C.c_void_p * S)(*[t.data_ptr() for t in ts]), C.c_void_p)
     for _ in range(2):                                   # accumulates: two launches = twice the gradient
@@ -506,7 +508,7 @@ def test_wsconv_kernel(cin, N, H, W, bias):
     ck.done()
     # raw kernel against the implicit GEMM on the same operands: same products, different fp32 summation order
     st = L.stream_ptr()
-    y_ws = torch.empty(N, H, W, cin, device=DEV, dtype=torch.bfloat16)
+    y_ws = torch.empty(N, H, W, cin, device=DEV, dtype=H16)
     ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y_ws, b, None, 1, st)
     d = geo.fwd[0]
     taps = [(d.tap_dh[t], d.tap_dw[t]) for t in range(9)]
@@ -577,10 +579,10 @@ def test_transpose_bf16(R, Cc, ldi, ldo, batch):
     """in [batch][R][ldi] (first Cc columns) -> out [batch][Cc][ldo] (columns >= R zero): the 16-byte kernel (aligned strides)
     and the scalar fallback (odd strides), bit exact."""
     from tcvom_amd import _lib as L
-    x = hu('tr.x', (batch, R, ldi)).to(DEV).to(torch.bfloat16)
-    out = torch.full((batch, Cc, ldo), 7.0, dtype=torch.bfloat16, device=DEV)
+    x = hu('tr.x', (batch, R, ldi)).to(DEV).to(H16)
+    out = torch.full((batch, Cc, ldo), 7.0, dtype=H16, device=DEV)
     L.call('tcvom_transpose_bf16', L.ptr(x), L.ptr(out), R, Cc, ldi, ldo, batch, R * ldi, Cc * ldo, L.stream_ptr())
-    ref = torch.zeros((batch, Cc, ldo), dtype=torch.bfloat16, device=DEV)
+    ref = torch.zeros((batch, Cc, ldo), dtype=H16, device=DEV)
     ref[:, :, :R] = x[:, :, :Cc].transpose(1, 2)
     assert torch.equal(out, ref)
 
@@ -596,23 +598,23 @@ def test_gca_fused_softmax_backward_gemm(B, N, DV):
     Pf = torch.softmax(hu('p.' + tag, (B, N, N)) * 8, dim=2)
     P = torch.zeros(B, N, ld)
     P[:, :, :N] = Pf
-    P = P.to(torch.bfloat16).to(DEV)
-    V = (hu('v.' + tag, (B, N, DV)) - 0.5).to(torch.bfloat16).to(DEV)
-    dO = (hu('do.' + tag, (B, N, DV)) - 0.5).to(torch.bfloat16).to(DEV)
+    P = P.to(H16).to(DEV)
+    V = (hu('v.' + tag, (B, N, DV)) - 0.5).to(H16).to(DEV)
+    dO = (hu('do.' + tag, (B, N, DV)) - 0.5).to(H16).to(DEV)
     cvec = (hu('c.' + tag, (B, N)) + 0.5).to(DEV)
     Pq, Vq, dOq = P[:, :, :N].float(), V.float(), dO.float()
     O = torch.bmm(Pq, Vq).contiguous()                            # what the forward saves (fp32)
     delta = torch.empty(B, N, device=DEV)
     L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
     assert rel_err(delta.cpu(), (dOq * O).sum(2).cpu()) < 1e-5
-    Ob = O.to(torch.bfloat16)
+    Ob = O.to(H16)
     L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(Ob), 0, L.ptr(delta), B * N, DV, st)
     assert rel_err(delta.cpu(), (dOq * Ob.float()).sum(2).cpu()) < 1e-5
     L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
-    T = torch.full((B, N, ld), float('nan'), dtype=torch.bfloat16, device=DEV)
+    T = torch.full((B, N, ld), float('nan'), dtype=H16, device=DEV)
     fused_t = ld % 256 == 0                                  # (1020 -> 1024, 500 -> 512: the epilogue also writes T^T and P^T)
-    Tt = torch.full((B, ld, ld), float('nan'), dtype=torch.bfloat16, device=DEV) if fused_t else None
-    Pt = torch.full((B, ld, ld), float('nan'), dtype=torch.bfloat16, device=DEV) if fused_t else None
+    Tt = torch.full((B, ld, ld), float('nan'), dtype=H16, device=DEV) if fused_t else None
+    Pt = torch.full((B, ld, ld), float('nan'), dtype=H16, device=DEV) if fused_t else None
     L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), L.ptr(Tt), L.ptr(Pt),
            N, DV, ld, B, st)
     dP = torch.bmm(dOq, Vq.transpose(1, 2))
@@ -621,9 +623,9 @@ def test_gca_fused_softmax_backward_gemm(B, N, DV):
     if ld > N:
         assert float(T[:, :, N:].float().abs().max()) == 0.0
     if fused_t:
-        want_t = torch.zeros(B, ld, ld, dtype=torch.bfloat16, device=DEV)
+        want_t = torch.zeros(B, ld, ld, dtype=H16, device=DEV)
         want_t[:, :, :N] = T.transpose(1, 2)
-        want_p = torch.zeros(B, ld, ld, dtype=torch.bfloat16, device=DEV)
+        want_p = torch.zeros(B, ld, ld, dtype=H16, device=DEV)
         want_p[:, :, :N] = P.transpose(1, 2)
         assert torch.equal(Tt, want_t) and torch.equal(Pt, want_p)          # exact transposes, zero padding rows / columns
 
@@ -636,7 +638,7 @@ def test_row_softmax_kernels(ncols):
     rows = 37
     ld = (ncols + 63) // 64 * 64
     S = (hu('sm.s%d' % ncols, (rows, ld)) * 6).to(DEV)
-    P = torch.empty(rows, ld, dtype=torch.bfloat16, device=DEV)
+    P = torch.empty(rows, ld, dtype=H16, device=DEV)
     st = L.stream_ptr()
     L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), rows, ncols, ld, ld, st)
     ref = torch.softmax(S[:, :ncols].float(), dim=1)
@@ -644,7 +646,7 @@ def test_row_softmax_kernels(ncols):
     assert float(P[:, ncols:].float().abs().max()) == 0.0 if ld > ncols else True
     dP = hu('sm.dp%d' % ncols, (rows, ld)).to(DEV)
     cvec = (hu('sm.c%d' % ncols, (ncols,)) + 1.5).to(DEV)
-    T = torch.empty(rows, ld, dtype=torch.bfloat16, device=DEV)
+    T = torch.empty(rows, ld, dtype=H16, device=DEV)
     L.call('tcvom_row_softmax_bwd', L.ptr(P), L.ptr(dP), L.ptr(cvec), L.ptr(T), rows, ncols, ld, ld, rows, st)
     Pf = P[:, :ncols].float()
     a = (Pf * dP[:, :ncols]).sum(1, keepdim=True)
@@ -660,11 +662,11 @@ def test_dense_gemm_256_tile_config(rows_b, rows_a, kred, fp32):
     import ctypes as C
     from tcvom_amd import _lib as L
     from tcvom_amd.conv_plan import dense_desc
-    B = (hu('g256.b', (rows_b, kred)) - 0.5).to(DEV).to(torch.bfloat16)
-    A = (hu('g256.a', (rows_a, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    B = (hu('g256.b', (rows_b, kred)) - 0.5).to(DEV).to(H16)
+    A = (hu('g256.a', (rows_a, kred)) - 0.5).to(DEV).to(H16)
     sc = (hu('g256.s', (rows_a,)) + 0.5).to(DEV)
     ld = (rows_a + 63) // 64 * 64
-    out = torch.zeros(rows_b, ld, device=DEV, dtype=torch.float32 if fp32 else torch.bfloat16)
+    out = torch.zeros(rows_b, ld, device=DEV, dtype=torch.float32 if fp32 else H16)
     d = dense_desc(rows_b, rows_a, kred, ld, out_fp32=fp32)
     L.call('tcvom_conv_igemm', L.ptr(B), L.ptr(A), L.ptr(out), None, L.ptr(sc), None, None, C.byref(d), L.stream_ptr())
     ref = (B.float() @ A.float().t()) * sc[None, :]
@@ -682,12 +684,12 @@ def test_dense_gemm_256_staggered_kernel_epilogues(fp32):
     from tcvom_amd.conv_plan import dense_desc
     nb, rows_b, rows_a, kred = 2, 2590, 2700, 192
     ld = (rows_a + 63) // 64 * 64
-    B = (hu('g2s.b', (nb, rows_b, kred)) - 0.5).to(DEV).to(torch.bfloat16)
-    A = (hu('g2s.a', (nb, rows_a, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    B = (hu('g2s.b', (nb, rows_b, kred)) - 0.5).to(DEV).to(H16)
+    A = (hu('g2s.a', (nb, rows_a, kred)) - 0.5).to(DEV).to(H16)
     sc = (hu('g2s.s', (nb, rows_a)) + 0.5).to(DEV)
     bias = (hu('g2s.bias', (nb, rows_a)) - 0.5).to(DEV)
     dg = (hu('g2s.d', (nb, rows_a)) * 3).to(DEV)
-    out = torch.zeros(nb, rows_b, ld, device=DEV, dtype=torch.float32 if fp32 else torch.bfloat16)
+    out = torch.zeros(nb, rows_b, ld, device=DEV, dtype=torch.float32 if fp32 else H16)
     d = dense_desc(rows_b, rows_a, kred, ld, batch=nb, in_bstride=rows_b * kred, w_bstride=rows_a * kred,
                    out_bstride=rows_b * ld, vec_bstride=rows_a, out_fp32=fp32)
     d.act = 1
@@ -712,9 +714,9 @@ def test_dense_gemm_pair_one_launch(rows_a, rows_b):
     from tcvom_amd.conv_plan import dense_desc
     nb, kred = 3, 512 if rows_a == 576 else 128
     pad = rows_b + 10                                         # rows of in2's per-batch allocation
-    W_ = (hu('gp.w', (nb, rows_a, kred)) - 0.5).to(DEV).to(torch.bfloat16)
-    X1 = (hu('gp.x1', (nb, rows_b, kred)) - 0.5).to(DEV).to(torch.bfloat16)
-    X2 = (hu('gp.x2', (nb, pad, kred)) - 0.5).to(DEV).to(torch.bfloat16)
+    W_ = (hu('gp.w', (nb, rows_a, kred)) - 0.5).to(DEV).to(H16)
+    X1 = (hu('gp.x1', (nb, rows_b, kred)) - 0.5).to(DEV).to(H16)
+    X2 = (hu('gp.x2', (nb, pad, kred)) - 0.5).to(DEV).to(H16)
     o1 = torch.full((nb, rows_b, rows_a), 7.0, device=DEV)
     o2 = torch.full((nb, rows_b, rows_a), 7.0, device=DEV)
     d = dense_desc(rows_b, rows_a, kred, rows_a, batch=nb, in_bstride=rows_b * kred, w_bstride=rows_a * kred,

@@ -8,6 +8,8 @@ import socket
 
 import pytest
 import torch
+
+from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of the loaded build (bf16 / fp16)
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -64,8 +66,8 @@ def _worker(rank, world, port, out, transport):
         from tcvom_amd.synthetic import formula_tensor
         xs = (formula_tensor('sync.x', (2, 24, 40, 64)) * 2).to(dev)
         xs[1] = xs[1] * 1.7 + 0.3                      # the two clips have different statistics
-        xs = xs.to(torch.bfloat16)
-        dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(torch.bfloat16)
+        xs = xs.to(H16)
+        dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(H16)
         w, bn, bank, cfg = _block(dev, True, 'sync')
         assert (bn.sync_mailbox is not None) == (transport == 'mailbox')
         got = _run(cfg, bank, bn, w, xs[rank:rank + 1].contiguous(), dzs[rank:rank + 1].contiguous())
@@ -159,8 +161,8 @@ def test_sync_batchnorm_loopback_mailbox_equals_local_statistics():
     from tcvom_amd.mailbox import PeerMailbox
     from tcvom_amd.synthetic import formula_tensor
     dev = torch.device('cuda:0')
-    xs = (formula_tensor('sync.x', (2, 24, 40, 64)) * 2).to(dev).to(torch.bfloat16)
-    dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(torch.bfloat16)
+    xs = (formula_tensor('sync.x', (2, 24, 40, 64)) * 2).to(dev).to(H16)
+    dzs = formula_tensor('sync.dz', (2, 24, 40, 128)).to(dev).to(H16)
     w, bn, bank, cfg = _block(dev, False, 'loop.sync')
     mb = PeerMailbox(loopback=True, timeout_s=5)
     convert_sync_batchnorm(bn, mailbox=mb)
@@ -184,8 +186,8 @@ def test_sync_batchnorm_mailbox_timeout_is_reported_not_hung():
     from tcvom_amd.mailbox import MailboxTimeout, PeerMailbox
     from tcvom_amd.synthetic import formula_tensor
     dev = torch.device('cuda:0')
-    xs = (formula_tensor('sync.x', (1, 24, 40, 64)) * 2).to(dev).to(torch.bfloat16)
-    dzs = formula_tensor('sync.dz', (1, 24, 40, 128)).to(dev).to(torch.bfloat16)
+    xs = (formula_tensor('sync.x', (1, 24, 40, 64)) * 2).to(dev).to(H16)
+    dzs = formula_tensor('sync.dz', (1, 24, 40, 128)).to(dev).to(H16)
     w, bn, bank, cfg = _block(dev, False, 'timeout')
     # pretend to be rank 0 of 2 whose peer is silent: both table entries point at the own mailbox (sized for one sender: the
     # second sender region is ring slot memory nobody writes with this tag)

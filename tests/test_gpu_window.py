@@ -287,6 +287,13 @@ def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
             assert p.grad is None, 'frozen parameter %s has a gradient (the reference leaves it None: Adam skips it)' % k
         elif p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    changed_tail = 0
+    for k in before:
+        if front(k):
+            assert torch.equal(before[k], after[k]), 'frozen state %s changed' % k
+        elif k.endswith(('running_mean', 'weight_u')):
+            changed_tail += int(not torch.equal(before[k], after[k]))
+    assert changed_tail > 0, 'the decoder tail must still update its BatchNorm statistics / power iteration'
     # an optimizer step with weight decay (train_ddp.py:296-297: Adam(weight_decay=1e-4)) must not move the frozen backbone
     from tcvom_amd.optim import FusedAdam
     opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=1e-1)
@@ -300,13 +307,7 @@ def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
             moved += int(not torch.equal(p.detach(), before[k]))
     assert moved > 0
     m.NET.load_state_dict(before)
-    changed_tail = 0
-    for k in before:
-        if front(k):
-            assert torch.equal(before[k], after[k]), 'frozen state %s changed' % k
-        elif k.endswith(('running_mean', 'weight_u')):
-            changed_tail += int(not torch.equal(before[k], after[k]))
-    assert changed_tail > 0, 'the decoder tail must still update its BatchNorm statistics / power iteration'
+    m.zero_grad(set_to_none=True)
     # the same weights in eval mode produce the same features -> with the tail's BatchNorm in train mode the alpha differs, so
     # compare through a second frozen run: deterministic, and different from a fully-trainable run of the same step
     out2 = m(a, fg, bg)
