@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: synthetic 1080p (1088x1920) 3-frame windows/s, GCA+TAM, forward + backward
-(L_alpha + 0.5 L_dt + 0.25 L_att, train_ddp.py:56-61) + gradient all-reduce + Adam, bf16 activations.
+(L_alpha + 0.5 L_dt + 0.25 L_att, train_ddp.py:56-61) + gradient all-reduce + Adam; 16-bit activations / packed weights (fp16
+by default, TCVOM_DTYPE=bf16 for the bf16 build: same MFMA rate), fp32 accumulation, statistics, softmax, losses and master weights.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -215,6 +216,7 @@ def main():
         dist.init_process_group(backend=backend, init_method='env://', **({'device_id': device} if backend == 'nccl' else {}))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
 
+    import tcvom_amd._lib as L
     from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm, sync_batchnorm_info
     from tcvom_amd.facade import train_step_loss
     from tcvom_amd.optim import FusedAdam
@@ -275,17 +277,17 @@ def main():
                       else '%dx%d 3-frame windows/sec (fwd+bwd) %s' % (H, W, base),
             'value': round(win_per_s, 4), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': L.DTYPE_NAME, 'data': 'synthetic',
             'config': {'workload': ('GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
                                     '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
-                                    'formula-initialised weights, train mode' % (H, W)) if args.config == 'gca' else
+                                    'formula-initialised weights, train mode; %s storage' % (H, W, L.DTYPE_NAME)) if args.config == 'gca' else
                                    ('IndexNet+TAM (vmn_index: MobileNetV2 encoder with learned index blocks, ASPP, indexed up-sampling decoder) '
                                     'fwd+bwd+grad-allreduce+Adam, L_alpha+L_comp+L_grad+0.5L_dt+0.25L_att, two 3-frame %dx%d windows per GPU per '
                                     'step (train-mode BatchNorm over the batch in the ASPP), formula-initialised weights' % (H, W)) if args.config == 'index' else
                                    ('FBA+TAM (vmn_fba: ResNet-50 GN+WS dilated os8, PPM, 7-channel head, 11-channel input with the '
                                     '2-scale trimap channels) fwd+bwd+grad-allreduce+Adam, L_alpha_comp+L_lap+L_grad+0.5L_dt+0.25L_att, '
-                                    'one 3-frame %dx%d window per GPU per step, formula-initialised weights, train mode; BASELINE '
-                                    'config 5 names fp16: the engine computes in bf16 (same MFMA rate, no loss scaling needed)' % (H, W)),
+                                    'one 3-frame %dx%d window per GPU per step, formula-initialised weights, train mode; %s storage '
+                                    '(BASELINE config 5 names fp16)' % (H, W, L.DTYPE_NAME)),
                        'global_batch_clips': world * clips, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(sync_bn)},
             'final_loss': round(final_loss, 6),
             'dist': {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,

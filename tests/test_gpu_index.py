@@ -9,7 +9,7 @@ from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of th
 import torch.nn as nn
 import torch.nn.functional as F
 
-from helpers import hu, golden, Checker, VMN_INDEX_CASES, golden_formula_state
+from helpers import hu, golden, Checker, VMN_INDEX_CASES, golden_formula_state, tol
 from tcvom_amd.synthetic import formula_tensor, synthetic_window
 
 pytestmark = pytest.mark.gpu
@@ -265,7 +265,7 @@ def test_window_against_oracle_256x320():
     d2 = (out[7][:, 1:2].cpu() - ref[7][:, 1:2]) ** 2
     mse_unknown = float(d2[unk].mean())
     print('vmn_index 256x320: unknown-pixel alpha MSE %.3e, whole-frame %.3e' % (mse_unknown, float(d2.mean())))
-    assert mse_unknown <= 1e-3
+    assert mse_unknown <= tol(1e-3, 1e-4)          # bf16: 5.9e-4, AT the bf16 storage floor (tests/test_bf16_noise_floor.py: 5.4e-4); fp16: 1.6e-5 -- the north-star bound holds
     # gradient fidelity by tensor: norm ratio and cosine against the fp32 oracle
     params = dict(fm.NET.named_parameters())
     rows = []
@@ -287,7 +287,7 @@ def test_window_against_oracle_256x320():
     # activations (4e-3 relative) decorrelate the encoder's gradient DIRECTIONS while the norms stay right; the decoder, which
     # sits behind few layers, keeps both.  Module by module the gradients agree to >= 0.99 in cosine (test_modules_against_oracle).
     assert min(r[1] for r in dec) >= 0.9 and max(r[1] for r in dec) <= 1.1 and min(r[2] for r in dec) >= 0.65 and med(dec, 2) >= 0.9
-    assert min(r[1] for r in enc) >= 0.6 and max(r[1] for r in enc) <= 1.8 and med(enc, 2) >= 0.3
+    assert min(r[1] for r in enc) >= tol(0.6, 0.9) and max(r[1] for r in enc) <= tol(1.8, 1.5) and med(enc, 2) >= tol(0.3, 0.65)      # fp16: 1.01 .. 1.33, median cosine 0.83
 
 
 def test_dropout_is_active_in_train_mode():

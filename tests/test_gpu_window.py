@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden, WINDOW_CASES, FULL_GRADS, assert_close
+from helpers import golden, WINDOW_CASES, FULL_GRADS, assert_close, tol
 from tcvom_amd.synthetic import formula_tensor, synthetic_window
 
 pytestmark = pytest.mark.gpu
@@ -47,10 +47,12 @@ def test_window_vs_reference_golden(name):
     # upwards the north-star bound holds against the REFERENCE golden: whole-frame MSE <= 1e-4 (measured 4.3e-5; unknown-only
     # 9.6e-5 against an emulated all-bf16 floor of 1.9e-4, asserted at 2e-4); test_window_north_star_parity asserts the
     # unknown-only bound at 544 x 960 and at the benchmark size.
+    # fp16 storage (the default build): 3.8e-6 / 7.9e-6 / 1.9e-6 whole frame, 6.7e-6 / 1.9e-5 / 4.3e-6 on the unknown pixels for the
+    # three goldens -- the north-star 1e-4 holds on all of them, 64-pixel windows included, unknown region included.
     if H * W >= 128 * 160:
-        assert mse <= 1e-4 and mse_unk <= 2e-4, 'alpha MSE vs reference'
+        assert mse <= tol(1e-4, 2e-5) and mse_unk <= tol(2e-4, 2e-5), 'alpha MSE vs reference'
     else:
-        assert mse <= 1e-3 and mse_unk <= 1e-3, 'alpha MSE vs reference'
+        assert mse <= tol(1e-3, 4e-5) and mse_unk <= tol(1e-3, 1e-4), 'alpha MSE vs reference'
     assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), g['losses'], 3e-2, 1e-3, 'losses')
     assert_close(out[8].sum().cpu(), g['comps_sum'], 1e-2, 1.0, 'comps')
     assert_close(out[6].sum().cpu(), g['tris_vis_sum'], 1e-5, 1e-2, 'tris_vis')
@@ -71,10 +73,12 @@ def test_window_vs_reference_golden(name):
     ratio = mine[big] / refn[big]
     print('grad-norm ratio (top tensors): min %.3f max %.3f' % (ratio.min(), ratio.max()))
     if H * W >= 128 * 160:      # the 64-pixel-high cases have 8..24-element BatchNorms: backward is ill-conditioned
-        # Two identical runs of this window differ by the fp32 order of the atomic partial sums only, yet the largest
-        # per-tensor ratio moves between 1.19 and 1.44 (10 runs): the backward map amplifies last-bit noise (DESIGN.md
-        # section 6).  The bulk must agree; single tensors get the measured spread plus margin.
-        assert abs(np.median(ratio) - 1) < 0.15 and 0.6 < ratio.min() and ratio.max() < 1.9, 'gradient norms'
+        # bf16: two identical runs of this window differ by the fp32 order of the atomic partial sums only, yet the largest
+        # per-tensor ratio moves between 1.19 and 1.44 (10 runs): the backward map amplifies the bf16 storage noise (DESIGN.md
+        # section 6).  fp16: 0.91 .. 1.03.
+        assert abs(np.median(ratio) - 1) < tol(0.15, 0.05) and tol(0.6, 0.8) < ratio.min() and ratio.max() < tol(1.9, 1.2), 'gradient norms'
+    elif tol(False, True):
+        assert abs(np.median(ratio) - 1) < 0.1 and 0.75 < ratio.min() and ratio.max() < 1.45, 'gradient norms'      # measured 0.98 .. 1.21
 
 
 def test_window_large_vs_oracle():
@@ -101,8 +105,8 @@ def test_window_large_vs_oracle():
         mse, mse_unk, dtssd_delta, [float(x) for x in out[:5]], [float(x) for x in ro[:5]]))
     # north star: alpha MSE <= 1e-4 vs the reference path, over the unknown region as calc_metric.py:25 defines it
     # (and a fortiori over the whole frame)
-    assert mse <= 1e-4 and mse_unk <= 1e-4
-    assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), torch.stack(list(ro[:5])), 3e-2, 1e-3, 'losses')
+    assert mse <= tol(1e-4, 1e-5) and mse_unk <= tol(1e-4, 2e-5)        # fp16: 8.5e-7 / 3.8e-6
+    assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), torch.stack(list(ro[:5])), tol(3e-2, 3e-3), 1e-3, 'losses')
 
 
 def _oracle_state(requires_grad=False):
@@ -147,8 +151,8 @@ def test_window_north_star_parity(H, W):
     dtssd_delta = float(torch.sqrt(((d_a - d_r)[um[:, 1]] ** 2).mean()))
     print('%dx%d: alpha MSE %.3e (unknown-only %.3e, %d unknown pixels), dtSSD-style delta %.3e, max |d| %.3e; losses %s vs %s; oracle %.0f s'
           % (H, W, mse, mse_unk, int(um.sum()), dtssd_delta, float(d.abs().max()), losses, [float(x) for x in ro[:5]], time.time() - t0))
-    assert mse <= 1e-4 and mse_unk <= 1e-4
-    assert_close(torch.tensor(losses), torch.stack(list(ro[:5])), 3e-2, 1e-3, 'losses')
+    assert mse <= tol(1e-4, 1e-5) and mse_unk <= tol(1e-4, 2e-5)        # fp16 at 512^2 / 544x960 / 1088x1920: unknown-only 3.2e-6 / 2.7e-6 / 2.6e-6
+    assert_close(torch.tensor(losses), torch.stack(list(ro[:5])), tol(3e-2, 3e-3), 1e-3, 'losses')
 
 
 def test_window_full_size_backward_parity():
@@ -207,12 +211,17 @@ def test_window_full_size_backward_parity():
     print('1088x1920 backward: total gradient norm HIP / oracle %.3f (rerun / run %.3f), cosine vs oracle %.3f, run vs rerun %.3f; oracle %.0f s'
           % (total, rerun, c_oracle, c_rerun, t_oracle))
     print('\n'.join('%-30s norm ratio %.3f  rerun %.3f  oracle norm %.3e  (%d tensors)' % r for r in rows))
-    assert 0.85 <= total <= 1.2, 'whole-network gradient norm vs the oracle'
+    # fp16 (measured): total 1.001, cosine of the whole-network gradient against the oracle 0.962 (two identical runs: 0.986),
+    # every module group 0.977 .. 1.038
+    lo, hi = tol((0.85, 1.2), (0.95, 1.05))
+    assert lo <= total <= hi, 'whole-network gradient norm vs the oracle'
     assert 0.9 <= rerun <= 1.1, 'two identical runs'
+    assert c_oracle >= tol(0.6, 0.9), 'whole-network gradient direction vs the oracle'
     top = max(r[3] for r in rows)
+    glo, ghi = tol((0.75, 1.35), (0.9, 1.12))
     for name, ratio, rr, on, n in rows:
         if on >= 0.02 * top:                      # groups that carry the gradient; tiny groups are dominated by amplified noise
-            assert 0.75 <= ratio <= 1.35, 'gradient norm of %s: %.3f of the oracle' % (name, ratio)
+            assert glo <= ratio <= ghi, 'gradient norm of %s: %.3f of the oracle' % (name, ratio)
 
 
 def test_gradient_fidelity_vs_oracle():
@@ -249,11 +258,13 @@ def test_gradient_fidelity_vs_oracle():
     print('\n'.join('%-30s weighted cos %.3f  min %.3f  (%d tensors)' % r for r in rows))
     dec = [r[1] for r in rows if r[0].startswith('decoder.')]
     enc = [r[1] for r in rows if r[0].startswith('encoder.')]
-    assert min(dec) >= 0.8, 'decoder gradient direction'
-    assert min(enc) >= 0.6, 'encoder gradient direction'
+    # fp16 storage: decoder groups 0.976 .. 1.0, encoder groups 0.944 .. 0.989 -- most of what the bf16 build loses against the
+    # oracle is storage noise amplified by the backward map, not summation order
+    assert min(dec) >= tol(0.8, 0.95), 'decoder gradient direction'
+    assert min(enc) >= tol(0.6, 0.9), 'encoder gradient direction'
     tot_h = torch.cat([g[k].flatten() for ks in groups.values() for k in ks])
     tot_o = torch.cat([go[k].flatten() for ks in groups.values() for k in ks])
-    assert cos(tot_h, tot_o) >= 0.7, 'whole-network gradient direction'       # measured 0.79
+    assert cos(tot_h, tot_o) >= tol(0.7, 0.9), 'whole-network gradient direction'       # measured 0.79 (bf16)
 
 
 def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
@@ -408,7 +419,7 @@ def test_single_image_bases_vs_reference_golden(name, arch, shape):
     losses = torch.stack([o.detach().float().cpu() for o in out[:3]])
     mse = float(((out[5].float().cpu() - torch.from_numpy(g['alphas'])) ** 2).mean())
     print('%s: alpha MSE %.3e, losses %s vs %s' % (name, mse, losses.tolist(), g['losses'].tolist()))
-    assert mse <= (1e-4 if arch == 'fba' else 1e-3)       # GCA at 128x160: small BatchNorms, see test_window_vs_reference_golden
+    assert mse <= tol(1e-4 if arch == 'fba' else 1e-3, 2e-5)       # bf16, GCA at 128x160: small BatchNorms, see test_window_vs_reference_golden; fp16: 3.2e-6 / 6.5e-7
     assert_close(losses, g['losses'], 3e-2, 1e-3, 'losses')
     params = dict(m.NET.named_parameters())
     names = [str(n) for n in g['grad_names']]
