@@ -1018,10 +1018,6 @@ def _r64(n):
     return (n + 63) // 64 * 64
 
 
-# study knob: run the attention GEMM chains frame by frame when a frame's probability matrix fits the Infinity Cache
-GCA_CHAIN = _os.environ.get('TCVOM_GCA_CHAIN', '0') == '1'
-GCA_CHAIN_BYTES = 200 << 20
-
 
 class _GcaAttention(torch.autograd.Function):
     @staticmethod
@@ -1041,7 +1037,6 @@ class _GcaAttention(torch.autograd.Function):
         nrm = torch.empty((B, N), dtype=torch.float32, device=dev)
         L.call('tcvom_gca_prepare', L.ptr(g8), L.ptr(unk_u8), L.ptr(G), L.ptr(scales), L.ptr(cvec), L.ptr(dvec), L.ptr(nrm),
                B, h8, w8, CG, st)
-        # S'[i][j] = c_j <G_i, G_j> - d_j [i==j]     (rows m = keys j, columns n = queries i)
         V = torch.empty((B, N, DV), dtype=H16, device=dev)
         L.call('tcvom_gca_value_patches', L.ptr(alpha), L.ptr(V), B, h8, w8, Ca, st)
         Vt = torch.empty((B, DV, ld), dtype=H16, device=dev)
@@ -1051,27 +1046,16 @@ class _GcaAttention(torch.autograd.Function):
         # (fp32: the backward forms sum_j P dP as <dO_i, O_i>; with a peaked softmax dP[i][i] - <dO_i, O_i> cancels to ~0 and
         # a bf16-rounded O would leave its rounding error as the gradient)
         O = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
-        if GCA_CHAIN and B > 1 and N * ld * 2 <= GCA_CHAIN_BYTES:
-            # Frame by frame: scores -> softmax -> P V of ONE frame back to back, so that the frame's P (N x ld 16-bit, 133 MB at
-            # 1080p) is still in the 256 MB Infinity Cache when the P V GEMM reads it (with all frames per launch the softmax of
-            # the last frame has evicted the first frame's P long before its GEMM runs).  The per-frame launches still fill
-            # the chip (1024 / 256 tiles of 256 x 256)
-            S = torch.empty((N, ld), dtype=torch.float32, device=dev)
-            d = dense_desc(N, N, D, ld, out_fp32=True)
-            d2 = dense_desc(N, DV, ld, DV, out_fp32=True)
-            for b in range(B):
-                L.call('tcvom_conv_igemm', L.ptr(G[b]), L.ptr(G[b]), L.ptr(S), None, L.ptr(cvec[b]), L.ptr(dvec[b]), None, C.byref(d), st)
-                L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P[b]), N, N, ld, ld, st)
-                L.call('tcvom_conv_igemm', L.ptr(P[b]), L.ptr(Vt[b]), L.ptr(O[b]), None, None, None, None, C.byref(d2), st)
-            del S
-        else:
-            S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
-            d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
-            L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
-            L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
-            del S
-            d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
-            L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
+        # (measured and dropped, round 3: scores -> softmax -> P V frame by frame, so that a frame's P is still in the Infinity Cache
+        #  when its GEMM reads it: 28.16 vs 28.13 ms per step -- the kernel is not bound by where P comes from)
+        # S'[i][j] = c_j <G_i, G_j> - d_j [i==j]     (rows m = keys j, columns n = queries i)
+        S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
+        d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
+        L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
+        L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
+        del S
+        d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
+        L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
         y = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_fold_f32', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
         ctx.save_for_backward(G, P, V, cvec, nrm, O)
