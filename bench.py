@@ -45,17 +45,67 @@ def profile_traffic(variant):
     m = re.match(r'(\w+?)(<.*>)?$', variant)
     base, targs = m.group(1), (m.group(2) or '')
     if base == 'gemm_nt256':
-        key = 'gemm_nt256_kernel<0'                    # <0, 4>: fp32-output 256x256 tiles, the bulk of the profiled launches
+        key = 'gemm_nt256_kernel<'                     # the family: every instantiation of the 256 x 256 GEMM, launch-weighted
     else:
         key = base + '_kernel' + (targs[:-1].replace(',', ', ') if targs else '')    # the table truncates long names
+    tot, launches = 0.0, 0
     for line in open(files[-1]):
         if line.startswith('| `') and key in line.replace('void ', ''):
             cols = [c.strip() for c in line.split('|')]
             try:
-                return (float(cols[3]) + float(cols[4])) * 2 ** 20, os.path.basename(files[-1])
+                n = int(cols[2])
+                tot += n * (float(cols[3]) + float(cols[4])) * 2 ** 20
+                launches += n
             except (ValueError, IndexError):
-                return None, os.path.basename(files[-1])
-    return None, os.path.basename(files[-1])
+                pass
+    return (tot / launches if launches else None), os.path.basename(files[-1])
+
+
+ALGO_GB_WINDOW_1080P = 17.8        # ideal conv+BN+act fusion, every layer reads its input and writes its output once, x3 for fwd+bwd
+
+
+def profile_step_traffic():
+    """(GiB of counter traffic per step, file) from the newest committed profiles/r*_hbm_traffic_pmc*.md: its last line is the total
+    over the traced process, which runs `bench.py --steps 2 --warmup 1` (3 steps; the instrumented extra step is switched off)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(PROFILE_DIR, 'r*_hbm_traffic_pmc*.md')))
+    if not files:
+        return None, None
+    m = re.search(r'total HBM traffic over the traced process: ([0-9.]+) GiB', open(files[-1]).read())
+    return (round(float(m.group(1)) / 3.0, 2) if m else None), os.path.basename(files[-1])
+
+
+def tam_all_unknown(device, h, w, C=128, window=7, reps=5):
+    """The Temporal Attention Module kernels on a window whose EVERY os8 pixel is unknown (the synthetic bench window has ~3 %):
+    algorithmic bytes / HIP-event time, forward and forward + backward, against the 8 TB/s HBM peak."""
+    import tcvom_amd._lib as L
+    from tcvom_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(0)
+    mk = lambda: torch.randn(1, h, w, C, generator=g).to(device).to(L.ACT_DTYPE).requires_grad_(True)
+    q, kb, kf, v = mk(), mk(), mk(), mk()
+    mask = torch.ones(1, h, w, dtype=torch.uint8, device=device)
+    w2 = window * window
+    fwd_bytes = 5 * h * w * C * 2 + h * w + 2 * w2 * h * w * 4
+    bwd_bytes = 7 * h * w * C * 2 + h * w + 2 * w2 * h * w * 4 * 3
+    res = {}
+    for name, nbytes, both in (('fwd', fwd_bytes, False), ('fwd+bwd', fwd_bytes + bwd_bytes, True)):
+        def run():
+            out, ab, af = ops.tam_attention(q, kb, kf, v, mask, window)
+            if both:
+                torch.autograd.backward([out, ab, af], [torch.ones_like(out), torch.ones_like(ab), torch.ones_like(af)])
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res[name] = {'ms': round(ms, 4), 'GBps': round(nbytes / ms / 1e6, 1), 'frac_of_8TBps': round(nbytes / ms / 1e6 / 8000.0, 4)}
+    return res
 
 
 def window_gflop(H, W, config='gca'):
@@ -92,6 +142,7 @@ def igemm_profile(step_fn):
     L.PROFILE = None
     agg = {}
     tam = {}
+    algo = {}
     for name, desc, e0, e1 in rec:
         ms = e0.elapsed_time(e1)
         if 'bytes' in desc:                          # Temporal Attention Module launches: an HBM-bound kernel family
@@ -103,7 +154,10 @@ def igemm_profile(step_fn):
         var = desc['variant']                       # the instantiation the library selected for this shape
         n, t, g = agg.get(var, (0, 0.0, 0.0))
         agg[var] = (n + 1, t + ms, g + gflop)
+        nb, bb = algo.get(var, (0, 0))
+        algo[var] = (nb + 1, bb + int(desc.get('algo_bytes', 0)))
     igemm_profile.tam = tam
+    igemm_profile.algo = algo                       # {variant: (launches, algorithmic bytes)}: every operand once
     return agg
 
 
@@ -324,6 +378,19 @@ def main():
                                                                        max(sum(v[1] for k, v in agg.items() if sel(k)), 1e-9), 1)}
                                                 for name, sel in (('all_conv_gemm', lambda k: True),
                                                                   ('igemm_nt_tt', lambda k: k.startswith('igemm_')))}}
+            algo = getattr(igemm_profile, 'algo', {})
+            result['roofline']['algorithmic_mib_per_launch'] = {k: round(v[1] / max(v[0], 1) / 2 ** 20, 2) for k, v in sorted(algo.items())}
+            if args.config == 'gca':
+                result['roofline']['tam_all_unknown'] = tam_all_unknown(device, H // 8, W // 8)
+    if rank == 0:
+        # the window against the HBM roofline (17.8 GB of ideal-fusion traffic per 1080p window) and the counter
+        # traffic of the newest committed PMC profile (FETCH_SIZE x2 + WRITE_SIZE over the traced process, per step)
+        if args.config == 'gca' and (H, W) == (FULL_H, FULL_W):
+            gib, src = profile_step_traffic()
+            result['hbm'] = {'algorithmic_gb_per_window': ALGO_GB_WINDOW_1080P, 'peak_tbps': 8.0,
+                             'achieved_tbps': round(ALGO_GB_WINDOW_1080P * win_per_s / world / 1e3, 4),
+                             'frac': round(ALGO_GB_WINDOW_1080P * win_per_s / world / 1e3 / 8.0, 4),
+                             'counter_gib_per_step': gib, 'counter_source': src}
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -261,6 +261,18 @@ def _profiled(name, args):
         taps = sum(len({(arr[i].tap_dh[t], arr[i].tap_dw[t]) for t in range(arr[i].ntaps) if arr[i].tap_w[t] >= 0}) for i in range(n))
         # (frame-batched launches: `batch` frames of P pixels each, ops._set_frames)
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': taps, 'tap_w': [0] * taps, 'batch': max(int(d.batch), 1), 'phases': n}
+    elif name == 'tcvom_gca_dp_softmax_bwd':
+        # dP[i][j] = sum_v dO[i][v] V[j][v] with the softmax backward in its epilogue: an N x N x DV GEMM per frame on gemm_nt256<2,4>
+        N_, DV_, ld_, B_ = args[8:12]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = _FNS[name](*args)
+        e1.record()
+        # algorithmic bytes: dO, V, P read; T, T^T, P^T written (16-bit)
+        nbytes = B_ * 2 * (2 * N_ * DV_ + 4 * N_ * ld_)
+        PROFILE.append((name, {'P': N_, 'K': N_, 'C': DV_, 'ntaps': 1, 'tap_w': [0], 'batch': B_, 'phases': 1, 'variant': 'gemm_nt256',
+                               'algo_bytes': nbytes}, e0, e1))
+        return rc
     elif name == 'tcvom_gemm_pair':
         n = 1
         d = args[5]._obj
@@ -273,6 +285,12 @@ def _profiled(name, args):
         info['variant'] = _FNS['tcvom_conv_igemm_variant'](C.byref(d), n).decode()
     else:
         info['variant'] = _FNS['tcvom_wgrad_igemm_variant'](C.byref(d)).decode()
+    # algorithmic bytes of the launch: every operand once -- input pixels x channels, the weights, the output (16-bit, or fp32 output)
+    osz = 4 if (name.startswith('tcvom_conv_igemm') or name == 'tcvom_gemm_pair') and int(d.out_fp32) else 2
+    if name.startswith('tcvom_wgrad'):
+        info['algo_bytes'] = info['batch'] * 2 * (d.N * d.H * d.W * d.C + info['P'] * d.K) + 4 * d.K * d.C * max(info['ntaps'], 1)
+    else:
+        info['algo_bytes'] = info['batch'] * (2 * d.N * d.H * d.W * d.C + osz * info['P'] * d.K * info['phases']) + 2 * d.K * d.C * max(info['ntaps'], 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = _FNS[name](*args)
@@ -305,7 +323,7 @@ def call(name, *args):
     if PROFILE is not None and name in ('tcvom_tam_fwd', 'tcvom_tam_bwd'):
         rc = _profiled_tam(name, args)
     elif PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
-                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi', 'tcvom_gemm_pair'):
+                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi', 'tcvom_gemm_pair', 'tcvom_gca_dp_softmax_bwd'):
         rc = _profiled(name, args)
     else:
         rc = _FNS[name](*args)

@@ -44,3 +44,29 @@ def test_struct_layout_matches_header():
     # 13 + 1 + 3*MAX_TAPS + 7 int32 fields, then 5 int64 (8-byte aligned)
     n_i32 = 14 + 3 * L.MAX_TAPS + 7
     assert ctypes.sizeof(L.ConvDesc) == ((n_i32 * 4 + 7) // 8) * 8 + 5 * 8
+
+
+def test_host_side_under_address_sanitizer():
+    """SURVEY.md section 5 (sanitizers): the host half of the C ABI -- descriptor planning, tile selection, argument validation, the
+    error channel -- built with -fsanitize=address (`make -C tcvom_amd/csrc asan`) and driven by the planning / ABI tests in a
+    subprocess under the clang ASAN runtime; a heap overflow or use-after-free in that code aborts the run.  (Device code is
+    compiled as usual: device-side ASAN needs xnack+ modes.)"""
+    import glob
+    import subprocess
+    import sys
+    rts = glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so')
+    if not rts:
+        import pytest
+        pytest.skip('clang ASAN runtime not found')
+    lib = os.path.join(REPO, 'tcvom_amd', 'lib', 'libtcvom_hip_asan.so')
+    srcs = glob.glob(os.path.join(REPO, 'tcvom_amd', 'csrc', '*.hip')) + [os.path.join(REPO, 'tcvom_amd', 'csrc', 'common.h'),
+                                                                         os.path.join(REPO, 'include', 'tcvom_hip.h')]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(['make', '-C', os.path.join(REPO, 'tcvom_amd', 'csrc'), 'asan', '-j8'], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=rts[0], ASAN_OPTIONS='detect_leaks=0:abort_on_error=1', TCVOM_LIB=lib, TCVOM_DTYPE='bf16')
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', os.path.join(REPO, 'tests', 'test_conv_plan.py'),
+           os.path.join(REPO, 'tests', 'test_abi.py'), '-k', 'not address_sanitizer']
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and ' passed' in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    assert 'AddressSanitizer' not in out.stderr
