@@ -49,7 +49,12 @@ class PeerMailbox(object):
         handle = (C.c_ubyte * 64)()
         nbytes = self.ring * self.world * self.capacity * 16
         with torch.cuda.device(self.device):
-            L.call('tcvom_mbox_alloc', nbytes, C.byref(self._ptr), handle)
+            try:
+                L.call('tcvom_mbox_alloc', nbytes, C.byref(self._ptr), handle)
+            except L.TcvomError:
+                if self.world == 1:
+                    raise
+                self._ptr = C.c_void_p()        # publishes an all-zero handle below: every rank then raises together
             bases = [0] * self.world
             bases[self.rank] = self._ptr.value
             if self.world > 1:
@@ -57,17 +62,20 @@ class PeerMailbox(object):
                 infos = [None] * self.world
                 dist.all_gather_object(infos, me, group=group)
                 hosts = {i[0] for i in infos}
+                # (decided from the gathered data: every rank raises or none does)
                 if len(hosts) != 1:
                     self.close()
                     raise RuntimeError('PeerMailbox: the ranks span %d hosts; hipIpc mailboxes need one node' % len(hosts))
+                if len({i[1] for i in infos}) != self.world:
+                    self.close()
+                    raise RuntimeError('PeerMailbox: two ranks in one process')
+                dead = [r for r, i in enumerate(infos) if not any(i[2])]
+                if dead:
+                    self.close()
+                    raise RuntimeError('PeerMailbox: rank(s) %s could not export their mailbox (hipIpcGetMemHandle)' % dead)
                 for r, (_, pid, h) in enumerate(infos):
                     if r == self.rank:
                         continue
-                    if pid == os.getpid():
-                        raise RuntimeError('PeerMailbox: two ranks in one process')
-                    if not any(h):
-                        self.close()
-                        raise RuntimeError('PeerMailbox: rank %d could not export its mailbox (hipIpcGetMemHandle)' % r)
                     p = C.c_void_p()
                     L.call('tcvom_mbox_open', (C.c_ubyte * 64).from_buffer_copy(h), C.byref(p))
                     self._opened.append(p)
@@ -77,8 +85,8 @@ class PeerMailbox(object):
         self.status = torch.zeros(4, dtype=torch.int32).pin_memory()
         self._sync = L.BnSync(peers=self.table.data_ptr(), world=self.world, rank=self.rank, seq=0, ring=self.ring,
                               capacity=self.capacity, timeout_ticks=self.timeout_ticks, status=self.status.data_ptr())
-        if self.world > 1:
-            dist.barrier(group=group)           # every peer has mapped every mailbox before the first push
+        # (every peer must have mapped every mailbox before the first push: mailbox_for() all-reduces a flag after construction;
+        #  a direct user of this class calls dist.barrier() itself)
 
     def fits(self, nframes, channels):
         return nframes * 2 * channels <= self.capacity
@@ -93,6 +101,33 @@ class PeerMailbox(object):
             self.check()
         self._sync.seq = self.seq
         return C.byref(self._sync)
+
+    def self_test(self, channels=64, timeout_s=10.0):
+        """One real exchange through the finalize kernel with known contributions (rank r contributes r + 1 to every channel's
+        sum): every rank must read world (world + 1) / 2 -- i.e. it saw every peer's push with the right tag and data.  Uses
+        (and consumes) one sequence number on every rank.  Returns False instead of hanging when a push never arrives."""
+        dev = self.device
+        saved_ticks = self._sync.timeout_ticks
+        self._sync.timeout_ticks = int(timeout_s * 1e8)
+        try:
+            with torch.cuda.device(dev):
+                K = channels
+                part = torch.empty((1, 2, K), dtype=torch.float32, device=dev)
+                part[0, 0] = float(self.rank + 1)
+                part[0, 1] = float((self.rank + 1) ** 2)
+                gamma = torch.ones(K, device=dev)
+                beta = torch.zeros(K, device=dev)
+                ss = torch.empty(2 * K, device=dev)
+                saved = torch.empty(2 * K, device=dev)
+                L.call('tcvom_bn_finalize_sync', L.ptr(part), 1, K, self.world, self.world, L.ptr(gamma), L.ptr(beta), 1e-5,
+                       L.ptr(ss), L.ptr(saved), None, 1, 0, self.next(), L.stream_ptr())
+                torch.cuda.synchronize(dev)
+                want = (self.world + 1) / 2.0                                  # mean of 1 .. world
+                ok = bool(torch.allclose(saved[:K], torch.full((K,), want, device=dev), rtol=0, atol=1e-6)) and int(self.status[0]) == 0
+                self.status.zero_()
+                return ok
+        finally:
+            self._sync.timeout_ticks = saved_ticks
 
     def check(self):
         """Raise if a kernel gave up waiting for a peer (no synchronisation: reads the pinned status word)."""
@@ -125,17 +160,52 @@ class PeerMailbox(object):
 _MAILBOXES = {}
 
 
+def _all_ok(ok, group, device):
+    """True when `ok` holds on EVERY rank (one small all-reduce)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == 'nccl' else 'cpu')
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 def mailbox_for(group=None, device=None):
     """The PeerMailbox of (process group, device), created collectively on first use; None when the mailbox transport is not
-    available (TCVOM_SYNCBN=rccl, ranks on several hosts, more than 32 ranks)."""
+    available or does not pass its self-test on every rank (then SyncBatchNorm uses one all-reduce per BatchNorm call):
+    TCVOM_SYNCBN=rccl, ranks on several hosts, more than 32 ranks, hipIpc export / mapping refused, or peers' writes not
+    observed.  Every decision is taken identically on all ranks (from gathered data or an all-reduced flag), so a failure on
+    one rank never leaves the others waiting in a collective."""
+    import warnings
     if os.environ.get('TCVOM_SYNCBN', 'mailbox') != 'mailbox':
         return None
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     key = (id(group) if group is not None else None, dev)
-    if key not in _MAILBOXES:
-        world = dist.get_world_size(group)
-        hosts = [None] * world
-        dist.all_gather_object(hosts, socket.gethostname(), group=group)
-        ok = len(set(hosts)) == 1 and world <= 32
-        _MAILBOXES[key] = PeerMailbox(group, torch.device('cuda', dev)) if ok else None
-    return _MAILBOXES[key]
+    if key in _MAILBOXES:
+        return _MAILBOXES[key]
+    cdev = torch.device('cuda', dev)
+    world = dist.get_world_size(group)
+    hosts = [None] * world
+    dist.all_gather_object(hosts, socket.gethostname(), group=group)
+    mb, why = None, None
+    if len(set(hosts)) != 1 or world > 32:
+        why = 'the ranks span %d hosts' % len(set(hosts)) if world <= 32 else 'more than 32 ranks'
+    else:
+        try:
+            mb = PeerMailbox(group, cdev)          # (its constructor gathers the handles: every rank reaches that collective,
+            ok = True                              #  a rank that cannot export publishes an all-zero handle and all ranks raise)
+        except Exception as e:                     # noqa: BLE001 -- any local failure turns into a collective fallback
+            mb, ok, why = None, False, 'setup failed on rank %d: %s' % (dist.get_rank(group), e)
+        if not _all_ok(ok, group, cdev):
+            if mb is not None:
+                mb.close()
+            mb, why = None, why or 'setup failed on another rank'
+        else:
+            try:
+                ok = mb.self_test()
+            except Exception as e:                 # noqa: BLE001
+                ok, why = False, 'self-test raised on rank %d: %s' % (dist.get_rank(group), e)
+            if not _all_ok(ok, group, cdev):
+                mb.close()
+                mb, why = None, why or 'self-test failed (a peer\'s pushes were not observed)'
+    if mb is None and dist.get_rank(group) == 0:
+        warnings.warn('SyncBatchNorm: peer mailboxes unavailable (%s); falling back to one all-reduce per BatchNorm call' % why)
+    _MAILBOXES[key] = mb
+    return mb
