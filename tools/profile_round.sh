@@ -18,7 +18,7 @@ rm -f $db
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $out/$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out/$c.log 2>&1
 done
-tail -1 $out/kt.log > $out/bench_line.json
+grep "^{" $out/kt.log | tail -1 > $out/bench_line.json
 python tools/rocpd_pmc.py $(find $out/FETCH_SIZE -name "*.db" | head -1) $(find $out/WRITE_SIZE -name "*.db" | head -1) 40 $out/bench_line.json > gpurun_out/${tag}_hbm_traffic_pmc.md
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $out/sq -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out/sq.log 2>&1
 python tools/rocpd_mfma.py $(find $out/sq -name "*.db" | head -1) 30 > gpurun_out/${tag}_mfma_busy.md
