@@ -284,6 +284,43 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         for (int b = 0; b < 2; ++b) dl[b] = pvalid[b] ? g.delta[(int64_t)bz * g.N + pglob[b]] : 0.f;
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
+        // Transposed copy of the LDS tile ([n][m], 512-byte rows, chunk-swizzled) into dst[m][n] with the gfx950 transposing LDS
+        // read: the 16 lanes of a group address a 4 (n) x 16 (m) block -- lane L the 4 contiguous m of row L >> 2 -- and lane L
+        // receives column m = L, rows 0..3 (tools/probes/tr_probe2.hip); two reads give 8 consecutive n of one m = one 16-byte
+        // store.  Wave w owns the tile columns m = 32 w .. 32 w + 31; the four groups of a wave take four consecutive 8-n
+        // blocks, so one store instruction writes 64 contiguous bytes of 16 rows (the register form this replaces -- a lane
+        // holds 4 m of ONE n -- stored 4 bytes per lane after a pair exchange: 8x the store instructions).
+        auto store_transposed = [&](h16raw* dst) {
+            const int L = lane & 15, gq = lane >> 4;
+            h16raw* db = dst + (int64_t)bz * g.ldt * g.ldt;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                const int mcol = wave * 32 + mh * 16, mread = mcol + 4 * (L & 3), mg = m0 + mcol + L;
+#pragma unroll
+                for (int nb4 = 0; nb4 < 256; nb4 += 128) {
+                    TrFrag f[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r0 = nb4 + u * 32 + gq * 8 + (L >> 2), r1 = r0 + 4;
+                        tr_issue(f[u], reinterpret_cast<const h16raw*>(lb + r0 * 512 + (((mread >> 3) ^ (r0 & 15)) << 4) + (mread & 4) * 2),
+                                 reinterpret_cast<const h16raw*>(lb + r1 * 512 + (((mread >> 3) ^ (r1 & 15)) << 4) + (mread & 4) * 2));
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        tr_fence(f[u]);
+                        const int ng = n0 + nb4 + u * 32 + gq * 8;
+                        if (mg < g.ldt && ng + 8 <= g.ldt)
+                            *reinterpret_cast<uint4*>(db + (int64_t)mg * g.ldt + ng) = __builtin_bit_cast(uint4, tr_value(f[u]));
+                    }
+                }
+            }
+        };
+        if (g.Tt) {
+            store_transposed(g.Pt);                    // P^T from the P tile, before T overwrites it in place
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+        }
 #pragma unroll
         for (int a = 0; a < MF; ++a) {
 #pragma unroll
@@ -300,31 +337,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     o.x = pack2h(hlo(pp.x) * (acc[a][b][q * 4 + 0] - dl[b]) * sc[0], hhi(pp.x) * (acc[a][b][q * 4 + 1] - dl[b]) * sc[1]);
                     o.y = pack2h(hlo(pp.y) * (acc[a][b][q * 4 + 2] - dl[b]) * sc[2], hhi(pp.y) * (acc[a][b][q * 4 + 3] - dl[b]) * sc[3]);
                     *cell = o;
-                    if (g.Tt) {
-                        // A lane holds 4 consecutive m of ONE n; its neighbour (lane ^ 1) the same m of n + 1.  After one pair
-                        // exchange the even lane owns (n, n + 1) of rows m, m + 2 and the odd lane of rows m + 1, m + 3: 4-byte
-                        // stores whose 32 lanes cover 2 x 64 contiguous bytes of two rows.
-                        const int odd = lane & 1;
-                        const int nn = pglob[b] - odd, mr = mrow + odd;
-                        const bool okt = nn < g.ldt && mr + 2 < g.ldt + 2 && mr < g.ldt;
-                        const int64_t tb = (int64_t)bz * g.ldt * g.ldt + (int64_t)mr * g.ldt + nn;
-                        {
-                            const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)o.x, 0xB1, 0xf, 0xf, true);
-                            const unsigned py = (unsigned)__builtin_amdgcn_mov_dpp((int)o.y, 0xB1, 0xf, 0xf, true);
-                            const unsigned v0 = odd ? ((px >> 16) | (o.x & 0xffff0000u)) : ((o.x & 0xffffu) | (px << 16));
-                            const unsigned v1 = odd ? ((py >> 16) | (o.y & 0xffff0000u)) : ((o.y & 0xffffu) | (py << 16));
-                            if (okt) *reinterpret_cast<unsigned*>(g.Tt + tb) = v0;
-                            if (okt && mr + 2 < g.ldt) *reinterpret_cast<unsigned*>(g.Tt + tb + 2 * (int64_t)g.ldt) = v1;
-                        }
-                        {
-                            const unsigned px = (unsigned)__builtin_amdgcn_mov_dpp((int)pp.x, 0xB1, 0xf, 0xf, true);
-                            const unsigned py = (unsigned)__builtin_amdgcn_mov_dpp((int)pp.y, 0xB1, 0xf, 0xf, true);
-                            const unsigned v0 = odd ? ((px >> 16) | (pp.x & 0xffff0000u)) : ((pp.x & 0xffffu) | (px << 16));
-                            const unsigned v1 = odd ? ((py >> 16) | (pp.y & 0xffff0000u)) : ((pp.y & 0xffffu) | (py << 16));
-                            if (okt) *reinterpret_cast<unsigned*>(g.Pt + tb) = v0;
-                            if (okt && mr + 2 < g.ldt) *reinterpret_cast<unsigned*>(g.Pt + tb + 2 * (int64_t)g.ldt) = v1;
-                        }
-                    }
                 }
             }
         }
@@ -337,6 +349,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             const uint4 v = *reinterpret_cast<const uint4*>(lb + r * 512 + cp * 16);
             if (n0 + r < g.N && m0 + c * 8 < g.ldo) *reinterpret_cast<uint4*>(Tb + (int64_t)(n0 + r) * g.ldo + m0 + c * 8) = v;
         }
+        if (g.Tt) store_transposed(g.Tt);              // T^T from the finished T tile
         return;
     } else {
     // ---- plain epilogue (bias / scale / diagonal / activation)

@@ -13,7 +13,7 @@ from tcvom_amd import _lib as L                                      # noqa: E40
 from tcvom_amd.conv_plan import dense_desc                           # noqa: E402
 
 DEV = 'cuda'
-BF = torch.bfloat16
+BF = L.ACT_DTYPE
 
 
 def timeit(fn, iters=10):
