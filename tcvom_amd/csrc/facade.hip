@@ -59,6 +59,35 @@ __global__ void dilate_kernel(const unsigned char* __restrict__ in, unsigned cha
         out[v] = m;
     }
 }
+// The same filter on 8-pixel words (W % 8 == 0, planes hold 0 / 1 bytes): a thread produces 8 horizontally adjacent pixels.
+// pass 0: OR of the 2 r + 1 byte-shifted copies of the row, taken from the 64-bit words around the target word (funnel shifts);
+// pass 1: OR of the same word position over rows y - r .. y + r (coalesced 8-byte loads).  25 byte loads per pixel become
+// 5 / 25 word loads per 8 pixels: 77 -> ~10 us per pass on a 3 x 1088 x 1920 window.
+__global__ __launch_bounds__(256) void dilate_words_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
+                                                           int64_t F, int H, int W8, int r, int pass) {
+    GRID_STRIDE(v, F * H * W8) {
+        const int xw = (int)(v % W8), y = (int)((v / W8) % H);
+        unsigned long long m = 0ull;
+        if (pass == 0) {
+            // words xw - nw .. xw + nw cover every pixel within r of the target word's 8 pixels
+            const int nw = (r + 7) >> 3;
+            const unsigned long long* row = in + (v - xw);
+            for (int d = -r; d <= r; ++d) {
+                // pixel i of the result ORs pixel i + d of the row: bytes [8 xw + d, 8 xw + d + 8)
+                const int b0 = 8 * xw + d;                            // first source byte (may be negative / beyond the row)
+                const int w0 = b0 >> 3, sh = (b0 & 7) * 8;            // (arithmetic shift: floor for negative b0)
+                const unsigned long long lo = (w0 >= 0 && w0 < W8) ? row[w0] : 0ull;
+                const unsigned long long hi = (sh && w0 + 1 >= 0 && w0 + 1 < W8) ? row[w0 + 1] : 0ull;
+                m |= sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+            }
+            (void)nw;
+        } else {
+            const int lo = max(0, y - r), hi = min(H - 1, y + r);
+            for (int i = lo; i <= hi; ++i) m |= in[v + (int64_t)(i - y) * W8];
+        }
+        out[v] = m;
+    }
+}
 // stage 3: network input x8 [F,H,W,8] bf16 = {norm R,G,B, onehot bg,unk,fg, 0, 0}; trimask fp32; tris_vis fp32
 __global__ void assemble_kernel(const float* __restrict__ gts, const float* __restrict__ imgs, const unsigned char* __restrict__ dil,
                                 uint4* __restrict__ x8, float* __restrict__ trimask, float* __restrict__ tris_vis,
@@ -125,6 +154,47 @@ __global__ __launch_bounds__(256) void masked_l1_fwd_kernel(
                 for (int c = 0; c < 3; ++c) {
                     const int64_t j = b * rgb_stride + c * HW + p;
                     comps[j] = fminf(fmaxf(fgs[j] * r1 + bgs[j] * (1.f - r1), 0.f), 1.f);
+                }
+            }
+        }
+    }
+    s = block_sum_256(s, red);
+    n = block_sum_256(n, red);
+    if (threadIdx.x == 0) { atomicAdd(acc, s); atomicAdd(acc + 1, n); }
+}
+// The single-frame form (p2 == NULL, alphas / comps written) on float4: grid (blocks, B); no 64-bit divisions, 16-byte accesses
+// (the scalar kernel above spends its time in v / HW, v % HW and 4-byte loads: 113 us for one 1088 x 1920 frame, ~107 MB).
+__global__ __launch_bounds__(256) void masked_l1_fwd4_kernel(
+    const float4* __restrict__ p1, const float4* __restrict__ g1, const float4* __restrict__ m1,
+    const float4* __restrict__ fgs, const float4* __restrict__ bgs, float4* __restrict__ alphas, float4* __restrict__ comps,
+    float* __restrict__ acc, int HW4, int64_t p_stride4, int64_t frame_stride4, int64_t rgb_stride4)
+{
+    __shared__ float red[4];
+    const int64_t b = blockIdx.y;
+    p1 += b * p_stride4; g1 += b * frame_stride4; m1 += b * frame_stride4;
+    if (alphas) alphas += b * frame_stride4;
+    if (comps) { comps += b * rgb_stride4; fgs += b * rgb_stride4; bgs += b * rgb_stride4; }
+    float s = 0.f, n = 0.f;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < HW4; v += gridDim.x * 256) {
+        const float4 m = m1[v], p = p1[v], g = g1[v];
+        const float mm[4] = {m.x, m.y, m.z, m.w}, pp[4] = {p.x, p.y, p.z, p.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = mm[k] != 0.f ? pp[k] : gg[k];
+            s += fabsf(r[k] - gg[k]) * mm[k];
+            n += mm[k] > 1.001e-5f ? 1.f : 0.f;
+        }
+        if (alphas) {
+            alphas[v] = make_float4(fminf(fmaxf(r[0], 0.f), 1.f), fminf(fmaxf(r[1], 0.f), 1.f), fminf(fmaxf(r[2], 0.f), 1.f), fminf(fmaxf(r[3], 0.f), 1.f));
+            if (comps) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4 f = fgs[(int64_t)c * HW4 + v], q = bgs[(int64_t)c * HW4 + v];
+                    comps[(int64_t)c * HW4 + v] = make_float4(fminf(fmaxf(f.x * r[0] + q.x * (1.f - r[0]), 0.f), 1.f),
+                                                              fminf(fmaxf(f.y * r[1] + q.y * (1.f - r[1]), 0.f), 1.f),
+                                                              fminf(fmaxf(f.z * r[2] + q.z * (1.f - r[2]), 0.f), 1.f),
+                                                              fminf(fmaxf(f.w * r[3] + q.w * (1.f - r[3]), 0.f), 1.f));
                 }
             }
         }
@@ -267,8 +337,16 @@ extern "C" int tcvom_preprocess(const float* a, const float* fg, const float* bg
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W;
     hipLaunchKernelGGL(preprocess_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, a, fg, bg, gts, fgs, bgs, imgs, unk_raw, frames, HW, eps);
-    hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_raw, unk_tmp, frames, H, W, dilate_radius, 0);
-    hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_tmp, unk_dil, frames, H, W, dilate_radius, 1);
+    if (W % 8 == 0 && ((uintptr_t)unk_raw & 7) == 0 && ((uintptr_t)unk_tmp & 7) == 0 && ((uintptr_t)unk_dil & 7) == 0) {
+        const int W8 = W / 8;
+        hipLaunchKernelGGL(dilate_words_kernel, dim3(sgrid(frames * H * W8)), dim3(256), 0, st, (const unsigned long long*)unk_raw,
+                           (unsigned long long*)unk_tmp, frames, H, W8, dilate_radius, 0);
+        hipLaunchKernelGGL(dilate_words_kernel, dim3(sgrid(frames * H * W8)), dim3(256), 0, st, (const unsigned long long*)unk_tmp,
+                           (unsigned long long*)unk_dil, frames, H, W8, dilate_radius, 1);
+    } else {
+        hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_raw, unk_tmp, frames, H, W, dilate_radius, 0);
+        hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_tmp, unk_dil, frames, H, W, dilate_radius, 1);
+    }
     hipLaunchKernelGGL(assemble_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, gts, imgs, unk_dil, (uint4*)x8, trimask, tris_vis, frames, HW, eps, tri_channels);
     TCVOM_LAUNCH_CHECK("preprocess");
     return TCVOM_OK;
@@ -281,6 +359,17 @@ extern "C" int tcvom_masked_l1_fwd(const float* p1, const float* g1, const float
     TCVOM_CHECK_ARG(p1 && g1 && m1 && acc && B > 0 && HW > 0, "masked_l1_fwd: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(acc, 0, 2 * sizeof(float), st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "masked_l1_fwd: memset");
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!p2 && HW % 4 == 0 && HW / 4 < (1ll << 30) && p_stride % 4 == 0 && frame_stride % 4 == 0 && rgb_stride % 4 == 0 && B <= 65535 &&
+        al16(p1) && al16(g1) && al16(m1) && al16(alphas) && al16(comps) && al16(fgs) && al16(bgs) && (!comps || (fgs && bgs && alphas))) {
+        const int HW4 = (int)(HW / 4);
+        int blocks = (HW4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(masked_l1_fwd4_kernel, dim3(blocks, (int)B), dim3(256), 0, st, (const float4*)p1, (const float4*)g1, (const float4*)m1,
+                           (const float4*)fgs, (const float4*)bgs, (float4*)alphas, (float4*)comps, acc, HW4, p_stride / 4, frame_stride / 4, rgb_stride / 4);
+        TCVOM_LAUNCH_CHECK("masked_l1_fwd");
+        return TCVOM_OK;
+    }
     hipLaunchKernelGGL(masked_l1_fwd_kernel, dim3(sgrid(B * HW)), dim3(256), 0, st, p1, g1, m1, p2, g2, m2, fgs, bgs, alphas, comps, acc, B, HW, p_stride, frame_stride, rgb_stride);
     TCVOM_LAUNCH_CHECK("masked_l1_fwd");
     return TCVOM_OK;
