@@ -125,6 +125,7 @@ class PeerMailbox(object):
                 want = (self.world + 1) / 2.0                                  # mean of 1 .. world
                 ok = bool(torch.allclose(saved[:K], torch.full((K,), want, device=dev), rtol=0, atol=1e-6)) and int(self.status[0]) == 0
                 self.status.zero_()
+                self.exchanges -= 1                                            # (the diagnostic counts BatchNorm exchanges only)
                 return ok
         finally:
             self._sync.timeout_ticks = saved_ticks

@@ -100,6 +100,9 @@ class ConvCfg(object):
         assert pre_slope in (0.0, 0.01)
         self.act, self.pre_relu, self.unbias_mult, self.pre_slope = act, pre_relu, unbias_mult, pre_slope
         self.group_norm = isinstance(bn, torch.nn.GroupNorm)
+        # the output of this op is consumed by the decoder TAIL only (shortcut branches fea1..fea3 of the GCA encoder): in a
+        # frame-batched window only the interior frames (bank.tail_frames) can receive a gradient, see _ConvBNAct.backward
+        self.tail_only = False
         self._geo = {}
 
     def geometry(self, N, H, W):
@@ -224,6 +227,8 @@ class _ConvBNAct(torch.autograd.Function):
         pre_act = (ACT_LEAKY01 if cfg.pre_slope else ACT_RELU) if cfg.pre_relu else ACT_NONE
         _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, pre_act, st, nf, wsf)
         ctx.cfg, ctx.training, ctx.call, ctx.geo, ctx.nf, ctx.wsb = cfg, training, call, geo, nf, wsb
+        tf = getattr(bank, 'tail_frames', None)
+        ctx.active = tf if (cfg.tail_only and tf is not None and nf > 1 and 0 <= tf[0] < tf[1] <= nf and tf[1] - tf[0] < nf) else None
         ctx.has_res1, ctx.has_res2, ctx.has_bias = res1 is not None, res2 is not None, bias is not None
         if not has_bn:
             assert res1 is None and res2 is None and cfg.act == ACT_NONE
@@ -300,6 +305,8 @@ class _ConvBNAct(torch.autograd.Function):
             dz2 = extra[0] if len(extra) == 1 else sum(extra[1:], extra[0])
             assert dz2.shape == dz.shape and dz2.dtype == dz.dtype
         P = geo.out_pixels
+        if ctx.active is not None and cfg.bn is not None and not ctx.has_res1 and not ctx.has_res2 and not ctx.has_bias:
+            return _ConvBNAct._backward_active(ctx, dz, dz2)
         if cfg.bn is None:
             if cfg.pre_relu:
                 x, y = ctx.saved_tensors
@@ -375,6 +382,72 @@ class _ConvBNAct(torch.autograd.Function):
             dx = None
         _unscale_(bank, dbias)
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None, None
+
+
+def _backward_active(ctx, dz, dz2):
+    """Backward of a frame-batched conv + BatchNorm op whose output reaches the loss through the interior frames only
+    (ctx.active = (f0, f1) of nf frames; the shortcut branches fea1 .. fea3 of the GCA encoder feed the decoder TAIL, which runs
+    for the interior frames -- VMN_model.py:107-110 -- so the reference's autograd never visits them for the end frames).  The
+    incoming gradient of the other frames is identically zero: their BatchNorm backward, data gradient and weight gradient are
+    skipped instead of computed on zeros (at 1080p the os1 / os2 / os4 branches are HBM-bound passes over 400 MB tensors).  The
+    returned input gradient is a full tensor, zero in the skipped frames."""
+    cfg, geo, nf = ctx.cfg, ctx.geo, ctx.nf
+    spec, bank = cfg.spec, cfg.bank
+    f0, f1 = ctx.active
+    nfa, N = f1 - f0, geo.N
+    st = L.stream_ptr()
+    K = spec.K
+    P = geo.out_pixels
+    x, y, gamma, _r1 = ctx.saved_tensors
+    if ctx.window_id != bank.window_id:
+        raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not supported' % spec.name)
+    fr = lambda t: t[f0 * N:f1 * N] if t is not None else None          # frame-major: a contiguous slice
+    dza, dz2a, ya, xa = fr(dz), fr(dz2), fr(y), fr(x)
+    stride = ctx.slot_stride
+    ss = C.c_void_p(ctx.ss.value + 4 * f0 * stride)
+    saved = C.c_void_p(ctx.saved.value + 4 * f0 * stride)
+    groups = L.call('tcvom_bn_bwd_groups', P, K)
+    partial = torch.empty(nfa * groups * 2 * K, dtype=torch.float32, device=dz.device)
+    yf = 1 if y.dtype == torch.float32 else 0
+    L.call('tcvom_bn_bwd_reduce', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(partial), P, K, cfg.act, yf, nfa, stride, st)
+    dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
+    coef = torch.empty(nfa * 3 * K, dtype=torch.float32, device=dz.device)
+    scratch = torch.empty(nfa * 128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
+    sync = ctx.sync if ctx.training else None
+    if cfg.group_norm:
+        L.call('tcvom_gn_bwd_finalize', L.ptr(partial), groups, K, P, cfg.bn.num_groups, L.ptr(gamma), saved, dgp, dbp,
+               L.ptr(coef), L.ptr(scratch), nfa, stride, st)
+    elif sync is None:
+        L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
+               L.ptr(coef), L.ptr(scratch), 1, nfa, stride, st)
+    elif sync.mailbox is not None and sync.mailbox.fits(nfa, K):
+        # (every rank skips the same frames: the exchange carries the sums of the active frames only)
+        L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, K, P * sync.world, L.ptr(gamma), saved, dgp, dbp,
+               L.ptr(coef), L.ptr(scratch), 1, nfa, stride, sync.mailbox.next(), st)
+    else:
+        local = torch.empty(nfa * 2 * K, dtype=torch.float64, device=dz.device)
+        L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), nfa, st)
+        total = local.clone()
+        SYNC_ALLREDUCES[0] += 1
+        dist.all_reduce(total, group=sync.group)
+        L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * sync.world, L.ptr(gamma), saved,
+               dgp, dbp, L.ptr(coef), 1, nfa, stride, st)
+    dya = torch.empty(ya.shape, dtype=H16, device=dz.device)
+    L.call('tcvom_bn_bwd_apply', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(coef), L.ptr(dya),
+           None, P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nfa, stride, st)
+    dx = None
+    if spec.needs_dgrad and ctx.needs_input_grad[0]:
+        cx = spec.cpad if spec.cpad > 8 else spec.C
+        dx = torch.zeros((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dz.device)
+        _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), fr(dx), None, None, ACT_NONE, st, nfa, ctx.wsb)
+    bank.defer_wgrad(spec, ctx.call + f0, dya, xa, geo, nfa)
+    if dx is not None and ctx.x_stash is not None and dx.shape == x.shape:
+        ctx.x_stash.append(dx)
+        dx = None
+    return dx, None, None, None, None, None, None, None, None, None
+
+
+_ConvBNAct._backward_active = staticmethod(_backward_active)
 
 
 # =============================================================================================

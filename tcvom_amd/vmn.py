@@ -68,6 +68,10 @@ def _mid_tensors(mid):
     return out
 
 
+import os as _os
+TAIL_SKIP = _os.environ.get('TCVOM_NO_TAIL_SKIP', '0') != '1'        # A/B switch (tools/ab_bench.sh TCVOM_NO_TAIL_SKIP)
+
+
 class VMN(nn.Module):
     """models/VMN/VMN_model.py:70-113."""
 
@@ -158,6 +162,9 @@ class VMN(nn.Module):
         front_training = training if front_training is None else front_training
         try:
             bank.frames_per_op = S
+            # only the interior frames are decoded (VMN_model.py:107-110): ops whose output feeds the decoder tail alone skip
+            # the backward of the end frames (ops._backward_active)
+            bank.tail_frames = (1, S - 1) if TAIL_SKIP else None
             if self.freeze_backbone:
                 with torch.no_grad():
                     mid, feat = self._front(X, U, token, front_training)
@@ -171,6 +178,7 @@ class VMN(nn.Module):
             pred, ab, af = self.decoder.run_tail(feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B], U[lo:hi], mid_c, token, training)
         finally:
             bank.frames_per_op = 1
+            bank.tail_frames = None
         preds, attb, attf = [None] * S, [None] * S, [None] * S
         for i in range(1, S - 1):
             sl = slice((i - 1) * B, i * B)
