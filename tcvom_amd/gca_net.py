@@ -208,6 +208,7 @@ class ResGuidedCxtAtten(nn.Module):
                                 reg(p + '.3', sc[3], sc[5], pre_relu=True)))
         for a, b in self._short[:3]:            # fea1 .. fea3 (os1, os2, os4) feed the decoder tail only (VMN_GCA.py:39-47)
             a.tail_only = b.tail_only = True
+            b.tail_last = True
         gh = self.guidance_head
         self._guid = [reg('guidance_head.1', gh[1], gh[3], pre_relu=True, needs_dgrad=False),
                       reg('guidance_head.5', gh[5], gh[7], pre_relu=True),

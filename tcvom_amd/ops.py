@@ -103,6 +103,7 @@ class ConvCfg(object):
         # the output of this op is consumed by the decoder TAIL only (shortcut branches fea1..fea3 of the GCA encoder): in a
         # frame-batched window only the interior frames (bank.tail_frames) can receive a gradient, see _ConvBNAct.backward
         self.tail_only = False
+        self.tail_last = False              # ... and it is the last op of such a branch (its output is the tail's input)
         self._geo = {}
 
     def geometry(self, N, H, W):
@@ -280,8 +281,16 @@ class _ConvBNAct(torch.autograd.Function):
         z = torch.empty((NT, geo.OH, geo.OW, K), dtype=H16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
-        L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0,
-               nf, slot_stride, st)
+        if ctx.active is not None and cfg.tail_last and r1 is None and r2 is None:
+            # last op of a tail-only branch: its output is read for the interior frames only -- the end frames still went
+            # through the conv (their batch statistics feed the BatchNorm's running statistics, as in the reference) but are
+            # not normalised / stored (z is uninitialised there; tcvom_amd.vmn slices the interior frames)
+            f0, f1 = ctx.active
+            L.call('tcvom_bn_apply', L.ptr(y[f0 * N:f1 * N]), C.c_void_p(ss.value + 4 * f0 * slot_stride), None, None,
+                   L.ptr(z[f0 * N:f1 * N]), geo.out_pixels, K, cfg.act, 1 if hp else 0, f1 - f0, slot_stride, st)
+        else:
+            L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0,
+                   nf, slot_stride, st)
         ctx.save_for_backward(x, y, gamma, r1)
         return z
 
@@ -291,22 +300,34 @@ class _ConvBNAct(torch.autograd.Function):
         spec, bank = cfg.spec, cfg.bank
         st = L.stream_ptr()
         K = spec.K
-        extra = []
+        extra, ranged = [], []
         if ctx.stash:                                      # gradients consumers deposited instead of returning them to autograd
-            extra = [_c(t) for t in ctx.stash]
+            for t in ctx.stash:
+                if isinstance(t, tuple):                   # ('rows', g, lo, hi): frame_slice's gradient of rows lo .. hi only
+                    ranged.append(t)
+                else:
+                    extra.append(_c(t))
             del ctx.stash[:]
+        if ranged and (ctx.active is None or any((lo, hi) != (ctx.active[0] * geo.N, ctx.active[1] * geo.N) for _, _, lo, hi in ranged)):
+            for _, g, lo, hi in ranged:                    # (not the skipping path after all: the plain zero-padded gradient)
+                full = g.new_zeros((geo.N * nf,) + tuple(g.shape[1:]))
+                full[lo:hi] = g
+                extra.append(full)
+            ranged = []
         if dz is None:
-            if not extra:
+            if not extra and not ranged:
                 return (None,) * 10                        # nothing arrived: the output did not reach the loss
-            dz = extra.pop(0)
-        dz = _c(dz)
+            if extra:
+                dz = extra.pop(0)
+        dz = _c(dz) if dz is not None else None
         dgamma = dbeta = dbias = dres1 = dz2 = None
         if extra:
             dz2 = extra[0] if len(extra) == 1 else sum(extra[1:], extra[0])
-            assert dz2.shape == dz.shape and dz2.dtype == dz.dtype
+            assert dz is not None and dz2.shape == dz.shape and dz2.dtype == dz.dtype
         P = geo.out_pixels
         if ctx.active is not None and cfg.bn is not None and not ctx.has_res1 and not ctx.has_res2 and not ctx.has_bias:
-            return _ConvBNAct._backward_active(ctx, dz, dz2)
+            return _ConvBNAct._backward_active(ctx, dz, dz2, [_c(g) for _, g, _, _ in ranged])
+        assert not ranged and dz is not None
         if cfg.bn is None:
             if cfg.pre_relu:
                 x, y = ctx.saved_tensors
@@ -384,7 +405,7 @@ class _ConvBNAct(torch.autograd.Function):
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None, None
 
 
-def _backward_active(ctx, dz, dz2):
+def _backward_active(ctx, dz, dz2, ranged=()):
     """Backward of a frame-batched conv + BatchNorm op whose output reaches the loss through the interior frames only
     (ctx.active = (f0, f1) of nf frames; the shortcut branches fea1 .. fea3 of the GCA encoder feed the decoder TAIL, which runs
     for the interior frames -- VMN_model.py:107-110 -- so the reference's autograd never visits them for the end frames).  The
@@ -402,17 +423,25 @@ def _backward_active(ctx, dz, dz2):
     if ctx.window_id != bank.window_id:
         raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not supported' % spec.name)
     fr = lambda t: t[f0 * N:f1 * N] if t is not None else None          # frame-major: a contiguous slice
-    dza, dz2a, ya, xa = fr(dz), fr(dz2), fr(y), fr(x)
+    # the incoming gradient of the active frames: slices of full-size gradients and / or the row-range gradients frame_slice
+    # deposited (those never existed at full size: no zero fill, no copy); the kernels take two addends
+    parts = [t for t in (fr(dz), fr(dz2)) if t is not None] + list(ranged)
+    assert parts, 'no gradient for the active frames'
+    while len(parts) > 2:
+        parts = [parts[0] + parts[1]] + parts[2:]
+    dza, dz2a = parts[0], (parts[1] if len(parts) > 1 else None)
+    ya, xa = fr(y), fr(x)
     stride = ctx.slot_stride
     ss = C.c_void_p(ctx.ss.value + 4 * f0 * stride)
     saved = C.c_void_p(ctx.saved.value + 4 * f0 * stride)
     groups = L.call('tcvom_bn_bwd_groups', P, K)
-    partial = torch.empty(nfa * groups * 2 * K, dtype=torch.float32, device=dz.device)
+    dev = dza.device
+    partial = torch.empty(nfa * groups * 2 * K, dtype=torch.float32, device=dev)
     yf = 1 if y.dtype == torch.float32 else 0
     L.call('tcvom_bn_bwd_reduce', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(partial), P, K, cfg.act, yf, nfa, stride, st)
     dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
-    coef = torch.empty(nfa * 3 * K, dtype=torch.float32, device=dz.device)
-    scratch = torch.empty(nfa * 128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
+    coef = torch.empty(nfa * 3 * K, dtype=torch.float32, device=dev)
+    scratch = torch.empty(nfa * 128 * K, dtype=torch.float64, device=dev) if groups > 256 else None
     sync = ctx.sync if ctx.training else None
     if cfg.group_norm:
         L.call('tcvom_gn_bwd_finalize', L.ptr(partial), groups, K, P, cfg.bn.num_groups, L.ptr(gamma), saved, dgp, dbp,
@@ -425,20 +454,20 @@ def _backward_active(ctx, dz, dz2):
         L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, K, P * sync.world, L.ptr(gamma), saved, dgp, dbp,
                L.ptr(coef), L.ptr(scratch), 1, nfa, stride, sync.mailbox.next(), st)
     else:
-        local = torch.empty(nfa * 2 * K, dtype=torch.float64, device=dz.device)
+        local = torch.empty(nfa * 2 * K, dtype=torch.float64, device=dev)
         L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), nfa, st)
         total = local.clone()
         SYNC_ALLREDUCES[0] += 1
         dist.all_reduce(total, group=sync.group)
         L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * sync.world, L.ptr(gamma), saved,
                dgp, dbp, L.ptr(coef), 1, nfa, stride, st)
-    dya = torch.empty(ya.shape, dtype=H16, device=dz.device)
+    dya = torch.empty(ya.shape, dtype=H16, device=dev)
     L.call('tcvom_bn_bwd_apply', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(coef), L.ptr(dya),
            None, P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nfa, stride, st)
     dx = None
     if spec.needs_dgrad and ctx.needs_input_grad[0]:
         cx = spec.cpad if spec.cpad > 8 else spec.C
-        dx = torch.zeros((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dz.device)
+        dx = torch.zeros((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dza.device)
         _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), fr(dx), None, None, ACT_NONE, st, nfa, ctx.wsb)
     bank.defer_wgrad(spec, ctx.call + f0, dya, xa, geo, nfa)
     if dx is not None and ctx.x_stash is not None and dx.shape == x.shape:
@@ -652,6 +681,41 @@ index_pool = _IndexPool.apply
 index_up = _IndexUp.apply
 
 
+class _FrameSlice(torch.autograd.Function):
+    """Rows [lo, hi) of a frame-major batch (the interior frames on their way to the decoder tail).  When the producer is a
+    tail-only op that skips the other frames in its backward (`_tcvom_tail_rows` on the tensor), the gradient of the slice is
+    DEPOSITED with the producer as a row-range gradient instead of being padded to full size: no zero fill of the end frames, no
+    copy (at 1080p the os1 branch alone: 400 MB of fill + 134 MB of copy per step)."""
+
+    @staticmethod
+    def forward(ctx, t, lo, hi, stash):
+        ctx.stash, ctx.rng, ctx.rows = stash, (lo, hi), t.shape[0]
+        ctx.set_materialize_grads(False)
+        return t[lo:hi]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        lo, hi = ctx.rng
+        if ctx.stash is not None:
+            ctx.stash.append(('rows', g, lo, hi))
+            return None, None, None, None
+        full = g.new_zeros((ctx.rows,) + tuple(g.shape[1:]))
+        full[lo:hi] = g
+        return full, None, None, None
+
+
+def frame_slice(t, lo, hi):
+    """t[lo:hi] along the frame-major batch dimension, see _FrameSlice."""
+    if not torch.is_tensor(t):
+        return t
+    rows = getattr(t, '_tcvom_tail_rows', None)
+    if not t.requires_grad or rows != (lo, hi):
+        return t[lo:hi]
+    return _FrameSlice.apply(t, lo, hi, getattr(t, '_tcvom_grad_stash', None))
+
+
 def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
     """conv (+BatchNorm +activation +residuals).  Skip-branch gradients: the output z of an op WITH a BatchNorm carries a list
     (`z._tcvom_grad_stash`); a later op that takes z as its residual input `res1` (the `out += identity` of a BasicBlock, whose
@@ -665,6 +729,12 @@ def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
     z = _ConvBNAct.apply(x, token, gamma, beta, cfg.spec.bias, res1, res2, cfg, training, stash)
     if stash is not None and z.requires_grad:
         z._tcvom_grad_stash = stash
+        tf, nf = getattr(cfg.bank, 'tail_frames', None), cfg.bank.frames_per_op
+        if (cfg.tail_only and tf is not None and nf > 1 and 0 <= tf[0] < tf[1] <= nf and tf[1] - tf[0] < nf and res1 is None
+                and res2 is None and cfg.spec.bias is None):
+            # (the condition under which _ConvBNAct.backward takes the frame-skipping path: frame_slice may deposit with it)
+            n = z.shape[0] // nf
+            z._tcvom_tail_rows = (tf[0] * n, tf[1] * n)
     return z
 
 

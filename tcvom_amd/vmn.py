@@ -60,6 +60,21 @@ class FeatureAggregationModule(nn.Module):
         return _to_nchw(out), attb, attf, small
 
 
+def _stack_frames(ts):
+    """The S per-frame tensors [B, ...] as ONE frame-major batch [S*B, ...]: a view when they already are consecutive slices
+    of one buffer (the facade's x8 [B, S, H, W, 8] with B = 1: 100 MB of torch.cat per 1080p window otherwise)."""
+    t0 = ts[0]
+    if len(ts) == 1:
+        return t0
+    n = t0.numel()
+    if n > 0 and not t0.requires_grad and all(
+            t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and not t.requires_grad and
+            t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() and t.storage_offset() == t0.storage_offset() + i * n
+            for i, t in enumerate(ts)):
+        return t0.new_empty(0).set_(t0.untyped_storage(), t0.storage_offset(), (len(ts) * t0.shape[0],) + tuple(t0.shape[1:]))
+    return torch.cat(ts, 0)
+
+
 def _mid_tensors(mid):
     """Every tensor an encoder handed to the decoder (skip features, pooling indices ...)."""
     out = []
@@ -157,7 +172,7 @@ class VMN(nn.Module):
         S = len(frames_x8)
         B = frames_x8[0].shape[0]
         bank = self._bank
-        X = torch.cat(frames_x8, 0) if S > 1 else frames_x8[0]
+        X = _stack_frames(frames_x8)
         U = torch.cat(unk_u8, 0) if S > 1 else unk_u8[0]
         front_training = training if front_training is None else front_training
         try:
@@ -172,7 +187,8 @@ class VMN(nn.Module):
                 mid, feat = self._front(X, U, token, front_training)
             bank.frames_per_op = S - 2
             lo, hi = B, (S - 1) * B                               # the interior frames 1 .. S-2
-            mid_c = {k: (tuple(t[lo:hi] for t in v) if isinstance(v, (tuple, list)) else v[lo:hi]) for k, v in mid.items()
+            fs = ops.frame_slice
+            mid_c = {k: (tuple(fs(t, lo, hi) for t in v) if isinstance(v, (tuple, list)) else fs(v, lo, hi)) for k, v in mid.items()
                      if k != 'unknown'}
             mid_c['unknown'] = U[lo:hi]
             pred, ab, af = self.decoder.run_tail(feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B], U[lo:hi], mid_c, token, training)
