@@ -283,7 +283,7 @@ int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, const int32_t
 int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
                       const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
                       const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,
-                      float* inner, int32_t max_calls, float* grad_arena, void* stream);
+                      float* inner, int32_t max_calls, float* grad_arena, float out_scale /* multiplies every written gradient: 1 / loss scale of the fp16 build, else 1 */, void* stream);
 
 /* ------------------------------------------------------------------ layout / resampling helpers (NHWC bf16) */
 int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

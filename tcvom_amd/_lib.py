@@ -107,7 +107,7 @@ _PROTOS = {
     'tcvom_mbox_free': [vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
-    'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, vp],
+    'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, f32, vp],
     'tcvom_avgpool2': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_upsample2': [vp, vp, i32, i32, i32, i32, f32, vp],
     'tcvom_sumpool2': [vp, vp, i32, i32, i32, i32, f32, vp],

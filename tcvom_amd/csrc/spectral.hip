@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const int64_t* __rest
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
                                                            const float* __restrict__ dw_arena, int64_t dw_call_stride,
                                                            const float* __restrict__ inner, SnScratch sc,
-                                                           const int* __restrict__ ncalls, float* __restrict__ grad_arena)
+                                                           const int* __restrict__ ncalls, float* __restrict__ grad_arena, float out_scale)
 {
     const int layer = work[blockIdx.x * 2];
     const int64_t* L = tab + (int64_t)layer * SN_WORDS;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
             g += d / sg - inner[(int64_t)call * sc.L + layer] / (sg * sg) * uu * vv;
         }
     }
-    grad_arena[L[SN_GRAD_OFF] + e] = g;
+    grad_arena[L[SN_GRAD_OFF] + e] = g * out_scale;           // (1 / loss scale of the fp16 build; ws_backward is linear in it)
 }
 
 // ------------------------------------------------------------------------------ weight standardisation
@@ -470,7 +470,7 @@ extern "C" int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, co
 extern "C" int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
                                  const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
                                  const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,
-                                 float* inner, int32_t max_calls, float* grad_arena, void* stream) {
+                                 float* inner, int32_t max_calls, float* grad_arena, float out_scale, void* stream) {
     TCVOM_CHECK_ARG(table && s && work_apply && ncalls && dw_arena && inner && grad_arena, "sn_backward: null pointer");
     hipStream_t st = (hipStream_t)stream;
     SnScratch sc = mk_scratch(s);
@@ -480,7 +480,7 @@ extern "C" int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s
         hipLaunchKernelGGL(sn_bwd_inner_kernel, dim3(n_inner), dim3(256), 0, st, table, work_inner, dw_arena,
                            dw_call_stride, inner, sc.L);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(n_apply), dim3(256), 0, st, table, work_apply, dw_arena, dw_call_stride,
-                       inner, sc, ncalls, grad_arena);
+                       inner, sc, ncalls, grad_arena, out_scale);
     TCVOM_LAUNCH_CHECK("sn_backward");
     return TCVOM_OK;
 }

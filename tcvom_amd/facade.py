@@ -429,6 +429,15 @@ class EvalModel(FullModel):
         return alphas, Fs, Bs
 
 
+_LOSS_WEIGHTS = {}
+
+
 def train_step_loss(out):
-    """train_ddp.py:56-61."""
-    return out[0].mean() + out[1].mean() + out[2].mean() + 0.5 * out[3].mean() + 0.25 * out[4].mean()
+    """train_ddp.py:56-61: L_alpha + L_comp + L_grad + 0.5 L_dt + 0.25 L_att (each `.mean()` of a 0-d loss) -- as one stack and one
+    weighted sum instead of a dozen scalar kernels."""
+    terms = [o if o.dim() == 0 else o.mean() for o in out[:5]]
+    dev = terms[0].device
+    w = _LOSS_WEIGHTS.get(dev)
+    if w is None:
+        w = _LOSS_WEIGHTS[dev] = torch.tensor([1.0, 1.0, 1.0, 0.5, 0.25], dtype=torch.float32).to(dev)
+    return (torch.stack([t.float() for t in terms]) * w).sum()

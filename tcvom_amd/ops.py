@@ -203,6 +203,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.stash = stash
         ctx.res1_stash = getattr(res1, '_tcvom_grad_stash', None) if res1 is not None else None
         ctx.x_stash = getattr(x, '_tcvom_grad_stash', None)
+        ctx.x_tail_rows = getattr(x, '_tcvom_tail_rows', None)      # x comes from a tail-only op: it takes row-range gradients
         ctx.set_materialize_grads(False)             # every consumer may have deposited: then autograd hands over None
         x = _c(x)
         NT, H, W, Cx = x.shape
@@ -467,8 +468,14 @@ def _backward_active(ctx, dz, dz2, ranged=()):
     dx = None
     if spec.needs_dgrad and ctx.needs_input_grad[0]:
         cx = spec.cpad if spec.cpad > 8 else spec.C
-        dx = torch.zeros((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dza.device)
-        _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), fr(dx), None, None, ACT_NONE, st, nfa, ctx.wsb)
+        if ctx.x_tail_rows == (f0 * N, f1 * N) and ctx.x_stash is not None and cx == x.shape[3]:
+            # the producer of x skips the same frames: hand it the gradient of the active rows only (no full-size tensor)
+            dxa = torch.empty((N * nfa, geo.H, geo.W, cx), dtype=H16, device=dev)
+            _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), dxa, None, None, ACT_NONE, st, nfa, ctx.wsb)
+            ctx.x_stash.append(('rows', dxa, f0 * N, f1 * N))
+        else:
+            dx = torch.zeros((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dev)
+            _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), fr(dx), None, None, ACT_NONE, st, nfa, ctx.wsb)
     bank.defer_wgrad(spec, ctx.call + f0, dya, xa, geo, nfa)
     if dx is not None and ctx.x_stash is not None and dx.shape == x.shape:
         ctx.x_stash.append(dx)

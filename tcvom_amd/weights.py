@@ -551,22 +551,20 @@ class WeightBank(object):
         grad = torch.empty(self.grad_numel, dtype=torch.float32, device=self.device)
         st = L.stream_ptr()
         hook = self.grad_span_hook
-        inv = 1.0 / self.loss_scale
+        inv = 1.0 / self.loss_scale                    # (fp16 build: the backward ran under the loss scale, ops.py; folded into sn_backward's writes)
         chunks = self._chunks(plan) if hook is not None else [(0, len(self.specs), 0, self.grad_numel, 0, plan['n_inner'], 0, self.n_apply)]
         for lo, hi, g0, g1, i0, ni, a0, na in chunks:
             self.run_deferred_wgrads(None if len(chunks) == 1 else (lo, hi))
             wi = C.c_void_p(plan['work_inner'].data_ptr() + 12 * i0) if ni else None
             wa = C.c_void_p(self.work_apply.data_ptr() + 8 * a0)
             L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), wi, ni, wa, na, L.ptr(plan['ncalls_dev']),
-                   L.ptr(self.dw_arena), self.dw_stride, L.ptr(self.inner), self.max_calls, L.ptr(grad), st)
+                   L.ptr(self.dw_arena), self.dw_stride, L.ptr(self.inner), self.max_calls, L.ptr(grad), inv, st)
             if self.n_ws:
                 rows = [(i, r) for i, r in self._ws_rows if lo <= i < hi]
                 if rows:
                     w0 = self._ws_rows.index(rows[0])
                     L.call('tcvom_ws_backward', L.ptr(self.table), C.c_void_p(self.work_ws.data_ptr() + 8 * w0), len(rows),
                            L.ptr(grad), st)
-            if inv != 1.0:                                 # (fp16 build: the backward ran under the loss scale, ops.py)
-                grad[g0:g1].mul_(inv)
             if hook is not None:
                 hook(grad, g0, g1)
         self.run_deferred_wgrads()                     # (nothing left unless a layer id fell outside the ranges)
