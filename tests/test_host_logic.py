@@ -1,0 +1,52 @@
+"""Host-side logic of the frame-batched window that needs no GPU: frame stacking without a copy, the row-range gradient
+deposit of `ops.frame_slice`, and the fused loss sum of train_ddp.py:56-61."""
+import torch
+
+
+def test_stack_frames_is_a_view_of_consecutive_slices():
+    from tcvom_amd.vmn import _stack_frames
+    buf = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(1, 6, 4, 5)          # facade layout [B = 1, S, ...]
+    frames = [buf[:, s] for s in range(3)]
+    X = _stack_frames(frames)
+    assert X.shape == (3, 4, 5) and X.data_ptr() == buf.data_ptr() and torch.equal(X, buf[0, :3])
+    # B = 2: the frames of one clip are not consecutive in a [B, S, ...] buffer -> a real concatenation, frame-major
+    buf2 = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
+    frames2 = [buf2[:, s].contiguous() for s in range(3)]
+    X2 = _stack_frames(frames2)
+    assert X2.shape == (6, 4) and torch.equal(X2, torch.cat(frames2, 0))
+    assert _stack_frames([buf2[:, 0]]) is not None
+
+
+def test_frame_slice_deposits_a_row_range_gradient_or_pads_with_zeros():
+    from tcvom_amd import ops
+    # a producer that takes row-range gradients: frame_slice hands the small gradient over and returns nothing to autograd
+    t = torch.randn(6, 3, requires_grad=True)
+    y = t * 2.0
+    stash = []
+    y._tcvom_grad_stash = stash
+    y._tcvom_tail_rows = (2, 4)
+    z = ops.frame_slice(y, 2, 4)
+    assert z.shape == (2, 3) and torch.equal(z, y[2:4])
+    z.sum().backward()
+    assert t.grad is None or float(t.grad.abs().sum()) == 0.0          # nothing flowed through autograd ...
+    assert len(stash) == 1 and stash[0][0] == 'rows' and stash[0][2:] == (2, 4) and torch.equal(stash[0][1], torch.ones(2, 3))
+    # any other tensor: the plain slice, whose gradient is the zero-padded one
+    t2 = torch.randn(6, 3, requires_grad=True)
+    ops.frame_slice(t2 * 1.0, 2, 4).sum().backward()
+    want = torch.zeros(6, 3)
+    want[2:4] = 1.0
+    assert torch.equal(t2.grad, want)
+    # a different row range than the producer skips: not deposited
+    y3 = (t2 * 1.0)
+    y3._tcvom_grad_stash, y3._tcvom_tail_rows = [], (2, 4)
+    assert ops.frame_slice(y3, 0, 2).grad_fn.__class__.__name__ != '_FrameSliceBackward'
+
+
+def test_train_step_loss_matches_the_reference_formula():
+    from tcvom_amd.facade import train_step_loss
+    vals = [torch.tensor(v, requires_grad=True) for v in (0.3, 0.0, 0.0, 0.7, 1.9)]
+    loss = train_step_loss(vals + [None] * 7)
+    want = vals[0].mean() + vals[1].mean() + vals[2].mean() + 0.5 * vals[3].mean() + 0.25 * vals[4].mean()
+    assert abs(float(loss) - float(want)) < 1e-7
+    loss.backward()
+    assert [float(v.grad) for v in vals] == [1.0, 1.0, 1.0, 0.5, 0.25]
