@@ -396,6 +396,9 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         // 128x128 tiles from 256 workgroups on (3-frame launches of the os16 / os32 layers: 16 vs 18 us per frame in isolation, the
         // step barely moves: 30.02 -> 29.85 ms); TCVOM_NT_T128 = study knob
         static const int t128 = getenv("TCVOM_NT_T128") ? atoi(getenv("TCVOM_NT_T128")) : 256;
+        // (measured and dropped, round 3: 256 (channels) x 128 (pixels) tiles for the 256-channel os16 layers -- 192 workgroups, one
+        //  per CU, 25 % fewer operand bytes per MAC than two co-resident 128 x 128 workgroups: 25.57 -> 25.80 ms per step; the
+        //  128 x 128 threshold lowered to 150 workgroups for the 512-channel os32 layers: no change)
         if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
         if (wgs >= t128) return {128, 128, 4};
         if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
