@@ -277,6 +277,8 @@ typedef struct {
 int tcvom_sn_power_iteration(const int64_t* table, const tcvom_sn_scratch* s,
                              const int32_t* work_wtu, int32_t n_wtu, const int32_t* work_wv, int32_t n_wv,
                              const int32_t* sn_layers, int32_t n_sn, int32_t call, int32_t training, void* stream);
+/* call >= 0: every work entry (layer, which, block) packs that power-iteration call; call < 0: the entry carries its own call in
+ * bits 8.. of `which` (all calls of a window in one launch). */
 int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, const int32_t* work_pack, int32_t n_pack,
                   int32_t call, void* fwd_arena, void* bwd_arena, int64_t fwd_call_stride,
                   int64_t bwd_call_stride, void* stream);

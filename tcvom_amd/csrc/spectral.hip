@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
                                                       int64_t fwd_call_stride, int64_t bwd_call_stride)
 {
     __shared__ h16raw tile_lds[SNP_TK * SNP_ROW];
-    const int layer = work[blockIdx.x * 3], which = work[blockIdx.x * 3 + 1];
+    // `call` < 0: the work entry carries its own call in bits 8.. of `which` (all power-iteration calls of a window packed in ONE
+    // launch: the fp32 weights are read once per tile from HBM and the later calls hit the cache)
+    const int layer = work[blockIdx.x * 3], wraw = work[blockIdx.x * 3 + 1], which = wraw & 0xff;
+    if (call < 0) call = wraw >> 8;
     const int64_t base = (int64_t)work[blockIdx.x * 3 + 2] * 256;
     const int64_t* L = tab + (int64_t)layer * SN_WORDS;
     const float* W = reinterpret_cast<const float*>(L[SN_W]);

@@ -96,6 +96,9 @@ def _wgrad_ws_key(geo):
     return key
 
 
+PACK_ALL_CALLS = os.environ.get('TCVOM_NO_PACK_ALL', '0') != '1'       # A/B switch (tools/ab_bench.sh TCVOM_NO_PACK_ALL)
+
+
 class WeightBank(object):
     def __init__(self):
         self.specs = []
@@ -366,6 +369,8 @@ class WeightBank(object):
                 if n_sn > 0:
                     L.call('tcvom_sn_power_iteration', L.ptr(self.table), sc, L.ptr(wtu), n_wtu, L.ptr(wv), n_wv,
                            L.ptr(ids), n_sn, call, flag, st)
+            if plan['iters'] > 1 and PACK_ALL_CALLS:
+                continue                                   # packed below, all calls in one launch
             if call == 0:
                 wp, npk = self.work_pack_all, self.n_pack_all
             else:
@@ -373,6 +378,12 @@ class WeightBank(object):
             if npk > 0:
                 L.call('tcvom_sn_pack', L.ptr(self.table), sc, L.ptr(wp), npk, call, L.ptr(self.fwd_arena),
                        L.ptr(self.bwd_arena), self.fwd_stride, self.bwd_stride, st)
+        if plan['iters'] > 1 and PACK_ALL_CALLS:
+            # sigma / u / v of every call are kept per call (sigma[call][layer]), the packs do not feed the iterations: ONE pack
+            # launch for all calls of the window (3 launches reading the 102 MB of fp32 weights each: 0.36 ms per 1080p step)
+            wp, npk = self._pack_all_calls(plan)
+            L.call('tcvom_sn_pack', L.ptr(self.table), sc, L.ptr(wp), npk, -1, L.ptr(self.fwd_arena),
+                   L.ptr(self.bwd_arena), self.fwd_stride, self.bwd_stride, st)
         self.current_plan = plan
         self.call_counter = [0] * len(self.specs)
         return plan
@@ -395,6 +406,19 @@ class WeightBank(object):
             wtu = [(s.layer_id, r0) for s in sel for r0 in range(0, s.h, 16)]
             wv = [(s.layer_id, r0) for s in sel for r0 in range(0, s.h, 4)]
             plan[key] = (i32([s.layer_id for s in sel]), len(sel), i32(wtu), len(wtu), i32(wv), len(wv))
+        return plan[key]
+
+    def _pack_all_calls(self, plan):
+        """Work list of ONE tcvom_sn_pack launch covering every call of the window: the per-call lists (call 0: all layers, later
+        calls: the layers that have that many calls) with the call in bits 8.. of `which`, ordered tile-major so that the calls of
+        one tile run close together."""
+        key = 'pack_all_calls'
+        if key not in plan:
+            rows = []
+            for layer, which, blk in self._pack_rows(self.specs):
+                nc = plan['ncalls'][layer] if self.specs[layer].spectral else 1
+                rows += [(layer, which | (c << 8), blk) for c in range(max(nc, 1))]
+            plan[key] = (torch.tensor(rows, dtype=torch.int32).reshape(-1).to(self.device), len(rows))
         return plan[key]
 
     def _restricted_pack(self, plan, call):
