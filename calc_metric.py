@@ -31,89 +31,7 @@ def _alpha_of(path):
     return im[..., -1] if im.ndim == 3 else im
 
 
-def _read_png16(path):
-    """Multi-channel 16-bit PNG -> uint16 [H, W, C] in FILE channel order (R, G, B[, A]).  Pillow cannot decode these and
-    OpenCV / imageio are optional: a dependency-free decoder (zlib + the five PNG row filters) is the last resort."""
-    try:
-        import imageio.v3 as iio
-        return np.asarray(iio.imread(path))
-    except ImportError:
-        pass
-    try:
-        import cv2
-        x = cv2.imread(path, cv2.IMREAD_UNCHANGED)
-        if x is None:
-            raise IOError('cv2 could not read %s' % path)
-        return x[..., ::-1] if x.shape[-1] == 3 else x[..., [2, 1, 0, 3]]
-    except ImportError:
-        pass
-    import struct
-    import zlib
-    with open(path, 'rb') as f:
-        raw = f.read()
-    if raw[:8] != b'\x89PNG\r\n\x1a\n':
-        raise IOError('%s is not a PNG file' % path)
-    pos, idat, hdr = 8, [], None
-    while pos < len(raw):
-        n, typ = struct.unpack('>I4s', raw[pos:pos + 8])
-        body = raw[pos + 8:pos + 8 + n]
-        if typ == b'IHDR':
-            hdr = struct.unpack('>IIBBBBB', body)
-        elif typ == b'IDAT':
-            idat.append(body)
-        pos += 12 + n
-    W, H, depth, ctype, _, _, interlace = hdr
-    nch = {0: 1, 2: 3, 4: 2, 6: 4}.get(ctype)
-    if depth != 16 or nch is None or interlace:
-        raise IOError('%s: unsupported PNG flavour (depth %d, colour type %d, interlace %d)' % (path, depth, ctype, interlace))
-    bpp, stride = 2 * nch, 2 * nch * W
-    data = zlib.decompress(b''.join(idat))
-    out = np.zeros((H, stride), np.uint8)
-    prev = np.zeros(stride, np.int64)
-    for y in range(H):
-        ft = data[y * (stride + 1)]
-        line = np.frombuffer(data, np.uint8, stride, y * (stride + 1) + 1).astype(np.int64)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft == 1:                    # Sub: a running sum per byte lane
-            cur = (np.cumsum(line.reshape(W, bpp), axis=0) & 255).reshape(-1)
-        else:                            # Average / Paeth depend on the reconstructed left neighbour: pixel by pixel
-            cur = np.zeros(stride, np.int64)
-            lp, pp = line.tolist(), prev.tolist()
-            c = [0] * stride
-            for i in range(stride):
-                left = c[i - bpp] if i >= bpp else 0
-                up = pp[i]
-                if ft == 3:
-                    pred = (left + up) >> 1
-                else:
-                    ul = pp[i - bpp] if i >= bpp else 0
-                    pa, pb, pc = abs(up - ul), abs(left - ul), abs(left + up - 2 * ul)
-                    pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else ul)
-                c[i] = (lp[i] + pred) & 255
-            cur = np.asarray(c, np.int64)
-        out[y] = cur
-        prev = cur
-    return out.reshape(H, W, nch, 2).astype(np.uint16)[..., 0] << 8 | out.reshape(H, W, nch, 2)[..., 1]
-
-
-def _flow(path):
-    """Optical-flow PNG of the VideoMatting108 tree -> float [H, W, 2] (x, y displacement in pixels, NaN where invalid), or
-    None when the pair has no flow file.  The reference decodes it with cv2.imread(IMREAD_UNCHANGED) and takes x[..., :-1] as
-    the flow and x[..., -1] as the validity mask (calc_metric.py:65-71); cv2 hands channels over in B, G, R order, so in FILE
-    order (what every other reader returns) the layout is R = mask, G = y flow, B = x flow: convert first, slice second.
-    A file that exists but cannot be decoded is an error (a silent None would zero MESSDdt)."""
-    if not os.path.exists(path):
-        return None
-    x = _read_png16(path)
-    if x.ndim != 3 or x.shape[-1] not in (3, 4):
-        raise IOError('%s: expected a 3- or 4-channel 16-bit flow image, got shape %s' % (path, x.shape))
-    x = x[..., ::-1] if x.shape[-1] == 3 else x[..., [2, 1, 0, 3]]          # file order -> cv2 order
-    flow = np.float32(np.ascontiguousarray(x[..., :-1][..., :2]).astype(np.uint16).view(np.int16))
-    flow[x[..., -1] == 0] = np.nan
-    return flow / 100.0
+from tcvom_amd.data import read_flow_png as _flow, read_png16 as _read_png16      # noqa: E402  (shared with dataset.VMD's flow branch)
 
 
 def main(args):

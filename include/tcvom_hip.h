@@ -501,6 +501,12 @@ int tcvom_crop_resize_u8(const void* src, float* dst, int32_t S, int32_t Hs, int
                          int32_t nc, int32_t ph, int32_t pw, int32_t nh, int32_t nw, int32_t Ho, int32_t Wo, int32_t form,
                          void* stream);
 int tcvom_count_unknown(const float* alpha, int32_t S, int64_t n, int32_t* counts, void* stream);
+/* flow_crop_and_resize of the loader's optical-flow branch (dataset/VMD.py:68-126): src fp32 [F][Hs][Ws][2] (x, y displacement
+ * in pixels, NaN = invalid), crop (ph, pw, nh, nw) -> dst fp32 [F][2][Ho][Wo]: corner-aligned bilinear resampling, vectors
+ * rescaled by nw / Wo and nh / Ho, NaN where the source is not smooth (VMD.py:76-99: neighbours within 45 degrees / 50 pixels)
+ * or the vector leaves the new frame (VMD.py:119-124). */
+int tcvom_flow_crop_resize(const float* src, float* dst, int32_t F, int32_t Hs, int32_t Ws, int32_t ph, int32_t pw, int32_t nh,
+                           int32_t nw, int32_t Ho, int32_t Wo, void* stream);
 int tcvom_pad_bottom_right(const float* src, float* dst, int32_t S, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                            const float* value, void* stream);
 

@@ -149,6 +149,7 @@ _PROTOS = {
     'tcvom_lap_bwd_fine': [vp, vp, vp, vp, i64, i32, i32, vp],
     'tcvom_crop_resize_u8': [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_count_unknown': [vp, i32, i64, vp, vp],
+    'tcvom_flow_crop_resize': [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_pad_bottom_right': [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     'tcvom_unfold': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_fold': [vp, vp, i32, i32, i32, i32, i32, vp],

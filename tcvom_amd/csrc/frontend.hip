@@ -119,3 +119,81 @@ extern "C" int tcvom_pad_bottom_right(const float* src, float* dst, int32_t S, i
     TCVOM_LAUNCH_CHECK("pad_bottom_right");
     return TCVOM_OK;
 }
+
+
+// ---------------------------------------------------------------- optical flow: flow_crop_and_resize (dataset/VMD.py:68-126)
+// src [F][Hs][Ws][2] fp32 (x, y displacement in pixels, NaN = invalid: the decoded flow files of a sample), crop window
+// (ph, pw, nh, nw), output [F][2][Ho][Wo].  Per output pixel: corner-aligned bilinear lookup of the crop (a NaN corner makes
+// the result NaN whatever its weight, as in grid_sample), NaN unless the flow is "smooth" at the lookup's top-left source pixel --
+// the neighbour to the right and the neighbour below each point within 45 degrees of it (or are shorter than a pixel on
+// average / zero) and differ by less than 50 pixels in length; the last column / row of the crop pass -- then the vector is
+// rescaled to the new pixel size and dropped if it leaves the new frame.
+#pragma clang fp contract(off)
+__device__ __forceinline__ bool flow_pair_ok(float ax, float ay, float bx, float by) {
+    const float dot = ax * bx + ay * by;
+    const float na = sqrtf(ax * ax + ay * ay), nb = sqrtf(bx * bx + by * by);
+    const float nab = na * nb;
+    float c = fabsf(dot / nab);
+    c = c != c ? c : fminf(fmaxf(c, 0.f), 1.0f - 1e-6f);                  // clamp keeps NaN
+    bool ok = acosf(c) <= 0.78539816339744830962f;                      // pi / 4 in the reference is a double compared with a float32 angle
+    ok = ok || nab == 0.f || (na + nb) < 2.f;
+    return ok && fabsf(na - nb) < 50.f;                                   // comparisons with NaN are false: an invalid neighbour fails
+}
+__global__ __launch_bounds__(256) void flow_crop_resize_kernel(const float2* __restrict__ src, float* __restrict__ dst, int F, int Hs, int Ws,
+                                                               int ph, int pw, int nh, int nw, int Ho, int Wo, float sx, float sy,
+                                                               float dvx, float dvy) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (int64_t)Ho * Wo;
+    if (i >= per * F) return;
+    const int f = (int)(i / per);
+    const int r = (int)(i - (int64_t)f * per);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const float2* fl = src + ((int64_t)f * Hs + ph) * Ws + pw;            // crop origin; element (y, x) at fl[y * Ws + x]
+    const float cx = (float)ox * sx, cy = (float)oy * sy;                 // source coordinates inside the crop
+    // grid_sample(align_corners=True) sees the coordinate after a round trip through [-1, 1]
+    const float gx = 2.f * cx / (float)(nw - 1) - 1.f, gy = 2.f * cy / (float)(nh - 1) - 1.f;
+    const float ix = (gx + 1.f) / 2.f * (float)(nw - 1), iy = (gy + 1.f) / 2.f * (float)(nh - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    float vx = 0.f, vy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                        // nw, ne, sw, se in ATen's order
+        const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        if (xx >= 0 && xx < nw && yy >= 0 && yy < nh) {
+            const float w = ((k & 1) ? wx1 : wx0) * ((k >> 1) ? wy1 : wy0);
+            const float2 v = fl[(int64_t)yy * Ws + xx];
+            vx += v.x * w;
+            vy += v.y * w;
+        }
+    }
+    // smoothness at the top-left source pixel of the (un-round-tripped) coordinate
+    const int qx = (int)floorf(cx), qy = (int)floorf(cy);
+    const float2 c0 = fl[(int64_t)qy * Ws + qx];
+    bool keep = true;
+    if (qx + 1 < nw) { const float2 c1 = fl[(int64_t)qy * Ws + qx + 1]; keep = keep && flow_pair_ok(c0.x, c0.y, c1.x, c1.y); }
+    if (qy + 1 < nh) { const float2 c2 = fl[(int64_t)(qy + 1) * Ws + qx]; keep = keep && flow_pair_ok(c0.x, c0.y, c2.x, c2.y); }
+    const float qnan = __builtin_nanf("");
+    vx = keep ? vx / dvx : qnan;
+    vy = keep ? vy / dvy : qnan;
+    const float lx = (float)ox + vx, ly = (float)oy + vy;
+    const bool outside = lx < 0.f || ly < 0.f || lx > (float)(Wo - 1) || ly > (float)(Ho - 1);
+    dst[((int64_t)f * 2 + 0) * per + r] = outside ? qnan : vx;
+    dst[((int64_t)f * 2 + 1) * per + r] = outside ? qnan : vy;
+}
+
+extern "C" int tcvom_flow_crop_resize(const float* src, float* dst, int32_t F, int32_t Hs, int32_t Ws, int32_t ph, int32_t pw, int32_t nh,
+                                      int32_t nw, int32_t Ho, int32_t Wo, void* stream) {
+    TCVOM_CHECK_ARG(src && dst && F > 0 && Hs > 0 && Ws > 0, "flow_crop_resize: bad args");
+    TCVOM_CHECK_ARG(ph >= 0 && pw >= 0 && nh >= 2 && nw >= 2 && ph + nh <= Hs && pw + nw <= Ws, "flow_crop_resize: crop %d+%d x %d+%d outside a %d x %d frame",
+                    ph, nh, pw, nw, Hs, Ws);
+    TCVOM_CHECK_ARG(Ho >= 2 && Wo >= 2, "flow_crop_resize: the output needs at least 2 x 2 pixels (corner-aligned sampling)");
+    // python doubles rounded to fp32 when they meet a fp32 tensor: (n - 1) / (out - 1) and n / out
+    const float sx = (float)((double)(nw - 1) / (double)(Wo - 1)), sy = (float)((double)(nh - 1) / (double)(Ho - 1));
+    const float dvx = (float)((double)nw / (double)Wo), dvy = (float)((double)nh / (double)Ho);
+    const int64_t n = (int64_t)F * Ho * Wo;
+    hipLaunchKernelGGL(flow_crop_resize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)src, dst, F, Hs, Ws, ph, pw,
+                       nh, nw, Ho, Wo, sx, sy, dvx, dvy);
+    TCVOM_LAUNCH_CHECK("flow_crop_resize");
+    return TCVOM_OK;
+}

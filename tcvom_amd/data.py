@@ -11,9 +11,10 @@ unknown-pixel test of the crop search and the validation padding run on the devi
     for raw in loader: fg, bg, a, idx = ds.transform(raw)
 
 Directory layout, file lists, frame neighbourhoods, the random draws of the crop search (python `random`, same order as the
-reference) and every rounding step follow dataset/VMD.py; line references below.  Not provided: the optical-flow branch
-(`no_flow=False`; every caller in the reference passes `no_flow=True`) and the imgaug colour / JPEG augmentation
-(VMD.py:50-55,253-262; imgaug is not part of this image) — training crops are geometric only.
+reference) and every rounding step follow dataset/VMD.py; line references below.  The optical-flow branch (`no_flow=False`:
+`fg, bg, a, wb, wf, idx`, VMD.py:203-213, 236-245, 153-165, 274-300) decodes the 16-bit flow files on the host and runs
+`flow_crop_and_resize` (VMD.py:68-126) on the device.  The colour / JPEG augmentation of training samples (VMD.py:50-55,
+253-262) runs on the host in the loader workers, as in the reference (`tcvom_amd/augment.py`).
 """
 import ctypes as C
 import json
@@ -35,6 +36,114 @@ def _read_png(path, mode):
         return np.asarray(im.convert(mode))
 
 
+def read_png16(path):
+    """Multi-channel 16-bit PNG -> uint16 [H, W, C] in FILE channel order (R, G, B[, A]).  Pillow cannot decode these and
+    OpenCV / imageio are optional: a dependency-free decoder (zlib + the five PNG row filters) is the last resort."""
+    try:
+        import imageio.v3 as iio
+        return np.asarray(iio.imread(path))
+    except ImportError:
+        pass
+    try:
+        import cv2
+        x = cv2.imread(path, cv2.IMREAD_UNCHANGED)
+        if x is None:
+            raise IOError('cv2 could not read %s' % path)
+        return x[..., ::-1] if x.shape[-1] == 3 else x[..., [2, 1, 0, 3]]
+    except ImportError:
+        pass
+    return png16_decode(path)
+
+
+def png16_decode(path):
+    """The dependency-free decoder behind read_png16."""
+    import struct
+    import zlib
+    with open(path, 'rb') as f:
+        raw = f.read()
+    if raw[:8] != b'\x89PNG\r\n\x1a\n':
+        raise IOError('%s is not a PNG file' % path)
+    pos, idat, hdr = 8, [], None
+    while pos < len(raw):
+        n, typ = struct.unpack('>I4s', raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        if typ == b'IHDR':
+            hdr = struct.unpack('>IIBBBBB', body)
+        elif typ == b'IDAT':
+            idat.append(body)
+        pos += 12 + n
+    W, H, depth, ctype, _, _, interlace = hdr
+    nch = {0: 1, 2: 3, 4: 2, 6: 4}.get(ctype)
+    if depth != 16 or nch is None or interlace:
+        raise IOError('%s: unsupported PNG flavour (depth %d, colour type %d, interlace %d)' % (path, depth, ctype, interlace))
+    bpp, stride = 2 * nch, 2 * nch * W
+    data = zlib.decompress(b''.join(idat))
+    out = np.zeros((H, stride), np.uint8)
+    prev = np.zeros(stride, np.int64)
+    for y in range(H):
+        ft = data[y * (stride + 1)]
+        line = np.frombuffer(data, np.uint8, stride, y * (stride + 1) + 1).astype(np.int64)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft == 1:                    # Sub: a running sum per byte lane
+            cur = (np.cumsum(line.reshape(W, bpp), axis=0) & 255).reshape(-1)
+        else:                            # Average / Paeth depend on the reconstructed left neighbour: pixel by pixel
+            cur = np.zeros(stride, np.int64)
+            lp, pp = line.tolist(), prev.tolist()
+            c = [0] * stride
+            for i in range(stride):
+                left = c[i - bpp] if i >= bpp else 0
+                up = pp[i]
+                if ft == 3:
+                    pred = (left + up) >> 1
+                else:
+                    ul = pp[i - bpp] if i >= bpp else 0
+                    pa, pb, pc = abs(up - ul), abs(left - ul), abs(left + up - 2 * ul)
+                    pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else ul)
+                c[i] = (lp[i] + pred) & 255
+            cur = np.asarray(c, np.int64)
+        out[y] = cur
+        prev = cur
+    return out.reshape(H, W, nch, 2).astype(np.uint16)[..., 0] << 8 | out.reshape(H, W, nch, 2)[..., 1]
+
+
+def read_flow_png(path):
+    """Optical-flow PNG of the VideoMatting108 tree -> float [H, W, 2] (x, y displacement in pixels, NaN where invalid), or
+    None when the pair has no flow file.  The reference decodes it with cv2.imread(IMREAD_UNCHANGED) and takes x[..., :-1] as
+    the flow and x[..., -1] as the validity mask (calc_metric.py:65-71); cv2 hands channels over in B, G, R order, so in FILE
+    order (what every other reader returns) the layout is R = mask, G = y flow, B = x flow: convert first, slice second.
+    A file that exists but cannot be decoded is an error (a silent None would zero MESSDdt)."""
+    if not os.path.exists(path):
+        return None
+    x = read_png16(path)
+    if x.ndim != 3 or x.shape[-1] not in (3, 4):
+        raise IOError('%s: expected a 3- or 4-channel 16-bit flow image, got shape %s' % (path, x.shape))
+    x = x[..., ::-1] if x.shape[-1] == 3 else x[..., [2, 1, 0, 3]]          # file order -> cv2 order
+    flow = np.float32(np.ascontiguousarray(x[..., :-1][..., :2]).astype(np.uint16).view(np.int16))
+    flow[x[..., -1] == 0] = np.nan
+    return flow / 100.0
+
+
+def write_png16(path, img):
+    """uint16 [H, W, 3 | 4] in FILE channel order -> 16-bit PNG (no row filtering).  The flow files of a VideoMatting108 tree are
+    such files (R = validity, G = y displacement, B = x displacement, see read_flow_png); Pillow cannot write them."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    H, W, Cn = img.shape
+    rows = img.astype('>u2').tobytes()
+    stride = W * Cn * 2
+    raw = b''.join(b'\x00' + rows[y * stride:(y + 1) * stride] for y in range(H))
+
+    def chunk(t, b):
+        return struct.pack('>I', len(b)) + t + b + struct.pack('>I', zlib.crc32(t + b) & 0xffffffff)
+    with open(path, 'wb') as fh:
+        fh.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 16, {3: 2, 4: 6}[Cn], 0, 0, 0)) +
+                 chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
+
+
 class _RawView(torch.utils.data.Dataset):
     def __init__(self, ds):
         self.ds = ds
@@ -50,13 +159,11 @@ class VideoMattingDataset(torch.utils.data.Dataset):
     VIDEO_SHAPE = (1080, 1920)
     FG_FOLDER = 'FG_done'
     BG_FOLDER = 'BG_done'
+    FLOW_FOLDER = 'flow_png'                          # VMD.py:25: 16-bit PNGs, (x, y) displacement x 100 as int16 + validity
     SCALES = [1.0, 1.25, 1.5, 1.75, 2.0]              # VMD.py:131
 
     def __init__(self, data_root, image_shape, plus1, mode, use_subset=False, no_flow=False, precomputed_val=None,
                  sample_length=5, device=None, worker_arithmetic=True):
-        if not no_flow:
-            raise NotImplementedError('the optical-flow branch of dataset/VMD.py is not part of this front-end: pass no_flow=True '
-                                      '(as train_ddp.py, pred_vmn.py and pred_single.py do)')
         assert mode in ('train', 'val')
         if precomputed_val is not None:
             assert mode == 'val'
@@ -115,7 +222,25 @@ class VideoMattingDataset(torch.utils.data.Dataset):
                 bgp = os.path.splitext(bgp)[0] + '.png'
             bg.append(_read_png(bgp, 'RGB'))
             assert bg[-1].shape[:2] == fg[-1].shape[:2]
-        return {'fg': torch.from_numpy(np.stack(fg)), 'bg': torch.from_numpy(np.stack(bg)), 'idx': idx}
+        raw = {'fg': torch.from_numpy(np.stack(fg)), 'bg': torch.from_numpy(np.stack(bg)), 'idx': idx}
+        if not self.no_flow:
+            # VMD.py:236-245: forward flows wf[i] = i -> i + 1 and backward flows wb[i] = i -> i - 1 of the inner frames
+            # 2 .. S - 3, plus wf[1] and wb[S - 2]; the other slots stay NaN
+            S = len(sample)
+            base = [os.path.splitext(os.path.basename(fn))[0] for fn in sample]
+            dn = os.path.dirname(sample[0])
+            slots = [('f', i, i + 1) for i in range(2, S - 2)] + [('b', i, i - 1) for i in range(2, S - 2)]
+            slots += [('f', 1, 2), ('b', S - 2, S - 3)]
+            flows = []
+            for _, i, j in slots:
+                path = os.path.join(root, self.FLOW_FOLDER, dn, 'flow_%s_%s.png' % (base[i], base[j]))
+                fl = read_flow_png(path)
+                if fl is None:
+                    raise IOError('missing flow file %s' % path)
+                flows.append(fl)
+            raw['flow'] = torch.from_numpy(np.stack(flows))                     # [nflow, H, W, 2] fp32, NaN = invalid
+            raw['flow_slots'] = [(d, i) for d, i, _ in slots]
+        return raw
 
     def raw_view(self):
         return _RawView(self)
@@ -166,6 +291,26 @@ class VideoMattingDataset(torch.utils.data.Dataset):
             if min(counts.tolist()) >= 1:
                 return ph, pw, nsize, pa
 
+    def _flows(self, raw, dev, S, crop):
+        """(wb, wf) fp32 [S, 2, Ho, Wo] from the decoded flow files of the sample: training crop / validation resize through
+        tcvom_flow_crop_resize (VMD.py:68-126), precomputed validation padded with NaN (VMD.py:274-280); empty slots NaN."""
+        fl = raw['flow'].to(dev, non_blocking=True).contiguous()
+        n, Hs, Ws, _ = fl.shape
+        Ho, Wo = self.image_shape
+        if self.mode == 'val' and self.precomputed_val is not None:
+            planes = fl.permute(0, 3, 1, 2).contiguous()
+            if (Hs, Ws) != (Ho, Wo):
+                planes = self._pad(planes, Ho, Wo, [float('nan'), float('nan')])
+        else:
+            ph, pw, nh, nw = crop if crop is not None else (0, 0, Hs, Ws)
+            planes = torch.empty((n, 2, Ho, Wo), dtype=torch.float32, device=dev)
+            L.call('tcvom_flow_crop_resize', L.ptr(fl), L.ptr(planes), n, Hs, Ws, ph, pw, nh, nw, Ho, Wo, L.stream_ptr())
+        wb = torch.full((S, 2, Ho, Wo), float('nan'), dtype=torch.float32, device=dev)
+        wf = torch.full((S, 2, Ho, Wo), float('nan'), dtype=torch.float32, device=dev)
+        for k, (d, i) in enumerate(raw['flow_slots']):
+            (wf if d == 'f' else wb)[i] = planes[k]
+        return wb, wf
+
     def transform(self, raw):
         """uint8 frames -> (fg, bg, a, idx) of the reference's loader (VMD.py:250-301, no_flow)."""
         dev = self._dev()
@@ -174,9 +319,11 @@ class VideoMattingDataset(torch.utils.data.Dataset):
         S, Hs, Ws, _ = fg_u8.shape
         Ho, Wo = self.image_shape
         bgr = [2, 1, 0]
+        crop = None
         if self.mode == 'train':
             assert (Hs, Ws) == self.VIDEO_SHAPE, 'training clips are %dx%d (VMD.py:22)' % self.VIDEO_SHAPE
             ph, pw, nsize, a = self.shape_aug(fg_u8)
+            crop = (ph, pw, nsize[0], nsize[1])
             fg = self._crop_resize(fg_u8, bgr, ph, pw, nsize[0], nsize[1], Ho, Wo, self.image_form)
             bg = self._crop_resize(bg_u8, bgr, ph, pw, nsize[0], nsize[1], Ho, Wo, self.image_form)
         elif self.precomputed_val is not None:
@@ -187,6 +334,9 @@ class VideoMattingDataset(torch.utils.data.Dataset):
             fg = self._crop_resize(fg_u8, bgr, 0, 0, Hs, Ws, Ho, Wo, self.image_form)
             bg = self._crop_resize(bg_u8, bgr, 0, 0, Hs, Ws, Ho, Wo, self.image_form)
             a = self._crop_resize(fg_u8, [3], 0, 0, Hs, Ws, Ho, Wo)
+        if not self.no_flow:
+            wb, wf = self._flows(raw, dev, S, crop)
+            return fg, bg, a, wb, wf, torch.tensor(raw['idx'])          # VMD.py:293-300
         return fg, bg, a, torch.tensor(raw['idx'])
 
     def __getitem__(self, idx):

@@ -35,6 +35,9 @@ def _import_reference_loader():
     cv2.IMREAD_UNCHANGED, cv2.IMREAD_COLOR, cv2.IMREAD_GRAYSCALE = -1, 1, 0
 
     def imread(path, flag=1):
+        if os.path.basename(path).startswith('flow_'):          # 16-bit 3-channel flow file: PIL cannot decode it
+            from tcvom_amd.data import png16_decode              # (a plain PNG decoder; returns FILE order R, G, B -> cv2's B, G, R)
+            return np.ascontiguousarray(png16_decode(path)[..., ::-1])
         with Image.open(path) as im:
             if flag == cv2.IMREAD_GRAYSCALE:
                 return np.asarray(im.convert('L')).copy()
@@ -118,9 +121,9 @@ VAL_SHAPE = [24, 40]
 SEEDS = (1234, 7, 99)
 
 
-def main():
+def main(ref):
     torch.set_num_threads(1)        # the loader runs in DataLoader workers, which torch pins to one thread (ATen's 3-channel
-    ref = _import_reference_loader()    # bilinear kernel rounds differently with several threads; oracle/data.py: `threads`)
+    # bilinear kernel rounds differently with several threads; oracle/data.py: `threads`)
     DS = ref.VideoMattingDataset
     fg, bg = make_frames(VIDEOS, NFRAMES, H, W, seed=0)
     root = tempfile.mkdtemp()
@@ -177,5 +180,91 @@ def main():
         shutil.rmtree(root)
 
 
+def make_flows(nframes, H, W, seed):
+    """int16 flow x 100 (x, y) + validity for every ordered pair of adjacent frames: a smooth field, a motion boundary (the
+    'gradient check' of VMD.py:76-92 must reject its neighbourhood), a block of invalid pixels, a patch pointing out of the frame."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    flows = {}
+    for a in range(nframes):
+        for b in (a - 1, a + 1):
+            if not 0 <= b < nframes:
+                continue
+            sgn = 1.0 if b > a else -1.0
+            fx = sgn * (2.0 + 0.05 * xx + 0.5 * np.sin(yy / 7.0 + a)) + rng.uniform(-0.2, 0.2, (H, W))
+            fy = sgn * (-1.0 + 0.03 * yy + 0.5 * np.cos(xx / 9.0 + b)) + rng.uniform(-0.2, 0.2, (H, W))
+            fx[:, W // 2:] += sgn * 9.0 * (yy[:, W // 2:] > H // 3)          # a motion boundary
+            fy[H // 2:, : W // 4] = -sgn * 40.0                              # points out of the frame after the crop
+            valid = np.ones((H, W), bool)
+            valid[5 + a:11 + a, 20:33] = False
+            q = np.stack([np.round(fx * 100), np.round(fy * 100)], -1).astype(np.int16)
+            flows[(a, b)] = (q, valid)
+    return flows
+
+
+def write_flows(root, videos, flows):
+    """flow_png/<video>/flow_<a>_<b>.png in OpenCV's layout: the FILE holds R = validity, G = y, B = x (cv2 reads B, G, R)."""
+    from tcvom_amd.data import write_png16
+    for name in videos:
+        os.makedirs(os.path.join(root, 'flow_png', name), exist_ok=True)
+        for (a, b), (q, valid) in flows.items():
+            img = np.stack([np.where(valid, 65535, 0).astype(np.uint16), q[..., 1].view(np.uint16), q[..., 0].view(np.uint16)], -1)
+            write_png16(os.path.join(root, 'flow_png', name, 'flow_%04d_%04d.png' % (a, b)), img)
+
+
+def gen_flow(ref):
+    """tests/golden/data_loader_flow.npz: the reference loader's optical-flow branch (VMD.py:68-126 flow_crop_and_resize, the flow
+    files of a sample :203-245, training crop :153-165, validation :274-291) on the synthetic tree + synthetic flow files."""
+    torch.set_num_threads(1)
+    DS = ref.VideoMattingDataset
+    fg, bg = make_frames(VIDEOS, NFRAMES, H, W, seed=0)
+    flows = make_flows(NFRAMES, H, W, seed=5)
+    root = tempfile.mkdtemp()
+    try:
+        write_tree(root, VIDEOS, fg, bg)
+        write_flows(root, VIDEOS, flows)
+        out = {'flow_pairs': np.array(sorted(flows)), 'flow_q': np.stack([flows[k][0] for k in sorted(flows)]),
+               'flow_valid': np.stack([flows[k][1] for k in sorted(flows)])}
+        DS.VIDEO_SHAPE = (H, W)
+        ds = DS(root, CROP, False, 'train', no_flow=False, sample_length=3)
+        q, valid = flows[(1, 2)]
+        fl = np.float32(q)
+        fl[~valid] = np.nan
+        fl = torch.from_numpy(fl) / 100
+        cases = [(0, 0, None), (5, 9, (32, 32)), (3, 7, (20, 20)), (10, 20, (24, 24)), (0, 0, (16, 16))]
+        out['fcr_cases'] = np.array([[c[0], c[1]] + list(c[2] or (-1, -1)) for c in cases])
+        for i, (ph, pw, n) in enumerate(cases):
+            out['fcr_%d' % i] = ds.flow_crop_and_resize(fl.clone(), ph, pw, n).numpy()
+        dval = DS(root, VAL_SHAPE, False, 'val', no_flow=False, sample_length=3)
+        out['fcr_val'] = dval.flow_crop_and_resize(fl.clone(), 0, 0).numpy()
+        # __getitem__ with flows: validation by resize (S = 3 and 5), validation by padding, training
+        for length in (3, 5):
+            dv = DS(root, VAL_SHAPE, False, 'val', no_flow=False, sample_length=length)
+            for idx in (0, 2, 5):
+                g = dv[idx]
+                assert len(g) == 6 and int(g[5]) == idx
+                out['val%d_%d_wb' % (length, idx)], out['val%d_%d_wf' % (length, idx)] = g[3].numpy(), g[4].numpy()
+                out['val%d_%d_a' % (length, idx)] = g[2].numpy()
+        dpad = DS(root, PAD_SHAPE, False, 'val', no_flow=False, precomputed_val=root, sample_length=3)
+        g = dpad[1]
+        out['pad_1_wb'], out['pad_1_wf'] = g[3].numpy(), g[4].numpy()
+        for length in (3, 5):
+            dt = DS(root, CROP, False, 'train', no_flow=False, sample_length=length)
+            for s in SEEDS:
+                random.seed(s)
+                g = dt[3]
+                out['train%d_%d_wb' % (length, s)], out['train%d_%d_wf' % (length, s)] = g[3].numpy(), g[4].numpy()
+                out['train%d_%d_a' % (length, s)] = g[2].numpy()
+                out['train%d_next_random_%d' % (length, s)] = np.array([random.random()])
+        np.savez_compressed(os.path.join(HERE, 'data_loader_flow.npz'), **out)
+        print('wrote data_loader_flow.npz with %d arrays' % len(out))
+    finally:
+        shutil.rmtree(root)
+
+
 if __name__ == '__main__':
-    main()
+    sys.path.insert(0, REPO)
+    import tcvom_amd.data  # noqa: F401  (the PNG16 helpers of the cv2 stub, imported before the reference takes over `dataset` / `utils`)
+    _ref = _import_reference_loader()
+    main(_ref)
+    gen_flow(_ref)

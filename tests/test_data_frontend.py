@@ -54,8 +54,10 @@ def test_parse_neighbourhoods(tmp_path):
     assert ds3.image_shape == [9, 9] and ds3.samples == odata.parse(corr, ['va', 'vb'], 3)
     raw = ds.load_raw(5)
     assert raw['fg'].shape == (5, 8, 8, 4) and raw['bg'].shape == (5, 8, 8, 3) and raw['fg'].dtype == torch.uint8
-    with pytest.raises(NotImplementedError):
-        VideoMattingDataset(root, [8, 8], False, 'val', no_flow=False)
+    # the optical-flow branch reads flow_png/<clip>/flow_<a>_<b>.png: a tree without them fails loudly, not with NaN planes
+    dsf = VideoMattingDataset(root, [8, 8], False, 'val', no_flow=False, sample_length=3)
+    with pytest.raises(IOError):
+        dsf.load_raw(0)
 
 
 @pytest.mark.gpu
@@ -128,3 +130,68 @@ def test_dataset_equals_reference_loader_math(tmp_path, mode, precomputed, shape
     if raw is not None:
         fg2, _, _, _ = ds.transform(raw)
         assert torch.equal(fg2, ds[1][0])
+
+
+def _write_flows(root, videos, nframes, H, W, seed=3):
+    """flow_png/<v>/flow_<a>_<b>.png for every ordered pair of adjacent frames (OpenCV layout: FILE R = validity, G = y, B = x,
+    int16 x 100): a smooth field with a motion boundary, a block of invalid pixels and a patch pointing out of the frame."""
+    from tcvom_amd.data import write_png16
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    store = {}
+    for v in videos:
+        os.makedirs(os.path.join(root, 'flow_png', v), exist_ok=True)
+        for a in range(nframes):
+            for b in (a - 1, a + 1):
+                if not 0 <= b < nframes:
+                    continue
+                sgn = 1.0 if b > a else -1.0
+                fx = sgn * (2.0 + 0.04 * xx + 0.6 * np.sin(yy / 9.0 + a)) + rng.uniform(-0.3, 0.3, (H, W))
+                fy = sgn * (-1.0 + 0.03 * yy + 0.5 * np.cos(xx / 11.0 + b)) + rng.uniform(-0.3, 0.3, (H, W))
+                fx[:, W // 2:] += sgn * 11.0 * (yy[:, W // 2:] > H // 3)
+                fy[H // 2:, : W // 5] = -sgn * 70.0
+                valid = np.ones((H, W), bool)
+                valid[7 + a:19 + a, 30:47] = False
+                q = np.stack([np.round(fx * 100), np.round(fy * 100)], -1).astype(np.int16)
+                img = np.stack([np.where(valid, 65535, 0).astype(np.uint16), q[..., 1].view(np.uint16), q[..., 0].view(np.uint16)], -1)
+                write_png16(os.path.join(root, 'flow_png', v, 'flow_%04d_%04d.png' % (a, b)), img)
+                store[(v, a, b)] = np.stack([q[..., 0].view(np.uint16), q[..., 1].view(np.uint16), img[..., 0]], -1)     # cv2 order
+    return store
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,precomputed,shape,S', [('train', False, [32, 32], 5), ('train', False, [32, 32], 3), ('val', False, [64, 96], 5),
+                                                       ('val', True, [128, 160], 3)])
+def test_dataset_flow_branch_equals_reference_loader_math(tmp_path, mode, precomputed, shape, S):
+    """no_flow=False: (fg, bg, a, wb, wf, idx) as dataset/VMD.py:293-300 -- the flow files decoded on the host, crop / resize /
+    smoothness / out-of-frame filter (flow_crop_and_resize, VMD.py:68-126) on the device -- against the oracle's restatement,
+    which is pinned by the reference's own outputs (tests/golden/data_loader_flow.npz).  Values to 1e-4 pixels; the NaN pattern
+    may differ on a handful of pixels whose 45-degree / 50-pixel / frame-border test sits within rounding of its threshold."""
+    from tcvom_amd.data import VideoMattingDataset
+
+    class Small(VideoMattingDataset):
+        VIDEO_SHAPE = (96, 128)
+    root = str(tmp_path)
+    corr = _write_clips(root, ['va', 'vb'], 6, 96, 128, seed=5)
+    store = _write_flows(root, ['va', 'vb'], 6, 96, 128)
+    ds = Small(root, shape, False, mode, no_flow=False, precomputed_val=root if precomputed else None, sample_length=S)
+    for idx in (0, 3, 8):
+        clip = os.path.dirname(ds.samples[idx][0])
+        read_flow = lambda a, b: store[(clip, int(a), int(b))]           # noqa: E731
+        random.seed(200 + idx)
+        got = ds[idx]
+        random.seed(200 + idx)
+        want = odata.get_item(root, corr, ds.samples[idx], mode, shape, (96, 128), precomputed, read_flow=read_flow)
+        assert len(got) == 6 and int(got[5]) == idx
+        assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[2].cpu(), want[2])
+        for k, name in ((3, 'wb'), (4, 'wf')):
+            g, w = got[k].cpu(), want[k]
+            assert tuple(g.shape) == (S, 2, shape[0], shape[1]) == tuple(w.shape), name
+            gn, wn = torch.isnan(g), torch.isnan(w)
+            # whole slots without a flow are NaN in both
+            assert torch.equal(gn.flatten(1).all(1), wn.flatten(1).all(1)), name
+            mism = int((gn != wn).sum())
+            assert mism <= 2e-3 * g.numel(), '%s: %d pixels differ in the NaN pattern' % (name, mism)
+            both = ~gn & ~wn
+            assert bool(both.any()) or bool(wn.all())
+            assert float((g[both] - w[both]).abs().max()) <= 1e-4 if bool(both.any()) else True

@@ -478,3 +478,57 @@ def test_data_loader_golden(tmp_path):
         got = odata.get_item(root, corr, samples[3], 'train', gen.CROP, (gen.H, gen.W))
         for t, k in zip(got, ('fg', 'bg', 'a')):
             assert np.array_equal(t.numpy(), g['train_%d_%s' % (s, k)]), (s, k)
+
+
+def test_data_loader_flow_branch_golden(tmp_path):
+    """oracle/data.py's optical-flow branch against the REFERENCE loader (dataset/VMD.py with no_flow=False, run behind the cv2 /
+    imgaug stubs by tests/golden/gen_data_golden.py on the synthetic tree plus synthetic flow files): flow_crop_and_resize for
+    five crops (NaN pattern included: motion boundaries, invalid pixels, vectors leaving the frame), and the (wb, wf) of
+    __getitem__ in validation (resize, S = 3 and 5; padding) and training (same crop search and RNG consumption)."""
+    import os
+    import random
+    import sys
+    from oracle import data as odata
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    try:
+        import gen_data_golden as gen
+    finally:
+        sys.path.pop(0)
+    g, g0 = golden('data_loader_flow'), golden('data_loader')
+    root = str(tmp_path)
+    corr = gen.write_tree(root, gen.VIDEOS, g0['fg'], g0['bg'])
+    pairs = [tuple(p) for p in g['flow_pairs'].tolist()]
+    store = {p: (g['flow_q'][i], g['flow_valid'][i]) for i, p in enumerate(pairs)}
+
+    def read_flow(a, b):          # what cv2.imread(..., IMREAD_UNCHANGED) returns for flow_<a>_<b>.png: uint16 (x, y, mask)
+        q, valid = store[(int(a), int(b))]
+        return np.stack([q[..., 0].view(np.uint16), q[..., 1].view(np.uint16), np.where(valid, 65535, 0).astype(np.uint16)], -1)
+
+    def same(got, want, what):
+        got, want = got.numpy(), np.asarray(want)
+        assert got.shape == want.shape, what
+        assert np.array_equal(np.isnan(got), np.isnan(want)), what + ': NaN pattern'
+        assert np.allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=0, atol=1e-6), what
+    fl = odata.flow_from_png16(read_flow(1, 2))
+    for i, (ph, pw, nh, nw) in enumerate(g['fcr_cases'].tolist()):
+        same(odata.flow_crop_and_resize(fl.clone(), gen.CROP, ph, pw, None if nh < 0 else (nh, nw)), g['fcr_%d' % i], 'fcr %d' % i)
+    same(odata.flow_crop_and_resize(fl.clone(), gen.VAL_SHAPE, 0, 0), g['fcr_val'], 'fcr val')
+    assert int(np.isnan(g['fcr_1']).sum()) > 0 and int((~np.isnan(g['fcr_1'])).sum()) > 0
+    for length in (3, 5):
+        samples = odata.parse(corr, gen.VIDEOS, length)
+        for idx in (0, 2, 5):
+            got = odata.get_item(root, corr, samples[idx], 'val', gen.VAL_SHAPE, (gen.H, gen.W), read_flow=read_flow)
+            same(got[3], g['val%d_%d_wb' % (length, idx)], 'val wb')
+            same(got[4], g['val%d_%d_wf' % (length, idx)], 'val wf')
+            assert np.array_equal(got[2].numpy(), g['val%d_%d_a' % (length, idx)])
+        for s in gen.SEEDS:
+            random.seed(s)
+            got = odata.get_item(root, corr, samples[3], 'train', gen.CROP, (gen.H, gen.W), read_flow=read_flow)
+            same(got[3], g['train%d_%d_wb' % (length, s)], 'train wb')
+            same(got[4], g['train%d_%d_wf' % (length, s)], 'train wf')
+            assert np.array_equal(got[2].numpy(), g['train%d_%d_a' % (length, s)])
+            assert random.random() == float(g['train%d_next_random_%d' % (length, s)][0])
+    samples = odata.parse(corr, gen.VIDEOS, 3)
+    got = odata.get_item(root, corr, samples[1], 'val', gen.PAD_SHAPE, (gen.H, gen.W), precomputed=True, read_flow=read_flow)
+    same(got[3], g['pad_1_wb'], 'pad wb')
+    same(got[4], g['pad_1_wf'], 'pad wf')
