@@ -163,7 +163,9 @@ class VideoMattingDataset(torch.utils.data.Dataset):
     SCALES = [1.0, 1.25, 1.5, 1.75, 2.0]              # VMD.py:131
 
     def __init__(self, data_root, image_shape, plus1, mode, use_subset=False, no_flow=False, precomputed_val=None,
-                 sample_length=5, device=None, worker_arithmetic=True):
+                 sample_length=5, device=None, worker_arithmetic=True, color_aug=True):
+        """color_aug: training samples also get the reference's colour / JPEG augmentation (VMD.py:50-55, 253-262;
+        tcvom_amd/augment.py); False = geometric crops only (what the bit-exact loader tests compare)."""
         assert mode in ('train', 'val')
         if precomputed_val is not None:
             assert mode == 'val'
@@ -181,6 +183,7 @@ class VideoMattingDataset(torch.utils.data.Dataset):
         # channels-last kernel there, csrc/frontend.hip): the reference loads through DataLoader workers, which are
         # single-threaded, so that is the default; False = the arithmetic of a num_workers=0 run on a multi-core host.
         self.image_form = 1 if worker_arithmetic else 0
+        self.color_aug = bool(color_aug)
 
     def __len__(self):
         return self.dataset_length
@@ -326,6 +329,9 @@ class VideoMattingDataset(torch.utils.data.Dataset):
             crop = (ph, pw, nsize[0], nsize[1])
             fg = self._crop_resize(fg_u8, bgr, ph, pw, nsize[0], nsize[1], Ho, Wo, self.image_form)
             bg = self._crop_resize(bg_u8, bgr, ph, pw, nsize[0], nsize[1], Ho, Wo, self.image_form)
+            if self.color_aug:
+                from .augment import augment_clip
+                fg, bg = augment_clip(fg, bg)                       # VMD.py:253-262 (after the crop, before stacking)
         elif self.precomputed_val is not None:
             fg = self._pad(self._crop_resize(fg_u8, bgr, 0, 0, Hs, Ws, Hs, Ws), Ho, Wo, IMG_PADDING_VALUE)
             bg = self._pad(self._crop_resize(bg_u8, bgr, 0, 0, Hs, Ws, Hs, Ws), Ho, Wo, IMG_PADDING_VALUE)

@@ -114,7 +114,7 @@ def test_dataset_equals_reference_loader_math(tmp_path, mode, precomputed, shape
         VIDEO_SHAPE = (96, 128)
     root = str(tmp_path)
     corr = _write_clips(root, ['va', 'vb'], 6, 96, 128, seed=5)
-    ds = Small(root, shape, False, mode, no_flow=True, precomputed_val=root if precomputed else None, sample_length=5)
+    ds = Small(root, shape, False, mode, no_flow=True, precomputed_val=root if precomputed else None, sample_length=5, color_aug=False)
     for idx in (0, 4, 11):
         random.seed(100 + idx)
         fg, bg, a, i = ds[idx]
@@ -174,7 +174,7 @@ def test_dataset_flow_branch_equals_reference_loader_math(tmp_path, mode, precom
     root = str(tmp_path)
     corr = _write_clips(root, ['va', 'vb'], 6, 96, 128, seed=5)
     store = _write_flows(root, ['va', 'vb'], 6, 96, 128)
-    ds = Small(root, shape, False, mode, no_flow=False, precomputed_val=root if precomputed else None, sample_length=S)
+    ds = Small(root, shape, False, mode, no_flow=False, precomputed_val=root if precomputed else None, sample_length=S, color_aug=False)
     for idx in (0, 3, 8):
         clip = os.path.dirname(ds.samples[idx][0])
         read_flow = lambda a, b: store[(clip, int(a), int(b))]           # noqa: E731
@@ -195,3 +195,32 @@ def test_dataset_flow_branch_equals_reference_loader_math(tmp_path, mode, precom
             both = ~gn & ~wn
             assert bool(both.any()) or bool(wn.all())
             assert float((g[both] - w[both]).abs().max()) <= 1e-4 if bool(both.any()) else True
+
+
+@pytest.mark.gpu
+def test_dataset_training_samples_get_the_colour_and_jpeg_augmentation(tmp_path):
+    """mode='train' with the default color_aug=True (VMD.py:253-262): the geometric crop is the one of the plain loader (same
+    python `random` draws before the augmentation), alpha is untouched, fg / bg stay integer-valued 0..255 BGR tensors on the
+    device and differ from the un-augmented crop; the same seed gives the same sample."""
+    from tcvom_amd.data import VideoMattingDataset
+
+    class Small(VideoMattingDataset):
+        VIDEO_SHAPE = (96, 128)
+    root = str(tmp_path)
+    _write_clips(root, ['va'], 6, 96, 128, seed=5)
+    plain = Small(root, [32, 32], False, 'train', no_flow=True, sample_length=3, color_aug=False)
+    aug = Small(root, [32, 32], False, 'train', no_flow=True, sample_length=3)
+    changed = 0
+    for idx in (0, 2, 4):
+        random.seed(300 + idx)
+        fg0, bg0, a0, _ = plain[idx]
+        random.seed(300 + idx)
+        fg1, bg1, a1, _ = aug[idx]
+        random.seed(300 + idx)
+        fg2, bg2, _, _ = aug[idx]
+        assert torch.equal(a0, a1) and fg1.is_cuda and fg1.shape == fg0.shape
+        assert torch.equal(fg1, fg2) and torch.equal(bg1, bg2)
+        for t in (fg1, bg1):
+            assert float(t.min()) >= 0 and float(t.max()) <= 255 and torch.equal(t, t.round())
+        changed += int(not torch.equal(fg0, fg1)) + int(not torch.equal(bg0, bg1))
+    assert changed >= 5
