@@ -328,6 +328,13 @@ int tcvom_gca_prepare(const void* g8, const uint8_t* unk8, void* G, float* scale
 int tcvom_row_softmax(const float* S, void* P, int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, void* stream);
 int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec /*[rows/rows_per_batch][ncols]*/, void* T,
                           int32_t rows, int32_t ncols, int64_t ld, int64_t ldp, int32_t rows_per_batch, void* stream);
+/* GuidedCxtAtten forward, scores + softmax in one pair of launches without the fp32 N x N score matrix (models/GCA/ops.py:177-190):
+ * P[b][i][j] = softmax_j( c[b][j] <G[b][i], G[b][j]> - d[b][j] [i == j] ) as bf16 [batch][N][ld], zeros in the padding columns.
+ * G bf16 [batch][N][D]; cvec / dvec fp32 [batch][N] (dvec may be NULL); stats fp32 scratch [batch][N][ld / 256][2].
+ * tcvom_gca_scores_softmax_ok: 1 when the shape is served (N % 8 == 0, D % 64 == 0, ld % 256 == 0, ld <= 16384). */
+int tcvom_gca_scores_softmax_ok(int32_t N, int32_t D, int64_t ld, int32_t batch);
+int tcvom_gca_scores_softmax(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
+                             int64_t ld, int32_t batch, void* stream);
 /* The same backward without the N x N fp32 dP matrix: one MFMA GEMM whose epilogue applies the softmax backward,
  *   T[b][i][j] = P[b][i][j] * (sum_v dO[b][i][v] V[b][j][v] - delta[b][i]) * cvec[b][j]   (bf16 [batch][N][ld], zero for j >= N),
  * with delta[b][i] = sum_j P dP = <dO[b][i], O[b][i]> from tcvom_rowdot_bf16 (O = the forward's P V, kept in fp32: for a

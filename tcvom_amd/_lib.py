@@ -177,6 +177,8 @@ _PROTOS = {
     'tcvom_act_dtype': [],
     'tcvom_conv_trace_read': [vp, i32],
     'tcvom_gca_dp_softmax_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
+    'tcvom_gca_scores_softmax_ok': [i32, i32, i64, i32],
+    'tcvom_gca_scores_softmax': [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_rowdot_bf16': [vp, vp, i32, vp, i64, i32, vp],
     'tcvom_gca_fold_f32': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_multi': [vp, vp, vp, i32, DP, i32, vp],
@@ -193,7 +195,7 @@ _PROTOS = {
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
-          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups'}
+          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}

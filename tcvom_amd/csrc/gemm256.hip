@@ -46,6 +46,8 @@ struct Gemm256Args {
     const h16raw* B2;
     void* out2;
     long long b2_bstride;
+    // EPI 3 (tcvom_gca_scores_softmax): out = bf16( exp(S - tile row max) ), stats[b][n][tile_m][2] = (tile row max, sum of exps)
+    float* stats;
 };
 
 #ifndef G256_STAGED_EPI
@@ -66,8 +68,8 @@ extern "C" int tcvom_trace256_read(unsigned long long* host) {
 }
 #endif
 
-// EPI: 0 = fp32 output, 1 = bf16 output, 2 = fused softmax backward (one instantiation each: a single kernel with all three
-// epilogues spilled registers in the main loop)
+// EPI: 0 = fp32 output, 1 = bf16 output, 2 = fused softmax backward, 3 = softmax numerators + per-tile row statistics (one
+// instantiation each: a single kernel with all epilogues spilled registers in the main loop)
 template <int EPI, int MF>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     // MF = 32-row A fragments per wave: 4 -> 256 x 256 tiles; 3 -> 192 (A rows) x 256 tiles for M = 576 (the d(query) / d(key)
@@ -368,6 +370,72 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         const float slope = g.act == 1 ? 0.f : g.act == 3 ? 0.01f : 1.f;          // activation as max(x, slope * x)
         // (the diagonal term is decided once per tile, not per element: `if (mdiag && ..)` / `if (act == ..)` inside the 128-value
         // loops were scalar branches)
+        if constexpr (EPI == 3) {
+            // ---- S' = acc * c[m] - d[m] [m == n] in place, then the softmax numerators of THIS tile: a row n of the tile has its
+            // 256 columns m in 2 lane halves x 2 wave groups; max and sum go lane -> partner lane (xor 32) -> partner wave (LDS)
+            float* red = reinterpret_cast<float*>(lb + 96 * 1024);       // 2 x [2 wm][4 wn][2 b][32] floats, beyond the staging regions
+            const float ninf = -__builtin_inff();
+            float tmax[2] = {ninf, ninf};
+#pragma unroll
+            for (int a = 0; a < MF; ++a) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mrow = m0 + wm * HM + a * 32 + 8 * q + 4 * h;
+                    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const bool mv = mrow < g.M;
+                    if (mv) {
+                        if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
+                        if (mdiag) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
+                    }
+                    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = acc[a][b][q * 4 + r] * sc[r] - ((mrow + r) == pglob[b] ? dg[r] : 0.f);
+                            x = mv ? x : ninf;                            // padding columns M <= m: no part of the row
+                            acc[a][b][q * 4 + r] = x;
+                            tmax[b] = fmaxf(tmax[b], x);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);            // keep the 16 coefficient loads from being hoisted together (spills)
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                tmax[b] = fmaxf(tmax[b], __shfl_xor(tmax[b], 32, 64));
+                if (h == 0) red[((wm * 4 + wn) * 2 + b) * 32 + nl] = tmax[b];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+            float tsum[2] = {0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                tmax[b] = fmaxf(tmax[b], red[(((wm ^ 1) * 4 + wn) * 2 + b) * 32 + nl]);
+#pragma unroll
+                for (int a = 0; a < MF; ++a)
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        const float x = acc[a][b][r16];
+                        const float e = x == ninf ? 0.f : __expf(x - tmax[b]);
+                        acc[a][b][r16] = e;
+                        tsum[b] += e;
+                    }
+                tsum[b] += __shfl_xor(tsum[b], 32, 64);
+                if (h == 0) red[512 + ((wm * 4 + wn) * 2 + b) * 32 + nl] = tsum[b];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+            if (wm == 0 && h == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (pvalid[b]) {
+                        float* st = g.stats + (((int64_t)bz * g.N + pglob[b]) * gridDim.y + blockIdx.y) * 2;
+                        st[0] = tmax[b];
+                        st[1] = tsum[b] + red[512 + ((1 * 4 + wn) * 2 + b) * 32 + nl];
+                    }
+            }
+        }
         auto emit = [&](auto diag_) {
         constexpr bool DIAG = decltype(diag_)::value;
 #pragma unroll
@@ -378,18 +446,24 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                 for (int q = 0; q < 4; ++q) {
                     const int mrow = m0 + wm * HM + a * 32 + 8 * q + 4 * h;
                     float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = bs;
-                    if (mrow < g.M) {                         // M % 4 == 0: a lane's 4 rows are valid together
-                        if (bias) bs = *reinterpret_cast<const float4*>(bias + mrow);
-                        if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
-                        if (DIAG) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
+                    if constexpr (EPI != 3) {
+                        if (mrow < g.M) {                     // M % 4 == 0: a lane's 4 rows are valid together
+                            if (bias) bs = *reinterpret_cast<const float4*>(bias + mrow);
+                            if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
+                            if (DIAG) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
+                        }
                     }
                     const float bsv[4] = {bs.x, bs.y, bs.z, bs.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x = acc[a][b][q * 4 + r] * sc[r] + bsv[r];
-                        if (DIAG) x -= (mrow + r) == pglob[b] ? dg[r] : 0.f;
-                        v[r] = fmaxf(x, x * slope);
+                        if constexpr (EPI == 3) {
+                            v[r] = acc[a][b][q * 4 + r];          // the softmax numerator computed above
+                        } else {
+                            float x = acc[a][b][q * 4 + r] * sc[r] + bsv[r];
+                            if (DIAG) x -= (mrow + r) == pglob[b] ? dg[r] : 0.f;
+                            v[r] = fmaxf(x, x * slope);
+                        }
                     }
                     if constexpr (F32)
                         *reinterpret_cast<float4*>(wl + nl * 512 + (((a * 8 + 2 * q + h) ^ nl) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
@@ -426,7 +500,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             }
         }
         };
-        if (mdiag) emit(std::true_type{}); else emit(std::false_type{});
+        if constexpr (EPI == 3) emit(std::false_type{});
+        else if (mdiag) emit(std::true_type{}); else emit(std::false_type{});
     } else {
     // stored straight from the registers (the 192-row tiles)
     const float slope3 = g.act == 1 ? 0.f : g.act == 3 ? 0.01f : 1.f;
@@ -509,6 +584,7 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.delta = nullptr;
     g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = (const h16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
+    g.stats = nullptr;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
@@ -553,8 +629,79 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     TCVOM_CHECK_ARG((Tt == nullptr) == (Pt == nullptr) && (!Tt || ld % 256 == 0), "gca_dp_softmax_bwd: the transposed copies come together and need ld %% 256 == 0");
     g.Tt = (h16raw*)Tt; g.Pt = (h16raw*)Pt; g.ldt = (int)ld;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
+    g.stats = nullptr;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
+    return TCVOM_OK;
+}
+
+
+// ---- GuidedCxtAtten forward, scores + softmax without the fp32 score matrix (models/GCA/ops.py:177-190):
+//   P[b][i][j] = softmax_j( c[b][j] <G[b][i], G[b][j]> - d[b][j] [i == j] ),   zeros in the padding columns N <= j < ld.
+// Pass 1 (gemm_nt256 EPI 3): every 256 x 256 tile writes exp(S' - its own row maxima) as 16-bit numbers and (row max, row sum)
+// of the tile into stats[b][i][tile_j][2]; pass 2 rescales every row by exp(tile max - row max) / row sum, in place.  The fp32
+// N x N matrix (802 MB written and read back per 3-frame launch at 1080p) is never stored: 401 MB written, read and rewritten.
+__global__ __launch_bounds__(256) void softmax_rescale_kernel(uint4* __restrict__ P, const float* __restrict__ stats, int N, int ld8, int tmt) {
+    __shared__ float f[64];
+    const int64_t row = blockIdx.x;
+    const float* st = stats + row * tmt * 2;
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        const float mx = t < tmt ? st[2 * t] : -__builtin_inff(), sm = t < tmt ? st[2 * t + 1] : 0.f;
+        const float M = wave_max(mx);
+        const float e = t < tmt ? __expf(mx - M) : 0.f;
+        const float Lsum = wave_sum(sm * e);
+        f[t] = e / Lsum;
+    }
+    __syncthreads();
+    uint4* p = P + row * ld8;
+    const int n8 = N >> 3;                               // N % 8 == 0
+    for (int i = threadIdx.x; i < ld8; i += 256) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);            // padding columns N <= j < ld
+        if (i < n8) {
+            float x[8];
+            unpack8(p[i], x);
+            const float s = f[i >> 5];                   // 32 octets per 256-column tile
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] *= s;
+            v = pack8(x);
+        }
+        p[i] = v;
+    }
+}
+
+extern "C" int tcvom_gca_scores_softmax_ok(int32_t N, int32_t D, int64_t ld, int32_t batch) {
+    return (N >= 256 && N % 8 == 0 && D % 64 == 0 && ld >= N && ld % 256 == 0 && ld / 256 <= 64 && batch >= 1) ? 1 : 0;
+}
+extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
+                                        int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(G && cvec && P && stats, "gca_scores_softmax: null pointer");
+    TCVOM_CHECK_ARG(tcvom_gca_scores_softmax_ok(N, D, ld, batch), "gca_scores_softmax: N=%d D=%d ld=%lld (N %% 8, D %% 64, ld %% 256 == 0, ld <= 16384)",
+                    N, D, (long long)ld);
+    TCVOM_CHECK_ARG(((uintptr_t)cvec % 16) == 0 && (!dvec || ((uintptr_t)dvec % 16) == 0) && ((uintptr_t)P % 16) == 0, "gca_scores_softmax: alignment");
+    Gemm256Args g;
+    g.A = (const h16raw*)G;          // rows m = keys j
+    g.B = (const h16raw*)G;          // columns n = queries i
+    g.out = P;
+    g.bias = nullptr;
+    g.mscale = cvec;
+    g.mdiag = dvec;
+    g.zero_page = tcvom_zero_page();
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_scores_softmax: could not allocate the zero page");
+    g.M = N; g.N = N; g.K = D; g.ldo = (int)ld; g.act = 0; g.out_fp32 = 0; g.batch = batch;
+    g.a_bstride = (long long)N * D;
+    g.b_bstride = (long long)N * D;
+    g.out_bstride = (long long)N * ld;
+    g.vec_bstride = N;
+    g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
+    g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
+    g.stats = stats;
+    const int tmt = (int)(ld / 256);
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)tmt, (unsigned)batch);
+    hipLaunchKernelGGL((gemm_nt256_kernel<3, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(softmax_rescale_kernel, dim3((unsigned)((int64_t)batch * N)), dim3(256), 0, (hipStream_t)stream, (uint4*)P, stats, N,
+                       (int)(ld / 8), tmt);
+    TCVOM_LAUNCH_CHECK("gca_scores_softmax");
     return TCVOM_OK;
 }

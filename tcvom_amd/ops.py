@@ -1168,6 +1168,9 @@ def _r64(n):
     return (n + 63) // 64 * 64
 
 
+GCA_FUSED_SOFTMAX = _os.environ.get('TCVOM_NO_FUSED_SOFTMAX', '0') != '1'      # A/B switch (tools/ab_bench.sh TCVOM_NO_FUSED_SOFTMAX)
+
+
 
 class _GcaAttention(torch.autograd.Function):
     @staticmethod
@@ -1199,11 +1202,18 @@ class _GcaAttention(torch.autograd.Function):
         # (measured and dropped, round 3: scores -> softmax -> P V frame by frame, so that a frame's P is still in the Infinity Cache
         #  when its GEMM reads it: 28.16 vs 28.13 ms per step -- the kernel is not bound by where P comes from)
         # S'[i][j] = c_j <G_i, G_j> - d_j [i==j]     (rows m = keys j, columns n = queries i)
-        S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
-        d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
-        L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
-        del S
+        tiles = ((N + 255) // 256) * (ld // 256) * B if ld % 256 == 0 else 0
+        if GCA_FUSED_SOFTMAX and tiles >= 192 and L.call('tcvom_gca_scores_softmax_ok', N, D, ld, B):
+            # scores + softmax without the fp32 N x N matrix: the score GEMM's epilogue writes exp(S' - tile row max) and the
+            # per-tile (max, sum) of every row, a second pass rescales the rows in place (csrc/gemm256.hip EPI 3)
+            stats = torch.empty((B, N, ld // 256, 2), dtype=torch.float32, device=dev)
+            L.call('tcvom_gca_scores_softmax', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(P), L.ptr(stats), N, D, ld, B, st)
+        else:
+            S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
+            d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
+            L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
+            L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
+            del S
         d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
         L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
         y = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)

@@ -15,7 +15,7 @@ from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of th
 import torch.nn as nn
 import torch.nn.functional as F
 
-from helpers import hu, golden, tam_mask, gca_unknown, TAM_CASES, GCA_CASES, assert_close, Checker
+from helpers import hu, golden, tam_mask, gca_unknown, TAM_CASES, GCA_CASES, assert_close, Checker, tol
 from tcvom_amd.synthetic import formula_tensor, synthetic_window
 
 pytestmark = pytest.mark.gpu
@@ -628,6 +628,36 @@ def test_gca_fused_softmax_backward_gemm(B, N, DV):
         want_p = torch.zeros(B, ld, ld, dtype=H16, device=DEV)
         want_p[:, :, :N] = P.transpose(1, 2)
         assert torch.equal(Tt, want_t) and torch.equal(Pt, want_p)          # exact transposes, zero padding rows / columns
+
+
+@pytest.mark.parametrize('B,N,D', [(2, 1016, 192), (1, 2040, 576), (3, 512, 64)])
+def test_gca_scores_softmax_without_the_score_matrix(B, N, D):
+    """tcvom_gca_scores_softmax (score GEMM whose epilogue writes exp(S' - tile row max) + per-tile row statistics, then an
+    in-place rescale) against softmax(c_j <G_i, G_j> - d_j [i == j]) in fp32 on the same 16-bit operands; padding columns zero;
+    rows sum to one; the -1e4 self-mask of unknown keys (ops.py:186-188) must survive as an exact zero probability."""
+    from tcvom_amd import _lib as L
+    ld = (N + 255) // 256 * 256
+    tag = 'gss%d_%d' % (N, D)
+    st = L.stream_ptr()
+    G = ((hu('g.' + tag, (B, N, D)) - 0.5) * 1.5).to(H16).to(DEV)
+    cvec = (hu('c.' + tag, (B, N)) * 2 + 0.2).to(DEV)
+    dvec = torch.where(hu('d.' + tag, (B, N)) > 0.5, torch.full((B, N), 1e4), torch.zeros(B, N)).to(DEV)
+    assert L.call('tcvom_gca_scores_softmax_ok', N, D, ld, B) == 1
+    P = torch.full((B, N, ld), float('nan'), dtype=H16, device=DEV)
+    stats = torch.empty((B, N, ld // 256, 2), dtype=torch.float32, device=DEV)
+    L.call('tcvom_gca_scores_softmax', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(P), L.ptr(stats), N, D, ld, B, st)
+    Gf = G.float()
+    S = torch.bmm(Gf, Gf.transpose(1, 2)) * cvec[:, None, :]
+    S = S - torch.diag_embed(dvec)
+    ref = torch.softmax(S, dim=2)
+    got = P[:, :, :N].float()
+    assert bool(torch.isfinite(P.float()).all())
+    if ld > N:
+        assert float(P[:, :, N:].float().abs().max()) == 0.0
+    assert float((got.sum(2) - 1).abs().max()) < 2e-3
+    assert rel_err(got.cpu(), ref.cpu()) < tol(1.5e-2, 2e-3)
+    masked = torch.diag_embed(dvec > 0)
+    assert float(got[masked].max()) == 0.0                   # exp(-1e4 - max) underflows to an exact zero, as in the reference
 
 
 @pytest.mark.parametrize('ncols', [8160, 2040, 3000, 250])
