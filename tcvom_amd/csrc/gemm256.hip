@@ -48,6 +48,11 @@ struct Gemm256Args {
     long long b2_bstride;
     // EPI 3 (tcvom_gca_scores_softmax): out = bf16( exp(S - tile row max) ), stats[b][n][tile_m][2] = (tile row max, sum of exps)
     float* stats;
+    // K-split tail (fp32 output, linear epilogue only): flat_nx > 0 -> 1-D grid of split_r * split_s + (tiles - split_r) workgroups
+    // over the nx x ny x nz tiles in x-fastest order; the LAST split_r tiles are each computed by split_s workgroups (launched
+    // first), one per 1/split_s of the reduction, and added into the zeroed output with fp32 atomics.  576 tiles (the paired
+    // dq / dk product at 1080p) are 2.25 rounds of 256 workgroups: 512 whole tiles + 64 x 4 quarter-length ones instead of 3 rounds.
+    int flat_nx, flat_ny, split_r, split_s;
 };
 
 #ifndef G256_STAGED_EPI
@@ -84,20 +89,40 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int wm = wave >> 2, wn = wave & 3;             // wm = wave group (0: rows 0..127 of the tile, 1: rows 128..255)
 
     // XCD-aware tile order over the pixel (N) tiles
-    int bx;
+    int bx, by = blockIdx.y, bzz = blockIdx.z, kpart = -1;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        int nwg = gridDim.x, fx = blockIdx.x;
+        if (g.flat_nx > 0) {                           // flat grid with a K-split tail (see Gemm256Args)
+            const int nsplit = g.split_r * g.split_s, f = blockIdx.x;
+            int tile;
+            if (f < nsplit) {
+                kpart = f / g.split_r;
+                tile = (int)gridDim.x - nsplit + (f - kpart * g.split_r);          // whole tiles: 0 .. gridDim.x - nsplit - 1
+            } else tile = f - nsplit;
+            nwg = g.flat_nx;
+            fx = tile % nwg;
+            const int yz = tile / nwg;
+            by = yz % g.flat_ny;
+            bzz = yz / g.flat_ny;
+        }
+        const int q = nwg >> 3, r = nwg & 7, xcd = fx & 7, idx = fx >> 3;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const bool second = (int)blockIdx.z >= g.batch;
-    const int bz = second ? blockIdx.z - g.batch : blockIdx.z;
+    const bool second = bzz >= g.batch;
+    const int bz = second ? bzz - g.batch : bzz;
     const h16raw* A = g.A + bz * g.a_bstride;
     const h16raw* B = second ? g.B2 + bz * g.b2_bstride : g.B + bz * g.b_bstride;
+    int ntile = g.K >> 6;
+    if (kpart >= 0) {                                  // this workgroup's share of the reduction
+        const int t0 = ntile * kpart / g.split_s, t1 = ntile * (kpart + 1) / g.split_s;
+        A += t0 * 64; B += t0 * 64;
+        ntile = t1 - t0;
+    }
     void* const gout = second ? g.out2 : g.out;
     const float* bias = g.bias ? g.bias + bz * g.vec_bstride : nullptr;
     const float* mscale = g.mscale ? g.mscale + bz * g.vec_bstride : nullptr;
     const float* mdiag = g.mdiag ? g.mdiag + bz * g.vec_bstride : nullptr;
-    const int n0 = bx * TN, m0 = blockIdx.y * TM;
+    const int n0 = bx * TN, m0 = by * TM;
     const int K = g.K;
 
     // DMA pieces (8 rows x 128 bytes per wave-instruction; lane -> row +lane/8, 16-byte chunk kc): B piece (it, wave) covers tile
@@ -175,7 +200,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #define G_BAR() __builtin_amdgcn_s_barrier()
 #endif
 
-    const int ntile = K >> 6;
     // prologue: K-tile 0 into buffer 0 (all waves), then the stagger
 #pragma unroll
     for (int it = 0; it < 4; ++it) { if (it < A_IT) G_ISSUE_A(0, it) G_ISSUE_B(0, it) }
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     if (pvalid[b]) {
-                        float* st = g.stats + (((int64_t)bz * g.N + pglob[b]) * gridDim.y + blockIdx.y) * 2;
+                        float* st = g.stats + (((int64_t)bz * g.N + pglob[b]) * gridDim.y + by) * 2;
                         st[0] = tmax[b];
                         st[1] = tsum[b] + red[512 + ((1 * 4 + wn) * 2 + b) * 32 + nl];
                     }
@@ -503,6 +527,39 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         if constexpr (EPI == 3) emit(std::false_type{});
         else if (mdiag) emit(std::true_type{}); else emit(std::false_type{});
     } else {
+    if constexpr (F32 && MF == 3) {
+        if (kpart >= 0) {
+            // K-split tail: this workgroup's partial products are ADDED to the zeroed output.  Atomics execute per cache line, so
+            // each wave turns its 64 (n) x 96 (m) block through a private LDS region, 32 rows at a time, and issues them along the
+            // rows (64 consecutive floats per instruction = 2 lines; straight from the MFMA layout an instruction touches 32 rows).
+            float* wl = reinterpret_cast<float*>(lb + wave * 12800);              // [32 rows][100 floats] per wave
+            const int nl = lane & 31, h = lane >> 5;
+            float* o = reinterpret_cast<float*>(gout) + obase;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int a = 0; a < MF; ++a) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ml = a * 32 + 8 * q + 4 * h, mrow = m0 + wm * HM + ml;
+                        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (mscale && mrow < g.M) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
+                        *reinterpret_cast<float4*>(wl + nl * 100 + ml) = make_float4(acc[a][b][q * 4 + 0] * sc4.x, acc[a][b][q * 4 + 1] * sc4.y,
+                                                                                      acc[a][b][q * 4 + 2] * sc4.z, acc[a][b][q * 4 + 3] * sc4.w);
+                    }
+                }
+                const int nbase = n0 + wn * 64 + b * 32, mbase = m0 + wm * HM;
+#pragma unroll 4
+                for (int i = 0; i < 48; ++i) {
+                    const int e = i * 64 + lane, row = e / 96, col = e - row * 96;
+                    const float v = wl[row * 100 + col];
+                    const int n = nbase + row, m = mbase + col;
+                    if (n < g.N && m < g.M) __hip_atomic_fetch_add(o + (int64_t)n * g.ldo + m, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
+    }
     // stored straight from the registers (the 192-row tiles)
     const float slope3 = g.act == 1 ? 0.f : g.act == 3 ? 0.01f : 1.f;
     int64_t out_off[2];
@@ -585,10 +642,30 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = (const h16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
     g.stats = nullptr;
+    g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
-    const dim3 grid((unsigned)((P + 255) / 256), (unsigned)cdiv(d->K, m192 ? 192 : 256), (unsigned)(in2 ? 2 * nb : nb));
+    dim3 grid((unsigned)((P + 255) / 256), (unsigned)cdiv(d->K, m192 ? 192 : 256), (unsigned)(in2 ? 2 * nb : nb));
+    // K-split tail: the tiles beyond the last whole round of 256 workgroups, when they are whole tile rows of the last output
+    // slice and would leave most of the chip idle for a full tile time
+    static const bool nosplit = getenv("TCVOM_NO_KSPLIT") != nullptr;              // A/B switch
+    if (!nosplit && m192 && g.out_fp32 && !bias && !mdiag && d->act == 0) {
+        const int nx = (int)grid.x, ny = (int)grid.y, tiles = nx * ny * (int)grid.z, rem = tiles % 256;
+        const int ntile = d->C / 64;
+        if (tiles > 256 && rem > 0 && rem <= 128 && rem % nx == 0 && rem / nx <= ny) {
+            const int sp = 256 / rem < 8 ? 256 / rem : 8;                          // 2 .. 8 parts, each >= 8 K-tiles
+            if (sp >= 2 && ntile / sp >= 8) {
+                const int rows = rem / nx, mlo = (ny - rows) * 192;                // the tail covers columns mlo .. M of the last slice
+                float* base = (float*)(in2 ? out2 : out) + (long long)(nb - 1) * g.out_bstride + mlo;
+                if (hipMemset2DAsync(base, sizeof(float) * (size_t)g.ldo, 0, sizeof(float) * (size_t)(d->K - mlo), (size_t)P,
+                                     (hipStream_t)stream) != hipSuccess)
+                    return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: memset of the K-split tail failed");
+                g.flat_nx = nx; g.flat_ny = ny; g.split_r = rem; g.split_s = sp;
+                grid = dim3((unsigned)(tiles - rem + rem * sp), 1, 1);
+            }
+        }
+    }
     if (m192) {
         if (g.out_fp32) hipLaunchKernelGGL((gemm_nt256_kernel<0, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
         else hipLaunchKernelGGL((gemm_nt256_kernel<1, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
@@ -630,6 +707,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.Tt = (h16raw*)Tt; g.Pt = (h16raw*)Pt; g.ldt = (int)ld;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
+    g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
@@ -697,6 +775,7 @@ extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const 
     g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = stats;
+    g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     const int tmt = (int)(ld / 256);
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)tmt, (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<3, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);

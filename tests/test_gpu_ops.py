@@ -654,7 +654,8 @@ def test_gca_scores_softmax_without_the_score_matrix(B, N, D):
     assert bool(torch.isfinite(P.float()).all())
     if ld > N:
         assert float(P[:, :, N:].float().abs().max()) == 0.0
-    assert float((got.sum(2) - 1).abs().max()) < 2e-3
+    # (peaked rows: one probability near 1 rounded twice -- numerator, then rescaled value -- to 8 / 11 significant bits)
+    assert float((got.sum(2) - 1).abs().max()) < tol(5e-3, 1.5e-3)
     assert rel_err(got.cpu(), ref.cpu()) < tol(1.5e-2, 2e-3)
     masked = torch.diag_embed(dvec > 0)
     assert float(got[masked].max()) == 0.0                   # exp(-1e4 - max) underflows to an exact zero, as in the reference
@@ -734,15 +735,16 @@ def test_dense_gemm_256_staggered_kernel_epilogues(fp32):
     assert float(out[:, :, rows_a:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('rows_a,rows_b', [(576, 5700), (64, 300)])
-def test_dense_gemm_pair_one_launch(rows_a, rows_b):
+@pytest.mark.parametrize('rows_a,rows_b,kred', [(576, 5700, 512), (64, 300, 128), (576, 8000, 2048)])
+def test_dense_gemm_pair_one_launch(rows_a, rows_b, kred):
     """tcvom_gemm_pair: two products against the same weight operand (the d(query) / d(key) GEMMs of the attention scores,
     576 rows on 192-row tiles), with different batch strides of the two inputs, against float matmuls; the small case takes
-    the two-launch fallback."""
+    the two-launch fallback; the third has 576 tiles = two rounds of 256 + 64 tiles whose reduction is split over 4 workgroups
+    each (fp32 atomics into the zeroed tail of the last output slice)."""
     import ctypes as C
     from tcvom_amd import _lib as L
     from tcvom_amd.conv_plan import dense_desc
-    nb, kred = 3, 512 if rows_a == 576 else 128
+    nb = 3
     pad = rows_b + 10                                         # rows of in2's per-batch allocation
     W_ = (hu('gp.w', (nb, rows_a, kred)) - 0.5).to(DEV).to(H16)
     X1 = (hu('gp.x1', (nb, rows_b, kred)) - 0.5).to(DEV).to(H16)
