@@ -400,6 +400,15 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         //  per CU, 25 % fewer operand bytes per MAC than two co-resident 128 x 128 workgroups: 25.57 -> 25.80 ms per step; the
         //  128 x 128 threshold lowered to 150 workgroups for the 512-channel os32 layers: no change)
         if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
+        // 128 (channels) x 96 (pixels) tiles, 4 waves of 32 x 96, where they spread evenly over the chip and the 128 x 128 ones do
+        // not: the 256-channel os16 layers at 1080p are 64 x 2 x 3 = 384 workgroups of 128 x 128 (half the CUs run two, half one)
+        // but 85 x 2 x 3 = 510 of 128 x 96 (two per CU on 255 CUs); TCVOM_NT_T96=0 switches it off
+        static const int t96 = getenv("TCVOM_NT_T96") ? atoi(getenv("TCVOM_NT_T96")) : 1;
+        if (t96 && wgs >= t128 && wgs < 1024) {
+            const long long w96 = (long long)cdiv(P, 96) * cdiv(d->K, 128) * nb;
+            auto eff = [](long long w) { const long long per = (w + 255) / 256; return (double)w / (double)(per * 256); };
+            if (eff(w96) > eff(wgs) + 0.1) return {128, 96, 1};
+        }
         if (wgs >= t128) return {128, 128, 4};
         if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
         return {64, 64, 2};
@@ -447,6 +456,7 @@ extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_
     const NtCfg c = nt_config(d, nphase);
     if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";
     if (c.tm == 128 && c.tn == 128) return "igemm_nt<128,128,64,32,2>";
+    if (c.tm == 128 && c.tn == 96) return "igemm_nt<128,96,32,96,2>";
     if (c.tm == 128) return "igemm_nt<128,64,32,32,3>";
     if (c.tm == 64 && c.tn == 64) return "igemm_nt<64,64,32,32,4>";
     if (c.tm == 64) return "igemm_nt<64,128,32,64,3>";
@@ -507,6 +517,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
                        stats_partial, zp, ps)
     if (c.tm == 256) NT_LAUNCH(512, 256, 256, 128, 64, 2);
     else if (c.tm == 128 && c.tn == 128) NT_LAUNCH(512, 128, 128, 64, 32, 2);
+    else if (c.tm == 128 && c.tn == 96) NT_LAUNCH(256, 128, 96, 32, 96, 2);
     else if (c.tm == 128) NT_LAUNCH(512, 128, 64, 32, 32, 3);
     else if (c.tm == 64 && c.tn == 64) NT_LAUNCH(256, 64, 64, 32, 32, 4);
     else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 3);

@@ -237,6 +237,7 @@ def test_conv_bn_act_train(act, pre_relu, res):
     (128, 128, 3, 1, False, 136, 240),     # the os8 class at 1080p: 128x64 tiles
     (32, 32, 3, 1, False, 272, 480),       # the os2/os1 class: 32x256 tiles
     (256, 256, 3, 1, False, 68, 120),      # the os16 class: 64x64 tiles, 4-slot ring
+    (256, 256, 3, 1, False, 136, 180),     # 24480 pixels (= 3 os16 frames): 128x96 tiles, 510 workgroups instead of 384 of 128x128
 ])
 def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     """Tile configurations are chosen from the problem size, so the production (1080p) configurations need their
