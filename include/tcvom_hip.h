@@ -192,12 +192,30 @@ int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
 int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                         const float* saved, float* partial /*[nframes][groups][2][C]*/, int64_t pixels, int32_t C,
                         int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream);
+/* _ranged: dz2 holds the frames dz2_f0 .. dz2_f1 - 1 of the batched call only ([dz2_f1 - dz2_f0][pixels][C], zero elsewhere): the
+ * gradient a consumer that ran for the interior frames of a window (VMN_model.py:107-110) deposits with its producer */
+int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                               const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32,
+                               int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
+/* Optional by-product of the BatchNorm backward of a SpectralNorm'd conv (models/GCA/ops.py:25-45: weight = weight_bar / sigma,
+ * differentiated by autograd): SpectralNorm's backward needs <dW~, weight_bar> = sigma <dW~, W~>, and <dW~, W~> = d(loss)/d(alpha) of
+ * y = conv(x, alpha W~) = <dy, y> -- which the two BatchNorm-backward sums determine per channel (training statistics:
+ * gamma invstd^2 eps sum(g xhat); running statistics: gamma invstd (mean sum(g) + sum(g xhat) / invstd)).  The finalize kernels ADD
+ * scale * sum_c <dy, y>_c of frame f to out[f * frame_stride]; tcvom_sn_backward multiplies by sigma.  Replaces a pass over the
+ * weight gradients of these layers.  Bias-free convs only (y must be conv(x, W~) itself). */
+typedef struct {
+    float* out;               /* NULL: off */
+    int64_t frame_stride;     /* elements between the slots of consecutive frames (0: all frames share one slot) */
+    float eps;                /* the BatchNorm's eps */
+    int32_t training;         /* != 0: batch statistics were used in the forward */
+    float scale;              /* 1, or 1 / world under SyncBatchNorm (every rank holds the GLOBAL sums; the gradient all-reduce averages) */
+} tcvom_sn_dot;
 /* dgamma/dbeta are written, or accumulated when `accumulate` is set; coef is [3][C] scratch consumed by bn_bwd_apply */
 int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count, const float* gamma,
                           const float* saved, float* dgamma, float* dbeta, float* coef /*[nframes][3][C]*/,
                           double* scratch /* nframes * tcvom_bn_finalize_scratch_doubles(C) doubles, or NULL */,
                           int32_t accumulate /* != 0: atomically ADD into dgamma/dbeta (required when nframes > 1) */,
-                          int32_t nframes, int64_t slot_stride, void* stream);
+                          int32_t nframes, int64_t slot_stride, const tcvom_sn_dot* dot /* or NULL */, void* stream);
 /* GroupNorm (FBA base, models/FBA/layers_WS.py:26-27, nn.GroupNorm(32, C)) on the same partial sums: one sample per
  * "frame"; count = pixels of one sample.  The (scale, shift) / (mean, invstd) / coef vectors it writes drive
  * tcvom_bn_apply / tcvom_bn_bwd_reduce / tcvom_bn_bwd_apply unchanged.  dgamma / dbeta are ADDED to (atomics). */
@@ -221,7 +239,7 @@ int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t
                            int64_t slot_stride, void* stream);
 int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
-                               int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream);
+                               int32_t accumulate, int32_t nframes, int64_t slot_stride, const tcvom_sn_dot* dot, void* stream);
 /* SyncBatchNorm WITHOUT a collective call (replaces the all_gather / all_reduce pairs nn.SyncBatchNorm issues per BatchNorm call
  * under train_ddp.py:271-280): every rank owns a mailbox of uncached device memory mapped into its peers
  * through hipIpc; the finalize kernel pushes its local fp64 sums into every peer's mailbox over xGMI as self-validating 8-byte
@@ -246,7 +264,7 @@ int tcvom_bn_finalize_sync(const float* stats_partial, int32_t groups, int32_t C
 int tcvom_bn_bwd_finalize_sync(const float* partial, int32_t groups, int32_t C, int64_t count,
                                const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
                                double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
-                               const tcvom_bn_sync* sync, void* stream);
+                               const tcvom_bn_sync* sync, const tcvom_sn_dot* dot, void* stream);
 /* The mailbox memory: the only entry points that own memory (uncached + hipIpc-exportable, which the caller's allocator cannot
  * provide).  alloc: zero-filled, *handle64 = the 64-byte hipIpc handle to hand to the peers (all zero if the runtime cannot
  * export: a one-rank mailbox still works).  open / close: map / unmap a peer's mailbox.  These four synchronise the device. */
@@ -260,6 +278,10 @@ int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const voi
                        const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                        int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                        int64_t slot_stride, void* stream);
+int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                              const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                              int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                              int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
 
 /* ------------------------------------------------------------------ batched SpectralNorm + weight packing
  * Replaces SpectralNorm._update_u_v/_noupdate_u_v (models/GCA/ops.py:25-45,74-80) for every wrapped
@@ -285,7 +307,10 @@ int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, const int32_t
 int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
                       const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
                       const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,
-                      float* inner, int32_t max_calls, float* grad_arena, float out_scale /* multiplies every written gradient: 1 / loss scale of the fp16 build, else 1 */, void* stream);
+                      float* inner, int32_t max_calls, float* grad_arena, float out_scale /* multiplies every written gradient: 1 / loss scale of the fp16 build, else 1 */,
+                      const float* dots /* [max_calls][layers]: <dy, y> of the layers flagged in dot_layers (tcvom_sn_dot), or NULL */,
+                      const int32_t* dot_layers /* [layers]: != 0 -> <dW~, W_bar> = sigma * dots (no work_inner rows for that layer) */,
+                      void* stream);
 
 /* ------------------------------------------------------------------ layout / resampling helpers (NHWC bf16) */
 int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

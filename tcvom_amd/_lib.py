@@ -54,6 +54,11 @@ class BnSync(C.Structure):
                 ('capacity', C.c_int64), ('timeout_ticks', C.c_int64), ('status', C.c_void_p)]
 
 
+class SnDot(C.Structure):
+    """struct tcvom_sn_dot: <dy, y> of a SpectralNorm'd conv as a by-product of its BatchNorm backward."""
+    _fields_ = [('out', C.c_void_p), ('frame_stride', C.c_int64), ('eps', C.c_float), ('training', C.c_int32), ('scale', C.c_float)]
+
+
 class TcvomError(RuntimeError):
     pass
 
@@ -76,6 +81,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 DP = C.POINTER(ConvDesc)
 SP = C.POINTER(SnScratch)
 YP = C.POINTER(BnSync)
+TP = C.POINTER(SnDot)
 
 # name -> argtypes (all return int except the explicitly listed ones)
 _PROTOS = {
@@ -93,21 +99,23 @@ _PROTOS = {
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
     'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
-    'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp],
+    'tcvom_bn_bwd_reduce_ranged': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i32, i32, vp],
+    'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, TP, vp],
     'tcvom_bn_ema_multi': [vp, i32, vp, vp, vp],
     'tcvom_bn_reduce_sums': [vp, i32, i32, vp, vp, i32, vp],
     'tcvom_bn_finalize_sums': [vp, i32, i64, i64, vp, vp, f32, vp, vp, i32, i64, vp],
-    'tcvom_bn_bwd_finalize_sums': [vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i64, vp],
+    'tcvom_bn_bwd_finalize_sums': [vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i64, TP, vp],
     'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_bwd_apply_ranged': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_finalize_sync': [vp, i32, i32, i64, i64, vp, vp, f32, vp, vp, vp, i32, i64, YP, vp],
-    'tcvom_bn_bwd_finalize_sync': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, YP, vp],
+    'tcvom_bn_bwd_finalize_sync': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, YP, TP, vp],
     'tcvom_mbox_alloc': [i64, C.POINTER(C.c_void_p), vp],
     'tcvom_mbox_open': [vp, C.POINTER(C.c_void_p)],
     'tcvom_mbox_close': [vp],
     'tcvom_mbox_free': [vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
-    'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, f32, vp],
+    'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, f32, vp, vp, vp],
     'tcvom_avgpool2': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_upsample2': [vp, vp, i32, i32, i32, i32, f32, vp],
     'tcvom_sumpool2': [vp, vp, i32, i32, i32, i32, f32, vp],

@@ -291,10 +291,12 @@ template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
-    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride)
+    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1)
 {
     extern __shared__ float red[];        // [2][256][8]
     const int tid = threadIdx.x;
+    // dz2 may cover the frames dz2_f0 .. dz2_f1 - 1 only (a consumer that ran for the interior frames of a window): zero elsewhere
+    if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
     scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
     saved += blockIdx.y * slot_stride;
     partial += (int64_t)blockIdx.y * gridDim.x * 2 * C;
@@ -365,11 +367,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+struct SnDot { float* out; long long stride; float eps, scale; };         // eps < 0: eval-mode statistics
+static const SnDot kNoDot = {nullptr, 0, 0.f, 0.f};
+static SnDot make_dot(const tcvom_sn_dot* d) {
+    if (!d || !d->out) return kNoDot;
+    SnDot o = {d->out, (long long)d->frame_stride, d->training ? d->eps : -1.f, d->scale};
+    return o;
+}
+
 template <typename PT>
 __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
     const PT* __restrict__ partial, int G, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ saved,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate, int64_t slot_stride, const BnSync sy)
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int accumulate, int64_t slot_stride, const BnSync sy,
+    const SnDot sd)
 {
     __shared__ double s1[FIN_SL][32], s2[FIN_SL][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -415,6 +426,20 @@ __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
         coef[C + c] = (float)(b / count) * gi;
         coef[2 * C + c] = gi;
     }
+    if (sd.out && threadIdx.x < 64) {
+        // <dy, y> over the frame = d(loss)/d(alpha) of y = conv(x, alpha W~) at alpha = 1 = <dW~, W~>: SpectralNorm's backward needs
+        // <dW~, W_bar> = sigma <dW~, W~> (models/GCA/ops.py:25-45 through autograd) and gets it here from the two BatchNorm sums
+        // instead of a pass over the weight gradient.  Per channel, with dy = gi (g - mean g - xhat mean(g xhat)):
+        //   training: sum dy y = gi * sum(g xhat) * invstd * eps     (BatchNorm is scale-invariant up to eps)
+        //   eval    : sum dy y = gi * (mean * sum g + sum(g xhat) / invstd)
+        float d = 0.f;
+        if (sl == 0 && c < C) {
+            const double mean = saved[c], is = saved[C + c], gi = (double)gamma[c] * is;
+            d = (float)((sd.eps >= 0.f ? gi * b * is * (double)sd.eps : gi * (mean * a + b / is)) * (double)sd.scale);
+        }
+        d = wave_sum(d);
+        if (threadIdx.x == 0 && d != 0.f) atomicAdd(sd.out + blockIdx.y * sd.stride, d);
+    }
 }
 
 template <bool YF32>
@@ -422,10 +447,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
-    int rows_per_block, int64_t slot_stride)
+    int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1)
 {
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
+    if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
     scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
     saved += blockIdx.y * slot_stride;
     coef += (int64_t)blockIdx.y * 3 * C;
@@ -667,9 +693,11 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
     return (int)g;
 }
 
-extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
-                                   const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
-                                   int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
+extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                                          const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
+                                          int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
+                                          void* stream) {
+    TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_reduce: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && nframes >= 1,
                     "bn_bwd_reduce: bad args (C=%d)", C);
     const int groups = tcvom_bn_bwd_groups(pixels, C);
@@ -677,26 +705,34 @@ extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* 
     const dim3 grid(groups, nframes);
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
+                           dz2_f0, dz2_f1);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride);
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
+                           dz2_f0, dz2_f1);
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
+}
+extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                                   const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
+                                   int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
+    return tcvom_bn_bwd_reduce_ranged(dz, dz2, y, res1, scale_shift, saved, partial, pixels, C, act, y_fp32, nframes, slot_stride, 0,
+                                      nframes, stream);
 }
 
 static int bn_bwd_finalize_impl(const float* partial, int32_t groups, int32_t C, int64_t count,
                                 const float* gamma, const float* saved, float* dgamma, float* dbeta,
                                 float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
-                                const BnSync& sy, void* stream) {
+                                const BnSync& sy, const SnDot& sd, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (groups > 4 * BN_SLICES && scratch) {
         hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, (const double*)scratch, BN_SLICES,
-                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride, sy);
+                           C, (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride, sy, sd);
     } else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, partial, groups, C,
-                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride, sy);
+                           (double)count, gamma, saved, dgamma, dbeta, coef, accumulate, slot_stride, sy, sd);
     }
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize");
     return TCVOM_OK;
@@ -705,24 +741,25 @@ static int bn_bwd_finalize_impl(const float* partial, int32_t groups, int32_t C,
 extern "C" int tcvom_bn_bwd_finalize(const float* partial, int32_t groups, int32_t C, int64_t count,
                                      const float* gamma, const float* saved, float* dgamma, float* dbeta,
                                      float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
-                                     void* stream) {
+                                     const tcvom_sn_dot* dot, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize: bad args");
     TCVOM_CHECK_ARG(nframes == 1 || accumulate, "bn_bwd_finalize: the frames of a batched call must ACCUMULATE dgamma/dbeta");
     return bn_bwd_finalize_impl(partial, groups, C, count, gamma, saved, dgamma, dbeta, coef, scratch, accumulate, nframes, slot_stride,
-                                kNoSync, stream);
+                                kNoSync, make_dot(dot), stream);
 }
 
 // SyncBatchNorm backward: (sum dy, sum dy * xhat) exchanged inside the finalize kernel; dgamma / dbeta from the LOCAL sums.
 extern "C" int tcvom_bn_bwd_finalize_sync(const float* partial, int32_t groups, int32_t C, int64_t count,
                                           const float* gamma, const float* saved, float* dgamma, float* dbeta,
                                           float* coef, double* scratch, int32_t accumulate, int32_t nframes, int64_t slot_stride,
-                                          const tcvom_bn_sync* sync, void* stream) {
+                                          const tcvom_bn_sync* sync, const tcvom_sn_dot* dot, void* stream) {
     TCVOM_CHECK_ARG(partial && gamma && saved && coef && groups > 0 && C > 0 && count > 0 && nframes >= 1 && sync, "bn_bwd_finalize_sync: bad args");
     TCVOM_CHECK_ARG(nframes == 1 || accumulate, "bn_bwd_finalize_sync: the frames of a batched call must ACCUMULATE dgamma/dbeta");
     BnSync sy;
     const int rc = make_sync(sync, C, nframes, &sy, "bn_bwd_finalize_sync");
     if (rc != TCVOM_OK) return rc;
-    return bn_bwd_finalize_impl(partial, groups, C, count, gamma, saved, dgamma, dbeta, coef, scratch, accumulate, nframes, slot_stride, sy, stream);
+    return bn_bwd_finalize_impl(partial, groups, C, count, gamma, saved, dgamma, dbeta, coef, scratch, accumulate, nframes, slot_stride, sy,
+                                make_dot(dot), stream);
 }
 
 // ---------------------------------------------------------------- GroupNorm (FBA base: models/FBA/layers_WS.py:26-27)
@@ -938,21 +975,22 @@ extern "C" int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t cou
 
 extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                           const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
-                                          int32_t accumulate, int32_t nframes, int64_t slot_stride, void* stream) {
+                                          int32_t accumulate, int32_t nframes, int64_t slot_stride, const tcvom_sn_dot* dot, void* stream) {
     TCVOM_CHECK_ARG(sums_all && sums_local && gamma && saved && coef && C > 0 && count > 0 && nframes >= 1, "bn_bwd_finalize_sums: bad args");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(cdiv(C, 32), nframes), dim3(FIN_SL * 32), 0, st, sums_all, 1, C, (double)count, gamma,
-                       saved, (float*)nullptr, (float*)nullptr, coef, 0, slot_stride, kNoSync);
+                       saved, (float*)nullptr, (float*)nullptr, coef, 0, slot_stride, kNoSync, make_dot(dot));
     // gamma / beta gradients stay LOCAL sums (torch SyncBatchNorm semantics); the gradient all-reduce averages them
     hipLaunchKernelGGL(bn_local_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums_local, C, dgamma, dbeta, accumulate, nframes);
     TCVOM_LAUNCH_CHECK("bn_bwd_finalize_sums");
     return TCVOM_OK;
 }
 
-extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
-                                  const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
-                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
-                                  int64_t slot_stride, void* stream) {
+extern "C" int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                                         const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                                         int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                                         int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
+    TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_apply: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0 && nframes >= 1, "bn_bwd_apply: bad args");
     TCVOM_CHECK_ARG(C <= 2048, "bn_bwd_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
@@ -960,11 +998,18 @@ extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1);
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
+}
+extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                                  const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                                  int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                                  int64_t slot_stride, void* stream) {
+    return tcvom_bn_bwd_apply_ranged(dz, dz2, y, res1, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
+                                     nframes, slot_stride, 0, nframes, stream);
 }

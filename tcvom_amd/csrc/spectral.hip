@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const int64_t* __rest
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
                                                            const float* __restrict__ dw_arena, int64_t dw_call_stride,
                                                            const float* __restrict__ inner, SnScratch sc,
-                                                           const int* __restrict__ ncalls, float* __restrict__ grad_arena, float out_scale)
+                                                           const int* __restrict__ ncalls, float* __restrict__ grad_arena, float out_scale,
+                                                           const float* __restrict__ dots, const int* __restrict__ dot_layers)
 {
     const int layer = work[blockIdx.x * 2];
     const int64_t* L = tab + (int64_t)layer * SN_WORDS;
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
     }
     float g = 0.f;
     const int nc = ncalls[layer];
+    const bool from_dot = dot_layers != nullptr && dot_layers[layer] != 0;
     for (int call = 0; call < nc; ++call) {
         const float d = dw_arena[call * dw_call_stride + L[SN_DW_OFF] + pidx];
         if (kind & 2) {
@@ -371,7 +373,9 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
             const float sg = sc.sigma[(int64_t)call * sc.L + layer];
             const float uu = sc.uhist[(int64_t)call * sc.sum_h + L[SN_S_OFF] + row];
             const float vv = sc.vhist[(int64_t)call * sc.sum_wd + L[SN_T_OFF] + col];
-            g += d / sg - inner[(int64_t)call * sc.L + layer] / (sg * sg) * uu * vv;
+            // <dW~, W_bar>: summed by sn_bwd_inner_kernel, or sigma <dy, y> delivered by the layer's BatchNorm backward (tcvom_sn_dot)
+            const float in_ = from_dot ? sg * dots[(int64_t)call * sc.L + layer] : inner[(int64_t)call * sc.L + layer];
+            g += d / sg - in_ / (sg * sg) * uu * vv;
         }
     }
     grad_arena[L[SN_GRAD_OFF] + e] = g * out_scale;           // (1 / loss scale of the fp16 build; ws_backward is linear in it)
@@ -473,8 +477,10 @@ extern "C" int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, co
 extern "C" int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
                                  const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
                                  const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,
-                                 float* inner, int32_t max_calls, float* grad_arena, float out_scale, void* stream) {
+                                 float* inner, int32_t max_calls, float* grad_arena, float out_scale,
+                                 const float* dots, const int32_t* dot_layers, void* stream) {
     TCVOM_CHECK_ARG(table && s && work_apply && ncalls && dw_arena && inner && grad_arena, "sn_backward: null pointer");
+    TCVOM_CHECK_ARG((dots == nullptr) == (dot_layers == nullptr), "sn_backward: dots and dot_layers come together");
     hipStream_t st = (hipStream_t)stream;
     SnScratch sc = mk_scratch(s);
     if (hipMemsetAsync(inner, 0, sizeof(float) * (size_t)max_calls * sc.L, st) != hipSuccess)
@@ -483,7 +489,7 @@ extern "C" int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s
         hipLaunchKernelGGL(sn_bwd_inner_kernel, dim3(n_inner), dim3(256), 0, st, table, work_inner, dw_arena,
                            dw_call_stride, inner, sc.L);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(n_apply), dim3(256), 0, st, table, work_apply, dw_arena, dw_call_stride,
-                       inner, sc, ncalls, grad_arena, out_scale);
+                       inner, sc, ncalls, grad_arena, out_scale, dots, dot_layers);
     TCVOM_LAUNCH_CHECK("sn_backward");
     return TCVOM_OK;
 }

@@ -30,6 +30,7 @@ H16 = L.ACT_DTYPE            # torch.bfloat16 or torch.float16: the 16-bit stora
 # ops called directly (tests, tools) are not scaled.  bf16 (8 exponent bits) needs none.
 import os as _os
 LOSS_SCALE = float(_os.environ.get('TCVOM_LOSS_SCALE', '65536' if L.DTYPE_NAME == 'fp16' else '1'))
+SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
 
 class _ScaleGrad(torch.autograd.Function):
@@ -100,6 +101,9 @@ class ConvCfg(object):
         assert pre_slope in (0.0, 0.01)
         self.act, self.pre_relu, self.unbias_mult, self.pre_slope = act, pre_relu, unbias_mult, pre_slope
         self.group_norm = isinstance(bn, torch.nn.GroupNorm)
+        # SpectralNorm's <dW~, weight_bar> comes out of the BatchNorm backward of this site (tcvom_sn_dot) instead of a pass over
+        # the weight gradient: bias-free conv straight into a BatchNorm
+        bank.set_sn_dot(spec, SN_DOT and bn is not None and not self.group_norm and spec.bias is None)
         # the output of this op is consumed by the decoder TAIL only (shortcut branches fea1..fea3 of the GCA encoder): in a
         # frame-batched window only the interior frames (bank.tail_frames) can receive a gradient, see _ConvBNAct.backward
         self.tail_only = False
@@ -112,6 +116,20 @@ class ConvCfg(object):
         if g is None:
             g = self._geo[key] = ConvGeometry(self.spec, N, H, W)
         return g
+
+
+def _sn_dot(cfg, call, training, sync):
+    """The tcvom_sn_dot of a BatchNorm-backward finalize (ctypes byref), or None: the slot of weight call `call` (frame f of a
+    batched op adds to call + f; a layer with one call per window -- eval mode, frozen backbone -- has one slot)."""
+    spec, bank = cfg.spec, cfg.bank
+    if not getattr(spec, 'sn_dot', False):
+        return None
+    n = bank.current_plan['ncalls'][spec.layer_id]
+    nl = len(bank.specs)
+    slot = call if n > 1 else 0
+    world = sync.world if sync is not None else 1
+    return C.byref(L.SnDot(bank.sn_dots.data_ptr() + 4 * (slot * nl + spec.layer_id), nl if n > 1 else 0, float(cfg.bn.eps),
+                           1 if training else 0, 1.0 / world))
 
 
 SYNC_ALLREDUCES = [0]          # diagnostic: SyncBatchNorm all-reduce calls issued by the fallback transport
@@ -309,11 +327,19 @@ class _ConvBNAct(torch.autograd.Function):
                 else:
                     extra.append(_c(t))
             del ctx.stash[:]
+        dz2_rng = None
         if ranged and (ctx.active is None or any((lo, hi) != (ctx.active[0] * geo.N, ctx.active[1] * geo.N) for _, _, lo, hi in ranged)):
-            for _, g, lo, hi in ranged:                    # (not the skipping path after all: the plain zero-padded gradient)
-                full = g.new_zeros((geo.N * nf,) + tuple(g.shape[1:]))
-                full[lo:hi] = g
-                extra.append(full)
+            # this op ran (and is differentiated) for all frames; a consumer deposited the gradient of some frames only
+            _, g0, lo0, hi0 = ranged[0]
+            if (RANGED_DZ2 and ctx.active is None and len(ranged) == 1 and cfg.bn is not None and not ctx.has_res2 and len(extra) + (dz is not None) == 1
+                    and lo0 % geo.N == 0 and hi0 % geo.N == 0 and g0.dtype == H16):
+                # the BatchNorm-backward kernels add it for those frames (dz2 with a frame range): no zero-padded copy
+                dz2_rng = (_c(g0), lo0 // geo.N, hi0 // geo.N)
+            else:
+                for _, g, lo, hi in ranged:                # the plain zero-padded gradient
+                    full = g.new_zeros((geo.N * nf,) + tuple(g.shape[1:]))
+                    full[lo:hi] = g
+                    extra.append(full)
             ranged = []
         if dz is None:
             if not extra and not ranged:
@@ -349,7 +375,12 @@ class _ConvBNAct(torch.autograd.Function):
             groups = L.call('tcvom_bn_bwd_groups', P, K)
             partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
             yf = 1 if y.dtype == torch.float32 else 0
-            L.call('tcvom_bn_bwd_reduce', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, st)
+            zf0, zf1 = 0, nf
+            if dz2_rng is not None:
+                assert dz2 is None
+                dz2, zf0, zf1 = dz2_rng
+            L.call('tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), P, K, cfg.act, yf,
+                   nf, stride, zf0, zf1, st)
             # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
             dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
             coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
@@ -360,10 +391,10 @@ class _ConvBNAct(torch.autograd.Function):
                        L.ptr(coef), L.ptr(scratch), nf, stride, st)
             elif sync is None:
                 L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
-                       L.ptr(coef), L.ptr(scratch), 1, nf, stride, st)
+                       L.ptr(coef), L.ptr(scratch), 1, nf, stride, _sn_dot(cfg, ctx.call, ctx.training, None), st)
             elif sync.mailbox is not None and sync.mailbox.fits(nf, K):
                 L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, K, P * sync.world, L.ptr(gamma), saved, dgp, dbp,
-                       L.ptr(coef), L.ptr(scratch), 1, nf, stride, sync.mailbox.next(), st)
+                       L.ptr(coef), L.ptr(scratch), 1, nf, stride, sync.mailbox.next(), _sn_dot(cfg, ctx.call, ctx.training, sync), st)
             else:
                 group, world = sync.group, sync.world
                 local = torch.empty(nf * 2 * K, dtype=torch.float64, device=dz.device)
@@ -372,12 +403,13 @@ class _ConvBNAct(torch.autograd.Function):
                 SYNC_ALLREDUCES[0] += 1
                 dist.all_reduce(total, group=group)
                 L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
-                       dgp, dbp, L.ptr(coef), 1, nf, stride, st)
+                       dgp, dbp, L.ptr(coef), 1, nf, stride, _sn_dot(cfg, ctx.call, ctx.training, sync), st)
             dy = torch.empty(y.shape, dtype=H16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
-            L.call('tcvom_bn_bwd_apply', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
-                   L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
+            L.call('tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
+                   L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
+                   zf0, zf1, st)
             if ctx.has_bias:
                 # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
                 # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
@@ -449,11 +481,11 @@ def _backward_active(ctx, dz, dz2, ranged=()):
                L.ptr(coef), L.ptr(scratch), nfa, stride, st)
     elif sync is None:
         L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
-               L.ptr(coef), L.ptr(scratch), 1, nfa, stride, st)
+               L.ptr(coef), L.ptr(scratch), 1, nfa, stride, _sn_dot(cfg, ctx.call + f0, ctx.training, None), st)
     elif sync.mailbox is not None and sync.mailbox.fits(nfa, K):
         # (every rank skips the same frames: the exchange carries the sums of the active frames only)
         L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, K, P * sync.world, L.ptr(gamma), saved, dgp, dbp,
-               L.ptr(coef), L.ptr(scratch), 1, nfa, stride, sync.mailbox.next(), st)
+               L.ptr(coef), L.ptr(scratch), 1, nfa, stride, sync.mailbox.next(), _sn_dot(cfg, ctx.call + f0, ctx.training, sync), st)
     else:
         local = torch.empty(nfa * 2 * K, dtype=torch.float64, device=dev)
         L.call('tcvom_bn_reduce_sums', L.ptr(partial), groups, K, L.ptr(local), L.ptr(scratch), nfa, st)
@@ -461,15 +493,16 @@ def _backward_active(ctx, dz, dz2, ranged=()):
         SYNC_ALLREDUCES[0] += 1
         dist.all_reduce(total, group=sync.group)
         L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * sync.world, L.ptr(gamma), saved,
-               dgp, dbp, L.ptr(coef), 1, nfa, stride, st)
+               dgp, dbp, L.ptr(coef), 1, nfa, stride, _sn_dot(cfg, ctx.call + f0, ctx.training, sync), st)
     dya = torch.empty(ya.shape, dtype=H16, device=dev)
     L.call('tcvom_bn_bwd_apply', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(coef), L.ptr(dya),
            None, P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nfa, stride, st)
     dx = None
     if spec.needs_dgrad and ctx.needs_input_grad[0]:
         cx = spec.cpad if spec.cpad > 8 else spec.C
-        if ctx.x_tail_rows == (f0 * N, f1 * N) and ctx.x_stash is not None and cx == x.shape[3]:
-            # the producer of x skips the same frames: hand it the gradient of the active rows only (no full-size tensor)
+        if ctx.x_stash is not None and cx == x.shape[3] and (RANGED_DZ2 or ctx.x_tail_rows == (f0 * N, f1 * N)):
+            # hand the producer of x the gradient of the active rows only (no full-size tensor): it either skips the same frames
+            # or adds the rows inside its BatchNorm-backward kernels (dz2 with a frame range)
             dxa = torch.empty((N * nfa, geo.H, geo.W, cx), dtype=H16, device=dev)
             _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), dxa, None, None, ACT_NONE, st, nfa, ctx.wsb)
             ctx.x_stash.append(('rows', dxa, f0 * N, f1 * N))
@@ -570,10 +603,10 @@ class _DwBNAct(torch.autograd.Function):
         scratch = torch.empty(nf * 128 * Cc, dtype=torch.float64, device=dz.device) if groups > 256 else None
         if ctx.sync is None or not ctx.training:
             L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, Cc, P, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef), L.ptr(scratch),
-                   1, nf, stride, st)
+                   1, nf, stride, None, st)
         elif ctx.sync.mailbox is not None and ctx.sync.mailbox.fits(nf, Cc):
             L.call('tcvom_bn_bwd_finalize_sync', L.ptr(partial), groups, Cc, P * ctx.sync.world, L.ptr(gamma), saved, dgp, dbp,
-                   L.ptr(coef), L.ptr(scratch), 1, nf, stride, ctx.sync.mailbox.next(), st)
+                   L.ptr(coef), L.ptr(scratch), 1, nf, stride, ctx.sync.mailbox.next(), None, st)
         else:
             group, world = ctx.sync.group, ctx.sync.world
             local = torch.empty(nf * 2 * Cc, dtype=torch.float64, device=dz.device)
@@ -582,7 +615,7 @@ class _DwBNAct(torch.autograd.Function):
             SYNC_ALLREDUCES[0] += 1
             dist.all_reduce(total, group=group)
             L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), Cc, P * world, L.ptr(gamma), saved, dgp, dbp, L.ptr(coef),
-                   1, nf, stride, st)
+                   1, nf, stride, None, st)
         dy = torch.empty(y.shape, dtype=H16, device=dz.device)
         L.call('tcvom_bn_bwd_apply', L.ptr(dz), None, L.ptr(y), None, ss, saved, L.ptr(coef), L.ptr(dy), None, P, Cc, cfg.act,
                1 if ctx.training else 0, 0, 0, nf, stride, st)
@@ -690,9 +723,10 @@ index_up = _IndexUp.apply
 
 class _FrameSlice(torch.autograd.Function):
     """Rows [lo, hi) of a frame-major batch (the interior frames on their way to the decoder tail).  When the producer is a
-    tail-only op that skips the other frames in its backward (`_tcvom_tail_rows` on the tensor), the gradient of the slice is
-    DEPOSITED with the producer as a row-range gradient instead of being padded to full size: no zero fill of the end frames, no
-    copy (at 1080p the os1 branch alone: 400 MB of fill + 134 MB of copy per step)."""
+    conv + BatchNorm op (`_tcvom_grad_stash` on the tensor) the gradient of the slice is DEPOSITED with it as a row-range
+    gradient instead of being padded to full size: no zero fill of the end frames, no copy (at 1080p the os1 branch alone:
+    400 MB of fill + 134 MB of copy per step).  A tail-only producer skips the other frames in its backward altogether; any
+    other one adds the rows inside its BatchNorm-backward kernels."""
 
     @staticmethod
     def forward(ctx, t, lo, hi, stash):
@@ -713,14 +747,53 @@ class _FrameSlice(torch.autograd.Function):
         return full, None, None, None
 
 
+RANGED_DZ2 = _os.environ.get('TCVOM_NO_RANGED') is None          # A/B switch: row-range gradients added inside the BatchNorm backward
+
+
+class _NeighbourSlices(torch.autograd.Function):
+    """(centre, previous, next) frames of a frame-major batch for the decoder tail (VMN_model.py:107-110: frame i is decoded
+    against frames i - 1 and i + 1): rows [B, (S-1)B), [0, (S-2)B), [2B, SB).  As three plain slices autograd zero-pads each
+    gradient to full size and adds them (3 fills + 3 copies + 2 adds of the os8 feature map per step); here the backward writes
+    the full gradient once -- for S = 3 the three gradients are simply its three frames."""
+
+    @staticmethod
+    def forward(ctx, t, B, S):
+        ctx.B, ctx.S = B, S
+        ctx.set_materialize_grads(False)
+        return t[B:(S - 1) * B], t[0:(S - 2) * B], t[2 * B:S * B]
+
+    @staticmethod
+    def backward(ctx, gc, gp, gn):
+        B, S = ctx.B, ctx.S
+        ref = next((g for g in (gc, gp, gn) if g is not None), None)
+        if ref is None:
+            return None, None, None
+        if S == 3 and gc is not None and gp is not None and gn is not None:
+            return torch.cat([gp, gc, gn], 0), None, None
+        full = ref.new_zeros((S * B,) + tuple(ref.shape[1:]))
+        for g, lo in ((gc, B), (gp, 0), (gn, 2 * B)):
+            if g is not None:
+                full[lo:lo + (S - 2) * B] += g
+        return full, None, None
+
+
+def neighbour_slices(t, B, S):
+    if not RANGED_DZ2:
+        return t[B:(S - 1) * B], t[0:(S - 2) * B], t[2 * B:S * B]
+    return _NeighbourSlices.apply(t, B, S)
+
+
 def frame_slice(t, lo, hi):
     """t[lo:hi] along the frame-major batch dimension, see _FrameSlice."""
     if not torch.is_tensor(t):
         return t
     rows = getattr(t, '_tcvom_tail_rows', None)
-    if not t.requires_grad or rows != (lo, hi):
+    stash = getattr(t, '_tcvom_grad_stash', None)
+    # a tail-only producer takes exactly its own rows; any other conv + BatchNorm op adds a row-range gradient inside its
+    # BatchNorm-backward kernels (dz2 with a frame range)
+    if not t.requires_grad or (rows != (lo, hi) if rows is not None else (stash is None or not RANGED_DZ2)):
         return t[lo:hi]
-    return _FrameSlice.apply(t, lo, hi, getattr(t, '_tcvom_grad_stash', None))
+    return _FrameSlice.apply(t, lo, hi, stash)
 
 
 def conv_bn_act(cfg, x, token, training, res1=None, res2=None):

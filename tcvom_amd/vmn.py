@@ -191,7 +191,8 @@ class VMN(nn.Module):
             mid_c = {k: (tuple(fs(t, lo, hi) for t in v) if isinstance(v, (tuple, list)) else fs(v, lo, hi)) for k, v in mid.items()
                      if k != 'unknown'}
             mid_c['unknown'] = U[lo:hi]
-            pred, ab, af = self.decoder.run_tail(feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B], U[lo:hi], mid_c, token, training)
+            f_c, f_p, f_n = ops.neighbour_slices(feat, B, S) if feat.requires_grad else (feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B])
+            pred, ab, af = self.decoder.run_tail(f_c, f_p, f_n, U[lo:hi], mid_c, token, training)
         finally:
             bank.frames_per_op = 1
             bank.tail_frames = None

@@ -213,8 +213,17 @@ class WeightBank(object):
     # ------------------------------------------------------------------ registration
     def register(self, spec):
         spec.layer_id = len(self.specs)
+        spec.sn_dot = None
         self.specs.append(spec)
         return spec.layer_id
+
+    def set_sn_dot(self, spec, ok):
+        """A conv site declares whether the BatchNorm backward behind this conv delivers SpectralNorm's <dW~, weight_bar> (ops._sn_dot,
+        tcvom_sn_dot); it does when EVERY site of the layer says so -- then the layer has no rows in the sn_bwd_inner work list."""
+        new = bool(ok) and spec.spectral if spec.sn_dot is None else (spec.sn_dot and bool(ok))
+        if new != spec.sn_dot:
+            spec.sn_dot = new
+            self._plans = {}
 
     def weight_params(self):
         return [s.weight for s in self.specs]
@@ -301,7 +310,9 @@ class WeightBank(object):
         self.max_calls = ncalls
         self.fwd_arena = torch.zeros(ncalls * self.fwd_stride, dtype=H16, device=dev)
         self.bwd_arena = torch.zeros(max(1, ncalls * self.bwd_stride), dtype=H16, device=dev)
-        self.dw_arena = torch.zeros(ncalls * self.dw_stride, dtype=torch.float32, device=dev)
+        # (+ the <dy, y> slots [call][layer] of tcvom_sn_dot at the end: zeroed with the arena at the start of every window)
+        self.dw_arena = torch.zeros(ncalls * self.dw_stride + ncalls * nl, dtype=torch.float32, device=dev)
+        self.sn_dots = self.dw_arena[ncalls * self.dw_stride:]
         self.sigma = torch.ones(ncalls * nl, device=dev)
         self.uhist = torch.zeros(ncalls * self.sum_h, device=dev)
         self.vhist = torch.zeros(ncalls * self.sum_wd, device=dev)
@@ -320,14 +331,16 @@ class WeightBank(object):
                 calls[s.layer_id] = 1           # eval mode (also a frozen backbone in a training window): no iteration, one copy
             else:
                 calls[s.layer_id] = frames if s.group == 'frame' else max(frames - 2, 1)
-        inner = [(s.layer_id, c, b) for s in self.specs if s.spectral
+        inner = [(s.layer_id, c, b) for s in self.specs if s.spectral and not s.sn_dot
                  for c in range(calls[s.layer_id]) for b in range((s.numel + 8191) // 8192)]      # SN_INNER_BLOCK of csrc/spectral.hip
         dev = self.device
+        dots = [1 if (s.spectral and s.sn_dot) else 0 for s in self.specs]
         plan = {
             'ncalls': calls,
             'ncalls_dev': torch.tensor([calls[i] for i in range(len(self.specs))], dtype=torch.int32, device=dev),
             'work_inner': torch.tensor(inner, dtype=torch.int32).reshape(-1).to(dev),
             'n_inner': len(inner),
+            'dot_layers': torch.tensor(dots, dtype=torch.int32, device=dev) if any(dots) else None,
             'iters': max(calls.values()),
         }
         self._plans[key] = plan
@@ -552,7 +565,7 @@ class WeightBank(object):
                 bounds.append(i + 1)
         bounds.append(len(specs))
         calls = plan['ncalls']
-        inner_rows = lambda sp: calls[sp.layer_id] * ((sp.numel + 8191) // 8192) if sp.spectral else 0
+        inner_rows = lambda sp: calls[sp.layer_id] * ((sp.numel + 8191) // 8192) if (sp.spectral and not sp.sn_dot) else 0
         apply_rows = lambda sp: (sp.numel + 255) // 256
         ck, i0, a0 = [], 0, 0
         for lo, hi in zip(bounds[:-1], bounds[1:]):
@@ -582,7 +595,8 @@ class WeightBank(object):
             wi = C.c_void_p(plan['work_inner'].data_ptr() + 12 * i0) if ni else None
             wa = C.c_void_p(self.work_apply.data_ptr() + 8 * a0)
             L.call('tcvom_sn_backward', L.ptr(self.table), C.byref(self.scratch), wi, ni, wa, na, L.ptr(plan['ncalls_dev']),
-                   L.ptr(self.dw_arena), self.dw_stride, L.ptr(self.inner), self.max_calls, L.ptr(grad), inv, st)
+                   L.ptr(self.dw_arena), self.dw_stride, L.ptr(self.inner), self.max_calls, L.ptr(grad), inv,
+                   L.ptr(self.sn_dots) if plan['dot_layers'] is not None else None, L.ptr(plan['dot_layers']), st)
             if self.n_ws:
                 rows = [(i, r) for i, r in self._ws_rows if lo <= i < hi]
                 if rows:

@@ -331,6 +331,47 @@ def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, trans
     assert not torch.allclose(a[0][0], a[0][1])
 
 
+def test_row_range_gradient_is_added_inside_the_batchnorm_backward():
+    """A frame-batched conv + BatchNorm op whose output is read by one consumer for all three frames and by another for the
+    centre frame only (ops.frame_slice: the decoder tail's shortcut inputs, VMN_model.py:107-110): the centre-frame gradient is
+    deposited with the producer and added inside tcvom_bn_bwd_reduce_ranged / tcvom_bn_bwd_apply_ranged.  Must equal the plain
+    slice, whose gradient autograd pads with zeros and adds."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    S, B, cin, cout, H, W = 3, 2, 64, 64, 20, 28
+
+    def run(deposit):
+        w = nn.Parameter(formula_tensor('conv.rr.weight', (cout, cin, 3, 3)).to(DEV))
+        bank = WeightBank()
+        spec = ConvSpec('rr', w, None, None, None, False, 1, 1, 'frame')
+        bank.register(spec)
+        bn = nn.BatchNorm2d(cout).to(DEV)
+        cfg = ops.ConvCfg(bank, spec, bn=bn, act=1)
+        xg = torch.cat([nhwc(hu('x%d.rr' % f, (B, cin, H, W))) for f in range(S)], 0).requires_grad_(True)
+        token = bank_token(bank, S, True)
+        bank.frames_per_op = S
+        z = ops.conv_bn_act(cfg, xg, token, True)
+        bank.frames_per_op = 1
+        assert getattr(z, '_tcvom_grad_stash', None) is not None
+        zc = ops.frame_slice(z, B, 2 * B) if deposit else z[B:2 * B]
+        assert (zc.grad_fn.__class__.__name__ == '_FrameSliceBackward') == deposit
+        g_all = nhwc(hu('g_all.rr', (S * B, cout, H, W)))
+        g_c = nhwc(hu('g_c.rr', (B, cout, H, W)))
+        ((z.float() * g_all.float()).sum() + 3.0 * (zc.float() * g_c.float()).sum()).backward()
+        bank.flush_bn_counters()
+        torch.cuda.synchronize()
+        return xg.grad.float().cpu(), w.grad.cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu()
+
+    a, b = run(True), run(False)
+    ck = Checker()
+    for f in range(S):
+        ck.rel('dx[%d]' % f, a[0][f * B:(f + 1) * B], b[0][f * B:(f + 1) * B], 1e-2)
+    ck.rel('dw', a[1], b[1], 1e-2)
+    ck.rel('dgamma', a[2], b[2], 1e-2)
+    ck.rel('dbeta', a[3], b[3], 1e-2)
+    ck.done()
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [(128, 128, 3, 1, False, 40, 64), (64, 64, 4, 2, True, 20, 24),
                                                                (32, 64, 3, 2, False, 48, 64), (32, 32, 3, 1, False, 48, 64)])
 def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
@@ -760,6 +801,53 @@ def test_dense_gemm_pair_one_launch(rows_a, rows_b, kred):
     r2 = torch.bmm(X2[:, :rows_b].float(), W_.float().transpose(1, 2))
     assert rel_err(o1.cpu(), r1.cpu()) < 1e-5
     assert rel_err(o2.cpu(), r2.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_spectral_norm_inner_product_from_the_batchnorm_backward(training, monkeypatch):
+    """<dW~, weight_bar> of a SpectralNorm'd conv in front of a BatchNorm (models/GCA/ops.py:25-45 under autograd) equals
+    sigma <dy, y>, which the BatchNorm-backward finalize derives from its two per-channel sums (tcvom_sn_dot) -- against the pass
+    over the weight gradient (sn_bwd_inner_kernel, itself checked against the oracle in test_spectral_norm_bank): the scalar per
+    (call, layer) and the weight_bar gradient.  eps = 0.5 in training mode makes the term large (it is proportional to eps:
+    batch-statistics BatchNorm is scale-invariant up to eps); eval mode uses running statistics, where it is not small at all."""
+    from tcvom_amd import ops
+    from tcvom_amd.weights import bank_token
+    S, B, cin, cout, H, W = 3, 1, 32, 64, 20, 28
+
+    def run(dot):
+        monkeypatch.setattr(ops, 'SN_DOT', dot)
+        bank, spec = _mini_bank(cin, cout, 3, 1, 1, False, spectral=True, tag='snd')
+        bn = nn.BatchNorm2d(cout, eps=0.5 if training else 1e-5).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(formula_tensor('bn.weight', (cout,)))
+            bn.bias.copy_(formula_tensor('bn.bias', (cout,)))
+            bn.running_mean.copy_(0.1 * formula_tensor('bn.rm', (cout,)))
+            bn.running_var.copy_(0.5 + formula_tensor('bn.rv', (cout,)).abs())
+        cfg = ops.ConvCfg(bank, spec, bn=bn, act=1)
+        assert bool(spec.sn_dot) == dot
+        xg = torch.cat([nhwc(hu('x%d.snd' % f, (B, cin, H, W)) * (1.0 + 0.5 * f)) for f in range(S)], 0).requires_grad_(True)
+        token = bank_token(bank, S, training)
+        bank.frames_per_op = S
+        z = ops.conv_bn_act(cfg, xg, token, training)
+        bank.frames_per_op = 1
+        g = nhwc(hu('g.snd', (S * B, cout, H, W)) - 0.3)
+        (z.float() * g.float()).sum().backward()
+        bank.flush_bn_counters()
+        torch.cuda.synchronize()
+        nl, calls = len(bank.specs), (S if training else 1)
+        sig = bank.sigma.view(-1, nl)[:calls, spec.layer_id].cpu()
+        inner = (sig * bank.sn_dots.view(-1, nl)[:calls, spec.layer_id].cpu()) if dot else bank.inner.view(-1, nl)[:calls, spec.layer_id].cpu()
+        return spec.weight.grad.cpu(), inner, xg.grad.float().cpu()
+
+    a, b = run(True), run(False)
+    assert float(b[1].abs().min()) > 0
+    # (the pass over dW~ sums products of 16-bit-rounded dy; the BatchNorm sums are taken before that rounding)
+    assert rel_err(a[1], b[1]) < 2e-2, (a[1], b[1])
+    assert rel_err(a[0], b[0]) < 1e-3
+    assert rel_err(a[2], b[2]) < 5e-3                        # (the power iteration's atomics: sigma may differ by an ulp between runs)
+    # the term matters in this test: without it the gradient would be visibly different
+    nsig = float((b[1].abs() / 1.0).max())
+    assert nsig > 1e-3 * float(b[0].abs().max())
 
 
 @pytest.mark.parametrize('transposed', [False, True])

@@ -1,5 +1,6 @@
 """Host-side logic of the frame-batched window that needs no GPU: frame stacking without a copy, the row-range gradient
 deposit of `ops.frame_slice`, and the fused loss sum of train_ddp.py:56-61."""
+import pytest
 import torch
 
 
@@ -36,10 +37,37 @@ def test_frame_slice_deposits_a_row_range_gradient_or_pads_with_zeros():
     want = torch.zeros(6, 3)
     want[2:4] = 1.0
     assert torch.equal(t2.grad, want)
-    # a different row range than the producer skips: not deposited
+    # a different row range than a tail-only producer skips: not deposited
     y3 = (t2 * 1.0)
     y3._tcvom_grad_stash, y3._tcvom_tail_rows = [], (2, 4)
     assert ops.frame_slice(y3, 0, 2).grad_fn.__class__.__name__ != '_FrameSliceBackward'
+    # a conv + BatchNorm producer that runs for all frames (a stash, no tail rows): deposited, any frame range
+    y4 = (t2 * 1.0)
+    y4._tcvom_grad_stash = []
+    ops.frame_slice(y4, 0, 2).sum().backward()
+    assert len(y4._tcvom_grad_stash) == 1 and y4._tcvom_grad_stash[0][2:] == (0, 2)
+
+
+@pytest.mark.parametrize('S', [3, 5])
+def test_neighbour_slices_gradient_equals_three_plain_slices(S):
+    from tcvom_amd import ops
+    B = 2
+    t = torch.randn(S * B, 4, requires_grad=True)
+    w = [torch.randn((S - 2) * B, 4) for _ in range(3)]
+    c, p, n = ops.neighbour_slices(t * 1.0, B, S)
+    assert torch.equal(c, t[B:(S - 1) * B]) and torch.equal(p, t[:(S - 2) * B]) and torch.equal(n, t[2 * B:])
+    ((c * w[0]).sum() + (p * w[1]).sum() + (n * w[2]).sum()).backward()
+    got = t.grad.clone()
+    t.grad = None
+    ((t[B:(S - 1) * B] * w[0]).sum() + (t[:(S - 2) * B] * w[1]).sum() + (t[2 * B:] * w[2]).sum()).backward()
+    assert torch.allclose(got, t.grad, atol=1e-6)
+    # one of the three unused: still the zero-padded sum of the others
+    t.grad = None
+    c, p, n = ops.neighbour_slices(t * 1.0, B, S)
+    (c * w[0]).sum().backward()
+    want = torch.zeros_like(t)
+    want[B:(S - 1) * B] = w[0]
+    assert torch.allclose(t.grad, want)
 
 
 def test_train_step_loss_matches_the_reference_formula():
