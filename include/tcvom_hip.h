@@ -312,6 +312,15 @@ int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
                       const int32_t* dot_layers /* [layers]: != 0 -> <dW~, W_bar> = sigma * dots (no work_inner rows for that layer) */,
                       void* stream);
 
+/* GuidedCxtAtten backward (models/GCA/ops.py:177-204 under autograd), the products that contract the ROW index of the N x N
+ * matrices P (probabilities) and T (score gradient), which are read as they lie in memory -- k-major operand through the
+ * transposing LDS read -- instead of transposed copies:
+ *   tcvom_gca_dv:    dV[b][j][v]  = sum_{i < N} P[b][i][j] dOt[b][v][i]          P: [batch][N][ld], dOt: [batch][DV][ld] (finite beyond N)
+ *   tcvom_gca_dq_dk: dWq[b][i][d] = sum_j T[b][i][j] Gt[b][d][j],  Mp[b][j][d] = sum_i T[b][i][j] Gt[b][d][i]    T: [batch][N][ld]
+ * fp32 outputs [batch][N][DV] / [batch][N][D]; ld % 256 == 0, zeros in the padding columns N <= j < ld of P / T. */
+int tcvom_gca_dv(const void* P, const void* dOt, float* dV, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream);
+int tcvom_gca_dq_dk(const void* T, const void* Gt, float* dWq, float* Mp, int32_t N, int32_t D, int64_t ld, int32_t batch, void* stream);
+
 /* ------------------------------------------------------------------ layout / resampling helpers (NHWC bf16) */
 int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int tcvom_upsample2(const void* y, void* x, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream);
@@ -360,6 +369,10 @@ int tcvom_row_softmax_bwd(const void* P, const float* dP, const float* cvec /*[r
 int tcvom_gca_scores_softmax_ok(int32_t N, int32_t D, int64_t ld, int32_t batch);
 int tcvom_gca_scores_softmax(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
                              int64_t ld, int32_t batch, void* stream);
+/* the two passes of tcvom_gca_scores_softmax as separate calls (the same kernels) */
+int tcvom_gca_scores_exp(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
+                         int64_t ld, int32_t batch, void* stream);
+int tcvom_gca_softmax_rescale(void* P, const float* stats, int32_t N, int64_t ld, int32_t batch, void* stream);
 /* The same backward without the N x N fp32 dP matrix: one MFMA GEMM whose epilogue applies the softmax backward,
  *   T[b][i][j] = P[b][i][j] * (sum_v dO[b][i][v] V[b][j][v] - delta[b][i]) * cvec[b][j]   (bf16 [batch][N][ld], zero for j >= N),
  * with delta[b][i] = sum_j P dP = <dO[b][i], O[b][i]> from tcvom_rowdot_bf16 (O = the forward's P V, kept in fp32: for a

@@ -53,6 +53,11 @@ struct Gemm256Args {
     // first), one per 1/split_s of the reduction, and added into the zeroed output with fp32 atomics.  576 tiles (the paired
     // dq / dk product at 1080p) are 2.25 rounds of 256 workgroups: 512 whole tiles + 64 x 4 quarter-length ones instead of 3 rounds.
     int flat_nx, flat_ny, split_r, split_s;
+    // k-major B operand (template BT = 1): B[k][n] with `ldb` elements per k row and `krows` valid rows (zeros
+    // beyond) instead of B[n][k] -- the N x N matrices P and T of GuidedCxtAtten's backward are read as they lie in memory by the
+    // products that contract their ROW index (dV = P^T dO, M' = T^T G): no transposed copies P^T / T^T (2 x 400 MB written by
+    // the softmax-backward epilogue and read back per 3-frame launch at 1080p)
+    int ldb, krows;
 };
 
 #ifndef G256_STAGED_EPI
@@ -75,7 +80,7 @@ extern "C" int tcvom_trace256_read(unsigned long long* host) {
 
 // EPI: 0 = fp32 output, 1 = bf16 output, 2 = fused softmax backward, 3 = softmax numerators + per-tile row statistics (one
 // instantiation each: a single kernel with all epilogues spilled registers in the main loop)
-template <int EPI, int MF>
+template <int EPI, int MF, int BT = 0>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     // MF = 32-row A fragments per wave: 4 -> 256 x 256 tiles; 3 -> 192 (A rows) x 256 tiles for M = 576 (the d(query) / d(key)
     // GEMMs of GuidedCxtAtten: 3 x 192 instead of 3 x 256 with a quarter of the MFMAs multiplying padding).  The quadrant
@@ -110,12 +115,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     }
     const bool second = bzz >= g.batch;
     const int bz = second ? bzz - g.batch : bzz;
+    constexpr bool bt = BT == 1;                          // the B operand is k-major
     const h16raw* A = g.A + bz * g.a_bstride;
     const h16raw* B = second ? g.B2 + bz * g.b2_bstride : g.B + bz * g.b_bstride;
     int ntile = g.K >> 6;
+    int krows = g.krows;
     if (kpart >= 0) {                                  // this workgroup's share of the reduction
         const int t0 = ntile * kpart / g.split_s, t1 = ntile * (kpart + 1) / g.split_s;
-        A += t0 * 64; B += t0 * 64;
+        A += t0 * 64;
+        if (BT != 0 && bt) { B += (int64_t)t0 * 64 * g.ldb; krows -= t0 * 64; } else B += t0 * 64;
         ntile = t1 - t0;
     }
     void* const gout = second ? g.out2 : g.out;
@@ -136,6 +144,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         const int ra = m0 + (a_piece + it * 4) * 8 + (lane >> 3), rb = n0 + (it * 8 + wave) * 8 + (lane >> 3);
         a_off[it] = (it < A_IT && ra < g.M) ? (int64_t)ra * K + kc8 : -1;
         b_off[it] = rb < g.N ? (int64_t)rb * K + kc8 : -1;
+        if (BT != 0 && bt) {
+            // k-major B tile [64 k][256 n] in LDS, 512-byte rows: piece (it, wave) = k rows (it*8 + wave)*2 + (lane >> 5); the lane
+            // at chunk position lane & 31 of its row fetches the 16-byte chunk (8 n) c = position ^ 4 (row & 3) (see G_READ_B)
+            const int kr = (it * 8 + wave) * 2 + (lane >> 5), col = n0 + (((lane & 31) ^ ((kr & 3) << 2)) << 3);
+            b_off[it] = col + 8 <= g.ldb ? (int64_t)kr * g.ldb + col : -1;
+        }
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -147,6 +161,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #define G_ISSUE_B(t, it)                                                                                     \
     {                                                                                                        \
         const h16raw* src_ = b_off[it] >= 0 ? B + b_off[it] + (t) * 64 : g.zero_page;                       \
+        if (BT != 0 && bt)                                                                                   \
+            src_ = (b_off[it] >= 0 && (t) * 64 + ((it) * 8 + wave) * 2 + (lane >> 5) < krows) ? B + b_off[it] + (int64_t)(t) * 64 * g.ldb : g.zero_page; \
         __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + TM * 64 + ((it) * 8 + wave) * 512), 16, 0, 0); \
     }
 
@@ -167,9 +183,30 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     _Pragma("unroll") for (int a_ = 0; a_ < ((mh) * 2 + 1 < MF ? 2 : 1); ++a_)                               \
         _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                  \
             fa[a_][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
+    // k-major B: the MFMA fragment (lane: n = lane & 31, 8 consecutive k from 8 (lane >> 5)) comes out of the [k][n] tile through the
+    // transposing LDS read -- a 16-lane group addresses a 4 (k) x 16 (n) block, lane L the 4 n at row L >> 2 / column 4 (L & 3), and
+    // receives column L, rows 0..3 -- two reads (k rows +0..3, +4..7) per fragment.  Bank layout: the 4 rows of a group are 512 B
+    // apart, so chunk c of row k sits at position c ^ 4 (k & 3): the two groups of a half wave then cover 8 distinct 32-byte
+    // columns of the 256-byte bank line.
+    const unsigned tr_b0 = (unsigned)(uintptr_t)(lptr_t)(lds + TM * 64) + (((lane >> 5) << 3) + ((lane & 15) >> 2)) * 512 + (lane & 1) * 8;
+    const int tr_c0 = wn * 8 + ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1), tr_sw = ((lane & 15) >> 2) << 2;
+    const unsigned tr_addr[2] = {tr_b0 + (unsigned)(((tr_c0) ^ tr_sw) << 4), tr_b0 + (unsigned)(((tr_c0 + 4) ^ tr_sw) << 4)};
+    TrFrag ft[2][4];
 #define G_READ_B(buf, nh)                                                                                    \
-    _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                      \
-        fb[nh][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3));
+    if (BT != 0 && bt) {                                                                                     \
+        const unsigned ad_ = tr_addr[nh] + (buf) * (SLOT * 2);                                               \
+        tr_issue_imm<0, 2048>(ft[nh][0], ad_); tr_issue_imm<8192, 2048>(ft[nh][1], ad_);                     \
+        tr_issue_imm<16384, 2048>(ft[nh][2], ad_); tr_issue_imm<24576, 2048>(ft[nh][3], ad_);                \
+    } else {                                                                                                 \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                  \
+            fb[nh][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + TM * 64 + (b_row + (nh) * 32) * 64 + (((kk_ * 2 + khalf) ^ b_swz) << 3)); \
+    }
+    // after the s_waitcnt that retires the transposing reads (they are inline asm: invisible to the compiler's wait insertion)
+#define G_FIX_B()                                                                                            \
+    if (BT != 0 && bt) {                                                                                     \
+        _Pragma("unroll") for (int nh_ = 0; nh_ < 2; ++nh_)                                                  \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) { tr_fence(ft[nh_][kk_]); fb[nh_][kk_] = tr_value(ft[nh_][kk_]); } \
+    }
     // 8 MFMAs of one quadrant; `DMA` = 0/1/2: interleave the A / B DMA instructions of K-tile tn behind MFMA pairs
 #define G_MFMA(mh, nh, DMA, tn)                                                                              \
     {                                                                                                        \
@@ -222,6 +259,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         G_READ_A(buf, 0) G_READ_B(buf, 0) G_READ_B(buf, 1)
         G_BAR();
         G_WAIT_LDS();
+        G_FIX_B()
         G_MFMA(0, 0, 2, t + 1)
         G_MFMA(0, 1, 1, t + 1)
         G_BAR();
@@ -235,6 +273,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         G_BAR();
     }
 #else
+    static_assert(BT == 0, "the four-phase loop has no k-major B path");
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         // phase 1: quadrant (m0, n0)
@@ -276,6 +315,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #undef G_MFMA
 #undef G_READ_A
 #undef G_READ_B
+#undef G_FIX_B
 #undef G_ISSUE_A
 #undef G_ISSUE_B
 #undef G_BAR
@@ -597,6 +637,27 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     }
 }
 
+// K-split tail of a launch on 192-row tiles with fp32 output and a linear epilogue: when the tiles beyond the last whole round of
+// 256 workgroups are whole tile rows of the LAST output slice and would leave most of the chip idle for a full tile time, they go
+// out first as split_s workgroups each (fp32 atomics into the zeroed tail); rewrites `grid` to the flat form.  < 0: error.
+static int g256_split_tail(Gemm256Args& g, dim3& grid, bool eligible, void* last_out, int nb, void* stream) {
+    static const bool nosplit = getenv("TCVOM_NO_KSPLIT") != nullptr;              // A/B switch
+    g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
+    if (nosplit || !eligible || !g.out_fp32) return 0;
+    const int nx = (int)grid.x, ny = (int)grid.y, tiles = nx * ny * (int)grid.z, rem = tiles % 256;
+    const int ntile = g.K / 64;
+    if (!(tiles > 256 && rem > 0 && rem <= 128 && rem % nx == 0 && rem / nx <= ny)) return 0;
+    const int sp = 256 / rem < 8 ? 256 / rem : 8;                                  // 2 .. 8 parts, each >= 8 K-tiles
+    if (sp < 2 || ntile / sp < 8) return 0;
+    const int rows = rem / nx, mlo = (ny - rows) * 192;                            // the tail covers columns mlo .. M of the last slice
+    float* base = (float*)last_out + (long long)(nb - 1) * g.out_bstride + mlo;
+    if (hipMemset2DAsync(base, sizeof(float) * (size_t)g.ldo, 0, sizeof(float) * (size_t)(g.M - mlo), (size_t)g.N, (hipStream_t)stream) != hipSuccess)
+        return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: memset of the K-split tail failed");
+    g.flat_nx = nx; g.flat_ny = ny; g.split_r = rem; g.split_s = sp;
+    grid = dim3((unsigned)(tiles - rem + rem * sp), 1, 1);
+    return 0;
+}
+
 // does the dense descriptor `d` run on this kernel?  (plain row-major operands, enough 256x256 tiles to fill the chip)
 int gemm_nt256_takes(const tcvom_conv_desc* d) {
     if (d->ntaps != 1 || d->tap_w[0] < 0) return 0;
@@ -643,28 +704,14 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.B2 = (const h16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
     g.stats = nullptr;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
+    g.ldb = 0; g.krows = 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
     dim3 grid((unsigned)((P + 255) / 256), (unsigned)cdiv(d->K, m192 ? 192 : 256), (unsigned)(in2 ? 2 * nb : nb));
-    // K-split tail: the tiles beyond the last whole round of 256 workgroups, when they are whole tile rows of the last output
-    // slice and would leave most of the chip idle for a full tile time
-    static const bool nosplit = getenv("TCVOM_NO_KSPLIT") != nullptr;              // A/B switch
-    if (!nosplit && m192 && g.out_fp32 && !bias && !mdiag && d->act == 0) {
-        const int nx = (int)grid.x, ny = (int)grid.y, tiles = nx * ny * (int)grid.z, rem = tiles % 256;
-        const int ntile = d->C / 64;
-        if (tiles > 256 && rem > 0 && rem <= 128 && rem % nx == 0 && rem / nx <= ny) {
-            const int sp = 256 / rem < 8 ? 256 / rem : 8;                          // 2 .. 8 parts, each >= 8 K-tiles
-            if (sp >= 2 && ntile / sp >= 8) {
-                const int rows = rem / nx, mlo = (ny - rows) * 192;                // the tail covers columns mlo .. M of the last slice
-                float* base = (float*)(in2 ? out2 : out) + (long long)(nb - 1) * g.out_bstride + mlo;
-                if (hipMemset2DAsync(base, sizeof(float) * (size_t)g.ldo, 0, sizeof(float) * (size_t)(d->K - mlo), (size_t)P,
-                                     (hipStream_t)stream) != hipSuccess)
-                    return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: memset of the K-split tail failed");
-                g.flat_nx = nx; g.flat_ny = ny; g.split_r = rem; g.split_s = sp;
-                grid = dim3((unsigned)(tiles - rem + rem * sp), 1, 1);
-            }
-        }
+    {
+        const int rc = g256_split_tail(g, grid, m192 && !bias && !mdiag && d->act == 0, in2 ? out2 : out, nb, stream);
+        if (rc < 0) return rc;
     }
     if (m192) {
         if (g.out_fp32) hipLaunchKernelGGL((gemm_nt256_kernel<0, 3>), grid, dim3(512), 0, (hipStream_t)stream, g);
@@ -708,6 +755,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
+    g.ldb = 0; g.krows = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
@@ -752,12 +800,13 @@ __global__ __launch_bounds__(256) void softmax_rescale_kernel(uint4* __restrict_
 extern "C" int tcvom_gca_scores_softmax_ok(int32_t N, int32_t D, int64_t ld, int32_t batch) {
     return (N >= 256 && N % 8 == 0 && D % 64 == 0 && ld >= N && ld % 256 == 0 && ld / 256 <= 64 && batch >= 1) ? 1 : 0;
 }
-extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
-                                        int64_t ld, int32_t batch, void* stream) {
-    TCVOM_CHECK_ARG(G && cvec && P && stats, "gca_scores_softmax: null pointer");
-    TCVOM_CHECK_ARG(tcvom_gca_scores_softmax_ok(N, D, ld, batch), "gca_scores_softmax: N=%d D=%d ld=%lld (N %% 8, D %% 64, ld %% 256 == 0, ld <= 16384)",
+// pass 1 alone (then tcvom_gca_softmax_rescale): P = exp(S' - tile row max), stats[b][i][tile][2] = (tile row max, tile row sum)
+extern "C" int tcvom_gca_scores_exp(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
+                                    int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(G && cvec && P && stats, "gca_scores_exp: null pointer");
+    TCVOM_CHECK_ARG(tcvom_gca_scores_softmax_ok(N, D, ld, batch), "gca_scores_exp: N=%d D=%d ld=%lld (N %% 8, D %% 64, ld %% 256 == 0, ld <= 16384)",
                     N, D, (long long)ld);
-    TCVOM_CHECK_ARG(((uintptr_t)cvec % 16) == 0 && (!dvec || ((uintptr_t)dvec % 16) == 0) && ((uintptr_t)P % 16) == 0, "gca_scores_softmax: alignment");
+    TCVOM_CHECK_ARG(((uintptr_t)cvec % 16) == 0 && (!dvec || ((uintptr_t)dvec % 16) == 0) && ((uintptr_t)P % 16) == 0, "gca_scores_exp: alignment");
     Gemm256Args g;
     g.A = (const h16raw*)G;          // rows m = keys j
     g.B = (const h16raw*)G;          // columns n = queries i
@@ -766,7 +815,7 @@ extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const 
     g.mscale = cvec;
     g.mdiag = dvec;
     g.zero_page = tcvom_zero_page();
-    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_scores_softmax: could not allocate the zero page");
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_scores_exp: could not allocate the zero page");
     g.M = N; g.N = N; g.K = D; g.ldo = (int)ld; g.act = 0; g.out_fp32 = 0; g.batch = batch;
     g.a_bstride = (long long)N * D;
     g.b_bstride = (long long)N * D;
@@ -776,11 +825,91 @@ extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const 
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = stats;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
-    const int tmt = (int)(ld / 256);
-    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)tmt, (unsigned)batch);
+    g.ldb = 0; g.krows = 0;
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)(ld / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<3, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    TCVOM_LAUNCH_CHECK("gca_scores_exp");
+    return TCVOM_OK;
+}
+// pass 2: every row scaled by exp(tile max - row max) / row sum, in place; zeros in the padding columns N <= j < ld
+extern "C" int tcvom_gca_softmax_rescale(void* P, const float* stats, int32_t N, int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(P && stats && N > 0 && N % 8 == 0 && ld >= N && ld % 256 == 0 && ld / 256 <= 64 && batch >= 1 && ((uintptr_t)P % 16) == 0,
+                    "gca_softmax_rescale: N=%d ld=%lld", N, (long long)ld);
     hipLaunchKernelGGL(softmax_rescale_kernel, dim3((unsigned)((int64_t)batch * N)), dim3(256), 0, (hipStream_t)stream, (uint4*)P, stats, N,
-                       (int)(ld / 8), tmt);
-    TCVOM_LAUNCH_CHECK("gca_scores_softmax");
+                       (int)(ld / 8), (int)(ld / 256));
+    TCVOM_LAUNCH_CHECK("gca_softmax_rescale");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const float* dvec, void* P, float* stats, int32_t N, int32_t D,
+                                        int64_t ld, int32_t batch, void* stream) {
+    const int rc = tcvom_gca_scores_exp(G, cvec, dvec, P, stats, N, D, ld, batch, stream);
+    return rc != TCVOM_OK ? rc : tcvom_gca_softmax_rescale(P, stats, N, ld, batch, stream);
+}
+
+
+// ---- GuidedCxtAtten backward, the two products that contract the ROW index of an N x N matrix, reading it as it lies in memory
+// (k-major B operand through transposing LDS reads) instead of a transposed copy:
+//   dV[b][j][v] = sum_{i < N} P[b][i][j] dO[b][i][v]            (tcvom_gca_dv:    A = dOt [DV][ld], B = P [N][ld] k-major)
+//   dWq[b][i][d] = sum_j T[b][i][j] G[b][j][d],  M'[b][j][d] = sum_i T[b][i][j] G[b][i][d]
+//                                                               (tcvom_gca_dq_dk: A = Gt [D][ld]; one launch, T read both ways)
+extern "C" int tcvom_gca_dv(const void* P, const void* dOt, float* dV, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(P && dOt && dV, "gca_dv: null pointer");
+    TCVOM_CHECK_ARG(N >= 256 && DV >= 256 && DV % 4 == 0 && ld >= N && ld % 256 == 0 && batch >= 1, "gca_dv: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
+    TCVOM_CHECK_ARG(((uintptr_t)P % 16) == 0 && ((uintptr_t)dOt % 16) == 0 && ((uintptr_t)dV % 16) == 0, "gca_dv: alignment");
+    Gemm256Args g;
+    g.A = (const h16raw*)dOt;        // rows m = value channels v, k = queries i
+    g.B = (const h16raw*)P;          // k-major: row k = query i, columns n = keys j
+    g.out = dV;
+    g.bias = nullptr; g.mscale = nullptr; g.mdiag = nullptr;
+    g.zero_page = tcvom_zero_page();
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_dv: could not allocate the zero page");
+    g.M = DV; g.N = N; g.K = (int)ld; g.ldo = DV; g.act = 0; g.out_fp32 = 1; g.batch = batch;
+    g.a_bstride = (long long)DV * ld;
+    g.b_bstride = (long long)N * ld;
+    g.out_bstride = (long long)N * DV;
+    g.vec_bstride = 0;
+    g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
+    g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
+    g.stats = nullptr;
+    g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
+    g.ldb = (int)ld; g.krows = N;
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((DV + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL((gemm_nt256_kernel<0, 4, 1>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    TCVOM_LAUNCH_CHECK("gca_dv");
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_gca_dq_dk(const void* T, const void* Gt, float* dWq, float* Mp, int32_t N, int32_t D, int64_t ld, int32_t batch,
+                               void* stream) {
+    TCVOM_CHECK_ARG(T && Gt && dWq && Mp, "gca_dq_dk: null pointer");
+    TCVOM_CHECK_ARG(N >= 256 && D >= 64 && D % 4 == 0 && ld >= N && ld % 256 == 0 && batch >= 1, "gca_dq_dk: N=%d D=%d ld=%lld", N, D, (long long)ld);
+    TCVOM_CHECK_ARG(((uintptr_t)T % 16) == 0 && ((uintptr_t)Gt % 16) == 0 && ((uintptr_t)dWq % 16) == 0 && ((uintptr_t)Mp % 16) == 0, "gca_dq_dk: alignment");
+    Gemm256Args g;
+    g.A = (const h16raw*)Gt;         // rows m = channels d, k contiguous
+    g.bias = nullptr; g.mscale = nullptr; g.mdiag = nullptr;
+    g.zero_page = tcvom_zero_page();
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_dq_dk: could not allocate the zero page");
+    g.M = D; g.N = N; g.K = (int)ld; g.ldo = D; g.act = 0; g.out_fp32 = 1; g.batch = batch;
+    g.a_bstride = (long long)D * ld;
+    g.b_bstride = (long long)N * ld;
+    g.out_bstride = (long long)N * D;
+    g.vec_bstride = 0;
+    g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
+    g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
+    g.stats = nullptr;
+    g.B = (const h16raw*)T;
+    // Two launches, each with its own K-split tail (3 frames at 1080p: 288 tiles = one round of 256 + 32 tiles x 8 eighth-length
+    // workgroups, 1.125 rounds each -- what the paired launch of tcvom_gemm_pair reaches with 576 tiles in one grid)
+    for (int second = 0; second < 2; ++second) {
+        g.out = second ? Mp : dWq;
+        g.ldb = second ? (int)ld : 0;            // second product: T k-major -- row k = query i, columns n = keys j
+        g.krows = second ? N : 0;
+        dim3 grid((unsigned)((N + 255) / 256), (unsigned)cdiv(D, 192), (unsigned)batch);
+        const int rc = g256_split_tail(g, grid, true, g.out, batch, stream);
+        if (rc < 0) return rc;
+        if (second) hipLaunchKernelGGL((gemm_nt256_kernel<0, 3, 1>), grid, dim3(512), 0, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL((gemm_nt256_kernel<0, 3, 0>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    }
+    TCVOM_LAUNCH_CHECK("gca_dq_dk");
     return TCVOM_OK;
 }

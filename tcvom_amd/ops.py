@@ -1241,6 +1241,7 @@ def _r64(n):
     return (n + 63) // 64 * 64
 
 
+GCA_KMAJOR = _os.environ.get('TCVOM_NO_GCA_KMAJOR') is None                  # A/B switch: dV / M' read P / T k-major (no P^T / T^T)
 GCA_FUSED_SOFTMAX = _os.environ.get('TCVOM_NO_FUSED_SOFTMAX', '0') != '1'      # A/B switch (tools/ab_bench.sh TCVOM_NO_FUSED_SOFTMAX)
 
 
@@ -1280,7 +1281,8 @@ class _GcaAttention(torch.autograd.Function):
             # scores + softmax without the fp32 N x N matrix: the score GEMM's epilogue writes exp(S' - tile row max) and the
             # per-tile (max, sum) of every row, a second pass rescales the rows in place (csrc/gemm256.hip EPI 3)
             stats = torch.empty((B, N, ld // 256, 2), dtype=torch.float32, device=dev)
-            L.call('tcvom_gca_scores_softmax', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(P), L.ptr(stats), N, D, ld, B, st)
+            L.call('tcvom_gca_scores_exp', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(P), L.ptr(stats), N, D, ld, B, st)
+            L.call('tcvom_gca_softmax_rescale', L.ptr(P), L.ptr(stats), N, ld, B, st)
         else:
             S = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
             d = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bstride=N * ld, vec_bstride=N, out_fp32=True)
@@ -1311,38 +1313,42 @@ class _GcaAttention(torch.autograd.Function):
         delta = torch.empty((B, N), dtype=torch.float32, device=dev)
         L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
         T = torch.empty((B, N, ld), dtype=H16, device=dev)
-        # the same epilogue also writes the transposed copies P^T and T^T that the dV and M' GEMMs read (when the padded row length
-        # is a whole number of 256-wide tiles; otherwise two transpose passes)
-        fused_t = ld % 256 == 0
-        Pt = torch.empty((B, ld, ld), dtype=H16, device=dev)
-        Tt = torch.empty((B, ld, ld), dtype=H16, device=dev)
-        L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T),
-               L.ptr(Tt) if fused_t else None, L.ptr(Pt) if fused_t else None, N, DV, ld, B, st)
-        # dV[j][v] = sum_i P[i][j] dO[i][v]: as an NT GEMM on the transposed operands (Pt = P^T, dOt = dO^T) it runs on the
-        # 256x256 tiles at ~1 PFLOP/s; the pixel-major TT form (atomics, transposing LDS reads) measured 437 us against
-        # 270 + 80 us of transposes here
-        if not fused_t:
-            L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Pt), N, ld, ld, ld, B, N * ld, ld * ld, st)
         dOt = torch.empty((B, DV, ld), dtype=H16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(dO), L.ptr(dOt), N, DV, DV, ld, B, N * DV, DV * ld, st)
         dV = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
-        d4 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=ld * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(Pt), L.ptr(dOt), L.ptr(dV), None, None, None, None, C.byref(d4), st)
-        del Pt, dOt
         dWq = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        Mp = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         Gt = torch.empty((B, D, ld), dtype=H16, device=dev)
         L.call('tcvom_transpose_bf16', L.ptr(G), L.ptr(Gt), N, D, D, ld, B, N * D, D * ld, st)
+        # dV[j][v]  = sum_i P[i][j] dO[i][v]
         # dWq[i][d] = sum_j T[i][j] G[j][d]            (rows m = d, columns n = queries i, reduce j)
-        # M'[j][d]  = sum_i T[i][j] G[i][d]: like dV, an NT GEMM on the transposed operand (Tt = T^T) on the 256-pixel tiles
-        # instead of the pixel-major TT form (320 workgroups, one long reduction each); measured -0.1 ms per step.
-        # Both share the weight operand Gt and go out as ONE launch (tcvom_gemm_pair: 2 x 288 workgroups fill 2.25 rounds of the
-        # 256 CUs instead of 2 x 1.125)
-        if not fused_t:
-            L.call('tcvom_transpose_bf16', L.ptr(T), L.ptr(Tt), N, ld, ld, ld, B, N * ld, ld * ld, st)
-        Mp = torch.empty((B, N, D), dtype=torch.float32, device=dev)
-        d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
-        L.call('tcvom_gemm_pair', L.ptr(T), L.ptr(Tt), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), C.byref(d3), ld * ld, st)
-        del Tt
+        # M'[j][d]  = sum_i T[i][j] G[i][d]
+        if GCA_KMAJOR and ld % 256 == 0 and N >= 256 and ((N + 255) // 256) * B >= 24:
+            # dV and M' contract the ROW index of P / T: the 256-tile GEMM reads them as they lie in memory (k-major operand through
+            # the transposing LDS read), so the softmax-backward epilogue writes T alone -- no P^T / T^T (2 x 400 MB written and
+            # read back per 3-frame launch at 1080p)
+            L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), None, None,
+                   N, DV, ld, B, st)
+            L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dOt), L.ptr(dV), N, DV, ld, B, st)
+            L.call('tcvom_gca_dq_dk', L.ptr(T), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), N, D, ld, B, st)
+        else:
+            # NT GEMMs on transposed copies (Pt = P^T, Tt = T^T), written by the same epilogue when the padded row length is a whole
+            # number of 256-wide tiles, else by two transpose passes
+            fused_t = ld % 256 == 0
+            Pt = torch.empty((B, ld, ld), dtype=H16, device=dev)
+            Tt = torch.empty((B, ld, ld), dtype=H16, device=dev)
+            L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T),
+                   L.ptr(Tt) if fused_t else None, L.ptr(Pt) if fused_t else None, N, DV, ld, B, st)
+            if not fused_t:
+                L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Pt), N, ld, ld, ld, B, N * ld, ld * ld, st)
+                L.call('tcvom_transpose_bf16', L.ptr(T), L.ptr(Tt), N, ld, ld, ld, B, N * ld, ld * ld, st)
+            d4 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=ld * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
+            L.call('tcvom_conv_igemm', L.ptr(Pt), L.ptr(dOt), L.ptr(dV), None, None, None, None, C.byref(d4), st)
+            # both products share the weight operand Gt and go out as ONE launch (tcvom_gemm_pair)
+            d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
+            L.call('tcvom_gemm_pair', L.ptr(T), L.ptr(Tt), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), C.byref(d3), ld * ld, st)
+            del Pt, Tt
+        del dOt
         dalpha = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_value_patches_bwd', L.ptr(dV), L.ptr(dalpha), B, h8, w8, Ca, st)
         dg8 = torch.empty((B, h8, w8, CG), dtype=H16, device=dev)

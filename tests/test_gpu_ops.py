@@ -672,6 +672,38 @@ def test_gca_fused_softmax_backward_gemm(B, N, DV):
         assert torch.equal(Tt, want_t) and torch.equal(Pt, want_p)          # exact transposes, zero padding rows / columns
 
 
+@pytest.mark.parametrize('B,N,DV,D', [(2, 1000, 512, 192), (3, 2040, 2048, 576), (1, 8160, 256, 576)])
+def test_gca_row_contractions_read_the_matrix_k_major(B, N, DV, D):
+    """tcvom_gca_dv (dV = P^T dO) and tcvom_gca_dq_dk (dWq = T G, M' = T^T G): the products of GuidedCxtAtten's backward that
+    contract the ROW index of an N x N matrix read it as it lies in memory (k-major B operand, transposing LDS reads) -- against
+    fp32 matmuls on the same 16-bit operands.  Ragged N (rows N .. ld of a batch entry's slot belong to the NEXT entry and must
+    count as zeros), the K-split tail of the 192-row tiles (3 x 2040 and 1 x 8160: 1.125 rounds of tiles per product)."""
+    from tcvom_amd import _lib as L
+    ld = (N + 255) // 256 * 256
+    tag = 'km%d_%d' % (N, DV)
+    st = L.stream_ptr()
+    P = torch.zeros((B, N, ld), dtype=H16, device=DEV)
+    P[:, :, :N] = (hu('p.' + tag, (B, N, N)) * (hu('pm.' + tag, (B, N, N)) > 0.7)).to(H16).to(DEV)      # zeros in the padding columns
+    dO = (hu('do.' + tag, (B, N, DV)) - 0.5).to(H16).to(DEV)
+    dOt = torch.zeros((B, DV, ld), dtype=H16, device=DEV)
+    dOt[:, :, :N] = dO.transpose(1, 2)
+    dV = torch.full((B, N, DV), 7.0, device=DEV)
+    L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dOt), L.ptr(dV), N, DV, ld, B, st)
+    ref = torch.bmm(P[:, :, :N].float().transpose(1, 2), dO.float())
+    assert rel_err(dV.cpu(), ref.cpu()) < 1e-5
+    del dV, ref, dOt
+    G = (hu('g.' + tag, (B, N, D)) - 0.5).to(H16).to(DEV)
+    Gt = torch.zeros((B, D, ld), dtype=H16, device=DEV)
+    Gt[:, :, :N] = G.transpose(1, 2)
+    T = P                                                              # (any N x N matrix with zero padding columns)
+    dWq = torch.full((B, N, D), 7.0, device=DEV)
+    Mp = torch.full((B, N, D), 7.0, device=DEV)
+    L.call('tcvom_gca_dq_dk', L.ptr(T), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), N, D, ld, B, st)
+    Tf = T[:, :, :N].float()
+    assert rel_err(dWq.cpu(), torch.bmm(Tf, G.float()).cpu()) < 1e-5
+    assert rel_err(Mp.cpu(), torch.bmm(Tf.transpose(1, 2), G.float()).cpu()) < 1e-5
+
+
 @pytest.mark.parametrize('B,N,D', [(2, 1016, 192), (1, 2040, 576), (3, 512, 64)])
 def test_gca_scores_softmax_without_the_score_matrix(B, N, D):
     """tcvom_gca_scores_softmax (score GEMM whose epilogue writes exp(S' - tile row max) + per-tile row statistics, then an
