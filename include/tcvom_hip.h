@@ -304,6 +304,8 @@ int tcvom_sn_power_iteration(const int64_t* table, const tcvom_sn_scratch* s,
 int tcvom_sn_pack(const int64_t* table, const tcvom_sn_scratch* s, const int32_t* work_pack, int32_t n_pack,
                   int32_t call, void* fwd_arena, void* bwd_arena, int64_t fwd_call_stride,
                   int64_t bwd_call_stride, void* stream);
+/* work_apply rows of one layer: (layer, block) for block < tcvom_sn_apply_blocks(kind, K, C, T, numel) */
+int tcvom_sn_apply_blocks(int32_t kind, int32_t K, int32_t C, int32_t T, int64_t numel);
 int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
                       const int32_t* work_inner, int32_t n_inner, const int32_t* work_apply, int32_t n_apply,
                       const int32_t* ncalls, const float* dw_arena, int64_t dw_call_stride,

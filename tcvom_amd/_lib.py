@@ -115,6 +115,7 @@ _PROTOS = {
     'tcvom_mbox_free': [vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
+    'tcvom_sn_apply_blocks': [i32, i32, i32, i32, i64],
     'tcvom_gca_dv': [vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_gca_dq_dk': [vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, f32, vp, vp, vp],
@@ -207,7 +208,7 @@ _PROTOS = {
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
-          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok'}
+          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}

@@ -12,6 +12,7 @@
 // Backward: the igemm_tt weight-gradient kernels accumulate dW~ (gradient w.r.t. the normalised,
 // packed weight) into an fp32 arena; sn_backward turns that into the gradient of weight_bar:
 //     dW_bar = dW~/sigma - (<dW~, W_bar>/sigma^2) * u v^T        (u, v constants, ops.py:32-36)
+#include <type_traits>
 #include "common.h"
 
 #define SN_WORDS 24
@@ -359,6 +360,12 @@ __global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const int64_t* __rest
     if (threadIdx.x == 0) atomicAdd(inner + (int64_t)call * L_total + layer, a);
 }
 
+constexpr int SN_APPLY_TMAX = 25;
+// work rows of sn_bwd_apply_kernel for one layer (the host builds its list from this)
+extern "C" int tcvom_sn_apply_blocks(int32_t kind, int32_t K, int32_t C, int32_t T, int64_t numel) {
+    if ((kind & 17) == 0 && T <= SN_APPLY_TMAX) return (int)(((int64_t)K * C + 255) / 256);
+    return (int)((numel + 255) / 256);
+}
 // grad[e] = sum_calls dW~[e]/sigma - inner/sigma^2 * u[row] v[col]
 // (element order: the pair-major order of sn_bwd_inner_kernel makes the gradient STORES 36-byte strided here -- 213 -> 313 us)
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __restrict__ tab, const int* __restrict__ work,
@@ -373,6 +380,84 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const int64_t* __rest
     const int kind = (int)L[SN_KIND];
     const int K = (int)L[SN_K], C = (int)L[SN_C], T = (int)L[SN_T], Cp = (int)L[SN_CPAD];
     const int wd = (int)L[SN_WD];
+    if ((kind & 17) == 0 && T <= SN_APPLY_TMAX) {
+        // Conv2d weights [K][C][T] (tcvom_sn_apply_blocks: a block = 256 (k, c) pairs, all T taps): the packed gradients [k][t][c]
+        // are read along c (256 consecutive floats per tap and call), the results cross an LDS buffer in element order and leave as
+        // 256-float runs.  (One thread per element gathered 7 c x 9 t per wave instruction from 9 rows: 216 us per 1080p step
+        // against ~80 us of traffic.)
+        __shared__ float buf[256 * SN_APPLY_TMAX];
+        const int64_t p0 = (int64_t)work[blockIdx.x * 2 + 1] * 256, npair = (int64_t)K * C;
+        const int64_t pr = p0 + threadIdx.x;
+        const int nc = ncalls[layer];
+        const bool from_dot = dot_layers != nullptr && dot_layers[layer] != 0;
+        if (pr < npair) {
+            const int k = (int)(pr / C), c = (int)(pr - (int64_t)k * C);
+            // per call: 1 / sigma and the rank-one coefficient inner / sigma^2 * u[k] (hoisted: two divisions per element and call
+            // were a third of the kernel)
+            constexpr int MAXC = 4;
+            float isg[MAXC], cf[MAXC];
+            const float* vrow[MAXC];
+            const float* drow[MAXC];
+#pragma unroll
+            for (int call = 0; call < MAXC; ++call) {
+                isg[call] = 1.f; cf[call] = 0.f; vrow[call] = nullptr; drow[call] = nullptr;
+                if (call < nc) {
+                    drow[call] = dw_arena + call * dw_call_stride + L[SN_DW_OFF] + (int64_t)k * T * Cp + c;
+                    if (!(kind & 2)) {
+                        const float sg = sc.sigma[(int64_t)call * sc.L + layer];
+                        const float in_ = from_dot ? sg * dots[(int64_t)call * sc.L + layer] : inner[(int64_t)call * sc.L + layer];
+                        isg[call] = 1.f / sg;
+                        cf[call] = in_ * isg[call] * isg[call] * sc.uhist[(int64_t)call * sc.sum_h + L[SN_S_OFF] + k];
+                        vrow[call] = sc.vhist + (int64_t)call * sc.sum_wd + L[SN_T_OFF] + (int64_t)c * T;
+                    }
+                }
+            }
+            auto taps = [&](auto tc_) {
+                // TC taps at a time, all calls: the loads of a group are issued together (the kernel is bound by the bytes in
+                // flight: a loop over single taps left 3 loads per thread outstanding -- 240 us against ~80 us of traffic)
+                constexpr int TC = decltype(tc_)::value;
+                for (int t0 = 0; t0 + TC <= T; t0 += TC) {
+                    float d[MAXC][TC], v[MAXC][TC];
+#pragma unroll
+                    for (int call = 0; call < MAXC; ++call)
+#pragma unroll
+                        for (int i = 0; i < TC; ++i) {
+                            d[call][i] = call < nc ? drow[call][(int64_t)(t0 + i) * Cp] : 0.f;
+                            v[call][i] = (call < nc && vrow[call]) ? vrow[call][t0 + i] : 0.f;
+                        }
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) {
+                        float g = 0.f;
+#pragma unroll
+                        for (int call = 0; call < MAXC; ++call) g += d[call][i] * isg[call] - cf[call] * v[call][i];
+                        buf[threadIdx.x * T + t0 + i] = g * out_scale;
+                    }
+                }
+            };
+            if (nc <= MAXC) {
+                if (T == 9) taps(std::integral_constant<int, 9>{});
+                else taps(std::integral_constant<int, 1>{});
+            } else {
+                for (int t = 0; t < T; ++t) {                            // (more than 4 calls per window: the plain form)
+                    float g = 0.f;
+                    for (int call = 0; call < nc; ++call) {
+                        const float d = dw_arena[call * dw_call_stride + L[SN_DW_OFF] + ((int64_t)k * T + t) * Cp + c];
+                        if (kind & 2) { g += d; continue; }
+                        const float sg = sc.sigma[(int64_t)call * sc.L + layer];
+                        const float in_ = from_dot ? sg * dots[(int64_t)call * sc.L + layer] : inner[(int64_t)call * sc.L + layer];
+                        g += d / sg - in_ / (sg * sg) * sc.uhist[(int64_t)call * sc.sum_h + L[SN_S_OFF] + k] *
+                                          sc.vhist[(int64_t)call * sc.sum_wd + L[SN_T_OFF] + c * T + t];
+                    }
+                    buf[threadIdx.x * T + t] = g * out_scale;
+                }
+            }
+        }
+        __syncthreads();
+        const int64_t e0 = p0 * T, e1 = min(numel, e0 + (int64_t)256 * T);
+        float* gout = grad_arena + L[SN_GRAD_OFF];
+        for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) gout[e] = buf[e - e0];
+        return;
+    }
     const int64_t e = (int64_t)work[blockIdx.x * 2 + 1] * 256 + threadIdx.x;
     if (e >= numel) return;
     int k, c, t, row, col;

@@ -294,7 +294,9 @@ class WeightBank(object):
         rows_all, rows_sn = self._pack_rows(specs), self._pack_rows(sn)
         self.work_pack_all, self.n_pack_all = i32(rows_all), len(rows_all)
         self.work_pack_sn, self.n_pack_sn = i32(rows_sn), len(rows_sn)
-        app = [(s.layer_id, b) for s in specs for b in range((s.numel + 255) // 256)]
+        for s in specs:                                  # work rows of sn_bwd_apply_kernel (256 (k, c) pairs or 256 elements each)
+            s.apply_blocks = L.call('tcvom_sn_apply_blocks', int(tab[s.layer_id, SN_KIND]), s.K, s.C, s.T, s.numel)
+        app = [(s.layer_id, b) for s in specs for b in range(s.apply_blocks)]
         self.work_apply, self.n_apply = i32(app), len(app)
         self.tvec = torch.zeros(self.sum_wd, device=device)
         self.svec = torch.zeros(self.sum_h, device=device)
@@ -566,7 +568,7 @@ class WeightBank(object):
         bounds.append(len(specs))
         calls = plan['ncalls']
         inner_rows = lambda sp: calls[sp.layer_id] * ((sp.numel + 8191) // 8192) if (sp.spectral and not sp.sn_dot) else 0
-        apply_rows = lambda sp: (sp.numel + 255) // 256
+        apply_rows = lambda sp: sp.apply_blocks
         ck, i0, a0 = [], 0, 0
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             ni = sum(inner_rows(sp) for sp in specs[lo:hi])
