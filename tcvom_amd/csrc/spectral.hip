@@ -64,6 +64,22 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const int64_t* __restrict_
     if (threadIdx.x < 16) us[threadIdx.x] = (r0 + threadIdx.x < h) ? u[r0 + threadIdx.x] : 0.f;
     __syncthreads();
     const int nr = min(16, h - r0);
+    if ((wd & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+        // 16 rows x 4 columns per thread: the 16 float4 loads are issued together (the kernel is bound by the bytes in flight;
+        // one 4-byte load per row and iteration: 60 us per call for 102 MB of weights)
+        const float4* W4 = reinterpret_cast<const float4*>(W + (int64_t)r0 * wd);
+        const int wd4 = wd >> 2;
+        for (int c4 = threadIdx.x; c4 < wd4; c4 += 256) {
+            float4 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = r < nr ? W4[(int64_t)r * wd4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a.x += w[r].x * us[r]; a.y += w[r].y * us[r]; a.z += w[r].z * us[r]; a.w += w[r].w * us[r]; }
+            atomicAdd(t + c4 * 4 + 0, a.x); atomicAdd(t + c4 * 4 + 1, a.y); atomicAdd(t + c4 * 4 + 2, a.z); atomicAdd(t + c4 * 4 + 3, a.w);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < wd; c += 256) {
         float a = 0.f;
         for (int r = 0; r < nr; ++r) a += W[(int64_t)(r0 + r) * wd + c] * us[r];
@@ -83,7 +99,21 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const int64_t* __restrict__
     const int r = r0 + (threadIdx.x >> 6);
     if (r >= h) return;
     float a = 0.f;
-    for (int c = threadIdx.x & 63; c < wd; c += 64) a += W[(int64_t)r * wd + c] * t[c];
+    if ((wd & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(t)) & 15) == 0) {
+        const float4* w4 = reinterpret_cast<const float4*>(W + (int64_t)r * wd);
+        const float4* t4 = reinterpret_cast<const float4*>(t);
+        const int wd4 = wd >> 2;
+        int c = threadIdx.x & 63;
+        for (; c + 192 < wd4; c += 256) {                       // 4 x 16 bytes of the row in flight per lane
+            const float4 w0 = w4[c], w1 = w4[c + 64], w2 = w4[c + 128], w3 = w4[c + 192];
+            const float4 x0 = t4[c], x1 = t4[c + 64], x2 = t4[c + 128], x3 = t4[c + 192];
+            a += w0.x * x0.x + w0.y * x0.y + w0.z * x0.z + w0.w * x0.w + w1.x * x1.x + w1.y * x1.y + w1.z * x1.z + w1.w * x1.w
+               + w2.x * x2.x + w2.y * x2.y + w2.z * x2.z + w2.w * x2.w + w3.x * x3.x + w3.y * x3.y + w3.z * x3.z + w3.w * x3.w;
+        }
+        for (; c < wd4; c += 64) { const float4 w0 = w4[c], x0 = t4[c]; a += w0.x * x0.x + w0.y * x0.y + w0.z * x0.z + w0.w * x0.w; }
+    } else {
+        for (int c = threadIdx.x & 63; c < wd; c += 64) a += W[(int64_t)r * wd + c] * t[c];
+    }
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) svec[L[SN_S_OFF] + r] = a;
 }
