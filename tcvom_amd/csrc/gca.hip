@@ -227,12 +227,26 @@ __global__ __launch_bounds__(256) void gca_value_patches_bwd_kernel(const float4
         const int y = (int)(t % h8);
         const int b = (int)(t / h8);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int jy = max(0, (y - 3) / 2 - 1); jy <= min(h - 1, (y + 3) / 2 + 1); ++jy)
-            for (int ky = 0; ky < 4; ++ky) {
-                if (refl(2 * jy - 1 + ky, h8) != y) continue;
-                for (int jx = max(0, (x - 3) / 2 - 1); jx <= min(w - 1, (x + 3) / 2 + 1); ++jx)
-                    for (int kx = 0; kx < 4; ++kx) {
-                        if (refl(2 * jx - 1 + kx, w8) != x) continue;
+        // the (patch, tap) pairs whose reflected source row is y: source rows s = y, plus the out-of-range rows that reflect onto
+        // y (-1 -> 1, h8 -> h8 - 2); row s is tap ky of patch jy = (s + 1 - ky) / 2 for the two ky of the parity of s + 1.
+        // (Enumerated directly: the search over all (patch, tap) candidates with a reflection test each -- up to 256 per thread --
+        // was the kernel: 92 us for 200 MB of gradients.)
+        int sy[3], sx[3], ny = 1, nx = 1;
+        sy[0] = y; sx[0] = x;
+        if (y == 1) sy[ny++] = -1;
+        if (y == h8 - 2) sy[ny++] = h8;
+        if (x == 1) sx[nx++] = -1;
+        if (x == w8 - 2) sx[nx++] = w8;
+        for (int a = 0; a < ny; ++a)
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa) {
+                const int ky = ((sy[a] + 1) & 1) + 2 * pa, jy = (sy[a] + 1 - ky) / 2;
+                if (sy[a] + 1 - ky < 0 || jy >= h) continue;
+                for (int bb = 0; bb < nx; ++bb)
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb) {
+                        const int kx = ((sx[bb] + 1) & 1) + 2 * pb, jx = (sx[bb] + 1 - kx) / 2;
+                        if (sx[bb] + 1 - kx < 0 || jx >= w) continue;
                         const float4 g = dV[(((int64_t)b * N + jy * w + jx) * 16 + ky * 4 + kx) * C4 + c];
                         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                     }
@@ -326,12 +340,23 @@ __global__ __launch_bounds__(256) void gca_patches_bwd_kernel(const float* __res
         float acc = 0.f;
         if ((y8 & 1) == 0 && (x8 & 1) == 0) {
             const int y = y8 / 2, x = x8 / 2;
-            for (int jy = max(0, y - 2); jy <= min(h - 1, y + 2); ++jy)
+            // source rows s = y, plus -1 (reflects onto 1) / h (onto h - 2); row s is tap ky of patch jy = s + 1 - ky
+            int sy[3], sx[3], ny = 1, nx = 1;
+            sy[0] = y; sx[0] = x;
+            if (y == 1) sy[ny++] = -1;
+            if (y == h - 2) sy[ny++] = h;
+            if (x == 1) sx[nx++] = -1;
+            if (x == w - 2) sx[nx++] = w;
+            for (int a = 0; a < ny; ++a)
+#pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    if (refl(jy + ky - 1, h) != y) continue;
-                    for (int jx = max(0, x - 2); jx <= min(w - 1, x + 2); ++jx)
+                    const int jy = sy[a] + 1 - ky;
+                    if (jy < 0 || jy >= h) continue;
+                    for (int bb = 0; bb < nx; ++bb)
+#pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            if (refl(jx + kx - 1, w) != x) continue;
+                            const int jx = sx[bb] + 1 - kx;
+                            if (jx < 0 || jx >= w) continue;
                             acc += dWp[(((int64_t)b * N + jy * w + jx) * 9 + ky * 3 + kx) * CG + c];
                         }
                 }

@@ -1036,7 +1036,7 @@ def test_gca_module_vs_reference_golden(name):
     ck.done()
 
 
-@pytest.mark.parametrize('B,h8,w8', [(2, 12, 16), (1, 20, 28)])
+@pytest.mark.parametrize('B,h8,w8', [(2, 12, 16), (1, 20, 28), (1, 6, 16)])
 def test_gca_attention_kernel_tight(B, h8, w8):
     """The attention core (patches, scores, softmax, PV, fold) against the oracle's dense formula on
     IDENTICAL bf16 guidance/value maps (so only accumulation order and the bf16 storage of P differ)."""
