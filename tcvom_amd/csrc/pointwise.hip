@@ -323,13 +323,21 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const h16raw* __rest
         alpha[p] = head_out<MODE>(acc);
     }
 }
+// (Measured and dropped, round 3: the channel contraction on v_dot2 with hi + residual 16-bit weight pairs in LDS -- 167 us with one
+//  thread per pixel, 102 us with one thread per (pixel, 8 channels) and lane shuffles, against 96 us for this form: the kernel is
+//  bound by the 9-fold re-read of the input through the vector memory path, not by its conversions; an LDS-tiled form would be next.)
+// dpre = d(loss) / d(pre-activation) of the head, once per pixel (the data- and the weight-gradient kernels read it 9 / 25 times)
+template <int MODE>
+__global__ __launch_bounds__(256) void head_dpre_kernel(const float* __restrict__ dalpha, const float* __restrict__ alpha,
+                                                        float* __restrict__ dpre, int64_t n) {
+    GRID_STRIDE(p, n) dpre[p] = head_dpre<MODE>(dalpha[p], alpha[p]);
+}
 // dx[p][c] = sum_t dpre[p - off_t] w[t][c]
-template <int KS, int MODE>
-__global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __restrict__ dalpha, const float* __restrict__ alpha,
-                                                                 const float* __restrict__ w, h16raw* __restrict__ dx,
-                                                                 float* __restrict__ dpre_out, int N, int H, int W, int C) {
+template <int KS>
+__global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __restrict__ dpre, const float* __restrict__ w,
+                                                                 h16raw* __restrict__ dx, int N, int H, int W, int C) {
     constexpr int T = KS * KS, R = KS / 2;
-    extern __shared__ float ws[];
+    extern __shared__ __attribute__((aligned(16))) float ws[];
     for (int i = threadIdx.x; i < T * C; i += 256) ws[i] = w[i];
     __syncthreads();
     const int C8 = C / 8;
@@ -340,19 +348,23 @@ __global__ __launch_bounds__(256) void head_conv_bwd_data_kernel(const float* __
         const int xw = (int)(p % W);
         const int yh = (int)((p / W) % H);
         const int nn = (int)(p / ((int64_t)W * H));
+        // output pixel q = p - (t offset):  x[p] contributed to pre[q] with tap t where p = q + off_t.  The T scalars first (they
+        // are independent loads), then the multiply-adds.
+        float dp[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int qh = yh - (t / KS - R), qw = xw - (t % KS - R);
+            const bool ok = qh >= 0 && qh < H && qw >= 0 && qw < W;
+            dp[t] = ok ? dpre[((int64_t)nn * H + qh) * W + qw] : 0.f;
+        }
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            // output pixel q = p - (t offset):  x[p] contributed to pre[q] with tap t where p = q + off_t
-            const int qh = yh - (t / KS - R), qw = xw - (t % KS - R);
-            if (qh < 0 || qh >= H || qw < 0 || qw >= W) continue;
-            const int64_t q = ((int64_t)nn * H + qh) * W + qw;
-            const float dp = head_dpre<MODE>(dalpha[q], alpha[q]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += dp * ws[t * C + c8 * 8 + k];
+            const float4 w0 = *reinterpret_cast<const float4*>(ws + t * C + c8 * 8), w1 = *reinterpret_cast<const float4*>(ws + t * C + c8 * 8 + 4);
+            acc[0] += dp[t] * w0.x; acc[1] += dp[t] * w0.y; acc[2] += dp[t] * w0.z; acc[3] += dp[t] * w0.w;
+            acc[4] += dp[t] * w1.x; acc[5] += dp[t] * w1.y; acc[6] += dp[t] * w1.z; acc[7] += dp[t] * w1.w;
         }
         *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8(acc);
-        if (c8 == 0 && dpre_out) dpre_out[p] = head_dpre<MODE>(dalpha[p], alpha[p]);
     }
 }
 // dw[t][c] = sum_p dpre[p] x[p + off_t][c];  db = sum_p dpre[p].
@@ -384,15 +396,23 @@ __global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* 
         float f[8];
         unpack8(*reinterpret_cast<const uint4*>(x + q * C + c8 * 8), f);
         if (c8 == 0) bsum += dpre[q];
+        // x[q] is tap t of the output pixel o = q - off_t.  The T scalars first (independent loads; one bounds test per pixel for
+        // the interior instead of four per tap), then the multiply-adds.
+        float dp[T];
+        if (yh >= R && yh < H - R && xw >= R && xw < W - R) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            // x[q] is tap t of the output pixel o = q - off_t
-            const int oh = yh - (t / KS - R), ow = xw - (t % KS - R);
-            if (oh < 0 || oh >= H || ow < 0 || ow >= W) continue;
-            const float dp = dpre[q - (int64_t)(t / KS - R) * W - (t % KS - R)];
+            for (int t = 0; t < T; ++t) dp[t] = dpre[q - (int64_t)(t / KS - R) * W - (t % KS - R)];
+        } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[t][k] += dp * f[k];
+            for (int t = 0; t < T; ++t) {
+                const int oh = yh - (t / KS - R), ow = xw - (t % KS - R);
+                dp[t] = (oh < 0 || oh >= H || ow < 0 || ow >= W) ? 0.f : dpre[q - (int64_t)(t / KS - R) * W - (t % KS - R)];
+            }
         }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[t][k] += dp[t] * f[k];
     }
     // combine the PL pixel lanes: for every k, red[t][thread]; then thread i < T*C8 sums (t = i / C8, c8' = i % C8)
 #pragma unroll
@@ -519,16 +539,20 @@ extern "C" int tcvom_head_conv_bwd(const float* dalpha, const float* alpha, cons
     TCVOM_CHECK_ARG((ksize == 3 && mode == 0) || (ksize == 5 && (mode == 1 || mode == 2)), "head_conv_bwd: ksize=%d mode=%d not instantiated", ksize, mode);
     hipStream_t st = (hipStream_t)stream;
     const int T = ksize * ksize;
-    const dim3 g(grid_for((int64_t)N * H * W * C / 8));
+    const int64_t P = (int64_t)N * H * W;
+    {
+        const dim3 gp(grid_for(P));
+        if (mode == 0) hipLaunchKernelGGL(head_dpre_kernel<0>, gp, dim3(256), 0, st, dalpha, alpha, dpre, P);
+        else if (mode == 1) hipLaunchKernelGGL(head_dpre_kernel<1>, gp, dim3(256), 0, st, dalpha, alpha, dpre, P);
+        else hipLaunchKernelGGL(head_dpre_kernel<2>, gp, dim3(256), 0, st, dalpha, alpha, dpre, P);
+    }
+    const dim3 g(grid_for(P * C / 8));
     if (ksize == 3)
-        hipLaunchKernelGGL((head_conv_bwd_data_kernel<3, 0>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (h16raw*)dx, dpre, N, H, W, C);
-    else if (mode == 1)
-        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 1>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (h16raw*)dx, dpre, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<3>), g, dim3(256), T * C * sizeof(float), st, dpre, w, (h16raw*)dx, N, H, W, C);
     else
-        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5, 2>), g, dim3(256), T * C * sizeof(float), st, dalpha, alpha, w, (h16raw*)dx, dpre, N, H, W, C);
+        hipLaunchKernelGGL((head_conv_bwd_data_kernel<5>), g, dim3(256), T * C * sizeof(float), st, dpre, w, (h16raw*)dx, N, H, W, C);
     if (hipMemsetAsync(dw, 0, sizeof(float) * T * C * replicas, st) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * replicas, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "head_conv_bwd: memset failed");
-    const int64_t P = (int64_t)N * H * W;
     // every block ends with T*C atomicAdds; `replicas` copies of dw (summed by the caller) keep them from serialising
     int64_t blocks = (P + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
