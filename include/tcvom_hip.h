@@ -317,10 +317,13 @@ int tcvom_sn_backward(const int64_t* table, const tcvom_sn_scratch* s,
 /* GuidedCxtAtten backward (models/GCA/ops.py:177-204 under autograd), the products that contract the ROW index of the N x N
  * matrices P (probabilities) and T (score gradient), which are read as they lie in memory -- k-major operand through the
  * transposing LDS read -- instead of transposed copies:
- *   tcvom_gca_dv:    dV[b][j][v]  = sum_{i < N} P[b][i][j] dOt[b][v][i]          P: [batch][N][ld], dOt: [batch][DV][ld] (finite beyond N)
+ *   tcvom_gca_dv:    dV[b][j][v]  = sum_{i < N} P[b][i][j] dO[b][i][v]           P: [batch][N][ld], dO: [batch][N][DV] (both k-major)
  *   tcvom_gca_dq_dk: dWq[b][i][d] = sum_j T[b][i][j] Gt[b][d][j],  Mp[b][j][d] = sum_i T[b][i][j] Gt[b][d][i]    T: [batch][N][ld]
- * fp32 outputs [batch][N][DV] / [batch][N][D]; ld % 256 == 0, zeros in the padding columns N <= j < ld of P / T. */
-int tcvom_gca_dv(const void* P, const void* dOt, float* dV, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream);
+ * and the forward value aggregation with V as it lies in memory (k-major A operand):
+ *   tcvom_gca_pv:    O[b][i][v]   = sum_{j < N} P[b][i][j] V[b][j][v]            V: [batch][N][DV]
+ * fp32 outputs [batch][N][DV] / [batch][N][D]; ld % 256 == 0 (pv: % 64), zeros in the padding columns N <= j < ld of P / T. */
+int tcvom_gca_dv(const void* P, const void* dO, float* dV, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream);
+int tcvom_gca_pv(const void* P, const void* V, float* O, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream);
 int tcvom_gca_dq_dk(const void* T, const void* Gt, float* dWq, float* Mp, int32_t N, int32_t D, int64_t ld, int32_t batch, void* stream);
 
 /* ------------------------------------------------------------------ layout / resampling helpers (NHWC bf16) */

@@ -117,6 +117,7 @@ _PROTOS = {
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],
     'tcvom_sn_apply_blocks': [i32, i32, i32, i32, i64],
     'tcvom_gca_dv': [vp, vp, vp, i32, i32, i64, i32, vp],
+    'tcvom_gca_pv': [vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_gca_dq_dk': [vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, f32, vp, vp, vp],
     'tcvom_avgpool2': [vp, vp, i32, i32, i32, i32, vp],
@@ -289,15 +290,15 @@ def _profiled(name, args):
         PROFILE.append((name, {'P': N_, 'K': N_, 'C': DV_, 'ntaps': 1, 'tap_w': [0], 'batch': B_, 'phases': 1, 'variant': 'gemm_nt256',
                                'algo_bytes': nbytes}, e0, e1))
         return rc
-    elif name in ('tcvom_gca_scores_exp', 'tcvom_gca_dv', 'tcvom_gca_dq_dk'):
+    elif name in ('tcvom_gca_scores_exp', 'tcvom_gca_dv', 'tcvom_gca_pv', 'tcvom_gca_dq_dk'):
         # the other GEMMs of GuidedCxtAtten on gemm_nt256: (rows P, columns K, reduction C, products), algorithmic bytes = every
         # operand once (16-bit N x N matrices, fp32 gradients)
         if name == 'tcvom_gca_scores_exp':              # S' = c_j <G_i, G_j>, exp + tile statistics in the epilogue (EPI 3)
             N_, D_, ld_, B_ = args[5:9]
             dims, nbytes = (N_, N_, D_, B_), B_ * 2 * (N_ * D_ + N_ * ld_)
-        elif name == 'tcvom_gca_dv':                    # dV = P^T dO, P read k-major
+        elif name in ('tcvom_gca_dv', 'tcvom_gca_pv'):   # dV = P^T dO (P, dO k-major) / O = P V (V k-major)
             N_, DV_, ld_, B_ = args[3:7]
-            dims, nbytes = (N_, DV_, N_, B_), B_ * (2 * N_ * ld_ + 2 * DV_ * ld_ + 4 * N_ * DV_)
+            dims, nbytes = (N_, DV_, N_, B_), B_ * (2 * N_ * ld_ + 2 * DV_ * N_ + 4 * N_ * DV_)
         else:                                           # dWq = T G and M' = T^T G: two products, T read twice
             N_, D_, ld_, B_ = args[4:8]
             dims, nbytes = (N_, D_, N_, 2 * B_), B_ * (4 * N_ * ld_ + 2 * D_ * ld_ + 8 * N_ * D_)
@@ -359,7 +360,7 @@ def call(name, *args):
         rc = _profiled_tam(name, args)
     elif PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
                                         'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi', 'tcvom_gemm_pair', 'tcvom_gca_dp_softmax_bwd',
-                                        'tcvom_gca_scores_exp', 'tcvom_gca_dv', 'tcvom_gca_dq_dk'):
+                                        'tcvom_gca_scores_exp', 'tcvom_gca_dv', 'tcvom_gca_pv', 'tcvom_gca_dq_dk'):
         rc = _profiled(name, args)
     else:
         rc = _FNS[name](*args)

@@ -58,6 +58,9 @@ struct Gemm256Args {
     // products that contract their ROW index (dV = P^T dO, M' = T^T G): no transposed copies P^T / T^T (2 x 400 MB written by
     // the softmax-backward epilogue and read back per 3-frame launch at 1080p)
     int ldb, krows;
+    // k-major A operand (template AT = 1, 256-row tiles): A[k][m] with `lda` elements per k row and `krows_a` valid rows -- V of O = P V
+    // and dO of dV = P^T dO as they lie in memory, no transposed copies V^T / dO^T
+    int lda, krows_a;
 };
 
 #ifndef G256_STAGED_EPI
@@ -80,8 +83,9 @@ extern "C" int tcvom_trace256_read(unsigned long long* host) {
 
 // EPI: 0 = fp32 output, 1 = bf16 output, 2 = fused softmax backward, 3 = softmax numerators + per-tile row statistics (one
 // instantiation each: a single kernel with all epilogues spilled registers in the main loop)
-template <int EPI, int MF, int BT = 0>
+template <int EPI, int MF, int BT = 0, int AT = 0>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
+    static_assert(AT == 0 || MF == 4, "the k-major A operand is built for the 256-row tiles");
     // MF = 32-row A fragments per wave: 4 -> 256 x 256 tiles; 3 -> 192 (A rows) x 256 tiles for M = 576 (the d(query) / d(key)
     // GEMMs of GuidedCxtAtten: 3 x 192 instead of 3 x 256 with a quarter of the MFMAs multiplying padding).  The quadrant
     // (m1, *) then holds one fragment: phases 3 and 4 issue 4 MFMAs instead of 8.
@@ -119,10 +123,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const h16raw* A = g.A + bz * g.a_bstride;
     const h16raw* B = second ? g.B2 + bz * g.b2_bstride : g.B + bz * g.b_bstride;
     int ntile = g.K >> 6;
-    int krows = g.krows;
+    int krows = g.krows, krows_a = g.krows_a;
     if (kpart >= 0) {                                  // this workgroup's share of the reduction
         const int t0 = ntile * kpart / g.split_s, t1 = ntile * (kpart + 1) / g.split_s;
-        A += t0 * 64;
+        if (AT != 0) { A += (int64_t)t0 * 64 * g.lda; krows_a -= t0 * 64; } else A += t0 * 64;
         if (BT != 0 && bt) { B += (int64_t)t0 * 64 * g.ldb; krows -= t0 * 64; } else B += t0 * 64;
         ntile = t1 - t0;
     }
@@ -144,6 +148,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         const int ra = m0 + (a_piece + it * 4) * 8 + (lane >> 3), rb = n0 + (it * 8 + wave) * 8 + (lane >> 3);
         a_off[it] = (it < A_IT && ra < g.M) ? (int64_t)ra * K + kc8 : -1;
         b_off[it] = rb < g.N ? (int64_t)rb * K + kc8 : -1;
+        if (AT != 0) {
+            // k-major A: group wm's half tile [64 k][128 m] in LDS, 256-byte rows; piece (it, wave & 3) = k rows 4 (it*4 + (wave & 3))
+            // + (lane >> 4); the lane at chunk position lane & 15 fetches chunk c = position ^ 4 (row & 3) (see G_READ_A)
+            const int kr = (it * 4 + (wave & 3)) * 4 + (lane >> 4), col = m0 + wm * HM + (((lane & 15) ^ ((kr & 3) << 2)) << 3);
+            a_off[it] = (col < g.M && col + 8 <= g.lda) ? (int64_t)kr * g.lda + col : -1;
+        }
         if (BT != 0 && bt) {
             // k-major B tile [64 k][256 n] in LDS, 512-byte rows: piece (it, wave) = k rows (it*8 + wave)*2 + (lane >> 5); the lane
             // at chunk position lane & 31 of its row fetches the 16-byte chunk (8 n) c = position ^ 4 (row & 3) (see G_READ_B)
@@ -156,6 +166,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #define G_ISSUE_A(t, it)                                                                                     \
     {                                                                                                        \
         const h16raw* src_ = a_off[it] >= 0 ? A + a_off[it] + (t) * 64 : g.zero_page;                       \
+        if (AT != 0)                                                                                         \
+            src_ = (a_off[it] >= 0 && (t) * 64 + ((it) * 4 + (wave & 3)) * 4 + (lane >> 4) < krows_a) ? A + a_off[it] + (int64_t)(t) * 64 * g.lda : g.zero_page; \
         __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + ((t) & 1) * SLOT + (a_piece + (it) * 4) * 512), 16, 0, 0); \
     }
 #define G_ISSUE_B(t, it)                                                                                     \
@@ -179,10 +191,30 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int khalf = lane >> 5;
     h16x8_t fa[2][4], fb[2][4];                       // A sub-tile (2 row-fragments x 4 k16), both B sub-tiles (1 x 4 each)
 
+    // k-major A: fragment (mh, a) = columns mh*64 + a*32 + (lane & 31) of the group's [64 k][128 m] half tile, through the transposing
+    // LDS read like the k-major B (rows 256 bytes apart: chunk c of row k at position c ^ 4 (k & 3), i.e. the fragment index
+    // mh*2 + a -- bits 2, 3 of the chunk -- XOR (k & 3))
+    const unsigned tra_b0 = (unsigned)(uintptr_t)(lptr_t)(lds) + wm * (HM * 64 * 2) + (((lane >> 5) << 3) + ((lane & 15) >> 2)) * 256
+                          + ((((lane >> 4) & 1) * 2 + ((lane & 3) >> 1)) << 4) + (lane & 1) * 8;
+    const int tra_s2 = (lane & 15) >> 2;
+    TrFrag fat[2][4];
 #define G_READ_A(buf, mh)                                                                                    \
-    _Pragma("unroll") for (int a_ = 0; a_ < ((mh) * 2 + 1 < MF ? 2 : 1); ++a_)                               \
-        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                                  \
-            fa[a_][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3));
+    if (AT != 0) {                                                                                           \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) {                                                   \
+            const unsigned ad_ = tra_b0 + (unsigned)(((((mh) * 2 + a_) ^ tra_s2) << 6)) + (buf) * (SLOT * 2); \
+            tr_issue_imm<0, 1024>(fat[a_][0], ad_); tr_issue_imm<4096, 1024>(fat[a_][1], ad_);               \
+            tr_issue_imm<8192, 1024>(fat[a_][2], ad_); tr_issue_imm<12288, 1024>(fat[a_][3], ad_);           \
+        }                                                                                                    \
+    } else {                                                                                                 \
+        _Pragma("unroll") for (int a_ = 0; a_ < ((mh) * 2 + 1 < MF ? 2 : 1); ++a_)                           \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_)                                              \
+                fa[a_][kk_] = *reinterpret_cast<const h16x8_t*>(lds + (buf) * SLOT + (a_row + (mh) * 64 + a_ * 32) * 64 + (((kk_ * 2 + khalf) ^ a_swz) << 3)); \
+    }
+#define G_FIX_A()                                                                                            \
+    if (AT != 0) {                                                                                           \
+        _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                                     \
+            _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) { tr_fence(fat[a_][kk_]); fa[a_][kk_] = tr_value(fat[a_][kk_]); } \
+    }
     // k-major B: the MFMA fragment (lane: n = lane & 31, 8 consecutive k from 8 (lane >> 5)) comes out of the [k][n] tile through the
     // transposing LDS read -- a 16-lane group addresses a 4 (k) x 16 (n) block, lane L the 4 n at row L >> 2 / column 4 (L & 3), and
     // receives column L, rows 0..3 -- two reads (k rows +0..3, +4..7) per fragment.  Bank layout: the 4 rows of a group are 512 B
@@ -259,6 +291,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         G_READ_A(buf, 0) G_READ_B(buf, 0) G_READ_B(buf, 1)
         G_BAR();
         G_WAIT_LDS();
+        G_FIX_A()
         G_FIX_B()
         G_MFMA(0, 0, 2, t + 1)
         G_MFMA(0, 1, 1, t + 1)
@@ -267,13 +300,14 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");
         G_BAR();
         G_WAIT_LDS();
+        G_FIX_A()
         G_MFMA(1, 1, 0, 0)
         G_MFMA(1, 0, 0, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G_BAR();
     }
 #else
-    static_assert(BT == 0, "the four-phase loop has no k-major B path");
+    static_assert(BT == 0 && AT == 0, "the four-phase loop has no k-major operand path");
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         // phase 1: quadrant (m0, n0)
@@ -316,6 +350,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 #undef G_READ_A
 #undef G_READ_B
 #undef G_FIX_B
+#undef G_FIX_A
 #undef G_ISSUE_A
 #undef G_ISSUE_B
 #undef G_BAR
@@ -704,7 +739,7 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.B2 = (const h16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
     g.stats = nullptr;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
-    g.ldb = 0; g.krows = 0;
+    g.ldb = 0; g.krows = 0; g.lda = 0; g.krows_a = 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
     static const bool no192 = getenv("TCVOM_NO_M192") != nullptr;                  // A/B switch
     const bool m192 = !no192 && (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256;
@@ -755,7 +790,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
-    g.ldb = 0; g.krows = 0;
+    g.ldb = 0; g.krows = 0; g.lda = 0; g.krows_a = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<2, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dp_softmax_bwd");
@@ -825,7 +860,7 @@ extern "C" int tcvom_gca_scores_exp(const void* G, const float* cvec, const floa
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = stats;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
-    g.ldb = 0; g.krows = 0;
+    g.ldb = 0; g.krows = 0; g.lda = 0; g.krows_a = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)(ld / 256), (unsigned)batch);
     hipLaunchKernelGGL((gemm_nt256_kernel<3, 4>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_scores_exp");
@@ -849,22 +884,16 @@ extern "C" int tcvom_gca_scores_softmax(const void* G, const float* cvec, const 
 
 // ---- GuidedCxtAtten backward, the two products that contract the ROW index of an N x N matrix, reading it as it lies in memory
 // (k-major B operand through transposing LDS reads) instead of a transposed copy:
-//   dV[b][j][v] = sum_{i < N} P[b][i][j] dO[b][i][v]            (tcvom_gca_dv:    A = dOt [DV][ld], B = P [N][ld] k-major)
+//   dV[b][j][v] = sum_{i < N} P[b][i][j] dO[b][i][v]            (tcvom_gca_dv:    A = dO [N][DV] k-major, B = P [N][ld] k-major)
 //   dWq[b][i][d] = sum_j T[b][i][j] G[b][j][d],  M'[b][j][d] = sum_i T[b][i][j] G[b][i][d]
 //                                                               (tcvom_gca_dq_dk: A = Gt [D][ld]; one launch, T read both ways)
-extern "C" int tcvom_gca_dv(const void* P, const void* dOt, float* dV, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
-    TCVOM_CHECK_ARG(P && dOt && dV, "gca_dv: null pointer");
-    TCVOM_CHECK_ARG(N >= 256 && DV >= 256 && DV % 4 == 0 && ld >= N && ld % 256 == 0 && batch >= 1, "gca_dv: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
-    TCVOM_CHECK_ARG(((uintptr_t)P % 16) == 0 && ((uintptr_t)dOt % 16) == 0 && ((uintptr_t)dV % 16) == 0, "gca_dv: alignment");
-    Gemm256Args g;
-    g.A = (const h16raw*)dOt;        // rows m = value channels v, k = queries i
-    g.B = (const h16raw*)P;          // k-major: row k = query i, columns n = keys j
-    g.out = dV;
+// A = dO / V [N][DV] k-major (rows beyond N count as zeros), shared set-up of tcvom_gca_dv / tcvom_gca_pv
+static void g256_gca_common(Gemm256Args& g, const void* Amat, int32_t N, int32_t DV, int64_t ld, int32_t batch) {
+    g.A = (const h16raw*)Amat;
     g.bias = nullptr; g.mscale = nullptr; g.mdiag = nullptr;
     g.zero_page = tcvom_zero_page();
-    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_dv: could not allocate the zero page");
     g.M = DV; g.N = N; g.K = (int)ld; g.ldo = DV; g.act = 0; g.out_fp32 = 1; g.batch = batch;
-    g.a_bstride = (long long)DV * ld;
+    g.a_bstride = (long long)N * DV;
     g.b_bstride = (long long)N * ld;
     g.out_bstride = (long long)N * DV;
     g.vec_bstride = 0;
@@ -872,10 +901,37 @@ extern "C" int tcvom_gca_dv(const void* P, const void* dOt, float* dV, int32_t N
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
+    g.ldb = 0; g.krows = 0;
+    g.lda = DV; g.krows_a = N;
+}
+extern "C" int tcvom_gca_dv(const void* P, const void* dO, float* dV, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(P && dO && dV, "gca_dv: null pointer");
+    TCVOM_CHECK_ARG(N >= 256 && DV >= 256 && DV % 8 == 0 && ld >= N && ld % 256 == 0 && batch >= 1, "gca_dv: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
+    TCVOM_CHECK_ARG(((uintptr_t)P % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dV % 16) == 0, "gca_dv: alignment");
+    Gemm256Args g;
+    g256_gca_common(g, dO, N, DV, ld, batch);        // A: rows k = queries i, columns m = value channels v
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_dv: could not allocate the zero page");
+    g.B = (const h16raw*)P;          // k-major: row k = query i, columns n = keys j
+    g.out = dV;
     g.ldb = (int)ld; g.krows = N;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((DV + 255) / 256), (unsigned)batch);
-    hipLaunchKernelGGL((gemm_nt256_kernel<0, 4, 1>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((gemm_nt256_kernel<0, 4, 1, 1>), grid, dim3(512), 0, (hipStream_t)stream, g);
     TCVOM_LAUNCH_CHECK("gca_dv");
+    return TCVOM_OK;
+}
+// O[b][i][v] = sum_{j < N} P[b][i][j] V[b][j][v]      (P: [batch][N][ld] row-major = the NT B operand; V: [batch][N][DV] k-major A)
+extern "C" int tcvom_gca_pv(const void* P, const void* V, float* O, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
+    TCVOM_CHECK_ARG(P && V && O, "gca_pv: null pointer");
+    TCVOM_CHECK_ARG(N >= 256 && DV >= 256 && DV % 8 == 0 && ld >= N && ld % 64 == 0 && batch >= 1, "gca_pv: N=%d DV=%d ld=%lld", N, DV, (long long)ld);
+    TCVOM_CHECK_ARG(((uintptr_t)P % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, "gca_pv: alignment");
+    Gemm256Args g;
+    g256_gca_common(g, V, N, DV, ld, batch);         // A: rows k = keys j, columns m = value channels v
+    TCVOM_CHECK_ARG(g.zero_page != nullptr, "gca_pv: could not allocate the zero page");
+    g.B = (const h16raw*)P;          // rows n = queries i, k = keys j contiguous (row stride K = ld)
+    g.out = O;
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((DV + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL((gemm_nt256_kernel<0, 4, 0, 1>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    TCVOM_LAUNCH_CHECK("gca_pv");
     return TCVOM_OK;
 }
 
@@ -897,6 +953,7 @@ extern "C" int tcvom_gca_dq_dk(const void* T, const void* Gt, float* dWq, float*
     g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
+    g.lda = 0; g.krows_a = 0;
     g.B = (const h16raw*)T;
     // Two launches, each with its own K-split tail (3 frames at 1080p: 288 tiles = one round of 256 + 32 tiles x 8 eighth-length
     // workgroups, 1.125 rounds each -- what the paired launch of tcvom_gemm_pair reaches with 576 tiles in one grid)

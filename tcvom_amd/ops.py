@@ -1241,6 +1241,7 @@ def _r64(n):
     return (n + 63) // 64 * 64
 
 
+GCA_KMAJOR_A = _os.environ.get('TCVOM_NO_GCA_KMAJOR_A') is None              # A/B switch: forward O = P V reads V k-major (no V^T)
 GCA_KMAJOR = _os.environ.get('TCVOM_NO_GCA_KMAJOR') is None                  # A/B switch: dV / M' read P / T k-major (no P^T / T^T)
 GCA_FUSED_SOFTMAX = _os.environ.get('TCVOM_NO_FUSED_SOFTMAX', '0') != '1'      # A/B switch (tools/ab_bench.sh TCVOM_NO_FUSED_SOFTMAX)
 
@@ -1266,8 +1267,9 @@ class _GcaAttention(torch.autograd.Function):
                B, h8, w8, CG, st)
         V = torch.empty((B, N, DV), dtype=H16, device=dev)
         L.call('tcvom_gca_value_patches', L.ptr(alpha), L.ptr(V), B, h8, w8, Ca, st)
-        Vt = torch.empty((B, DV, ld), dtype=H16, device=dev)
-        L.call('tcvom_transpose_bf16', L.ptr(V), L.ptr(Vt), N, DV, DV, ld, B, N * DV, DV * ld, st)
+        # the value aggregation reads V as it lies in memory (k-major A operand of the 256-tile GEMM) when the shape fills the chip;
+        # else an NT GEMM on the transposed copy V^T
+        kmajor = GCA_KMAJOR and GCA_KMAJOR_A and ld % 256 == 0 and N >= 256 and DV >= 256 and ((N + 255) // 256) * (DV // 256) * B >= 192
         P = torch.empty((B, N, ld), dtype=H16, device=dev)
         # O[i][v] = sum_j P[i][j] V[j][v]             (rows m = v, columns n = queries i, reduce j)
         # (fp32: the backward forms sum_j P dP as <dO_i, O_i>; with a peaked softmax dP[i][i] - <dO_i, O_i> cancels to ~0 and
@@ -1289,8 +1291,14 @@ class _GcaAttention(torch.autograd.Function):
             L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, L.ptr(cvec), L.ptr(dvec), None, C.byref(d), st)
             L.call('tcvom_row_softmax', L.ptr(S), L.ptr(P), B * N, N, ld, ld, st)
             del S
-        d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
-        L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
+        if kmajor:
+            L.call('tcvom_gca_pv', L.ptr(P), L.ptr(V), L.ptr(O), N, DV, ld, B, st)
+        else:
+            Vt = torch.empty((B, DV, ld), dtype=H16, device=dev)
+            L.call('tcvom_transpose_bf16', L.ptr(V), L.ptr(Vt), N, DV, DV, ld, B, N * DV, DV * ld, st)
+            d2 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=N * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
+            L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
+            del Vt
         y = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_fold_f32', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
         ctx.save_for_backward(G, P, V, cvec, nrm, O)
@@ -1313,8 +1321,6 @@ class _GcaAttention(torch.autograd.Function):
         delta = torch.empty((B, N), dtype=torch.float32, device=dev)
         L.call('tcvom_rowdot_bf16', L.ptr(dO), L.ptr(O), 1, L.ptr(delta), B * N, DV, st)
         T = torch.empty((B, N, ld), dtype=H16, device=dev)
-        dOt = torch.empty((B, DV, ld), dtype=H16, device=dev)
-        L.call('tcvom_transpose_bf16', L.ptr(dO), L.ptr(dOt), N, DV, DV, ld, B, N * DV, DV * ld, st)
         dV = torch.empty((B, N, DV), dtype=torch.float32, device=dev)
         dWq = torch.empty((B, N, D), dtype=torch.float32, device=dev)
         Mp = torch.empty((B, N, D), dtype=torch.float32, device=dev)
@@ -1323,13 +1329,13 @@ class _GcaAttention(torch.autograd.Function):
         # dV[j][v]  = sum_i P[i][j] dO[i][v]
         # dWq[i][d] = sum_j T[i][j] G[j][d]            (rows m = d, columns n = queries i, reduce j)
         # M'[j][d]  = sum_i T[i][j] G[i][d]
-        if GCA_KMAJOR and ld % 256 == 0 and N >= 256 and ((N + 255) // 256) * B >= 24:
+        if GCA_KMAJOR and ld % 256 == 0 and N >= 256 and DV >= 256 and ((N + 255) // 256) * B >= 24:
             # dV and M' contract the ROW index of P / T: the 256-tile GEMM reads them as they lie in memory (k-major operand through
             # the transposing LDS read), so the softmax-backward epilogue writes T alone -- no P^T / T^T (2 x 400 MB written and
             # read back per 3-frame launch at 1080p)
             L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), None, None,
                    N, DV, ld, B, st)
-            L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dOt), L.ptr(dV), N, DV, ld, B, st)
+            L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dO), L.ptr(dV), N, DV, ld, B, st)
             L.call('tcvom_gca_dq_dk', L.ptr(T), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), N, D, ld, B, st)
         else:
             # NT GEMMs on transposed copies (Pt = P^T, Tt = T^T), written by the same epilogue when the padded row length is a whole
@@ -1342,13 +1348,15 @@ class _GcaAttention(torch.autograd.Function):
             if not fused_t:
                 L.call('tcvom_transpose_bf16', L.ptr(P), L.ptr(Pt), N, ld, ld, ld, B, N * ld, ld * ld, st)
                 L.call('tcvom_transpose_bf16', L.ptr(T), L.ptr(Tt), N, ld, ld, ld, B, N * ld, ld * ld, st)
+            dOt = torch.empty((B, DV, ld), dtype=H16, device=dev)
+            L.call('tcvom_transpose_bf16', L.ptr(dO), L.ptr(dOt), N, DV, DV, ld, B, N * DV, DV * ld, st)
             d4 = dense_desc(N, DV, ld, DV, batch=B, in_bstride=ld * ld, w_bstride=DV * ld, out_bstride=N * DV, out_fp32=True)
             L.call('tcvom_conv_igemm', L.ptr(Pt), L.ptr(dOt), L.ptr(dV), None, None, None, None, C.byref(d4), st)
+            del dOt
             # both products share the weight operand Gt and go out as ONE launch (tcvom_gemm_pair)
             d3 = dense_desc(N, D, ld, D, batch=B, in_bstride=N * ld, w_bstride=D * ld, out_bstride=N * D, out_fp32=True)
             L.call('tcvom_gemm_pair', L.ptr(T), L.ptr(Tt), L.ptr(Gt), L.ptr(dWq), L.ptr(Mp), C.byref(d3), ld * ld, st)
             del Pt, Tt
-        del dOt
         dalpha = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_value_patches_bwd', L.ptr(dV), L.ptr(dalpha), B, h8, w8, Ca, st)
         dg8 = torch.empty((B, h8, w8, CG), dtype=H16, device=dev)

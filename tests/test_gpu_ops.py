@@ -674,9 +674,9 @@ def test_gca_fused_softmax_backward_gemm(B, N, DV):
 
 @pytest.mark.parametrize('B,N,DV,D', [(2, 1000, 512, 192), (3, 2040, 2048, 576), (1, 8160, 256, 576)])
 def test_gca_row_contractions_read_the_matrix_k_major(B, N, DV, D):
-    """tcvom_gca_dv (dV = P^T dO) and tcvom_gca_dq_dk (dWq = T G, M' = T^T G): the products of GuidedCxtAtten's backward that
-    contract the ROW index of an N x N matrix read it as it lies in memory (k-major B operand, transposing LDS reads) -- against
-    fp32 matmuls on the same 16-bit operands.  Ragged N (rows N .. ld of a batch entry's slot belong to the NEXT entry and must
+    """tcvom_gca_dv (dV = P^T dO), tcvom_gca_pv (O = P V) and tcvom_gca_dq_dk (dWq = T G, M' = T^T G): the N x N matrix is read
+    as it lies in memory by the products that contract its ROW index (k-major B operand), dO / V likewise (k-major A operand),
+    through transposing LDS reads -- against fp32 matmuls on the same 16-bit operands.  Ragged N (rows N .. ld of a batch entry's slot belong to the NEXT entry and must
     count as zeros), the K-split tail of the 192-row tiles (3 x 2040 and 1 x 8160: 1.125 rounds of tiles per product)."""
     from tcvom_amd import _lib as L
     ld = (N + 255) // 256 * 256
@@ -685,13 +685,15 @@ def test_gca_row_contractions_read_the_matrix_k_major(B, N, DV, D):
     P = torch.zeros((B, N, ld), dtype=H16, device=DEV)
     P[:, :, :N] = (hu('p.' + tag, (B, N, N)) * (hu('pm.' + tag, (B, N, N)) > 0.7)).to(H16).to(DEV)      # zeros in the padding columns
     dO = (hu('do.' + tag, (B, N, DV)) - 0.5).to(H16).to(DEV)
-    dOt = torch.zeros((B, DV, ld), dtype=H16, device=DEV)
-    dOt[:, :, :N] = dO.transpose(1, 2)
     dV = torch.full((B, N, DV), 7.0, device=DEV)
-    L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dOt), L.ptr(dV), N, DV, ld, B, st)
+    L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dO), L.ptr(dV), N, DV, ld, B, st)
     ref = torch.bmm(P[:, :, :N].float().transpose(1, 2), dO.float())
     assert rel_err(dV.cpu(), ref.cpu()) < 1e-5
-    del dV, ref, dOt
+    # O = P V with V k-major (the A operand)
+    L.call('tcvom_gca_pv', L.ptr(P), L.ptr(dO), L.ptr(dV), N, DV, ld, B, st)
+    ref = torch.bmm(P[:, :, :N].float(), dO.float())
+    assert rel_err(dV.cpu(), ref.cpu()) < 1e-5
+    del dV, ref
     G = (hu('g.' + tag, (B, N, D)) - 0.5).to(H16).to(DEV)
     Gt = torch.zeros((B, D, ld), dtype=H16, device=DEV)
     Gt[:, :, :N] = G.transpose(1, 2)
