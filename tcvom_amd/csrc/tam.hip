@@ -216,12 +216,19 @@ __global__ __launch_bounds__(256) void tam_bwd_key_kernel(
     float acc[NP][2];
 #pragma unroll
     for (int i = 0; i < NP; ++i) acc[i][0] = acc[i][1] = 0.f;
-#pragma unroll 7
-    for (int j = 0; j < W2; ++j) {
+    // which of the W2 neighbours are unknown pixels: lane j tests neighbour j, one ballot (a serial loop of W2 dependent mask loads
+    // per wave -- all of them misses for the 97 % of the key pixels that have no unknown neighbour -- was most of the kernel: 195 us)
+    bool hit = false;
+    if (lane < W2) {
+        const int uy = y - (lane / WIN - R), ux = x - (lane % WIN - R);
+        if (uy >= 0 && uy < H && ux >= 0 && ux < W) hit = mask[(int64_t)b * N + (int64_t)uy * W + ux] != 0;
+    }
+    unsigned long long bits = __ballot(hit);
+    while (bits) {
+        const int j = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
         const int uy = y - (j / WIN - R), ux = x - (j % WIN - R);
-        if (uy < 0 || uy >= H || ux < 0 || ux >= W) continue;
         const int64_t u = (int64_t)uy * W + ux;
-        if (mask[(int64_t)b * N + u] == 0) continue;
         const float p = pb[(int64_t)j * N + u], ds = db[(int64_t)j * N + u];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -263,8 +270,12 @@ __device__ __forceinline__ float tam_lane(float v, int j) {
 // MODE 0: forward (out, logits).  MODE 1: backward pass A (dq, p and ds / sqrt(C) for pass B); `g` = dout, datt* may be NULL.
 // TH x TW = pixel tile, C8MAX = 16-byte chunks per pixel the LDS arrays are sized for (16: C <= 128, tiles 8x8;
 // 32: C <= 256 as in the FBA / DIM bases, tiles 4x8 forward and 4x4 backward so that everything stays below 160 KiB).
+// TAM_NW waves per workgroup: a tile's unknown pixels are spread over them one pixel per wave, and the LDS footprint allows ONE
+// workgroup per CU -- with 4 waves (one per SIMD, nothing to hide the LDS latency of the dependent chains) a fully unknown 8 x 8
+// tile took 16 pixels x 7.7 us per wave, and the densest tile sets the launch time (157 us on a 3 %-unknown window).
+constexpr int TAM_NW = 16;
 template <int WIN, int MODE, int TH, int TW, int C8MAX>
-__global__ __launch_bounds__(256) void tam_tiled_kernel(
+__global__ __launch_bounds__(TAM_NW * 64) void tam_tiled_kernel(
     const uint4* __restrict__ q, const uint4* __restrict__ kb, const uint4* __restrict__ kf, const unsigned* __restrict__ v,
     const uint4* __restrict__ g, const unsigned char* __restrict__ mask, unsigned* __restrict__ out,
     float* __restrict__ att0, float* __restrict__ att1, const float* __restrict__ datt0, const float* __restrict__ datt1,
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
     __syncthreads();
     const int nu = cnt;
     if (nu == 0) return;
-    for (int idx = tid; idx < 2 * HH * HW * C8; idx += 256) {
+    for (int idx = tid; idx < 2 * HH * HW * C8; idx += TAM_NW * 64) {
         const int d = idx / (HH * HW * C8), rem = idx - d * (HH * HW * C8);
         const int r = rem / C8, c = rem - r * C8;
         const int y = ty0 + r / HW - R, x = tx0 + r % HW - R;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
         if (y >= 0 && y < H && x >= 0 && x < W) val = (d == 0 ? kb : kf)[(b * N + (int64_t)y * W + x) * C8 + c];
         halo[(d * HH * HW + r) * C8 + c] = val;
     }
-    for (int idx = tid; idx < NT * C8; idx += 256) {
+    for (int idx = tid; idx < NT * C8; idx += TAM_NW * 64) {
         const int p = idx / C8, c = idx - p * C8;
         const int y = ty0 + p / TW, x = tx0 + p % TW;
         const bool in = y < H && x < W;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void tam_tiled_kernel(
     }
     __syncthreads();
     const int j = lane < W2 ? lane : W2 - 1;            // idle lanes shadow the last neighbour
-    for (int li = wave; li < nu; li += 4) {
+    for (int li = wave; li < nu; li += TAM_NW) {
         const int t = list[li];
         const int py = t / TW, px = t % TW;
         const int64_t u = (int64_t)(ty0 + py) * W + tx0 + px;
@@ -411,7 +422,7 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
         return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_fwd: memset / copy failed");
     if (window == 7 && C % 8 == 0) {
 #define TAM_TILED_FWD(TH, TW, CM)                                                                                     \
-        hipLaunchKernelGGL((tam_tiled_kernel<7, 0, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(256), 0, st,   \
+        hipLaunchKernelGGL((tam_tiled_kernel<7, 0, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(TAM_NW * 64), 0, st,   \
                            (const uint4*)q, (const uint4*)kb, (const uint4*)kf, (const unsigned*)v, (const uint4*)nullptr, \
                            mask, (unsigned*)out, attb, attf, (const float*)nullptr, (const float*)nullptr, H, W, C, isc)
         if (C <= 128) TAM_TILED_FWD(8, 8, 16); else TAM_TILED_FWD(4, 8, 32);
@@ -441,7 +452,7 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
     if (hipMemsetAsync(dq, 0, sizeof(h16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
     if (window == 7 && C % 8 == 0) {
 #define TAM_TILED_BWD(TH, TW, CM)                                                                                     \
-        hipLaunchKernelGGL((tam_tiled_kernel<7, 1, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(256), 0, st,   \
+        hipLaunchKernelGGL((tam_tiled_kernel<7, 1, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(TAM_NW * 64), 0, st,   \
                            (const uint4*)q, (const uint4*)kb, (const uint4*)kf, (const unsigned*)nullptr, (const uint4*)dout, \
                            mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, C, isc)
         if (C <= 128) TAM_TILED_BWD(8, 8, 16); else TAM_TILED_BWD(4, 4, 32);
