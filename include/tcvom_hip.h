@@ -185,7 +185,9 @@ int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
                    int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                    void* stream);
-int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);
+int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);                       /* = tcvom_bn_bwd_groups_n(pixels, C, 1) */
+/* partial-sum groups per frame of a backward reduction over `nframes` frames (what tcvom_bn_bwd_reduce launches and writes) */
+int tcvom_bn_bwd_groups_n(int64_t pixels, int32_t C, int32_t nframes);
 /* dz2 (or NULL): a second addend of the incoming gradient, bf16 like dz -- the skip-branch gradient of a residual block
  * (`out += identity`, resnet_enc.py:45-47: the block input feeds conv1 AND the residual add), summed in fp32 on the fly
  * instead of by a separate element-wise pass */

@@ -98,6 +98,7 @@ _PROTOS = {
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
+    'tcvom_bn_bwd_groups_n': [i64, i32, i32],
     'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_reduce_ranged': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, TP, vp],
@@ -208,7 +209,7 @@ _PROTOS = {
     'tcvom_wgrad_ws_max_problems': [],
 }
 # entry points that return a count, not a status
-_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
+_PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_bn_bwd_groups_n', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
           'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks'}
 
 # entry points that return a string

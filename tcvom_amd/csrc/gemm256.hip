@@ -684,9 +684,10 @@ static int g256_split_tail(Gemm256Args& g, dim3& grid, bool eligible, void* last
     if (!(tiles > 256 && rem > 0 && rem <= 128 && rem % nx == 0 && rem / nx <= ny)) return 0;
     const int sp = 256 / rem < 8 ? 256 / rem : 8;                                  // 2 .. 8 parts, each >= 8 K-tiles
     if (sp < 2 || ntile / sp < 8) return 0;
-    const int rows = rem / nx, mlo = (ny - rows) * 192;                            // the tail covers columns mlo .. M of the last slice
-    float* base = (float*)last_out + (long long)(nb - 1) * g.out_bstride + mlo;
-    if (hipMemset2DAsync(base, sizeof(float) * (size_t)g.ldo, 0, sizeof(float) * (size_t)(g.M - mlo), (size_t)g.N, (hipStream_t)stream) != hipSuccess)
+    // the tail covers the last rem / nx tile rows of the LAST output slice: the whole slice is zeroed (one linear memset; its other
+    // tiles store over it -- a strided 2-D memset of the tail columns alone took 14 us per launch)
+    float* base = (float*)last_out + (long long)(nb - 1) * g.out_bstride;
+    if (hipMemsetAsync(base, 0, sizeof(float) * (size_t)g.N * (size_t)g.ldo, (hipStream_t)stream) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_nt256: memset of the K-split tail failed");
     g.flat_nx = nx; g.flat_ny = ny; g.split_r = rem; g.split_s = sp;
     grid = dim3((unsigned)(tiles - rem + rem * sp), 1, 1);

@@ -4,6 +4,7 @@
 // (models/GCA/encoders/resnet_enc.py:33-49, decoders/resnet_dec.py:43-59) and the
 // conv->ReLU->BN shortcut order of res_gca_enc.py:47-55.  All HBM-bound streaming kernels:
 // 16-byte (8 x bf16) accesses per lane, fp32 math, statistics combined in fp64.
+#include <cstdlib>
 #include "common.h"
 
 // ---------------------------------------------------------------- statistics finalize
@@ -684,14 +685,20 @@ extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const voi
     return TCVOM_OK;
 }
 
-extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) {
+// Partial-sum groups (= blocks per frame) of the backward reduction.  A batched call of >= 3 frames stays at <= 4 * BN_SLICES groups
+// per frame -- >= 768 blocks in all, enough to stream at full rate -- so that its finalize is ONE launch (more groups go through
+// bn_partial_reduce first: 28 extra dependent 5 us launches per 1080p step for the os1 / os2 / os4 layers).
+extern "C" int tcvom_bn_bwd_groups_n(int64_t pixels, int32_t C, int32_t nframes) {
+    static const int cap_on = getenv("TCVOM_NO_BN_GROUP_CAP") == nullptr;            // A/B switch
     const int rows = 256 / (C / 8);
     int64_t per = (int64_t)rows * 8;                // >= 8 loop iterations per thread
     int64_t g = (pixels + per - 1) / per;
     if (g > 2048) g = 2048;
+    if (cap_on && nframes >= 3 && g > 4 * BN_SLICES) g = 4 * BN_SLICES;
     if (g < 1) g = 1;
     return (int)g;
 }
+extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) { return tcvom_bn_bwd_groups_n(pixels, C, 1); }
 
 extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                           const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
@@ -700,7 +707,7 @@ extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const
     TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_reduce: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && nframes >= 1,
                     "bn_bwd_reduce: bad args (C=%d)", C);
-    const int groups = tcvom_bn_bwd_groups(pixels, C);
+    const int groups = tcvom_bn_bwd_groups_n(pixels, C, nframes);
     const int rpb = (int)((pixels + groups - 1) / groups);
     const dim3 grid(groups, nframes);
     if (y_fp32)

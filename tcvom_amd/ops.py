@@ -372,7 +372,7 @@ class _ConvBNAct(torch.autograd.Function):
                 raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not '
                                    'supported (the per-window BatchNorm / weight arenas were reused)' % spec.name)
             ss, saved, stride = ctx.ss, ctx.saved, ctx.slot_stride
-            groups = L.call('tcvom_bn_bwd_groups', P, K)
+            groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
             partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
             yf = 1 if y.dtype == torch.float32 else 0
             zf0, zf1 = 0, nf
@@ -467,7 +467,7 @@ def _backward_active(ctx, dz, dz2, ranged=()):
     stride = ctx.slot_stride
     ss = C.c_void_p(ctx.ss.value + 4 * f0 * stride)
     saved = C.c_void_p(ctx.saved.value + 4 * f0 * stride)
-    groups = L.call('tcvom_bn_bwd_groups', P, K)
+    groups = L.call('tcvom_bn_bwd_groups_n', P, K, nfa)
     dev = dza.device
     partial = torch.empty(nfa * groups * 2 * K, dtype=torch.float32, device=dev)
     yf = 1 if y.dtype == torch.float32 else 0
@@ -595,7 +595,7 @@ class _DwBNAct(torch.autograd.Function):
         dz = _c(dz)
         P = N * OH * OW
         ss, saved, stride = ctx.ss, ctx.saved, ctx.slot_stride
-        groups = L.call('tcvom_bn_bwd_groups', P, Cc)
+        groups = L.call('tcvom_bn_bwd_groups_n', P, Cc, nf)
         partial = torch.empty(nf * groups * 2 * Cc, dtype=torch.float32, device=dz.device)
         L.call('tcvom_bn_bwd_reduce', L.ptr(dz), None, L.ptr(y), None, ss, saved, L.ptr(partial), P, Cc, cfg.act, 0, nf, stride, st)
         dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
