@@ -1,0 +1,57 @@
+"""The A/B switches of tcvom_amd/ops.py select alternative code paths that stay in the product as fall-backs (shapes the fast paths
+do not take) -- the NT attention GEMMs on transposed copies + the fp32 score matrix + row softmax (TCVOM_NO_GCA_KMAJOR,
+TCVOM_NO_FUSED_SOFTMAX), SpectralNorm's inner product as a pass over the weight gradient, zero-padded instead of row-range
+gradients, the end frames of the tail-only branches run on zero gradients (TCVOM_NO_SN_DOT, TCVOM_NO_RANGED, TCVOM_NO_TAIL_SKIP).
+One 544 x 960 training window through each set must give the losses and per-group gradient norms of the default paths."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _probe(extra):
+    env = dict(os.environ, **extra)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tests', '_switch_probe.py')], cwd=REPO, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + '\n' + out.stderr[-1500:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('PROBE ')][-1]
+    return json.loads(line[6:])
+
+
+def test_alternative_code_paths_agree_with_the_default_ones():
+    if os.environ.get('TCVOM_DTYPE_SUBTEST'):
+        pytest.skip('default storage type only')
+    base = _probe({})
+    again = _probe({})
+    sets = {'attention': {'TCVOM_NO_GCA_KMAJOR': '1', 'TCVOM_NO_FUSED_SOFTMAX': '1'},
+            'gradients': {'TCVOM_NO_SN_DOT': '1', 'TCVOM_NO_RANGED': '1', 'TCVOM_NO_TAIL_SKIP': '1'}}
+
+    def worst(a, b):
+        w = 0.0
+        for k, v in a['grad_norm'].items():
+            w = max(w, abs(v - b['grad_norm'][k]) / max(abs(v), 1e-12))
+        return w
+
+    def total(r):
+        return sum(v * v for v in r['grad_norm'].values()) ** 0.5
+
+    # run-to-run: fp32 atomics in the weight gradients / power iteration flip 16-bit roundings; the small-gradient groups of the
+    # encoder move by percents between two identical runs (tests/test_gpu_window.py: cosine 0.98 between two runs at 1088 x 1920)
+    noise = worst(base, again)
+    tnoise = abs(total(base) - total(again)) / total(base)
+    print('run-to-run gradient-norm difference: worst group %.2e, total %.2e' % (noise, tnoise))
+    for name, env in sets.items():
+        alt = _probe(env)
+        for x, y in zip(base['losses'], alt['losses']):
+            assert abs(x - y) <= 2e-3 * max(abs(x), 1e-3), (name, base['losses'], alt['losses'])
+        w = worst(base, alt)
+        print('%s: worst per-group gradient-norm difference %.2e' % (name, w))
+        assert w < max(3e-2, 5 * noise), (name, w)
+        t = abs(total(base) - total(alt)) / total(base)
+        print('%s: total gradient-norm difference %.2e' % (name, t))
+        assert t < max(1e-2, 5 * tnoise), (name, t)
