@@ -399,6 +399,8 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         // (measured and dropped, round 3: 256 (channels) x 128 (pixels) tiles for the 256-channel os16 layers -- 192 workgroups, one
         //  per CU, 25 % fewer operand bytes per MAC than two co-resident 128 x 128 workgroups: 25.57 -> 25.80 ms per step; the
         //  128 x 128 threshold lowered to 150 workgroups for the 512-channel os32 layers: no change)
+        // (measured, round 3: 4x as many 128 x 128 tiles where the 256 x 256 tile count leaves the last round of 256 mostly empty
+        //  -- 384 tiles -> 1536 -- is neutral: 24.19 vs 24.20 ms)
         if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
         // 128 (channels) x 96 (pixels) tiles, 4 waves of 32 x 96, where they spread evenly over the chip and the 128 x 128 ones do
         // not: the 256-channel os16 layers at 1080p are 64 x 2 x 3 = 384 workgroups of 128 x 128 (half the CUs run two, half one)
@@ -406,7 +408,9 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         static const int t96 = getenv("TCVOM_NT_T96") ? atoi(getenv("TCVOM_NT_T96")) : 1;
         if (t96 && wgs >= t128 && wgs < 1024) {
             const long long w96 = (long long)cdiv(P, 96) * cdiv(d->K, 128) * nb;
-            auto eff = [](long long w) { const long long per = (w + 255) / 256; return (double)w / (double)(per * 256); };
+            // (both tiles run two workgroups per CU: 512 slots; TCVOM_NT_T96=2: the round-1 rule with 256 slots)
+            const long long slots = t96 == 2 ? 256 : 512;
+            auto eff = [slots](long long w) { const long long per = (w + slots - 1) / slots; return (double)w / (double)(per * slots); };
             if (eff(w96) > eff(wgs) + 0.1) return {128, 96, 1};
         }
         if (wgs >= t128) return {128, 128, 4};
@@ -521,7 +525,14 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     //  workgroups hide the DMA latency better than one with a deeper ring)
     else if (c.tm == 128 && c.tn == 96) NT_LAUNCH(256, 128, 96, 32, 96, 2);
     else if (c.tm == 128) NT_LAUNCH(512, 128, 64, 32, 32, 3);
-    else if (c.tm == 64 && c.tn == 64) NT_LAUNCH(256, 64, 64, 32, 32, 4);
+    else if (c.tm == 64 && c.tn == 64) {
+        // 4 ring slots = 64 KB: two workgroups per CU (512 on the chip); 3 slots = 48 KB: three.  A grid of 513 .. 768 workgroups
+        // (the 512-channel os32 layers at 1080p: 32 x 8 x 3) is ONE round with three per CU instead of a full and a half one.
+        static const int nst3 = getenv("TCVOM_NT_6464_NST3") ? atoi(getenv("TCVOM_NT_6464_NST3")) : 1;
+        const long long nwg = (long long)grid.x * grid.y * grid.z;
+        if (nst3 && nwg > 512 && nwg <= 768) NT_LAUNCH(256, 64, 64, 32, 32, 3);
+        else NT_LAUNCH(256, 64, 64, 32, 32, 4);
+    }
     else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 3);
     else NT_LAUNCH(256, 32, 256, 32, 64, 2);
 #undef NT_LAUNCH
