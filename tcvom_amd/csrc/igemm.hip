@@ -923,6 +923,8 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     }
     int tm, tn;
     tt_tile(d, &tm, &tn);
+    // (measured, round 3: 64 x 128 tiles -- 49 KB, three workgroups per CU -- for the launches of 513 .. 768 workgroups of 128 x 128
+    //  (the 4-phase transposed convs of os32 -> os16: a full round and a half): neutral, 23.72 vs 23.73 ms)
     const int mt = cdiv(d->K, tm), nt = cdiv(ncols, tn);
     // pixel chunks: every workgroup ends with tm*tn atomic adds, so chunks must be long enough to amortise them
     // (>= 512 pixels), and the whole grid should fit in ONE round of co-resident workgroups (LDS-limited occupancy
