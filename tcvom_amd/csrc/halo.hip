@@ -39,7 +39,7 @@ struct HaloArgs {
     int org;                     // 1: taps 0..2 on an input that carries its own (reflection) padding ring -- the tile origin moves by (1, 1)
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
     int wgs_per_frame;           // a workgroup stays inside ONE frame: tiles [f*tpf + w*tiles_per_wg, ..) of frame f = v / wgs_per_frame
-    long long stats_bstride;     // statistics groups between frames; a frame has wgs_per_frame * 4 groups (workgroup, wave)
+    long long stats_bstride;     // statistics groups between frames; a frame has wgs_per_frame groups (one per workgroup)
     int spf;                     // samples per frame (weights change every spf samples: w_bstride elements further)
     long long w_bstride;
     int tap_dh[HALO_MAX_TAPS + 2], tap_dw[HALO_MAX_TAPS + 2], tap_w[HALO_MAX_TAPS + 2];   // compacted; tap_w < 0: zero tap
@@ -319,18 +319,39 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
 #undef HALO_ISSUE
 #undef HALO_NEXT
     if (a.stats && HALO_ABL != 2) {
-        // BatchNorm partial statistics: ONE group per (workgroup, wave) and frame -- the sums ride in registers over the tile run
-        // and cross the 32 pixel lanes of each half wave once, with DPP adds (per tile that reduction was 256 of the epilogue's
-        // 600 instructions)
-        const int64_t grp = a.stats_group_offset + (int64_t)frame * a.stats_bstride + wslot * 4 + wave;
-        float* sp = a.stats + grp * 2 * a.K + 4 * half;
+        // BatchNorm partial statistics: ONE group per workgroup and frame -- the sums ride in registers over the tile run, cross the
+        // 32 pixel lanes of each half wave once with DPP adds (per tile that reduction was 256 of the epilogue's 600 instructions) and
+        // the four waves through LDS (170 groups per frame at 1080p instead of 680: the finalize is one launch, no bn_partial_reduce)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                 // the halo / weight arrays are free: every wave is past its last tile
+        float* red = reinterpret_cast<float*>(lds);      // [4 waves][4 groups][2 halves][8]
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float t8[8] = {s1[g][0], s1[g][1], s1[g][2], s1[g][3], s2[g][0], s2[g][1], s2[g][2], s2[g][3]};
             halo_reduce8(t8);
-            if ((lane & 31) == 16 && 8 * g + 4 * half < a.K) {
-                *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(t8[0], t8[1], t8[2], t8[3]);
-                *reinterpret_cast<float4*>(sp + a.K + 8 * g) = make_float4(t8[4], t8[5], t8[6], t8[7]);
+            if ((lane & 31) == 16) {
+                float* rp = red + ((wave * 4 + g) * 2 + half) * 8;
+                *reinterpret_cast<float4*>(rp) = make_float4(t8[0], t8[1], t8[2], t8[3]);
+                *reinterpret_cast<float4*>(rp + 4) = make_float4(t8[4], t8[5], t8[6], t8[7]);
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && (lane & 31) == 16) {
+            const int64_t grp = a.stats_group_offset + (int64_t)frame * a.stats_bstride + wslot;
+            float* sp = a.stats + grp * 2 * a.K + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g + 4 * half >= a.K) continue;
+                float4 u1 = make_float4(0.f, 0.f, 0.f, 0.f), u2 = u1;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float* rp = red + ((w * 4 + g) * 2 + half) * 8;
+                    const float4 x1 = *reinterpret_cast<const float4*>(rp), x2 = *reinterpret_cast<const float4*>(rp + 4);
+                    u1.x += x1.x; u1.y += x1.y; u1.z += x1.z; u1.w += x1.w;
+                    u2.x += x2.x; u2.y += x2.y; u2.z += x2.z; u2.w += x2.w;
+                }
+                *reinterpret_cast<float4*>(sp + 8 * g) = u1;
+                *reinterpret_cast<float4*>(sp + a.K + 8 * g) = u2;
             }
         }
     }
@@ -408,7 +429,7 @@ int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase) {
     int tpw, wpf;
     size_t lds;
     halo_grid(d, p, &tpw, &wpf, &lds);
-    return wpf * 4;                                            // per batch element (frame): one per (workgroup, wave)
+    return wpf;                                                // per batch element (frame): one per workgroup
 }
 
 // returns 1 when the conv was launched here, 0 when the caller should use the implicit GEMM, < 0 on error
@@ -443,7 +464,7 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
     size_t lds_bytes;
     const int grid = halo_grid(d, p, &a.tiles_per_wg, &a.wgs_per_frame, &lds_bytes);
     a.stats_bstride = nb > 1 ? d->stats_bstride : 0;
-    if (stats && nb > 1 && d->stats_bstride < (long long)a.wgs_per_frame * 4)
+    if (stats && nb > 1 && d->stats_bstride < (long long)a.wgs_per_frame)
         return tcvom_fail(TCVOM_ERR_ARG, "halo_conv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
