@@ -436,6 +436,13 @@ int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gt
                      float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
                      int32_t tri_channels /* 3: one-hot {bg,unk,fg} (GCA); 1: 128/255-in-unknown plane (DIM, Index) */,
                      void* stream);
+/* The same with one dilation radius PER CLIP (models/model.py:60-64: `kernel_rad` is drawn inside `for i in range(b)` when
+ * DILATION_KERNEL is None).  frames = clips * frames_per_clip; clip_radii: HOST array of `clips` radii (read before the call
+ * returns; consecutive clips of equal radius share a launch). */
+int tcvom_preprocess_clips(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                           float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
+                           float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
+                           const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream);
 int tcvom_masked_l1_fwd(const float* p1, const float* g1, const float* m1, const float* p2, const float* g2,
                         const float* m2, const float* fgs, const float* bgs, float* alphas, float* comps,
                         float* acc, int64_t B, int64_t HW, int64_t p_stride, int64_t frame_stride, int64_t rgb_stride, void* stream);

@@ -25,13 +25,20 @@ TAM_OS = 8
 
 def make_trimap(alpha, dilate_kernel, eps=0.0):
     """alpha [B,S,1,H,W] in 0..1 -> (one-hot trimap [B,S,3,H,W] {bg,unk,fg}, dilated unknown mask [B,S,1,H,W]).
-    models/model.py:54-80 with a fixed dilation radius (dilate_kernel is not None)."""
+    models/model.py:54-80.  dilate_kernel None: one radius PER CLIP from torch's global generator, `int(torch.randint(0, 26, ()))`
+    in clip order (models/model.py:60-64); an int: that radius; a sequence: the given per-clip radii."""
     alpha = torch.where(alpha < eps, torch.zeros_like(alpha), alpha)
     alpha = torch.where(alpha > 1 - eps, torch.ones_like(alpha), alpha)
     unk = ((alpha > 0) & (alpha < 1)).float()
     B, S, _, H, W = unk.shape
-    r = int(dilate_kernel)
-    dil = F.max_pool2d(unk.reshape(B * S, 1, H, W), 2 * r + 1, 1, r).reshape(B, S, 1, H, W)
+    if dilate_kernel is None:
+        radii = [int(torch.randint(0, 26, size=())) for _ in range(B)]
+    elif isinstance(dilate_kernel, (list, tuple)):
+        radii = [int(r) for r in dilate_kernel]
+    else:
+        radii = [int(dilate_kernel)] * B
+    assert len(radii) == B
+    dil = torch.stack([F.max_pool2d(unk[i], 2 * r + 1, 1, r) for i, r in enumerate(radii)])
     cls = torch.where(dil > 0.5, torch.ones_like(alpha), 2 * alpha).long()   # 0 bg, 1 unknown, 2 fg
     onehot = F.one_hot(cls.squeeze(2), 3).permute(0, 1, 4, 2, 3).float()
     return onehot, dil

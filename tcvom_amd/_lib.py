@@ -179,6 +179,7 @@ _PROTOS = {
     'tcvom_gca_unfold': [vp, vp, i32, i32, i32, i32, vp],
     'tcvom_gca_patches_bwd': [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_preprocess': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
+    'tcvom_preprocess_clips': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), f32, i32, vp],
     'tcvom_masked_l1_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
     'tcvom_masked_l1_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i64, i64, i64, vp],
     'tcvom_avgpool8': [vp, vp, i64, i32, i32, vp],

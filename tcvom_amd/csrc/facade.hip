@@ -325,31 +325,49 @@ __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ t
 }
 
 // ---------------------------------------------------------------- C ABI
-extern "C" int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
-                                float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
-                                float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
-                                int32_t tri_channels, void* stream) {
+extern "C" int tcvom_preprocess_clips(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                                      float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
+                                      float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
+                                      const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream) {
     // bg == NULL (then bgs may be NULL too): EvalModel.preprocess (models/model.py:360-386) -- `fg` is the frame, `a` the trimap
-    TCVOM_CHECK_ARG(a && fg && gts && fgs && (bgs || !bg) && imgs && unk_raw && unk_tmp && unk_dil && x8 && trimask && tris_vis,
+    TCVOM_CHECK_ARG(a && fg && gts && fgs && (bgs || !bg) && imgs && unk_raw && unk_tmp && unk_dil && x8 && trimask && tris_vis && clip_radii,
                     "preprocess: null pointer");
-    TCVOM_CHECK_ARG(frames > 0 && H > 0 && W > 0 && dilate_radius >= 0, "preprocess: bad shape");
+    TCVOM_CHECK_ARG(clips > 0 && frames_per_clip > 0 && H > 0 && W > 0, "preprocess: bad shape");
+    for (int c = 0; c < clips; ++c) TCVOM_CHECK_ARG(clip_radii[c] >= 0, "preprocess: negative dilation radius (clip %d)", c);
     TCVOM_CHECK_ARG(tri_channels == 3 || tri_channels == 1, "preprocess: %d trimap channels (3: one-hot, 1: DIM/Index)", tri_channels);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t HW = (int64_t)H * W;
+    const int64_t HW = (int64_t)H * W, frames = (int64_t)clips * frames_per_clip;
     hipLaunchKernelGGL(preprocess_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, a, fg, bg, gts, fgs, bgs, imgs, unk_raw, frames, HW, eps);
-    if (W % 8 == 0 && ((uintptr_t)unk_raw & 7) == 0 && ((uintptr_t)unk_tmp & 7) == 0 && ((uintptr_t)unk_dil & 7) == 0) {
-        const int W8 = W / 8;
-        hipLaunchKernelGGL(dilate_words_kernel, dim3(sgrid(frames * H * W8)), dim3(256), 0, st, (const unsigned long long*)unk_raw,
-                           (unsigned long long*)unk_tmp, frames, H, W8, dilate_radius, 0);
-        hipLaunchKernelGGL(dilate_words_kernel, dim3(sgrid(frames * H * W8)), dim3(256), 0, st, (const unsigned long long*)unk_tmp,
-                           (unsigned long long*)unk_dil, frames, H, W8, dilate_radius, 1);
-    } else {
-        hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_raw, unk_tmp, frames, H, W, dilate_radius, 0);
-        hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, unk_tmp, unk_dil, frames, H, W, dilate_radius, 1);
+    const bool words = W % 8 == 0 && ((uintptr_t)unk_raw & 7) == 0 && ((uintptr_t)unk_tmp & 7) == 0 && ((uintptr_t)unk_dil & 7) == 0;
+    for (int c0 = 0; c0 < clips;) {                                   // one pair of passes per run of clips with the same radius
+        int c1 = c0 + 1;
+        while (c1 < clips && clip_radii[c1] == clip_radii[c0]) ++c1;
+        const int r = clip_radii[c0];
+        const int64_t off = (int64_t)c0 * frames_per_clip * HW, nf = (int64_t)(c1 - c0) * frames_per_clip;
+        if (words) {
+            const int W8 = W / 8;
+            hipLaunchKernelGGL(dilate_words_kernel, dim3(sgrid(nf * H * W8)), dim3(256), 0, st, (const unsigned long long*)(unk_raw + off),
+                               (unsigned long long*)(unk_tmp + off), nf, H, W8, r, 0);
+            hipLaunchKernelGGL(dilate_words_kernel, dim3(sgrid(nf * H * W8)), dim3(256), 0, st, (const unsigned long long*)(unk_tmp + off),
+                               (unsigned long long*)(unk_dil + off), nf, H, W8, r, 1);
+        } else {
+            hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(nf * HW)), dim3(256), 0, st, unk_raw + off, unk_tmp + off, nf, H, W, r, 0);
+            hipLaunchKernelGGL(dilate_kernel, dim3(sgrid(nf * HW)), dim3(256), 0, st, unk_tmp + off, unk_dil + off, nf, H, W, r, 1);
+        }
+        c0 = c1;
     }
     hipLaunchKernelGGL(assemble_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, gts, imgs, unk_dil, (uint4*)x8, trimask, tris_vis, frames, HW, eps, tri_channels);
     TCVOM_LAUNCH_CHECK("preprocess");
     return TCVOM_OK;
+}
+
+extern "C" int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                                float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
+                                float* tris_vis, int64_t frames, int32_t H, int32_t W, int32_t dilate_radius, float eps,
+                                int32_t tri_channels, void* stream) {
+    TCVOM_CHECK_ARG(frames > 0 && frames < (1ll << 31), "preprocess: bad shape");
+    return tcvom_preprocess_clips(a, fg, bg, gts, fgs, bgs, imgs, unk_raw, unk_tmp, unk_dil, x8, trimask, tris_vis, 1, (int32_t)frames, H, W,
+                                  &dilate_radius, eps, tri_channels, stream);
 }
 
 extern "C" int tcvom_masked_l1_fwd(const float* p1, const float* g1, const float* m1, const float* p2, const float* g2,

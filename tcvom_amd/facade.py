@@ -6,6 +6,8 @@ forward() signatures (models/model.py:15-453), running on libtcvom_hip.so.
         -> [L_alpha, L_comp, L_grad, L_dt, L_att, scaled_imgs, tris_vis, alphas, comps, scaled_gts, Fs, Bs]
     .NET                                                      state_dict == the reference checkpoint layout
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -47,9 +49,14 @@ def preprocess_window(a, fg, bg, dilate_kernel, eps, tri_channels=3):
     p.x8 = torch.empty((B, S, H, W, 8), dtype=H16, device=dev)
     p.trimask = _f32((B, S, 1, H, W), dev)
     p.tris_vis = _f32((B, S, 1, H, W), dev)
-    L.call('tcvom_preprocess', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
-           L.ptr(p.unk_raw), L.ptr(tmp), L.ptr(p.unk), L.ptr(p.x8), L.ptr(p.trimask), L.ptr(p.tris_vis), B * S, H, W,
-           int(dilate_kernel), float(eps), int(tri_channels), L.stream_ptr())
+    # one radius per clip (models/model.py:60-64): an int serves every clip, a sequence names them in clip order
+    radii = [int(r) for r in dilate_kernel] if hasattr(dilate_kernel, '__len__') else [int(dilate_kernel)] * B
+    if len(radii) != B:
+        raise ValueError('preprocess_window: %d dilation radii for %d clips' % (len(radii), B))
+    p.radii = radii
+    L.call('tcvom_preprocess_clips', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
+           L.ptr(p.unk_raw), L.ptr(tmp), L.ptr(p.unk), L.ptr(p.x8), L.ptr(p.trimask), L.ptr(p.tris_vis), B, S, H, W,
+           (ctypes.c_int32 * B)(*radii), float(eps), int(tri_channels), L.stream_ptr())
     return p
 
 
@@ -217,15 +224,17 @@ class FullModel(nn.Module):
         self.TRIMAP_CHANNEL = self.TRIMAP_CHANNEL_DICT[self.method]
         self.att_thres, self.label_smooth = 0.3, 0.2          # FullModel_VMD's defaults (its forward serves VMN archs here too)
 
-    def _dilation(self):
+    def _dilation(self, clips):
+        """The dilation radius of every clip of the batch (models/model.py:60-64): with `dilate_kernel=None` (train_ddp.py's
+        default) the reference draws `int(torch.randint(0, 26, size=()))` INSIDE its loop over the clips -- one draw per clip from
+        torch's global CPU generator, in clip order: trimap widths 1..51, a different one per clip, and the generator ends in the
+        state the reference leaves it in.  (The draw is a CPU tensor: no device synchronisation.)"""
         if self.DILATION_KERNEL is None:
-            # trimap width 1..51, drawn per call (models/model.py:62-64).  The reference draws one radius per
-            # clip with a host sync; here one host-side draw per window keeps the step sync-free.
-            return int(torch.randint(0, 26, size=()))
-        return int(self.DILATION_KERNEL)
+            return [int(torch.randint(0, 26, size=())) for _ in range(clips)]
+        return [int(self.DILATION_KERNEL)] * clips
 
     def preprocess(self, a, fg, bg):
-        p = preprocess_window(a, fg, bg, self._dilation(), self.EPS, self.TRIMAP_CHANNEL)
+        p = preprocess_window(a, fg, bg, self._dilation(a.shape[0]), self.EPS, self.TRIMAP_CHANNEL)
         tris = p.x8[..., 3:3 + self.TRIMAP_CHANNEL].permute(0, 1, 4, 2, 3).float()
         imgs = p.x8[..., 0:3].permute(0, 1, 4, 2, 3).float()
         return p.imgs, p.fgs, p.bgs, p.gts, tris, p.trimask, imgs
@@ -241,7 +250,7 @@ class FullModel(nn.Module):
             out = FullModel_VMD.forward(self, a, fg, bg)
             return out[:3] + out[5:]
         c = S // 2
-        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
+        prep = preprocess_window(a, fg, bg, self._dilation(a.shape[0]), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
         if self.method == 'fba':
             from . import fba_losses as FL
             x2, extras, _ = fba_network_input(prep, self.EPS)
@@ -276,7 +285,7 @@ class FullModel_VMD(FullModel):
         assert S >= 3, 'a window needs at least 3 frames'
         H, W = a.shape[-2:]
         assert H % 32 == 0 and W % 32 == 0, 'H and W must be multiples of 32 (pred_vmn.py:90)'
-        prep = preprocess_window(a, fg, bg, self._dilation(), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
+        prep = preprocess_window(a, fg, bg, self._dilation(a.shape[0]), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
         if self.method == 'fba':
             return self._forward_fba(prep, B, S, H, W)
         frames = [prep.x8[:, s].contiguous() for s in range(S)]

@@ -182,6 +182,26 @@ def gen_facade():
     save('facade', **arrs)
 
 
+def gen_facade_random():
+    """make_trimap with dilate_kernel=None (train_ddp.py's default): one radius per clip from torch's global generator
+    (models/model.py:60-64).  Stored: the trimaps, the radii the reference drew and the generator's next draw afterwards."""
+    arrs = {}
+    for tag, ctor, B, S, H, W, seed in (('gca', lambda: ref_model.FullModel_VMD('vmn_gca', agg_window=7), 3, 3, 48, 64, 1234),
+                                        ('gca6', lambda: ref_model.FullModel_VMD('vmn_gca', agg_window=7), 6, 5, 32, 40, 7),
+                                        ('dim', lambda: ref_model.FullModel('dim'), 4, 3, 40, 56, 99)):
+        fm = ctor()                                         # (weight initialisation consumes the generator: seed afterwards)
+        a, fg, bg = synthetic_window(B, S, H, W, seed=5)
+        torch.manual_seed(seed)
+        _, _, _, _, tris, trimasks, _ = fm.preprocess(a, fg, bg)
+        arrs[tag + '_next_draw'] = np.array(int(torch.randint(0, 2 ** 31 - 1, size=())))
+        torch.manual_seed(seed)
+        arrs[tag + '_radii'] = np.array([int(torch.randint(0, 26, size=())) for _ in range(B)])
+        arrs[tag + '_tris'] = (tris.numpy() * (255 if tag == 'dim' else 1)).round().astype(np.uint8)
+        arrs[tag + '_trimask'] = trimasks.numpy().astype(np.uint8)
+        arrs[tag + '_shape'] = np.array([B, S, H, W, seed])
+    save('facade_random', **arrs)
+
+
 # ----------------------------------------------------------------------------- whole window
 WINDOW_CASES = {
     # name: (B, S, H, W, dilate, window)
@@ -517,6 +537,6 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]                                   # e.g. `python gen_golden.py fba dim`; default: everything
-    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_vmn_index, gen_metrics, gen_single):
+    for fn in (gen_state_keys, gen_sn, gen_tam, gen_gca, gen_facade, gen_facade_random, gen_window, gen_eval, gen_dim, gen_fba, gen_vmn_dim, gen_vmn_index, gen_metrics, gen_single):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -123,6 +123,23 @@ def test_facade_preprocess_and_trimap():
     assert_close(oracle.l1_mask(x, y, torch.zeros_like(m)), g['l1_empty'], 1e-6, 1e-7)
 
 
+def test_facade_random_trimap_width_per_clip():
+    """dilate_kernel=None: one radius per clip, drawn in clip order from torch's generator (models/model.py:60-64)."""
+    g = golden('facade_random')
+    for tag in ('gca', 'gca6'):
+        B, S, H, W, seed = (int(v) for v in g[tag + '_shape'])
+        a, fg, bg = synthetic_window(B, S, H, W, seed=5)
+        torch.manual_seed(seed)
+        _, _, _, _, tris, trimasks, _ = oracle.preprocess(a, fg, bg, None)
+        assert int(torch.randint(0, 2 ** 31 - 1, size=())) == int(g[tag + '_next_draw']), 'generator state after the draws'
+        assert np.array_equal(tris.numpy().astype(np.uint8), g[tag + '_tris'])
+        assert np.array_equal(trimasks.numpy().astype(np.uint8), g[tag + '_trimask'])
+        assert len(set(g[tag + '_radii'].tolist())) > 1                      # the case really has different widths
+        # the same radii given explicitly
+        _, _, _, _, tris2, _, _ = oracle.preprocess(a, fg, bg, g[tag + '_radii'].tolist())
+        assert torch.equal(tris, tris2)
+
+
 @pytest.mark.parametrize('name', list(WINDOW_CASES))
 def test_window_forward_backward(name):
     B, S, H, W, dil, win = WINDOW_CASES[name]
