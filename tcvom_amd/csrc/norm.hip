@@ -106,6 +106,10 @@ __device__ __forceinline__ void bn_sync_exchange(const BnSync& sy, double (*s1)[
             }
             if (wall_clock64() - t0 > sy.timeout) {                // a peer never arrived: report, do not hang the device
                 if (sy.status) __hip_atomic_store(sy.status, (int)sy.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // ... and POISON this rank's sums: statistics from partial sums would differ between the ranks silently; NaN
+                // scale / shift / gradient coefficients turn the loss NaN at once (the host raises MailboxTimeout on every rank
+                // before the optimizer step: GradientAverager exchanges the status word, tcvom_amd/ddp.py)
+                pa = pb = __longlong_as_double(0x7ff8000000000000ll);
                 break;
             }
             __builtin_amdgcn_s_sleep(4);

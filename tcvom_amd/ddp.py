@@ -54,7 +54,10 @@ def convert_sync_batchnorm(module, process_group=None, mailbox='auto'):
 
 
 def sync_batchnorm_info(module):
-    """(transport, exchanges issued so far) of a converted module: 'mailbox' / 'allreduce' / None."""
+    """(transport, exchanges issued so far) of a converted module: 'mailbox' / 'allreduce' / None; 'pending' when the module
+    was converted by torch's own function and no BatchNorm has made a train-mode call yet (ops._sync_group adopts each
+    nn.SyncBatchNorm on its first one)."""
+    pending = False
     for m in module.modules():
         if getattr(m, 'sync', False):
             mb = getattr(m, 'sync_mailbox', None)
@@ -62,12 +65,14 @@ def sync_batchnorm_info(module):
                 return ('mailbox', mb.exchanges)
             from .ops import SYNC_ALLREDUCES
             return ('allreduce', SYNC_ALLREDUCES[0])
-    return (None, None)
+        pending = pending or isinstance(m, torch.nn.SyncBatchNorm)
+    return ('pending', 0) if pending else (None, None)
 
 
 class GradientAverager(object):
     """All-reduce(mean) of the gradients of `params` (DDP's reduction, train_ddp.py:275-280).  Parameters whose
-    .grad is None on this rank (unused in this step: DDP's find_unused_parameters=True case) contribute zeros.
+    .grad is None on this rank (unused in this step: DDP's find_unused_parameters=True case) contribute zeros when another
+    rank has a gradient for them and stay None when no rank has (`_fill_locally_unused`).
 
     The weight bank hands autograd views of ONE flat fp32 buffer (WeightBank.backward) and the BatchNorm arenas do
     the same, so most of the 25.6 M gradient elements already sit in a few contiguous spans: those are all-reduced
@@ -92,6 +97,8 @@ class GradientAverager(object):
         # other leaves -- BatchNorm scales, biases -- legitimately have their .grad by then)
         self._bank_params = {id(bank): bank.weight_params() for bank in banks}
         self.early_spans = 0     # diagnostic: spans started before backward returned, last step
+        self.globally_unused = 0  # diagnostic: parameters no rank had a gradient for, last step (left None)
+        self._cpu_group = None
         if self._active():       # (a one-process run keeps the bank's single-launch backward)
             import functools
             for bank in banks:
@@ -125,6 +132,52 @@ class GradientAverager(object):
         view = flat[lo:hi]
         work = dist.all_reduce(view, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True)
         self._early.append((view, work, flat.untyped_storage().data_ptr(), flat.storage_offset() + lo, hi - lo))
+
+    def _host_group(self):
+        """A process group whose collectives run on HOST tensors (the default group when it is gloo, else a gloo group created
+        collectively on first use): the per-step presence vector travels there without touching the GPU stream."""
+        if self._cpu_group is None:
+            if dist.get_backend() == 'gloo':
+                self._cpu_group = dist.group.WORLD
+            else:
+                try:
+                    self._cpu_group = dist.new_group(backend='gloo')
+                except Exception as e:                   # noqa: BLE001 -- (every rank fails or none: same build, same store)
+                    import warnings
+                    warnings.warn('GradientAverager: no host-side process group (%s); locally unused parameters contribute zeros '
+                                  'even when no rank used them' % e)
+                    self._cpu_group = False
+        return self._cpu_group
+
+    def _fill_locally_unused(self):
+        """DDP's find_unused_parameters=True rule (train_ddp.py:275-280): a parameter without a gradient on THIS rank contributes
+        zeros when ANY rank has one -- and keeps `.grad = None` when NO rank has one (DDP leaves the gradient of a globally unused
+        parameter untouched), so that Adam skips it: its weight decay must not move a frozen backbone (VMN freeze_backbone),
+        exactly as in a one-process run.  The presence vector (one int32 per parameter) is summed over the ranks on the HOST (a
+        2.4 KB gloo all-reduce: no device synchronisation); its last element carries the SyncBatchNorm mailbox status, so a
+        timed-out exchange on one rank raises MailboxTimeout on EVERY rank before the optimizer step."""
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        group = self._host_group()
+        if group is False:
+            return [self.params[i] for i in missing]
+        vec = torch.ones(len(self.params) + 1, dtype=torch.int32)
+        vec[missing] = 0
+        vec[-1] = 0
+        for mb in self._mailboxes():
+            vec[-1] += int(mb.status[0] != 0)
+        dist.all_reduce(vec, group=group)
+        if int(vec[-1]) != 0:
+            from .mailbox import MailboxTimeout
+            for mb in self._mailboxes():
+                mb.check()                                  # the rank that saw the timeout reports the exchange number
+            raise MailboxTimeout('SyncBatchNorm mailbox: an exchange timed out on another rank; the statistics of this step are '
+                                 'invalid (no optimizer step taken)')
+        self.globally_unused = sum(1 for i in missing if int(vec[i]) == 0)
+        return [self.params[i] for i in missing if int(vec[i]) != 0]
+
+    def _mailboxes(self):
+        from .mailbox import _MAILBOXES
+        return [mb for mb in _MAILBOXES.values() if mb is not None]
 
     @staticmethod
     def plan(grads, min_span):
@@ -164,8 +217,7 @@ class GradientAverager(object):
             return
         avg = dist.get_backend() == 'nccl'
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        missing = [p for p in self.params if p.grad is None]
-        for p in missing:
+        for p in self._fill_locally_unused():
             p.grad = torch.zeros_like(p)
 
         def covered(g):          # already being reduced by a span started from the bank hook
@@ -173,7 +225,7 @@ class GradientAverager(object):
                 return False
             sp, off = g.untyped_storage().data_ptr(), g.storage_offset()
             return any(sp == e[2] and e[3] <= off and off + g.numel() <= e[3] + e[4] for e in early)
-        grads = [p.grad for p in self.params]
+        grads = [p.grad for p in self.params if p.grad is not None]
         if early:
             # (parameters of the bank that do not require a gradient -- a frozen backbone -- leave holes in the spans: reduced
             #  along with the rest, harmless)

@@ -56,7 +56,7 @@ class DeepMatting(nn.Module):
         """x8: NHWC bf16 [B,H,W,8] = {normalised R,G,B, trimap, 0,0,0,0} -> alpha fp32 [B,1,H,W]."""
         training = self.training and not self.freeze_bn
         bank, cfgs = self._bank, self._cfgs
-        token = bank_token(bank, 1, training)
+        token = bank_token(bank, 1, training, self)
         x, idx = x8, []
         for stage in _STAGES:
             for tag in stage:

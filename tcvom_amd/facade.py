@@ -403,7 +403,7 @@ class EvalModel(FullModel):
                     prep = preprocess_window(tris[lo:hi].unsqueeze(0).to(dev), imgs[lo:hi].unsqueeze(0).to(dev), None, dil, 0.0)
                     X = prep.x8[0].contiguous()
                     U = prep.unk[0, :, ::TAM_OS, ::TAM_OS].contiguous()
-                    token = bank_token(bank, hi - lo, False)
+                    token = bank_token(bank, hi - lo, False, net)
                     emb, mid = net.encoder.run(X, U, token, False)
                     feat = net.decoder.run_front(emb, mid, token, False)
                     for k, i in enumerate(range(lo, hi)):
@@ -412,7 +412,7 @@ class EvalModel(FullModel):
                                    for key, v in mid.items() if key != 'unknown'}
                         mids[i]['unknown'] = U[k:k + 1]
                         unk8[i], trimask[i], gts[i] = U[k:k + 1], prep.trimask[0, k], prep.gts[0, k]
-                token = bank_token(bank, 1, False)
+                token = bank_token(bank, 1, False, net)
                 pred, _ab, _af = net.decoder.run_tail(feats[c], feats[p], feats[n], unk8[c], mids[c], token, False)
                 alphas[c] = torch.where(trimask[c] > 0, pred[0].float(), gts[c])
                 for i in [i for i in feats if i < c - 1]:               # frames no later window needs

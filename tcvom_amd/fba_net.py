@@ -205,7 +205,7 @@ class VMN_FBA(nn.Module):
         bank = self._bank
         training = self.training
         F = B * S
-        token = bank_token(bank, F, training)
+        token = bank_token(bank, F, training, self)
         fm = lambda t: t.transpose(0, 1).reshape((S * B,) + tuple(t.shape[2:]))          # frame-major [S*B, ...]
         X2, EX, U = fm(x2), fm(extras), fm(unk_small)
         lo, hi = B, (S - 1) * B
@@ -254,7 +254,7 @@ class MattingModule(nn.Module):
         """x2 [B,H/2,W/2,64] bf16 space-to-depth input, extras [B,H,W,8] bf16, img fp32 [B,3,H,W] -> pred fp32 [B,7,H,W]."""
         bank, training = self._bank, self.training
         F = x2.shape[0]
-        token = bank_token(bank, F, training)
+        token = bank_token(bank, F, training, self)
         try:
             bank.frames_per_op = F
             outs = self.encoder.run(x2, token, training)

@@ -107,7 +107,7 @@ class GuidedCxtAtten(nn.Module):
     def forward(self, f, alpha, unknown=None):
         assert self._own_bank, 'use .run() inside a network'
         training = self.training
-        token = bank_token(self._bank, 1, training)
+        token = bank_token(self._bank, 1, training, self)
         to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(H16)
         if unknown is None:
             unknown = torch.ones_like(alpha[:, :1])
@@ -382,7 +382,7 @@ class Generator(nn.Module):
     def run(self, x8, unk_u8):
         """x8 [B,H,W,8] bf16 (normalised RGB + one-hot trimap), unk_u8 uint8 [B,H/8,W/8] -> alpha fp32 [B,1,H,W]."""
         training = self.training
-        token = bank_token(self._bank, 1, training)
+        token = bank_token(self._bank, 1, training, self)
         emb, mid = self.encoder.run(x8, unk_u8, token, training)
         x = self.decoder.run_front(emb, mid, token, training)
         alpha = self.decoder.run_tail_single(x, mid, token, training)

@@ -378,7 +378,7 @@ class IndexMatting(nn.Module):
         """x8 [B, H, W, 8] bf16 (normalised RGB + 1-channel trimap) -> raw alpha prediction [B, 1, H, W] fp32."""
         from .weights import bank_token
         training = self.training
-        token = bank_token(self._bank, 1, training)
+        token = bank_token(self._bank, 1, training, self)
         l, mid = self.encoder.run(x8, None, token, training)
         pred = self.decoder.run_tail_single(self.decoder.run_front(l, mid, token, training), mid, token, training)
         self._bank.flush_bn_counters()

@@ -95,9 +95,10 @@ class ConvCfg(object):
         """bn: nn.BatchNorm2d, nn.GroupNorm (FBA base: statistics per sample, no running state) or None.
         pre_relu: activation fused into the conv epilogue BEFORE the norm (or the layer's only activation when there is
         no norm): ReLU, or LeakyReLU(pre_slope) for pre_slope == 0.01."""
-        self.bank, self.spec, self.bn = bank, spec, bn
-        if bn is not None:
-            bank.register_bn(bn)
+        self.bank, self.spec = bank, spec
+        # the norm module is read through the bank (property `bn`): WeightBank.adopt_norm_modules follows replacements in the
+        # module tree (torch's SyncBatchNorm conversion)
+        self._bn_idx = bank.register_bn(bn) if bn is not None else None
         assert pre_slope in (0.0, 0.01)
         self.act, self.pre_relu, self.unbias_mult, self.pre_slope = act, pre_relu, unbias_mult, pre_slope
         self.group_norm = isinstance(bn, torch.nn.GroupNorm)
@@ -109,6 +110,8 @@ class ConvCfg(object):
         self.tail_only = False
         self.tail_last = False              # ... and it is the last op of such a branch (its output is the tail's input)
         self._geo = {}
+
+    bn = property(lambda self: None if self._bn_idx is None else self.bank.bns[self._bn_idx])
 
     def geometry(self, N, H, W):
         key = (N, H, W)
@@ -143,19 +146,31 @@ class _Sync(tuple):
 
 
 def _sync_group(bn):
-    """_Sync when `bn` was converted by tcvom_amd.ddp.convert_sync_batchnorm and more than one rank is running (or the module
-    carries a one-rank loop-back mailbox: bench.py --sync-bn on one GPU, tests), else None.  With a mailbox the statistics are
-    exchanged inside the finalize kernels (tcvom_amd/mailbox.py); without one through an all-reduce of the process group."""
-    if not getattr(bn, 'sync', False):
+    """_Sync when `bn` takes its train-mode statistics over the ranks and more than one rank is running (or the module carries a
+    one-rank loop-back mailbox: bench.py --sync-bn on one GPU, tests), else None.  Two ways in, same result:
+    `tcvom_amd.ddp.convert_sync_batchnorm` (marks the modules, keeps their class) and torch's own
+    `nn.SyncBatchNorm.convert_sync_batchnorm` -- the line the reference runs, train_ddp.py:271-273 -- whose nn.SyncBatchNorm
+    modules are adopted on their first train-mode call: process group = the module's `process_group`, transport = the peer
+    mailbox of that group when it is available (a collective decision, taken at the same call on every rank), else one
+    all-reduce per BatchNorm call.  With a mailbox the statistics are exchanged inside the finalize kernels
+    (tcvom_amd/mailbox.py); without one through an all-reduce of the process group."""
+    stock = isinstance(bn, torch.nn.SyncBatchNorm)
+    if not getattr(bn, 'sync', False) and not stock:
         return None
     mb = getattr(bn, 'sync_mailbox', None)
     if mb is not None and mb.group is None and mb.world == 1:
         return _Sync((None, 1, mb))
     if not dist.is_available() or not dist.is_initialized():
         return None
-    group = getattr(bn, 'sync_group', None)
+    group = bn.sync_group if hasattr(bn, 'sync_group') else bn.process_group
     world = dist.get_world_size(group)
-    return _Sync((group, world, mb)) if world > 1 else None
+    if world <= 1:
+        return None
+    if not hasattr(bn, 'sync_mailbox'):          # a stock nn.SyncBatchNorm seen for the first time
+        from .mailbox import mailbox_for
+        mb = mailbox_for(group) if bn.weight.is_cuda else None
+        bn.sync, bn.sync_group, bn.sync_mailbox = True, group, mb
+    return _Sync((group, world, mb))
 
 
 def _phase_array(descs):
@@ -527,8 +542,10 @@ class DwCfg(object):
     values, not worth a packed copy), stride 1."""
 
     def __init__(self, bank, weight, bn, dilation=1, pad=0, act=ACT_RELU6):
-        self.bank, self.weight, self.bn, self.dilation, self.pad, self.act = bank, weight, bn, int(dilation), int(pad), act
-        bank.register_bn(bn)
+        self.bank, self.weight, self.dilation, self.pad, self.act = bank, weight, int(dilation), int(pad), act
+        self._bn_idx = bank.register_bn(bn)
+
+    bn = property(lambda self: self.bank.bns[self._bn_idx])
 
 
 class _DwBNAct(torch.autograd.Function):

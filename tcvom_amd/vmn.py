@@ -54,7 +54,7 @@ class FeatureAggregationModule(nn.Module):
         B, C, H, W = x.shape
         sh, sw = mask.shape[2] // H, mask.shape[3] // W
         small = mask[:, :, ::sh, ::sw] != 0                      # nearest down-sampling (VMN_model.py:22)
-        token = bank_token(self._bank, 3, self.training)
+        token = bank_token(self._bank, 3, self.training, self)
         out, attb, attf = self.run(_to_nhwc(x), _to_nhwc(b), _to_nhwc(f), small[:, 0].to(torch.uint8).contiguous(),
                                    token, self.training)
         return _to_nchw(out), attb, attf, small
@@ -117,7 +117,7 @@ class VMN(nn.Module):
         Returns (alphas list (None at the ends), attb, attf) for interior frames."""
         S = len(frames_x8)
         training = self.training
-        token = bank_token(self._bank, S, training)
+        token = bank_token(self._bank, S, training, self)
         front_training = training and not self.freeze_backbone
         if self.batched_frames:
             return self._run_batched(frames_x8, unk_u8, token, training, front_training)

@@ -107,6 +107,7 @@ class WeightBank(object):
         self.max_calls = 0
         self.bns, self.bn_ch, self._bn_sig, self._bn_cap = [], 0, None, 0
         self.bn_mask, self.window_id = [], 0
+        self._bn_sites = None             # (weakref(root), [(parent module, attribute, bank index)], count) of adopt_norm_modules
         self.frozen_groups = set()          # spec groups run in eval mode inside a training window (VMN freeze_backbone: {'frame'})
         self.frames_per_op = 1              # >1 while VMN.run pushes the S frames of a window through the layers together
         self._deferred = []
@@ -127,6 +128,39 @@ class WeightBank(object):
         self.bn_ch += _nch(bn)
         self._bn_sig = None
         return idx
+
+    def adopt_norm_modules(self, root):
+        """The ops find their BatchNorm through `bank.bns`; `torch.nn.SyncBatchNorm.convert_sync_batchnorm` (train_ddp.py:271-273)
+        REPLACES every BatchNorm of the module tree by a new nn.SyncBatchNorm built around the same Parameters -- and a later
+        `.to(device)` moves the buffers of the modules IN the tree only.  Called at the start of every window with the network
+        that owns the bank: each registered site (parent module, attribute name) is looked up again and a replaced module takes
+        the slot of the one it replaced, so that `.train()` / `.eval()`, the running statistics and the process group the
+        kernels see are those of the module the caller's tree holds.  (72 dict lookups per window.)"""
+        sites = self._bn_sites
+        if sites is None or sites[0]() is not root:
+            import weakref
+            # (a module converted BEFORE the first window is recognised by the Parameter it shares with the one it replaced)
+            by_weight = {id(bn.weight): i for i, bn in enumerate(self.bns) if getattr(bn, 'weight', None) is not None}
+            found = []
+            for parent in root.modules():
+                for name, child in parent._modules.items():
+                    idx = by_weight.get(id(getattr(child, 'weight', None))) if child is not None else None
+                    if idx is not None and isinstance(child, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm)):
+                        found.append((parent, name, idx))
+            sites = self._bn_sites = (weakref.ref(root), found, len(self.bns))
+        if sites[2] != len(self.bns):                      # a BatchNorm registered since (lazy construction): walk again
+            self._bn_sites = None
+            return self.adopt_norm_modules(root)
+        for parent, name, idx in sites[1]:
+            cur, old = parent._modules[name], self.bns[idx]
+            if cur is old:
+                continue
+            if not isinstance(cur, torch.nn.modules.batchnorm._BatchNorm) or _nch(cur) != _nch(old) or cur.weight is None:
+                raise TypeError('tcvom_amd: %s.%s was replaced by %s: the HIP network runs BatchNorm / SyncBatchNorm modules with '
+                                'affine parameters of the original width there' % (type(parent).__name__, name, type(cur).__name__))
+            cur._tcvom_bank_idx, cur._tcvom_ch_off = idx, old._tcvom_ch_off
+            self.bns[idx] = cur
+            self._bn_sig = None
 
     def _ensure_bn(self, frames, dev):
         if not self.bns:
@@ -632,5 +666,8 @@ class _BankToken(torch.autograd.Function):
         return (None, None, None) + tuple(grads) + tuple(ctx.bank.bn_backward())
 
 
-def bank_token(bank, frames, training):
+def bank_token(bank, frames, training, root=None):
+    """root: the network that owns the bank -- BatchNorm modules replaced in its tree since the last window are adopted first."""
+    if root is not None and bank.bns:
+        bank.adopt_norm_modules(root)
     return _BankToken.apply(bank, frames, training, *(bank.weight_params() + bank.bn_params()))

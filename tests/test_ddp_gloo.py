@@ -58,7 +58,18 @@ def _worker(rank, world, port, q):
     av = GradientAverager(ps)
     av.MIN_SPAN = 8
     av.average()
-    q.put(_plain((rank, flat_state, grads, float(loss), arena.clone(), av.last_plan, [p.grad.data_ptr() - arena.data_ptr() for p in ps])))
+    # a parameter NO rank has a gradient for (frozen backbone: VMN freeze_backbone) keeps .grad = None, as DDP leaves globally
+    # unused parameters untouched -- Adam's weight decay must not move it; one that only THIS rank lacks contributes zeros
+    fz = [nn.Parameter(torch.full((4,), 3.0)), nn.Parameter(torch.full((4,), 5.0)), nn.Parameter(torch.full((2,), 1.0))]
+    fz[1].grad = torch.full((4,), float(rank + 1))
+    if rank == 0:
+        fz[2].grad = torch.full((2,), 4.0)
+    av2 = GradientAverager(fz)
+    av2.average()
+    opt = torch.optim.Adam(fz, lr=0.1, weight_decay=0.5)
+    opt.step()
+    frozen = (fz[0].grad is None, av2.globally_unused, fz[0].detach().clone(), fz[1].grad.clone(), fz[2].grad.clone())
+    q.put(_plain((rank, flat_state, grads, float(loss), arena.clone(), av.last_plan, [p.grad.data_ptr() - arena.data_ptr() for p in ps], frozen)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,7 +85,11 @@ def test_two_rank_gradient_average_and_broadcast():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, s0, g0, l0, a0, plan0, offs0), (_, s1, g1, l1, a1, plan1, offs1) = res
+    (_, s0, g0, l0, a0, plan0, offs0, fz0), (_, s1, g1, l1, a1, plan1, offs1, fz1) = res
+    for none, n_unused, w, g1_, g2_ in (fz0, fz1):
+        assert none and n_unused == 1                          # left without a gradient on both ranks ...
+        assert torch.equal(w, torch.full((4,), 3.0))           # ... so the optimizer (weight decay 0.5) did not move it
+        assert torch.equal(g1_, torch.full((4,), 1.5)) and torch.equal(g2_, torch.full((2,), 2.0))
     base = torch.arange(40, dtype=torch.float32)
     for arena, scale in ((a0, 1.0), (a1, 2.0)):
         want = base * scale                               # outside the gradient views: untouched, rank-specific
@@ -242,3 +257,57 @@ def test_tensor_expression_sync_batchnorm_matches_one_process_batch():
         assert torch.allclose(out, ref.detach()[:, sl], atol=1e-5)
         assert torch.allclose(gx, x_all.grad[:, sl], atol=1e-5)
         assert torch.allclose(m, mean.detach()[:, 0], atol=1e-6) and torch.allclose(v, var.detach()[:, 0], atol=1e-5)
+
+
+def _stock_worker(rank, world, port, q):
+    """The reference's own lines (train_ddp.py:271-280) on the product model, host side: torch's SyncBatchNorm conversion
+    REPLACES the BatchNorm modules of the tree; the HIP ops must follow (WeightBank.adopt_norm_modules) and treat an
+    nn.SyncBatchNorm as converted (ops._sync_group); DistributedDataParallel(find_unused_parameters=True) must construct."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from models.model import FullModel_VMD
+    from tcvom_amd import ops
+    from tcvom_amd.ddp import banks_of, sync_batchnorm_info
+    torch.manual_seed(rank)
+    model = FullModel_VMD('vmn_gca', agg_window=7)
+    bank = banks_of(model)[0]
+    before = list(bank.bns)
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)                  # train_ddp.py:273
+    # (DDP refuses nn.SyncBatchNorm inside a CPU module -- the converted model under DDP runs in tests/test_gpu_syncbn.py; here DDP
+    #  wraps the un-converted product model, as train_ddp.py:271-280 does for FBA)
+    torch.manual_seed(rank)
+    plain = torch.nn.parallel.DistributedDataParallel(FullModel_VMD('vmn_gca', agg_window=7), find_unused_parameters=True)
+    net = model.NET
+    info0 = sync_batchnorm_info(model)
+    bank.adopt_norm_modules(net)                                                   # what every window does first
+    tree = {id(m) for m in net.modules()}
+    adopted = all(isinstance(b, nn.SyncBatchNorm) and id(b) in tree for b in bank.bns)
+    replaced = all(a is not b and a.weight is b.weight and a.running_mean is b.running_mean for a, b in zip(before, bank.bns))
+    cfg = net.encoder._cfgs['conv1'] if hasattr(net.encoder, '_cfgs') else None
+    sync = ops._sync_group(bank.bns[0])
+    model.eval()
+    eval_follows = not bank.bns[0].training and not bank.bns[-1].training
+    model.train()
+    w0 = torch.cat([p.detach().reshape(-1)[:4] for p in list(plain.module.NET.parameters())[:8]])      # DDP broadcast rank 0's weights
+    q.put(_plain((rank, info0[0], adopted, replaced, len(bank.bns), sync is not None and sync.world == 2 and sync.mailbox is None,
+                  eval_follows, w0, sync_batchnorm_info(model)[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_ddp_lines_on_product_model_host_side():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stock_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([_tensors(q.get(timeout=300)) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, info0, adopted, replaced, nbn, sync_ok, eval_follows, w0, info1 in res:
+        assert info0 == 'pending' and info1 == 'allreduce'       # adopted on the first _sync_group call (CPU weights: no mailbox)
+        assert adopted and replaced and nbn == 72
+        assert sync_ok and eval_follows
+    assert torch.equal(res[0][7], res[1][7])

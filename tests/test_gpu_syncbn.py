@@ -205,10 +205,130 @@ def test_sync_batchnorm_mailbox_timeout_is_reported_not_hung():
     ops._sync_group = lambda b: ops._Sync((None, 2, b.sync_mailbox)) if getattr(b, 'sync', False) else None
     try:
         t0 = time.time()
-        _run(cfg, bank, bn, w, xs, dzs)
+        got = _run(cfg, bank, bn, w, xs, dzs)
         assert time.time() - t0 < 10.0
+        # the statistics of the timed-out exchange are poisoned, not computed from partial sums: NaN outputs / gradients
+        assert bool(torch.isnan(got[0]).any()) and bool(torch.isnan(got[1]).any())
         with pytest.raises(MailboxTimeout):
             mb2.check()
     finally:
         ops._sync_group = real
         mb2.close()
+
+
+
+def _stock_worker(rank, world, port, out, transport):
+    """The reference's own lines (train_ddp.py:271-280: torch's SyncBatchNorm conversion, .to(device), DistributedDataParallel with
+    find_unused_parameters=True) on the product model against the tcvom_amd.ddp path (convert_sync_batchnorm +
+    broadcast_module_state + GradientAverager): same clips, same weights -> same alphas, gradients and running statistics."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TCVOM_SYNCBN=transport, TCVOM_MBOX_TIMEOUT_S='20')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm, sync_batchnorm_info
+        from tcvom_amd.facade import FullModel_VMD, train_step_loss
+        from tcvom_amd.synthetic import formula_tensor, synthetic_window
+
+        def fresh():
+            m = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+            m.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()})
+            return m
+        a, fg, bg = [t.to(dev) for t in synthetic_window(1, 3, 128, 160, seed=20 + rank)]
+
+        def step(model, net, average):
+            outs = model(a, fg, bg)
+            train_step_loss(outs).backward()
+            average()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None}
+            stats = {k: b.detach().float().clone() for k, b in net.named_buffers() if 'running' in k}
+            return outs[7].detach().float().clone(), grads, stats
+
+        # (A) the reference's lines, verbatim
+        model = fresh()
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = model.to(dev)
+        model = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True, device_ids=[0], output_device=0)
+        model.train()
+        assert sync_batchnorm_info(model)[0] == 'pending'
+        alpha_a, grads_a, stats_a = step(model, model.module.NET, lambda: None)
+        kind, n = sync_batchnorm_info(model)
+        assert kind == ('mailbox' if transport == 'mailbox' else 'allreduce') and n > 100, (kind, n)
+        bank = banks_of(model)[0]
+        assert all(isinstance(b, torch.nn.SyncBatchNorm) for b in bank.bns)
+        # (B) this repo's counterparts of the same lines
+        m2 = fresh().to(dev).train()
+        convert_sync_batchnorm(m2)
+        broadcast_module_state(m2)
+        av = GradientAverager([p for p in m2.parameters() if p.requires_grad], banks=banks_of(m2))
+        alpha_b, grads_b, stats_b = step(m2, m2.NET, av.average)
+        assert set(grads_a) == set(grads_b) and len(grads_a) > 200
+        gerr = max(float((grads_a[k] - grads_b[k]).norm() / (grads_b[k].norm() + 1e-12)) for k in grads_a)
+        serr = max(float((stats_a[k] - stats_b[k]).abs().max()) for k in stats_a)
+        # the gradients DDP left on the two ranks are the same (it averaged them)
+        flat = torch.cat([grads_a[k].reshape(-1) for k in sorted(grads_a)])
+        other = flat.clone()
+        dist.broadcast(other, 0)
+        torch.save(dict(alpha=float((alpha_a - alpha_b).abs().max()), gerr=gerr, serr=serr,
+                        ranks_agree=float((flat - other).abs().max())), out + str(rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('transport', ['mailbox', 'rccl'])
+def test_reference_ddp_lines_equal_tcvom_ddp_path(tmp_path, transport):
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_stock_worker, args=(2, _free_port(), out, transport), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(out + str(rank))
+        print(transport, rank, r)
+        assert r['alpha'] == 0.0, r                           # same statistics exchange, same kernels: bit-equal forward
+        assert r['gerr'] <= 2e-3 and r['serr'] <= 1e-6, r     # (weight gradients add with fp32 atomics: not bit-reproducible)
+        assert r['ranks_agree'] == 0.0, r
+
+
+def _frozen_worker(rank, world, port, out):
+    """with world_size > 1 the averager used to fill the gradients of a frozen backbone with zeros and Adam's weight
+    decay moved the "frozen" encoder in multi-GPU runs only."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TCVOM_MBOX_TIMEOUT_S='20')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm
+        from tcvom_amd.facade import FullModel_VMD, train_step_loss
+        from tcvom_amd.optim import FusedAdam
+        from tcvom_amd.synthetic import formula_tensor, synthetic_window
+        m = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12, freeze_backbone=True)
+        m.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()})
+        m = m.to(dev).train()
+        convert_sync_batchnorm(m)
+        broadcast_module_state(m)
+        params = [p for p in m.parameters() if p.requires_grad]
+        av = GradientAverager(params, banks=banks_of(m))
+        opt = FusedAdam(params, lr=1e-3, weight_decay=1e-2)
+        before = {k: p.detach().clone() for k, p in m.NET.named_parameters()}
+        a, fg, bg = [t.to(dev) for t in synthetic_window(1, 3, 128, 160, seed=30 + rank)]
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            train_step_loss(m(a, fg, bg)).backward()
+            av.average()
+            opt.step()
+        torch.cuda.synchronize()
+        moved = [k for k, p in m.NET.named_parameters() if not torch.equal(p.detach(), before[k])]
+        frozen_moved = [k for k in moved if k.startswith('encoder.')]
+        torch.save(dict(moved=len(moved), frozen_moved=frozen_moved, unused=av.globally_unused), out + str(rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frozen_backbone_stays_frozen_under_two_ranks_with_weight_decay(tmp_path):
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_frozen_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(out + str(rank))
+        print(rank, r['moved'], r['unused'], r['frozen_moved'][:3])
+        assert r['frozen_moved'] == [] and r['moved'] > 0 and r['unused'] > 100, r
