@@ -235,6 +235,41 @@ def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
                          '' if (H, W) == (FULL_H, FULL_W) else ', scaled to 3x%dx%d by the algorithmic FLOP ratio %.4f' % (FULL_H, FULL_W, ratio))}
 
 
+def other_configs():
+    """The BASELINE.json configurations the headline line does not time, each as a short run of THIS script in a subprocess on the
+    same GPU (HIP-event-free: the subprocess's own barrier-bracketed wall clock over its timed steps, as the headline): configs[1]
+    = GCA+TAM forward-only 3x512x512; configs[4] = FBA+TAM fwd+bwd 3x1088x1920 (with its own window_mfma_frac); and configs[2]
+    again in the OTHER 16-bit storage build of the library (TCVOM_DTYPE: the north star names bf16, the default build stores fp16)."""
+    import subprocess
+    import tcvom_amd._lib as L
+    other_dtype = 'bf16' if L.DTYPE_NAME == 'fp16' else 'fp16'
+    runs = (('config2_gca_tam_fwd_512', ['--height', '512', '--width', '512', '--forward-only', '--steps', '30', '--warmup', '5'], {}),
+            ('config5_fba_tam_fwd_bwd_1080p', ['--config', 'fba', '--steps', '6', '--warmup', '2'], {}),
+            ('config3_gca_tam_fwd_bwd_1080p_%s' % other_dtype, ['--steps', '12', '--warmup', '3'], {'TCVOM_DTYPE': other_dtype}))
+    out = {}
+    for name, flags, env in runs:
+        t0 = time.time()
+        e = dict(os.environ)
+        e.update(env)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+            e.pop(k, None)
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-cpu-baseline', '--no-profile', '--no-other-configs'] + flags,
+                               env=e, capture_output=True, text=True, timeout=600)
+            line = [l for l in p.stdout.splitlines() if l.startswith('{')]
+            if p.returncode != 0 or not line:
+                out[name] = {'error': (p.stderr or p.stdout)[-400:]}
+                continue
+            r = json.loads(line[-1])
+            out[name] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'window_mfma_frac', 'final_loss')}
+            out[name]['workload'] = r['config']['workload']
+            out[name]['forward_only'] = r['config'].get('forward_only', False)
+            out[name]['subprocess_s'] = round(time.time() - t0, 1)
+        except Exception as ex:                     # noqa: BLE001 -- the headline line must survive a failing side run
+            out[name] = {'error': repr(ex)[-400:]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -246,6 +281,11 @@ def main():
                     help='gca: the headline GCA+TAM window (BASELINE.json configs[2]); fba: FBA+TAM (configs[4], the heaviest base); '
                          'index: IndexNet+TAM (not a BASELINE config; 2 clips per step: its ASPP has a BatchNorm over the batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--forward-only', action='store_true',
+                    help='time the forward pass alone (train-mode statistics, no_grad): BASELINE.json configs[1] with --height 512 --width 512')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the `other_configs` object of the default 1-GPU run (config 2, config 5 and the bf16 build of config 3, each a '
+                         'short event-timed run of this script in a subprocess)')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--sync-bn', dest='sync_bn', action='store_true', default=None,
                     help='SyncBatchNorm statistics over the ranks, as train_ddp.py:271-273 converts every non-FBA model: the DEFAULT '
@@ -292,12 +332,24 @@ def main():
     # the banks finish the flat gradient in layer ranges; each range's all-reduce starts while the next still computes
     averager = GradientAverager(params, banks=banks_of(model))
 
+    ar_events = []           # (before, after) HIP events around the gradient averaging of every timed step (N > 1)
+
     def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return train_step_loss(model(a, fg, bg))
         out = model(a, fg, bg)
         loss = train_step_loss(out)
         model.zero_grad(set_to_none=True)
         loss.backward()
-        averager.average()
+        if world > 1 and ar_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            averager.average()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            averager.average()
         opt.step()
         return loss
 
@@ -311,6 +363,10 @@ def main():
         step()
     fence()
     sync_transport, sync_n0 = sync_batchnorm_info(model)
+    del ar_events[:]
+    mbox = next((getattr(m, 'sync_mailbox', None) for m in model.modules() if getattr(m, 'sync', False)), None)
+    if mbox is not None:
+        mbox.wait_stats(reset=True)
     t0 = time.time()
     for _ in range(args.steps):
         loss = step()
@@ -321,14 +377,34 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed)
     final_loss = float(loss.detach())
+    # ---- per-rank diagnostics of the N > 1 path (gathered to rank 0; the one-rank loop-back line carries the same fields)
+    # exposed all-reduce: time the compute stream spent inside GradientAverager.average() -- waiting for the spans whose all-reduce
+    # started during backward, plus the small remainder (BatchNorm arena, biases) -- per step, from HIP events on that stream
+    diag = {'rank': rank, 'device': dev_index,
+            'allreduce_exposed_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1), 4) if ar_events else 0.0,
+            'sync_bn_transport': sync_transport}
+    if mbox is not None:
+        mx, sm = mbox.wait_stats(reset=True)
+        diag.update(mailbox_max_wait_ms=round(mx, 4), mailbox_wait_ms_per_step=round(sm / max(args.steps, 1), 4),
+                    mailbox_exchanges_per_step=(sync_n1 - sync_n0) // max(args.steps, 1), mailbox_world=mbox.world,
+                    ipc_peer_devices=dict(mbox.peer_devices), ipc_crossed_devices=mbox.crossed_devices(),
+                    mailbox_self_test='passed' if mbox.world > 1 else 'loop-back (one rank)')
+    ar_events = None
+    diags = [diag]
+    if world > 1:
+        diags = [None] * world
+        dist.all_gather_object(diags, diag)
 
     result = None
     if rank == 0:
         win_per_s = world * clips * args.steps / elapsed
         gflop = window_gflop(H, W, args.config) if args.config != 'index' else None      # (no FLOP count taken for IndexNet)
+        mode = 'fwd' if args.forward_only else 'fwd+bwd'
+        if args.forward_only and gflop is not None:
+            gflop *= (GFLOP_FWD_CONV_1080P + GFLOP_FWD_GCA_1080P) / GFLOP_WINDOW_1080P       # the forward share of the window's work
         result = {
-            'metric': '1080p 3-frame windows/sec (fwd+bwd) %s' % base if (H, W) == (FULL_H, FULL_W)
-                      else '%dx%d 3-frame windows/sec (fwd+bwd) %s' % (H, W, base),
+            'metric': ('1080p 3-frame windows/sec (%s) %s' % (mode, base)) if (H, W) == (FULL_H, FULL_W)
+                      else '%dx%d 3-frame windows/sec (%s) %s' % (H, W, mode, base),
             'value': round(win_per_s, 4), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': L.DTYPE_NAME, 'data': 'synthetic',
@@ -342,17 +418,21 @@ def main():
                                     '2-scale trimap channels) fwd+bwd+grad-allreduce+Adam, L_alpha_comp+L_lap+L_grad+0.5L_dt+0.25L_att, '
                                     'one 3-frame %dx%d window per GPU per step, formula-initialised weights, train mode; %s storage '
                                     '(BASELINE config 5 names fp16)' % (H, W, L.DTYPE_NAME)),
-                       'global_batch_clips': world * clips, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(sync_bn)},
+                       'global_batch_clips': world * clips, 'frames': 3, 'height': H, 'width': W, 'parallelism': 'dp%d' % world, 'sync_bn': bool(sync_bn),
+                       'forward_only': bool(args.forward_only)},
             'final_loss': round(final_loss, 6),
             'dist': {'backend': backend if world > 1 else None, 'world_size': dist.get_world_size() if world > 1 else 1,
                      'sync_bn_transport': sync_transport,            # 'mailbox': in-kernel peer exchange; 'allreduce': one collective per BN call
                      'sync_bn_exchanges_per_step': (sync_n1 - sync_n0) // args.steps if sync_n1 is not None else None,
                      'grad_spans_overlapped_with_backward': averager.early_spans,
-                     'grad_allreduce_plan': averager.last_plan},
+                     'grad_allreduce_plan': averager.last_plan,
+                     'grads_unused_on_every_rank': averager.globally_unused,
+                     'visible_devices': torch.cuda.device_count(),
+                     'per_rank': diags},
             'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5) if gflop is not None else None,
         }
     # ---- roofline of the dominant kernel (event-instrumented extra step on rank 0's stream)
-    if not args.no_profile:
+    if not args.no_profile and not args.forward_only:
         agg = igemm_profile(step)
         if rank == 0 and agg:
             dom = max(agg, key=lambda k: agg[k][1])
@@ -393,6 +473,11 @@ def main():
                              'counter_gib_per_step': gib, 'counter_source': src}
     if world > 1:
         dist.barrier()
+    if (rank == 0 and world == 1 and not args.no_other_configs and not args.forward_only and args.config == 'gca'
+            and (H, W) == (FULL_H, FULL_W)):
+        del model, opt, averager, params
+        torch.cuda.empty_cache()
+        result['other_configs'] = other_configs()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if args.config != 'index':                      # (no CPU line for the extra IndexNet configuration)

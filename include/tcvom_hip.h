@@ -259,6 +259,8 @@ typedef struct {
     int64_t capacity;         /* doubles per (slot, sender): nframes * 2 * C must fit */
     int64_t timeout_ticks;    /* 100 MHz ticks a poll may spin (0: 30 s) */
     int32_t* status;          /* device-visible word (pinned host memory), or NULL */
+    int64_t* wait_ticks;      /* DEVICE int64[2] or NULL: [0] = longest pull (100 MHz ticks) seen so far (atomic max), [1] = sum of
+                               * the pulls, one sample per (exchange, workgroup): how long this rank waited for its slowest peer */
 } tcvom_bn_sync;
 int tcvom_bn_finalize_sync(const float* stats_partial, int32_t groups, int32_t C, int64_t count, int64_t unbias_count,
                            const float* gamma, const float* beta, float eps, float* scale_shift, float* saved,
@@ -273,6 +275,9 @@ int tcvom_bn_bwd_finalize_sync(const float* partial, int32_t groups, int32_t C, 
 int tcvom_mbox_alloc(int64_t bytes, void** ptr, void* handle64);
 int tcvom_mbox_open(const void* handle64, void** ptr);
 int tcvom_mbox_close(void* ptr);
+/* *device = the HIP device ordinal (in this process) the memory behind `ptr` lives on: a mapped peer mailbox that reports another
+ * device than the caller's own shows that hipIpcOpenMemHandle crossed devices (diagnostic of bench.py --gpus N) */
+int tcvom_mbox_device(const void* ptr, int32_t* device);
 int tcvom_mbox_free(void* ptr);
 /* in_relu != 0: y is the output of a fused ReLU (conv->ReLU->BN order, res_gca_enc.py:47-55) and the
  * gradient is additionally masked by y > 0 */

@@ -51,7 +51,7 @@ class SnScratch(C.Structure):
 class BnSync(C.Structure):
     """struct tcvom_bn_sync: one in-kernel SyncBatchNorm exchange (tcvom_amd/mailbox.py fills it)."""
     _fields_ = [('peers', C.c_void_p), ('world', C.c_int32), ('rank', C.c_int32), ('seq', C.c_uint32), ('ring', C.c_int32),
-                ('capacity', C.c_int64), ('timeout_ticks', C.c_int64), ('status', C.c_void_p)]
+                ('capacity', C.c_int64), ('timeout_ticks', C.c_int64), ('status', C.c_void_p), ('wait_ticks', C.c_void_p)]
 
 
 class SnDot(C.Structure):
@@ -113,6 +113,7 @@ _PROTOS = {
     'tcvom_mbox_alloc': [i64, C.POINTER(C.c_void_p), vp],
     'tcvom_mbox_open': [vp, C.POINTER(C.c_void_p)],
     'tcvom_mbox_close': [vp],
+    'tcvom_mbox_device': [vp, C.POINTER(C.c_int32)],
     'tcvom_mbox_free': [vp],
     'tcvom_sn_power_iteration': [vp, SP, vp, i32, vp, i32, vp, i32, i32, i32, vp],
     'tcvom_sn_pack': [vp, SP, vp, i32, i32, vp, vp, i64, i64, vp],

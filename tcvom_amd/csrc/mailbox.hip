@@ -59,3 +59,12 @@ extern "C" int tcvom_mbox_free(void* ptr) {
     if (e != hipSuccess) { (void)hipGetLastError(); return tcvom_fail(TCVOM_ERR_LAUNCH, "mbox_free: %s", hipGetErrorString(e)); }
     return TCVOM_OK;
 }
+
+extern "C" int tcvom_mbox_device(const void* ptr, int32_t* device) {
+    TCVOM_CHECK_ARG(ptr && device, "mbox_device: bad args");
+    hipPointerAttribute_t at;
+    const hipError_t e = hipPointerGetAttributes(&at, ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return tcvom_fail(TCVOM_ERR_LAUNCH, "mbox_device: hipPointerGetAttributes: %s", hipGetErrorString(e)); }
+    *device = (int32_t)at.device;
+    return TCVOM_OK;
+}

@@ -70,6 +70,7 @@ struct BnSync {
     long long cap2;                            // granules per (slot, sender) = 2 * capacity in doubles
     long long timeout;                         // wall_clock64() ticks (100 MHz) a pull may spin before it gives up
     int* status;                               // set to seq when a pull timed out (host-visible: pinned memory)
+    long long* wait;                           // device int64[2] or NULL: max / sum of the pull spin times (diagnostic)
 };
 
 // Threads (sl, cl) of a FIN_SL x 32 block; on entry the sl == 0 threads hold the LOCAL sums (a, b) of channel c of `frame`;
@@ -113,6 +114,13 @@ __device__ __forceinline__ void bn_sync_exchange(const BnSync& sy, double (*s1)[
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
+        }
+        // how long this rank waited for its neighbour's push: one sample per (exchange, workgroup), from the thread that pulls the
+        // NEXT rank's region (a peer's push; in a one-rank mailbox its own)
+        if (sy.wait && cl == 0 && frame == 0 && sl == (sy.rank + 1) % sy.world) {
+            const long long dt = wall_clock64() - t0;
+            atomicMax((unsigned long long*)sy.wait, (unsigned long long)dt);
+            atomicAdd((unsigned long long*)sy.wait + 1, (unsigned long long)dt);
         }
     }
     if (sl < FIN_SL) { s1[sl][cl] = pa; s2[sl][cl] = pb; }
@@ -527,7 +535,7 @@ static int stream_grid(int64_t n, int per_block) {
     return (int)b;
 }
 
-static const BnSync kNoSync = {nullptr, 1, 0, 0u, 0, 0, 0, nullptr};
+static const BnSync kNoSync = {nullptr, 1, 0, 0u, 0, 0, 0, nullptr, nullptr};
 
 // host view of tcvom_bn_sync -> kernel argument
 static int make_sync(const tcvom_bn_sync* s, int32_t C, int32_t nframes, BnSync* out, const char* who) {
@@ -544,6 +552,7 @@ static int make_sync(const tcvom_bn_sync* s, int32_t C, int32_t nframes, BnSync*
     out->slot_off = (long long)(s->seq % (uint32_t)s->ring) * s->world * out->cap2;
     out->timeout = s->timeout_ticks > 0 ? s->timeout_ticks : 3000000000ll;      // default 30 s
     out->status = s->status;
+    out->wait = (long long*)s->wait_ticks;
     return TCVOM_OK;
 }
 

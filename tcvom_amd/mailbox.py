@@ -45,6 +45,7 @@ class PeerMailbox(object):
         self.seq = 0
         self.exchanges = 0                      # diagnostic: exchanges issued so far
         self._opened = []
+        self.peer_devices = {}                  # rank -> HIP device ordinal the mapped peer mailbox reports (diagnostic)
         self._ptr = C.c_void_p()
         handle = (C.c_ubyte * 64)()
         nbytes = self.ring * self.world * self.capacity * 16
@@ -80,11 +81,19 @@ class PeerMailbox(object):
                     L.call('tcvom_mbox_open', (C.c_ubyte * 64).from_buffer_copy(h), C.byref(p))
                     self._opened.append(p)
                     bases[r] = p.value
+                    d = C.c_int32(-1)
+                    try:                                            # diagnostic only: which device the mapped memory reports
+                        L.call('tcvom_mbox_device', p, C.byref(d))
+                    except L.TcvomError:
+                        pass
+                    self.peer_devices[r] = int(d.value)
             self.table = torch.tensor(bases, dtype=torch.int64, device=self.device)
         # pinned host word the kernels write on a timeout: read by the host without a synchronisation
         self.status = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self.wait_ticks = torch.zeros(2, dtype=torch.int64, device=self.device)       # [max, sum] of the pull spin times (100 MHz ticks)
         self._sync = L.BnSync(peers=self.table.data_ptr(), world=self.world, rank=self.rank, seq=0, ring=self.ring,
-                              capacity=self.capacity, timeout_ticks=self.timeout_ticks, status=self.status.data_ptr())
+                              capacity=self.capacity, timeout_ticks=self.timeout_ticks, status=self.status.data_ptr(),
+                              wait_ticks=self.wait_ticks.data_ptr())
         # (every peer must have mapped every mailbox before the first push: mailbox_for() all-reduces a flag after construction;
         #  a direct user of this class calls dist.barrier() itself)
 
@@ -129,6 +138,21 @@ class PeerMailbox(object):
                 return ok
         finally:
             self._sync.timeout_ticks = saved_ticks
+
+    def wait_stats(self, reset=True):
+        """(longest pull in ms, sum of the pulls in ms) since the last reset: how long this rank's finalize kernels spun waiting
+        for the next rank's push (one sample per exchange and workgroup).  Synchronises the device."""
+        v = self.wait_ticks.tolist()
+        if reset:
+            self.wait_ticks.zero_()
+        return v[0] / 1e5, v[1] / 1e5
+
+    def crossed_devices(self):
+        """True when a mapped peer mailbox lives on another HIP device than this rank's own (hipIpcOpenMemHandle crossed devices);
+        None for a one-rank mailbox."""
+        if not self.peer_devices:
+            return None
+        return any(d != self.device.index for d in self.peer_devices.values())
 
     def check(self):
         """Raise if a kernel gave up waiting for a peer (no synchronisation: reads the pinned status word)."""
