@@ -464,6 +464,16 @@ int tcvom_loss_finalize(const float* acc, float* out, float weight, int32_t deno
                         int32_t window, int32_t accumulate, void* stream);
 int tcvom_adam_mt(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+/* The same with a device-side guard: when *skip_if_nonzero != 0 at execution time NOTHING is updated (the step of an
+ * overflowed backward is dropped on the device, without a host synchronisation; torch.cuda.amp.GradScaler's rule). */
+int tcvom_adam_mt_guarded(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t step, float grad_scale, const int32_t* skip_if_nonzero,
+                          void* stream);
+/* fp16 storage build: the conversions to the 16-bit type SATURATE at +-65504 (common.h h16_clamp).  `counters` (DEVICE int32[2]
+ * or NULL; process-wide, read when a kernel is launched) receives: [0] += 1 per workgroup of a BatchNorm-backward reduction that
+ * read a gradient element at the saturation value (an activation gradient overflowed under the current loss scale), [1] += 1 per
+ * workgroup of a BatchNorm apply pass that read a saturated conv output.  The caller zeroes them.  No-op in the bf16 build. */
+int tcvom_overflow_sink(int32_t* counters);
 
 /* ------------------------------------------------------------------ FBA base (config 5: FullModel_VMD('vmn_fba'))
  * Weight standardisation (models/FBA/layers_WS.py:13-23) lives in the weight table of tcvom_sn_pack: layers with kind

@@ -186,6 +186,8 @@ _PROTOS = {
     'tcvom_avgpool8': [vp, vp, i64, i32, i32, vp],
     'tcvom_att_bce': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, i64, i32, vp],
     'tcvom_att_bce_bwd': [vp, vp, vp, f32, vp, i64, i32, vp],
+    'tcvom_adam_mt_guarded': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp, vp],
+    'tcvom_overflow_sink': [vp],
     'tcvom_loss_finalize': [vp, vp, f32, i32, f32, i32, i32, vp],
     'tcvom_adam_mt': [vp, vp, i32, f32, f32, f32, f32, f32, i64, f32, vp],
     'tcvom_abi_version': [],

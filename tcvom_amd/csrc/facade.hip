@@ -300,7 +300,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, float* __res
 // table: per tensor 5 int64 words {param, grad, exp_avg, exp_avg_sq, numel}; work: per block {tensor, chunk}
 __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ table, const int* __restrict__ work,
                                                    float lr, float beta1, float beta2, float eps, float wd,
-                                                   float bc1, float bc2_sqrt, float grad_scale) {
+                                                   float bc1, float bc2_sqrt, float grad_scale, const int* __restrict__ skip) {
+    if (skip && *skip != 0) return;                                   // the backward of this step overflowed: no update (block-uniform)
     const int64_t* T = table + (int64_t)work[blockIdx.x * 2] * 5;
     float* p = reinterpret_cast<float*>(T[0]);
     const float* g = reinterpret_cast<const float*>(T[1]);
@@ -434,12 +435,18 @@ extern "C" int tcvom_loss_finalize(const float* acc, float* out, float weight, i
     TCVOM_LAUNCH_CHECK("loss_finalize");
     return TCVOM_OK;
 }
-extern "C" int tcvom_adam_mt(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+extern "C" int tcvom_adam_mt_guarded(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, int64_t step, float grad_scale, const int32_t* skip_if_nonzero,
+                                     void* stream) {
     TCVOM_CHECK_ARG(table && work && nblocks > 0 && step >= 1, "adam_mt: bad args");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, table, work, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, table, work, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                       (const int*)skip_if_nonzero);
     TCVOM_LAUNCH_CHECK("adam_mt");
     return TCVOM_OK;
+}
+extern "C" int tcvom_adam_mt(const int64_t* table, const int32_t* work, int32_t nblocks, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+    return tcvom_adam_mt_guarded(table, work, nblocks, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
 }

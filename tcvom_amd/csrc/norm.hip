@@ -235,6 +235,24 @@ __device__ __forceinline__ void load_coef8(const float* __restrict__ p, float* f
     const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
+// ---------------------------------------------------------------- fp16 build: saturation counters (tcvom_overflow_sink)
+// process-wide: the backward kernels are launched from autograd's worker thread, not from the thread that set the sink
+#include <atomic>
+static std::atomic<int*> g_overflow_sink{nullptr};
+extern "C" int tcvom_overflow_sink(int32_t* counters) {
+    g_overflow_sink.store((int*)counters, std::memory_order_relaxed);
+    return TCVOM_OK;
+}
+#ifdef TCVOM_F16
+__device__ __forceinline__ unsigned sat8(const uint4& q) {
+    // |x| == 65504 = 0x7bff in any of the 8 halves
+    auto h2 = [](unsigned u) { return (unsigned)((u & 0x7fffu) == 0x7bffu) | (unsigned)(((u >> 16) & 0x7fffu) == 0x7bffu); };
+    return h2(q.x) | h2(q.y) | h2(q.z) | h2(q.w);
+}
+#else
+__device__ __forceinline__ unsigned sat8(const uint4&) { return 0u; }
+#endif
+
 template <bool YF32> struct YRaw { uint4 a; };
 template <> struct YRaw<true> { float4 a, b; };
 template <bool YF32>
@@ -257,10 +275,11 @@ template <bool YF32>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const void* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
-    int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride)
+    int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int* __restrict__ overflow)
 {
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
+    unsigned sat = 0u;
     // blockIdx.y = frame of a batched call: P pixels per frame, own (scale, shift) vector
     scale_shift += blockIdx.y * slot_stride;
     const int64_t fo = (int64_t)blockIdx.y * P * C8;
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0}, n2 = res2 ? res2[vn] : uint4{0, 0, 0, 0};
         float f[8], r1[8], r2[8];
         unpack_yraw<YF32>(yr, f);
+        if constexpr (!YF32) sat |= sat8(yr.a);
         unpack8(q1, r1);
         unpack8(q2, r2);
 #pragma unroll
@@ -296,6 +316,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         if (!more) break;
         p = pn; v = vn; yr = yn; q1 = n1; q2 = n2;
     }
+    if (overflow && sat) atomicAdd(overflow + 1, 1);                  // a conv output at the fp16 saturation value (never in a healthy step)
 }
 
 // ---------------------------------------------------------------- backward, pass 1: per-channel sums
@@ -304,9 +325,11 @@ template <bool YF32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
-    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1)
+    float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1,
+    int* __restrict__ overflow)
 {
     extern __shared__ float red[];        // [2][256][8]
+    unsigned sat = 0u;
     const int tid = threadIdx.x;
     // dz2 may cover the frames dz2_f0 .. dz2_f1 - 1 only (a consumer that ran for the interior frames of a window): zero elsewhere
     if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             float g[8], g2[8], yy[8], r1[8];
             unpack8(qg, g);
             unpack8(qh, g2);
+            sat |= sat8(qg) | sat8(qh);
             unpack_yraw<YF32>(yr, yy);
             unpack8(q1, r1);
 #pragma unroll
@@ -358,6 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             p = pn; qg = ng; qh = nh; yr = yn; q1 = n1;
         }
     }
+    if (overflow && __any(sat != 0u) && (tid & 63) == 0) atomicAdd(overflow, 1);      // (never taken in a healthy step)
     float* r_g = red;                 // [256][8]
     float* r_x = red + 256 * 8;
 #pragma unroll
@@ -690,10 +715,12 @@ extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const voi
     const dim3 grid(cdiv(pixels, rpb), nframes);
     if (y_fp32)
         hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
-                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride);
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
+                           g_overflow_sink.load(std::memory_order_relaxed));
     else
         hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
-                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride);
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
+                           g_overflow_sink.load(std::memory_order_relaxed));
     TCVOM_LAUNCH_CHECK("bn_apply");
     return TCVOM_OK;
 }
@@ -726,11 +753,11 @@ extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1);
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed));
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1);
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed));
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
 }

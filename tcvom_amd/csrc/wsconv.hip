@@ -599,7 +599,9 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
         if (d->in_bstride != (long long)d->N * d->H * d->W * d->C || d->out_bstride != (long long)d->N * d->H * d->W * d->ldo) return p;
         if (d->vec_bstride != 0) return p;
     }
-    if ((long long)d->N * nb * d->H * d->W * d->C >= (1ll << 31) || (long long)d->N * nb * d->H * d->W * d->ldo >= (1ll << 31)) return p;
+    // (one FRAME must stay below 2^31 elements -- the conv engine's own limit, igemm.hip; a frame-batched launch whose frames
+    //  together exceed it is split into runs of frames by wsconv_try_launch: fragment-major weights have no other kernel)
+    if ((long long)d->N * d->H * d->W * d->C >= (1ll << 31) || (long long)d->N * d->H * d->W * d->ldo >= (1ll << 31)) return p;
     for (int t = 0; t < 9; ++t) p.wslot[t] = -1;
     int n = 0;
     for (int t = 0; t < d->ntaps; ++t) {
@@ -667,36 +669,52 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     a.w_bstride = nb > 1 ? d->w_bstride : 0;
     a.stats_group_offset = d->stats_group_offset;
     a.stats_bstride = nb > 1 ? d->stats_bstride : 0;
-    a.out_bytes = (unsigned)((long long)d->N * nb * d->H * d->W * d->ldo * 2);
-    a.in_bytes = (unsigned)((long long)d->N * nb * d->H * d->W * d->C * 2);
     for (int t = 0; t < 9; ++t) a.wslot[t] = p.wslot[t];
     a.w_frag = d->w_layout == 1;
     a.trace = ws_trace_buffer();
-    ws_grid(d, p, &a.tiles_per_frame, &a.tiles_per_wg, &a.wgs_per_frame);
+    ws_grid(d, p, &a.tiles_per_frame, &a.tiles_per_wg, &a.wgs_per_frame);      // (from the WHOLE batch: the statistics layout the caller sized)
     const long long gpf = p.C == 128 ? a.tiles_per_frame : (long long)a.wgs_per_frame * ws_ps(p);
     if (stats && nb > 1 && d->stats_bstride < gpf)
         return tcvom_fail(TCVOM_ERR_ARG, "wsconv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);
     {
         const long long sb = ((long long)a.stats_group_offset + (nb > 1 ? (long long)(nb - 1) * a.stats_bstride : 0) + gpf) * 2 * d->K * 4;
-        if (sb >= (1ll << 32)) return 0;
+        if (sb >= (1ll << 32)) return d->w_layout == 1 ? tcvom_fail(TCVOM_ERR_ARG, "wsconv: statistics buffer beyond 4 GiB") : 0;
         a.stats_bytes = (unsigned)sb;
     }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    const dim3 grid(a.wgs_per_frame * nb);
-    if (p.C == 64) {
-        auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32>;
-        constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
-        static bool attr = false;
-        if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
-    } else {
-        auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16>;
-        constexpr size_t lds_bytes = 2 * WsCfg<128, 4, 1, 4, 2, 16>::SLOTB + 1024 + WsCfg<128, 4, 1, 4, 2, 16>::XCHB + 128 * 4;
-        static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-        static bool attr = false;
-        if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+    // frames per launch: the buffer descriptors of the kernel address 32-bit byte ranges -- a batch whose frames together reach
+    // 2^31 elements goes out as runs of frames (same tiles, same statistics groups per frame)
+    const long long frame_elems = (long long)d->N * d->H * d->W * (d->C > d->ldo ? d->C : d->ldo);
+    long long fmax = ((1ll << 31) - 1) / (frame_elems > 0 ? frame_elems : 1);
+    static const int test_fmax = getenv("TCVOM_WS_MAX_FRAMES") ? atoi(getenv("TCVOM_WS_MAX_FRAMES")) : 0;      // (tests: force the split)
+    if (test_fmax > 0 && test_fmax < fmax) fmax = test_fmax;
+    if (fmax < 1) fmax = 1;
+    const WsArgs base = a;
+    for (int f0 = 0; f0 < nb; f0 += (int)fmax) {
+        const int nf = nb - f0 < fmax ? nb - f0 : (int)fmax;
+        a = base;
+        a.in = base.in + (long long)f0 * d->N * d->H * d->W * d->C;
+        a.out = (char*)base.out + (long long)f0 * d->N * d->H * d->W * d->ldo * 2;
+        a.wgt = base.wgt + (long long)f0 * base.w_bstride;
+        a.stats_group_offset = base.stats_group_offset + (int)((long long)f0 * base.stats_bstride);
+        a.out_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->ldo * 2);
+        a.in_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->C * 2);
+        const dim3 grid(a.wgs_per_frame * nf);
+        if (p.C == 64) {
+            auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32>;
+            constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
+            static bool attr = false;
+            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+        } else {
+            auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16>;
+            constexpr size_t lds_bytes = 2 * WsCfg<128, 4, 1, 4, 2, 16>::SLOTB + 1024 + WsCfg<128, 4, 1, 4, 2, 16>::XCHB + 128 * 4;
+            static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+            static bool attr = false;
+            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+        }
     }
     if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "wsconv: %s", hipGetErrorString(e));
     hipError_t e2 = hipGetLastError();

@@ -13,8 +13,10 @@ unknown-pixel test of the crop search and the validation padding run on the devi
 Directory layout, file lists, frame neighbourhoods, the random draws of the crop search (python `random`, same order as the
 reference) and every rounding step follow dataset/VMD.py; line references below.  The optical-flow branch (`no_flow=False`:
 `fg, bg, a, wb, wf, idx`, VMD.py:203-213, 236-245, 153-165, 274-300) decodes the 16-bit flow files on the host and runs
-`flow_crop_and_resize` (VMD.py:68-126) on the device.  The colour / JPEG augmentation of training samples (VMD.py:50-55,
-253-262) runs on the host in the loader workers, as in the reference (`tcvom_amd/augment.py`).
+`flow_crop_and_resize` (VMD.py:68-126) on the device.  NOT built: the colour / JPEG augmentation of training samples
+(VMD.py:50-55, 253-262 -- imgaug's AddToHueAndSaturation / JpegCompression): it is outside SURVEY.md section 8, and imgaug /
+OpenCV are not in this image, so its arithmetic cannot be pinned against the reference; a restatement without vectors was
+removed in round 4.  Training samples get the geometric augmentation only.
 """
 import ctypes as C
 import json
@@ -163,9 +165,12 @@ class VideoMattingDataset(torch.utils.data.Dataset):
     SCALES = [1.0, 1.25, 1.5, 1.75, 2.0]              # VMD.py:131
 
     def __init__(self, data_root, image_shape, plus1, mode, use_subset=False, no_flow=False, precomputed_val=None,
-                 sample_length=5, device=None, worker_arithmetic=True, color_aug=True):
-        """color_aug: training samples also get the reference's colour / JPEG augmentation (VMD.py:50-55, 253-262;
-        tcvom_amd/augment.py); False = geometric crops only (what the bit-exact loader tests compare)."""
+                 sample_length=5, device=None, worker_arithmetic=True, color_aug=False):
+        """color_aug: the reference's imgaug colour / JPEG augmentation of training samples (VMD.py:50-55, 253-262) is not built
+        (see the module docstring); asking for it raises."""
+        if color_aug:
+            raise NotImplementedError('dataset.VMD: the imgaug colour / JPEG augmentation (VMD.py:253-262) is not part of this build '
+                                      '(outside SURVEY.md section 8; no imgaug / OpenCV here to pin it against)')
         assert mode in ('train', 'val')
         if precomputed_val is not None:
             assert mode == 'val'
@@ -329,9 +334,6 @@ class VideoMattingDataset(torch.utils.data.Dataset):
             crop = (ph, pw, nsize[0], nsize[1])
             fg = self._crop_resize(fg_u8, bgr, ph, pw, nsize[0], nsize[1], Ho, Wo, self.image_form)
             bg = self._crop_resize(bg_u8, bgr, ph, pw, nsize[0], nsize[1], Ho, Wo, self.image_form)
-            if self.color_aug:
-                from .augment import augment_clip
-                fg, bg = augment_clip(fg, bg)                       # VMD.py:253-262 (after the crop, before stacking)
         elif self.precomputed_val is not None:
             fg = self._pad(self._crop_resize(fg_u8, bgr, 0, 0, Hs, Ws, Hs, Ws), Ho, Wo, IMG_PADDING_VALUE)
             bg = self._pad(self._crop_resize(bg_u8, bgr, 0, 0, Hs, Ws, Hs, Ws), Ho, Wo, IMG_PADDING_VALUE)

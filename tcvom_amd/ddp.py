@@ -219,6 +219,11 @@ class GradientAverager(object):
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         for p in self._fill_locally_unused():
             p.grad = torch.zeros_like(p)
+        # fp16 build: an overflowed backward on ANY rank drops the step on every rank (ops.LossScaler: the guarded Adam reads it)
+        from .ops import SCALER
+        ovf = None
+        if SCALER.enabled and self.params and self.params[0].is_cuda:
+            ovf = dist.all_reduce(SCALER.counter(self.params[0].device), op=dist.ReduceOp.MAX, async_op=True)
 
         def covered(g):          # already being reduced by a span started from the bank hook
             if not early or not g.is_contiguous():
@@ -248,6 +253,8 @@ class GradientAverager(object):
         for bucket in buckets:
             flat = torch.cat([g.reshape(-1) for g in bucket])
             works.append((flat, bucket, dist.all_reduce(flat, op=op, async_op=True)))
+        if ovf is not None:
+            ovf.wait()
         for flat, bucket, work in works:
             work.wait()
             if not avg:

@@ -219,7 +219,7 @@ class FullModel(nn.Module):
             self.NET = self.ARCH_DICT[model]()
         from .ddp import banks_of
         for bank in banks_of(self.NET):                        # fp16 build: the network's backward runs under a loss scale (ops.py)
-            bank.loss_scale = ops.LOSS_SCALE
+            ops.SCALER.register(bank)                              # (bank.loss_scale; halves after an overflowed backward: ops.LossScaler)
         self.method = model[model.rfind('_') + 1:]
         self.TRIMAP_CHANNEL = self.TRIMAP_CHANNEL_DICT[self.method]
         self.att_thres, self.label_smooth = 0.3, 0.2          # FullModel_VMD's defaults (its forward serves VMN archs here too)

@@ -30,6 +30,84 @@ H16 = L.ACT_DTYPE            # torch.bfloat16 or torch.float16: the 16-bit stora
 # ops called directly (tests, tools) are not scaled.  bf16 (8 exponent bits) needs none.
 import os as _os
 LOSS_SCALE = float(_os.environ.get('TCVOM_LOSS_SCALE', '65536' if L.DTYPE_NAME == 'fp16' else '1'))
+class LossScaler(object):
+    """Overflow guard + dynamic loss scale of the fp16 build (torch.cuda.amp.GradScaler's rule, without a host synchronisation).
+
+    The 16-bit conversions saturate at +-65504 instead of producing inf (csrc/common.h), so an overflowing activation gradient
+    would be clipped silently.  The BatchNorm-backward reductions -- which read every activation gradient of the network --
+    count workgroups that saw an element AT the saturation value into a device counter (`tcvom_overflow_sink`; forward: conv
+    outputs read by the BatchNorm apply pass, counter [1]).  Per optimizer step (FusedAdam.step):
+      * the Adam kernel reads the counter ON THE DEVICE and updates nothing when it is non-zero (`tcvom_adam_mt_guarded`);
+      * the counter is copied to pinned memory asynchronously and zeroed; the host looks at it one step later (the copy of step
+        t - 1 has long finished when step t's optimizer call runs): after an overflow the scale of every registered bank halves
+        (floor 1) and the Adam step counters of the skipped step are taken back; after `growth_interval` clean steps it doubles,
+        up to its initial value (the calibrated 2^16: gradient maxima of 1e-5 .. 4e-3 sit at 1 .. 300).
+    With several ranks GradientAverager all-reduces (MAX) the counter, so every rank skips the same steps."""
+
+    def __init__(self, init_scale, growth_interval=1000):
+        import weakref
+        self.init_scale, self.scale, self.growth_interval = float(init_scale), float(init_scale), int(growth_interval)
+        self.banks = weakref.WeakSet()
+        self.counters = {}           # device index -> (device int32[2], pinned int32[2, 2], [event, event])
+        self.clean_steps, self.skipped_steps, self.forward_saturations, self.t = 0, 0, 0, 0
+        self.enabled = L.DTYPE_NAME == 'fp16' and self.init_scale != 1.0 and _os.environ.get('TCVOM_NO_OVERFLOW_GUARD') is None
+
+    def register(self, bank):
+        bank.loss_scale = self.scale
+        self.banks.add(bank)
+
+    def counter(self, device):
+        """The device counter pair of `device` (created on first use and announced to the library)."""
+        idx = torch.device(device).index or 0
+        ent = self.counters.get(idx)
+        if ent is None:
+            dev = torch.zeros(2, dtype=torch.int32, device=torch.device('cuda', idx))
+            ent = self.counters[idx] = (dev, torch.zeros((2, 2), dtype=torch.int32).pin_memory(), [None, None])
+            L.call('tcvom_overflow_sink', L.ptr(dev))
+        return ent[0]
+
+    def _set_scale(self, s):
+        self.scale = s
+        for bank in self.banks:
+            bank.loss_scale = s
+
+    def before_step(self, device):
+        """Host side, at the start of an optimizer step: evaluate the read-back of the PREVIOUS step.  Returns True when that
+        step was skipped on the device (the caller takes its step counters back)."""
+        ent = self.counters.get(torch.device(device).index or 0)
+        if ent is None:
+            return False
+        ev = ent[2][(self.t - 1) & 1]
+        if ev is None:
+            return False
+        ev.synchronize()                                   # recorded a whole step ago: returns at once
+        ent[2][(self.t - 1) & 1] = None
+        bwd, fwd = (int(v) for v in ent[1][(self.t - 1) & 1])
+        self.forward_saturations += fwd
+        if bwd:
+            self.skipped_steps += 1
+            self.clean_steps = 0
+            self._set_scale(max(self.scale * 0.5, 1.0))
+            return True
+        self.clean_steps += 1
+        if self.clean_steps >= self.growth_interval and self.scale < self.init_scale:
+            self.clean_steps = 0
+            self._set_scale(min(self.scale * 2.0, self.init_scale))
+        return False
+
+    def after_step(self, device):
+        """Stream side, after the guarded Adam launch: read the counters back asynchronously and zero them for the next step."""
+        ent = self.counters[torch.device(device).index or 0]
+        slot = self.t & 1
+        ent[1][slot].copy_(ent[0], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[2][slot] = ev
+        ent[0].zero_()
+        self.t += 1
+
+
+SCALER = LossScaler(LOSS_SCALE)
 SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
 

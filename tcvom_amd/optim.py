@@ -14,6 +14,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
         self.table_rebuilds = 0        # diagnostic: how often the pointer table had to be rebuilt
+        self._last_step_of = {}        # id(state) -> step number handed to the last launch (taken back when that step was dropped)
 
     def _table(self, key, plist):
         # the kernel writes through the cached pointers: exp_avg / exp_avg_sq are part of the signature, so that a
@@ -55,6 +56,19 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        # fp16 build: overflow guard + dynamic loss scale (ops.LossScaler): the step is dropped ON THE DEVICE when the backward
+        # saturated; the host learns of it one step later and takes the step counters of the dropped step back
+        from .ops import SCALER
+        guard, dev0 = None, None
+        if SCALER.enabled:
+            dev0 = next((p.device for g in self.param_groups for p in g['params'] if p.grad is not None and p.is_cuda), None)
+            if dev0 is not None:
+                if SCALER.before_step(dev0):
+                    for st in self.state.values():
+                        if st and int(st.get('step', 0)) == self._last_step_of.get(id(st), -1):
+                            st['step'] = int(st['step']) - 1
+                guard = L.ptr(SCALER.counter(dev0))
+        self._last_step_of = {}
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group['params'] if p.grad is not None]
             if not plist:
@@ -72,6 +86,7 @@ class FusedAdam(torch.optim.Optimizer):
                 # the bias correction uses each parameter's OWN step count (torch.optim.Adam): a parameter that receives its
                 # first gradient later than the others (find_unused_parameters) runs in its own launch
                 st['step'] = int(st['step']) + 1
+                self._last_step_of[id(st)] = st['step']
                 by_step.setdefault(st['step'], []).append(p)
             b1, b2 = group['betas']
             if len(self._tables) > 64:                      # step groups come and go: no unbounded cache of pointer tables
@@ -80,6 +95,8 @@ class FusedAdam(torch.optim.Optimizer):
                 # several step groups: keyed by the parameter set (stable from step to step), not by the step count
                 key = (gi, False) if len(by_step) == 1 else (gi, tuple(id(p) for p in ps))
                 _, table, work, nblk = self._table(key, ps)
-                L.call('tcvom_adam_mt', L.ptr(table), L.ptr(work), nblk, float(group['lr']), float(b1), float(b2),
-                       float(group['eps']), float(group['weight_decay']), int(step), float(grad_scale), L.stream_ptr())
+                L.call('tcvom_adam_mt_guarded', L.ptr(table), L.ptr(work), nblk, float(group['lr']), float(b1), float(b2),
+                       float(group['eps']), float(group['weight_decay']), int(step), float(grad_scale), guard, L.stream_ptr())
+        if guard is not None:
+            SCALER.after_step(dev0)
         return loss

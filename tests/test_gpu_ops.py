@@ -1151,3 +1151,71 @@ def test_window_losses_vs_oracle():
     assert_close(alphas.cpu()[:, 1:-1], al[:, 1:-1].clamp(0, 1), 1e-6, 1e-6, 'alphas')
     for got, want in zip(dp, rp):
         assert_close(got.grad.cpu(), want.grad, 1e-3, 1e-9 + 1e-4 * float(want.grad.abs().max()), 'grad')
+
+
+def test_fp16_overflow_guard_drops_the_step_and_halves_the_loss_scale():
+    """the fp16 conversions saturate at +-65504, so an overflowing activation gradient was clipped silently.  The
+    BatchNorm-backward reductions count workgroups that read a saturated gradient element (tcvom_overflow_sink); FusedAdam drops
+    the step ON THE DEVICE (tcvom_adam_mt_guarded) and the host, one step later, halves the loss scale of the registered banks and
+    takes the dropped step's counters back (ops.LossScaler; torch.cuda.amp.GradScaler's rule)."""
+    import tcvom_amd._lib as L
+    from tcvom_amd import ops
+    from tcvom_amd.optim import FusedAdam
+    from tcvom_amd.weights import WeightBank
+    if L.DTYPE_NAME != 'fp16':
+        pytest.skip('bf16 storage has fp32 range: no loss scale, no guard')
+    sc = ops.SCALER
+    assert sc.enabled
+    saved = (sc.scale, sc.clean_steps, sc.skipped_steps)
+    bank = WeightBank()
+    sc.register(bank)
+    try:
+        sc._set_scale(65536.0)
+        cnt = sc.counter(DEV)
+        # (1) the reduction kernel counts saturated gradient elements, and only those
+        Cn, P = 64, 4096
+        x = hu('ovf.x', (1, P, Cn)).to(DEV).to(H16)
+        dz = (hu('ovf.dz', (1, P, Cn)) * 100).to(DEV).to(H16)
+        ss = torch.cat([torch.ones(Cn), torch.zeros(Cn)]).to(DEV)
+        stat = torch.cat([torch.zeros(Cn), torch.ones(Cn)]).to(DEV)
+        groups = L.call('tcvom_bn_bwd_groups', P, Cn)
+        part = torch.empty((groups, 2, Cn), dtype=torch.float32, device=DEV)
+
+        def reduce_pass(g):
+            L.call('tcvom_bn_bwd_reduce', L.ptr(g), None, L.ptr(x), None, L.ptr(ss), L.ptr(stat), L.ptr(part), P, Cn, 0, 0, 1, 0, L.stream_ptr())
+        cnt.zero_()
+        reduce_pass(dz)
+        assert cnt.tolist() == [0, 0]
+        bad = dz.clone()
+        bad[0, 1234, 7] = 65504.0
+        bad[0, 77, 3] = -65504.0
+        reduce_pass(bad)
+        assert cnt.tolist()[0] >= 1
+        # (2) the guarded Adam: nothing moves while the counter is non-zero; one step later the host reacts
+        p = torch.nn.Parameter(torch.ones(5000, device=DEV))
+        opt = FusedAdam([p], lr=0.1, weight_decay=0.01)
+        p.grad = torch.full_like(p, 0.5)
+        opt.step()                                                     # dropped: the counter still holds the saturation of (1)
+        torch.cuda.synchronize()
+        assert torch.equal(p.detach(), torch.ones_like(p)) and float(opt.state[p]['exp_avg'].abs().max()) == 0.0
+        assert cnt.tolist() == [0, 0]                                  # read back and zeroed for the next step
+        before = sc.skipped_steps
+        opt.step()                                                     # clean step; the host now learns of the dropped one
+        torch.cuda.synchronize()
+        assert sc.skipped_steps == before + 1 and sc.scale == 32768.0 and bank.loss_scale == 32768.0
+        assert opt.state[p]['step'] == 1                               # the dropped step does not count (bias correction of step 1)
+        ref = torch.nn.Parameter(torch.ones(5000, device=DEV))
+        ropt = torch.optim.Adam([ref], lr=0.1, weight_decay=0.01)
+        ref.grad = torch.full_like(ref, 0.5)
+        ropt.step()
+        assert_close(p.detach().cpu(), ref.detach().cpu(), 1e-6, 1e-6, 'first real step = torch.optim.Adam step 1')
+        # (3) the scale grows back after `growth_interval` clean steps
+        gi, sc.growth_interval = sc.growth_interval, 3
+        for _ in range(4):
+            opt.step()
+        torch.cuda.synchronize()
+        sc.growth_interval = gi
+        assert sc.scale == 65536.0 and bank.loss_scale == 65536.0
+    finally:
+        sc._set_scale(saved[0])
+        sc.clean_steps, sc.skipped_steps = saved[1], saved[2]

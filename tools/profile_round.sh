@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 10 
 db=$(find $out/kt -name "*.db" | head -1)
 python tools/rocpd_summary.py $db 70 > gpurun_out/${tag}_kernel_stats.md
 python tools/rocpd_shapes.py $db > gpurun_out/${tag}_kernel_shapes.md 2>/dev/null
+( python tools/rocpd_timeline.py $db 0.5 40; python tools/rocpd_timeline.py $db step ) > gpurun_out/${tag}_timeline.md 2>&1
 tail -1 $out/kt.log | cut -c1-300
 rm -f $db
 for c in FETCH_SIZE WRITE_SIZE; do
