@@ -242,20 +242,6 @@ int tcvom_bn_finalize_sums(const double* sums, int32_t C, int64_t count, int64_t
 int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* sums_local, int32_t C, int64_t count,
                                const float* gamma, const float* saved, float* dgamma, float* dbeta, float* coef,
                                int32_t accumulate, int32_t nframes, int64_t slot_stride, const tcvom_sn_dot* dot, void* stream);
-/* One-rank train-mode BatchNorm with the finalize step INSIDE the streaming passes (the 5 us finalize launches between two
- * streaming kernels are 144 launches of a 1080p step): every block reduces the [groups][2][C] partial sums of its channel octets
- * itself (fp64, same arithmetic as tcvom_bn_finalize / tcvom_bn_bwd_finalize) and block (0, frame) publishes scale_shift / saved
- * (forward) or adds dgamma / dbeta and the tcvom_sn_dot term (backward).  Channel counts whose octet count is not a power of two
- * <= 64 run the two launches.  Op chain: models/GCA/encoders/resnet_enc.py:33-49. */
-int tcvom_bn_apply_fused(const void* y, const float* stats_partial, int32_t groups, int64_t count, const float* gamma,
-                         const float* beta, float eps, float* scale_shift, float* saved, double* scratch, const void* res1,
-                         const void* res2, void* z, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes,
-                         int64_t slot_stride, void* stream);
-int tcvom_bn_bwd_apply_fused(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
-                             const float* saved, const float* partial, int32_t groups, int64_t count, const float* gamma,
-                             float* dgamma, float* dbeta, float* coef, double* scratch, const tcvom_sn_dot* dot, void* dy,
-                             void* dres1, int64_t pixels, int32_t C, int32_t act, int32_t in_relu, int32_t y_fp32,
-                             int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
 /* SyncBatchNorm WITHOUT a collective call (replaces the all_gather / all_reduce pairs nn.SyncBatchNorm issues per BatchNorm call
  * under train_ddp.py:271-280): every rank owns a mailbox of uncached device memory mapped into its peers
  * through hipIpc; the finalize kernel pushes its local fp64 sums into every peer's mailbox over xGMI as self-validating 8-byte

@@ -108,8 +108,6 @@ _PROTOS = {
     'tcvom_bn_bwd_finalize_sums': [vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, i32, i64, TP, vp],
     'tcvom_bn_bwd_apply': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_apply_ranged': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp],
-    'tcvom_bn_apply_fused': [vp, vp, i32, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
-    'tcvom_bn_bwd_apply_fused': [vp, vp, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, TP, vp, vp, i64, i32, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_finalize_sync': [vp, i32, i32, i64, i64, vp, vp, f32, vp, vp, vp, i32, i64, YP, vp],
     'tcvom_bn_bwd_finalize_sync': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, YP, TP, vp],
     'tcvom_mbox_alloc': [i64, C.POINTER(C.c_void_p), vp],

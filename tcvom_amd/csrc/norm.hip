@@ -319,118 +319,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     if (overflow && sat) atomicAdd(overflow + 1, 1);                  // a conv output at the fp16 saturation value (never in a healthy step)
 }
 
-// ---------------------------------------------------------------- finalize INSIDE the streaming kernels (one rank, G small)
-// The finalize kernels are 5 us launches between two streaming passes (144 per 1080p step).  With few partial-sum groups every
-// block of the apply pass can reduce the [G][2][C] partials of ITS channel octet itself: thread (oct, prow) sums the groups
-// prow, prow + RP, .. in fp64 (two 16-byte loads per group and sum), the RP partial results of an octet meet through shuffles
-// (inside a wave) and LDS (across the 4 waves), and every thread ends with the totals of its 8 channels in registers -- the same
-// values in every block (same order of additions).  Block (0, frame) publishes what the backward pass reads.
-// red: 4 * C8 * 16 doubles of LDS.  PT = float (raw partials) or double (bn_partial_reduce output).
-template <typename PT>
-__device__ __forceinline__ void octet_sums(const PT* __restrict__ partial, int G, int C, int C8, int oct, int prow, int RP,
-                                           double* red, double* a, double* b) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { a[k] = 0.0; b[k] = 0.0; }
-    if (prow < RP) {
-        for (int g = prow; g < G; g += RP) {
-            const PT* q = partial + (int64_t)g * 2 * C + oct * 8;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { a[k] += (double)q[k]; b[k] += (double)q[C + k]; }
-        }
-    }
-    // lanes of one wave with the same octet: tid = prow * C8 + oct, C8 a power of two <= 64 -> xor-shuffle over the prow bits
-    for (int o = C8; o < 64; o <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { a[k] += __shfl_xor(a[k], o, 64); b[k] += __shfl_xor(b[k], o, 64); }
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (C8 <= 64) {
-        __syncthreads();
-        if (lane < C8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { red[(wave * C8 + lane) * 16 + k] = a[k]; red[(wave * C8 + lane) * 16 + 8 + k] = b[k]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { a[k] = 0.0; b[k] = 0.0; }
-        for (int w = 0; w < 4; ++w) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { a[k] += red[(w * C8 + oct) * 16 + k]; b[k] += red[(w * C8 + oct) * 16 + 8 + k]; }
-        }
-    }
-}
-static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
-template <bool YF32, typename PT>
-__global__ __launch_bounds__(256) void bn_apply_fused_kernel(
-    const void* __restrict__ y, const PT* __restrict__ partial, int G, double count,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    float* __restrict__ scale_shift, float* __restrict__ saved,
-    const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
-    int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int* __restrict__ overflow)
-{
-    extern __shared__ double fred[];
-    const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
-    double sa[8], sb[8];
-    octet_sums<PT>(partial + (int64_t)blockIdx.y * G * 2 * C, G, C, C8, oct, prow, RP, fred, sa, sb);
-    if (prow >= RP) return;
-    float sc[8], sh[8];
-    {
-        float g8[8], b8[8], mu[8], is[8];
-        load_coef8(gamma + oct * 8, g8);
-        load_coef8(beta + oct * 8, b8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {                                 // (bn_finalize_kernel's arithmetic)
-            const double mean = sa[k] / count;
-            double var = sb[k] / count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            sc[k] = g8[k] * invstd;
-            sh[k] = b8[k] - (float)mean * sc[k];
-            mu[k] = (float)mean;
-            is[k] = invstd;
-        }
-        if (blockIdx.x == 0 && prow == 0) {                           // what the backward pass and the deferred EMA read
-            float* ss = scale_shift + blockIdx.y * slot_stride;
-            float* sv = saved + blockIdx.y * slot_stride;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { ss[oct * 8 + k] = sc[k]; ss[C + oct * 8 + k] = sh[k]; sv[oct * 8 + k] = mu[k]; sv[C + oct * 8 + k] = is[k]; }
-        }
-    }
-    unsigned sat = 0u;
-    const int64_t fo = (int64_t)blockIdx.y * P * C8;
-    const float slope = act_slope(act), cap = act_cap(act);
-    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    int64_t p = pbeg + prow;
-    if (p >= pend) return;
-    int64_t v = fo + p * C8 + oct;
-    YRaw<YF32> yr = load_yraw<YF32>(y, v);
-    uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0}, q2 = res2 ? res2[v] : uint4{0, 0, 0, 0};
-    while (true) {
-        const int64_t pn = p + RP;
-        const bool more = pn < pend;
-        const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-        const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
-        const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0}, n2 = res2 ? res2[vn] : uint4{0, 0, 0, 0};
-        float f[8], r1[8], r2[8];
-        unpack_yraw<YF32>(yr, f);
-        if constexpr (!YF32) sat |= sat8(yr.a);
-        unpack8(q1, r1);
-        unpack8(q2, r2);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float x = f[k] * sc[k] + sh[k] + r1[k];
-            x = fminf(x > 0.f ? x : slope * x, cap);
-            f[k] = x + r2[k];
-        }
-        z[v] = pack8(f);
-        if (!more) break;
-        p = pn; v = vn; yr = yn; q1 = n1; q2 = n2;
-    }
-    if (overflow && sat) atomicAdd(overflow + 1, 1);
-}
-
 // ---------------------------------------------------------------- backward, pass 1: per-channel sums
 // block = 256 threads = RP pixel rows x C8 channel octets (C8 <= 256); partial[block][2][C]
 template <bool YF32>
@@ -624,101 +512,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     int64_t p = pbeg + prow;
     if (p >= pend) return;
     // two-deep software pipeline (see bn_apply_kernel)
-    int64_t v = fo + p * C8 + oct;
-    uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
-    YRaw<YF32> yr = load_yraw<YF32>(y, v);
-    uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
-    while (true) {
-        const int64_t pn = p + RP;
-        const bool more = pn < pend;
-        const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-        const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
-        const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
-        const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
-        float g[8], g2[8], yy[8], r1[8], o[8];
-        unpack8(qg, g);
-        unpack8(qh, g2);
-        unpack_yraw<YF32>(yr, yy);
-        unpack8(q1, r1);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-            const float gg = (g[k] + g2[k]) * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
-            g[k] = gg;
-            const float xh = (yy[k] - mu[k]) * is[k];
-            o[k] = gi[k] * gg - c1[k] - xh * c2[k];
-            if (in_relu && yy[k] <= 0.f) o[k] = 0.f;
-        }
-        dy[v] = pack8(o);
-        if (dres1) dres1[v] = pack8(g);
-        if (!more) break;
-        p = pn; v = vn; qg = ng; qh = nh; yr = yn; q1 = n1;
-    }
-}
-
-// bn_bwd_apply with bn_bwd_finalize in its prologue (see octet_sums): coefficients in registers, block (0, frame) adds the
-// gamma / beta gradients and SpectralNorm's <dy, y> term
-template <bool YF32, typename PT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(
-    const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
-    const float* __restrict__ scale_shift, const float* __restrict__ saved, const PT* __restrict__ partial, int G, double count,
-    const float* __restrict__ gamma, float* __restrict__ dgamma, float* __restrict__ dbeta, const SnDot sd,
-    uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int in_relu,
-    int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1)
-{
-    extern __shared__ double fred[];
-    const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
-    double sa[8], sb[8];
-    octet_sums<PT>(partial + (int64_t)blockIdx.y * G * 2 * C, G, C, C8, oct, prow, RP, fred, sa, sb);
-    scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
-    saved += blockIdx.y * slot_stride;
-    float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], gi[8];
-    if (prow < RP) {
-        load_coef8(scale_shift + oct * 8, sc);
-        load_coef8(scale_shift + C + oct * 8, sh);
-        load_coef8(saved + oct * 8, mu);
-        load_coef8(saved + C + oct * 8, is);
-        load_coef8(gamma + oct * 8, gi);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {                                 // (bn_bwd_finalize_kernel's arithmetic)
-            gi[k] *= is[k];
-            c1[k] = (float)(sa[k] / count) * gi[k];
-            c2[k] = (float)(sb[k] / count) * gi[k];
-        }
-    }
-    if (blockIdx.x == 0) {                                            // block-uniform
-        float d = 0.f;
-        if (prow == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (dbeta) atomicAdd(dbeta + oct * 8 + k, (float)sa[k]);
-                if (dgamma) atomicAdd(dgamma + oct * 8 + k, (float)sb[k]);
-                if (sd.out) {
-                    const double m = mu[k], i = is[k], g = (double)gi[k];
-                    d += (float)((sd.eps >= 0.f ? g * sb[k] * i * (double)sd.eps : g * (m * sa[k] + sb[k] / i)) * (double)sd.scale);
-                }
-            }
-        }
-        if (sd.out) {
-            float* fr = reinterpret_cast<float*>(fred);
-            __syncthreads();                                          // (octet_sums is done with fred)
-            d = wave_sum(d);
-            if ((threadIdx.x & 63) == 0) fr[threadIdx.x >> 6] = d;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const float t = fr[0] + fr[1] + fr[2] + fr[3];
-                if (t != 0.f) atomicAdd(sd.out + blockIdx.y * sd.stride, t);
-            }
-        }
-    }
-    if (prow >= RP) return;
-    if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
-    const int64_t fo = (int64_t)blockIdx.y * P * C8;
-    const float slope = act_slope(act), cap = act_cap(act);
-    const int64_t pbeg = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t pend = pbeg + rows_per_block < P ? pbeg + rows_per_block : P;
-    int64_t p = pbeg + prow;
-    if (p >= pend) return;
     int64_t v = fo + p * C8 + oct;
     uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
     YRaw<YF32> yr = load_yraw<YF32>(y, v);
@@ -1266,81 +1059,4 @@ extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y
                                   int64_t slot_stride, void* stream) {
     return tcvom_bn_bwd_apply_ranged(dz, dz2, y, res1, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
                                      nframes, slot_stride, 0, nframes, stream);
-}
-
-// ---------------------------------------------------------------- finalize fused into the streaming passes (one rank)
-static bool fused_ok(int32_t C) {
-    static const bool off = getenv("TCVOM_NO_BN_FUSED_FINALIZE") != nullptr;          // A/B switch
-    return !off && C % 8 == 0 && pow2(C / 8) && C / 8 <= 64;
-}
-
-// tcvom_bn_finalize + tcvom_bn_apply of a train-mode BatchNorm call as ONE streaming launch (plus the stage-1 reduction when the
-// conv wrote more than 256 partial-sum groups per frame); channel counts the fused kernel does not serve take the two launches.
-extern "C" int tcvom_bn_apply_fused(const void* y, const float* stats_partial, int32_t groups, int64_t count, const float* gamma,
-                                    const float* beta, float eps, float* scale_shift, float* saved, double* scratch, const void* res1,
-                                    const void* res2, void* z, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes,
-                                    int64_t slot_stride, void* stream) {
-    TCVOM_CHECK_ARG(y && stats_partial && gamma && beta && scale_shift && saved && z && groups > 0 && count > 0 && pixels > 0 && C > 0 &&
-                    C % 8 == 0 && C <= 2048 && nframes >= 1, "bn_apply_fused: bad args (C=%d)", C);
-    if (!fused_ok(C) || (groups > 4 * BN_SLICES && !scratch)) {
-        const int rc = bn_finalize_impl(stats_partial, groups, C, count, count, gamma, beta, nullptr, nullptr, 0.f, eps, scale_shift, saved,
-                                        scratch, nframes, slot_stride, kNoSync, stream);
-        if (rc != TCVOM_OK) return rc;
-        return tcvom_bn_apply(y, scale_shift, res1, res2, z, pixels, C, act, y_fp32, nframes, slot_stride, stream);
-    }
-    hipStream_t st = (hipStream_t)stream;
-    const int rpb = bn_rows_per_block(pixels, C);
-    const dim3 grid(cdiv(pixels, rpb), nframes);
-    const size_t lds = (size_t)4 * (C / 8) * 16 * sizeof(double);
-    int* ovf = g_overflow_sink.load(std::memory_order_relaxed);
-#define FUSED_APPLY(YF, PT, part, G)                                                                                          \
-    hipLaunchKernelGGL((bn_apply_fused_kernel<YF, PT>), grid, dim3(256), lds, st, y, (const PT*)(part), (int)(G), (double)count, gamma, \
-                       beta, eps, scale_shift, saved, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb,   \
-                       slot_stride, ovf)
-    if (groups > 4 * BN_SLICES) {
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, stats_partial, groups, C, scratch);
-        if (y_fp32) FUSED_APPLY(true, double, scratch, BN_SLICES); else FUSED_APPLY(false, double, scratch, BN_SLICES);
-    } else {
-        if (y_fp32) FUSED_APPLY(true, float, stats_partial, groups); else FUSED_APPLY(false, float, stats_partial, groups);
-    }
-#undef FUSED_APPLY
-    TCVOM_LAUNCH_CHECK("bn_apply_fused");
-    return TCVOM_OK;
-}
-
-// tcvom_bn_bwd_finalize + tcvom_bn_bwd_apply_ranged likewise (train mode, batch statistics of one rank; dgamma / dbeta are added to).
-// coef: [nframes][3][C] floats, used only when the channel count takes the two-launch path.
-extern "C" int tcvom_bn_bwd_apply_fused(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
-                                        const float* saved, const float* partial, int32_t groups, int64_t count, const float* gamma,
-                                        float* dgamma, float* dbeta, float* coef, double* scratch, const tcvom_sn_dot* dot, void* dy,
-                                        void* dres1, int64_t pixels, int32_t C, int32_t act, int32_t in_relu, int32_t y_fp32,
-                                        int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
-    TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_apply_fused: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
-    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && gamma && coef && dy && groups > 0 && count > 0 && pixels > 0 && C % 8 == 0 &&
-                    C <= 2048 && nframes >= 1, "bn_bwd_apply_fused: bad args");
-    if (!fused_ok(C) || (groups > 4 * BN_SLICES && !scratch)) {
-        const int rc = bn_bwd_finalize_impl(partial, groups, C, count, gamma, saved, dgamma, dbeta, coef, scratch, 1, nframes, slot_stride,
-                                            kNoSync, make_dot(dot), stream);
-        if (rc != TCVOM_OK) return rc;
-        return tcvom_bn_bwd_apply_ranged(dz, dz2, y, res1, scale_shift, saved, coef, dy, dres1, pixels, C, act, 1, in_relu, y_fp32, nframes,
-                                         slot_stride, dz2_f0, dz2_f1, stream);
-    }
-    hipStream_t st = (hipStream_t)stream;
-    const int rpb = bn_rows_per_block(pixels, C);
-    const dim3 grid(cdiv(pixels, rpb), nframes);
-    const size_t lds = (size_t)4 * (C / 8) * 16 * sizeof(double);
-    const SnDot sd = make_dot(dot);
-#define FUSED_BWD(YF, PT, part, G)                                                                                             \
-    hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<YF, PT>), grid, dim3(256), lds, st, (const uint4*)dz, (const uint4*)dz2, y,  \
-                       (const uint4*)res1, scale_shift, saved, (const PT*)(part), (int)(G), (double)count, gamma, dgamma, dbeta, sd, \
-                       (uint4*)dy, (uint4*)dres1, pixels, C / 8, C, act, in_relu, rpb, slot_stride, dz2_f0, dz2_f1)
-    if (groups > 4 * BN_SLICES) {
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, 32), BN_SLICES, nframes), dim3(256), 0, st, partial, groups, C, scratch);
-        if (y_fp32) FUSED_BWD(true, double, scratch, BN_SLICES); else FUSED_BWD(false, double, scratch, BN_SLICES);
-    } else {
-        if (y_fp32) FUSED_BWD(true, float, partial, groups); else FUSED_BWD(false, float, partial, groups);
-    }
-#undef FUSED_BWD
-    TCVOM_LAUNCH_CHECK("bn_bwd_apply_fused");
-    return TCVOM_OK;
 }

@@ -108,7 +108,6 @@ class LossScaler(object):
 
 
 SCALER = LossScaler(LOSS_SCALE)
-FUSED_FINALIZE = _os.environ.get('TCVOM_NO_BN_FUSED_FINALIZE') is None      # A/B switch: BatchNorm finalize inside the apply passes (one rank)
 SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
 
@@ -357,9 +356,6 @@ class _ConvBNAct(torch.autograd.Function):
             P = P * sync[1]
         ss_i, saved_i, slot_stride = bank.bn_slots(bn, nf, training and not gn, P * cfg.unbias_mult)
         ss, saved = C.c_void_p(ss_i), C.c_void_p(saved_i)
-        # last op of a tail-only branch: the apply pass covers the interior frames only (below) -- its finalize stays a launch
-        tail_apply = ctx.active is not None and cfg.tail_last and res1 is None and res2 is None
-        fused_fwd = None
         if gn:
             # GroupNorm: per-sample statistics in train AND eval mode, no running state
             groups = stats.numel() // (2 * K * nf)
@@ -369,10 +365,7 @@ class _ConvBNAct(torch.autograd.Function):
         elif training:
             groups = stats.numel() // (2 * K * nf)
             scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=x.device) if groups > 256 else None
-            if sync is None and FUSED_FINALIZE and not tail_apply:
-                # one rank: the finalize runs in the prologue of the apply pass below (tcvom_bn_apply_fused)
-                fused_fwd = (stats, groups, scratch)
-            elif sync is None:
+            if sync is None:
                 # running statistics / num_batches_tracked are updated after the window, in call order: see
                 # WeightBank.flush_bn_counters
                 L.call('tcvom_bn_finalize', L.ptr(stats), groups, K, P, P * cfg.unbias_mult,
@@ -400,11 +393,7 @@ class _ConvBNAct(torch.autograd.Function):
         z = torch.empty((NT, geo.OH, geo.OW, K), dtype=H16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
-        if fused_fwd is not None:
-            fstats, fgroups, fscratch = fused_fwd
-            L.call('tcvom_bn_apply_fused', L.ptr(y), L.ptr(fstats), fgroups, P, L.ptr(gamma), L.ptr(beta), float(bn.eps), ss, saved,
-                   L.ptr(fscratch), L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0, nf, slot_stride, st)
-        elif tail_apply:
+        if ctx.active is not None and cfg.tail_last and r1 is None and r2 is None:
             # last op of a tail-only branch: its output is read for the interior frames only -- the end frames still went
             # through the conv (their batch statistics feed the BatchNorm's running statistics, as in the reference) but are
             # not normalised / stored (z is uninitialised there; tcvom_amd.vmn slices the interior frames)
@@ -490,12 +479,9 @@ class _ConvBNAct(torch.autograd.Function):
             coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
             scratch = torch.empty(nf * 128 * K, dtype=torch.float64, device=dz.device) if groups > 256 else None
             sync = ctx.sync if ctx.training else None
-            fused_bwd = False
             if cfg.group_norm:
                 L.call('tcvom_gn_bwd_finalize', L.ptr(partial), groups, K, P, cfg.bn.num_groups, L.ptr(gamma), saved, dgp, dbp,
                        L.ptr(coef), L.ptr(scratch), nf, stride, st)
-            elif sync is None and ctx.training and FUSED_FINALIZE:
-                fused_bwd = True                           # one rank: finalize in the prologue of the apply pass below
             elif sync is None:
                 L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
                        L.ptr(coef), L.ptr(scratch), 1, nf, stride, _sn_dot(cfg, ctx.call, ctx.training, None), st)
@@ -514,14 +500,9 @@ class _ConvBNAct(torch.autograd.Function):
             dy = torch.empty(y.shape, dtype=H16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
-            if fused_bwd:
-                L.call('tcvom_bn_bwd_apply_fused', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), groups, P,
-                       L.ptr(gamma), dgp, dbp, L.ptr(coef), L.ptr(scratch), _sn_dot(cfg, ctx.call, ctx.training, None), L.ptr(dy),
-                       L.ptr(dres1), P, K, cfg.act, 1 if cfg.pre_relu else 0, yf, nf, stride, zf0, zf1, st)
-            else:
-                L.call('tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
-                       L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
-                       zf0, zf1, st)
+            L.call('tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
+                   L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
+                   zf0, zf1, st)
             if ctx.has_bias:
                 # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
                 # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
@@ -588,12 +569,9 @@ def _backward_active(ctx, dz, dz2, ranged=()):
     coef = torch.empty(nfa * 3 * K, dtype=torch.float32, device=dev)
     scratch = torch.empty(nfa * 128 * K, dtype=torch.float64, device=dev) if groups > 256 else None
     sync = ctx.sync if ctx.training else None
-    fused_bwd = False
     if cfg.group_norm:
         L.call('tcvom_gn_bwd_finalize', L.ptr(partial), groups, K, P, cfg.bn.num_groups, L.ptr(gamma), saved, dgp, dbp,
                L.ptr(coef), L.ptr(scratch), nfa, stride, st)
-    elif sync is None and ctx.training and FUSED_FINALIZE:
-        fused_bwd = True
     elif sync is None:
         L.call('tcvom_bn_bwd_finalize', L.ptr(partial), groups, K, P, L.ptr(gamma), saved, dgp, dbp,
                L.ptr(coef), L.ptr(scratch), 1, nfa, stride, _sn_dot(cfg, ctx.call + f0, ctx.training, None), st)
@@ -610,13 +588,8 @@ def _backward_active(ctx, dz, dz2, ranged=()):
         L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * sync.world, L.ptr(gamma), saved,
                dgp, dbp, L.ptr(coef), 1, nfa, stride, _sn_dot(cfg, ctx.call + f0, ctx.training, sync), st)
     dya = torch.empty(ya.shape, dtype=H16, device=dev)
-    if fused_bwd:
-        L.call('tcvom_bn_bwd_apply_fused', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(partial), groups, P, L.ptr(gamma),
-               dgp, dbp, L.ptr(coef), L.ptr(scratch), _sn_dot(cfg, ctx.call + f0, ctx.training, None), L.ptr(dya), None, P, K, cfg.act,
-               1 if cfg.pre_relu else 0, yf, nfa, stride, 0, nfa, st)
-    else:
-        L.call('tcvom_bn_bwd_apply', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(coef), L.ptr(dya),
-               None, P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nfa, stride, st)
+    L.call('tcvom_bn_bwd_apply', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(coef), L.ptr(dya),
+           None, P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nfa, stride, st)
     dx = None
     if spec.needs_dgrad and ctx.needs_input_grad[0]:
         cx = spec.cpad if spec.cpad > 8 else spec.C

@@ -5,7 +5,6 @@ Tolerances: activations are stored in bf16 (8-bit mantissa) with fp32 accumulati
 is expected within ~2^-8 relative of an fp32 evaluation of the same bf16 inputs; tolerances are
 stated per test.  Integer/mask outputs must be bit-exact.
 """
-import ctypes as C_
 import math
 
 import numpy as np
@@ -1220,62 +1219,3 @@ def test_fp16_overflow_guard_drops_the_step_and_halves_the_loss_scale():
     finally:
         sc._set_scale(saved[0])
         sc.clean_steps, sc.skipped_steps = saved[1], saved[2]
-
-
-@pytest.mark.parametrize('Cn,P,G,nf,yf32', [(32, 5000, 40, 3, False), (64, 3000, 256, 1, False), (128, 2000, 300, 3, False),
-                                              (256, 700, 17, 2, True), (512, 300, 5, 1, False), (96, 900, 12, 2, False)])
-def test_batchnorm_finalize_fused_into_the_streaming_passes(Cn, P, G, nf, yf32):
-    """tcvom_bn_apply_fused / tcvom_bn_bwd_apply_fused (finalize in the prologue of the apply passes) against the launch pairs they
-    replace -- tcvom_bn_finalize + tcvom_bn_apply and tcvom_bn_bwd_finalize + tcvom_bn_bwd_apply -- on the same partial sums:
-    > 256 groups (stage-1 reduction), fp32 conv outputs, residual + second addend, a channel count that falls back (96)."""
-    import tcvom_amd._lib as L
-    st = L.stream_ptr()
-    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=DEV)
-    y = (hu('ff.y', (nf, P, Cn)) * 2).to(DEV)
-    y = y if yf32 else y.to(H16)
-    r1 = hu('ff.r1', (nf, P, Cn)).to(DEV).to(H16)
-    part = (hu('ff.part', (nf, G, 2, Cn)).abs() * 50).to(DEV)
-    part[:, :, 1] += part[:, :, 0] ** 2 / (P / G) + 5.0                         # sum of squares consistent with a positive variance
-    gamma = (hu('ff.g', (Cn,)) * 0.5 + 1).to(DEV)
-    beta = hu('ff.b', (Cn,)).to(DEV)
-    scratch = torch.empty(nf * 128 * Cn, dtype=torch.float64, device=DEV)
-    ss_a, sv_a, ss_b, sv_b = f32(nf, 2 * Cn), f32(nf, 2 * Cn), f32(nf, 2 * Cn), f32(nf, 2 * Cn)
-    z_a = torch.empty((nf, P, Cn), dtype=H16, device=DEV)
-    z_b = torch.empty_like(z_a)
-    L.call('tcvom_bn_finalize', L.ptr(part), G, Cn, P, P, L.ptr(gamma), L.ptr(beta), None, None, 0.1, 1e-5, L.ptr(ss_a), L.ptr(sv_a),
-           L.ptr(scratch), nf, 2 * Cn, st)
-    L.call('tcvom_bn_apply', L.ptr(y), L.ptr(ss_a), L.ptr(r1), None, L.ptr(z_a), P, Cn, 2, 1 if yf32 else 0, nf, 2 * Cn, st)
-    L.call('tcvom_bn_apply_fused', L.ptr(y), L.ptr(part), G, P, L.ptr(gamma), L.ptr(beta), 1e-5, L.ptr(ss_b), L.ptr(sv_b), L.ptr(scratch),
-           L.ptr(r1), None, L.ptr(z_b), P, Cn, 2, 1 if yf32 else 0, nf, 2 * Cn, st)
-    torch.cuda.synchronize()
-    assert_close(ss_b.cpu(), ss_a.cpu(), 1e-6, 1e-6, 'scale / shift')
-    assert_close(sv_b.cpu(), sv_a.cpu(), 1e-6, 1e-6, 'mean / invstd')
-    assert float((z_a.float() - z_b.float()).abs().max()) <= 2e-2 * float(z_a.float().abs().max()) * (2 ** -7)   # <= one 16-bit rounding step
-    # backward: the partial sums of the reduction pass, then both forms of finalize + apply
-    dz = hu('ff.dz', (nf, P, Cn)).to(DEV).to(H16)
-    dz2 = hu('ff.dz2', (max(nf - 1, 1), P, Cn)).to(DEV).to(H16)                   # second addend for the frames 0 .. nf - 2 only
-    f1 = max(nf - 1, 1)
-    Gb = L.call('tcvom_bn_bwd_groups_n', P, Cn, nf)
-    pb = f32(nf, Gb, 2, Cn)
-    L.call('tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), L.ptr(ss_a), L.ptr(sv_a), L.ptr(pb), P, Cn, 2,
-           1 if yf32 else 0, nf, 2 * Cn, 0, f1, st)
-    coef = f32(nf, 3, Cn)
-    dg_a, db_a, dg_b, db_b = (torch.zeros(Cn, device=DEV) for _ in range(4))
-    dots = torch.zeros(2 * nf, device=DEV)
-    dot_a = C_.byref(L.SnDot(dots.data_ptr(), 1, 1e-5, 1, 0.5))
-    dot_b = C_.byref(L.SnDot(dots.data_ptr() + 4 * nf, 1, 1e-5, 1, 0.5))
-    dy_a = torch.empty((nf, P, Cn), dtype=H16, device=DEV)
-    dr_a, dy_b, dr_b = torch.empty_like(dy_a), torch.empty_like(dy_a), torch.empty_like(dy_a)
-    L.call('tcvom_bn_bwd_finalize', L.ptr(pb), Gb, Cn, P, L.ptr(gamma), L.ptr(sv_a), L.ptr(dg_a), L.ptr(db_a), L.ptr(coef), L.ptr(scratch),
-           1, nf, 2 * Cn, dot_a, st)
-    L.call('tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), L.ptr(ss_a), L.ptr(sv_a), L.ptr(coef), L.ptr(dy_a),
-           L.ptr(dr_a), P, Cn, 2, 1, 0, 1 if yf32 else 0, nf, 2 * Cn, 0, f1, st)
-    L.call('tcvom_bn_bwd_apply_fused', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), L.ptr(ss_a), L.ptr(sv_a), L.ptr(pb), Gb, P, L.ptr(gamma),
-           L.ptr(dg_b), L.ptr(db_b), L.ptr(coef), L.ptr(scratch), dot_b, L.ptr(dy_b), L.ptr(dr_b), P, Cn, 2, 0, 1 if yf32 else 0, nf,
-           2 * Cn, 0, f1, st)
-    torch.cuda.synchronize()
-    assert_close(dg_b.cpu(), dg_a.cpu(), 1e-5, 1e-5, 'dgamma')
-    assert_close(db_b.cpu(), db_a.cpu(), 1e-5, 1e-5, 'dbeta')
-    assert_close(dots[nf:].cpu(), dots[:nf].cpu(), 1e-4, 1e-6, 'SpectralNorm <dy, y> term')
-    assert torch.equal(dr_a, dr_b)
-    assert float((dy_a.float() - dy_b.float()).abs().max()) <= float(dy_a.float().abs().max()) * (2 ** -7)

@@ -32,9 +32,7 @@ def test_alternative_code_paths_agree_with_the_default_ones():
             'gradients': {'TCVOM_NO_SN_DOT': '1', 'TCVOM_NO_RANGED': '1', 'TCVOM_NO_TAIL_SKIP': '1'},
             # the weight-stationary conv splits a frame-batched launch into runs of frames when the frames together would reach 2^31
             # elements (fragment-major weights have no other kernel): forced here to one frame per launch
-            'wsconv frame runs': {'TCVOM_WS_MAX_FRAMES': '1'},
-            # BatchNorm finalize as its own launches (what N > 1 / SyncBatchNorm runs) instead of inside the apply passes
-            'unfused BatchNorm finalize': {'TCVOM_NO_BN_FUSED_FINALIZE': '1'}}
+            'wsconv frame runs': {'TCVOM_WS_MAX_FRAMES': '1'}}
 
     def worst(a, b):
         w = 0.0
