@@ -42,7 +42,10 @@ def test_rccl_gradient_average_and_sync_bn_on_one_rank():
         numel_spans, nspans, numel_rest, nbuckets = av.last_plan
         assert nspans >= 1 and numel_spans == 3 * 70000 and nbuckets >= 1
         for p, w in zip(params, want):
-            assert torch.equal(p.grad, torch.zeros_like(p) if w is None else w)       # AVG over one rank = identity
+            # AVG over one rank = identity; a parameter NO rank has a gradient for keeps .grad = None (DDP leaves globally unused
+            # parameters untouched: Adam must not decay a frozen backbone)
+            assert (p.grad is None) if w is None else torch.equal(p.grad, w)
+        assert av.globally_unused == 1
         assert params[0].grad.data_ptr() == arena.data_ptr()                           # reduced in place
         assert float(reduce_tensor(torch.tensor(3.0, device=dev))) == 3.0
         # the overlapped path on a real network: the bank hands over its flat gradient in >= 3 spans, each all-reduced
