@@ -573,12 +573,24 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             const int nbase = n0 + wn * 64 + b * 32, mbase = m0 + wm * HM;
             if constexpr (F32) {
                 float* o = reinterpret_cast<float*>(gout) + obase;
+                if (kpart >= 0) {
+                    // K-split over every tile (gemm_tt256: weight gradients): the partial products are ADDED.  Atomics execute per
+                    // cache line: 64 CONSECUTIVE floats of one row per instruction (2 lines); a lane adding its float4 as four
+                    // scalar atomics spreads every instruction over 8 lines (measured: 0.23 TB/s of atomic traffic, 4x slower)
+#pragma unroll 4
+                    for (int i = 0; i < 64; ++i) {
+                        const int row = i >> 1, e = (i & 1) * 64 + lane;
+                        const float v = *reinterpret_cast<const float*>(wl + row * 512 + (((e >> 2) ^ row) << 4) + (e & 3) * 4);
+                        const int n = nbase + row, m = mbase + e;
+                        if (n < g.N && m < g.M) __hip_atomic_fetch_add(o + (int64_t)n * g.ldo + m, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = i * 2 + h, c = nl ^ row;                     // (row < 32: row & 31 == row)
                     const float4 t = *reinterpret_cast<const float4*>(wl + row * 512 + nl * 16);
                     const int n = nbase + row, m = mbase + c * 4;
-                    if (n < g.N && m < g.M) *reinterpret_cast<float4*>(o + (int64_t)n * g.ldo + m) = t;
+                    if (kpart < 0 && n < g.N && m < g.M) *reinterpret_cast<float4*>(o + (int64_t)n * g.ldo + m) = t;
                 }
             } else {
                 h16raw* o = reinterpret_cast<h16raw*>(gout) + obase;
@@ -761,10 +773,73 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     return 1;
 }
 
+// ---- weight gradient of a dense (1 x 1, stride 1) conv as ONE TT GEMM on the k-major operand path (both operands read as they lie
+// in memory -- pixels are the reduction index and the outer memory index -- through the transposing LDS reads of gca_dv):
+//     dw[k][c] += sum_p dy[p][k] * x[p][c]          dy: [P][ldy], x: [P][C], dw: [K][C] fp32 (added to: the caller's arena is zeroed)
+// The output is a handful of 256 x 256 tiles (K, C <= 2048) over a reduction of 10^4 .. 10^5 pixels, so EVERY tile is split over the
+// reduction (split_s workgroups per tile, fp32 atomics along the rows).  Replaces igemm_tt for these shapes (measured 480 .. 550
+// TFLOP/s on the bottleneck 1 x 1 convs of the FBA base, models/FBA/resnet_GN_WS.py:50-137, against 1.25 PFLOP/s of this loop on dV).
+// 1: launched; 0: not a shape for this kernel.
+extern const h16raw* tcvom_zero_page(void);
+int gemm_tt256_takes(const tcvom_conv_desc* d) {                                   // (shape only: bench labels)
+    static const bool off = getenv("TCVOM_NO_TT256") != nullptr;                   // A/B switch
+    if (off) return 0;
+    if (d->ntaps != 1 || d->tap_w[0] != 0 || d->tap_dh[0] != 0 || d->tap_dw[0] != 0 || d->wt != 1) return 0;
+    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return 0;
+    const long long P = (long long)d->N * d->PH * d->PW;
+    if ((long long)d->N * d->H * d->W != P || (long long)d->N * d->OH * d->OW != P) return 0;
+    static const int tt_min_tiles = getenv("TCVOM_TT256_MIN_TILES") ? atoi(getenv("TCVOM_TT256_MIN_TILES")) : 8;
+    // (every workgroup ends with 256 KB of atomics: worth it from 8 tiles on -- K C >= 512 K weights; the 4-tile shapes measured
+    //  slower than igemm_tt)
+    return d->K >= 256 && d->C >= 256 && d->K % 8 == 0 && d->C % 8 == 0 && P >= 4096 && cdiv(d->K, 256) * cdiv(d->C, 256) >= tt_min_tiles;
+}
+int gemm_tt256_try_launch(const void* dy, const void* x, float* dw, const tcvom_conv_desc* d, int ldy, void* stream, int nb,
+                          long long dy_stride, long long x_stride, long long dw_stride) {
+    // nb > 1: nb problems `*_stride` ELEMENTS apart (the frames of a frame-batched layer) in one launch -- the tiles of all problems
+    // share the chip, so every tile is split into fewer parts (fewer atomics per flop)
+    if (!gemm_tt256_takes(d)) return 0;
+    const long long P = (long long)d->N * d->PH * d->PW;
+    if (ldy % 8 != 0 || ldy < d->K) return 0;
+    if (P < 4096 || P * (long long)(ldy > d->C ? ldy : d->C) >= (1ll << 31)) return 0;
+    if ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) & 15) != 0) return 0;
+    Gemm256Args g;
+    g.A = (const h16raw*)x;          // k-major A: row k = pixel p, columns m = input channels c
+    g.B = (const h16raw*)dy;         // k-major B: row k = pixel p, columns n = output channels k
+    g.out = dw;
+    g.bias = nullptr; g.mscale = nullptr; g.mdiag = nullptr;
+    g.zero_page = tcvom_zero_page();
+    if (!g.zero_page) return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_tt256: could not allocate the zero page");
+    g.M = d->C; g.N = d->K; g.K = (int)((P + 63) / 64 * 64); g.ldo = d->C; g.act = 0; g.out_fp32 = 1; g.batch = nb;
+    g.a_bstride = x_stride; g.b_bstride = dy_stride; g.out_bstride = dw_stride; g.vec_bstride = 0;
+    g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
+    g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
+    g.stats = nullptr;
+    g.ldb = ldy; g.krows = (int)P;
+    g.lda = d->C; g.krows_a = (int)P;
+    const int nx = cdiv(d->K, 256), ny = cdiv(d->C, 256), tiles = nx * ny * nb, ntile = g.K / 64;
+    // one workgroup per CU (128 KB of LDS): ~256 workgroups per problem (the frames of a layer are launched back to back), every
+    // part at least 8 K-tiles long
+    // parts per tile: whole rounds of 256 workgroups (one per CU), each round as long as its share of the reduction plus the
+    // atomic epilogue (~20 K-tiles' worth): minimise rounds x (K-tiles per part + 20)
+    int sp = 1;
+    {
+        long long best = -1;
+        for (int c = 1; c <= 64 && ntile / c >= 8; ++c) {
+            const long long rounds = ((long long)tiles * c + 255) / 256, cost = rounds * ((ntile + c - 1) / c + 20);
+            if (best < 0 || cost < best) { best = cost; sp = c; }
+        }
+    }
+    g.flat_nx = nx; g.flat_ny = ny; g.split_r = tiles; g.split_s = sp;
+    const dim3 grid((unsigned)(tiles * sp), 1, 1);
+    hipLaunchKernelGGL((gemm_nt256_kernel<0, 4, 1, 1>), grid, dim3(512), 0, (hipStream_t)stream, g);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "gemm_tt256: %s", hipGetErrorString(e));
+    return 1;
+}
+
 // ---- GuidedCxtAtten backward, fused: T[b][i][j] = P[b][i][j] * (sum_v dO[b][i][v] V[b][j][v] - delta[b][i]) * c[b][j] (bf16,
 // zero in the padding columns N <= j < ld), delta[b][i] = sum_j P dP = <dO[b][i], O[b][i]>.  Replaces the fp32 dP GEMM
 // (800 MB written and read back per 3-frame launch at 1080p) + tcvom_row_softmax_bwd of models/GCA/ops.py:190's backward.
-extern const h16raw* tcvom_zero_page(void);
 extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const void* P, const float* delta, const float* cvec, void* T,
                                         void* Tt, void* Pt, int32_t N, int32_t DV, int64_t ld, int32_t batch, void* stream) {
     TCVOM_CHECK_ARG(dO && V && P && delta && cvec && T, "gca_dp_softmax_bwd: null pointer");

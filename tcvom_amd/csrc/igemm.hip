@@ -367,7 +367,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
 // Tile configuration.  The ResNet layers all have the same FLOP count but very different pixel counts: at
 // os16/os32 (8160 / 2040 pixels at 1080p) a 128x128 tiling yields only 64-128 workgroups for 256 CUs, so those
 // layers switch to 64x64 tiles (4x the workgroups, ~2.5x the co-resident workgroups per CU).
-struct NtCfg { int tm, tn, waves_n; };
+struct NtCfg { int tm, tn, waves_n; int nst = 0; };
 
 // 256 zero bytes per device: the source of every out-of-image / dummy tap (allocated once, on first use —
 // before any graph capture — and never freed; the only allocation the library ever makes)
@@ -417,7 +417,13 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         if ((long long)cdiv(P, 64) * cdiv(d->K, 128) * nb >= 400) return {128, 64, 2};
         return {64, 64, 2};
     }
-    if (d->K > 32) return {64, 128, 2};
+    // K <= 64: short reductions (1 .. 9 K-steps), bound by the latency of ONE workgroup times the rounds of co-resident workgroups:
+    // a 2-slot ring (49 KB: three workgroups per CU instead of two) measured +0.1 windows/s; TCVOM_NT_K64_NST=3 is the old 3-slot form.
+    // (Measured without effect, round 4: 32 x 128 tiles for K <= 32 -- twice the workgroups per CU -- and whole-row stores of the
+    //  16-bit outputs through LDS: these layers re-fetch every input pixel once per tap through the L2 -> LDS DMA path, which bounds
+    //  them at ~3.5 TB/s of DMA traffic -- ConvTranspose 32 -> 32 at 1088 x 1920: 535 MB through the DMA path for 33 MB of input.)
+    static const int k64nst = getenv("TCVOM_NT_K64_NST") ? atoi(getenv("TCVOM_NT_K64_NST")) : 2;
+    if (d->K > 32) return {64, 128, 2, k64nst};
     return {32, 256, 4};
 }
 
@@ -429,6 +435,9 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
 int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int wsconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                       float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream);
+int gemm_tt256_try_launch(const void* dy, const void* x, float* dw, const tcvom_conv_desc* d, int ldy, void* stream, int nb,
+                          long long dy_stride, long long x_stride, long long dw_stride);
+int gemm_tt256_takes(const tcvom_conv_desc* d);
 // gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                           const tcvom_conv_desc* d, const h16raw* zero_page, void* stream, const void* in2, void* out2,
@@ -533,6 +542,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         if (nst3 && nwg > 512 && nwg <= 768) NT_LAUNCH(256, 64, 64, 32, 32, 3);
         else NT_LAUNCH(256, 64, 64, 32, 32, 4);
     }
+    else if (c.tm == 64 && c.nst == 2) NT_LAUNCH(256, 64, 128, 32, 64, 2);
     else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 3);
     else NT_LAUNCH(256, 32, 256, 32, 64, 2);
 #undef NT_LAUNCH
@@ -868,6 +878,7 @@ extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
         if (ok) return "halo_wgrad<32>";
     }
     if (const char* v = wgradws_variant(d, d->K)) return v;
+    if (gemm_tt256_takes(d)) return "gemm_tt256";
     int tm, tn;
     tt_tile(d, &tm, &tn);
     if (tm == 128) return "igemm_tt<128,128,64,32,1>";
@@ -920,6 +931,29 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     {
         const int r = wgradws_try_launch(dys, ins, dws, nbatch, descs, nphase, ldy, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
+    bool tt256 = nphase == 1 && gemm_tt256_takes(d) && ldy % 8 == 0 && ldy >= d->K &&
+                 (long long)d->N * d->PH * d->PW * (long long)(ldy > d->C ? ldy : d->C) < (1ll << 31);
+    for (int i = 0; i < nbatch && tt256; ++i) tt256 = ((((uintptr_t)dys[i]) | ((uintptr_t)ins[i]) | ((uintptr_t)dws[i])) & 15) == 0;
+    if (tt256) {
+        // dense 1 x 1 convs with large K x C: split-K TT GEMMs on the k-major path of gemm_nt256 (gemm256.hip) -- one launch when the
+        // problems lie at uniform strides (the frames of a frame-batched layer), else one per problem
+        bool uniform = nbatch > 1;
+        long long sdy = 0, sx = 0, sdw = 0;
+        if (uniform) {
+            sdy = (const char*)dys[1] - (const char*)dys[0]; sx = (const char*)ins[1] - (const char*)ins[0]; sdw = (const char*)dws[1] - (const char*)dws[0];
+            for (int i = 2; i < nbatch; ++i)
+                uniform = uniform && (const char*)dys[i] - (const char*)dys[i - 1] == sdy && (const char*)ins[i] - (const char*)ins[i - 1] == sx &&
+                          (const char*)dws[i] - (const char*)dws[i - 1] == sdw;
+            // (sdw == 0: the calls of a layer whose weight does not change between frames add into ONE gradient -- atomics)
+            uniform = uniform && sdy > 0 && sx > 0 && sdw >= 0 && sdy % 16 == 0 && sx % 16 == 0 && sdw % 16 == 0;
+        }
+        int r = 1;
+        if (uniform) r = gemm_tt256_try_launch(dys[0], ins[0], dws[0], d, ldy, stream, nbatch, sdy / 2, sx / 2, sdw / 4);
+        else for (int i = 0; i < nbatch && r == 1; ++i) r = gemm_tt256_try_launch(dys[i], ins[i], dws[i], d, ldy, stream, 1, 0, 0, 0);
+        if (r < 0) return r;
+        TCVOM_CHECK_ARG(r == 1, "wgrad_igemm: the dense weight-gradient GEMM refused a shape it was asked about");
+        return TCVOM_OK;
     }
     int tm, tn;
     tt_tile(d, &tm, &tn);

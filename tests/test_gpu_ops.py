@@ -1219,3 +1219,41 @@ def test_fp16_overflow_guard_drops_the_step_and_halves_the_loss_scale():
     finally:
         sc._set_scale(saved[0])
         sc.clean_steps, sc.skipped_steps = saved[1], saved[2]
+
+
+@pytest.mark.parametrize('cin,cout,H,W,S', [(512, 2048, 72, 96, 1), (2048, 512, 68, 120, 3), (1024, 1024, 64, 80, 2), (520, 2040, 70, 61, 1)])
+def test_dense_weight_gradient_on_the_kmajor_gemm(cin, cout, H, W, S):
+    """Weight gradient of a 1 x 1 conv with K, C >= 256 as a split-K TT GEMM on the k-major operand path of gemm_nt256
+    (gemm256.hip: gemm_tt256_try_launch; every tile split over the pixel reduction, fp32 atomics) against an fp32 matmul of the
+    same 16-bit operands: ragged channel counts (masked 256-tiles), a pixel count that is not a multiple of 64, batched calls."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.ops import _phase_array
+    tag = 'tt%d_%d_%d' % (cin, cout, H)
+    bank, spec = _mini_bank(cin, cout, 1, 1, 0, False, spectral=False, tag=tag)
+    geo = ConvGeometry(spec, 1, H, W)
+    arr = _phase_array(geo.wgrad)
+    assert L._FNS['tcvom_wgrad_igemm_variant'](C.byref(arr[0])).decode() == 'gemm_tt256'
+    xs = [hu('x%d.%s' % (i, tag), (1, H, W, cin)).to(DEV).to(H16) for i in range(S)]
+    dys = [hu('dy%d.%s' % (i, tag), (1, H, W, cout)).to(DEV).to(H16) for i in range(S)]
+    dw = torch.zeros(S, cout * cin, device=DEV)
+    vp = lambda ts: C.cast((C.c_void_p * S)(*[t.data_ptr() for t in ts]), C.c_void_p)
+    L.call('tcvom_wgrad_igemm_batched', vp(dys), vp(xs), vp([dw[i] for i in range(S)]), S, arr, len(geo.wgrad), cout, L.stream_ptr())
+    torch.cuda.synchronize()
+    refs = [dys[i].float().reshape(-1, cout).t() @ xs[i].float().reshape(-1, cin) for i in range(S)]           # [K][C]
+    for i in range(S):
+        assert rel_err(dw[i].reshape(cout, cin).cpu(), refs[i].cpu()) < 1e-4, i
+    if S > 1:
+        # (a) the problems at UNIFORM strides (frames of one tensor) go out as one launch; (b) ... into ONE shared gradient (a layer
+        # whose weight does not change between the frames)
+        xcat, dycat = torch.stack(xs), torch.stack(dys)
+        dwu = torch.zeros(S, cout * cin, device=DEV)
+        L.call('tcvom_wgrad_igemm_batched', vp([dycat[i] for i in range(S)]), vp([xcat[i] for i in range(S)]), vp([dwu[i] for i in range(S)]),
+               S, arr, len(geo.wgrad), cout, L.stream_ptr())
+        one = torch.zeros(cout * cin, device=DEV)
+        L.call('tcvom_wgrad_igemm_batched', vp([dycat[i] for i in range(S)]), vp([xcat[i] for i in range(S)]), vp([one] * S),
+               S, arr, len(geo.wgrad), cout, L.stream_ptr())
+        torch.cuda.synchronize()
+        assert rel_err(dwu.cpu(), dw.cpu()) < 1e-5
+        assert rel_err(one.reshape(cout, cin).cpu(), sum(refs).cpu()) < 1e-4
