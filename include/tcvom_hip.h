@@ -489,6 +489,9 @@ int tcvom_maxpool3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int32_t N
 /* pyramid pooling (models/VMN/VMN_FBA.py:23-31): nn.AdaptiveAvgPool2d(s) -> fp32 [N][s][s][C]; the backward sums the
  * gradients of up to 4 scales (dout / scales are HOST arrays) into dx (NHWC bf16) */
 int tcvom_adaptive_avgpool(const void* x, float* out, int32_t N, int32_t h, int32_t w, int32_t C, int32_t s, void* stream);
+/* every scale of the pyramid in one pass over x (outs / scales: HOST arrays of nscales <= 4 entries; outs[i]: fp32 [N][s_i][s_i][C]) */
+int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, int32_t N, int32_t h,
+                                 int32_t w, int32_t C, void* stream);
 int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N,
                                int32_t h, int32_t w, int32_t C, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) between channel slices of NHWC bf16 tensors (pixel strides ld_*,

@@ -143,6 +143,7 @@ _PROTOS = {
     'tcvom_maxpool3s2': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_maxpool3s2_bwd': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool': [vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_adaptive_avgpool_multi': [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool_bwd': [vp, vp, i32, vp, i32, i32, i32, i32, vp],
     'tcvom_bilinear': [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_bilinear_up2_bwd': [vp, vp, i32, i32, i32, i32, i32, i32, vp],

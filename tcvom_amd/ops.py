@@ -1154,11 +1154,20 @@ class _PyramidPool(torch.autograd.Function):
         x = _c(x)
         N, h, w, Cc = x.shape
         st = L.stream_ptr()
-        outs = []
-        for s in scales:
-            o = torch.empty((N, s, s, Cc), dtype=torch.float32, device=x.device)
-            L.call('tcvom_adaptive_avgpool', L.ptr(x), L.ptr(o), N, h, w, Cc, s, st)
-            outs.append(o.to(H16))
+        n = len(scales)
+        if 1 <= n <= 4 and 256 % (Cc // 8) == 0:
+            # one pass over x for all scales (tcvom_adaptive_avgpool_multi)
+            o32 = [torch.empty((N, s, s, Cc), dtype=torch.float32, device=x.device) for s in scales]
+            ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in o32])
+            sc = (C.c_int32 * n)(*[int(s) for s in scales])
+            L.call('tcvom_adaptive_avgpool_multi', L.ptr(x), C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, N, h, w, Cc, st)
+            outs = [o.to(H16) for o in o32]
+        else:
+            outs = []
+            for s in scales:
+                o = torch.empty((N, s, s, Cc), dtype=torch.float32, device=x.device)
+                L.call('tcvom_adaptive_avgpool', L.ptr(x), L.ptr(o), N, h, w, Cc, s, st)
+                outs.append(o.to(H16))
         ctx.shape, ctx.scales = (N, h, w, Cc), tuple(scales)
         return tuple(outs)
 
