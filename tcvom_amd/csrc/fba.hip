@@ -161,35 +161,65 @@ __global__ __launch_bounds__(256) void adaptive_pool_multi_kernel(const uint4* _
     }
 }
 // dx = sum over the scales of dout_s[bin] / |bin| for every bin that contains the pixel
-struct PoolGrads { const float* d[4]; int s[4]; int n; };
-__global__ void adaptive_pool_bwd_kernel(PoolGrads pg, uint4* __restrict__ dx, int64_t n, int h, int w, int C8) {
-    GRID_STRIDE(v, n) {
-        const int c8 = (int)(v % C8);
-        int64_t t = v / C8;
-        const int xx = (int)(t % w); t /= w;
-        const int yy = (int)(t % h);
-        const int64_t nb = t / h;
+// dx = sum over the scales of dout_s[bin] / |bin| for every bin that contains the pixel.  Inside a CELL of the union partition
+// (see adaptive_pool_multi_kernel) the set of bins is the same for every pixel, so dx is CONSTANT per channel there: a block computes
+// the 8 values of its channel octets once per (sample, cell) and streams them over the cell's pixels -- a pure write pass.  (Per pixel,
+// every 16-byte output re-read up to 16 x 32 bytes of pooled gradients through L2: 742 us for the 400 MB gradient of a 1080p window.)
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const PoolMulti pm, uint4* __restrict__ dx, int h, int w, int C8) {
+    const int ncell = (pm.nr - 1) * (pm.nc - 1);
+    const int cell = blockIdx.x % ncell, nb = blockIdx.x / ncell;
+    const int ci = cell / (pm.nc - 1), cj = cell % (pm.nc - 1);
+    const int h0 = pm.rows[ci], h1 = pm.rows[ci + 1], w0 = pm.cols[cj], w1 = pm.cols[cj + 1];
+    const int lanes = C8 >= 256 ? 1 : 256 / C8, pl = C8 >= 256 ? 0 : threadIdx.x / C8;
+    const int bw = w1 - w0;
+    const int npix = (h1 - h0) * bw;
+    for (int c8 = C8 >= 256 ? threadIdx.x : threadIdx.x % C8; c8 < C8; c8 += 256) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < pg.n; ++q) {
-            const int s = pg.s[q];
-            // bins overlap by at most one row / column: the candidates are floor(yy s / h) and its two neighbours (the loop over all
-            // s^2 bins of all scales made this pass 742 us for 400 MB written at 1080p)
-            const int bi_c = (yy * s) / h, bj_c = (xx * s) / w;
-            for (int bi = max(bi_c - 1, 0); bi <= min(bi_c + 1, s - 1); ++bi) {
-                const int h0 = bin_lo(bi, h, s), h1 = bin_hi(bi, h, s);
-                if (yy < h0 || yy >= h1) continue;
-                for (int bj = max(bj_c - 1, 0); bj <= min(bj_c + 1, s - 1); ++bj) {
-                    const int w0 = bin_lo(bj, w, s), w1 = bin_hi(bj, w, s);
-                    if (xx < w0 || xx >= w1) continue;
-                    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
-                    const float* g = pg.d[q] + (((nb * s + bi) * s + bj) * C8 + c8) * 8;
+        for (int q = 0; q < pm.n; ++q) {
+            const int sc = pm.s[q];
+            for (int bi = 0; bi < sc; ++bi) {
+                const int bh0 = bin_lo(bi, h, sc), bh1 = bin_hi(bi, h, sc);
+                if (h0 < bh0 || h1 > bh1) continue;
+                for (int bj = 0; bj < sc; ++bj) {
+                    const int bw0 = bin_lo(bj, w, sc), bw1 = bin_hi(bj, w, sc);
+                    if (w0 < bw0 || w1 > bw1) continue;
+                    const float inv = 1.f / (float)((bh1 - bh0) * (bw1 - bw0));
+                    const float* g = pm.out[q] + ((((int64_t)nb * sc + bi) * sc + bj) * C8 + c8) * 8;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) acc[k] += g[k] * inv;
                 }
             }
         }
-        dx[v] = pack8(acc);
+        const uint4 val = pack8(acc);
+        for (int p = blockIdx.y * lanes + pl; p < npix; p += gridDim.y * lanes) {
+            const int yy = h0 + p / bw, xx = w0 + p % bw;
+            dx[(((int64_t)nb * h + yy) * w + xx) * C8 + c8] = val;
+        }
     }
+}
+
+// host: the union of every scale's bin boundaries (sorted, unique) -> cells
+static int pool_cells(PoolMulti& pm, const int32_t* scales, int nscales, int h, int w) {
+    int rows[64], cols[64], nr = 0, nc = 0;
+    for (int q = 0; q < nscales; ++q) {
+        const int sc = scales[q];
+        for (int b = 0; b < sc; ++b) {
+            rows[nr++] = (b * h) / sc; rows[nr++] = ((b + 1) * h + sc - 1) / sc;
+            cols[nc++] = (b * w) / sc; cols[nc++] = ((b + 1) * w + sc - 1) / sc;
+        }
+    }
+    auto uniq = [](int* v, int n) {
+        for (int i = 1; i < n; ++i) { const int t = v[i]; int j = i - 1; while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; --j; } v[j + 1] = t; }
+        int m = 0;
+        for (int i = 0; i < n; ++i) if (m == 0 || v[m - 1] != v[i]) v[m++] = v[i];
+        return m;
+    };
+    nr = uniq(rows, nr); nc = uniq(cols, nc);
+    if (nr > 40 || nc > 40) return -1;
+    for (int i = 0; i < nr; ++i) pm.rows[i] = rows[i];
+    for (int i = 0; i < nc; ++i) pm.cols[i] = cols[i];
+    pm.nr = nr; pm.nc = nc;
+    return 0;
 }
 
 extern "C" int tcvom_adaptive_avgpool(const void* x, float* out, int32_t N, int32_t h, int32_t w, int32_t C, int32_t s, void* stream) {
@@ -211,31 +241,16 @@ extern "C" int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, c
     hipStream_t st = (hipStream_t)stream;
     PoolMulti pm;
     pm.n = nscales;
-    int rows[64], cols[64], nr = 0, nc = 0;
     for (int q = 0; q < 4; ++q) {
         const int i = q < nscales ? q : 0;
         TCVOM_CHECK_ARG(outs[i] && scales[i] >= 1 && scales[i] <= 8 && h >= scales[i] && w >= scales[i], "adaptive_avgpool_multi: scale %d", scales[i]);
         pm.out[q] = outs[i];
         pm.s[q] = scales[i];
-        if (q >= nscales) continue;
-        const int sc = scales[i];
-        if (hipMemsetAsync(outs[i], 0, sizeof(float) * (size_t)N * sc * sc * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "adaptive_avgpool_multi: memset failed");
-        for (int b = 0; b < sc; ++b) {
-            rows[nr++] = (b * h) / sc; rows[nr++] = ((b + 1) * h + sc - 1) / sc;
-            cols[nc++] = (b * w) / sc; cols[nc++] = ((b + 1) * w + sc - 1) / sc;
-        }
+        if (q < nscales && hipMemsetAsync(outs[i], 0, sizeof(float) * (size_t)N * scales[i] * scales[i] * C, st) != hipSuccess)
+            return tcvom_fail(TCVOM_ERR_LAUNCH, "adaptive_avgpool_multi: memset failed");
     }
-    auto uniq = [](int* v, int n) {
-        for (int i = 1; i < n; ++i) { const int t = v[i]; int j = i - 1; while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; --j; } v[j + 1] = t; }
-        int m = 0;
-        for (int i = 0; i < n; ++i) if (m == 0 || v[m - 1] != v[i]) v[m++] = v[i];
-        return m;
-    };
-    nr = uniq(rows, nr); nc = uniq(cols, nc);
-    TCVOM_CHECK_ARG(nr <= 40 && nc <= 40, "adaptive_avgpool_multi: too many bin boundaries");
-    for (int i = 0; i < nr; ++i) pm.rows[i] = rows[i];
-    for (int i = 0; i < nc; ++i) pm.cols[i] = cols[i];
-    pm.nr = nr; pm.nc = nc;
+    TCVOM_CHECK_ARG(pool_cells(pm, scales, nscales, h, w) == 0, "adaptive_avgpool_multi: too many bin boundaries");
+    const int nr = pm.nr, nc = pm.nc;
     // ~1024 blocks: row splits per cell
     const int cells = (nr - 1) * (nc - 1) * N;
     int split = (1024 + cells - 1) / cells;
@@ -246,12 +261,22 @@ extern "C" int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, c
 }
 extern "C" int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N, int32_t h,
                                           int32_t w, int32_t C, void* stream) {
-    TCVOM_CHECK_ARG(dout && scales && dx && nscales >= 1 && nscales <= 4 && N > 0 && C % 8 == 0, "adaptive_avgpool_bwd: bad args");
-    PoolGrads pg;
-    pg.n = nscales;
-    for (int i = 0; i < 4; ++i) { pg.d[i] = dout[i < nscales ? i : 0]; pg.s[i] = scales[i < nscales ? i : 0]; }
-    const int64_t n = (int64_t)N * h * w * (C / 8);
-    hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, pg, (uint4*)dx, n, h, w, C / 8);
+    TCVOM_CHECK_ARG(dout && scales && dx && nscales >= 1 && nscales <= 4 && N > 0 && C % 8 == 0 && (256 % (C / 8) == 0 || (C / 8) % 256 == 0),
+                    "adaptive_avgpool_bwd: bad args");
+    TCVOM_CHECK_ARG((256 % (C / 8) == 0 || (C / 8) % 256 == 0) && C <= 16384, "adaptive_avgpool_bwd: C=%d", C);
+    PoolMulti pm;
+    pm.n = nscales;
+    for (int q = 0; q < 4; ++q) {
+        const int i = q < nscales ? q : 0;
+        TCVOM_CHECK_ARG(dout[i] && scales[i] >= 1 && scales[i] <= 8 && h >= scales[i] && w >= scales[i], "adaptive_avgpool_bwd: scale %d", scales[i]);
+        pm.out[q] = const_cast<float*>(dout[i]);
+        pm.s[q] = scales[i];
+    }
+    TCVOM_CHECK_ARG(pool_cells(pm, scales, nscales, h, w) == 0, "adaptive_avgpool_bwd: too many bin boundaries");
+    const int cells = (pm.nr - 1) * (pm.nc - 1) * N;
+    int split = (2048 + cells - 1) / cells;
+    if (split > 32) split = 32;
+    hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3((unsigned)cells, (unsigned)split), dim3(256), 0, (hipStream_t)stream, pm, (uint4*)dx, h, w, C / 8);
     TCVOM_LAUNCH_CHECK("adaptive_avgpool_bwd");
     return TCVOM_OK;
 }
