@@ -6,7 +6,7 @@ root=$PWD
 cd /tmp
 for k in 4 14; do
   rm -rf /tmp/kt$k
-  rocprofv3 --kernel-trace --stats -d /tmp/kt$k -o kt -- python $root/bench.py --steps $k --warmup 2 --no-cpu-baseline --no-profile > /tmp/kt$k.log 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/kt$k -o kt -- python $root/bench.py --steps $k --warmup 2 --no-cpu-baseline --no-profile --no-other-configs > /tmp/kt$k.log 2>&1
   python $root/tools/rocpd_summary.py $(find /tmp/kt$k -name "*.db" | head -1) 400 > /tmp/kt$k.md
   grep "total kernel time" /tmp/kt$k.md
 done

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 10 --warmup 4 --no-cpu-baseline > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-other-configs > $out/kt.log 2>&1
 db=$(find $out/kt -name "*.db" | head -1)
 python tools/rocpd_summary.py $db 70 > gpurun_out/${tag}_kernel_stats.md
 python tools/rocpd_shapes.py $db > gpurun_out/${tag}_kernel_shapes.md 2>/dev/null
@@ -17,11 +17,11 @@ python tools/rocpd_shapes.py $db > gpurun_out/${tag}_kernel_shapes.md 2>/dev/nul
 tail -1 $out/kt.log | cut -c1-300
 rm -f $db
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $out/$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out/$c.log 2>&1
+  rocprofv3 --pmc $c -d $out/$c -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-other-configs > $out/$c.log 2>&1
 done
 grep "^{" $out/kt.log | tail -1 > $out/bench_line.json
 python tools/rocpd_pmc.py $(find $out/FETCH_SIZE -name "*.db" | head -1) $(find $out/WRITE_SIZE -name "*.db" | head -1) 40 $out/bench_line.json > gpurun_out/${tag}_hbm_traffic_pmc.md
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $out/sq -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $out/sq.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $out/sq -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-other-configs > $out/sq.log 2>&1
 python tools/rocpd_mfma.py $(find $out/sq -name "*.db" | head -1) 30 > gpurun_out/${tag}_mfma_busy.md
 find $out -name "*.db" -delete
 ls -la gpurun_out/${tag}_*
