@@ -153,6 +153,41 @@ def _unscale_(bank, *grads):
                 g.mul_(1.0 / bank.loss_scale)
 
 
+class _GradStash(list):
+    """The deposit list of a conv + BatchNorm output (`z._tcvom_grad_stash`).  Deposits bypass autograd's edges, hence also its
+    stream synchronisation: when the depositing op runs on another HIP stream than the op that consumes the list (the shortcut
+    branches of the GCA encoder on their side stream, gca_net.py), the deposit records an event and the consumer waits for it."""
+    __slots__ = ('events',)
+
+    def deposit(self, item):
+        self.append(item)
+        if SIDE_STREAMS[0]:
+            ev = torch.cuda.Event()
+            ev.record()
+            if getattr(self, 'events', None) is None:
+                self.events = []
+            self.events.append(ev)
+
+    def collect(self):
+        """Called by the consumer before it reads the deposits: wait for their streams, keep their memory from being reused early."""
+        evs = getattr(self, 'events', None)
+        if evs:
+            cur = torch.cuda.current_stream()
+            for ev in evs:
+                cur.wait_event(ev)
+            for t in self:
+                g = t[1] if isinstance(t, tuple) else t
+                g.record_stream(cur)
+            self.events = None
+
+
+SIDE_STREAMS = [False]          # set once a network runs part of its window on other streams (deposits then carry events)
+# (Round 4, measured and dropped: the tail-only shortcut branches of the GCA encoder -- os1 / os2 / os4 halo convs + BatchNorm passes,
+#  ~2.5 ms of HBM-bound work per 1080p step -- on a SIDE stream beside the MFMA-bound trunk, autograd replaying the stream in backward:
+#  parity-green, but 40.0 against 41.1 windows/s on the same box at any stream priority: the streaming kernels take CU slots and L2
+#  from the attention GEMMs, which lose more than the overlap gains.)
+
+
 def _need_cuda(t):
     if not t.is_cuda:
         raise RuntimeError('tcvom_amd ops run on the GPU through libtcvom_hip.so only (no CPU fallback); got a %s tensor'
@@ -414,6 +449,7 @@ class _ConvBNAct(torch.autograd.Function):
         K = spec.K
         extra, ranged = [], []
         if ctx.stash:                                      # gradients consumers deposited instead of returning them to autograd
+            ctx.stash.collect()
             for t in ctx.stash:
                 if isinstance(t, tuple):                   # ('rows', g, lo, hi): frame_slice's gradient of rows lo .. hi only
                     ranged.append(t)
@@ -522,10 +558,10 @@ class _ConvBNAct(torch.autograd.Function):
         if dres1 is not None and ctx.res1_stash is not None:
             # the producer of res1 (a conv + BatchNorm op further up) adds this to its incoming gradient inside its
             # BatchNorm-backward kernels (dz2 of tcvom_bn_bwd_reduce / tcvom_bn_bwd_apply): no element-wise add pass
-            ctx.res1_stash.append(dres1)
+            ctx.res1_stash.deposit(dres1)
             dres1 = None
         if dx is not None and ctx.x_stash is not None and dx.shape == x.shape:
-            ctx.x_stash.append(dx)                         # likewise the data gradient, when the input came from such an op
+            ctx.x_stash.deposit(dx)                        # likewise the data gradient, when the input came from such an op
             dx = None
         _unscale_(bank, dbias)
         return dx, None, dgamma, dbeta, dbias, dres1, dres2, None, None, None
@@ -598,13 +634,13 @@ def _backward_active(ctx, dz, dz2, ranged=()):
             # or adds the rows inside its BatchNorm-backward kernels (dz2 with a frame range)
             dxa = torch.empty((N * nfa, geo.H, geo.W, cx), dtype=H16, device=dev)
             _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), dxa, None, None, ACT_NONE, st, nfa, ctx.wsb)
-            ctx.x_stash.append(('rows', dxa, f0 * N, f1 * N))
+            ctx.x_stash.deposit(('rows', dxa, f0 * N, f1 * N))
         else:
             dx = torch.zeros((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dev)
             _launch_conv(geo.dgrad, dya, bank.bwd_ptr(spec, ctx.call + f0), fr(dx), None, None, ACT_NONE, st, nfa, ctx.wsb)
     bank.defer_wgrad(spec, ctx.call + f0, dya, xa, geo, nfa)
     if dx is not None and ctx.x_stash is not None and dx.shape == x.shape:
-        ctx.x_stash.append(dx)
+        ctx.x_stash.deposit(dx)
         dx = None
     return dx, None, None, None, None, None, None, None, None, None
 
@@ -835,7 +871,7 @@ class _FrameSlice(torch.autograd.Function):
             return None, None, None, None
         lo, hi = ctx.rng
         if ctx.stash is not None:
-            ctx.stash.append(('rows', g, lo, hi))
+            ctx.stash.deposit(('rows', g, lo, hi))
             return None, None, None, None
         full = g.new_zeros((ctx.rows,) + tuple(g.shape[1:]))
         full[lo:hi] = g
@@ -900,7 +936,7 @@ def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
     bn = cfg.bn
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
-    stash = [] if (bn is not None and torch.is_grad_enabled()) else None
+    stash = _GradStash() if (bn is not None and torch.is_grad_enabled()) else None
     z = _ConvBNAct.apply(x, token, gamma, beta, cfg.spec.bias, res1, res2, cfg, training, stash)
     if stash is not None and z.requires_grad:
         z._tcvom_grad_stash = stash

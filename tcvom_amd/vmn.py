@@ -138,6 +138,7 @@ class VMN(nn.Module):
         main = torch.cuda.current_stream()
         # (SyncBatchNorm: the mailbox exchanges of a rank must run in ONE stream order -- tcvom_amd/mailbox.py)
         if self.frame_streams and not any(getattr(m, 'sync', False) for m in self.modules()):
+            ops.SIDE_STREAMS[0] = True                     # gradient deposits between ops carry stream events (ops._GradStash)
             if len(self._streams) < S:
                 object.__setattr__(self, '_streams', [torch.cuda.Stream() for _ in range(S)])
             for i in range(S):

@@ -544,6 +544,10 @@ class WeightBank(object):
         for s in {e[5] for e in pend}:
             if s != cur:
                 cur.wait_stream(s)
+        for e in pend:                                      # operands produced on another stream: no early reuse of their memory
+            if e[5] != cur:
+                e[2].record_stream(cur)
+                e[3].record_stream(cur)
         # Layers of one geometry share launches of the accumulator-stationary kernel (csrc/wgradws.hip): with every call of every
         # such layer in one launch a block of dw is owned by one or two workgroups instead of ~40.  Other shapes: the calls of
         # a layer as one batched launch.

@@ -23,7 +23,7 @@ def test_frame_slice_deposits_a_row_range_gradient_or_pads_with_zeros():
     # a producer that takes row-range gradients: frame_slice hands the small gradient over and returns nothing to autograd
     t = torch.randn(6, 3, requires_grad=True)
     y = t * 2.0
-    stash = []
+    stash = ops._GradStash()
     y._tcvom_grad_stash = stash
     y._tcvom_tail_rows = (2, 4)
     z = ops.frame_slice(y, 2, 4)
@@ -39,11 +39,11 @@ def test_frame_slice_deposits_a_row_range_gradient_or_pads_with_zeros():
     assert torch.equal(t2.grad, want)
     # a different row range than a tail-only producer skips: not deposited
     y3 = (t2 * 1.0)
-    y3._tcvom_grad_stash, y3._tcvom_tail_rows = [], (2, 4)
+    y3._tcvom_grad_stash, y3._tcvom_tail_rows = ops._GradStash(), (2, 4)
     assert ops.frame_slice(y3, 0, 2).grad_fn.__class__.__name__ != '_FrameSliceBackward'
     # a conv + BatchNorm producer that runs for all frames (a stash, no tail rows): deposited, any frame range
     y4 = (t2 * 1.0)
-    y4._tcvom_grad_stash = []
+    y4._tcvom_grad_stash = ops._GradStash()
     ops.frame_slice(y4, 0, 2).sum().backward()
     assert len(y4._tcvom_grad_stash) == 1 and y4._tcvom_grad_stash[0][2:] == (0, 2)
 
