@@ -15,6 +15,7 @@
 // Other windows (1, 3, 5): one wave (64 lanes) per unknown pixel taken from a compacted work list; a lane owns channel pairs
 // {lane + 64*i}; the w*w neighbour key slices stay in registers between the logit and the aggregation pass.
 // HBM-bound: algorithmic traffic = read q, v, kb, kf + write out + 2 logit maps.
+#include <cstdlib>
 #include "common.h"
 
 template <int WIN, int NP>
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(TAM_NW * 64) void tam_tiled_kernel(
     const uint4* __restrict__ q, const uint4* __restrict__ kb, const uint4* __restrict__ kf, const unsigned* __restrict__ v,
     const uint4* __restrict__ g, const unsigned char* __restrict__ mask, unsigned* __restrict__ out,
     float* __restrict__ att0, float* __restrict__ att1, const float* __restrict__ datt0, const float* __restrict__ datt1,
-    int H, int W, int C, float inv_sqrt_c)
+    int H, int W, int C, float inv_sqrt_c, int cnt_hi)
 {
     constexpr int W2 = WIN * WIN, R = WIN / 2, HH = TH + 2 * R, HW = TW + 2 * R, NT = TH * TW, NP = C8MAX / 16;
     __shared__ uint4 halo[2 * HH * HW * C8MAX];        // both directions
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(TAM_NW * 64) void tam_tiled_kernel(
     }
     __syncthreads();
     const int nu = cnt;
-    if (nu == 0) return;
+    if (nu == 0 || nu >= cnt_hi) return;                    // (denser tiles: tam_mfma_kernel)
     for (int idx = tid; idx < 2 * HH * HW * C8; idx += TAM_NW * 64) {
         const int d = idx / (HH * HW * C8), rem = idx - d * (HH * HW * C8);
         const int r = rem / C8, c = rem - r * C8;
@@ -380,6 +381,236 @@ __global__ __launch_bounds__(TAM_NW * 64) void tam_tiled_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------ MFMA tile kernel (window 7, C = 128)
+// The same 8 x 8 pixel tile with its 14 x 14 key halos in LDS, but the two contractions of a tile are DENSE products on the matrix
+// cores instead of one wave per pixel on the vector ALUs:
+//     S^T [224 keys][64 queries] = K_halo [224][128] * Q_tile^T        (196 halo keys padded to 7 blocks of 32; 56 MFMA 32x32x16)
+//     O^T [128 ch][64 queries]  += K_halo^T [128][224] * P [224][64]   (P = softmax of the 49 in-window entries of a column, 0 elsewhere)
+// 4x the useful flops (a query needs 49 of the 196 columns), at ~30x the rate.  Wave = (query block of 32, direction).  A lane of
+// the S^T accumulators holds ONE query (lane & 31) and 16 key rows per block, so the softmax is a reduction over its own registers
+// plus ONE exchange with the partner lane (lane ^ 32).  P feeds the second product straight from those registers as the B operand:
+// the reduction index of a k-step is taken in the accumulator's own row order (rows 16 t + 4 h + r and 16 t + 8 + 4 h + r of a block
+// for lane half h), and the A operand -- K^T, channels x keys -- is read with that row order through the transposing LDS read
+// (ds_read_b64_tr_b16: 4 key rows per read), so no lane exchange and no LDS round trip of P.
+// LDS rows are 256 bytes (128 channels); the 16-byte chunk c of row r sits at c ^ 4 (r & 3) ^ ((r >> 2) & 3): the 32 rows of a
+// ds_read_b128 fragment read (GEMM 1) fall on 16 distinct bank groups, and the 4 rows of a transposing read on distinct 64-byte groups.
+// MODE 0: forward (out = v + both directions, logits).  MODE 1: backward pass A (dq, p and ds / sqrt(C) for pass B): a third product
+// dP^T = K_halo * dO^T of the first kind, the softmax backward in registers, dq^T = K_halo^T * dS.
+__device__ __forceinline__ int tam_swz(int c, int r) { return c ^ ((r & 3) << 2) ^ ((r >> 2) & 3); }
+template <int MODE>
+__global__ __launch_bounds__(256) void tam_mfma_kernel(
+    const uint4* __restrict__ q, const uint4* __restrict__ kb, const uint4* __restrict__ kf, const unsigned* __restrict__ v,
+    const uint4* __restrict__ g, const unsigned char* __restrict__ mask, unsigned* __restrict__ out,
+    float* __restrict__ att0, float* __restrict__ att1, const float* __restrict__ datt0, const float* __restrict__ datt1,
+    int H, int W, float inv_sqrt_c, int cnt_lo)
+{
+    constexpr int WIN = 7, W2 = 49, R = 3, TH = 8, TW = 8, HW = 14, NKEY = 196, NK = 224, C8 = 16, NT = 64;
+    extern __shared__ __attribute__((aligned(16))) uint4 tam_lds[];
+    uint4* halo = tam_lds;                                  // [2][224][16]
+    uint4* qt = halo + 2 * NK * C8;                         // [64][16]
+    uint4* gt = qt + NT * C8;                               // [64][16] (MODE 1)
+    // (the query / gradient tiles are dead after the first products: the 2 x 16 KB exchange area of the epilogue lies over them; the
+    //  forward kernel has no gradient tile, its second half is extra)
+    float* comb = reinterpret_cast<float*>(qt);             // [2 query blocks][4][16][64] fp32
+    __shared__ unsigned char unk[NT];
+    __shared__ int cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const int64_t N = (int64_t)H * W;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    if (tid < NT) {
+        const int y = ty0 + tid / TW, x = tx0 + tid % TW;
+        const bool u = y < H && x < W && mask[b * N + (int64_t)y * W + x] != 0;
+        unk[tid] = u ? 1 : 0;
+        if (u) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (cnt < cnt_lo) return;                               // (sparser tiles: the one-wave-per-pixel kernel, see the launchers)
+    {
+        // thread -> (chunk c = tid & 15, halo row r = (tid >> 4) + 16 i): 14 rows of 16 threads per pass and direction, all loads of a
+        // thread issued before its stores
+        const int c = tid & 15;
+        uint4 val[2][14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            const int hy = r / HW, hx = r - hy * HW;
+            const int y = ty0 + hy - R, x = tx0 + hx - R;
+            const bool ok = r < NKEY && y >= 0 && y < H && x >= 0 && x < W;
+            const int64_t off = (b * N + (int64_t)y * W + x) * C8 + c;
+            val[0][i] = ok ? kb[off] : make_uint4(0u, 0u, 0u, 0u);
+            val[1][i] = ok ? kf[off] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            halo[r * C8 + tam_swz(c, r)] = val[0][i];
+            halo[(NK + r) * C8 + tam_swz(c, r)] = val[1][i];
+        }
+    }
+    for (int idx = tid; idx < NT * C8; idx += 256) {
+        const int p = idx >> 4, c = idx & 15;
+        const int y = ty0 + p / TW, x = tx0 + p % TW;
+        const bool in = y < H && x < W;
+        qt[p * C8 + tam_swz(c, p)] = in ? q[(b * N + (int64_t)y * W + x) * C8 + c] : make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == 1) gt[p * C8 + tam_swz(c, p)] = in ? g[(b * N + (int64_t)y * W + x) * C8 + c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int qb = wave & 1, dir = wave >> 1;
+    const int n = lane & 31, h = lane >> 5;
+    const int qi = qb * 32 + n, qy = qi >> 3, qx = qi & 7;
+    const bool q_unk = unk[qi] != 0;
+    const int64_t u = (int64_t)(ty0 + qy) * W + tx0 + qx;       // (valid when q_unk)
+    const uint4* hl = halo + dir * NK * C8;
+    // ---- GEMM 1 (and the dP product of the backward): accumulators [7 key blocks][16 rows 8 g + 4 h + r]
+    f32x16_t acc[7], accd[MODE == 1 ? 7 : 1];
+#pragma unroll
+    for (int k7 = 0; k7 < 7; ++k7)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[k7][r] = 0.f; if (MODE == 1) accd[k7][r] = 0.f; }
+    {
+        h16x8_t fq[8], fg[MODE == 1 ? 8 : 1];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            fq[ks] = *reinterpret_cast<const h16x8_t*>(qt + qi * C8 + tam_swz(ks * 2 + h, qi));
+            if (MODE == 1) fg[ks] = *reinterpret_cast<const h16x8_t*>(gt + qi * C8 + tam_swz(ks * 2 + h, qi));
+        }
+#pragma unroll
+        for (int k7 = 0; k7 < 7; ++k7) {
+            const int row = k7 * 32 + n;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const h16x8_t fk = *reinterpret_cast<const h16x8_t*>(hl + row * C8 + tam_swz(ks * 2 + h, row));
+                acc[k7] = mfma16(fk, fq[ks], acc[k7], 0, 0, 0);
+                if (MODE == 1) accd[k7] = mfma16(fk, fg[ks], accd[k7], 0, 0, 0);
+            }
+        }
+    }
+    // ---- softmax over the 49 in-window keys of this lane's query (this lane + its partner lane ^ 32 hold them)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k7 = 0; k7 < 7; ++k7)
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const int row0 = k7 * 32 + 8 * (r16 >> 2) + (r16 & 3);         // (a constant after unrolling; + 4 for the upper lane half)
+            const int ky = h ? (row0 + 4) / HW : row0 / HW, kx = h ? (row0 + 4) % HW : row0 % HW;
+            const bool rel = (unsigned)(ky - qy) < (unsigned)WIN && (unsigned)(kx - qx) < (unsigned)WIN;
+            const float l = rel ? acc[k7][r16] * inv_sqrt_c : -3.0e38f;
+            acc[k7][r16] = l;
+            mx = fmaxf(mx, l);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f, dot = 0.f;
+    float* attd = dir == 0 ? att0 : att1;
+#pragma unroll
+    for (int k7 = 0; k7 < 7; ++k7)
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const float l = acc[k7][r16];
+            const bool rel = l > -1.0e38f;
+            if (MODE == 0 && rel && q_unk) {
+                const int row0 = k7 * 32 + 8 * (r16 >> 2) + (r16 & 3);
+                const int ky = h ? (row0 + 4) / HW : row0 / HW, kx = h ? (row0 + 4) % HW : row0 % HW;
+                attd[((int64_t)b * W2 + (ky - qy) * WIN + (kx - qx)) * N + u] = l;
+            }
+            const float e = rel ? __expf(l - mx) : 0.f;
+            acc[k7][r16] = e;
+            den += e;
+        }
+    den += __shfl_xor(den, 32, 64);
+    const float rden = 1.f / den;
+    if (MODE == 1) {
+#pragma unroll
+        for (int k7 = 0; k7 < 7; ++k7)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) dot += acc[k7][r16] * rden * accd[k7][r16];
+        dot += __shfl_xor(dot, 32, 64);
+    }
+    // ---- GEMM 2: O^T / dq^T [4 channel blocks][query]; B fragments from the registers, A = K^T through transposing reads
+    f32x16_t acc2[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[cb][r] = 0.f;
+    typedef __attribute__((address_space(3))) const void* tam_lp;
+    const unsigned hl_addr = (unsigned)(uintptr_t)(tam_lp)hl;
+    const int trow = (lane & 15) >> 2, cig = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    const float* dattd = dir == 0 ? datt0 : datt1;
+#pragma unroll
+    for (int k7 = 0; k7 < 7; ++k7) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float w8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r16 = (2 * t + (i >> 2)) * 4 + (i & 3);
+                float p = acc[k7][r16] * rden;
+                if (MODE == 1) {
+                    const int row0 = k7 * 32 + 8 * (r16 >> 2) + (r16 & 3);
+                    const int ky = h ? (row0 + 4) / HW : row0 / HW, kx = h ? (row0 + 4) % HW : row0 % HW;
+                    const bool rel = (unsigned)(ky - qy) < (unsigned)WIN && (unsigned)(kx - qx) < (unsigned)WIN;
+                    float ds = 0.f;
+                    if (rel && q_unk) {
+                        const int64_t o = ((int64_t)b * W2 + (ky - qy) * WIN + (kx - qx)) * N + u;
+                        const float da = dattd ? dattd[o] : 0.f;
+                        ds = (p * (accd[k7][r16] - dot) + da) * inv_sqrt_c;
+                        const int64_t o2 = (((int64_t)b * 2 + dir) * W2 + (ky - qy) * WIN + (kx - qx)) * N + u;
+                        att0[o2] = p;                      // p and ds / sqrt(C) for pass B: [b][dir][j][u]
+                        att1[o2] = ds;
+                    }
+                    p = ds;
+                }
+                w8[i] = p;
+            }
+            uint4 pk = make_uint4(pack2h(w8[0], w8[1]), pack2h(w8[2], w8[3]), pack2h(w8[4], w8[5]), pack2h(w8[6], w8[7]));
+            const h16x8_t fp = __builtin_bit_cast(h16x8_t, pk);
+            const int rlo = k7 * 32 + 16 * t + 4 * h + trow, rhi = rlo + 8;
+            TrFrag fa[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const unsigned alo = hl_addr + rlo * 256 + ((((cb ^ (rlo & 3)) << 2) | (cig ^ ((rlo >> 2) & 3))) << 4) + (lane & 1) * 8;
+                const unsigned ahi = hl_addr + rhi * 256 + ((((cb ^ (rhi & 3)) << 2) | (cig ^ ((rhi >> 2) & 3))) << 4) + (lane & 1) * 8;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fa[cb].lo) : "v"(alo));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fa[cb].hi) : "v"(ahi));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                tr_fence(fa[cb]);
+                acc2[cb] = mfma16(tr_value(fa[cb]), fp, acc2[cb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the two directions of a query block meet in LDS; the direction-0 wave adds v (forward) and stores the unknown queries
+    __syncthreads();
+    float* cm = comb + qb * (4 * 16 * 64);
+    if (dir == 1) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cm[(cb * 16 + r) * 64 + lane] = acc2[cb][r];
+    }
+    __syncthreads();
+    if (dir == 0 && q_unk) {
+        const int64_t pix = b * N + u;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = cb * 32 + 8 * gq + 4 * h;             // 4 consecutive channels
+                float o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = acc2[cb][gq * 4 + r] + cm[(cb * 16 + gq * 4 + r) * 64 + lane];
+                if (MODE == 0) {
+                    const uint2 vv = *reinterpret_cast<const uint2*>(v + pix * 64 + (ch >> 1));
+                    o4[0] += hlo(vv.x); o4[1] += hhi(vv.x); o4[2] += hlo(vv.y); o4[3] += hhi(vv.y);
+                }
+                *reinterpret_cast<uint2*>(out + pix * 64 + (ch >> 1)) = make_uint2(pack2h(o4[0], o4[1]), pack2h(o4[2], o4[3]));
+            }
+    }
+}
+
 #define TAM_DISPATCH(KERNEL, GRID, ...)                                                                        \
     do {                                                                                                       \
         const int np = C <= 128 ? 1 : 2;                                                                       \
@@ -420,11 +651,32 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
         hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
         hipMemcpyAsync(out, v, sizeof(h16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_fwd: memset / copy failed");
+    // window 7, C = 128: tiles with at least TCVOM_TAM_DENSE unknown pixels go to the MFMA tile kernel (its cost does not depend on the
+    // count), sparser ones to the one-wave-per-pixel tile kernel (cost ~ count / 16 waves); each launch skips the other's tiles.
+    // Default 1 = every active tile on the MFMA kernel: on the bench window (a 5-pixel band, 8 .. 40 unknown pixels per active tile)
+    // forward 58 -> 38 us, all-unknown 104 -> 47 us; the split launches (16 / 24 / 32) measured slower than either kernel alone.
+    static const int dense = getenv("TCVOM_TAM_DENSE") ? atoi(getenv("TCVOM_TAM_DENSE")) : 1;      // 65: never the MFMA kernel
+    int tile_hi = 1 << 30;
+    if (window == 7 && C == 128 && dense <= 64) {
+        auto kern = tam_mfma_kernel<0>;
+        constexpr size_t lds = (size_t)(2 * 224 * 16 + 2 * 64 * 16) * 16;
+        static bool attr = false;
+        if (!attr) {
+            const hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) { (void)hipGetLastError(); return tcvom_fail(TCVOM_ERR_LAUNCH, "tam: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(ea)); }
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cdiv(W, 8), cdiv(H, 8), B), dim3(256), lds, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
+                           (const unsigned*)v, (const uint4*)nullptr, mask, (unsigned*)out, attb, attf, (const float*)nullptr,
+                           (const float*)nullptr, H, W, isc, dense < 1 ? 1 : dense);
+        tile_hi = dense;
+        if (dense <= 1) { TCVOM_LAUNCH_CHECK("tam_fwd"); return TCVOM_OK; }
+    }
     if (window == 7 && C % 8 == 0) {
 #define TAM_TILED_FWD(TH, TW, CM)                                                                                     \
         hipLaunchKernelGGL((tam_tiled_kernel<7, 0, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(TAM_NW * 64), 0, st,   \
                            (const uint4*)q, (const uint4*)kb, (const uint4*)kf, (const unsigned*)v, (const uint4*)nullptr, \
-                           mask, (unsigned*)out, attb, attf, (const float*)nullptr, (const float*)nullptr, H, W, C, isc)
+                           mask, (unsigned*)out, attb, attf, (const float*)nullptr, (const float*)nullptr, H, W, C, isc, tile_hi)
         if (C <= 128) TAM_TILED_FWD(8, 8, 16); else TAM_TILED_FWD(4, 8, 32);
 #undef TAM_TILED_FWD
         TCVOM_LAUNCH_CHECK("tam_fwd");
@@ -450,11 +702,29 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
     const dim3 grid2(cdiv(n, 4), 2);
     const float isc = 1.0f / sqrtf((float)C);
     if (hipMemsetAsync(dq, 0, sizeof(h16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
-    if (window == 7 && C % 8 == 0) {
+    static const int dense = getenv("TCVOM_TAM_DENSE") ? atoi(getenv("TCVOM_TAM_DENSE")) : 1;      // (pass A: 90 -> 96 us on the band window, 118 -> 90 us all-unknown)
+    int tile_hi = 1 << 30;
+    if (window == 7 && C == 128 && dense <= 64) {
+        auto kern = tam_mfma_kernel<1>;
+        constexpr size_t lds = (size_t)(2 * 224 * 16 + 2 * 64 * 16) * 16;
+        static bool attr = false;
+        if (!attr) {
+            const hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) { (void)hipGetLastError(); return tcvom_fail(TCVOM_ERR_LAUNCH, "tam: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(ea)); }
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cdiv(W, 8), cdiv(H, 8), B), dim3(256), lds, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
+                           (const unsigned*)nullptr, (const uint4*)dout, mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, isc,
+                           dense < 1 ? 1 : dense);
+        tile_hi = dense;
+    }
+    if (window == 7 && C % 8 == 0 && tile_hi <= 1) {
+        // (every tile went to the MFMA kernel)
+    } else if (window == 7 && C % 8 == 0) {
 #define TAM_TILED_BWD(TH, TW, CM)                                                                                     \
         hipLaunchKernelGGL((tam_tiled_kernel<7, 1, TH, TW, CM>), dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(TAM_NW * 64), 0, st,   \
                            (const uint4*)q, (const uint4*)kb, (const uint4*)kf, (const unsigned*)nullptr, (const uint4*)dout, \
-                           mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, C, isc)
+                           mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, C, isc, tile_hi)
         if (C <= 128) TAM_TILED_BWD(8, 8, 16); else TAM_TILED_BWD(4, 4, 32);
 #undef TAM_TILED_BWD
     } else {

@@ -11,10 +11,15 @@ from tcvom_amd import ops                                            # noqa: E40
 
 H, W, C = 136, 240, 128
 torch.manual_seed(0)
-mk = lambda: torch.randn(1, H, W, C, device='cuda').to(torch.bfloat16)
+mk = lambda: torch.randn(1, H, W, C, device='cuda').to(ops.H16)
 q, kb, kf, v = (mk().requires_grad_(True) for _ in range(4))
-for frac in (0.0, 0.001, 0.03, 0.25, 1.0):
-    mask = (torch.rand(1, H, W, device='cuda') < frac).to(torch.uint8)
+for frac in (0.0, 0.03, 0.25, 1.0, -1.0):
+    if frac < 0:                                      # a band of unknown pixels along a circle (what a trimap looks like)
+        yy, xx = torch.meshgrid(torch.arange(H, device='cuda'), torch.arange(W, device='cuda'), indexing='ij')
+        rr = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2).float().sqrt()
+        mask = ((rr - 34).abs() < 2.5).to(torch.uint8)[None]
+    else:
+        mask = (torch.rand(1, H, W, device='cuda') < frac).to(torch.uint8)
     n = int(mask.sum())
 
     def fwd():
