@@ -194,6 +194,10 @@ __global__ __launch_bounds__(256) void tam_bwd_query_kernel(
     }
 }
 
+// (Round 4, measured and dropped: pass B on 8 x 8 key-pixel tiles with the dout / q halos staged in LDS once for both directions --
+//  all-unknown 195 -> 147 us, but 96 -> 112 us on the bench window (a 5-pixel band), with the hits walked four at a time as well: the
+//  [b][dir][j][u] layout of p / ds makes lane j's fetch 49 cache lines per wave either way; a tile-major layout written by pass A
+//  would be the next step.)
 // Backward pass B (per key pixel v, one direction per blockIdx.y): gather form of the scatter
 //   dk_v = sum_j [u = v - d_j in image, unknown]  p_j(u) * dout_u + ds_j(u)/sqrt(C) * q_u
 template <int WIN, int NP>
