@@ -431,6 +431,11 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
 int halo_conv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int halo_conv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                          float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream);
+// sconv.hip: halo-tile direct conv for the K <= 64 transposed / stride-2-gradient / 64 <-> 32 channel layers
+int sconv_stats_groups(const tcvom_conv_desc* d, int nphase);
+const char* sconv_variant(const tcvom_conv_desc* d, int nphase);
+int sconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                     float* stats, const tcvom_conv_desc* d, int nphase, const h16raw* zero_page, void* stream);
 // wsconv.hip: weight-stationary 3x3 conv for the 64 / 128-channel stride-1 layers
 int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase);
 int wsconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
@@ -454,6 +459,8 @@ const char* wgradws_variant(const tcvom_conv_desc* d, int ldy);
 extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase) {
     const int hg = halo_conv_stats_groups(d, nphase);
     if (hg > 0) return hg;
+    const int sg = sconv_stats_groups(d, nphase);
+    if (sg > 0) return sg;
     const int wg = wsconv_stats_groups(d, nphase);
     if (wg > 0) return wg;
     const NtCfg c = nt_config(d, nphase);
@@ -464,6 +471,7 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
 // name of the kernel instantiation tcvom_conv_igemm(_phases) launches for this shape (profiling / bench labels)
 extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase) {
     if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
+    if (const char* sv = sconv_variant(d, nphase)) return sv;
     if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? "wsconv<64>" : "wsconv<128>";
     if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
@@ -513,6 +521,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
+    {
+        const int r = sconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     {

@@ -503,6 +503,68 @@ def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
     ck.done()
 
 
+SCONV_CASES = [
+    # cin, cout, k, stride, transposed, N, H, W, which launches go to the kernel
+    (32, 32, 4, 2, True, 2, 16, 64, 'fwd'),        # decoder conv1 (resnet_dec.py:23-41): 4 phases x 4 taps, C = 32, one channel block
+    (64, 64, 4, 2, True, 1, 24, 40, 'fwd'),        # decoder layer4's ConvTranspose: two channel blocks, W not a multiple of the tile
+    (64, 32, 3, 1, False, 2, 16, 96, 'fwd+dgrad'), # 64 -> 32 at os2; its data gradient is the 32 -> 64 shape
+    (32, 64, 3, 1, False, 1, 40, 70, 'fwd+dgrad'),
+    (32, 64, 3, 2, False, 1, 32, 128, 'dgrad'),    # encoder conv3: the stride-2 data gradient = phases of 1 / 2 / 2 / 4 taps on dy
+    (16, 32, 3, 2, False, 2, 48, 64, 'dgrad'),     # guidance head: 32-channel dy
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,transposed,N,H,W,which', SCONV_CASES)
+@pytest.mark.parametrize('bias', [False, True])
+def test_sconv_kernel(cin, cout, k, stride, transposed, N, H, W, which, bias):
+    """Shapes served by the halo-tile direct conv of csrc/sconv.hip (K <= 64, C in {32, 64}: transposed 4x4 stride-2 forwards,
+    stride-2 data gradients, 3x3 between 32 and 64 channels): conv (+ bias) + ReLU + batch statistics, data gradient and weight
+    gradient against fp32 PyTorch on the same 16-bit operands."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd import ops
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.ops import _phase_array
+    from tcvom_amd.weights import bank_token
+    tag = 'sc%d_%d_%d_%d_%d_%d' % (cin, cout, k, stride, H, int(bias))
+    bank, spec = _mini_bank(cin, cout, k, stride, 1, transposed, spectral=False, bias=bias, tag=tag)
+    with torch.no_grad():
+        spec.weight.mul_(0.3)
+    geo = ConvGeometry(spec, N, H, W)
+    variant = L._FNS['tcvom_conv_igemm_variant']
+    if 'fwd' in which:
+        assert variant(C.byref(_phase_array(geo.fwd)[0]), len(geo.fwd)).decode().startswith('sconv')
+    if 'dgrad' in which:
+        assert variant(C.byref(_phase_array(geo.dgrad)[0]), len(geo.dgrad)).decode().startswith('sconv')
+    bn = nn.BatchNorm2d(cout).to(DEV)
+    cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
+    x = hu('x.' + tag, (N, cin, H, W)) - 0.5
+    xg = nhwc(x).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    z = ops.conv_bn_act(cfg, xg, token, True)
+    bank.flush_bn_counters()
+    xr = bf(x).requires_grad_(True)
+    wr = bf(spec.weight.detach().cpu()).requires_grad_(True)
+    br = spec.bias.detach().cpu().clone().requires_grad_(True) if bias else None
+    yr = F.relu(F.conv_transpose2d(xr, wr, br, stride, 1) if transposed else F.conv2d(xr, wr, br, stride, 1))
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    yq = yr + (bf(yr) - yr).detach()
+    zr = (yq - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.rel('running_mean', bn.running_mean, 0.1 * mean.detach(), 1e-2)
+    n_el = yr.numel() // cout
+    ck.rel('running_var', bn.running_var, 0.9 + 0.1 * var.detach() * n_el / (n_el - 1), 1e-2)
+    gz = hu('gz.' + tag, tuple(zr.shape)) - 0.5
+    (z.float() * nhwc(gz).float()).sum().backward()
+    (zr * bf(gz)).sum().backward()
+    ck.rel('dx', nchw(xg.grad)[:, :cin], xr.grad, 4e-2)
+    ck.rel('dw', spec.weight.grad, wr.grad, 3e-2)
+    if bias:
+        ck.rel('dbias', spec.bias.grad, br.grad, 3e-2)
+    ck.done()
+
+
 @pytest.mark.parametrize('cin,N,H,W,bias', [(64, 2, 20, 44, False), (64, 1, 48, 64, True), (128, 1, 13, 21, True),
                                              (128, 2, 24, 32, False), (128, 1, 40, 72, False)])
 def test_wsconv_kernel(cin, N, H, W, bias):

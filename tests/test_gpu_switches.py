@@ -33,6 +33,8 @@ def test_alternative_code_paths_agree_with_the_default_ones():
             # the weight-stationary conv splits a frame-batched launch into runs of frames when the frames together would reach 2^31
             # elements (fragment-major weights have no other kernel): forced here to one frame per launch
             'wsconv frame runs': {'TCVOM_WS_MAX_FRAMES': '1'},
+            # the K <= 64 transposed / stride-2-gradient / 64 <-> 32 channel convs on the implicit GEMM instead of csrc/sconv.hip
+            'sconv off': {'TCVOM_NO_SCONV': '1'},
             # the Temporal Attention Module on the one-wave-per-pixel tile kernels (what C != 128 runs) and split between both
             'TAM vector kernels': {'TCVOM_TAM_DENSE': '65'}, 'TAM split': {'TCVOM_TAM_DENSE': '12'}}
 
