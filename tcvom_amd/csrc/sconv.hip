@@ -35,6 +35,7 @@ struct SconvArgs {
     float* stats;
     const h16raw* zero_page;
     int H, W, K, ldo, wt, act, out_fp32;
+    int PH, PW;                                                          // phase grid (tiles cover it; input pixels outside H x W read zero)
     int OH, OW, ostep, nphase;
     int off_h[4], off_w[4], stats_group_offset[4];
     int tap_dh[4][SC_MAXT], tap_dw[4][SC_MAXT], tap_w[4][SC_MAXT];      // tap_w < 0: zero tap (padding of a short phase)
@@ -236,14 +237,14 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
         const int tx = ctx, ty = cty, n = cn;
         ctx = ntx; cty = nty; cn = nn;
         const int y0 = ty * SC_TH + 2 * wave, x = tx * SC_TW + col;
-        const bool xin = x < W;
+        const bool xin = x < a.PW;
         const int64_t o0 = ((int64_t)(n * a.OH + y0 * ostep + ooh) * a.OW + x * ostep + oow) * a.ldo + 4 * half;
         const int64_t orow = (int64_t)a.OW * a.ldo * ostep;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bool pin = xin && (y0 + j) < H;
+                const bool pin = xin && (y0 + j) < a.PH;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 b4 = *reinterpret_cast<const float4*>(bl + kb * 32 + 8 * g + 4 * half);
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        if (xin && (y0 + j) < H && kb * 32 + 8 * g + 4 * half < a.K)
+                        if (xin && (y0 + j) < a.PH && kb * 32 + 8 * g + 4 * half < a.K)
                             *reinterpret_cast<float4*>(op + j * orow + kb * 32 + 8 * g) =
                                 make_float4(acc[kb][j][g * 4], acc[kb][j][g * 4 + 1], acc[kb][j][g * 4 + 2], acc[kb][j][g * 4 + 3]);
         } else {
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        if (xin && (y0 + j) < H && kb * 32 + 8 * g + 4 * half < a.K)
+                        if (xin && (y0 + j) < a.PH && kb * 32 + 8 * g + 4 * half < a.K)
                             *reinterpret_cast<uint2*>(op + j * orow + kb * 32 + 8 * g) =
                                 make_uint2(pack2h(acc[kb][j][g * 4], acc[kb][j][g * 4 + 1]), pack2h(acc[kb][j][g * 4 + 2], acc[kb][j][g * 4 + 3]));
         }
@@ -343,7 +344,8 @@ static SconvPlan sconv_plan(const tcvom_conv_desc* d, int nphase) {
         if (e->C != d0->C || e->K != d0->K || e->H != d0->H || e->W != d0->W || e->N != d0->N || e->OH != d0->OH || e->OW != d0->OW ||
             e->ldo != d0->ldo || e->wt != d0->wt || e->batch != d0->batch)
             return p;
-        if (e->in_step != 1 || e->PH != e->H || e->PW != e->W) return p;           // the phase grid IS the input grid
+        // the phase grid is the input grid, or reaches past it (data gradient onto a reflection-padded input: one more row / column)
+        if (e->in_step != 1 || e->PH != d0->PH || e->PW != d0->PW || e->PH < e->H || e->PW < e->W || e->PH > e->H + 8 || e->PW > e->W + 8) return p;
         if (e->out_step != (nphase == 4 ? 2 : 1) || e->out_step * e->PH != e->OH || e->out_step * e->PW != e->OW) return p;
         if (e->out_off_h < 0 || e->out_off_h >= e->out_step || e->out_off_w < 0 || e->out_off_w >= e->out_step) return p;
         if (e->w_layout != 0) return p;
@@ -362,7 +364,7 @@ static SconvPlan sconv_plan(const tcvom_conv_desc* d, int nphase) {
     }
     const int nb = d0->batch > 1 ? d0->batch : 1;
     if ((long long)d0->N * nb * d0->H * d0->W * d0->C >= (1ll << 31) || (long long)d0->N * nb * d0->OH * d0->OW * d0->ldo >= (1ll << 31)) return p;
-    if (d0->H % SC_TH != 0 || d0->W < 32) return p;
+    if (d0->W < 32 || d0->H < SC_TH) return p;
     // the single-phase 32 -> 32 3x3 layers belong to halo.hip, the 64 -> 64 / 128 -> 128 ones to wsconv.hip
     if (nphase == 1 && d0->C == d0->K) return p;
     // 1x1 convs would pay for 4 padded taps (measured 19.4 us against 18.0 us on the implicit GEMM): 4-tap tables are for phases
@@ -390,7 +392,7 @@ static int sconv_grid(const tcvom_conv_desc* d, const SconvPlan& p, int nphase, 
     if (occ > 4) occ = 4;
     if (occ < 1) occ = 1;
     const int nb = d->batch > 1 ? d->batch : 1;
-    const int tpf = d->N * (d->H / SC_TH) * ((d->W + SC_TW - 1) / SC_TW);
+    const int tpf = d->N * ((d->PH + SC_TH - 1) / SC_TH) * ((d->PW + SC_TW - 1) / SC_TW);
     int wpf = 256 * occ / (nb * nphase);
     if (wpf < 1) wpf = 1;
     if (wpf > tpf) wpf = tpf;
@@ -445,8 +447,9 @@ int sconv_try_launch(const void* in, const void* w, void* out, const float* bias
         }
         for (; n < SC_MAXT; ++n) { a.tap_dh[i][n] = 0; a.tap_dw[i][n] = 0; a.tap_w[i][n] = -1; }
     }
-    a.tiles_x = (d->W + SC_TW - 1) / SC_TW;
-    a.tiles_y = d->H / SC_TH;
+    a.PH = d->PH; a.PW = d->PW;
+    a.tiles_x = (d->PW + SC_TW - 1) / SC_TW;
+    a.tiles_y = (d->PH + SC_TH - 1) / SC_TH;
     const int grid = sconv_grid(d, p, nphase, &a.tiles_per_wg, &a.wgs_per_fp);
     if (stats && nb > 1 && d->stats_bstride < (long long)a.wgs_per_fp * nphase)
         return tcvom_fail(TCVOM_ERR_ARG, "sconv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);

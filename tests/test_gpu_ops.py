@@ -504,19 +504,21 @@ def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
 
 
 SCONV_CASES = [
-    # cin, cout, k, stride, transposed, N, H, W, which launches go to the kernel
-    (32, 32, 4, 2, True, 2, 16, 64, 'fwd'),        # decoder conv1 (resnet_dec.py:23-41): 4 phases x 4 taps, C = 32, one channel block
-    (64, 64, 4, 2, True, 1, 24, 40, 'fwd'),        # decoder layer4's ConvTranspose: two channel blocks, W not a multiple of the tile
-    (64, 32, 3, 1, False, 2, 16, 96, 'fwd+dgrad'), # 64 -> 32 at os2; its data gradient is the 32 -> 64 shape
-    (32, 64, 3, 1, False, 1, 40, 70, 'fwd+dgrad'),
-    (32, 64, 3, 2, False, 1, 32, 128, 'dgrad'),    # encoder conv3: the stride-2 data gradient = phases of 1 / 2 / 2 / 4 taps on dy
-    (16, 32, 3, 2, False, 2, 48, 64, 'dgrad'),     # guidance head: 32-channel dy
+    # cin, cout, k, stride, pad, transposed, N, H, W, which launches go to the kernel
+    (32, 32, 4, 2, 1, True, 2, 16, 64, 'fwd'),        # decoder conv1 (resnet_dec.py:23-41): 4 phases x 4 taps, C = 32, one channel block
+    (64, 64, 4, 2, 1, True, 1, 24, 40, 'fwd'),        # decoder layer4's ConvTranspose: two channel blocks, W not a multiple of the tile
+    (64, 32, 3, 1, 1, False, 2, 16, 96, 'fwd+dgrad'), # 64 -> 32 at os2; its data gradient is the 32 -> 64 shape
+    (32, 64, 3, 1, 1, False, 1, 40, 70, 'fwd+dgrad'),
+    (32, 64, 3, 2, 1, False, 1, 32, 128, 'dgrad'),    # encoder conv3: the stride-2 data gradient = phases of 1 / 2 / 2 / 4 taps on dy
+    (16, 32, 3, 2, 1, False, 2, 48, 64, 'dgrad'),     # 32-channel dy
+    (16, 32, 3, 2, 0, False, 2, 38, 134, 'dgrad'),    # guidance head (res_gca_enc.py:20-28): stride 2, padding 0 on a reflection-padded
+                                                      # input -> the phase grid (19 x 67) is one larger than dy (18 x 66), not a tile multiple
 ]
 
 
-@pytest.mark.parametrize('cin,cout,k,stride,transposed,N,H,W,which', SCONV_CASES)
+@pytest.mark.parametrize('cin,cout,k,stride,pad,transposed,N,H,W,which', SCONV_CASES)
 @pytest.mark.parametrize('bias', [False, True])
-def test_sconv_kernel(cin, cout, k, stride, transposed, N, H, W, which, bias):
+def test_sconv_kernel(cin, cout, k, stride, pad, transposed, N, H, W, which, bias):
     """Shapes served by the halo-tile direct conv of csrc/sconv.hip (K <= 64, C in {32, 64}: transposed 4x4 stride-2 forwards,
     stride-2 data gradients, 3x3 between 32 and 64 channels): conv (+ bias) + ReLU + batch statistics, data gradient and weight
     gradient against fp32 PyTorch on the same 16-bit operands."""
@@ -527,7 +529,7 @@ def test_sconv_kernel(cin, cout, k, stride, transposed, N, H, W, which, bias):
     from tcvom_amd.ops import _phase_array
     from tcvom_amd.weights import bank_token
     tag = 'sc%d_%d_%d_%d_%d_%d' % (cin, cout, k, stride, H, int(bias))
-    bank, spec = _mini_bank(cin, cout, k, stride, 1, transposed, spectral=False, bias=bias, tag=tag)
+    bank, spec = _mini_bank(cin, cout, k, stride, pad, transposed, spectral=False, bias=bias, tag=tag)
     with torch.no_grad():
         spec.weight.mul_(0.3)
     geo = ConvGeometry(spec, N, H, W)
@@ -546,7 +548,7 @@ def test_sconv_kernel(cin, cout, k, stride, transposed, N, H, W, which, bias):
     xr = bf(x).requires_grad_(True)
     wr = bf(spec.weight.detach().cpu()).requires_grad_(True)
     br = spec.bias.detach().cpu().clone().requires_grad_(True) if bias else None
-    yr = F.relu(F.conv_transpose2d(xr, wr, br, stride, 1) if transposed else F.conv2d(xr, wr, br, stride, 1))
+    yr = F.relu(F.conv_transpose2d(xr, wr, br, stride, pad) if transposed else F.conv2d(xr, wr, br, stride, pad))
     mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
     yq = yr + (bf(yr) - yr).detach()
     zr = (yq - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
