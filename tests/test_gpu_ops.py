@@ -269,7 +269,10 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
 
 @pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W,hp', [(64, 128, 3, 2, False, 24, 40, False), (128, 64, 4, 2, True, 12, 20, False),
                                                                   (32, 32, 3, 1, False, 16, 64, True), (256, 256, 1, 1, False, 10, 12, False),
-                                                                  (128, 128, 3, 1, False, 20, 36, False), (64, 64, 3, 1, False, 36, 40, False)])
+                                                                  (128, 128, 3, 1, False, 20, 36, False), (64, 64, 3, 1, False, 36, 40, False),
+                                                                  # csrc/sconv.hip: four phases x three frames with statistics; two channel blocks
+                                                                  (64, 64, 4, 2, True, 16, 40, False), (32, 32, 4, 2, True, 24, 64, False),
+                                                                  (32, 64, 3, 1, False, 16, 48, False), (64, 32, 3, 1, False, 24, 33, False)])
 def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, transposed, H, W, hp):
     """Three frames through a SpectralNorm'd conv + BatchNorm + ReLU as ONE frame-batched op (bank.frames_per_op = 3: per-frame
     weight slot, per-frame batch statistics, batched data gradient, deferred batched weight gradient) must equal three
