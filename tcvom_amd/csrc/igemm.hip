@@ -701,7 +701,8 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
         divmod_any(t, PH, rcp_ph, small_p, a_n[it], a_i[it]);
     }
     int b_c0[B_IT], b_dh[B_IT], b_dw[B_IT], b_n[B_IT], b_i[B_IT], b_j[B_IT];
-    bool b_ok[B_IT];
+    bool b_ok[B_IT], b_live[B_IT];            // b_live: the lane's column exists (columns past ntaps * C of a wide tile are never loaded,
+                                              // their accumulator columns never stored)
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int ii = it * NW + wave;
@@ -709,6 +710,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
         const int cs = (lane % TB::LPR) ^ (TB::swz(row) << 2);
         const int col = n0 + cs * 8;
         b_ok[it] = false;
+        b_live[it] = ii < TB::NI && col < ncols;
         b_c0[it] = b_dh[it] = b_dw[it] = 0;
         if (ii < TB::NI && col < ncols) {
             const int tap = (int)__umulhi((unsigned)col, cmagic);
@@ -770,7 +772,7 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
         h16raw* bbase = abase + 64 * TM;                                                                        \
         _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                                  \
             const int ii = it * NW + wave;                                                                        \
-            if (ii < TB::NI) {                                                                                   \
+            if (ii < TB::NI && b_live[it]) {                                                                     \
                 const int p = pbeg + (s) * 64 + ii * TB::RPI + lane / TB::LPR;                                   \
                 const int ih = b_i[it] * b_is + b_dh[it], iw = b_j[it] * b_is + b_dw[it];                        \
                 const bool okb = b_ok[it] && p < pend && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W; \
@@ -880,7 +882,14 @@ static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
     const int ncols = d->ntaps * d->C;
     if (d->K >= 128 && ncols >= 128) { *tm = *tn = 128; }
     else if (d->K > 32) { *tm = 64; *tn = ncols >= 128 ? 128 : 64; }
-    else { *tm = 32; *tn = ncols >= 128 ? 128 : 32; }
+    else {
+        // K <= 32: one 128-column tile as soon as the columns (taps x C) do not fit a 32-column one -- the C = 8 layers (72 columns)
+        // read dy once instead of three times (os1 8 -> 32: 130 -> 90 us, the two stride-2 layers on 8-channel inputs 81 -> 73 and
+        // 73 -> 67 us; what is left is the 9-fold gather of x through the L2 -> LDS path, ~4.8 TB/s).  TCVOM_TT_NARROW=1: the old rule
+        static const bool narrow = getenv("TCVOM_TT_NARROW") != nullptr;
+        *tm = 32;
+        *tn = (narrow ? ncols >= 128 : ncols > 32) ? 128 : 32;
+    }
 }
 extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
     if (d->C == 32 && d->K == 32 && d->in_step == 1 && d->out_step == 1 && d->H == d->OH && d->W == d->OW && d->H % 8 == 0 && d->W % 32 == 0) {
@@ -977,6 +986,8 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     // x 256 CUs): a partial second round costs as much as a full one
     const int lds_bytes = 2 * 64 * (tm + tn) * 2 + 256;
     int occ = (160 * 1024) / lds_bytes;
+    // (the 32 x 32 tile would fit 8 workgroups per CU; planning for 8 measured 130 -> 175 us on the os1 8 -> 32 layer: half as long
+    //  chunks, twice the atomic epilogues)
     if (occ > 4) occ = 4;
     long long want = (256ll * occ) / ((long long)mt * nt * nphase * nbatch);
     if (want < 1) want = 1;
