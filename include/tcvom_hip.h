@@ -111,7 +111,7 @@ int tcvom_wgrad_igemm_phases(const void* dy, const void* in, float* dw, const tc
 int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, float* const* dw, int32_t nbatch,
                               const tcvom_conv_desc* descs, int32_t nphase, int32_t ldy, void* stream);
 /* Accumulator-stationary weight gradient (csrc/wgradws.hip) of `nprob` (1..tcvom_wgrad_ws_max_problems()) stride-1 3x3
- * convolutions of ONE geometry `d` (C = 64 or a multiple of 128, K a multiple of 64; K == ldy): the backward of the conv
+ * convolutions of ONE geometry `d` (C a multiple of 64, K = 32 or a multiple of 64; K == ldy): the backward of the conv
  * layers of resnet_enc.py:33-49 / resnet_dec.py:43-59 for ALL layers and calls of that shape in a window -- with many
  * problems per launch a (problem, 64 k x 128 c x 9 tap) block of dw is owned by one or two workgroups and the atomic
  * partial sums shrink to ~1x the size of dw.  dy / in / dw are HOST arrays of nprob device pointers; dw accumulates.

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
         float* __restrict__ dw = a.dw[prob];
         const int kb = kg * 64 + kf * 32 + 4 * (lane >> 5);
         const int c = cg * CWIN + cf * 32 + (lane & 31);
+        const bool rows_exist = kg * 64 + kf * 32 < a.K;              // (K = 32: the odd waves' fragment lies past the weight)
 #pragma unroll
         for (int j = 0; j < G::NB; ++j) {
             const int ws = a.wslot[j];
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
 #if WG_ABL == 1
                 if (acc[j][r] == 1.2345f)
 #endif
-                atomicAdd(dw + ((int64_t)k * a.wt + ws) * a.C + c, acc[j][r]);
+                if (rows_exist) atomicAdd(dw + ((int64_t)k * a.wt + ws) * a.C + c, acc[j][r]);
                 acc[j][r] = 0.f;
             }
         }
@@ -280,7 +281,9 @@ static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot) {
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return false;
     if (d->H != d->OH || d->W != d->OW || d->PH != d->H || d->PW != d->W) return false;
     const int C = d->C, K = d->K;
-    if (ldy != K || K % 64 != 0 || !(C == 64 || C % 128 == 0)) return false;
+    // C: 128-channel windows when C is a multiple of 128, else 64-channel windows (C = 64, 192, 320 ...).  K = 32: one k group whose
+    // upper 32 rows (the k fragment of the odd waves) multiply the next pixel's values and are never written.
+    if (ldy != K || !(K % 64 == 0 || K == 32) || C % 64 != 0) return false;
     if (d->H < 4 || d->W < 8) return false;
     int slots[9];
     for (int t = 0; t < 9; ++t) slots[t] = -1;
@@ -313,12 +316,12 @@ int wgradws_try_launch(const void* const* dys, const void* const* ins, float* co
         const int j = i < nprob ? i : 0;
         a.dy[i] = (const h16raw*)dys[j]; a.in[i] = (const h16raw*)ins[j]; a.dw[i] = dws[j];
     }
-    const int cwin = C == 64 ? 64 : 128, tw = C == 64 ? 32 : 16;
+    const int cwin = C % 128 == 0 ? 128 : 64, tw = cwin == 64 ? 32 : 16;
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = C; a.K = K; a.wt = d->wt;
     a.tiles_x = cdiv(d->W, tw);
     a.tiles_y = cdiv(d->H, 8);
     a.ntiles = d->N * a.tiles_x * a.tiles_y;
-    a.kgroups = K / 64;
+    a.kgroups = cdiv(K, 64);
     a.cgroups = C / cwin;
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * C * 2);
     a.dy_bytes = (unsigned)((long long)d->N * d->H * d->W * K * 2);
@@ -360,7 +363,7 @@ extern "C" int tcvom_wgrad_ws_multi(const void* const* dy, const void* const* in
     TCVOM_CHECK_ARG(nprob >= 1 && nprob <= WG_MAX_PROBLEMS, "wgrad_ws_multi: %d problems (1..%d)", nprob, WG_MAX_PROBLEMS);
     for (int i = 0; i < nprob; ++i) TCVOM_CHECK_ARG(dy[i] && in[i] && dw[i], "wgrad_ws_multi: null pointer in problem %d", i);
     const int r = wgradws_try_launch(dy, in, dw, nprob, d, 1, ldy, stream);
-    TCVOM_CHECK_ARG(r != 0, "wgrad_ws_multi: not a stride-1 3x3 convolution with C = 64 or a multiple of 128 and K a multiple of 64");
+    TCVOM_CHECK_ARG(r != 0, "wgrad_ws_multi: not a stride-1 3x3 convolution with C a multiple of 64 and K = 32 or a multiple of 64");
     return r < 0 ? r : TCVOM_OK;
 }
 extern "C" int32_t tcvom_wgrad_ws_max_problems(void) { return WG_MAX_PROBLEMS; }
@@ -368,5 +371,5 @@ extern "C" int32_t tcvom_wgrad_ws_max_problems(void) { return WG_MAX_PROBLEMS; }
 // name for profiles / bench labels
 const char* wgradws_variant(const tcvom_conv_desc* d, int ldy) {
     if (!wgradws_takes(d, ldy, nullptr)) return nullptr;
-    return d->C == 64 ? "wgrad_ws<64>" : "wgrad_ws<128>";
+    return d->C % 128 == 0 ? "wgrad_ws<128>" : "wgrad_ws<64>";
 }

@@ -408,9 +408,12 @@ def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
 @pytest.mark.parametrize('cin,cout,N,H,W,S', [(64, 64, 2, 20, 40, 1), (64, 64, 1, 33, 70, 3), (128, 128, 1, 17, 30, 3),
                                               (128, 128, 2, 40, 64, 1), (256, 128, 1, 9, 16, 2), (128, 256, 1, 24, 20, 1),
                                               (512, 512, 1, 6, 10, 3), (64, 128, 1, 16, 32, 1), (128, 128, 1, 17, 30, 20),
-                                              (64, 64, 1, 16, 32, 40), (256, 256, 1, 9, 12, 112)])
+                                              (64, 64, 1, 16, 32, 40), (256, 256, 1, 9, 12, 112),
+                                              # 64-channel windows of a C that is not a multiple of 128; K = 32 (half a k group)
+                                              (320, 64, 1, 20, 36, 1), (192, 128, 2, 9, 33, 2), (64, 32, 2, 24, 40, 3),
+                                              (128, 32, 1, 17, 30, 1), (192, 32, 1, 16, 64, 9)])
 def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
-    """Accumulator-stationary weight gradient (csrc/wgradws.hip; stride-1 3x3, C = 64 or a multiple of 128, K a multiple
+    """Accumulator-stationary weight gradient (csrc/wgradws.hip; stride-1 3x3, C a multiple of 64, K = 32 or a multiple
     of 64): ragged tiles, several samples, several problems per launch, every (k, c) block split -- against
     torch.nn.grad.conv2d_weight in fp32 on the same bf16 operands."""
     import ctypes as C
