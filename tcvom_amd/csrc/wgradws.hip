@@ -30,7 +30,9 @@ struct WgArgs {
     const h16raw* dy[WG_MAX_PROBLEMS];
     const h16raw* in[WG_MAX_PROBLEMS];
     float* dw[WG_MAX_PROBLEMS];
-    int N, H, W, C, K, wt;
+    int N, H, W, C, K, wt;                 // N, H, W: the samples the tiles walk over -- for a dilation-d conv the N * d * d sub-grids
+                                           // (pixels of one residue class mod d) of H / d x W / d pixels, each a dilation-1 problem
+    int dil, Hf, Wf;                       // dilation; the full image (pixel (y, x) of sub-grid (sy, sx) is (sy + y dil, sx + x dil))
     int tiles_x, tiles_y, ntiles;          // pixel tiles of one problem (N * tiles_y * tiles_x)
     int kgroups, cgroups;                  // K / 64, C / CWIN: the (k, c) blocks of dw
     int total, per_wg;                     // length of the (problem, block, tile) sequence and the run of one workgroup
@@ -104,14 +106,14 @@ __device__ __forceinline__ void wg_dma_map(const WgArgs& a, int wave, int lane, 
             const int hy = p / G::HW, hx = p - hy * G::HW;
             const int sw = UX >= 16 ? (hx & 3) : ((hx >> 1) & 1);
             const int c = (((sl >> 2) ^ sw) << 2) | (sl & 3);
-            rel[it] = (unsigned)(((hy * a.W + hx) * a.C + c * 8) * 2);
+            rel[it] = (unsigned)(((hy * a.Wf + hx) * a.dil * a.C + c * 8) * 2);
             pk[it] = p < G::HH * G::HW ? (unsigned)(hy << 16 | hx) : 0x7fff0000u;
         } else {
             // dy tile: pixel q = v / 8, LDS position sy holds chunk ((sy >> 2) ^ ((q >> 1) & 1)) << 2 | (sy & 3)
             const int v = u - G::XU, q = v >> 3, sy = v & 7;
             const int ty = q / G::TW, tx = q - ty * G::TW;
             const int cy = (((sy >> 2) ^ ((q >> 1) & 1)) << 2) | (sy & 3);
-            rel[it] = (unsigned)(((ty * a.W + tx) * a.K + cy * 8) * 2);
+            rel[it] = (unsigned)(((ty * a.Wf + tx) * a.dil * a.K + cy * 8) * 2);
             pk[it] = v < G::YU ? (unsigned)(ty << 16 | tx) : 0x7fff0000u;
         }
     }
@@ -196,8 +198,10 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
         d.yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.dy[prob_]), 0, a.dy_bytes, 0x00020000); \
         d.ym = (q_) < q_end ? (r_ / a.tiles_x) * G::TH : (1 << 20);                                           \
         d.xm = (r_ % a.tiles_x) * TW;                                                                         \
-        d.xbase = (unsigned)((((n_ * a.H + d.ym - 1) * a.W + d.xm - 1) * a.C + cg_ * CWIN) * 2);              \
-        d.ybase = (unsigned)((((n_ * a.H + d.ym) * a.W + d.xm) * a.K + kg_ * 64) * 2);                        \
+        const int dd_ = a.dil * a.dil, nf_ = n_ / dd_, sg_ = n_ - nf_ * dd_, sy_ = sg_ / a.dil, sx_ = sg_ - sy_ * a.dil; \
+        const int org_ = (nf_ * a.Hf + sy_) * a.Wf + sx_;                      /* first pixel of the sub-grid */ \
+        d.xbase = (unsigned)(((org_ + ((d.ym - 1) * a.Wf + d.xm - 1) * a.dil) * a.C + cg_ * CWIN) * 2);       \
+        d.ybase = (unsigned)(((org_ + (d.ym * a.Wf + d.xm) * a.dil) * a.K + kg_ * 64) * 2);                   \
         d.slot = (slot_);                                                                                     \
     }
     WG_SET(q_begin, 0)
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot) {
+static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot, int* dil_out = nullptr) {
     static const bool disabled = getenv("TCVOM_NO_WGRADWS") != nullptr;     // A/B switch
     if (disabled) return false;
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return false;
@@ -288,9 +292,18 @@ static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot) {
     int slots[9];
     for (int t = 0; t < 9; ++t) slots[t] = -1;
     int n = 0;
+    // dilation: the taps are {-dil, 0, dil}^2 (ResnetDilated, models/FBA/models.py:203-217: dilation 2 and 4 with padding = dilation)
+    int dil = 1;
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->tap_w[t] >= 0 && abs(d->tap_dh[t]) > dil) dil = abs(d->tap_dh[t]);
+    static const bool no_dil = getenv("TCVOM_WGRADWS_NO_DIL") != nullptr;     // A/B switch: dilated layers on igemm_tt
+    if (dil > 1 && no_dil) return false;
+    if (dil > 8 || d->H % dil != 0 || d->W % dil != 0 || d->H / dil < 4 || d->W / dil < 8) return false;
+    if ((long long)d->N * dil * dil * cdiv(d->H / dil, 8) * cdiv(d->W / dil, 16) >= (1ll << 24)) return false;
     for (int t = 0; t < d->ntaps; ++t) {
         if (d->tap_w[t] < 0) continue;
-        const int dh = d->tap_dh[t], dw_ = d->tap_dw[t];
+        if (d->tap_dh[t] % dil != 0 || d->tap_dw[t] % dil != 0) return false;
+        const int dh = d->tap_dh[t] / dil, dw_ = d->tap_dw[t] / dil;
         if (dh < -1 || dh > 1 || dw_ < -1 || dw_ > 1) return false;
         const int c = (dh + 1) * 3 + (dw_ + 1);
         if (slots[c] >= 0) return false;
@@ -301,6 +314,7 @@ static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot) {
     const long long in_b = (long long)d->N * d->H * d->W * C * 2, dy_b = (long long)d->N * d->H * d->W * K * 2;
     if (in_b >= (1ll << 31) || dy_b >= (1ll << 31)) return false;
     if (wslot) for (int t = 0; t < 9; ++t) wslot[t] = slots[t];
+    if (dil_out) *dil_out = dil;
     return true;
 }
 
@@ -310,17 +324,19 @@ static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot) {
 int wgradws_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nprob, const tcvom_conv_desc* d,
                        int nphase, int ldy, void* stream) {
     WgArgs a;
-    if (nphase != 1 || nprob < 1 || nprob > WG_MAX_PROBLEMS || !wgradws_takes(d, ldy, a.wslot)) return 0;
+    int dil = 1;
+    if (nphase != 1 || nprob < 1 || nprob > WG_MAX_PROBLEMS || !wgradws_takes(d, ldy, a.wslot, &dil)) return 0;
     const int C = d->C, K = d->K;
     for (int i = 0; i < WG_MAX_PROBLEMS; ++i) {
         const int j = i < nprob ? i : 0;
         a.dy[i] = (const h16raw*)dys[j]; a.in[i] = (const h16raw*)ins[j]; a.dw[i] = dws[j];
     }
     const int cwin = C % 128 == 0 ? 128 : 64, tw = cwin == 64 ? 32 : 16;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.C = C; a.K = K; a.wt = d->wt;
-    a.tiles_x = cdiv(d->W, tw);
-    a.tiles_y = cdiv(d->H, 8);
-    a.ntiles = d->N * a.tiles_x * a.tiles_y;
+    a.dil = dil; a.Hf = d->H; a.Wf = d->W;
+    a.N = d->N * dil * dil; a.H = d->H / dil; a.W = d->W / dil; a.C = C; a.K = K; a.wt = d->wt;
+    a.tiles_x = cdiv(a.W, tw);
+    a.tiles_y = cdiv(a.H, 8);
+    a.ntiles = a.N * a.tiles_x * a.tiles_y;
     a.kgroups = cdiv(K, 64);
     a.cgroups = C / cwin;
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * C * 2);

@@ -509,6 +509,37 @@ def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
     ck.done()
 
 
+@pytest.mark.parametrize('cin,cout,dil,N,H,W,S', [(256, 256, 2, 1, 16, 24, 3), (512, 512, 4, 1, 16, 32, 1), (64, 64, 2, 2, 10, 18, 2),
+                                                  (128, 32, 4, 1, 32, 64, 1), (128, 64, 2, 2, 34, 44, 1), (64, 128, 3, 1, 27, 30, 4)])
+def test_wgrad_ws_kernel_dilated(cin, cout, dil, N, H, W, S):
+    """Dilated 3x3 layers (ResnetDilated of the FBA base, models/FBA/models.py:203-217: dilation 2 and 4, padding = dilation) through
+    the accumulator-stationary weight gradient: the N * dil^2 sub-grids (pixels of one residue class mod dil) are dilation-1
+    problems on strided pixels.  Against torch.nn.grad.conv2d_weight(dilation=dil) in fp32 on the same 16-bit operands."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.ops import _phase_array
+    from tcvom_amd.weights import ConvSpec, WeightBank
+    tag = 'wgwsd%d_%d_%d_%d' % (cin, cout, dil, H)
+    w = nn.Parameter(formula_tensor('conv.%s.weight' % tag, (cout, cin, 3, 3)).to(DEV))
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, None, None, None, False, 1, dil, 'frame', dilation=dil)
+    bank.register(spec)
+    geo = ConvGeometry(spec, N, H, W)
+    assert L._FNS['tcvom_wgrad_igemm_variant'](C.byref(_phase_array(geo.wgrad)[0])).decode().startswith('wgrad_ws')
+    xs = [(hu('x%d.%s' % (i, tag), (N, H, W, cin)) - 0.5).to(DEV).to(H16) for i in range(S)]
+    dys = [(hu('dy%d.%s' % (i, tag), (N, H, W, cout)) - 0.5).to(DEV).to(H16) for i in range(S)]
+    dw = torch.zeros(S, cout * 9 * cin, device=DEV)
+    vp = lambda ts: C.cast((C.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), C.c_void_p)     # noqa: E731
+    L.call('tcvom_wgrad_ws_multi', vp(dys), vp(xs), vp([dw[i] for i in range(S)]), S, _phase_array(geo.wgrad), cout, L.stream_ptr())
+    torch.cuda.synchronize()
+    for i in range(S):
+        ref = torch.nn.grad.conv2d_weight(xs[i].float().cpu().permute(0, 3, 1, 2), (cout, cin, 3, 3),
+                                          dys[i].float().cpu().permute(0, 3, 1, 2), padding=dil, dilation=dil)
+        got = dw[i].cpu().view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        assert rel_err(got, ref) < 1e-5, 'problem %d' % i
+
+
 SCONV_CASES = [
     # cin, cout, k, stride, pad, transposed, N, H, W, which launches go to the kernel
     (32, 32, 4, 2, 1, True, 2, 16, 64, 'fwd'),        # decoder conv1 (resnet_dec.py:23-41): 4 phases x 4 taps, C = 32, one channel block
