@@ -71,14 +71,17 @@ def test_window_vs_reference_golden(name):
     refn = g['grad_norms']
     big = refn > 0.05 * refn.max()
     ratio = mine[big] / refn[big]
-    print('grad-norm ratio (top tensors): min %.3f max %.3f' % (ratio.min(), ratio.max()))
+    print('grad-norm ratio (top tensors): min %.3f median %.3f max %.3f' % (ratio.min(), float(np.median(ratio)), ratio.max()))
     if H * W >= 128 * 160:      # the 64-pixel-high cases have 8..24-element BatchNorms: backward is ill-conditioned
         # bf16: two identical runs of this window differ by the fp32 order of the atomic partial sums only, yet the largest
         # per-tensor ratio moves between 1.19 and 1.44 (10 runs): the backward map amplifies the bf16 storage noise (DESIGN.md
         # section 6).  fp16: 0.91 .. 1.03.
         assert abs(np.median(ratio) - 1) < tol(0.15, 0.05) and tol(0.6, 0.8) < ratio.min() and ratio.max() < tol(1.9, 1.2), 'gradient norms'
     elif tol(False, True):
-        assert abs(np.median(ratio) - 1) < 0.25 and 0.75 < ratio.min() and ratio.max() < 1.5, 'gradient norms'      # 64-pixel windows, measured: min 0.98, max 1.21, median up to 1.15
+        # 64-pixel windows, 65 runs of window_s5_64x96 (tools/probes/ratio_probe.sh; the same spread with the round-4 kernels switched
+        # off): min 0.95 .. 1.00, median ~1.2, max 1.22 .. 1.57 -- the order of the fp32 atomics alone moves the largest per-tensor ratio
+        # that much through the 8..24-element BatchNorm backward; the earlier bound of 1.5 sat inside that tail (1 run in ~20 failed)
+        assert abs(np.median(ratio) - 1) < 0.35 and 0.75 < ratio.min() and ratio.max() < 2.0, 'gradient norms'
 
 
 def test_window_large_vs_oracle():
