@@ -401,6 +401,8 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         //  128 x 128 threshold lowered to 150 workgroups for the 512-channel os32 layers: no change)
         // (measured, round 3: 4x as many 128 x 128 tiles where the 256 x 256 tile count leaves the last round of 256 mostly empty
         //  -- 384 tiles -> 1536 -- is neutral: 24.19 vs 24.20 ms)
+        // (round 4, FBA's fifteen K = 256 os8 launches -- 384 tiles of 256 x 256, 1.5 rounds: as 1530 tiles of 128 x 128 the FBA+TAM step is
+        //  53.3 -> 53.5 ms, same box: the better balance does not pay for twice the operand bytes per MAC)
         if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
         // 128 (channels) x 96 (pixels) tiles, 4 waves of 32 x 96, where they spread evenly over the chip and the 128 x 128 ones do
         // not: the 256-channel os16 layers at 1080p are 64 x 2 x 3 = 384 workgroups of 128 x 128 (half the CUs run two, half one)
