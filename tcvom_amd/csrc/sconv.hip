@@ -16,6 +16,9 @@
 //   c ^ ((hx >> 2) & 3) (C = 32: 64-byte pixels) / c ^ ((hx >> 1) & 7) (C = 64: 128-byte pixels): the 16 consecutive pixels of a
 //   ds_read_b128 group cover 16 distinct bank groups (hx = the pixel's column in the halo, so the second tile row of a wave and the
 //   chunks of a tap are immediate offsets / XOR constants of ONE address register per tap).  Weight rows are padded by 16 bytes.
+// (Measured and dropped: issuing a tile's 16-bit stores one tile late -- packed in registers, behind the next halo's DMA, so that the
+//  loop-top vmcnt(0) does not wait for stores issued a moment earlier: 54 / 46 / 73 / 51 / 41 / 80 us -> 58 / 49 / 80 / 54 / 45 / 86 us
+//  on the six launches of a 1080p step.  The store round trip is not what a tile waits for.)
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
