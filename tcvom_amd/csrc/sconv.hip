@@ -29,6 +29,9 @@
 #define SC_HH (SC_TH + 2)
 #define SC_PIX (SC_HW * SC_HH)          // 340
 #define SC_MAXT 9
+#ifndef SC_ABL
+#define SC_ABL 0          // kernel ablations for timing (1: no output stores, 2: no halo DMA after the first tile, 3: no MFMAs / fragment reads;
+#endif                    // study builds: tcvom_amd/lib/study via TCVOM_LIB); 0 in the product
 
 struct SconvArgs {
     const h16raw* in;
@@ -197,7 +200,9 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         SC_NEXT();
+#if SC_ABL != 2
         if (tile + 1 < t_end) SC_ISSUE(ntx, nty, nn, slot ^ 1);
+#endif
         f32x16_t acc[KB][2];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
             sc_read<0>(fb[n][0], ba);
             sc_read<ROWB>(fb[n][1], ba);
         };
+#if SC_ABL < 3
         sc_static_for<0, (PF < NCH ? PF : NCH)>(issue);
         sc_static_for<0, NCH>([&](auto c_) {
             constexpr int c = decltype(c_)::value;
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+#endif
 
         // ---- epilogue: bias, activation, store at the phase's output pixels, running channel sums
         const int tx = ctx, ty = cty, n = cn;
@@ -263,6 +270,11 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
                     }
                 }
             }
+#if SC_ABL == 1
+        if (a.K == 12345) {
+#else
+        {
+#endif
         if (a.out_fp32) {
             float* op = reinterpret_cast<float*>(a.out) + o0;
 #pragma unroll
@@ -285,6 +297,7 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
                         if (xin && (y0 + j) < a.PH && kb * 32 + 8 * g + 4 * half < a.K)
                             *reinterpret_cast<uint2*>(op + j * orow + kb * 32 + 8 * g) =
                                 make_uint2(pack2h(acc[kb][j][g * 4], acc[kb][j][g * 4 + 1]), pack2h(acc[kb][j][g * 4 + 2], acc[kb][j][g * 4 + 3]));
+        }
         }
         slot ^= 1;
     }
