@@ -117,18 +117,6 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
     const int t_end = min(tiles_per_frame, t_begin + a.tiles_per_wg);
     const int n_base = frame * a.spf;                   // first sample of this frame
 
-    // ---- weights of this (frame, phase) -> LDS: wl[k][t*C + c] = wgt[frame][(k*wt + slot(t))*C + c]
-    {
-        const h16raw* wsrc = a.wgt + (int64_t)frame * a.w_bstride;
-        for (int u = tid; u < KB * 32 * NTAPS * CU; u += 256) {
-            const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
-            const int ws = a.tap_w[phase][t];
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (ws >= 0 && k < a.K) val = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)k * a.wt + ws) * C + cu * 8);
-            *reinterpret_cast<uint4*>(wl + k * WROW + t * C + cu * 8) = val;
-        }
-        if (tid < KB * 32) bl[tid] = (a.bias && tid < a.K) ? a.bias[tid] : 0.f;
-    }
     // ---- per-lane constants
     int d_rel[DMA_IT], d_yx[DMA_IT];
 #pragma unroll
@@ -186,6 +174,36 @@ __global__ __launch_bounds__(256) void sconv_kernel(const SconvArgs a) {
     const int ostep = a.ostep, ooh = a.off_h[phase], oow = a.off_w[phase];
 
     if (t_begin < t_end) SC_ISSUE(ntx, nty, nn, 0);
+    // ---- weights of this (frame, phase) -> LDS: wl[k][t*C + c] = wgt[frame][(k*wt + slot(t))*C + c], behind the first halo's DMA.
+    // All loads of a thread are issued before its first store (as a load -> wait -> store loop, with the lane-indexed tap table read
+    // in front of every load, the 9-tap C = 64 variant spent 18 dependent round trips here before its first tile: a fixed ~10 us per
+    // launch); padding taps and rows past K read the zero page.
+    {
+        constexpr int WUNITS = KB * 32 * NTAPS * CU, WIT = (WUNITS + 255) / 256;
+        const h16raw* wsrc = a.wgt + (int64_t)frame * a.w_bstride;
+        int wsl[WIT];
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+            const int u = tid + i * 256, t = (u / CU) % NTAPS;
+            wsl[i] = a.tap_w[phase][t];
+        }
+        uint4 wv[WIT];
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+            const int u = tid + i * 256;
+            const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
+            const bool ok = u < WUNITS && wsl[i] >= 0 && k < a.K;
+            const h16raw* src = ok ? wsrc + ((int64_t)k * a.wt + wsl[i]) * C + cu * 8 : a.zero_page;
+            wv[i] = *reinterpret_cast<const uint4*>(src);
+        }
+#pragma unroll
+        for (int i = 0; i < WIT; ++i) {
+            const int u = tid + i * 256;
+            const int cu = u % CU, t = (u / CU) % NTAPS, k = u / (CU * NTAPS);
+            if (u < WUNITS) *reinterpret_cast<uint4*>(wl + k * WROW + t * C + cu * 8) = wv[i];
+        }
+        if (tid < KB * 32) bl[tid] = (a.bias && tid < a.K) ? a.bias[tid] : 0.f;
+    }
     int ctx = ntx, cty = nty, cn = nn;
     int slot = 0;
     float s1[KB][4][4], s2[KB][4][4];
