@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Headline benchmark: synthetic 1080p (1088x1920) 3-frame windows/s, GCA+TAM, forward + backward
-(L_alpha + 0.5 L_dt + 0.25 L_att, train_ddp.py:56-61) + gradient all-reduce + Adam; 16-bit activations / packed weights (fp16
-by default, TCVOM_DTYPE=bf16 for the bf16 build: same MFMA rate), fp32 accumulation, statistics, softmax, losses and master weights.
+(L_alpha + 0.5 L_dt + 0.25 L_att, train_ddp.py:56-61) + gradient all-reduce + Adam; 16-bit activations / packed weights (bf16, the
+north star's type, for the GCA+TAM window; fp16 for --config fba as BASELINE config 5 names it; TCVOM_DTYPE overrides: same MFMA rate),
+fp32 accumulation, statistics, softmax, losses and master weights.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -235,22 +236,22 @@ def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
                          '' if (H, W) == (FULL_H, FULL_W) else ', scaled to 3x%dx%d by the algorithmic FLOP ratio %.4f' % (FULL_H, FULL_W, ratio))}
 
 
-def other_configs():
-    """The BASELINE.json configurations the headline line does not time, each as a short run of THIS script in a subprocess on the
-    same GPU (HIP-event-free: the subprocess's own barrier-bracketed wall clock over its timed steps, as the headline): configs[1]
-    = GCA+TAM forward-only 3x512x512; configs[4] = FBA+TAM fwd+bwd 3x1088x1920 (with its own window_mfma_frac); and configs[2]
-    again in the OTHER 16-bit storage build of the library (TCVOM_DTYPE: the north star names bf16, the default build stores fp16)."""
+def other_configs(steps, warmup):
+    """The BASELINE.json configurations the headline line does not time, each as a run of THIS script in a subprocess on the same
+    GPU (the subprocess's own barrier-bracketed wall clock over its timed steps, as the headline), every one in the storage type
+    BASELINE.json names for it AND in the other 16-bit build (TCVOM_DTYPE): configs[1] = GCA+TAM forward-only 3x512x512 (bf16);
+    configs[4] = FBA+TAM fwd+bwd 3x1088x1920 (fp16; with its own window_mfma_frac); and configs[2] -- the headline, bf16 -- again in
+    the fp16 build with the SAME steps / warm-up as the headline run (a co-equal line, not a side note)."""
     import subprocess
-    import tcvom_amd._lib as L
-    other_dtype = 'bf16' if L.DTYPE_NAME == 'fp16' else 'fp16'
-    runs = (('config2_gca_tam_fwd_512', ['--height', '512', '--width', '512', '--forward-only', '--steps', '30', '--warmup', '5'], {}),
-            ('config5_fba_tam_fwd_bwd_1080p', ['--config', 'fba', '--steps', '6', '--warmup', '2'], {}),
-            ('config3_gca_tam_fwd_bwd_1080p_%s' % other_dtype, ['--steps', '12', '--warmup', '3'], {'TCVOM_DTYPE': other_dtype}))
+    runs = (('config2_gca_tam_fwd_512_bf16', ['--height', '512', '--width', '512', '--forward-only', '--steps', '30', '--warmup', '5'], 'bf16'),
+            ('config2_gca_tam_fwd_512_fp16', ['--height', '512', '--width', '512', '--forward-only', '--steps', '30', '--warmup', '5'], 'fp16'),
+            ('config5_fba_tam_fwd_bwd_1080p_fp16', ['--config', 'fba', '--steps', '8', '--warmup', '2'], 'fp16'),
+            ('config5_fba_tam_fwd_bwd_1080p_bf16', ['--config', 'fba', '--steps', '8', '--warmup', '2'], 'bf16'),
+            ('config3_gca_tam_fwd_bwd_1080p_fp16', ['--steps', str(steps), '--warmup', str(warmup)], 'fp16'))
     out = {}
-    for name, flags, env in runs:
+    for name, flags, dtype in runs:
         t0 = time.time()
-        e = dict(os.environ)
-        e.update(env)
+        e = dict(os.environ, TCVOM_DTYPE=dtype)
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
             e.pop(k, None)
         try:
@@ -284,8 +285,8 @@ def main():
     ap.add_argument('--forward-only', action='store_true',
                     help='time the forward pass alone (train-mode statistics, no_grad): BASELINE.json configs[1] with --height 512 --width 512')
     ap.add_argument('--no-other-configs', action='store_true',
-                    help='skip the `other_configs` object of the default 1-GPU run (config 2, config 5 and the bf16 build of config 3, each a '
-                         'short event-timed run of this script in a subprocess)')
+                    help='skip the `other_configs` object of the default 1-GPU run (config 2 and config 5 in both 16-bit builds, config 3 in '
+                         'the fp16 build at the headline steps / warm-up: each a run of this script in a subprocess)')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--sync-bn', dest='sync_bn', action='store_true', default=None,
                     help='SyncBatchNorm statistics over the ranks, as train_ddp.py:271-273 converts every non-FBA model: the DEFAULT '
@@ -293,8 +294,13 @@ def main():
                          'through hipIpc peer mailboxes (TCVOM_SYNCBN=rccl: one all-reduce per BatchNorm call instead).  With '
                          '--gpus 1 the exchange runs against a one-rank loop-back mailbox (its cost on one GPU)')
     ap.add_argument('--no-sync-bn', dest='sync_bn', action='store_false', help='per-rank BatchNorm statistics (the A/B of --sync-bn)')
+    ap.add_argument('--no-ab', action='store_true',
+                    help='N > 1 with SyncBatchNorm: skip the short per-rank-BatchNorm A/B (`dist.no_sync_bn_ms_per_step`) that follows the timed steps')
     args = ap.parse_args()
 
+    # storage type of the run, unless TCVOM_DTYPE says otherwise: what BASELINE.json names for the configuration -- bf16 for the
+    # GCA+TAM window (configs[1..3], the north star), fp16 for FBA+TAM (configs[4])
+    os.environ.setdefault('TCVOM_DTYPE', 'fp16' if args.config == 'fba' else 'bf16')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -395,6 +401,47 @@ def main():
         diags = [None] * world
         dist.all_gather_object(diags, diag)
 
+    # ---- N > 1 with SyncBatchNorm: the same job again WITHOUT the statistics exchange (per-rank BatchNorm), a short A/B inside
+    # this run, so that one multi-GPU lease separates the cost of SyncBatchNorm from the cost of the gradient all-reduce
+    no_sync = None
+    if world > 1 and sync_bn and not args.forward_only and not args.no_ab:
+        ab_steps, ab_warm = max(2, min(args.steps, 6)), 2
+        model_b, a_b, fg_b, bg_b = build(device, H, W, seed=rank, config=args.config)
+        broadcast_module_state(model_b)
+        params_b = [p for p in model_b.parameters() if p.requires_grad]
+        opt_b = FusedAdam(params_b, lr=1e-4, weight_decay=1e-4)
+        av_b = GradientAverager(params_b, banks=banks_of(model_b))
+        ar_b = []
+
+        def step_b(record):
+            out = model_b(a_b, fg_b, bg_b)
+            loss_b = train_step_loss(out)
+            model_b.zero_grad(set_to_none=True)
+            loss_b.backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            av_b.average()
+            e1.record()
+            if record:
+                ar_b.append((e0, e1))
+            opt_b.step()
+        for _ in range(ab_warm):
+            step_b(False)
+        fence()
+        tb = time.time()
+        for _ in range(ab_steps):
+            step_b(True)
+        fence()
+        el_b = torch.tensor([time.time() - tb], dtype=torch.float64, device=device)
+        dist.all_reduce(el_b, op=dist.ReduceOp.MAX)
+        ar_ms = torch.tensor([sum(e0.elapsed_time(e1) for e0, e1 in ar_b) / ab_steps], dtype=torch.float64, device=device)
+        dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        no_sync = {'no_sync_bn_ms_per_step': round(1e3 * float(el_b) / ab_steps, 3), 'no_sync_bn_steps': ab_steps, 'no_sync_bn_warmup': ab_warm,
+                   'no_sync_bn_windows_per_s': round(world * clips * ab_steps / float(el_b), 4),
+                   'no_sync_bn_allreduce_exposed_ms_per_step_max_over_ranks': round(float(ar_ms), 4)}
+        del model_b, opt_b, av_b, params_b
+        torch.cuda.empty_cache()
+
     result = None
     if rank == 0:
         win_per_s = world * clips * args.steps / elapsed
@@ -430,7 +477,7 @@ def main():
                      'grad_allreduce_plan': averager.last_plan,
                      'grads_unused_on_every_rank': averager.globally_unused,
                      'visible_devices': torch.cuda.device_count(),
-                     'per_rank': diags},
+                     'per_rank': diags, **(no_sync or {})},
             'window_mfma_frac': round(gflop * win_per_s / world / 1e3 / MFMA_PEAK_TFLOPS, 5) if gflop is not None else None,
         }
     # ---- roofline of the dominant kernel (event-instrumented extra step on rank 0's stream)
@@ -479,7 +526,7 @@ def main():
             and (H, W) == (FULL_H, FULL_W)):
         del model, opt, averager, params
         torch.cuda.empty_cache()
-        result['other_configs'] = other_configs()
+        result['other_configs'] = other_configs(args.steps, args.warmup)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if args.config != 'index':                      # (no CPU line for the extra IndexNet configuration)

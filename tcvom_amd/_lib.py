@@ -8,12 +8,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# The 16-bit storage type of activations and packed weights: one build of the library per type, same ABI (csrc/common.h).
-#   TCVOM_DTYPE=fp16  libtcvom_hip_f16.so  (default) IEEE fp16: 3 more mantissa bits than bf16 at the same MFMA rate -- the alpha-matte error of
-#                     16-bit storage falls ~35x (tests/test_bf16_noise_floor.py), the doubled-tap high-precision stem is not needed;
-#                     the backward runs under an internal loss scale (ops.LOSS_SCALE).  BASELINE config 5 names this dtype.
-#   TCVOM_DTYPE=bf16  libtcvom_hip.so      bf16: fp32's exponent range, no loss scale.
-DTYPE_NAME = os.environ.get('TCVOM_DTYPE', 'fp16').lower()        # default: fp16 (measured: 25x lower alpha error, 0.8 ms faster per 1080p step)
+# The 16-bit storage type of activations and packed weights: one build of the library per type, same sources, same ABI (csrc/common.h).
+#   TCVOM_DTYPE=bf16  libtcvom_hip.so      (default, round 5) bf16: the type BASELINE.json's north star names for the GCA+TAM window (fp32's
+#                     exponent range, no loss scale); the stem + layer1 run the doubled-tap high-precision forward (gca_net.HP_LAYERS) that
+#                     keeps the alpha-matte error under the 1e-4 bound.
+#   TCVOM_DTYPE=fp16  libtcvom_hip_f16.so  IEEE fp16: 3 more mantissa bits at the same MFMA rate -- the alpha-matte error of 16-bit storage
+#                     falls ~35x (tests/test_bf16_noise_floor.py), no high-precision stem (0.8 ms faster per 1080p step); the backward runs
+#                     under an internal loss scale with an overflow guard (ops.LOSS_SCALE, ops.LossScaler).  BASELINE config 5 (FBA+TAM) names
+#                     this type: `bench.py --config fba` selects it.
+DTYPE_NAME = os.environ.get('TCVOM_DTYPE', 'bf16').lower()
 if DTYPE_NAME in ('f16', 'half', 'float16'):
     DTYPE_NAME = 'fp16'
 if DTYPE_NAME not in ('bf16', 'fp16'):

@@ -172,6 +172,13 @@ class VideoMattingDataset(torch.utils.data.Dataset):
             raise NotImplementedError('dataset.VMD: the imgaug colour / JPEG augmentation (VMD.py:253-262) is not part of this build '
                                       '(outside SURVEY.md section 8; no imgaug / OpenCV here to pin it against)')
         assert mode in ('train', 'val')
+        if mode == 'train':
+            import warnings
+            warnings.warn('dataset.VMD (tcvom_amd.data): train-mode samples get the GEOMETRIC augmentation only (crop search, scale, '
+                          'flip, pad). The reference ALWAYS applies imgaug pixel_aug + jpeg_aug to train samples '
+                          '(dataset/VMD.py:50-55, 253-262); imgaug / OpenCV are absent from this image, parity could not be pinned, so '
+                          'the colour / JPEG step is NOT built: a training run from disk differs from the reference recipe here. '
+                          'Open gap, listed in README.md and DESIGN.md section 8.', stacklevel=2)
         if precomputed_val is not None:
             assert mode == 'val'
         self.no_flow, self.mode, self.precomputed_val, self.sample_length = no_flow, mode, precomputed_val, sample_length

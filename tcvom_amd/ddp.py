@@ -224,6 +224,7 @@ class GradientAverager(object):
         ovf = None
         if SCALER.enabled and self.params and self.params[0].is_cuda:
             ovf = dist.all_reduce(SCALER.counter(self.params[0].device), op=dist.ReduceOp.MAX, async_op=True)
+            SCALER.reduced_over_ranks = True
 
         def covered(g):          # already being reduced by a span started from the bank hook
             if not early or not g.is_contiguous():

@@ -4,12 +4,11 @@
 loss as 3 levels x (reduction, per-sample terms), the Laplacian loss of alpha, F and B as ONE 7-channel pyramid of the
 difference image (the pyramid is linear) -- csrc/fba_loss.hip; ~40 launches forward, ~30 backward per frame, no host
 sync.  The handful of scalars in between (means, fourth roots, weights) are tiny device-side tensor expressions.
-`attention_loss` / `dtssd` (L_att, L_dt) are small tensor expressions on os8 / masked tensors.
+`attention_loss` (L_att) runs on the facade's `avgpool8` / `att_bce` kernels; `dtssd` (L_dt) is a small tensor expression on masked tensors.
 """
 import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -131,26 +130,65 @@ def fba_single_image_loss(preds, trimasks, gts, fgs, bgs, imgs, normalize=True):
     return sum(La) / n, sum(Ll) / n, sum(Lg) / n, alphas, comps, Fs, Bs
 
 
+class _AttLoss(torch.autograd.Function):
+    """L_att (models/model.py:285-323) on the kernels the GCA facade uses (csrc/facade.hip): `avgpool8` pools the ground truth to the
+    TAM grid, `att_bce` takes the 49 neighbour targets of every unknown os8 pixel from the pooled adjacent frame in place (no unfold
+    temporary) and accumulates the BCE sum + the unknown count of both directions, `loss_finalize` divides ON THE DEVICE (no host
+    read of the count), `att_bce_bwd` scales the saved sigmoid(x) - t."""
+
+    @staticmethod
+    def forward(ctx, gts, unk_small, window, att_thres, label_smooth, S, *logits):
+        ctx.set_materialize_grads(False)
+        ni = S - 2
+        attb, attf = logits[:ni], logits[ni:]
+        B, _, _, H, W = gts.shape
+        h, w = unk_small.shape[-2:]
+        dev = gts.device
+        st = L.stream_ptr()
+        pooled = torch.empty((B, S, h, w), dtype=torch.float32, device=dev)
+        L.call('tcvom_avgpool8', L.ptr(gts.contiguous()), L.ptr(pooled), B * S, H, W, st)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        acc = torch.zeros((S, 2), dtype=torch.float32, device=dev)
+        dlog = []
+        for k in range(ni):
+            c = k + 1
+            mask = unk_small[:, c].contiguous()
+            db, df = torch.empty_like(attb[k]), torch.empty_like(attf[k])
+            L.call('tcvom_att_bce', L.ptr(attb[k].contiguous()), L.ptr(pooled[:, c]), L.ptr(pooled[:, c - 1]), L.ptr(mask),
+                   L.ptr(db), L.ptr(acc[c]), B, h, w, window, att_thres, label_smooth, S * h * w, 1, st)
+            L.call('tcvom_att_bce', L.ptr(attf[k].contiguous()), L.ptr(pooled[:, c]), L.ptr(pooled[:, c + 1]), L.ptr(mask),
+                   L.ptr(df), L.ptr(acc[c]), B, h, w, window, att_thres, label_smooth, S * h * w, 0, st)
+            L.call('tcvom_loss_finalize', L.ptr(acc[c]), L.ptr(loss), 1.0 / ni, 1, 0.0, window, 1, st)
+            dlog.append((db, df))
+        ctx.acc, ctx.dlog, ctx.window, ctx.ni = acc, dlog, window, ni
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ni, acc = ctx.ni, ctx.acc
+        if g is None:
+            return (None,) * (6 + 2 * ni)
+        st = L.stream_ptr()
+        g = g.reshape(1).float().contiguous()
+        outs_b, outs_f = [], []
+        for k in range(ni):
+            db, df = ctx.dlog[k]
+            ob, of = torch.empty_like(db), torch.empty_like(df)
+            L.call('tcvom_att_bce_bwd', L.ptr(db), L.ptr(acc[k + 1]), L.ptr(g), 1.0 / ni, L.ptr(ob), db.numel(), ctx.window, st)
+            L.call('tcvom_att_bce_bwd', L.ptr(df), L.ptr(acc[k + 1]), L.ptr(g), 1.0 / ni, L.ptr(of), df.numel(), ctx.window, st)
+            outs_b.append(ob)
+            outs_f.append(of)
+        return (None,) * 6 + tuple(outs_b) + tuple(outs_f)
+
+
 def attention_loss(attb, attf, unk_small, gts, window, att_thres, label_smooth, os=8):
     """L_att (models/model.py:285-323): attb / attf lists of S ([B,w*w,h*w] logits, None at the ends), unk_small
     uint8 [B,S,h,w].  Zero for a frame without unknown os8 pixels."""
+    assert os == 8, 'the pooling kernel is the 8 x 8 average of the TAM grid'
     B, S = gts.shape[:2]
-    h, w = gts.shape[-2] // os, gts.shape[-1] // os
-    w2 = window * window
-    pooled = F.avg_pool2d(gts.reshape(B * S, 1, gts.shape[-2], gts.shape[-1]), os, os).reshape(B, S, 1, h, w)
-    terms = []
-    for c in range(1, S - 1):
-        m = (unk_small[:, c] != 0).reshape(B, 1, h * w).float()
-        cnt = m.sum()
-        cgt = pooled[:, c].reshape(B, 1, h * w)
-        tot = 0.0
-        for logits, adj in ((attb[c], pooled[:, c - 1]), (attf[c], pooled[:, c + 1])):
-            nb = F.unfold(adj, window, padding=window // 2)
-            tgt = ((cgt - nb).abs() < att_thres).float() * (1.0 - label_smooth)
-            bce = F.binary_cross_entropy_with_logits(logits, tgt, reduction='none')
-            tot = tot + (bce * m).sum() / (cnt * w2).clamp(min=1.0)
-        terms.append(tot / 2.0)
-    return sum(terms) / float(len(terms))
+    assert gts.shape[-2] // os == unk_small.shape[-2] and gts.shape[-1] // os == unk_small.shape[-1]
+    return _AttLoss.apply(gts, unk_small, int(window), float(att_thres), float(label_smooth), S,
+                          *([attb[c] for c in range(1, S - 1)] + [attf[c] for c in range(1, S - 1)]))
 
 
 def dtssd(pred, gt, trimasks, normalize=True, epsilon=1.001e-5):

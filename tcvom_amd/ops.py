@@ -50,17 +50,29 @@ class LossScaler(object):
         self.banks = weakref.WeakSet()
         self.counters = {}           # device index -> (device int32[2], pinned int32[2, 2], [event, event])
         self.clean_steps, self.skipped_steps, self.forward_saturations, self.t = 0, 0, 0, 0
+        self.reduced_over_ranks = False   # set by GradientAverager.average() (MAX over the ranks), consumed by FusedAdam.step()
+        self._ignore_next = False         # the read-back that follows a detected skip belongs to a backward run at the OLD scale
         self.enabled = L.DTYPE_NAME == 'fp16' and self.init_scale != 1.0 and _os.environ.get('TCVOM_NO_OVERFLOW_GUARD') is None
 
-    def register(self, bank):
+    def register(self, bank, device=None):
+        """`device`: the bank's device when known -- the counter pair is then created and announced to the library BEFORE the
+        first backward (a lazily created one missed the first step)."""
         bank.loss_scale = self.scale
         self.banks.add(bank)
+        if self.enabled and device is not None and torch.device(device).type == 'cuda':
+            self.counter(device)
 
     def counter(self, device):
         """The device counter pair of `device` (created on first use and announced to the library)."""
         idx = torch.device(device).index or 0
         ent = self.counters.get(idx)
         if ent is None:
+            # the library holds ONE process-wide sink pointer (csrc/norm.hip: g_overflow_sink; one process per GPU is the
+            # deployment): a second device in the same process would have its kernels count into the first device's memory
+            if self.counters:
+                raise RuntimeError('tcvom_amd: the fp16 overflow guard supports one GPU per process (counter registered on '
+                                   'cuda:%d, asked for cuda:%d); run one process per GPU or set TCVOM_NO_OVERFLOW_GUARD=1'
+                                   % (next(iter(self.counters)), idx))
             dev = torch.zeros(2, dtype=torch.int32, device=torch.device('cuda', idx))
             ent = self.counters[idx] = (dev, torch.zeros((2, 2), dtype=torch.int32).pin_memory(), [None, None])
             L.call('tcvom_overflow_sink', L.ptr(dev))
@@ -84,7 +96,16 @@ class LossScaler(object):
         ent[2][(self.t - 1) & 1] = None
         bwd, fwd = (int(v) for v in ent[1][(self.t - 1) & 1])
         self.forward_saturations += fwd
+        if self._ignore_next:
+            # step t-1's backward had already run at the old scale when step t-2's overflow became known: whatever it counted
+            # (the device dropped or applied it by its own counter) must not halve the scale a second time
+            self._ignore_next = False
+            if bwd:
+                self.skipped_steps += 1
+                return True
+            return False
         if bwd:
+            self._ignore_next = True
             self.skipped_steps += 1
             self.clean_steps = 0
             self._set_scale(max(self.scale * 0.5, 1.0))
@@ -105,6 +126,7 @@ class LossScaler(object):
         ent[2][slot] = ev
         ent[0].zero_()
         self.t += 1
+        self.reduced_over_ranks = False
 
 
 SCALER = LossScaler(LOSS_SCALE)

@@ -68,6 +68,14 @@ class FusedAdam(torch.optim.Optimizer):
                         if st and int(st.get('step', 0)) == self._last_step_of.get(id(st), -1):
                             st['step'] = int(st['step']) - 1
                 guard = L.ptr(SCALER.counter(dev0))
+                # several ranks WITHOUT GradientAverager (stock DistributedDataParallel averages the gradients itself,
+                # train_ddp.py:275-280): the counter is rank-local, so a rank whose backward saturated would drop the step alone and
+                # the replicas would drift apart -- take the MAX over the ranks here, on the stream, before the guarded launch
+                import torch.distributed as dist
+                if (not SCALER.reduced_over_ranks and dist.is_available() and dist.is_initialized()
+                        and dist.get_world_size() > 1):
+                    dist.all_reduce(SCALER.counter(dev0), op=dist.ReduceOp.MAX)
+                    SCALER.reduced_over_ranks = True
         self._last_step_of = {}
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group['params'] if p.grad is not None]

@@ -137,7 +137,9 @@ class VMN(nn.Module):
         # replays the same streams in backward.  Order-dependent state (BN running statistics) is applied afterwards.
         main = torch.cuda.current_stream()
         # (SyncBatchNorm: the mailbox exchanges of a rank must run in ONE stream order -- tcvom_amd/mailbox.py)
-        if self.frame_streams and not any(getattr(m, 'sync', False) for m in self.modules()):
+        # (a stock nn.SyncBatchNorm carries no `.sync` until its first train-mode call -- ops._sync_group sets it lazily)
+        if self.frame_streams and not any(getattr(m, 'sync', False) or isinstance(m, torch.nn.SyncBatchNorm)
+                                          for m in self.modules()):
             ops.SIDE_STREAMS[0] = True                     # gradient deposits between ops carry stream events (ops._GradStash)
             if len(self._streams) < S:
                 object.__setattr__(self, '_streams', [torch.cuda.Stream() for _ in range(S)])
@@ -235,7 +237,16 @@ def build_vmn_gca(agg_window, agg_reduction=1, freeze_backbone=False):
 
 
 def get_VMN_models(arch, agg_window, agg_reduction=1, freeze_backbone=False, **kwargs):
-    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4), `vmn_fba` (config 5), `vmn_dim` and `vmn_index` run on the HIP path."""
+    """models/VMN/__init__.py:11-29.  `vmn_gca` (configs 2-4), `vmn_fba` (config 5), `vmn_dim` and `vmn_index` run on the HIP path.
+
+    agg_reduction != 1: the reference CONSTRUCTS such a model but its first forward raises for every architecture --
+    FeatureAggregationModule._attention reshapes the C / reduction-channel keys with the input's channel count
+    (VMN_model.py:33-37: "shape '[128, -1, 64]' is invalid"; checked against the imported reference, all four archs, reductions 2
+    and 4) and the GCA decoder's layer_multi is inconsistent with it (VMN_GCA.py:12-15).  No behaviour to reproduce: refused here,
+    at construction, with the reason."""
+    if agg_reduction != 1:
+        raise ValueError('agg_reduction=%r: only 1 is usable -- the reference\'s FeatureAggregationModule fails in its first forward '
+                         'for any other value (models/VMN/VMN_model.py:33-37 reshapes C/reduction-channel keys as C channels)' % (agg_reduction,))
     if arch == 'vmn_gca':
         return build_vmn_gca(agg_window, agg_reduction, freeze_backbone)
     if arch == 'vmn_fba':

@@ -386,6 +386,10 @@ class WeightBank(object):
     def prepare(self, frames, training):
         """Run every power iteration of this window and write the packed weights.  Returns the plan."""
         dev = self.specs[0].weight.device
+        if self.loss_scale != 1.0 and dev.type == 'cuda':
+            from . import ops                               # fp16 build: the saturation counters exist (and the library knows them)
+            if ops.SCALER.enabled:                          # before the FIRST backward of this bank, not from the first optimizer step
+                ops.SCALER.counter(dev)
         self.flush_bn_counters()
         if self._ptr_sig is None or self._ptr_sig != self._signature():
             self._build(dev)

@@ -208,6 +208,7 @@ WINDOW_CASES = {
     'window_s3_64x64': (2, 3, 64, 64, 3, 7),
     'window_s5_64x96': (1, 5, 64, 96, 4, 7),
     'window_s3_128x160': (1, 3, 128, 160, 12, 7),
+    'window_s3_64x96_w5': (1, 3, 64, 96, 4, 5),      # agg_window 5 at model level (models/VMN/VMN_model.py:10-16)
 }
 FULL_GRADS = ('decoder.fam.key_conv.bias', 'decoder.fam.query_conv.bias', 'encoder.bn1.weight',
               'decoder.conv2.weight', 'encoder.gca.W.1.weight', 'decoder.layer3.0.bn1.bias')

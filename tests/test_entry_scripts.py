@@ -446,6 +446,44 @@ def test_bench_two_ranks_dry_run():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_full_size_syncbn_preflight():
+    """BASELINE config 4 has never run on 8 GPUs (the driver's to take); this is what one GPU can check of it: the SAME command at
+    the FULL 3 x 1088 x 1920 geometry with two ranks sharing this device (gloo for the hipIpc handles), every one of the 72
+    BatchNorms exchanging its [3 frames][2][C <= 512] sums through the peer mailboxes in forward and backward (train_ddp.py:271-280):
+    144 exchanges per step over a ring of 4 (36 reuses per slot and step), mailbox capacity for the widest layer, per-rank
+    diagnostics present, and the per-rank-BatchNorm A/B (`dist.no_sync_bn_ms_per_step`) in the same JSON line."""
+    import json
+    import socket
+    import subprocess
+    from tcvom_amd.mailbox import CAPACITY, RING
+    assert 3 * 2 * 512 <= CAPACITY and RING >= 4          # PeerMailbox.fits(3, 512): the os32 bottleneck, three frames per exchange
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TCVOM_DIST_BACKEND='gloo', TCVOM_MBOX_TIMEOUT_S='60')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    d = res['dist']
+    print({k: v for k, v in d.items() if k != 'per_rank'}, d['per_rank'])
+    assert res['n_gpus'] == 2 and res['config']['height'] == 1088 and res['config']['width'] == 1920 and res['config']['sync_bn'] is True
+    assert d['sync_bn_transport'] == 'mailbox' and d['sync_bn_exchanges_per_step'] == 144, d
+    assert len(d['per_rank']) == 2
+    for r in d['per_rank']:
+        assert r['sync_bn_transport'] == 'mailbox' and r['mailbox_exchanges_per_step'] == 144 and r['mailbox_world'] == 2, r
+        assert r['mailbox_self_test'] == 'passed' and r['mailbox_max_wait_ms'] >= 0.0 and r['ipc_peer_devices'], r
+        assert r['allreduce_exposed_ms_per_step'] >= 0.0
+    assert d['grad_spans_overlapped_with_backward'] >= 3
+    assert d['no_sync_bn_ms_per_step'] > 0 and d['no_sync_bn_steps'] >= 2, d
+    assert np.isfinite(res['final_loss']) and res['value'] > 0
+
+
+@pytest.mark.gpu
 def test_bench_fba_config_line():
     """`bench.py --config fba` (BASELINE.json config 5) prints the same one-line JSON contract as the headline run."""
     import json

@@ -89,3 +89,53 @@ def test_rccl_gradient_average_and_sync_bn_on_one_rank():
         assert float(t.sum()) == 8.0
     finally:
         dist.destroy_process_group()
+
+
+def _overflow_worker(rank, world, port, out):
+    """FusedAdam under stock DDP semantics (no GradientAverager): a saturated backward on ONE rank must drop the step on BOTH."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # both ranks share cuda:0 (RCCL refuses that); gloo carries the MAX
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        from tcvom_amd import ops
+        from tcvom_amd.optim import FusedAdam
+        assert ops.SCALER.enabled
+        p = torch.nn.Parameter(torch.ones(4096, device=dev))
+        opt = FusedAdam([p], lr=0.1)
+        res = {}
+        for step, sat_rank in enumerate((None, 1, None)):
+            p.grad = torch.full_like(p, 0.5)               # identical ("already averaged") gradients on both ranks
+            if sat_rank == rank:
+                ops.SCALER.counter(dev)[0] = 3             # what bn_bwd_reduce counts when it reads a gradient at +-65504
+            before = p.detach().clone()
+            opt.step()
+            torch.cuda.synchronize()
+            res['moved%d' % step] = bool((p.detach() != before).any())
+        res['scale'] = ops.SCALER.scale
+        res['skipped'] = ops.SCALER.skipped_steps
+        res['step'] = int(opt.state[p]['step'])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        if rank == 0:
+            torch.save(gathered, out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_overflow_on_one_rank_drops_the_adam_step_on_every_rank_without_an_averager(tmp_path):
+    """ADVICE round 4: with stock DistributedDataParallel (INTEGRATION.md) nothing but FusedAdam sees the fp16 saturation counter;
+    it must take the MAX over the ranks itself, or the replicas drift apart."""
+    import torch.multiprocessing as mp
+    from tcvom_amd import ops
+    if not ops.SCALER.enabled:
+        pytest.skip('the overflow guard belongs to the fp16 build (TCVOM_DTYPE=fp16)')
+    out = str(tmp_path / 'ovf.pt')
+    mp.spawn(_overflow_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out)
+    print(r0, r1)
+    for r in (r0, r1):
+        assert r['moved0'] and not r['moved1'] and r['moved2'], r      # step 1 dropped on BOTH ranks, steps 0 and 2 applied
+    assert r0 == r1                                                    # same scale, same skip count, same Adam step counter

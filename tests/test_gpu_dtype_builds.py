@@ -1,7 +1,8 @@
-"""Both builds of the library are products: libtcvom_hip_f16.so (fp16 storage, the default) and libtcvom_hip.so (bf16 storage,
-TCVOM_DTYPE=bf16).  The suite runs in whichever type the environment selects; this test runs the kernel-level tests, the reference
-goldens of the whole window and the benchmark-size forward parity in the OTHER type in a subprocess, so that one `pytest -m gpu`
-covers both."""
+"""Both builds of the library are products: libtcvom_hip.so (bf16 storage -- the north star's type, the default since round 5) and
+libtcvom_hip_f16.so (fp16 storage, TCVOM_DTYPE=fp16 -- the type BASELINE config 5 names).  The suite runs in whichever type the
+environment selects; this test runs the kernel-level tests, every whole-window test of the GCA+TAM path (reference goldens, benchmark-size
+forward AND backward parity, gradient fidelity), the FBA+TAM tests (goldens, 544 x 960 oracle parity, the 1080p window) and the gradient
+exchange tests in the OTHER type in a subprocess, so that one `pytest -m gpu` covers both builds with nothing excluded."""
 import os
 import subprocess
 import sys
@@ -18,9 +19,8 @@ def test_the_other_storage_type_passes_its_parity_tests():
         pytest.skip('already inside the other-dtype run')
     other = 'bf16' if DTYPE_NAME == 'fp16' else 'fp16'
     env = dict(os.environ, TCVOM_DTYPE=other, TCVOM_DTYPE_SUBTEST='1')
-    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.join(REPO, 'tests', 'test_gpu_ops.py'),
-           os.path.join(REPO, 'tests', 'test_gpu_window.py'), '-k',
-           'not full_size_backward and not gradient_fidelity and not (north_star and not 1088)']
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider'] + \
+          [os.path.join(REPO, 'tests', f) for f in ('test_gpu_ops.py', 'test_gpu_window.py', 'test_gpu_fba.py', 'test_gpu_ddp.py')]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1800)
     tail = '\n'.join(out.stdout.splitlines()[-15:])
     print('TCVOM_DTYPE=%s:\n%s' % (other, tail))

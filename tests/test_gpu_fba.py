@@ -9,7 +9,7 @@ from tcvom_amd._lib import ACT_DTYPE as H16      # the 16-bit storage type of th
 import torch.nn as nn
 import torch.nn.functional as F
 
-from helpers import hu, golden, assert_close, Checker, FBA_CASES, FBA_FULL_GRADS
+from helpers import hu, golden, assert_close, Checker, FBA_CASES, FBA_FULL_GRADS, tol
 from tcvom_amd.synthetic import formula_tensor, synthetic_window
 
 pytestmark = pytest.mark.gpu
@@ -401,3 +401,68 @@ def test_window_1080p_forward_backward():
     # GroupNorm has no running statistics and weight standardisation no power iteration: a second pass is the same function,
     # up to the summation order of the fp32 atomics in the pyramid pooling (a flipped bf16 rounding moves single pixels)
     assert float((again - first).abs().mean()) <= 1e-4 and float((again - first).abs().max()) <= 0.1
+
+
+def test_window_544x960_forward_backward_vs_oracle():
+    """Config 5 at a size that SELECTS the full-size kernels (the goldens stop at 96 x 160, where every layer runs on the small
+    tiles): one 3 x 544 x 960 window -- 68 x 120 os8 maps: the 2048-channel trunk on `gemm_nt256` (K >= 1024 expand convs), the
+    3072 -> 4096-padded pyramid concat into the 3x3 256-channel conv, the `gemm_tt256` split-K dense weight gradients, the dilated
+    `wgrad_ws` sub-grid problems -- forward + losses + BACKWARD against oracle.fba_net.fba_window_forward under torch autograd
+    (fp32, same formula weights, same clip; models/VMN/VMN_FBA.py:6-59, models/model.py:129-197).
+    Bounds: alpha / F / B MSE <= 1e-4 (north star), losses within 3 %, whole-network gradient norm and every module group that
+    carries gradient within the printed ratios."""
+    import os
+    import time
+    from oracle import fba_net
+    from helpers import fba_formula_state
+    from tcvom_amd.facade import train_step_loss
+    H, W, dil = 544, 960, 12
+    a, fg, bg = synthetic_window(1, 3, H, W, seed=5)
+    fm = _build('p544', dil, 3)
+    out = fm(a.to(DEV), fg.to(DEV), bg.to(DEV))
+    loss = train_step_loss(out)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {i: out[i].detach().float().cpu() for i in (7, 10, 11)}
+    losses = torch.stack([o.detach().float().cpu() for o in out[:5]])
+    g1 = {k: p.grad.double().cpu() for k, p in fm.NET.named_parameters() if p.grad is not None}
+    need = [k for k, p in fm.NET.named_parameters() if p.requires_grad]
+    del out, loss, fm
+    torch.cuda.empty_cache()
+    assert not [k for k in need if k not in g1]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    state = fba_formula_state(True)
+    ref, _ = fba_net.fba_window_forward(state, a, fg, bg, window=7, dilate_kernel=dil)
+    (ref[0] + ref[1] + ref[2] + 0.5 * ref[3] + 0.25 * ref[4]).backward()
+    go = {k: v.grad.double() for k, v in state.items() if getattr(v, 'grad', None) is not None}
+    t_oracle = time.time() - t0
+    ck = Checker()
+    rl = torch.stack([r.detach().float() for r in ref[:5]])
+    for i, nm in enumerate(('L_alpha_comp', 'L_lap', 'L_grad', 'L_dt', 'L_att')):
+        if float(rl[i]) != 0:
+            ck.rel(nm, losses[i], rl[i], 3e-2)
+    mses = {nm: float(((got[i] - ref[i].detach()) ** 2).mean()) for i, nm in ((7, 'alphas'), (10, 'Fs'), (11, 'Bs'))}
+    norm = lambda gs, ks: float(torch.sqrt(sum((gs[k] ** 2).sum() for k in ks)))
+    cos = lambda x, y: float((x * y).sum() / (x.norm() * y.norm() + 1e-300))
+    keys = [k for k in need if k in go and float(go[k].norm()) > 0]
+    assert len(keys) >= 0.95 * len(need)
+    groups = {}
+    for k in keys:
+        groups.setdefault('.'.join(k.split('.')[:2]), []).append(k)
+    rows = [(top, norm(g1, ks) / norm(go, ks), norm(go, ks), len(ks)) for top, ks in sorted(groups.items())]
+    total = norm(g1, keys) / norm(go, keys)
+    cat = lambda gs: torch.cat([gs[k].flatten() for k in keys])
+    c_all = cos(cat(g1), cat(go))
+    print('FBA 544x960: MSE %s; losses %s vs %s; gradient norm HIP / oracle %.3f, cosine %.3f; oracle %.0f s'
+          % (', '.join('%s %.2e' % kv for kv in mses.items()), losses.tolist(), rl.tolist(), total, c_all, t_oracle))
+    print('\n'.join('%-28s norm ratio %.3f  oracle norm %.3e  (%d tensors)' % r for r in rows))
+    ck.done()
+    for nm, m in mses.items():
+        assert m <= 1e-4, '%s MSE %.3e' % (nm, m)
+    assert 0.9 <= total <= 1.1, 'whole-network gradient norm vs the oracle: %.3f' % total
+    assert c_all >= tol(0.9, 0.97), 'whole-network gradient direction vs the oracle: %.3f' % c_all
+    top = max(r[2] for r in rows)
+    for name, ratio, on, n in rows:
+        if on >= 0.02 * top:
+            assert 0.85 <= ratio <= 1.15, 'gradient norm of %s: %.3f of the oracle' % (name, ratio)

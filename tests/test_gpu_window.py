@@ -270,6 +270,76 @@ def test_gradient_fidelity_vs_oracle():
     assert cos(tot_h, tot_o) >= tol(0.7, 0.9), 'whole-network gradient direction'       # measured 0.79 (bf16)
 
 
+@pytest.mark.parametrize('regime', ['formula_gains', 'damped_residual_gains'])
+def test_gradient_noise_on_a_conditioned_network(regime):
+    """Run-to-run and HIP-vs-oracle agreement of the WHOLE-network gradient on a network that is two optimizer steps into
+    training, at 256 x 320.  The only run-to-run difference of the HIP path is the order of fp32
+    atomic partial sums (igemm_tt / wgrad_ws / SpectralNorm sums); how far that moves the gradient depends on how strongly the
+    backward map of the 60-layer train-mode-BatchNorm stack amplifies last-bit differences, so two regimes are bounded:
+      * formula_gains: the formula weights as they are -- every BatchNorm scale 0.6 +- 0.25, INCLUDING every BasicBlock's bn2
+        (the reference zero-initialises those, resnet_enc.py:96-98; SURVEY App. A asks for O(1) values in parity tests) -- a
+        random network whose residual branches carry as much signal as the identity paths: the ill-conditioned end;
+      * damped_residual_gains: bn2.weight x 0.15 (what zero-init-residual training leaves early on): the identity paths dominate
+        and the amplification argument no longer applies -- here the kernels themselves are what is measured.
+    Both start from two FusedAdam steps of the HIP path (running statistics, power-iteration vectors and weights moved off the
+    formula state); the resulting state_dict is loaded into the fp32 CPU oracle, and the third step's gradient is compared."""
+    import os
+    import oracle
+    from tcvom_amd.facade import train_step_loss
+    from tcvom_amd.optim import FusedAdam
+    H, W = 256, 320
+    m = _model(7, 12)
+    if regime == 'damped_residual_gains':
+        with torch.no_grad():
+            for k, p in m.NET.named_parameters():
+                if k.endswith('bn2.weight'):
+                    p.mul_(0.15)
+    m = m.train()
+    a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
+    ad, fd, bd = a.to(DEV), fg.to(DEV), bg.to(DEV)
+    opt = FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        train_step_loss(m(ad, fd, bd)).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in m.NET.state_dict().items()}
+
+    def hip_grad():
+        m.NET.load_state_dict(sd)                      # the third step from the SAME state (a forward moves u / v / running stats)
+        m.zero_grad(set_to_none=True)
+        train_step_loss(m(ad, fd, bd)).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.double().cpu() for k, p in m.NET.named_parameters() if p.grad is not None}
+    g1, g2 = hip_grad(), hip_grad()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    state = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    for k, v in state.items():
+        if v.is_floating_point() and not any(t in k for t in ('weight_u', 'weight_v', 'running_')):
+            v.requires_grad_(True)
+    out, _ = oracle.window_forward(state, a, fg, bg, window=7, dilate_kernel=12, training=True)
+    oracle.train_step_loss(out).backward()
+    go = {k: v.grad.double() for k, v in state.items() if getattr(v, 'grad', None) is not None}
+    keys = [k for k in g1 if k in go and float(go[k].norm()) > 0]
+    assert len(keys) >= 0.95 * len(g1)
+    cat = lambda gs: torch.cat([gs[k].flatten() for k in keys])
+    cos = lambda x, y: float((x * y).sum() / (x.norm() * y.norm() + 1e-300))
+    c_oracle, c_rerun = cos(cat(g1), cat(go)), cos(cat(g1), cat(g2))
+    nr = float(cat(g1).norm() / cat(go).norm())
+    enc = [k for k in keys if k.startswith('encoder.')]
+    dec = [k for k in keys if k.startswith('decoder.')]
+    sub = lambda gs, ks: torch.cat([gs[k].flatten() for k in ks])
+    print('%s, two Adam steps in, 256x320: whole-network gradient cosine HIP vs oracle %.4f (encoder %.4f, decoder %.4f), run vs rerun %.4f, '
+          'norm ratio %.4f' % (regime, c_oracle, cos(sub(g1, enc), sub(go, enc)), cos(sub(g1, dec), sub(go, dec)), c_rerun, nr))
+    if regime == 'damped_residual_gains':
+        assert c_oracle >= tol(0.95, 0.99) and c_rerun >= tol(0.95, 0.99), (c_oracle, c_rerun)
+        assert abs(nr - 1) <= tol(0.1, 0.03)
+    else:
+        # measured floor of the ill-conditioned regime (DESIGN.md section 6): the rerun distance IS the amplified atomics order
+        assert c_oracle >= tol(0.7, 0.9) and c_rerun >= tol(0.7, 0.9), (c_oracle, c_rerun)
+        assert abs(nr - 1) <= tol(0.2, 0.06)
+
+
 def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
     """freeze_backbone=True (pretrain_ddp.py's TAM pre-training; VMN_model.py:77-103, VMN_GCA.py:18-24): encoder and decoder
     front run in eval mode under no_grad inside a training step -- no gradient, BatchNorm running statistics and

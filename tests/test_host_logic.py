@@ -78,3 +78,50 @@ def test_train_step_loss_matches_the_reference_formula():
     assert abs(float(loss) - float(want)) < 1e-7
     loss.backward()
     assert [float(v.grad) for v in vals] == [1.0, 1.0, 1.0, 0.5, 0.25]
+
+
+def test_loss_scaler_halves_once_per_overflow_and_ignores_the_stale_read_back():
+    """ops.LossScaler reads the device counter one step late: when step t's overflow becomes known, step t+1's backward has
+    already run at the OLD scale.  Its read-back must not halve the scale a second time."""
+    from tcvom_amd import ops
+
+    class Ev(object):
+        def synchronize(self):
+            pass
+
+    sc = ops.LossScaler(65536.0)
+    host = torch.zeros((2, 2), dtype=torch.int32)
+    sc.counters[0] = (None, host, [None, None])
+
+    def finish_step(bwd):              # what after_step() leaves behind for the next before_step()
+        slot = sc.t & 1
+        host[slot, 0] = bwd
+        sc.counters[0][2][slot] = Ev()
+        sc.t += 1
+
+    assert sc.before_step('cuda:0') is False                 # nothing recorded yet
+    finish_step(0)
+    assert sc.before_step('cuda:0') is False and sc.scale == 65536.0
+    finish_step(5)                                           # step 1 overflowed
+    finish_step_skipped = sc.before_step('cuda:0')
+    assert finish_step_skipped is True and sc.scale == 32768.0 and sc.skipped_steps == 1
+    finish_step(7)                                           # step 2 ran its backward at the old scale: overflowed again
+    assert sc.before_step('cuda:0') is True                  # the device dropped it (counter != 0) -> step counters taken back ...
+    assert sc.scale == 32768.0 and sc.skipped_steps == 2     # ... but the scale is halved ONCE
+    finish_step(0)
+    assert sc.before_step('cuda:0') is False and sc.scale == 32768.0
+    finish_step(3)                                           # a fresh overflow at the new scale halves again
+    assert sc.before_step('cuda:0') is True and sc.scale == 16384.0
+
+
+@pytest.mark.parametrize('arch', ['vmn_gca', 'vmn_dim', 'vmn_fba', 'vmn_index'])
+def test_agg_reduction_other_than_one_is_refused_like_the_reference_fails(arch):
+    """models/VMN/__init__.py:11 accepts agg_reduction, but the reference's own forward raises for every value != 1 (the TAM reshapes
+    C / reduction-channel keys as C channels, VMN_model.py:33-37 -- verified on the imported reference for all four archs): the
+    product refuses at construction instead of at the first window.  agg_window != 7 IS supported: golden window_s3_64x96_w5."""
+    from tcvom_amd.vmn import get_VMN_models
+    with pytest.raises(ValueError, match='agg_reduction'):
+        get_VMN_models(arch, 7, agg_reduction=2)
+    from models.model import FullModel_VMD
+    with pytest.raises(ValueError, match='agg_reduction'):
+        FullModel_VMD(arch, agg_window=5, agg_reduction=2)
