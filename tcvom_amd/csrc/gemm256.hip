@@ -92,6 +92,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     constexpr int TM = MF * 64, TN = 256, HM = TM / 2, A_IT = TM / 64;
     constexpr int SLOT = (TM + TN) * 64;                 // bf16 elements per K-tile buffer
     __shared__ __attribute__((aligned(16))) h16raw lds[2 * SLOT];
+    // EPI 2 / 3: the tile's 256 column coefficients c[m] (and d[m]) wait in LDS from the prologue on -- read per (a, q) step of the
+    // epilogue from global memory they were 16 dependent L2 round trips per workgroup behind the main loop (the scores product has
+    // only 9 K-tiles: its epilogue was longer than its main loop)
+    __shared__ __attribute__((aligned(16))) float coef[(EPI == 2 || EPI == 3) ? 512 : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,6 +276,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     // prologue: K-tile 0 into buffer 0 (all waves), then the stagger
 #pragma unroll
     for (int it = 0; it < 4; ++it) { if (it < A_IT) G_ISSUE_A(0, it) G_ISSUE_B(0, it) }
+    if constexpr (EPI == 2 || EPI == 3) {
+        // waves 0..3: c[m0 .. m0 + 255], waves 4..7: d[...] (zeros beyond M / without a diagonal term); 4 bytes per lane
+        const int ci = (wave & 3) * 64 + lane;
+        const float* vec = wave < 4 ? mscale : mdiag;
+        const void* src_ = (vec && m0 + ci < g.M) ? (const void*)(vec + m0 + ci) : (const void*)g.zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(coef + wave * 64), 4, 0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G_BAR();
     if (wm == 1) G_BAR();                              // group 1 runs one barrier interval behind group 0
@@ -426,9 +437,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         for (int a = 0; a < MF; ++a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ml = wm * HM + a * 32 + 8 * q + 4 * (lane >> 5), mrow = m0 + ml;
-                float sc[4] = {0.f, 0.f, 0.f, 0.f};
-                if (mrow < g.M) { const float4 c4 = *reinterpret_cast<const float4*>(mscale + mrow); sc[0] = c4.x; sc[1] = c4.y; sc[2] = c4.z; sc[3] = c4.w; }
+                const int ml = wm * HM + a * 32 + 8 * q + 4 * (lane >> 5);
+                const float4 c4 = *reinterpret_cast<const float4*>(coef + ml);           // (zeros in the columns M <= m)
+                const float sc[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int r = wn * 64 + b * 32 + (lane & 31);
@@ -479,13 +490,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             for (int a = 0; a < MF; ++a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int mrow = m0 + wm * HM + a * 32 + 8 * q + 4 * h;
-                    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), dg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int ml = wm * HM + a * 32 + 8 * q + 4 * h, mrow = m0 + ml;
                     const bool mv = mrow < g.M;
-                    if (mv) {
-                        if (mscale) sc4 = *reinterpret_cast<const float4*>(mscale + mrow);
-                        if (mdiag) dg4 = *reinterpret_cast<const float4*>(mdiag + mrow);
-                    }
+                    const float4 sc4 = *reinterpret_cast<const float4*>(coef + ml), dg4 = *reinterpret_cast<const float4*>(coef + 256 + ml);
                     const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {

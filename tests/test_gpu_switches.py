@@ -51,11 +51,13 @@ def test_alternative_code_paths_agree_with_the_default_ones():
     # encoder move by percents between two identical runs (tests/test_gpu_window.py: cosine 0.98 between two runs at 1088 x 1920)
     noise = worst(base, again)
     tnoise = abs(total(base) - total(again)) / total(base)
-    print('run-to-run gradient-norm difference: worst group %.2e, total %.2e' % (noise, tnoise))
+    lnoise = max(abs(x - y) / max(abs(x), 1e-3) for x, y in zip(base['losses'], again['losses']))
+    print('run-to-run gradient-norm difference: worst group %.2e, total %.2e; losses %.2e' % (noise, tnoise, lnoise))
     for name, env in sets.items():
         alt = _probe(env)
         for x, y in zip(base['losses'], alt['losses']):
-            assert abs(x - y) <= 2e-3 * max(abs(x), 1e-3), (name, base['losses'], alt['losses'])
+            # (bf16 storage: two identical runs already differ by ~1e-3 in L_att -- the statistics atomics flip 16-bit roundings)
+            assert abs(x - y) <= max(2e-3, 4 * lnoise) * max(abs(x), 1e-3), (name, base['losses'], alt['losses'], lnoise)
         w = worst(base, alt)
         print('%s: worst per-group gradient-norm difference %.2e' % (name, w))
         assert w < max(3e-2, 5 * noise), (name, w)

@@ -332,12 +332,15 @@ def test_gradient_noise_on_a_conditioned_network(regime):
     print('%s, two Adam steps in, 256x320: whole-network gradient cosine HIP vs oracle %.4f (encoder %.4f, decoder %.4f), run vs rerun %.4f, '
           'norm ratio %.4f' % (regime, c_oracle, cos(sub(g1, enc), sub(go, enc)), cos(sub(g1, dec), sub(go, dec)), c_rerun, nr))
     if regime == 'damped_residual_gains':
-        assert c_oracle >= tol(0.95, 0.99) and c_rerun >= tol(0.95, 0.99), (c_oracle, c_rerun)
-        assert abs(nr - 1) <= tol(0.1, 0.03)
+        # measured (MI355X, round 5): bf16 0.9988 vs the oracle / 0.9993 run vs rerun, norm ratio 0.9997; fp16 0.9998 / 0.9999 / 0.9996
+        assert c_oracle >= tol(0.995, 0.999) and c_rerun >= tol(0.995, 0.999), (c_oracle, c_rerun)
+        assert abs(nr - 1) <= tol(0.02, 0.01)
     else:
-        # measured floor of the ill-conditioned regime: the rerun distance IS the amplified atomics order
-        assert c_oracle >= tol(0.7, 0.9) and c_rerun >= tol(0.7, 0.9), (c_oracle, c_rerun)
-        assert abs(nr - 1) <= tol(0.2, 0.06)
+        # measured floor of the ill-conditioned regime: bf16 0.828 vs the oracle with 0.912 between two identical
+        # runs; fp16 0.967 / 0.986 -- the rerun distance IS the amplified order of the fp32 atomics, and the distance to the oracle is
+        # about twice it (storage rounding amplified the same way)
+        assert c_oracle >= tol(0.7, 0.93) and c_rerun >= tol(0.8, 0.96), (c_oracle, c_rerun)
+        assert abs(nr - 1) <= tol(0.08, 0.03)
 
 
 def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():

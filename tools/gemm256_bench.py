@@ -74,10 +74,36 @@ def main():
     dW2 = torch.empty(B, N, D, device=DEV)
     rows.append(('dWq, M\' in one launch', 4.0 * B * N * N * D,
                  lambda: L.call('tcvom_gemm_pair', L.ptr(P), L.ptr(Pt), L.ptr(Gt), L.ptr(dW), L.ptr(dW2), C.byref(d3), ld * ld, st)))
+    # the launches the product actually makes (ops._GcaAttention): fused scores + softmax numerators, O = P V and dV with k-major
+    # operands, dq / dk with their K-split tails
+    stats = torch.empty(B, N, ld // 256, 2, device=DEV)
+    dvec = torch.rand(B, N, device=DEV)
+    Pn = torch.empty(B, N, ld, device=DEV, dtype=BF)
+    dV = torch.empty(B, N, DV, device=DEV)
+    Mp = torch.empty(B, N, D, device=DEV)
+    rows += [
+        ('P~ = exp(S - tile max) EPI3', 2.0 * B * N * N * D,
+         lambda: L.call('tcvom_gca_scores_exp', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(Pn), L.ptr(stats), N, D, ld, B, st)),
+        ('softmax rescale pass', 0.0, lambda: L.call('tcvom_gca_softmax_rescale', L.ptr(Pn), L.ptr(stats), N, ld, B, st)),
+        ('O = P V  (V k-major)', 2.0 * B * N * N * DV, lambda: L.call('tcvom_gca_pv', L.ptr(P), L.ptr(V), L.ptr(O), N, DV, ld, B, st)),
+        ('dV = P^T dO (k-major)', 2.0 * B * N * N * DV, lambda: L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dO), L.ptr(dV), N, DV, ld, B, st)),
+        ('dq + dk (two launches)', 4.0 * B * N * N * D, lambda: L.call('tcvom_gca_dq_dk', L.ptr(P), L.ptr(Gt), L.ptr(dW), L.ptr(Mp), N, D, ld, B, st)),
+    ]
     for name, flop, fn in rows:
         t = timeit(fn)
-        print('%-28s %7.1f us  %6.0f TFLOP/s' % (name, t * 1e3, flop / t / 1e9))
+        print('%-30s %7.1f us  %6.0f TFLOP/s' % (name, t * 1e3, flop / t / 1e9))
+    # numerics of the fused scores + softmax (pass 1 + rescale) on the first frame, rows 0..255
+    G = (G.float() * 0.15).to(BF)                     # |S| of a few units: rows with many comparable entries, not one-hot ones
+    L.call('tcvom_gca_scores_exp', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(Pn), L.ptr(stats), N, D, ld, B, st)
+    L.call('tcvom_gca_softmax_rescale', L.ptr(Pn), L.ptr(stats), N, ld, B, st)
+    Sr = (G[0, :256].float() @ G[0].float().t()) * cvec[0][None, :]
+    Sr[torch.arange(256), torch.arange(256)] -= dvec[0, :256]
+    Pr = torch.softmax(Sr, dim=1)
+    perr = (Pn[0, :256, :N].float() - Pr).abs().max().item() / Pr.max().item()
+    print('fused softmax max error / max P = %.2e ; padding columns zero: %s' % (perr, bool((Pn[0, :256, N:] == 0).all())))
+    assert perr < 2e-2
     # numerics of O = P V on the first frame, rows 0..511
+    L.call('tcvom_conv_igemm', L.ptr(P), L.ptr(Vt), L.ptr(O), None, None, None, None, C.byref(d2), st)
     ref = P[0, :512].float() @ Vt[0].float().t()
     err = (O[0, :512] - ref).abs().max().item() / ref.abs().max().item()
     print('O = P V max error / max |O| = %.2e' % err)
