@@ -74,6 +74,17 @@ struct Gemm256Args {
 // round of workgroups, from the one-frame launch whose operands stay in the 256 MB Infinity Cache, 224 us.)
 // (Issuing the LDS-DMA instructions in the LOAD sections of the four-phase loop, as the guide's 8-phase template does, instead of
 // behind MFMA pairs measured 6-8 % SLOWER here: O = P V 792 -> 852 us per 3-frame launch.)
+#ifdef G256_LIFE
+// life cycle of two workgroups (first and a late round) in 100 MHz ticks: entry, first K-tile landed, main loop done, epilogue phases,
+// stores issued, stores retired -- tools/g256_life.py
+__device__ unsigned long long g256_life[64];
+extern "C" int tcvom_life256_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g256_life), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#define G_LIFE(i) if (life_on) g256_life[life_slot * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define G_LIFE(i)
+#endif
 #ifdef G256_TRACE
 __device__ unsigned long long g256_trace[512];
 extern "C" int tcvom_trace256_read(unsigned long long* host) {
@@ -100,6 +111,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;             // wm = wave group (0: rows 0..127 of the tile, 1: rows 128..255)
+#ifdef G256_LIFE
+    const int life_slot = (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0) ? 0 : (blockIdx.x == 8 && blockIdx.y == gridDim.y / 2 && blockIdx.z == gridDim.z - 1) ? 1 : -1;
+    const bool life_on = life_slot >= 0 && tid == 0;
+    G_LIFE(0)
+#endif
 
     // XCD-aware tile order over the pixel (N) tiles
     int bx, by = blockIdx.y, bzz = blockIdx.z, kpart = -1;
@@ -284,6 +300,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(coef + wave * 64), 4, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G_LIFE(1)
     G_BAR();
     if (wm == 1) G_BAR();                              // group 1 runs one barrier interval behind group 0
 
@@ -369,8 +386,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
 
     // ------------------------------------------------------------------ epilogue
     // A lane holds 4 consecutive m of ONE row n, its 32 neighbours 32 different rows.
+    if constexpr (EPI == 3) coef[tid] *= 1.4426950408889634f;          // c[m], d[m] in base-2 units (512 threads, 512 floats)
     __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): nothing of the main loop is in flight
     __builtin_amdgcn_s_barrier();
+    G_LIFE(2)
     int pglob[2];
     bool pvalid[2];
 #pragma unroll
@@ -486,27 +505,41 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             float* red = reinterpret_cast<float*>(lb + 96 * 1024);       // 2 x [2 wm][4 wn][2 b][32] floats, beyond the staging regions
             const float ninf = -__builtin_inff();
             float tmax[2] = {ninf, ninf};
+            // The scores live in base-2 units from here on (the coefficients in LDS were multiplied by log2 e at the head of the
+            // epilogue): x' = log2e (acc c[m] - d[m] [m == n]), numerator = exp2(x' - max x') -- one v_exp_f32 per value, no multiply.
+            // Per-element work the tile does not need is decided ONCE per tile: the diagonal term exists in the tiles on the
+            // diagonal only (m0 == n0: 1 tile in 32 at 1080p), padding columns M <= m in the last tile column only.
+            auto pass1 = [&](auto diag_, auto pad_) {
+                constexpr bool DIAG = decltype(diag_)::value, PAD = decltype(pad_)::value;
 #pragma unroll
-            for (int a = 0; a < MF; ++a) {
+                for (int a = 0; a < MF; ++a) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ml = wm * HM + a * 32 + 8 * q + 4 * h, mrow = m0 + ml;
-                    const bool mv = mrow < g.M;
-                    const float4 sc4 = *reinterpret_cast<const float4*>(coef + ml), dg4 = *reinterpret_cast<const float4*>(coef + 256 + ml);
-                    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
+                    for (int q = 0; q < 4; ++q) {
+                        const int ml = wm * HM + a * 32 + 8 * q + 4 * h, mrow = m0 + ml;
+                        const bool mv = mrow < g.M;
+                        const float4 sc4 = *reinterpret_cast<const float4*>(coef + ml);
+                        float4 dg4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (DIAG) dg4 = *reinterpret_cast<const float4*>(coef + 256 + ml);
+                        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
+                        for (int b = 0; b < 2; ++b) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float x = acc[a][b][q * 4 + r] * sc[r] - ((mrow + r) == pglob[b] ? dg[r] : 0.f);
-                            x = mv ? x : ninf;                            // padding columns M <= m: no part of the row
-                            acc[a][b][q * 4 + r] = x;
-                            tmax[b] = fmaxf(tmax[b], x);
+                            for (int r = 0; r < 4; ++r) {
+                                float x = acc[a][b][q * 4 + r] * sc[r];
+                                if constexpr (DIAG) x -= (mrow + r) == pglob[b] ? dg[r] : 0.f;
+                                if constexpr (PAD) x = mv ? x : ninf;         // padding columns M <= m: no part of the row
+                                acc[a][b][q * 4 + r] = x;
+                                tmax[b] = fmaxf(tmax[b], x);
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);        // keep the 16 coefficient reads from being hoisted together (spills)
                     }
-                    __builtin_amdgcn_sched_barrier(0);            // keep the 16 coefficient loads from being hoisted together (spills)
                 }
-            }
+            };
+            const bool diag_tile = m0 == n0 && mdiag != nullptr, pad_tile = m0 + TM > g.M;
+            if (pad_tile) { if (diag_tile) pass1(std::true_type{}, std::true_type{}); else pass1(std::false_type{}, std::true_type{}); }
+            else if (diag_tile) pass1(std::true_type{}, std::false_type{});
+            else pass1(std::false_type{}, std::false_type{});
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 tmax[b] = fmaxf(tmax[b], __shfl_xor(tmax[b], 32, 64));
@@ -514,16 +547,18 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             }
             __builtin_amdgcn_s_waitcnt(0x0070);
             __builtin_amdgcn_s_barrier();
+            G_LIFE(3)
             float tsum[2] = {0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 tmax[b] = fmaxf(tmax[b], red[(((wm ^ 1) * 4 + wn) * 2 + b) * 32 + nl]);
+                // (a row whose every column of this tile is padding cannot occur: the last tile column holds M - (tiles - 1) 256 >= 1
+                //  valid columns, so tmax is finite and exp2(-inf - tmax) = 0 for the padding columns)
 #pragma unroll
                 for (int a = 0; a < MF; ++a)
 #pragma unroll
                     for (int r16 = 0; r16 < 16; ++r16) {
-                        const float x = acc[a][b][r16];
-                        const float e = x == ninf ? 0.f : __expf(x - tmax[b]);
+                        const float e = __builtin_amdgcn_exp2f(acc[a][b][r16] - tmax[b]);
                         acc[a][b][r16] = e;
                         tsum[b] += e;
                     }
@@ -532,12 +567,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             }
             __builtin_amdgcn_s_waitcnt(0x0070);
             __builtin_amdgcn_s_barrier();
+            G_LIFE(4)
             if (wm == 0 && h == 0) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     if (pvalid[b]) {
                         float* st = g.stats + (((int64_t)bz * g.N + pglob[b]) * gridDim.y + by) * 2;
-                        st[0] = tmax[b];
+                        st[0] = tmax[b] * 0.6931471805599453f;         // back to natural units (softmax_rescale: exp(max - row max))
                         st[1] = tsum[b] + red[512 + ((1 * 4 + wn) * 2 + b) * 32 + nl];
                     }
             }
@@ -620,6 +656,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         };
         if constexpr (EPI == 3) emit(std::false_type{});
         else if (mdiag) emit(std::true_type{}); else emit(std::false_type{});
+        G_LIFE(5)
+#ifdef G256_LIFE
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        G_LIFE(6)
+#endif
     } else {
     if constexpr (F32 && MF == 3) {
         if (kpart >= 0) {
