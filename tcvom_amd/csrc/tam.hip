@@ -406,8 +406,11 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
     const uint4* __restrict__ q, const uint4* __restrict__ kb, const uint4* __restrict__ kf, const unsigned* __restrict__ v,
     const uint4* __restrict__ g, const unsigned char* __restrict__ mask, unsigned* __restrict__ out,
     float* __restrict__ att0, float* __restrict__ att1, const float* __restrict__ datt0, const float* __restrict__ datt1,
-    int H, int W, float inv_sqrt_c, int cnt_lo)
+    int H, int W, float inv_sqrt_c, int cnt_lo, int self_init)
 {
+    // self_init != 0 (every active tile runs here, cnt_lo == 1): the kernel writes EVERY pixel of its tile -- known pixels get out = v and
+    // zero logits (forward) / dq = 0 (backward) -- so the launcher needs no memsets of the logit maps / dq and no copy of v
+    // (three ~5 us fill / copy launches per call: a fifth of the all-unknown forward)
     constexpr int WIN = 7, W2 = 49, R = 3, TH = 8, TW = 8, HW = 14, NKEY = 196, NK = 224, C8 = 16, NT = 64;
     extern __shared__ __attribute__((aligned(16))) uint4 tam_lds[];
     uint4* halo = tam_lds;                                  // [2][224][16]
@@ -430,7 +433,27 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
         if (u) atomicAdd(&cnt, 1);
     }
     __syncthreads();
-    if (cnt < cnt_lo) return;                               // (sparser tiles: the one-wave-per-pixel kernel, see the launchers)
+    if (cnt < cnt_lo) {                                     // (sparser tiles: the one-wave-per-pixel kernel, see the launchers)
+        if (self_init && cnt == 0) {
+            // a tile of known pixels: out = v (forward) or dq = 0 (backward), zero logits
+            for (int idx = tid; idx < NT * C8; idx += 256) {
+                const int p = idx >> 4, c = idx & 15;
+                const int y = ty0 + p / TW, x = tx0 + p % TW;
+                if (y < H && x < W) {
+                    const int64_t o = (b * N + (int64_t)y * W + x) * C8 + c;
+                    reinterpret_cast<uint4*>(out)[o] = MODE == 0 ? reinterpret_cast<const uint4*>(v)[o] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            if (MODE == 0) {
+                for (int idx = tid; idx < 2 * W2 * NT; idx += 256) {
+                    const int p = idx & 63, jd = idx >> 6;              // jd = dir * 49 + j
+                    const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
+                    if (y < H && x < W) (jd < W2 ? att0 : att1)[((int64_t)b * W2 + (jd < W2 ? jd : jd - W2)) * N + (int64_t)y * W + x] = 0.f;
+                }
+            }
+        }
+        return;
+    }
     {
         // thread -> (chunk c = tid & 15, halo row r = (tid >> 4) + 16 i): 14 rows of 16 threads per pass and direction, all loads of a
         // thread issued before its stores
@@ -465,7 +488,8 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
     const int n = lane & 31, h = lane >> 5;
     const int qi = qb * 32 + n, qy = qi >> 3, qx = qi & 7;
     const bool q_unk = unk[qi] != 0;
-    const int64_t u = (int64_t)(ty0 + qy) * W + tx0 + qx;       // (valid when q_unk)
+    const bool q_in = ty0 + qy < H && tx0 + qx < W;
+    const int64_t u = (int64_t)(ty0 + qy) * W + tx0 + qx;       // (valid when q_in)
     const uint4* hl = halo + dir * NK * C8;
     // ---- GEMM 1 (and the dP product of the backward): accumulators [7 key blocks][16 rows 8 g + 4 h + r]
     f32x16_t acc[7], accd[MODE == 1 ? 7 : 1];
@@ -513,10 +537,10 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
         for (int r16 = 0; r16 < 16; ++r16) {
             const float l = acc[k7][r16];
             const bool rel = l > -1.0e38f;
-            if (MODE == 0 && rel && q_unk) {
+            if (MODE == 0 && rel && (q_unk || (self_init && q_in))) {
                 const int row0 = k7 * 32 + 8 * (r16 >> 2) + (r16 & 3);
                 const int ky = h ? (row0 + 4) / HW : row0 / HW, kx = h ? (row0 + 4) % HW : row0 % HW;
-                attd[((int64_t)b * W2 + (ky - qy) * WIN + (kx - qx)) * N + u] = l;
+                attd[((int64_t)b * W2 + (ky - qy) * WIN + (kx - qx)) * N + u] = q_unk ? l : 0.f;
             }
             const float e = rel ? __expf(l - mx) : 0.f;
             acc[k7][r16] = e;
@@ -541,8 +565,25 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
     const unsigned hl_addr = (unsigned)(uintptr_t)(tam_lp)hl;
     const int trow = (lane & 15) >> 2, cig = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
     const float* dattd = dir == 0 ? datt0 : datt1;
+    // backward: the incoming logit gradients of this query's 49 neighbours, all loads in flight at once (inside the product loop they
+    // were one exposed L2 round trip per k-step: 14 per wave)
+    float dal[MODE == 1 ? 7 : 1][16];
+    auto load_datt = [&](int k7) {
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const int row0 = k7 * 32 + 8 * (r16 >> 2) + (r16 & 3);
+            const int ky = h ? (row0 + 4) / HW : row0 / HW, kx = h ? (row0 + 4) % HW : row0 % HW;
+            const bool rel = (unsigned)(ky - qy) < (unsigned)WIN && (unsigned)(kx - qx) < (unsigned)WIN;
+            dal[k7][r16] = (rel && q_unk && dattd) ? dattd[((int64_t)b * W2 + (ky - qy) * WIN + (kx - qx)) * N + u] : 0.f;
+        }
+    };
+    if (MODE == 1) load_datt(0);                            // one key block ahead of its use (16 registers in flight)
 #pragma unroll
     for (int k7 = 0; k7 < 7; ++k7) {
+        if (MODE == 1) {
+            if (k7 + 1 < 7) load_datt(k7 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float w8[8];
@@ -556,12 +597,17 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
                     const bool rel = (unsigned)(ky - qy) < (unsigned)WIN && (unsigned)(kx - qx) < (unsigned)WIN;
                     float ds = 0.f;
                     if (rel && q_unk) {
-                        const int64_t o = ((int64_t)b * W2 + (ky - qy) * WIN + (kx - qx)) * N + u;
-                        const float da = dattd ? dattd[o] : 0.f;
-                        ds = (p * (accd[k7][r16] - dot) + da) * inv_sqrt_c;
-                        const int64_t o2 = (((int64_t)b * 2 + dir) * W2 + (ky - qy) * WIN + (kx - qx)) * N + u;
-                        att0[o2] = p;                      // p and ds / sqrt(C) for pass B: [b][dir][j][u]
-                        att1[o2] = ds;
+                        ds = (p * (accd[k7][r16] - dot) + dal[k7][r16]) * inv_sqrt_c;
+                        if (att1) {
+                            const int64_t o2 = (((int64_t)b * 2 + dir) * W2 + (ky - qy) * WIN + (kx - qx)) * N + u;
+                            att0[o2] = p;                  // p and ds / sqrt(C) for the vector pass B: [b][dir][j][u] fp32
+                            att1[o2] = ds;
+                        } else {
+                            // pass B on the matrix cores (tam_mfma_key_kernel): one 32-bit word (p, ds / sqrt(C)) in the 16-bit storage
+                            // type per (query, neighbour), QUERY-major [b][dir][u][49] -- a key tile gathers the 49-word rows of its
+                            // 14 x 14 query halo, a lane's gather stays inside one 196-byte row
+                            reinterpret_cast<unsigned*>(att0)[(((int64_t)b * 2 + dir) * N + u) * W2 + (ky - qy) * WIN + (kx - qx)] = pack2h(p, ds);
+                        }
                     }
                     p = ds;
                 }
@@ -596,6 +642,13 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
             for (int r = 0; r < 16; ++r) cm[(cb * 16 + r) * 64 + lane] = acc2[cb][r];
     }
     __syncthreads();
+    if (dir == 0 && !q_unk && self_init && q_in) {
+        // a known pixel inside an active tile: out = v / dq = 0 (lane half h takes channels 64 h .. 64 h + 63)
+        const int64_t o = (b * N + u) * C8 + 8 * h;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            reinterpret_cast<uint4*>(out)[o + c] = MODE == 0 ? reinterpret_cast<const uint4*>(v)[o + c] : make_uint4(0u, 0u, 0u, 0u);
+    }
     if (dir == 0 && q_unk) {
         const int64_t pix = b * N + u;
 #pragma unroll
@@ -611,6 +664,150 @@ __global__ __launch_bounds__(256) void tam_mfma_kernel(
                     o4[0] += hlo(vv.x); o4[1] += hhi(vv.x); o4[2] += hlo(vv.y); o4[3] += hhi(vv.y);
                 }
                 *reinterpret_cast<uint2*>(out + pix * 64 + (ch >> 1)) = make_uint2(pack2h(o4[0], o4[1]), pack2h(o4[2], o4[3]));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward pass B on the matrix cores
+// (window 7, C = 128, after tam_mfma_kernel<1> wrote (p, ds / sqrt(C)) query-major).  A workgroup owns an 8 x 8 tile of KEY pixels; the
+// queries that attend to them lie in the 14 x 14 halo around it.  Per direction
+//     dK^T [128 ch][64 keys] = dO_halo^T [128][224 queries] * P [224][64] + Q_halo^T [128][224] * dS [224][64]
+// (P[u][v] = p_j(u) with j the offset v - u when it lies in the window and u is an unknown pixel, 0 otherwise): the mirror image of the
+// forward's second product -- there the halo holds keys and P comes out of the accumulators, here the halo holds dO / Q and the B
+// fragments are gathered from pass A's rows.  Wave = (key block of 32, direction); A fragments through the transposing LDS read with
+// the same row order as the forward (rows 16 s + 4 h + r and 16 s + 8 + 4 h + r of k-step s for lane half h).  k-steps whose 16 halo
+// queries are all known are skipped (a band-shaped unknown region leaves most of them out); a tile without an unknown query in its
+// halo exits at once (the launcher zero-fills dk).  Replaces the one-wave-per-key-pixel gather kernel: 195 us all-unknown at 136 x 240.
+__global__ __launch_bounds__(256) void tam_mfma_key_kernel(
+    const uint4* __restrict__ q, const uint4* __restrict__ g, const unsigned char* __restrict__ mask, const unsigned* __restrict__ pd,
+    unsigned* __restrict__ dkb, unsigned* __restrict__ dkf, int H, int W)
+{
+    constexpr int R = 3, TW = 8, HW = 14, NQ = 196, NK = 224, C8 = 16, W2 = 49;
+    extern __shared__ __attribute__((aligned(16))) uint4 tam_lds[];
+    uint4* gh = tam_lds;                                    // dO halo [224][16], rows of known / outside queries are zero
+    uint4* qh = gh + NK * C8;                               // Q halo
+    __shared__ __attribute__((aligned(16))) unsigned char um[NK];
+    __shared__ int cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 8;
+    const int64_t N = (int64_t)H * W;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    if (tid < NK) {
+        const int hy = (tid * 4682) >> 16, hx = tid - hy * HW;          // tid / 14 for tid < 224
+        const int y = ty0 + hy - R, x = tx0 + hx - R;
+        const bool u = tid < NQ && y >= 0 && y < H && x >= 0 && x < W && mask[b * N + (int64_t)y * W + x] != 0;
+        um[tid] = u ? 1 : 0;
+        if (u) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (cnt == 0) {                                         // no query attends to this tile's keys: dk = 0
+        for (int idx = tid; idx < 2 * 64 * C8; idx += 256) {
+            const int d = idx >> 10, p = (idx >> 4) & 63, c = idx & 15;
+            const int y = ty0 + (p >> 3), x = tx0 + (p & 7);
+            if (y < H && x < W) reinterpret_cast<uint4*>(d == 0 ? dkb : dkf)[(b * N + (int64_t)y * W + x) * C8 + c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
+    const int kb = wave & 1, dir = wave >> 1;
+    const int n = lane & 31, h = lane >> 5;
+    const int kq = kb * 32 + n, ky = kq >> 3, kx = kq & 7;
+    const unsigned* pdd = pd + ((int64_t)b * 2 + dir) * N * W2;
+    const unsigned* um32 = reinterpret_cast<const unsigned*>(um);
+    // ---- the (p, ds) words of all 14 k-steps: element i of step s <-> halo query row 16 s + 8 (i >> 2) + 4 h + (i & 3).  Issued before
+    // the halos are staged: one exposed memory latency per tile instead of one per k-step
+    unsigned w[14][8];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const unsigned mlo = um32[s * 4 + h], mhi = um32[s * 4 + 2 + h];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = s * 16 + 8 * (i >> 2) + 4 * h + (i & 3);
+            const int uy = (row * 4682) >> 16, ux = row - uy * HW;
+            const int dy = ky + R - uy, dx = kx + R - ux;
+            const bool unk = (((i >> 2) ? mhi : mlo) >> (8 * (i & 3))) & 1u;
+            const bool ok = unk && (unsigned)(dy + R) < 7u && (unsigned)(dx + R) < 7u;
+            const int64_t u = (int64_t)(ty0 - R + uy) * W + (tx0 - R + ux);
+            w[s][i] = ok ? pdd[u * W2 + (dy + R) * 7 + (dx + R)] : 0u;
+        }
+    }
+    {
+        const int c = tid & 15;
+        uint4 vg[14], vq[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            const int hy = (r * 4682) >> 16, hx = r - hy * HW;
+            const bool ok = um[r] != 0;
+            const int64_t off = (b * N + (int64_t)(ty0 + hy - R) * W + (tx0 + hx - R)) * C8 + c;
+            vg[i] = ok ? g[off] : make_uint4(0u, 0u, 0u, 0u);
+            vq[i] = ok ? q[off] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            gh[r * C8 + tam_swz(c, r)] = vg[i];
+            qh[r * C8 + tam_swz(c, r)] = vq[i];
+        }
+    }
+    __syncthreads();
+    // which of the 14 k-steps hold an unknown query (wave-uniform)
+    unsigned long long ksm;
+    {
+        bool any = false;
+        if (lane < 14) {
+            const uint4 m4 = *reinterpret_cast<const uint4*>(um + lane * 16);
+            any = (m4.x | m4.y | m4.z | m4.w) != 0u;
+        }
+        ksm = __ballot(any);
+    }
+    f32x16_t acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    typedef __attribute__((address_space(3))) const void* tam_lp;
+    const unsigned gh_addr = (unsigned)(uintptr_t)(tam_lp)gh, qh_addr = (unsigned)(uintptr_t)(tam_lp)qh;
+    const int trow = (lane & 15) >> 2, cig = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        if (!((ksm >> s) & 1ull)) continue;
+        uint4 pp, dd;
+        pp.x = (w[s][0] & 0xffffu) | (w[s][1] << 16); pp.y = (w[s][2] & 0xffffu) | (w[s][3] << 16);
+        pp.z = (w[s][4] & 0xffffu) | (w[s][5] << 16); pp.w = (w[s][6] & 0xffffu) | (w[s][7] << 16);
+        dd.x = (w[s][0] >> 16) | (w[s][1] & 0xffff0000u); dd.y = (w[s][2] >> 16) | (w[s][3] & 0xffff0000u);
+        dd.z = (w[s][4] >> 16) | (w[s][5] & 0xffff0000u); dd.w = (w[s][6] >> 16) | (w[s][7] & 0xffff0000u);
+        const h16x8_t fp = __builtin_bit_cast(h16x8_t, pp), fd = __builtin_bit_cast(h16x8_t, dd);
+        // ---- A fragments: dO^T and Q^T, channels x queries, through the transposing reads
+        const int rlo = s * 16 + 4 * h + trow, rhi = rlo + 8;
+        TrFrag fg[4], fq[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const unsigned olo = rlo * 256 + ((((cb ^ (rlo & 3)) << 2) | (cig ^ ((rlo >> 2) & 3))) << 4) + (lane & 1) * 8;
+            const unsigned ohi = rhi * 256 + ((((cb ^ (rhi & 3)) << 2) | (cig ^ ((rhi >> 2) & 3))) << 4) + (lane & 1) * 8;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fg[cb].lo) : "v"(gh_addr + olo));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fg[cb].hi) : "v"(gh_addr + ohi));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fq[cb].lo) : "v"(qh_addr + olo));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fq[cb].hi) : "v"(qh_addr + ohi));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) { tr_fence(fg[cb]); tr_fence(fq[cb]); }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = mfma16(tr_value(fg[cb]), fp, acc[cb], 0, 0, 0);      // (four independent chains)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = mfma16(tr_value(fq[cb]), fd, acc[cb], 0, 0, 0);
+    }
+    const int y = ty0 + ky, x = tx0 + kx;
+    if (y < H && x < W) {
+        unsigned* dk = (dir == 0 ? dkb : dkf) + (b * N + (int64_t)y * W + x) * 64;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = cb * 32 + 8 * gq + 4 * h;
+                *reinterpret_cast<uint2*>(dk + (ch >> 1)) = make_uint2(pack2h(acc[cb][gq * 4 + 0], acc[cb][gq * 4 + 1]),
+                                                                       pack2h(acc[cb][gq * 4 + 2], acc[cb][gq * 4 + 3]));
             }
     }
 }
@@ -651,9 +848,14 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
     TCVOM_CHECK_ARG(n < (1ll << 31), "tam_fwd: too many pixels");
     const float isc = 1.0f / sqrtf((float)C);
     const size_t att_bytes = sizeof(float) * (size_t)n * window * window;
-    if (hipMemsetAsync(attb, 0, att_bytes, st) != hipSuccess || hipMemsetAsync(attf, 0, att_bytes, st) != hipSuccess ||
-        hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
-        hipMemcpyAsync(out, v, sizeof(h16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    static const int dense0 = getenv("TCVOM_TAM_DENSE") ? atoi(getenv("TCVOM_TAM_DENSE")) : 1;
+    static const bool no_self_init = getenv("TCVOM_TAM_MEMSET") != nullptr;          // A/B switch: the launcher's memsets / copy
+    // window 7, C = 128 with every active tile on the MFMA kernel: that kernel writes every pixel itself (known ones: out = v, zero logits)
+    const bool self_init = window == 7 && C == 128 && dense0 <= 1 && !no_self_init;
+    if (!self_init &&
+        (hipMemsetAsync(attb, 0, att_bytes, st) != hipSuccess || hipMemsetAsync(attf, 0, att_bytes, st) != hipSuccess ||
+         hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
+         hipMemcpyAsync(out, v, sizeof(h16raw) * (size_t)n * C, hipMemcpyDeviceToDevice, st) != hipSuccess))
         return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_fwd: memset / copy failed");
     // window 7, C = 128: tiles with at least TCVOM_TAM_DENSE unknown pixels go to the MFMA tile kernel (its cost does not depend on the
     // count), sparser ones to the one-wave-per-pixel tile kernel (cost ~ count / 16 waves); each launch skips the other's tiles.
@@ -672,7 +874,7 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
         }
         hipLaunchKernelGGL(kern, dim3(cdiv(W, 8), cdiv(H, 8), B), dim3(256), lds, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
                            (const unsigned*)v, (const uint4*)nullptr, mask, (unsigned*)out, attb, attf, (const float*)nullptr,
-                           (const float*)nullptr, H, W, isc, dense < 1 ? 1 : dense);
+                           (const float*)nullptr, H, W, isc, dense < 1 ? 1 : dense, self_init ? 1 : 0);
         tile_hi = dense;
         if (dense <= 1) { TCVOM_LAUNCH_CHECK("tam_fwd"); return TCVOM_OK; }
     }
@@ -705,8 +907,11 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
     const dim3 grid(tam_heavy_grid(n));
     const dim3 grid2(cdiv(n, 4), 2);
     const float isc = 1.0f / sqrtf((float)C);
-    if (hipMemsetAsync(dq, 0, sizeof(h16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
     static const int dense = getenv("TCVOM_TAM_DENSE") ? atoi(getenv("TCVOM_TAM_DENSE")) : 1;      // (pass A: 90 -> 96 us on the band window, 118 -> 90 us all-unknown)
+    static const bool no_self_init = getenv("TCVOM_TAM_MEMSET") != nullptr;
+    static const bool key_valu0 = getenv("TCVOM_TAM_KEY_VALU") != nullptr;
+    const bool self_init = window == 7 && C == 128 && dense <= 1 && !no_self_init;   // (the MFMA kernels write every pixel themselves)
+    if (!self_init && hipMemsetAsync(dq, 0, sizeof(h16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
     int tile_hi = 1 << 30;
     if (window == 7 && C == 128 && dense <= 64) {
         auto kern = tam_mfma_kernel<1>;
@@ -717,10 +922,29 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
             if (ea != hipSuccess) { (void)hipGetLastError(); return tcvom_fail(TCVOM_ERR_LAUNCH, "tam: hipFuncSetAttribute(%d bytes of LDS): %s", (int)lds, hipGetErrorString(ea)); }
             attr = true;
         }
+        // every active tile on the MFMA kernel (dense <= 1): pass B runs on the matrix cores too, fed by query-major (p, ds) words
+        static const bool key_valu = getenv("TCVOM_TAM_KEY_VALU") != nullptr;           // A/B switch: the one-wave-per-key gather kernel
+        const bool key_mfma = dense <= 1 && !key_valu;
         hipLaunchKernelGGL(kern, dim3(cdiv(W, 8), cdiv(H, 8), B), dim3(256), lds, st, (const uint4*)q, (const uint4*)kb, (const uint4*)kf,
-                           (const unsigned*)nullptr, (const uint4*)dout, mask, (unsigned*)dq, pbuf, dsbuf, dattb, dattf, H, W, isc,
-                           dense < 1 ? 1 : dense);
+                           (const unsigned*)nullptr, (const uint4*)dout, mask, (unsigned*)dq, pbuf, key_mfma ? (float*)nullptr : dsbuf,
+                           dattb, dattf, H, W, isc, dense < 1 ? 1 : dense, self_init ? 1 : 0);
         tile_hi = dense;
+        (void)key_valu0;
+        if (key_mfma) {
+            auto kkern = tam_mfma_key_kernel;
+            constexpr size_t klds = (size_t)(2 * 224 * 16) * 16;
+            static bool kattr = false;
+            if (!kattr) {
+                const hipError_t ea = hipFuncSetAttribute((const void*)kkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds);
+                if (ea != hipSuccess) { (void)hipGetLastError(); return tcvom_fail(TCVOM_ERR_LAUNCH, "tam: hipFuncSetAttribute(%d bytes of LDS): %s", (int)klds, hipGetErrorString(ea)); }
+                kattr = true;
+            }
+            // (no memset of dk: a key tile without an unknown query in its halo writes its own zeros)
+            hipLaunchKernelGGL(kkern, dim3(cdiv(W, 8), cdiv(H, 8), B), dim3(256), klds, st, (const uint4*)q, (const uint4*)dout, mask,
+                               (const unsigned*)pbuf, (unsigned*)dkb, (unsigned*)dkf, H, W);
+            TCVOM_LAUNCH_CHECK("tam_bwd");
+            return TCVOM_OK;
+        }
     }
     if (window == 7 && C % 8 == 0 && tile_hi <= 1) {
         // (every tile went to the MFMA kernel)
