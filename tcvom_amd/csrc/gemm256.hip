@@ -48,6 +48,12 @@ struct Gemm256Args {
     long long b2_bstride;
     // EPI 3 (tcvom_gca_scores_softmax): out = bf16( exp(S - tile row max) ), stats[b][n][tile_m][2] = (tile row max, sum of exps)
     float* stats;
+    // EPI 1 (16-bit output, 256-row tiles): per-channel (sum, sum of squares) of the tile's outputs for the BatchNorm / GroupNorm that
+    // follows a 1 x 1 conv -- the layout igemm_nt<256,256> writes: cstats[group][2][M], group = cstats_goff + z * cstats_bstride +
+    // 4 * (pixel tile) + wave column, one group per wave column (64 pixels), reduced by bn_finalize / gn_finalize
+    float* cstats;
+    int cstats_goff;
+    long long cstats_bstride;
     // K-split tail (fp32 output, linear epilogue only): flat_nx > 0 -> 1-D grid of split_r * split_s + (tiles - split_r) workgroups
     // over the nx x ny x nz tiles in x-fastest order; the LAST split_r tiles are each computed by split_s workgroups (launched
     // first), one per 1/split_s of the reduction, and added into the zeroed output with fp32 atomics.  576 tiles (the paired
@@ -62,6 +68,21 @@ struct Gemm256Args {
     // and dO of dV = P^T dO as they lie in memory, no transposed copies V^T / dO^T
     int lda, krows_a;
 };
+
+// 8 sums over the 32 pixel lanes of each half wave with DPP adds (igemm.hip: nt_reduce8): lanes 16..31 / 48..63 hold the totals
+#define G256_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
+__device__ __forceinline__ void g256_reduce8(float (&t)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0xB1, 0xF);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x4E, 0xF);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x141, 0xF);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x140, 0xF);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x142, 0xA);
+}
 
 #ifndef G256_STAGED_EPI
 #define G256_STAGED_EPI 1     // 1: the plain epilogue of the 256-row tiles goes through per-wave LDS regions (whole-row stores)
@@ -578,6 +599,39 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                     }
             }
         }
+        if constexpr (EPI == 1) {
+            if (g.cstats) {
+                // ---- normalisation statistics of this conv's outputs (the launcher allows it without a scale / diagonal term only), summed over the wave's 64 pixels in fp32 before the 16-bit rounding, as igemm_nt does
+                float* sp0 = g.cstats + ((int64_t)g.cstats_goff + bz * g.cstats_bstride + (int64_t)bx * 4 + wn) * 2 * g.M;
+#pragma unroll
+                for (int a = 0; a < MF; ++a) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mrow = m0 + wm * HM + a * 32 + 8 * q + 4 * h;
+                        float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (bias && mrow < g.M) bs4 = *reinterpret_cast<const float4*>(bias + mrow);
+                        const float bsv[4] = {bs4.x, bs4.y, bs4.z, bs4.w};
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float x = acc[a][b][q * 4 + r] + bsv[r];
+                                x = fmaxf(x, x * slope);
+                                const float xs = pvalid[b] ? x : 0.f;
+                                t8[r] += xs;
+                                t8[4 + r] = fmaf(xs, xs, t8[4 + r]);
+                            }
+                        }
+                        g256_reduce8(t8);
+                        if ((lane & 31) == 16 && mrow < g.M) {
+                            *reinterpret_cast<float4*>(sp0 + mrow) = make_float4(t8[0], t8[1], t8[2], t8[3]);
+                            *reinterpret_cast<float4*>(sp0 + g.M + mrow) = make_float4(t8[4], t8[5], t8[6], t8[7]);
+                        }
+                    }
+                }
+            }
+        }
         auto emit = [&](auto diag_) {
         constexpr bool DIAG = decltype(diag_)::value;
 #pragma unroll
@@ -767,12 +821,26 @@ int gemm_nt256_takes(const tcvom_conv_desc* d) {
     return 1;
 }
 
+// ... and writes the normalisation statistics of its outputs itself?  (16-bit output on the 256-row tiles: the 1 x 1 convs in front of
+// a GroupNorm / BatchNorm -- the bottleneck reduce / expand layers of the FBA trunk, models/FBA/resnet_GN_WS.py:50-137 -- ran on
+// igemm_nt<256,256> for their statistics epilogue alone: 370 .. 500 TFLOP/s there against 590 .. 790 here)
+int gemm_nt256_takes_stats(const tcvom_conv_desc* d) {
+    static const bool off = getenv("TCVOM_NO_G256_STATS") != nullptr;              // A/B switch
+    if (off || !gemm_nt256_takes(d) || d->out_fp32 || d->K % 4 != 0) return 0;
+    return (long long)cdiv(d->K, 192) * 192 < (long long)cdiv(d->K, 256) * 256 ? 0 : 1;          // (not the 192-row tiles)
+}
+int gemm_nt256_stats_groups(const tcvom_conv_desc* d) {
+    return cdiv((long long)d->N * d->PH * d->PW, 256) * 4;
+}
+
 // 1: launched; 0: not a shape for this kernel.  Called from conv_igemm_launch for dense descriptors (ntaps == 1).
 // in2 / out2 non-null: paired launch, the second product in2 x w -> out2 rides in grid z (same descriptor).
+// cstats non-null: per-channel statistics of the outputs (the caller checked gemm_nt256_takes_stats and passes no bias / scale / diagonal).
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                           const tcvom_conv_desc* d, const h16raw* zero_page, void* stream, const void* in2, void* out2,
-                          long long in2_bstride) {
+                          long long in2_bstride, float* cstats) {
     if (!gemm_nt256_takes(d)) return 0;
+    if (cstats && (!gemm_nt256_takes_stats(d) || mscale || mdiag || in2)) return 0;
     const long long P = (long long)d->N * d->PH * d->PW;
     const int nb = d->batch > 1 ? d->batch : 1;
     Gemm256Args g;
@@ -799,6 +867,7 @@ int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float*
     g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = (const h16raw*)in2; g.out2 = out2; g.b2_bstride = nb > 1 ? in2_bstride : 0;
     g.stats = nullptr;
+    g.cstats = cstats; g.cstats_goff = d->stats_group_offset; g.cstats_bstride = d->stats_bstride;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     g.ldb = 0; g.krows = 0; g.lda = 0; g.krows_a = 0;
     // 192-row A tiles where they leave less padding than 256-row ones (M = 576: 3 x 192)
@@ -862,6 +931,7 @@ int gemm_tt256_try_launch(const void* dy, const void* x, float* dw, const tcvom_
     g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
+    g.cstats = nullptr; g.cstats_goff = 0; g.cstats_bstride = 0;
     g.ldb = ldy; g.krows = (int)P;
     g.lda = d->C; g.krows_a = (int)P;
     const int nx = cdiv(d->K, 256), ny = cdiv(d->C, 256), tiles = nx * ny * nb, ntile = g.K / 64;
@@ -913,6 +983,7 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
     g.Tt = (h16raw*)Tt; g.Pt = (h16raw*)Pt; g.ldt = (int)ld;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
+    g.cstats = nullptr; g.cstats_goff = 0; g.cstats_bstride = 0;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     g.ldb = 0; g.krows = 0; g.lda = 0; g.krows_a = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ld + 255) / 256), (unsigned)batch);
@@ -983,6 +1054,7 @@ extern "C" int tcvom_gca_scores_exp(const void* G, const float* cvec, const floa
     g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = stats;
+    g.cstats = nullptr; g.cstats_goff = 0; g.cstats_bstride = 0;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     g.ldb = 0; g.krows = 0; g.lda = 0; g.krows_a = 0;
     const dim3 grid((unsigned)((N + 255) / 256), (unsigned)(ld / 256), (unsigned)batch);
@@ -1024,6 +1096,7 @@ static void g256_gca_common(Gemm256Args& g, const void* Amat, int32_t N, int32_t
     g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
+    g.cstats = nullptr; g.cstats_goff = 0; g.cstats_bstride = 0;
     g.flat_nx = g.flat_ny = g.split_r = g.split_s = 0;
     g.ldb = 0; g.krows = 0;
     g.lda = DV; g.krows_a = N;
@@ -1077,6 +1150,7 @@ extern "C" int tcvom_gca_dq_dk(const void* T, const void* Gt, float* dWq, float*
     g.P = nullptr; g.delta = nullptr; g.Tt = nullptr; g.Pt = nullptr; g.ldt = 0;
     g.B2 = nullptr; g.out2 = nullptr; g.b2_bstride = 0;
     g.stats = nullptr;
+    g.cstats = nullptr; g.cstats_goff = 0; g.cstats_bstride = 0;
     g.lda = 0; g.krows_a = 0;
     g.B = (const h16raw*)T;
     // Two launches, each with its own K-split tail (3 frames at 1080p: 288 tiles = one round of 256 + 32 tiles x 8 eighth-length

@@ -448,8 +448,10 @@ int gemm_tt256_takes(const tcvom_conv_desc* d);
 // gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                           const tcvom_conv_desc* d, const h16raw* zero_page, void* stream, const void* in2, void* out2,
-                          long long in2_bstride);
+                          long long in2_bstride, float* cstats);
 int gemm_nt256_takes(const tcvom_conv_desc* d);
+int gemm_nt256_takes_stats(const tcvom_conv_desc* d);
+int gemm_nt256_stats_groups(const tcvom_conv_desc* d);
 // halo.hip: weight gradient of the 32 -> 32 channel full-resolution layers from LDS-resident x halo / dy tiles
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
                           int nphase, int ldy, const h16raw* zero_page, void* stream);
@@ -465,6 +467,9 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
     if (sg > 0) return sg;
     const int wg = wsconv_stats_groups(d, nphase);
     if (wg > 0) return wg;
+    // (a 1 x 1 conv on the dense 256-tile GEMM writes its statistics itself; a caller that also passes a bias gets the implicit GEMM,
+    //  whose 256 x 256 tiling has the same group count)
+    if (nphase == 1 && d->w_layout == 0 && gemm_nt256_takes_stats(d)) return gemm_nt256_stats_groups(d);
     const NtCfg c = nt_config(d, nphase);
     const long long P = (long long)d->N * d->PH * d->PW;
     return cdiv(P, c.tn) * c.waves_n;
@@ -534,8 +539,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     TCVOM_CHECK_ARG(d0->w_layout == 0, "conv_igemm: fragment-major weights (w_layout = 1) are only served by the weight-stationary kernel");
-    if (nphase == 1 && !stats_partial) {
-        const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream, nullptr, nullptr, 0);
+    TCVOM_CHECK_ARG(!(stats_partial && (mscale || mdiag) && nphase == 1 && gemm_nt256_takes_stats(d0)),
+                    "conv_igemm: statistics together with a column scale / diagonal term are not built for this shape");
+    if (nphase == 1 && (!stats_partial || gemm_nt256_takes_stats(d0))) {
+        const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream, nullptr, nullptr, 0, stats_partial);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
@@ -575,7 +582,7 @@ extern "C" int tcvom_gemm_pair(const void* in1, const void* in2, const void* w, 
         const h16raw* zp = zero_page_for_current_device();
         TCVOM_CHECK_ARG(zp != nullptr, "gemm_pair: could not allocate the zero page");
         TCVOM_CHECK_ARG(desc->w_layout == 0, "gemm_pair: plain weight layout only");
-        const int r = gemm_nt256_try_launch(in1, w, out1, nullptr, nullptr, nullptr, desc, zp, stream, in2, out2, in2_bstride);
+        const int r = gemm_nt256_try_launch(in1, w, out1, nullptr, nullptr, nullptr, desc, zp, stream, in2, out2, in2_bstride, nullptr);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     const int r1 = conv_igemm_launch(in1, w, out1, nullptr, nullptr, nullptr, nullptr, desc, 1, stream);

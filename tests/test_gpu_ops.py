@@ -238,6 +238,8 @@ def test_conv_bn_act_train(act, pre_relu, res):
     (32, 32, 3, 1, False, 272, 480),       # the os2/os1 class: 32x256 tiles
     (256, 256, 3, 1, False, 68, 120),      # the os16 class: 64x64 tiles, 4-slot ring
     (256, 256, 3, 1, False, 136, 180),     # 24480 pixels (= 3 os16 frames): 128x96 tiles, 510 workgroups instead of 384 of 128x128
+    (512, 1024, 1, 1, False, 96, 130),     # 1 x 1 expand conv of the FBA trunk class: gemm_nt256 WITH the statistics epilogue (196 tiles, ragged tail)
+    (64, 256, 1, 1, False, 200, 260),      # the os4 expand conv: one K-tile
 ])
 def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     """Tile configurations are chosen from the problem size, so the production (1080p) configurations need their
@@ -245,7 +247,8 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     from tcvom_amd import ops
     from tcvom_amd.weights import bank_token
     tag = 'big%d_%d_%d_%d' % (cin, cout, k, H)
-    bank, spec = _mini_bank(cin, cout, k, stride, 1, transposed, spectral=False, tag=tag)
+    pad = 0 if k == 1 else 1
+    bank, spec = _mini_bank(cin, cout, k, stride, pad, transposed, spectral=False, tag=tag)
     bn = nn.BatchNorm2d(cout).to(DEV)
     cfg = ops.ConvCfg(bank, spec, bn=bn, act=1)
     x = hu('x.' + tag, (1, cin, H, W))
@@ -254,7 +257,7 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     z = ops.conv_bn_act(cfg, xg, token, True)
     bank.flush_bn_counters()
     wr = bf(spec.weight.detach().cpu())
-    yr = F.conv_transpose2d(bf(x), wr, None, stride, 1) if transposed else F.conv2d(bf(x), wr, None, stride, 1)
+    yr = F.conv_transpose2d(bf(x), wr, None, stride, pad) if transposed else F.conv2d(bf(x), wr, None, stride, pad)
     mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
     zr = F.relu((bf(yr) - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5))
     ck = Checker()
@@ -272,7 +275,10 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
                                                                   (128, 128, 3, 1, False, 20, 36, False), (64, 64, 3, 1, False, 36, 40, False),
                                                                   # csrc/sconv.hip: four phases x three frames with statistics; two channel blocks
                                                                   (64, 64, 4, 2, True, 16, 40, False), (32, 32, 4, 2, True, 24, 64, False),
-                                                                  (32, 64, 3, 1, False, 16, 48, False), (64, 32, 3, 1, False, 24, 33, False)])
+                                                                  (32, 64, 3, 1, False, 16, 48, False), (64, 32, 3, 1, False, 24, 33, False),
+                                                                  # the 3-frame launch runs on gemm_nt256 with statistics (396 tiles), the
+                                                                  # frame-by-frame ones (132 tiles each) on igemm_nt: same groups, same sums
+                                                                  (512, 1024, 1, 1, False, 48, 86, False)])
 def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, transposed, H, W, hp):
     """Three frames through a SpectralNorm'd conv + BatchNorm + ReLU as ONE frame-batched op (bank.frames_per_op = 3: per-frame
     weight slot, per-frame batch statistics, batched data gradient, deferred batched weight gradient) must equal three
