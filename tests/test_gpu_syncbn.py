@@ -231,9 +231,16 @@ def _stock_worker(rank, world, port, out, transport):
         from tcvom_amd.facade import FullModel_VMD, train_step_loss
         from tcvom_amd.synthetic import formula_tensor, synthetic_window
 
+        damp = os.environ.get('TCVOM_TEST_DAMP') == '1'
+
         def fresh():
             m = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
-            m.NET.load_state_dict({k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()})
+            sd = {k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()}
+            if damp:                                    # residual gains x 0.15: a well-conditioned backward map (test_gpu_window.py:
+                for k in sd:                            # test_gradient_noise_on_a_conditioned_network) -> tight bounds below
+                    if k.endswith('bn2.weight'):
+                        sd[k] = sd[k] * 0.15
+            m.NET.load_state_dict(sd)
             return m
         a, fg, bg = [t.to(dev) for t in synthetic_window(1, 3, 128, 160, seed=20 + rank)]
 
@@ -300,6 +307,22 @@ def test_reference_ddp_lines_equal_tcvom_ddp_path(tmp_path, transport):
         assert r['cos_ab'] >= min(0.97, 1 - 3 * (1 - r['cos_bc'])) - 1e-4, r               # whole-network gradient direction
         assert abs(r['norm_ab'] - 1) <= max(3 * abs(r['norm_bc'] - 1), 1.5e-2), r
         assert r['serr_ab'] <= max(3 * r['serr_bc'], 1e-5), r                              # BatchNorm running statistics
+        assert r['ranks_agree'] == 0.0, r
+
+
+def test_reference_ddp_lines_equal_tcvom_ddp_path_tight_on_a_conditioned_network(tmp_path, monkeypatch):
+    """The same comparison on a network whose backward map does not amplify last-bit noise (BasicBlock bn2 gains x 0.15): there the
+    bounds can be absolute and tight -- a 3 % direction error or a 2x error in one tensor's gradient fails."""
+    monkeypatch.setenv('TCVOM_TEST_DAMP', '1')
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_stock_worker, args=(2, _free_port(), out, 'mailbox'), nprocs=2, join=True)
+    from helpers import tol
+    for rank in range(2):
+        r = torch.load(out + str(rank))
+        print('damped', rank, r)
+        assert r['mse_ab'] <= 1e-5, r
+        assert r['cos_ab'] >= tol(0.995, 0.999) and r['cos_bc'] >= tol(0.995, 0.999), r         # measured 0.9985 (bf16) / 0.9998 (fp16)
+        assert abs(r['norm_ab'] - 1) <= tol(2e-2, 5e-3), r
         assert r['ranks_agree'] == 0.0, r
 
 
