@@ -185,6 +185,13 @@ int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
                    int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                    void* stream);
+/* ... and `mask`: one byte per 8-channel vector ([nframes * pixels * C / 8]), bit k = the pre-activation value
+ * norm(y) + res1 of channel k is positive.  The backward of a residual site (z = act(norm(y) + res1): the `out += identity` of
+ * models/GCA/encoders/resnet_enc.py:33-49 and models/FBA/resnet_GN_WS.py:112-137) takes the activation's slope from these bits
+ * (tcvom_bn_bwd_reduce_mask / tcvom_bn_bwd_apply_mask) instead of re-reading res1 in both passes.  act: ReLU / LeakyReLU / none. */
+int tcvom_bn_apply_mask(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z, uint8_t* mask,
+                        int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
+                        void* stream);
 int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);                       /* = tcvom_bn_bwd_groups_n(pixels, C, 1) */
 /* partial-sum groups per frame of a backward reduction over `nframes` frames (what tcvom_bn_bwd_reduce launches and writes) */
 int tcvom_bn_bwd_groups_n(int64_t pixels, int32_t C, int32_t nframes);
@@ -199,6 +206,9 @@ int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const vo
 int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32,
                                int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
+int tcvom_bn_bwd_reduce_mask(const void* dz, const void* dz2, const void* y, const uint8_t* mask, const float* scale_shift,
+                             const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32,
+                             int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
 /* Optional by-product of the BatchNorm backward of a SpectralNorm'd conv (models/GCA/ops.py:25-45: weight = weight_bar / sigma,
  * differentiated by autograd): SpectralNorm's backward needs <dW~, weight_bar> = sigma <dW~, W~>, and <dW~, W~> = d(loss)/d(alpha) of
  * y = conv(x, alpha W~) = <dy, y> -- which the two BatchNorm-backward sums determine per channel (training statistics:
@@ -289,6 +299,10 @@ int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const void* y, co
                               const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                               int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                               int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
+int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const void* y, const uint8_t* mask, const float* scale_shift,
+                            const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                            int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                            int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
 
 /* ------------------------------------------------------------------ batched SpectralNorm + weight packing
  * Replaces SpectralNorm._update_u_v/_noupdate_u_v (models/GCA/ops.py:25-45,74-80) for every wrapped

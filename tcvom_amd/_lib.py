@@ -100,6 +100,9 @@ _PROTOS = {
     'tcvom_bn_ema_update': [vp, vp, vp, i32, f32, f32, i64, vp],
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_apply_mask': [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_bwd_reduce_mask': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i32, i32, vp],
+    'tcvom_bn_bwd_apply_mask': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
     'tcvom_bn_bwd_groups_n': [i64, i32, i32],
     'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],

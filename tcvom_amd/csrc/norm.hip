@@ -275,8 +275,12 @@ template <bool YF32>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const void* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
-    int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int* __restrict__ overflow)
+    int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int* __restrict__ overflow,
+    unsigned char* __restrict__ mask_out = nullptr)
 {
+    // mask_out (or NULL): one byte per 8-channel vector, bit k = the pre-activation value of channel k is positive.  The backward of a
+    // site with a residual input (z = act(norm(y) + res1)) then takes the activation's slope from that bit instead of re-reading res1
+    // in both of its passes: 1/16 of the residual tensor's bytes, twice (the bottleneck outputs of the FBA trunk are 400 MB each).
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
     unsigned sat = 0u;
@@ -306,13 +310,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         if constexpr (!YF32) sat |= sat8(yr.a);
         unpack8(q1, r1);
         unpack8(q2, r2);
+        unsigned bits = 0u;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float x = f[k] * sc[k] + sh[k] + r1[k];
+            bits |= x > 0.f ? (1u << k) : 0u;
             x = fminf(x > 0.f ? x : slope * x, cap);
             f[k] = x + r2[k];
         }
         z[v] = pack8(f);
+        if (mask_out) mask_out[v] = (unsigned char)bits;
         if (!more) break;
         p = pn; v = vn; yr = yn; q1 = n1; q2 = n2;
     }
@@ -326,8 +333,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
     float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1,
-    int* __restrict__ overflow)
+    int* __restrict__ overflow, const unsigned char* __restrict__ mask = nullptr)
 {
+    // mask (or NULL): the activation bits bn_apply_kernel wrote (then res1 is NULL: the pre-activation sign comes from the bit)
     extern __shared__ float red[];        // [2][256][8]
     unsigned sat = 0u;
     const int tid = threadIdx.x;
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
         YRaw<YF32> yr = load_yraw<YF32>(y, v);
         uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
+        unsigned mb = mask ? mask[v] : 0u;
         while (true) {
             const int64_t pn = p + RP;
             const bool more = pn < pend;
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
             const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
             const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
+            const unsigned nb = mask ? mask[vn] : 0u;
             float g[8], g2[8], yy[8], r1[8];
             unpack8(qg, g);
             unpack8(qh, g2);
@@ -374,12 +384,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-                const float gg = (g[k] + g2[k]) * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
+                const float fac = mask ? (((mb >> k) & 1u) ? 1.f : slope) : (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
+                const float gg = (g[k] + g2[k]) * fac;
                 sg[k] += gg;
                 sx[k] += gg * (yy[k] - mu[k]) * is[k];
             }
             if (!more) break;
-            p = pn; qg = ng; qh = nh; yr = yn; q1 = n1;
+            p = pn; qg = ng; qh = nh; yr = yn; q1 = n1; mb = nb;
         }
     }
     if (overflow && __any(sat != 0u) && (tid & 63) == 0) atomicAdd(overflow, 1);      // (never taken in a healthy step)
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
-    int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1)
+    int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1, const unsigned char* __restrict__ mask = nullptr)
 {
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
@@ -516,6 +527,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
     YRaw<YF32> yr = load_yraw<YF32>(y, v);
     uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
+    unsigned mb = mask ? mask[v] : 0u;
     while (true) {
         const int64_t pn = p + RP;
         const bool more = pn < pend;
@@ -523,6 +535,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
         const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
         const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
+        const unsigned nb = mask ? mask[vn] : 0u;
         float g[8], g2[8], yy[8], r1[8], o[8];
         unpack8(qg, g);
         unpack8(qh, g2);
@@ -531,7 +544,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-            const float gg = (g[k] + g2[k]) * (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
+            const float fac = mask ? (((mb >> k) & 1u) ? 1.f : slope) : (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
+            const float gg = (g[k] + g2[k]) * fac;
             g[k] = gg;
             const float xh = (yy[k] - mu[k]) * is[k];
             o[k] = gi[k] * gg - c1[k] - xh * c2[k];
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         dy[v] = pack8(o);
         if (dres1) dres1[v] = pack8(g);
         if (!more) break;
-        p = pn; v = vn; qg = ng; qh = nh; yr = yn; q1 = n1;
+        p = pn; v = vn; qg = ng; qh = nh; yr = yn; q1 = n1; mb = nb;
     }
 }
 
@@ -706,9 +720,8 @@ extern "C" int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* 
     return TCVOM_OK;
 }
 
-extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
-                              int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
-                              void* stream) {
+static int bn_apply_impl(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z, uint8_t* mask,
+                         int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
     TCVOM_CHECK_ARG(y && scale_shift && z && pixels > 0 && C > 0 && C % 8 == 0 && nframes >= 1, "bn_apply: bad args (C=%d)", C);
     TCVOM_CHECK_ARG(C <= 2048, "bn_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
@@ -716,13 +729,26 @@ extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const voi
     if (y_fp32)
         hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
                            y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
-                           g_overflow_sink.load(std::memory_order_relaxed));
+                           g_overflow_sink.load(std::memory_order_relaxed), mask);
     else
         hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                            y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
-                           g_overflow_sink.load(std::memory_order_relaxed));
+                           g_overflow_sink.load(std::memory_order_relaxed), mask);
     TCVOM_LAUNCH_CHECK("bn_apply");
     return TCVOM_OK;
+}
+extern "C" int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
+                              int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
+                              void* stream) {
+    return bn_apply_impl(y, scale_shift, res1, res2, z, nullptr, pixels, C, act, y_fp32, nframes, slot_stride, stream);
+}
+// ... and one byte per 8-channel vector with the signs of the pre-activation values (bit k = channel k positive), for
+// tcvom_bn_bwd_reduce_mask / tcvom_bn_bwd_apply_mask: the backward of a residual site without re-reading res1
+extern "C" int tcvom_bn_apply_mask(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z, uint8_t* mask,
+                                   int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
+                                   void* stream) {
+    TCVOM_CHECK_ARG(mask && act != 4, "bn_apply_mask: null mask / a capped activation (one bit cannot hold ReLU6's two thresholds)");
+    return bn_apply_impl(y, scale_shift, res1, res2, z, mask, pixels, C, act, y_fp32, nframes, slot_stride, stream);
 }
 
 // Partial-sum groups (= blocks per frame) of the backward reduction.  A batched call of >= 3 frames stays at <= 4 * BN_SLICES groups
@@ -740,10 +766,10 @@ extern "C" int tcvom_bn_bwd_groups_n(int64_t pixels, int32_t C, int32_t nframes)
 }
 extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) { return tcvom_bn_bwd_groups_n(pixels, C, 1); }
 
-extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
-                                          const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
-                                          int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
-                                          void* stream) {
+static int bn_bwd_reduce_impl(const void* dz, const void* dz2, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
+                              const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
+                              int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
+                              void* stream) {
     TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_reduce: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && nframes >= 1,
                     "bn_bwd_reduce: bad args (C=%d)", C);
@@ -753,13 +779,29 @@ extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed));
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed));
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask);
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
+}
+extern "C" int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                                          const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
+                                          int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
+                                          void* stream) {
+    return bn_bwd_reduce_impl(dz, dz2, y, res1, nullptr, scale_shift, saved, partial, pixels, C, act, y_fp32, nframes, slot_stride, dz2_f0,
+                              dz2_f1, stream);
+}
+// the residual site's activation signs from tcvom_bn_apply_mask's bytes instead of from (y, res1)
+extern "C" int tcvom_bn_bwd_reduce_mask(const void* dz, const void* dz2, const void* y, const uint8_t* mask, const float* scale_shift,
+                                        const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
+                                        int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
+                                        void* stream) {
+    TCVOM_CHECK_ARG(mask && act != 4, "bn_bwd_reduce_mask: null mask / capped activation");
+    return bn_bwd_reduce_impl(dz, dz2, y, nullptr, mask, scale_shift, saved, partial, pixels, C, act, y_fp32, nframes, slot_stride, dz2_f0,
+                              dz2_f1, stream);
 }
 extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                    const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
@@ -1033,10 +1075,10 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
     return TCVOM_OK;
 }
 
-extern "C" int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
-                                         const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
-                                         int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
-                                         int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
+static int bn_bwd_apply_impl(const void* dz, const void* dz2, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
+                             const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                             int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                             int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
     TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_apply: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0 && nframes >= 1, "bn_bwd_apply: bad args");
     TCVOM_CHECK_ARG(C <= 2048, "bn_bwd_apply: C=%d (multiples of 8 up to 2048)", C);
@@ -1045,13 +1087,28 @@ extern "C" int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const 
     if (y_fp32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask);
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
+}
+extern "C" int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
+                                         const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                                         int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                                         int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
+    return bn_bwd_apply_impl(dz, dz2, y, res1, nullptr, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
+                             nframes, slot_stride, dz2_f0, dz2_f1, stream);
+}
+extern "C" int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const void* y, const uint8_t* mask, const float* scale_shift,
+                                       const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
+                                       int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
+                                       int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
+    TCVOM_CHECK_ARG(mask && act != 4, "bn_bwd_apply_mask: null mask / capped activation");
+    return bn_bwd_apply_impl(dz, dz2, y, nullptr, mask, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
+                             nframes, slot_stride, dz2_f0, dz2_f1, stream);
 }
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,

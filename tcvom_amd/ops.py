@@ -130,6 +130,7 @@ class LossScaler(object):
 
 
 SCALER = LossScaler(LOSS_SCALE)
+RES_MASK = _os.environ.get('TCVOM_NO_RES_MASK') is None          # A/B switch: activation bitmask of the residual sites (tcvom_bn_apply_mask)
 SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
 
@@ -400,6 +401,7 @@ class _ConvBNAct(torch.autograd.Function):
         tf = getattr(bank, 'tail_frames', None)
         ctx.active = tf if (cfg.tail_only and tf is not None and nf > 1 and 0 <= tf[0] < tf[1] <= nf and tf[1] - tf[0] < nf) else None
         ctx.has_res1, ctx.has_res2, ctx.has_bias = res1 is not None, res2 is not None, bias is not None
+        ctx.res_mask = False
         if not has_bn:
             assert res1 is None and res2 is None and cfg.act == ACT_NONE
             if cfg.pre_relu:                 # conv + bias + ReLU without BatchNorm (DIM decoder): the mask needs y
@@ -457,6 +459,15 @@ class _ConvBNAct(torch.autograd.Function):
             f0, f1 = ctx.active
             L.call('tcvom_bn_apply', L.ptr(y[f0 * N:f1 * N]), C.c_void_p(ss.value + 4 * f0 * slot_stride), None, None,
                    L.ptr(z[f0 * N:f1 * N]), geo.out_pixels, K, cfg.act, 1 if hp else 0, f1 - f0, slot_stride, st)
+        elif r1 is not None and RES_MASK and cfg.act != ACT_RELU6 and any(ctx.needs_input_grad[:6]):
+            # residual site: one byte per 8 channels with the signs of norm(y) + res1 -- the backward takes the activation slope from it
+            # instead of reading res1 again in both of its passes (saved in place of res1)
+            amask = torch.empty(NT * geo.out_pixels * (K // 8), dtype=torch.uint8, device=x.device)
+            L.call('tcvom_bn_apply_mask', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), L.ptr(amask), geo.out_pixels, K, cfg.act,
+                   1 if hp else 0, nf, slot_stride, st)
+            ctx.res_mask = True
+            ctx.save_for_backward(x, y, gamma, amask)
+            return z
         else:
             L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0,
                    nf, slot_stride, st)
@@ -530,8 +541,8 @@ class _ConvBNAct(torch.autograd.Function):
             if dz2_rng is not None:
                 assert dz2 is None
                 dz2, zf0, zf1 = dz2_rng
-            L.call('tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(partial), P, K, cfg.act, yf,
-                   nf, stride, zf0, zf1, st)
+            L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,
+                   saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, zf0, zf1, st)          # (r1 = the activation mask when res_mask)
             # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
             dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
             coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
@@ -558,7 +569,7 @@ class _ConvBNAct(torch.autograd.Function):
             dy = torch.empty(y.shape, dtype=H16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
-            L.call('tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
+            L.call('tcvom_bn_bwd_apply_mask' if ctx.res_mask else 'tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
                    L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
                    zf0, zf1, st)
             if ctx.has_bias:

@@ -13,7 +13,7 @@ from tcvom_amd.facade import train_step_loss                        # noqa: E402
 from tcvom_amd.optim import FusedAdam                               # noqa: E402
 
 dev = torch.device('cuda', 0)
-model, a, fg, bg = bench.build(dev, 1088, 1920, 0)
+model, a, fg, bg = bench.build(dev, 1088, 1920, 0, config=os.environ.get('ATEN_WHERE_CONFIG', 'gca'))
 params = [p for p in model.parameters() if p.requires_grad]
 opt = FusedAdam(params, lr=1e-4, weight_decay=1e-4)
 
