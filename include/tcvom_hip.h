@@ -508,6 +508,14 @@ int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, const int32_
                                  int32_t w, int32_t C, void* stream);
 int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N,
                                int32_t h, int32_t w, int32_t C, void* stream);
+/* ... + add[..., :C] (`add`: NHWC with add_ld channels per pixel): the second gradient of a tensor that feeds the pooling and the
+ * pyramid concat (models/VMN/VMN_FBA.py:25-31) without a separate copy + add pass */
+int tcvom_adaptive_avgpool_bwd_add(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, const void* add,
+                                   int32_t add_ld, int32_t N, int32_t h, int32_t w, int32_t C, void* stream);
+/* cat(F.interpolate(x, scale_factor=2, bilinear), skip) zero-padded to ld channels in one pass (models/VMN/VMN_FBA.py:37-48):
+ * x [N][hs][ws][Cx], skip [N][2hs][2ws][Cs] -> dst [N][2hs][2ws][ld] */
+int tcvom_up2_concat(const void* x, const void* skip, void* dst, int32_t N, int32_t hs, int32_t ws, int32_t Cx, int32_t Cs,
+                     int32_t ld, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) between channel slices of NHWC bf16 tensors (pixel strides ld_*,
  * first channel c_*): any size ratio forward; backward for the exact x2 case (gather, bf16 out) and for small sources
  * such as the s x s pooled maps (fp32 out) */

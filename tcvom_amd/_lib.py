@@ -151,6 +151,8 @@ _PROTOS = {
     'tcvom_adaptive_avgpool': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool_multi': [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool_bwd': [vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    'tcvom_adaptive_avgpool_bwd_add': [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_up2_concat': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_bilinear': [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_bilinear_up2_bwd': [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_bilinear_small_bwd': [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],

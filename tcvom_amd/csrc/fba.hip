@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256) void adaptive_pool_multi_kernel(const uint4* _
 // (see adaptive_pool_multi_kernel) the set of bins is the same for every pixel, so dx is CONSTANT per channel there: a block computes
 // the 8 values of its channel octets once per (sample, cell) and streams them over the cell's pixels -- a pure write pass.  (Per pixel,
 // every 16-byte output re-read up to 16 x 32 bytes of pooled gradients through L2: 742 us for the 400 MB gradient of a 1080p window.)
-__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const PoolMulti pm, uint4* __restrict__ dx, int h, int w, int C8) {
+// `add` (or NULL): a second gradient of x, read with a pixel stride of add_ld8 16-byte chunks and added -- the slice of the pyramid
+// concat buffer's gradient that belongs to x (VMN_FBA.py:25-31: x feeds the pooling AND the concat); as two autograd gradients that
+// cost a strided 400 MB copy and a 400 MB add per 1080p window
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const PoolMulti pm, uint4* __restrict__ dx, int h, int w, int C8,
+                                                                const uint4* __restrict__ add, int add_ld8) {
     const int ncell = (pm.nr - 1) * (pm.nc - 1);
     const int cell = blockIdx.x % ncell, nb = blockIdx.x / ncell;
     const int ci = cell / (pm.nc - 1), cj = cell % (pm.nc - 1);
@@ -193,7 +197,14 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const PoolMulti 
         const uint4 val = pack8(acc);
         for (int p = blockIdx.y * lanes + pl; p < npix; p += gridDim.y * lanes) {
             const int yy = h0 + p / bw, xx = w0 + p % bw;
-            dx[(((int64_t)nb * h + yy) * w + xx) * C8 + c8] = val;
+            const int64_t pix = ((int64_t)nb * h + yy) * w + xx;
+            if (add) {
+                float a8[8];
+                unpack8(add[pix * add_ld8 + c8], a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a8[k] += acc[k];
+                dx[pix * C8 + c8] = pack8(a8);
+            } else dx[pix * C8 + c8] = val;
         }
     }
 }
@@ -259,8 +270,8 @@ extern "C" int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, c
     TCVOM_LAUNCH_CHECK("adaptive_avgpool_multi");
     return TCVOM_OK;
 }
-extern "C" int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N, int32_t h,
-                                          int32_t w, int32_t C, void* stream) {
+static int adaptive_avgpool_bwd_impl(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, const void* add,
+                                     int32_t add_ld, int32_t N, int32_t h, int32_t w, int32_t C, void* stream) {
     TCVOM_CHECK_ARG(dout && scales && dx && nscales >= 1 && nscales <= 4 && N > 0 && C % 8 == 0 && (256 % (C / 8) == 0 || (C / 8) % 256 == 0),
                     "adaptive_avgpool_bwd: bad args");
     TCVOM_CHECK_ARG((256 % (C / 8) == 0 || (C / 8) % 256 == 0) && C <= 16384, "adaptive_avgpool_bwd: C=%d", C);
@@ -276,9 +287,20 @@ extern "C" int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_
     const int cells = (pm.nr - 1) * (pm.nc - 1) * N;
     int split = (2048 + cells - 1) / cells;
     if (split > 32) split = 32;
-    hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3((unsigned)cells, (unsigned)split), dim3(256), 0, (hipStream_t)stream, pm, (uint4*)dx, h, w, C / 8);
+    hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3((unsigned)cells, (unsigned)split), dim3(256), 0, (hipStream_t)stream, pm, (uint4*)dx, h, w, C / 8,
+                       (const uint4*)add, add_ld / 8);
     TCVOM_LAUNCH_CHECK("adaptive_avgpool_bwd");
     return TCVOM_OK;
+}
+extern "C" int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N, int32_t h,
+                                          int32_t w, int32_t C, void* stream) {
+    return adaptive_avgpool_bwd_impl(dout, scales, nscales, dx, nullptr, 0, N, h, w, C, stream);
+}
+// dx = (pooling gradient) + add[..., :C], `add` NHWC with add_ld channels per pixel
+extern "C" int tcvom_adaptive_avgpool_bwd_add(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, const void* add,
+                                              int32_t add_ld, int32_t N, int32_t h, int32_t w, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(add && add_ld % 8 == 0 && add_ld >= C && ((uintptr_t)add % 16) == 0, "adaptive_avgpool_bwd_add: bad addend");
+    return adaptive_avgpool_bwd_impl(dout, scales, nscales, dx, add, add_ld, N, h, w, C, stream);
 }
 
 // ------------------------------------------------------------------------------------------ bilinear resize
@@ -390,6 +412,45 @@ extern "C" int tcvom_bilinear(const void* src, void* dst, int32_t N, int32_t hs,
     hipLaunchKernelGGL(bilinear_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const h16raw*)src, (h16raw*)dst, n, hs, ws, hd, wd,
                        C / 8, ld_src, c_src, ld_dst, c_dst, (float)hs / (float)hd, (float)ws / (float)wd);
     TCVOM_LAUNCH_CHECK("bilinear");
+    return TCVOM_OK;
+}
+// cat(bilinear x2 of x, skip) zero-padded to ld channels, every output row written once and whole (VMN_FBA.py:37-48): the
+// up-sampling kernel + a strided copy of the skip tensor + a strided zero fill were three passes over the concat buffer
+__global__ void up2_concat_kernel(const h16raw* __restrict__ x, const h16raw* __restrict__ skip, h16raw* __restrict__ dst, int64_t n,
+                                  int hs, int ws, int Cx8, int Cs8, int ld8) {
+    const int hd = 2 * hs, wd = 2 * ws;
+    GRID_STRIDE(v, n) {
+        const int c8 = (int)(v % ld8);
+        int64_t t = v / ld8;
+        const int X = (int)(t % wd); t /= wd;
+        const int Y = (int)(t % hd);
+        const int64_t nb = t / hd;
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        if (c8 < Cx8) {
+            const Lerp ly = lerp_of(Y, 0.5f, hs), lx = lerp_of(X, 0.5f, ws);
+            const h16raw* sb = x + nb * hs * ws * (Cx8 * 8) + c8 * 8;
+            float a[8], b[8], c[8], d[8], r[8];
+            unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i0 * ws + lx.i0) * (Cx8 * 8)), a);
+            unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i0 * ws + lx.i1) * (Cx8 * 8)), b);
+            unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i1 * ws + lx.i0) * (Cx8 * 8)), c);
+            unpack8(*reinterpret_cast<const uint4*>(sb + ((int64_t)ly.i1 * ws + lx.i1) * (Cx8 * 8)), d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                r[k] = (1.f - ly.l) * ((1.f - lx.l) * a[k] + lx.l * b[k]) + ly.l * ((1.f - lx.l) * c[k] + lx.l * d[k]);
+            o = pack8(r);
+        } else if (c8 < Cx8 + Cs8) {
+            o = *reinterpret_cast<const uint4*>(skip + (((nb * hd + Y) * wd + X) * Cs8 + (c8 - Cx8)) * 8);
+        }
+        *reinterpret_cast<uint4*>(dst + (((nb * hd + Y) * wd + X) * ld8 + c8) * 8) = o;
+    }
+}
+extern "C" int tcvom_up2_concat(const void* x, const void* skip, void* dst, int32_t N, int32_t hs, int32_t ws, int32_t Cx, int32_t Cs,
+                                int32_t ld, void* stream) {
+    TCVOM_CHECK_ARG(x && skip && dst && N > 0 && hs > 0 && ws > 0 && Cx % 8 == 0 && Cs % 8 == 0 && ld % 8 == 0 && Cx + Cs <= ld, "up2_concat: bad args");
+    const int64_t n = (int64_t)N * 4 * hs * ws * (ld / 8);
+    hipLaunchKernelGGL(up2_concat_kernel, dim3(dgrid(n)), dim3(256), 0, (hipStream_t)stream, (const h16raw*)x, (const h16raw*)skip, (h16raw*)dst, n,
+                       hs, ws, Cx / 8, Cs / 8, ld / 8);
+    TCVOM_LAUNCH_CHECK("up2_concat");
     return TCVOM_OK;
 }
 extern "C" int tcvom_bilinear_up2_bwd(const void* ddst, void* dsrc, int32_t N, int32_t hs, int32_t ws, int32_t C, int32_t ld_dst, int32_t c_dst,

@@ -158,9 +158,10 @@ class vmn_fba_decoder(nn.Module):
     def run_feature(self, conv5, token, training):
         """extract_feature=True (VMN_FBA.py:21-33): pyramid pooling + conv_up1 -> [F, h, w, 256] at os8."""
         cf = self._cfgs
-        pooled = ops.pyramid_pool(conv5, PPM_SCALES)
+        link = {}                                       # conv5 feeds the pooling AND the concat: one gradient kernel for both (ops._PyramidPool)
+        pooled = ops.pyramid_pool(conv5, PPM_SCALES, link)
         maps = [ops.conv_bn_act(cf['decoder.ppm.%d.1' % i], pooled[i], token, training) for i in range(4)]
-        x = ops.pyramid_concat(3072, conv5, maps)
+        x = ops.pyramid_concat(3072, conv5, maps, link)
         x = ops.conv_bn_act(cf['decoder.conv_up1.0'], x, token, training)
         return ops.conv_bn_act(cf['decoder.conv_up1.3'], x, token, training)
 

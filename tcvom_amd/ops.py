@@ -1219,7 +1219,10 @@ class _PyramidPool(torch.autograd.Function):
     tuple of [N,s,s,C] bf16.  The backward adds the gradients of all scales in one pass over x."""
 
     @staticmethod
-    def forward(ctx, x, scales):
+    def forward(ctx, x, scales, link=None):
+        # link (a dict shared with the _PyramidConcat that takes the same x): the concat's backward leaves its gradient slice there
+        # and this backward -- which autograd runs later: the pooled maps feed the concat -- adds it inside the pooling-gradient kernel
+        ctx.link = link
         x = _c(x)
         N, h, w, Cc = x.shape
         st = L.stream_ptr()
@@ -1248,19 +1251,27 @@ class _PyramidPool(torch.autograd.Function):
         ptrs = (C.c_void_p * n)(*[g.data_ptr() for g in gs])
         sc = (C.c_int32 * n)(*ctx.scales)
         dx = torch.empty(ctx.shape, dtype=H16, device=gs[0].device)
-        L.call('tcvom_adaptive_avgpool_bwd', C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, L.ptr(dx), N, h, w, Cc, L.stream_ptr())
-        return dx, None
+        pend = ctx.link.pop('dbuf', None) if ctx.link is not None else None
+        if pend is not None:
+            dbuf, cpad = pend
+            L.call('tcvom_adaptive_avgpool_bwd_add', C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, L.ptr(dx), L.ptr(dbuf), cpad,
+                   N, h, w, Cc, L.stream_ptr())
+        else:
+            L.call('tcvom_adaptive_avgpool_bwd', C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, L.ptr(dx), N, h, w, Cc, L.stream_ptr())
+        return dx, None, None
 
 
 class _PyramidConcat(torch.autograd.Function):
     """cat(conv5, bilinear(pooled_s -> h x w) for every scale) zero-padded to `cpad` channels (VMN_FBA.py:25-31)."""
 
     @staticmethod
-    def forward(ctx, cpad, x, *maps):
+    def forward(ctx, cpad, link, x, *maps):
         x = _c(x)
         N, h, w, Cx = x.shape
         st = L.stream_ptr()
-        buf = torch.zeros((N, h, w, cpad), dtype=H16, device=x.device)
+        ctx.link = link
+        full = Cx + sum(m.shape[3] for m in maps) == cpad      # every channel gets written: no zero fill (3072 = 2048 + 4 x 256)
+        buf = (torch.empty if full else torch.zeros)((N, h, w, cpad), dtype=H16, device=x.device)
         buf[..., :Cx].copy_(x)
         off = Cx
         shapes = []
@@ -1279,13 +1290,17 @@ class _PyramidConcat(torch.autograd.Function):
         N, h, w, Cx, cpad, shapes = ctx.geo
         dbuf = _c(dbuf)
         st = L.stream_ptr()
-        dx = dbuf[..., :Cx].contiguous()
+        if ctx.link is not None and cpad % 8 == 0 and PPM_LINK:
+            ctx.link['dbuf'] = (dbuf, cpad)                     # added by the pooling backward of the same x (no copy, no autograd add)
+            dx = None
+        else:
+            dx = dbuf[..., :Cx].contiguous()
         dmaps = []
         for hs, ws, Cm, off in shapes:
             d = torch.empty((N, hs, ws, Cm), dtype=torch.float32, device=dbuf.device)
             L.call('tcvom_bilinear_small_bwd', L.ptr(dbuf), L.ptr(d), N, hs, ws, h, w, Cm, cpad, off, st)
             dmaps.append(d.to(H16))
-        return (None, dx) + tuple(dmaps)
+        return (None, None, dx) + tuple(dmaps)
 
 
 class _Up2Concat(torch.autograd.Function):
@@ -1299,10 +1314,14 @@ class _Up2Concat(torch.autograd.Function):
         Cs = skip.shape[3]
         assert skip.shape[:3] == (N, 2 * h, 2 * w) and Cx + Cs <= cpad and Cx % 8 == 0
         buf = torch.empty((N, 2 * h, 2 * w, cpad), dtype=H16, device=x.device)
-        L.call('tcvom_bilinear', L.ptr(x), L.ptr(buf), N, h, w, 2 * h, 2 * w, Cx, Cx, 0, cpad, 0, L.stream_ptr())
-        buf[..., Cx:Cx + Cs].copy_(skip)
-        if Cx + Cs < cpad:
-            buf[..., Cx + Cs:].zero_()
+        if Cs % 8 == 0 and cpad % 8 == 0:
+            # up-sampling, skip copy and zero padding in one pass of whole rows
+            L.call('tcvom_up2_concat', L.ptr(x), L.ptr(skip), L.ptr(buf), N, h, w, Cx, Cs, cpad, L.stream_ptr())
+        else:
+            L.call('tcvom_bilinear', L.ptr(x), L.ptr(buf), N, h, w, 2 * h, 2 * w, Cx, Cx, 0, cpad, 0, L.stream_ptr())
+            buf[..., Cx:Cx + Cs].copy_(skip)
+            if Cx + Cs < cpad:
+                buf[..., Cx + Cs:].zero_()
         ctx.geo = (N, h, w, Cx, Cs, cpad)
         return buf
 
@@ -1351,12 +1370,15 @@ class _FbaHead(torch.autograd.Function):
 maxpool3s2 = _MaxPool3S2.apply
 
 
-def pyramid_pool(x, scales):
-    return _PyramidPool.apply(x, tuple(scales))
+PPM_LINK = _os.environ.get('TCVOM_NO_PPM_LINK') is None              # A/B switch
 
 
-def pyramid_concat(cpad, x, maps):
-    return _PyramidConcat.apply(cpad, x, *maps)
+def pyramid_pool(x, scales, link=None):
+    return _PyramidPool.apply(x, tuple(scales), link)
+
+
+def pyramid_concat(cpad, x, maps, link=None):
+    return _PyramidConcat.apply(cpad, link, x, *maps)
 
 
 def up2_concat(cpad, x, skip):

@@ -43,15 +43,18 @@ def test_maxpool_3x3_stride2_bit_exact():
     assert_close(nchw(xg.grad), bf(xr.grad), 1e-2, 1e-2, 'maxpool3s2 dx')       # up to 4 bf16 terms summed in fp32, rounded once
 
 
-@pytest.mark.parametrize('h,w', [(12, 18), (17, 30)])
-def test_pyramid_pooling_and_concat(h, w):
-    """AdaptiveAvgPool2d(1, 2, 3, 6) -> (identity instead of the conv) -> bilinear back to h x w -> concat, fwd + bwd."""
+@pytest.mark.parametrize('h,w,linked', [(12, 18, False), (17, 30, False), (17, 30, True)])
+def test_pyramid_pooling_and_concat(h, w, linked):
+    """AdaptiveAvgPool2d(1, 2, 3, 6) -> (identity instead of the conv) -> bilinear back to h x w -> concat, fwd + bwd.
+    linked: the two gradients of x (through the pooling and through the concat) are added inside the pooling-gradient kernel, as
+    fba_net.run_feature runs it, instead of by autograd."""
     from tcvom_amd import ops
     N, Cc = 2, 64
     x = bf(hu('fba.ppm.x', (N, Cc, h, w)))
     xg = nhwc(x).requires_grad_(True)
-    pooled = ops.pyramid_pool(xg, (1, 2, 3, 6))
-    buf = ops.pyramid_concat(512, xg, pooled)
+    link = {} if linked else None
+    pooled = ops.pyramid_pool(xg, (1, 2, 3, 6), link)
+    buf = ops.pyramid_concat(512, xg, pooled, link)
     xr = x.clone().requires_grad_(True)
     parts = [xr] + [F.interpolate(bf(F.adaptive_avg_pool2d(xr, s)), (h, w), mode='bilinear', align_corners=False) for s in (1, 2, 3, 6)]
     ref = torch.cat(parts, 1)
