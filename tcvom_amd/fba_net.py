@@ -222,7 +222,9 @@ class VMN_FBA(nn.Module):
             bank.frames_per_op = hi - lo
             img = imgs.transpose(0, 1)[1:S - 1].reshape((hi - lo, 3) + tuple(imgs.shape[-2:]))
             pred, ab, af = self.decoder.run_tail(feat[lo:hi], feat[0:hi - B], feat[2 * B:hi + B], U[lo:hi].contiguous(),
-                                                 outs[1][lo:hi], outs[0][lo:hi], EX[lo:hi], img, token, training)
+                                                 ops.frame_slice(outs[1], lo, hi), ops.frame_slice(outs[0], lo, hi), EX[lo:hi], img, token,
+                                                 training)       # (frame_slice: the skip gradients of the interior frames go into the
+                                                                 #  producers' GroupNorm backward as row ranges, not as zero-padded tensors)
         finally:
             bank.frames_per_op = 1
         H, W = pred.shape[-2:]

@@ -373,6 +373,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.res1_stash = getattr(res1, '_tcvom_grad_stash', None) if res1 is not None else None
         ctx.x_stash = getattr(x, '_tcvom_grad_stash', None)
         ctx.x_tail_rows = getattr(x, '_tcvom_tail_rows', None)      # x comes from a tail-only op: it takes row-range gradients
+        ctx.x_pad_unread = getattr(x, '_tcvom_pad_unread', False)   # x is a concat buffer whose backward never reads the padding channels
         ctx.set_materialize_grads(False)             # every consumer may have deposited: then autograd hands over None
         x = _c(x)
         NT, H, W, Cx = x.shape
@@ -581,7 +582,7 @@ class _ConvBNAct(torch.autograd.Function):
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
             # zero-padded concat inputs (spec.cpad > spec.C): the gradient keeps the padded layout, zeros in the padding
             cx = spec.cpad if spec.cpad > 8 else spec.C
-            alloc = torch.zeros if cx != spec.C else torch.empty
+            alloc = torch.zeros if (cx != spec.C and not ctx.x_pad_unread) else torch.empty
             dx = alloc((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dz.device)
             _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st, nf, ctx.wsb)
         # the weight gradients are deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
@@ -1378,11 +1379,15 @@ def pyramid_pool(x, scales, link=None):
 
 
 def pyramid_concat(cpad, x, maps, link=None):
-    return _PyramidConcat.apply(cpad, link, x, *maps)
+    buf = _PyramidConcat.apply(cpad, link, x, *maps)
+    buf._tcvom_pad_unread = True               # (its backward reads the channel slices of x and the maps only)
+    return buf
 
 
 def up2_concat(cpad, x, skip):
-    return _Up2Concat.apply(cpad, x, skip)
+    buf = _Up2Concat.apply(cpad, x, skip)
+    buf._tcvom_pad_unread = True
+    return buf
 
 
 fba_head = _FbaHead.apply
