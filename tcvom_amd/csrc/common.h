@@ -96,6 +96,45 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- 8 sums over the 32 lanes of each half wave, as a HALVING butterfly: the statistics epilogues of the conv / GEMM kernels hold, per
+// lane, the (sum, sum of squares) of 4 consecutive channels over the lane's own pixels: t[0..3] = sums, t[4..7] = sums of squares.
+// Stage 1 (lane ^ 1) leaves every lane with 4 of the 8 values summed over its pair, stage 2 (lane ^ 2) with 2 values summed over its
+// quad -- index 4 b0 + 2 b1 + {0, 1} for lane bits b0, b1 -- which two row rotations (by 4 and by 8 lanes) and one 16-lane swap then
+// sum over the 8 quads: 12 cross-lane operations instead of the 40 of a full butterfly on all 8 values (5 dependent DPP stages x 8
+// values were 8 us of a 256 x 256 tile's epilogue).  Result: EVERY lane of the half wave holds the two totals of its (b0, b1):
+//   b0 == 0: out[0], out[1] = sums of channels 2 b1, 2 b1 + 1;     b0 == 1: sums of SQUARES of channels 2 b1, 2 b1 + 1.
+#define H16_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ void reduce8_pairs(const float (&t)[8], int lane, float& o0, float& o1) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float send = b0 ? t[i] : t[4 + i], keep = b0 ? t[4 + i] : t[i];
+        k[i] = keep + H16_DPP(send, 0xB1);                  // quad_perm [1,0,3,2]: lane ^ 1
+    }
+    float m[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float send = b1 ? k[i] : k[2 + i], keep = b1 ? k[2 + i] : k[i];
+        m[i] = keep + H16_DPP(send, 0x4E);                  // quad_perm [2,3,0,1]: lane ^ 2
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        m[i] += H16_DPP(m[i], 0x124);                       // row_ror:4  -> two quads of the row
+        m[i] += H16_DPP(m[i], 0x128);                       // row_ror:8  -> the four quads of the 16-lane row
+        m[i] += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, m[i]), 0x401F));   // lane ^ 16
+    }
+    o0 = m[0];
+    o1 = m[1];
+}
+// ... and the store: stats row `sp` ([2][K] floats: sums, then sums of squares), `mrow` = first of the lane's 4 channels
+__device__ __forceinline__ void reduce8_store(const float (&t)[8], int lane, float* sp, int K, int mrow, bool valid) {
+    float o0, o1;
+    reduce8_pairs(t, lane, o0, o1);
+    if ((lane & 28) == 0 && valid)                          // the four lanes of quad 0 of each half wave (lanes 0..3, 32..35)
+        *reinterpret_cast<float2*>(sp + ((lane & 1) ? K : 0) + mrow + (lane & 2)) = make_float2(o0, o1);
+}
+
 // ---- gfx950 LDS transposing reads (ds_read_b64_tr_b16) issued as inline asm
 // The compiler treats the ds_read_tr builtin as a possible reader of what an in-flight global_load_lds writes and puts
 // s_waitcnt vmcnt(0) in front of the first one: the next stage's DMA then never overlaps this stage's MFMAs.  The reduction

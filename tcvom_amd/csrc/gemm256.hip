@@ -69,21 +69,6 @@ struct Gemm256Args {
     int lda, krows_a;
 };
 
-// 8 sums over the 32 pixel lanes of each half wave with DPP adds (igemm.hip: nt_reduce8): lanes 16..31 / 48..63 hold the totals
-#define G256_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
-__device__ __forceinline__ void g256_reduce8(float (&t)[8]) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0xB1, 0xF);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x4E, 0xF);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x141, 0xF);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x140, 0xF);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += G256_DPP(t[r], 0x142, 0xA);
-}
-
 #ifndef G256_STAGED_EPI
 #define G256_STAGED_EPI 1     // 1: the plain epilogue of the 256-row tiles goes through per-wave LDS regions (whole-row stores)
 #endif
@@ -623,11 +608,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
                                 t8[4 + r] = fmaf(xs, xs, t8[4 + r]);
                             }
                         }
-                        g256_reduce8(t8);
-                        if ((lane & 31) == 16 && mrow < g.M) {
-                            *reinterpret_cast<float4*>(sp0 + mrow) = make_float4(t8[0], t8[1], t8[2], t8[3]);
-                            *reinterpret_cast<float4*>(sp0 + g.M + mrow) = make_float4(t8[4], t8[5], t8[6], t8[7]);
-                        }
+                        reduce8_store(t8, lane, sp0, g.M, mrow, mrow < g.M);
                     }
                 }
             }

@@ -63,22 +63,6 @@ extern "C" int tcvom_trace_read(unsigned long long* host, int n) {
 #ifndef NT_DBG
 #define NT_DBG 0            // kernel study builds only: 1 = no LDS reads / MFMAs, 2 = no DMA, 3 = no epilogue
 #endif
-// 8 sums over the 32 pixel lanes of each half wave with DPP adds: within quads, half rows, rows, then row 0 -> row 1 / row 2 -> row 3
-// (row_bcast15): lanes 16..31 and 48..63 hold the totals
-#define NT_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
-__device__ __forceinline__ void nt_reduce8(float (&t)[8]) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0xB1, 0xF);      // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x4E, 0xF);      // quad_perm [2,3,0,1]
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x141, 0xF);     // row_half_mirror
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x140, 0xF);     // row_mirror
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] += NT_DPP(t[r], 0x142, 0xA);     // row_bcast15 into rows 1 and 3
-}
-
 template <int TM, int TN, int WM, int WN, int NST>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const h16raw* __restrict__ in, const h16raw* __restrict__ wgt, void* __restrict__ outp,
@@ -341,12 +325,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                     }
                 }
                 if (do_stats) {
-                    nt_reduce8(t8);                      // lanes 16..31 / 48..63 hold the totals of the two lane halves
-                    if ((lane & 31) == 16 && mrow < K) {
-                        float* sp = stats + sgrp * 2 * K + mrow;
-                        *reinterpret_cast<float4*>(sp) = make_float4(t8[0], t8[1], t8[2], t8[3]);
-                        *reinterpret_cast<float4*>(sp + K) = make_float4(t8[4], t8[5], t8[6], t8[7]);
-                    }
+                    reduce8_store(t8, lane, stats + sgrp * 2 * K, K, mrow, mrow < K);                  // (common.h: halving butterfly)
                 }
             }
         }
