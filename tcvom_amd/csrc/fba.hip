@@ -399,9 +399,21 @@ __global__ __launch_bounds__(256) void bilinear_small_bwd_kernel(const h16raw* _
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += wgt * g[k];
     }
-    float* o = dsrc + ((int64_t)blockIdx.x * C8 + c8) * 8;
+    // the `lanes` pixel groups of the block hold partial sums of the SAME channels: summed through LDS first, one atomic per
+    // (channel, block) instead of one per thread (with many row splits every thread's atomics hit the same few hundred addresses)
+    __shared__ float red[256 * 8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(o + k, acc[k]);
+    for (int k = 0; k < 8; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    if (pl == 0) {
+        float* o = dsrc + ((int64_t)blockIdx.x * C8 + c8) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += red[k * 256 + l * C8 + c8];
+            atomicAdd(o + k, t);
+        }
+    }
 }
 
 extern "C" int tcvom_bilinear(const void* src, void* dst, int32_t N, int32_t hs, int32_t ws, int32_t hd, int32_t wd, int32_t C,
@@ -471,6 +483,13 @@ extern "C" int tcvom_bilinear_small_bwd(const void* ddst, float* dsrc, int32_t N
     const int64_t npix = (int64_t)(2 * hd / hs + 4) * (2 * wd / ws + 4);
     int split = (int)((npix * (C / 8) + 256 * 64 - 1) / (256 * 64));
     if (split > 64) split = 64;
+    // the 1 x 1 and 2 x 2 maps have 1 .. 4 source pixels per sample: 64 row splits left the launch at 192 .. 768 workgroups walking a
+    // 50 MB slice each (106 .. 215 us per map at 1080p); at least ~1024 workgroups, each still >= 4 pixel rows per lane group
+    const int64_t per_split_min = (int64_t)(256 / (C / 8)) * 4;
+    const int want = (1024 + N * hs * ws - 1) / (N * hs * ws);
+    if (split < want) split = want;
+    if ((int64_t)split * per_split_min > npix) split = (int)(npix / per_split_min);
+    if (split > 1024) split = 1024;
     if (split < 1) split = 1;
     hipLaunchKernelGGL(bilinear_small_bwd_kernel, dim3(N * hs * ws, split), dim3(256), 0, st, (const h16raw*)ddst, dsrc, hs, ws, hd, wd, C / 8,
                        ld_dst, c_dst, (float)hs / (float)hd, (float)ws / (float)wd);
