@@ -506,6 +506,11 @@ int tcvom_adaptive_avgpool(const void* x, float* out, int32_t N, int32_t h, int3
 /* every scale of the pyramid in one pass over x (outs / scales: HOST arrays of nscales <= 4 entries; outs[i]: fp32 [N][s_i][s_i][C]) */
 int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, int32_t N, int32_t h,
                                  int32_t w, int32_t C, void* stream);
+/* the same without atomics: per-(cell, row split) sums into `scratch` (tcvom_adaptive_avgpool_scratch_floats floats; 0 = the scales have
+ * too many bin boundaries), combined by a second launch in a fixed order; outs need no zeroing */
+int tcvom_adaptive_avgpool_scratch_floats(const int32_t* scales, int32_t nscales, int32_t N, int32_t h, int32_t w, int32_t C);
+int tcvom_adaptive_avgpool_multi_ws(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, float* scratch, int32_t N,
+                                    int32_t h, int32_t w, int32_t C, void* stream);
 int tcvom_adaptive_avgpool_bwd(const float* const* dout, const int32_t* scales, int32_t nscales, void* dx, int32_t N,
                                int32_t h, int32_t w, int32_t C, void* stream);
 /* ... + add[..., :C] (`add`: NHWC with add_ld channels per pixel): the second gradient of a tensor that feeds the pooling and the

@@ -150,6 +150,8 @@ _PROTOS = {
     'tcvom_maxpool3s2_bwd': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool': [vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool_multi': [vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'tcvom_adaptive_avgpool_multi_ws': [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp],
+    'tcvom_adaptive_avgpool_scratch_floats': [vp, i32, i32, i32, i32, i32],
     'tcvom_adaptive_avgpool_bwd': [vp, vp, i32, vp, i32, i32, i32, i32, vp],
     'tcvom_adaptive_avgpool_bwd_add': [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     'tcvom_up2_concat': [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
@@ -223,7 +225,8 @@ _PROTOS = {
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_bn_bwd_groups_n', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
-          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks'}
+          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks',
+          'tcvom_adaptive_avgpool_scratch_floats'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}

@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256) void adaptive_pool_kernel(const uint4* __restr
 // scale: 4 x 177 us): the union of every scale's bin boundaries cuts the map into cells, each cell lies inside or outside any bin; a
 // block sums one (sample, cell, row split) and adds the sum / |bin| to every bin of every scale that contains the cell.
 struct PoolMulti { float* out[4]; int s[4]; int n; int rows[40], cols[40]; int nr, nc; };
-__global__ __launch_bounds__(256) void adaptive_pool_multi_kernel(const uint4* __restrict__ x, const PoolMulti pm, int h, int w, int C8) {
+// partial (or NULL): [sample][cell][row split][C] fp32 -- the block's cell sum is STORED there and adaptive_pool_combine_kernel adds the
+// cells of every bin (with atomics every block added its 2048 channel sums to up to 4 maps: 8.8 M atomics on 0.3 M addresses per 1080p
+// window, which -- not the 400 MB read -- was what the pass took: 317 us)
+__global__ __launch_bounds__(256) void adaptive_pool_multi_kernel(const uint4* __restrict__ x, const PoolMulti pm, int h, int w, int C8,
+                                                                  float* __restrict__ partial) {
     const int ncell = (pm.nr - 1) * (pm.nc - 1);
     const int cell = blockIdx.x % ncell, nb = blockIdx.x / ncell;
     const int ci = cell / (pm.nc - 1), cj = cell % (pm.nc - 1);
@@ -136,12 +140,53 @@ __global__ __launch_bounds__(256) void adaptive_pool_multi_kernel(const uint4* _
     const int64_t npix = (int64_t)(h1 - h0) * bw;
     for (int c8 = threadIdx.x % C8; c8 < C8; c8 += 256) {           // (C8 <= 256: one pass)
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int64_t p = (int64_t)blockIdx.y * lanes + pl; p < npix; p += (int64_t)gridDim.y * lanes) {
+        // four pixels per trip, their loads in flight together (one dependent 16-byte load per trip left this pass latency bound:
+        // 342 us for the 400 MB map of a 1080p window)
+        const int64_t pstep = (int64_t)gridDim.y * lanes;
+        int64_t p = (int64_t)blockIdx.y * lanes + pl;
+        for (; p + 3 * pstep < npix; p += 4 * pstep) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pu = p + u * pstep;
+                const int yy = h0 + (int)(pu / bw), xx = w0 + (int)(pu % bw);
+                v[u] = x[(((int64_t)nb * h + yy) * w + xx) * C8 + c8];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += f[k];
+            }
+        }
+        for (; p < npix; p += pstep) {
             const int yy = h0 + (int)(p / bw), xx = w0 + (int)(p % bw);
             float f[8];
             unpack8(x[(((int64_t)nb * h + yy) * w + xx) * C8 + c8], f);
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += f[k];
+        }
+        if (partial) {
+            float* o = partial + ((((int64_t)blockIdx.x) * gridDim.y + blockIdx.y) * C8 + c8) * 8;
+            if (lanes > 1) {                                   // (C8 < 256: the block's pixel lanes hold partial sums of the same channels)
+                __shared__ float red[256 * 8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) red[k * 256 + threadIdx.x] = acc[k];
+                __syncthreads();
+                if (pl == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float t = 0.f;
+                        for (int l = 0; l < lanes; ++l) t += red[k * 256 + l * C8 + c8];
+                        o[k] = t;
+                    }
+                }
+            } else {
+                *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
+            continue;
         }
         for (int q = 0; q < pm.n; ++q) {
             const int sc = pm.s[q];
@@ -159,6 +204,33 @@ __global__ __launch_bounds__(256) void adaptive_pool_multi_kernel(const uint4* _
             }
         }
     }
+}
+// second stage: one block per (sample, scale, bin) sums the partial sums of the cells inside the bin, in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void adaptive_pool_combine_kernel(const float* __restrict__ partial, const PoolMulti pm, int h, int w, int C,
+                                                                    int split, int nbins_total) {
+    const int ncell = (pm.nr - 1) * (pm.nc - 1);
+    const int nb = blockIdx.x / nbins_total;
+    int b = blockIdx.x % nbins_total, q = 0;
+    while (b >= pm.s[q] * pm.s[q]) { b -= pm.s[q] * pm.s[q]; ++q; }
+    const int sc = pm.s[q], bi = b / sc, bj = b % sc;
+    const int bh0 = bin_lo(bi, h, sc), bh1 = bin_hi(bi, h, sc), bw0 = bin_lo(bj, w, sc), bw1 = bin_hi(bj, w, sc);
+    const float inv = 1.f / (float)((bh1 - bh0) * (bw1 - bw0));
+    const int c = blockIdx.y * 256 + threadIdx.x;              // grid.y = channel chunks of 256
+    if (c >= C) return;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int ci = 0; ci < pm.nr - 1; ++ci) {
+        if (pm.rows[ci] < bh0 || pm.rows[ci + 1] > bh1) continue;
+        for (int cj = 0; cj < pm.nc - 1; ++cj) {
+            if (pm.cols[cj] < bw0 || pm.cols[cj + 1] > bw1) continue;
+            const float* p = partial + (((int64_t)nb * ncell + ci * (pm.nc - 1) + cj) * split) * C + c;
+            int y = 0;
+            for (; y + 3 < split; y += 4) {                     // four loads in flight; the order of the sum is fixed
+                t0 += p[(int64_t)y * C]; t1 += p[(int64_t)(y + 1) * C]; t2 += p[(int64_t)(y + 2) * C]; t3 += p[(int64_t)(y + 3) * C];
+            }
+            for (; y < split; ++y) t0 += p[(int64_t)y * C];
+        }
+    }
+    pm.out[q][(((int64_t)nb * sc + bi) * sc + bj) * C + c] = ((t0 + t1) + (t2 + t3)) * inv;
 }
 // dx = sum over the scales of dout_s[bin] / |bin| for every bin that contains the pixel
 // dx = sum over the scales of dout_s[bin] / |bin| for every bin that contains the pixel.  Inside a CELL of the union partition
@@ -245,8 +317,31 @@ extern "C" int tcvom_adaptive_avgpool(const void* x, float* out, int32_t N, int3
     TCVOM_LAUNCH_CHECK("adaptive_avgpool");
     return TCVOM_OK;
 }
+// floats of scratch tcvom_adaptive_avgpool_multi_ws needs (0: too many bin boundaries)
+static int pool_cells(PoolMulti& pm, const int32_t* scales, int nscales, int h, int w);
+static int pool_split(int cells) { int split = (1024 + cells - 1) / cells; return split > 16 ? 16 : split; }
+extern "C" int tcvom_adaptive_avgpool_scratch_floats(const int32_t* scales, int32_t nscales, int32_t N, int32_t h, int32_t w, int32_t C) {
+    PoolMulti pm;
+    if (!scales || nscales < 1 || nscales > 4 || pool_cells(pm, scales, nscales, h, w) != 0) return 0;
+    const int cells = (pm.nr - 1) * (pm.nc - 1) * N;
+    const long long nfl = (long long)cells * pool_split(cells) * C;
+    return nfl < (1ll << 31) ? (int)nfl : 0;
+}
+static int adaptive_avgpool_multi_impl(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, float* scratch, int32_t N,
+                                       int32_t h, int32_t w, int32_t C, void* stream);
 extern "C" int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, int32_t N, int32_t h,
                                             int32_t w, int32_t C, void* stream) {
+    return adaptive_avgpool_multi_impl(x, outs, scales, nscales, nullptr, N, h, w, C, stream);
+}
+// two-stage form: per-(cell, row split) sums into `scratch` (tcvom_adaptive_avgpool_scratch_floats floats), then one combine launch:
+// no atomics, no memsets of the outputs, deterministic
+extern "C" int tcvom_adaptive_avgpool_multi_ws(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, float* scratch,
+                                               int32_t N, int32_t h, int32_t w, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(scratch, "adaptive_avgpool_multi_ws: null scratch");
+    return adaptive_avgpool_multi_impl(x, outs, scales, nscales, scratch, N, h, w, C, stream);
+}
+static int adaptive_avgpool_multi_impl(const void* x, float* const* outs, const int32_t* scales, int32_t nscales, float* scratch, int32_t N,
+                                       int32_t h, int32_t w, int32_t C, void* stream) {
     TCVOM_CHECK_ARG(x && outs && scales && nscales >= 1 && nscales <= 4 && N > 0 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0,
                     "adaptive_avgpool_multi: bad args");
     hipStream_t st = (hipStream_t)stream;
@@ -257,16 +352,20 @@ extern "C" int tcvom_adaptive_avgpool_multi(const void* x, float* const* outs, c
         TCVOM_CHECK_ARG(outs[i] && scales[i] >= 1 && scales[i] <= 8 && h >= scales[i] && w >= scales[i], "adaptive_avgpool_multi: scale %d", scales[i]);
         pm.out[q] = outs[i];
         pm.s[q] = scales[i];
-        if (q < nscales && hipMemsetAsync(outs[i], 0, sizeof(float) * (size_t)N * scales[i] * scales[i] * C, st) != hipSuccess)
+        if (!scratch && q < nscales && hipMemsetAsync(outs[i], 0, sizeof(float) * (size_t)N * scales[i] * scales[i] * C, st) != hipSuccess)
             return tcvom_fail(TCVOM_ERR_LAUNCH, "adaptive_avgpool_multi: memset failed");
     }
     TCVOM_CHECK_ARG(pool_cells(pm, scales, nscales, h, w) == 0, "adaptive_avgpool_multi: too many bin boundaries");
     const int nr = pm.nr, nc = pm.nc;
     // ~1024 blocks: row splits per cell
     const int cells = (nr - 1) * (nc - 1) * N;
-    int split = (1024 + cells - 1) / cells;
-    if (split > 16) split = 16;
-    hipLaunchKernelGGL(adaptive_pool_multi_kernel, dim3((unsigned)cells, (unsigned)split), dim3(256), 0, st, (const uint4*)x, pm, h, w, C / 8);
+    const int split = pool_split(cells);
+    hipLaunchKernelGGL(adaptive_pool_multi_kernel, dim3((unsigned)cells, (unsigned)split), dim3(256), 0, st, (const uint4*)x, pm, h, w, C / 8, scratch);
+    if (scratch) {
+        int nbins = 0;
+        for (int q = 0; q < nscales; ++q) nbins += scales[q] * scales[q];
+        hipLaunchKernelGGL(adaptive_pool_combine_kernel, dim3((unsigned)(N * nbins), (unsigned)cdiv(C, 256)), dim3(256), 0, st, (const float*)scratch, pm, h, w, C, split, nbins);
+    }
     TCVOM_LAUNCH_CHECK("adaptive_avgpool_multi");
     return TCVOM_OK;
 }

@@ -1233,7 +1233,13 @@ class _PyramidPool(torch.autograd.Function):
             o32 = [torch.empty((N, s, s, Cc), dtype=torch.float32, device=x.device) for s in scales]
             ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in o32])
             sc = (C.c_int32 * n)(*[int(s) for s in scales])
-            L.call('tcvom_adaptive_avgpool_multi', L.ptr(x), C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, N, h, w, Cc, st)
+            nfl = L.call('tcvom_adaptive_avgpool_scratch_floats', C.cast(sc, C.c_void_p), n, N, h, w, Cc)
+            if nfl > 0:          # per-cell partial sums + one combine launch: no atomics (8.8 M of them per 1080p window otherwise)
+                scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+                L.call('tcvom_adaptive_avgpool_multi_ws', L.ptr(x), C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, L.ptr(scratch),
+                       N, h, w, Cc, st)
+            else:
+                L.call('tcvom_adaptive_avgpool_multi', L.ptr(x), C.cast(ptrs, C.c_void_p), C.cast(sc, C.c_void_p), n, N, h, w, Cc, st)
             outs = [o.to(H16) for o in o32]
         else:
             outs = []
