@@ -979,7 +979,8 @@ extern "C" int tcvom_gca_dp_softmax_bwd(const void* dO, const void* V, const voi
 // Pass 1 (gemm_nt256 EPI 3): every 256 x 256 tile writes exp(S' - its own row maxima) as 16-bit numbers and (row max, row sum)
 // of the tile into stats[b][i][tile_j][2]; pass 2 rescales every row by exp(tile max - row max) / row sum, in place.  The fp32
 // N x N matrix (802 MB written and read back per 3-frame launch at 1080p) is never stored: 401 MB written, read and rewritten.
-__global__ __launch_bounds__(256) void softmax_rescale_kernel(uint4* __restrict__ P, const float* __restrict__ stats, int N, int ld8, int tmt) {
+__global__ __launch_bounds__(256) void softmax_rescale_kernel(uint4* __restrict__ P, const float* __restrict__ stats, int N, int ld8, int tmt,
+                                                              int flush_tiny) {
     __shared__ float f[64];
     const int64_t row = blockIdx.x;
     const float* st = stats + row * tmt * 2;
@@ -1002,6 +1003,15 @@ __global__ __launch_bounds__(256) void softmax_rescale_kernel(uint4* __restrict_
             const float s = f[i >> 5];                   // 32 octets per 256-column tile
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] *= s;
+#ifndef TCVOM_F16
+            // bf16 keeps probabilities down to 1e-38 that carry nothing (fp16 rounds everything below 2^-25 to zero, and its parity is the
+            // tighter one): as exact zeros they cost the matrix cores no switching power in O = P V, dP, dV and -- through T = P (..) --
+            // dq / dk, which run 5-8 % faster on the fp16 build's mostly-zero matrices at the same instruction stream (sustained clock)
+            if (flush_tiny) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = x[k] < 2.98023224e-08f ? 0.f : x[k];
+            }
+#endif
             v = pack8(x);
         }
         p[i] = v;
@@ -1047,8 +1057,9 @@ extern "C" int tcvom_gca_scores_exp(const void* G, const float* cvec, const floa
 extern "C" int tcvom_gca_softmax_rescale(void* P, const float* stats, int32_t N, int64_t ld, int32_t batch, void* stream) {
     TCVOM_CHECK_ARG(P && stats && N > 0 && N % 8 == 0 && ld >= N && ld % 256 == 0 && ld / 256 <= 64 && batch >= 1 && ((uintptr_t)P % 16) == 0,
                     "gca_softmax_rescale: N=%d ld=%lld", N, (long long)ld);
+    static const int flush = getenv("TCVOM_NO_P_FLUSH") ? 0 : 1;                  // A/B switch (bf16 build)
     hipLaunchKernelGGL(softmax_rescale_kernel, dim3((unsigned)((int64_t)batch * N)), dim3(256), 0, (hipStream_t)stream, (uint4*)P, stats, N,
-                       (int)(ld / 8), (int)(ld / 256));
+                       (int)(ld / 8), (int)(ld / 256), flush);
     TCVOM_LAUNCH_CHECK("gca_softmax_rescale");
     return TCVOM_OK;
 }
