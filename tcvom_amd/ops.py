@@ -1453,6 +1453,9 @@ GCA_FUSED_SOFTMAX = _os.environ.get('TCVOM_NO_FUSED_SOFTMAX', '0') != '1'      #
 
 
 
+GCA_KEEP = None
+
+
 class _GcaAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g8, alpha, unk_u8):
@@ -1508,6 +1511,8 @@ class _GcaAttention(torch.autograd.Function):
         y = torch.empty((B, h8, w8, Ca), dtype=H16, device=dev)
         L.call('tcvom_gca_fold_f32', L.ptr(O), L.ptr(y), B, h8, w8, Ca, st)
         ctx.save_for_backward(G, P, V, cvec, nrm, O)
+        if GCA_KEEP is not None:
+            GCA_KEEP.append(P)                       # (tools/gca_sparsity.py: statistics of the attention matrix)
         ctx.dims = (B, h8, w8, CG, Ca, N, ld)
         ctx.mark_non_differentiable(scales)
         return y, scales
