@@ -1090,11 +1090,13 @@ def test_tam_module_vs_reference_golden(name):
         assert_close(got.cpu(), want, 0, 3e-2 * float(np.abs(want).max()) + 1e-6, key)
 
 
-def test_tam_attention_kernel_tight():
-    """The fused attention kernel alone against the oracle's dense formula on identical bf16 inputs."""
+@pytest.mark.parametrize('C', [16, 128, 256])
+def test_tam_attention_kernel_tight(C):
+    """The fused attention kernels alone against the oracle's dense formula on identical 16-bit inputs: C = 128 runs on the matrix
+    cores (forward, backward pass A and -- round 5 -- pass B), C = 16 and C = 256 (the FBA / DIM bases) on the LDS-tiled vector kernels."""
     import oracle
     from tcvom_amd import ops
-    B, C, H, W, win = 2, 128, 10, 14, 7
+    B, H, W, win = 2, 10, 14, 7
     q, kb, kf, v = (hu('tamk.' + t, (B, C, H, W)) for t in ('q', 'kb', 'kf', 'v'))
     mask = (hu('tamk.m', (B, 1, H, W)) > -0.2)
     args = [nhwc(t).requires_grad_(True) for t in (q, kb, kf, v)]
