@@ -576,6 +576,14 @@ int tcvom_excl_bwd(const float* lvl, const float* sums, const float* wts, const 
  * per channel c = plane % 7, sgn = sign(resid); lap_bwd_coarse / lap_bwd_fine: the transposed operators, level by level. */
 int tcvom_lap_down(const float* cur, float* down, int64_t planes, int32_t h, int32_t w, void* stream);
 int tcvom_lap_resid(const float* cur, const float* down, int8_t* sgn, float* acc, int64_t planes, int32_t h, int32_t w, void* stream);
+/* the scalar arithmetic between the FBA loss kernels (models/model.py:142-175) in one launch each: acc = the accumulator block of
+ * tcvom_amd/fba_losses.py ([0..5] point sums, [6 + 7 l + c] Laplacian sums, per exclusion level sums[4] + terms[B][2]);
+ * finish: out[3] = (L_alpha_comp, L_lap, L_grad); coefs: out = coef[6] | d L / d terms [3][B][2] | Laplacian level weights [5][7] from
+ * the three incoming gradients (device scalars, NULL = 0).  excl_n* = 3 h w of the three exclusion levels. */
+int tcvom_fba_loss_finish(const float* acc, int32_t B, float n1, float n3, float excl_n0, float excl_n1, float excl_n2, float* out,
+                          void* stream);
+int tcvom_fba_loss_coefs(const float* acc, const float* g_ac, const float* g_lap, const float* g_grad, int32_t B, float n1, float n3,
+                         float excl_n0, float excl_n1, float excl_n2, float* out, void* stream);
 int tcvom_lap_bwd_coarse(const int8_t* sgn, const float* coef, const float* gnext, float* r, int64_t planes, int32_t h, int32_t w,
                          void* stream);
 int tcvom_lap_bwd_fine(const int8_t* sgn, const float* coef, const float* r, float* g, int64_t planes, int32_t h, int32_t w,

@@ -170,6 +170,8 @@ _PROTOS = {
     'tcvom_excl_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'tcvom_lap_down': [vp, vp, i64, i32, i32, vp],
     'tcvom_lap_resid': [vp, vp, vp, vp, i64, i32, i32, vp],
+    'tcvom_fba_loss_finish': [vp, i32, f32, f32, f32, f32, f32, vp, vp],
+    'tcvom_fba_loss_coefs': [vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp, vp],
     'tcvom_lap_bwd_coarse': [vp, vp, vp, vp, i64, i32, i32, vp],
     'tcvom_lap_bwd_fine': [vp, vp, vp, vp, i64, i32, i32, vp],
     'tcvom_crop_resize_u8': [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],

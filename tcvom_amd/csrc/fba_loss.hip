@@ -444,3 +444,68 @@ extern "C" int tcvom_lap_bwd_fine(const int8_t* sgn, const float* coef, const fl
     TCVOM_LAUNCH_CHECK("lap_bwd_fine");
     return TCVOM_OK;
 }
+
+// ------------------------------------------------------------------------------------------ the scalars between the loss kernels
+// acc layout (tcvom_amd/fba_losses.py): [0..5] point sums, [6 + 7 l + c] Laplacian |residual| sums of level l / channel c (5 levels),
+// then per exclusion level: sums[4], terms[B][2].  One thread: the ~100 ATen scalar kernels these replace were 0.3 ms of a 1080p step.
+//   out[0] = L_alpha_comp, out[1] = L_lap, out[2] = L_grad                     (models/model.py:142-175, normalize = True)
+__global__ void fba_loss_finish_kernel(const float* __restrict__ acc, int B, float n1, float n3, float en0, float en1, float en2,
+                                       float* __restrict__ out) {
+    const float en[3] = {en0, en1, en2};
+    float excl = 0.f;
+    int off = 6 + 35;
+    for (int l = 0; l < 3; ++l) {
+        const float* t = acc + off + 4;
+        float mx = 0.f, my = 0.f;
+        for (int b = 0; b < B; ++b) { mx += powf(t[2 * b] / en[l] + EPS_L, 0.25f); my += powf(t[2 * b + 1] / en[l] + EPS_L, 0.25f); }
+        excl += (mx + my) / (float)B;
+        off += 4 + 2 * B;
+    }
+    excl *= 1.f / 3.f;
+    float lap = 0.f;
+    for (int l = 0; l < 5; ++l) {
+        const float pw = (float)(1 << l);
+        lap += acc[6 + 7 * l] * (1.f / n1) * pw;
+        for (int c = 1; c < 7; ++c) lap += acc[6 + 7 * l + c] * (0.25f / n3) * pw;
+    }
+    out[0] = acc[0] / n1 + acc[1] / n3 + 0.25f * (acc[2] / n3 + acc[3] / n3 + acc[4] / n3);
+    out[1] = lap;
+    out[2] = acc[5] / n1 + 0.25f * excl;
+}
+// backward coefficients: out = coef[6] | wts[3][B][2] (d L / d terms of the exclusion levels) | cf[5][7] (Laplacian level weights)
+__global__ void fba_loss_coefs_kernel(const float* __restrict__ acc, const float* __restrict__ g_ac, const float* __restrict__ g_lap,
+                                      const float* __restrict__ g_grad, int B, float n1, float n3, float en0, float en1, float en2,
+                                      float* __restrict__ out) {
+    const float ga = g_ac ? *g_ac : 0.f, gl = g_lap ? *g_lap : 0.f, gg = g_grad ? *g_grad : 0.f;
+    out[0] = ga / n1; out[1] = ga / n3; out[2] = 0.25f * ga / n3; out[3] = 0.25f * ga / n3; out[4] = 0.25f * ga / n3; out[5] = gg / n1;
+    const float en[3] = {en0, en1, en2};
+    int off = 6 + 35;
+    float* w = out + 6;
+    for (int l = 0; l < 3; ++l) {
+        const float* t = acc + off + 4;
+        for (int i = 0; i < 2 * B; ++i)
+            w[l * 2 * B + i] = gg * (0.25f / 3.f / (float)B) * 0.25f * powf(t[i] / en[l] + EPS_L, -0.75f) / en[l];
+        off += 4 + 2 * B;
+    }
+    float* cf = out + 6 + 6 * B;
+    for (int l = 0; l < 5; ++l) {
+        const float pw = (float)(1 << l);
+        cf[7 * l] = gl * pw / n1;
+        for (int c = 1; c < 7; ++c) cf[7 * l + c] = gl * pw * 0.25f / n3;
+    }
+}
+extern "C" int tcvom_fba_loss_finish(const float* acc, int32_t B, float n1, float n3, float excl_n0, float excl_n1, float excl_n2, float* out,
+                                     void* stream) {
+    TCVOM_CHECK_ARG(acc && out && B > 0 && B <= 64, "fba_loss_finish: bad args");
+    hipLaunchKernelGGL(fba_loss_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, B, n1, n3, excl_n0, excl_n1, excl_n2, out);
+    TCVOM_LAUNCH_CHECK("fba_loss_finish");
+    return TCVOM_OK;
+}
+extern "C" int tcvom_fba_loss_coefs(const float* acc, const float* g_ac, const float* g_lap, const float* g_grad, int32_t B, float n1, float n3,
+                                    float excl_n0, float excl_n1, float excl_n2, float* out /* 6 + 6 B + 35 floats */, void* stream) {
+    TCVOM_CHECK_ARG(acc && out && B > 0 && B <= 64, "fba_loss_coefs: bad args");
+    hipLaunchKernelGGL(fba_loss_coefs_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, g_ac, g_lap, g_grad, B, n1, n3, excl_n0, excl_n1,
+                       excl_n2, out);
+    TCVOM_LAUNCH_CHECK("fba_loss_coefs");
+    return TCVOM_OK;
+}

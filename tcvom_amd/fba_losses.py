@@ -49,7 +49,6 @@ class _FbaFrameLoss(torch.autograd.Function):
                 nxt = f32(B, 6, h // 2, w // 2)
                 L.call('tcvom_avgpool2_f32', L.ptr(lv[l]), L.ptr(nxt), B * 6, h, w, st)
                 lv.append(nxt)
-        excl = sum(((t / n + EPS) ** 0.25).mean(0).sum() for _, t, n in ex) / float(EXCL_LEVELS)
         # Laplacian loss: one pyramid of d0 = (refine - gt, F - fg, B - bg)
         cur, sgns = d0, []
         for l in range(LAP_LEVELS):
@@ -61,16 +60,14 @@ class _FbaFrameLoss(torch.autograd.Function):
             sgns.append(sg)
             cur = down
         n1, n3 = float(B * HW), float(3 * B * HW)
-        lap_w = torch.tensor([1.0 / n1] + [0.25 / n3] * 6, dtype=torch.float32, device=dev)
-        lap_acc = acc[6:6 + 7 * LAP_LEVELS].view(LAP_LEVELS, 7)
-        pw = torch.tensor([float(2 ** l) for l in range(LAP_LEVELS)], dtype=torch.float32, device=dev)
-        L_lap = (lap_acc * lap_w[None, :] * pw[:, None]).sum()
-        L_ac = acc[0] / n1 + acc[1] / n3 + 0.25 * (acc[2] / n3 + acc[3] / n3 + acc[4] / n3)
-        L_grad = acc[5] / n1 + 0.25 * excl
+        # the scalar arithmetic on the accumulators (fourth roots of the exclusion terms, level weights of the pyramid) in ONE launch
+        out3 = f32(3)
+        ctx.excl_n = tuple(float(n) for _, _, n in ex)
+        L.call('tcvom_fba_loss_finish', L.ptr(acc), B, n1, n3, ctx.excl_n[0], ctx.excl_n[1], ctx.excl_n[2], L.ptr(out3), st)
         ctx.frame_tensors = (pred, gts, trimask, fgs, bgs, imgs)
-        ctx.c, ctx.lv, ctx.ex, ctx.sgns, ctx.lap_w, ctx.pw = c, lv, ex, sgns, lap_w, pw
+        ctx.c, ctx.lv, ctx.ex, ctx.sgns, ctx.acc = c, lv, ex, sgns, acc
         ctx.mark_non_differentiable(alphas, comps, Fs, Bs)
-        return L_ac, L_lap, L_grad
+        return out3[0], out3[1], out3[2]
 
     @staticmethod
     def backward(ctx, g_ac, g_lap, g_grad):
@@ -80,19 +77,20 @@ class _FbaFrameLoss(torch.autograd.Function):
         HW = H * W
         dev = pred.device
         st = L.stream_ptr()
-        zero = torch.zeros((), dtype=torch.float32, device=dev)
-        g_ac = zero if g_ac is None else g_ac.float()
-        g_lap = zero if g_lap is None else g_lap.float()
-        g_grad = zero if g_grad is None else g_grad.float()
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         n1, n3 = float(B * HW), float(3 * B * HW)
-        coef = torch.stack([g_ac / n1, g_ac / n3, 0.25 * g_ac / n3, 0.25 * g_ac / n3, 0.25 * g_ac / n3, g_grad / n1]).contiguous()
+        gp = lambda g: None if g is None else g.float().contiguous()
+        g_ac, g_lap, g_grad = gp(g_ac), gp(g_lap), gp(g_grad)
+        cbuf = f32(6 + 6 * B + 7 * LAP_LEVELS)            # coef[6] | exclusion d L / d terms [3][B][2] | Laplacian level weights [5][7]
+        L.call('tcvom_fba_loss_coefs', L.ptr(ctx.acc), L.ptr(g_ac), L.ptr(g_lap), L.ptr(g_grad), B, n1, n3, ctx.excl_n[0], ctx.excl_n[1],
+               ctx.excl_n[2], L.ptr(cbuf), st)
+        coef = cbuf[:6]
         # exclusion: d L / d terms, then level by level from the coarsest
         dl = None
         for l in reversed(range(EXCL_LEVELS)):
             sums, terms, n = ctx.ex[l]
             h, w = H >> l, W >> l
-            wts = (g_grad * (0.25 / float(EXCL_LEVELS) / float(B)) * 0.25 * (terms / n + EPS) ** (-0.75) / n).contiguous()
+            wts = cbuf[6 + 2 * B * l:6 + 2 * B * (l + 1)]
             dsum = torch.zeros(2, dtype=torch.float32, device=dev)
             L.call('tcvom_excl_terms', L.ptr(ctx.lv[l]), L.ptr(sums), L.ptr(wts), L.ptr(dsum), 1, B, h, w, st)
             cur = f32(B, 6, h, w)
@@ -102,7 +100,7 @@ class _FbaFrameLoss(torch.autograd.Function):
         g = None
         for l in reversed(range(LAP_LEVELS)):
             h, w = H >> l, W >> l
-            cf = (g_lap * ctx.pw[l] * ctx.lap_w).contiguous()
+            cf = cbuf[6 + 6 * B + 7 * l:6 + 6 * B + 7 * (l + 1)]
             r = f32(B, 7, h // 2, w // 2)
             L.call('tcvom_lap_bwd_coarse', L.ptr(ctx.sgns[l]), L.ptr(cf), L.ptr(g), L.ptr(r), B * 7, h, w, st)
             g = f32(B, 7, h, w)
