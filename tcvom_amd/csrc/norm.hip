@@ -559,7 +559,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 // pixel rows per block for the streaming BN kernels: ~8 loop iterations per thread (fewer iterations / more blocks
-// measured SLOWER: every thread first loads its 16..56 per-channel coefficients), at most 8192 blocks
+// measured SLOWER: every thread first loads its 16..56 per-channel coefficients; MORE iterations for the wide layers -- 32 / 64 for
+// C >= 512, round 5 -- measured slower too: FBA 47.3 -> 47.7 / 48.1 ms, GCA 23.67 -> 23.80), at most 8192 blocks
 static int bn_rows_per_block(int64_t pixels, int C) {
     const int rp = 256 / (C / 8);
     int64_t rows = (int64_t)rp * 8;
