@@ -130,6 +130,12 @@ class LossScaler(object):
 
 
 SCALER = LossScaler(LOSS_SCALE)
+# BatchNorm backward (local statistics) as ONE cooperative launch (csrc/norm.hip: bn_bwd_fused_kernel): built and measured in round 5,
+# OFF by default -- it LOSES at every size (same box, ms per 1080p step: 24.22 with the three launches; fused for tensors up to
+# 1 M / 4 M / 16 M / all elements: 24.24 / 24.58 / 29.67 / 31.75): the fp64 atomics of the statistics and the spin at the grid barrier cost
+# more than the two kernel boundaries + the 5 us finalize launch they replace.  TCVOM_FUSED_BN_BWD=1 switches it on (A/B, tests).
+FUSED_BN_MAX = int(_os.environ.get('TCVOM_FUSED_BN_MAX', str(1 << 62)))
+FUSED_BN_BWD = _os.environ.get('TCVOM_FUSED_BN_BWD') == '1'
 RES_MASK = _os.environ.get('TCVOM_NO_RES_MASK') is None          # A/B switch: activation bitmask of the residual sites (tcvom_bn_apply_mask)
 SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
@@ -358,6 +364,31 @@ def _launch_conv(descs, x, wptr, out, bias, stats, act, st, nf=1, w_stride=0):
     L.call('tcvom_conv_igemm_phases', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), L.ptr(stats), arr, n, st)
 
 
+def _bn_fused_workspace(bank, dev):
+    """Zero-initialised scratch of tcvom_bn_bwd_fused (every launch leaves it zero again), one per bank and device."""
+    ws = getattr(bank, '_bn_fused_ws', None)
+    if ws is None or ws.device != dev:
+        ws = torch.zeros(L.call('tcvom_bn_bwd_fused_workspace_bytes'), dtype=torch.uint8, device=dev)
+        bank._bn_fused_ws = ws
+    return ws
+
+
+def _bn_bwd_fused(ctx, cfg, bank, dz, dz2, y, r1, gamma, ss, saved, dy, dres1, P, K, yf, nf, stride, zf0, zf1, call, st):
+    """The BatchNorm backward of one site in ONE launch (csrc/norm.hip: bn_bwd_fused_kernel) when the statistics are local (no
+    SyncBatchNorm), every op runs on one stream and the shape qualifies; False -> the caller runs reduce / finalize / apply."""
+    if not FUSED_BN_BWD or SIDE_STREAMS[0] or cfg.group_norm or (ctx.sync is not None and ctx.training):
+        return False
+    if P * K * nf > FUSED_BN_MAX:
+        return False
+    dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
+    mask = r1 if ctx.res_mask else None
+    res1 = None if ctx.res_mask else r1
+    rc = L.call('tcvom_bn_bwd_fused', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(res1), L.ptr(mask), ss, saved, L.ptr(gamma), dgp, dbp,
+                L.ptr(dy), L.ptr(dres1), L.ptr(_bn_fused_workspace(bank, dz.device)), P, K, cfg.act, 1 if ctx.training else 0,
+                1 if cfg.pre_relu else 0, yf, nf, stride, zf0, zf1, P, 1, _sn_dot(cfg, call, ctx.training, None), st)
+    return rc == 0
+
+
 class _ConvBNAct(torch.autograd.Function):
     """conv (+bias) (+ReLU) (+BatchNorm) (+residual) (+activation) (+residual) of one layer, for `bank.frames_per_op`
     frames at once: x is [nf*B, H, W, C] frame-major; every frame has its own SpectralNorm call slot (weight copy) and
@@ -535,13 +566,18 @@ class _ConvBNAct(torch.autograd.Function):
                 raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not '
                                    'supported (the per-window BatchNorm / weight arenas were reused)' % spec.name)
             ss, saved, stride = ctx.ss, ctx.saved, ctx.slot_stride
-            groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
-            partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
             yf = 1 if y.dtype == torch.float32 else 0
             zf0, zf1 = 0, nf
             if dz2_rng is not None:
                 assert dz2 is None
                 dz2, zf0, zf1 = dz2_rng
+            dy = torch.empty(y.shape, dtype=H16, device=dz.device)
+            if ctx.has_res1 and ctx.needs_input_grad[5]:
+                dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
+            fused = _bn_bwd_fused(ctx, cfg, bank, dz, dz2, y, r1, gamma, ss, saved, dy, dres1, P, K, yf, nf, stride, zf0, zf1, ctx.call, st)
+        if cfg.bn is not None and not fused:
+            groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
+            partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
             L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,
                    saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, zf0, zf1, st)          # (r1 = the activation mask when res_mask)
             # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
@@ -567,17 +603,14 @@ class _ConvBNAct(torch.autograd.Function):
                 dist.all_reduce(total, group=group)
                 L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
                        dgp, dbp, L.ptr(coef), 1, nf, stride, _sn_dot(cfg, ctx.call, ctx.training, sync), st)
-            dy = torch.empty(y.shape, dtype=H16, device=dz.device)
-            if ctx.has_res1 and ctx.needs_input_grad[5]:
-                dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
             L.call('tcvom_bn_bwd_apply_mask' if ctx.res_mask else 'tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
                    L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
                    zf0, zf1, st)
-            if ctx.has_bias:
-                # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
-                # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
-                dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
-                L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P * nf, K, K, st)
+        if cfg.bn is not None and ctx.has_bias:
+            # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
+            # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
+            dbias = torch.empty(K, dtype=torch.float32, device=dz.device)
+            L.call('tcvom_colsum', L.ptr(dy), L.ptr(dbias), P * nf, K, K, st)
         dx = None
         if spec.needs_dgrad and ctx.needs_input_grad[0]:
             # zero-padded concat inputs (spec.cpad > spec.C): the gradient keeps the padded layout, zeros in the padding
