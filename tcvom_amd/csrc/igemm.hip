@@ -458,7 +458,7 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
 extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase) {
     if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
     if (const char* sv = sconv_variant(d, nphase)) return sv;
-    if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? "wsconv<64>" : "wsconv<128>";
+    if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? (d->ntaps == 18 ? "wsconv<64,18>" : "wsconv<64>") : "wsconv<128>";
     if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
     if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";

@@ -53,14 +53,20 @@ struct WsArgs {
     long long stats_bstride;
     int wslot[9];                 // weight slot of the canonical tap t = (dh + 1) * 3 + (dw + 1)
     int w_frag;                   // weights are fragment-major (tcvom_conv_desc.w_layout = 1)
+    int wres;                     // doubled taps: weight slot of the residual of tap t = wslot[t] + wres
     unsigned long long* trace;    // NULL, or 64 cycle stamps of workgroup 8 / wave 0 (tcvom_conv_trace_read, env TCVOM_CONV_TRACE)
 };
 #define WS_STAMP(i) if (tracing) a.trace[i] = __builtin_readcyclecounter()
 
 // compile-time geometry of one kernel configuration
-template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_>
+// NT_ = 18: the high-precision layers of the bf16 build (gca_net.py: HP_LAYERS) -- every tap twice, weight slot t (the 16-bit head of
+// the fp32 weight) and slot 9 + t (its 16-bit residual) on the SAME input pixels; OF32_: fp32 output (their conv results stay fp32
+// until the BatchNorm has been applied)
+template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int NT_ = 9, bool OF32_ = false>
 struct WsCfg {
-    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_;
+    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = NT_;
+    static constexpr bool OF32 = OF32_;
+    static constexpr int OB = OF32_ ? 4 : 2;                   // bytes per output element
     static constexpr int CU = C / 8, PIXB = C * 2;
     static constexpr int TH = PS * NI * FH, TW = FW, HW = TW + 2, HH = TH + 2, HPIX = HH * HW;
     static constexpr int NDMA = (HPIX * CU + 63) / 64;          // DMA wave-instructions (1 KiB each) per halo
@@ -68,7 +74,7 @@ struct WsCfg {
     static constexpr int SLOTB = NDMA * 1024;                   // bytes per halo buffer
     static constexpr int DUMPB = 1024;                          // where the DMA instructions past NDMA of the last round land
     static constexpr int NCC = C / 16;                          // 16-channel chunks per tap
-    static constexpr int NS = 9 * NCC;                          // k-steps (A fragments held by a wave)
+    static constexpr int NS = NT * NCC;                         // k-steps (A fragments held by a wave)
     static constexpr int PF = 2;                                // B fragments are requested PF k-steps ahead of their MFMAs
     // schedule of the work that rides on the MFMA stream of a tile: the halo DMA of the NEXT tile (DPS instructions per
     // k-step from step 0) and the epilogue of the PREVIOUS tile (NQ pieces spread over steps E0 .. E1 - 1)
@@ -78,14 +84,14 @@ struct WsCfg {
     static constexpr int E1 = NS - NS / 8;                      // the last stores get an eighth of the tile to complete
     // C = 128 (no registers to spare): the channel sums are reduced and stored per TILE by an extra piece per channel group
     // (its 40 DPP adds fit the MFMA shadow there); C = 64: 32 running sums per lane, reduced once per workgroup
-    static constexpr bool SPT = C_ == 128;
+    static constexpr bool SPT = C_ * NT_ == 128 * 9;            // 288 weight registers (C = 128, or C = 64 with doubled taps)
     static constexpr int NQG = NI + (SPT ? 1 : 0);              // pieces per channel group
     static constexpr int NQ = 4 * NQG;                          // epilogue pieces: 4 channel groups x (NI fragments (+ statistics))
     static constexpr int step_of(int q) { return E0 + q * (E1 - E0) / NQ; }
     // C = 128: 288 weight + 64 accumulator registers leave no room for a register copy of the previous tile's results: they
     // wait in LDS (16 KiB per wave, [quad q = fragment * 4 + group][lane] float4) and every fragment piece fetches its
     // float4 one k-step ahead with an inline-asm read that the hand-counted lgkmcnt waits include
-    static constexpr bool OLDS = C_ == 128;
+    static constexpr bool OLDS = SPT;
     static constexpr int XCHB = OLDS ? 4 * 16 * 1024 : 0;
     // fragment pieces scheduled AT k-step s (their LDS reads are issued in step s - 1)
     static constexpr int frag_pieces_at(int s) {
@@ -102,7 +108,8 @@ struct WsCfg {
         for (int u = s - PF; u < s; ++u) n += er(u) + (u > s - PF ? nb(u + PF) : 0);
         return n;
     }
-    static_assert(MF * PS == 4 && FH * FW == 32 && (C == 64 || C == 128), "unsupported configuration");
+    static_assert(MF * PS == 4 && FH * FW == 32 && (C == 64 || C == 128) && (NT == 9 || (NT == 18 && C == 64)), "unsupported configuration");
+    static constexpr int tap_of(int s) { return (s / NCC) % 9; }   // stencil position of k-step s (steps 9 NCC .. are the residual weights)
     static_assert(HW % 2 == 0, "halo rows must hold an even number of pixels (bank parity of 128-byte pixels)");
 };
 
@@ -230,9 +237,10 @@ __device__ __forceinline__ void ws_epi_piece(WsCtx<G>& c, const f32x4_t vals) {
             c.s1[sg][r] += vals[r];
             c.s2[sg][r] = fmaf(vals[r], vals[r], c.s2[sg][r]);
         }
-        const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * 2) + 16u * g : 0xffffffffu;
+        const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * G::OB) + (unsigned)(8 * G::OB) * g : 0xffffffffu;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2h(vals[0], vals[1]), pack2h(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
+        if constexpr (G::OF32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vals), c.orsrc, (int)o, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2h(vals[0], vals[1]), pack2h(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
     } else {
         float t[8];
 #pragma unroll
@@ -306,13 +314,13 @@ __device__ __forceinline__ void ws_epi_fetch(WsCtx<G>& c) {
 // (bbase[t % 3] ^ (cc << 5)) + buffer base, the row / column displacement of (fragment i, tap) as the immediate offset
 template <class G, int S, int I>
 __device__ __forceinline__ void ws_read(u32x4_t (&bq)[G::PF + 1][G::NI], unsigned ad) {
-    constexpr int t = S / G::NCC;
+    constexpr int t = G::tap_of(S);
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[S % (G::PF + 1)][I]) : "v"(ad), "n"(((I * G::FH + t / 3) * G::HW + t % 3) * G::PIXB));
     if constexpr (I + 1 < G::NI) ws_read<G, S, I + 1>(bq, ad);
 }
 template <class G, int S>
 __device__ __forceinline__ void ws_read_step(u32x4_t (&bq)[G::PF + 1][G::NI], const unsigned (&bbase)[3], unsigned lb) {
-    constexpr int t = S / G::NCC, cc = S % G::NCC;
+    constexpr int t = G::tap_of(S), cc = S % G::NCC;
     unsigned b = bbase[t % 3];
     asm volatile("" : "+v"(b));           // opaque: the 3 * NCC address variants are recomputed (2 VALU) instead of held in registers
     ws_read<G, S, 0>(bq, (b ^ (unsigned)(cc << 5)) + lb);
@@ -329,7 +337,7 @@ __device__ __forceinline__ void ws_prefetch(u32x4_t (&bq)[G::PF + 1][G::NI], con
 template <class G, int S, int I0, int I1>
 __device__ __forceinline__ void ws_read_some(u32x4_t (&bq)[G::PF + 1][G::NI], unsigned ad) {
     if constexpr (I0 < I1 && I0 < G::NI) {
-        constexpr int t = S / G::NCC;
+        constexpr int t = G::tap_of(S);
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[S % (G::PF + 1)][I0]) : "v"(ad), "n"(((I0 * G::FH + t / 3) * G::HW + t % 3) * G::PIXB));
         ws_read_some<G, S, I0 + 1, I1>(bq, ad);
     }
@@ -352,7 +360,7 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
     __builtin_amdgcn_sched_barrier(0);
     unsigned ad = 0;
     if constexpr (rd) {
-        constexpr int t = SN / G::NCC, cc = SN % G::NCC;
+        constexpr int t = G::tap_of(SN), cc = SN % G::NCC;
         unsigned b = bbase[t % 3];
         asm volatile("" : "+v"(b));       // opaque: the 3 * NCC address variants are recomputed (2 VALU) instead of held in registers
         ad = (b ^ (unsigned)(cc << 5)) + lb;
@@ -389,9 +397,9 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
     if constexpr (S + 1 < G::NS) ws_step<G, S + 1>(c, wr, acc, bq, bbase, lb);
 }
 
-template <int C, int MF, int PS, int NI, int FH, int FW>
+template <int C, int MF, int PS, int NI, int FH, int FW, int NT = 9, bool OF32 = false>
 __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
-    typedef WsCfg<C, MF, PS, NI, FH, FW> G;
+    typedef WsCfg<C, MF, PS, NI, FH, FW, NT, OF32> G;
     constexpr int TH = G::TH, TW = G::TW, HW = G::HW, PIXB = G::PIXB, CU = G::CU, NCC = G::NCC, NS = G::NS, SLOTB = G::SLOTB;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][SLOTB] halo, DUMPB, (+ XCHB bytes of results and the bias in the LDS form)
 
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
         c.ptile = (tile);                                                                                     \
         c.py0 = (rr_ / a.tiles_x) * TH + c.ps * NI * FH;                                                      \
         c.pgx = (rr_ % a.tiles_x) * TW + c.fx;                                                                \
-        c.pbase = (unsigned)((((c.frame * a.spf + (tile) / txy) * a.H + c.py0 + c.fy) * a.W + c.pgx) * a.ldo + c.mf * 32 + 4 * c.half) * 2u; \
+        c.pbase = (unsigned)((((c.frame * a.spf + (tile) / txy) * a.H + c.py0 + c.fy) * a.W + c.pgx) * a.ldo + c.mf * 32 + 4 * c.half) * (unsigned)G::OB; \
         c.has_prev = true;                                                                                    \
     }
     WS_SET_NEXT(t_begin, 0)
@@ -476,8 +484,8 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
         const h16raw* wsrc = a.wgt + (int64_t)c.frame * a.w_bstride;
         const int m = c.mf * 32 + col;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ws = a.wslot[t];
+        for (int t = 0; t < NT; ++t) {
+            const int ws = (t >= 9 && a.wslot[t % 9] >= 0) ? a.wslot[t % 9] + a.wres : a.wslot[t % 9];
 #pragma unroll
             for (int cc = 0; cc < NCC; ++cc) {
                 h16x8_t v = __builtin_bit_cast(h16x8_t, u32x4_t{0u, 0u, 0u, 0u});
@@ -584,14 +592,14 @@ extern "C" int tcvom_conv_trace_read(uint64_t* host, int32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-struct WsPlan { bool ok; int C, th, tw; int wslot[9]; };
+struct WsPlan { bool ok; int C, th, tw, nt, wres; int wslot[9]; };
 
 static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     WsPlan p;
     p.ok = false;
     static const bool disabled = getenv("TCVOM_NO_WSCONV") != nullptr;      // A/B switch (tools/igemm_bench.py, tests)
     if (disabled || nphase != 1) return p;
-    if (d->C != d->K || (d->C != 64 && d->C != 128) || d->ldo % 4 != 0 || d->out_fp32) return p;
+    if (d->C != d->K || (d->C != 64 && d->C != 128) || d->ldo % 4 != 0) return p;
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return p;
     if (d->PH != d->H || d->PW != d->W || d->OH != d->H || d->OW != d->W) return p;
     const int nb = d->batch > 1 ? d->batch : 1;
@@ -603,17 +611,28 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     //  together exceed it is split into runs of frames by wsconv_try_launch: fragment-major weights have no other kernel)
     if ((long long)d->N * d->H * d->W * d->C >= (1ll << 31) || (long long)d->N * d->H * d->W * d->ldo >= (1ll << 31)) return p;
     for (int t = 0; t < 9; ++t) p.wslot[t] = -1;
-    int n = 0;
+    int n = 0, n2 = 0;
+    p.wres = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         if (d->tap_w[t] < 0) continue;
         const int dh = d->tap_dh[t], dw = d->tap_dw[t];
         if (dh < -1 || dh > 1 || dw < -1 || dw > 1) return p;
         const int c = (dh + 1) * 3 + (dw + 1);
-        if (p.wslot[c] >= 0) return p;                  // a doubled tap list (high-precision layers) stays on the igemm
+        if (p.wslot[c] >= 0) {
+            // a doubled tap list (the high-precision layers of the bf16 build, conv_plan.py: slot ws = the 16-bit head of the
+            // weight, slot wt / 2 + ws = its residual): the 64-channel layers run the 18-tap instantiation
+            static const bool no18 = getenv("TCVOM_NO_WSCONV18") != nullptr;          // A/B switch
+            if (no18 || d->C != 64 || d->w_layout != 0 || d->wt != 18 || d->tap_w[t] != p.wslot[c] + 9) return p;
+            p.wres = 9;
+            ++n2;
+            continue;
+        }
         p.wslot[c] = d->tap_w[t];
         ++n;
     }
-    if (n != 9) return p;
+    if (n != 9 || (n2 != 0 && n2 != 9)) return p;
+    p.nt = n2 ? 18 : 9;
+    if (p.nt == 9 && d->out_fp32) return p;             // (fp32 results are built for the doubled-tap instantiation only)
     p.C = d->C;
     p.th = 8;
     p.tw = d->C == 64 ? 32 : 16;
@@ -621,6 +640,9 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     // the weights are packed for this kernel
     if (d->w_layout == 0 && (d->H < p.th / 2 || d->W < p.tw / 2)) return p;
     if (d->w_layout != 0 && (d->w_layout != 1 || d->wt != 9)) return p;
+    if (p.nt == 18) {                                   // fp32 byte offsets of one frame in 32 bits
+        if ((long long)d->N * d->H * d->W * d->ldo >= (1ll << 30)) return p;
+    }
     p.ok = true;
     return p;
 }
@@ -645,7 +667,8 @@ int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase) {
     if (!p.ok) return 0;
     int tpf, tpw, wpf;
     ws_grid(d, p, &tpf, &tpw, &wpf);
-    return p.C == 128 ? tpf : wpf * ws_ps(p);             // C = 128: one group per tile; C = 64: one per (workgroup, pixel group)
+    // C = 128 / doubled taps: one group per (tile, pixel group); C = 64: one per (workgroup, pixel group)
+    return (p.C == 128 || p.nt == 18) ? tpf * ws_ps(p) : wpf * ws_ps(p);
 }
 
 // returns 1 when the conv was launched here, 0 when the caller should use another kernel, < 0 on error
@@ -670,10 +693,12 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     a.stats_group_offset = d->stats_group_offset;
     a.stats_bstride = nb > 1 ? d->stats_bstride : 0;
     for (int t = 0; t < 9; ++t) a.wslot[t] = p.wslot[t];
+    a.wres = p.wres;
     a.w_frag = d->w_layout == 1;
     a.trace = ws_trace_buffer();
     ws_grid(d, p, &a.tiles_per_frame, &a.tiles_per_wg, &a.wgs_per_frame);      // (from the WHOLE batch: the statistics layout the caller sized)
-    const long long gpf = p.C == 128 ? a.tiles_per_frame : (long long)a.wgs_per_frame * ws_ps(p);
+    const long long gpf = (p.C == 128 || p.nt == 18) ? (long long)a.tiles_per_frame * ws_ps(p) : (long long)a.wgs_per_frame * ws_ps(p);
+    const int ob = d->out_fp32 ? 4 : 2;
     if (stats && nb > 1 && d->stats_bstride < gpf)
         return tcvom_fail(TCVOM_ERR_ARG, "wsconv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);
     {
@@ -686,7 +711,7 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     // frames per launch: the buffer descriptors of the kernel address 32-bit byte ranges -- a batch whose frames together reach
     // 2^31 elements goes out as runs of frames (same tiles, same statistics groups per frame)
     const long long frame_elems = (long long)d->N * d->H * d->W * (d->C > d->ldo ? d->C : d->ldo);
-    long long fmax = ((1ll << 31) - 1) / (frame_elems > 0 ? frame_elems : 1);
+    long long fmax = ((1ll << (d->out_fp32 ? 30 : 31)) - 1) / (frame_elems > 0 ? frame_elems : 1);
     static const int test_fmax = getenv("TCVOM_WS_MAX_FRAMES") ? atoi(getenv("TCVOM_WS_MAX_FRAMES")) : 0;      // (tests: force the split)
     if (test_fmax > 0 && test_fmax < fmax) fmax = test_fmax;
     if (fmax < 1) fmax = 1;
@@ -695,13 +720,25 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
         const int nf = nb - f0 < fmax ? nb - f0 : (int)fmax;
         a = base;
         a.in = base.in + (long long)f0 * d->N * d->H * d->W * d->C;
-        a.out = (char*)base.out + (long long)f0 * d->N * d->H * d->W * d->ldo * 2;
+        a.out = (char*)base.out + (long long)f0 * d->N * d->H * d->W * d->ldo * ob;
         a.wgt = base.wgt + (long long)f0 * base.w_bstride;
         a.stats_group_offset = base.stats_group_offset + (int)((long long)f0 * base.stats_bstride);
-        a.out_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->ldo * 2);
+        a.out_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->ldo * ob);
         a.in_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->C * 2);
         const dim3 grid(a.wgs_per_frame * nf);
-        if (p.C == 64) {
+        if (p.C == 64 && p.nt == 18) {
+            typedef WsCfg<64, 2, 2, 4, 1, 32, 18, true> G18;
+            constexpr size_t lds_bytes = 2 * G18::SLOTB + 1024 + G18::XCHB + 128 * 4;
+            static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+            static bool attr = false;
+            if (!attr) {
+                e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr = true;
+            }
+            if (d->out_fp32) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, true>), grid, dim3(256), lds_bytes, st, a);
+            else hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, false>), grid, dim3(256), lds_bytes, st, a);
+        } else if (p.C == 64) {
             auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32>;
             constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
             static bool attr = false;

@@ -548,6 +548,67 @@ def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
     ck.done()
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 20, 44), (1, 48, 64), (1, 13, 37)])
+def test_wsconv_kernel_doubled_taps(N, H, W):
+    """The high-precision 64 -> 64 layers of the bf16 build (gca_net.py HP_LAYERS: encoder layer1; every tap twice -- the 16-bit head of
+    the fp32 weight and its 16-bit residual -- and an fp32 conv output) on the weight-stationary kernel's 18-tap instantiation
+    (csrc/wsconv.hip: WsCfg<64, .., 18, OF32>): raw kernel in both output types against fp32 PyTorch with the UNROUNDED weight
+    (hi + residual reproduce it to ~2^-16, so the bound is tight), batch statistics per tile, then conv + BatchNorm + ReLU and the
+    gradients through the op."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd import ops
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    cin = 64
+    tag = 'ws18_%d_%d_%d' % (N, H, W)
+    w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cin, cin, 3, 3)) * 0.2).to(DEV))
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, None, None, None, False, 1, 1, 'frame', hp=True)
+    bank.register(spec)
+    geo = ConvGeometry(spec, N, H, W)
+    assert geo.fwd[0].ntaps == 18
+    assert L._FNS['tcvom_conv_igemm_variant'](C.byref(geo.fwd[0]), 1).decode() == 'wsconv<64,18>'
+    bn = nn.BatchNorm2d(cin).to(DEV)
+    cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
+    x = hu('x.' + tag, (N, cin, H, W)) - 0.5
+    xg = nhwc(x).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    z = ops.conv_bn_act(cfg, xg, token, True)
+    bank.flush_bn_counters()
+    xr = bf(x).requires_grad_(True)
+    wf = spec.weight.detach().cpu()
+    wr = wf.clone().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, wr, None, 1, 1))
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    zr = (yr - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.rel('running_mean', bn.running_mean, 0.1 * mean.detach(), 1e-3)
+    n_el = yr.numel() // cin
+    ck.rel('running_var', bn.running_var, 0.9 + 0.1 * var.detach() * n_el / (n_el - 1), 1e-3)
+    gz = hu('gz.' + tag, tuple(zr.shape)) - 0.5
+    (z.float() * nhwc(gz).float()).sum().backward()
+    (zr * bf(gz)).sum().backward()
+    ck.rel('dx', nchw(xg.grad), xr.grad, 4e-2)
+    ck.rel('dw', spec.weight.grad, wr.grad, 3e-2)
+    ck.done()
+    # raw kernel: fp32 and 16-bit results, with and without the statistics epilogue
+    st = L.stream_ptr()
+    yref = F.conv2d(bf(x), wf, None, 1, 1)
+    groups = ops._stats_groups(geo.fwd, 1)
+    y32 = torch.empty(N, H, W, cin, device=DEV, dtype=torch.float32)
+    stats = torch.full((groups * 2 * cin,), float('nan'), device=DEV, dtype=torch.float32)
+    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y32, None, stats, 0, st)
+    assert rel_err(nchw(y32), yref) < 2e-5, rel_err(nchw(y32), yref)
+    sums = stats.view(groups, 2, cin).double().sum(0).cpu()
+    assert torch.isfinite(sums).all()
+    assert rel_err(sums[0], yref.double().sum((0, 2, 3))) < 1e-5 and rel_err(sums[1], (yref.double() ** 2).sum((0, 2, 3))) < 1e-5
+    y16 = torch.empty(N, H, W, cin, device=DEV, dtype=H16)
+    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y16, None, None, 1, st)
+    assert rel_err(nchw(y16), F.relu(yref)) < 6e-3
+
+
 @pytest.mark.parametrize('cin,cout,dil,N,H,W,S', [(256, 256, 2, 1, 16, 24, 3), (512, 512, 4, 1, 16, 32, 1), (64, 64, 2, 2, 10, 18, 2),
                                                   (128, 32, 4, 1, 32, 64, 1), (128, 64, 2, 2, 34, 44, 1), (64, 128, 3, 1, 27, 30, 4)])
 def test_wgrad_ws_kernel_dilated(cin, cout, dil, N, H, W, S):
