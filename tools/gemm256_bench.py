@@ -86,6 +86,9 @@ def main():
          lambda: L.call('tcvom_gca_scores_exp', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(Pn), L.ptr(stats), N, D, ld, B, st)),
         ('softmax rescale pass', 0.0, lambda: L.call('tcvom_gca_softmax_rescale', L.ptr(Pn), L.ptr(stats), N, ld, B, st)),
         ('O = P V  (V k-major)', 2.0 * B * N * N * DV, lambda: L.call('tcvom_gca_pv', L.ptr(P), L.ptr(V), L.ptr(O), N, DV, ld, B, st)),
+        ('T = softmax bwd (T alone)', 2.0 * B * N * N * DV,
+         lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(V), L.ptr(P), L.ptr(delta), L.ptr(cvec), L.ptr(T), None, None,
+                        N, DV, ld, B, st)),
         ('dV = P^T dO (k-major)', 2.0 * B * N * N * DV, lambda: L.call('tcvom_gca_dv', L.ptr(P), L.ptr(dO), L.ptr(dV), N, DV, ld, B, st)),
         ('dq + dk (two launches)', 4.0 * B * N * N * D, lambda: L.call('tcvom_gca_dq_dk', L.ptr(P), L.ptr(Gt), L.ptr(dW), L.ptr(Mp), N, D, ld, B, st)),
     ]
