@@ -300,13 +300,17 @@ def test_reference_ddp_lines_equal_tcvom_ddp_path(tmp_path, transport):
     for rank in range(2):
         r = torch.load(out + str(rank))
         print(transport, rank, r)
-        # floors at the observed run-to-run scale of the SAME path (atomics order -> ReLU mask flips): alpha mse 3-6e-7, gradient-norm
-        # ratio 1 +- 0.2 .. 0.7 %, cosine 0.976 .. 0.985.  The reference distance (b vs c) is itself a sample: a lucky near-zero one
-        # must not turn the bound into a tighter one than the path can meet against itself
-        assert r['mse_ab'] <= max(3 * r['mse_bc'], 2e-6) and r['mse_ab'] <= 1e-4, r        # alphas: within the run-to-run distance
+        # floors at the observed run-to-run scale of the SAME path (atomics order -> ReLU mask flips) on this noise-amplifying network
+        # (the tight, absolute bounds live in the conditioned-network test below).  fp16 build: alpha mse 3-6e-7, gradient-norm ratio
+        # 1 +- 0.2 .. 0.7 %, cosine 0.976 .. 0.985.  bf16 build, 16 runs of each transport on one box (round 5): alpha mse 1.1-2.3e-5 for
+        # BOTH distances, norm ratio 1 +- 2.2 % (a-b) / 1.6 % (b-c), cosine 0.856 .. 0.902, statistics error 1.8-3.6e-3 -- the fp16 floors
+        # sat at ~1 sigma of that spread (one failure in ~20 runs of the suite).  The reference distance (b vs c) is itself a sample: a
+        # lucky near-zero one must not turn the bound into a tighter one than the path can meet against itself
+        from helpers import tol
+        assert r['mse_ab'] <= max(3 * r['mse_bc'], tol(5e-5, 2e-6)) and r['mse_ab'] <= 1e-4, r        # alphas: within the run-to-run distance
         assert r['cos_ab'] >= min(0.97, 1 - 3 * (1 - r['cos_bc'])) - 1e-4, r               # whole-network gradient direction
-        assert abs(r['norm_ab'] - 1) <= max(3 * abs(r['norm_bc'] - 1), 1.5e-2), r
-        assert r['serr_ab'] <= max(3 * r['serr_bc'], 1e-5), r                              # BatchNorm running statistics
+        assert abs(r['norm_ab'] - 1) <= max(3 * abs(r['norm_bc'] - 1), tol(5e-2, 1.5e-2)), r
+        assert r['serr_ab'] <= max(3 * r['serr_bc'], tol(8e-3, 1e-5)), r                   # BatchNorm running statistics
         assert r['ranks_agree'] == 0.0, r
 
 
