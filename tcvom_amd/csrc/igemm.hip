@@ -424,6 +424,11 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
 int gemm_tt256_try_launch(const void* dy, const void* x, float* dw, const tcvom_conv_desc* d, int ldy, void* stream, int nb,
                           long long dy_stride, long long x_stride, long long dw_stride);
 int gemm_tt256_takes(const tcvom_conv_desc* d);
+// pwconv.hip: weight-stationary streaming 1x1 conv for the reduction-poor pointwise layers (C <= 512)
+int pwconv_stats_groups(const tcvom_conv_desc* d, int nphase);
+const char* pwconv_variant(const tcvom_conv_desc* d, int nphase);
+int pwconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
+                      float* stats, const tcvom_conv_desc* d, int nphase, void* stream);
 // gemm256.hip: staggered two-group 256x256 dense GEMM for the attention GEMMs of GCA
 int gemm_nt256_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                           const tcvom_conv_desc* d, const h16raw* zero_page, void* stream, const void* in2, void* out2,
@@ -446,6 +451,8 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
     if (sg > 0) return sg;
     const int wg = wsconv_stats_groups(d, nphase);
     if (wg > 0) return wg;
+    const int pg = pwconv_stats_groups(d, nphase);
+    if (pg > 0) return pg;
     // (a 1 x 1 conv on the dense 256-tile GEMM writes its statistics itself; a caller that also passes a bias gets the implicit GEMM,
     //  whose 256 x 256 tiling has the same group count)
     if (nphase == 1 && d->w_layout == 0 && gemm_nt256_takes_stats(d)) return gemm_nt256_stats_groups(d);
@@ -459,6 +466,7 @@ extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_
     if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
     if (const char* sv = sconv_variant(d, nphase)) return sv;
     if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? (d->ntaps == 18 ? "wsconv<64,18>" : "wsconv<64>") : "wsconv<128>";
+    if (const char* pv = pwconv_variant(d, nphase)) return pv;
     if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
     if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";
@@ -515,6 +523,10 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     }
     {
         const int r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        if (r != 0) return r < 0 ? r : TCVOM_OK;
+    }
+    {
+        const int r = pwconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     TCVOM_CHECK_ARG(d0->w_layout == 0, "conv_igemm: fragment-major weights (w_layout = 1) are only served by the weight-stationary kernel");

@@ -548,6 +548,71 @@ def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
     ck.done()
 
 
+PWCONV_CASES = [
+    # cin, cout, N, H, W, bias      (pixels per frame >= 1024; sizes that are not multiples of the 32 .. 256-pixel tiles mask the tail)
+    (64, 128, 1, 40, 72, False), (128, 64, 2, 24, 33, True), (128, 128, 1, 37, 53, False), (32, 64, 1, 64, 96, True),
+    (64, 32, 1, 50, 70, False), (256, 128, 1, 34, 60, False), (128, 256, 2, 20, 31, True), (256, 512, 1, 34, 60, False),
+    (512, 256, 1, 34, 60, False), (64, 256, 1, 48, 80, False), (256, 1024, 1, 36, 44, True), (512, 2048, 1, 32, 40, False),
+    (32, 32, 1, 40, 40, False), (256, 64, 1, 33, 47, False),
+]
+
+
+@pytest.mark.parametrize('cin,cout,N,H,W,bias', PWCONV_CASES)
+def test_pwconv_kernel(cin, cout, N, H, W, bias):
+    """Shapes served by the weight-stationary streaming 1x1 conv (csrc/pwconv.hip: one tap, stride 1, C in {32 .. 512}): forward with
+    fused ReLU + batch statistics (+ bias), data gradient (the transposed 1x1 shape, through the same kernel where it qualifies) and
+    weight gradient, against fp32 PyTorch on the same 16-bit operands; then the raw kernel, tight, with its statistics groups."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd import ops
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    tag = 'pw%d_%d_%d_%d_%d' % (cin, cout, N, H, W)
+    w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cout, cin, 1, 1)) * 0.3).to(DEV))
+    b = nn.Parameter(formula_tensor('conv.%s.bias' % tag, (cout,)).to(DEV)) if bias else None
+    bank = WeightBank()
+    spec = ConvSpec(tag, w, None, None, b, False, 1, 0, 'frame')
+    bank.register(spec)
+    geo = ConvGeometry(spec, N, H, W)
+    assert L._FNS['tcvom_conv_igemm_variant'](C.byref(geo.fwd[0]), 1).decode().startswith('pwconv<%d,' % cin)
+    bn = nn.BatchNorm2d(cout).to(DEV)
+    cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
+    x = hu('x.' + tag, (N, cin, H, W)) - 0.5
+    xg = nhwc(x).requires_grad_(True)
+    token = bank_token(bank, 1, True)
+    z = ops.conv_bn_act(cfg, xg, token, True)
+    bank.flush_bn_counters()
+    xr = bf(x).requires_grad_(True)
+    wr = bf(spec.weight.detach().cpu()).clone().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, wr, b.detach().cpu() if bias else None, 1, 0))
+    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
+    yq = yr + (bf(yr) - yr).detach()
+    zr = (yq - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
+    ck = Checker()
+    ck.rel('z', nchw(z), zr, 2e-2)
+    ck.rel('running_mean', bn.running_mean, 0.1 * mean.detach(), 1e-2)
+    n_el = yr.numel() // cout
+    ck.rel('running_var', bn.running_var, 0.9 + 0.1 * var.detach() * n_el / (n_el - 1), 1e-2)
+    gz = hu('gz.' + tag, tuple(zr.shape)) - 0.5
+    (z.float() * nhwc(gz).float()).sum().backward()
+    (zr * bf(gz)).sum().backward()
+    ck.rel('dx', nchw(xg.grad), xr.grad, 4e-2)
+    ck.rel('dw', spec.weight.grad, wr.grad, 3e-2)
+    ck.done()
+    # raw kernel: tight against fp32 on the same 16-bit operands (only the output rounding and the summation order differ), the
+    # statistics groups against the unrounded results
+    st = L.stream_ptr()
+    yref = F.conv2d(bf(x), bf(spec.weight.detach().cpu()), b.detach().cpu() if bias else None, 1, 0)
+    groups = ops._stats_groups(geo.fwd, 1)
+    y16 = torch.empty(N, H, W, cout, device=DEV, dtype=H16)
+    stats = torch.full((groups * 2 * cout,), float('nan'), device=DEV, dtype=torch.float32)
+    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y16, b, stats, 0, st)
+    assert rel_err(nchw(y16), yref) < 6e-3
+    sums = stats.view(groups, 2, cout).double().sum(0).cpu()
+    assert torch.isfinite(sums).all()
+    assert rel_err(sums[0], yref.double().sum((0, 2, 3))) < 1e-4 and rel_err(sums[1], (yref.double() ** 2).sum((0, 2, 3))) < 1e-4
+
+
 @pytest.mark.parametrize('N,H,W', [(2, 20, 44), (1, 48, 64), (1, 13, 37)])
 def test_wsconv_kernel_doubled_taps(N, H, W):
     """The high-precision 64 -> 64 layers of the bf16 build (gca_net.py HP_LAYERS: encoder layer1; every tap twice -- the 16-bit head of
