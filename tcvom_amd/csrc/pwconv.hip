@@ -27,6 +27,9 @@
 typedef __attribute__((ext_vector_type(4))) unsigned int pw_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int pw_u32x2_t;
 typedef __attribute__((address_space(3))) void* pw_lptr_t;
+#ifndef PW_DMA_AT_HEAD
+#define PW_DMA_AT_HEAD 0      // study builds: 1 = the next tile's DMA instructions in one burst behind the barrier
+#endif
 
 struct PwArgs {
     const h16raw* in;
@@ -47,8 +50,9 @@ template <int C, int MF>
 struct PwCfg {
     static constexpr int PS = 4 / MF;                            // pixel groups: wave = (mf, ps)
     static constexpr int CU = C / 8, PIXB = C * 2, NCC = C / 16;
-    static constexpr int TP = C <= 64 ? 256 : 16384 / C;         // pixels per tile
-    static constexpr int TB = TP * PIXB;                         // bytes per tile buffer (16 KiB for C = 32, else 32 KiB)
+    static constexpr int TP0 = C <= 64 ? 256 : 16384 / C;
+    static constexpr int TP = TP0 < 128 * PS ? TP0 : 128 * PS;   // pixels per tile: <= 32 KiB and <= 4 fragments per wave
+    static constexpr int TB = TP * PIXB;                         // bytes per tile buffer
     static constexpr int NI = TP / 32 / PS;                      // 32-pixel fragments per wave and tile
     static constexpr int NDMA = TB / 1024 / 4;                   // DMA wave-instructions per wave and tile
     static constexpr int NST = NI * 2;                           // store instructions per wave and tile
@@ -89,21 +93,21 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
 
     // ---- DMA of one tile: instruction j of this wave covers the 64 16-byte units (j * 4 + wave) * 64 .. of the tile buffer; unit u =
     // (pixel u / CU, slot u % CU) holds chunk slot ^ f(pixel).  Out-of-frame pixels use an out-of-range offset: zeros.
-    auto issue_tile = [&](int tile, int buf) {
-        const int p0 = tile * TP;
-#pragma unroll
-        for (int j = 0; j < G::NDMA; ++j) {
-            const int u = (j * 4 + wave) * 64 + lane, p = u / CU, s = u % CU;
-            const int c8 = s ^ G::swz(p);
-            const unsigned off = (p0 + p < a.P) ? (unsigned)(((p0 + p) * C + c8 * 8) * 2) : 0xffffffffu;
+    // p0 < 0: nothing to fetch (the slot of a tile past the run: zeros into the idle buffer, no branch in the MFMA stream)
+    auto issue_piece = [&](int p0, int buf, int j) {
+        const int u = (j * 4 + wave) * 64 + lane, p = u / CU, s = u % CU;
+        const int c8 = s ^ G::swz(p);
+        const unsigned off = (p0 >= 0 && p0 + p < a.P) ? (unsigned)(((p0 + p) * C + c8 * 8) * 2) : 0xffffffffu;
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(irsrc, (pw_lptr_t)(lds + buf * TB + (j * 4 + wave) * 1024), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(irsrc, (pw_lptr_t)(lds + buf * TB + (j * 4 + wave) * 1024), 16, (int)off, 0, 0, 0);
 #else
-            (void)off;
+        (void)off;
 #endif
-        }
     };
-    if (t_begin < t_end) issue_tile(t_begin, 0);
+    if (t_begin < t_end) {
+#pragma unroll
+        for (int j = 0; j < G::NDMA; ++j) issue_piece(t_begin * TP, 0, j);
+    }
 
     // ---- weights -> registers: A fragment cc = rows kbase + col, channels cc * 16 + half * 8 .. + 7
     h16x8_t wr[NCC];
@@ -143,7 +147,16 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
         if (tile == t_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NST) : "memory");
         __builtin_amdgcn_s_barrier();               // tile landed for every wave; every wave is done reading the other buffer
-        if (tile + 1 < t_end) issue_tile(tile + 1, buf ^ 1);
+#if PW_DMA_AT_HEAD
+        {
+            const int np0h = tile + 1 < t_end ? (tile + 1) * TP : -1;
+#pragma unroll
+            for (int j = 0; j < G::NDMA; ++j) issue_piece(np0h, buf ^ 1, j);
+        }
+#endif
+        // the DMA instructions of the next tile ride between the MFMAs of this one (an LDS-DMA instruction holds its wave's issue
+        // for ~100 cycles: all of them at the head of the tile were NDMA x 100 cycles in which this wave fed no MFMA)
+        const int np0 = tile + 1 < t_end ? (tile + 1) * TP : -1;
         f32x16_t acc[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] = binit;
@@ -153,6 +166,13 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
             const int so = ((cc * 2 + half) ^ bswz) << 4;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
+                constexpr int TOTAL = NCC * NI;
+                const int m = cc * NI + i;                       // (compile-time after unrolling)
+#if !PW_DMA_AT_HEAD
+#pragma unroll
+                for (int j = 0; j < G::NDMA; ++j)
+                    if (m == (j * TOTAL) / G::NDMA + (TOTAL >= 2 * G::NDMA ? 1 : 0)) issue_piece(np0, buf ^ 1, j);
+#endif
                 const h16x8_t b = *reinterpret_cast<const h16x8_t*>(bt + i * 32 * PIXB + so);
                 acc[i] = mfma16(wr[cc], b, acc[i], 0, 0, 0);
             }
@@ -222,6 +242,7 @@ static PwPlan pw_plan(const tcvom_conv_desc* d, int nphase) {
     p.ps = 4 / p.mf;
     p.tp = C <= 64 ? 256 : 16384 / C;
     if (p.tp < 32 * p.ps) return p;                       // (C = 256 with K = 32, C = 512 with K < 128: no instantiation)
+    if (p.tp > 128 * p.ps) p.tp = 128 * p.ps;             // (PwCfg::TP)
     const long long P = (long long)d->N * d->H * d->W;
     static const int minp = getenv("TCVOM_PWCONV_MINP") ? atoi(getenv("TCVOM_PWCONV_MINP")) : 1024;     // study knob
     if (P < minp || P * C >= (1ll << 30) || P * d->ldo >= (1ll << 30)) return p;        // 32-bit byte offsets inside a frame
