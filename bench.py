@@ -166,7 +166,7 @@ def igemm_profile(step_fn):
             tam[desc['variant']] = (n + 1, t + ms, b + desc['bytes'])
             continue
         real_taps = sum(1 for t in range(desc['ntaps']) if desc['tap_w'][t] >= 0)
-        gflop = 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
+        gflop = desc['gflop'] if 'gflop' in desc else 2.0 * desc['P'] * desc['K'] * real_taps * desc['C'] * max(desc['batch'], 1) / 1e9
         var = desc['variant']                       # the instantiation the library selected for this shape
         n, t, g = agg.get(var, (0, 0.0, 0.0))
         agg[var] = (n + 1, t + ms, g + gflop)

@@ -119,6 +119,14 @@ int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, floa
 int tcvom_wgrad_ws_multi(const void* const* dy, const void* const* in, float* const* dw, int32_t nprob,
                          const tcvom_conv_desc* d, int32_t ldy, void* stream);
 int32_t tcvom_wgrad_ws_max_problems(void);
+/* The same for problems of up to tcvom_wgrad_ws_max_geometries() DIFFERENT geometries in one launch: problem i is a convolution
+ * like descs[geo_index[i]] (dy pixel stride = its K).  All geometries must share the channel window of the kernel (C a multiple of
+ * 128 for all of them, or for none) and the tap -> weight-slot map.  The atomic flush of the accumulators costs a launch the same
+ * ~45 us however few problems it has, so the layers whose shape occurs only 1 - 9 times in a window (the channel-changing convs of
+ * resnet_enc.py:76-84 / resnet_dec.py:61-72) ride in the launch of the big groups.  TCVOM_ERR_ARG for other shapes. */
+int tcvom_wgrad_ws_hetero(const void* const* dy, const void* const* in, float* const* dw, int32_t nprob,
+                          const tcvom_conv_desc* descs, int32_t ngeo, const int32_t* geo_index, void* stream);
+int32_t tcvom_wgrad_ws_max_geometries(void);
 
 /* ------------------------------------------------------------------ depthwise 3x3 (IndexNet / MobileNetV2 blocks)
  * Replaces nn.Conv2d(C, C, 3, 1, padding, dilation, groups=C, bias=False) of models/Index/net.py:38-61 (InvertedResidual, run

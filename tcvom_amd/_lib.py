@@ -226,10 +226,12 @@ _PROTOS = {
     'tcvom_dw3x3': [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_dw3x3_wgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_max_problems': [],
+    'tcvom_wgrad_ws_hetero': [vp, vp, vp, i32, DP, i32, vp, vp],
+    'tcvom_wgrad_ws_max_geometries': [],
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_bn_bwd_groups_n', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
-          'tcvom_wgrad_ws_max_problems', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks',
+          'tcvom_wgrad_ws_max_problems', 'tcvom_wgrad_ws_max_geometries', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks',
           'tcvom_adaptive_avgpool_scratch_floats', 'tcvom_bn_bwd_fused_workspace_bytes', 'tcvom_bn_bwd_fused'}
 
 # entry points that return a string
@@ -285,6 +287,20 @@ def _profiled(name, args):
     if name == 'tcvom_wgrad_ws_multi':
         d, n, nb = args[4][0], 1, args[3]
         info = {'P': d.N * d.PH * d.PW, 'K': d.K, 'C': d.C, 'ntaps': 9, 'tap_w': [0] * 9, 'batch': nb, 'phases': 1}
+    elif name == 'tcvom_wgrad_ws_hetero':
+        # problems of several geometries in one launch: explicit totals (the per-shape formula of the readers does not apply)
+        nb, descs, gidx = args[3], args[4], C.cast(args[6], C.POINTER(C.c_int32))
+        gs = [descs[gidx[i]] for i in range(nb)]
+        d = descs[0]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = _FNS[name](*args)
+        e1.record()
+        PROFILE.append((name, {'P': sum(g.N * g.PH * g.PW for g in gs) // nb, 'K': d.K, 'C': d.C, 'ntaps': 9, 'tap_w': [0] * 9, 'batch': nb,
+                               'phases': 1, 'variant': _FNS['tcvom_wgrad_igemm_variant'](C.byref(d)).decode() + '+%dgeo' % args[5],
+                               'gflop': sum(2.0 * g.N * g.PH * g.PW * g.K * 9 * g.C for g in gs) / 1e9,
+                               'algo_bytes': sum(2 * g.N * g.H * g.W * (g.C + g.K) + 4 * g.K * g.C * 9 for g in gs)}, e0, e1))
+        return rc
     elif name == 'tcvom_wgrad_igemm_batched':
         arr, n, nb = args[4], args[5], args[3]
         d = arr[0]
@@ -380,7 +396,7 @@ def call(name, *args):
     if PROFILE is not None and name in ('tcvom_tam_fwd', 'tcvom_tam_bwd'):
         rc = _profiled_tam(name, args)
     elif PROFILE is not None and name in ('tcvom_conv_igemm', 'tcvom_wgrad_igemm', 'tcvom_conv_igemm_phases', 'tcvom_wgrad_igemm_phases',
-                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi', 'tcvom_gemm_pair', 'tcvom_gca_dp_softmax_bwd',
+                                        'tcvom_wgrad_igemm_batched', 'tcvom_wgrad_ws_multi', 'tcvom_wgrad_ws_hetero', 'tcvom_gemm_pair', 'tcvom_gca_dp_softmax_bwd',
                                         'tcvom_gca_scores_exp', 'tcvom_gca_dv', 'tcvom_gca_pv', 'tcvom_gca_dq_dk'):
         rc = _profiled(name, args)
     else:

@@ -25,18 +25,28 @@ typedef __attribute__((address_space(3))) void* wg_lptr_t;
 #define WG_ABL 0          // kernel ablations for timing (1: no atomics, 2: no DMA inside the tile loop); 0 in the product
 #endif
 
-#define WG_MAX_PROBLEMS 112                // 3 pointer arrays of this length stay inside the 4 KiB kernel-argument segment
-struct WgArgs {
-    const h16raw* dy[WG_MAX_PROBLEMS];
-    const h16raw* in[WG_MAX_PROBLEMS];
-    float* dw[WG_MAX_PROBLEMS];
+// One launch serves problems of up to WG_MAX_GEO different geometries (same channel window CWIN): the atomic flush of the
+// accumulators costs a launch ~45 us whatever its length (every workgroup adds 1 - 2 blocks of 295 KB), so the layers with a
+// geometry of their own (the channel-changing convs of a trunk: 3 - 9 problems per launch, 105 - 150 us each at 180 - 570 TFLOP/s)
+// ride in the launch of the big groups instead.
+#define WG_MAX_PROBLEMS 96                 // 3 pointer arrays + the tables below stay inside the 4 KiB kernel-argument segment
+#define WG_MAX_GEO 8
+struct WgGeo {
     int N, H, W, C, K, wt;                 // N, H, W: the samples the tiles walk over -- for a dilation-d conv the N * d * d sub-grids
                                            // (pixels of one residue class mod d) of H / d x W / d pixels, each a dilation-1 problem
     int dil, Hf, Wf;                       // dilation; the full image (pixel (y, x) of sub-grid (sy, sx) is (sy + y dil, sx + x dil))
     int tiles_x, tiles_y, ntiles;          // pixel tiles of one problem (N * tiles_y * tiles_x)
     int kgroups, cgroups;                  // K / 64, C / CWIN: the (k, c) blocks of dw
-    int total, per_wg;                     // length of the (problem, block, tile) sequence and the run of one workgroup
     unsigned dy_bytes, in_bytes;
+};
+struct WgArgs {
+    const h16raw* dy[WG_MAX_PROBLEMS];
+    const h16raw* in[WG_MAX_PROBLEMS];
+    float* dw[WG_MAX_PROBLEMS];
+    int qend[WG_MAX_PROBLEMS];             // end of problem i in the flat (problem, block, tile) sequence
+    unsigned char geo_of[WG_MAX_PROBLEMS]; // its geometry
+    WgGeo geo[WG_MAX_GEO];
+    int nprob, total, per_wg;              // length of the sequence and the run of one workgroup
     int wslot[9];                          // dw slot of the canonical tap t = (dh + 1) * 3 + (dw + 1)
 };
 
@@ -86,6 +96,7 @@ __device__ __forceinline__ void wg_read_a(TrFrag& f, unsigned ya) {
 }
 
 struct WgDma {                   // per-wave state of the tile being fetched
+    int H, W;                    // image (sub-grid) size of its problem
     int ym, xm;                  // tile origin (y0, x0); the x halo starts one pixel up / left
     unsigned xbase, ybase;       // byte offset of halo pixel (0, 0) channel cbase / of tile pixel (0, 0) channel kbase
     int slot;
@@ -95,7 +106,7 @@ struct WgDma {                   // per-wave state of the tile being fetched
 // unit relative to the image's first pixel, pk[IT] = (row << 16 | column) inside the image for the bounds test (row 0x7fff:
 // padding unit, never loaded).  Unit u = (IT*NW + wave)*64 + lane; units [0, XU) are the x halo, then the dy tile.
 template <class G>
-__device__ __forceinline__ void wg_dma_map(const WgArgs& a, int wave, int lane, unsigned (&rel)[G::DMA_IT], unsigned (&pk)[G::DMA_IT]) {
+__device__ __forceinline__ void wg_dma_map(const WgGeo& a, int wave, int lane, unsigned (&rel)[G::DMA_IT], unsigned (&pk)[G::DMA_IT]) {
 #pragma unroll
     for (int it = 0; it < G::DMA_IT; ++it) {
         const int u = (it * G::NW + wave) * 64 + lane;
@@ -125,7 +136,7 @@ __device__ __forceinline__ void wg_dma_piece(const WgArgs& a, const WgDma& d, ch
     const int j = IT * G::NW + wave;
     const bool is_x = (IT * G::NW + G::NW - 1) * 64 + 63 < G::XU ? true : IT * G::NW * 64 >= G::XU ? false : j * 64 < G::XU;   // wave-uniform
     const int y = (is_x ? d.ym - 1 : d.ym) + (int)(pk[IT] >> 16), x = (is_x ? d.xm - 1 : d.xm) + (int)(pk[IT] & 0xffff);
-    const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
     const unsigned off = (is_x ? d.xbase : d.ybase) + rel[IT];
     char* dst = (IT * G::NW + G::NW - 1 < G::NDMA || j < G::NDMA) ? lds + d.slot * G::SLOTB + j * 1024 : lds + 2 * G::SLOTB;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -178,33 +189,48 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kf = wave & 1, cf = wave >> 1;                         // this wave's 32 k rows and 32 c columns of the block
-    // The launch is the flat sequence q = (problem * blocks + block) * ntiles + tile; this workgroup owns [q_begin, q_end) and
-    // flushes its accumulators whenever q crosses into another (problem, block).
+    // The launch is the flat sequence of (problem, block, tile) triples, problem i occupying [qend[i - 1], qend[i]); this workgroup
+    // owns [q_begin, q_end) and flushes its accumulators whenever the sequence crosses into another (problem, block).
     const int q_begin = blockIdx.x * a.per_wg, q_end = min(a.total, q_begin + a.per_wg);
     if (q_begin >= q_end) return;
-    const int txy = a.tiles_x * a.tiles_y, blocks = a.kgroups * a.cgroups;
 
+    struct Loc { int prob, gi, item, tl; };          // problem, geometry, (k, c) block of the problem, tile of the block
+    int cursor = 0;                                  // problems are located front to back (q only grows)
+    auto locate = [&](int q) {
+        const int qq = min(q, a.total - 1);
+        while (qq >= a.qend[cursor]) ++cursor;
+        const int q0 = cursor ? a.qend[cursor - 1] : 0;
+        Loc l;
+        l.prob = cursor;
+        l.gi = a.geo_of[cursor];
+        const int nt = a.geo[l.gi].ntiles;
+        l.item = (qq - q0) / nt;
+        l.tl = (qq - q0) - l.item * nt;
+        return l;
+    };
     unsigned rel[G::DMA_IT], pk[G::DMA_IT];
-    wg_dma_map<G>(a, wave, lane, rel, pk);
     WgDma d;
     // (q >= q_end: an origin below the image, every unit loads zeros into the free buffer -- keeps the loop branch-free)
-#define WG_SET(q_, slot_)                                                                                     \
-    {                                                                                                         \
-        const int qq_ = min((q_), a.total - 1), item_ = qq_ / a.ntiles, tl_ = qq_ - item_ * a.ntiles;          \
-        const int prob_ = item_ / blocks, blk_ = item_ - prob_ * blocks;                                      \
-        const int kg_ = blk_ / a.cgroups, cg_ = blk_ - kg_ * a.cgroups;                                       \
-        const int n_ = tl_ / txy, r_ = tl_ - n_ * txy;                                                        \
-        d.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.in[prob_]), 0, a.in_bytes, 0x00020000); \
-        d.yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.dy[prob_]), 0, a.dy_bytes, 0x00020000); \
-        d.ym = (q_) < q_end ? (r_ / a.tiles_x) * G::TH : (1 << 20);                                           \
-        d.xm = (r_ % a.tiles_x) * TW;                                                                         \
-        const int dd_ = a.dil * a.dil, nf_ = n_ / dd_, sg_ = n_ - nf_ * dd_, sy_ = sg_ / a.dil, sx_ = sg_ - sy_ * a.dil; \
-        const int org_ = (nf_ * a.Hf + sy_) * a.Wf + sx_;                      /* first pixel of the sub-grid */ \
-        d.xbase = (unsigned)(((org_ + ((d.ym - 1) * a.Wf + d.xm - 1) * a.dil) * a.C + cg_ * CWIN) * 2);       \
-        d.ybase = (unsigned)(((org_ + (d.ym * a.Wf + d.xm) * a.dil) * a.K + kg_ * 64) * 2);                   \
-        d.slot = (slot_);                                                                                     \
-    }
-    WG_SET(q_begin, 0)
+    auto set_tile = [&](const Loc& l, int q, int slot_) {
+        const WgGeo& g = a.geo[l.gi];
+        const int kg_ = l.item / g.cgroups, cg_ = l.item - kg_ * g.cgroups;
+        const int txy = g.tiles_x * g.tiles_y;
+        const int n_ = l.tl / txy, r_ = l.tl - n_ * txy;
+        d.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.in[l.prob]), 0, g.in_bytes, 0x00020000);
+        d.yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16raw*>(a.dy[l.prob]), 0, g.dy_bytes, 0x00020000);
+        d.H = g.H; d.W = g.W;
+        d.ym = q < q_end ? (r_ / g.tiles_x) * G::TH : (1 << 20);
+        d.xm = (r_ % g.tiles_x) * TW;
+        const int dd_ = g.dil * g.dil, nf_ = n_ / dd_, sg_ = n_ - nf_ * dd_, sy_ = sg_ / g.dil, sx_ = sg_ - sy_ * g.dil;
+        const int org_ = (nf_ * g.Hf + sy_) * g.Wf + sx_;                      /* first pixel of the sub-grid */
+        d.xbase = (unsigned)(((org_ + ((d.ym - 1) * g.Wf + d.xm - 1) * g.dil) * g.C + cg_ * CWIN) * 2);
+        d.ybase = (unsigned)(((org_ + (d.ym * g.Wf + d.xm) * g.dil) * g.K + kg_ * 64) * 2);
+        d.slot = slot_;
+    };
+    Loc cur = locate(q_begin);
+    int map_gi = cur.gi;                             // geometry the (lane, instruction) -> offset map of the DMA was built for
+    wg_dma_map<G>(a.geo[map_gi], wave, lane, rel, pk);
+    set_tile(cur, q_begin, 0);
     wg_dma_all<G, 0>(a, d, lds, wave, rel, pk);
 
     f32x16_t acc[G::NB];
@@ -229,13 +255,13 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
     const unsigned yrel = (unsigned)(G::XB + tr_p * G::YPB + ((kf ^ ((tr_p >> 1) & 1)) << 6) + tr_c * 2);
 
     // dw[(k * wt + slot(t)) * C + c] += acc: rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31
-    auto flush = [&](int item) {
-        const int prob = item / blocks, blk = item - prob * blocks;
-        const int kg = blk / a.cgroups, cg = blk - kg * a.cgroups;
-        float* __restrict__ dw = a.dw[prob];
+    auto flush = [&](const Loc& l) {
+        const WgGeo& g = a.geo[l.gi];
+        const int kg = l.item / g.cgroups, cg = l.item - kg * g.cgroups;
+        float* __restrict__ dw = a.dw[l.prob];
         const int kb = kg * 64 + kf * 32 + 4 * (lane >> 5);
         const int c = cg * CWIN + cf * 32 + (lane & 31);
-        const bool rows_exist = kg * 64 + kf * 32 < a.K;              // (K = 32: the odd waves' fragment lies past the weight)
+        const bool rows_exist = kg * 64 + kf * 32 < g.K;              // (K = 32: the odd waves' fragment lies past the weight)
 #pragma unroll
         for (int j = 0; j < G::NB; ++j) {
             const int ws = a.wslot[j];
@@ -245,23 +271,27 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
 #if WG_ABL == 1
                 if (acc[j][r] == 1.2345f)
 #endif
-                if (rows_exist) atomicAdd(dw + ((int64_t)k * a.wt + ws) * a.C + c, acc[j][r]);
+                if (rows_exist) atomicAdd(dw + ((int64_t)k * g.wt + ws) * g.C + c, acc[j][r]);
                 acc[j][r] = 0.f;
             }
         }
     };
 
     __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): the first tile has landed (compiler-visible)
-    int slot = 0, item = q_begin / a.ntiles;
-    int next_change = (item + 1) * a.ntiles;                          // first q of the next (problem, block)
+    int slot = 0;
+    Loc held = cur;                                                   // the (problem, block) the accumulators belong to
     for (int q = q_begin; q < q_end; ++q) {
-        if (q == next_change) {                                       // (wave-uniform, a few times per workgroup)
-            flush(item);
-            ++item;
-            next_change += a.ntiles;
+        if (cur.prob != held.prob || cur.item != held.item) {         // (wave-uniform, a few times per workgroup)
+            flush(held);
+            held = cur;
         }
         __builtin_amdgcn_s_barrier();                                 // tile landed for every wave; the other buffer is free
-        WG_SET(q + 1, slot ^ 1)
+        const Loc nxt = locate(q + 1);
+        if (nxt.gi != map_gi) {                                       // (the next tile belongs to a problem of another geometry)
+            map_gi = nxt.gi;
+            wg_dma_map<G>(a.geo[map_gi], wave, lane, rel, pk);
+        }
+        set_tile(nxt, q + 1, slot ^ 1);
         const unsigned sb = lds0 + slot * G::SLOTB;
         unsigned xb[3];
 #pragma unroll
@@ -273,9 +303,9 @@ __global__ __launch_bounds__(CWIN * 4) void wgrad_ws_kernel(const WgArgs a) {
         wg_mfma<G, 0>(a, d, lds, wave, acc, fa, fb, xb, ya, rel, pk);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next tile has landed (this wave's part)
         slot ^= 1;
+        cur = nxt;
     }
-#undef WG_SET
-    flush(item);
+    flush(held);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -318,31 +348,54 @@ static bool wgradws_takes(const tcvom_conv_desc* d, int ldy, int* wslot, int* di
     return true;
 }
 
-// 1: launched, 0: not a shape for this kernel, < 0: error.  `nprob` problems of identical geometry (the calls of one layer in a
-// window, or of several layers of the same shape): the more problems, the fewer workgroups share a (problem, block) and the fewer
-// atomic partial sums -- weights.py: WeightBank.run_deferred_wgrads groups the deferred weight gradients by geometry.
-int wgradws_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nprob, const tcvom_conv_desc* d,
-                       int nphase, int ldy, void* stream) {
-    WgArgs a;
+// geometry of one descriptor as the kernel wants it; false: not a shape for this kernel
+static bool wg_make_geo(const tcvom_conv_desc* d, int ldy, WgGeo* g, int* cwin_out, int* wslot) {
     int dil = 1;
-    if (nphase != 1 || nprob < 1 || nprob > WG_MAX_PROBLEMS || !wgradws_takes(d, ldy, a.wslot, &dil)) return 0;
+    if (!wgradws_takes(d, ldy, wslot, &dil)) return false;
     const int C = d->C, K = d->K;
+    const int cwin = C % 128 == 0 ? 128 : 64, tw = cwin == 64 ? 32 : 16;
+    g->dil = dil; g->Hf = d->H; g->Wf = d->W;
+    g->N = d->N * dil * dil; g->H = d->H / dil; g->W = d->W / dil; g->C = C; g->K = K; g->wt = d->wt;
+    g->tiles_x = cdiv(g->W, tw);
+    g->tiles_y = cdiv(g->H, 8);
+    g->ntiles = g->N * g->tiles_x * g->tiles_y;
+    g->kgroups = cdiv(K, 64);
+    g->cgroups = C / cwin;
+    g->in_bytes = (unsigned)((long long)d->N * d->H * d->W * C * 2);
+    g->dy_bytes = (unsigned)((long long)d->N * d->H * d->W * K * 2);
+    *cwin_out = cwin;
+    return true;
+}
+
+// 1: launched, 0: not shapes for this kernel (or not ONE channel window), < 0: error.  `nprob` problems, problem i of geometry
+// descs[geo_index[i]] (geo_index == NULL: all of descs[0]): the calls of one layer in a window, of several layers of one shape, and --
+// since the atomic flush costs every launch the same ~45 us -- of layers of different shapes: the more problems, the fewer
+// workgroups share a (problem, block) and the fewer launches pay the flush.  weights.py: WeightBank.run_deferred_wgrads.
+static int wgradws_launch(const void* const* dys, const void* const* ins, float* const* dws, int nprob, const tcvom_conv_desc* descs,
+                          int ngeo, const int32_t* geo_index, void* stream) {
+    WgArgs a;
+    if (nprob < 1 || nprob > WG_MAX_PROBLEMS || ngeo < 1 || ngeo > WG_MAX_GEO) return 0;
+    int cwin = 0;
+    for (int gi = 0; gi < WG_MAX_GEO; ++gi) {
+        const int j = gi < ngeo ? gi : 0;
+        int cw = 0, slots[9];
+        if (!wg_make_geo(descs + j, descs[j].K, &a.geo[gi], &cw, slots)) return 0;
+        if (gi == 0) { cwin = cw; for (int t = 0; t < 9; ++t) a.wslot[t] = slots[t]; }
+        if (cw != cwin) return 0;
+        for (int t = 0; t < 9; ++t) if (slots[t] != a.wslot[t]) return 0;
+    }
+    long long total = 0;
     for (int i = 0; i < WG_MAX_PROBLEMS; ++i) {
         const int j = i < nprob ? i : 0;
         a.dy[i] = (const h16raw*)dys[j]; a.in[i] = (const h16raw*)ins[j]; a.dw[i] = dws[j];
+        const int gi = geo_index ? geo_index[j] : 0;
+        if (gi < 0 || gi >= ngeo) return tcvom_fail(TCVOM_ERR_ARG, "wgrad_ws: geometry index %d of problem %d (0..%d)", gi, j, ngeo - 1);
+        a.geo_of[i] = (unsigned char)gi;
+        if (i < nprob) total += (long long)a.geo[gi].kgroups * a.geo[gi].cgroups * a.geo[gi].ntiles;
+        if (total >= (1ll << 31)) return 0;
+        a.qend[i] = (int)total;
     }
-    const int cwin = C % 128 == 0 ? 128 : 64, tw = cwin == 64 ? 32 : 16;
-    a.dil = dil; a.Hf = d->H; a.Wf = d->W;
-    a.N = d->N * dil * dil; a.H = d->H / dil; a.W = d->W / dil; a.C = C; a.K = K; a.wt = d->wt;
-    a.tiles_x = cdiv(a.W, tw);
-    a.tiles_y = cdiv(a.H, 8);
-    a.ntiles = a.N * a.tiles_x * a.tiles_y;
-    a.kgroups = cdiv(K, 64);
-    a.cgroups = C / cwin;
-    a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * C * 2);
-    a.dy_bytes = (unsigned)((long long)d->N * d->H * d->W * K * 2);
-    const long long total = (long long)nprob * a.kgroups * a.cgroups * a.ntiles;
-    if (total >= (1ll << 31)) return 0;
+    a.nprob = nprob;
     a.total = (int)total;
     // one persistent workgroup per CU; a run shorter than 2 tiles is all pipeline fill
     int wgs = 256;
@@ -372,6 +425,13 @@ int wgradws_try_launch(const void* const* dys, const void* const* ins, float* co
     return 1;
 }
 
+// the problems of ONE geometry (tcvom_wgrad_igemm_batched routes eligible shapes here)
+int wgradws_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nprob, const tcvom_conv_desc* d,
+                       int nphase, int ldy, void* stream) {
+    if (nphase != 1 || ldy != d->K) return 0;
+    return wgradws_launch(dys, ins, dws, nprob, d, 1, nullptr, stream);
+}
+
 // C ABI: the weight gradients of up to WG_MAX_PROBLEMS convolutions of ONE geometry in one launch (declared in tcvom_hip.h)
 extern "C" int tcvom_wgrad_ws_multi(const void* const* dy, const void* const* in, float* const* dw, int32_t nprob,
                                     const tcvom_conv_desc* d, int32_t ldy, void* stream) {
@@ -383,6 +443,18 @@ extern "C" int tcvom_wgrad_ws_multi(const void* const* dy, const void* const* in
     return r < 0 ? r : TCVOM_OK;
 }
 extern "C" int32_t tcvom_wgrad_ws_max_problems(void) { return WG_MAX_PROBLEMS; }
+extern "C" int32_t tcvom_wgrad_ws_max_geometries(void) { return WG_MAX_GEO; }
+// ... of up to WG_MAX_GEO geometries that share the channel window (C a multiple of 128, or not): problem i has descs[geo_index[i]]
+extern "C" int tcvom_wgrad_ws_hetero(const void* const* dy, const void* const* in, float* const* dw, int32_t nprob,
+                                     const tcvom_conv_desc* descs, int32_t ngeo, const int32_t* geo_index, void* stream) {
+    TCVOM_CHECK_ARG(dy && in && dw && descs && geo_index, "wgrad_ws_hetero: null pointer");
+    TCVOM_CHECK_ARG(nprob >= 1 && nprob <= WG_MAX_PROBLEMS, "wgrad_ws_hetero: %d problems (1..%d)", nprob, WG_MAX_PROBLEMS);
+    TCVOM_CHECK_ARG(ngeo >= 1 && ngeo <= WG_MAX_GEO, "wgrad_ws_hetero: %d geometries (1..%d)", ngeo, WG_MAX_GEO);
+    for (int i = 0; i < nprob; ++i) TCVOM_CHECK_ARG(dy[i] && in[i] && dw[i], "wgrad_ws_hetero: null pointer in problem %d", i);
+    const int r = wgradws_launch(dy, in, dw, nprob, descs, ngeo, geo_index, stream);
+    TCVOM_CHECK_ARG(r != 0, "wgrad_ws_hetero: not stride-1 3x3 convolutions of one channel window (C a multiple of 64 / of 128, K = 32 or a multiple of 64)");
+    return r < 0 ? r : TCVOM_OK;
+}
 
 // name for profiles / bench labels
 const char* wgradws_variant(const tcvom_conv_desc* d, int ldy) {

@@ -82,6 +82,18 @@ def _wgrad_ws_cap():
     return _WS_CAP[0]
 
 
+_WS_GEO_CAP = []
+
+
+def _wgrad_ws_geo_cap():
+    if not _WS_GEO_CAP:
+        _WS_GEO_CAP.append(int(L.call('tcvom_wgrad_ws_max_geometries')))
+    return _WS_GEO_CAP[0]
+
+
+WGRAD_HETERO = os.environ.get('TCVOM_NO_WGRAD_HETERO') is None          # A/B switch: one launch per geometry
+
+
 def _wgrad_ws_key(geo):
     """Geometry signature of a layer whose weight gradient runs on the accumulator-stationary kernel, else None (cached
     on the geometry object)."""
@@ -565,6 +577,36 @@ class WeightBank(object):
                 groups.setdefault((e[0].layer_id, id(geo)), []).append(e)
         st = L.stream_ptr()
         cap = _wgrad_ws_cap()
+        if WGRAD_HETERO:
+            # ... and the geometries that share the kernel's channel window (C a multiple of 128, or not) share launches too: the
+            # atomic flush costs a launch ~45 us however few problems it has (csrc/wgradws.hip: tcvom_wgrad_ws_hetero)
+            gcap = _wgrad_ws_geo_cap()
+            for cw in (0, 1):
+                keys = [k for k in multi if (k[3] % 128 == 0) == bool(cw)]
+                batch, descs = [], []                   # problems (entry, geometry index) and descriptors of the launch being filled
+
+                def launch():
+                    n = len(batch)
+                    dys = (C.c_void_p * n)(*[e[2].data_ptr() + e[6] for e, _ in batch])
+                    xs = (C.c_void_p * n)(*[e[3].data_ptr() + e[7] for e, _ in batch])
+                    dws = (C.c_void_p * n)(*[self.dw_ptr(e[0], e[1]).value for e, _ in batch])
+                    gidx = (C.c_int32 * n)(*[g for _, g in batch])
+                    arr = (type(descs[0]) * len(descs))(*descs)
+                    L.call('tcvom_wgrad_ws_hetero', C.cast(dys, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(dws, C.c_void_p), n,
+                           arr, len(descs), C.cast(gidx, C.c_void_p), st)
+                for k in keys:
+                    items = multi[k]
+                    d = items[0][4].wgrad[0]
+                    for i in range(0, len(items), cap):
+                        part = items[i:i + cap]
+                        if batch and (len(batch) + len(part) > cap or len(descs) >= gcap):
+                            launch()
+                            batch, descs = [], []
+                        descs.append(d)
+                        batch += [(e, len(descs) - 1) for e in part]
+                if batch:
+                    launch()
+            multi = {}
         for items in multi.values():
             arr = _phase_array(items[0][4].wgrad)
             for i in range(0, len(items), cap):

@@ -447,7 +447,7 @@ def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):
 @pytest.mark.parametrize('cin,cout,N,H,W,S', [(64, 64, 2, 20, 40, 1), (64, 64, 1, 33, 70, 3), (128, 128, 1, 17, 30, 3),
                                               (128, 128, 2, 40, 64, 1), (256, 128, 1, 9, 16, 2), (128, 256, 1, 24, 20, 1),
                                               (512, 512, 1, 6, 10, 3), (64, 128, 1, 16, 32, 1), (128, 128, 1, 17, 30, 20),
-                                              (64, 64, 1, 16, 32, 40), (256, 256, 1, 9, 12, 112),
+                                              (64, 64, 1, 16, 32, 40), (256, 256, 1, 9, 12, 96),
                                               # 64-channel windows of a C that is not a multiple of 128; K = 32 (half a k group)
                                               (320, 64, 1, 20, 36, 1), (192, 128, 2, 9, 33, 2), (64, 32, 2, 24, 40, 3),
                                               (128, 32, 1, 17, 30, 1), (192, 32, 1, 16, 64, 9)])
@@ -460,6 +460,7 @@ def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
     from tcvom_amd.conv_plan import ConvGeometry
     from tcvom_amd.ops import _phase_array
     tag = 'wgws%d_%d_%d' % (cin, cout, H)
+    assert S <= L.call('tcvom_wgrad_ws_max_problems')    # (96: the largest case fills a launch)
     bank, spec = _mini_bank(cin, cout, 3, 1, 1, False, spectral=False, tag=tag)
     geo = ConvGeometry(spec, N, H, W)
     assert L._FNS['tcvom_wgrad_igemm_variant'](C.byref(_phase_array(geo.wgrad)[0])).decode().startswith('wgrad_ws')
@@ -703,6 +704,60 @@ def test_wgrad_ws_kernel_dilated(cin, cout, dil, N, H, W, S):
                                           dys[i].float().cpu().permute(0, 3, 1, 2), padding=dil, dilation=dil)
         got = dw[i].cpu().view(cout, 3, 3, cin).permute(0, 3, 1, 2)
         assert rel_err(got, ref) < 1e-5, 'problem %d' % i
+
+
+@pytest.mark.parametrize('cw', [128, 64])
+def test_wgrad_ws_hetero_launch(cw):
+    """Problems of DIFFERENT geometries (image size, channel counts, dilation, samples) in one launch of the accumulator-stationary
+    weight gradient (csrc/wgradws.hip: tcvom_wgrad_ws_hetero) -- the channel-changing convs of a trunk riding with the big groups: a
+    workgroup's run crosses problem and geometry borders (DMA map rebuilt, accumulators flushed), runs of one tile included.
+    Against torch.nn.grad.conv2d_weight in fp32 on the same 16-bit operands, and against one launch per geometry."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.weights import ConvSpec, WeightBank
+    if cw == 128:
+        shapes = [(128, 128, 1, 1, 24, 40, 3), (256, 128, 1, 1, 13, 21, 2), (128, 64, 1, 2, 17, 33, 1), (256, 256, 2, 1, 16, 24, 2),
+                  (128, 32, 1, 1, 9, 50, 1), (512, 128, 1, 1, 8, 16, 1)]
+    else:
+        shapes = [(64, 64, 1, 1, 20, 44, 3), (192, 64, 1, 1, 11, 37, 1), (64, 128, 2, 1, 12, 36, 2), (320, 64, 1, 2, 9, 33, 1), (64, 32, 1, 1, 40, 64, 1)]
+    bank = WeightBank()
+    descs, dys, xs, dws, gidx, refs = [], [], [], [], [], []
+    for gi, (cin, cout, dil, N, H, W, S) in enumerate(shapes):
+        tag = 'wgh%d_%d_%d_%d_%d' % (cw, gi, cin, cout, dil)
+        w = nn.Parameter(formula_tensor('conv.%s.weight' % tag, (cout, cin, 3, 3)).to(DEV))
+        spec = ConvSpec(tag, w, None, None, None, False, 1, dil, 'frame', dilation=dil)
+        bank.register(spec)
+        geo = ConvGeometry(spec, N, H, W)
+        assert len(geo.wgrad) == 1 and L._FNS['tcvom_wgrad_igemm_variant'](C.byref(geo.wgrad[0])).decode() == 'wgrad_ws<%d>' % cw
+        descs.append(geo.wgrad[0])
+        for i in range(S):
+            x = (hu('x%d.%s' % (i, tag), (N, H, W, cin)) - 0.5).to(DEV).to(H16)
+            dy = (hu('dy%d.%s' % (i, tag), (N, H, W, cout)) - 0.5).to(DEV).to(H16)
+            xs.append(x); dys.append(dy); gidx.append(gi)
+            dws.append(torch.zeros(cout * 9 * cin, device=DEV))
+            refs.append((torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2), (cout, cin, 3, 3),
+                                                     dy.float().cpu().permute(0, 3, 1, 2), padding=dil, dilation=dil), cout, cin))
+    n = len(xs)
+    vp = lambda ts: C.cast((C.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), C.c_void_p)     # noqa: E731
+    arr = (type(descs[0]) * len(descs))(*descs)
+    gi_arr = (C.c_int32 * n)(*gidx)
+    assert n <= L.call('tcvom_wgrad_ws_max_problems') and len(descs) <= L.call('tcvom_wgrad_ws_max_geometries')
+    L.call('tcvom_wgrad_ws_hetero', vp(dys), vp(xs), vp(dws), n, arr, len(descs), C.cast(gi_arr, C.c_void_p), L.stream_ptr())
+    torch.cuda.synchronize()
+    for i in range(n):
+        ref, cout, cin = refs[i]
+        got = dws[i].cpu().view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        assert rel_err(got, ref) < 1e-5, 'problem %d (geometry %d)' % (i, gidx[i])
+    # a mixed channel window is refused, not mis-launched
+    if cw == 128:
+        w64 = nn.Parameter(formula_tensor('conv.wgh_mix.weight', (64, 64, 3, 3)).to(DEV))
+        s64 = ConvSpec('wgh_mix', w64, None, None, None, False, 1, 1, 'frame')
+        bank.register(s64)
+        g64 = ConvGeometry(s64, 1, 16, 32)
+        arr2 = (type(descs[0]) * 2)(descs[0], g64.wgrad[0])
+        with pytest.raises(L.TcvomError):
+            L.call('tcvom_wgrad_ws_hetero', vp(dys[:1]), vp(xs[:1]), vp(dws[:1]), 1, arr2, 2, C.cast((C.c_int32 * 1)(0), C.c_void_p), L.stream_ptr())
 
 
 SCONV_CASES = [

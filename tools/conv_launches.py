@@ -35,7 +35,7 @@ for name, d, e0, e1 in rec:
         continue
     ms = e0.elapsed_time(e1)
     taps = sum(1 for t in range(d['ntaps']) if d['tap_w'][t] >= 0)
-    gf = 2.0 * d['P'] * d['K'] * taps * d['C'] * max(d['batch'], 1) / 1e9
+    gf = d['gflop'] if 'gflop' in d else 2.0 * d['P'] * d['K'] * taps * d['C'] * max(d['batch'], 1) / 1e9
     rows.append((ms, name.replace('tcvom_', ''), d['variant'], d['P'], d['K'], d['C'], taps, d['batch'], d.get('phases', 1), gf, d.get('algo_bytes', 0)))
 sel = sys.argv[1] if len(sys.argv) > 1 else ''
 print('%-26s %-30s %8s %5s %5s %4s %3s %3s %8s %8s %8s %8s' % ('entry', 'variant', 'P', 'K', 'C', 'taps', 'b', 'ph', 'us', 'TFLOP/s', 'MiB', 'GB/s'))
