@@ -94,6 +94,20 @@ def _wgrad_ws_geo_cap():
 WGRAD_HETERO = os.environ.get('TCVOM_NO_WGRAD_HETERO') is None          # A/B switch: one launch per geometry
 
 
+WGRAD_GROUP_LAYERS = os.environ.get('TCVOM_NO_WGRAD_GROUP_LAYERS') is None        # A/B switch: one launch per layer
+
+
+
+def _wgrad_geo_key(geo, K):
+    """Signature of a layer's weight-gradient launch (all phases): layers with equal signatures share batched launches."""
+    key = getattr(geo, '_wg_key', None)
+    if key is None:
+        key = (K,) + tuple((d.N, d.H, d.W, d.C, d.OH, d.OW, d.K, d.PH, d.PW, d.in_step, d.out_step, d.out_off_h, d.out_off_w, d.wt, d.ldo,
+                            tuple((d.tap_dh[t], d.tap_dw[t], d.tap_w[t]) for t in range(d.ntaps))) for d in geo.wgrad)
+        geo._wg_key = key
+    return key
+
+
 def _wgrad_ws_key(geo):
     """Geometry signature of a layer whose weight gradient runs on the accumulator-stationary kernel, else None (cached
     on the geometry object)."""
@@ -543,7 +557,7 @@ class WeightBank(object):
         st = torch.cuda.current_stream()
         dyb, xb = dy.numel() // nf * dy.element_size(), x.numel() // nf * x.element_size()
         for f in range(nf):
-            self._deferred.append((spec, (call + f) if n > 1 else 0, dy, x, geo, st, f * dyb, f * xb))
+            self._deferred.append((spec, (call + f) if n > 1 else 0, dy, x, geo, st, f * dyb, f * xb, dyb + xb))
 
     def run_deferred_wgrads(self, layers=None):
         """Issue the queued weight-gradient launches; `layers` = (lo, hi): only those of layer ids lo <= id < hi (the
@@ -574,7 +588,14 @@ class WeightBank(object):
             if key is not None:
                 multi.setdefault(key, []).append(e)
             else:
-                groups.setdefault((e[0].layer_id, id(geo)), []).append(e)
+                # the other shapes: the calls of every layer of one geometry, 8 problems per launch (the more problems a launch has,
+                # the less its pixel reduction is split and the fewer atomic partial sums it adds)
+                # -- except for the large 1x1 problems (>= 32 MB of operands: the 40 - 80 MB pointwise convs of the FBA bottlenecks stream
+                # at 2.3 - 3.8 TB/s as launches of 3 and lose as launches of 8: 47.88 -> 48.12 ms); the 1x1 / stride-2 / transposed /
+                # 32-channel convs of the GCA trunk, 20 - 100 us per layer, gain: GCA+TAM 24.25 -> 24.01 ms
+                # (e[8]: operand bytes of this problem, one frame's dy + x)
+                small = WGRAD_GROUP_LAYERS and (e[8] < (32 << 20) or geo.wgrad[0].ntaps > 1)
+                groups.setdefault(_wgrad_geo_key(geo, e[0].K) if small else (e[0].layer_id, id(geo)), []).append(e)
         st = L.stream_ptr()
         cap = _wgrad_ws_cap()
         if WGRAD_HETERO:
@@ -625,7 +646,7 @@ class WeightBank(object):
                 n = len(part)
                 dys = (C.c_void_p * n)(*[e[2].data_ptr() + e[6] for e in part])
                 xs = (C.c_void_p * n)(*[e[3].data_ptr() + e[7] for e in part])
-                dws = (C.c_void_p * n)(*[self.dw_ptr(spec, e[1]).value for e in part])
+                dws = (C.c_void_p * n)(*[self.dw_ptr(e[0], e[1]).value for e in part])
                 L.call('tcvom_wgrad_igemm_batched', C.cast(dys, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(dws, C.c_void_p), n,
                        arr, len(geo.wgrad), spec.K, st)
         for e in pend:
