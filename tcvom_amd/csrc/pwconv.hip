@@ -27,6 +27,9 @@
 typedef __attribute__((ext_vector_type(4))) unsigned int pw_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int pw_u32x2_t;
 typedef __attribute__((address_space(3))) void* pw_lptr_t;
+#ifndef PW_ABL
+#define PW_ABL 0              // study builds (wrong results): 1 = no output stores, 2 = no statistics, 4 = no DMA after the first tile, 8 = no MFMAs
+#endif
 #ifndef PW_DMA_AT_HEAD
 #define PW_DMA_AT_HEAD 0      // study builds: 1 = the next tile's DMA instructions in one burst behind the barrier
 #endif
@@ -171,10 +174,11 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
 #if !PW_DMA_AT_HEAD
 #pragma unroll
                 for (int j = 0; j < G::NDMA; ++j)
-                    if (m == (j * TOTAL) / G::NDMA + (TOTAL >= 2 * G::NDMA ? 1 : 0)) issue_piece(np0, buf ^ 1, j);
+                    if (!(PW_ABL & 4) && m == (j * TOTAL) / G::NDMA + (TOTAL >= 2 * G::NDMA ? 1 : 0)) issue_piece(np0, buf ^ 1, j);
 #endif
                 const h16x8_t b = *reinterpret_cast<const h16x8_t*>(bt + i * 32 * PIXB + so);
-                acc[i] = mfma16(wr[cc], b, acc[i], 0, 0, 0);
+                if (!(PW_ABL & 8)) acc[i] = mfma16(wr[cc], b, acc[i], 0, 0, 0);
+                else acc[i][cc & 15] += (float)b[0];
             }
         }
         // ---- epilogue: activation, statistics, 16-bit rows through the staging region
@@ -191,8 +195,10 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
                     x = fmaxf(x, x * slope);
                     x = pin ? x : 0.f;
                     v[r] = x;
-                    s1[g][r] += x;
-                    s2[g][r] = fmaf(x, x, s2[g][r]);
+                    if (!(PW_ABL & 2)) {
+                        s1[g][r] += x;
+                        s2[g][r] = fmaf(x, x, s2[g][r]);
+                    }
                 }
                 // (inline asm: a compiler-visible LDS WRITE gets an s_waitcnt vmcnt(0) in front of it while an LDS-DMA is in flight --
                 //  the next tile's DMA would be drained at every tile's epilogue)
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
                 const pw_u32x4_t row = *reinterpret_cast<const pw_u32x4_t*>(stg + q * 64 + ((rc ^ ((q >> 2) & 3)) << 4));
                 const int px = pw0 + i * 32 + q;
                 const unsigned o = px < a.P ? (unsigned)((px * a.ldo + kbase + rc * 8) * 2) : 0xffffffffu;
-                __builtin_amdgcn_raw_buffer_store_b128(row, orsrc, (int)o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(row, orsrc, (int)((PW_ABL & 1) ? 0xffffffffu : o), 0, 0);
             }
         }
     }
