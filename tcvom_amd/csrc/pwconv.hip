@@ -172,9 +172,13 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const PwArgs a) {
                 constexpr int TOTAL = NCC * NI;
                 const int m = cc * NI + i;                       // (compile-time after unrolling)
 #if !PW_DMA_AT_HEAD
-#pragma unroll
-                for (int j = 0; j < G::NDMA; ++j)
-                    if (!(PW_ABL & 4) && m == (j * TOTAL) / G::NDMA + (TOTAL >= 2 * G::NDMA ? 1 : 0)) issue_piece(np0, buf ^ 1, j);
+                // DMA instruction j goes out in front of MFMA j * STEP (+ 1 where there is room: the first MFMA of the tile starts at once).
+                // (As a loop over j with `m == f(j)` tests the nest no longer unrolled at 64 k-steps x 16 instructions -- a C = 1024
+                //  instantiation, 2 x 64 KiB tiles and one workgroup per CU, kept its weights in scratch; with that fixed it measured
+                //  neutral on the FBA step, 46.21 vs 46.16 ms, and is not built.)
+                constexpr int STEP = TOTAL / G::NDMA, OFF = STEP >= 2 ? 1 : 0;
+                static_assert(TOTAL % G::NDMA == 0, "the DMA instructions spread evenly over the MFMAs of a tile");
+                if (!(PW_ABL & 4) && m % STEP == OFF) issue_piece(np0, buf ^ 1, m / STEP);
 #endif
                 const h16x8_t b = *reinterpret_cast<const h16x8_t*>(bt + i * 32 * PIXB + so);
                 if (!(PW_ABL & 8)) acc[i] = mfma16(wr[cc], b, acc[i], 0, 0, 0);
