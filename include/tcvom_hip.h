@@ -61,7 +61,8 @@ typedef struct {
     int32_t wt;                  /* weight slots: w is [K][wt][C] bf16 */
     int32_t ldo;                 /* output pixel stride in elements */
     int32_t act;                 /* 0 none, 1 ReLU (before store and statistics) */
-    int32_t out_fp32;            /* store fp32 instead of bf16 */
+    int32_t out_fp32;            /* 1: store fp32 instead of the 16-bit storage type; 2: IEEE fp16 whatever the build stores (the
+                                    doubled-tap 64-channel layers on the weight-stationary kernel only) */
     int32_t stats_group_offset;  /* first statistics group written by this launch */
     int32_t batch;               /* >1: `batch` independent problems with the strides below: the dense GEMMs of GCA,
                                     and the S frames of a window through one conv layer (N samples per frame, own
@@ -189,7 +190,7 @@ int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_
 int tcvom_bn_ema_multi(const int64_t* table, int32_t nbn, const uint32_t* masks, const float* unbias, void* stream);
 int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
-/* y_fp32 != 0: the conv output y is fp32 (high-precision layers) instead of bf16 */
+/* y_fp32: 0 = the conv output y has the 16-bit storage type, 1 = fp32 (high-precision layers), 2 = IEEE fp16 whatever the build stores */
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
                    int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                    void* stream);

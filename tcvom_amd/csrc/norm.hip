@@ -204,10 +204,29 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
     saved[C + c] = invstd;
 }
 
-// conv output `y` is bf16, or fp32 for the high-precision layers (YF32)
-template <bool YF32>
+// conv output `y` is 16-bit in the build's storage type (YF32 = 0), fp32 (1: the high-precision layers of the bf16 build) or IEEE
+// fp16 (2: their layer1 convs on the weight-stationary kernel -- 11 significant bits instead of bf16's 8 at half the bytes of fp32; in
+// the fp16 build the same thing as 0)
+typedef __attribute__((ext_vector_type(2))) _Float16 bn_f16x2_t;
+__device__ __forceinline__ void unpack8_ieee(const uint4& q, float* f) {
+    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bn_f16x2_t h = __builtin_bit_cast(bn_f16x2_t, u[i]);
+        f[2 * i] = (float)h.x;
+        f[2 * i + 1] = (float)h.y;
+    }
+}
+static inline int bn_y_mode(int y_fp32) {
+#ifdef TCVOM_F16
+    return y_fp32 == 1 ? 1 : 0;
+#else
+    return y_fp32 == 1 ? 1 : y_fp32 == 2 ? 2 : 0;
+#endif
+}
+template <int YF32>
 __device__ __forceinline__ void load_y8(const void* __restrict__ y, int64_t v, float* f) {
-    if (YF32) {
+    if (YF32 == 1) {
         const float4* p = reinterpret_cast<const float4*>(y) + 2 * v;
         const float4 a = p[0], b = p[1];
         f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
@@ -253,25 +272,26 @@ __device__ __forceinline__ unsigned sat8(const uint4& q) {
 __device__ __forceinline__ unsigned sat8(const uint4&) { return 0u; }
 #endif
 
-template <bool YF32> struct YRaw { uint4 a; };
-template <> struct YRaw<true> { float4 a, b; };
-template <bool YF32>
+template <int YF32> struct YRaw { uint4 a; };
+template <> struct YRaw<1> { float4 a, b; };
+template <int YF32>
 __device__ __forceinline__ YRaw<YF32> load_yraw(const void* __restrict__ y, int64_t v) {
     YRaw<YF32> r;
-    if constexpr (YF32) { const float4* p = reinterpret_cast<const float4*>(y) + 2 * v; r.a = p[0]; r.b = p[1]; }
+    if constexpr (YF32 == 1) { const float4* p = reinterpret_cast<const float4*>(y) + 2 * v; r.a = p[0]; r.b = p[1]; }
     else r.a = reinterpret_cast<const uint4*>(y)[v];
     return r;
 }
-template <bool YF32>
+template <int YF32>
 __device__ __forceinline__ void unpack_yraw(const YRaw<YF32>& r, float* f) {
-    if constexpr (YF32) { f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w; }
+    if constexpr (YF32 == 1) { f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w; }
+    else if constexpr (YF32 == 2) unpack8_ieee(r.a, f);
     else unpack8(r.a, f);
 }
 
 // A block owns a contiguous pixel range; a thread owns ONE channel octet for the whole range (its 16 scale/shift
 // values live in registers) and walks the pixels with stride 256/C8: every access is a 16-byte load/store and
 // consecutive lanes cover consecutive 16-byte chunks of a pixel row.
-template <bool YF32>
+template <int YF32>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const void* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0}, n2 = res2 ? res2[vn] : uint4{0, 0, 0, 0};
         float f[8], r1[8], r2[8];
         unpack_yraw<YF32>(yr, f);
-        if constexpr (!YF32) sat |= sat8(yr.a);
+        if constexpr (YF32 == 0) sat |= sat8(yr.a);
         unpack8(q1, r1);
         unpack8(q2, r2);
         unsigned bits = 0u;
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 
 // ---------------------------------------------------------------- backward, pass 1: per-channel sums
 // block = 256 threads = RP pixel rows x C8 channel octets (C8 <= 256); partial[block][2][C]
-template <bool YF32>
+template <int YF32>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
     }
 }
 
-template <bool YF32>
+template <int YF32>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
@@ -583,7 +603,7 @@ struct BnFusedArgs {
     int C8, C, act, training, in_relu, rows_per_block, dz2_f0, dz2_f1, accumulate;
     SnDot sd;
 };
-template <bool YF32>
+template <int YF32>
 __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const BnFusedArgs a)
 {
     __shared__ float red[2 * 256 * 8];
@@ -933,14 +953,17 @@ static int bn_apply_impl(const void* y, const float* scale_shift, const void* re
     TCVOM_CHECK_ARG(C <= 2048, "bn_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
-    if (y_fp32)
-        hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+    switch (bn_y_mode(y_fp32)) {
+    case 1: hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
                            y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
-                           g_overflow_sink.load(std::memory_order_relaxed), mask);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                           g_overflow_sink.load(std::memory_order_relaxed), mask); break;
+    case 2: hipLaunchKernelGGL(bn_apply_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
                            y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
-                           g_overflow_sink.load(std::memory_order_relaxed), mask);
+                           g_overflow_sink.load(std::memory_order_relaxed), mask); break;
+    default: hipLaunchKernelGGL(bn_apply_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream,
+                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
+                           g_overflow_sink.load(std::memory_order_relaxed), mask); break;
+    }
     TCVOM_LAUNCH_CHECK("bn_apply");
     return TCVOM_OK;
 }
@@ -983,14 +1006,17 @@ static int bn_bwd_reduce_impl(const void* dz, const void* dz2, const void* y, co
     const int groups = tcvom_bn_bwd_groups_n(pixels, C, nframes);
     const int rpb = (int)((pixels + groups - 1) / groups);
     const dim3 grid(groups, nframes);
-    if (y_fp32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+    switch (bn_y_mode(y_fp32)) {
+    case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
+    case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask);
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
+    default: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
+                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
+    }
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
 }
@@ -1291,14 +1317,17 @@ static int bn_bwd_apply_impl(const void* dz, const void* dz2, const void* y, con
     TCVOM_CHECK_ARG(C <= 2048, "bn_bwd_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
-    if (y_fp32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+    switch (bn_y_mode(y_fp32)) {
+    case 1: hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;
+    case 2: hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask);
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;
+    default: hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
+                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;
+    }
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
 }
@@ -1350,8 +1379,11 @@ extern "C" int tcvom_bn_bwd_fused(const void* dz, const void* dz2, const void* y
     a.dz2_f0 = dz2_f0; a.dz2_f1 = dz2_f1; a.accumulate = accumulate;
     a.sd = make_dot(dot);
     const dim3 grid(G, nframes);
-    if (y_fp32) hipLaunchKernelGGL(bn_bwd_fused_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(bn_bwd_fused_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    switch (bn_y_mode(y_fp32)) {
+    case 1: hipLaunchKernelGGL(bn_bwd_fused_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(bn_bwd_fused_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(bn_bwd_fused_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    }
     TCVOM_LAUNCH_CHECK("bn_bwd_fused");
     return TCVOM_OK;
 }

@@ -60,13 +60,14 @@ struct WsArgs {
 
 // compile-time geometry of one kernel configuration
 // NT_ = 18: the high-precision layers of the bf16 build (gca_net.py: HP_LAYERS) -- every tap twice, weight slot t (the 16-bit head of
-// the fp32 weight) and slot 9 + t (its 16-bit residual) on the SAME input pixels; OF32_: fp32 output (their conv results stay fp32
-// until the BatchNorm has been applied)
-template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int NT_ = 9, bool OF32_ = false>
+// the fp32 weight) and slot 9 + t (its 16-bit residual) on the SAME input pixels; OM_: output type -- 0 the build's 16-bit storage type,
+// 1 fp32, 2 IEEE fp16 whatever the build stores (the conv results of the high-precision layers must not be rounded to bf16's 8
+// significant bits before the BatchNorm has been applied: fp16 keeps 11 at half the bytes of fp32)
+template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int NT_ = 9, int OM_ = 0>
 struct WsCfg {
-    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = NT_;
-    static constexpr bool OF32 = OF32_;
-    static constexpr int OB = OF32_ ? 4 : 2;                   // bytes per output element
+    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = NT_, OM = OM_;
+    static constexpr bool OF32 = OM_ == 1;
+    static constexpr int OB = OM_ == 1 ? 4 : 2;                // bytes per output element
     static constexpr int CU = C / 8, PIXB = C * 2;
     static constexpr int TH = PS * NI * FH, TW = FW, HW = TW + 2, HH = TH + 2, HPIX = HH * HW;
     static constexpr int NDMA = (HPIX * CU + 63) / 64;          // DMA wave-instructions (1 KiB each) per halo
@@ -182,6 +183,12 @@ __device__ __forceinline__ void ws_dma_pieces(WsCtx<G>& c) {
 
 // (mov_dpp: no `old` operand -- lanes a row mask disables hold garbage afterwards, here rows 0 and 2 of the last level, unused;
 // with an `old` of 0 the compiler kept v_mov 0 + v_mov_dpp + v_add instead of one v_add_f32_dpp)
+// two values as IEEE fp16 (round to nearest even, saturated at the largest finite value), whatever the build's storage type
+__device__ __forceinline__ unsigned ws_pack2_ieee(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f16x2_t v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, v);
+}
 #define WS_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
 
 // ---- epilogue piece Q of the previous tile.  Q = g * (NI + 1) + j: j < NI: activation, store and channel sums of the 4
@@ -240,6 +247,7 @@ __device__ __forceinline__ void ws_epi_piece(WsCtx<G>& c, const f32x4_t vals) {
         const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * G::OB) + (unsigned)(8 * G::OB) * g : 0xffffffffu;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
         if constexpr (G::OF32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vals), c.orsrc, (int)o, 0, 0);
+        else if constexpr (G::OM == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ws_pack2_ieee(vals[0], vals[1]), ws_pack2_ieee(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2h(vals[0], vals[1]), pack2h(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
     } else {
         float t[8];
@@ -397,9 +405,9 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
     if constexpr (S + 1 < G::NS) ws_step<G, S + 1>(c, wr, acc, bq, bbase, lb);
 }
 
-template <int C, int MF, int PS, int NI, int FH, int FW, int NT = 9, bool OF32 = false>
+template <int C, int MF, int PS, int NI, int FH, int FW, int NT = 9, int OM = 0>
 __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
-    typedef WsCfg<C, MF, PS, NI, FH, FW, NT, OF32> G;
+    typedef WsCfg<C, MF, PS, NI, FH, FW, NT, OM> G;
     constexpr int TH = G::TH, TW = G::TW, HW = G::HW, PIXB = G::PIXB, CU = G::CU, NCC = G::NCC, NS = G::NS, SLOTB = G::SLOTB;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][SLOTB] halo, DUMPB, (+ XCHB bytes of results and the bias in the LDS form)
 
@@ -632,7 +640,8 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     }
     if (n != 9 || (n2 != 0 && n2 != 9)) return p;
     p.nt = n2 ? 18 : 9;
-    if (p.nt == 9 && d->out_fp32) return p;             // (fp32 results are built for the doubled-tap instantiation only)
+    if (p.nt == 9 && d->out_fp32) return p;             // (fp32 / fp16 results are built for the doubled-tap instantiation only)
+    if (d->out_fp32 < 0 || d->out_fp32 > 2) return p;
     p.C = d->C;
     p.th = 8;
     p.tw = d->C == 64 ? 32 : 16;
@@ -698,7 +707,7 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     a.trace = ws_trace_buffer();
     ws_grid(d, p, &a.tiles_per_frame, &a.tiles_per_wg, &a.wgs_per_frame);      // (from the WHOLE batch: the statistics layout the caller sized)
     const long long gpf = (p.C == 128 || p.nt == 18) ? (long long)a.tiles_per_frame * ws_ps(p) : (long long)a.wgs_per_frame * ws_ps(p);
-    const int ob = d->out_fp32 ? 4 : 2;
+    const int ob = d->out_fp32 == 1 ? 4 : 2;
     if (stats && nb > 1 && d->stats_bstride < gpf)
         return tcvom_fail(TCVOM_ERR_ARG, "wsconv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);
     {
@@ -711,7 +720,7 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     // frames per launch: the buffer descriptors of the kernel address 32-bit byte ranges -- a batch whose frames together reach
     // 2^31 elements goes out as runs of frames (same tiles, same statistics groups per frame)
     const long long frame_elems = (long long)d->N * d->H * d->W * (d->C > d->ldo ? d->C : d->ldo);
-    long long fmax = ((1ll << (d->out_fp32 ? 30 : 31)) - 1) / (frame_elems > 0 ? frame_elems : 1);
+    long long fmax = ((1ll << (d->out_fp32 == 1 ? 30 : 31)) - 1) / (frame_elems > 0 ? frame_elems : 1);
     static const int test_fmax = getenv("TCVOM_WS_MAX_FRAMES") ? atoi(getenv("TCVOM_WS_MAX_FRAMES")) : 0;      // (tests: force the split)
     if (test_fmax > 0 && test_fmax < fmax) fmax = test_fmax;
     if (fmax < 1) fmax = 1;
@@ -727,17 +736,19 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
         a.in_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->C * 2);
         const dim3 grid(a.wgs_per_frame * nf);
         if (p.C == 64 && p.nt == 18) {
-            typedef WsCfg<64, 2, 2, 4, 1, 32, 18, true> G18;
+            typedef WsCfg<64, 2, 2, 4, 1, 32, 18, 1> G18;
             constexpr size_t lds_bytes = 2 * G18::SLOTB + 1024 + G18::XCHB + 128 * 4;
             static_assert(lds_bytes <= 160 * 1024, "LDS budget");
             static bool attr = false;
             if (!attr) {
-                e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr = true;
             }
-            if (d->out_fp32) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, true>), grid, dim3(256), lds_bytes, st, a);
-            else hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, false>), grid, dim3(256), lds_bytes, st, a);
+            if (d->out_fp32 == 1) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 1>), grid, dim3(256), lds_bytes, st, a);
+            else if (d->out_fp32 == 2) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 2>), grid, dim3(256), lds_bytes, st, a);
+            else hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 0>), grid, dim3(256), lds_bytes, st, a);
         } else if (p.C == 64) {
             auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32>;
             constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;

@@ -338,6 +338,31 @@ def _set_frames(arr, n, nf, w_stride):
             d.vec_bstride = 0
 
 
+HP_FP16 = _os.environ.get('TCVOM_NO_HP_FP16') is None        # A/B switch: fp32 conv outputs in every high-precision layer
+
+
+def _y_mode(t):
+    """The conv-output type code of the C ABI (tcvom_conv_desc.out_fp32 / y_fp32 of the norm kernels): 0 = the build's 16-bit storage
+    type, 1 = fp32, 2 = IEEE fp16 in a build that stores bf16."""
+    if t.dtype == torch.float32:
+        return 1
+    return 2 if (t.dtype == torch.float16 and H16 != torch.float16) else 0
+
+
+def _hp_y_dtype(descs, nf):
+    """Type of the conv output of a high-precision layer (it must not be rounded to bf16 before the BatchNorm has been applied): fp32,
+    or IEEE fp16 -- 11 significant bits at half the bytes through the conv store, the apply pass and both backward passes -- where the
+    kernel that writes it exists (the doubled-tap 64-channel layers on the weight-stationary kernel: encoder layer1)."""
+    if not (HP_FP16 and H16 != torch.float16 and len(descs) == 1):
+        return torch.float32
+    cache = descs[0].__dict__.setdefault('_hp_y', {})
+    if nf not in cache:
+        arr = _phase_array(descs)
+        _set_frames(arr, 1, nf, 0)
+        cache[nf] = torch.float16 if L._FNS['tcvom_conv_igemm_variant'](C.byref(arr[0]), 1) == b'wsconv<64,18>' else torch.float32
+    return cache[nf]
+
+
 def _stats_groups(descs, nf=1):
     """Statistics groups ONE frame of a launch of these phases writes (depends on the tile the library picks, which
     depends on the total workgroup count, hence on nf)."""
@@ -355,7 +380,7 @@ def _launch_conv(descs, x, wptr, out, bias, stats, act, st, nf=1, w_stride=0):
     n = len(descs)
     gf = _stats_groups(descs, nf)                  # groups per frame (all phases)
     _set_frames(arr, n, nf, w_stride)
-    f32 = 1 if out.dtype == torch.float32 else 0
+    f32 = _y_mode(out)
     for i in range(n):
         arr[i].act = act
         arr[i].out_fp32 = f32
@@ -420,7 +445,7 @@ class _ConvBNAct(torch.autograd.Function):
         has_bn = bn is not None
         # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
         hp = spec.hp and has_bn
-        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=torch.float32 if hp else H16, device=x.device)
+        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=_hp_y_dtype(geo.fwd, nf) if hp else H16, device=x.device)
         stats = None
         gn = cfg.group_norm
         if gn:
@@ -490,18 +515,18 @@ class _ConvBNAct(torch.autograd.Function):
             # not normalised / stored (z is uninitialised there; tcvom_amd.vmn slices the interior frames)
             f0, f1 = ctx.active
             L.call('tcvom_bn_apply', L.ptr(y[f0 * N:f1 * N]), C.c_void_p(ss.value + 4 * f0 * slot_stride), None, None,
-                   L.ptr(z[f0 * N:f1 * N]), geo.out_pixels, K, cfg.act, 1 if hp else 0, f1 - f0, slot_stride, st)
+                   L.ptr(z[f0 * N:f1 * N]), geo.out_pixels, K, cfg.act, _y_mode(y), f1 - f0, slot_stride, st)
         elif r1 is not None and RES_MASK and cfg.act != ACT_RELU6 and any(ctx.needs_input_grad[:6]):
             # residual site: one byte per 8 channels with the signs of norm(y) + res1 -- the backward takes the activation slope from it
             # instead of reading res1 again in both of its passes (saved in place of res1)
             amask = torch.empty(NT * geo.out_pixels * (K // 8), dtype=torch.uint8, device=x.device)
             L.call('tcvom_bn_apply_mask', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), L.ptr(amask), geo.out_pixels, K, cfg.act,
-                   1 if hp else 0, nf, slot_stride, st)
+                   _y_mode(y), nf, slot_stride, st)
             ctx.res_mask = True
             ctx.save_for_backward(x, y, gamma, amask)
             return z
         else:
-            L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, 1 if hp else 0,
+            L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, _y_mode(y),
                    nf, slot_stride, st)
         ctx.save_for_backward(x, y, gamma, r1)
         return z
@@ -566,7 +591,7 @@ class _ConvBNAct(torch.autograd.Function):
                 raise RuntimeError('conv %s: backward of a window after a newer forward of the same network is not '
                                    'supported (the per-window BatchNorm / weight arenas were reused)' % spec.name)
             ss, saved, stride = ctx.ss, ctx.saved, ctx.slot_stride
-            yf = 1 if y.dtype == torch.float32 else 0
+            yf = _y_mode(y)
             zf0, zf1 = 0, nf
             if dz2_rng is not None:
                 assert dz2 is None
@@ -666,7 +691,7 @@ def _backward_active(ctx, dz, dz2, ranged=()):
     groups = L.call('tcvom_bn_bwd_groups_n', P, K, nfa)
     dev = dza.device
     partial = torch.empty(nfa * groups * 2 * K, dtype=torch.float32, device=dev)
-    yf = 1 if y.dtype == torch.float32 else 0
+    yf = _y_mode(y)
     L.call('tcvom_bn_bwd_reduce', L.ptr(dza), L.ptr(dz2a), L.ptr(ya), None, ss, saved, L.ptr(partial), P, K, cfg.act, yf, nfa, stride, st)
     dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
     coef = torch.empty(nfa * 3 * K, dtype=torch.float32, device=dev)

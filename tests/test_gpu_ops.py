@@ -673,6 +673,10 @@ def test_wsconv_kernel_doubled_taps(N, H, W):
     y16 = torch.empty(N, H, W, cin, device=DEV, dtype=H16)
     ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y16, None, None, 1, st)
     assert rel_err(nchw(y16), F.relu(yref)) < 6e-3
+    # IEEE fp16 results whatever the build stores (what the layer1 convs of the bf16 build write: 11 significant bits)
+    yh = torch.empty(N, H, W, cin, device=DEV, dtype=torch.float16)
+    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), yh, None, None, 0, st)
+    assert rel_err(nchw(yh), yref) < 6e-4
 
 
 @pytest.mark.parametrize('cin,cout,dil,N,H,W,S', [(256, 256, 2, 1, 16, 24, 3), (512, 512, 4, 1, 16, 32, 1), (64, 64, 2, 2, 10, 18, 2),
