@@ -62,7 +62,7 @@ typedef struct {
     int32_t ldo;                 /* output pixel stride in elements */
     int32_t act;                 /* 0 none, 1 ReLU (before store and statistics) */
     int32_t out_fp32;            /* 1: store fp32 instead of the 16-bit storage type; 2: IEEE fp16 whatever the build stores (the
-                                    doubled-tap 64-channel layers on the weight-stationary kernel only) */
+                                    halo-tile kernel and the doubled-tap 64-channel layers on the weight-stationary kernel only) */
     int32_t stats_group_offset;  /* first statistics group written by this launch */
     int32_t batch;               /* >1: `batch` independent problems with the strides below: the dense GEMMs of GCA,
                                     and the S frames of a window through one conv layer (N samples per frame, own

@@ -63,6 +63,13 @@ __device__ __forceinline__ h16raw f2h(float a) {
     return __builtin_bit_cast(h16raw, v);
 }
 #endif
+// two values as IEEE fp16 (round to nearest even, saturated at the largest finite value), whatever the build's storage type: the conv
+// outputs of the high-precision layers of the bf16 build (tcvom_conv_desc.out_fp32 = 2)
+__device__ __forceinline__ unsigned pack2_ieee(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t_;
+    const f16x2_t_ v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, v);
+}
 __device__ __forceinline__ void unpack8(const uint4& q, float* f) {
     f[0] = hlo(q.x); f[1] = hhi(q.x); f[2] = hlo(q.y); f[3] = hhi(q.y);
     f[4] = hlo(q.z); f[5] = hhi(q.z); f[6] = hlo(q.w); f[7] = hhi(q.w);

@@ -295,7 +295,15 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
             }
         }
 #if HALO_ABL != 1
-        if (a.out_fp32) {
+        if (a.out_fp32 == 2) {                   // IEEE fp16 whatever the build stores (high-precision stem of the bf16 build)
+            h16raw* op = reinterpret_cast<h16raw*>(a.out) + o0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (8 * g + 4 * half < a.K)
+                        *reinterpret_cast<uint2*>(op + j * ostep + 8 * g) = make_uint2(pack2_ieee(acc[j][g * 4], acc[j][g * 4 + 1]), pack2_ieee(acc[j][g * 4 + 2], acc[j][g * 4 + 3]));
+        } else if (a.out_fp32) {
             float* op = reinterpret_cast<float*>(a.out) + o0;
 #pragma unroll
             for (int j = 0; j < 2; ++j)

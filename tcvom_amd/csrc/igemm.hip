@@ -514,10 +514,11 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     const h16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     if (d0->out_fp32 == 2) {
-        // IEEE fp16 results whatever the build stores: only the doubled-tap instantiation of the weight-stationary kernel writes them
-        // (ops.py asks for them where tcvom_conv_igemm_variant names that kernel)
-        const int r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
-        TCVOM_CHECK_ARG(r != 0, "conv_igemm: out_fp32 = 2 (fp16 results) is built for wsconv<64,18> only");
+        // IEEE fp16 results whatever the build stores: the halo kernel and the doubled-tap instantiation of the weight-stationary kernel
+        // write them (ops.py asks for them where tcvom_conv_igemm_variant names one of the two)
+        int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        if (r == 0) r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
+        TCVOM_CHECK_ARG(r != 0, "conv_igemm: out_fp32 = 2 (fp16 results) is built for halo_conv and wsconv<64,18> only");
         return r < 0 ? r : TCVOM_OK;
     }
     for (int i = 0; i < nphase; ++i) TCVOM_CHECK_ARG(descs[i].out_fp32 == 0 || descs[i].out_fp32 == 1, "conv_igemm: out_fp32 = %d", descs[i].out_fp32);

@@ -183,12 +183,6 @@ __device__ __forceinline__ void ws_dma_pieces(WsCtx<G>& c) {
 
 // (mov_dpp: no `old` operand -- lanes a row mask disables hold garbage afterwards, here rows 0 and 2 of the last level, unused;
 // with an `old` of 0 the compiler kept v_mov 0 + v_mov_dpp + v_add instead of one v_add_f32_dpp)
-// two values as IEEE fp16 (round to nearest even, saturated at the largest finite value), whatever the build's storage type
-__device__ __forceinline__ unsigned ws_pack2_ieee(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-    const f16x2_t v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
-    return __builtin_bit_cast(unsigned, v);
-}
 #define WS_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, true))
 
 // ---- epilogue piece Q of the previous tile.  Q = g * (NI + 1) + j: j < NI: activation, store and channel sums of the 4
@@ -247,7 +241,7 @@ __device__ __forceinline__ void ws_epi_piece(WsCtx<G>& c, const f32x4_t vals) {
         const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * G::OB) + (unsigned)(8 * G::OB) * g : 0xffffffffu;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
         if constexpr (G::OF32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vals), c.orsrc, (int)o, 0, 0);
-        else if constexpr (G::OM == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ws_pack2_ieee(vals[0], vals[1]), ws_pack2_ieee(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
+        else if constexpr (G::OM == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2_ieee(vals[0], vals[1]), pack2_ieee(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2h(vals[0], vals[1]), pack2h(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
     } else {
         float t[8];

@@ -352,14 +352,16 @@ def _y_mode(t):
 def _hp_y_dtype(descs, nf):
     """Type of the conv output of a high-precision layer (it must not be rounded to bf16 before the BatchNorm has been applied): fp32,
     or IEEE fp16 -- 11 significant bits at half the bytes through the conv store, the apply pass and both backward passes -- where the
-    kernel that writes it exists (the doubled-tap 64-channel layers on the weight-stationary kernel: encoder layer1)."""
+    kernel that writes it exists (the doubled-tap 64-channel layers on the weight-stationary kernel and the halo-tile kernel: encoder
+    layer1, stem conv1 / conv2)."""
     if not (HP_FP16 and H16 != torch.float16 and len(descs) == 1):
         return torch.float32
     cache = descs[0].__dict__.setdefault('_hp_y', {})
     if nf not in cache:
         arr = _phase_array(descs)
         _set_frames(arr, 1, nf, 0)
-        cache[nf] = torch.float16 if L._FNS['tcvom_conv_igemm_variant'](C.byref(arr[0]), 1) == b'wsconv<64,18>' else torch.float32
+        var = L._FNS['tcvom_conv_igemm_variant'](C.byref(arr[0]), 1)
+        cache[nf] = torch.float16 if (var == b'wsconv<64,18>' or var.startswith(b'halo_conv')) else torch.float32
     return cache[nf]
 
 
