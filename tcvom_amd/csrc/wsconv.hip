@@ -634,7 +634,7 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     }
     if (n != 9 || (n2 != 0 && n2 != 9)) return p;
     p.nt = n2 ? 18 : 9;
-    if (p.nt == 9 && d->out_fp32) return p;             // (fp32 / fp16 results are built for the doubled-tap instantiation only)
+    if (p.nt == 9 && d->out_fp32 == 1) return p;        // (fp32 results are built for the doubled-tap instantiation only)
     if (d->out_fp32 < 0 || d->out_fp32 > 2) return p;
     p.C = d->C;
     p.th = 8;
@@ -743,6 +743,18 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
             if (d->out_fp32 == 1) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 1>), grid, dim3(256), lds_bytes, st, a);
             else if (d->out_fp32 == 2) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 2>), grid, dim3(256), lds_bytes, st, a);
             else hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 0>), grid, dim3(256), lds_bytes, st, a);
+        } else if (p.C == 64 && d->out_fp32 == 2) {
+            auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32, 9, 2>;
+            constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
+            static bool attr = false;
+            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+        } else if (p.C == 128 && d->out_fp32 == 2) {
+            auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16, 9, 2>;
+            constexpr size_t lds_bytes = 2 * WsCfg<128, 4, 1, 4, 2, 16>::SLOTB + 1024 + WsCfg<128, 4, 1, 4, 2, 16>::XCHB + 128 * 4;
+            static bool attr = false;
+            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
         } else if (p.C == 64) {
             auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32>;
             constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;

@@ -16,14 +16,23 @@ from .ops import ACT_NONE, ACT_RELU, ACT_LEAKY, ConvCfg, H16
 from .weights import ConvSpec, WeightBank, bank_token
 
 TRIMAP_CHANNEL = 3
-# which encoder stages run the high-precision forward (doubled-tap weights hi + residual, conv output in fp32 until the BatchNorm
-# has been applied).  The bf16 build needs it for the stem + layer1 to get the alpha error under the north-star 1e-4 (DESIGN.md
-# section 6); the fp16 build does not (3 more mantissa bits: the plain pipeline sits ~25x below the bound) and runs none.
+# which encoder stages run the high-precision forward (doubled-tap weights hi + residual, conv output in fp32 / IEEE fp16 until the
+# BatchNorm has been applied).  The bf16 build needs it for the stem to get the alpha error under the north-star 1e-4 (DESIGN.md
+# section 6; until late round 5 layer1 too -- its share of the noise is now removed by fp16 conv outputs instead of doubled taps, see
+# Y16_LAYERS); the fp16 build does not (3 more mantissa bits: the plain pipeline sits ~25x below the bound) and runs none.
 # Study knob: TCVOM_HP_LAYERS=conv1,conv2,conv3,layer1 / TCVOM_HP_LAYERS= (none)
 import os as _os
 from . import _lib as _L
-HP_LAYERS = tuple(n for n in _os.environ.get('TCVOM_HP_LAYERS', 'conv1,conv2,conv3,layer1' if _L.DTYPE_NAME == 'bf16' else '').split(',') if n)
+HP_LAYERS = tuple(n for n in _os.environ.get('TCVOM_HP_LAYERS', 'conv1,conv2,conv3' if _L.DTYPE_NAME == 'bf16' else '').split(',') if n)
 HIGH_PRECISION_STEM = bool(HP_LAYERS)
+# encoder stages whose (plain, single-tap-list) convs store their outputs as IEEE fp16 where the kernel that writes it exists (the
+# weight-stationary 3x3 kernel): the same bytes as bf16 with 11 instead of 8 significant bits in front of the BatchNorm
+# Measured (round 5, one box; unknown-pixel alpha MSE vs the oracle at 256x320 (two runs) / 512^2 / 544x960 / 1088x1920, bound 1e-4, ms / step):
+#   HP stem + layer1 (doubled taps, fp32 / fp16 outputs), no y16     9.49, 9.69e-5 / 7.58e-5 / 6.92e-5 / 6.45e-5   22.67
+#   the same + y16 layer2                                           9.43, 9.14e-5 / 7.30e-5 / 6.74e-5 / 6.34e-5   22.64
+#   HP stem only, y16 layer1 + layer2  (the default)                 9.43, 9.54e-5 / 7.71e-5 / 7.14e-5 / 6.75e-5   22.41
+# (the forward differs from run to run by the atomics order of the SpectralNorm sums: +-2 % on these numbers)
+Y16_LAYERS = tuple(n for n in _os.environ.get('TCVOM_Y16_LAYERS', 'layer1,layer2').split(',') if n) if _L.DTYPE_NAME == 'bf16' else ()
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -186,6 +195,7 @@ class ResGuidedCxtAtten(nn.Module):
             # residual (exact to ~2^-16) and their conv outputs stay fp32 until BatchNorm has been applied.
             hp = HIGH_PRECISION_STEM and name.split('.')[0] in HP_LAYERS
             spec = sn.spec('encoder.' + name, 'frame', needs_dgrad, hp=hp)
+            spec.y16 = (not hp) and name.split('.')[0] in Y16_LAYERS
             bank.register(spec)
             return ConvCfg(bank, spec, bn=bn, act=act, pre_relu=pre_relu)
         self._stem = [reg('conv1', self.conv1, self.bn1, ACT_RELU, needs_dgrad=False),

@@ -349,20 +349,20 @@ def _y_mode(t):
     return 2 if (t.dtype == torch.float16 and H16 != torch.float16) else 0
 
 
-def _hp_y_dtype(descs, nf):
+def _hp_y_dtype(descs, nf, want=torch.float16, otherwise=torch.float32):
     """Type of the conv output of a high-precision layer (it must not be rounded to bf16 before the BatchNorm has been applied): fp32,
     or IEEE fp16 -- 11 significant bits at half the bytes through the conv store, the apply pass and both backward passes -- where the
     kernel that writes it exists (the doubled-tap 64-channel layers on the weight-stationary kernel and the halo-tile kernel: encoder
     layer1, stem conv1 / conv2)."""
     if not (HP_FP16 and H16 != torch.float16 and len(descs) == 1):
-        return torch.float32
+        return otherwise
     cache = descs[0].__dict__.setdefault('_hp_y', {})
     if nf not in cache:
         arr = _phase_array(descs)
         _set_frames(arr, 1, nf, 0)
         var = L._FNS['tcvom_conv_igemm_variant'](C.byref(arr[0]), 1)
-        cache[nf] = torch.float16 if (var == b'wsconv<64,18>' or var.startswith(b'halo_conv')) else torch.float32
-    return cache[nf]
+        cache[nf] = var.startswith(b'wsconv') or var.startswith(b'halo_conv')
+    return want if cache[nf] else otherwise
 
 
 def _stats_groups(descs, nf=1):
@@ -447,7 +447,9 @@ class _ConvBNAct(torch.autograd.Function):
         has_bn = bn is not None
         # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
         hp = spec.hp and has_bn
-        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=_hp_y_dtype(geo.fwd, nf) if hp else H16, device=x.device)
+        # (y16 layers: the conv output in IEEE fp16 where the kernel that writes it exists -- same bytes as bf16, 11 significant bits)
+        ydt = _hp_y_dtype(geo.fwd, nf) if hp else (_hp_y_dtype(geo.fwd, nf, torch.float16, H16) if (getattr(spec, 'y16', False) and has_bn) else H16)
+        y = torch.empty((NT, geo.OH, geo.OW, K), dtype=ydt, device=x.device)
         stats = None
         gn = cfg.group_norm
         if gn:
