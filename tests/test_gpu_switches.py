@@ -1,7 +1,8 @@
 """The A/B switches of tcvom_amd/ops.py select alternative code paths that stay in the product as fall-backs (shapes the fast paths
 do not take) -- the NT attention GEMMs on transposed copies + the fp32 score matrix + row softmax (TCVOM_NO_GCA_KMAJOR,
 TCVOM_NO_FUSED_SOFTMAX), SpectralNorm's inner product as a pass over the weight gradient, zero-padded instead of row-range
-gradients, the end frames of the tail-only branches run on zero gradients (TCVOM_NO_SN_DOT, TCVOM_NO_RANGED, TCVOM_NO_TAIL_SKIP).
+gradients, the end frames of the tail-only branches run on zero gradients (TCVOM_NO_SN_DOT, TCVOM_NO_RANGED, TCVOM_NO_TAIL_SKIP), the
+round-5 re-routings (TCVOM_NO_PWCONV, TCVOM_NO_WGRAD_HETERO, TCVOM_NO_WGRAD_GROUP_LAYERS, TCVOM_NO_HP_FP16).
 One 544 x 960 training window through each set must give the losses and per-group gradient norms of the default paths."""
 import json
 import os
@@ -36,7 +37,12 @@ def test_alternative_code_paths_agree_with_the_default_ones():
             # the K <= 64 transposed / stride-2-gradient / 64 <-> 32 channel convs on the implicit GEMM instead of csrc/sconv.hip
             'sconv off': {'TCVOM_NO_SCONV': '1'},
             # the Temporal Attention Module on the one-wave-per-pixel tile kernels (what C != 128 runs) and split between both
-            'TAM vector kernels': {'TCVOM_TAM_DENSE': '65'}, 'TAM split': {'TCVOM_TAM_DENSE': '12'}}
+            'TAM vector kernels': {'TCVOM_TAM_DENSE': '65'}, 'TAM split': {'TCVOM_TAM_DENSE': '12'},
+            # round 5: the 1x1 convs on the implicit GEMM / 256-tile GEMM instead of csrc/pwconv.hip; one weight-gradient launch per
+            # geometry (no tcvom_wgrad_ws_hetero) and per layer (no cross-layer batches)
+            'pwconv / grouped weight gradients off': {'TCVOM_NO_PWCONV': '1', 'TCVOM_NO_WGRAD_HETERO': '1', 'TCVOM_NO_WGRAD_GROUP_LAYERS': '1'},
+            # fp32 instead of IEEE fp16 conv outputs in the high-precision stem (and bf16 instead of fp16 ones in layer1 / layer2)
+            'fp32 / bf16 conv outputs': {'TCVOM_NO_HP_FP16': '1'}}
 
     def worst(a, b):
         w = 0.0
