@@ -31,7 +31,8 @@ HIGH_PRECISION_STEM = bool(HP_LAYERS)
 #   HP stem + layer1 (doubled taps, fp32 / fp16 outputs), no y16     9.49, 9.69e-5 / 7.58e-5 / 6.92e-5 / 6.45e-5   22.67
 #   the same + y16 layer2                                           9.43, 9.14e-5 / 7.30e-5 / 6.74e-5 / 6.34e-5   22.64
 #   HP stem only, y16 layer1 + layer2  (the default)                 9.43, 9.54e-5 / 7.71e-5 / 7.14e-5 / 6.75e-5   22.41
-# (the forward differs from run to run by the atomics order of the SpectralNorm sums: +-2 % on these numbers)
+# (the forward differs from run to run by the atomics order of the SpectralNorm sums: +-2 % on these numbers; 12 more runs of the
+#  default at 256x320 on another box: 9.13 .. 9.38e-5, mean 9.25e-5)
 Y16_LAYERS = tuple(n for n in _os.environ.get('TCVOM_Y16_LAYERS', 'layer1,layer2').split(',') if n) if _L.DTYPE_NAME == 'bf16' else ()
 
 
