@@ -470,7 +470,11 @@ def main():
             'value': round(win_per_s, 4), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': L.DTYPE_NAME, 'data': 'synthetic',
-            'config': {'workload': ('GCA+TAM (vmn_gca) forward only (train-mode statistics, no_grad; losses computed), one 3-frame %dx%d window (B=1 clip) '
+            'config': {'precision_notes': ('bf16 MFMA operands, activations and gradients; fp32 accumulation, statistics, softmax, losses, master weights; '
+                                          'encoder stem on doubled-tap (16-bit head + residual) weights; conv outputs of the stem / layer1 / layer2 stored as '
+                                          'IEEE fp16 (stem conv3: fp32) until the BatchNorm has been applied (DESIGN.md section 6)') if (L.DTYPE_NAME == 'bf16' and args.config == 'gca') else
+                                         ('%s storage, fp32 accumulation / statistics / softmax / losses / master weights' % L.DTYPE_NAME),
+                       'workload': ('GCA+TAM (vmn_gca) forward only (train-mode statistics, no_grad; losses computed), one 3-frame %dx%d window (B=1 clip) '
                                     'per step, agg_window 7, dilate_kernel 12, formula-initialised weights; %s storage' % (H, W, L.DTYPE_NAME)) if args.forward_only else
                                    ('GCA+TAM (vmn_gca) fwd+bwd+grad-allreduce+Adam, L_alpha+0.5L_dt+0.25L_att, one 3-frame '
                                     '%dx%d window (B=1 clip) per GPU per step, agg_window 7, dilate_kernel 12, '
