@@ -881,6 +881,10 @@ def test_wsconv_kernel(cin, N, H, W, bias):
     taps = [(d.tap_dh[t], d.tap_dw[t]) for t in range(9)]
     yref = F.relu(F.conv2d(bf(x), bf(spec.weight.detach().cpu()), b.detach().cpu() if bias else None, 1, 1))
     assert len(taps) == 9 and rel_err(nchw(y_ws), yref) < 1e-2
+    # IEEE fp16 results whatever the build stores (what the plain convs of encoder layer1 / layer2 write in the bf16 build)
+    y_h = torch.empty(N, H, W, cin, device=DEV, dtype=torch.float16)
+    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y_h, b, None, 1, st)
+    assert rel_err(nchw(y_h), yref) < 1.5e-3
 
 
 # --------------------------------------------------------------------------------------------- spectral norm
