@@ -62,7 +62,7 @@ typedef struct {
     int32_t ldo;                 /* output pixel stride in elements */
     int32_t act;                 /* 0 none, 1 ReLU (before store and statistics) */
     int32_t out_fp32;            /* 1: store fp32 instead of the 16-bit storage type; 2: IEEE fp16 whatever the build stores (the
-                                    halo-tile kernel and the doubled-tap 64-channel layers on the weight-stationary kernel only) */
+                                    halo-tile kernel, the weight-stationary kernel and -- with in_f16 -- the implicit GEMM) */
     int32_t stats_group_offset;  /* first statistics group written by this launch */
     int32_t batch;               /* >1: `batch` independent problems with the strides below: the dense GEMMs of GCA,
                                     and the S frames of a window through one conv layer (N samples per frame, own
@@ -71,6 +71,10 @@ typedef struct {
                                     only, served by the weight-stationary kernel): element (k, slot, c) at
                                     ((((k/32)*wt + slot)*(C/16) + c/16)*64 + ((c/8)&1)*32 + k%32)*8 + c%8, i.e. every
                                     32 x 16 MFMA A fragment is one contiguous 1 KiB block in lane order */
+    int32_t in_f16;              /* 1 (bf16 build; ignored by the fp16 build, where it is the only format): `in` and `w` hold IEEE fp16
+                                    and the product runs on v_mfma_f32_32x32x16_f16 -- the forward convs of the encoder stem, layer1 and
+                                    layer2 ("fp16 island", tcvom_amd/gca_net.py); requires out_fp32 == 2.  Served by the halo-tile
+                                    kernel, the weight-stationary kernel and the implicit GEMM */
     int64_t in_bstride, w_bstride, out_bstride, vec_bstride;
     int64_t stats_bstride;       /* statistics groups between batch elements (frame f writes groups
                                     stats_group_offset + f*stats_bstride + ...) */
@@ -201,6 +205,14 @@ int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, co
 int tcvom_bn_apply_mask(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z, uint8_t* mask,
                         int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                         void* stream);
+/* The apply pass inside the "fp16 island" of the bf16 build (the encoder stem, layer1 and layer2 of models/GCA/encoders/resnet_enc.py:70-84,
+ * whose forward runs on IEEE fp16 operands: tcvom_conv_desc.in_f16): y is IEEE fp16 (y_fp32 must be 2); z is stored twice -- in the
+ * build's type to `z` (what the backward, the weight gradient and every consumer outside the island read) and as IEEE fp16 to `z16`
+ * (what the island's next forward conv and the residual input of its block read); res1 is IEEE fp16 when res1_f16 != 0;
+ * mask as in tcvom_bn_apply_mask, or NULL. */
+int tcvom_bn_apply_f16(const void* y, const float* scale_shift, const void* res1, int32_t res1_f16, const void* res2, void* z,
+                       void* z16, uint8_t* mask, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes,
+                       int64_t slot_stride, void* stream);
 int tcvom_bn_bwd_groups(int64_t pixels, int32_t C);                       /* = tcvom_bn_bwd_groups_n(pixels, C, 1) */
 /* partial-sum groups per frame of a backward reduction over `nframes` frames (what tcvom_bn_bwd_reduce launches and writes) */
 int tcvom_bn_bwd_groups_n(int64_t pixels, int32_t C, int32_t nframes);
@@ -369,6 +381,9 @@ int tcvom_gca_dq_dk(const void* T, const void* Gt, float* dWq, float* Mp, int32_
 
 /* ------------------------------------------------------------------ layout / resampling helpers (NHWC bf16) */
 int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* the AvgPool2d(2, 2) of encoder layer2's downsample branch (resnet_enc.py:107-111) inside the fp16 island of the bf16 build: x16 is
+ * IEEE fp16; the result is stored in the build's type (y) and as IEEE fp16 (y16) */
+int tcvom_avgpool2_f16(const void* x16, void* y, void* y16, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int tcvom_upsample2(const void* y, void* x, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream);
 int tcvom_sumpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream);
 int tcvom_reflect_pad1(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
@@ -482,6 +497,12 @@ int tcvom_preprocess_clips(const float* a, const float* fg, const float* bg, flo
                            float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
                            float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
                            const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream);
+/* ... and the network input a second time as IEEE fp16 (x8_f16: same shape as x8; NULL = tcvom_preprocess_clips): what the first
+ * conv of the fp16 island of the bf16 build reads */
+int tcvom_preprocess_clips_f16(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                               float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, void* x8_f16,
+                               float* trimask, float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
+                               const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream);
 int tcvom_masked_l1_fwd(const float* p1, const float* g1, const float* m1, const float* p2, const float* g2,
                         const float* m2, const float* fgs, const float* bgs, float* alphas, float* comps,
                         float* acc, int64_t B, int64_t HW, int64_t p_stride, int64_t frame_stride, int64_t rgb_stride, void* stream);

@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ('ntaps', C.c_int32),
         ('tap_dh', C.c_int32 * MAX_TAPS), ('tap_dw', C.c_int32 * MAX_TAPS), ('tap_w', C.c_int32 * MAX_TAPS),
         ('wt', C.c_int32), ('ldo', C.c_int32), ('act', C.c_int32), ('out_fp32', C.c_int32),
-        ('stats_group_offset', C.c_int32), ('batch', C.c_int32), ('w_layout', C.c_int32),
+        ('stats_group_offset', C.c_int32), ('batch', C.c_int32), ('w_layout', C.c_int32), ('in_f16', C.c_int32),
         ('in_bstride', C.c_int64), ('w_bstride', C.c_int64), ('out_bstride', C.c_int64), ('vec_bstride', C.c_int64),
         ('stats_bstride', C.c_int64),
     ]
@@ -101,6 +101,7 @@ _PROTOS = {
     'tcvom_bn_eval_coeffs': [i32, vp, vp, vp, vp, f32, vp, vp, vp],
     'tcvom_bn_apply': [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_apply_mask': [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_apply_f16': [vp, vp, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_reduce_mask': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_apply_mask': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
@@ -131,6 +132,7 @@ _PROTOS = {
     'tcvom_gca_dq_dk': [vp, vp, vp, vp, i32, i32, i64, i32, vp],
     'tcvom_sn_backward': [vp, SP, vp, i32, vp, i32, vp, vp, i64, vp, i32, vp, f32, vp, vp, vp],
     'tcvom_avgpool2': [vp, vp, i32, i32, i32, i32, vp],
+    'tcvom_avgpool2_f16': [vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_upsample2': [vp, vp, i32, i32, i32, i32, f32, vp],
     'tcvom_sumpool2': [vp, vp, i32, i32, i32, i32, f32, vp],
     'tcvom_reflect_pad1': [vp, vp, i32, i32, i32, i32, vp],
@@ -196,6 +198,7 @@ _PROTOS = {
     'tcvom_gca_patches_bwd': [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'tcvom_preprocess': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
     'tcvom_preprocess_clips': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), f32, i32, vp],
+    'tcvom_preprocess_clips_f16': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(i32), f32, i32, vp],
     'tcvom_masked_l1_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp],
     'tcvom_masked_l1_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i64, i64, i64, i64, vp],
     'tcvom_avgpool8': [vp, vp, i64, i32, i32, vp],

@@ -21,6 +21,11 @@ typedef __bf16 act_t;
 #define mfma16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define dot2_h16 __builtin_amdgcn_fdot2_f32_bf16
 #endif
+#ifdef TCVOM_F16
+#define TCVOM_BUILD_F16 1
+#else
+#define TCVOM_BUILD_F16 0
+#endif
 typedef __attribute__((ext_vector_type(8))) act_t h16x8_t;
 typedef __attribute__((ext_vector_type(2))) act_t h16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -69,6 +74,45 @@ __device__ __forceinline__ unsigned pack2_ieee(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t_;
     const f16x2_t_ v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
     return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ h16raw f2h_ieee(float a) {
+    const _Float16 v = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    return __builtin_bit_cast(h16raw, v);
+}
+__device__ __forceinline__ void unpack8_ieee(const uint4& q, float* f) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t_;
+    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2_t_ h = __builtin_bit_cast(f16x2_t_, u[i]);
+        f[2 * i] = (float)h.x;
+        f[2 * i + 1] = (float)h.y;
+    }
+}
+__device__ __forceinline__ uint4 pack8_ieee(const float* f) {
+    uint4 q;
+    q.x = pack2_ieee(f[0], f[1]); q.y = pack2_ieee(f[2], f[3]);
+    q.z = pack2_ieee(f[4], f[5]); q.w = pack2_ieee(f[6], f[7]);
+    return q;
+}
+// ---- the "fp16 island" of the bf16 build (tcvom_conv_desc.in_f16, gca_net.py: F16_ISLAND): the forward convs of the encoder stem,
+// layer1 and layer2 take IEEE fp16 activations and IEEE fp16 packed weights whatever the build stores -- same MFMA rate, same bytes,
+// three more significant bits in every stored value of the layers that inject >= 99 % of the storage noise of the alpha matte.
+// XF = 1 selects v_mfma_f32_32x32x16_f16 on the raw operand bits; XF = 0 (and every XF in the fp16 build) the build's own instruction.
+template <int XF>
+__device__ __forceinline__ f32x16_t mfma16x(h16x8_t a, h16x8_t b, f32x16_t c) {
+#ifndef TCVOM_F16
+    if constexpr (XF) {
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t_;
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t_, a), __builtin_bit_cast(f16x8_t_, b), c, 0, 0, 0);
+    } else
+#endif
+    return mfma16(a, b, c, 0, 0, 0);
+}
+// ... and the 16-bit store of such a kernel: IEEE fp16 in XF mode, the build's type otherwise
+template <int XF>
+__device__ __forceinline__ unsigned pack2x(float a, float b) {
+    if constexpr (XF) return pack2_ieee(a, b); else return pack2h(a, b);
 }
 __device__ __forceinline__ void unpack8(const uint4& q, float* f) {
     f[0] = hlo(q.x); f[1] = hhi(q.x); f[2] = hlo(q.y); f[3] = hhi(q.y);

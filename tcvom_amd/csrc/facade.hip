@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void dilate_words_kernel(const unsigned long l
 // stage 3: network input x8 [F,H,W,8] bf16 = {norm R,G,B, onehot bg,unk,fg, 0, 0}; trimask fp32; tris_vis fp32
 __global__ void assemble_kernel(const float* __restrict__ gts, const float* __restrict__ imgs, const unsigned char* __restrict__ dil,
                                 uint4* __restrict__ x8, float* __restrict__ trimask, float* __restrict__ tris_vis,
-                                int64_t F, int64_t HW, float eps, int tri_channels) {
+                                int64_t F, int64_t HW, float eps, int tri_channels, uint4* __restrict__ x8_f16) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
     GRID_STRIDE(v, F * HW) {
         const int64_t f = v / HW, p = v % HW;
@@ -115,6 +115,7 @@ __global__ void assemble_kernel(const float* __restrict__ gts, const float* __re
         o[6] = 0.f;
         o[7] = 0.f;
         x8[v] = pack8(o);
+        if (x8_f16) x8_f16[v] = pack8_ieee(o);       // the same input in IEEE fp16 (fp16 island of the bf16 build: encoder conv1 reads it)
         trimask[v] = u ? 1.f : 0.f;
         tris_vis[v] = u ? 128.f / 255.f : (tri_channels == 3 ? g : al);
     }
@@ -326,10 +327,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const int64_t* __restrict__ t
 }
 
 // ---------------------------------------------------------------- C ABI
-extern "C" int tcvom_preprocess_clips(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
-                                      float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
-                                      float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
-                                      const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream) {
+static int preprocess_clips_impl(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                                 float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, void* x8_f16, float* trimask,
+                                 float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
+                                 const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream) {
     // bg == NULL (then bgs may be NULL too): EvalModel.preprocess (models/model.py:360-386) -- `fg` is the frame, `a` the trimap
     TCVOM_CHECK_ARG(a && fg && gts && fgs && (bgs || !bg) && imgs && unk_raw && unk_tmp && unk_dil && x8 && trimask && tris_vis && clip_radii,
                     "preprocess: null pointer");
@@ -357,9 +358,25 @@ extern "C" int tcvom_preprocess_clips(const float* a, const float* fg, const flo
         }
         c0 = c1;
     }
-    hipLaunchKernelGGL(assemble_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, gts, imgs, unk_dil, (uint4*)x8, trimask, tris_vis, frames, HW, eps, tri_channels);
+    hipLaunchKernelGGL(assemble_kernel, dim3(sgrid(frames * HW)), dim3(256), 0, st, gts, imgs, unk_dil, (uint4*)x8, trimask, tris_vis, frames, HW, eps, tri_channels, (uint4*)x8_f16);
     TCVOM_LAUNCH_CHECK("preprocess");
     return TCVOM_OK;
+}
+extern "C" int tcvom_preprocess_clips(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                                      float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, float* trimask,
+                                      float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
+                                      const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream) {
+    return preprocess_clips_impl(a, fg, bg, gts, fgs, bgs, imgs, unk_raw, unk_tmp, unk_dil, x8, nullptr, trimask, tris_vis, clips, frames_per_clip,
+                                 H, W, clip_radii, eps, tri_channels, stream);
+}
+// ... and the network input a second time as IEEE fp16 (x8_f16, same shape; NULL = tcvom_preprocess_clips): what the first conv of the
+// fp16 island of the bf16 build reads (tcvom_conv_desc.in_f16)
+extern "C" int tcvom_preprocess_clips_f16(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,
+                                          float* imgs, uint8_t* unk_raw, uint8_t* unk_tmp, uint8_t* unk_dil, void* x8, void* x8_f16,
+                                          float* trimask, float* tris_vis, int32_t clips, int32_t frames_per_clip, int32_t H, int32_t W,
+                                          const int32_t* clip_radii, float eps, int32_t tri_channels, void* stream) {
+    return preprocess_clips_impl(a, fg, bg, gts, fgs, bgs, imgs, unk_raw, unk_tmp, unk_dil, x8, x8_f16, trimask, tris_vis, clips, frames_per_clip,
+                                 H, W, clip_radii, eps, tri_channels, stream);
 }
 
 extern "C" int tcvom_preprocess(const float* a, const float* fg, const float* bg, float* gts, float* fgs, float* bgs,

@@ -792,6 +792,7 @@ static int g256_split_tail(Gemm256Args& g, dim3& grid, bool eligible, void* last
 // does the dense descriptor `d` run on this kernel?  (plain row-major operands, enough 256x256 tiles to fill the chip)
 int gemm_nt256_takes(const tcvom_conv_desc* d) {
     if (d->ntaps != 1 || d->tap_w[0] < 0) return 0;
+    if (d->in_f16 && !TCVOM_BUILD_F16) return 0;          // IEEE fp16 operands in the bf16 build: igemm_nt
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0 || d->wt != 1) return 0;
     if (d->C % 64 != 0 || d->K % 4 != 0 || d->ldo % 4 != 0) return 0;
     const long long P = (long long)d->N * d->PH * d->PW;

@@ -86,7 +86,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // S = input stride (1, or 2: the stride-2 3x3 convs on the 8-channel full-resolution inputs, resnet_enc.py:68 conv1 and the
 // guidance head res_gca_enc.py:20-28): the output tile stays 8 x 32 pixels, its halo covers (S*8 + 2) x (S*32 + 2) input pixels.
-template <int C, int NCH, int S>
+// XF = 1: IEEE fp16 operands whatever the build stores (tcvom_conv_desc.in_f16: the fp16 island of the bf16 build, common.h)
+template <int C, int NCH, int S, int XF = 0>
 __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
     constexpr int CU = C / 8;                           // 16-byte units per pixel
     constexpr int HW_ = S * HALO_TW + 2, HH_ = S * HALO_TH + 2, PIX_ = HW_ * HH_;
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(ahead) : "memory");
             constexpr int k = c % (HALO_PF + 1);
             halo_fence(fa[k]); halo_fence(fb[k][0]); halo_fence(fb[k][1]);
-            acc[0] = mfma16(halo_value(fa[k]), halo_value(fb[k][0]), acc[0], 0, 0, 0);
-            acc[1] = mfma16(halo_value(fa[k]), halo_value(fb[k][1]), acc[1], 0, 0, 0);
+            acc[0] = mfma16x<XF>(halo_value(fa[k]), halo_value(fb[k][0]), acc[0]);
+            acc[1] = mfma16x<XF>(halo_value(fa[k]), halo_value(fb[k][1]), acc[1]);
             __builtin_amdgcn_sched_barrier(0);
         });
         HALO_STAMP(3);
@@ -366,11 +367,12 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-struct HaloPlan { bool ok; int C, nch, ntaps, S, org; int taps[HALO_MAX_TAPS + 2]; };
+struct HaloPlan { bool ok, xf; int C, nch, ntaps, S, org; int taps[HALO_MAX_TAPS + 2]; };
 
 static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     HaloPlan p;
     p.ok = false;
+    p.xf = false;
     if (nphase != 1) return p;
     if (d->batch > 1) {           // frame-batched call: frames must be contiguous sample groups
         if (d->in_bstride != (long long)d->N * d->H * d->W * d->C || d->out_bstride != (long long)d->N * d->OH * d->OW * d->ldo) return p;
@@ -401,6 +403,10 @@ static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     // instantiated shapes: C=8 with 9 taps (5 chunks; stride 2 also with the 18 taps = 9 chunks of a high-precision layer),
     // C=32 with 9 taps (18 chunks) or 18 taps (36 chunks)
     if (!((d->C == 8 && (nch == 5 || (S == 2 && nch == 9))) || (d->C == 32 && (nch == 18 || nch == 36)))) return p;
+    // IEEE fp16 operands in the bf16 build (tcvom_conv_desc.in_f16): instantiated for the two stem layers of the fp16 island, with
+    // fp16 results; other shapes go to the implicit GEMM (the plan -- not the launch -- declines: the statistics layout follows it)
+    p.xf = d->in_f16 != 0 && !TCVOM_BUILD_F16;
+    if (p.xf && !(d->out_fp32 == 2 && ((S == 2 && nch == 5) || (S == 1 && d->C == 32 && nch == 18)))) return p;
     for (int t = n; t < padded; ++t) p.taps[t] = -1;
     p.ok = true;
     p.C = d->C;
@@ -482,7 +488,12 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
         if (!attr_) { e = hipFuncSetAttribute((const void*)halo_conv_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
         hipLaunchKernelGGL((halo_conv_kernel<__VA_ARGS__>), dim3(grid), dim3(256), lds_bytes, st, a);        \
     }
-    if (p.S == 2 && p.nch == 5) HALO_LAUNCH(8, 5, 2)
+    if (p.xf) {
+        // fp16 island: encoder conv1 (8 -> 32, stride 2) and conv2 (32 -> 32); IEEE fp16 in, IEEE fp16 out (halo_plan admits no other)
+        if (p.S == 2) HALO_LAUNCH(8, 5, 2, 1)
+        else HALO_LAUNCH(32, 18, 1, 1)
+    }
+    else if (p.S == 2 && p.nch == 5) HALO_LAUNCH(8, 5, 2)
     else if (p.S == 2) HALO_LAUNCH(8, 9, 2)
     else if (p.C == 8) HALO_LAUNCH(8, 5, 1)
     else if (p.nch == 18) HALO_LAUNCH(32, 18, 1)

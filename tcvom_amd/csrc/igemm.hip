@@ -63,7 +63,8 @@ extern "C" int tcvom_trace_read(unsigned long long* host, int n) {
 #ifndef NT_DBG
 #define NT_DBG 0            // kernel study builds only: 1 = no LDS reads / MFMAs, 2 = no DMA, 3 = no epilogue
 #endif
-template <int TM, int TN, int WM, int WN, int NST>
+// XF = 1: IEEE fp16 operands and IEEE fp16 16-bit results whatever the build stores (tcvom_conv_desc.in_f16, common.h)
+template <int TM, int TN, int WM, int WN, int NST, int XF = 0>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const h16raw* __restrict__ in, const h16raw* __restrict__ wgt, void* __restrict__ outp,
     const float* __restrict__ bias, const float* __restrict__ mscale, const float* __restrict__ mdiag,
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
             for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b)
-                    acc[a][b] = mfma16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = mfma16x<XF>(af[a], bfr[b], acc[a][b]);
         }
         slot = slot + 1 == NST ? 0 : slot + 1;
         islot = islot + 1 == NST ? 0 : islot + 1;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                     }
                     if (pvalid[b] && mrow < K) {
                         if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
-                        else *reinterpret_cast<uint2*>(reinterpret_cast<h16raw*>(outp) + out_off[b] + mrow) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+                        else *reinterpret_cast<uint2*>(reinterpret_cast<h16raw*>(outp) + out_off[b] + mrow) = make_uint2(pack2x<XF>(v[0], v[1]), pack2x<XF>(v[2], v[3]));
                     }
                 }
                 if (do_stats) {
@@ -330,7 +331,9 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
             }
         }
     };
-    if (mdiag) {
+    if constexpr (XF) {                  // (the host admits out_fp32 == 2 only: fp16 results, no diagonal term)
+        emit(std::false_type{}, std::false_type{});
+    } else if (mdiag) {
         if (d.out_fp32) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{});
     } else {
         if (d.out_fp32) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{});
@@ -513,7 +516,15 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     const NtCfg c = nt_config(d0, nphase);
     const h16raw* zp = zero_page_for_current_device();
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
-    if (d0->out_fp32 == 2) {
+    // IEEE fp16 operands in the bf16 build (the fp16 island, tcvom_conv_desc.in_f16): fp16 results; halo_conv / wsconv where their plans
+    // take the shape, else the implicit GEMM's XF instantiations
+    const bool xf = d0->in_f16 != 0 && !TCVOM_BUILD_F16;
+    if (xf) {
+        for (int i = 0; i < nphase; ++i)
+            TCVOM_CHECK_ARG(descs[i].in_f16 != 0 && descs[i].out_fp32 == 2, "conv_igemm: in_f16 needs out_fp32 == 2 (fp16 results) in every phase");
+        TCVOM_CHECK_ARG(!mscale && !mdiag, "conv_igemm: in_f16 with a column scale / diagonal term is not built");
+    }
+    if (d0->out_fp32 == 2 && !xf) {
         // IEEE fp16 results whatever the build stores: the halo kernel and the doubled-tap instantiation of the weight-stationary kernel
         // write them (ops.py asks for them where tcvom_conv_igemm_variant names one of the two)
         int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
@@ -521,7 +532,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         TCVOM_CHECK_ARG(r != 0, "conv_igemm: out_fp32 = 2 (fp16 results) is built for halo_conv and wsconv<64,18> only");
         return r < 0 ? r : TCVOM_OK;
     }
-    for (int i = 0; i < nphase; ++i) TCVOM_CHECK_ARG(descs[i].out_fp32 == 0 || descs[i].out_fp32 == 1, "conv_igemm: out_fp32 = %d", descs[i].out_fp32);
+    for (int i = 0; i < nphase; ++i) TCVOM_CHECK_ARG(xf || descs[i].out_fp32 == 0 || descs[i].out_fp32 == 1, "conv_igemm: out_fp32 = %d", descs[i].out_fp32);
     {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
@@ -546,10 +557,16 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
-#define NT_LAUNCH(threads, ...)                                                                                          \
+#define NT_LAUNCH0(threads, ...)                                                                                         \
     hipLaunchKernelGGL((igemm_nt_kernel<__VA_ARGS__>), grid, dim3(threads), 0, st, ip, wp, out, bias, mscale, mdiag,     \
                        stats_partial, zp, ps)
-    if (c.tm == 256) NT_LAUNCH(512, 256, 256, 128, 64, 2);
+#define NT_LAUNCH(threads, ...)                                                                                          \
+    do {                                                                                                                 \
+        if (xf) NT_LAUNCH0(threads, __VA_ARGS__, 1);                                                                     \
+        else NT_LAUNCH0(threads, __VA_ARGS__);                                                                           \
+    } while (0)
+    TCVOM_CHECK_ARG(!(xf && c.tm == 256), "conv_igemm: in_f16 is not built for the 256 x 256 tile (K >= 256 with >= 1024 tiles)");
+    if (c.tm == 256) NT_LAUNCH0(512, 256, 256, 128, 64, 2);
     else if (c.tm == 128 && c.tn == 128) NT_LAUNCH(512, 128, 128, 64, 32, 2);
     // (a 3- or 4-slot ring for this tile -- 84 / 112 KB of LDS, one workgroup per CU -- measured +0.45 ms per step: two co-resident
     //  workgroups hide the DMA latency better than one with a deeper ring)
@@ -567,6 +584,7 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 3);
     else NT_LAUNCH(256, 32, 256, 32, 64, 2);
 #undef NT_LAUNCH
+#undef NT_LAUNCH0
     TCVOM_LAUNCH_CHECK("conv_igemm");
     return TCVOM_OK;
 }

@@ -207,16 +207,7 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
 // conv output `y` is 16-bit in the build's storage type (YF32 = 0), fp32 (1: the high-precision layers of the bf16 build) or IEEE
 // fp16 (2: their layer1 convs on the weight-stationary kernel -- 11 significant bits instead of bf16's 8 at half the bytes of fp32; in
 // the fp16 build the same thing as 0)
-typedef __attribute__((ext_vector_type(2))) _Float16 bn_f16x2_t;
-__device__ __forceinline__ void unpack8_ieee(const uint4& q, float* f) {
-    const unsigned u[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bn_f16x2_t h = __builtin_bit_cast(bn_f16x2_t, u[i]);
-        f[2 * i] = (float)h.x;
-        f[2 * i + 1] = (float)h.y;
-    }
-}
+// (unpack8_ieee: common.h)
 static inline int bn_y_mode(int y_fp32) {
 #ifdef TCVOM_F16
     return y_fp32 == 1 ? 1 : 0;
@@ -291,12 +282,15 @@ __device__ __forceinline__ void unpack_yraw(const YRaw<YF32>& r, float* f) {
 // A block owns a contiguous pixel range; a thread owns ONE channel octet for the whole range (its 16 scale/shift
 // values live in registers) and walks the pixels with stride 256/C8: every access is a 16-byte load/store and
 // consecutive lanes cover consecutive 16-byte chunks of a pixel row.
-template <int YF32>
+// DUAL = 1 (the fp16 island of the bf16 build, tcvom_bn_apply_f16): z is written twice -- in the build's type to `z` (what the backward,
+// the weight gradient and every consumer outside the island read) and as IEEE fp16 to `z16` (what the next forward conv of the island
+// and the residual input of its block read); res1 is IEEE fp16 when res1_f16 is set.
+template <int YF32, int DUAL = 0>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const void* __restrict__ y, const float* __restrict__ scale_shift,
     const uint4* __restrict__ res1, const uint4* __restrict__ res2, uint4* __restrict__ z,
     int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int* __restrict__ overflow,
-    unsigned char* __restrict__ mask_out = nullptr)
+    unsigned char* __restrict__ mask_out = nullptr, uint4* __restrict__ z16 = nullptr, int res1_f16 = 0)
 {
     // mask_out (or NULL): one byte per 8-channel vector, bit k = the pre-activation value of channel k is positive.  The backward of a
     // site with a residual input (z = act(norm(y) + res1)) then takes the activation's slope from that bit instead of re-reading res1
@@ -328,7 +322,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         float f[8], r1[8], r2[8];
         unpack_yraw<YF32>(yr, f);
         if constexpr (YF32 == 0) sat |= sat8(yr.a);
-        unpack8(q1, r1);
+        if (DUAL && res1_f16) unpack8_ieee(q1, r1); else unpack8(q1, r1);
         unpack8(q2, r2);
         unsigned bits = 0u;
 #pragma unroll
@@ -339,6 +333,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
             f[k] = x + r2[k];
         }
         z[v] = pack8(f);
+        if constexpr (DUAL) z16[v] = pack8_ieee(f);
         if (mask_out) mask_out[v] = (unsigned char)bits;
         if (!more) break;
         p = pn; v = vn; yr = yn; q1 = n1; q2 = n2;
@@ -979,6 +974,23 @@ extern "C" int tcvom_bn_apply_mask(const void* y, const float* scale_shift, cons
                                    void* stream) {
     TCVOM_CHECK_ARG(mask && act != 4, "bn_apply_mask: null mask / a capped activation (one bit cannot hold ReLU6's two thresholds)");
     return bn_apply_impl(y, scale_shift, res1, res2, z, mask, pixels, C, act, y_fp32, nframes, slot_stride, stream);
+}
+
+// The apply pass of the fp16 island (bf16 build: encoder stem, layer1, layer2 of the GCA network): y is IEEE fp16 (y_fp32 must be 2), z is
+// stored in the build's type AND as IEEE fp16 (z16); res1 is IEEE fp16 when res1_f16 != 0; mask may be NULL.
+extern "C" int tcvom_bn_apply_f16(const void* y, const float* scale_shift, const void* res1, int32_t res1_f16, const void* res2, void* z,
+                                  void* z16, uint8_t* mask, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes,
+                                  int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(y && scale_shift && z && z16 && pixels > 0 && C > 0 && C % 8 == 0 && C <= 2048 && nframes >= 1, "bn_apply_f16: bad args (C=%d)", C);
+    TCVOM_CHECK_ARG(y_fp32 == 2, "bn_apply_f16: the conv output must be IEEE fp16 (y_fp32 = 2), got %d", y_fp32);
+    TCVOM_CHECK_ARG(!(mask && act == 4), "bn_apply_f16: a capped activation has no one-bit mask");
+    const int rpb = bn_rows_per_block(pixels, C);
+    const dim3 grid(cdiv(pixels, rpb), nframes);
+    hipLaunchKernelGGL((bn_apply_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream,
+                       y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
+                       g_overflow_sink.load(std::memory_order_relaxed), mask, (uint4*)z16, res1_f16);
+    TCVOM_LAUNCH_CHECK("bn_apply_f16");
+    return TCVOM_OK;
 }
 
 // Partial-sum groups (= blocks per frame) of the backward reduction.  A batched call of >= 3 frames stays at <= 4 * BN_SLICES groups

@@ -15,7 +15,9 @@ static int grid_for(int64_t n) {
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < (n); v += (int64_t)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------- avgpool 2x2 s2 (fwd) / its backward
-__global__ void avgpool2_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8) {
+// DUAL = 1 (fp16 island of the bf16 build, tcvom_avgpool2_f16): x is IEEE fp16; the result goes to y in the build's type and to y16 in IEEE fp16
+template <int DUAL = 0>
+__global__ void avgpool2_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int N, int H, int W, int C8, uint4* __restrict__ y16 = nullptr) {
     const int OH = H / 2, OW = W / 2;
     const int64_t n = (int64_t)N * OH * OW * C8;
     GRID_STRIDE(v, n) {
@@ -29,13 +31,15 @@ __global__ void avgpool2_kernel(const uint4* __restrict__ x, uint4* __restrict__
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                unpack8(x[(((int64_t)nn * H + 2 * oh + dy) * W + 2 * ow + dx) * C8 + c], f);
+                const uint4 q = x[(((int64_t)nn * H + 2 * oh + dy) * W + 2 * ow + dx) * C8 + c];
+                if constexpr (DUAL) unpack8_ieee(q, f); else unpack8(q, f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += f[k];
             }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] *= 0.25f;
         y[v] = pack8(acc);
+        if constexpr (DUAL) y16[v] = pack8_ieee(acc);
     }
 }
 // dx[n,h,w] = scale * dy[n,h/2,w/2]      (avgpool backward: scale .25; nearest-upsample forward: scale 1)
@@ -441,9 +445,18 @@ __global__ __launch_bounds__(256) void head_conv_bwd_weight_kernel(const float* 
 // ---------------------------------------------------------------- C ABI
 extern "C" int tcvom_avgpool2(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
     TCVOM_CHECK_ARG(x && y && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "avgpool2: bad args");
-    hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((int64_t)N * H * W * C / 32)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)x, (uint4*)y, N, H, W, C / 8);
+    hipLaunchKernelGGL(avgpool2_kernel<0>, dim3(grid_for((int64_t)N * H * W * C / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, (uint4*)y, N, H, W, C / 8, (uint4*)nullptr);
     TCVOM_LAUNCH_CHECK("avgpool2");
+    return TCVOM_OK;
+}
+// the same inside the fp16 island of the bf16 build (gca_net.py: the AvgPool2d of encoder layer2's downsample branch): x16 IEEE fp16 in,
+// y (the build's type: what the 1x1 conv's weight gradient reads) and y16 (IEEE fp16: what its forward reads) out
+extern "C" int tcvom_avgpool2_f16(const void* x16, void* y, void* y16, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    TCVOM_CHECK_ARG(x16 && y && y16 && C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "avgpool2_f16: bad args");
+    hipLaunchKernelGGL(avgpool2_kernel<1>, dim3(grid_for((int64_t)N * H * W * C / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x16, (uint4*)y, N, H, W, C / 8, (uint4*)y16);
+    TCVOM_LAUNCH_CHECK("avgpool2_f16");
     return TCVOM_OK;
 }
 extern "C" int tcvom_upsample2(const void* y, void* x, int32_t N, int32_t H, int32_t W, int32_t C, float scale, void* stream) {

@@ -243,6 +243,7 @@ static PwPlan pw_plan(const tcvom_conv_desc* d, int nphase) {
     static const int maxc = getenv("TCVOM_PWCONV_MAXC") ? atoi(getenv("TCVOM_PWCONV_MAXC")) : 512;      // study knob
     if (disabled || nphase != 1 || d->ntaps != 1 || d->tap_w[0] != 0 || d->wt != 1 || d->tap_dh[0] != 0 || d->tap_dw[0] != 0) return p;
     if (d->w_layout != 0 || d->out_fp32) return p;
+    if (d->in_f16 && !TCVOM_BUILD_F16) return p;          // IEEE fp16 operands in the bf16 build: igemm_nt
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return p;
     if (d->PH != d->H || d->PW != d->W || d->OH != d->H || d->OW != d->W) return p;
     const int C = d->C, K = d->K;

@@ -370,6 +370,7 @@ static SconvPlan sconv_plan(const tcvom_conv_desc* d, int nphase) {
     p.ok = false;
     static const bool off = getenv("TCVOM_NO_SCONV") != nullptr;                   // A/B switch
     if (off || !(nphase == 1 || nphase == 4)) return p;
+    if (d->in_f16 && !TCVOM_BUILD_F16) return p;          // IEEE fp16 operands in the bf16 build: halo_conv / wsconv / igemm_nt
     const tcvom_conv_desc* d0 = d;
     if ((d0->C != 32 && d0->C != 64) || d0->K > 64 || d0->K % 4 != 0 || d0->ldo % 4 != 0) return p;
     int maxt = 0;

@@ -21,7 +21,7 @@ enum {
     SN_W = 0, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD,
     SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS
 };
-// kind bits: 32 = fragment-major packs (sn_frag_index), 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual),
+// kind bits: 64 = forward pack in IEEE fp16 (bf16 build: the fp16 island), 32 = fragment-major packs (sn_frag_index), 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual),
 //            8 = weight-standardised (FBA base, models/FBA/layers_WS.py:13-23): packed value = (w - mean_row) * inv_row
 //                with the row statistics at SN_WS_STATS (float4 per output channel: mean, 1/(std + 1e-5), std, unused),
 //           16 = 7x7 stride-2 stem in space-to-depth form: the packed weight is the 4x4 stride-1 kernel over the 2x2
@@ -178,9 +178,13 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
     const int kind = (int)L[SN_KIND];
     const int K = (int)L[SN_K], C = (int)L[SN_C], T = TC ? TC : (int)L[SN_T], Cp = (int)L[SN_CPAD];
     const bool hp = kind & 4, transposed = kind & 1, ws = kind & 8;
-    const int TT = hp ? 2 * T : T;               // slots per (k, c)   (all divisions below are by T, 2 T or constants:
+    // kind bit 64 (bf16 build): the FORWARD pack in IEEE fp16 (the fp16 island, tcvom_conv_desc.in_f16), the data-gradient pack in the
+    // build's type as ever: LDS slot t holds the build-type value, slot T + t the fp16 one (the slot pair of the hp layers)
+    const bool f16f = (kind & 64) && !TCVOM_BUILD_F16;
+    const int TT = hp ? 2 * T : T;               // slots per (k, c) of the forward pack  (all divisions below are by T, 2 T or constants:
                                                  // with a runtime T the integer divisions WERE the kernel, ~250 VALU ops / element)
-    const int rp = SNP_TC * TT + 2;              // row pitch of this layer (<= SNP_ROW)
+    const int TL = (hp || f16f) ? 2 * T : T;     // ... of the LDS image
+    const int rp = SNP_TC * TL + 2;              // row pitch of this layer (<= SNP_ROW)
     const int nct = (Cp + SNP_TC - 1) / SNP_TC;
     const int k0 = (tile / nct) * SNP_TK, c0 = (tile % nct) * SNP_TC;
     const int nk = min(SNP_TK, K - k0), nc = min(SNP_TC, C - c0);        // nc <= 0: a tile of padding channels only
@@ -206,9 +210,10 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
                 float val = w[u] * inv;
                 if (ws) { const float4 st = wstat[k0 + kl]; val = (w[u] - st.x) * st.y; }
                 const h16raw hi = f2h(val);
-                h16raw* dst = lds + kl * rp + cl * TT + t;
+                h16raw* dst = lds + kl * rp + cl * TL + t;
                 dst[0] = hi;
                 if (hp) dst[T] = f2h(val - h2f(hi));
+                else if (f16f) dst[T] = f2h_ieee(val);
             }
         }
     }
@@ -224,10 +229,10 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
         int kl, slot;
         if (hp) { kl = row / (2 * T); slot = row - kl * (2 * T); } else { kl = row / T; slot = row - kl * T; }
         if (cl < ncp) {                                   // (Cp % 8 == 0: the 8 channels are inside the padded row together)
-            const h16raw* src = lds + kl * rp + cl * TT + slot;
+            const h16raw* src = lds + kl * rp + cl * TL + slot + (f16f ? T : 0);
             h16raw v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = cl + i < nc ? src[i * TT] : (h16raw)0;
+            for (int i = 0; i < 8; ++i) v[i] = cl + i < nc ? src[i * TL] : (h16raw)0;
             const int64_t di = frag ? sn_frag_index(k0 + kl, slot, c0 + cl, TT, Cp) : ((int64_t)(k0 + kl) * TT + slot) * Cp + c0 + cl;
             uint4 q;
             q.x = v[0] | ((unsigned)v[1] << 16); q.y = v[2] | ((unsigned)v[3] << 16);
@@ -242,7 +247,7 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
             for (int e = tid; e < nc * T * (SNP_TK / 8); e += 256) {
                 const int kl = (e % (SNP_TK / 8)) * 8, row = e / (SNP_TK / 8), t = row % T, cl = row / T;
                 if (kl < nk) {
-                    const h16raw* src = lds + kl * rp + cl * TT + t;
+                    const h16raw* src = lds + kl * rp + cl * TL + t;
                     h16raw v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = src[i * rp];
@@ -258,7 +263,7 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
                 const int kl = e % SNP_TK, row = e / SNP_TK, t = row % T, cl = row / T;
                 if (kl < nk) {
                     const int64_t di = frag ? sn_frag_index(c0 + cl, t, k0 + kl, T, K) : ((int64_t)(c0 + cl) * T + t) * K + k0 + kl;
-                    bdst[di] = lds[kl * rp + cl * TT + t];
+                    bdst[di] = lds[kl * rp + cl * TL + t];
                 }
             }
         }
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
     }
     int64_t di = idx;
     if (kind & 32) di = which == 0 ? sn_frag_index(k, t, c, T, Cp) : sn_frag_index(c, t, k, T, K);
-    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + di] = f2h(val);
+    if (which == 0) fwd_arena[call * fwd_call_stride + L[SN_FWD_OFF] + di] = ((kind & 64) && !TCVOM_BUILD_F16) ? f2h_ieee(val) : f2h(val);
     else bwd_arena[call * bwd_call_stride + L[SN_BWD_OFF] + di] = f2h(val);
 }
 

@@ -63,9 +63,10 @@ struct WsArgs {
 // the fp32 weight) and slot 9 + t (its 16-bit residual) on the SAME input pixels; OM_: output type -- 0 the build's 16-bit storage type,
 // 1 fp32, 2 IEEE fp16 whatever the build stores (the conv results of the high-precision layers must not be rounded to bf16's 8
 // significant bits before the BatchNorm has been applied: fp16 keeps 11 at half the bytes of fp32)
-template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int NT_ = 9, int OM_ = 0>
+// XF_ = 1: IEEE fp16 operands whatever the build stores (tcvom_conv_desc.in_f16: the fp16 island of the bf16 build, common.h)
+template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int NT_ = 9, int OM_ = 0, int XF_ = 0>
 struct WsCfg {
-    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = NT_, OM = OM_;
+    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = NT_, OM = OM_, XF = XF_;
     static constexpr bool OF32 = OM_ == 1;
     static constexpr int OB = OM_ == 1 ? 4 : 2;                // bytes per output element
     static constexpr int CU = C / 8, PIXB = C * 2;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
 #pragma unroll
     for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bq[set][i]));
     __builtin_amdgcn_sched_barrier(0);
-    acc[0] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][0]), acc[0], 0, 0, 0);
+    acc[0] = mfma16x<G::XF>(wr[S], __builtin_bit_cast(h16x8_t, bq[set][0]), acc[0]);
     __builtin_amdgcn_sched_barrier(0);
     unsigned ad = 0;
     if constexpr (rd) {
@@ -369,7 +370,7 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
         ws_read_some<G, SN, 0, 2>(bq, ad);
     }
     __builtin_amdgcn_sched_barrier(0);
-    acc[1] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][1]), acc[1], 0, 0, 0);
+    acc[1] = mfma16x<G::XF>(wr[S], __builtin_bit_cast(h16x8_t, bq[set][1]), acc[1]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (rd) ws_read_some<G, SN, 2, 4>(bq, ad);
     if constexpr (G::er(S) > 0) ws_epi_fetch<G, S + 1, 0>(c);   // unconditional: the counts rely on it
@@ -379,8 +380,8 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
 #endif
     constexpr bool has_dma = S * G::DPS < G::DMA_IT && !(WS_ABL & 1);
     constexpr bool has_epi = S >= G::E0 && S < G::E1 && !(WS_ABL & 2);
-    acc[2] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][2]), acc[2], 0, 0, 0);
-    acc[3] = mfma16(wr[S], __builtin_bit_cast(h16x8_t, bq[set][3]), acc[3], 0, 0, 0);
+    acc[2] = mfma16x<G::XF>(wr[S], __builtin_bit_cast(h16x8_t, bq[set][2]), acc[2]);
+    acc[3] = mfma16x<G::XF>(wr[S], __builtin_bit_cast(h16x8_t, bq[set][3]), acc[3]);
     if constexpr (has_dma) ws_dma_pieces<G, S * G::DPS, G::DPS>(c);      // without a next tile: zeros into the idle buffer
     if constexpr (has_epi) {
         if constexpr (G::er(S - 1) > 0) {                       // the float4 requested in step S - 1
@@ -399,9 +400,9 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
     if constexpr (S + 1 < G::NS) ws_step<G, S + 1>(c, wr, acc, bq, bbase, lb);
 }
 
-template <int C, int MF, int PS, int NI, int FH, int FW, int NT = 9, int OM = 0>
+template <int C, int MF, int PS, int NI, int FH, int FW, int NT = 9, int OM = 0, int XF = 0>
 __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
-    typedef WsCfg<C, MF, PS, NI, FH, FW, NT, OM> G;
+    typedef WsCfg<C, MF, PS, NI, FH, FW, NT, OM, XF> G;
     constexpr int TH = G::TH, TW = G::TW, HW = G::HW, PIXB = G::PIXB, CU = G::CU, NCC = G::NCC, NS = G::NS, SLOTB = G::SLOTB;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][SLOTB] halo, DUMPB, (+ XCHB bytes of results and the bias in the LDS form)
 
@@ -594,11 +595,12 @@ extern "C" int tcvom_conv_trace_read(uint64_t* host, int32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-struct WsPlan { bool ok; int C, th, tw, nt, wres; int wslot[9]; };
+struct WsPlan { bool ok, xf; int C, th, tw, nt, wres; int wslot[9]; };
 
 static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     WsPlan p;
     p.ok = false;
+    p.xf = d->in_f16 != 0 && !TCVOM_BUILD_F16;
     static const bool disabled = getenv("TCVOM_NO_WSCONV") != nullptr;      // A/B switch (tools/igemm_bench.py, tests)
     if (disabled || nphase != 1) return p;
     if (d->C != d->K || (d->C != 64 && d->C != 128) || d->ldo % 4 != 0) return p;
@@ -636,6 +638,7 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     p.nt = n2 ? 18 : 9;
     if (p.nt == 9 && d->out_fp32 == 1) return p;        // (fp32 results are built for the doubled-tap instantiation only)
     if (d->out_fp32 < 0 || d->out_fp32 > 2) return p;
+    if (p.xf && (p.nt != 9 || d->out_fp32 != 2)) return p;     // (IEEE fp16 operands: plain taps, fp16 results)
     p.C = d->C;
     p.th = 8;
     p.tw = d->C == 64 ? 32 : 16;
@@ -743,6 +746,18 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
             if (d->out_fp32 == 1) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 1>), grid, dim3(256), lds_bytes, st, a);
             else if (d->out_fp32 == 2) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 2>), grid, dim3(256), lds_bytes, st, a);
             else hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 0>), grid, dim3(256), lds_bytes, st, a);
+        } else if (p.xf && p.C == 64) {                 // fp16 island of the bf16 build: IEEE fp16 operands and results
+            auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32, 9, 2, 1>;
+            constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
+            static bool attr = false;
+            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
+        } else if (p.xf) {
+            auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16, 9, 2, 1>;
+            constexpr size_t lds_bytes = 2 * WsCfg<128, 4, 1, 4, 2, 16>::SLOTB + 1024 + WsCfg<128, 4, 1, 4, 2, 16>::XCHB + 128 * 4;
+            static bool attr = false;
+            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
         } else if (p.C == 64 && d->out_fp32 == 2) {
             auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32, 9, 2>;
             constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;

@@ -47,6 +47,9 @@ def preprocess_window(a, fg, bg, dilate_kernel, eps, tri_channels=3):
     u8 = lambda: torch.empty((B, S, H, W), dtype=torch.uint8, device=dev)
     p.unk_raw, tmp, p.unk = u8(), u8(), u8()
     p.x8 = torch.empty((B, S, H, W, 8), dtype=H16, device=dev)
+    # bf16 build, GCA input: the same tensor a second time as IEEE fp16 -- the first conv of the encoder's fp16 island reads it
+    # (gca_net.py: F16_ISLAND; ops.f16_twin)
+    p.x8_f16 = torch.empty((B, S, H, W, 8), dtype=torch.float16, device=dev) if (ops.F16_ISLAND and tri_channels == 3) else None
     p.trimask = _f32((B, S, 1, H, W), dev)
     p.tris_vis = _f32((B, S, 1, H, W), dev)
     # one radius per clip (models/model.py:60-64): an int serves every clip, a sequence names them in clip order
@@ -54,10 +57,18 @@ def preprocess_window(a, fg, bg, dilate_kernel, eps, tri_channels=3):
     if len(radii) != B:
         raise ValueError('preprocess_window: %d dilation radii for %d clips' % (len(radii), B))
     p.radii = radii
-    L.call('tcvom_preprocess_clips', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
-           L.ptr(p.unk_raw), L.ptr(tmp), L.ptr(p.unk), L.ptr(p.x8), L.ptr(p.trimask), L.ptr(p.tris_vis), B, S, H, W,
+    L.call('tcvom_preprocess_clips_f16', L.ptr(a), L.ptr(fg), L.ptr(bg), L.ptr(p.gts), L.ptr(p.fgs), L.ptr(p.bgs), L.ptr(p.imgs),
+           L.ptr(p.unk_raw), L.ptr(tmp), L.ptr(p.unk), L.ptr(p.x8), L.ptr(p.x8_f16), L.ptr(p.trimask), L.ptr(p.tris_vis), B, S, H, W,
            (ctypes.c_int32 * B)(*radii), float(eps), int(tri_channels), L.stream_ptr())
     return p
+
+
+def x8_frame(prep, s):
+    """Frame s of the network input [B, H, W, 8] (a view for B = 1), with its IEEE fp16 twin attached where the window has one."""
+    t = prep.x8[:, s].contiguous()
+    if getattr(prep, 'x8_f16', None) is not None:
+        ops.set_f16_twin(t, prep.x8_f16[:, s].contiguous())
+    return t
 
 
 class _WindowLoss(torch.autograd.Function):
@@ -261,7 +272,7 @@ class FullModel(nn.Module):
             L1, L2, L3 = FL._FbaFrameLoss.apply(pred, prep.gts, prep.trimask, prep.fgs, prep.bgs, prep.imgs, c, alphas, comps, Fs, Bs)
             return [L1, L2, L3, prep.imgs, prep.tris_vis, alphas, comps, prep.gts, Fs, Bs]
         if self.method == 'gca':
-            pred = ops.enter_backward(self.NET.run(prep.x8[:, c].contiguous(), prep.unk[:, c, ::TAM_OS, ::TAM_OS].contiguous()), self.NET._bank)
+            pred = ops.enter_backward(self.NET.run(x8_frame(prep, c), prep.unk[:, c, ::TAM_OS, ::TAM_OS].contiguous()), self.NET._bank)
             L_alpha, _lc, _lg, alphas, comps = _SingleImageLoss.apply(prep, c, S, pred)
             zero = torch.zeros_like(L_alpha)                   # GCA: alpha loss only (models/model.py:110-114)
             return [L_alpha, zero, zero.clone(), prep.imgs, prep.tris_vis, alphas, comps, prep.gts, prep.fgs, prep.bgs]
@@ -288,7 +299,7 @@ class FullModel_VMD(FullModel):
         prep = preprocess_window(a, fg, bg, self._dilation(a.shape[0]), self.EPS, 1 if self.TRIMAP_CHANNEL == 1 else 3)
         if self.method == 'fba':
             return self._forward_fba(prep, B, S, H, W)
-        frames = [prep.x8[:, s].contiguous() for s in range(S)]
+        frames = [x8_frame(prep, s) for s in range(S)]
         prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
         # (fp16 build: the gradients the loss kernels send back into the network are scaled here -- ops.LOSS_SCALE)
         preds, attb, attf = ops.enter_backward(self.NET.run(frames, prep.unk8), self.NET._bank)
@@ -369,7 +380,7 @@ class EvalModel(FullModel):
             prep = preprocess_window(tris, imgs, None, dil, 0.0, 1 if self.TRIMAP_CHANNEL == 1 else 3)
             if self.method == 'fba':
                 return self._forward_fba_eval(prep, B, S, H, W)
-            frames = [prep.x8[:, s].contiguous() for s in range(S)]
+            frames = [x8_frame(prep, s) for s in range(S)]
             prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
             preds, _attb, _attf = self.NET.run(frames, prep.unk8)
             alphas = torch.zeros((B, S, 1, H, W), dtype=torch.float32, device=imgs.device)
@@ -402,6 +413,8 @@ class EvalModel(FullModel):
                     hi = min(T, lo + chunk)
                     prep = preprocess_window(tris[lo:hi].unsqueeze(0).to(dev), imgs[lo:hi].unsqueeze(0).to(dev), None, dil, 0.0)
                     X = prep.x8[0].contiguous()
+                    if getattr(prep, 'x8_f16', None) is not None:
+                        ops.set_f16_twin(X, prep.x8_f16[0].contiguous())
                     U = prep.unk[0, :, ::TAM_OS, ::TAM_OS].contiguous()
                     token = bank_token(bank, hi - lo, False, net)
                     emb, mid = net.encoder.run(X, U, token, False)

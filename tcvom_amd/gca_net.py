@@ -23,7 +23,11 @@ TRIMAP_CHANNEL = 3
 # Study knob: TCVOM_HP_LAYERS=conv1,conv2,conv3,layer1 / TCVOM_HP_LAYERS= (none)
 import os as _os
 from . import _lib as _L
-HP_LAYERS = tuple(n for n in _os.environ.get('TCVOM_HP_LAYERS', 'conv1,conv2,conv3' if _L.DTYPE_NAME == 'bf16' else '').split(',') if n)
+# Round 6: the bf16 build's default is the FP16 ISLAND instead (ops.F16_ISLAND, ISLAND_LAYERS below): stem, layer1 and layer2 run
+# their forward on IEEE fp16 weights / activations / conv outputs; no doubled taps, no fp32 outputs.  TCVOM_NO_F16_ISLAND=1 restores the
+# round-5 scheme described here (A/B).
+ISLAND_LAYERS = ('conv1', 'conv2', 'conv3', 'layer1', 'layer2') if ops.F16_ISLAND else ()
+HP_LAYERS = tuple(n for n in _os.environ.get('TCVOM_HP_LAYERS', 'conv1,conv2,conv3' if (_L.DTYPE_NAME == 'bf16' and not ops.F16_ISLAND) else '').split(',') if n)
 HIGH_PRECISION_STEM = bool(HP_LAYERS)
 # encoder stages whose (plain, single-tap-list) convs store their outputs as IEEE fp16 where the kernel that writes it exists (the
 # weight-stationary 3x3 kernel): the same bytes as bf16 with 11 instead of 8 significant bits in front of the BatchNorm
@@ -33,7 +37,7 @@ HIGH_PRECISION_STEM = bool(HP_LAYERS)
 #   HP stem only, y16 layer1 + layer2  (the default)                 9.43, 9.54e-5 / 7.71e-5 / 7.14e-5 / 6.75e-5   22.41
 # (the forward differs from run to run by the atomics order of the SpectralNorm sums: +-2 % on these numbers; 12 more runs of the
 #  default at 256x320 on another box: 9.13 .. 9.38e-5, mean 9.25e-5)
-Y16_LAYERS = tuple(n for n in _os.environ.get('TCVOM_Y16_LAYERS', 'layer1,layer2').split(',') if n) if _L.DTYPE_NAME == 'bf16' else ()
+Y16_LAYERS = tuple(n for n in _os.environ.get('TCVOM_Y16_LAYERS', '' if ops.F16_ISLAND else 'layer1,layer2').split(',') if n) if _L.DTYPE_NAME == 'bf16' else ()
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -196,7 +200,8 @@ class ResGuidedCxtAtten(nn.Module):
             # residual (exact to ~2^-16) and their conv outputs stay fp32 until BatchNorm has been applied.
             hp = HIGH_PRECISION_STEM and name.split('.')[0] in HP_LAYERS
             spec = sn.spec('encoder.' + name, 'frame', needs_dgrad, hp=hp)
-            spec.y16 = (not hp) and name.split('.')[0] in Y16_LAYERS
+            spec.f16 = (not hp) and name.split('.')[0] in ISLAND_LAYERS
+            spec.y16 = (not hp) and (not spec.f16) and name.split('.')[0] in Y16_LAYERS
             bank.register(spec)
             return ConvCfg(bank, spec, bn=bn, act=act, pre_relu=pre_relu)
         self._stem = [reg('conv1', self.conv1, self.bn1, ACT_RELU, needs_dgrad=False),

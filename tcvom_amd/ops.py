@@ -217,6 +217,29 @@ SIDE_STREAMS = [False]          # set once a network runs part of its window on 
 #  from the attention GEMMs, which lose more than the overlap gains.)
 
 
+# ---------------------------------------------------------------------------------------------
+# The fp16 island of the bf16 build.  tests/study_bf16_noise.py: >= 99 % of the storage noise of the alpha matte
+# is injected in the encoder stem, layer1 and layer2 -- a third each by the rounding of weights, conv outputs and stored activations.
+# Those layers therefore run their FORWARD in IEEE fp16 (same bytes, same MFMA rate, 11 instead of 8 significant bits): fp16 packed
+# weights (weights.ConvSpec.f16), fp16 conv outputs (tcvom_conv_desc.out_fp32 = 2) and an IEEE fp16 "twin" of every activation of the
+# island, written by the apply pass next to the bf16 tensor (tcvom_bn_apply_f16).  The twin is what the next forward conv of the island
+# and the residual input of its block read; the bf16 tensor is what autograd sees: the backward (data gradient, weight gradient,
+# BatchNorm backward) and every consumer outside the island are unchanged.  TCVOM_NO_F16_ISLAND=1: the round-5 scheme (doubled taps in
+# the stem, fp16 conv outputs in layer1 / layer2) for A/B runs.  The fp16 build has no island (it is one).
+F16_ISLAND = H16 == torch.bfloat16 and _os.environ.get('TCVOM_NO_F16_ISLAND') is None
+
+
+def f16_twin(t):
+    """The IEEE fp16 twin of an activation of the fp16 island (same shape), or None."""
+    return getattr(t, '_tcvom_f16', None) if t is not None else None
+
+
+def set_f16_twin(t, t16):
+    assert t16.dtype == torch.float16 and t16.shape == t.shape
+    t._tcvom_f16 = t16
+    return t
+
+
 def _need_cuda(t):
     if not t.is_cuda:
         raise RuntimeError('tcvom_amd ops run on the GPU through libtcvom_hip.so only (no CPU fallback); got a %s tensor'
@@ -433,6 +456,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.x_tail_rows = getattr(x, '_tcvom_tail_rows', None)      # x comes from a tail-only op: it takes row-range gradients
         ctx.x_pad_unread = getattr(x, '_tcvom_pad_unread', False)   # x is a concat buffer whose backward never reads the padding channels
         ctx.set_materialize_grads(False)             # every consumer may have deposited: then autograd hands over None
+        x16 = f16_twin(x)
         x = _c(x)
         NT, H, W, Cx = x.shape
         assert Cx == spec.cpad and x.dtype == H16, 'conv %s: input %s %s, expected %d channels' % (
@@ -447,8 +471,14 @@ class _ConvBNAct(torch.autograd.Function):
         has_bn = bn is not None
         # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
         hp = spec.hp and has_bn
+        # fp16 island (bf16 build): IEEE fp16 input twin x IEEE fp16 packed weight -> IEEE fp16 conv output (the geometry's forward
+        # descriptors carry in_f16 = 1 / out_fp32 = 2, conv_plan.py); an input without a twin (a caller that built x itself) is converted
+        island = getattr(spec, 'f16', False)
+        if island:
+            assert has_bn and not hp and H16 == torch.bfloat16, 'fp16 island: conv + BatchNorm sites of the bf16 build'
+            x16 = _c(x16) if x16 is not None else x.to(torch.float16)
         # (y16 layers: the conv output in IEEE fp16 where the kernel that writes it exists -- same bytes as bf16, 11 significant bits)
-        ydt = _hp_y_dtype(geo.fwd, nf) if hp else (_hp_y_dtype(geo.fwd, nf, torch.float16, H16) if (getattr(spec, 'y16', False) and has_bn) else H16)
+        ydt = torch.float16 if island else _hp_y_dtype(geo.fwd, nf) if hp else (_hp_y_dtype(geo.fwd, nf, torch.float16, H16) if (getattr(spec, 'y16', False) and has_bn) else H16)
         y = torch.empty((NT, geo.OH, geo.OW, K), dtype=ydt, device=x.device)
         stats = None
         gn = cfg.group_norm
@@ -457,7 +487,7 @@ class _ConvBNAct(torch.autograd.Function):
         if has_bn and (training or gn):
             stats = torch.empty(nf * _stats_groups(geo.fwd, nf) * 2 * K, dtype=torch.float32, device=x.device)
         pre_act = (ACT_LEAKY01 if cfg.pre_slope else ACT_RELU) if cfg.pre_relu else ACT_NONE
-        _launch_conv(geo.fwd, x, bank.fwd_ptr(spec, call), y, bias, stats, pre_act, st, nf, wsf)
+        _launch_conv(geo.fwd, x16 if island else x, bank.fwd_ptr(spec, call), y, bias, stats, pre_act, st, nf, wsf)
         ctx.cfg, ctx.training, ctx.call, ctx.geo, ctx.nf, ctx.wsb = cfg, training, call, geo, nf, wsb
         tf = getattr(bank, 'tail_frames', None)
         ctx.active = tf if (cfg.tail_only and tf is not None and nf > 1 and 0 <= tf[0] < tf[1] <= nf and tf[1] - tf[0] < nf) else None
@@ -513,7 +543,23 @@ class _ConvBNAct(torch.autograd.Function):
         z = torch.empty((NT, geo.OH, geo.OW, K), dtype=H16, device=x.device)
         r1 = _c(res1) if res1 is not None else None
         r2 = _c(res2) if res2 is not None else None
-        if ctx.active is not None and cfg.tail_last and r1 is None and r2 is None:
+        if island:
+            # z twice: bf16 (autograd's tensor: saved for the weight gradient, read by everything outside the island) and IEEE fp16 (the
+            # twin: read by the island's next forward conv and as the residual input of its block, here through res1's own twin)
+            assert ctx.active is None and not gn
+            z16 = torch.empty((NT, geo.OH, geo.OW, K), dtype=torch.float16, device=x.device)
+            r1_16 = f16_twin(res1)
+            r1_16 = _c(r1_16) if r1_16 is not None else None
+            want_mask = r1 is not None and RES_MASK and cfg.act != ACT_RELU6 and any(ctx.needs_input_grad[:6])
+            amask = torch.empty(NT * geo.out_pixels * (K // 8), dtype=torch.uint8, device=x.device) if want_mask else None
+            L.call('tcvom_bn_apply_f16', L.ptr(y), ss, L.ptr(r1_16 if r1_16 is not None else r1), 1 if r1_16 is not None else 0, L.ptr(r2),
+                   L.ptr(z), L.ptr(z16), L.ptr(amask), geo.out_pixels, K, cfg.act, _y_mode(y), nf, slot_stride, st)
+            cfg._z16 = z16                       # conv_bn_act attaches it to the tensor autograd returns
+            if want_mask:
+                ctx.res_mask = True
+                ctx.save_for_backward(x, y, gamma, amask)
+                return z
+        elif ctx.active is not None and cfg.tail_last and r1 is None and r2 is None:
             # last op of a tail-only branch: its output is read for the interior frames only -- the end frames still went
             # through the conv (their batch statistics feed the BatchNorm's running statistics, as in the reference) but are
             # not normalised / stored (z is uninitialised there; tcvom_amd.vmn slices the interior frames)
@@ -1034,6 +1080,9 @@ def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
     beta = bn.bias if bn is not None else None
     stash = _GradStash() if (bn is not None and torch.is_grad_enabled()) else None
     z = _ConvBNAct.apply(x, token, gamma, beta, cfg.spec.bias, res1, res2, cfg, training, stash)
+    z16 = cfg.__dict__.pop('_z16', None)
+    if z16 is not None:
+        set_f16_twin(z, z16)
     if stash is not None and z.requires_grad:
         z._tcvom_grad_stash = stash
         tf, nf = getattr(cfg.bank, 'tail_frames', None), cfg.bank.frames_per_op
@@ -1054,7 +1103,13 @@ class _AvgPool2(torch.autograd.Function):
         x = _c(x)
         N, H, W, Cc = x.shape
         y = torch.empty((N, H // 2, W // 2, Cc), dtype=H16, device=x.device)
-        L.call('tcvom_avgpool2', L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream_ptr())
+        x16 = _AvgPool2.twin_in
+        if x16 is not None:                      # fp16 island: pool the IEEE fp16 twin, write both formats
+            y16 = torch.empty((N, H // 2, W // 2, Cc), dtype=torch.float16, device=x.device)
+            L.call('tcvom_avgpool2_f16', L.ptr(_c(x16)), L.ptr(y), L.ptr(y16), N, H, W, Cc, L.stream_ptr())
+            _AvgPool2.twin_out = y16
+        else:
+            L.call('tcvom_avgpool2', L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream_ptr())
         ctx.shape = (N, H, W, Cc)
         return y
 
@@ -1102,7 +1157,20 @@ class _ReflectPad1(torch.autograd.Function):
         return dx
 
 
-avgpool2 = _AvgPool2.apply
+_AvgPool2.twin_in = _AvgPool2.twin_out = None
+
+
+def avgpool2(x):
+    """AvgPool2d(2, 2); an input of the fp16 island (ops.f16_twin) is pooled from its IEEE fp16 twin and the result carries one."""
+    _AvgPool2.twin_in, _AvgPool2.twin_out = f16_twin(x), None
+    try:
+        y = _AvgPool2.apply(x)
+    finally:
+        _AvgPool2.twin_in = None
+    if _AvgPool2.twin_out is not None:
+        set_f16_twin(y, _AvgPool2.twin_out)
+        _AvgPool2.twin_out = None
+    return y
 upsample2 = _Upsample2.apply
 reflect_pad1 = _ReflectPad1.apply
 

@@ -66,6 +66,14 @@ def _stack_frames(ts):
     t0 = ts[0]
     if len(ts) == 1:
         return t0
+    tw = [ops.f16_twin(t) for t in ts]
+    if all(t is not None for t in tw):          # the IEEE fp16 twins of the frames (bf16 build, fp16 island) travel with them
+        return ops.set_f16_twin(_stack_frames_plain(ts), _stack_frames_plain(tw))
+    return _stack_frames_plain(ts)
+
+
+def _stack_frames_plain(ts):
+    t0 = ts[0]
     n = t0.numel()
     if n > 0 and not t0.requires_grad and all(
             t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and not t.requires_grad and
@@ -216,6 +224,10 @@ class VMN(nn.Module):
             B, Cc, H, W = img.shape
             x8 = torch.zeros((B, H, W, 8), dtype=H16, device=img.device)
             x8[..., :Cc] = img.permute(0, 2, 3, 1).to(H16)
+            if ops.F16_ISLAND and Cc == 6:      # (GCA input; bf16 build: the fp16 island's first conv reads the IEEE fp16 twin)
+                x16 = torch.zeros((B, H, W, 8), dtype=torch.float16, device=img.device)
+                x16[..., :Cc] = img.permute(0, 2, 3, 1).to(torch.float16)
+                ops.set_f16_twin(x8, x16)
             frames.append(x8)
             m = masks[i].squeeze(1)
             unks.append((m[:, 0, ::8, ::8] != 0).to(torch.uint8).contiguous())

@@ -44,6 +44,9 @@ class ConvSpec(object):
         self.name = name
         self.dilation, self.ws, self.stem = dilation, ws, stem
         self.hp = hp                         # high-precision forward: packed weight = bf16 hi + bf16 residual (2T slots)
+        # fp16 island (bf16 build; gca_net.py F16_ISLAND): the FORWARD pack is IEEE fp16 and the forward conv runs on IEEE fp16
+        # activations (tcvom_conv_desc.in_f16); the data-gradient pack, the weight gradient and everything downstream stay bf16
+        self.f16 = False
         self.weight, self.u, self.v, self.bias = weight, u, v, bias
         self.transposed = transposed
         shp = tuple(weight.shape)
@@ -304,7 +307,9 @@ class WeightBank(object):
             tab[i, SN_V] = s.v.data_ptr() if s.spectral else 0
             tab[i, SN_H], tab[i, SN_WD] = s.h, s.wd
             tab[i, SN_KIND] = ((1 if s.transposed else 0) | (0 if s.spectral else 2) | (4 if s.hp else 0) |
-                               (8 if s.ws else 0) | (16 if s.stem else 0) | (32 if s.frag else 0))
+                               (8 if s.ws else 0) | (16 if s.stem else 0) | (32 if s.frag else 0) | (64 if s.f16 else 0))
+            assert not (s.f16 and (s.hp or s.ws or s.stem or s.T > 9)), 'fp16 forward pack: plain 3x3 / 1x1 layers'
+
             assert not (s.ws and (s.spectral or s.transposed or s.hp)) and (s.ws or not s.stem)
             tab[i, SN_K], tab[i, SN_C], tab[i, SN_T], tab[i, SN_CPAD] = s.K, s.C, s.T, s.cpad
             tab[i, SN_FWD_OFF] = fwd_off
@@ -513,7 +518,8 @@ class WeightBank(object):
         rows = []
         for s in sel:
             slots = s.T * (2 if s.hp else 1)
-            if TILED_PACK and not getattr(s, 'stem', False) and slots <= 18:
+            lds_slots = s.T * (2 if (s.hp or getattr(s, 'f16', False)) else 1)     # (sn_pack_tile keeps both formats of an f16 layer)
+            if TILED_PACK and not getattr(s, 'stem', False) and lds_slots <= 18:
                 # csrc/spectral.hip sn_pack_tile: 32 (k) x 64 (c) tiles, which = 3 also writes the data-gradient pack
                 ntile = ((s.K + 31) // 32) * ((s.cpad + 63) // 64)
                 rows += [(s.layer_id, 3 if s.needs_dgrad else 2, b) for b in range(ntile)]
