@@ -33,11 +33,16 @@ FULL_H, FULL_W = 1088, 1920
 PROFILE_DIR = os.path.join(ROOT, 'profiles')
 
 
-def profile_traffic(variant):
-    """HBM bytes per launch of the kernel behind `variant`, read from the newest committed PMC summary
+TRACED_STEPS = 3                   # the PMC passes trace `bench.py --steps 2 --warmup 1` (the instrumented extra step switched off)
+
+
+def profile_traffic(variant, calls_per_step):
+    """HBM bytes per C-ABI LAUNCH of the kernel family behind `variant`, read from the newest committed PMC summary
     (profiles/r*_hbm_traffic_pmc.md: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes of this script, fetch
-    side doubled per MI355X_MICROARCH.md's gfx950 correction, averaged over the launches of that kernel in a 1080p
-    step).  bench.py cannot run rocprofv3 on itself; returns (bytes or None, file name or None)."""
+    side doubled per MI355X_MICROARCH.md's gfx950 correction): the family's counter bytes per STEP divided by `calls_per_step`, the
+    number of C-ABI calls the event-instrumented step counted -- the same denominator as `algorithmic_mib_per_launch` (a C-ABI call may
+    be two kernels: tcvom_gca_dq_dk; dividing by the table's kernel-launch count made the two figures incomparable).
+    bench.py cannot run rocprofv3 on itself; returns (bytes or None, file name or None)."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(PROFILE_DIR, 'r*_hbm_traffic_pmc*.md')))
@@ -59,7 +64,7 @@ def profile_traffic(variant):
                 launches += n
             except (ValueError, IndexError):
                 pass
-    return (tot / launches if launches else None), os.path.basename(files[-1])
+    return (tot / TRACED_STEPS / calls_per_step if (launches and calls_per_step) else None), os.path.basename(files[-1])
 
 
 ALGO_GB_WINDOW_1080P = 17.8        # ideal conv+BN+act fusion, every layer reads its input and writes its output once, x3 for fwd+bwd
@@ -74,7 +79,7 @@ def profile_step_traffic():
     if not files:
         return None, None
     m = re.search(r'total HBM traffic over the traced process: ([0-9.]+) GiB', open(files[-1]).read())
-    return (round(float(m.group(1)) / 3.0, 2) if m else None), os.path.basename(files[-1])
+    return (round(float(m.group(1)) / TRACED_STEPS, 2) if m else None), os.path.basename(files[-1])
 
 
 def tam_all_unknown(device, h, w, C=128, window=7, reps=20):
@@ -262,15 +267,23 @@ def other_configs(steps, warmup):
             ('config2_gca_tam_fwd_512_fp16', ['--height', '512', '--width', '512', '--forward-only', '--steps', '30', '--warmup', '5'], 'fp16'),
             ('config5_fba_tam_fwd_bwd_1080p_fp16', ['--config', 'fba', '--steps', '8', '--warmup', '2'], 'fp16'),
             ('config5_fba_tam_fwd_bwd_1080p_bf16', ['--config', 'fba', '--steps', '8', '--warmup', '2'], 'bf16'),
-            ('config3_gca_tam_fwd_bwd_1080p_fp16', ['--steps', str(steps), '--warmup', str(warmup)], 'fp16'))
+            ('config3_gca_tam_fwd_bwd_1080p_fp16', ['--steps', str(steps), '--warmup', str(warmup)], 'fp16'),
+            # the headline again with the attention probabilities NOT flushed to exact zeros below 2^-25 (TCVOM_NO_P_FLUSH=1, DESIGN.md
+            # section 0(6)): the dominant GEMM family on dense operands -- the sustained clock, hence `frac`, leans on the zeros of the
+            # bench window; this line is the figure without that help (`roofline.frac_dense_operands`)
+            ('config3_dense_operands_bf16', ['--steps', '5', '--warmup', '2'], 'bf16'))
+    with_roofline = ('config5_fba_tam_fwd_bwd_1080p_fp16', 'config5_fba_tam_fwd_bwd_1080p_bf16', 'config3_dense_operands_bf16')
     out = {}
     for name, flags, dtype in runs:
         t0 = time.time()
         e = dict(os.environ, TCVOM_DTYPE=dtype)
+        if name == 'config3_dense_operands_bf16':
+            e['TCVOM_NO_P_FLUSH'] = '1'
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
             e.pop(k, None)
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-cpu-baseline', '--no-profile', '--no-other-configs'] + flags,
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--no-cpu-baseline', '--no-other-configs'] +
+                               ([] if name in with_roofline else ['--no-profile']) + flags,
                                env=e, capture_output=True, text=True, timeout=600)
             line = [l for l in p.stdout.splitlines() if l.startswith('{')]
             if p.returncode != 0 or not line:
@@ -280,6 +293,10 @@ def other_configs(steps, warmup):
             out[name] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'window_mfma_frac', 'final_loss')}
             out[name]['workload'] = r['config']['workload']
             out[name]['forward_only'] = r['config'].get('forward_only', False)
+            if name in with_roofline and 'roofline' in r:        # the side run's own dominant kernel against the MFMA peak, event-timed live
+                out[name]['roofline'] = {k: r['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches_per_step',
+                                                                       'avg_launch_ms', 'algorithmic_gflop_per_launch', 'all_igemm', 'aggregate')
+                                         if k in r['roofline']}
             out[name]['subprocess_s'] = round(time.time() - t0, 1)
         except Exception as ex:                     # noqa: BLE001 -- the headline line must survive a failing side run
             out[name] = {'error': repr(ex)[-400:]}
@@ -470,9 +487,11 @@ def main():
             'value': round(win_per_s, 4), 'unit': 'windows/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': L.DTYPE_NAME, 'data': 'synthetic',
-            'config': {'precision_notes': ('bf16 MFMA operands, activations and gradients; fp32 accumulation, statistics, softmax, losses, master weights; '
-                                          'encoder stem on doubled-tap (16-bit head + residual) weights; conv outputs of the stem / layer1 / layer2 stored as '
-                                          'IEEE fp16 (stem conv3: fp32) until the BatchNorm has been applied (DESIGN.md section 6)') if (L.DTYPE_NAME == 'bf16' and args.config == 'gca') else
+            'config': {'precision_notes': ('bf16 MFMA operands, stored activations and gradients everywhere EXCEPT the forward of the encoder stem + layer1 + layer2 '
+                                          '(18 of 201 conv layers, 9 % of the forward FLOPs): there IEEE fp16 packed weights, IEEE fp16 stored activations '
+                                          '(written next to the bf16 copy the backward reads) and IEEE fp16 conv outputs on v_mfma_f32_32x32x16_f16 -- same '
+                                          'bytes, same MFMA rate (DESIGN.md section 6); attention probabilities P and softmax-backward T in bf16; TAM p / ds '
+                                          'as bf16 pairs; fp32 accumulation, statistics, softmax, scores, losses, master weights, Adam') if (L.DTYPE_NAME == 'bf16' and args.config == 'gca' and os.environ.get('TCVOM_NO_F16_ISLAND') is None) else
                                          ('%s storage, fp32 accumulation / statistics / softmax / losses / master weights' % L.DTYPE_NAME),
                        'workload': ('GCA+TAM (vmn_gca) forward only (train-mode statistics, no_grad; losses computed), one 3-frame %dx%d window (B=1 clip) '
                                     'per step, agg_window 7, dilate_kernel 12, formula-initialised weights; %s storage' % (H, W, L.DTYPE_NAME)) if args.forward_only else
@@ -506,7 +525,7 @@ def main():
             dom = max(agg, key=lambda k: agg[k][1])
             n, ms, gf = agg[dom]
             tf = gf / ms                                    # GFLOP / ms == TFLOP/s
-            traffic, tsrc = profile_traffic(dom)
+            traffic, tsrc = profile_traffic(dom, n)
             result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(tf, 2), 'peak': MFMA_PEAK_TFLOPS,
                                   'unit': 'TFLOP/s', 'frac': round(tf / MFMA_PEAK_TFLOPS, 4),
                                   'traffic': (round(traffic) if traffic is not None and (H, W) == (FULL_H, FULL_W) else None),
@@ -546,6 +565,11 @@ def main():
         del model, opt, averager, params
         torch.cuda.empty_cache()
         result['other_configs'] = other_configs(args.steps, args.warmup)
+        dense = result['other_configs'].get('config3_dense_operands_bf16', {}).get('roofline')
+        if dense and 'roofline' in result and dense.get('kernel') == result['roofline'].get('kernel'):
+            result['roofline']['frac_dense_operands'] = dense['frac']
+            result['roofline']['frac_dense_operands_note'] = ('the same kernel family in a 5-step side run with TCVOM_NO_P_FLUSH=1: attention probabilities '
+                                                              'below 2^-25 kept as denormal-scale values instead of exact zeros (no work is skipped either way)')
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if args.config != 'index':                      # (no CPU line for the extra IndexNet configuration)

@@ -320,17 +320,6 @@ int tcvom_bn_bwd_apply_ranged(const void* dz, const void* dz2, const void* y, co
                               const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                               int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                               int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
-/* The BatchNorm backward with LOCAL statistics in ONE launch (reduce -> grid barrier -> coefficients -> apply; csrc/norm.hip:
- * bn_bwd_fused_kernel): replaces tcvom_bn_bwd_reduce(_ranged / _mask) + tcvom_bn_bwd_finalize + tcvom_bn_bwd_apply(_ranged / _mask).
- * `workspace`: tcvom_bn_bwd_fused_workspace_bytes() bytes of device memory, ZERO before the first use and left zero by every launch
- * (one per stream of launches).  res1 / mask: alternatives (or both NULL).  Returns 0 = launched, 1 = not a case for this form (the
- * caller runs the three launches), < 0 = error.  The last int of the workspace is raised when a workgroup waited > 4 s at the barrier. */
-int tcvom_bn_bwd_fused_workspace_bytes(void);
-int tcvom_bn_bwd_fused(const void* dz, const void* dz2, const void* y, const void* res1, const uint8_t* mask,
-                       const float* scale_shift, const float* saved, const float* gamma, float* dgamma, float* dbeta,
-                       void* dy, void* dres1, void* workspace, int64_t pixels, int32_t C, int32_t act, int32_t training,
-                       int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
-                       int64_t count, int32_t accumulate, const tcvom_sn_dot* dot, void* stream);
 int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const void* y, const uint8_t* mask, const float* scale_shift,
                             const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                             int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,

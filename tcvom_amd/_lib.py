@@ -109,8 +109,6 @@ _PROTOS = {
     'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_reduce_ranged': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_finalize': [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, i64, TP, vp],
-    'tcvom_bn_bwd_fused_workspace_bytes': [],
-    'tcvom_bn_bwd_fused': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, i32, i32, i64, i32, TP, vp],
     'tcvom_bn_ema_multi': [vp, i32, vp, vp, vp],
     'tcvom_bn_reduce_sums': [vp, i32, i32, vp, vp, i32, vp],
     'tcvom_bn_finalize_sums': [vp, i32, i64, i64, vp, vp, f32, vp, vp, i32, i64, vp],
@@ -235,7 +233,7 @@ _PROTOS = {
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_bn_bwd_groups_n', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
           'tcvom_wgrad_ws_max_problems', 'tcvom_wgrad_ws_max_geometries', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks',
-          'tcvom_adaptive_avgpool_scratch_floats', 'tcvom_bn_bwd_fused_workspace_bytes', 'tcvom_bn_bwd_fused'}
+          'tcvom_adaptive_avgpool_scratch_floats'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}

@@ -573,212 +573,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
-// ---------------------------------------------------------------- backward in ONE launch (local statistics: no SyncBatchNorm)
-// reduce -> (grid barrier) -> coefficients -> apply, the three launches above as one kernel whose workgroups are all co-resident
-// (<= BNF_MAX_BLOCKS of 256 threads: every CU can hold several).  Phase 1 = bn_bwd_reduce_kernel's loop; a block adds its per-channel
-// sums to the frame's totals with fp64 atomics (the order changes the result at the 1e-16 level only); the blocks of a frame meet at a
-// counter; every thread then takes the totals of its OWN 8 channels (16 doubles) and forms its coefficients itself -- no serial
-// finalize -- and phase 3 = bn_bwd_apply_kernel's loop over the same pixel rows (they come back from L2 / the Infinity Cache for all
-// but the full-resolution layers).  Block 0 of a frame writes the gamma / beta gradients and the SpectralNorm inner product.  The last
-// block to finish zeroes the frame's workspace again: the workspace is all-zero between launches.
-// A block that waits longer than ~4 s (a workgroup that never became resident) raises *err and goes on: no hang.
-#define BNF_MAX_BLOCKS 512
-#define BNF_MAX_FRAMES 8
-#define BNF_MAX_C 2048
-struct BnFusedArgs {
-    const uint4* dz; const uint4* dz2; const void* y; const uint4* res1; const unsigned char* mask;
-    const float* scale_shift; const float* saved; const float* gamma; float* dgamma; float* dbeta;
-    uint4* dy; uint4* dres1;
-    double* tot;                  // [BNF_MAX_FRAMES][2][BNF_MAX_C]
-    unsigned* cnt;                // [BNF_MAX_FRAMES][2]: arrived, finished
-    int* err;
-    int* overflow;
-    long long P, slot_stride;
-    double count;
-    int C8, C, act, training, in_relu, rows_per_block, dz2_f0, dz2_f1, accumulate;
-    SnDot sd;
-};
-template <int YF32>
-__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const BnFusedArgs a)
-{
-    __shared__ float red[2 * 256 * 8];
-    __shared__ float dred[4];
-    const int tid = threadIdx.x, frame = blockIdx.y;
-    const int C8 = a.C8, C = a.C;
-    const uint4* dz = a.dz;
-    const uint4* dz2 = a.dz2;
-    if (dz2) dz2 = (frame >= a.dz2_f0 && frame < a.dz2_f1) ? dz2 - (int64_t)a.dz2_f0 * a.P * C8 : nullptr;
-    const float* scale_shift = a.scale_shift + frame * a.slot_stride;
-    const float* saved = a.saved + frame * a.slot_stride;
-    double* tot = a.tot + (int64_t)frame * 2 * BNF_MAX_C;
-    unsigned* cnt = a.cnt + frame * 2;
-    const int64_t fo = (int64_t)frame * a.P * C8;
-    const int oct = tid % C8, prow = tid / C8, RP = 256 / C8, c0 = oct * 8;
-    float sc[8], sh[8], mu[8], is[8];
-    load_coef8(scale_shift + c0, sc);
-    load_coef8(scale_shift + C + c0, sh);
-    load_coef8(saved + c0, mu);
-    load_coef8(saved + C + c0, is);
-    const float slope = act_slope(a.act), cap = act_cap(a.act);
-    const int64_t pbeg = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t pend = pbeg + a.rows_per_block < a.P ? pbeg + a.rows_per_block : a.P;
-    const bool active = prow < RP && pbeg + prow < pend;
-    // ---- phase 1: per-channel sums of g and g * xhat over this block's pixel rows
-    {
-        float sg[8], sx[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sx[k] = 0.f; }
-        unsigned sat = 0u;
-        if (active) {
-            int64_t p = pbeg + prow;
-            int64_t v = fo + p * C8 + oct;
-            uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
-            YRaw<YF32> yr = load_yraw<YF32>(a.y, v);
-            uint4 q1 = a.res1 ? a.res1[v] : uint4{0, 0, 0, 0};
-            unsigned mb = a.mask ? a.mask[v] : 0u;
-            while (true) {
-                const int64_t pn = p + RP;
-                const bool more = pn < pend;
-                const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-                const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
-                const YRaw<YF32> yn = load_yraw<YF32>(a.y, vn);
-                const uint4 n1 = a.res1 ? a.res1[vn] : uint4{0, 0, 0, 0};
-                const unsigned nb = a.mask ? a.mask[vn] : 0u;
-                float g[8], g2[8], yy[8], r1[8];
-                unpack8(qg, g);
-                unpack8(qh, g2);
-                sat |= sat8(qg) | sat8(qh);
-                unpack_yraw<YF32>(yr, yy);
-                unpack8(q1, r1);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-                    const float fac = a.mask ? (((mb >> k) & 1u) ? 1.f : slope) : (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
-                    const float gg = (g[k] + g2[k]) * fac;
-                    sg[k] += gg;
-                    sx[k] += gg * (yy[k] - mu[k]) * is[k];
-                }
-                if (!more) break;
-                p = pn; qg = ng; qh = nh; yr = yn; q1 = n1; mb = nb;
-            }
-        }
-        if (a.overflow && __any(sat != 0u) && (tid & 63) == 0) atomicAdd(a.overflow, 1);
-        float* r_g = red;
-        float* r_x = red + 256 * 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { r_g[tid * 8 + k] = sg[k]; r_x[tid * 8 + k] = sx[k]; }
-        __syncthreads();
-        if (tid < C8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float ag = 0.f, ax = 0.f;
-                for (int r = 0; r < RP; ++r) { ag += r_g[(r * C8 + tid) * 8 + k]; ax += r_x[(r * C8 + tid) * 8 + k]; }
-                __hip_atomic_fetch_add(tot + tid * 8 + k, (double)ag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(tot + BNF_MAX_C + tid * 8 + k, (double)ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    // ---- the blocks of this frame meet
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { if (a.err) atomicExch(a.err, 1); break; }
-        }
-    }
-    __syncthreads();
-    // ---- coefficients of this thread's 8 channels from the frame totals
-    float c1[8], c2[8], gi[8];
-    {
-        const double* tp = tot + c0;
-        float gm[8];
-        load_coef8(a.gamma + c0, gm);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double ta = __hip_atomic_load(tp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double tb = __hip_atomic_load(tp + BNF_MAX_C + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gi[k] = gm[k] * is[k];
-            c1[k] = a.training ? (float)(ta / a.count) * gi[k] : 0.f;
-            c2[k] = a.training ? (float)(tb / a.count) * gi[k] : 0.f;
-            if (blockIdx.x == 0 && prow == 0) {
-                // gamma / beta gradients (the S calls of one BatchNorm add up) and SpectralNorm's <dy, y> (see bn_bwd_finalize_kernel)
-                const int c = c0 + k;
-                if (a.dbeta) { if (a.accumulate) atomicAdd(a.dbeta + c, (float)ta); else a.dbeta[c] = (float)ta; }
-                if (a.dgamma) { if (a.accumulate) atomicAdd(a.dgamma + c, (float)tb); else a.dgamma[c] = (float)tb; }
-            }
-        }
-        if (a.sd.out && blockIdx.x == 0) {
-            float d = 0.f;
-            if (prow == 0) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double ta = __hip_atomic_load(tp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double tb = __hip_atomic_load(tp + BNF_MAX_C + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double mean = mu[k], isd = is[k], gid = (double)gm[k] * isd;
-                    d += (float)((a.sd.eps >= 0.f ? gid * tb * isd * (double)a.sd.eps : gid * (mean * ta + tb / isd)) * (double)a.sd.scale);
-                }
-            }
-            d = wave_sum(d);
-            if ((tid & 63) == 0) dred[tid >> 6] = d;
-            __syncthreads();
-            if (tid == 0) {
-                const float dd = dred[0] + dred[1] + dred[2] + dred[3];
-                if (dd != 0.f) atomicAdd(a.sd.out + frame * a.sd.stride, dd);
-            }
-        }
-    }
-    // ---- phase 3: dy (and d res1) over the same pixel rows
-    if (active) {
-        int64_t p = pbeg + prow;
-        int64_t v = fo + p * C8 + oct;
-        uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
-        YRaw<YF32> yr = load_yraw<YF32>(a.y, v);
-        uint4 q1 = a.res1 ? a.res1[v] : uint4{0, 0, 0, 0};
-        unsigned mb = a.mask ? a.mask[v] : 0u;
-        while (true) {
-            const int64_t pn = p + RP;
-            const bool more = pn < pend;
-            const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-            const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
-            const YRaw<YF32> yn = load_yraw<YF32>(a.y, vn);
-            const uint4 n1 = a.res1 ? a.res1[vn] : uint4{0, 0, 0, 0};
-            const unsigned nb = a.mask ? a.mask[vn] : 0u;
-            float g[8], g2[8], yy[8], r1[8], o[8];
-            unpack8(qg, g);
-            unpack8(qh, g2);
-            unpack_yraw<YF32>(yr, yy);
-            unpack8(q1, r1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float pre = yy[k] * sc[k] + sh[k] + r1[k];
-                const float fac = a.mask ? (((mb >> k) & 1u) ? 1.f : slope) : (pre > 0.f ? (pre < cap ? 1.f : 0.f) : slope);
-                const float gg = (g[k] + g2[k]) * fac;
-                g[k] = gg;
-                const float xh = (yy[k] - mu[k]) * is[k];
-                o[k] = gi[k] * gg - c1[k] - xh * c2[k];
-                if (a.in_relu && yy[k] <= 0.f) o[k] = 0.f;
-            }
-            a.dy[v] = pack8(o);
-            if (a.dres1) a.dres1[v] = pack8(g);
-            if (!more) break;
-            p = pn; v = vn; qg = ng; qh = nh; yr = yn; q1 = n1; mb = nb;
-        }
-    }
-    // ---- the last block of the frame to finish leaves the workspace zeroed for the next launch
-    __syncthreads();
-    __shared__ unsigned last;
-    if (tid == 0) last = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (last) {
-        for (int i = tid; i < C; i += 256) { tot[i] = 0.0; tot[BNF_MAX_C + i] = 0.0; }
-        __threadfence();
-        if (tid == 0) { __hip_atomic_store(cnt, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-    }
-}
-
 // pixel rows per block for the streaming BN kernels: ~8 loop iterations per thread (fewer iterations / more blocks
 // measured SLOWER: every thread first loads its 16..56 per-channel coefficients; MORE iterations for the wide layers -- 32 / 64 for
 // C >= 512, round 5 -- measured slower too: FBA 47.3 -> 47.7 / 48.1 ms, GCA 23.67 -> 23.80), at most 8192 blocks
@@ -1357,47 +1151,6 @@ extern "C" int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const vo
     TCVOM_CHECK_ARG(mask && act != 4, "bn_bwd_apply_mask: null mask / capped activation");
     return bn_bwd_apply_impl(dz, dz2, y, nullptr, mask, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
                              nframes, slot_stride, dz2_f0, dz2_f1, stream);
-}
-extern "C" int tcvom_bn_bwd_fused_workspace_bytes(void) {
-    return (int)(sizeof(double) * BNF_MAX_FRAMES * 2 * BNF_MAX_C + sizeof(unsigned) * (BNF_MAX_FRAMES * 2 + 2));
-}
-// 0 = launched, > 0 = not a case for the one-launch form (the caller runs reduce / finalize / apply), < 0 = error
-extern "C" int tcvom_bn_bwd_fused(const void* dz, const void* dz2, const void* y, const void* res1, const uint8_t* mask,
-                                  const float* scale_shift, const float* saved, const float* gamma, float* dgamma, float* dbeta,
-                                  void* dy, void* dres1, void* workspace, int64_t pixels, int32_t C, int32_t act, int32_t training,
-                                  int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
-                                  int64_t count, int32_t accumulate, const tcvom_sn_dot* dot, void* stream) {
-    TCVOM_CHECK_ARG(dz && y && scale_shift && saved && gamma && dy && workspace && pixels > 0 && C >= 8 && C % 8 == 0 && nframes >= 1 && count > 0,
-                    "bn_bwd_fused: bad args");
-    TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_fused: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
-    TCVOM_CHECK_ARG(!(res1 && mask) && !(mask && act == 4), "bn_bwd_fused: res1 and mask are alternatives; no capped activation with a mask");
-    if (C > BNF_MAX_C || 256 % (C / 8) != 0 || nframes > BNF_MAX_FRAMES || (nframes > 1 && !accumulate)) return 1;
-    // every workgroup must be resident at once: at most BNF_MAX_BLOCKS blocks in all, whole multiples of the thread block's pixel rows
-    const int rp = 256 / (C / 8);
-    const int per_frame = BNF_MAX_BLOCKS / nframes;
-    int64_t rows = (int64_t)rp * 8;
-    if ((pixels + rows - 1) / rows > per_frame) rows = ((pixels + per_frame - 1) / per_frame + rp - 1) / rp * rp;
-    const int G = (int)((pixels + rows - 1) / rows);
-    BnFusedArgs a;
-    a.dz = (const uint4*)dz; a.dz2 = (const uint4*)dz2; a.y = y; a.res1 = (const uint4*)res1; a.mask = mask;
-    a.scale_shift = scale_shift; a.saved = saved; a.gamma = gamma; a.dgamma = dgamma; a.dbeta = dbeta;
-    a.dy = (uint4*)dy; a.dres1 = (uint4*)dres1;
-    a.tot = (double*)workspace;
-    a.cnt = (unsigned*)((double*)workspace + BNF_MAX_FRAMES * 2 * BNF_MAX_C);
-    a.err = (int*)(a.cnt + BNF_MAX_FRAMES * 2);
-    a.overflow = g_overflow_sink.load(std::memory_order_relaxed);
-    a.P = pixels; a.slot_stride = slot_stride; a.count = (double)count;
-    a.C8 = C / 8; a.C = C; a.act = act; a.training = training; a.in_relu = in_relu; a.rows_per_block = (int)rows;
-    a.dz2_f0 = dz2_f0; a.dz2_f1 = dz2_f1; a.accumulate = accumulate;
-    a.sd = make_dot(dot);
-    const dim3 grid(G, nframes);
-    switch (bn_y_mode(y_fp32)) {
-    case 1: hipLaunchKernelGGL(bn_bwd_fused_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(bn_bwd_fused_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(bn_bwd_fused_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    }
-    TCVOM_LAUNCH_CHECK("bn_bwd_fused");
-    return TCVOM_OK;
 }
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,

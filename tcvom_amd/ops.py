@@ -130,12 +130,6 @@ class LossScaler(object):
 
 
 SCALER = LossScaler(LOSS_SCALE)
-# BatchNorm backward (local statistics) as ONE cooperative launch (csrc/norm.hip: bn_bwd_fused_kernel): built and measured in round 5,
-# OFF by default -- it LOSES at every size (same box, ms per 1080p step: 24.22 with the three launches; fused for tensors up to
-# 1 M / 4 M / 16 M / all elements: 24.24 / 24.58 / 29.67 / 31.75): the fp64 atomics of the statistics and the spin at the grid barrier cost
-# more than the two kernel boundaries + the 5 us finalize launch they replace.  TCVOM_FUSED_BN_BWD=1 switches it on (A/B, tests).
-FUSED_BN_MAX = int(_os.environ.get('TCVOM_FUSED_BN_MAX', str(1 << 62)))
-FUSED_BN_BWD = _os.environ.get('TCVOM_FUSED_BN_BWD') == '1'
 RES_MASK = _os.environ.get('TCVOM_NO_RES_MASK') is None          # A/B switch: activation bitmask of the residual sites (tcvom_bn_apply_mask)
 SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
@@ -414,31 +408,6 @@ def _launch_conv(descs, x, wptr, out, bias, stats, act, st, nf=1, w_stride=0):
     L.call('tcvom_conv_igemm_phases', L.ptr(x), wptr, L.ptr(out), L.ptr(bias), L.ptr(stats), arr, n, st)
 
 
-def _bn_fused_workspace(bank, dev):
-    """Zero-initialised scratch of tcvom_bn_bwd_fused (every launch leaves it zero again), one per bank and device."""
-    ws = getattr(bank, '_bn_fused_ws', None)
-    if ws is None or ws.device != dev:
-        ws = torch.zeros(L.call('tcvom_bn_bwd_fused_workspace_bytes'), dtype=torch.uint8, device=dev)
-        bank._bn_fused_ws = ws
-    return ws
-
-
-def _bn_bwd_fused(ctx, cfg, bank, dz, dz2, y, r1, gamma, ss, saved, dy, dres1, P, K, yf, nf, stride, zf0, zf1, call, st):
-    """The BatchNorm backward of one site in ONE launch (csrc/norm.hip: bn_bwd_fused_kernel) when the statistics are local (no
-    SyncBatchNorm), every op runs on one stream and the shape qualifies; False -> the caller runs reduce / finalize / apply."""
-    if not FUSED_BN_BWD or SIDE_STREAMS[0] or cfg.group_norm or (ctx.sync is not None and ctx.training):
-        return False
-    if P * K * nf > FUSED_BN_MAX:
-        return False
-    dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
-    mask = r1 if ctx.res_mask else None
-    res1 = None if ctx.res_mask else r1
-    rc = L.call('tcvom_bn_bwd_fused', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(res1), L.ptr(mask), ss, saved, L.ptr(gamma), dgp, dbp,
-                L.ptr(dy), L.ptr(dres1), L.ptr(_bn_fused_workspace(bank, dz.device)), P, K, cfg.act, 1 if ctx.training else 0,
-                1 if cfg.pre_relu else 0, yf, nf, stride, zf0, zf1, P, 1, _sn_dot(cfg, call, ctx.training, None), st)
-    return rc == 0
-
-
 class _ConvBNAct(torch.autograd.Function):
     """conv (+bias) (+ReLU) (+BatchNorm) (+residual) (+activation) (+residual) of one layer, for `bank.frames_per_op`
     frames at once: x is [nf*B, H, W, C] frame-major; every frame has its own SpectralNorm call slot (weight copy) and
@@ -649,8 +618,7 @@ class _ConvBNAct(torch.autograd.Function):
             dy = torch.empty(y.shape, dtype=H16, device=dz.device)
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
-            fused = _bn_bwd_fused(ctx, cfg, bank, dz, dz2, y, r1, gamma, ss, saved, dy, dres1, P, K, yf, nf, stride, zf0, zf1, ctx.call, st)
-        if cfg.bn is not None and not fused:
+        if cfg.bn is not None:
             groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
             partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
             L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,

@@ -608,8 +608,9 @@ class WeightBank(object):
             # ... and the geometries that share the kernel's channel window (C a multiple of 128, or not) share launches too: the
             # atomic flush costs a launch ~45 us however few problems it has (csrc/wgradws.hip: tcvom_wgrad_ws_hetero)
             gcap = _wgrad_ws_geo_cap()
-            for cw in (0, 1):
-                keys = [k for k in multi if (k[3] % 128 == 0) == bool(cw)]
+            # (one launch = one channel window AND one tap -> weight-slot map, k[5:] = (wt, taps): tcvom_wgrad_ws_hetero refuses mixed maps)
+            for cw in sorted({((k[3] % 128 == 0),) + tuple(k[5:]) for k in multi}, key=repr):
+                keys = [k for k in multi if ((k[3] % 128 == 0),) + tuple(k[5:]) == cw]
                 batch, descs = [], []                   # problems (entry, geometry index) and descriptors of the launch being filled
 
                 def launch():

@@ -231,39 +231,6 @@ def test_conv_bn_act_train(act, pre_relu, res):
     ck.done()
 
 
-def test_batchnorm_backward_in_one_launch_equals_the_three_launches(monkeypatch):
-    """csrc/norm.hip: bn_bwd_fused_kernel (reduce -> grid barrier -> coefficients -> apply in one cooperative launch; measured slower than
-    the three launches at every size and therefore off by default) must still compute the same gradients: a
-    residual block with a row-range deposit, frame-batched, both ways."""
-    from tcvom_amd import ops
-    from tcvom_amd.weights import bank_token
-
-    def run(fused):
-        monkeypatch.setattr(ops, 'FUSED_BN_BWD', fused)
-        S, B, cin, cout, H, W = 3, 1, 64, 64, 24, 40
-        bank, spec = _mini_bank(cin, cout, 3, 1, 1, False, spectral=True, tag='fusedbn')
-        bn = nn.BatchNorm2d(cout).to(DEV)
-        with torch.no_grad():
-            bn.weight.copy_(formula_tensor('fusedbn.g', (cout,)))
-            bn.bias.copy_(formula_tensor('fusedbn.b', (cout,)))
-        cfg = ops.ConvCfg(bank, spec, bn=bn, act=1)
-        xg = nhwc(hu('fusedbn.x', (S * B, cin, H, W))).requires_grad_(True)
-        rg = nhwc(hu('fusedbn.r', (S * B, cout, H, W))).requires_grad_(True)
-        token = bank_token(bank, S, True)
-        bank.frames_per_op = S
-        z = ops.conv_bn_act(cfg, xg, token, True, res1=rg)
-        bank.frames_per_op = 1
-        bank.flush_bn_counters()
-        (z.float() * nhwc(hu('fusedbn.gz', (S * B, cout, H, W))).float()).sum().backward()
-        torch.cuda.synchronize()
-        return [t.float().cpu() for t in (z.detach(), xg.grad, rg.grad, bn.weight.grad, bn.bias.grad, spec.weight.grad)]
-    a, b = run(True), run(False)
-    ck = Checker()
-    for nm, x, y in zip(('z', 'dx', 'dres1', 'dgamma', 'dbeta', 'dw'), a, b):
-        ck.rel(nm, x, y, 1e-2 if nm in ('dx', 'dw') else 2e-3)
-    ck.done()
-
-
 @pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [
     (64, 128, 3, 1, False, 256, 264),      # >= 512 tiles of 128x128: the 8-wave 128x128 configuration WITH statistics
     (128, 128, 4, 2, True, 136, 120),      # 4 phases in one launch, 128x128 tiles, statistics per phase

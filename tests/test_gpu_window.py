@@ -49,10 +49,13 @@ def test_window_vs_reference_golden(name):
     # unknown-only bound at 544 x 960 and at the benchmark size.
     # fp16 storage (the default build): 3.8e-6 / 7.9e-6 / 1.9e-6 whole frame, 6.7e-6 / 1.9e-5 / 4.3e-6 on the unknown pixels for the
     # three goldens -- the north-star 1e-4 holds on all of them, 64-pixel windows included, unknown region included.
+    # Round 6, bf16 build with the fp16 island (encoder stem + layer1 + layer2 forward in IEEE fp16, ops.F16_ISLAND): measured whole frame /
+    # unknown-only 1.2e-5 / 2.1e-5 (64x64), 2.9e-5 / 6.9e-5 (s5 64x96), 2.0e-5 / 4.6e-5 (w5 64x96), 7.4e-6 / 1.6e-5 (128x160): the north-star
+    # 1e-4 now holds in bf16 against every REFERENCE-held golden, unknown region included (round 5: 1e-3 / 2e-4 bounds).
     if H * W >= 128 * 160:
-        assert mse <= tol(1e-4, 2e-5) and mse_unk <= tol(2e-4, 2e-5), 'alpha MSE vs reference'
+        assert mse <= tol(2e-5, 2e-5) and mse_unk <= tol(4e-5, 2e-5), 'alpha MSE vs reference'
     else:
-        assert mse <= tol(1e-3, 4e-5) and mse_unk <= tol(1e-3, 1e-4), 'alpha MSE vs reference'
+        assert mse <= tol(6e-5, 4e-5) and mse_unk <= tol(1e-4, 1e-4), 'alpha MSE vs reference'
     assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), g['losses'], 3e-2, 1e-3, 'losses')
     assert_close(out[8].sum().cpu(), g['comps_sum'], 1e-2, 1.0, 'comps')
     assert_close(out[6].sum().cpu(), g['tris_vis_sum'], 1e-5, 1e-2, 'tris_vis')
@@ -76,12 +79,14 @@ def test_window_vs_reference_golden(name):
         # bf16: two identical runs of this window differ by the fp32 order of the atomic partial sums only, yet the largest
         # per-tensor ratio moves between 1.19 and 1.44 (10 runs): the backward map amplifies the bf16 storage noise (DESIGN.md
         # section 6).  fp16: 0.91 .. 1.03.
-        assert abs(np.median(ratio) - 1) < tol(0.15, 0.05) and tol(0.6, 0.8) < ratio.min() and ratio.max() < tol(1.9, 1.2), 'gradient norms'
-    elif tol(False, True):
+        # round 6 (fp16 island), bf16: min 0.938 median 0.996 max 1.092
+        assert abs(np.median(ratio) - 1) < tol(0.08, 0.05) and tol(0.8, 0.8) < ratio.min() and ratio.max() < tol(1.3, 1.2), 'gradient norms'
+    else:
         # 64-pixel windows, 65 runs of window_s5_64x96 (tools/probes/ratio_probe.sh; the same spread with the round-4 kernels switched
         # off): min 0.95 .. 1.00, median ~1.2, max 1.22 .. 1.57 -- the order of the fp32 atomics alone moves the largest per-tensor ratio
         # that much through the 8..24-element BatchNorm backward; the earlier bound of 1.5 sat inside that tail (1 run in ~20 failed)
-        assert abs(np.median(ratio) - 1) < 0.35 and 0.75 < ratio.min() and ratio.max() < 2.0, 'gradient norms'
+        # (bf16 with the fp16 island, one run each: 0.747 / 0.994 / 1.089, 0.927 / 1.033 / 1.103, 0.915 / 0.979 / 1.175)
+        assert abs(np.median(ratio) - 1) < 0.35 and tol(0.55, 0.75) < ratio.min() and ratio.max() < 2.0, 'gradient norms'
 
 
 def test_window_large_vs_oracle():
@@ -108,8 +113,11 @@ def test_window_large_vs_oracle():
         mse, mse_unk, dtssd_delta, [float(x) for x in out[:5]], [float(x) for x in ro[:5]]))
     # north star: alpha MSE <= 1e-4 vs the reference path, over the unknown region as calc_metric.py:25 defines it
     # (and a fortiori over the whole frame)
-    assert mse <= tol(1e-4, 1e-5) and mse_unk <= tol(1e-4, 2e-5)        # fp16: 8.5e-7 / 3.8e-6
-    assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), torch.stack(list(ro[:5])), tol(3e-2, 3e-3), 1e-3, 'losses')
+    # bf16 with the fp16 island (round 6): 2.7e-6 / 1.21e-5, delta 9.0e-3 (round 5: 9.1 .. 9.7e-5 on the unknown pixels, 5 % under the
+    # bound); the asserted ceilings are 2x the measured values
+    assert mse <= tol(6e-6, 1e-5) and mse_unk <= tol(2.5e-5, 2e-5)        # fp16: 8.5e-7 / 3.8e-6
+    assert dtssd_delta <= 1.8e-2
+    assert_close(torch.stack([o.detach().float().cpu() for o in out[:5]]), torch.stack(list(ro[:5])), tol(1e-2, 3e-3), 1e-3, 'losses')
 
 
 def _oracle_state(requires_grad=False):
@@ -154,8 +162,11 @@ def test_window_north_star_parity(H, W):
     dtssd_delta = float(torch.sqrt(((d_a - d_r)[um[:, 1]] ** 2).mean()))
     print('%dx%d: alpha MSE %.3e (unknown-only %.3e, %d unknown pixels), dtSSD-style delta %.3e, max |d| %.3e; losses %s vs %s; oracle %.0f s'
           % (H, W, mse, mse_unk, int(um.sum()), dtssd_delta, float(d.abs().max()), losses, [float(x) for x in ro[:5]], time.time() - t0))
-    assert mse <= tol(1e-4, 1e-5) and mse_unk <= tol(1e-4, 2e-5)        # fp16 at 512^2 / 544x960 / 1088x1920: unknown-only 3.2e-6 / 2.7e-6 / 2.6e-6
-    assert_close(torch.tensor(losses), torch.stack(list(ro[:5])), tol(3e-2, 3e-3), 1e-3, 'losses')
+    # bf16 with the fp16 island (round 6) at 512^2 / 544x960 / 1088x1920: unknown-only 1.04e-5 / 9.98e-6 / 9.87e-6 (round 5: 7.7 / 7.1 / 6.75e-5),
+    # whole frame 1.5e-6 / 7.6e-7 / 3.7e-7, dtSSD-style delta 8.3 / 8.2 / 8.1e-3 (2.0e-2), max |d| 0.042 / 0.046 / 0.041 (0.12); ceilings = 2x
+    assert mse <= tol(4e-6, 1e-5) and mse_unk <= tol(2.5e-5, 2e-5)        # fp16 at 512^2 / 544x960 / 1088x1920: unknown-only 3.2e-6 / 2.7e-6 / 2.6e-6
+    assert dtssd_delta <= 1.7e-2 and float(d.abs().max()) <= 0.09
+    assert_close(torch.tensor(losses), torch.stack(list(ro[:5])), tol(1e-2, 3e-3), 1e-3, 'losses')
 
 
 def test_window_full_size_backward_parity():
@@ -216,12 +227,14 @@ def test_window_full_size_backward_parity():
     print('\n'.join('%-30s norm ratio %.3f  rerun %.3f  oracle norm %.3e  (%d tensors)' % r for r in rows))
     # fp16 (measured): total 1.001, cosine of the whole-network gradient against the oracle 0.962 (two identical runs: 0.986),
     # every module group 0.977 .. 1.038
-    lo, hi = tol((0.85, 1.2), (0.95, 1.05))
+    # bf16 with the fp16 island (round 6): total 1.001, cosine against the oracle 0.936 (two identical runs: 0.946 -- the distance to the
+    # oracle IS the run-to-run distance of the atomics order, amplified by the backward map), every module group 0.973 .. 1.054
+    lo, hi = tol((0.95, 1.05), (0.95, 1.05))
     assert lo <= total <= hi, 'whole-network gradient norm vs the oracle'
     assert 0.9 <= rerun <= 1.1, 'two identical runs'
-    assert c_oracle >= tol(0.6, 0.9), 'whole-network gradient direction vs the oracle'
+    assert c_oracle >= tol(0.85, 0.9), 'whole-network gradient direction vs the oracle'
     top = max(r[3] for r in rows)
-    glo, ghi = tol((0.75, 1.35), (0.9, 1.12))
+    glo, ghi = tol((0.9, 1.12), (0.9, 1.12))
     for name, ratio, rr, on, n in rows:
         if on >= 0.02 * top:                      # groups that carry the gradient; tiny groups are dominated by amplified noise
             assert glo <= ratio <= ghi, 'gradient norm of %s: %.3f of the oracle' % (name, ratio)
@@ -269,11 +282,12 @@ def test_gradient_fidelity_vs_oracle():
     enc = [r[1] for r in rows if r[0].startswith('encoder.')]
     # fp16 storage: decoder groups 0.976 .. 1.0, encoder groups 0.944 .. 0.989 -- most of what the bf16 build loses against the
     # oracle is storage noise amplified by the backward map, not summation order
-    assert min(dec) >= tol(0.8, 0.95), 'decoder gradient direction'
-    assert min(enc) >= tol(0.6, 0.9), 'encoder gradient direction'
+    # bf16 with the fp16 island (round 6): decoder groups 0.955 .. 1.0, encoder groups 0.919 .. 0.981 (round 5: 0.89.. / 0.67..)
+    assert min(dec) >= tol(0.9, 0.95), 'decoder gradient direction'
+    assert min(enc) >= tol(0.85, 0.9), 'encoder gradient direction'
     tot_h = torch.cat([g[k].flatten() for ks in groups.values() for k in ks])
     tot_o = torch.cat([go[k].flatten() for ks in groups.values() for k in ks])
-    assert cos(tot_h, tot_o) >= tol(0.7, 0.9), 'whole-network gradient direction'       # measured 0.79 (bf16)
+    assert cos(tot_h, tot_o) >= tol(0.88, 0.9), 'whole-network gradient direction'       # measured 0.94 (bf16, round 6; 0.79 in round 5)
 
 
 @pytest.mark.parametrize('regime', ['formula_gains', 'damped_residual_gains'])
@@ -339,14 +353,16 @@ def test_gradient_noise_on_a_conditioned_network(regime):
           'norm ratio %.4f' % (regime, c_oracle, cos(sub(g1, enc), sub(go, enc)), cos(sub(g1, dec), sub(go, dec)), c_rerun, nr))
     if regime == 'damped_residual_gains':
         # measured (MI355X, round 5): bf16 0.9988 vs the oracle / 0.9993 run vs rerun, norm ratio 0.9997; fp16 0.9998 / 0.9999 / 0.9996
-        assert c_oracle >= tol(0.995, 0.999) and c_rerun >= tol(0.995, 0.999), (c_oracle, c_rerun)
-        assert abs(nr - 1) <= tol(0.02, 0.01)
+        # round 6 (fp16 island), bf16: 0.9993 / 0.9995, norm ratio 0.9986
+        assert c_oracle >= tol(0.998, 0.999) and c_rerun >= tol(0.998, 0.999), (c_oracle, c_rerun)
+        assert abs(nr - 1) <= tol(0.01, 0.01)
     else:
         # measured floor of the ill-conditioned regime: bf16 0.828 vs the oracle with 0.912 between two identical
         # runs; fp16 0.967 / 0.986 -- the rerun distance IS the amplified order of the fp32 atomics, and the distance to the oracle is
         # about twice it (storage rounding amplified the same way)
-        assert c_oracle >= tol(0.7, 0.93) and c_rerun >= tol(0.8, 0.96), (c_oracle, c_rerun)
-        assert abs(nr - 1) <= tol(0.08, 0.03)
+        # round 6 (fp16 island), bf16: 0.9415 vs the oracle, 0.9458 between two identical runs, norm ratio 0.992
+        assert c_oracle >= tol(0.88, 0.93) and c_rerun >= tol(0.88, 0.96), (c_oracle, c_rerun)
+        assert abs(nr - 1) <= tol(0.04, 0.03)
 
 
 def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
