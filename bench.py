@@ -402,6 +402,7 @@ def main():
     fence()
     sync_transport, sync_n0 = sync_batchnorm_info(model)
     del ar_events[:]
+    averager.host_presence_ms_total, averager.host_presence_calls = 0.0, 0
     mbox = next((getattr(m, 'sync_mailbox', None) for m in model.modules() if getattr(m, 'sync', False)), None)
     if mbox is not None:
         mbox.wait_stats(reset=True)
@@ -420,7 +421,9 @@ def main():
     # started during backward, plus the small remainder (BatchNorm arena, biases) -- per step, from HIP events on that stream
     diag = {'rank': rank, 'device': dev_index,
             'allreduce_exposed_ms_per_step': round(sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1), 4) if ar_events else 0.0,
-            'sync_bn_transport': sync_transport}
+            'sync_bn_transport': sync_transport,
+            # the one blocking HOST collective of a step: GradientAverager._fill_locally_unused's 2.4 KB gloo all-reduce (wall time)
+            'host_presence_allreduce_ms_per_step': round(averager.host_presence_ms_total / max(averager.host_presence_calls, 1), 4)}
     if mbox is not None:
         mx, sm = mbox.wait_stats(reset=True)
         diag.update(mailbox_max_wait_ms=round(mx, 4), mailbox_wait_ms_per_step=round(sm / max(args.steps, 1), 4),

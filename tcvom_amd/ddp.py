@@ -98,6 +98,8 @@ class GradientAverager(object):
         self._bank_params = {id(bank): bank.weight_params() for bank in banks}
         self.early_spans = 0     # diagnostic: spans started before backward returned, last step
         self.globally_unused = 0  # diagnostic: parameters no rank had a gradient for, last step (left None)
+        self.host_presence_ms = 0.0          # diagnostic: wall time of the host-side presence all-reduce (_fill_locally_unused), last step
+        self.host_presence_ms_total, self.host_presence_calls = 0.0, 0
         self._cpu_group = None
         if self._active():       # (a one-process run keeps the bank's single-launch backward)
             import functools
@@ -158,6 +160,7 @@ class GradientAverager(object):
         timed-out exchange on one rank raises MailboxTimeout on EVERY rank before the optimizer step."""
         missing = [i for i, p in enumerate(self.params) if p.grad is None]
         group = self._host_group()
+        self._partial = set()
         if group is False:
             return [self.params[i] for i in missing]
         vec = torch.ones(len(self.params) + 1, dtype=torch.int32)
@@ -173,6 +176,10 @@ class GradientAverager(object):
             raise MailboxTimeout('SyncBatchNorm mailbox: an exchange timed out on another rank; the statistics of this step are '
                                  'invalid (no optimizer step taken)')
         self.globally_unused = sum(1 for i in missing if int(vec[i]) == 0)
+        # parameters only SOME ranks have a gradient for: the ranks that lack one substitute a fresh zero tensor, which is not part of
+        # any flat buffer -- such parameters must not shape the in-place spans (every rank has to issue the same collectives)
+        ws = dist.get_world_size(group)
+        self._partial = {i for i in range(len(self.params)) if 0 < int(vec[i]) < ws}
         return [self.params[i] for i in missing if int(vec[i]) != 0]
 
     def _mailboxes(self):
@@ -217,7 +224,15 @@ class GradientAverager(object):
             return
         avg = dist.get_backend() == 'nccl'
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        for p in self._fill_locally_unused():
+        # (the host-side presence all-reduce is timed: it is the one blocking host collective of a step -- a 2.4 KB gloo all-reduce whose
+        #  cost with 8 ranks is reported as `host_presence_allreduce_ms` by bench.py and the world-8 pre-flight test)
+        import time as _time
+        t0 = _time.perf_counter()
+        fill = self._fill_locally_unused()
+        self.host_presence_ms = 1e3 * (_time.perf_counter() - t0)
+        self.host_presence_ms_total += self.host_presence_ms
+        self.host_presence_calls += 1
+        for p in fill:
             p.grad = torch.zeros_like(p)
         # fp16 build: an overflowed backward on ANY rank drops the step on every rank (ops.LossScaler: the guarded Adam reads it)
         from .ops import SCALER
@@ -231,12 +246,14 @@ class GradientAverager(object):
                 return False
             sp, off = g.untyped_storage().data_ptr(), g.storage_offset()
             return any(sp == e[2] and e[3] <= off and off + g.numel() <= e[3] + e[4] for e in early)
-        grads = [p.grad for p in self.params if p.grad is not None]
+        partial = getattr(self, '_partial', set())
+        grads = [p.grad for i, p in enumerate(self.params) if p.grad is not None and i not in partial]
         if early:
             # (parameters of the bank that do not require a gradient -- a frozen backbone -- leave holes in the spans: reduced
             #  along with the rest, harmless)
             grads = [g for g in grads if not covered(g)]
         spans, rest = self.plan(grads, self.MIN_SPAN)
+        rest = rest + [p.grad for i, p in enumerate(self.params) if p.grad is not None and i in partial and not covered(p.grad)]
         works = [(e[0], None, e[1]) for e in early]
         for run, storage, first, n in spans:
             flat = run[0].new_empty(0).set_(storage, first, (n,))

@@ -311,3 +311,60 @@ def test_reference_ddp_lines_on_product_model_host_side():
         assert adopted and replaced and nbn == 72
         assert sync_ok and eval_follows
     assert torch.equal(res[0][7], res[1][7])
+
+
+# ------------------------------------------------------------------------------------------------ world 8 (BASELINE config 4's rank count)
+def _world8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tcvom_amd.ddp import GradientAverager
+    # gradients as views of one flat buffer (the bank's layout) + stray tensors; parameter 1 has a gradient on the even ranks only,
+    # parameter 4 on rank 5 only, parameter 5 on no rank
+    ps = [nn.Parameter(torch.zeros(n)) for n in (6, 10, 4, 3, 2, 5)]
+    arena = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    ps[0].grad = arena[2:8]
+    if rank % 2 == 0:
+        ps[1].grad = arena[8:18]
+    ps[2].grad, ps[3].grad = arena[18:22], arena[30:33]
+    if rank == 5:
+        ps[4].grad = torch.full((2,), 16.0)
+    av = GradientAverager(ps)
+    av.MIN_SPAN = 4
+    for _ in range(3):                                       # (the presence vector is exchanged every step)
+        av.average()
+        first = [None if p.grad is None else p.grad.clone() for p in ps] if _ == 0 else first
+        for p, g in zip(ps, (arena[2:8], arena[8:18] if rank % 2 == 0 else None, arena[18:22], arena[30:33],
+                             torch.full((2,), 16.0) if rank == 5 else None, None)):
+            p.grad = g
+        arena.copy_(torch.arange(40, dtype=torch.float32) * (rank + 1))
+    q.put(_plain((rank, first, av.globally_unused, av.host_presence_calls, av.host_presence_ms_total)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gradient_average_and_presence_vector():
+    """GradientAverager with 8 ranks (every other multi-process test has 2): the mean over 8, parameters that only SOME ranks have a
+    gradient for (zeros from the others: DDP's find_unused_parameters rule), one that no rank has (stays None), and the host-side
+    presence all-reduce with 8 participants, three steps in a row."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([_tensors(q.get(timeout=300)) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    base = torch.arange(40, dtype=torch.float32)
+    mean_scale = sum(r + 1 for r in range(world)) / world                                 # 4.5
+    even_scale = sum(r + 1 for r in range(0, world, 2)) / world                           # ranks 0, 2, 4, 6 only: 16 / 8
+    for rank, grads, unused, calls, ms in res:
+        assert unused == 1 and calls == 3 and ms >= 0.0
+        assert grads[5] is None
+        assert torch.allclose(grads[0], base[2:8] * mean_scale)
+        assert torch.allclose(grads[1], base[8:18] * even_scale)
+        assert torch.allclose(grads[2], base[18:22] * mean_scale) and torch.allclose(grads[3], base[30:33] * mean_scale)
+        assert torch.allclose(grads[4], torch.full((2,), 2.0))
+    print('host presence all-reduce, 8 ranks (gloo, this host): %.2f ms per step' % (sum(r[4] for r in res) / sum(r[3] for r in res)))

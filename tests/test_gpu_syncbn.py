@@ -373,3 +373,107 @@ def test_frozen_backbone_stays_frozen_under_two_ranks_with_weight_decay(tmp_path
         r = torch.load(out + str(rank))
         print(rank, r['moved'], r['unused'], r['frozen_moved'][:3])
         assert r['frozen_moved'] == [] and r['moved'] > 0 and r['unused'] > 100, r
+
+
+# ------------------------------------------------------------------------------------------------ world 8 (BASELINE config 4's rank count)
+def _world8_worker(rank, world, port, out):
+    """Config 4's process layout on ONE GPU: `world` ranks share cuda:0 (gloo carries the hipIpc handles and the host collectives; RCCL
+    refuses several ranks per device), one 3 x 128 x 160 clip each, SyncBatchNorm through the peer mailboxes, forward + backward +
+    GradientAverager + FusedAdam for 3 steps (train_ddp.py:271-280,292-297).  Damped residual gains (bn2 x 0.15) so that the comparison
+    with the one-process batch of `world` clips can be tight."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TCVOM_SYNCBN='mailbox', TCVOM_MBOX_TIMEOUT_S='60')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        from tcvom_amd.ddp import GradientAverager, banks_of, broadcast_module_state, convert_sync_batchnorm, sync_batchnorm_info
+        from tcvom_amd.facade import FullModel_VMD, train_step_loss
+        from tcvom_amd.optim import FusedAdam
+        from tcvom_amd.synthetic import formula_tensor, synthetic_window
+
+        def fresh():
+            m = FullModel_VMD('vmn_gca', agg_window=7, dilate_kernel=12)
+            sd = {k: formula_tensor(k, v.shape, v.dtype) for k, v in m.NET.state_dict().items()}
+            for k in sd:
+                if k.endswith('bn2.weight'):
+                    sd[k] = sd[k] * 0.15
+            m.NET.load_state_dict(sd)
+            return m.to(dev).train()
+        clips = [synthetic_window(1, 3, 128, 160, seed=40 + i) for i in range(world)]
+        a, fg, bg = [t.to(dev) for t in clips[rank]]
+        m = convert_sync_batchnorm(fresh())
+        broadcast_module_state(m)
+        params = [p for p in m.parameters() if p.requires_grad]
+        av = GradientAverager(params, banks=banks_of(m))
+        opt = FusedAdam(params, lr=1e-4, weight_decay=1e-4)
+        mb = next(b for b in m.modules() if getattr(b, 'sync', False)).sync_mailbox
+        assert mb is not None and mb.world == world
+        per_step, presence, first = [], [], None
+        for it in range(3):
+            n0 = mb.exchanges
+            outs = m(a, fg, bg)
+            m.zero_grad(set_to_none=True)
+            train_step_loss(outs).backward()
+            av.average()
+            presence.append(av.host_presence_ms)
+            if it == 0:
+                torch.cuda.synchronize()
+                first = (outs[7].detach().float().cpu().clone(),
+                         {k: p.grad.detach().float().cpu().clone() for k, p in m.NET.named_parameters() if p.grad is not None},
+                         {k: b.detach().float().cpu().clone() for k, b in m.NET.named_buffers() if 'running' in k})
+            opt.step()
+            torch.cuda.synchronize()
+            mb.check()
+            per_step.append(mb.exchanges - n0)
+        kind, n = sync_batchnorm_info(m)
+        assert kind == 'mailbox' and n == sum(per_step)
+        # every ring slot was reused many times (the ring holds mb.ring exchanges; a step issues > 100)
+        assert per_step[0] > 100 and per_step[0] == per_step[1] == per_step[2] and sum(per_step) > 3 * mb.ring
+        # all ranks end the three steps with the same weights (same averaged gradients, same Adam)
+        wsum = torch.stack([p.detach().double().sum() for p in params]).cpu()
+        ws = [None] * world
+        dist.all_gather_object(ws, wsum)
+        res = dict(rank=rank, exchanges_per_step=per_step[0], ring=mb.ring, presence_ms=presence,
+                   weights_agree=float(max((w - ws[0]).abs().max() for w in ws)))
+        if rank == 0:
+            # ONE process, the `world` clips as one batch, plain BatchNorm: what SyncBatchNorm + gradient averaging must reproduce
+            m2 = fresh()
+            a2, fg2, bg2 = [torch.cat([c[k] for c in clips], 0).to(dev) for k in range(3)]
+            o2 = m2(a2, fg2, bg2)
+            train_step_loss(o2).backward()
+            torch.cuda.synchronize()
+            g2 = {k: p.grad.detach().float().cpu() for k, p in m2.NET.named_parameters() if p.grad is not None}
+            s2 = {k: b.detach().float().cpu() for k, b in m2.NET.named_buffers() if 'running' in k}
+            keys = sorted(k for k in first[1] if k in g2)
+            fa = torch.cat([first[1][k].reshape(-1) for k in keys]).double()
+            fb = torch.cat([g2[k].reshape(-1) for k in keys]).double()
+            res.update(alpha_mse=float(((first[0] - o2[7].detach().float().cpu()[0:1]) ** 2).mean()),
+                       stats_err=max(float((first[2][k] - s2[k]).abs().max()) for k in s2),
+                       grad_cos=float((fa * fb).sum() / (fa.norm() * fb.norm())), grad_norm_ratio=float(fa.norm() / fb.norm()),
+                       n_grads=len(keys))
+        torch.save(res, out + str(rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_preflight_on_one_gpu(tmp_path):
+    """BASELINE config 4 has 8 ranks; every other distributed test here has 2.  Eight ranks on one GPU: the mailbox lanes sl < world, the ring
+    reuse with 8 senders (norm.hip: slot_off = seq % ring * world * cap2) and the host-side presence all-reduce with 8 participants all run;
+    SyncBatchNorm statistics, alphas and the AVERAGED gradient are compared with the one-process batch of 8 clips."""
+    from helpers import tol
+    world = 8
+    out = str(tmp_path / 'res.pt')
+    mp.spawn(_world8_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rs = [torch.load(out + str(r)) for r in range(world)]
+    r0 = rs[0]
+    print('world 8 on one GPU:', {k: v for k, v in r0.items() if k != 'presence_ms'})
+    print('host_presence_allreduce_ms per step, per rank:', [[round(x, 2) for x in r['presence_ms']] for r in rs])
+    assert all(r['weights_agree'] == 0.0 for r in rs), [r['weights_agree'] for r in rs]
+    assert all(r['exchanges_per_step'] == r0['exchanges_per_step'] for r in rs)
+    # SyncBatchNorm over 8 ranks == BatchNorm over the batch of 8: running statistics to fp32 rounding, alphas to the storage type
+    assert r0['stats_err'] <= tol(2e-3, 1e-4), r0
+    assert r0['alpha_mse'] <= tol(1e-5, 1e-6), r0
+    assert r0['n_grads'] > 200 and r0['grad_cos'] >= tol(0.99, 0.998) and abs(r0['grad_norm_ratio'] - 1) <= tol(3e-2, 1e-2), r0
+    # the one blocking host collective of a step: report it, and fail only if it is pathological (seconds)
+    assert max(max(r['presence_ms'][1:]) for r in rs) < 2000.0
