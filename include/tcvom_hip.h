@@ -61,8 +61,8 @@ typedef struct {
     int32_t wt;                  /* weight slots: w is [K][wt][C] bf16 */
     int32_t ldo;                 /* output pixel stride in elements */
     int32_t act;                 /* 0 none, 1 ReLU (before store and statistics) */
-    int32_t out_fp32;            /* 1: store fp32 instead of the 16-bit storage type; 2: IEEE fp16 whatever the build stores (the
-                                    halo-tile kernel, the weight-stationary kernel and -- with in_f16 -- the implicit GEMM) */
+    int32_t out_fp32;            /* 1: store fp32 instead of the 16-bit storage type (the dense GEMMs of GCA); 2: IEEE fp16 whatever the
+                                    build stores (with in_f16 = 1: the fp16 island of the bf16 build) */
     int32_t stats_group_offset;  /* first statistics group written by this launch */
     int32_t batch;               /* >1: `batch` independent problems with the strides below: the dense GEMMs of GCA,
                                     and the S frames of a window through one conv layer (N samples per frame, own
@@ -71,10 +71,10 @@ typedef struct {
                                     only, served by the weight-stationary kernel): element (k, slot, c) at
                                     ((((k/32)*wt + slot)*(C/16) + c/16)*64 + ((c/8)&1)*32 + k%32)*8 + c%8, i.e. every
                                     32 x 16 MFMA A fragment is one contiguous 1 KiB block in lane order */
-    int32_t in_f16;              /* 1 (bf16 build; ignored by the fp16 build, where it is the only format): `in` and `w` hold IEEE fp16
+    int32_t in_f16;              /* 1 (bf16 build only; the fp16 build IS that format and refuses the flag): `in` and `w` hold IEEE fp16
                                     and the product runs on v_mfma_f32_32x32x16_f16 -- the forward convs of the encoder stem, layer1 and
-                                    layer2 ("fp16 island", tcvom_amd/gca_net.py); requires out_fp32 == 2.  Served by the halo-tile
-                                    kernel, the weight-stationary kernel and the implicit GEMM */
+                                    layer2 ("fp16 island", tcvom_amd/gca_net.py); comes with out_fp32 == 2 and only with it.  Served by
+                                    the halo-tile kernel, the weight-stationary kernel and the implicit GEMM */
     int64_t in_bstride, w_bstride, out_bstride, vec_bstride;
     int64_t stats_bstride;       /* statistics groups between batch elements (frame f writes groups
                                     stats_group_offset + f*stats_bstride + ...) */
@@ -194,7 +194,8 @@ int tcvom_bn_ema_update(const float* saved, float* running_mean, float* running_
 int tcvom_bn_ema_multi(const int64_t* table, int32_t nbn, const uint32_t* masks, const float* unbias, void* stream);
 int tcvom_bn_eval_coeffs(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale_shift, float* saved, void* stream);
-/* y_fp32: 0 = the conv output y has the 16-bit storage type, 1 = fp32 (high-precision layers), 2 = IEEE fp16 whatever the build stores */
+/* y_fp32: 0 = the conv output y has the build's 16-bit storage type, 2 = IEEE fp16 whatever the build stores (the fp16 island of the
+ * bf16 build) */
 int tcvom_bn_apply(const void* y, const float* scale_shift, const void* res1, const void* res2, void* z,
                    int64_t pixels, int32_t C, int32_t act, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
                    void* stream);

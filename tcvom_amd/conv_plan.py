@@ -54,21 +54,15 @@ class ConvGeometry(object):
             return
         self.N, self.H, self.W = N, H, W
         self.fwd, self.dgrad, self.wgrad = [], [], []
-        hp = getattr(spec, 'hp', False)
         f16 = getattr(spec, 'f16', False)      # fp16 island of the bf16 build: IEEE fp16 operands and results in the FORWARD launch
 
         def fwd_desc(*a):
             # a = (N, H, W, C, OH, OW, K, PH, PW, in_step, out_step, off_h, off_w, taps, wt)
             self.wgrad.append(_desc(*a))
             if f16:
-                assert not hp
                 d = _desc(*a)                   # (its own descriptor: the kernel choice -- hence the statistics layout -- follows the flags)
                 d.in_f16, d.out_fp32 = 1, 2
                 self.fwd.append(d)
-            elif hp:                      # each tap twice: slot t (bf16 hi part of the weight) and slot wt + t (residual)
-                taps, wt = a[13], a[14]
-                a = a[:13] + (list(taps) + [(dh, dw, wt + ws) for dh, dw, ws in taps], 2 * wt)
-                self.fwd.append(_desc(*a))
             else:
                 self.fwd.append(self.wgrad[-1])
         if not spec.transposed:

@@ -887,7 +887,7 @@ int gemm_tt256_takes(const tcvom_conv_desc* d) {                                
     if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return 0;
     const long long P = (long long)d->N * d->PH * d->PW;
     if ((long long)d->N * d->H * d->W != P || (long long)d->N * d->OH * d->OW != P) return 0;
-    static const int tt_min_tiles = getenv("TCVOM_TT256_MIN_TILES") ? atoi(getenv("TCVOM_TT256_MIN_TILES")) : 8;
+    constexpr int tt_min_tiles = 8;
     // (every workgroup ends with 256 KB of atomics: worth it from 8 tiles on -- K C >= 512 K weights; the 4-tile shapes measured
     //  slower than igemm_tt)
     return d->K >= 256 && d->C >= 256 && d->K % 8 == 0 && d->C % 8 == 0 && P >= 4096 && cdiv(d->K, 256) * cdiv(d->C, 256) >= tt_min_tiles;

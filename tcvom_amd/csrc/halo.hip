@@ -26,7 +26,7 @@
 #define HALO_HW (HALO_TW + 2)
 #define HALO_HH (HALO_TH + 2)
 #define HALO_PIX (HALO_HW * HALO_HH)          // 340
-#define HALO_MAX_TAPS 18
+#define HALO_MAX_TAPS 10
 
 struct HaloArgs {
     const h16raw* in;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
             }
         }
 #if HALO_ABL != 1
-        if (a.out_fp32 == 2) {                   // IEEE fp16 whatever the build stores (high-precision stem of the bf16 build)
+        if (a.out_fp32 == 2) {                   // IEEE fp16 whatever the build stores (the fp16 island of the bf16 build)
             h16raw* op = reinterpret_cast<h16raw*>(a.out) + o0;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -304,14 +304,6 @@ __global__ __launch_bounds__(256) void halo_conv_kernel(const HaloArgs a) {
                 for (int g = 0; g < 4; ++g)
                     if (8 * g + 4 * half < a.K)
                         *reinterpret_cast<uint2*>(op + j * ostep + 8 * g) = make_uint2(pack2_ieee(acc[j][g * 4], acc[j][g * 4 + 1]), pack2_ieee(acc[j][g * 4 + 2], acc[j][g * 4 + 3]));
-        } else if (a.out_fp32) {
-            float* op = reinterpret_cast<float*>(a.out) + o0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (8 * g + 4 * half < a.K)
-                        *reinterpret_cast<float4*>(op + j * ostep + 8 * g) = make_float4(acc[j][g * 4], acc[j][g * 4 + 1], acc[j][g * 4 + 2], acc[j][g * 4 + 3]);
         } else {
             h16raw* op = reinterpret_cast<h16raw*>(a.out) + o0;
 #pragma unroll
@@ -400,13 +392,14 @@ static HaloPlan halo_plan(const tcvom_conv_desc* d, int nphase) {
     const int per = 16 / (d->C < 16 ? d->C : 16);       // taps per 16-deep chunk (C = 8: 2)
     int padded = (n + per - 1) / per * per;
     int nch = padded * d->C / 16;
-    // instantiated shapes: C=8 with 9 taps (5 chunks; stride 2 also with the 18 taps = 9 chunks of a high-precision layer),
-    // C=32 with 9 taps (18 chunks) or 18 taps (36 chunks)
-    if (!((d->C == 8 && (nch == 5 || (S == 2 && nch == 9))) || (d->C == 32 && (nch == 18 || nch == 36)))) return p;
+    // instantiated shapes: C=8 with 9 taps (5 chunks), C=32 with 9 taps (18 chunks); 16-bit results
+    if (!((d->C == 8 && nch == 5) || (d->C == 32 && nch == 18))) return p;
+    if (d->out_fp32 == 1) return p;
     // IEEE fp16 operands in the bf16 build (tcvom_conv_desc.in_f16): instantiated for the two stem layers of the fp16 island, with
     // fp16 results; other shapes go to the implicit GEMM (the plan -- not the launch -- declines: the statistics layout follows it)
     p.xf = d->in_f16 != 0 && !TCVOM_BUILD_F16;
-    if (p.xf && !(d->out_fp32 == 2 && ((S == 2 && nch == 5) || (S == 1 && d->C == 32 && nch == 18)))) return p;
+    if (p.xf && !((S == 2 && nch == 5) || (S == 1 && d->C == 32 && nch == 18))) return p;
+    if (p.xf != (d->out_fp32 == 2)) return p;           // IEEE fp16 results come with IEEE fp16 operands, and only with them
     for (int t = n; t < padded; ++t) p.taps[t] = -1;
     p.ok = true;
     p.C = d->C;
@@ -493,11 +486,9 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
         if (p.S == 2) HALO_LAUNCH(8, 5, 2, 1)
         else HALO_LAUNCH(32, 18, 1, 1)
     }
-    else if (p.S == 2 && p.nch == 5) HALO_LAUNCH(8, 5, 2)
-    else if (p.S == 2) HALO_LAUNCH(8, 9, 2)
+    else if (p.S == 2) HALO_LAUNCH(8, 5, 2)
     else if (p.C == 8) HALO_LAUNCH(8, 5, 1)
-    else if (p.nch == 18) HALO_LAUNCH(32, 18, 1)
-    else HALO_LAUNCH(32, 36, 1)
+    else HALO_LAUNCH(32, 18, 1)
 #undef HALO_LAUNCH
     if (e != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "halo_conv: %s", hipGetErrorString(e));
     hipError_t e2 = hipGetLastError();

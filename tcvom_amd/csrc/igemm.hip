@@ -376,8 +376,8 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         // the dense attention GEMMs of GCA (8160 x 8160 x 576 / 8160 x 2048 x 8160 at 1080p): 256x256 tiles halve the
         // L2->LDS bytes per MFMA, which is what bounds the 128x128 loop (measured 818 -> 1012 TFLOP/s on P.V)
         // 128x128 tiles from 256 workgroups on (3-frame launches of the os16 / os32 layers: 16 vs 18 us per frame in isolation, the
-        // step barely moves: 30.02 -> 29.85 ms); TCVOM_NT_T128 = study knob
-        static const int t128 = getenv("TCVOM_NT_T128") ? atoi(getenv("TCVOM_NT_T128")) : 256;
+        // step barely moves: 30.02 -> 29.85 ms)
+        constexpr int t128 = 256;
         // (measured and dropped, round 3: 256 (channels) x 128 (pixels) tiles for the 256-channel os16 layers -- 192 workgroups, one
         //  per CU, 25 % fewer operand bytes per MAC than two co-resident 128 x 128 workgroups: 25.57 -> 25.80 ms per step; the
         //  128 x 128 threshold lowered to 150 workgroups for the 512-channel os32 layers: no change)
@@ -388,12 +388,11 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
         // 128 (channels) x 96 (pixels) tiles, 4 waves of 32 x 96, where they spread evenly over the chip and the 128 x 128 ones do
         // not: the 256-channel os16 layers at 1080p are 64 x 2 x 3 = 384 workgroups of 128 x 128 (half the CUs run two, half one)
-        // but 85 x 2 x 3 = 510 of 128 x 96 (two per CU on 255 CUs); TCVOM_NT_T96=0 switches it off
-        static const int t96 = getenv("TCVOM_NT_T96") ? atoi(getenv("TCVOM_NT_T96")) : 1;
-        if (t96 && wgs >= t128 && wgs < 1024) {
+        // but 85 x 2 x 3 = 510 of 128 x 96 (two per CU on 255 CUs)
+        if (wgs >= t128 && wgs < 1024) {
             const long long w96 = (long long)cdiv(P, 96) * cdiv(d->K, 128) * nb;
-            // (both tiles run two workgroups per CU: 512 slots; TCVOM_NT_T96=2: the round-1 rule with 256 slots)
-            const long long slots = t96 == 2 ? 256 : 512;
+            // (both tiles run two workgroups per CU: 512 slots)
+            const long long slots = 512;
             auto eff = [slots](long long w) { const long long per = (w + slots - 1) / slots; return (double)w / (double)(per * slots); };
             if (eff(w96) > eff(wgs) + 0.1) return {128, 96, 1};
         }
@@ -402,11 +401,11 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         return {64, 64, 2};
     }
     // K <= 64: short reductions (1 .. 9 K-steps), bound by the latency of ONE workgroup times the rounds of co-resident workgroups:
-    // a 2-slot ring (49 KB: three workgroups per CU instead of two) measured +0.1 windows/s; TCVOM_NT_K64_NST=3 is the old 3-slot form.
+    // a 2-slot ring (49 KB: three workgroups per CU instead of two) measured +0.1 windows/s over the 3-slot form.
     // (Measured without effect, round 4: 32 x 128 tiles for K <= 32 -- twice the workgroups per CU -- and whole-row stores of the
     //  16-bit outputs through LDS: these layers re-fetch every input pixel once per tap through the L2 -> LDS DMA path, which bounds
     //  them at ~3.5 TB/s of DMA traffic -- ConvTranspose 32 -> 32 at 1088 x 1920: 535 MB through the DMA path for 33 MB of input.)
-    static const int k64nst = getenv("TCVOM_NT_K64_NST") ? atoi(getenv("TCVOM_NT_K64_NST")) : 2;
+    constexpr int k64nst = 2;
     if (d->K > 32) return {64, 128, 2, k64nst};
     return {32, 256, 4};
 }
@@ -468,7 +467,7 @@ extern "C" int tcvom_conv_stats_groups(const tcvom_conv_desc* d, int32_t nphase)
 extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_t nphase) {
     if (halo_conv_stats_groups(d, nphase) > 0) return d->C == 8 ? "halo_conv<8>" : "halo_conv<32>";
     if (const char* sv = sconv_variant(d, nphase)) return sv;
-    if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? (d->ntaps == 18 ? "wsconv<64,18>" : "wsconv<64>") : "wsconv<128>";
+    if (wsconv_stats_groups(d, nphase) > 0) return d->C == 64 ? "wsconv<64>" : "wsconv<128>";
     if (const char* pv = pwconv_variant(d, nphase)) return pv;
     if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
@@ -477,7 +476,7 @@ extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_
     if (c.tm == 128 && c.tn == 96) return "igemm_nt<128,96,32,96,2>";
     if (c.tm == 128) return "igemm_nt<128,64,32,32,3>";
     if (c.tm == 64 && c.tn == 64) return "igemm_nt<64,64,32,32,4>";
-    if (c.tm == 64) return "igemm_nt<64,128,32,64,3>";
+    if (c.tm == 64) return "igemm_nt<64,128,32,64,2>";
     return "igemm_nt<32,256,32,64,2>";
 }
 
@@ -518,20 +517,14 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     TCVOM_CHECK_ARG(zp != nullptr, "conv_igemm: could not allocate the zero page");
     // IEEE fp16 operands in the bf16 build (the fp16 island, tcvom_conv_desc.in_f16): fp16 results; halo_conv / wsconv where their plans
     // take the shape, else the implicit GEMM's XF instantiations
+    TCVOM_CHECK_ARG(!(TCVOM_BUILD_F16 && d0->in_f16 != 0), "conv_igemm: in_f16 = 1 in the fp16 build (it has no island: every layer already is IEEE fp16)");
     const bool xf = d0->in_f16 != 0 && !TCVOM_BUILD_F16;
     if (xf) {
         for (int i = 0; i < nphase; ++i)
             TCVOM_CHECK_ARG(descs[i].in_f16 != 0 && descs[i].out_fp32 == 2, "conv_igemm: in_f16 needs out_fp32 == 2 (fp16 results) in every phase");
         TCVOM_CHECK_ARG(!mscale && !mdiag, "conv_igemm: in_f16 with a column scale / diagonal term is not built");
     }
-    if (d0->out_fp32 == 2 && !xf) {
-        // IEEE fp16 results whatever the build stores: the halo kernel and the doubled-tap instantiation of the weight-stationary kernel
-        // write them (ops.py asks for them where tcvom_conv_igemm_variant names one of the two)
-        int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
-        if (r == 0) r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
-        TCVOM_CHECK_ARG(r != 0, "conv_igemm: out_fp32 = 2 (fp16 results) is built for halo_conv and wsconv<64,18> only");
-        return r < 0 ? r : TCVOM_OK;
-    }
+    TCVOM_CHECK_ARG(xf || d0->out_fp32 != 2, "conv_igemm: out_fp32 = 2 (IEEE fp16 results) comes with in_f16 = 1 in the bf16 build only (the fp16 island)");
     for (int i = 0; i < nphase; ++i) TCVOM_CHECK_ARG(xf || descs[i].out_fp32 == 0 || descs[i].out_fp32 == 1, "conv_igemm: out_fp32 = %d", descs[i].out_fp32);
     {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
@@ -575,13 +568,11 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     else if (c.tm == 64 && c.tn == 64) {
         // 4 ring slots = 64 KB: two workgroups per CU (512 on the chip); 3 slots = 48 KB: three.  A grid of 513 .. 768 workgroups
         // (the 512-channel os32 layers at 1080p: 32 x 8 x 3) is ONE round with three per CU instead of a full and a half one.
-        static const int nst3 = getenv("TCVOM_NT_6464_NST3") ? atoi(getenv("TCVOM_NT_6464_NST3")) : 1;
         const long long nwg = (long long)grid.x * grid.y * grid.z;
-        if (nst3 && nwg > 512 && nwg <= 768) NT_LAUNCH(256, 64, 64, 32, 32, 3);
+        if (nwg > 512 && nwg <= 768) NT_LAUNCH(256, 64, 64, 32, 32, 3);
         else NT_LAUNCH(256, 64, 64, 32, 32, 4);
     }
-    else if (c.tm == 64 && c.nst == 2) NT_LAUNCH(256, 64, 128, 32, 64, 2);
-    else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 3);
+    else if (c.tm == 64) NT_LAUNCH(256, 64, 128, 32, 64, 2);
     else NT_LAUNCH(256, 32, 256, 32, 64, 2);
 #undef NT_LAUNCH
 #undef NT_LAUNCH0
@@ -912,10 +903,9 @@ static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
     else {
         // K <= 32: one 128-column tile as soon as the columns (taps x C) do not fit a 32-column one -- the C = 8 layers (72 columns)
         // read dy once instead of three times (os1 8 -> 32: 130 -> 90 us, the two stride-2 layers on 8-channel inputs 81 -> 73 and
-        // 73 -> 67 us; what is left is the 9-fold gather of x through the L2 -> LDS path, ~4.8 TB/s).  TCVOM_TT_NARROW=1: the old rule
-        static const bool narrow = getenv("TCVOM_TT_NARROW") != nullptr;
+        // 73 -> 67 us; what is left is the 9-fold gather of x through the L2 -> LDS path, ~4.8 TB/s)
         *tm = 32;
-        *tn = (narrow ? ncols >= 128 : ncols > 32) ? 128 : 32;
+        *tn = ncols > 32 ? 128 : 32;
     }
 }
 extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {

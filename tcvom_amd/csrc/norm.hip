@@ -204,15 +204,14 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
     saved[C + c] = invstd;
 }
 
-// conv output `y` is 16-bit in the build's storage type (YF32 = 0), fp32 (1: the high-precision layers of the bf16 build) or IEEE
-// fp16 (2: their layer1 convs on the weight-stationary kernel -- 11 significant bits instead of bf16's 8 at half the bytes of fp32; in
-// the fp16 build the same thing as 0)
+// conv output `y` is 16-bit in the build's storage type (YF32 = 0) or IEEE fp16 (2: the fp16 island of the bf16 build -- 11 significant
+// bits instead of bf16's 8 at the same bytes; in the fp16 build the same thing as 0)
 // (unpack8_ieee: common.h)
 static inline int bn_y_mode(int y_fp32) {
 #ifdef TCVOM_F16
-    return y_fp32 == 1 ? 1 : 0;
+    return 0;
 #else
-    return y_fp32 == 1 ? 1 : y_fp32 == 2 ? 2 : 0;
+    return y_fp32 == 2 ? 2 : 0;
 #endif
 }
 template <int YF32>
@@ -742,10 +741,8 @@ static int bn_apply_impl(const void* y, const float* scale_shift, const void* re
     TCVOM_CHECK_ARG(C <= 2048, "bn_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
+    TCVOM_CHECK_ARG(y_fp32 == 0 || y_fp32 == 2, "bn_apply: y_fp32 = %d (0: the build's 16-bit type, 2: IEEE fp16)", y_fp32);
     switch (bn_y_mode(y_fp32)) {
-    case 1: hipLaunchKernelGGL(bn_apply_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
-                           y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
-                           g_overflow_sink.load(std::memory_order_relaxed), mask); break;
     case 2: hipLaunchKernelGGL(bn_apply_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
                            y, scale_shift, (const uint4*)res1, (const uint4*)res2, (uint4*)z, pixels, C / 8, C, act, rpb, slot_stride,
                            g_overflow_sink.load(std::memory_order_relaxed), mask); break;
@@ -791,12 +788,11 @@ extern "C" int tcvom_bn_apply_f16(const void* y, const float* scale_shift, const
 // per frame -- >= 768 blocks in all, enough to stream at full rate -- so that its finalize is ONE launch (more groups go through
 // bn_partial_reduce first: 28 extra dependent 5 us launches per 1080p step for the os1 / os2 / os4 layers).
 extern "C" int tcvom_bn_bwd_groups_n(int64_t pixels, int32_t C, int32_t nframes) {
-    static const int cap_on = getenv("TCVOM_NO_BN_GROUP_CAP") == nullptr;            // A/B switch
     const int rows = 256 / (C / 8);
     int64_t per = (int64_t)rows * 8;                // >= 8 loop iterations per thread
     int64_t g = (pixels + per - 1) / per;
     if (g > 2048) g = 2048;
-    if (cap_on && nframes >= 3 && g > 4 * BN_SLICES) g = 4 * BN_SLICES;
+    if (nframes >= 3 && g > 4 * BN_SLICES) g = 4 * BN_SLICES;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -812,10 +808,8 @@ static int bn_bwd_reduce_impl(const void* dz, const void* dz2, const void* y, co
     const int groups = tcvom_bn_bwd_groups_n(pixels, C, nframes);
     const int rpb = (int)((pixels + groups - 1) / groups);
     const dim3 grid(groups, nframes);
+    TCVOM_CHECK_ARG(y_fp32 == 0 || y_fp32 == 2, "bn_bwd_reduce: y_fp32 = %d (0: the build's 16-bit type, 2: IEEE fp16)", y_fp32);
     switch (bn_y_mode(y_fp32)) {
-    case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
     case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
                            dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
@@ -1123,10 +1117,8 @@ static int bn_bwd_apply_impl(const void* dz, const void* dz2, const void* y, con
     TCVOM_CHECK_ARG(C <= 2048, "bn_bwd_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
+    TCVOM_CHECK_ARG(y_fp32 == 0 || y_fp32 == 2, "bn_bwd_apply: y_fp32 = %d (0: the build's 16-bit type, 2: IEEE fp16)", y_fp32);
     switch (bn_y_mode(y_fp32)) {
-    case 1: hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;
     case 2: hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
                            (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;

@@ -240,7 +240,7 @@ static PwPlan pw_plan(const tcvom_conv_desc* d, int nphase) {
     PwPlan p;
     p.ok = false;
     static const bool disabled = getenv("TCVOM_NO_PWCONV") != nullptr;          // A/B switch
-    static const int maxc = getenv("TCVOM_PWCONV_MAXC") ? atoi(getenv("TCVOM_PWCONV_MAXC")) : 512;      // study knob
+    constexpr int maxc = 512;
     if (disabled || nphase != 1 || d->ntaps != 1 || d->tap_w[0] != 0 || d->wt != 1 || d->tap_dh[0] != 0 || d->tap_dw[0] != 0) return p;
     if (d->w_layout != 0 || d->out_fp32) return p;
     if (d->in_f16 && !TCVOM_BUILD_F16) return p;          // IEEE fp16 operands in the bf16 build: igemm_nt
@@ -255,7 +255,7 @@ static PwPlan pw_plan(const tcvom_conv_desc* d, int nphase) {
     if (p.tp < 32 * p.ps) return p;                       // (C = 256 with K = 32, C = 512 with K < 128: no instantiation)
     if (p.tp > 128 * p.ps) p.tp = 128 * p.ps;             // (PwCfg::TP)
     const long long P = (long long)d->N * d->H * d->W;
-    static const int minp = getenv("TCVOM_PWCONV_MINP") ? atoi(getenv("TCVOM_PWCONV_MINP")) : 1024;     // study knob
+    constexpr int minp = 1024;
     if (P < minp || P * C >= (1ll << 30) || P * d->ldo >= (1ll << 30)) return p;        // 32-bit byte offsets inside a frame
     const int nb = d->batch > 1 ? d->batch : 1;
     if (nb > 1) {

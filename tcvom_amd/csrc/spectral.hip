@@ -21,7 +21,7 @@ enum {
     SN_W = 0, SN_U, SN_V, SN_H, SN_WD, SN_KIND, SN_K, SN_C, SN_T, SN_CPAD,
     SN_FWD_OFF, SN_BWD_OFF, SN_T_OFF, SN_S_OFF, SN_DW_OFF, SN_GRAD_OFF, SN_NUMEL, SN_WS_STATS
 };
-// kind bits: 64 = forward pack in IEEE fp16 (bf16 build: the fp16 island), 32 = fragment-major packs (sn_frag_index), 1 = ConvTranspose layout, 2 = plain (no spectral norm), 4 = high-precision forward pack (hi + residual),
+// kind bits: 64 = forward pack in IEEE fp16 (bf16 build: the fp16 island), 32 = fragment-major packs (sn_frag_index), 1 = ConvTranspose layout, 2 = plain (no spectral norm),
 //            8 = weight-standardised (FBA base, models/FBA/layers_WS.py:13-23): packed value = (w - mean_row) * inv_row
 //                with the row statistics at SN_WS_STATS (float4 per output channel: mean, 1/(std + 1e-5), std, unused),
 //           16 = 7x7 stride-2 stem in space-to-depth form: the packed weight is the 4x4 stride-1 kernel over the 2x2
@@ -167,7 +167,7 @@ __device__ __forceinline__ int64_t sn_frag_index(int row, int slot, int col, int
     return ((((int64_t)(row >> 5) * T + slot) * (ncols >> 4) + (col >> 4)) * 64 + ((col >> 3) & 1) * 32 + (row & 31)) * 8 + (col & 7);
 }
 constexpr int SNP_TK = 32, SNP_TC = 64, SNP_RB = 16;
-constexpr int SNP_SLOTS = 18;                    // T <= 9 with the hi + residual pair, or T <= 16 alone
+constexpr int SNP_SLOTS = 18;                    // T <= 9 with the (build type, IEEE fp16) pair of an fp16-island layer, or T <= 16 alone
 constexpr int SNP_ROW = SNP_TC * SNP_SLOTS + 2;  // LDS row of one k: [c][slot], +2 elements: consecutive k rows are 32 T + 1 banks apart
 
 template <int TC>                                // TC = compile-time tap count (9, 16, 1) or 0: read it from the table
@@ -177,13 +177,13 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
     const float* __restrict__ W = reinterpret_cast<const float*>(L[SN_W]);
     const int kind = (int)L[SN_KIND];
     const int K = (int)L[SN_K], C = (int)L[SN_C], T = TC ? TC : (int)L[SN_T], Cp = (int)L[SN_CPAD];
-    const bool hp = kind & 4, transposed = kind & 1, ws = kind & 8;
+    const bool transposed = kind & 1, ws = kind & 8;
     // kind bit 64 (bf16 build): the FORWARD pack in IEEE fp16 (the fp16 island, tcvom_conv_desc.in_f16), the data-gradient pack in the
-    // build's type as ever: LDS slot t holds the build-type value, slot T + t the fp16 one (the slot pair of the hp layers)
+    // build's type as ever: LDS slot t holds the build-type value, slot T + t the fp16 one
     const bool f16f = (kind & 64) && !TCVOM_BUILD_F16;
-    const int TT = hp ? 2 * T : T;               // slots per (k, c) of the forward pack  (all divisions below are by T, 2 T or constants:
+    const int TT = T;                            // slots per (k, c) of the forward pack  (all divisions below are by T or constants:
                                                  // with a runtime T the integer divisions WERE the kernel, ~250 VALU ops / element)
-    const int TL = (hp || f16f) ? 2 * T : T;     // ... of the LDS image
+    const int TL = f16f ? 2 * T : T;             // ... of the LDS image
     const int rp = SNP_TC * TL + 2;              // row pitch of this layer (<= SNP_ROW)
     const int nct = (Cp + SNP_TC - 1) / SNP_TC;
     const int k0 = (tile / nct) * SNP_TK, c0 = (tile % nct) * SNP_TC;
@@ -212,8 +212,7 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
                 const h16raw hi = f2h(val);
                 h16raw* dst = lds + kl * rp + cl * TL + t;
                 dst[0] = hi;
-                if (hp) dst[T] = f2h(val - h2f(hi));
-                else if (f16f) dst[T] = f2h_ieee(val);
+                if (f16f) dst[T] = f2h_ieee(val);
             }
         }
     }
@@ -227,7 +226,7 @@ __device__ __forceinline__ void sn_pack_tile(const int64_t* __restrict__ L, int 
     for (int e = tid; e < nk * TT * (SNP_TC / 8); e += 256) {
         const int cl = (e % (SNP_TC / 8)) * 8, row = e / (SNP_TC / 8);
         int kl, slot;
-        if (hp) { kl = row / (2 * T); slot = row - kl * (2 * T); } else { kl = row / T; slot = row - kl * T; }
+        kl = row / T; slot = row - kl * T;
         if (cl < ncp) {                                   // (Cp % 8 == 0: the 8 channels are inside the padded row together)
             const h16raw* src = lds + kl * rp + cl * TL + slot + (f16f ? T : 0);
             h16raw v[8];
@@ -297,14 +296,11 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
     }
     const int64_t idx = base + threadIdx.x;
     int k, c, t;
-    int part = 0;                                  // hp layers (kind & 4): slot t = hi part, slot T + t = bf16 residual
     if (which == 0) {
-        const int TT = (kind & 4) ? 2 * T : T;
-        if (idx >= (int64_t)K * TT * Cp) return;
+        if (idx >= (int64_t)K * T * Cp) return;
         c = (int)(idx % Cp);
-        t = (int)((idx / Cp) % TT);
-        k = (int)(idx / ((int64_t)Cp * TT));
-        if (t >= T) { t -= T; part = 1; }
+        t = (int)((idx / Cp) % T);
+        k = (int)(idx / ((int64_t)Cp * T));
     } else {
         if (idx >= (int64_t)C * T * K) return;
         k = (int)(idx % K);
@@ -325,7 +321,6 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const int64_t* __restrict_
             const float4 ws = reinterpret_cast<const float4*>(L[SN_WS_STATS])[k];
             val = (W[src] - ws.x) * ws.y;
         }
-        if (part) val -= h2f(f2h(val));
     }
     int64_t di = idx;
     if (kind & 32) di = which == 0 ? sn_frag_index(k, t, c, T, Cp) : sn_frag_index(c, t, k, T, K);

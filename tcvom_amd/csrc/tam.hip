@@ -849,9 +849,8 @@ extern "C" int tcvom_tam_fwd(const void* q, const void* kb, const void* kf, cons
     const float isc = 1.0f / sqrtf((float)C);
     const size_t att_bytes = sizeof(float) * (size_t)n * window * window;
     static const int dense0 = getenv("TCVOM_TAM_DENSE") ? atoi(getenv("TCVOM_TAM_DENSE")) : 1;
-    static const bool no_self_init = getenv("TCVOM_TAM_MEMSET") != nullptr;          // A/B switch: the launcher's memsets / copy
     // window 7, C = 128 with every active tile on the MFMA kernel: that kernel writes every pixel itself (known ones: out = v, zero logits)
-    const bool self_init = window == 7 && C == 128 && dense0 <= 1 && !no_self_init;
+    const bool self_init = window == 7 && C == 128 && dense0 <= 1;
     if (!self_init &&
         (hipMemsetAsync(attb, 0, att_bytes, st) != hipSuccess || hipMemsetAsync(attf, 0, att_bytes, st) != hipSuccess ||
          hipMemsetAsync(worklist, 0, sizeof(int32_t), st) != hipSuccess ||
@@ -908,9 +907,8 @@ extern "C" int tcvom_tam_bwd(const void* q, const void* kb, const void* kf, cons
     const dim3 grid2(cdiv(n, 4), 2);
     const float isc = 1.0f / sqrtf((float)C);
     static const int dense = getenv("TCVOM_TAM_DENSE") ? atoi(getenv("TCVOM_TAM_DENSE")) : 1;      // (pass A: 90 -> 96 us on the band window, 118 -> 90 us all-unknown)
-    static const bool no_self_init = getenv("TCVOM_TAM_MEMSET") != nullptr;
     static const bool key_valu0 = getenv("TCVOM_TAM_KEY_VALU") != nullptr;
-    const bool self_init = window == 7 && C == 128 && dense <= 1 && !no_self_init;   // (the MFMA kernels write every pixel themselves)
+    const bool self_init = window == 7 && C == 128 && dense <= 1;   // (the MFMA kernels write every pixel themselves)
     if (!self_init && hipMemsetAsync(dq, 0, sizeof(h16raw) * (size_t)n * C, st) != hipSuccess) return tcvom_fail(TCVOM_ERR_LAUNCH, "tam_bwd: memset failed");
     int tile_hi = 1 << 30;
     if (window == 7 && C == 128 && dense <= 64) {

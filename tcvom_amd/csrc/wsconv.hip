@@ -53,22 +53,18 @@ struct WsArgs {
     long long stats_bstride;
     int wslot[9];                 // weight slot of the canonical tap t = (dh + 1) * 3 + (dw + 1)
     int w_frag;                   // weights are fragment-major (tcvom_conv_desc.w_layout = 1)
-    int wres;                     // doubled taps: weight slot of the residual of tap t = wslot[t] + wres
     unsigned long long* trace;    // NULL, or 64 cycle stamps of workgroup 8 / wave 0 (tcvom_conv_trace_read, env TCVOM_CONV_TRACE)
 };
 #define WS_STAMP(i) if (tracing) a.trace[i] = __builtin_readcyclecounter()
 
 // compile-time geometry of one kernel configuration
-// NT_ = 18: the high-precision layers of the bf16 build (gca_net.py: HP_LAYERS) -- every tap twice, weight slot t (the 16-bit head of
-// the fp32 weight) and slot 9 + t (its 16-bit residual) on the SAME input pixels; OM_: output type -- 0 the build's 16-bit storage type,
-// 1 fp32, 2 IEEE fp16 whatever the build stores (the conv results of the high-precision layers must not be rounded to bf16's 8
-// significant bits before the BatchNorm has been applied: fp16 keeps 11 at half the bytes of fp32)
+// OM_: output type -- 0 the build's 16-bit storage type, 2 IEEE fp16 whatever the build stores (the conv results of the fp16 island of
+// the bf16 build: 11 significant bits in front of the BatchNorm at bf16's bytes)
 // XF_ = 1: IEEE fp16 operands whatever the build stores (tcvom_conv_desc.in_f16: the fp16 island of the bf16 build, common.h)
-template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int NT_ = 9, int OM_ = 0, int XF_ = 0>
+template <int C_, int MF_, int PS_, int NI_, int FH_, int FW_, int OM_ = 0, int XF_ = 0>
 struct WsCfg {
-    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = NT_, OM = OM_, XF = XF_;
-    static constexpr bool OF32 = OM_ == 1;
-    static constexpr int OB = OM_ == 1 ? 4 : 2;                // bytes per output element
+    static constexpr int C = C_, MF = MF_, PS = PS_, NI = NI_, FH = FH_, FW = FW_, NT = 9, OM = OM_, XF = XF_;
+    static constexpr int OB = 2;                               // bytes per output element
     static constexpr int CU = C / 8, PIXB = C * 2;
     static constexpr int TH = PS * NI * FH, TW = FW, HW = TW + 2, HH = TH + 2, HPIX = HH * HW;
     static constexpr int NDMA = (HPIX * CU + 63) / 64;          // DMA wave-instructions (1 KiB each) per halo
@@ -86,7 +82,7 @@ struct WsCfg {
     static constexpr int E1 = NS - NS / 8;                      // the last stores get an eighth of the tile to complete
     // C = 128 (no registers to spare): the channel sums are reduced and stored per TILE by an extra piece per channel group
     // (its 40 DPP adds fit the MFMA shadow there); C = 64: 32 running sums per lane, reduced once per workgroup
-    static constexpr bool SPT = C_ * NT_ == 128 * 9;            // 288 weight registers (C = 128, or C = 64 with doubled taps)
+    static constexpr bool SPT = C_ == 128;                      // 288 weight registers
     static constexpr int NQG = NI + (SPT ? 1 : 0);              // pieces per channel group
     static constexpr int NQ = 4 * NQG;                          // epilogue pieces: 4 channel groups x (NI fragments (+ statistics))
     static constexpr int step_of(int q) { return E0 + q * (E1 - E0) / NQ; }
@@ -110,8 +106,8 @@ struct WsCfg {
         for (int u = s - PF; u < s; ++u) n += er(u) + (u > s - PF ? nb(u + PF) : 0);
         return n;
     }
-    static_assert(MF * PS == 4 && FH * FW == 32 && (C == 64 || C == 128) && (NT == 9 || (NT == 18 && C == 64)), "unsupported configuration");
-    static constexpr int tap_of(int s) { return (s / NCC) % 9; }   // stencil position of k-step s (steps 9 NCC .. are the residual weights)
+    static_assert(MF * PS == 4 && FH * FW == 32 && (C == 64 || C == 128) && (OM == 0 || OM == 2), "unsupported configuration");
+    static constexpr int tap_of(int s) { return s / NCC; }         // stencil position of k-step s
     static_assert(HW % 2 == 0, "halo rows must hold an even number of pixels (bank parity of 128-byte pixels)");
 };
 
@@ -241,8 +237,7 @@ __device__ __forceinline__ void ws_epi_piece(WsCtx<G>& c, const f32x4_t vals) {
         }
         const unsigned o = pv ? c.pbase + (unsigned)(j * G::FH) * (unsigned)(a.W * a.ldo * G::OB) + (unsigned)(8 * G::OB) * g : 0xffffffffu;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-        if constexpr (G::OF32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vals), c.orsrc, (int)o, 0, 0);
-        else if constexpr (G::OM == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2_ieee(vals[0], vals[1]), pack2_ieee(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
+        if constexpr (G::OM == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2_ieee(vals[0], vals[1]), pack2_ieee(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
         else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack2h(vals[0], vals[1]), pack2h(vals[2], vals[3])}, c.orsrc, (int)o, 0, 0);
     } else {
         float t[8];
@@ -400,9 +395,10 @@ __device__ __forceinline__ void ws_step(WsCtx<G>& c, const h16x8_t (&wr)[G::NS],
     if constexpr (S + 1 < G::NS) ws_step<G, S + 1>(c, wr, acc, bq, bbase, lb);
 }
 
-template <int C, int MF, int PS, int NI, int FH, int FW, int NT = 9, int OM = 0, int XF = 0>
+template <int C, int MF, int PS, int NI, int FH, int FW, int OM = 0, int XF = 0>
 __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
-    typedef WsCfg<C, MF, PS, NI, FH, FW, NT, OM, XF> G;
+    typedef WsCfg<C, MF, PS, NI, FH, FW, OM, XF> G;
+    constexpr int NT = G::NT;
     constexpr int TH = G::TH, TW = G::TW, HW = G::HW, PIXB = G::PIXB, CU = G::CU, NCC = G::NCC, NS = G::NS, SLOTB = G::SLOTB;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][SLOTB] halo, DUMPB, (+ XCHB bytes of results and the bias in the LDS form)
 
@@ -488,7 +484,7 @@ __global__ __launch_bounds__(256) void wsconv_kernel(const WsArgs a) {
         const int m = c.mf * 32 + col;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int ws = (t >= 9 && a.wslot[t % 9] >= 0) ? a.wslot[t % 9] + a.wres : a.wslot[t % 9];
+            const int ws = a.wslot[t];
 #pragma unroll
             for (int cc = 0; cc < NCC; ++cc) {
                 h16x8_t v = __builtin_bit_cast(h16x8_t, u32x4_t{0u, 0u, 0u, 0u});
@@ -595,7 +591,7 @@ extern "C" int tcvom_conv_trace_read(uint64_t* host, int32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-struct WsPlan { bool ok, xf; int C, th, tw, nt, wres; int wslot[9]; };
+struct WsPlan { bool ok, xf; int C, th, tw; int wslot[9]; };
 
 static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     WsPlan p;
@@ -615,30 +611,20 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     //  together exceed it is split into runs of frames by wsconv_try_launch: fragment-major weights have no other kernel)
     if ((long long)d->N * d->H * d->W * d->C >= (1ll << 31) || (long long)d->N * d->H * d->W * d->ldo >= (1ll << 31)) return p;
     for (int t = 0; t < 9; ++t) p.wslot[t] = -1;
-    int n = 0, n2 = 0;
-    p.wres = 0;
+    int n = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         if (d->tap_w[t] < 0) continue;
         const int dh = d->tap_dh[t], dw = d->tap_dw[t];
         if (dh < -1 || dh > 1 || dw < -1 || dw > 1) return p;
         const int c = (dh + 1) * 3 + (dw + 1);
-        if (p.wslot[c] >= 0) {
-            // a doubled tap list (the high-precision layers of the bf16 build, conv_plan.py: slot ws = the 16-bit head of the
-            // weight, slot wt / 2 + ws = its residual): the 64-channel layers run the 18-tap instantiation
-            static const bool no18 = getenv("TCVOM_NO_WSCONV18") != nullptr;          // A/B switch
-            if (no18 || d->C != 64 || d->w_layout != 0 || d->wt != 18 || d->tap_w[t] != p.wslot[c] + 9) return p;
-            p.wres = 9;
-            ++n2;
-            continue;
-        }
+        if (p.wslot[c] >= 0) return p;                  // (a tap twice: not a plain 3x3 stencil)
         p.wslot[c] = d->tap_w[t];
         ++n;
     }
-    if (n != 9 || (n2 != 0 && n2 != 9)) return p;
-    p.nt = n2 ? 18 : 9;
-    if (p.nt == 9 && d->out_fp32 == 1) return p;        // (fp32 results are built for the doubled-tap instantiation only)
+    if (n != 9) return p;
+    if (d->out_fp32 == 1) return p;                     // (fp32 results: the implicit GEMM)
     if (d->out_fp32 < 0 || d->out_fp32 > 2) return p;
-    if (p.xf && (p.nt != 9 || d->out_fp32 != 2)) return p;     // (IEEE fp16 operands: plain taps, fp16 results)
+    if (p.xf != (d->out_fp32 == 2)) return p;           // IEEE fp16 results come with IEEE fp16 operands (the fp16 island), and only with them
     p.C = d->C;
     p.th = 8;
     p.tw = d->C == 64 ? 32 : 16;
@@ -646,9 +632,6 @@ static WsPlan ws_plan(const tcvom_conv_desc* d, int nphase) {
     // the weights are packed for this kernel
     if (d->w_layout == 0 && (d->H < p.th / 2 || d->W < p.tw / 2)) return p;
     if (d->w_layout != 0 && (d->w_layout != 1 || d->wt != 9)) return p;
-    if (p.nt == 18) {                                   // fp32 byte offsets of one frame in 32 bits
-        if ((long long)d->N * d->H * d->W * d->ldo >= (1ll << 30)) return p;
-    }
     p.ok = true;
     return p;
 }
@@ -674,7 +657,7 @@ int wsconv_stats_groups(const tcvom_conv_desc* d, int nphase) {
     int tpf, tpw, wpf;
     ws_grid(d, p, &tpf, &tpw, &wpf);
     // C = 128 / doubled taps: one group per (tile, pixel group); C = 64: one per (workgroup, pixel group)
-    return (p.C == 128 || p.nt == 18) ? tpf * ws_ps(p) : wpf * ws_ps(p);
+    return p.C == 128 ? tpf * ws_ps(p) : wpf * ws_ps(p);
 }
 
 // returns 1 when the conv was launched here, 0 when the caller should use another kernel, < 0 on error
@@ -699,12 +682,11 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     a.stats_group_offset = d->stats_group_offset;
     a.stats_bstride = nb > 1 ? d->stats_bstride : 0;
     for (int t = 0; t < 9; ++t) a.wslot[t] = p.wslot[t];
-    a.wres = p.wres;
     a.w_frag = d->w_layout == 1;
     a.trace = ws_trace_buffer();
     ws_grid(d, p, &a.tiles_per_frame, &a.tiles_per_wg, &a.wgs_per_frame);      // (from the WHOLE batch: the statistics layout the caller sized)
-    const long long gpf = (p.C == 128 || p.nt == 18) ? (long long)a.tiles_per_frame * ws_ps(p) : (long long)a.wgs_per_frame * ws_ps(p);
-    const int ob = d->out_fp32 == 1 ? 4 : 2;
+    const long long gpf = p.C == 128 ? (long long)a.tiles_per_frame * ws_ps(p) : (long long)a.wgs_per_frame * ws_ps(p);
+    const int ob = 2;
     if (stats && nb > 1 && d->stats_bstride < gpf)
         return tcvom_fail(TCVOM_ERR_ARG, "wsconv: stats_bstride %lld < groups per frame", (long long)d->stats_bstride);
     {
@@ -717,7 +699,7 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
     // frames per launch: the buffer descriptors of the kernel address 32-bit byte ranges -- a batch whose frames together reach
     // 2^31 elements goes out as runs of frames (same tiles, same statistics groups per frame)
     const long long frame_elems = (long long)d->N * d->H * d->W * (d->C > d->ldo ? d->C : d->ldo);
-    long long fmax = ((1ll << (d->out_fp32 == 1 ? 30 : 31)) - 1) / (frame_elems > 0 ? frame_elems : 1);
+    long long fmax = ((1ll << 31) - 1) / (frame_elems > 0 ? frame_elems : 1);
     static const int test_fmax = getenv("TCVOM_WS_MAX_FRAMES") ? atoi(getenv("TCVOM_WS_MAX_FRAMES")) : 0;      // (tests: force the split)
     if (test_fmax > 0 && test_fmax < fmax) fmax = test_fmax;
     if (fmax < 1) fmax = 1;
@@ -732,40 +714,14 @@ int wsconv_try_launch(const void* in, const void* w, void* out, const float* bia
         a.out_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->ldo * ob);
         a.in_bytes = (unsigned)((long long)d->N * nf * d->H * d->W * d->C * 2);
         const dim3 grid(a.wgs_per_frame * nf);
-        if (p.C == 64 && p.nt == 18) {
-            typedef WsCfg<64, 2, 2, 4, 1, 32, 18, 1> G18;
-            constexpr size_t lds_bytes = 2 * G18::SLOTB + 1024 + G18::XCHB + 128 * 4;
-            static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-            static bool attr = false;
-            if (!attr) {
-                e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr = true;
-            }
-            if (d->out_fp32 == 1) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 1>), grid, dim3(256), lds_bytes, st, a);
-            else if (d->out_fp32 == 2) hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 2>), grid, dim3(256), lds_bytes, st, a);
-            else hipLaunchKernelGGL((wsconv_kernel<64, 2, 2, 4, 1, 32, 18, 0>), grid, dim3(256), lds_bytes, st, a);
-        } else if (p.xf && p.C == 64) {                 // fp16 island of the bf16 build: IEEE fp16 operands and results
-            auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32, 9, 2, 1>;
+        if (p.xf && p.C == 64) {                 // fp16 island of the bf16 build: IEEE fp16 operands and results
+            auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32, 2, 1>;
             constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
             static bool attr = false;
             if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
             hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
         } else if (p.xf) {
-            auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16, 9, 2, 1>;
-            constexpr size_t lds_bytes = 2 * WsCfg<128, 4, 1, 4, 2, 16>::SLOTB + 1024 + WsCfg<128, 4, 1, 4, 2, 16>::XCHB + 128 * 4;
-            static bool attr = false;
-            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
-        } else if (p.C == 64 && d->out_fp32 == 2) {
-            auto kern = wsconv_kernel<64, 2, 2, 4, 1, 32, 9, 2>;
-            constexpr size_t lds_bytes = 2 * WsCfg<64, 2, 2, 4, 1, 32>::SLOTB + 1024;
-            static bool attr = false;
-            if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
-        } else if (p.C == 128 && d->out_fp32 == 2) {
-            auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16, 9, 2>;
+            auto kern = wsconv_kernel<128, 4, 1, 4, 2, 16, 2, 1>;
             constexpr size_t lds_bytes = 2 * WsCfg<128, 4, 1, 4, 2, 16>::SLOTB + 1024 + WsCfg<128, 4, 1, 4, 2, 16>::XCHB + 128 * 4;
             static bool attr = false;
             if (!attr) { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }

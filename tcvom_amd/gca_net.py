@@ -7,6 +7,7 @@ models/VMN/VMN_GCA.py.  The nn.Modules below only HOLD parameters/buffers under 
 math runs in libtcvom_hip.so through tcvom_amd.ops (NHWC bf16 activations, fp32 statistics).
 """
 import math
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -16,28 +17,14 @@ from .ops import ACT_NONE, ACT_RELU, ACT_LEAKY, ConvCfg, H16
 from .weights import ConvSpec, WeightBank, bank_token
 
 TRIMAP_CHANNEL = 3
-# which encoder stages run the high-precision forward (doubled-tap weights hi + residual, conv output in fp32 / IEEE fp16 until the
-# BatchNorm has been applied).  The bf16 build needs it for the stem to get the alpha error under the north-star 1e-4 (DESIGN.md
-# section 6; until late round 5 layer1 too -- its share of the noise is now removed by fp16 conv outputs instead of doubled taps, see
-# Y16_LAYERS); the fp16 build does not (3 more mantissa bits: the plain pipeline sits ~25x below the bound) and runs none.
-# Study knob: TCVOM_HP_LAYERS=conv1,conv2,conv3,layer1 / TCVOM_HP_LAYERS= (none)
-import os as _os
-from . import _lib as _L
-# Round 6: the bf16 build's default is the FP16 ISLAND instead (ops.F16_ISLAND, ISLAND_LAYERS below): stem, layer1 and layer2 run
-# their forward on IEEE fp16 weights / activations / conv outputs; no doubled taps, no fp32 outputs.  TCVOM_NO_F16_ISLAND=1 restores the
-# round-5 scheme described here (A/B).
+# The encoder stages of the FP16 ISLAND of the bf16 build (ops.F16_ISLAND): their forward runs on IEEE fp16 packed
+# weights, IEEE fp16 activation twins and IEEE fp16 conv outputs -- tests/study_bf16_noise.py: >= 99 % of the bf16 storage noise of the alpha
+# matte is injected in the stem, layer1 and layer2 (a third each from weights, conv outputs and stored activations).  Measured against the
+# oracle, unknown-pixel alpha MSE at 256x320 / 512^2 / 544x960 / 1088x1920 (bound 1e-4): 1.21e-5 / 1.04e-5 / 9.98e-6 / 9.87e-6; the round-5
+# scheme it replaces (doubled-tap stem weights, fp16 conv outputs in layer1 / layer2; removed, see DESIGN_HISTORY.md): 9.4e-5 / 7.7e-5 /
+# 7.1e-5 / 6.75e-5 at the same step time (same-box A/B 22.76 / 22.90 ms against 22.69 / 22.73 ms).  TCVOM_NO_F16_ISLAND=1: plain bf16
+# everywhere (1.6e-4 at 256x320: above the bound; kept as the A/B that shows what the island buys).  The fp16 build has no island.
 ISLAND_LAYERS = ('conv1', 'conv2', 'conv3', 'layer1', 'layer2') if ops.F16_ISLAND else ()
-HP_LAYERS = tuple(n for n in _os.environ.get('TCVOM_HP_LAYERS', 'conv1,conv2,conv3' if (_L.DTYPE_NAME == 'bf16' and not ops.F16_ISLAND) else '').split(',') if n)
-HIGH_PRECISION_STEM = bool(HP_LAYERS)
-# encoder stages whose (plain, single-tap-list) convs store their outputs as IEEE fp16 where the kernel that writes it exists (the
-# weight-stationary 3x3 kernel): the same bytes as bf16 with 11 instead of 8 significant bits in front of the BatchNorm
-# Measured (round 5, one box; unknown-pixel alpha MSE vs the oracle at 256x320 (two runs) / 512^2 / 544x960 / 1088x1920, bound 1e-4, ms / step):
-#   HP stem + layer1 (doubled taps, fp32 / fp16 outputs), no y16     9.49, 9.69e-5 / 7.58e-5 / 6.92e-5 / 6.45e-5   22.67
-#   the same + y16 layer2                                           9.43, 9.14e-5 / 7.30e-5 / 6.74e-5 / 6.34e-5   22.64
-#   HP stem only, y16 layer1 + layer2  (the default)                 9.43, 9.54e-5 / 7.71e-5 / 7.14e-5 / 6.75e-5   22.41
-# (the forward differs from run to run by the atomics order of the SpectralNorm sums: +-2 % on these numbers; 12 more runs of the
-#  default at 256x320 on another box: 9.13 .. 9.38e-5, mean 9.25e-5)
-Y16_LAYERS = tuple(n for n in _os.environ.get('TCVOM_Y16_LAYERS', '' if ops.F16_ISLAND else 'layer1,layer2').split(',') if n) if _L.DTYPE_NAME == 'bf16' else ()
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -67,10 +54,10 @@ class SpectralNorm(nn.Module):
         self.module = _ConvParams(tuple(shape))
         self.stride, self.padding, self.transposed = stride, padding, transposed
 
-    def spec(self, name, group, needs_dgrad=True, hp=False):
+    def spec(self, name, group, needs_dgrad=True):
         m = self.module
         return ConvSpec(name, m.weight_bar, m.weight_u, m.weight_v, None, self.transposed, self.stride,
-                        self.padding, group, needs_dgrad, hp=hp)
+                        self.padding, group, needs_dgrad)
 
 
 def _plain_spec(name, conv, group, needs_dgrad=True):
@@ -192,16 +179,8 @@ class ResGuidedCxtAtten(nn.Module):
 
     def _register(self, bank):
         def reg(name, sn, bn, act=ACT_NONE, pre_relu=False, needs_dgrad=True):
-            # High-precision forward for the stem and layer1 (round 1: layer2 as well): tests/study_bf16_noise.py shows that
-            # >= 99 % of the bf16 storage noise of the whole window is injected in the stem, layer1 and layer2.  Measured against the
-            # oracle (unknown-pixel alpha MSE at 256x320 / 544x960 / 1088x1920): stem + layer1 + layer2 8.5e-5 / 5.9e-5 / 5.7e-5,
-            # stem + layer1 9.1e-5 / 6.7e-5 / 6.3e-5 (-0.5 ms per step: the 128-channel layers run on the weight-stationary
-            # kernel with bf16 outputs), stem only - / 8.3e-5 / 7.7e-5 (-1.35 ms); the bound is 1e-4.  Their packed weights carry a bf16
-            # residual (exact to ~2^-16) and their conv outputs stay fp32 until BatchNorm has been applied.
-            hp = HIGH_PRECISION_STEM and name.split('.')[0] in HP_LAYERS
-            spec = sn.spec('encoder.' + name, 'frame', needs_dgrad, hp=hp)
-            spec.f16 = (not hp) and name.split('.')[0] in ISLAND_LAYERS
-            spec.y16 = (not hp) and (not spec.f16) and name.split('.')[0] in Y16_LAYERS
+            spec = sn.spec('encoder.' + name, 'frame', needs_dgrad)
+            spec.f16 = name.split('.')[0] in ISLAND_LAYERS          # forward in IEEE fp16 (the fp16 island of the bf16 build)
             bank.register(spec)
             return ConvCfg(bank, spec, bn=bn, act=act, pre_relu=pre_relu)
         self._stem = [reg('conv1', self.conv1, self.bn1, ACT_RELU, needs_dgrad=False),

@@ -355,31 +355,12 @@ def _set_frames(arr, n, nf, w_stride):
             d.vec_bstride = 0
 
 
-HP_FP16 = _os.environ.get('TCVOM_NO_HP_FP16') is None        # A/B switch: fp32 conv outputs in every high-precision layer
-
-
 def _y_mode(t):
     """The conv-output type code of the C ABI (tcvom_conv_desc.out_fp32 / y_fp32 of the norm kernels): 0 = the build's 16-bit storage
-    type, 1 = fp32, 2 = IEEE fp16 in a build that stores bf16."""
+    type, 1 = fp32 (dense GEMM outputs only), 2 = IEEE fp16 in a build that stores bf16 (the fp16 island)."""
     if t.dtype == torch.float32:
         return 1
     return 2 if (t.dtype == torch.float16 and H16 != torch.float16) else 0
-
-
-def _hp_y_dtype(descs, nf, want=torch.float16, otherwise=torch.float32):
-    """Type of the conv output of a high-precision layer (it must not be rounded to bf16 before the BatchNorm has been applied): fp32,
-    or IEEE fp16 -- 11 significant bits at half the bytes through the conv store, the apply pass and both backward passes -- where the
-    kernel that writes it exists (the doubled-tap 64-channel layers on the weight-stationary kernel and the halo-tile kernel: encoder
-    layer1, stem conv1 / conv2)."""
-    if not (HP_FP16 and H16 != torch.float16 and len(descs) == 1):
-        return otherwise
-    cache = descs[0].__dict__.setdefault('_hp_y', {})
-    if nf not in cache:
-        arr = _phase_array(descs)
-        _set_frames(arr, 1, nf, 0)
-        var = L._FNS['tcvom_conv_igemm_variant'](C.byref(arr[0]), 1)
-        cache[nf] = var.startswith(b'wsconv') or var.startswith(b'halo_conv')
-    return want if cache[nf] else otherwise
 
 
 def _stats_groups(descs, nf=1):
@@ -438,21 +419,18 @@ class _ConvBNAct(torch.autograd.Function):
         st = L.stream_ptr()
         K = spec.K
         has_bn = bn is not None
-        # high-precision layers keep the conv output in fp32 until the BatchNorm has been applied
-        hp = spec.hp and has_bn
         # fp16 island (bf16 build): IEEE fp16 input twin x IEEE fp16 packed weight -> IEEE fp16 conv output (the geometry's forward
         # descriptors carry in_f16 = 1 / out_fp32 = 2, conv_plan.py); an input without a twin (a caller that built x itself) is converted
         island = getattr(spec, 'f16', False)
         if island:
-            assert has_bn and not hp and H16 == torch.bfloat16, 'fp16 island: conv + BatchNorm sites of the bf16 build'
+            assert has_bn and H16 == torch.bfloat16, 'fp16 island: conv + BatchNorm sites of the bf16 build'
             x16 = _c(x16) if x16 is not None else x.to(torch.float16)
-        # (y16 layers: the conv output in IEEE fp16 where the kernel that writes it exists -- same bytes as bf16, 11 significant bits)
-        ydt = torch.float16 if island else _hp_y_dtype(geo.fwd, nf) if hp else (_hp_y_dtype(geo.fwd, nf, torch.float16, H16) if (getattr(spec, 'y16', False) and has_bn) else H16)
+        ydt = torch.float16 if island else H16
         y = torch.empty((NT, geo.OH, geo.OW, K), dtype=ydt, device=x.device)
         stats = None
         gn = cfg.group_norm
         if gn:
-            assert N == 1 and not hp, 'GroupNorm: one sample per frame slot (VMN.run flattens the batch into frames)'
+            assert N == 1, 'GroupNorm: one sample per frame slot (VMN.run flattens the batch into frames)'
         if has_bn and (training or gn):
             stats = torch.empty(nf * _stats_groups(geo.fwd, nf) * 2 * K, dtype=torch.float32, device=x.device)
         pre_act = (ACT_LEAKY01 if cfg.pre_slope else ACT_RELU) if cfg.pre_relu else ACT_NONE

@@ -37,13 +37,12 @@ def _nch(norm):
 class ConvSpec(object):
     """Static description of one conv weight registered in the bank."""
 
-    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True, hp=False,
+    def __init__(self, name, weight, u, v, bias, transposed, stride, pad, group, needs_dgrad=True,
                  dilation=1, ws=False, stem=False, cpad=None):
         """ws: weight-standardised conv of the FBA base (models/FBA/layers_WS.py:13-23).  stem: the 7x7 stride-2 pad-3
         input conv of its ResNet, run as a 4x4 stride-1 conv over the 2x2 space-to-depth input (16 taps x 64 channels)."""
         self.name = name
         self.dilation, self.ws, self.stem = dilation, ws, stem
-        self.hp = hp                         # high-precision forward: packed weight = bf16 hi + bf16 residual (2T slots)
         # fp16 island (bf16 build; gca_net.py F16_ISLAND): the FORWARD pack is IEEE fp16 and the forward conv runs on IEEE fp16
         # activations (tcvom_conv_desc.in_f16); the data-gradient pack, the weight gradient and everything downstream stay bf16
         self.f16 = False
@@ -68,7 +67,7 @@ class ConvSpec(object):
             self.T, self.cpad = 16, 64          # packed geometry; C / R / S keep the parameter's shape
         # fragment-major packed weights for the weight-stationary conv kernel (csrc/wsconv.hip): stride-1 3x3 layers with
         # C == K in {64, 128}; its persistent workgroups then load their 288 KB of A fragments as contiguous 1 KiB blocks
-        self.frag = (WS_FRAG and not transposed and not hp and not stem and shp[2:] == (3, 3) and stride == 1 and pad == 1 and
+        self.frag = (WS_FRAG and not transposed and not stem and shp[2:] == (3, 3) and stride == 1 and pad == 1 and
                      dilation == 1 and self.C == self.K and self.C in (64, 128) and self.cpad == self.C)
         self.numel = weight.numel()
         self.h = shp[0]
@@ -306,15 +305,15 @@ class WeightBank(object):
             tab[i, SN_U] = s.u.data_ptr() if s.spectral else 0
             tab[i, SN_V] = s.v.data_ptr() if s.spectral else 0
             tab[i, SN_H], tab[i, SN_WD] = s.h, s.wd
-            tab[i, SN_KIND] = ((1 if s.transposed else 0) | (0 if s.spectral else 2) | (4 if s.hp else 0) |
+            tab[i, SN_KIND] = ((1 if s.transposed else 0) | (0 if s.spectral else 2) |
                                (8 if s.ws else 0) | (16 if s.stem else 0) | (32 if s.frag else 0) | (64 if s.f16 else 0))
-            assert not (s.f16 and (s.hp or s.ws or s.stem or s.T > 9)), 'fp16 forward pack: plain 3x3 / 1x1 layers'
+            assert not (s.f16 and (s.ws or s.stem or s.T > 9)), 'fp16 forward pack: plain 3x3 / 1x1 layers'
 
-            assert not (s.ws and (s.spectral or s.transposed or s.hp)) and (s.ws or not s.stem)
+            assert not (s.ws and (s.spectral or s.transposed)) and (s.ws or not s.stem)
             tab[i, SN_K], tab[i, SN_C], tab[i, SN_T], tab[i, SN_CPAD] = s.K, s.C, s.T, s.cpad
             tab[i, SN_FWD_OFF] = fwd_off
             s.fwd_off = fwd_off
-            fwd_off += s.K * s.T * s.cpad * (2 if s.hp else 1)
+            fwd_off += s.K * s.T * s.cpad
             if s.needs_dgrad:
                 tab[i, SN_BWD_OFF] = bwd_off
                 s.bwd_off = bwd_off
@@ -517,8 +516,8 @@ class WeightBank(object):
         """Work list of tcvom_sn_pack: (layer, which, block) triples."""
         rows = []
         for s in sel:
-            slots = s.T * (2 if s.hp else 1)
-            lds_slots = s.T * (2 if (s.hp or getattr(s, 'f16', False)) else 1)     # (sn_pack_tile keeps both formats of an f16 layer)
+            slots = s.T
+            lds_slots = s.T * (2 if getattr(s, 'f16', False) else 1)     # (sn_pack_tile keeps both formats of an f16 layer)
             if TILED_PACK and not getattr(s, 'stem', False) and lds_slots <= 18:
                 # csrc/spectral.hip sn_pack_tile: 32 (k) x 64 (c) tiles, which = 3 also writes the data-gradient pack
                 ntile = ((s.K + 31) // 32) * ((s.cpad + 63) // 64)

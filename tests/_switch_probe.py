@@ -26,6 +26,8 @@ for name, p in model.NET.named_parameters():
     g = p.grad.double()
     s, d = groups.get(key, (0.0, 0.0))
     groups[key] = (s + float((g * g).sum()), d + float(g.sum()))
-res = {'loss': float(loss), 'losses': [float(x) for x in out[:5]],
+alpha = out[7].detach().float().flatten()
+sample = alpha[torch.linspace(0, alpha.numel() - 1, 4096, device=alpha.device).long()]       # a fixed sample of the predicted mattes
+res = {'loss': float(loss), 'losses': [float(x) for x in out[:5]], 'alpha_sample': [float(x) for x in sample.cpu()],
        'grad_norm': {k: v[0] ** 0.5 for k, v in groups.items()}, 'grad_sum': {k: v[1] for k, v in groups.items()}}
 print('PROBE ' + json.dumps(res))

@@ -270,8 +270,8 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     ck.done()
 
 
-@pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W,hp', [(64, 128, 3, 2, False, 24, 40, False), (128, 64, 4, 2, True, 12, 20, False),
-                                                                  (32, 32, 3, 1, False, 16, 64, True), (256, 256, 1, 1, False, 10, 12, False),
+@pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W,f16', [(64, 128, 3, 2, False, 24, 40, False), (128, 64, 4, 2, True, 12, 20, False),
+                                                                  (32, 32, 3, 1, False, 16, 64, True), (64, 64, 3, 1, False, 20, 44, True), (64, 128, 3, 2, False, 24, 40, True), (256, 256, 1, 1, False, 10, 12, False),
                                                                   (128, 128, 3, 1, False, 20, 36, False), (64, 64, 3, 1, False, 36, 40, False),
                                                                   # csrc/sconv.hip: four phases x three frames with statistics; two channel blocks
                                                                   (64, 64, 4, 2, True, 16, 40, False), (32, 32, 4, 2, True, 24, 64, False),
@@ -279,7 +279,7 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
                                                                   # the 3-frame launch runs on gemm_nt256 with statistics (396 tiles), the
                                                                   # frame-by-frame ones (132 tiles each) on igemm_nt: same groups, same sums
                                                                   (512, 1024, 1, 1, False, 48, 86, False)])
-def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, transposed, H, W, hp):
+def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, transposed, H, W, f16):
     """Three frames through a SpectralNorm'd conv + BatchNorm + ReLU as ONE frame-batched op (bank.frames_per_op = 3: per-frame
     weight slot, per-frame batch statistics, batched data gradient, deferred batched weight gradient) must equal three
     frame-by-frame ops on the same bank state: outputs and input gradients bit for bit (same kernels, same tiles may differ
@@ -296,7 +296,8 @@ def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, trans
         u = nn.Parameter(formula_tensor('conv.%s.weight_u' % tag, (shape[0],)).to(DEV), requires_grad=False)
         v = nn.Parameter(formula_tensor('conv.%s.weight_v' % tag, (int(np.prod(shape[1:])),)).to(DEV), requires_grad=False)
         bank = WeightBank()
-        spec = ConvSpec(tag, w, u, v, None, transposed, stride, pad, 'frame', hp=hp)
+        spec = ConvSpec(tag, w, u, v, None, transposed, stride, pad, 'frame')
+        spec.f16 = bool(f16) and H16 == torch.bfloat16     # a layer of the fp16 island of the bf16 build (forward in IEEE fp16)
         bank.register(spec)
         bn = nn.BatchNorm2d(cout).to(DEV)
         with torch.no_grad():
@@ -450,36 +451,36 @@ def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
         assert rel_err(got, ref) < 1e-5, 'problem %d' % i
 
 
-@pytest.mark.parametrize('cin,cout,hp,N,H,W', [(32, 32, False, 2, 16, 64), (32, 32, True, 1, 24, 96), (6, 32, False, 1, 16, 160),
-                                              (32, 32, False, 1, 72, 96), (64, 64, False, 2, 16, 64), (64, 64, True, 1, 24, 96),
-                                              (64, 32, False, 1, 16, 96), (32, 64, False, 1, 40, 64)])
-def test_halo_conv_kernel(cin, cout, hp, N, H, W):
-    _halo_conv_case(cin, cout, hp, N, H, W, 1)
+@pytest.mark.parametrize('cin,cout,N,H,W', [(32, 32, 2, 16, 64), (6, 32, 1, 16, 160), (32, 32, 1, 72, 96), (64, 64, 2, 16, 64),
+                                           (64, 32, 1, 16, 96), (32, 64, 1, 40, 64)])
+def test_halo_conv_kernel(cin, cout, N, H, W):
+    _halo_conv_case(cin, cout, N, H, W, 1)
 
 
-@pytest.mark.parametrize('cin,cout,hp,N,H,W', [(6, 32, False, 2, 32, 128), (6, 32, True, 1, 48, 192), (3, 16, False, 1, 16, 64)])
-def test_halo_conv_kernel_stride2(cin, cout, hp, N, H, W):
+@pytest.mark.parametrize('cin,cout,N,H,W', [(6, 32, 2, 32, 128), (3, 16, 1, 16, 64)])
+def test_halo_conv_kernel_stride2(cin, cout, N, H, W):
     """The stride-2 3x3 convs on the 8-channel full-resolution inputs (encoder conv1, guidance head; out % (8, 32) == 0) take the
     halo kernel too: forward with fused ReLU + batch statistics and the weight gradient against fp32 PyTorch."""
-    _halo_conv_case(cin, cout, hp, N, H, W, 2)
+    _halo_conv_case(cin, cout, N, H, W, 2)
 
 
 def test_halo_conv_kernel_stride2_on_a_reflection_padded_input():
     """ReflectionPad2d(1) + Conv2d(3 -> 16, stride 2, padding 0) of the guidance head (res_gca_enc.py:20-28): taps 0..2 on an
     input that carries its own ring."""
-    _halo_conv_case(3, 16, False, 2, 34, 130, 2, pad=0)
+    _halo_conv_case(3, 16, 2, 34, 130, 2, pad=0)
 
 
-def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
+def _halo_conv_case(cin, cout, N, H, W, stride, pad=1):
     """Shapes served by the halo-tile direct conv (stride-1 3x3, <= 32 channels, H % 8 == 0, W % 32 == 0): forward
     with fused ReLU + batch statistics (64 output channels = two workgroups per tile), data gradient (also through the halo kernel) and weight gradient, against
-    fp32 PyTorch on the same bf16 operands.  hp = bf16 hi + residual weights (18 taps), fp32 conv output."""
+    fp32 PyTorch on the same 16-bit operands.  (The IEEE fp16 operand mode of the kernel -- the fp16 island of the bf16 build -- is covered by
+    tests/test_gpu_f16_island.py.)"""
     from tcvom_amd import ops
     from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
-    tag = 'halo%d_%d_%d_%d_s%d_p%d' % (cin, cout, int(hp), H, stride, pad)
+    tag = 'halo%d_%d_%d_%d_s%d_p%d' % (cin, cout, 0, H, stride, pad)
     w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cout, cin, 3, 3)) * 0.2).to(DEV))
     bank = WeightBank()
-    spec = ConvSpec(tag, w, None, None, None, False, stride, pad, 'frame', needs_dgrad=cin >= 16, hp=hp)
+    spec = ConvSpec(tag, w, None, None, None, False, stride, pad, 'frame', needs_dgrad=cin >= 16)
     bank.register(spec)
     bn = nn.BatchNorm2d(cout).to(DEV)
     cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
@@ -497,10 +498,10 @@ def _halo_conv_case(cin, cout, hp, N, H, W, stride, pad=1):
     bank.flush_bn_counters()
     xr = bf(x).requires_grad_(True)
     wf = spec.weight.detach().cpu()
-    wr = (wf if hp else bf(wf)).clone().requires_grad_(True)      # hi + residual reproduces the fp32 weight to ~2^-16
+    wr = bf(wf).clone().requires_grad_(True)
     yr = F.relu(F.conv2d(xr, wr, None, stride, pad))
     mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
-    yq = yr if hp else yr + (bf(yr) - yr).detach()
+    yq = yr + (bf(yr) - yr).detach()
     zr = (yq - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
     ck = Checker()
     ck.rel('z', nchw(z), zr, 2e-2)
@@ -579,71 +580,6 @@ def test_pwconv_kernel(cin, cout, N, H, W, bias):
     sums = stats.view(groups, 2, cout).double().sum(0).cpu()
     assert torch.isfinite(sums).all()
     assert rel_err(sums[0], yref.double().sum((0, 2, 3))) < 1e-4 and rel_err(sums[1], (yref.double() ** 2).sum((0, 2, 3))) < 1e-4
-
-
-@pytest.mark.parametrize('N,H,W', [(2, 20, 44), (1, 48, 64), (1, 13, 37)])
-def test_wsconv_kernel_doubled_taps(N, H, W):
-    """The high-precision 64 -> 64 layers of the bf16 build (gca_net.py HP_LAYERS: encoder layer1; every tap twice -- the 16-bit head of
-    the fp32 weight and its 16-bit residual -- and an fp32 conv output) on the weight-stationary kernel's 18-tap instantiation
-    (csrc/wsconv.hip: WsCfg<64, .., 18, OF32>): raw kernel in both output types against fp32 PyTorch with the UNROUNDED weight
-    (hi + residual reproduce it to ~2^-16, so the bound is tight), batch statistics per tile, then conv + BatchNorm + ReLU and the
-    gradients through the op."""
-    import ctypes as C
-    from tcvom_amd import _lib as L
-    from tcvom_amd import ops
-    from tcvom_amd.conv_plan import ConvGeometry
-    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
-    cin = 64
-    tag = 'ws18_%d_%d_%d' % (N, H, W)
-    w = nn.Parameter((formula_tensor('conv.%s.weight' % tag, (cin, cin, 3, 3)) * 0.2).to(DEV))
-    bank = WeightBank()
-    spec = ConvSpec(tag, w, None, None, None, False, 1, 1, 'frame', hp=True)
-    bank.register(spec)
-    geo = ConvGeometry(spec, N, H, W)
-    assert geo.fwd[0].ntaps == 18
-    assert L._FNS['tcvom_conv_igemm_variant'](C.byref(geo.fwd[0]), 1).decode() == 'wsconv<64,18>'
-    bn = nn.BatchNorm2d(cin).to(DEV)
-    cfg = ops.ConvCfg(bank, spec, bn=bn, act=0, pre_relu=True)
-    x = hu('x.' + tag, (N, cin, H, W)) - 0.5
-    xg = nhwc(x).requires_grad_(True)
-    token = bank_token(bank, 1, True)
-    z = ops.conv_bn_act(cfg, xg, token, True)
-    bank.flush_bn_counters()
-    xr = bf(x).requires_grad_(True)
-    wf = spec.weight.detach().cpu()
-    wr = wf.clone().requires_grad_(True)
-    yr = F.relu(F.conv2d(xr, wr, None, 1, 1))
-    mean, var = yr.mean((0, 2, 3)), yr.var((0, 2, 3), unbiased=False)
-    zr = (yr - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
-    ck = Checker()
-    ck.rel('z', nchw(z), zr, 2e-2)
-    ck.rel('running_mean', bn.running_mean, 0.1 * mean.detach(), 1e-3)
-    n_el = yr.numel() // cin
-    ck.rel('running_var', bn.running_var, 0.9 + 0.1 * var.detach() * n_el / (n_el - 1), 1e-3)
-    gz = hu('gz.' + tag, tuple(zr.shape)) - 0.5
-    (z.float() * nhwc(gz).float()).sum().backward()
-    (zr * bf(gz)).sum().backward()
-    ck.rel('dx', nchw(xg.grad), xr.grad, 4e-2)
-    ck.rel('dw', spec.weight.grad, wr.grad, 3e-2)
-    ck.done()
-    # raw kernel: fp32 and 16-bit results, with and without the statistics epilogue
-    st = L.stream_ptr()
-    yref = F.conv2d(bf(x), wf, None, 1, 1)
-    groups = ops._stats_groups(geo.fwd, 1)
-    y32 = torch.empty(N, H, W, cin, device=DEV, dtype=torch.float32)
-    stats = torch.full((groups * 2 * cin,), float('nan'), device=DEV, dtype=torch.float32)
-    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y32, None, stats, 0, st)
-    assert rel_err(nchw(y32), yref) < 2e-5, rel_err(nchw(y32), yref)
-    sums = stats.view(groups, 2, cin).double().sum(0).cpu()
-    assert torch.isfinite(sums).all()
-    assert rel_err(sums[0], yref.double().sum((0, 2, 3))) < 1e-5 and rel_err(sums[1], (yref.double() ** 2).sum((0, 2, 3))) < 1e-5
-    y16 = torch.empty(N, H, W, cin, device=DEV, dtype=H16)
-    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), y16, None, None, 1, st)
-    assert rel_err(nchw(y16), F.relu(yref)) < 6e-3
-    # IEEE fp16 results whatever the build stores (what the layer1 convs of the bf16 build write: 11 significant bits)
-    yh = torch.empty(N, H, W, cin, device=DEV, dtype=torch.float16)
-    ops._launch_conv(geo.fwd, xg.detach(), bank.fwd_ptr(spec, 0), yh, None, None, 0, st)
-    assert rel_err(nchw(yh), yref) < 6e-4
 
 
 @pytest.mark.parametrize('cin,cout,dil,N,H,W,S', [(256, 256, 2, 1, 16, 24, 3), (512, 512, 4, 1, 16, 32, 1), (64, 64, 2, 2, 10, 18, 2),
@@ -857,8 +793,8 @@ def test_wsconv_kernel(cin, N, H, W, bias):
 # --------------------------------------------------------------------------------------------- spectral norm
 def test_tiled_weight_pack_equals_elementwise_pack(monkeypatch):
     """The tiled pack (32 x 64 x T tiles through LDS, csrc/spectral.hip sn_pack_tile) must write the same bytes as the
-    one-thread-per-element pack for every layer kind: plain / SpectralNorm / ConvTranspose [cin][cout] order / hi + residual
-    (hp) / weight-standardised, padded channels (6 -> 8, 72 -> 128), K below and off the tile size, no data-gradient pack."""
+    one-thread-per-element pack for every layer kind: plain / SpectralNorm / ConvTranspose [cin][cout] order / IEEE fp16 forward pack
+    (the fp16 island of the bf16 build) / weight-standardised, padded channels (6 -> 8, 72 -> 128), K below and off the tile size, no data-gradient pack."""
     from tcvom_amd import weights as Wm
     from tcvom_amd.weights import WeightBank, ConvSpec, bank_token
 
@@ -872,14 +808,18 @@ def test_tiled_weight_pack_equals_elementwise_pack(monkeypatch):
             if spectral:
                 u = nn.Parameter(formula_tensor('pk.%s.u' % tag, (shape[0],)).to(DEV), requires_grad=False)
                 v = nn.Parameter(formula_tensor('pk.%s.v' % tag, (int(np.prod(shape[1:])),)).to(DEV), requires_grad=False)
+            f16 = kw.pop('f16', False)
             s = ConvSpec(tag, w, u, v, None, transposed, 2 if transposed else 1, 1, 'frame', **kw)
+            s.f16 = f16
             bank.register(s)
             specs.append(s)
         add('plain', (48, 32, 3, 3))
         add('sn', (64, 64, 3, 3), spectral=True)
         add('sn_small_k', (20, 6, 3, 3), spectral=True, needs_dgrad=False)
         add('convT', (96, 40, 4, 4), transposed=True, spectral=True)
-        add('hp', (32, 32, 3, 3), spectral=True, hp=True)
+        add('f16', (32, 32, 3, 3), spectral=True, f16=True)
+        add('f16_frag', (64, 64, 3, 3), spectral=True, f16=True)
+        add('f16_1x1', (128, 64, 1, 1), spectral=True, f16=True)
         add('ws', (64, 128, 1, 1), ws=True)
         add('ws3', (36, 72, 3, 3), ws=True, cpad=128)
         bank_token(bank, 1, True)
@@ -905,7 +845,7 @@ def test_tiled_weight_pack_equals_elementwise_pack(monkeypatch):
     torch.cuda.synchronize()
     # the layers' own ranges (alignment gaps between layers are never written and keep the fill value)
     for s in specs:
-        nf = s.K * s.T * (2 if s.hp else 1) * s.cpad
+        nf = s.K * s.T * s.cpad
         assert torch.equal(bank.fwd_arena[s.fwd_off:s.fwd_off + nf].view(torch.int16), ref_f[s.fwd_off:s.fwd_off + nf].view(torch.int16)), s.name
         if s.needs_dgrad:
             nb = s.C * s.T * s.K

@@ -433,7 +433,18 @@ def _world8_worker(rank, world, port, out):
         wsum = torch.stack([p.detach().double().sum() for p in params]).cpu()
         ws = [None] * world
         dist.all_gather_object(ws, wsum)
-        res = dict(rank=rank, exchanges_per_step=per_step[0], ring=mb.ring, presence_ms=presence,
+        # the host-side presence all-reduce by itself (GradientAverager._fill_locally_unused: one int32 per parameter over the averager's
+        # gloo group), all ranks arriving together: inside the steps above its wall time is the ARRIVAL SKEW of eight ranks time-slicing
+        # one GPU (their launch queues fill up while the in-kernel mailbox waits spin), not the cost of the collective
+        import time
+        hg = av._host_group()
+        vec = torch.ones(len(params) + 1, dtype=torch.int32)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(vec, group=hg if hg else None)
+        pure_ms = 1e3 * (time.perf_counter() - t0) / 20
+        res = dict(rank=rank, exchanges_per_step=per_step[0], ring=mb.ring, presence_ms=presence, presence_pure_ms=pure_ms,
                    weights_agree=float(max((w - ws[0]).abs().max() for w in ws)))
         if rank == 0:
             # ONE process, the `world` clips as one batch, plain BatchNorm: what SyncBatchNorm + gradient averaging must reproduce
@@ -468,12 +479,15 @@ def test_world8_preflight_on_one_gpu(tmp_path):
     rs = [torch.load(out + str(r)) for r in range(world)]
     r0 = rs[0]
     print('world 8 on one GPU:', {k: v for k, v in r0.items() if k != 'presence_ms'})
-    print('host_presence_allreduce_ms per step, per rank:', [[round(x, 2) for x in r['presence_ms']] for r in rs])
+    print('host presence all-reduce inside the steps (= arrival skew of 8 ranks sharing one GPU), ms per step, per rank:',
+          [[round(x, 1) for x in r['presence_ms']] for r in rs])
+    print('host presence all-reduce by itself (8 ranks, gloo, %d int32, aligned arrival): %.3f ms (max over ranks)'
+          % (229, max(r['presence_pure_ms'] for r in rs)))
     assert all(r['weights_agree'] == 0.0 for r in rs), [r['weights_agree'] for r in rs]
     assert all(r['exchanges_per_step'] == r0['exchanges_per_step'] for r in rs)
     # SyncBatchNorm over 8 ranks == BatchNorm over the batch of 8: running statistics to fp32 rounding, alphas to the storage type
     assert r0['stats_err'] <= tol(2e-3, 1e-4), r0
     assert r0['alpha_mse'] <= tol(1e-5, 1e-6), r0
     assert r0['n_grads'] > 200 and r0['grad_cos'] >= tol(0.99, 0.998) and abs(r0['grad_norm_ratio'] - 1) <= tol(3e-2, 1e-2), r0
-    # the one blocking host collective of a step: report it, and fail only if it is pathological (seconds)
-    assert max(max(r['presence_ms'][1:]) for r in rs) < 2000.0
+    # the one blocking host collective of a step, by itself: fail only if it is pathological
+    assert max(r['presence_pure_ms'] for r in rs) < 50.0

@@ -290,24 +290,14 @@ def test_gradient_fidelity_vs_oracle():
     assert cos(tot_h, tot_o) >= tol(0.88, 0.9), 'whole-network gradient direction'       # measured 0.94 (bf16, round 6; 0.79 in round 5)
 
 
-@pytest.mark.parametrize('regime', ['formula_gains', 'damped_residual_gains'])
-def test_gradient_noise_on_a_conditioned_network(regime):
-    """Run-to-run and HIP-vs-oracle agreement of the WHOLE-network gradient on a network that is two optimizer steps into
-    training, at 256 x 320 (VERDICT round 4, weak #4).  The only run-to-run difference of the HIP path is the order of fp32
-    atomic partial sums (igemm_tt / wgrad_ws / SpectralNorm sums); how far that moves the gradient depends on how strongly the
-    backward map of the 60-layer train-mode-BatchNorm stack amplifies last-bit differences, so two regimes are bounded:
-      * formula_gains: the formula weights as they are -- every BatchNorm scale 0.6 +- 0.25, INCLUDING every BasicBlock's bn2
-        (the reference zero-initialises those, resnet_enc.py:96-98; SURVEY App. A asks for O(1) values in parity tests) -- a
-        random network whose residual branches carry as much signal as the identity paths: the ill-conditioned end;
-      * damped_residual_gains: bn2.weight x 0.15 (what zero-init-residual training leaves early on): the identity paths dominate
-        and the amplification argument no longer applies -- here the kernels themselves are what is measured.
-    Both start from two FusedAdam steps of the HIP path (running statistics, power-iteration vectors and weights moved off the
-    formula state); the resulting state_dict is loaded into the fp32 CPU oracle, and the third step's gradient is compared."""
+def _conditioned_gradient(regime, H, W):
+    """Two FusedAdam steps of the HIP path from the formula state (`damped_residual_gains`: bn2.weight x 0.15 first), then the THIRD step's
+    gradient twice on the HIP path and once in the fp32 CPU oracle from the same state_dict: cosines, norm ratio, per-group norm ratios."""
+
     import os
     import oracle
     from tcvom_amd.facade import train_step_loss
     from tcvom_amd.optim import FusedAdam
-    H, W = 256, 320
     m = _model(7, 12)
     if regime == 'damped_residual_gains':
         with torch.no_grad():
@@ -349,8 +339,30 @@ def test_gradient_noise_on_a_conditioned_network(regime):
     enc = [k for k in keys if k.startswith('encoder.')]
     dec = [k for k in keys if k.startswith('decoder.')]
     sub = lambda gs, ks: torch.cat([gs[k].flatten() for k in ks])
-    print('%s, two Adam steps in, 256x320: whole-network gradient cosine HIP vs oracle %.4f (encoder %.4f, decoder %.4f), run vs rerun %.4f, '
-          'norm ratio %.4f' % (regime, c_oracle, cos(sub(g1, enc), sub(go, enc)), cos(sub(g1, dec), sub(go, dec)), c_rerun, nr))
+    print('%s, two Adam steps in, %dx%d: whole-network gradient cosine HIP vs oracle %.4f (encoder %.4f, decoder %.4f), run vs rerun %.4f, '
+          'norm ratio %.4f' % (regime, H, W, c_oracle, cos(sub(g1, enc), sub(go, enc)), cos(sub(g1, dec), sub(go, dec)), c_rerun, nr))
+    groups = {}
+    for k in keys:
+        groups.setdefault('.'.join(k.split('.')[:2]), []).append(k)
+    gn = lambda gs, ks: float(torch.sqrt(sum((gs[k] ** 2).sum() for k in ks)))
+    rows = {top: (gn(g1, ks) / gn(go, ks), gn(go, ks)) for top, ks in sorted(groups.items())}
+    return c_oracle, c_rerun, nr, rows
+
+
+@pytest.mark.parametrize('regime', ['formula_gains', 'damped_residual_gains'])
+def test_gradient_noise_on_a_conditioned_network(regime):
+    """Run-to-run and HIP-vs-oracle agreement of the WHOLE-network gradient on a network that is two optimizer steps into
+    training, at 256 x 320 (VERDICT round 4, weak #4).  The only run-to-run difference of the HIP path is the order of fp32
+    atomic partial sums (igemm_tt / wgrad_ws / SpectralNorm sums); how far that moves the gradient depends on how strongly the
+    backward map of the 60-layer train-mode-BatchNorm stack amplifies last-bit differences, so two regimes are bounded:
+      * formula_gains: the formula weights as they are -- every BatchNorm scale 0.6 +- 0.25, INCLUDING every BasicBlock's bn2
+        (the reference zero-initialises those, resnet_enc.py:96-98; SURVEY App. A asks for O(1) values in parity tests) -- a
+        random network whose residual branches carry as much signal as the identity paths: the ill-conditioned end;
+      * damped_residual_gains: bn2.weight x 0.15 (what zero-init-residual training leaves early on): the identity paths dominate
+        and the amplification argument no longer applies -- here the kernels themselves are what is measured.
+    Both start from two FusedAdam steps of the HIP path (running statistics, power-iteration vectors and weights moved off the
+    formula state); the resulting state_dict is loaded into the fp32 CPU oracle, and the third step's gradient is compared."""
+    c_oracle, c_rerun, nr, _rows = _conditioned_gradient(regime, 256, 320)
     if regime == 'damped_residual_gains':
         # measured (MI355X, round 5): bf16 0.9988 vs the oracle / 0.9993 run vs rerun, norm ratio 0.9997; fp16 0.9998 / 0.9999 / 0.9996
         # round 6 (fp16 island), bf16: 0.9993 / 0.9995, norm ratio 0.9986
@@ -363,6 +375,23 @@ def test_gradient_noise_on_a_conditioned_network(regime):
         # round 6 (fp16 island), bf16: 0.9415 vs the oracle, 0.9458 between two identical runs, norm ratio 0.992
         assert c_oracle >= tol(0.88, 0.93) and c_rerun >= tol(0.88, 0.96), (c_oracle, c_rerun)
         assert abs(nr - 1) <= tol(0.04, 0.03)
+
+
+
+def test_full_size_gradient_direction_on_a_conditioned_network():
+    """the kernels that ONLY run at the benchmark geometry (the ld % 256 fused-transpose branch of the attention
+    backward, the 112-problem accumulator-stationary weight-gradient launches, the heterogeneous geometry tables, 32-bit offset limits) were
+    pinned by gradient NORMS within +-25 % and a cosine >= 0.6 on the noise-amplifying formula network.  On the damped network (bn2 x 0.15,
+    two Adam steps in) the backward map does not amplify last-bit noise, so the same 3 x 1088 x 1920 window is held to the oracle tightly:
+    whole-network gradient cosine >= 0.99, every module group that carries gradient within 5 % in norm."""
+    c_oracle, c_rerun, nr, rows = _conditioned_gradient('damped_residual_gains', 1088, 1920)
+    print('\n'.join('%-30s norm ratio %.4f  oracle norm %.3e' % (k, v[0], v[1]) for k, v in rows.items()))
+    assert c_oracle >= tol(0.99, 0.995) and c_rerun >= tol(0.99, 0.995), (c_oracle, c_rerun)
+    assert abs(nr - 1) <= 0.02
+    top = max(v[1] for v in rows.values())
+    for k, (ratio, on) in rows.items():
+        if on >= 0.02 * top:
+            assert 0.95 <= ratio <= 1.05, 'gradient norm of %s: %.4f of the oracle' % (k, ratio)
 
 
 def test_freeze_backbone_keeps_the_feature_extractor_in_eval_mode():
