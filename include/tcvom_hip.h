@@ -115,6 +115,19 @@ int tcvom_wgrad_igemm_phases(const void* dy, const void* in, float* dw, const tc
  * (same descriptors; dy / in / dw are HOST arrays of nbatch device pointers) */
 int tcvom_wgrad_igemm_batched(const void* const* dy, const void* const* in, float* const* dw, int32_t nbatch,
                               const tcvom_conv_desc* descs, int32_t nphase, int32_t ldy, void* stream);
+/* Problems of DIFFERENT descriptors in ONE launch of the same kernel (the weight gradients of the 1 x 1, stride-2, transposed and
+ * small-channel convs of resnet_enc.py:76-111 / resnet_dec.py:33-72, which stay on the implicit-GEMM TT kernel: each a 20 - 100 us launch
+ * of a few dozen workgroups on its own).  All problems of a launch share the tile (tm, tn) that tcvom_wgrad_igemm_variant names for them.
+ *   tcvom_wgrad_igemm_hetero_plan: HOST planning, once per set of problems.  descs = the phase descriptors of all problems, concatenated
+ *     (nphase[i] of them for problem i: that concatenation is also the DEVICE descriptor table the launch reads); ldy[i] = pixel stride of
+ *     dy.  Writes 8 int32 per work item to `work` (HOST, capacity max_items items; NULL: count only) and returns the item count.
+ *   tcvom_wgrad_igemm_hetero: the launch.  dys / ins / dws: HOST arrays of nprob DEVICE pointers (they may change from step to step);
+ *     desc_table / work: DEVICE copies of `descs` / the planned work items (16-byte aligned, caller-owned).  dw accumulates (atomics). */
+int tcvom_wgrad_igemm_hetero_plan(const tcvom_conv_desc* descs, const int32_t* nphase, const int32_t* ldy, int32_t nprob,
+                                  int32_t tm, int32_t tn, int32_t* work, int32_t max_items);
+int tcvom_wgrad_igemm_hetero(const void* const* dys, const void* const* ins, float* const* dws, int32_t nprob,
+                             const tcvom_conv_desc* desc_table, const int32_t* work, int32_t nwork, int32_t tm, int32_t tn, void* stream);
+int32_t tcvom_wgrad_igemm_hetero_max_problems(void);
 /* Accumulator-stationary weight gradient (csrc/wgradws.hip) of `nprob` (1..tcvom_wgrad_ws_max_problems()) stride-1 3x3
  * convolutions of ONE geometry `d` (C a multiple of 64, K = 32 or a multiple of 64; K == ldy): the backward of the conv
  * layers of resnet_enc.py:33-49 / resnet_dec.py:43-59 for ALL layers and calls of that shape in a window -- with many

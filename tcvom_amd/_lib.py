@@ -228,12 +228,15 @@ _PROTOS = {
     'tcvom_dw3x3_wgrad': [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'tcvom_wgrad_ws_max_problems': [],
     'tcvom_wgrad_ws_hetero': [vp, vp, vp, i32, DP, i32, vp, vp],
+    'tcvom_wgrad_igemm_hetero_plan': [DP, vp, vp, i32, i32, i32, vp, i32],
+    'tcvom_wgrad_igemm_hetero': [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
+    'tcvom_wgrad_igemm_hetero_max_problems': [],
     'tcvom_wgrad_ws_max_geometries': [],
 }
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_bn_bwd_groups_n', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
           'tcvom_wgrad_ws_max_problems', 'tcvom_wgrad_ws_max_geometries', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks',
-          'tcvom_adaptive_avgpool_scratch_floats'}
+          'tcvom_adaptive_avgpool_scratch_floats', 'tcvom_wgrad_igemm_hetero_plan', 'tcvom_wgrad_igemm_hetero_max_problems'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}
@@ -389,6 +392,22 @@ def _profiled_tam(name, args):
     rc = _FNS[name](*args)
     e1.record()
     PROFILE.append((name, {'variant': name[6:], 'bytes': nbytes, 'P': 0, 'K': 0, 'C': 0, 'ntaps': 0, 'tap_w': [], 'batch': 1}, e0, e1))
+    return rc
+
+
+def call_with_info(name, info, *args):
+    """`call` for launches whose algorithmic work the generic readers of bench.py's event-instrumented step cannot derive from the
+    arguments (descriptor tables in device memory): `info` = {'variant', 'gflop', 'algo_bytes', ...} is recorded with the events."""
+    if PROFILE is None:
+        return call(name, *args)
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = _FNS[name](*args)
+    e1.record()
+    PROFILE.append((name, dict({'P': 0, 'K': 0, 'C': 0, 'ntaps': 1, 'tap_w': [0], 'batch': 1, 'phases': 1}, **info), e0, e1))
+    if rc != 0:
+        raise TcvomError('%s failed (%d): %s' % (name, rc, last_error()))
     return rc
 
 

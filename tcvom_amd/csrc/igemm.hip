@@ -646,23 +646,16 @@ struct TtBatch {
     int n;
 };
 
+// the body of one (problem, phase, pixel chunk, column tile, row tile) workgroup; `d` lies in the kernel-argument segment (uniform
+// launches) or in device memory (heterogeneous launches: a descriptor table)
 template <int TM, int TN, int WM, int WN, int KS>
-__global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kernel(
-    const TtBatch bt, const h16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk,
-    const int chunks_per_phase)
+__device__ __forceinline__ void igemm_tt_body(const h16raw* __restrict__ dy, const h16raw* __restrict__ in, float* __restrict__ dw,
+                                              const tcvom_conv_desc& d, const h16raw* __restrict__ zero_page, const int ldy,
+                                              const int chunk, const int pchunk, const int ntile, const int mtile)
 {
 #ifdef NT_TRACE
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
-    const int per_problem = chunks_per_phase * ps.n;
-    const int prob = blockIdx.x / per_problem;
-    const int rem = blockIdx.x - prob * per_problem;
-    const h16raw* __restrict__ dy = bt.dy[prob];
-    const h16raw* __restrict__ in = bt.in[prob];
-    float* __restrict__ dw = bt.dw[prob];
-    const int phase = rem / chunks_per_phase;
-    const tcvom_conv_desc& d = ps.d[phase];
-    const int chunk = rem - phase * chunks_per_phase;
     if (chunk * pchunk >= d.N * d.PH * d.PW) return;
     constexpr int WAVES_M = TM / WM, WAVES_N = TN / WN;
     constexpr int NW = WAVES_M * WAVES_N * KS;
@@ -697,8 +690,8 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
     const int Ptot = d.N * d.PH * d.PW;
     const int pbeg = chunk * pchunk;
     const int pend = min(Ptot, pbeg + pchunk);
-    const int n0 = blockIdx.y * TN;
-    const int m0 = blockIdx.z * TM;
+    const int n0 = ntile * TN;
+    const int m0 = mtile * TM;
     const int PW = d.PW, PH = d.PH;
     const bool small_p = Ptot + 64 * 4 < (1 << 24);     // rows past the chunk end are divided too
     const float rcp_pw = 1.0f / (float)PW, rcp_ph = 1.0f / (float)PH;
@@ -895,6 +888,43 @@ __global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kern
 #endif
 }
 
+template <int TM, int TN, int WM, int WN, int KS>
+__global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_kernel(
+    const TtBatch bt, const h16raw* __restrict__ zero_page, const TcvomPhases ps, const int ldy, const int pchunk,
+    const int chunks_per_phase)
+{
+    const int per_problem = chunks_per_phase * ps.n;
+    const int prob = blockIdx.x / per_problem;
+    const int rem = blockIdx.x - prob * per_problem;
+    const int phase = rem / chunks_per_phase;
+    igemm_tt_body<TM, TN, WM, WN, KS>(bt.dy[prob], bt.in[prob], bt.dw[prob], ps.d[phase], zero_page, ldy, rem - phase * chunks_per_phase,
+                                      pchunk, blockIdx.y, blockIdx.z);
+}
+
+// Problems of DIFFERENT descriptors in one launch (tcvom_wgrad_igemm_hetero): the weight gradients that stay on this kernel -- the
+// 1 x 1, stride-2, transposed and small-channel convs of the trunk -- are 20 - 100 us launches of a few dozen workgroups each, bound by
+// the latency of ONE workgroup (prologue, 3.4 us per 64-pixel step, atomic epilogue) while most of the chip idles: 21 launches per
+// 1080p step at 4 - 10 % of the MFMA peak.  Here a workgroup reads its (problem, descriptor, chunk, tile) from a work table in device
+// memory and its descriptor from a descriptor table next to it (both built once per network geometry by the caller, see
+// tcvom_wgrad_igemm_hetero_plan); the operand pointers of the problems travel in the kernel arguments.
+#define TT_HET_MAX 64
+struct TtHetBatch {
+    const h16raw* dy[TT_HET_MAX];
+    const h16raw* in[TT_HET_MAX];
+    float* dw[TT_HET_MAX];
+};
+template <int TM, int TN, int WM, int WN, int KS>
+__global__ __launch_bounds__((TM / WM) * (TN / WN) * KS * 64) void igemm_tt_hetero_kernel(
+    const TtHetBatch bt, const h16raw* __restrict__ zero_page, const tcvom_conv_desc* __restrict__ dtab, const int4* __restrict__ work)
+{
+    // work item: {problem | descriptor << 8, chunk, column tile | row tile << 16, ldy}, then {pchunk, -, -, -}
+    const int4 w0 = work[2 * blockIdx.x], w1 = work[2 * blockIdx.x + 1];
+    const int prob = __builtin_amdgcn_readfirstlane(w0.x & 0xff), di = __builtin_amdgcn_readfirstlane(w0.x >> 8);
+    igemm_tt_body<TM, TN, WM, WN, KS>(bt.dy[prob], bt.in[prob], bt.dw[prob], dtab[di], zero_page, __builtin_amdgcn_readfirstlane(w0.w),
+                                      __builtin_amdgcn_readfirstlane(w0.y), __builtin_amdgcn_readfirstlane(w1.x),
+                                      __builtin_amdgcn_readfirstlane(w0.z & 0xffff), __builtin_amdgcn_readfirstlane(w0.z >> 16));
+}
+
 // tile: wide-N tiles for the small-channel layers so that dy is re-read ncols/128 (not ncols/32) times
 static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
     const int ncols = d->ntaps * d->C;
@@ -1025,6 +1055,103 @@ static int wgrad_igemm_launch(const void* const* dys, const void* const* ins, fl
     TCVOM_LAUNCH_CHECK("wgrad_igemm");
     return TCVOM_OK;
 }
+
+// ---- heterogeneous launches (igemm_tt_hetero_kernel)
+static int tt_het_check(const tcvom_conv_desc* d, int nphase, int ldy, int tm, int tn) {
+    TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "wgrad_igemm_hetero: %d phases (1..4)", nphase);
+    for (int i = 0; i < nphase; ++i) {
+        const tcvom_conv_desc* e = d + i;
+        TCVOM_CHECK_ARG(e->ntaps >= 1 && e->ntaps <= TCVOM_MAX_TAPS, "wgrad_igemm_hetero: ntaps=%d", e->ntaps);
+        TCVOM_CHECK_ARG(e->C >= 8 && e->C % 8 == 0 && e->C <= 32768 && ldy % 8 == 0, "wgrad_igemm_hetero: C=%d ldy=%d must be multiples of 8", e->C, ldy);
+        TCVOM_CHECK_ARG(e->K == d->K && e->C == d->C && e->ntaps == d->ntaps, "wgrad_igemm_hetero: phases must share K, C and the tap count");
+        const long long Pi = (long long)e->N * e->PH * e->PW;
+        TCVOM_CHECK_ARG(Pi > 0 && Pi < (1ll << 31), "wgrad_igemm_hetero: bad pixel count %lld", Pi);
+        TCVOM_CHECK_ARG((long long)e->N * e->OH * e->OW * ldy < (1ll << 31) && (long long)e->N * e->H * e->W * e->C < (1ll << 31),
+                        "wgrad_igemm_hetero: operand too large for 32-bit element offsets");
+    }
+    int a, b;
+    tt_tile(d, &a, &b);
+    TCVOM_CHECK_ARG(a == tm && b == tn, "wgrad_igemm_hetero: a problem of the %d x %d tile in a %d x %d launch", a, b, tm, tn);
+    return TCVOM_OK;
+}
+
+extern "C" int tcvom_wgrad_igemm_hetero_plan(const tcvom_conv_desc* descs, const int32_t* nphase, const int32_t* ldy, int32_t nprob,
+                                             int32_t tm, int32_t tn, int32_t* work, int32_t max_items) {
+    TCVOM_CHECK_ARG(descs && nphase && ldy && nprob >= 1 && nprob <= TT_HET_MAX, "wgrad_igemm_hetero_plan: %d problems (1..%d)", nprob, TT_HET_MAX);
+    TCVOM_CHECK_ARG((tm == 128 && tn == 128) || (tm == 64 && (tn == 128 || tn == 64)) || (tm == 32 && (tn == 128 || tn == 32)),
+                    "wgrad_igemm_hetero_plan: no %d x %d tile", tm, tn);
+    // pixel chunks: the whole launch should fit in ONE round of co-resident workgroups (LDS-limited occupancy x 256 CUs), and every
+    // workgroup ends with tm * tn atomic adds: chunks of at least 512 pixels (the rule of the uniform launches, over all problems)
+    const int lds_bytes = 2 * 64 * (tm + tn) * 2 + 256;
+    int occ = (160 * 1024) / lds_bytes;
+    if (occ > 4) occ = 4;
+    double units = 0.0;                                  // sum over (problem, phase, tile) of its pixels
+    int di = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const tcvom_conv_desc* d = descs + di;
+        if (int e = tt_het_check(d, nphase[i], ldy[i], tm, tn)) return e;
+        const int tiles = cdiv(d->K, tm) * cdiv(d->ntaps * d->C, tn);
+        for (int ph = 0; ph < nphase[i]; ++ph) units += (double)d[ph].N * d[ph].PH * d[ph].PW * tiles;
+        di += nphase[i];
+    }
+    TCVOM_CHECK_ARG(di < (1 << 20), "wgrad_igemm_hetero_plan: too many descriptors");
+    long long chunk_px = ((long long)(units / (256.0 * occ)) + 63) / 64 * 64;
+    if (chunk_px < 512) chunk_px = 512;
+    int n = 0;
+    di = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const tcvom_conv_desc* d = descs + di;
+        const int mt = cdiv(d->K, tm), nt = cdiv(d->ntaps * d->C, tn);
+        TCVOM_CHECK_ARG(mt < (1 << 15) && nt < (1 << 16), "wgrad_igemm_hetero_plan: too many tiles");
+        for (int ph = 0; ph < nphase[i]; ++ph) {
+            const long long P = (long long)d[ph].N * d[ph].PH * d[ph].PW;
+            const int chunks = cdiv(P, chunk_px);
+            for (int c = 0; c < chunks; ++c)
+                for (int y = 0; y < nt; ++y)
+                    for (int z = 0; z < mt; ++z) {
+                        if (work) {
+                            TCVOM_CHECK_ARG(n < max_items, "wgrad_igemm_hetero_plan: more than %d work items", max_items);
+                            int32_t* w = work + (size_t)n * 8;
+                            w[0] = i | ((di + ph) << 8); w[1] = c; w[2] = y | (z << 16); w[3] = ldy[i];
+                            w[4] = (int32_t)chunk_px; w[5] = w[6] = w[7] = 0;
+                        }
+                        ++n;
+                    }
+        }
+        di += nphase[i];
+    }
+    return n;
+}
+
+extern "C" int tcvom_wgrad_igemm_hetero(const void* const* dys, const void* const* ins, float* const* dws, int32_t nprob,
+                                        const tcvom_conv_desc* desc_table, const int32_t* work, int32_t nwork, int32_t tm, int32_t tn,
+                                        void* stream) {
+    TCVOM_CHECK_ARG(dys && ins && dws && desc_table && work && nwork >= 1, "wgrad_igemm_hetero: null pointer / empty work list");
+    TCVOM_CHECK_ARG(nprob >= 1 && nprob <= TT_HET_MAX, "wgrad_igemm_hetero: %d problems (1..%d)", nprob, TT_HET_MAX);
+    TCVOM_CHECK_ARG((((uintptr_t)work) & 15) == 0, "wgrad_igemm_hetero: the work table must be 16-byte aligned");
+    TtHetBatch bt;
+    for (int i = 0; i < TT_HET_MAX; ++i) {
+        const int j = i < nprob ? i : 0;
+        TCVOM_CHECK_ARG(dys[j] && ins[j] && dws[j], "wgrad_igemm_hetero: null pointer in problem %d", j);
+        bt.dy[i] = (const h16raw*)dys[j];
+        bt.in[i] = (const h16raw*)ins[j];
+        bt.dw[i] = dws[j];
+    }
+    const h16raw* zp = zero_page_for_current_device();
+    TCVOM_CHECK_ARG(zp != nullptr, "wgrad_igemm_hetero: could not allocate the zero page");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(nwork);
+    const int4* wk = reinterpret_cast<const int4*>(work);
+    if (tm == 128 && tn == 128) hipLaunchKernelGGL((igemm_tt_hetero_kernel<128, 128, 64, 32, 1>), grid, dim3(512), 0, st, bt, zp, desc_table, wk);
+    else if (tm == 64 && tn == 128) hipLaunchKernelGGL((igemm_tt_hetero_kernel<64, 128, 32, 32, 1>), grid, dim3(512), 0, st, bt, zp, desc_table, wk);
+    else if (tm == 64 && tn == 64) hipLaunchKernelGGL((igemm_tt_hetero_kernel<64, 64, 32, 32, 1>), grid, dim3(256), 0, st, bt, zp, desc_table, wk);
+    else if (tm == 32 && tn == 128) hipLaunchKernelGGL((igemm_tt_hetero_kernel<32, 128, 32, 32, 1>), grid, dim3(256), 0, st, bt, zp, desc_table, wk);
+    else if (tm == 32 && tn == 32) hipLaunchKernelGGL((igemm_tt_hetero_kernel<32, 32, 32, 32, 4>), grid, dim3(256), 0, st, bt, zp, desc_table, wk);
+    else return tcvom_fail(TCVOM_ERR_ARG, "wgrad_igemm_hetero: no %d x %d tile", tm, tn);
+    TCVOM_LAUNCH_CHECK("wgrad_igemm_hetero");
+    return TCVOM_OK;
+}
+extern "C" int32_t tcvom_wgrad_igemm_hetero_max_problems(void) { return TT_HET_MAX; }
 
 extern "C" int tcvom_wgrad_igemm(const void* dy, const void* in, float* dw, const tcvom_conv_desc* d,
                                  int32_t ldy, void* stream) {

@@ -97,6 +97,22 @@ WGRAD_HETERO = os.environ.get('TCVOM_NO_WGRAD_HETERO') is None          # A/B sw
 
 
 WGRAD_GROUP_LAYERS = os.environ.get('TCVOM_NO_WGRAD_GROUP_LAYERS') is None        # A/B switch: one launch per layer
+# A/B switch: the weight gradients that stay on the implicit-GEMM TT kernel (1x1, stride-2, transposed, small-channel convs) as one launch
+# per layer geometry instead of one per TILE SHAPE (csrc/igemm.hip: igemm_tt_hetero_kernel)
+WGRAD_TT_HETERO = os.environ.get('TCVOM_NO_WGRAD_TT_HETERO') is None
+
+
+def _wgrad_tt_tile(geo):
+    """(tm, tn) of the implicit-GEMM TT kernel when the weight gradient of this geometry runs there, else None (cached on the object)."""
+    t = getattr(geo, '_tt_tile', False)
+    if t is False:
+        t = None
+        v = L._FNS['tcvom_wgrad_igemm_variant'](C.byref(geo.wgrad[0])).decode()
+        if v.startswith('igemm_tt<'):
+            a = v[len('igemm_tt<'):].split(',')
+            t = (int(a[0]), int(a[1]))
+        geo._tt_tile = t
+    return t
 
 
 
@@ -564,6 +580,49 @@ class WeightBank(object):
         for f in range(nf):
             self._deferred.append((spec, (call + f) if n > 1 else 0, dy, x, geo, st, f * dyb, f * xb, dyb + xb))
 
+    def _tt_hetero_cap(self):
+        c = getattr(self, '_tt_het_cap', None)
+        if c is None:
+            c = self._tt_het_cap = int(L.call('tcvom_wgrad_igemm_hetero_max_problems'))
+        return c
+
+    def _launch_tt_hetero(self, part, tm, tn, st):
+        """One igemm_tt launch for problems of different descriptors (tcvom_wgrad_igemm_hetero).  The descriptor table and the work list
+        depend on the geometries only: planned on the host once per set of problems and kept on the device (the operand pointers are
+        per step: they travel in the kernel arguments)."""
+        cache = self.__dict__.setdefault('_tt_het_tables', {})
+        key = (tm, tn, self.device) + tuple(id(e[4]) for e in part)
+        ent = cache.get(key)
+        n = len(part)
+        if ent is None:
+            descs = [d for e in part for d in e[4].wgrad]
+            arr = (L.ConvDesc * len(descs))(*descs)
+            nph = (C.c_int32 * n)(*[len(e[4].wgrad) for e in part])
+            ldys = (C.c_int32 * n)(*[e[0].K for e in part])
+            nwork = L.call('tcvom_wgrad_igemm_hetero_plan', arr, C.cast(nph, C.c_void_p), C.cast(ldys, C.c_void_p), n, tm, tn, None, 0)
+            if nwork <= 0:
+                raise RuntimeError('tcvom_wgrad_igemm_hetero_plan: %s' % L.last_error())
+            work = (C.c_int32 * (8 * nwork))()
+            got = L.call('tcvom_wgrad_igemm_hetero_plan', arr, C.cast(nph, C.c_void_p), C.cast(ldys, C.c_void_p), n, tm, tn,
+                         C.cast(work, C.c_void_p), nwork)
+            assert got == nwork
+            dtab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            wtab = torch.frombuffer(bytearray(bytes(work)), dtype=torch.int32).to(self.device)
+            ent = cache[key] = (dtab, wtab, nwork, [e[4] for e in part])        # (the geometries stay alive: their ids are the key)
+        dtab, wtab, nwork, _ = ent
+        dys = (C.c_void_p * n)(*[e[2].data_ptr() + e[6] for e in part])
+        xs = (C.c_void_p * n)(*[e[3].data_ptr() + e[7] for e in part])
+        dws = (C.c_void_p * n)(*[self.dw_ptr(e[0], e[1]).value for e in part])
+        info = None
+        if L.PROFILE is not None:                        # bench.py's event-instrumented step: the launch's algorithmic work
+            def taps(g):
+                return sum(len({(d.tap_dh[t], d.tap_dw[t]) for t in range(d.ntaps) if d.tap_w[t] >= 0}) for d in g.wgrad)
+            info = {'variant': 'igemm_tt<%d,%d>+%dprob' % (tm, tn, n),
+                    'gflop': sum(2.0 * e[4].wgrad[0].N * e[4].wgrad[0].PH * e[4].wgrad[0].PW * e[0].K * taps(e[4]) * e[4].wgrad[0].C for e in part) / 1e9,
+                    'algo_bytes': sum(e[8] + 4 * e[0].K * e[0].T * e[0].cpad for e in part)}
+        L.call_with_info('tcvom_wgrad_igemm_hetero', info or {}, C.cast(dys, C.c_void_p), C.cast(xs, C.c_void_p), C.cast(dws, C.c_void_p), n,
+                         L.ptr(dtab), L.ptr(wtab), nwork, tm, tn, st)
+
     def run_deferred_wgrads(self, layers=None):
         """Issue the queued weight-gradient launches; `layers` = (lo, hi): only those of layer ids lo <= id < hi (the
         chunked bank backward), the others stay queued."""
@@ -586,7 +645,7 @@ class WeightBank(object):
         # Layers of one geometry share launches of the accumulator-stationary kernel (csrc/wgradws.hip): with every call of every
         # such layer in one launch a block of dw is owned by one or two workgroups instead of ~40.  Other shapes: the calls of
         # a layer as one batched launch.
-        groups, multi = {}, {}
+        groups, multi, small_keys = {}, {}, set()
         for e in pend:
             geo = e[4]
             key = _wgrad_ws_key(geo)
@@ -600,9 +659,23 @@ class WeightBank(object):
                 # 32-channel convs of the GCA trunk, 20 - 100 us per layer, gain: GCA+TAM 24.25 -> 24.01 ms
                 # (e[8]: operand bytes of this problem, one frame's dy + x)
                 small = WGRAD_GROUP_LAYERS and (e[8] < (32 << 20) or geo.wgrad[0].ntaps > 1)
-                groups.setdefault(_wgrad_geo_key(geo, e[0].K) if small else (e[0].layer_id, id(geo)), []).append(e)
+                gkey = _wgrad_geo_key(geo, e[0].K) if small else (e[0].layer_id, id(geo))
+                groups.setdefault(gkey, []).append(e)
+                if small:
+                    small_keys.add(gkey)
         st = L.stream_ptr()
         cap = _wgrad_ws_cap()
+        if WGRAD_TT_HETERO and WGRAD_GROUP_LAYERS:
+            # the small problems of the implicit-GEMM TT kernel, whatever their descriptors: one launch per tile shape
+            tt = {}
+            for key in [k for k in groups if k in small_keys]:
+                tile = _wgrad_tt_tile(groups[key][0][4])
+                if tile is not None:
+                    tt.setdefault(tile, []).extend(groups.pop(key))
+            hcap = self._tt_hetero_cap()
+            for (tm, tn), items in tt.items():
+                for i in range(0, len(items), hcap):
+                    self._launch_tt_hetero(items[i:i + hcap], tm, tn, st)
         if WGRAD_HETERO:
             # ... and the geometries that share the kernel's channel window (C a multiple of 128, or not) share launches too: the
             # atomic flush costs a launch ~45 us however few problems it has (csrc/wgradws.hip: tcvom_wgrad_ws_hetero)
