@@ -385,7 +385,18 @@ static NtCfg nt_config(const tcvom_conv_desc* d, int nphase) {
         //  -- 384 tiles -> 1536 -- is neutral: 24.19 vs 24.20 ms)
         // (round 4, FBA's fifteen K = 256 os8 launches -- 384 tiles of 256 x 256, 1.5 rounds: as 1530 tiles of 128 x 128 the FBA+TAM step is
         //  53.3 -> 53.5 ms, same box: the better balance does not pay for twice the operand bytes per MAC)
-        if (d->K >= 256 && wgs >= 1024) return {256, 256, 4};
+        if (d->K >= 256 && wgs >= 1024) {
+            // 256 (channels) x 192 (pixels) tiles where the 256 x 256 grid ends in a half-empty round: FBA's K = 256 os8 layers at 1080p are
+            // 128 x 3 = 384 tiles of 256 x 256 -- two rounds on 256 CUs, the second half empty -- but 170 x 3 = 510 of 256 x 192: two rounds
+            // of 3/4 the work each (the 128 x 96 rule above, one tile size up; same operand bytes per MAC along the channel side)
+            static const bool no192 = getenv("TCVOM_NO_NT_T192") != nullptr;          // A/B switch
+            const long long t256 = (long long)cdiv(P, 256) * cdiv(d->K, 256) * nb, t192 = (long long)cdiv(P, 192) * cdiv(d->K, 256) * nb;
+            const double c256 = (double)((t256 + 255) / 256), c192 = 0.75 * (double)((t192 + 255) / 256);
+            // (3 x 3 / multi-tap layers only: a 1 x 1 conv that falls back from gemm_nt256 to this kernel -- a caller with a bias -- keeps the
+            //  256 x 256 tiling, whose statistics-group count equals gemm_nt256's, tcvom_conv_stats_groups)
+            if (!no192 && d->ntaps > 1 && c192 < 0.9 * c256) return {256, 192, 2};
+            return {256, 256, 4};
+        }
         // 128 (channels) x 96 (pixels) tiles, 4 waves of 32 x 96, where they spread evenly over the chip and the 128 x 128 ones do
         // not: the 256-channel os16 layers at 1080p are 64 x 2 x 3 = 384 workgroups of 128 x 128 (half the CUs run two, half one)
         // but 85 x 2 x 3 = 510 of 128 x 96 (two per CU on 255 CUs)
@@ -471,6 +482,7 @@ extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_
     if (const char* pv = pwconv_variant(d, nphase)) return pv;
     if (nphase == 1 && gemm_nt256_takes(d)) return "gemm_nt256";
     const NtCfg c = nt_config(d, nphase);
+    if (c.tm == 256 && c.tn == 192) return "igemm_nt<256,192,64,96,2>";
     if (c.tm == 256) return "igemm_nt<256,256,128,64,2>";
     if (c.tm == 128 && c.tn == 128) return "igemm_nt<128,128,64,32,2>";
     if (c.tm == 128 && c.tn == 96) return "igemm_nt<128,96,32,96,2>";
@@ -559,7 +571,8 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
         else NT_LAUNCH0(threads, __VA_ARGS__);                                                                           \
     } while (0)
     TCVOM_CHECK_ARG(!(xf && c.tm == 256), "conv_igemm: in_f16 is not built for the 256 x 256 tile (K >= 256 with >= 1024 tiles)");
-    if (c.tm == 256) NT_LAUNCH0(512, 256, 256, 128, 64, 2);
+    if (c.tm == 256 && c.tn == 192) NT_LAUNCH0(512, 256, 192, 64, 96, 2);
+    else if (c.tm == 256) NT_LAUNCH0(512, 256, 256, 128, 64, 2);
     else if (c.tm == 128 && c.tn == 128) NT_LAUNCH(512, 128, 128, 64, 32, 2);
     // (a 3- or 4-slot ring for this tile -- 84 / 112 KB of LDS, one workgroup per CU -- measured +0.45 ms per step: two co-resident
     //  workgroups hide the DMA latency better than one with a deeper ring)

@@ -238,6 +238,7 @@ def test_conv_bn_act_train(act, pre_relu, res):
     (32, 32, 3, 1, False, 272, 480),       # the os2/os1 class: 32x256 tiles
     (256, 256, 3, 1, False, 68, 120),      # the os16 class: 64x64 tiles, 4-slot ring
     (256, 256, 3, 1, False, 136, 180),     # 24480 pixels (= 3 os16 frames): 128x96 tiles, 510 workgroups instead of 384 of 128x128
+    (256, 256, 3, 1, False, 408, 240),     # 97920 pixels (= 3 os8 frames of FBA's 256-plane layers): 256x192 tiles, 510 workgroups instead of 383 of 256x256 (round 6)
     (512, 1024, 1, 1, False, 96, 130),     # 1 x 1 expand conv of the FBA trunk class: gemm_nt256 WITH the statistics epilogue (196 tiles, ragged tail)
     (64, 256, 1, 1, False, 200, 260),      # the os4 expand conv: one K-tile
 ])
@@ -254,6 +255,10 @@ def test_conv_bn_large_tile_configs(cin, cout, k, stride, transposed, H, W):
     x = hu('x.' + tag, (1, cin, H, W))
     xg = nhwc(x).requires_grad_(True)
     token = bank_token(bank, 1, True)
+    if (cin, H) == (256, 408):
+        import ctypes as C
+        from tcvom_amd import _lib as L
+        assert L._FNS['tcvom_conv_igemm_variant'](C.byref(cfg.geometry(1, H, W).fwd[0]), 1).decode() == 'igemm_nt<256,192,64,96,2>'
     z = ops.conv_bn_act(cfg, xg, token, True)
     bank.flush_bn_counters()
     wr = bf(spec.weight.detach().cpu())

@@ -62,6 +62,8 @@ NOT_CODE_PATHS = {
     'TCVOM_SYNCBN': 'SyncBatchNorm transport, mailbox / rccl: both parametrised in tests/test_gpu_syncbn.py',
     'TCVOM_CONV_TRACE': 'profiling aid (cycle stamps of one wsconv workgroup)',
     'TCVOM_NO_PPM_LINK': 'FBA only (pyramid pooling link): tests/test_gpu_fba.py',
+    'TCVOM_NO_NT_T192': 'FBA only (256 x 192 tiles of the K = 256 os8 3x3 layers at 1080p; the GCA window never selects them): the tile itself '
+                        'is covered by test_conv_bn_large_tile_configs, the switch is the same-box A/B of bench.py --config fba',
     'TCVOM_NO_F16_ISLAND': 'plain bf16 forward everywhere: the precision A/B of the fp16 island -- test_the_fp16_island_is_what_meets_the_bound below',
 }
 
