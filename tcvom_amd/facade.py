@@ -71,6 +71,13 @@ def x8_frame(prep, s):
     return t
 
 
+def unk8_frames(prep, S):
+    """The unknown mask at the TAM's stride (VMN_model.py:22: nearest, every 8th pixel) per frame, [B, h, w] uint8 each: ONE strided copy
+    into a frame-major buffer (the frames are consecutive slices of it: vmn._stack_frames hands the batched path a view)."""
+    u = prep.unk.transpose(0, 1)[:, :, ::TAM_OS, ::TAM_OS].contiguous()          # [S, B, h, w]
+    return [u[s] for s in range(S)]
+
+
 class _WindowLoss(torch.autograd.Function):
     """L_alpha (masked L1 on interior frames), L_dt (temporal, S >= 5) and L_att (attention BCE), plus the
     visualisation tensors `alphas` / `comps` — models/model.py:94-127,285-345."""
@@ -300,7 +307,7 @@ class FullModel_VMD(FullModel):
         if self.method == 'fba':
             return self._forward_fba(prep, B, S, H, W)
         frames = [x8_frame(prep, s) for s in range(S)]
-        prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
+        prep.unk8 = unk8_frames(prep, S)
         # (fp16 build: the gradients the loss kernels send back into the network are scaled here -- ops.LOSS_SCALE)
         preds, attb, attf = ops.enter_backward(self.NET.run(frames, prep.unk8), self.NET._bank)
         ni = S - 2
@@ -381,7 +388,7 @@ class EvalModel(FullModel):
             if self.method == 'fba':
                 return self._forward_fba_eval(prep, B, S, H, W)
             frames = [x8_frame(prep, s) for s in range(S)]
-            prep.unk8 = [prep.unk[:, s, ::TAM_OS, ::TAM_OS].contiguous() for s in range(S)]
+            prep.unk8 = unk8_frames(prep, S)
             preds, _attb, _attf = self.NET.run(frames, prep.unk8)
             alphas = torch.zeros((B, S, 1, H, W), dtype=torch.float32, device=imgs.device)
             for c in range(1, S - 1):

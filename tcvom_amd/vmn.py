@@ -184,7 +184,7 @@ class VMN(nn.Module):
         B = frames_x8[0].shape[0]
         bank = self._bank
         X = _stack_frames(frames_x8)
-        U = torch.cat(unk_u8, 0) if S > 1 else unk_u8[0]
+        U = _stack_frames_plain(unk_u8) if S > 1 else unk_u8[0]
         front_training = training if front_training is None else front_training
         try:
             bank.frames_per_op = S
