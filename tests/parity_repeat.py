@@ -3,7 +3,7 @@
 CPU oracle at the four tested sizes, `reps` HIP runs each (the oracle once per size).  The HIP forward is not bit-reproducible (fp32 atomics in
 the SpectralNorm sums / statistics): the MAX over the runs is what a bound has to hold.
 
-    python tools/parity_repeat.py [reps=8]
+    python tests/parity_repeat.py [reps=8]
 """
 import os
 import sys
