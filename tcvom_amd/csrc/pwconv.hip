@@ -315,10 +315,16 @@ static hipError_t pw_launch(const PwArgs& a, int grid, hipStream_t st) {
 // returns 1 when the conv was launched here, 0 when the caller should use another kernel, < 0 on error
 int pwconv_try_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale, const float* mdiag,
                       float* stats, const tcvom_conv_desc* d, int nphase, void* stream) {
-    if (mscale || mdiag) return 0;
     const PwPlan p = pw_plan(d, nphase);
     if (!p.ok) return 0;
-    if ((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) != 0) return 0;
+    // The plan took the shape, so tcvom_conv_stats_groups told the caller THIS kernel's statistics layout: a launch-time reason to decline
+    // (a column scale / diagonal term, an operand that is not 16-byte aligned) must not silently hand the launch to a kernel that writes
+    // another number of groups into the buffer sized for this one -- without statistics the fall-through is harmless.
+    const bool decline = mscale || mdiag || (((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) != 0;
+    if (decline && stats)
+        return tcvom_fail(TCVOM_ERR_ARG, "pwconv: statistics were sized for the pointwise kernel but the launch cannot use it (column scale / "
+                                         "diagonal term or an operand that is not 16-byte aligned)");
+    if (decline) return 0;
     PwArgs a;
     a.in = (const h16raw*)in;
     a.wgt = (const h16raw*)w;
