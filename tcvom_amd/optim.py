@@ -61,7 +61,10 @@ class FusedAdam(torch.optim.Optimizer):
         from .ops import SCALER
         guard, dev0 = None, None
         if SCALER.enabled:
-            dev0 = next((p.device for g in self.param_groups for p in g['params'] if p.grad is not None and p.is_cuda), None)
+            # (the device of the PARAMETERS, with or without a gradient on this rank in this step: whether the ranks meet in the
+            #  all-reduce below must not depend on which of them received gradients -- ADVICE round 5: a rank without any would skip
+            #  the collective the others block in)
+            dev0 = next((p.device for g in self.param_groups for p in g['params'] if p.is_cuda), None)
             if dev0 is not None:
                 if SCALER.before_step(dev0):
                     for st in self.state.values():
