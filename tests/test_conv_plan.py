@@ -73,3 +73,92 @@ def test_small_channel_inputs_are_padded_to_eight():
     # 9 taps x 8 channels = 72 elements = two 64-deep steps; the second ends in the zero-tap slots 9 .. 15
     assert spec.cpad == 8 and d.C == 8 and d.ntaps == 9 and list(d.tap_w)[9:16] == [-1] * 7
     assert not geo.dgrad
+
+
+# ------------------------------------------------------------------------------------------------ round 6: host-side planners (no GPU)
+def _geo(cin, cout, k, stride, transposed, N, H, W, f16=False):
+    shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    spec = ConvSpec('p', torch.zeros(shape), None, None, None, transposed, stride, 1 if k in (3, 4) else 0, 'frame', needs_dgrad=False)
+    spec.f16 = f16
+    return spec, ConvGeometry(spec, N, H, W)
+
+
+def test_hetero_wgrad_plan_covers_every_pixel_tile_and_phase_exactly_once():
+    """tcvom_wgrad_igemm_hetero_plan (csrc/igemm.hip, host code): for a launch of problems with different descriptors the work list must
+    hold, for every (problem, phase, column tile, row tile), pixel chunks that tile the phase's pixels without gap or overlap; the
+    descriptor index of an item is the problem's first descriptor + its phase; ldy and the chunk length ride along."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.weights import _wgrad_tt_tile
+    probs = [_geo(64, 128, 3, 2, False, 1, 272, 480), _geo(128, 128, 1, 1, False, 3, 136, 240), _geo(512, 512, 4, 2, True, 1, 34, 60),
+             _geo(256, 128, 1, 1, False, 1, 68, 120), _geo(128, 256, 3, 2, False, 2, 40, 36)]
+    assert {_wgrad_tt_tile(g) for _, g in probs} == {(128, 128)}
+    tm = tn = 128
+    descs = [d for _, g in probs for d in g.wgrad]
+    arr = (L.ConvDesc * len(descs))(*descs)
+    n = len(probs)
+    nph = (C.c_int32 * n)(*[len(g.wgrad) for _, g in probs])
+    ldy = (C.c_int32 * n)(*[s.K for s, _ in probs])
+    nwork = L.call('tcvom_wgrad_igemm_hetero_plan', arr, C.cast(nph, C.c_void_p), C.cast(ldy, C.c_void_p), n, tm, tn, None, 0)
+    assert nwork > 0
+    work = (C.c_int32 * (8 * nwork))()
+    assert L.call('tcvom_wgrad_igemm_hetero_plan', arr, C.cast(nph, C.c_void_p), C.cast(ldy, C.c_void_p), n, tm, tn, C.cast(work, C.c_void_p), nwork) == nwork
+    # a too small table is refused
+    assert L.call('tcvom_wgrad_igemm_hetero_plan', arr, C.cast(nph, C.c_void_p), C.cast(ldy, C.c_void_p), n, tm, tn, C.cast(work, C.c_void_p), nwork - 1) < 0
+    w = np.ctypeslib.as_array(work).reshape(nwork, 8)
+    first = np.cumsum([0] + [len(g.wgrad) for _, g in probs])
+    seen = {}
+    for prob_desc, chunk, tiles, ld, pchunk, *_ in w.tolist():
+        prob, di = prob_desc & 0xff, prob_desc >> 8
+        ph = di - first[prob]
+        spec, geo = probs[prob]
+        assert 0 <= ph < len(geo.wgrad) and ld == spec.K and pchunk % 64 == 0 and pchunk >= 512
+        d = geo.wgrad[ph]
+        nt, mt = -(-d.ntaps * d.C // tn), -(-d.K // tm)
+        y, z = tiles & 0xffff, tiles >> 16
+        assert y < nt and z < mt
+        seen.setdefault((prob, ph, y, z), []).append((chunk, pchunk))
+    for prob, (spec, geo) in enumerate(probs):
+        for ph, d in enumerate(geo.wgrad):
+            P = d.N * d.PH * d.PW
+            for y in range(-(-d.ntaps * d.C // tn)):
+                for z in range(-(-d.K // tm)):
+                    items = sorted(seen.pop((prob, ph, y, z)))
+                    pc = items[0][1]
+                    assert [c for c, _ in items] == list(range(len(items))) and all(p == pc for _, p in items)
+                    assert (len(items) - 1) * pc < P <= len(items) * pc, 'chunks must tile the %d pixels of problem %d phase %d' % (P, prob, ph)
+    assert not seen
+    # problems of another tile shape in the same launch are refused
+    mixed = probs + [_geo(6, 32, 3, 2, False, 1, 64, 64)]
+    descs = [d for _, g in mixed for d in g.wgrad]
+    arr = (L.ConvDesc * len(descs))(*descs)
+    nph = (C.c_int32 * (n + 1))(*[len(g.wgrad) for _, g in mixed])
+    ldy = (C.c_int32 * (n + 1))(*[s.K for s, _ in mixed])
+    assert L.call('tcvom_wgrad_igemm_hetero_plan', arr, C.cast(nph, C.c_void_p), C.cast(ldy, C.c_void_p), n + 1, tm, tn, None, 0) < 0
+
+
+@pytest.mark.parametrize('H,W', [(64, 64), (64, 96), (128, 160), (256, 320), (512, 512), (544, 960), (1088, 1920)])
+def test_fp16_island_descriptors_select_kernels_that_serve_them(H, W):
+    """The forward descriptors of the fp16 island (in_f16 = 1, out_fp32 = 2; gca_net.ISLAND_LAYERS) at every tested window size, 1 and 3
+    frames per launch: the planner names one of the three kernels with an IEEE fp16 operand mode (halo_conv, wsconv, igemm_nt below the
+    256-row tile) -- never pwconv / sconv / gemm_nt256 -- and the weight-gradient descriptors of the same layers carry no such flag."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    layers = [(6, 32, 3, 2, 1), (32, 32, 3, 1, 2), (32, 64, 3, 2, 2), (64, 64, 3, 1, 4), (64, 128, 3, 2, 4), (128, 128, 3, 1, 8), (64, 128, 1, 1, 8)]
+    for cin, cout, k, stride, ds in layers:
+        spec, geo = _geo(cin, cout, k, stride, False, 1, H // ds, W // ds, f16=True)
+        assert all(d.in_f16 == 1 and d.out_fp32 == 2 for d in geo.fwd) and all(d.in_f16 == 0 and d.out_fp32 == 0 for d in geo.wgrad)
+        for nf in (1, 3):
+            arr = (L.ConvDesc * 1)(*geo.fwd)
+            d = arr[0]
+            d.batch = nf
+            if nf > 1:
+                d.in_bstride, d.out_bstride, d.w_bstride, d.vec_bstride = d.N * d.H * d.W * d.C, d.N * d.OH * d.OW * d.ldo, d.K * d.wt * d.C, 0
+            var = L._FNS['tcvom_conv_igemm_variant'](C.byref(d), 1).decode()
+            assert var.startswith(('halo_conv', 'wsconv', 'igemm_nt<')) and not var.startswith('igemm_nt<256'), (cin, cout, k, stride, H, W, nf, var)
+            assert L.call('tcvom_conv_stats_groups', C.byref(d), 1) > 0
+            # the same layer without the flags may go elsewhere (the 1 x 1 downsample conv: pwconv at the large sizes) -- with them it may not
+            d.in_f16, d.out_fp32 = 0, 0
+            plain = L._FNS['tcvom_conv_igemm_variant'](C.byref(d), 1).decode()
+            if plain.startswith(('pwconv', 'sconv', 'gemm_nt256')):
+                assert not var.startswith(plain.split('<')[0])
