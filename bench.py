@@ -235,6 +235,8 @@ def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
         if v.is_floating_point() and not any(t in k for t in ('weight_u', 'weight_v', 'running_')):
             v.requires_grad_(True)
 
+    keep = {}
+
     def one(H, W):
         a, fg, bg = synthetic_window(1, 3, H, W, seed=0)
         t0 = time.time()
@@ -242,11 +244,15 @@ def cpu_baseline(sample_hw=(FULL_H, FULL_W), threads=32, reps=3):
         oracle.train_step_loss(out).backward()
         for v in state.values():
             v.grad = None
-        return time.time() - t0
+        dt = time.time() - t0
+        if (H, W) == tuple(sample_hw) and 'alpha' not in keep:      # the checker's matte of this window, for the `parity` object (after the clock)
+            keep['alpha'], keep['tris_vis'] = out[7].detach().clone(), out[6].detach().clone()
+        return dt
 
     one(256, 448)                                            # warm-up, not timed
     H, W = sample_hw
     times = sorted(one(H, W) for _ in range(reps))
+    cpu_baseline.oracle_outputs = keep
     dt = statistics.median(times)
     ratio = window_gflop(H, W) / window_gflop(FULL_H, FULL_W)
     return {'value': round(ratio / dt, 6), 'unit': 'windows/s', 'cores': cores, 'host_logical_cores': host_cores, 'kind': 'port',
@@ -577,6 +583,24 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.config != 'index':                      # (no CPU line for the extra IndexNet configuration)
                 result['cpu_baseline'] = cpu_baseline((H, W)) if args.config == 'gca' else cpu_baseline_fba()
+            keep = getattr(cpu_baseline, 'oracle_outputs', None)
+            if args.config == 'gca' and keep and 'alpha' in keep:
+                # BASELINE.json's metric carries "alpha MSE vs ref": the oracle pass that was just timed is also the CHECKER of this window --
+                # a fresh formula-initialised network (the timed one has taken K optimizer steps), same window, train-mode forward, against
+                # the oracle's matte; MSE over the unknown region as calc_metric.py:25 defines it, dtSSD-style delta as tests/test_gpu_window.py
+                model_p, a_p, fg_p, bg_p = build(device, H, W, seed=0, config='gca')
+                with torch.no_grad():
+                    out_p = model_p(a_p, fg_p, bg_p)
+                al, rl = out_p[7].float().cpu(), keep['alpha']
+                um = keep['tris_vis'].isclose(torch.tensor(128.0 / 255.0))
+                dd = al - rl
+                d_a, d_r = al[:, 1] - al[:, 1].roll(1, -1), rl[:, 1] - rl[:, 1].roll(1, -1)
+                result['parity'] = {'checker': 'oracle (pinned by outputs of the reference, tests/golden), the same pass the cpu_baseline timed',
+                                    'window': '3x%dx%d, formula weights, train-mode forward' % (H, W),
+                                    'alpha_mse_unknown': float((dd[um] ** 2).mean()), 'alpha_mse': float((dd ** 2).mean()),
+                                    'dtssd_style_delta': float(torch.sqrt(((d_a - d_r)[um[:, 1]] ** 2).mean())),
+                                    'max_abs_diff': float(dd.abs().max()), 'unknown_pixels': int(um.sum()), 'bound_alpha_mse': 1e-4}
+                del model_p, out_p
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
