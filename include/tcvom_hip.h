@@ -88,16 +88,6 @@ int tcvom_conv_igemm(const void* in, const void* w, void* out, const float* bias
  * descs[i].stats_group_offset must be i * tcvom_conv_stats_groups(descs, nphase). */
 int tcvom_conv_igemm_phases(const void* in, const void* w, void* out, const float* bias, float* stats_partial,
                             const tcvom_conv_desc* descs, int32_t nphase, void* stream);
-/* A DATA-GRADIENT launch whose epilogue also forms the BatchNorm-backward partial sums of the conv + BatchNorm site its output dz flows
- * into (the site that produced this conv's input: bn1 of a BasicBlock, resnet_enc.py:33-49 / resnet_dec.py:43-59; GroupNorm of an FBA
- * Bottleneck, resnet_GN_WS.py:50-137) -- sum(g) and sum(g * xhat), g = dz * act'(y * scale + shift), in tcvom_bn_bwd_reduce's
- * [frames][groups][2][K] layout -- so that the site's backward skips its reduce pass over dz and y.  y / scale_shift / saved / slot_stride /
- * act: that site's conv output, coefficient vectors and activation (as tcvom_bn_bwd_reduce takes them).  Returns 0 = launched, 1 = not a
- * case for this form (the shape runs on another kernel, or the layouts differ): the caller then launches tcvom_conv_igemm_phases and
- * tcvom_bn_bwd_reduce as before. */
-int tcvom_conv_igemm_phases_bstat(const void* in, const void* w, void* out, const tcvom_conv_desc* descs, int32_t nphase,
-                                  const void* y, const float* scale_shift, const float* saved, int64_t slot_stride,
-                                  int32_t act, float* partial, void* stream);
 /* Two dense products against ONE weight operand (out1 = in1 x w^T, out2 = in2 x w^T, both described by `desc`: ntaps = 1;
  * in2's batch stride is in2_bstride instead of desc->in_bstride) in one launch where the 256-tile GEMM takes the shape, else as two launches.  Replaces the two `torch.matmul`s autograd
  * runs for d(query) and d(key) of models/GCA/ops.py:177's F.conv2d (same correlation weights, two gradient operands). */

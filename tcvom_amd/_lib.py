@@ -91,7 +91,6 @@ _PROTOS = {
     'tcvom_conv_igemm': [vp, vp, vp, vp, vp, vp, vp, DP, vp],
     'tcvom_conv_stats_groups': [DP, i32],
     'tcvom_conv_igemm_phases': [vp, vp, vp, vp, vp, DP, i32, vp],
-    'tcvom_conv_igemm_phases_bstat': [vp, vp, vp, DP, i32, vp, vp, vp, i64, i32, vp, vp],
     'tcvom_gemm_pair': [vp, vp, vp, vp, vp, DP, i64, vp],
     'tcvom_wgrad_igemm_phases': [vp, vp, vp, DP, i32, i32, vp],
     'tcvom_wgrad_igemm': [vp, vp, vp, DP, i32, vp],
@@ -237,7 +236,7 @@ _PROTOS = {
 # entry points that return a count, not a status
 _PLAIN = {'tcvom_conv_stats_groups', 'tcvom_bn_bwd_groups', 'tcvom_bn_bwd_groups_n', 'tcvom_abi_version', 'tcvom_act_dtype', 'tcvom_bn_finalize_scratch_doubles',
           'tcvom_wgrad_ws_max_problems', 'tcvom_wgrad_ws_max_geometries', 'tcvom_dw3x3_stats_groups', 'tcvom_gca_scores_softmax_ok', 'tcvom_sn_apply_blocks',
-          'tcvom_adaptive_avgpool_scratch_floats', 'tcvom_wgrad_igemm_hetero_plan', 'tcvom_wgrad_igemm_hetero_max_problems', 'tcvom_conv_igemm_phases_bstat'}
+          'tcvom_adaptive_avgpool_scratch_floats', 'tcvom_wgrad_igemm_hetero_plan', 'tcvom_wgrad_igemm_hetero_max_problems'}
 
 # entry points that return a string
 _STRING = {'tcvom_conv_igemm_variant': [DP, i32], 'tcvom_wgrad_igemm_variant': [DP]}

@@ -16,23 +16,11 @@
 // accumulator registers are 4 consecutive channels of ONE pixel -> 8-byte NHWC stores, and the
 // BatchNorm statistics of a channel are a reduction across lanes.
 #include <cstdlib>
-#include <cstring>
 #include <type_traits>
 #include "common.h"
 #include <mutex>
 
 struct TcvomPhases { tcvom_conv_desc d[4]; int n; };
-// BatchNorm-backward statistics in the epilogue of a DATA-GRADIENT launch (tcvom_conv_igemm_phases_bstat): the launch's output is the
-// incoming gradient dz of the conv + BatchNorm site that produced this conv's input.  With that site's conv output y, its (scale, shift)
-// and (mean, invstd) vectors and its activation, the epilogue forms the two sums tcvom_bn_bwd_reduce would form in a pass of its own over
-// dz and y -- sum(g) and sum(g * xhat), g = dz * act'(y * scale + shift) -- per statistics group, in bn_bwd_reduce's [group][2][K] layout.
-struct NtBstat {
-    const h16raw* y;             // NULL: a plain launch
-    const float* ss;             // [frames][slot_stride]: scale[K], shift[K]
-    const float* saved;          // [frames][slot_stride]: mean[K], invstd[K]
-    long long slot_stride;
-    float slope;                 // act'(x) for x <= 0 (ReLU 0, LeakyReLU 0.2 / 0.01, none 1)
-};
 
 
 // igemm_nt main loop: 64-deep k-steps, operands DMA'd global->LDS with global_load_lds_dwordx4
@@ -80,7 +68,7 @@ template <int TM, int TN, int WM, int WN, int NST, int XF = 0>
 __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const h16raw* __restrict__ in, const h16raw* __restrict__ wgt, void* __restrict__ outp,
     const float* __restrict__ bias, const float* __restrict__ mscale, const float* __restrict__ mdiag,
-    float* __restrict__ stats, const h16raw* __restrict__ zero_page, const TcvomPhases ps, const NtBstat bs)
+    float* __restrict__ stats, const h16raw* __restrict__ zero_page, const TcvomPhases ps)
 {
     // up to 4 phases (sub-pixel phases of a transposed conv / stride-2 data gradient) share ONE launch: blockIdx.z
     // selects the phase, so their small grids fill the chip together
@@ -298,9 +286,8 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
     const float slope = d.act == 1 ? 0.f : d.act == 3 ? 0.01f : 1.f;
     const bool vec_ok = (((uintptr_t)bias | (uintptr_t)mscale | (uintptr_t)mdiag) & 15) == 0;     // 16-byte loads of the row vectors
     const int64_t sgrp = do_stats ? d.stats_group_offset + bz * d.stats_bstride + (int64_t)bx * WAVES_N + wn : 0;
-    const NtBstat& bst = bs;
-    auto emit = [&](auto diag_, auto f32_, auto bst_) {
-        constexpr bool DIAG = decltype(diag_)::value, F32 = decltype(f32_)::value, BST = decltype(bst_)::value;
+    auto emit = [&](auto diag_, auto f32_) {
+        constexpr bool DIAG = decltype(diag_)::value, F32 = decltype(f32_)::value;
 #pragma unroll
         for (int a = 0; a < MI; ++a) {
 #pragma unroll
@@ -320,28 +307,9 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                 }
                 const float bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, dg[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
                 float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                // BST: the consumer site's coefficients of this lane's 4 channels (frame bz of a batched launch)
-                float4 ysc = make_float4(0.f, 0.f, 0.f, 0.f), ysh = ysc, ymu = ysc, yis = ysc;
-                if constexpr (BST) {
-                    if (mrow < K) {
-                        const float* cs = bst.ss + (int64_t)bz * bst.slot_stride + mrow;
-                        const float* cm = bst.saved + (int64_t)bz * bst.slot_stride + mrow;
-                        ysc = *reinterpret_cast<const float4*>(cs); ysh = *reinterpret_cast<const float4*>(cs + K);
-                        ymu = *reinterpret_cast<const float4*>(cm); yis = *reinterpret_cast<const float4*>(cm + K);
-                    }
-                }
-                const float ysc_[4] = {ysc.x, ysc.y, ysc.z, ysc.w}, ysh_[4] = {ysh.x, ysh.y, ysh.z, ysh.w},
-                            ymu_[4] = {ymu.x, ymu.y, ymu.z, ymu.w}, yis_[4] = {yis.x, yis.y, yis.z, yis.w};
 #pragma unroll
                 for (int b = 0; b < NI; ++b) {
                     float v[4];
-                    float yv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (BST) {
-                        if (pvalid[b] && mrow < K) {
-                            const uint2 yq = *reinterpret_cast<const uint2*>(bst.y + out_off[b] + mrow);
-                            yv[0] = hlo(yq.x); yv[1] = hhi(yq.x); yv[2] = hlo(yq.y); yv[3] = hhi(yq.y);
-                        }
-                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float x = acc[a][b][g * 4 + r] * sc[r] + bs[r];
@@ -349,15 +317,8 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
                         x = fmaxf(x, x * slope);
                         v[r] = x;
                         const float xs = pvalid[b] ? x : 0.f;
-                        if constexpr (BST) {
-                            const float pre = yv[r] * ysc_[r] + ysh_[r];
-                            const float gg = xs * (pre > 0.f ? 1.f : bst.slope);
-                            t8[r] += gg;
-                            t8[4 + r] = fmaf(gg, (yv[r] - ymu_[r]) * yis_[r], t8[4 + r]);
-                        } else {
-                            t8[r] += xs;
-                            t8[4 + r] = fmaf(xs, xs, t8[4 + r]);
-                        }
+                        t8[r] += xs;
+                        t8[4 + r] = fmaf(xs, xs, t8[4 + r]);
                     }
                     if (pvalid[b] && mrow < K) {
                         if (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + out_off[b] + mrow) = make_float4(v[0], v[1], v[2], v[3]);
@@ -371,13 +332,11 @@ __global__ __launch_bounds__(((TM / WM) * (TN / WN)) * 64) void igemm_nt_kernel(
         }
     };
     if constexpr (XF) {                  // (the host admits out_fp32 == 2 only: fp16 results, no diagonal term)
-        emit(std::false_type{}, std::false_type{}, std::false_type{});
-    } else if (bs.y) {                   // (the host admits 16-bit results without a diagonal term)
-        emit(std::false_type{}, std::false_type{}, std::true_type{});
+        emit(std::false_type{}, std::false_type{});
     } else if (mdiag) {
-        if (d.out_fp32) emit(std::true_type{}, std::true_type{}, std::false_type{}); else emit(std::true_type{}, std::false_type{}, std::false_type{});
+        if (d.out_fp32) emit(std::true_type{}, std::true_type{}); else emit(std::true_type{}, std::false_type{});
     } else {
-        if (d.out_fp32) emit(std::false_type{}, std::true_type{}, std::false_type{}); else emit(std::false_type{}, std::false_type{}, std::false_type{});
+        if (d.out_fp32) emit(std::false_type{}, std::true_type{}); else emit(std::false_type{}, std::false_type{});
     }
 #ifdef NT_TRACE
     if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW - 1)) {
@@ -535,7 +494,7 @@ extern "C" const char* tcvom_conv_igemm_variant(const tcvom_conv_desc* d, int32_
 
 static int conv_igemm_launch(const void* in, const void* w, void* out, const float* bias, const float* mscale,
                              const float* mdiag, float* stats_partial, const tcvom_conv_desc* descs, int nphase,
-                             void* stream, const NtBstat* bstat = nullptr) {
+                             void* stream) {
     TCVOM_CHECK_ARG(in && w && out && descs, "conv_igemm: null pointer");
     TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "conv_igemm: %d phases (1..4)", nphase);
     TcvomPhases ps;
@@ -579,35 +538,33 @@ static int conv_igemm_launch(const void* in, const void* w, void* out, const flo
     }
     TCVOM_CHECK_ARG(xf || d0->out_fp32 != 2, "conv_igemm: out_fp32 = 2 (IEEE fp16 results) comes with in_f16 = 1 in the bf16 build only (the fp16 island)");
     for (int i = 0; i < nphase; ++i) TCVOM_CHECK_ARG(xf || descs[i].out_fp32 == 0 || descs[i].out_fp32 == 1, "conv_igemm: out_fp32 = %d", descs[i].out_fp32);
-    // (bstat: tcvom_conv_igemm_phases_bstat asked tcvom_conv_igemm_variant first -- the launch is this file's implicit GEMM)
-    if (!bstat) {
+    {
         const int r = halo_conv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
-    if (!bstat) {
+    {
         const int r = sconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
-    if (!bstat) {
+    {
         const int r = wsconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, zp, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
-    if (!bstat) {
+    {
         const int r = pwconv_try_launch(in, w, out, bias, mscale, mdiag, stats_partial, d0, nphase, stream);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     TCVOM_CHECK_ARG(d0->w_layout == 0, "conv_igemm: fragment-major weights (w_layout = 1) are only served by the weight-stationary kernel");
     TCVOM_CHECK_ARG(!(stats_partial && (mscale || mdiag) && nphase == 1 && gemm_nt256_takes_stats(d0)),
                     "conv_igemm: statistics together with a column scale / diagonal term are not built for this shape");
-    if (!bstat && nphase == 1 && (!stats_partial || gemm_nt256_takes_stats(d0))) {
+    if (nphase == 1 && (!stats_partial || gemm_nt256_takes_stats(d0))) {
         const int r = gemm_nt256_try_launch(in, w, out, bias, mscale, mdiag, d0, zp, stream, nullptr, nullptr, 0, stats_partial);
         if (r != 0) return r < 0 ? r : TCVOM_OK;
     }
     dim3 grid(cdiv(Pmax, c.tn), cdiv(d0->K, c.tm), nb);
-    const NtBstat nbs = bstat ? *bstat : NtBstat{nullptr, nullptr, nullptr, 0, 1.f};
 #define NT_LAUNCH0(threads, ...)                                                                                         \
     hipLaunchKernelGGL((igemm_nt_kernel<__VA_ARGS__>), grid, dim3(threads), 0, st, ip, wp, out, bias, mscale, mdiag,     \
-                       stats_partial, zp, ps, nbs)
+                       stats_partial, zp, ps)
 #define NT_LAUNCH(threads, ...)                                                                                          \
     do {                                                                                                                 \
         if (xf) NT_LAUNCH0(threads, __VA_ARGS__, 1);                                                                     \
@@ -666,30 +623,6 @@ extern "C" int tcvom_conv_igemm(const void* in, const void* w, void* out, const 
 extern "C" int tcvom_conv_igemm_phases(const void* in, const void* w, void* out, const float* bias, float* stats_partial,
                                        const tcvom_conv_desc* descs, int32_t nphase, void* stream) {
     return conv_igemm_launch(in, w, out, bias, nullptr, nullptr, stats_partial, descs, nphase, stream);
-}
-
-// A data-gradient launch that also writes the BatchNorm-backward partial sums of the site its output flows into (NtBstat above).
-// Returns 0 = launched, 1 = not a case for this form (another kernel serves the shape, or the output layout differs from y's: the caller
-// launches tcvom_conv_igemm_phases and runs tcvom_bn_bwd_reduce as before), < 0 = error.  partial: [frames][groups][2][K] fp32 with
-// groups = tcvom_conv_stats_groups(descs, nphase) per phase, written through the descriptors' stats_group_offset / stats_bstride.
-extern "C" int tcvom_conv_igemm_phases_bstat(const void* in, const void* w, void* out, const tcvom_conv_desc* descs, int32_t nphase,
-                                             const void* y, const float* scale_shift, const float* saved, int64_t slot_stride,
-                                             int32_t act, float* partial, void* stream) {
-    TCVOM_CHECK_ARG(in && w && out && descs && y && scale_shift && saved && partial, "conv_igemm_phases_bstat: null pointer");
-    TCVOM_CHECK_ARG(nphase >= 1 && nphase <= 4, "conv_igemm_phases_bstat: %d phases (1..4)", nphase);
-    if (strncmp(tcvom_conv_igemm_variant(descs, nphase), "igemm_nt<", 9) != 0) return 1;
-    if (act == 4) return 1;                                   // (ReLU6: two thresholds)
-    for (int i = 0; i < nphase; ++i) {
-        const tcvom_conv_desc* d = descs + i;
-        // the output pixel (n, oh, ow) must sit at the same element offset in `out` and in y: dense K-channel pixels, every pixel written
-        if (d->out_fp32 != 0 || d->in_f16 != 0 || d->ldo != d->K || d->K % 4 != 0) return 1;
-        if (d->batch > 1 && d->out_bstride != (long long)d->N * d->OH * d->OW * d->K) return 1;
-    }
-    if ((((uintptr_t)y) & 7) != 0 || (((uintptr_t)scale_shift | (uintptr_t)saved) & 15) != 0 || slot_stride % 4 != 0 || descs[0].K % 4 != 0) return 1;
-    NtBstat bs;
-    bs.y = (const h16raw*)y; bs.ss = scale_shift; bs.saved = saved; bs.slot_stride = slot_stride;
-    bs.slope = act == 1 ? 0.f : act == 2 ? 0.2f : act == 3 ? 0.01f : 1.f;
-    return conv_igemm_launch(in, w, out, nullptr, nullptr, nullptr, partial, descs, nphase, stream, &bs);
 }
 
 // =====================================================================================

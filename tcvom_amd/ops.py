@@ -130,10 +130,6 @@ class LossScaler(object):
 
 
 SCALER = LossScaler(LOSS_SCALE)
-# A/B switch: BatchNorm-backward statistics of a single-producer site in the epilogue of the data-gradient launch that produces its dz
-# (tcvom_conv_igemm_phases_bstat: the implicit-GEMM data gradients -- 256 / 512-channel trunk layers, FBA's dilated 3x3 convs)
-DGRAD_BSTAT = _os.environ.get('TCVOM_NO_DGRAD_BSTAT') is None
-BSTAT_USED = [0]                 # diagnostic: BatchNorm backwards that took their sums from a data-gradient epilogue
 RES_MASK = _os.environ.get('TCVOM_NO_RES_MASK') is None          # A/B switch: activation bitmask of the residual sites (tcvom_bn_apply_mask)
 SN_DOT = _os.environ.get('TCVOM_NO_SN_DOT') is None            # A/B switch: SpectralNorm's <dW~, weight_bar> from the BatchNorm backward
 
@@ -378,40 +374,6 @@ def _stats_groups(descs, nf=1):
     return cache[nf]
 
 
-def _launch_dgrad_bstat(descs, dy, wptr, dx, site, st, nf, w_stride):
-    """The data gradient of a conv whose input came from `site` (a conv + BatchNorm op with this conv as its only consumer), with the
-    site's BatchNorm-backward sums written by the launch's epilogue (tcvom_conv_igemm_phases_bstat).  True: launched, site['partial'] set;
-    False: not a case for that form (the caller launches the plain data gradient)."""
-    arr = _phase_array(descs)
-    n = len(descs)
-    ok = getattr(descs[0], '_bstat_ok', None)
-    if ok is None:                                  # (the kernel choice is a property of the geometry: asked once)
-        _set_frames(arr, n, nf, w_stride)
-        # (every phase must cover the same number of pixels: a phase with fewer tiles than the grid leaves its statistics groups unwritten)
-        ok = descs[0]._bstat_ok = (L._FNS['tcvom_conv_igemm_variant'](C.byref(arr[0]), n).startswith(b'igemm_nt<') and
-                                   len({(d.N, d.PH, d.PW) for d in descs}) == 1)
-    if not ok:
-        return False
-    gf = _stats_groups(descs, nf)
-    _set_frames(arr, n, nf, w_stride)
-    for i in range(n):
-        arr[i].act = ACT_NONE
-        arr[i].out_fp32 = 0
-        arr[i].stats_group_offset = i * (gf // n)
-        arr[i].stats_bstride = gf
-    K = site['K']
-    partial = torch.empty(nf * gf * 2 * K, dtype=torch.float32, device=dy.device)
-    rc = L.call('tcvom_conv_igemm_phases_bstat', L.ptr(dy), wptr, L.ptr(dx), arr, n, L.ptr(site['y']), site['ss'], site['saved'],
-                site['stride'], site['act'], L.ptr(partial), st)
-    if rc < 0:
-        raise L.TcvomError('tcvom_conv_igemm_phases_bstat failed (%d): %s' % (rc, L.last_error()))
-    if rc != 0:
-        descs[0]._bstat_ok = False
-        return False
-    site['partial'] = (partial, gf, dx.data_ptr())
-    return True
-
-
 def _launch_conv(descs, x, wptr, out, bias, stats, act, st, nf=1, w_stride=0):
     """All phases of a conv in ONE launch (stride-2 data gradients / ConvTranspose forwards have 4), for nf frames."""
     arr = _phase_array(descs)
@@ -441,8 +403,6 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.stash = stash
         ctx.res1_stash = getattr(res1, '_tcvom_grad_stash', None) if res1 is not None else None
         ctx.x_stash = getattr(x, '_tcvom_grad_stash', None)
-        ctx.x_site = getattr(x, '_tcvom_bn_site', None)           # x = act(norm(y')) of a site that may take its backward sums from our dgrad
-        ctx.site = None
         ctx.x_tail_rows = getattr(x, '_tcvom_tail_rows', None)      # x comes from a tail-only op: it takes row-range gradients
         ctx.x_pad_unread = getattr(x, '_tcvom_pad_unread', False)   # x is a concat buffer whose backward never reads the padding channels
         ctx.set_materialize_grads(False)             # every consumer may have deposited: then autograd hands over None
@@ -565,12 +525,6 @@ class _ConvBNAct(torch.autograd.Function):
         else:
             L.call('tcvom_bn_apply', L.ptr(y), ss, L.ptr(r1), L.ptr(r2), L.ptr(z), geo.out_pixels, K, cfg.act, _y_mode(y),
                    nf, slot_stride, st)
-        if (DGRAD_BSTAT and r1 is None and r2 is None and not island and ctx.active is None and cfg.act != ACT_RELU6 and y.dtype == H16
-                and any(ctx.needs_input_grad[:5])):
-            # a site whose backward may take its reduce-pass sums from the data-gradient launch of its (single) consumer: what that
-            # launch needs of this site, handed over on z by conv_bn_act (ops._ConvBNAct.backward of the consumer fills 'partial')
-            ctx.site = cfg._site = {'y': y, 'ss': ss, 'saved': saved, 'stride': slot_stride, 'act': cfg.act, 'K': K, 'nf': nf,
-                                    'shape': tuple(y.shape), 'window': bank.window_id}
         ctx.save_for_backward(x, y, gamma, r1)
         return z
 
@@ -643,16 +597,10 @@ class _ConvBNAct(torch.autograd.Function):
             if ctx.has_res1 and ctx.needs_input_grad[5]:
                 dres1 = torch.empty(y.shape, dtype=H16, device=dz.device)
         if cfg.bn is not None:
-            pre = ctx.site.pop('partial', None) if ctx.site is not None else None
-            if pre is not None and dz2 is None and pre[2] == dz.data_ptr() and not ctx.res_mask:
-                # the ONE producer of dz -- the data-gradient launch of the consumer conv -- already formed the sums over (dz, y)
-                partial, groups = pre[0], pre[1]
-                BSTAT_USED[0] += 1
-            else:
-                groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
-                partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
-                L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,
-                       saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, zf0, zf1, st)          # (r1 = the activation mask when res_mask)
+            groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
+            partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
+            L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,
+                   saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, zf0, zf1, st)          # (r1 = the activation mask when res_mask)
             # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
             dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
             coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
@@ -690,11 +638,7 @@ class _ConvBNAct(torch.autograd.Function):
             cx = spec.cpad if spec.cpad > 8 else spec.C
             alloc = torch.zeros if (cx != spec.C and not ctx.x_pad_unread) else torch.empty
             dx = alloc((geo.N * nf, geo.H, geo.W, cx), dtype=H16, device=dz.device)
-            site = ctx.x_site
-            if not (site is not None and ctx.x_stash is not None and L.PROFILE is None and site['window'] == bank.window_id
-                    and site['shape'] == tuple(dx.shape) and site['nf'] == nf
-                    and _launch_dgrad_bstat(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, site, st, nf, ctx.wsb)):
-                _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st, nf, ctx.wsb)
+            _launch_conv(geo.dgrad, dy, bank.bwd_ptr(spec, ctx.call), dx, None, None, ACT_NONE, st, nf, ctx.wsb)
         # the weight gradients are deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
         bank.defer_wgrad(spec, ctx.call, dy, x, geo, nf)
         # res2 is added after the activation: its gradient is the op's WHOLE incoming gradient, deposited part included
@@ -1085,9 +1029,6 @@ def conv_bn_act(cfg, x, token, training, res1=None, res2=None):
     z16 = cfg.__dict__.pop('_z16', None)
     if z16 is not None:
         set_f16_twin(z, z16)
-    site = cfg.__dict__.pop('_site', None)
-    if site is not None and stash is not None and z.requires_grad:
-        z._tcvom_bn_site = site
     if stash is not None and z.requires_grad:
         z._tcvom_grad_stash = stash
         tf, nf = getattr(cfg.bank, 'tail_frames', None), cfg.bank.frames_per_op

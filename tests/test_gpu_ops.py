@@ -346,53 +346,6 @@ def test_frame_batched_conv_bn_equals_frame_by_frame(cin, cout, k, stride, trans
     assert not torch.allclose(a[0][0], a[0][1])
 
 
-@pytest.mark.parametrize('cin,cmid,cout,k,stride,H,W,nf,act', [(256, 256, 256, 3, 1, 34, 60, 3, 1), (512, 512, 256, 3, 1, 17, 30, 3, 2),
-                                                              (128, 256, 256, 3, 1, 20, 28, 1, 1), (64, 256, 128, 3, 2, 32, 48, 3, 1),
-                                                              (64, 256, 512, 1, 1, 24, 40, 1, 3)])
-def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(cin, cmid, cout, k, stride, H, W, nf, act, monkeypatch):
-    """tcvom_conv_igemm_phases_bstat (round 6): a conv + BatchNorm + activation site whose ONLY consumer is a conv on the implicit GEMM
-    gets (sum g, sum g xhat) of its backward from the epilogue of that conv's data-gradient launch instead of a reduce pass over (dz, y):
-    frame-batched and single launches, ReLU / LeakyReLU(0.2 / 0.01), a stride-2 consumer (4-phase data gradient), a 1 x 1 consumer --
-    every gradient against the same graph with the switch off, and the diagnostic counter says the fused form really ran."""
-    from tcvom_amd import ops
-    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
-
-    def run(on):
-        monkeypatch.setattr(ops, 'DGRAD_BSTAT', on)
-        ops.BSTAT_USED[0] = 0
-        bank = WeightBank()
-        tag = 'bst%d_%d_%d_%d' % (cin, cmid, cout, k)
-        w0 = nn.Parameter((formula_tensor('%s.w0' % tag, (cmid, cin, 3, 3)) * 0.3).to(DEV))
-        w1 = nn.Parameter((formula_tensor('%s.w1' % tag, (cout, cmid, k, k)) * 0.3).to(DEV))
-        s0 = ConvSpec(tag + '.0', w0, None, None, None, False, 1, 1, 'frame')
-        s1 = ConvSpec(tag + '.1', w1, None, None, None, False, stride, (k - 1) // 2, 'frame')
-        bank.register(s0); bank.register(s1)
-        bn0, bn1 = nn.BatchNorm2d(cmid).to(DEV), nn.BatchNorm2d(cout).to(DEV)
-        with torch.no_grad():
-            bn0.weight.copy_(hu(tag + '.g0', (cmid,)) * 0.5 + 0.7); bn0.bias.copy_(hu(tag + '.b0', (cmid,)) * 0.4 - 0.2)
-            bn1.weight.copy_(hu(tag + '.g1', (cout,)) * 0.5 + 0.7); bn1.bias.copy_(hu(tag + '.b1', (cout,)) * 0.4 - 0.2)
-        c0 = ops.ConvCfg(bank, s0, bn=bn0, act=act)
-        c1 = ops.ConvCfg(bank, s1, bn=bn1, act=ops.ACT_RELU)
-        xg = nhwc(hu(tag + '.x', (nf, cin, H, W)) - 0.5).requires_grad_(True)
-        token = bank_token(bank, nf, True)
-        bank.frames_per_op = nf
-        z0 = ops.conv_bn_act(c0, xg, token, True)
-        z1 = ops.conv_bn_act(c1, z0, token, True)
-        bank.frames_per_op = 1
-        bank.flush_bn_counters()
-        gz = nhwc(hu(tag + '.gz', (nf, cout, z1.shape[1], z1.shape[2])) - 0.5)
-        (z1.float() * gz.float()).sum().backward()
-        torch.cuda.synchronize()
-        return ([t.float().cpu() for t in (xg.grad, w0.grad, w1.grad, bn0.weight.grad, bn0.bias.grad, bn1.weight.grad)], ops.BSTAT_USED[0])
-    a, used = run(True)
-    b, used_off = run(False)
-    assert used == 1 and used_off == 0, (used, used_off)
-    ck = Checker()
-    for nm, x, y in zip(('dx', 'dw0', 'dw1', 'dgamma0', 'dbeta0', 'dgamma1'), a, b):
-        ck.l2(nm, x, y, 4e-3)               # (the fused sums see the unrounded data gradient, the reduce pass its 16-bit copy)
-    ck.done()
-
-
 def test_row_range_gradient_is_added_inside_the_batchnorm_backward():
     """A frame-batched conv + BatchNorm op whose output is read by one consumer for all three frames and by another for the
     centre frame only (ops.frame_slice: the decoder tail's shortcut inputs, VMN_model.py:107-110): the centre-frame gradient is
