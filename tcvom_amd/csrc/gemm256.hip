@@ -421,6 +421,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         for (int b = 0; b < 2; ++b) dl[b] = pvalid[b] ? g.delta[(int64_t)bz * g.N + pglob[b]] : 0.f;
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
+        G_LIFE(3)
         // Transposed copy of the LDS tile ([n][m], 512-byte rows, chunk-swizzled) into dst[m][n] with the gfx950 transposing LDS
         // read: the 16 lanes of a group address a 4 (n) x 16 (m) block -- lane L the 4 contiguous m of row L >> 2 -- and lane L
         // receives column m = L, rows 0..3 (tools/probes/tr_probe2.hip); two reads give 8 consecutive n of one m = one 16-byte
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
         }
         __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
+        G_LIFE(4)
         h16raw* Tb = reinterpret_cast<h16raw*>(gout) + obase;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -487,6 +489,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const Gemm256Args g) {
             if (n0 + r < g.N && m0 + c * 8 < g.ldo) *reinterpret_cast<uint4*>(Tb + (int64_t)(n0 + r) * g.ldo + m0 + c * 8) = v;
         }
         if (g.Tt) store_transposed(g.Tt);              // T^T from the finished T tile
+        G_LIFE(5)
+#ifdef G256_LIFE
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        G_LIFE(6)
+#endif
         return;
     } else {
     // ---- plain epilogue (bias / scale / diagonal / activation)

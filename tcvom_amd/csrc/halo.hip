@@ -497,12 +497,14 @@ int halo_conv_try_launch(const void* in, const void* w, void* out, const float* 
 }
 
 // ------------------------------------------------------------------------------------------ weight gradient, halo form
-// dW[k][tap][c] += sum_p dy[p][k] * x[p + tap][c] for the same layers (32 -> 32 channels, taps within +-1): the implicit-GEMM
-// TT kernel streams x once per TAP and dy once per column tile through L2 -> LDS; here a persistent workgroup DMAs the x halo
-// and the dy tile of an 8x32 pixel tile ONCE (38 KB), forms all 9 tap products from LDS and keeps the 9 [32 x 32]
-// accumulators in registers over its whole tile run: HBM traffic = x + dy once.
-//   MFMA 32x32x16: A = dy^T [32 out-ch][16 pixels], B = x^T(tap) [32 in-ch][16 pixels]; the reduction runs over pixels, both
-//   operands are pixel-major in LDS and are read with ds_read_b64_tr_b16 (a 32-lane group reads 4 whole 64-byte pixels).
+// dW[k][tap][c] += sum_p dy[p][k] * x[S p + tap][c] for the same layers (<= 32 input channels, <= 32 output channels, 3 x 3 taps,
+// stride 1 or 2): the implicit-GEMM TT kernel streams x once per TAP and dy once per column tile through L2 -> LDS; here a
+// persistent workgroup DMAs the x halo and the dy tile of an 8x32 output-pixel tile ONCE, forms all 9 tap products from LDS and
+// keeps the accumulators in registers over its whole tile run: HBM traffic = x + dy once.
+//   MFMA 32x32x16: A = dy^T [32 out-ch][16 pixels], B = x^T [32 (tap, in-ch) columns][16 pixels] -- 32 / C taps per MFMA (C = 32:
+//   nine products per 16 pixels, C = 16: five, C = 8: three; the columns past tap 8 repeat tap 8 and are never stored); the
+//   reduction runs over pixels, both operands are pixel-major in LDS and are read with ds_read_b64_tr_b16 (a 16-lane group reads
+//   4 pixels x 16 columns; stride 2 = every second halo pixel).  K = 16: the upper 16 rows of A repeat the lower ones, never stored.
 //   The reads are inline asm (common.h: the builtin form makes the compiler drain the next tile's DMA first).
 //   Wave w owns tile rows 2w, 2w+1 (4 k-steps of 16 pixels per tile).  At the end the 4 waves' accumulators are summed
 //   through LDS and added to dw with fp32 atomics, once per workgroup.
@@ -511,23 +513,27 @@ struct HaloWgArgs {
     const h16raw* in[8];
     float* dw[8];
     const h16raw* zero_page;
-    int N, H, W, wt;
+    int N, H, W, OH, OW, wt, org;             // H, W: the input (with its padding ring when org = 1); OH, OW: the dy grid
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
-    int tap_dh[9], tap_dw[9], tap_w[9];
-    int ntaps;
+    int tap_dh[9], tap_dw[9], tap_w[9];       // offsets relative to S * (output pixel) + org: -1 .. 1
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_wgrad_kernel(const HaloWgArgs a) {
-    constexpr int C = 32, XU = HALO_PIX * 4, YU = HALO_TH * HALO_TW * 4;         // 16-byte units of the x halo / the dy tile
-    constexpr int XI = (XU + 63) / 64, YI = YU / 64;                              // DMA wave-instructions: 22 and 16
-    constexpr int SLOT = (XI + YI) * 512;                                         // bf16 elements per tile buffer
+template <int C, int S, int KO>
+__device__ __forceinline__ void halo_wgrad_body(const HaloWgArgs& a) {
+    constexpr int CU = C / 8, KU = KO / 8;                                        // 16-byte units per x / dy pixel
+    constexpr int IW = S * HALO_TW + 2, IH = S * HALO_TH + 2;                     // the x halo (as halo_conv_kernel's)
+    constexpr int XU = IW * IH * CU, YU = HALO_TH * HALO_TW * KU;                 // 16-byte units of the x halo / the dy tile
+    constexpr int XI = (XU + 63) / 64, YI = YU / 64;                              // DMA wave-instructions
+    constexpr int SLOT = (XI + YI) * 512;                                         // 16-bit elements per tile buffer
+    constexpr int TPM = 32 / C, NM = (9 + TPM - 1) / TPM, G0 = (NM + 1) / 2;      // taps per MFMA, MFMAs per 16 pixels, first read group
+    static_assert(2 * NM * 4 * 64 * 16 <= 2 * SLOT * 2, "reduction buffers must fit the tile buffers");
     __shared__ __attribute__((aligned(16))) h16raw lds[2 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int prob = blockIdx.y;
     const h16raw* __restrict__ dy = a.dy[prob];
     const h16raw* __restrict__ in = a.in[prob];
-    const int H = a.H, W = a.W;
+    const int H = a.H, W = a.W, OH = a.OH, OW = a.OW;
     const int t_begin = blockIdx.x * a.tiles_per_wg;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
     if (t_begin >= t_end) return;
@@ -541,56 +547,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int ii = wave; ii < XI + YI; ii += 4) {                                                         \
             const h16raw* src_;                                                                             \
             if (ii < XI) {                                                                                   \
-                const int q_ = ii * 64 + lane, p_ = q_ >> 2, hy_ = p_ / HALO_HW, hx_ = p_ - hy_ * HALO_HW;   \
-                const int y_ = y0_ + hy_ - 1, x_ = x0_ + hx_ - 1;                                            \
+                const int q_ = ii * 64 + lane, p_ = q_ / CU, hy_ = p_ / IW, hx_ = p_ - hy_ * IW;             \
+                const int y_ = y0_ * S + a.org + hy_ - 1, x_ = x0_ * S + a.org + hx_ - 1;                    \
                 const bool ok_ = q_ < XU && (unsigned)y_ < (unsigned)H && (unsigned)x_ < (unsigned)W;        \
-                src_ = ok_ ? in + ((int64_t)(n_ * H + y_) * W + x_) * C + (q_ & 3) * 8 : a.zero_page;        \
+                src_ = ok_ ? in + ((int64_t)(n_ * H + y_) * W + x_) * C + (q_ % CU) * 8 : a.zero_page;       \
             } else {                                                                                         \
-                const int q_ = (ii - XI) * 64 + lane, p_ = q_ >> 2;                                          \
-                src_ = dy + ((int64_t)(n_ * H + y0_ + p_ / HALO_TW) * W + x0_ + p_ % HALO_TW) * C + (q_ & 3) * 8; \
+                const int q_ = (ii - XI) * 64 + lane, p_ = q_ / KU;                                          \
+                src_ = dy + ((int64_t)(n_ * OH + y0_ + p_ / HALO_TW) * OW + x0_ + p_ % HALO_TW) * KO + (q_ % KU) * 8; \
             }                                                                                                \
             __builtin_amdgcn_global_load_lds((gptr_t)src_, (lptr_t)(lds + (slot) * SLOT + ii * 512), 16, 0, 0); \
         }                                                                                                    \
     }
 
-    f32x16_t acc[9];
+    f32x16_t acc[NM];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NM; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // transposing reads: lane -> pixel (lane >> 5) * 8 + ((lane & 15) >> 2) (+4 for the hi half: +256 bytes), channels
-    // ((lane >> 4) & 1) * 16 + (lane & 3) * 4 ..+3.  Byte addresses inside a tile buffer; the k-step moves them by immediates.
+    // transposing reads: lane -> pixel (lane >> 5) * 8 + ((lane & 15) >> 2) (+4 for the hi half), columns
+    // cq = ((lane >> 4) & 1) * 16 + (lane & 3) * 4 ..+3 of the 32: out-channel cq (mod KO) of dy; tap j TPM + cq / C, channel cq % C of x.
+    // Byte addresses inside a tile buffer; the k-step moves them by immediates.
     const int tr_p = (lane >> 5) * 8 + ((lane & 15) >> 2);
-    const int tr_c = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const int cq = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
-    const unsigned y_rel = XI * 1024 + ((2 * wave * HALO_TW + tr_p) * C + tr_c) * 2;
-    unsigned x_rel[9];
+    const unsigned y_rel = XI * 1024 + ((2 * wave * HALO_TW + tr_p) * KO + (cq % KO)) * 2;
+    unsigned x_rel[NM];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-        x_rel[t] = (((2 * wave + a.tap_dh[t] + 1) * HALO_HW + a.tap_dw[t] + 1 + tr_p) * C + tr_c) * 2;
-    constexpr int XROW = HALO_HW * C * 2, YROW = HALO_TW * C * 2, HALF = 16 * C * 2, HI = 4 * C * 2;
+    for (int j = 0; j < NM; ++j) {
+        const int tap = min(j * TPM + cq / C, 8);            // (columns past tap 8 repeat it)
+        int dh = 0, dw = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { dh = tap == t ? a.tap_dh[t] : dh; dw = tap == t ? a.tap_dw[t] : dw; }
+        x_rel[j] = (((2 * wave * S + dh + 1) * IW + tr_p * S + dw + 1) * C + (cq % C)) * 2;
+    }
+    constexpr int XROW = S * IW * C * 2, YROW = HALO_TW * KO * 2, XHALF = 16 * S * C * 2, YHALF = 16 * KO * 2, XHI = 4 * S * C * 2, YHI = 4 * KO * 2;
 
-    // k-step ks = tile row 2 wave + (ks >> 1), pixels (ks & 1) * 16 ..+15.  The 9 taps of a k-step are read in two groups
-    // (taps 0-4, taps 5-8) so that the reads of one group are in flight under the MFMAs of the other.
-    TrFrag fy[2], fx[9];
-#define HWG_READ_Y(ks, set) tr_issue_imm<((ks) >> 1) * YROW + ((ks) & 1) * HALF, HI>(fy[set], ya)
-#define HWG_READ_X(ks, t) tr_issue_imm<((ks) >> 1) * XROW + ((ks) & 1) * HALF, HI>(fx[t], xa[t])
+    // k-step ks = tile row 2 wave + (ks >> 1), pixels (ks & 1) * 16 ..+15.  The NM products of a k-step are read in two groups
+    // so that the reads of one group are in flight under the MFMAs of the other.
+    TrFrag fy[2], fx[NM];
+#define HWG_READ_Y(ks, set) tr_issue_imm<((ks) >> 1) * YROW + ((ks) & 1) * YHALF, YHI>(fy[set], ya)
+#define HWG_READ_X(ks, t) tr_issue_imm<((ks) >> 1) * XROW + ((ks) & 1) * XHALF, XHI>(fx[t], xa[t])
 #define HWG_STEP(ks)                                                                                          \
     {                                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
         tr_fence(fy[(ks) & 1]);                                                                               \
-        _Pragma("unroll") for (int t = 0; t < 5; ++t) tr_fence(fx[t]);                                        \
-        _Pragma("unroll") for (int t = 5; t < 9; ++t) HWG_READ_X(ks, t);                                      \
-        _Pragma("unroll") for (int t = 0; t < 5; ++t)                                                         \
-            acc[t] = mfma16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < G0; ++t) tr_fence(fx[t]);                                       \
+        _Pragma("unroll") for (int t = G0; t < NM; ++t) HWG_READ_X(ks, t);                                    \
+        _Pragma("unroll") for (int t = 0; t < G0; ++t)                                                        \
+            acc[t] = mfma16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0);                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-        _Pragma("unroll") for (int t = 5; t < 9; ++t) tr_fence(fx[t]);                                        \
+        _Pragma("unroll") for (int t = G0; t < NM; ++t) tr_fence(fx[t]);                                      \
         if ((ks) < 3) {                                                                                       \
             HWG_READ_Y((ks) + 1, ((ks) + 1) & 1);                                                             \
-            _Pragma("unroll") for (int t = 0; t < 5; ++t) HWG_READ_X((ks) + 1, t);                            \
+            _Pragma("unroll") for (int t = 0; t < G0; ++t) HWG_READ_X((ks) + 1, t);                           \
         }                                                                                                     \
-        _Pragma("unroll") for (int t = 5; t < 9; ++t)                                                         \
-            acc[t] = mfma16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0); \
+        _Pragma("unroll") for (int t = G0; t < NM; ++t)                                                       \
+            acc[t] = mfma16(tr_value(fy[(ks) & 1]), tr_value(fx[t]), acc[t], 0, 0, 0);                        \
     }
 
     HWG_ISSUE(t_begin, 0);
@@ -601,12 +613,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (tile + 1 < t_end) HWG_ISSUE(tile + 1, slot ^ 1);
         const unsigned sb = lds0 + slot * (SLOT * 2);
         const unsigned ya = sb + y_rel;
-        unsigned xa[9];
+        unsigned xa[NM];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) xa[t] = sb + x_rel[t];
+        for (int t = 0; t < NM; ++t) xa[t] = sb + x_rel[t];
         HWG_READ_Y(0, 0);
 #pragma unroll
-        for (int t = 0; t < 5; ++t) HWG_READ_X(0, t);
+        for (int t = 0; t < G0; ++t) HWG_READ_X(0, t);
         HWG_STEP(0)
         HWG_STEP(1)
         HWG_STEP(2)
@@ -617,23 +629,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef HWG_STEP
 #undef HWG_READ_X
 #undef HWG_READ_Y
-    // ---- accumulators -> dw[(k * wt + slot(t)) * C + c]: rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31
+    // ---- accumulators -> dw: rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 = (tap, c)
     // The sum over the 4 waves is formed in LDS with plain stores / loads (waves 2, 3 -> waves 0, 1 -> wave 0; LDS float
     // atomics measured far slower), then wave 0 alone issues the fp32 global atomics: 4x fewer than one set per wave, and
-    // they were the tail of the kernel (all workgroups finish together and hit the same 36 KB of dw).
+    // they were the tail of the kernel (all workgroups finish together and hit the same few KB of dw).
     float* __restrict__ dw = a.dw[prob];
     __builtin_amdgcn_s_barrier();                         // every wave is done with the tile buffers
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);       // [2 regions][9 taps][4 quads][64 lanes] float4 = 2 x 36 KB
-    static_assert(2 * 9 * 4 * 64 * 16 <= 2 * SLOT * 2, "reduction buffers must fit the tile buffers");
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(lds);       // [2 regions][NM products][4 quads][64 lanes] float4
 #define HWG_PUT(region)                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                            \
+    _Pragma("unroll") for (int t = 0; t < NM; ++t)                                                           \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                        \
-            red[(((region) * 9 + t) * 4 + q) * 64 + lane] =                                                  \
+            red[(((region) * NM + t) * 4 + q) * 64 + lane] =                                                 \
                 f32x4_t{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
 #define HWG_GET(region)                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                            \
+    _Pragma("unroll") for (int t = 0; t < NM; ++t)                                                           \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-            const f32x4_t v = red[(((region) * 9 + t) * 4 + q) * 64 + lane];                                 \
+            const f32x4_t v = red[(((region) * NM + t) * 4 + q) * 64 + lane];                                \
             acc[t][4 * q] += v[0]; acc[t][4 * q + 1] += v[1]; acc[t][4 * q + 2] += v[2]; acc[t][4 * q + 3] += v[3]; \
         }
     if (wave >= 2) HWG_PUT(wave - 2)
@@ -646,49 +657,99 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     HWG_GET(0)
 #undef HWG_PUT
 #undef HWG_GET
-    // accumulator rows k = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c = lane & 31 -> dw[(k * wt + slot(t)) * C + c]
+    const int cc = (lane & 31) % C;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NM; ++t) {
+        const int tap = t * TPM + (lane & 31) / C;        // (the column's own tap: taps past 8 exist in the last product only)
+        if (tap > 8) continue;
+        int ws = 0;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) ws = tap == u ? a.tap_w[u] : ws;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(dw + ((int64_t)k * a.wt + a.tap_w[t]) * C + (lane & 31), acc[t][r]);
+            if (k < KO) atomicAdd(dw + ((int64_t)k * a.wt + ws) * C + cc, acc[t][r]);
         }
     }
+}
+
+// (two co-resident workgroups per CU, i.e. 2 waves per SIMD with the full register budget -- except 16 -> 32 stride 2, whose two
+// 51 KB tile buffers leave room for one)
+template <int C, int S, int KO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_wgrad_kernel(const HaloWgArgs a) { halo_wgrad_body<C, S, KO>(a); }
+template <int C, int S, int KO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void halo_wgrad_kernel_lds(const HaloWgArgs a) { halo_wgrad_body<C, S, KO>(a); }
+
+// the instantiated (input channels, stride, output channels) shapes: 32 -> 32 (os1 / os2 shortcut, stem conv2), 8 -> 32 (os1 shortcut),
+// 8 -> 32 / 8 -> 16 stride 2 (stem conv1, guidance head conv1), 16 -> 32 stride 2 (guidance head conv2)
+static int halo_wgrad_shape(const tcvom_conv_desc* d, int nphase, int ldy, int* org_out) {
+    static const bool disabled = getenv("TCVOM_NO_HALO_WGRAD") != nullptr;      // A/B switches for tools/igemm_bench.py
+    static const bool thin_off = getenv("TCVOM_NO_HALO_WGRAD_THIN") != nullptr; // ... the shapes other than 32 -> 32 (round 6)
+    if (disabled || nphase != 1) return 0;
+    const int S = d->in_step;
+    int shape = 0;
+    if (d->C == 32 && d->K == 32 && S == 1) shape = 1;
+    else if (thin_off) return 0;
+    else if (d->C == 8 && d->K == 32 && S == 1) shape = 2;
+    else if (d->C == 8 && d->K == 32 && S == 2) shape = 3;
+    else if (d->C == 8 && d->K == 16 && S == 2) shape = 4;
+    else if (d->C == 16 && d->K == 32 && S == 2) shape = 5;
+    if (!shape || ldy != d->K) return 0;                    // (d->batch is a forward-only field)
+    if (d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return 0;
+    int org = d->ntaps > 0 ? 1 : 0, nt = 0;                 // org = 1: taps 0..2 on an input with its own padding ring (as halo_plan)
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->tap_w[t] >= 0 && (d->tap_dh[t] < 0 || d->tap_dw[t] < 0)) org = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        if (d->tap_w[t] < 0) continue;
+        if (d->tap_dh[t] - org < -1 || d->tap_dh[t] - org > 1 || d->tap_dw[t] - org < -1 || d->tap_dw[t] - org > 1) return 0;
+        ++nt;
+    }
+    if (nt != 9) return 0;                                  // the kernel is written for the full 3x3 stencil
+    if (d->PH != d->OH || d->PW != d->OW || d->OH * S != d->H - 2 * org || d->OW * S != d->W - 2 * org) return 0;
+    if (d->OH % HALO_TH != 0 || d->OW % HALO_TW != 0) return 0;
+    if ((long long)d->N * d->H * d->W * d->C >= (1ll << 31) || (long long)d->N * d->OH * d->OW * d->K >= (1ll << 31)) return 0;
+    if (org_out) *org_out = org;
+    return shape;
+}
+const char* halo_wgrad_variant(const tcvom_conv_desc* d, int ldy) {
+    static const char* const names[] = {nullptr, "halo_wgrad<32>", "halo_wgrad<8,1,32>", "halo_wgrad<8,2,32>", "halo_wgrad<8,2,16>", "halo_wgrad<16,2,32>"};
+    return names[halo_wgrad_shape(d, 1, ldy, nullptr)];
 }
 
 // 1: launched, 0: not a shape for this kernel, -1: launch error
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
                           int nphase, int ldy, const h16raw* zero_page, void* stream) {
-    static const bool disabled = getenv("TCVOM_NO_HALO_WGRAD") != nullptr;      // A/B switch for tools/igemm_bench.py
-    if (disabled) return 0;
-    if (nphase != 1 || nbatch < 1 || nbatch > 8 || d->C != 32 || d->K != 32 || ldy != 32) return 0;   // (d->batch is a forward-only field)
-    if (d->in_step != 1 || d->out_step != 1 || d->out_off_h != 0 || d->out_off_w != 0) return 0;
-    if (d->H != d->OH || d->W != d->OW || d->PH != d->H || d->PW != d->W || d->H % HALO_TH != 0 || d->W % HALO_TW != 0) return 0;
+    int org = 0;
+    const int shape = halo_wgrad_shape(d, nphase, ldy, &org);
+    if (!shape || nbatch < 1 || nbatch > 8) return 0;
     HaloWgArgs a;
     int nt = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         if (d->tap_w[t] < 0) continue;
-        if (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1 || nt >= 9) return 0;
-        a.tap_dh[nt] = d->tap_dh[t]; a.tap_dw[nt] = d->tap_dw[t]; a.tap_w[nt] = d->tap_w[t];
+        a.tap_dh[nt] = d->tap_dh[t] - org; a.tap_dw[nt] = d->tap_dw[t] - org; a.tap_w[nt] = d->tap_w[t];
         ++nt;
     }
-    if (nt != 9) return 0;                                  // the kernel is written for the full 3x3 stencil
-    a.ntaps = nt;
     for (int i = 0; i < 8; ++i) {
         const int j = i < nbatch ? i : 0;
         a.dy[i] = (const h16raw*)dys[j]; a.in[i] = (const h16raw*)ins[j]; a.dw[i] = dws[j];
     }
     a.zero_page = zero_page;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.wt = d->wt;
-    a.tiles_x = d->W / HALO_TW; a.tiles_y = d->H / HALO_TH;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.wt = d->wt; a.org = org;
+    a.tiles_x = d->OW / HALO_TW; a.tiles_y = d->OH / HALO_TH;
     a.ntiles = d->N * a.tiles_x * a.tiles_y;
-    if ((long long)d->N * d->H * d->W * 32 >= (1ll << 31)) return 0;
-    int wgs = 512 / nbatch;                               // two co-resident workgroups per CU over all problems
+    int wgs = (shape == 5 ? 256 : 512) / nbatch;          // co-resident workgroups over all problems (16 -> 32 stride 2: 102 KB of LDS, one per CU)
     if (wgs < 1) wgs = 1;
     if (wgs > a.ntiles) wgs = a.ntiles;
     a.tiles_per_wg = (a.ntiles + wgs - 1) / wgs;
     wgs = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-    hipLaunchKernelGGL(halo_wgrad_kernel, dim3(wgs, nbatch), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid(wgs, nbatch), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (shape) {
+        case 1: hipLaunchKernelGGL((halo_wgrad_kernel<32, 1, 32>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((halo_wgrad_kernel<8, 1, 32>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((halo_wgrad_kernel<8, 2, 32>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((halo_wgrad_kernel<8, 2, 16>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((halo_wgrad_kernel_lds<16, 2, 32>), grid, block, 0, st, a); break;
+    }
     return hipGetLastError() == hipSuccess ? 1 : -1;
 }

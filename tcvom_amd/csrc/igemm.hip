@@ -450,6 +450,7 @@ int gemm_nt256_takes(const tcvom_conv_desc* d);
 int gemm_nt256_takes_stats(const tcvom_conv_desc* d);
 int gemm_nt256_stats_groups(const tcvom_conv_desc* d);
 // halo.hip: weight gradient of the 32 -> 32 channel full-resolution layers from LDS-resident x halo / dy tiles
+const char* halo_wgrad_variant(const tcvom_conv_desc* d, int ldy);
 int halo_wgrad_try_launch(const void* const* dys, const void* const* ins, float* const* dws, int nbatch, const tcvom_conv_desc* d,
                           int nphase, int ldy, const h16raw* zero_page, void* stream);
 // wgradws.hip: accumulator-stationary weight gradient of the stride-1 3x3 layers with 64 / 128-multiple channel counts
@@ -952,12 +953,7 @@ static void tt_tile(const tcvom_conv_desc* d, int* tm, int* tn) {
     }
 }
 extern "C" const char* tcvom_wgrad_igemm_variant(const tcvom_conv_desc* d) {
-    if (d->C == 32 && d->K == 32 && d->in_step == 1 && d->out_step == 1 && d->H == d->OH && d->W == d->OW && d->H % 8 == 0 && d->W % 32 == 0) {
-        bool ok = true;
-        for (int t = 0; t < d->ntaps; ++t)
-            if (d->tap_w[t] >= 0 && (d->tap_dh[t] < -1 || d->tap_dh[t] > 1 || d->tap_dw[t] < -1 || d->tap_dw[t] > 1)) ok = false;
-        if (ok) return "halo_wgrad<32>";
-    }
+    if (const char* v = halo_wgrad_variant(d, d->K)) return v;
     if (const char* v = wgradws_variant(d, d->K)) return v;
     if (gemm_tt256_takes(d)) return "gemm_tt256";
     int tm, tn;

@@ -456,6 +456,53 @@ def test_wgrad_ws_kernel(cin, cout, N, H, W, S):
         assert rel_err(got, ref) < 1e-5, 'problem %d' % i
 
 
+HALO_WGRAD_CASES = [
+    # cin, cout, stride, pad, N, H, W (input), problems, variant
+    (32, 32, 1, 1, 2, 16, 64, 3, 'halo_wgrad<32>'),
+    (6, 32, 1, 1, 1, 24, 96, 1, 'halo_wgrad<8,1,32>'),           # os1 shortcut (8 -> 32)
+    (8, 32, 1, 1, 2, 16, 64, 3, 'halo_wgrad<8,1,32>'),
+    (6, 32, 2, 1, 1, 48, 192, 3, 'halo_wgrad<8,2,32>'),          # encoder conv1
+    (3, 16, 2, 0, 2, 34, 130, 2, 'halo_wgrad<8,2,16>'),          # guidance head conv1 on a reflection-padded input (taps 0..2)
+    (3, 16, 2, 1, 1, 32, 64, 1, 'halo_wgrad<8,2,16>'),
+    (16, 32, 2, 0, 1, 50, 130, 3, 'halo_wgrad<16,2,32>'),        # guidance head conv2 on a reflection-padded input
+    (16, 32, 2, 1, 2, 16, 64, 1, 'halo_wgrad<16,2,32>'),
+    (6, 32, 1, 1, 1, 136, 320, 1, 'halo_wgrad<8,1,32>'),         # 170 tiles: several per workgroup, both tile buffers in use
+    (6, 32, 2, 1, 3, 272, 640, 2, 'halo_wgrad<8,2,32>'),         # 1020 tiles over 3 samples and 2 problems
+]
+
+
+@pytest.mark.parametrize('cin,cout,stride,pad,N,H,W,S,variant', HALO_WGRAD_CASES)
+def test_halo_wgrad_kernel(cin, cout, stride, pad, N, H, W, S, variant):
+    """Halo-form weight gradient (csrc/halo.hip: halo_wgrad_kernel<C, S, K>; 3x3, <= 32 channels in and out, stride 1 or 2, the dy grid
+    a multiple of 8 x 32): every instantiated shape, several samples and problems per launch, inputs with their own padding ring --
+    against torch.nn.grad.conv2d_weight in fp32 on the same 16-bit operands."""
+    import ctypes as C
+    from tcvom_amd import _lib as L
+    from tcvom_amd.conv_plan import ConvGeometry
+    from tcvom_amd.ops import _phase_array
+    tag = 'hwg%d_%d_%d_%d_%d' % (cin, cout, stride, pad, H)
+    bank, spec = _mini_bank(cin, cout, 3, stride, pad, False, spectral=False, tag=tag)
+    geo = ConvGeometry(spec, N, H, W)
+    arr = _phase_array(geo.wgrad)
+    assert L._FNS['tcvom_wgrad_igemm_variant'](C.byref(arr[0])).decode() == variant
+    cp = spec.cpad
+    xs = [hu('x%d.%s' % (i, tag), (N, H, W, cp)).to(DEV).to(H16) for i in range(S)]
+    for x in xs:
+        x[..., cin:] = 0
+    dys = [hu('dy%d.%s' % (i, tag), (N, geo.OH, geo.OW, cout)).to(DEV).to(H16) for i in range(S)]
+    dw = torch.zeros(S, cout, 9, cp, device=DEV)
+    vp = lambda ts: C.cast((C.c_void_p * S)(*[t.data_ptr() for t in ts]), C.c_void_p)
+    for _ in range(2):                                   # accumulates: two launches = twice the gradient
+        L.call('tcvom_wgrad_igemm_batched', vp(dys), vp(xs), vp([dw[i] for i in range(S)]), S, arr, len(geo.wgrad), cout, L.stream_ptr())
+    torch.cuda.synchronize()
+    for i in range(S):
+        ref = torch.nn.grad.conv2d_weight(xs[i][..., :cin].double().cpu().permute(0, 3, 1, 2), (cout, cin, 3, 3),
+                                          dys[i].double().cpu().permute(0, 3, 1, 2), stride=stride, padding=pad)
+        got = dw[i].cpu().view(cout, 3, 3, cp).permute(0, 3, 1, 2) / 2
+        assert rel_err(got[:, :cin], ref) < 1e-5, 'problem %d' % i
+        assert float(got[:, cin:].abs().max()) == 0 if cp > cin else True
+
+
 @pytest.mark.parametrize('cin,cout,N,H,W', [(32, 32, 2, 16, 64), (6, 32, 1, 16, 160), (32, 32, 1, 72, 96), (64, 64, 2, 16, 64),
                                            (64, 32, 1, 16, 96), (32, 64, 1, 40, 64)])
 def test_halo_conv_kernel(cin, cout, N, H, W):

@@ -39,6 +39,9 @@ SETS = {
     # every weight gradient on igemm_tt: no accumulator-stationary / halo / 256-tile TT kernels, no grouped launches
     'igemm_tt weight gradients': {'TCVOM_NO_WGRADWS': '1', 'TCVOM_NO_HALO_WGRAD': '1', 'TCVOM_NO_TT256': '1', 'TCVOM_NO_WGRAD_HETERO': '1',
                                   'TCVOM_NO_WGRAD_GROUP_LAYERS': '1'},
+    # round 6: the halo-form weight gradient for the 32 -> 32 layers only (the 8 / 16-channel and stride-2 stem, guidance-head and os1 shortcut
+    # layers back on igemm_tt<32,128>)
+    'halo weight gradient 32 -> 32 only': {'TCVOM_NO_HALO_WGRAD_THIN': '1'},
     # round 6: the implicit-GEMM TT weight gradients as one launch per layer geometry instead of one per tile shape (tcvom_wgrad_igemm_hetero)
     'igemm_tt one launch per geometry': {'TCVOM_NO_WGRAD_TT_HETERO': '1'},
     # the accumulator-stationary weight gradient without its dilated form (FBA's layers; a no-op for GCA, kept for enumeration)

@@ -31,9 +31,14 @@ d1 = dense_desc(N, N, D, ld, batch=B, in_bstride=N * D, w_bstride=N * D, out_bst
 st = L.stream_ptr()
 fn = L._lib.tcvom_life256_read
 fn.argtypes = [C.c_void_p]
+dO, Vv = rnd(B, N, DV), rnd(B, N, DV)
+Pp = (torch.rand(B, N, ld, device='cuda', generator=g) * 1e-3).to(BF)
+delta, T = torch.rand(B, N, device='cuda'), torch.empty(B, N, ld, device='cuda', dtype=BF)
 names = ['entry', 'K-tile 0 landed', 'main loop done', 'max pass', 'exp pass', 'stores issued', 'stores retired']
 for what, call in (('scores + softmax numerators (EPI 3, K = 576)', lambda: L.call('tcvom_gca_scores_exp', L.ptr(G), L.ptr(cvec), L.ptr(dvec), L.ptr(Pn), L.ptr(stats), N, D, ld, B, st)),
                    ('S = G G^T fp32 (EPI 0, K = 576)', lambda: L.call('tcvom_conv_igemm', L.ptr(G), L.ptr(G), L.ptr(S), None, None, None, None, C.byref(d1), st)),
+                   ('T = P (dO V^T - delta) c (EPI 2, K = 2048; stamps: P tile landed / T computed in LDS)',
+                    lambda: L.call('tcvom_gca_dp_softmax_bwd', L.ptr(dO), L.ptr(Vv), L.ptr(Pp), L.ptr(delta), L.ptr(cvec), L.ptr(T), None, None, N, DV, ld, B, st)),
                    ('O = P V (K = 8192)', lambda: L.call('tcvom_gca_pv', L.ptr(P), L.ptr(V), L.ptr(O), N, DV, ld, B, st))):
     for _ in range(5):
         call()
