@@ -75,6 +75,10 @@ struct Gemm256Args {
 #ifndef G256_PHASES
 #define G256_PHASES 2         // barrier phases per K-tile (2 or 4), see the main loop
 #endif
+// (Round 6, the softmax-backward product <2, 4>: life-cycle stamps put a tile at 1.3-2.3 us of prologue, 60-62 us of main loop, 6-9 us
+// until the P tile has landed, 2.6 us of arithmetic, 1.8 us of stores.  Starting the first round of workgroups in 8 phases 0.5 .. 2 us
+// apart -- so that an eighth of the CUs fetches P at a time instead of all 256 in one burst -- left the fetch at 6-9 us and the launch
+// at 940-966 us: the fetch time is not a burst effect.  Dropped.)
 // (An L2 prefetch of K-tile t+2 -- one 4-byte LDS-DMA per lane and K-tile into a dump area, i.e. one cache line per tile row --
 // measured 8 % SLOWER: 772 -> 833 us; the one-K-tile prefetch distance is not what separates the 3-frame launch, 259 us per
 // round of workgroups, from the one-frame launch whose operands stay in the 256 MB Infinity Cache, 224 us.)
