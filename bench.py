@@ -556,6 +556,11 @@ def main():
                                                                   ('igemm_nt_tt', lambda k: k.startswith('igemm_')))}}
             algo = getattr(igemm_profile, 'algo', {})
             result['roofline']['algorithmic_mib_per_launch'] = {k: round(v[1] / max(v[0], 1) / 2 ** 20, 2) for k, v in sorted(algo.items())}
+            # every family against BOTH roofs: the thin-channel layers (halo / sconv / pwconv / igemm_tt<32,128>) are bound by their
+            # operand bytes, not by the matrix pipe -- `hbm_frac` = algorithmic bytes / event time / 8 TB/s
+            for k, e in result['roofline']['all_igemm'].items():
+                if k in algo and e['ms'] > 0:
+                    e['hbm_frac'] = round(algo[k][1] / (e['ms'] * 1e-3) / 8e12, 3)
             if args.config == 'gca':
                 result['roofline']['tam_all_unknown'] = tam_all_unknown(device, H // 8, W // 8)
     if rank == 0:
