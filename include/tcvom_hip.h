@@ -344,7 +344,7 @@ int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const void* y, cons
  * conv of the network at once; see tcvom_amd/csrc/spectral.hip for the table layout (24 int64 words
  * per layer) and tcvom_amd/weights.py for the host side that builds it.                      */
 typedef struct {
-    float* tvec;   /* [sum_wd] */
+    float* tvec;   /* [sum_wd]: ZERO before the first training call (every training call leaves it zero again) */
     float* svec;   /* [sum_h]  */
     float* sigma;  /* [max_calls][num_layers] */
     float* uhist;  /* [max_calls][sum_h]  */

@@ -42,7 +42,7 @@ __device__ __forceinline__ int stem_dst(int ch, int u, int v) {
 }
 
 struct SnScratch {
-    float* tvec;      // [sum wd]      W^T u   (zeroed before each iteration)
+    float* tvec;      // [sum wd]      W^T u   (atomic sums: zero on entry; sn_finalize_kernel zeroes a layer's slice after its last read)
     float* svec;      // [sum h]       W t
     float* sigma;     // [ncalls][L]
     float* uhist;     // [ncalls][sum h]
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(const int64_t* __restr
     float* u = reinterpret_cast<float*>(L[SN_U]);
     float* v = reinterpret_cast<float*>(L[SN_V]);
     const int h = (int)L[SN_H], wd = (int)L[SN_WD];
-    const float* t = sc.tvec + L[SN_T_OFF];
+    float* t = sc.tvec + L[SN_T_OFF];
     const float* s = sc.svec + L[SN_S_OFF];
     float* uh = sc.uhist + (int64_t)call * sc.sum_h + L[SN_S_OFF];
     float* vh = sc.vhist + (int64_t)call * sc.sum_wd + L[SN_T_OFF];
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void sn_finalize_kernel(const int64_t* __restr
         const float inv_t = 1.f / (nt + eps);
         const float ns = ns_raw * inv_t;               // ||W v||
         const float inv_s = inv_t / (ns + eps);        // u = (s_raw*inv_t)/(ns+eps)
-        for (int c = threadIdx.x; c < wd; c += 256) { const float x = t[c] * inv_t; v[c] = x; vh[c] = x; }
+        // (t is an accumulator of atomics: left zero for the next training iteration -- no memset launch in front of every call)
+        for (int c = threadIdx.x; c < wd; c += 256) { const float x = t[c] * inv_t; v[c] = x; vh[c] = x; t[c] = 0.f; }
         for (int r = threadIdx.x; r < h; r += 256) { const float x = s[r] * inv_s; u[r] = x; uh[r] = x; }
         if (threadIdx.x == 0) sc.sigma[(int64_t)call * sc.L + layer] = ns * ns / (ns + eps);
     } else {
@@ -595,11 +596,8 @@ extern "C" int tcvom_sn_power_iteration(const int64_t* table, const tcvom_sn_scr
     if (n_sn <= 0) return TCVOM_OK;
     hipStream_t st = (hipStream_t)stream;
     SnScratch sc = mk_scratch(s);
-    if (training) {
-        if (hipMemsetAsync(sc.tvec, 0, sizeof(float) * sc.sum_wd, st) != hipSuccess)
-            return tcvom_fail(TCVOM_ERR_LAUNCH, "sn_power_iteration: memset failed");
-        hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n_wtu), dim3(256), 0, st, table, work_wtu, sc.tvec);
-    }
+    // (tvec is zero here: allocated so, and the finalize kernel of every training call leaves the slices it read zero)
+    if (training) hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n_wtu), dim3(256), 0, st, table, work_wtu, sc.tvec);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(n_wv), dim3(256), 0, st, table, work_wv, sc.tvec, sc.svec, training ? 0 : 1);
     hipLaunchKernelGGL(sn_finalize_kernel, dim3(n_sn), dim3(256), 0, st, table, sn_layers, sc, call, training ? 0 : 1);
     TCVOM_LAUNCH_CHECK("sn_power_iteration");
