@@ -244,6 +244,13 @@ int tcvom_bn_bwd_reduce_ranged(const void* dz, const void* dz2, const void* y, c
 int tcvom_bn_bwd_reduce_mask(const void* dz, const void* dz2, const void* y, const uint8_t* mask, const float* scale_shift,
                              const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32,
                              int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
+/* three addends: dz (all frames) + dz2 and dz3, each holding its own frame range (NULL = absent): the outputs of the encoder stages
+ * (resnet_enc.py:130-138 layer1 .. layer3, res_gca_enc.py:47-55 shortcuts) have three consumers -- the next stage's conv1, its
+ * down-sampling branch and the shortcut branch.  res1 XOR mask (both may be NULL). */
+int tcvom_bn_bwd_reduce3(const void* dz, const void* dz2, int32_t dz2_f0, int32_t dz2_f1, const void* dz3, int32_t dz3_f0,
+                         int32_t dz3_f1, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
+                         const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32,
+                         int32_t nframes, int64_t slot_stride, void* stream);
 /* Optional by-product of the BatchNorm backward of a SpectralNorm'd conv (models/GCA/ops.py:25-45: weight = weight_bar / sigma,
  * differentiated by autograd): SpectralNorm's backward needs <dW~, weight_bar> = sigma <dW~, W~>, and <dW~, W~> = d(loss)/d(alpha) of
  * y = conv(x, alpha W~) = <dy, y> -- which the two BatchNorm-backward sums determine per channel (training statistics:
@@ -338,6 +345,10 @@ int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const void* y, cons
                             const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                             int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                             int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
+int tcvom_bn_bwd_apply3(const void* dz, const void* dz2, int32_t dz2_f0, int32_t dz2_f1, const void* dz3, int32_t dz3_f0,
+                        int32_t dz3_f1, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
+                        const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels, int32_t C, int32_t act,
+                        int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream);
 
 /* ------------------------------------------------------------------ batched SpectralNorm + weight packing
  * Replaces SpectralNorm._update_u_v/_noupdate_u_v (models/GCA/ops.py:25-45,74-80) for every wrapped

@@ -342,12 +342,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 
 // ---------------------------------------------------------------- backward, pass 1: per-channel sums
 // block = 256 threads = RP pixel rows x C8 channel octets (C8 <= 256); partial[block][2][C]
-template <int YF32>
+// HAS3: a third addend of the incoming gradient (dz3, frames dz3_f0 .. dz3_f1 - 1 like dz2): the outputs of the encoder stages have three
+// consumers (the next stage's conv1, its down-sampling branch, the shortcut branch) -- summed here in fp32 instead of by an element-wise
+// pass (and its 16-bit rounding) in front of the two BatchNorm-backward kernels
+template <int YF32, bool HAS3 = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved,
     float* __restrict__ partial, int64_t P, int C8, int C, int act, int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1,
-    int* __restrict__ overflow, const unsigned char* __restrict__ mask = nullptr)
+    int* __restrict__ overflow, const unsigned char* __restrict__ mask = nullptr, const uint4* __restrict__ dz3 = nullptr, int dz3_f0 = 0,
+    int dz3_f1 = 0)
 {
     // mask (or NULL): the activation bits bn_apply_kernel wrote (then res1 is NULL: the pre-activation sign comes from the bit)
     extern __shared__ float red[];        // [2][256][8]
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const int tid = threadIdx.x;
     // dz2 may cover the frames dz2_f0 .. dz2_f1 - 1 only (a consumer that ran for the interior frames of a window): zero elsewhere
     if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
+    if (HAS3 && dz3) dz3 = ((int)blockIdx.y >= dz3_f0 && (int)blockIdx.y < dz3_f1) ? dz3 - (int64_t)dz3_f0 * P * C8 : nullptr;
     scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
     saved += blockIdx.y * slot_stride;
     partial += (int64_t)blockIdx.y * gridDim.x * 2 * C;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         // two-deep software pipeline (see bn_apply_kernel)
         int64_t p = pbeg + prow;
         int64_t v = fo + p * C8 + oct;
-        uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
+        uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0}, q3 = (HAS3 && dz3) ? dz3[v] : uint4{0, 0, 0, 0};
         YRaw<YF32> yr = load_yraw<YF32>(y, v);
         uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
         unsigned mb = mask ? mask[v] : 0u;
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const int64_t pn = p + RP;
             const bool more = pn < pend;
             const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-            const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
+            const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0}, n3 = (HAS3 && dz3) ? dz3[vn] : uint4{0, 0, 0, 0};
             const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
             const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
             const unsigned nb = mask ? mask[vn] : 0u;
@@ -393,6 +398,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             unpack8(qg, g);
             unpack8(qh, g2);
             sat |= sat8(qg) | sat8(qh);
+            if constexpr (HAS3) {
+                float g3[8];
+                unpack8(q3, g3);
+                sat |= sat8(q3);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g2[k] += g3[k];
+            }
             unpack_yraw<YF32>(yr, yy);
             unpack8(q1, r1);
 #pragma unroll
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 sx[k] += gg * (yy[k] - mu[k]) * is[k];
             }
             if (!more) break;
-            p = pn; qg = ng; qh = nh; yr = yn; q1 = n1; mb = nb;
+            p = pn; qg = ng; qh = nh; q3 = n3; yr = yn; q1 = n1; mb = nb;
         }
     }
     if (overflow && __any(sat != 0u) && (tid & 63) == 0) atomicAdd(overflow, 1);      // (never taken in a healthy step)
@@ -505,16 +517,18 @@ __global__ __launch_bounds__(FIN_SL * 32) void bn_bwd_finalize_kernel(
     }
 }
 
-template <int YF32>
+template <int YF32, bool HAS3 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint4* __restrict__ dz, const uint4* __restrict__ dz2, const void* __restrict__ y, const uint4* __restrict__ res1,
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
-    int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1, const unsigned char* __restrict__ mask = nullptr)
+    int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1, const unsigned char* __restrict__ mask = nullptr,
+    const uint4* __restrict__ dz3 = nullptr, int dz3_f0 = 0, int dz3_f1 = 0)
 {
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
     if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
+    if (HAS3 && dz3) dz3 = ((int)blockIdx.y >= dz3_f0 && (int)blockIdx.y < dz3_f1) ? dz3 - (int64_t)dz3_f0 * P * C8 : nullptr;
     scale_shift += blockIdx.y * slot_stride;                         // blockIdx.y = frame of a batched call
     saved += blockIdx.y * slot_stride;
     coef += (int64_t)blockIdx.y * 3 * C;
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     if (p >= pend) return;
     // two-deep software pipeline (see bn_apply_kernel)
     int64_t v = fo + p * C8 + oct;
-    uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0};
+    uint4 qg = dz[v], qh = dz2 ? dz2[v] : uint4{0, 0, 0, 0}, q3 = (HAS3 && dz3) ? dz3[v] : uint4{0, 0, 0, 0};
     YRaw<YF32> yr = load_yraw<YF32>(y, v);
     uint4 q1 = res1 ? res1[v] : uint4{0, 0, 0, 0};
     unsigned mb = mask ? mask[v] : 0u;
@@ -546,13 +560,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const int64_t pn = p + RP;
         const bool more = pn < pend;
         const int64_t vn = fo + (more ? pn : p) * C8 + oct;
-        const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0};
+        const uint4 ng = dz[vn], nh = dz2 ? dz2[vn] : uint4{0, 0, 0, 0}, n3 = (HAS3 && dz3) ? dz3[vn] : uint4{0, 0, 0, 0};
         const YRaw<YF32> yn = load_yraw<YF32>(y, vn);
         const uint4 n1 = res1 ? res1[vn] : uint4{0, 0, 0, 0};
         const unsigned nb = mask ? mask[vn] : 0u;
         float g[8], g2[8], yy[8], r1[8], o[8];
         unpack8(qg, g);
         unpack8(qh, g2);
+        if constexpr (HAS3) {
+            float g3[8];
+            unpack8(q3, g3);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g2[k] += g3[k];
+        }
         unpack_yraw<YF32>(yr, yy);
         unpack8(q1, r1);
 #pragma unroll
@@ -568,7 +588,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         dy[v] = pack8(o);
         if (dres1) dres1[v] = pack8(g);
         if (!more) break;
-        p = pn; v = vn; qg = ng; qh = nh; yr = yn; q1 = n1; mb = nb;
+        p = pn; v = vn; qg = ng; qh = nh; q3 = n3; yr = yn; q1 = n1; mb = nb;
     }
 }
 
@@ -801,22 +821,22 @@ extern "C" int tcvom_bn_bwd_groups(int64_t pixels, int32_t C) { return tcvom_bn_
 static int bn_bwd_reduce_impl(const void* dz, const void* dz2, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
                               const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
                               int32_t y_fp32, int32_t nframes, int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1,
-                              void* stream) {
+                              void* stream, const void* dz3 = nullptr, int32_t dz3_f0 = 0, int32_t dz3_f1 = 0) {
     TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_reduce: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
+    TCVOM_CHECK_ARG(!dz3 || (dz3_f0 >= 0 && dz3_f0 <= dz3_f1 && dz3_f1 <= nframes), "bn_bwd_reduce: dz3 frames %d..%d of %d", dz3_f0, dz3_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && partial && pixels > 0 && C >= 8 && C % 8 == 0 && C <= 2048 && nframes >= 1,
                     "bn_bwd_reduce: bad args (C=%d)", C);
     const int groups = tcvom_bn_bwd_groups_n(pixels, C, nframes);
     const int rpb = (int)((pixels + groups - 1) / groups);
     const dim3 grid(groups, nframes);
     TCVOM_CHECK_ARG(y_fp32 == 0 || y_fp32 == 2, "bn_bwd_reduce: y_fp32 = %d (0: the build's 16-bit type, 2: IEEE fp16)", y_fp32);
-    switch (bn_y_mode(y_fp32)) {
-    case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
-    default: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, slot_stride,
-                           dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask); break;
-    }
+#define BN_BWD_REDUCE_LAUNCH(YM, H3)                                                                                              \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<YM, H3>), grid, dim3(256), 2 * 256 * 8 * sizeof(float), (hipStream_t)stream,          \
+                       (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, partial, pixels, C / 8, C, act, rpb, \
+                       slot_stride, dz2_f0, dz2_f1, g_overflow_sink.load(std::memory_order_relaxed), mask, (const uint4*)dz3, dz3_f0, dz3_f1)
+    if (bn_y_mode(y_fp32) == 2) { if (dz3) BN_BWD_REDUCE_LAUNCH(2, true); else BN_BWD_REDUCE_LAUNCH(2, false); }
+    else { if (dz3) BN_BWD_REDUCE_LAUNCH(0, true); else BN_BWD_REDUCE_LAUNCH(0, false); }
+#undef BN_BWD_REDUCE_LAUNCH
     TCVOM_LAUNCH_CHECK("bn_bwd_reduce");
     return TCVOM_OK;
 }
@@ -835,6 +855,15 @@ extern "C" int tcvom_bn_bwd_reduce_mask(const void* dz, const void* dz2, const v
     TCVOM_CHECK_ARG(mask && act != 4, "bn_bwd_reduce_mask: null mask / capped activation");
     return bn_bwd_reduce_impl(dz, dz2, y, nullptr, mask, scale_shift, saved, partial, pixels, C, act, y_fp32, nframes, slot_stride, dz2_f0,
                               dz2_f1, stream);
+}
+// three addends: dz (all frames) + dz2 / dz3 (each for its frame range; NULL = absent); res1 XOR mask as in the two entries above
+extern "C" int tcvom_bn_bwd_reduce3(const void* dz, const void* dz2, int32_t dz2_f0, int32_t dz2_f1, const void* dz3, int32_t dz3_f0,
+                                    int32_t dz3_f1, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
+                                    const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act, int32_t y_fp32,
+                                    int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(!(res1 && mask) && !(mask && act == 4), "bn_bwd_reduce3: res1 and mask exclude each other; no mask with a capped activation");
+    return bn_bwd_reduce_impl(dz, dz2, y, res1, mask, scale_shift, saved, partial, pixels, C, act, y_fp32, nframes, slot_stride, dz2_f0,
+                              dz2_f1, stream, dz3, dz3_f0, dz3_f1);
 }
 extern "C" int tcvom_bn_bwd_reduce(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                    const float* saved, float* partial, int64_t pixels, int32_t C, int32_t act,
@@ -1111,21 +1140,22 @@ extern "C" int tcvom_bn_bwd_finalize_sums(const double* sums_all, const double* 
 static int bn_bwd_apply_impl(const void* dz, const void* dz2, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
                              const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                              int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
-                             int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream) {
+                             int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream, const void* dz3 = nullptr,
+                             int32_t dz3_f0 = 0, int32_t dz3_f1 = 0) {
     TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_apply: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
+    TCVOM_CHECK_ARG(!dz3 || (dz3_f0 >= 0 && dz3_f0 <= dz3_f1 && dz3_f1 <= nframes), "bn_bwd_apply: dz3 frames %d..%d of %d", dz3_f0, dz3_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0 && nframes >= 1, "bn_bwd_apply: bad args");
     TCVOM_CHECK_ARG(C <= 2048, "bn_bwd_apply: C=%d (multiples of 8 up to 2048)", C);
     const int rpb = bn_rows_per_block(pixels, C);
     const dim3 grid(cdiv(pixels, rpb), nframes);
     TCVOM_CHECK_ARG(y_fp32 == 0 || y_fp32 == 2, "bn_bwd_apply: y_fp32 = %d (0: the build's 16-bit type, 2: IEEE fp16)", y_fp32);
-    switch (bn_y_mode(y_fp32)) {
-    case 2: hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;
-    default: hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)dz, (const uint4*)dz2, y, (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy,
-                           (uint4*)dres1, pixels, C / 8, C, act, training, in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask); break;
-    }
+#define BN_BWD_APPLY_LAUNCH(YM, H3)                                                                                               \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<YM, H3>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dz, (const uint4*)dz2, y, \
+                       (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy, (uint4*)dres1, pixels, C / 8, C, act, training,    \
+                       in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask, (const uint4*)dz3, dz3_f0, dz3_f1)
+    if (bn_y_mode(y_fp32) == 2) { if (dz3) BN_BWD_APPLY_LAUNCH(2, true); else BN_BWD_APPLY_LAUNCH(2, false); }
+    else { if (dz3) BN_BWD_APPLY_LAUNCH(0, true); else BN_BWD_APPLY_LAUNCH(0, false); }
+#undef BN_BWD_APPLY_LAUNCH
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
 }
@@ -1143,6 +1173,14 @@ extern "C" int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const vo
     TCVOM_CHECK_ARG(mask && act != 4, "bn_bwd_apply_mask: null mask / capped activation");
     return bn_bwd_apply_impl(dz, dz2, y, nullptr, mask, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
                              nframes, slot_stride, dz2_f0, dz2_f1, stream);
+}
+extern "C" int tcvom_bn_bwd_apply3(const void* dz, const void* dz2, int32_t dz2_f0, int32_t dz2_f1, const void* dz3, int32_t dz3_f0,
+                                   int32_t dz3_f1, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
+                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels, int32_t C, int32_t act,
+                                   int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
+    TCVOM_CHECK_ARG(!(res1 && mask) && !(mask && act == 4), "bn_bwd_apply3: res1 and mask exclude each other; no mask with a capped activation");
+    return bn_bwd_apply_impl(dz, dz2, y, res1, mask, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
+                             nframes, slot_stride, dz2_f0, dz2_f1, stream, dz3, dz3_f0, dz3_f1);
 }
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,

@@ -544,6 +544,17 @@ class _ConvBNAct(torch.autograd.Function):
                     extra.append(_c(t))
             del ctx.stash[:]
         dz2_rng = None
+        # three addends inside the BatchNorm-backward kernels (dz for all frames + two more, each a whole tensor or the rows of a frame
+        # range): the stage outputs of the encoder feed the next stage's conv1, its down-sampling branch and the shortcut branch --
+        # without this the third gradient costs an element-wise add (and a zero-padded copy when it covers the interior frames only)
+        add3 = None
+        if (THREE_ADDENDS and ctx.active is None and cfg.bn is not None and not ctx.has_res2 and len(extra) + len(ranged) + (dz is not None) == 3
+                and len(extra) + (dz is not None) >= 1 and (dz if dz is not None else extra[0]).dtype == H16
+                and all(lo % geo.N == 0 and hi % geo.N == 0 and g.dtype == H16 for _, g, lo, hi in ranged)):
+            full = ([dz] if dz is not None else []) + extra
+            others = [(_c(t), 0, nf) for t in full[1:]] + [(_c(g), lo // geo.N, hi // geo.N) for _, g, lo, hi in ranged]
+            if all(t.shape[1:] == full[0].shape[1:] and t.dtype == H16 for t, _, _ in others) and full[0].shape[0] == geo.N * nf:
+                dz, extra, ranged, add3 = full[0], [], [], others
         if ranged and (ctx.active is None or any((lo, hi) != (ctx.active[0] * geo.N, ctx.active[1] * geo.N) for _, _, lo, hi in ranged)):
             # this op ran (and is differentiated) for all frames; a consumer deposited the gradient of some frames only
             _, g0, lo0, hi0 = ranged[0]
@@ -599,8 +610,13 @@ class _ConvBNAct(torch.autograd.Function):
         if cfg.bn is not None:
             groups = L.call('tcvom_bn_bwd_groups_n', P, K, nf)
             partial = torch.empty(nf * groups * 2 * K, dtype=torch.float32, device=dz.device)
-            L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,
-                   saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, zf0, zf1, st)          # (r1 = the activation mask when res_mask)
+            if add3 is not None:
+                (t2, a0, a1), (t3, b0, b1) = add3
+                L.call('tcvom_bn_bwd_reduce3', L.ptr(dz), L.ptr(t2), a0, a1, L.ptr(t3), b0, b1, L.ptr(y), None if ctx.res_mask else L.ptr(r1),
+                       L.ptr(r1) if ctx.res_mask else None, ss, saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, st)
+            else:
+                L.call('tcvom_bn_bwd_reduce_mask' if ctx.res_mask else 'tcvom_bn_bwd_reduce_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss,
+                       saved, L.ptr(partial), P, K, cfg.act, yf, nf, stride, zf0, zf1, st)      # (r1 = the activation mask when res_mask)
             # gamma / beta gradients of the S calls of one BatchNorm add up in the bank (delivered by the bank token)
             dgp, dbp = (C.c_void_p(a) for a in bank.bn_grad_ptrs(cfg.bn))
             coef = torch.empty(nf * 3 * K, dtype=torch.float32, device=dz.device)
@@ -624,9 +640,15 @@ class _ConvBNAct(torch.autograd.Function):
                 dist.all_reduce(total, group=group)
                 L.call('tcvom_bn_bwd_finalize_sums', L.ptr(total), L.ptr(local), K, P * world, L.ptr(gamma), saved,
                        dgp, dbp, L.ptr(coef), 1, nf, stride, _sn_dot(cfg, ctx.call, ctx.training, sync), st)
-            L.call('tcvom_bn_bwd_apply_mask' if ctx.res_mask else 'tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
-                   L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
-                   zf0, zf1, st)
+            if add3 is not None:
+                (t2, a0, a1), (t3, b0, b1) = add3
+                L.call('tcvom_bn_bwd_apply3', L.ptr(dz), L.ptr(t2), a0, a1, L.ptr(t3), b0, b1, L.ptr(y), None if ctx.res_mask else L.ptr(r1),
+                       L.ptr(r1) if ctx.res_mask else None, ss, saved, L.ptr(coef), L.ptr(dy), L.ptr(dres1), P, K, cfg.act,
+                       1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
+            else:
+                L.call('tcvom_bn_bwd_apply_mask' if ctx.res_mask else 'tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
+                       L.ptr(dres1), P, K, cfg.act, 1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride,
+                       zf0, zf1, st)
         if cfg.bn is not None and ctx.has_bias:
             # a conv bias in front of a BatchNorm (DIM encoder): its gradient is the column sum of dy -- ~0 with
             # batch statistics, but not None (weight decay still acts on it in the reference's Adam)
@@ -966,6 +988,7 @@ class _FrameSlice(torch.autograd.Function):
         return full, None, None, None
 
 
+THREE_ADDENDS = _os.environ.get('TCVOM_NO_ADD3') is None       # A/B switch: a third gradient addend inside the BatchNorm backward (round 6)
 RANGED_DZ2 = _os.environ.get('TCVOM_NO_RANGED') is None          # A/B switch: row-range gradients added inside the BatchNorm backward
 
 

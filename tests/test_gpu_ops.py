@@ -387,6 +387,60 @@ def test_row_range_gradient_is_added_inside_the_batchnorm_backward():
     ck.done()
 
 
+@pytest.mark.parametrize('residual', [False, True])
+def test_three_gradient_addends_inside_the_batchnorm_backward(residual, monkeypatch):
+    """The output of a frame-batched conv + BatchNorm op with THREE consumers -- autograd (all frames), a second conv + BatchNorm op (its
+    data gradient is deposited with the producer) and ops.frame_slice of the centre frame (a row-range deposit): the encoder stage
+    outputs of the window (next stage's conv1, its down-sampling branch, the shortcut branch).  tcvom_bn_bwd_reduce3 / _apply3 add all
+    three in fp32; must equal the two-addend path, where the third gradient is zero-padded and added by element-wise passes.
+    residual: the producer is a residual site (activation mask instead of res1 in its backward)."""
+    from tcvom_amd import ops
+    from tcvom_amd import _lib as L
+    from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
+    S, B, cin, cout, H, W = 3, 1, 64, 64, 24, 40
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, 'call', lambda name, *a: (calls.append(name), real(name, *a))[1])
+
+    def run(three):
+        monkeypatch.setattr(ops, 'THREE_ADDENDS', three)
+        del calls[:]
+        bank = WeightBank()
+        specs, cfgs = [], []
+        for i in range(2):
+            w = nn.Parameter(formula_tensor('conv.t3%d.weight' % i, (cout, cin, 3, 3)).to(DEV))
+            spec = ConvSpec('t3%d' % i, w, None, None, None, False, 1, 1, 'frame')
+            bank.register(spec)
+            specs.append(spec)
+            cfgs.append(ops.ConvCfg(bank, spec, bn=nn.BatchNorm2d(cout).to(DEV), act=1))
+        xg = torch.cat([nhwc(hu('x%d.t3' % f, (B, cin, H, W))) for f in range(S)], 0).requires_grad_(True)
+        res = torch.cat([nhwc(hu('r%d.t3' % f, (B, cout, H, W))) for f in range(S)], 0).requires_grad_(True) if residual else None
+        token = bank_token(bank, S, True)
+        bank.frames_per_op = S
+        z = ops.conv_bn_act(cfgs[0], xg, token, True, res1=res)
+        z2 = ops.conv_bn_act(cfgs[1], z, token, True)                  # consumer 2: deposits its data gradient with z's producer
+        bank.frames_per_op = 1
+        zc = ops.frame_slice(z, B, 2 * B)                              # consumer 3: the centre frame only
+        g1, g2 = nhwc(hu('g1.t3', (S * B, cout, H, W))), nhwc(hu('g2.t3', (S * B, cout, H, W)))
+        g3 = nhwc(hu('g3.t3', (B, cout, H, W)))
+        ((z.float() * g1.float()).sum() + 0.5 * (z2.float() * g2.float()).sum() + 2.0 * (zc.float() * g3.float()).sum()).backward()
+        bank.flush_bn_counters()
+        torch.cuda.synchronize()
+        return (xg.grad.float().cpu(), specs[0].weight.grad.cpu(), cfgs[0].bn.weight.grad.cpu(), cfgs[0].bn.bias.grad.cpu(),
+                res.grad.float().cpu() if residual else None, list(calls))
+
+    a, b = run(True), run(False)
+    assert 'tcvom_bn_bwd_reduce3' in a[5] and 'tcvom_bn_bwd_apply3' in a[5] and 'tcvom_bn_bwd_reduce3' not in b[5]
+    ck = Checker()
+    ck.rel('dx', a[0], b[0], 1e-2)
+    ck.rel('dw', a[1], b[1], 1e-2)
+    ck.rel('dgamma', a[2], b[2], 1e-2)
+    ck.rel('dbeta', a[3], b[3], 1e-2)
+    if residual:
+        ck.rel('dres1', a[4], b[4], 1e-2)
+    ck.done()
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,transposed,H,W', [(128, 128, 3, 1, False, 40, 64), (64, 64, 4, 2, True, 20, 24),
                                                                (32, 64, 3, 2, False, 48, 64), (32, 32, 3, 1, False, 48, 64)])
 def test_batched_weight_gradient_launch(cin, cout, k, stride, transposed, H, W):

@@ -30,7 +30,7 @@ SETS = {
     'attention': {'TCVOM_NO_GCA_KMAJOR': '1', 'TCVOM_NO_FUSED_SOFTMAX': '1'},
     # (k-major A off alone: the forward O = P V on a transposed copy of V while the backward keeps its k-major operands)
     'attention, V^T copy': {'TCVOM_NO_GCA_KMAJOR_A': '1'},
-    'gradients': {'TCVOM_NO_SN_DOT': '1', 'TCVOM_NO_RANGED': '1', 'TCVOM_NO_TAIL_SKIP': '1', 'TCVOM_NO_RES_MASK': '1'},
+    'gradients': {'TCVOM_NO_SN_DOT': '1', 'TCVOM_NO_RANGED': '1', 'TCVOM_NO_TAIL_SKIP': '1', 'TCVOM_NO_RES_MASK': '1', 'TCVOM_NO_ADD3': '1'},
     # the weight-stationary conv splits a frame-batched launch into runs of frames when the frames together would reach 2^31
     # elements (fragment-major weights have no other kernel): forced here to one frame per launch
     'wsconv frame runs': {'TCVOM_WS_MAX_FRAMES': '1'},
