@@ -347,7 +347,9 @@ int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const void* y, cons
                             int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream);
 int tcvom_bn_bwd_apply3(const void* dz, const void* dz2, int32_t dz2_f0, int32_t dz2_f1, const void* dz3, int32_t dz3_f0,
                         int32_t dz3_f1, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
-                        const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels, int32_t C, int32_t act,
+                        const float* saved, const float* coef, void* dy, void* dres1,
+                        void* dsum /* or NULL: dz + dz2 + dz3 itself, 16-bit (whole-tensor addends): the gradient of a residual added AFTER the activation */,
+                        int64_t pixels, int32_t C, int32_t act,
                         int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream);
 
 /* ------------------------------------------------------------------ batched SpectralNorm + weight packing

@@ -105,7 +105,7 @@ _PROTOS = {
     'tcvom_bn_bwd_reduce_mask': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_apply_mask': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp],
     'tcvom_bn_bwd_reduce3': [vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],
-    'tcvom_bn_bwd_apply3': [vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
+    'tcvom_bn_bwd_apply3': [vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i64, vp],
     'tcvom_bn_bwd_groups': [i64, i32],
     'tcvom_bn_bwd_groups_n': [i64, i32, i32],
     'tcvom_bn_bwd_reduce': [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, vp],

@@ -523,8 +523,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ scale_shift, const float* __restrict__ saved, const float* __restrict__ coef,
     uint4* __restrict__ dy, uint4* __restrict__ dres1, int64_t P, int C8, int C, int act, int training, int in_relu,
     int rows_per_block, int64_t slot_stride, int dz2_f0, int dz2_f1, const unsigned char* __restrict__ mask = nullptr,
-    const uint4* __restrict__ dz3 = nullptr, int dz3_f0 = 0, int dz3_f1 = 0)
+    const uint4* __restrict__ dz3 = nullptr, int dz3_f0 = 0, int dz3_f1 = 0, uint4* __restrict__ dsum = nullptr)
 {
+    // dsum (HAS3 instantiations, or NULL): the incoming gradient itself, dz + dz2 + dz3 in the 16-bit type -- the gradient of a residual
+    // that is added AFTER the activation (res2 of the decoder blocks), otherwise an element-wise pass over the same addends
     const int oct = threadIdx.x % C8, prow = threadIdx.x / C8, RP = 256 / C8;
     if (prow >= RP) return;
     if (dz2) dz2 = ((int)blockIdx.y >= dz2_f0 && (int)blockIdx.y < dz2_f1) ? dz2 - (int64_t)dz2_f0 * P * C8 : nullptr;
@@ -572,6 +574,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             unpack8(q3, g3);
 #pragma unroll
             for (int k = 0; k < 8; ++k) g2[k] += g3[k];
+            if (dsum) {
+                float t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = g[k] + g2[k];
+                dsum[v] = pack8(t);
+            }
         }
         unpack_yraw<YF32>(yr, yy);
         unpack8(q1, r1);
@@ -1141,7 +1149,7 @@ static int bn_bwd_apply_impl(const void* dz, const void* dz2, const void* y, con
                              const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,
                              int32_t C, int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes,
                              int64_t slot_stride, int32_t dz2_f0, int32_t dz2_f1, void* stream, const void* dz3 = nullptr,
-                             int32_t dz3_f0 = 0, int32_t dz3_f1 = 0) {
+                             int32_t dz3_f0 = 0, int32_t dz3_f1 = 0, void* dsum = nullptr) {
     TCVOM_CHECK_ARG(dz2_f0 >= 0 && dz2_f0 <= dz2_f1 && dz2_f1 <= nframes, "bn_bwd_apply: dz2 frames %d..%d of %d", dz2_f0, dz2_f1, nframes);
     TCVOM_CHECK_ARG(!dz3 || (dz3_f0 >= 0 && dz3_f0 <= dz3_f1 && dz3_f1 <= nframes), "bn_bwd_apply: dz3 frames %d..%d of %d", dz3_f0, dz3_f1, nframes);
     TCVOM_CHECK_ARG(dz && y && scale_shift && saved && coef && dy && pixels > 0 && C % 8 == 0 && nframes >= 1, "bn_bwd_apply: bad args");
@@ -1152,9 +1160,9 @@ static int bn_bwd_apply_impl(const void* dz, const void* dz2, const void* y, con
 #define BN_BWD_APPLY_LAUNCH(YM, H3)                                                                                               \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<YM, H3>), grid, dim3(256), 0, (hipStream_t)stream, (const uint4*)dz, (const uint4*)dz2, y, \
                        (const uint4*)res1, scale_shift, saved, coef, (uint4*)dy, (uint4*)dres1, pixels, C / 8, C, act, training,    \
-                       in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask, (const uint4*)dz3, dz3_f0, dz3_f1)
-    if (bn_y_mode(y_fp32) == 2) { if (dz3) BN_BWD_APPLY_LAUNCH(2, true); else BN_BWD_APPLY_LAUNCH(2, false); }
-    else { if (dz3) BN_BWD_APPLY_LAUNCH(0, true); else BN_BWD_APPLY_LAUNCH(0, false); }
+                       in_relu, rpb, slot_stride, dz2_f0, dz2_f1, mask, (const uint4*)dz3, dz3_f0, dz3_f1, (uint4*)dsum)
+    if (bn_y_mode(y_fp32) == 2) { if (dz3 || dsum) BN_BWD_APPLY_LAUNCH(2, true); else BN_BWD_APPLY_LAUNCH(2, false); }
+    else { if (dz3 || dsum) BN_BWD_APPLY_LAUNCH(0, true); else BN_BWD_APPLY_LAUNCH(0, false); }
 #undef BN_BWD_APPLY_LAUNCH
     TCVOM_LAUNCH_CHECK("bn_bwd_apply");
     return TCVOM_OK;
@@ -1176,11 +1184,14 @@ extern "C" int tcvom_bn_bwd_apply_mask(const void* dz, const void* dz2, const vo
 }
 extern "C" int tcvom_bn_bwd_apply3(const void* dz, const void* dz2, int32_t dz2_f0, int32_t dz2_f1, const void* dz3, int32_t dz3_f0,
                                    int32_t dz3_f1, const void* y, const void* res1, const uint8_t* mask, const float* scale_shift,
-                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels, int32_t C, int32_t act,
-                                   int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride, void* stream) {
+                                   const float* saved, const float* coef, void* dy, void* dres1, void* dsum, int64_t pixels, int32_t C,
+                                   int32_t act, int32_t training, int32_t in_relu, int32_t y_fp32, int32_t nframes, int64_t slot_stride,
+                                   void* stream) {
     TCVOM_CHECK_ARG(!(res1 && mask) && !(mask && act == 4), "bn_bwd_apply3: res1 and mask exclude each other; no mask with a capped activation");
+    TCVOM_CHECK_ARG(!dsum || ((!dz2 || (dz2_f0 == 0 && dz2_f1 == nframes)) && (!dz3 || (dz3_f0 == 0 && dz3_f1 == nframes)) && dsum != dz),
+                    "bn_bwd_apply3: dsum with whole-tensor addends only");
     return bn_bwd_apply_impl(dz, dz2, y, res1, mask, scale_shift, saved, coef, dy, dres1, pixels, C, act, training, in_relu, y_fp32,
-                             nframes, slot_stride, dz2_f0, dz2_f1, stream, dz3, dz3_f0, dz3_f1);
+                             nframes, slot_stride, dz2_f0, dz2_f1, stream, dz3, dz3_f0, dz3_f1, dsum);
 }
 extern "C" int tcvom_bn_bwd_apply(const void* dz, const void* dz2, const void* y, const void* res1, const float* scale_shift,
                                   const float* saved, const float* coef, void* dy, void* dres1, int64_t pixels,

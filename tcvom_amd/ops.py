@@ -574,7 +574,7 @@ class _ConvBNAct(torch.autograd.Function):
             if extra:
                 dz = extra.pop(0)
         dz = _c(dz) if dz is not None else None
-        dgamma = dbeta = dbias = dres1 = dz2 = None
+        dgamma = dbeta = dbias = dres1 = dz2 = dsum = None
         if extra:
             dz2 = extra[0] if len(extra) == 1 else sum(extra[1:], extra[0])
             assert dz is not None and dz2.shape == dz.shape and dz2.dtype == dz.dtype
@@ -643,7 +643,13 @@ class _ConvBNAct(torch.autograd.Function):
             if add3 is not None:
                 (t2, a0, a1), (t3, b0, b1) = add3
                 L.call('tcvom_bn_bwd_apply3', L.ptr(dz), L.ptr(t2), a0, a1, L.ptr(t3), b0, b1, L.ptr(y), None if ctx.res_mask else L.ptr(r1),
-                       L.ptr(r1) if ctx.res_mask else None, ss, saved, L.ptr(coef), L.ptr(dy), L.ptr(dres1), P, K, cfg.act,
+                       L.ptr(r1) if ctx.res_mask else None, ss, saved, L.ptr(coef), L.ptr(dy), L.ptr(dres1), None, P, K, cfg.act,
+                       1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
+            elif THREE_ADDENDS and ctx.has_res2 and dz2 is not None and dz2_rng is None and ctx.needs_input_grad[6]:
+                # res2 is added after the activation: its gradient is the op's whole incoming gradient dz + dz2 -- written by the same pass
+                dsum = torch.empty_like(dz)
+                L.call('tcvom_bn_bwd_apply3', L.ptr(dz), L.ptr(dz2), 0, nf, None, 0, 0, L.ptr(y), None if ctx.res_mask else L.ptr(r1),
+                       L.ptr(r1) if ctx.res_mask else None, ss, saved, L.ptr(coef), L.ptr(dy), L.ptr(dres1), L.ptr(dsum), P, K, cfg.act,
                        1 if (ctx.training or cfg.group_norm) else 0, 1 if cfg.pre_relu else 0, yf, nf, stride, st)
             else:
                 L.call('tcvom_bn_bwd_apply_mask' if ctx.res_mask else 'tcvom_bn_bwd_apply_ranged', L.ptr(dz), L.ptr(dz2), L.ptr(y), L.ptr(r1), ss, saved, L.ptr(coef), L.ptr(dy),
@@ -664,7 +670,7 @@ class _ConvBNAct(torch.autograd.Function):
         # the weight gradients are deferred: the bank runs the S calls of a layer as ONE launch at the end of backward
         bank.defer_wgrad(spec, ctx.call, dy, x, geo, nf)
         # res2 is added after the activation: its gradient is the op's WHOLE incoming gradient, deposited part included
-        dres2 = (dz if dz2 is None else dz + dz2) if ctx.has_res2 else None
+        dres2 = (dsum if dsum is not None else dz if dz2 is None else dz + dz2) if ctx.has_res2 else None
         if dres1 is not None and ctx.res1_stash is not None:
             # the producer of res1 (a conv + BatchNorm op further up) adds this to its incoming gradient inside its
             # BatchNorm-backward kernels (dz2 of tcvom_bn_bwd_reduce / tcvom_bn_bwd_apply): no element-wise add pass

@@ -387,13 +387,14 @@ def test_row_range_gradient_is_added_inside_the_batchnorm_backward():
     ck.done()
 
 
-@pytest.mark.parametrize('residual', [False, True])
+@pytest.mark.parametrize('residual', [False, True, 'res2'])
 def test_three_gradient_addends_inside_the_batchnorm_backward(residual, monkeypatch):
     """The output of a frame-batched conv + BatchNorm op with THREE consumers -- autograd (all frames), a second conv + BatchNorm op (its
     data gradient is deposited with the producer) and ops.frame_slice of the centre frame (a row-range deposit): the encoder stage
     outputs of the window (next stage's conv1, its down-sampling branch, the shortcut branch).  tcvom_bn_bwd_reduce3 / _apply3 add all
     three in fp32; must equal the two-addend path, where the third gradient is zero-padded and added by element-wise passes.
-    residual: the producer is a residual site (activation mask instead of res1 in its backward)."""
+    residual: the producer is a residual site (activation mask instead of res1 in its backward).  'res2': a residual added AFTER the
+    activation (the decoder blocks) and two consumers -- its gradient, dz + dz2 itself, is written by tcvom_bn_bwd_apply3 (dsum)."""
     from tcvom_amd import ops
     from tcvom_amd import _lib as L
     from tcvom_amd.weights import ConvSpec, WeightBank, bank_token
@@ -417,10 +418,10 @@ def test_three_gradient_addends_inside_the_batchnorm_backward(residual, monkeypa
         res = torch.cat([nhwc(hu('r%d.t3' % f, (B, cout, H, W))) for f in range(S)], 0).requires_grad_(True) if residual else None
         token = bank_token(bank, S, True)
         bank.frames_per_op = S
-        z = ops.conv_bn_act(cfgs[0], xg, token, True, res1=res)
+        z = ops.conv_bn_act(cfgs[0], xg, token, True, res2=res) if residual == 'res2' else ops.conv_bn_act(cfgs[0], xg, token, True, res1=res)
         z2 = ops.conv_bn_act(cfgs[1], z, token, True)                  # consumer 2: deposits its data gradient with z's producer
         bank.frames_per_op = 1
-        zc = ops.frame_slice(z, B, 2 * B)                              # consumer 3: the centre frame only
+        zc = z[B:2 * B] * 0.0 if residual == 'res2' else ops.frame_slice(z, B, 2 * B)      # consumer 3: the centre frame only
         g1, g2 = nhwc(hu('g1.t3', (S * B, cout, H, W))), nhwc(hu('g2.t3', (S * B, cout, H, W)))
         g3 = nhwc(hu('g3.t3', (B, cout, H, W)))
         ((z.float() * g1.float()).sum() + 0.5 * (z2.float() * g2.float()).sum() + 2.0 * (zc.float() * g3.float()).sum()).backward()
@@ -430,7 +431,8 @@ def test_three_gradient_addends_inside_the_batchnorm_backward(residual, monkeypa
                 res.grad.float().cpu() if residual else None, list(calls))
 
     a, b = run(True), run(False)
-    assert 'tcvom_bn_bwd_reduce3' in a[5] and 'tcvom_bn_bwd_apply3' in a[5] and 'tcvom_bn_bwd_reduce3' not in b[5]
+    assert 'tcvom_bn_bwd_apply3' in a[5] and 'tcvom_bn_bwd_apply3' not in b[5]
+    assert residual == 'res2' or ('tcvom_bn_bwd_reduce3' in a[5] and 'tcvom_bn_bwd_reduce3' not in b[5])
     ck = Checker()
     ck.rel('dx', a[0], b[0], 1e-2)
     ck.rel('dw', a[1], b[1], 1e-2)
